@@ -1,0 +1,158 @@
+"""ctypes front end for the CPU oracle -- TEST INFRASTRUCTURE ONLY.
+
+``Oracle("port")``      -> oracle/liboracle.so   (our restatement, ac_oracle.c)
+``Oracle("reference")`` -> oracle/_ref/libmf_ref.so (the reference's own C, built in place)
+
+Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg import this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PORT_SO = os.path.join(_HERE, "liboracle.so")
+REF_SO = os.path.join(_HERE, "_ref", "libmf_ref.so")
+
+
+def build(quiet: bool = True) -> None:
+    """Compile liboracle.so (always) and _ref/libmf_ref.so (only when /root/reference exists)."""
+    subprocess.run(["make", "-C", _HERE], check=True,
+                   stdout=subprocess.DEVNULL if quiet else None)
+
+
+def have_reference() -> bool:
+    return os.path.exists(REF_SO)
+
+
+_u8p = C.POINTER(C.c_uint8)
+_u32p = C.POINTER(C.c_uint32)
+_u64p = C.POINTER(C.c_uint64)
+
+
+def _ptr(a: np.ndarray, typ):
+    return a.ctypes.data_as(typ)
+
+
+class Oracle:
+    """One trie.  Mirrors the call sequence of the PHP layer (reverse insertion, keep=0)."""
+
+    def __init__(self, kind: str = "port"):
+        if kind == "port":
+            if not os.path.exists(PORT_SO):
+                build()
+            self.lib, self.pfx = C.CDLL(PORT_SO), "orc_"
+        elif kind == "reference":
+            if not os.path.exists(REF_SO):
+                raise FileNotFoundError(REF_SO)
+            self.lib, self.pfx = C.CDLL(REF_SO), "ref_"
+        else:
+            raise ValueError(kind)
+        self.kind = kind
+        f = self._f
+        f("create", C.c_void_p)
+        f("add", C.c_int, C.c_void_p, _u8p, C.c_size_t, C.c_uint32)
+        f("finalize", None, C.c_void_p)
+        f("release", None, C.c_void_p)
+        f("node_count", C.c_size_t, C.c_void_p)
+        f("pattern_count", C.c_size_t, C.c_void_p)
+        f("php_add_patterns", C.c_size_t, C.c_void_p, _u8p, _u64p, C.c_size_t, C.c_uint32)
+        f("php_match", C.c_size_t, C.c_void_p, _u8p, C.c_size_t, C.c_int, C.c_uint32, _u32p, C.c_size_t)
+        f("php_match_batch", C.c_size_t, C.c_void_p, _u8p, _u64p, C.c_size_t, C.c_int, _u64p, _u32p,
+          C.c_size_t)
+        f("php_scan_checksum", C.c_size_t, C.c_void_p, _u8p, _u64p, C.c_size_t, _u64p)
+        self.t = self._c("create")()
+        self.n_added = 0
+
+    def _f(self, name, res, *args):
+        fn = getattr(self.lib, self.pfx + name)
+        fn.restype, fn.argtypes = res, list(args)
+
+    def _c(self, name):
+        return getattr(self.lib, self.pfx + name)
+
+    def close(self):
+        if self.t:
+            self._c("release")(self.t)
+            self.t = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- build -------------------------------------------------------------------------
+    def add_patterns(self, patterns) -> int:
+        """One init()/add_patterns() call; ``patterns`` is a list of bytes or (blob, off)."""
+        if isinstance(patterns, tuple):
+            blob, off = patterns
+        else:
+            from php_aho_corasick_amd.synth import pack
+            blob, off = pack([bytes(p) for p in patterns])
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = len(off) - 1
+        keep = blob if blob.size else np.zeros(1, np.uint8)
+        acc = self._c("php_add_patterns")(self.t, _ptr(keep, _u8p), _ptr(off, _u64p), n, self.n_added)
+        self.n_added += n
+        return int(acc)
+
+    def finalize(self):
+        self._c("finalize")(self.t)
+
+    def node_count(self) -> int:
+        return int(self._c("node_count")(self.t))
+
+    def pattern_count(self) -> int:
+        return int(self._c("pattern_count")(self.t))
+
+    # -- scan --------------------------------------------------------------------------
+    def match(self, text: bytes, find_all: bool = True, hay: int = 0) -> np.ndarray:
+        """Records of one haystack as an (n, 4) uint32 array {hay, pos, start, index}."""
+        buf = np.frombuffer(text, dtype=np.uint8) if len(text) else np.zeros(1, np.uint8)
+        cap = 64
+        while True:
+            out = np.zeros((cap, 4), dtype=np.uint32)
+            n = self._c("php_match")(self.t, _ptr(buf, _u8p), len(text), int(find_all), hay,
+                                     _ptr(out, _u32p), cap)
+            if n <= cap:
+                return out[:n].copy()
+            cap = int(n)
+
+    def match_batch(self, blob: np.ndarray, off: np.ndarray, find_all: bool = True):
+        """(counts_prefix[nh+1] uint64, records (n,4) uint32) over a batch, haystack order."""
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        nh = len(off) - 1
+        keep = blob if blob.size else np.zeros(1, np.uint8)
+        prefix = np.zeros(nh + 1, dtype=np.uint64)
+        total = self._c("php_match_batch")(self.t, _ptr(keep, _u8p), _ptr(off, _u64p), nh,
+                                           int(find_all), _ptr(prefix, _u64p), None, 0)
+        out = np.zeros((max(int(total), 1), 4), dtype=np.uint32)
+        self._c("php_match_batch")(self.t, _ptr(keep, _u8p), _ptr(off, _u64p), nh, int(find_all),
+                                   _ptr(prefix, _u64p), _ptr(out, _u32p), int(total))
+        return prefix, out[:int(total)]
+
+    def scan_checksum(self, blob: np.ndarray, off: np.ndarray):
+        """(record count, checksum) without materialising records (cpu_baseline timing leg)."""
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        ck = C.c_uint64(0)
+        n = self._c("php_scan_checksum")(self.t, _ptr(blob, _u8p), _ptr(off, _u64p), len(off) - 1,
+                                         C.byref(ck))
+        return int(n), int(ck.value)
+
+
+def record_checksum(records: np.ndarray) -> int:
+    """Same checksum as orc_php_scan_checksum over an (n,4) uint32 record array."""
+    if len(records) == 0:
+        return 0
+    r = records.astype(np.uint64)
+    with np.errstate(over="ignore"):
+        v = (r[:, 0] * np.uint64(0x9E3779B1)) ^ (r[:, 1] * np.uint64(0x85EBCA77)) ^ \
+            (r[:, 2] * np.uint64(0xC2B2AE3D)) ^ r[:, 3]
+        return int(np.sum(v, dtype=np.uint64))

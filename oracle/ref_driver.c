@@ -1,0 +1,145 @@
+/*
+ * ref_driver.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Thin driver around the REFERENCE's own MultiFast sources, compiled where they
+ * lie under /root/reference/src/multifast by oracle/Makefile into
+ * oracle/_ref/libmf_ref.so.  No reference source is copied into this repo and
+ * no stand-in header is written: the only PHP dependency of the MultiFast core
+ * is acmem.h (it includes php.h solely to redirect AC_MALLOC to emalloc); the
+ * Makefile pre-defines that header's own include guard
+ * (-DPHP_AHO_CORASICK_ACMEM_H) so it expands to nothing and mpool.h's own
+ * built-in fallback (AC_MALLOC = malloc, mpool.h:26-32) applies.
+ *
+ * The driver mimics what php_ahocorasick.c does around the core:
+ *   - patterns are inserted in reverse caller order with copy=1, id.type =
+ *     NUMBER, id.u.number = caller index, status ignored
+ *     (php_ahocorasick.c:457-486);
+ *   - search runs with keep=0 (php_ahocorasick.c:745);
+ *   - the callback walks j = 0..size-1 and emits
+ *     {hay, position, position - ptext.length, id} (php_ahocorasick.c:555-583),
+ *     returning 1 when findAll is false (:588).
+ * It exports the same entry points as oracle/ac_oracle.c with a ref_ prefix so
+ * tests can run both through one ctypes wrapper.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "ahocorasick.h" /* from /root/reference/src/multifast (-I) */
+
+typedef struct {
+    int ret_val;
+    uint32_t hay;
+    uint32_t *out;
+    size_t cap, n;
+    uint64_t checksum;
+} ref_payload;
+
+static int ref_handler(AC_MATCH_t *m, void *param)
+{
+    ref_payload *p = (ref_payload *)param;
+    for (size_t j = 0; j < m->size; j++) {
+        uint32_t pos = (uint32_t)m->position;
+        uint32_t start = pos - (uint32_t)m->patterns[j].ptext.length;
+        uint32_t idx = (uint32_t)m->patterns[j].id.u.number;
+        if (p->out && p->n < p->cap) {
+            uint32_t *r = p->out + 4 * p->n;
+            r[0] = p->hay; r[1] = pos; r[2] = start; r[3] = idx;
+        }
+        p->checksum += ((uint64_t)p->hay * 0x9E3779B1u) ^ ((uint64_t)pos * 0x85EBCA77u) ^
+                       ((uint64_t)start * 0xC2B2AE3Du) ^ (uint64_t)idx;
+        p->n++;
+    }
+    return p->ret_val == 0 ? 0 : 1;
+}
+
+void *ref_create(void) { return ac_trie_create(); }
+
+int ref_add(void *t, const uint8_t *p, size_t len, uint32_t index)
+{
+    AC_PATTERN_t patt;
+    patt.ptext.astring = (const AC_ALPHABET_t *)p;
+    patt.ptext.length = len;
+    patt.rtext.astring = NULL;
+    patt.rtext.length = 0;
+    patt.id.type = AC_PATTID_TYPE_NUMBER;
+    patt.id.u.number = (long)index;
+    patt.aux = NULL;
+    return (int)ac_trie_add((AC_TRIE_t *)t, &patt, 1);
+}
+
+void ref_finalize(void *t) { ac_trie_finalize((AC_TRIE_t *)t); }
+void ref_release(void *t) { ac_trie_release((AC_TRIE_t *)t); }
+size_t ref_pattern_count(const void *t) { return ((const AC_TRIE_t *)t)->patterns_count; }
+
+size_t ref_php_add_patterns(void *t, const uint8_t *blob, const uint64_t *off, size_t n,
+                            uint32_t base_index)
+{
+    size_t accepted = 0;
+    for (size_t k = n; k-- > 0;)
+        if (ref_add(t, blob + off[k], (size_t)(off[k + 1] - off[k]), base_index + (uint32_t)k) ==
+            ACERR_SUCCESS)
+            accepted++;
+    return accepted;
+}
+
+size_t ref_php_match(void *t, const uint8_t *text, size_t len, int find_all, uint32_t hay,
+                     uint32_t *out, size_t cap)
+{
+    AC_TRIE_t *trie = (AC_TRIE_t *)t;
+    if (trie->trie_open)
+        ac_trie_finalize(trie);
+    AC_TEXT_t txt;
+    txt.astring = (const AC_ALPHABET_t *)text;
+    txt.length = len;
+    ref_payload p = { find_all ? 0 : 1, hay, out, cap, 0, 0 };
+    ac_trie_search(trie, &txt, 0, ref_handler, &p);
+    return p.n;
+}
+
+size_t ref_php_match_batch(void *t, const uint8_t *blob, const uint64_t *off, size_t nh,
+                           int find_all, uint64_t *counts_prefix, uint32_t *out, size_t cap)
+{
+    size_t total = 0;
+    if (counts_prefix)
+        counts_prefix[0] = 0;
+    for (size_t h = 0; h < nh; h++) {
+        size_t room = total < cap ? cap - total : 0;
+        size_t n = ref_php_match(t, blob + off[h], (size_t)(off[h + 1] - off[h]), find_all,
+                                 (uint32_t)h, (out && room) ? out + 4 * total : NULL, room);
+        total += n;
+        if (counts_prefix)
+            counts_prefix[h + 1] = total;
+    }
+    return total;
+}
+
+size_t ref_php_scan_checksum(void *t, const uint8_t *blob, const uint64_t *off, size_t nh,
+                             uint64_t *checksum)
+{
+    AC_TRIE_t *trie = (AC_TRIE_t *)t;
+    if (trie->trie_open)
+        ac_trie_finalize(trie);
+    ref_payload p = { 0, 0, NULL, 0, 0, 0 };
+    for (size_t h = 0; h < nh; h++) {
+        AC_TEXT_t txt;
+        txt.astring = (const AC_ALPHABET_t *)(blob + off[h]);
+        txt.length = (size_t)(off[h + 1] - off[h]);
+        p.hay = (uint32_t)h;
+        ac_trie_search(trie, &txt, 0, ref_handler, &p);
+    }
+    if (checksum)
+        *checksum = p.checksum;
+    return p.n;
+}
+
+/* Node count = 1 + number of edges, by DFS over the reference's own structs. */
+#include "node.h"
+static size_t count_nodes(const ACT_NODE_t *n)
+{
+    size_t c = 1;
+    for (size_t i = 0; i < n->outgoing_size; i++)
+        c += count_nodes(n->outgoing[i].next);
+    return c;
+}
+size_t ref_node_count(const void *t) { return count_nodes(((const AC_TRIE_t *)t)->root); }

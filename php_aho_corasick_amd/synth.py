@@ -1,0 +1,218 @@
+"""Deterministic synthetic pattern / haystack generators.
+
+The reference's own workload generator (examples/benchmark.php:9-31) draws from
+PHP's unseeded ``rand()``, so only its SHAPE is reproducible (2048 needles x 16
+chars, 256 haystacks x 8192 chars, alphabet ``abcdef``).  Every dataset in this
+repo therefore comes from one seeded splitmix64 stream:
+
+* all pattern bytes first (pattern-major, ``NP x PLmax`` draws even when a
+  pattern uses fewer), then all haystack bytes (haystack-major);
+* alphabet draw ``alphabet[next() % len(alphabet)]``; Sigma=256 draw
+  ``next() & 0xFF``;
+* variable length ``len_k = Lmin + ((k * 2654435761) >> 7) % (Lmax - Lmin + 1)``;
+* plants are applied after generation.
+
+Pure numpy, no device code: the same bytes are fed to the HIP path, to the
+oracle and to the compiled reference.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+_GAMMA = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+
+def splitmix64(seed: int, n: int, start: int = 0) -> np.ndarray:
+    """Outputs ``start .. start+n-1`` of the splitmix64 stream seeded with ``seed``."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(start + 1, start + n + 1, dtype=np.uint64)
+        z = np.uint64(seed) + idx * _GAMMA
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        return z ^ (z >> np.uint64(31))
+
+
+def _draw_bytes(seed: int, n: int, start: int, alphabet: bytes | None) -> np.ndarray:
+    out = np.empty(n, dtype=np.uint8)
+    step = 1 << 22
+    alpha = None if alphabet is None else np.frombuffer(alphabet, dtype=np.uint8)
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        r = splitmix64(seed, hi - lo, start + lo)
+        if alpha is None:
+            out[lo:hi] = (r & np.uint64(0xFF)).astype(np.uint8)
+        else:
+            out[lo:hi] = alpha[(r % np.uint64(len(alpha))).astype(np.int64)]
+    return out
+
+
+@dataclass
+class Dataset:
+    """Patterns and haystacks as (blob, offsets) pairs; offsets are uint64, n+1 long."""
+
+    name: str
+    pat_blob: np.ndarray
+    pat_off: np.ndarray
+    hay_blob: np.ndarray
+    hay_off: np.ndarray
+
+    @property
+    def n_patterns(self) -> int:
+        return len(self.pat_off) - 1
+
+    @property
+    def n_haystacks(self) -> int:
+        return len(self.hay_off) - 1
+
+    def pattern(self, k: int) -> bytes:
+        return self.pat_blob[int(self.pat_off[k]):int(self.pat_off[k + 1])].tobytes()
+
+    def haystack(self, h: int) -> bytes:
+        return self.hay_blob[int(self.hay_off[h]):int(self.hay_off[h + 1])].tobytes()
+
+    def patterns(self) -> list[bytes]:
+        return [self.pattern(k) for k in range(self.n_patterns)]
+
+
+def pack(items: list[bytes]) -> tuple[np.ndarray, np.ndarray]:
+    off = np.zeros(len(items) + 1, dtype=np.uint64)
+    if items:
+        off[1:] = np.cumsum([len(b) for b in items], dtype=np.uint64)
+    blob = np.frombuffer(b"".join(items), dtype=np.uint8).copy() if items else np.zeros(0, np.uint8)
+    return blob, off
+
+
+def var_lengths(n: int, lmin: int, lmax: int) -> np.ndarray:
+    k = np.arange(n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        return (np.uint64(lmin) + ((k * np.uint64(2654435761)) >> np.uint64(7)) %
+                np.uint64(lmax - lmin + 1)).astype(np.int64)
+
+
+def generate(name: str, seed: int, n_pat: int, pat_lmin: int, pat_lmax: int,
+             n_hay: int, hay_len: int, alphabet: bytes | None) -> Dataset:
+    """Generic seeded dataset: fixed-length patterns when ``pat_lmin == pat_lmax``."""
+    raw = _draw_bytes(seed, n_pat * pat_lmax, 0, alphabet).reshape(n_pat, pat_lmax) if n_pat else \
+        np.zeros((0, pat_lmax), np.uint8)
+    lens = np.full(n_pat, pat_lmax, dtype=np.int64) if pat_lmin == pat_lmax else \
+        var_lengths(n_pat, pat_lmin, pat_lmax)
+    pat_off = np.zeros(n_pat + 1, dtype=np.uint64)
+    pat_off[1:] = np.cumsum(lens, dtype=np.uint64)
+    if pat_lmin == pat_lmax:
+        pat_blob = raw.reshape(-1).copy()
+    else:
+        mask = np.arange(pat_lmax)[None, :] < lens[:, None]
+        pat_blob = raw[mask].copy()
+    hay_blob = _draw_bytes(seed, n_hay * hay_len, n_pat * pat_lmax, alphabet)
+    hay_off = (np.arange(n_hay + 1, dtype=np.uint64) * np.uint64(hay_len))
+    return Dataset(name, pat_blob, pat_off, hay_blob, hay_off)
+
+
+def plant(ds: Dataset, pos_mul: int, pos_add: int, pos_mod: int, pat_mul: int, pat_add: int) -> None:
+    """hay[h][(pos_mul*h+pos_add) % pos_mod ...) = pat[(pat_mul*h+pat_add) % NP] for every h."""
+    for h in range(ds.n_haystacks):
+        p = ds.pattern((pat_mul * h + pat_add) % ds.n_patterns)
+        at = int(ds.hay_off[h]) + (pos_mul * h + pos_add) % pos_mod
+        ds.hay_blob[at:at + len(p)] = np.frombuffer(p, dtype=np.uint8)
+
+
+# ---- the named datasets of SURVEY.md section 8c/8d ---------------------------------------
+
+def g1(n_hay: int = 256) -> Dataset:
+    """Config 1/2 shape (examples/benchmark.php:20-31): 2048 x 16 B, n_hay x 8192 B, abcdef, seed 1."""
+    return generate("G1", 1, 2048, 16, 16, n_hay, 8192, b"abcdef")
+
+
+def g2(n_hay: int = 256) -> Dataset:
+    """G1 plus one planted pattern per haystack."""
+    ds = g1(n_hay)
+    ds.name = "G2"
+    plant(ds, 31, 5, 8176, 7, 3)
+    return ds
+
+
+def g3(n_hay: int = 4, hay_len: int = 8192, k: int = 16) -> Dataset:
+    """Adversarial dense set: patterns a^1..a^k over haystacks a^hay_len (k records per byte)."""
+    pat_blob, pat_off = pack([b"a" * (i + 1) for i in range(k)])
+    hay_blob = np.full(n_hay * hay_len, ord("a"), dtype=np.uint8)
+    hay_off = np.arange(n_hay + 1, dtype=np.uint64) * np.uint64(hay_len)
+    return Dataset("G3", pat_blob, pat_off, hay_blob, hay_off)
+
+
+def g4(n_hay: int = 4, hay_len: int = 8192) -> Dataset:
+    """All 30 strings of length 1..4 over {a,b}; random {a,b} haystacks, seed 4."""
+    pats = []
+    for length in range(1, 5):
+        for v in range(1 << length):
+            pats.append(bytes(ord("a") + ((v >> (length - 1 - i)) & 1) for i in range(length)))
+    pat_blob, pat_off = pack(pats)
+    hay_blob = _draw_bytes(4, n_hay * hay_len, 0, b"ab")
+    hay_off = np.arange(n_hay + 1, dtype=np.uint64) * np.uint64(hay_len)
+    return Dataset("G4", pat_blob, pat_off, hay_blob, hay_off)
+
+
+def g5() -> Dataset:
+    """Duplicate / empty / over-long pattern rules on one tiny haystack."""
+    pats = [b"ab", b"ab", b"b", b"", b"x" * 1025, b"xab"]
+    pat_blob, pat_off = pack(pats)
+    hay_blob, hay_off = pack([b"xabab_xxabb__ab_"])
+    return Dataset("G5", pat_blob, pat_off, hay_blob, hay_off)
+
+
+def g6(n_hay: int = 64, hay_len: int = 4096, n_pat: int = 65536) -> Dataset:
+    """Config 3 automaton: 65,536 patterns of 8..64 B over Sigma=256, seed 7, one plant per haystack."""
+    ds = generate("G6", 7, n_pat, 8, 64, n_hay, hay_len, None)
+    plant(ds, 37, 11, hay_len - 64, 1021, 17)
+    return ds
+
+
+def bench_batch(n_hay: int, hay_len: int = 8192, seed: int = 1, planted: bool = True) -> Dataset:
+    """Headline workload: the G1/G2 pattern set over ``n_hay`` haystacks of ``hay_len`` bytes."""
+    ds = generate("bench", seed, 2048, 16, 16, n_hay, hay_len, b"abcdef")
+    if planted:
+        plant(ds, 31, 5, hay_len - 16, 7, 3)
+    return ds
+
+
+def ragged(name: str, seed: int, n_pat: int, pat_lmin: int, pat_lmax: int, n_hay: int,
+           hay_lmin: int, hay_lmax: int, alphabet: bytes | None) -> Dataset:
+    """Variable-length haystacks (including empty ones) packed back to back, so their
+    start offsets are unaligned -- exercises head/tail handling and empty inputs."""
+    base = generate(name, seed, n_pat, pat_lmin, pat_lmax, n_hay, hay_lmax, alphabet)
+    k = np.arange(n_hay, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        lens = (np.uint64(hay_lmin) + ((k * np.uint64(40503) + np.uint64(seed)) * np.uint64(2654435761) >> np.uint64(11)) %
+                np.uint64(hay_lmax - hay_lmin + 1)).astype(np.int64)
+    full = base.hay_blob.reshape(n_hay, hay_lmax)
+    mask = np.arange(hay_lmax)[None, :] < lens[:, None]
+    hay_off = np.zeros(n_hay + 1, dtype=np.uint64)
+    hay_off[1:] = np.cumsum(lens, dtype=np.uint64)
+    return Dataset(name, base.pat_blob, base.pat_off, full[mask].copy(), hay_off)
+
+
+def r1() -> Dataset:
+    """Dense ragged: 24 patterns of 1..5 B over {a,b,NUL,0xFF}; 67 haystacks of 0..300 B."""
+    return ragged("R1", 11, 24, 1, 5, 67, 0, 300, b"ab\x00\xff")
+
+
+def r2() -> Dataset:
+    """Binary ragged: 300 patterns of 2..6 B over Sigma=256 (2-byte ones do hit); 129 haystacks of 0..5000 B."""
+    return ragged("R2", 12, 300, 2, 6, 129, 0, 5000, None)
+
+
+def r3() -> Dataset:
+    """Long patterns: 40 patterns of 900..1024 B over {x,y}; haystacks of 0..20000 B with plants."""
+    ds = ragged("R3", 13, 40, 900, 1024, 9, 3000, 20000, b"xy")
+    for h in range(ds.n_haystacks):
+        p = ds.pattern((5 * h + 1) % ds.n_patterns)
+        lo, hi = int(ds.hay_off[h]), int(ds.hay_off[h + 1])
+        at = lo + (977 * h + 13) % max(1, hi - lo - len(p))
+        ds.hay_blob[at:at + len(p)] = np.frombuffer(p, dtype=np.uint8)
+    return ds
+
+
+NAMED = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "R1": r1, "R2": r2, "R3": r3}
