@@ -1,0 +1,213 @@
+/*
+ * acmi.h -- C ABI of libacmi.so, the MI355X-native Aho-Corasick batch matcher that
+ * replaces the ac_trie_search() hot path of ph4r05/php_aho_corasick.
+ *
+ * Plain C, plain pointers and sizes, no torch / HIP types in any signature.
+ * Each entry point cites the reference interface it replaces (paths relative
+ * to the reference tree).  The inner seam being replaced is the MultiFast C API
+ * (src/multifast/ahocorasick.h:73-80) as called from exactly six sites in
+ * src/php_ahocorasick.c (:140 finalize, :484 add, :504/:821 release, :745
+ * search, :812 create).  INTEGRATION.md shows the Zend-side binding.
+ *
+ * Threading: a handle is single-caller (the reference's AC_TRIE_t carries
+ * mutable scan state, ahocorasick.h:49-65, and PHP is single-threaded);
+ * different handles may be used from different threads.
+ *
+ * Ownership: the library copies pattern bytes at acmi_add_patterns()
+ * (the reference deep-copies too: node.c:238-261 with copy=1).  Haystack
+ * buffers are borrowed for the duration of a call (php_ahocorasick.c:725-727).
+ * Result buffers returned by acmi_match()/acmi_match_batch() are owned by the
+ * handle and stay valid until the next match call on that handle or
+ * acmi_destroy().
+ */
+#ifndef ACMI_H
+#define ACMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACMI_VERSION "0.1.0"
+
+/* ---- status codes (negative = error; never aborts) ------------------------
+ * The Zend shim maps them onto the reference's PHP-level behaviour:
+ *   ACMI_E_INVALID   -> E_WARNING "Invalid resource." + false   (php_ahocorasick.c:696-699)
+ *   ACMI_E_NOT_INIT  -> E_WARNING "Not initialized."  + false   (:701-704)
+ *   ACMI_E_FINALIZED -> E_WARNING + false on add after finalize (:914-917)
+ *   device / memory errors -> E_WARNING + false (no reference counterpart).   */
+#define ACMI_OK            0
+#define ACMI_E_INVALID    (-1)   /* NULL or destroyed handle                      */
+#define ACMI_E_NOT_INIT   (-2)   /* handle exists but init_ok != 1                */
+#define ACMI_E_FINALIZED  (-3)   /* add_patterns after finalize                   */
+#define ACMI_E_ARG        (-4)   /* bad argument (NULL pointer, decreasing offsets, haystack >= 4 GiB) */
+#define ACMI_E_NOMEM      (-5)   /* host or device allocation failed              */
+#define ACMI_E_DEVICE     (-6)   /* a HIP call failed; acmi_last_error() has text */
+#define ACMI_E_NO_DEVICE  (-7)   /* no usable gfx950 device: matching is refused, there is NO CPU fallback */
+#define ACMI_E_TOO_LARGE  (-8)   /* automaton or result exceeds a hard limit      */
+
+/* Pattern identifier kinds: src/multifast/actypes.h:57-62 (enum ac_pattid_type). */
+#define ACMI_ID_DEFAULT 0
+#define ACMI_ID_NUMBER  1
+#define ACMI_ID_STRING  2
+
+/* Longest accepted pattern: src/multifast/actypes.h:148 (AC_PATTRN_MAX_LENGTH). */
+#define ACMI_PATTERN_MAX_LENGTH 1024
+
+/* One pattern as handed over by the host shim.  Replaces AC_PATTERN_t
+ * (src/multifast/actypes.h:88-94) as filled at php_ahocorasick.c:462-484:
+ * `value` = ptext, `id_type`/`id_number` = id, `user` = the aux slot that carries
+ * the shim's ahocorasick_pattern_t* (holder of the key / value / aux zvals). */
+typedef struct acmi_pattern {
+    const uint8_t *value;
+    uint32_t length;
+    uint32_t id_type;
+    int64_t id_number;
+    uint64_t user;
+} acmi_pattern;
+
+/* One match record.  Replaces what php_ahocorasick_match_handler() reads out of
+ * AC_MATCH_t for pattern j of an event (php_ahocorasick.c:555-583):
+ *   pos     = m->position                      ("pos", end offset, exclusive)
+ *   start   = m->position - strlen(value)      ("start_postion")
+ *   pattern = dense caller-order pattern index (0-based over ALL patterns ever
+ *             passed to acmi_add_patterns, accepted or not) -> key/keyIdx/aux/value
+ *   hay     = haystack index inside the batch (0 for acmi_match).
+ * Records of one haystack are in the reference's callback order: pos ascending,
+ * and within one pos longest pattern first (node.c:424-441). */
+typedef struct acmi_record {
+    uint32_t hay;
+    uint32_t pos;
+    uint32_t start;
+    uint32_t pattern;
+} acmi_record;
+
+typedef struct acmi_handle acmi_handle;
+
+/* ---- lifecycle ---------------------------------------------------------------- */
+
+/* ac_trie_create() (src/multifast/ahocorasick.c:59-77) + the master struct of
+ * PHP_FUNCTION(ahocorasick_init) (php_ahocorasick.c:811-816, init_ok=1 at :827).
+ * `device` = HIP device ordinal, or -1 for the current device.  Creating a
+ * handle does not need a GPU; the device is first touched by a match call. */
+int acmi_create(int device, acmi_handle **out);
+
+/* php_ahocorasick_process_patterns() insertion loop (php_ahocorasick.c:455-486)
+ * + ac_trie_add() (ahocorasick.c:91-131).  One call == one ahocorasick_init() /
+ * ahocorasick_add_patterns() call: the n patterns get indices base..base+n-1 in
+ * CALLER order and are inserted in REVERSE caller order; empty, over-long and
+ * duplicate patterns are silently dropped (first inserted wins, so within one
+ * call the LAST duplicate in caller order wins).  *accepted (optional) receives
+ * the number inserted.  Returns ACMI_OK, ACMI_E_FINALIZED, ... */
+int acmi_add_patterns(acmi_handle *h, const acmi_pattern *patterns, size_t n, size_t *accepted);
+
+/* php_ahocorasick_finalize() (php_ahocorasick.c:130-142) + ac_trie_finalize()
+ * (ahocorasick.c:143-155).  Builds the flat automaton.  Returns 1 the first
+ * time, 0 when already finalized (idempotent), <0 on error. */
+int acmi_finalize(acmi_handle *h);
+
+/* PHP_FUNCTION(ahocorasick_isValid) (php_ahocorasick.c:623-655): 1 / 0. */
+int acmi_is_valid(const acmi_handle *h);
+
+/* PHP_FUNCTION(ahocorasick_deinit) + resource dtor (php_ahocorasick.c:754-791,
+ * :494-512) + ac_trie_release() (ahocorasick.c:288-296).  Frees host and device
+ * memory.  Returns ACMI_OK, or ACMI_E_INVALID for NULL. */
+int acmi_destroy(acmi_handle *h);
+
+/* ---- matching ----------------------------------------------------------------- */
+
+/* PHP_FUNCTION(ahocorasick_match) (php_ahocorasick.c:664-746): one haystack,
+ * keep=0 (every call starts at the root, tests/test6.phpt), lazy finalize.
+ * find_all == 0 reproduces findAll=false: all records of the FIRST event only
+ * (php_ahocorasick.c:555-588).  *records / *n_records: handle-owned result. */
+int acmi_match(acmi_handle *h, const uint8_t *text, size_t length, int find_all,
+               const acmi_record **records, size_t *n_records);
+
+/* Batch form of the above (NEW: the reference loops in PHP userland,
+ * examples/benchmark.php:65-67).  `blob` holds the haystacks back to back,
+ * `offsets[n_haystacks+1]` their byte offsets (non-decreasing).  On return
+ * (*prefix)[k] .. (*prefix)[k+1] delimit haystack k's records in *records. */
+int acmi_match_batch(acmi_handle *h, const uint8_t *blob, const uint64_t *offsets,
+                     size_t n_haystacks, int find_all, const uint64_t **prefix,
+                     const acmi_record **records, size_t *n_records);
+
+/* Same, with blob and offsets ALREADY RESIDENT in device memory (HBM) and the
+ * results left there.  `d_blob` should be 16-byte aligned; `blob_bytes` is the
+ * size of the blob (== offsets[n_haystacks]).  *n_records receives the total. */
+int acmi_match_batch_device(acmi_handle *h, const void *d_blob, uint64_t blob_bytes,
+                            const void *d_offsets, size_t n_haystacks, int find_all,
+                            uint64_t *n_records);
+
+/* Device pointers of the last result: prefix = uint64[n_haystacks+1],
+ * records = acmi_record[n_records].  Valid until the next match call. */
+int acmi_result_device(acmi_handle *h, const void **d_prefix, const void **d_records,
+                       uint64_t *n_records);
+
+/* Drain the last device-resident result into caller HOST memory (either may be NULL):
+ * the "device match-buffer drain" that replaces the per-event callback
+ * (php_ahocorasick.c:542-589). */
+int acmi_result_to_host(acmi_handle *h, uint64_t *prefix, acmi_record *records);
+
+/* Copy the last result into caller-owned DEVICE buffers (either may be NULL), e.g. the
+ * send buffers of the multi-GPU all-gather.  Ordered on the handle's stream and
+ * synchronized before returning. */
+int acmi_result_to_device(acmi_handle *h, void *d_prefix_dst, void *d_records_dst);
+
+/* ---- pattern metadata for the shim's zval pack (php_ahocorasick.c:562-583) ---- */
+
+size_t acmi_pattern_count(const acmi_handle *h);
+/* Fills *out for caller-order pattern `index` (value pointer = library copy). */
+int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
+
+/* ---- knobs, statistics, diagnostics ---------------------------------------------- */
+
+/* Integer options, set before finalize unless noted:
+ *   "lds_bytes"      LDS budget for the hot-state tile (default 160 KiB minus slack)
+ *   "slab_events"    per work-item event slots before the overflow path (default 8)
+ *   "chunk_bytes"    force the work-item size (0 = automatic)            [any time]
+ *   "kernel"         0 = plain global-table kernel, 1 = LDS-tile kernel  [any time]
+ *   "ilp"            streams per lane in the LDS-tile kernel (1 or 2)    [any time]
+ *   "profile"        1 = bracket the scan kernel with HIP events         [any time] */
+int acmi_set_option(acmi_handle *h, const char *key, int64_t value);
+
+/* Numeric facts about the automaton and the last match call, e.g. "states",
+ * "hot_states", "columns", "entry_bytes", "lds_image_bytes", "table_bytes",
+ * "max_pattern_length", "items", "overflow_items", "scan_ms", "total_ms". */
+int acmi_get_stat(const acmi_handle *h, const char *key, double *value);
+
+/* Run subsequent launches on this hipStream_t (passed as void*); NULL = the
+ * handle's own stream. */
+int acmi_set_stream(acmi_handle *h, void *hip_stream);
+
+/* Flat host tables of the finalized automaton, for CPU-side inspection by
+ * tests (no device needed).  Pointers are handle-owned. */
+typedef struct acmi_tables {
+    uint32_t n_states;       /* incl. the trap row                             */
+    uint32_t n_columns;      /* byte classes per row                           */
+    uint32_t entry_bytes;    /* 2 or 4                                         */
+    uint32_t first_hot_final;/* F1: states [F1, trap) are hot and final        */
+    uint32_t trap;           /* T : states [0, T) are LDS-resident             */
+    uint32_t first_cold_final;/* F2: states [F2, n_states) are cold and final  */
+    uint32_t class_mode;     /* 0 = table lookup, 1 = 3-bit window (SWAR)      */
+    uint32_t swar_shift;
+    uint32_t swar_other;
+    uint32_t max_pattern_length;
+    const void *table;       /* n_states x n_columns transitions               */
+    const void *lds_image;   /* (trap+1) x n_columns, cold targets -> trap     */
+    const uint8_t *class_of_byte; /* 256 entries                               */
+    const uint32_t *own_pattern;  /* per state, 0xFFFFFFFF = none              */
+    const uint32_t *dict_link;    /* per state, 0xFFFFFFFF = none              */
+    const uint32_t *out_count;    /* per state                                 */
+} acmi_tables;
+int acmi_debug_tables(const acmi_handle *h, acmi_tables *out);
+
+const char *acmi_strerror(int status);
+const char *acmi_last_error(const acmi_handle *h);
+const char *acmi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACMI_H */

@@ -1,0 +1,113 @@
+"""Device-resident batch entry and multi-GPU sharding.
+
+torch is plumbing here: device memory for the haystack blob, the current HIP stream, and
+``torch.distributed`` (backend "nccl" == RCCL over xGMI on ROCm; "gloo" in CPU tests).
+
+Sharding: haystacks are independent (keep=0, php_ahocorasick.c:745;
+tests/test6.phpt), so a batch is cut into contiguous haystack ranges, one per rank; the
+automaton is replicated (every rank builds it from the same pattern list); the only exchange
+step is the all-gatherv that concatenates the per-rank match arrays in rank order, which is
+the reference's global order because the shards are contiguous.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+from .api import AhoResource
+
+
+def shard_range(n: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous balanced split of n haystacks: ranks [0, n % world) get one extra."""
+    q, r = divmod(n, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def bind_current_stream(res: AhoResource) -> None:
+    """Run the handle's launches on torch's current HIP stream."""
+    import torch
+    N.check(N.lib.acmi_set_stream(res._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)), res._h)
+
+
+def match_device(res: AhoResource, d_blob, d_off, find_all: bool = True) -> int:
+    """Scan a batch that already lives in HBM.  ``d_blob``: uint8 CUDA tensor, ``d_off``: int64 CUDA
+    tensor of n+1 byte offsets.  Results stay on the device (see ``result_tensors``).  Returns the
+    number of records."""
+    assert d_blob.is_cuda and d_off.is_cuda and d_blob.is_contiguous() and d_off.is_contiguous()
+    nh = d_off.numel() - 1
+    total = C.c_uint64(0)
+    N.check(N.lib.acmi_match_batch_device(res._h, C.c_void_p(d_blob.data_ptr()), d_blob.numel(),
+                                          C.c_void_p(d_off.data_ptr()), nh, 1 if find_all else 0,
+                                          C.byref(total)), res._h)
+    return int(total.value)
+
+
+def result_tensors(res: AhoResource, n_haystacks: int, total: int, device=None):
+    """Copy the last result into torch-owned CUDA tensors: (prefix int64[nh+1], records int32[n,4])."""
+    import torch
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    prefix = torch.empty(n_haystacks + 1, dtype=torch.int64, device=device)
+    records = torch.empty((max(total, 1), 4), dtype=torch.int32, device=device)
+    N.check(N.lib.acmi_result_to_device(res._h, C.c_void_p(prefix.data_ptr()), C.c_void_p(records.data_ptr())),
+            res._h)
+    return prefix, records[:total]
+
+
+def result_numpy(res: AhoResource, n_haystacks: int, total: int):
+    prefix = np.zeros(n_haystacks + 1, dtype=np.uint64)
+    records = np.zeros((max(total, 1), 4), dtype=np.uint32)
+    N.check(N.lib.acmi_result_to_host(res._h, prefix.ctypes.data, records.ctypes.data), res._h)
+    return prefix, records[:total]
+
+
+def allgatherv_records(counts_local, records_local, hay_base: int, group=None):
+    """All-gatherv of match arrays: every rank ends with the concatenation, in rank order, of all
+    ranks' per-haystack counts and records (haystack ids made global with ``hay_base``).
+
+    RCCL has no native v-variant; sizes are exchanged first (fixed-size all_gather), then the
+    payloads are padded to the largest shard and exchanged with one all_gather each.  Match arrays
+    are tiny next to the haystacks on sparse workloads (16 B per record), so padding costs nothing
+    that matters; the dense adversarial case would rather gather to the caller's rank only.
+
+    ``counts_local``: int64[n_local] records per local haystack; ``records_local``: int32[n,4].
+    Returns (prefix int64[n_global+1], records int32[total,4]) on the same device as the inputs.
+    """
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    dev = records_local.device
+    rec = records_local.clone()
+    if rec.numel():
+        rec[:, 0] += hay_base
+    sizes = torch.tensor([rec.shape[0], counts_local.numel()], dtype=torch.int64, device=dev)
+    all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes, group=group)
+    all_sizes = torch.stack(all_sizes).cpu()
+    max_rec, max_cnt = int(all_sizes[:, 0].max()), int(all_sizes[:, 1].max())
+
+    rec_pad = torch.zeros((max(max_rec, 1), 4), dtype=torch.int32, device=dev)
+    rec_pad[:rec.shape[0]] = rec
+    cnt_pad = torch.zeros(max(max_cnt, 1), dtype=torch.int64, device=dev)
+    cnt_pad[:counts_local.numel()] = counts_local
+    rec_all = [torch.empty_like(rec_pad) for _ in range(world)]
+    cnt_all = [torch.empty_like(cnt_pad) for _ in range(world)]
+    dist.all_gather(rec_all, rec_pad, group=group)
+    dist.all_gather(cnt_all, cnt_pad, group=group)
+    records = torch.cat([rec_all[r][:int(all_sizes[r, 0])] for r in range(world)])
+    counts = torch.cat([cnt_all[r][:int(all_sizes[r, 1])] for r in range(world)])
+    prefix = torch.zeros(counts.numel() + 1, dtype=torch.int64, device=dev)
+    prefix[1:] = torch.cumsum(counts, 0)
+    return prefix, records
+
+
+def sharded_match(res: AhoResource, d_blob_local, d_off_local, hay_base: int, find_all: bool = True, group=None):
+    """One rank's part of a sharded batch: scan the local contiguous haystack range on this GPU,
+    then all-gatherv.  Returns the GLOBAL (prefix, records) on every rank."""
+    nh = d_off_local.numel() - 1
+    total = match_device(res, d_blob_local, d_off_local, find_all)
+    prefix, records = result_tensors(res, nh, total, d_blob_local.device)
+    counts = prefix[1:] - prefix[:-1]
+    return allgatherv_records(counts, records, hay_base, group)

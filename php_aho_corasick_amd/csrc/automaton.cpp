@@ -1,0 +1,283 @@
+// automaton.cpp -- see automaton.hpp.
+#include "automaton.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace acmi {
+
+namespace {
+inline uint64_t mix(uint64_t k) {
+    k *= 0x9E3779B97F4A7C15ull;
+    return k ^ (k >> 29);
+}
+
+template <typename E>
+void build_tables(FlatAutomaton &fa, const std::vector<uint32_t> &order,
+                  const std::vector<uint32_t> &fail, const std::vector<uint32_t> &newid,
+                  const std::vector<uint32_t> &child_off, const std::vector<uint32_t> &child_list,
+                  const std::vector<uint8_t> &in_byte) {
+    const size_t nc = fa.n_columns;
+    fa.table.assign(size_t(fa.n_states) * nc * sizeof(E), 0);
+    E *tab = reinterpret_cast<E *>(fa.table.data());
+    for (uint32_t u : order) {  // BFS order: the failure state's row is already complete
+        E *row = tab + size_t(newid[u]) * nc;
+        if (u != 0)
+            std::memcpy(row, tab + size_t(newid[fail[u]]) * nc, nc * sizeof(E));
+        // (root row stays all-zero: every byte without a goto edge returns to the root)
+        for (uint32_t e = child_off[u]; e < child_off[u + 1]; ++e) {
+            uint32_t c = child_list[e];
+            row[fa.class_of_byte[in_byte[c]]] = E(newid[c]);
+        }
+    }
+    E *trap_row = tab + size_t(fa.trap) * nc;
+    for (size_t j = 0; j < nc; ++j) trap_row[j] = E(fa.trap);
+
+    // LDS tile: hot rows only; a transition that leaves the tile lands on the trap row
+    const size_t hot_rows = size_t(fa.trap) + 1;
+    fa.lds_image.resize(hot_rows * nc * sizeof(E));
+    E *img = reinterpret_cast<E *>(fa.lds_image.data());
+    for (size_t i = 0; i < hot_rows * nc; ++i) img[i] = tab[i] > E(fa.trap) ? E(fa.trap) : tab[i];
+}
+}  // namespace
+
+Automaton::Automaton() {
+    parent_.push_back(kNone);
+    in_byte_.push_back(0);
+    own_.push_back(kNone);
+    rehash(1024);
+}
+
+void Automaton::rehash(size_t new_cap) {
+    std::vector<uint64_t> keys(new_cap, 0);
+    std::vector<uint32_t> vals(new_cap, 0);
+    const size_t mask = new_cap - 1;
+    for (size_t i = 0; i < map_keys_.size(); ++i) {
+        if (!map_keys_[i]) continue;
+        size_t s = mix(map_keys_[i]) & mask;
+        while (keys[s]) s = (s + 1) & mask;
+        keys[s] = map_keys_[i];
+        vals[s] = map_vals_[i];
+    }
+    map_keys_.swap(keys);
+    map_vals_.swap(vals);
+}
+
+uint32_t Automaton::find_child(uint32_t node, uint8_t byte) const {
+    const uint64_t key = ((uint64_t(node) << 8) | byte) + 1;
+    const size_t mask = map_keys_.size() - 1;
+    size_t s = mix(key) & mask;
+    while (map_keys_[s]) {
+        if (map_keys_[s] == key) return map_vals_[s];
+        s = (s + 1) & mask;
+    }
+    return kNone;
+}
+
+uint32_t Automaton::add_child(uint32_t node, uint8_t byte) {
+    if ((map_used_ + 1) * 2 > map_keys_.size()) rehash(map_keys_.size() * 2);
+    const uint32_t child = uint32_t(parent_.size());
+    parent_.push_back(node);
+    in_byte_.push_back(byte);
+    own_.push_back(kNone);
+    const uint64_t key = ((uint64_t(node) << 8) | byte) + 1;
+    const size_t mask = map_keys_.size() - 1;
+    size_t s = mix(key) & mask;
+    while (map_keys_[s]) s = (s + 1) & mask;
+    map_keys_[s] = key;
+    map_vals_[s] = child;
+    ++map_used_;
+    return child;
+}
+
+size_t Automaton::add_batch(const uint8_t *const *values, const uint32_t *lengths,
+                            const uint32_t *id_types, const int64_t *id_numbers,
+                            const uint64_t *users, size_t n) {
+    const uint32_t base = uint32_t(patterns_.size());
+    for (size_t k = 0; k < n; ++k) {
+        PatternMeta m;
+        m.byte_off = pattern_bytes_.size();
+        m.length = lengths[k];
+        m.id_type = id_types ? id_types[k] : 0;
+        m.id_number = id_numbers ? id_numbers[k] : 0;
+        m.user = users ? users[k] : 0;
+        m.accepted = false;
+        if (lengths[k]) pattern_bytes_.insert(pattern_bytes_.end(), values[k], values[k] + lengths[k]);
+        patterns_.push_back(m);
+    }
+    size_t accepted = 0;
+    for (size_t k = n; k-- > 0;) {  // reverse caller order (php_ahocorasick.c:410-421,457-486)
+        const uint32_t len = lengths[k];
+        if (len == 0 || len > kMaxPatternLength) continue;  // ahocorasick.c:101-105
+        const uint8_t *p = values[k];
+        uint32_t node = 0;
+        for (uint32_t i = 0; i < len; ++i) {
+            uint32_t nx = find_child(node, p[i]);
+            if (nx == kNone) nx = add_child(node, p[i]);
+            node = nx;
+        }
+        if (own_[node] != kNone) continue;  // duplicate: first inserted wins (ahocorasick.c:123-124)
+        own_[node] = base + uint32_t(k);
+        patterns_[base + k].accepted = true;
+        ++accepted;
+    }
+    accepted_ += accepted;
+    return accepted;
+}
+
+bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
+    if (finalized_) return true;
+    const uint32_t ns = uint32_t(parent_.size());
+    FlatAutomaton &fa = flat_;
+
+    // ---- children in CSR form, BFS order ------------------------------------------------
+    std::vector<uint32_t> child_off(ns + 1, 0), child_list(ns > 1 ? ns - 1 : 0);
+    for (uint32_t v = 1; v < ns; ++v) ++child_off[parent_[v] + 1];
+    for (uint32_t v = 0; v < ns; ++v) child_off[v + 1] += child_off[v];
+    {
+        std::vector<uint32_t> cur(child_off.begin(), child_off.end() - 1);
+        for (uint32_t v = 1; v < ns; ++v) child_list[cur[parent_[v]]++] = v;
+    }
+    std::vector<uint32_t> order;
+    order.reserve(ns);
+    order.push_back(0);
+    for (size_t head = 0; head < order.size(); ++head) {
+        const uint32_t u = order[head];
+        for (uint32_t e = child_off[u]; e < child_off[u + 1]; ++e) order.push_back(child_list[e]);
+    }
+
+    // ---- failure links (textbook BFS; same function as ahocorasick.c:344-368 defines) ----
+    std::vector<uint32_t> fail(ns, 0);
+    for (uint32_t u : order) {
+        if (u == 0) continue;
+        const uint32_t p = parent_[u];
+        if (p == 0) continue;
+        const uint8_t b = in_byte_[u];
+        uint32_t f = fail[p];
+        for (;;) {
+            const uint32_t c = find_child(f, b);
+            if (c != kNone) { fail[u] = c; break; }
+            if (f == 0) break;
+            f = fail[f];
+        }
+    }
+
+    // ---- per-state output: final flag, record count, dictionary link (node.c:424-441) ----
+    std::vector<uint8_t> is_final(ns, 0);
+    std::vector<uint32_t> cnt(ns, 0), dict(ns, kNone);
+    for (uint32_t u : order) {
+        if (u == 0) continue;
+        const uint32_t f = fail[u];
+        is_final[u] = (own_[u] != kNone) || is_final[f];
+        cnt[u] = (own_[u] != kNone ? 1u : 0u) + cnt[f];
+        dict[u] = own_[f] != kNone ? f : dict[f];
+    }
+
+    // ---- byte classes ----------------------------------------------------------------------
+    bool used[256] = {false};
+    for (uint32_t v = 1; v < ns; ++v) used[in_byte_[v]] = true;
+    uint32_t nused = 0;
+    for (int b = 0; b < 256; ++b) nused += used[b];
+    fa.n_used_bytes = nused;
+    fa.class_mode = kClassTable;
+    if (nused <= 8) {
+        for (uint32_t k = 0; k <= 5 && fa.class_mode != kClassSwar3; ++k) {
+            bool seen[8] = {false};
+            bool ok = true;
+            for (int b = 0; b < 256 && ok; ++b) {
+                if (!used[b]) continue;
+                const uint32_t j = (uint32_t(b) >> k) & 7;
+                if (seen[j]) ok = false;
+                seen[j] = true;
+            }
+            if (!ok) continue;
+            fa.class_mode = kClassSwar3;
+            fa.swar_shift = k;
+            uint32_t other = 8, maxb = 0;
+            for (uint32_t j = 0; j < 8; ++j) {
+                if (!seen[j] && other == 8) other = j;
+                if (seen[j]) maxb = j;
+            }
+            fa.swar_other = other;
+            fa.n_columns = std::max(maxb, other) + 1;
+            uint8_t expect[8];
+            for (uint32_t j = 0; j < 8; ++j) expect[j] = uint8_t(((j + 1) & 7) << k);  // lands in bucket j+1: never validates
+            for (int b = 0; b < 256; ++b)
+                if (used[b]) expect[(uint32_t(b) >> k) & 7] = uint8_t(b);
+            fa.swar_expect_lo = expect[0] | (expect[1] << 8) | (expect[2] << 16) | (uint32_t(expect[3]) << 24);
+            fa.swar_expect_hi = expect[4] | (expect[5] << 8) | (expect[6] << 16) | (uint32_t(expect[7]) << 24);
+            for (int b = 0; b < 256; ++b)
+                fa.class_of_byte[b] = uint8_t(used[b] ? ((uint32_t(b) >> k) & 7) : other);
+        }
+    }
+    if (fa.class_mode == kClassTable) {
+        if (nused == 256) {
+            fa.n_columns = 256;
+            for (int b = 0; b < 256; ++b) fa.class_of_byte[b] = uint8_t(b);
+        } else {
+            uint32_t next = 1;  // column 0 = every byte outside the alphabet
+            for (int b = 0; b < 256; ++b) fa.class_of_byte[b] = uint8_t(used[b] ? next++ : 0);
+            fa.n_columns = nused + 1;
+        }
+    }
+
+    // ---- state numbering: [hot non-final | hot final | trap | cold non-final | cold final] ----
+    fa.n_states = ns + 1;
+    fa.entry_bytes = ns <= 65535 ? 2 : 4;
+    const uint64_t row_bytes = uint64_t(fa.n_columns) * fa.entry_bytes;
+    const uint64_t table_bytes = row_bytes * fa.n_states;
+    if (table_bytes > opt.max_table_bytes) {
+        if (error) *error = "transition table of " + std::to_string(table_bytes) + " bytes exceeds the limit";
+        return false;
+    }
+    const uint64_t class_tab = fa.class_mode == kClassTable ? 512 : 0;  // uint16 column offsets
+    uint64_t max_rows = opt.lds_bytes > class_tab ? (opt.lds_bytes - class_tab) / row_bytes : 0;
+    if (max_rows < 2) max_rows = 2;  // root + trap always fit (row <= 1 KiB)
+    const uint32_t hot = uint32_t(std::min<uint64_t>(ns, max_rows - 1));
+    std::vector<uint32_t> newid(ns);
+    uint32_t hot_nf = 0, cold_nf = 0;
+    for (uint32_t i = 0; i < ns; ++i) {
+        const uint32_t u = order[i];
+        if (!is_final[u]) (i < hot ? hot_nf : cold_nf)++;
+    }
+    fa.f1 = hot_nf;
+    fa.trap = hot;
+    fa.f2 = hot + 1 + cold_nf;
+    {
+        uint32_t a = 0, b = hot_nf, c = hot + 1, d = fa.f2;
+        for (uint32_t i = 0; i < ns; ++i) {
+            const uint32_t u = order[i];
+            if (i < hot) newid[u] = is_final[u] ? b++ : a++;
+            else newid[u] = is_final[u] ? d++ : c++;
+        }
+    }
+
+    // ---- tables ----------------------------------------------------------------------------------
+    if (fa.entry_bytes == 2)
+        build_tables<uint16_t>(fa, order, fail, newid, child_off, child_list, in_byte_);
+    else
+        build_tables<uint32_t>(fa, order, fail, newid, child_off, child_list, in_byte_);
+
+    fa.own_pattern.assign(fa.n_states, kNone);
+    fa.dict_link.assign(fa.n_states, kNone);
+    fa.out_count.assign(fa.n_states, 0);
+    for (uint32_t u = 0; u < ns; ++u) {
+        fa.own_pattern[newid[u]] = own_[u];
+        fa.dict_link[newid[u]] = dict[u] == kNone ? kNone : newid[dict[u]];
+        fa.out_count[newid[u]] = cnt[u];
+    }
+    fa.pattern_length.resize(patterns_.size());
+    fa.max_pattern_length = 0;
+    for (size_t i = 0; i < patterns_.size(); ++i) {
+        fa.pattern_length[i] = patterns_[i].length;
+        if (patterns_[i].accepted) fa.max_pattern_length = std::max(fa.max_pattern_length, patterns_[i].length);
+    }
+
+    // the build-time trie is no longer needed
+    std::vector<uint64_t>().swap(map_keys_);
+    std::vector<uint32_t>().swap(map_vals_);
+    finalized_ = true;
+    return true;
+}
+
+}  // namespace acmi

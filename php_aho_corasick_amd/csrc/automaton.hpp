@@ -1,0 +1,109 @@
+// automaton.hpp -- host-side builder: ordered pattern list -> flat device automaton.
+//
+// Replaces the reference's build path (ac_trie_add, ahocorasick.c:91-131;
+// ac_trie_finalize, :143-155; ac_trie_set_failure, :344-368; node_collect_matches,
+// node.c:424-441) with a from-scratch design whose OUTPUT is what the HIP kernels
+// want: a failure-free transition table (one lookup per haystack byte), states
+// renumbered so that "LDS-resident" and "final" are range tests, and per-state
+// output lists kept as (own pattern, dictionary link) chains.
+//
+// What must be reproduced from the reference is behaviour, not code:
+//   * reverse-within-call insertion, first inserted wins on duplicates
+//     (php_ahocorasick.c:410-421,457-486; ahocorasick.c:123-124);
+//   * empty and > 1024 B patterns are dropped (ahocorasick.c:101-105);
+//   * a state reports when any pattern is a suffix of its path (`final` ORed
+//     along the failure chain, node.c:436-437) and lists them longest first
+//     (own pattern, then every failure ancestor's, node.c:429-435).
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace acmi {
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr uint32_t kMaxPatternLength = 1024;  // actypes.h:148
+
+struct PatternMeta {
+    uint64_t byte_off;   // into Automaton::pattern_bytes
+    uint32_t length;
+    uint32_t id_type;
+    int64_t id_number;
+    uint64_t user;
+    bool accepted;
+};
+
+struct BuildOptions {
+    uint32_t lds_bytes = 160 * 1024 - 512;  // budget for class table + hot tile
+    uint64_t max_table_bytes = 64ull << 30; // refuse automata whose table exceeds this
+};
+
+enum ClassMode : uint32_t { kClassTable = 0, kClassSwar3 = 1 };
+
+// Everything the device needs, in host memory, after finalize().
+struct FlatAutomaton {
+    uint32_t n_states = 0;       // real states + 1 trap row
+    uint32_t n_columns = 0;      // byte classes per row
+    uint32_t entry_bytes = 2;    // 2 (uint16) when n_states <= 65536, else 4
+    uint32_t f1 = 0;             // [0,f1) hot non-final, [f1,trap) hot final
+    uint32_t trap = 0;           // id of the trap row == number of hot states
+    uint32_t f2 = 0;             // (trap,f2) cold non-final, [f2,n_states) cold final
+    uint32_t class_mode = kClassTable;
+    uint32_t swar_shift = 0;     // class = (byte >> shift) & 7 when byte is in the alphabet
+    uint32_t swar_other = 0;     // column of every byte outside the alphabet
+    uint32_t swar_expect_lo = 0; // expected byte of buckets 0..3 (v_perm source)
+    uint32_t swar_expect_hi = 0; // expected byte of buckets 4..7
+    uint32_t max_pattern_length = 0;
+    uint32_t n_used_bytes = 0;
+    std::vector<uint8_t> table;      // n_states x n_columns entries, true transitions
+    std::vector<uint8_t> lds_image;  // (trap+1) x n_columns entries, cold targets -> trap
+    uint8_t class_of_byte[256] = {0};
+    std::vector<uint32_t> own_pattern;  // per state
+    std::vector<uint32_t> dict_link;    // per state: nearest failure ancestor owning a pattern
+    std::vector<uint32_t> out_count;    // per state: records one event expands to
+    std::vector<uint32_t> pattern_length;  // per caller-order pattern index
+};
+
+class Automaton {
+public:
+    Automaton();
+
+    // One init()/add_patterns() call.  Returns number accepted.
+    size_t add_batch(const uint8_t *const *values, const uint32_t *lengths,
+                     const uint32_t *id_types, const int64_t *id_numbers,
+                     const uint64_t *users, size_t n);
+
+    // Returns false (and sets error) when the automaton cannot be represented.
+    bool finalize(const BuildOptions &opt, std::string *error);
+
+    bool finalized() const { return finalized_; }
+    size_t node_count() const { return parent_.size(); }
+    size_t accepted_count() const { return accepted_; }
+    const std::vector<PatternMeta> &patterns() const { return patterns_; }
+    const std::vector<uint8_t> &pattern_bytes() const { return pattern_bytes_; }
+    const FlatAutomaton &flat() const { return flat_; }
+
+private:
+    uint32_t find_child(uint32_t node, uint8_t byte) const;
+    uint32_t add_child(uint32_t node, uint8_t byte);
+    void rehash(size_t new_cap);
+
+    // trie: node 0 is the root; every other node is one edge (parent, byte) -> node
+    std::vector<uint32_t> parent_;
+    std::vector<uint8_t> in_byte_;
+    std::vector<uint32_t> own_;  // pattern index owned by the node, or kNone
+
+    // open-addressing map (parent << 8 | byte) -> child
+    std::vector<uint64_t> map_keys_;
+    std::vector<uint32_t> map_vals_;
+    size_t map_used_ = 0;
+
+    std::vector<PatternMeta> patterns_;
+    std::vector<uint8_t> pattern_bytes_;
+    size_t accepted_ = 0;
+    bool finalized_ = false;
+    FlatAutomaton flat_;
+};
+
+}  // namespace acmi

@@ -1,0 +1,46 @@
+// device_types.hpp -- plain structs shared by the host engine and the HIP kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace acmi {
+
+// Automaton as the kernels see it (all pointers are device pointers).
+struct DevAutomaton {
+    const void *table;           // n_states x n_columns transitions (uint16 or uint32)
+    const void *lds_image;       // [class offsets (TABLE mode, 512 B)] + (trap+1) x n_columns tile
+    const uint16_t *class_off;   // 256 entries: byte -> column * entry_bytes (global copy)
+    const uint32_t *own_pattern; // per state
+    const uint32_t *dict_link;   // per state
+    const uint32_t *out_count;   // per state
+    const uint32_t *pattern_length;  // per pattern
+    uint32_t n_states;
+    uint32_t n_columns;
+    uint32_t row_bytes;          // n_columns * entry_bytes
+    uint32_t f1, trap, f2;       // state-id ranges, see automaton.hpp
+    uint32_t lds_image_bytes;    // bytes to stage into LDS (class offsets + tile)
+    uint32_t tile_offset;        // byte offset of the tile inside the LDS image (0 or 512)
+    uint32_t swar_shift, swar_expect_lo, swar_expect_hi, swar_other_off;  // other column * entry_bytes
+};
+
+// One batch launch.
+struct BatchArgs {
+    const uint8_t *blob;
+    const uint64_t *offsets;     // n_haystacks + 1
+    const uint64_t *item_base;   // n_haystacks + 1: first work item of each haystack
+    uint32_t n_haystacks;
+    uint32_t chunk_bytes;        // reporting bytes per work item
+    uint32_t warm_bytes;         // max_pattern_length - 1
+    uint32_t slab_events;        // K: event slots per work item
+    uint32_t first_only;         // findAll == false
+    uint32_t *item_hay;          // per item: haystack index
+    uint32_t *ev_count;          // per item: events seen
+    uint64_t *rec_count;         // per item: records those events expand to
+    uint2 *slab;                 // per item: K x {pos, state}
+    uint32_t *overflow_list;     // items whose events did not fit their slab
+    uint32_t *counters;          // [0] = number of overflowed items
+};
+
+}  // namespace acmi

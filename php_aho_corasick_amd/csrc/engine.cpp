@@ -1,0 +1,610 @@
+// engine.cpp -- handle lifecycle, device memory, batch pipeline and the C ABI (include/acmi.h).
+//
+// Host-side counterpart of the reference's Zend glue around MultiFast
+// (src/php_ahocorasick.c): what PHP_FUNCTION(ahocorasick_match) + the match callback do per
+// haystack (:664-746, :542-589) is done here per BATCH: stage haystacks, run the HIP scan,
+// drain the device match buffer into {hay,pos,start,pattern} records.  There is no CPU
+// matching path in this library: without a usable gfx950 device every match call fails with
+// ACMI_E_NO_DEVICE / ACMI_E_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/acmi.h"
+#include "automaton.hpp"
+#include "device_types.hpp"
+#include "kernels.hpp"
+
+using namespace acmi;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 256;  // grow-only workspace with a little slack
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
+std::mutex g_live_mutex;
+std::unordered_set<const acmi_handle *> g_live;
+
+}  // namespace
+
+struct acmi_handle {
+    int init_ok = 0;
+    int device_request = -1;
+    Automaton aut;
+    BuildOptions bopt;
+
+    // options
+    uint32_t slab_events = 8;
+    uint64_t chunk_opt = 0;
+    int kernel = 1;
+    int ilp = 1;
+    int profile = 0;
+
+    // device state
+    bool dev_ready = false;
+    int dev_id = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    DevAutomaton dA{};
+    DevBuf d_table, d_lds, d_class, d_own, d_dict, d_cnt, d_plen;
+
+    // workspace (grow-only)
+    DevBuf d_blob, d_off, d_nitems, d_item_base, d_item_hay, d_ev, d_rec_cnt, d_rec_base, d_slab, d_ovf, d_counters,
+        d_scan_tmp, d_prefix, d_out;
+    uint64_t *pinned = nullptr;  // [0] total records, [1] overflow items
+
+    // last result
+    uint64_t last_total = 0;
+    uint32_t last_nh = 0;
+    bool have_result = false;
+    std::vector<acmi_record> h_records;
+    std::vector<uint64_t> h_prefix;
+
+    // statistics of the last call
+    double scan_ms = 0, total_ms = 0;
+    uint64_t items = 0, chunk_used = 0;
+    uint32_t overflow_items = 0;
+
+    std::string last_error;
+};
+
+namespace {
+
+bool live(const acmi_handle *h) {
+    if (!h) return false;
+    std::lock_guard<std::mutex> g(g_live_mutex);
+    return g_live.count(h) != 0;
+}
+
+int fail_hip(acmi_handle *h, hipError_t e, const char *what) {
+    h->last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return (e == hipErrorOutOfMemory) ? ACMI_E_NOMEM : ACMI_E_DEVICE;
+}
+
+#define HIPCHK(h, call)                                   \
+    do {                                                  \
+        hipError_t _e = (call);                           \
+        if (_e != hipSuccess) return fail_hip(h, _e, #call); \
+    } while (0)
+
+int ensure_finalized(acmi_handle *h) {
+    if (h->aut.finalized()) return 0;
+    std::string err;
+    if (!h->aut.finalize(h->bopt, &err)) {
+        h->last_error = err;
+        return ACMI_E_TOO_LARGE;
+    }
+    return 1;
+}
+
+int ensure_device(acmi_handle *h) {
+    if (h->dev_ready) {
+        HIPCHK(h, hipSetDevice(h->dev_id));
+        return ACMI_OK;
+    }
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        h->last_error = "no HIP device visible (this library has no CPU matching path)";
+        return ACMI_E_NO_DEVICE;
+    }
+    int dev = h->device_request;
+    if (dev < 0) HIPCHK(h, hipGetDevice(&dev));
+    if (dev >= count) {
+        h->last_error = "device ordinal out of range";
+        return ACMI_E_NO_DEVICE;
+    }
+    HIPCHK(h, hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    HIPCHK(h, hipGetDeviceProperties(&prop, dev));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        h->last_error = std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only";
+        return ACMI_E_NO_DEVICE;
+    }
+    h->dev_id = dev;
+    HIPCHK(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    if (!h->stream) h->stream = h->own_stream;
+    for (auto &evt : h->ev) HIPCHK(h, hipEventCreate(&evt));
+    HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->pinned), 64, hipHostMallocDefault));
+
+    // upload the flat automaton
+    const FlatAutomaton &fa = h->aut.flat();
+    const bool table_mode = fa.class_mode == kClassTable;
+    uint16_t class_off[256];
+    for (int b = 0; b < 256; ++b) class_off[b] = uint16_t(fa.class_of_byte[b] * fa.entry_bytes);
+    std::vector<uint8_t> image;
+    if (table_mode) image.insert(image.end(), reinterpret_cast<uint8_t *>(class_off), reinterpret_cast<uint8_t *>(class_off) + 512);
+    image.insert(image.end(), fa.lds_image.begin(), fa.lds_image.end());
+    while (image.size() % 16) image.push_back(0);
+
+    HIPCHK(h, h->d_table.ensure(fa.table.size()));
+    HIPCHK(h, hipMemcpy(h->d_table.p, fa.table.data(), fa.table.size(), hipMemcpyHostToDevice));
+    HIPCHK(h, h->d_lds.ensure(image.size()));
+    HIPCHK(h, hipMemcpy(h->d_lds.p, image.data(), image.size(), hipMemcpyHostToDevice));
+    HIPCHK(h, h->d_class.ensure(512));
+    HIPCHK(h, hipMemcpy(h->d_class.p, class_off, 512, hipMemcpyHostToDevice));
+    const size_t ns4 = size_t(fa.n_states) * 4;
+    HIPCHK(h, h->d_own.ensure(ns4));
+    HIPCHK(h, hipMemcpy(h->d_own.p, fa.own_pattern.data(), ns4, hipMemcpyHostToDevice));
+    HIPCHK(h, h->d_dict.ensure(ns4));
+    HIPCHK(h, hipMemcpy(h->d_dict.p, fa.dict_link.data(), ns4, hipMemcpyHostToDevice));
+    HIPCHK(h, h->d_cnt.ensure(ns4));
+    HIPCHK(h, hipMemcpy(h->d_cnt.p, fa.out_count.data(), ns4, hipMemcpyHostToDevice));
+    const size_t np4 = std::max<size_t>(4, fa.pattern_length.size() * 4);
+    HIPCHK(h, h->d_plen.ensure(np4));
+    if (!fa.pattern_length.empty())
+        HIPCHK(h, hipMemcpy(h->d_plen.p, fa.pattern_length.data(), fa.pattern_length.size() * 4, hipMemcpyHostToDevice));
+
+    DevAutomaton &A = h->dA;
+    A.table = h->d_table.p;
+    A.lds_image = h->d_lds.p;
+    A.class_off = h->d_class.as<uint16_t>();
+    A.own_pattern = h->d_own.as<uint32_t>();
+    A.dict_link = h->d_dict.as<uint32_t>();
+    A.out_count = h->d_cnt.as<uint32_t>();
+    A.pattern_length = h->d_plen.as<uint32_t>();
+    A.n_states = fa.n_states;
+    A.n_columns = fa.n_columns;
+    A.row_bytes = fa.n_columns * fa.entry_bytes;
+    A.f1 = fa.f1;
+    A.trap = fa.trap;
+    A.f2 = fa.f2;
+    A.lds_image_bytes = uint32_t(image.size());
+    A.tile_offset = table_mode ? 512u : 0u;
+    A.swar_shift = fa.swar_shift;
+    A.swar_expect_lo = fa.swar_expect_lo;
+    A.swar_expect_hi = fa.swar_expect_hi;
+    A.swar_other_off = fa.swar_other * fa.entry_bytes;
+    h->dev_ready = true;
+    return ACMI_OK;
+}
+
+uint32_t choose_chunk(const acmi_handle *h, uint64_t blob_bytes) {
+    const uint32_t warm = h->aut.flat().max_pattern_length ? h->aut.flat().max_pattern_length - 1 : 0;
+    if (h->chunk_opt) {
+        uint64_t c = (h->chunk_opt + 15) & ~uint64_t(15);
+        return uint32_t(std::min<uint64_t>(std::max<uint64_t>(c, 16), 1u << 30));
+    }
+    // enough work items to fill 256 CUs x 1024 lanes x 2 streams, but never so small that the
+    // (Lmax-1)-byte warm-up of a chunk costs more than 1/8 of its work
+    const uint64_t target_items = 256ull * 1024 * 2;
+    uint64_t c0 = (blob_bytes + target_items - 1) / target_items;
+    uint64_t cmin = std::max<uint64_t>(256, (uint64_t(warm) * 8 + 127) & ~uint64_t(127));
+    uint64_t c = std::max<uint64_t>(cmin, (c0 + 127) & ~uint64_t(127));
+    return uint32_t(std::min<uint64_t>(c, 1u << 30));
+}
+
+// The batch pipeline on device-resident input.
+int run_batch(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, const uint64_t *d_off, size_t nh,
+              int find_all) {
+    h->have_result = false;
+    h->scan_ms = h->total_ms = 0;
+    h->items = 0;
+    h->overflow_items = 0;
+    if (nh > 0xFFFFFFF0ull) { h->last_error = "too many haystacks"; return ACMI_E_TOO_LARGE; }
+    hipStream_t st = h->stream;
+    HIPCHK(h, h->d_prefix.ensure((nh + 1) * 8));
+    h->last_nh = uint32_t(nh);
+    h->last_total = 0;
+    if (h->profile) HIPCHK(h, hipEventRecord(h->ev[0], st));
+
+    if (nh == 0 || h->aut.accepted_count() == 0) {  // empty batch / empty automaton -> no records
+        HIPCHK(h, hipMemsetAsync(h->d_prefix.p, 0, (nh + 1) * 8, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        h->have_result = true;
+        return ACMI_OK;
+    }
+
+    const FlatAutomaton &fa = h->aut.flat();
+    const uint32_t chunk = choose_chunk(h, blob_bytes);
+    const uint64_t max_items = blob_bytes / chunk + nh;
+    const uint32_t K = std::max<uint32_t>(1, h->slab_events);
+    h->chunk_used = chunk;
+
+    HIPCHK(h, h->d_nitems.ensure((nh + 1) * 8));
+    HIPCHK(h, h->d_item_base.ensure((nh + 1) * 8));
+    HIPCHK(h, h->d_item_hay.ensure(max_items * 4));
+    HIPCHK(h, h->d_ev.ensure(max_items * 4));
+    HIPCHK(h, h->d_rec_cnt.ensure((max_items + 1) * 8));
+    HIPCHK(h, h->d_rec_base.ensure((max_items + 1) * 8));
+    HIPCHK(h, h->d_slab.ensure(max_items * K * 8));
+    HIPCHK(h, h->d_ovf.ensure(max_items * 4));
+    HIPCHK(h, h->d_counters.ensure(64));
+    HIPCHK(h, h->d_scan_tmp.ensure(scan_temp_elems(std::max<uint64_t>(max_items + 1, nh + 1)) * 8 * 2));
+
+    HIPCHK(h, hipMemsetAsync(h->d_ev.p, 0, max_items * 4, st));
+    HIPCHK(h, hipMemsetAsync(h->d_rec_cnt.p, 0, (max_items + 1) * 8, st));
+    HIPCHK(h, hipMemsetAsync(h->d_counters.p, 0, 64, st));
+
+    BatchArgs B{};
+    B.blob = d_blob;
+    B.offsets = d_off;
+    B.item_base = h->d_item_base.as<uint64_t>();
+    B.n_haystacks = uint32_t(nh);
+    B.chunk_bytes = chunk;
+    B.warm_bytes = fa.max_pattern_length ? fa.max_pattern_length - 1 : 0;
+    B.slab_events = K;
+    B.first_only = find_all ? 0u : 1u;
+    B.item_hay = h->d_item_hay.as<uint32_t>();
+    B.ev_count = h->d_ev.as<uint32_t>();
+    B.rec_count = h->d_rec_cnt.as<uint64_t>();
+    B.slab = h->d_slab.as<uint2>();
+    B.overflow_list = h->d_ovf.as<uint32_t>();
+    B.counters = h->d_counters.as<uint32_t>();
+
+    launch_count_items(d_off, uint32_t(nh), chunk, h->d_nitems.as<uint64_t>(), st);
+    exclusive_scan_u64(h->d_nitems.as<uint64_t>(), h->d_item_base.as<uint64_t>(), nh + 1, h->d_scan_tmp.as<uint64_t>(), st);
+
+    if (h->profile) HIPCHK(h, hipEventRecord(h->ev[1], st));
+    HIPCHK(h, launch_scan(h->dA, B, max_items, int(fa.entry_bytes), h->kernel, int(fa.class_mode), h->ilp, st));
+    if (h->profile) HIPCHK(h, hipEventRecord(h->ev[2], st));
+
+    if (!find_all) launch_first_only(B, st);
+    exclusive_scan_u64(h->d_rec_cnt.as<uint64_t>(), h->d_rec_base.as<uint64_t>(), max_items + 1,
+                       h->d_scan_tmp.as<uint64_t>(), st);
+    launch_hay_prefix(h->d_item_base.as<uint64_t>(), h->d_rec_base.as<uint64_t>(), uint32_t(nh),
+                      h->d_prefix.as<uint64_t>(), st);
+
+    // the one mid-pipeline host sync: how many records / overflowed items are there?
+    h->pinned[0] = h->pinned[1] = h->pinned[2] = 0;
+    HIPCHK(h, hipMemcpyAsync(&h->pinned[0], h->d_rec_base.as<uint64_t>() + max_items, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(&h->pinned[1], h->d_counters.p, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(&h->pinned[2], h->d_item_base.as<uint64_t>() + nh, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    const uint64_t total = h->pinned[0];
+    const uint32_t n_ovf = find_all ? uint32_t(h->pinned[1] & 0xFFFFFFFFu) : 0u;
+    h->items = h->pinned[2];
+    h->overflow_items = n_ovf;
+
+    HIPCHK(h, h->d_out.ensure(std::max<uint64_t>(16, total * 16)));
+    if (total) {
+        launch_expand(h->dA, B, max_items, h->d_rec_base.as<uint64_t>(), h->d_out.p, st);
+        launch_refill(h->dA, B, int(fa.entry_bytes), h->d_rec_base.as<uint64_t>(), h->d_out.p, n_ovf, st);
+    }
+    HIPCHK(h, hipGetLastError());
+    if (h->profile) {
+        HIPCHK(h, hipEventRecord(h->ev[3], st));
+        HIPCHK(h, hipEventSynchronize(h->ev[3]));
+        float ms = 0;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev[1], h->ev[2]));
+        h->scan_ms = ms;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[3]));
+        h->total_ms = ms;
+    }
+    h->last_total = total;
+    h->have_result = true;
+    return ACMI_OK;
+}
+
+int check_ready(acmi_handle *h) {
+    if (!live(h)) return ACMI_E_INVALID;
+    if (h->init_ok != 1) return ACMI_E_NOT_INIT;
+    int f = ensure_finalized(h);  // lazy finalize (php_ahocorasick.c:707)
+    if (f < 0) return f;
+    return ensure_device(h);
+}
+
+}  // namespace
+
+extern "C" {
+
+int acmi_create(int device, acmi_handle **out) {
+    if (!out) return ACMI_E_ARG;
+    acmi_handle *h = new (std::nothrow) acmi_handle();
+    if (!h) return ACMI_E_NOMEM;
+    h->device_request = device;
+    h->init_ok = 1;
+    {
+        std::lock_guard<std::mutex> g(g_live_mutex);
+        g_live.insert(h);
+    }
+    *out = h;
+    return ACMI_OK;
+}
+
+int acmi_add_patterns(acmi_handle *h, const acmi_pattern *patterns, size_t n, size_t *accepted) {
+    if (!live(h)) return ACMI_E_INVALID;
+    if (h->init_ok != 1) return ACMI_E_NOT_INIT;
+    if (h->aut.finalized()) return ACMI_E_FINALIZED;
+    if (n && !patterns) return ACMI_E_ARG;
+    std::vector<const uint8_t *> vals(n);
+    std::vector<uint32_t> lens(n), types(n);
+    std::vector<int64_t> ids(n);
+    std::vector<uint64_t> users(n);
+    for (size_t k = 0; k < n; ++k) {
+        if (patterns[k].length && !patterns[k].value) return ACMI_E_ARG;
+        vals[k] = patterns[k].value;
+        lens[k] = patterns[k].length;
+        types[k] = patterns[k].id_type;
+        ids[k] = patterns[k].id_number;
+        users[k] = patterns[k].user;
+    }
+    size_t acc = h->aut.add_batch(vals.data(), lens.data(), types.data(), ids.data(), users.data(), n);
+    if (accepted) *accepted = acc;
+    return ACMI_OK;
+}
+
+int acmi_finalize(acmi_handle *h) {
+    if (!live(h)) return ACMI_E_INVALID;
+    if (h->init_ok != 1) return ACMI_E_NOT_INIT;
+    return ensure_finalized(h);
+}
+
+int acmi_is_valid(const acmi_handle *h) { return live(h) && h->init_ok == 1 ? 1 : 0; }
+
+int acmi_destroy(acmi_handle *h) {
+    {
+        std::lock_guard<std::mutex> g(g_live_mutex);
+        if (!h || !g_live.erase(h)) return ACMI_E_INVALID;
+    }
+    h->init_ok = 0;
+    if (h->dev_ready) {
+        (void)hipSetDevice(h->dev_id);
+        if (h->stream) (void)hipStreamSynchronize(h->stream);
+        for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_blob,
+                          &h->d_off, &h->d_nitems, &h->d_item_base, &h->d_item_hay, &h->d_ev, &h->d_rec_cnt,
+                          &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_scan_tmp, &h->d_prefix, &h->d_out})
+            b->release();
+        for (auto &evt : h->ev)
+            if (evt) (void)hipEventDestroy(evt);
+        if (h->pinned) (void)hipHostFree(h->pinned);
+        if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    }
+    delete h;
+    return ACMI_OK;
+}
+
+int acmi_match_batch_device(acmi_handle *h, const void *d_blob, uint64_t blob_bytes, const void *d_offsets,
+                            size_t n_haystacks, int find_all, uint64_t *n_records) {
+    int rc = check_ready(h);
+    if (rc < 0) return rc;
+    if (n_haystacks && !d_offsets) return ACMI_E_ARG;
+    rc = run_batch(h, static_cast<const uint8_t *>(d_blob), blob_bytes, static_cast<const uint64_t *>(d_offsets),
+                   n_haystacks, find_all);
+    if (rc < 0) return rc;
+    if (n_records) *n_records = h->last_total;
+    return ACMI_OK;
+}
+
+int acmi_result_device(acmi_handle *h, const void **d_prefix, const void **d_records, uint64_t *n_records) {
+    if (!live(h)) return ACMI_E_INVALID;
+    if (!h->have_result) return ACMI_E_ARG;
+    if (d_prefix) *d_prefix = h->d_prefix.p;
+    if (d_records) *d_records = h->d_out.p;
+    if (n_records) *n_records = h->last_total;
+    return ACMI_OK;
+}
+
+int acmi_result_to_host(acmi_handle *h, uint64_t *prefix, acmi_record *records) {
+    if (!live(h)) return ACMI_E_INVALID;
+    if (!h->have_result) return ACMI_E_ARG;
+    HIPCHK(h, hipSetDevice(h->dev_id));
+    hipStream_t st = h->stream;
+    if (prefix) HIPCHK(h, hipMemcpyAsync(prefix, h->d_prefix.p, (size_t(h->last_nh) + 1) * 8, hipMemcpyDeviceToHost, st));
+    if (records && h->last_total)
+        HIPCHK(h, hipMemcpyAsync(records, h->d_out.p, h->last_total * sizeof(acmi_record), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    return ACMI_OK;
+}
+
+int acmi_result_to_device(acmi_handle *h, void *d_prefix_dst, void *d_records_dst) {
+    if (!live(h)) return ACMI_E_INVALID;
+    if (!h->have_result) return ACMI_E_ARG;
+    HIPCHK(h, hipSetDevice(h->dev_id));
+    hipStream_t st = h->stream;
+    if (d_prefix_dst)
+        HIPCHK(h, hipMemcpyAsync(d_prefix_dst, h->d_prefix.p, (size_t(h->last_nh) + 1) * 8, hipMemcpyDeviceToDevice, st));
+    if (d_records_dst && h->last_total)
+        HIPCHK(h, hipMemcpyAsync(d_records_dst, h->d_out.p, h->last_total * sizeof(acmi_record), hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    return ACMI_OK;
+}
+
+int acmi_match_batch(acmi_handle *h, const uint8_t *blob, const uint64_t *offsets, size_t n_haystacks, int find_all,
+                     const uint64_t **prefix, const acmi_record **records, size_t *n_records) {
+    int rc = check_ready(h);
+    if (rc < 0) return rc;
+    if (n_haystacks && !offsets) return ACMI_E_ARG;
+    uint64_t blob_bytes = 0;
+    if (n_haystacks) {
+        for (size_t k = 0; k < n_haystacks; ++k) {
+            if (offsets[k + 1] < offsets[k]) { h->last_error = "offsets must be non-decreasing"; return ACMI_E_ARG; }
+            if (offsets[k + 1] - offsets[k] >= 0xFFFFFFFFull) { h->last_error = "haystack of 4 GiB or more"; return ACMI_E_ARG; }
+        }
+        blob_bytes = offsets[n_haystacks];
+        if (blob_bytes && !blob) return ACMI_E_ARG;
+    }
+    hipStream_t st = h->stream;
+    // stage the borrowed host buffers (php_ahocorasick.c:725-727 borrows the zend_string)
+    HIPCHK(h, h->d_blob.ensure(blob_bytes + 64));
+    HIPCHK(h, h->d_off.ensure((n_haystacks + 1) * 8));
+    if (blob_bytes) HIPCHK(h, hipMemcpyAsync(h->d_blob.p, blob, blob_bytes, hipMemcpyHostToDevice, st));
+    if (n_haystacks) HIPCHK(h, hipMemcpyAsync(h->d_off.p, offsets, (n_haystacks + 1) * 8, hipMemcpyHostToDevice, st));
+    rc = run_batch(h, h->d_blob.as<uint8_t>(), blob_bytes, h->d_off.as<uint64_t>(), n_haystacks, find_all);
+    if (rc < 0) return rc;
+    // drain: device match buffer -> host records
+    h->h_prefix.assign(n_haystacks + 1, 0);
+    h->h_records.resize(h->last_total);
+    rc = acmi_result_to_host(h, h->h_prefix.data(), h->h_records.data());
+    if (rc < 0) return rc;
+    if (prefix) *prefix = h->h_prefix.data();
+    if (records) *records = h->h_records.data();
+    if (n_records) *n_records = h->last_total;
+    return ACMI_OK;
+}
+
+int acmi_match(acmi_handle *h, const uint8_t *text, size_t length, int find_all, const acmi_record **records,
+               size_t *n_records) {
+    const uint64_t off[2] = {0, length};
+    if (length >= 0xFFFFFFFFull) return live(h) ? ACMI_E_ARG : ACMI_E_INVALID;
+    return acmi_match_batch(h, text, off, 1, find_all, nullptr, records, n_records);
+}
+
+size_t acmi_pattern_count(const acmi_handle *h) { return live(h) ? h->aut.patterns().size() : 0; }
+
+int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out) {
+    if (!live(h)) return ACMI_E_INVALID;
+    if (!out || index >= h->aut.patterns().size()) return ACMI_E_ARG;
+    const PatternMeta &m = h->aut.patterns()[index];
+    out->value = h->aut.pattern_bytes().data() + m.byte_off;
+    out->length = m.length;
+    out->id_type = m.id_type;
+    out->id_number = m.id_number;
+    out->user = m.user;
+    return m.accepted ? 1 : 0;
+}
+
+int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
+    if (!live(h)) return ACMI_E_INVALID;
+    if (!key) return ACMI_E_ARG;
+    const std::string k(key);
+    if (k == "lds_bytes") {
+        if (h->aut.finalized()) return ACMI_E_FINALIZED;
+        if (value < 2048 || value > 160 * 1024 - 64) return ACMI_E_ARG;
+        h->bopt.lds_bytes = uint32_t(value);
+    } else if (k == "slab_events") {
+        if (value < 1 || value > 4096) return ACMI_E_ARG;
+        h->slab_events = uint32_t(value);
+    } else if (k == "chunk_bytes") {
+        if (value < 0) return ACMI_E_ARG;
+        h->chunk_opt = uint64_t(value);
+    } else if (k == "kernel") {
+        if (value != 0 && value != 1) return ACMI_E_ARG;
+        h->kernel = int(value);
+    } else if (k == "ilp") {
+        if (value != 1 && value != 2) return ACMI_E_ARG;
+        h->ilp = int(value);
+    } else if (k == "profile") {
+        h->profile = value ? 1 : 0;
+    } else if (k == "max_table_bytes") {
+        if (h->aut.finalized()) return ACMI_E_FINALIZED;
+        if (value < 1024) return ACMI_E_ARG;
+        h->bopt.max_table_bytes = uint64_t(value);
+    } else {
+        return ACMI_E_ARG;
+    }
+    return ACMI_OK;
+}
+
+int acmi_get_stat(const acmi_handle *h, const char *key, double *value) {
+    if (!live(h)) return ACMI_E_INVALID;
+    if (!key || !value) return ACMI_E_ARG;
+    const std::string k(key);
+    const FlatAutomaton &fa = h->aut.flat();
+    if (k == "nodes") *value = double(h->aut.node_count());
+    else if (k == "accepted") *value = double(h->aut.accepted_count());
+    else if (k == "patterns") *value = double(h->aut.patterns().size());
+    else if (k == "states") *value = fa.n_states;
+    else if (k == "hot_states") *value = fa.trap;
+    else if (k == "columns") *value = fa.n_columns;
+    else if (k == "entry_bytes") *value = fa.entry_bytes;
+    else if (k == "class_mode") *value = fa.class_mode;
+    else if (k == "lds_image_bytes") *value = double(fa.lds_image.size() + (fa.class_mode == kClassTable ? 512 : 0));
+    else if (k == "table_bytes") *value = double(fa.table.size());
+    else if (k == "max_pattern_length") *value = fa.max_pattern_length;
+    else if (k == "used_bytes") *value = fa.n_used_bytes;
+    else if (k == "items") *value = double(h->items);
+    else if (k == "chunk_bytes") *value = double(h->chunk_used);
+    else if (k == "overflow_items") *value = h->overflow_items;
+    else if (k == "scan_ms") *value = h->scan_ms;
+    else if (k == "total_ms") *value = h->total_ms;
+    else if (k == "records") *value = double(h->last_total);
+    else return ACMI_E_ARG;
+    return ACMI_OK;
+}
+
+int acmi_set_stream(acmi_handle *h, void *hip_stream) {
+    if (!live(h)) return ACMI_E_INVALID;
+    h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+    return ACMI_OK;
+}
+
+int acmi_debug_tables(const acmi_handle *h, acmi_tables *out) {
+    if (!live(h)) return ACMI_E_INVALID;
+    if (!out || !h->aut.finalized()) return ACMI_E_ARG;
+    const FlatAutomaton &fa = h->aut.flat();
+    out->n_states = fa.n_states;
+    out->n_columns = fa.n_columns;
+    out->entry_bytes = fa.entry_bytes;
+    out->first_hot_final = fa.f1;
+    out->trap = fa.trap;
+    out->first_cold_final = fa.f2;
+    out->class_mode = fa.class_mode;
+    out->swar_shift = fa.swar_shift;
+    out->swar_other = fa.swar_other;
+    out->max_pattern_length = fa.max_pattern_length;
+    out->table = fa.table.data();
+    out->lds_image = fa.lds_image.data();
+    out->class_of_byte = fa.class_of_byte;
+    out->own_pattern = fa.own_pattern.data();
+    out->dict_link = fa.dict_link.data();
+    out->out_count = fa.out_count.data();
+    return ACMI_OK;
+}
+
+const char *acmi_strerror(int status) {
+    switch (status) {
+    case ACMI_OK: return "ok";
+    case ACMI_E_INVALID: return "Invalid resource.";
+    case ACMI_E_NOT_INIT: return "Not initialized.";
+    case ACMI_E_FINALIZED: return "automaton already finalized";
+    case ACMI_E_ARG: return "bad argument";
+    case ACMI_E_NOMEM: return "out of memory";
+    case ACMI_E_DEVICE: return "HIP error";
+    case ACMI_E_NO_DEVICE: return "no usable gfx950 device (no CPU fallback)";
+    case ACMI_E_TOO_LARGE: return "automaton or result too large";
+    default: return status > 0 ? "ok" : "unknown error";
+    }
+}
+
+const char *acmi_last_error(const acmi_handle *h) { return live(h) ? h->last_error.c_str() : "Invalid resource."; }
+
+const char *acmi_version(void) { return ACMI_VERSION; }
+
+}  // extern "C"

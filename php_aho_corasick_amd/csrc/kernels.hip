@@ -1,0 +1,509 @@
+// kernels.hip -- hand-written HIP kernels for gfx950 (MI355X / CDNA4).
+//
+// The hot path replaces ac_trie_search() (reference src/multifast/ahocorasick.c:175-241)
+// and node_find_next_bs() (src/multifast/node.c:119-140): instead of a goto edge binary
+// search plus failure hops (~1.9 pointer-chased node visits per byte), every haystack byte
+// costs ONE lookup in a failure-free transition table whose hot rows live in LDS.
+//
+// Pipeline for one batch (all on one stream):
+//   k_count_items  -> exclusive scan                  work items per haystack
+//   k_scan_*                                          the hot kernel: events -> per-item slabs
+//   k_first_only   (findAll == false)                 keep only the first event per haystack
+//   exclusive scan of per-item record counts          -> record base of every item
+//   k_hay_prefix                                      -> per-haystack prefix array
+//   k_expand                                          slab events -> records (callback order)
+//   k_refill                                          overflowed items re-scanned straight into
+//                                                     their final slots (dense-match inputs)
+//
+// No MFMA anywhere: this is byte/integer indexing, bounded by HBM reads of the haystack and
+// by LDS bank throughput of the table lookups.  Wave64, 1024-thread workgroups, one per CU.
+#include <hip/hip_runtime.h>
+
+#include "device_types.hpp"
+#include "kernels.hpp"
+
+namespace acmi {
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+
+struct ItemDesc {
+    uint64_t begin;   // blob offset of the first byte this item REPORTS on
+    uint32_t len;     // bytes it reports on
+    uint32_t warm;    // bytes before `begin` (same haystack) consumed silently from the root
+    uint32_t pos0;    // begin - haystack begin
+    uint32_t hay;
+};
+
+// Work item i -> (haystack, chunk).  item_base is non-decreasing; empty haystacks own no item.
+__device__ __forceinline__ bool decode_item(const BatchArgs &B, uint64_t i, ItemDesc &it) {
+    const uint64_t total = B.item_base[B.n_haystacks];
+    if (i >= total) return false;
+    uint32_t lo = 0, hi = B.n_haystacks;  // item_base[lo] <= i < item_base[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (B.item_base[mid] <= i) lo = mid; else hi = mid;
+    }
+    const uint64_t hb = B.offsets[lo], he = B.offsets[lo + 1];
+    const uint64_t k = i - B.item_base[lo];
+    const uint64_t p0 = k * B.chunk_bytes;
+    it.hay = lo;
+    it.pos0 = uint32_t(p0);
+    it.begin = hb + p0;
+    const uint64_t rest = he - it.begin;
+    it.len = rest < B.chunk_bytes ? uint32_t(rest) : B.chunk_bytes;
+    it.warm = p0 < B.warm_bytes ? uint32_t(p0) : B.warm_bytes;
+    return true;
+}
+
+__device__ __forceinline__ bool is_final(const DevAutomaton &A, uint32_t s) {
+    return (s >= A.f1 && s < A.trap) || s >= A.f2;
+}
+
+// Per-item event sink.  Events, not records, are stored: one {pos, state} per arrival in a
+// final state; the per-state output list is expanded later (k_expand / k_refill).
+struct Sink {
+    uint2 *slab;
+    uint64_t n_rec;
+    uint32_t n_ev;
+    uint32_t cap;
+    uint32_t first_only;
+};
+
+__device__ __forceinline__ void on_event(const DevAutomaton &A, Sink &k, uint32_t pos, uint32_t s) {
+    if (k.first_only && k.n_ev) return;  // findAll=false: the first event only (php_ahocorasick.c:588)
+    k.n_rec += A.out_count[s];
+    if (k.n_ev < k.cap) k.slab[k.n_ev] = make_uint2(pos, s);
+    ++k.n_ev;
+}
+
+__device__ __forceinline__ void finish_item(const BatchArgs &B, const Sink &k, uint64_t i, uint32_t hay) {
+    B.item_hay[i] = hay;
+    B.ev_count[i] = k.n_ev;
+    B.rec_count[i] = k.n_rec;
+    if (k.n_ev > k.cap) B.overflow_list[atomicAdd(&B.counters[0], 1u)] = uint32_t(i);
+}
+
+// One exact transition.  `tile` (LDS) may be null; hot rows are read from it unless the
+// stored target is the trap row, which stands for "the real target is cold".
+template <typename E>
+__device__ __forceinline__ uint32_t exact_step(const DevAutomaton &A, const uint8_t *tile, uint32_t s,
+                                               uint32_t byte) {
+    const uint32_t coff = A.class_off[byte];
+    if (tile != nullptr && s < A.trap) {
+        const uint32_t w = *reinterpret_cast<const E *>(tile + s * A.row_bytes + coff);
+        if (w < A.trap) return w;
+    }
+    return *reinterpret_cast<const E *>(static_cast<const uint8_t *>(A.table) + uint64_t(s) * A.row_bytes + coff);
+}
+
+// Walk bytes [j0, j1) of a stream one by one with full semantics (events, cold states).
+template <typename E>
+__device__ __forceinline__ uint32_t exact_bytes(const DevAutomaton &A, const uint8_t *tile, Sink &k,
+                                                const uint8_t *p, uint32_t j0, uint32_t j1, uint32_t warm,
+                                                uint32_t pos0, uint32_t s) {
+#pragma unroll 1
+    for (uint32_t j = j0; j < j1; ++j) {
+        s = exact_step<E>(A, tile, s, p[j]);
+        if (j >= warm && is_final(A, s)) on_event(A, k, pos0 + (j - warm) + 1, s);
+    }
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_count_items: work items per haystack
+// ------------------------------------------------------------------------------------------
+__global__ void k_count_items(const uint64_t *offsets, uint32_t nh, uint32_t chunk, uint64_t *n_items) {
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h > nh) return;
+    if (h == nh) { n_items[h] = 0; return; }
+    const uint64_t len = offsets[h + 1] - offsets[h];
+    n_items[h] = (len + chunk - 1) / chunk;
+}
+
+// ------------------------------------------------------------------------------------------
+// exclusive scan of uint64 (three small kernels, recursive on the block sums)
+// ------------------------------------------------------------------------------------------
+constexpr int kScanThreads = 256;
+constexpr int kScanPerThread = 8;
+constexpr int kScanTile = kScanThreads * kScanPerThread;
+
+__global__ void k_scan_tiles(const uint64_t *in, uint64_t *out, uint64_t n, uint64_t *tile_sums) {
+    __shared__ uint64_t wave_sums[kScanThreads / 64];
+    const uint64_t base = uint64_t(blockIdx.x) * kScanTile + uint64_t(threadIdx.x) * kScanPerThread;
+    uint64_t v[kScanPerThread];
+    uint64_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < kScanPerThread; ++i) {
+        v[i] = base + i < n ? in[base + i] : 0;
+        sum += v[i];
+    }
+    // inclusive scan of `sum` across the wave, then across the block's 4 waves
+    uint64_t inc = sum;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) wave_sums[wave] = inc;
+    __syncthreads();
+    uint64_t wave_base = 0;
+    for (int w = 0; w < wave; ++w) wave_base += wave_sums[w];
+    uint64_t run = wave_base + inc - sum;
+#pragma unroll
+    for (int i = 0; i < kScanPerThread; ++i) {
+        if (base + i < n) out[base + i] = run;
+        run += v[i];
+    }
+    if (threadIdx.x == kScanThreads - 1) tile_sums[blockIdx.x] = wave_base + inc;
+}
+
+__global__ void k_scan_add(uint64_t *out, uint64_t n, const uint64_t *tile_base) {
+    const uint64_t i = uint64_t(blockIdx.x) * kScanTile + threadIdx.x;
+    const uint64_t add = tile_base[blockIdx.x];
+#pragma unroll
+    for (int r = 0; r < kScanPerThread; ++r) {
+        const uint64_t j = i + uint64_t(r) * kScanThreads;
+        if (j < n) out[j] += add;
+    }
+}
+
+size_t scan_temp_elems(uint64_t n) {
+    size_t total = 0;
+    while (n > 1) {
+        n = (n + kScanTile - 1) / kScanTile;
+        total += n + 1;
+        if (n == 1) break;
+    }
+    return total + 2;
+}
+
+// out[i] = sum(in[0..i)) for i < n.  `temp` needs scan_temp_elems(n) uint64.
+void exclusive_scan_u64(const uint64_t *in, uint64_t *out, uint64_t n, uint64_t *temp, hipStream_t st) {
+    if (n == 0) return;
+    const uint64_t tiles = (n + kScanTile - 1) / kScanTile;
+    uint64_t *sums = temp;
+    hipLaunchKernelGGL(k_scan_tiles, dim3(uint32_t(tiles)), dim3(kScanThreads), 0, st, in, out, n, sums);
+    if (tiles > 1) {
+        uint64_t *sums_scanned = sums;  // scanned in place
+        exclusive_scan_u64(sums, sums_scanned, tiles, temp + tiles + 1, st);
+        hipLaunchKernelGGL(k_scan_add, dim3(uint32_t(tiles)), dim3(kScanThreads), 0, st, out, n, sums_scanned);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_scan_simple: one thread per work item, every lookup from the global table.  The plain,
+// obviously-correct form; also what the LDS kernel degenerates to for states outside the tile.
+// ------------------------------------------------------------------------------------------
+template <typename E>
+__global__ void k_scan_simple(DevAutomaton A, BatchArgs B) {
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    ItemDesc it;
+    if (!decode_item(B, i, it)) return;
+    Sink k{B.slab + i * B.slab_events, 0, 0, B.slab_events, B.first_only};
+    const uint8_t *p = B.blob + (it.begin - it.warm);
+    exact_bytes<E>(A, nullptr, k, p, 0, it.warm + it.len, it.warm, it.pos0, 0u);
+    finish_item(B, k, i, it.hay);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_scan_lds: the hot kernel.
+//
+// * Workgroup = 1024 threads (16 waves, 4 per SIMD), one workgroup per CU; it stages the hot
+//   tile of the transition table (up to ~160 KiB: every state within the first few trie
+//   levels) into LDS once and then streams its work items.
+// * Each lane owns ILP independent work items (streams).  A lane reads its haystack in whole
+//   128-byte lines: eight 16-byte loads into a rolling register buffer, each slot re-loaded
+//   with the line after next as soon as it has been consumed, so every HBM line is fetched
+//   exactly once and ~100 byte-steps of work hide its latency.
+// * The inner step is optimistic: 16 bytes are pushed through the LDS tile with no branch at
+//   all (per byte: one bit-field extract, one multiply-add for the address, one ds_read, one
+//   max).  Transitions that would leave the tile land on an absorbing TRAP row and final states
+//   are numbered >= f1, so "max state seen >= f1" after the 16 bytes says the quad needs the
+//   exact path (an event to record, a cold state, a byte outside the alphabet); only then is
+//   the quad replayed from its saved entry state with full semantics.  On sparse-match text
+//   (the headline workload) replays are rare and the wave runs branch-free.
+// * SWAR3 mode maps 4 haystack bytes to 4 table columns with three VALU ops when the
+//   pattern alphabet has <= 8 symbols distinguishable by a 3-bit window (abcdef, ACGT, ...):
+//   column = (byte >> shift) & 7, validated against the expected byte of that bucket with one
+//   v_perm_b32.  TABLE mode reads a 256-entry column-offset table from LDS instead.
+// ------------------------------------------------------------------------------------------
+constexpr int kLdsThreads = 1024;
+constexpr int kQuadsPerLine = 8;
+
+template <typename E>
+__device__ __forceinline__ uint32_t tile_read(const uint8_t *tile, uint32_t addr) {
+    return *reinterpret_cast<const E *>(tile + addr);
+}
+
+template <typename E, int MODE, int ILP>
+__global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchArgs B) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint64_t first = uint64_t(blockIdx.x) * (kLdsThreads * ILP);
+    if (first >= B.item_base[B.n_haystacks]) return;
+
+    {   // stage [class offsets +] hot tile into LDS
+        const uint4 *src = static_cast<const uint4 *>(A.lds_image);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        const uint32_t n16 = (A.lds_image_bytes + 15u) >> 4;
+        for (uint32_t t = threadIdx.x; t < n16; t += kLdsThreads) dst[t] = src[t];
+    }
+    __syncthreads();
+    const uint8_t *tile = smem + A.tile_offset;
+    const uint32_t row_bytes = A.row_bytes;
+    const uint32_t f1 = A.f1;
+
+    ItemDesc it[ILP];
+    bool valid[ILP];
+    Sink sink[ILP];
+    uint32_t s[ILP], head[ILP], nq[ILP], n[ILP];
+    const uint8_t *p[ILP];
+    const uint4 *qp[ILP];
+    uint32_t nq_max = 0;
+#pragma unroll
+    for (int k = 0; k < ILP; ++k) {
+        const uint64_t i = first + uint64_t(threadIdx.x) * ILP + k;
+        valid[k] = decode_item(B, i, it[k]);
+        sink[k] = Sink{B.slab + i * B.slab_events, 0, 0, B.slab_events, B.first_only};
+        s[k] = 0;
+        n[k] = 0; head[k] = 0; nq[k] = 0; p[k] = B.blob; qp[k] = nullptr;
+        if (valid[k]) {
+            p[k] = B.blob + (it[k].begin - it[k].warm);
+            n[k] = it[k].warm + it[k].len;
+            const uint32_t mis = uint32_t(-reinterpret_cast<uintptr_t>(p[k])) & 15u;
+            head[k] = mis < n[k] ? mis : n[k];
+            // unaligned head, byte by byte
+            s[k] = exact_bytes<E>(A, tile, sink[k], p[k], 0, head[k], it[k].warm, it[k].pos0, s[k]);
+            nq[k] = (n[k] - head[k]) >> 4;
+            qp[k] = reinterpret_cast<const uint4 *>(p[k] + head[k]);
+            nq_max = nq[k] > nq_max ? nq[k] : nq_max;
+        }
+    }
+
+    // rolling line buffer: slot r holds quad (base + r), re-loaded with quad (base + r + 8)
+    uint4 buf[ILP][kQuadsPerLine];
+#pragma unroll
+    for (int k = 0; k < ILP; ++k)
+#pragma unroll
+        for (int r = 0; r < kQuadsPerLine; ++r)
+            buf[k][r] = uint32_t(r) < nq[k] ? qp[k][r] : make_uint4(0, 0, 0, 0);
+
+    for (uint32_t base = 0; base < nq_max; base += kQuadsPerLine) {
+#pragma unroll
+        for (int r = 0; r < kQuadsPerLine; ++r) {
+            const uint32_t q = base + r;
+            if (q < nq_max) {
+                uint4 cur[ILP];
+                uint32_t s_in[ILP], m[ILP], bad[ILP];
+#pragma unroll
+                for (int k = 0; k < ILP; ++k) {
+                    cur[k] = buf[k][r];
+                    if (q + kQuadsPerLine < nq[k]) buf[k][r] = qp[k][q + kQuadsPerLine];
+                    s_in[k] = s[k];
+                    // a cold entry state has no row in the tile: enter through the absorbing trap
+                    // row instead, which forces the exact replay below (from the true s_in)
+                    s[k] = s[k] < A.trap ? s[k] : A.trap;
+                    m[k] = 0;
+                    bad[k] = 0;
+                }
+                // ---- optimistic 16 byte-steps per stream, branch-free ----
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    uint32_t o4[ILP];
+                    uint32_t o[ILP][4];
+#pragma unroll
+                    for (int k = 0; k < ILP; ++k) {
+                        const uint32_t d = w == 0 ? cur[k].x : w == 1 ? cur[k].y : w == 2 ? cur[k].z : cur[k].w;
+                        if (MODE == 1) {
+                            const uint32_t c4 = (d >> A.swar_shift) & 0x07070707u;
+                            const uint32_t e4 = __builtin_amdgcn_perm(A.swar_expect_hi, A.swar_expect_lo, c4);
+                            bad[k] |= e4 ^ d;
+                            o4[k] = c4 * uint32_t(sizeof(E));
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) o[k][b] = __builtin_amdgcn_ubfe(o4[k], 8 * b, 8);
+                        } else {
+                            const uint16_t *coff = reinterpret_cast<const uint16_t *>(smem);
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) o[k][b] = coff[__builtin_amdgcn_ubfe(d, 8 * b, 8)];
+                        }
+                    }
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+#pragma unroll
+                        for (int k = 0; k < ILP; ++k) {
+                            const uint32_t addr = __umul24(s[k], row_bytes) + o[k][b];
+                            s[k] = tile_read<E>(tile, addr);
+                            m[k] = s[k] > m[k] ? s[k] : m[k];
+                        }
+                    }
+                }
+                // ---- rare: replay the quad exactly ----
+#pragma unroll
+                for (int k = 0; k < ILP; ++k) {
+                    if (q < nq[k]) {
+                        if (m[k] >= f1 || bad[k] != 0) {
+                            uint32_t t = s_in[k];
+                            const uint32_t j0 = head[k] + (q << 4);
+#pragma unroll 1
+                            for (uint32_t b = 0; b < 16; ++b) {
+                                const uint32_t wsel = b >> 2;
+                                const uint32_t d = wsel == 0 ? cur[k].x : wsel == 1 ? cur[k].y : wsel == 2 ? cur[k].z : cur[k].w;
+                                const uint32_t byte = (d >> ((b & 3u) * 8u)) & 0xffu;
+                                t = exact_step<E>(A, tile, t, byte);
+                                const uint32_t j = j0 + b;
+                                if (j >= it[k].warm && is_final(A, t))
+                                    on_event(A, sink[k], it[k].pos0 + (j - it[k].warm) + 1, t);
+                            }
+                            s[k] = t;
+                        }
+                    } else {
+                        s[k] = s_in[k];
+                    }
+                }
+            }
+        }
+    }
+
+    // tail (< 16 bytes) and bookkeeping
+#pragma unroll
+    for (int k = 0; k < ILP; ++k) {
+        if (valid[k]) {
+            const uint32_t j0 = head[k] + (nq[k] << 4);
+            s[k] = exact_bytes<E>(A, tile, sink[k], p[k], j0, n[k], it[k].warm, it[k].pos0, s[k]);
+            finish_item(B, sink[k], first + uint64_t(threadIdx.x) * ILP + k, it[k].hay);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// findAll == false: keep the first event of the first item (per haystack) that has one
+// ------------------------------------------------------------------------------------------
+__global__ void k_first_only(BatchArgs B) {
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= B.n_haystacks) return;
+    bool found = false;
+    for (uint64_t i = B.item_base[h]; i < B.item_base[h + 1]; ++i) {
+        if (found) { B.ev_count[i] = 0; B.rec_count[i] = 0; }
+        else if (B.ev_count[i]) found = true;
+    }
+}
+
+__global__ void k_hay_prefix(const uint64_t *item_base, const uint64_t *rec_base, uint32_t nh, uint64_t *prefix) {
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h <= nh) prefix[h] = rec_base[item_base[h]];
+}
+
+// Expand one event into records, longest pattern first (node.c:424-441 order).
+__device__ __forceinline__ uint64_t emit_event(const DevAutomaton &A, uint4 *out, uint64_t w, uint32_t hay,
+                                               uint32_t pos, uint32_t state) {
+    uint32_t t = A.own_pattern[state] != 0xFFFFFFFFu ? state : A.dict_link[state];
+    while (t != 0xFFFFFFFFu) {
+        const uint32_t pat = A.own_pattern[t];
+        out[w++] = make_uint4(hay, pos, pos - A.pattern_length[pat], pat);
+        t = A.dict_link[t];
+    }
+    return w;
+}
+
+__global__ void k_expand(DevAutomaton A, BatchArgs B, const uint64_t *rec_base, uint4 *out) {
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= B.item_base[B.n_haystacks]) return;
+    const uint32_t n = B.ev_count[i];
+    if (n == 0 || n > B.slab_events) return;  // overflowed items are k_refill's
+    const uint32_t hay = B.item_hay[i];
+    uint64_t w = rec_base[i];
+    const uint2 *ev = B.slab + i * B.slab_events;
+    for (uint32_t e = 0; e < n; ++e) w = emit_event(A, out, w, hay, ev[e].x, ev[e].y);
+}
+
+// Overflowed items: scan again, writing records straight into their final slots.
+template <typename E>
+__global__ void k_refill(DevAutomaton A, BatchArgs B, const uint64_t *rec_base, uint4 *out, uint32_t n_overflow) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_overflow) return;
+    const uint64_t i = B.overflow_list[t];
+    ItemDesc it;
+    if (!decode_item(B, i, it)) return;
+    uint64_t w = rec_base[i];
+    const uint8_t *p = B.blob + (it.begin - it.warm);
+    const uint32_t n = it.warm + it.len;
+    uint32_t s = 0;
+#pragma unroll 1
+    for (uint32_t j = 0; j < n; ++j) {
+        s = exact_step<E>(A, nullptr, s, p[j]);
+        if (j >= it.warm && is_final(A, s)) w = emit_event(A, out, w, it.hay, it.pos0 + (j - it.warm) + 1, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side launchers
+// ------------------------------------------------------------------------------------------
+void launch_count_items(const uint64_t *offsets, uint32_t nh, uint32_t chunk, uint64_t *n_items, hipStream_t st) {
+    hipLaunchKernelGGL(k_count_items, dim3((nh + 1 + 255) / 256), dim3(256), 0, st, offsets, nh, chunk, n_items);
+}
+
+template <typename E, int MODE, int ILP>
+static hipError_t launch_lds_t(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, uint32_t lds_bytes,
+                               hipStream_t st) {
+    auto fn = k_scan_lds<E, MODE, ILP>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
+    if (e != hipSuccess) return e;
+    const uint64_t per_block = uint64_t(kLdsThreads) * ILP;
+    const uint32_t blocks = uint32_t((max_items + per_block - 1) / per_block);
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(kLdsThreads), lds_bytes, st, A, B);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes,
+                       int kernel, int class_mode, int ilp, hipStream_t st) {
+    if (max_items == 0) return hipSuccess;
+    if (kernel == 0) {
+        const uint32_t blocks = uint32_t((max_items + 255) / 256);
+        if (entry_bytes == 2) hipLaunchKernelGGL(k_scan_simple<uint16_t>, dim3(blocks), dim3(256), 0, st, A, B);
+        else hipLaunchKernelGGL(k_scan_simple<uint32_t>, dim3(blocks), dim3(256), 0, st, A, B);
+        return hipGetLastError();
+    }
+    const uint32_t lds = ((A.lds_image_bytes + 15u) & ~15u) + 32u;
+    if (entry_bytes == 2) {
+        if (class_mode == 1) return ilp == 2 ? launch_lds_t<uint16_t, 1, 2>(A, B, max_items, lds, st)
+                                             : launch_lds_t<uint16_t, 1, 1>(A, B, max_items, lds, st);
+        return ilp == 2 ? launch_lds_t<uint16_t, 0, 2>(A, B, max_items, lds, st)
+                        : launch_lds_t<uint16_t, 0, 1>(A, B, max_items, lds, st);
+    }
+    if (class_mode == 1) return ilp == 2 ? launch_lds_t<uint32_t, 1, 2>(A, B, max_items, lds, st)
+                                         : launch_lds_t<uint32_t, 1, 1>(A, B, max_items, lds, st);
+    return ilp == 2 ? launch_lds_t<uint32_t, 0, 2>(A, B, max_items, lds, st)
+                    : launch_lds_t<uint32_t, 0, 1>(A, B, max_items, lds, st);
+}
+
+void launch_first_only(const BatchArgs &B, hipStream_t st) {
+    if (B.n_haystacks == 0) return;
+    hipLaunchKernelGGL(k_first_only, dim3((B.n_haystacks + 255) / 256), dim3(256), 0, st, B);
+}
+
+void launch_hay_prefix(const uint64_t *item_base, const uint64_t *rec_base, uint32_t nh, uint64_t *prefix,
+                       hipStream_t st) {
+    hipLaunchKernelGGL(k_hay_prefix, dim3((nh + 1 + 255) / 256), dim3(256), 0, st, item_base, rec_base, nh, prefix);
+}
+
+void launch_expand(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, const uint64_t *rec_base,
+                   void *out, hipStream_t st) {
+    if (max_items == 0) return;
+    hipLaunchKernelGGL(k_expand, dim3(uint32_t((max_items + 255) / 256)), dim3(256), 0, st, A, B, rec_base,
+                       static_cast<uint4 *>(out));
+}
+
+void launch_refill(const DevAutomaton &A, const BatchArgs &B, int entry_bytes, const uint64_t *rec_base, void *out,
+                   uint32_t n_overflow, hipStream_t st) {
+    if (n_overflow == 0) return;
+    const uint32_t blocks = (n_overflow + 63) / 64;
+    if (entry_bytes == 2)
+        hipLaunchKernelGGL(k_refill<uint16_t>, dim3(blocks), dim3(64), 0, st, A, B, rec_base, static_cast<uint4 *>(out), n_overflow);
+    else
+        hipLaunchKernelGGL(k_refill<uint32_t>, dim3(blocks), dim3(64), 0, st, A, B, rec_base, static_cast<uint4 *>(out), n_overflow);
+}
+
+}  // namespace acmi

@@ -1,0 +1,93 @@
+"""Shared test helpers (CPU side)."""
+from __future__ import annotations
+
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def load_json(name):
+    with open(os.path.join(GOLDEN, name), encoding="utf-8") as f:
+        return json.load(f)
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def pack_record(pattern: dict, pos: int, start: int) -> list:
+    """Independent restatement of the record layout (php_ahocorasick.c:562-583) as ordered pairs."""
+    out = [["pos", pos]]
+    if "key" in pattern:
+        out.append(["key", pattern["key"]])
+    elif "id" in pattern:
+        out.append(["keyIdx", pattern["id"]])
+    if "aux" in pattern:
+        out.append(["aux", pattern["aux"]])
+    out.append(["start_postion", start])
+    out.append(["value", pattern["value"]])
+    return out
+
+
+def as_pairs(record: dict) -> list:
+    return [[k, v] for k, v in record.items()]
+
+
+class FlatTables:
+    """numpy view of acmi_debug_tables() for CPU-side inspection of the builder's output."""
+
+    def __init__(self, res):
+        from php_aho_corasick_amd import _native as N
+        t = N.Tables()
+        N.check(N.lib.acmi_debug_tables(res._h, C.byref(t)), res._h)
+        self.n_states, self.n_columns, self.entry_bytes = t.n_states, t.n_columns, t.entry_bytes
+        self.f1, self.trap, self.f2 = t.first_hot_final, t.trap, t.first_cold_final
+        self.class_mode, self.swar_shift, self.swar_other = t.class_mode, t.swar_shift, t.swar_other
+        self.max_pattern_length = t.max_pattern_length
+        dt = np.uint16 if t.entry_bytes == 2 else np.uint32
+        n = t.n_states * t.n_columns
+        self.table = np.ctypeslib.as_array(C.cast(t.table, C.POINTER(C.c_uint16 if t.entry_bytes == 2 else C.c_uint32)),
+                                           shape=(n,)).astype(np.int64).reshape(t.n_states, t.n_columns)
+        m = (t.trap + 1) * t.n_columns
+        self.lds = np.ctypeslib.as_array(C.cast(t.lds_image, C.POINTER(C.c_uint16 if t.entry_bytes == 2 else C.c_uint32)),
+                                         shape=(m,)).astype(np.int64).reshape(t.trap + 1, t.n_columns)
+        self.cls = np.ctypeslib.as_array(t.class_of_byte, shape=(256,)).astype(np.int64)
+        self.own = np.ctypeslib.as_array(t.own_pattern, shape=(t.n_states,)).astype(np.int64)
+        self.dict = np.ctypeslib.as_array(t.dict_link, shape=(t.n_states,)).astype(np.int64)
+        self.cnt = np.ctypeslib.as_array(t.out_count, shape=(t.n_states,)).astype(np.int64)
+        _ = dt
+
+    def is_final(self, s: int) -> bool:
+        return (self.f1 <= s < self.trap) or s >= self.f2
+
+    def walk(self, text: bytes, pat_len, hay: int = 0, find_all: bool = True, use_lds: bool = True):
+        """Scan one haystack over the flat tables exactly as the device's exact path does."""
+        NONE = 0xFFFFFFFF
+        recs = []
+        s = 0
+        tab, lds, cls, trap = self.table, self.lds, self.cls, self.trap
+        for j, b in enumerate(text):
+            c = cls[b]
+            if use_lds and s < trap:
+                w = lds[s, c]
+                s = int(w) if w < trap else int(tab[s, c])
+            else:
+                s = int(tab[s, c])
+            if self.is_final(s):
+                pos = j + 1
+                t = s if self.own[s] != NONE else int(self.dict[s])
+                n0 = len(recs)
+                while t != NONE:
+                    pat = int(self.own[t])
+                    recs.append((hay, pos, pos - int(pat_len[pat]), pat))
+                    t = int(self.dict[t])
+                assert len(recs) - n0 == self.cnt[s]
+                if not find_all:
+                    break
+        return recs

@@ -1,0 +1,213 @@
+"""Parity of the HIP path with the oracle / reference goldens.  Needs an MI355X: -m gpu.
+
+Everything goes through the C ABI of libacmi.so (acmi_match / acmi_match_batch /
+acmi_match_batch_device).  The oracle is only the checker.
+"""
+import itertools
+
+import numpy as np
+import pytest
+
+from helpers import as_pairs, sha
+from gpu_util import device_match, host_match, resource_for
+from oracle.pyoracle import Oracle
+from php_aho_corasick_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+SMALL = ["G1", "G2", "G3", "G4", "G5", "R1", "R2", "R3"]
+
+
+def _check_golden(res, ds, golden, name, path=host_match):
+    for find_all in (True, False):
+        g = golden[(name, find_all)]
+        prefix, rec = path(res, ds, find_all)
+        assert len(rec) == g["n_records"], (name, find_all)
+        assert sha(rec) == g["sha256"], (name, find_all)
+        assert sha(prefix) == g["prefix_sha256"], (name, find_all)
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_golden_default(name, golden):
+    """Committed goldens (made by the compiled reference), default configuration, host-buffer entry."""
+    ds = synth.NAMED[name]()
+    res = resource_for(ds)
+    _check_golden(res, ds, golden, name)
+    assert api.ahocorasick_deinit(res)
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_golden_device_entry(name, golden):
+    """Same through acmi_match_batch_device (haystacks resident in HBM, torch-allocated)."""
+    ds = synth.NAMED[name]()
+    res = resource_for(ds)
+    _check_golden(res, ds, golden, name, device_match)
+    api.ahocorasick_deinit(res)
+
+
+def test_golden_g6_64k_patterns(golden):
+    """Config 3 automaton: 65,536 patterns, 2.27 M states, uint32 entries, 256 columns."""
+    ds = synth.g6()
+    res = resource_for(ds)
+    _check_golden(res, ds, golden, "G6")
+    assert res.stat("nodes") == golden[("G6", True)]["nodes"]
+    assert res.stat("entry_bytes") == 4
+    api.ahocorasick_deinit(res)
+
+
+VARIANTS = [dict(kernel=0), dict(kernel=1, ilp=1), dict(kernel=1, ilp=2),
+            dict(kernel=1, ilp=1, lds_bytes=4096), dict(kernel=1, ilp=2, lds_bytes=2048),
+            dict(kernel=1, ilp=1, chunk_bytes=64), dict(kernel=1, ilp=2, chunk_bytes=256),
+            dict(kernel=0, chunk_bytes=16), dict(kernel=1, ilp=1, chunk_bytes=4096, slab_events=1),
+            dict(kernel=1, ilp=2, slab_events=1), dict(kernel=1, ilp=1, slab_events=3, chunk_bytes=128)]
+
+
+@pytest.mark.parametrize("name,variant", list(itertools.product(["G2", "G4", "G5", "R1", "R2", "R3"], range(len(VARIANTS)))))
+def test_golden_variants(name, variant, golden):
+    """Every kernel / ILP / LDS-tile size (forces cold states + trap) / chunk size (forces warm-up
+    overlap, R3 has 1 KiB patterns) / slab size (forces the overflow -> refill path)."""
+    ds = synth.NAMED[name]()
+    res = resource_for(ds, **VARIANTS[variant])
+    _check_golden(res, ds, golden, name)
+    api.ahocorasick_deinit(res)
+
+
+def test_overflow_path_is_taken():
+    ds = synth.g3(n_hay=3, hay_len=4096)
+    res = resource_for(ds, slab_events=2)
+    prefix, rec = host_match(res, ds)
+    assert res.stat("overflow_items") > 0
+    assert len(rec) == 3 * (16 * 4096 - 120)  # NH * (K*HL - K(K-1)/2), SURVEY.md 8d config 5
+    o = Oracle("port")
+    o.add_patterns((ds.pat_blob, ds.pat_off))
+    _, exp = o.match_batch(ds.hay_blob, ds.hay_off)
+    assert np.array_equal(rec, exp)
+    api.ahocorasick_deinit(res)
+
+
+def test_incremental_adds_equal_single_init(golden):
+    """tests/test3.phpt's property on a big set: N add_patterns calls vs one init differ only by the
+    duplicate rule, which the oracle reproduces call by call."""
+    ds = synth.r1()
+    res = resource_for(ds, calls=4)
+    o = Oracle("port")
+    pats = ds.patterns()
+    step = (len(pats) + 3) // 4
+    for lo in range(0, len(pats), step):
+        o.add_patterns(pats[lo:lo + step])
+    for find_all in (True, False):
+        p, r = host_match(res, ds, find_all)
+        pe, re_ = o.match_batch(ds.hay_blob, ds.hay_off, find_all)
+        assert np.array_equal(p, pe) and np.array_equal(r, re_)
+    api.ahocorasick_deinit(res)
+
+
+def test_kat_through_php_surface(kat):
+    """The reference's .phpt cases through the mirrored PHP function surface."""
+    for case in kat:
+        res = api.ahocorasick_init(case["init"])
+        assert res is not False
+        for call in case["adds"]:
+            assert api.ahocorasick_add_patterns(res, call) is True
+        reps = 3 if case["name"] == "KAT-6" else 1
+        for _ in range(reps):
+            for q in case["queries"]:
+                if "findAll" in q:
+                    got = api.ahocorasick_match(q["haystack"], res, q["findAll"])
+                else:
+                    got = api.ahocorasick_match(q["haystack"], res)
+                assert [as_pairs(r) for r in got] == q["expect"], (case["name"], q["haystack"])
+        if "isValid_before_deinit" in case:
+            assert api.ahocorasick_isValid(res) is case["isValid_before_deinit"]
+        if case.get("deinit"):
+            assert api.ahocorasick_deinit(res) is True
+            if "isValid_after_deinit" in case:
+                assert api.ahocorasick_isValid(res) is False
+                assert api.ahocorasick_deinit(res) is case["second_deinit"]
+
+
+def test_kat6_init_match_deinit_cycles(kat):
+    """tests/test4.phpt shape (scaled down): repeated init / many matches / deinit stays exact."""
+    case = next(c for c in kat if c["name"] == "KAT-6")
+    q = case["queries"][0]
+    for _ in range(4):
+        res = api.ahocorasick_init(case["init"])
+        for _ in range(50):
+            d = api.ahocorasick_match(q["haystack"], res)
+            assert d and len(d) == 4
+        assert api.ahocorasick_deinit(res)
+
+
+def test_batch_equals_foreach(kat):
+    """ahocorasick_match_batch (new) == foreach ahocorasick_match (examples/benchmark.php:65-67)."""
+    case = next(c for c in kat if c["name"] == "KAT-3/4")
+    res = api.ahocorasick_init(case["init"])
+    hays = [q["haystack"] for q in case["queries"]] + ["", "aux", "éé"]
+    each = [api.ahocorasick_match(h, res) for h in hays]
+    assert api.ahocorasick_match_batch(hays, res) == each
+    assert api.ahocorasick_match_batch(hays, res, False) == [api.ahocorasick_match(h, res, False) for h in hays]
+    api.ahocorasick_deinit(res)
+
+
+def test_empty_inputs():
+    res = api.ahocorasick_init([])
+    assert api.ahocorasick_match("anything", res) == []          # empty automaton
+    assert api.ahocorasick_match_batch([], res) == []
+    api.ahocorasick_deinit(res)
+    res = api.ahocorasick_init([{"value": "a"}])
+    assert api.ahocorasick_match("", res) == []                  # empty haystack
+    assert api.ahocorasick_match_batch(["", "", "a", ""], res) == [[], [], [{"pos": 1, "start_postion": 0, "value": "a"}], []]
+    api.ahocorasick_deinit(res)
+
+
+def test_bytes_nul_and_high():
+    """Opaque bytes: NUL and >= 0x80 inside patterns and haystacks."""
+    pats = [{"value": b"\x00\xff"}, {"value": b"\xff"}, {"id": 7, "value": b"a\x00b"}]
+    res = api.ahocorasick_init(pats)
+    o = Oracle("port")
+    o.add_patterns([p["value"] for p in pats])
+    text = b"xa\x00b\x00\xff\xff\x00"
+    got = api.ahocorasick_match(text, res)
+    exp = o.match(text)
+    assert [(r["pos"], r["start_postion"]) for r in got] == [(int(r[1]), int(r[2])) for r in exp]
+    assert got[0] == {"pos": 4, "keyIdx": 7, "start_postion": 1, "value": b"a\x00b"}
+    api.ahocorasick_deinit(res)
+
+
+def test_unaligned_device_blob():
+    """Haystack blob that starts at an odd device address (head/tail byte paths)."""
+    import torch
+    from php_aho_corasick_amd import batch
+    ds = synth.r2()
+    res = resource_for(ds)
+    o = Oracle("port")
+    o.add_patterns((ds.pat_blob, ds.pat_off))
+    pe, re_ = o.match_batch(ds.hay_blob, ds.hay_off)
+    for shift in (1, 7, 13):
+        raw = torch.zeros(ds.hay_blob.size + 64, dtype=torch.uint8, device="cuda")
+        view = raw[shift:shift + ds.hay_blob.size]
+        view.copy_(torch.from_numpy(ds.hay_blob))
+        d_off = torch.from_numpy(ds.hay_off.astype(np.int64)).cuda()
+        batch.bind_current_stream(res)
+        total = batch.match_device(res, view, d_off)
+        p, r = batch.result_numpy(res, ds.n_haystacks, total)
+        assert np.array_equal(p, pe) and np.array_equal(r, re_)
+    api.ahocorasick_deinit(res)
+
+
+def test_random_against_oracle():
+    """Seeded random automata/haystacks at sizes the oracle finishes instantly, all entry points."""
+    for seed in range(60, 72):
+        alpha = [b"ab", b"abcdefgh", b"ACGT", None, b"xyz\x00\x01\x02\x03\x04\x05"][seed % 5]
+        ds = synth.ragged(f"S{seed}", seed, 20 + 13 * (seed % 7), 1, 3 + seed % 9, 33 + seed, 0, 700 + 97 * (seed % 4), alpha)
+        o = Oracle("port")
+        o.add_patterns((ds.pat_blob, ds.pat_off))
+        res = resource_for(ds, kernel=1, ilp=1 + seed % 2, chunk_bytes=[0, 48, 512][seed % 3], slab_events=[8, 1, 2][seed % 3])
+        for find_all in (True, False):
+            pe, re_ = o.match_batch(ds.hay_blob, ds.hay_off, find_all)
+            for path in (host_match, device_match):
+                p, r = path(res, ds, find_all)
+                assert np.array_equal(p, pe), (seed, find_all, path.__name__)
+                assert np.array_equal(r, re_), (seed, find_all, path.__name__)
+        api.ahocorasick_deinit(res)
+        o.close()

@@ -1,0 +1,87 @@
+"""BASELINE.json-size checks through size-independent properties.  Needs an MI355X: -m gpu."""
+import numpy as np
+import pytest
+
+from gpu_util import resource_for
+from oracle.pyoracle import Oracle
+from php_aho_corasick_amd import api, batch, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _device_batch(ds):
+    import torch
+    return torch.from_numpy(ds.hay_blob).cuda(), torch.from_numpy(ds.hay_off.astype(np.int64)).cuda()
+
+
+@pytest.mark.parametrize("ilp", [1, 2])
+def test_config2_planted_at_scale(ilp):
+    """2048x16 B patterns over 2^15 x 8 KiB haystacks (256 MiB): every haystack carries exactly one
+    planted pattern at a known place; unplanted hits in random abcdef text are ~6e-6 per haystack.
+    A 2,048-haystack slice is also checked record-for-record against the oracle."""
+    nh = 1 << 15
+    ds = synth.bench_batch(nh)
+    res = resource_for(ds, ilp=ilp)
+    d_blob, d_off = _device_batch(ds)
+    batch.bind_current_stream(res)
+    total = batch.match_device(res, d_blob, d_off)
+    prefix, rec = batch.result_numpy(res, nh, total)
+    h = np.arange(nh)
+    at = (31 * h + 5) % (8192 - 16)
+    planted = np.stack([h, at + 16, at, (7 * h + 3) % 2048], axis=1).astype(np.uint32)
+    # every planted record is present, in order
+    idx = prefix[:-1].astype(np.int64)
+    assert total >= nh and np.all(np.diff(prefix.astype(np.int64)) >= 1)
+    keys = rec[:, 0].astype(np.int64) * (1 << 32) + rec[:, 1]
+    assert np.all(np.diff(keys) >= 0), "records must be ordered by (haystack, pos)"
+    got = {tuple(int(x) for x in r) for r in rec}
+    assert all(tuple(int(x) for x in p) in got for p in planted[:: 97])
+    assert total - nh <= 4  # accidental extra hits are astronomically rare
+    # oracle slice
+    o = Oracle("port")
+    o.add_patterns((ds.pat_blob, ds.pat_off))
+    lo, hi = 4096, 4096 + 2048
+    sub_off = ds.hay_off[lo:hi + 1] - ds.hay_off[lo]
+    pe, re_ = o.match_batch(ds.hay_blob[int(ds.hay_off[lo]):int(ds.hay_off[hi])], sub_off)
+    re_[:, 0] += lo
+    assert np.array_equal(rec[int(prefix[lo]):int(prefix[hi])], re_)
+    _ = idx
+    api.ahocorasick_deinit(res)
+
+
+def test_config5_dense_count_formula():
+    """Adversarial a^1..a^16 over a^8192: records = NH*(K*HL - K(K-1)/2); order and content exact."""
+    nh, hl, k = 64, 8192, 16
+    ds = synth.g3(n_hay=nh, hay_len=hl, k=k)
+    res = resource_for(ds)
+    d_blob, d_off = _device_batch(ds)
+    batch.bind_current_stream(res)
+    total = batch.match_device(res, d_blob, d_off)
+    assert total == nh * (k * hl - k * (k - 1) // 2)
+    prefix, rec = batch.result_numpy(res, nh, total)
+    per = k * hl - k * (k - 1) // 2
+    assert np.array_equal(prefix, np.arange(nh + 1, dtype=np.uint64) * np.uint64(per))
+    # one haystack's stream, closed form: at pos p the patterns min(p,16)..1, longest first
+    one = rec[:per]
+    pos = np.concatenate([np.full(min(p, k), p) for p in range(1, hl + 1)])
+    ln = np.concatenate([np.arange(min(p, k), 0, -1) for p in range(1, hl + 1)])
+    assert np.array_equal(one[:, 1], pos) and np.array_equal(one[:, 3], ln - 1) and np.array_equal(one[:, 2], pos - ln)
+    assert np.array_equal(rec[per:2 * per, 1:], one[:, 1:]) and np.all(rec[per:2 * per, 0] == 1)
+    api.ahocorasick_deinit(res)
+
+
+def test_idempotent_and_chunk_invariant():
+    """Same batch, different work-item sizes / kernels -> byte-identical result arrays."""
+    ds = synth.bench_batch(1 << 12)
+    ref = None
+    for opts in (dict(kernel=1, ilp=1), dict(kernel=1, ilp=2, chunk_bytes=1024), dict(kernel=0, chunk_bytes=2048)):
+        res = resource_for(ds, **opts)
+        d_blob, d_off = _device_batch(ds)
+        batch.bind_current_stream(res)
+        for _ in range(2):
+            total = batch.match_device(res, d_blob, d_off)
+            out = batch.result_numpy(res, ds.n_haystacks, total)
+            if ref is None:
+                ref = out
+            assert np.array_equal(out[0], ref[0]) and np.array_equal(out[1], ref[1])
+        api.ahocorasick_deinit(res)

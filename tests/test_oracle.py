@@ -1,0 +1,99 @@
+"""The oracle (oracle/ac_oracle.c) against the reference's own vectors.  CPU only.
+
+* tests/golden/kat.json    -- transcribed from the reference's tests/test1..6.phpt
+* tests/golden/golden.json -- streams produced by the reference's C sources (oracle/_ref)
+* live comparison with oracle/_ref when it is present (build container)
+"""
+import numpy as np
+import pytest
+
+from helpers import pack_record, sha
+from oracle import pyoracle
+from oracle.pyoracle import Oracle, record_checksum
+from php_aho_corasick_amd import synth
+
+
+def _values(pats):
+    return [p["value"].encode("utf-8") for p in pats]
+
+
+def test_kat_vectors(kat):
+    """Every known-answer case of the reference's .phpt files, through the oracle + an independent packer."""
+    for case in kat:
+        o = Oracle("port")
+        pats = []
+        for call in ([case["init"]] if case["init"] else []) + case["adds"]:
+            o.add_patterns(_values(call))
+            pats += call
+        for q in case["queries"]:
+            find_all = q.get("findAll", True)
+            rec = o.match(q["haystack"].encode("utf-8"), find_all)
+            got = [pack_record(pats[int(r[3])], int(r[1]), int(r[2])) for r in rec]
+            assert got == q["expect"], (case["name"], q["haystack"])
+        o.close()
+
+
+@pytest.mark.parametrize("name", list(synth.NAMED))
+def test_golden_streams(name, golden):
+    ds = synth.NAMED[name]()
+    o = Oracle("port")
+    acc = o.add_patterns((ds.pat_blob, ds.pat_off))
+    o.finalize()
+    for find_all in (True, False):
+        g = golden[(name, find_all)]
+        assert acc == g["accepted"] and o.node_count() == g["nodes"]
+        prefix, rec = o.match_batch(ds.hay_blob, ds.hay_off, find_all)
+        assert len(rec) == g["n_records"]
+        assert sha(rec) == g["sha256"]
+        assert sha(prefix) == g["prefix_sha256"]
+        assert [[int(x) for x in r] for r in rec[:len(g["first"])]] == g["first"]
+    o.close()
+
+
+def test_survey_pinned_hashes(golden):
+    """The hashes SURVEY.md section 8c quotes for G1..G6 (measured there from the reference)."""
+    want = {"G1": (0, "e3b0c44298fc1c149afbf4c8996fb92427ae41e4649b934ca495991b7852b855"),
+            "G2": (256, "3fd5779c2e568419620a83dbbabd101284e9209cc70e8c3180dc59c46eb9b1ff"),
+            "G3": (523808, "6ca233fd54392620281d258a86275622c3f9419d8ac86282c99ecf76567c6234"),
+            "G4": (131048, "1f6e94ccf99812b1865b6836ee75a1f0c96ee7e5c0b715d2c96cc58fa13d569c"),
+            "G6": (64, "273e7e5d120c754e472af4ca6e8293c80a0573af12723a625719e03435add735")}
+    for name, (n, h) in want.items():
+        assert golden[(name, True)]["n_records"] == n and golden[(name, True)]["sha256"] == h
+    assert golden[("G5", True)]["first"][:11] == [[0, 3, 0, 5], [0, 3, 1, 1], [0, 3, 2, 2], [0, 5, 3, 1], [0, 5, 4, 2],
+                                                  [0, 10, 7, 5], [0, 10, 8, 1], [0, 10, 9, 2], [0, 11, 10, 2],
+                                                  [0, 15, 13, 1], [0, 15, 14, 2]]
+
+
+@pytest.mark.skipif(not pyoracle.have_reference(), reason="oracle/_ref not built (no /root/reference here)")
+def test_port_equals_reference_live():
+    """Random small automata: our restatement and the compiled reference agree record for record."""
+    for seed in range(40, 52):
+        ds = synth.ragged(f"L{seed}", seed, 30 + seed, 1, 6, 20, 0, 400, b"abc\x00" if seed % 2 else None)
+        a, b = Oracle("port"), Oracle("reference")
+        half = ds.n_patterns // 2
+        pats = ds.patterns()
+        for o in (a, b):  # two add calls: reverse insertion happens per call
+            assert o.add_patterns(pats[:half]) >= 0
+            o.add_patterns(pats[half:])
+        assert a.pattern_count() == b.pattern_count() and a.node_count() == b.node_count()
+        for find_all in (True, False):
+            pa, ra = a.match_batch(ds.hay_blob, ds.hay_off, find_all)
+            pb, rb = b.match_batch(ds.hay_blob, ds.hay_off, find_all)
+            assert np.array_equal(pa, pb) and np.array_equal(ra, rb)
+        n, ck = a.scan_checksum(ds.hay_blob, ds.hay_off)
+        _, ra = a.match_batch(ds.hay_blob, ds.hay_off, True)
+        assert n == len(ra) and ck == record_checksum(ra)
+        a.close(), b.close()
+
+
+def test_duplicate_and_rejection_rules():
+    """ahocorasick.c:98-105,123-124 + reverse insertion: the LAST duplicate in caller order wins."""
+    o = Oracle("port")
+    acc = o.add_patterns([b"ab", b"ab", b"b", b"", b"x" * 1025, b"xab"])
+    assert acc == 3
+    rec = o.match(b"xab")
+    assert [tuple(int(x) for x in r[1:]) for r in rec] == [(3, 0, 5), (3, 1, 1), (3, 2, 2)]
+    o2 = Oracle("port")  # across calls the FIRST call's pattern wins
+    o2.add_patterns([b"ab"])
+    o2.add_patterns([b"ab"])
+    assert [int(r[3]) for r in o2.match(b"ab")] == [0]
