@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Throughput bench of the ac_trie_search() replacement on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--haystacks NH]
+
+One "step" = one pass of the hot path over one batch that is already resident in HBM:
+acmi_match_batch_device() = work-item table, LDS-tile scan kernel, record-base scan, expansion of
+events into the final {hay,pos,start,pattern} array (left on the device).  With N > 1 (launched by
+torch.distributed.run, one rank per GPU, backend "nccl" == RCCL) every rank scans its own shard of
+the same size (weak scaling) and the per-rank match arrays are all-gathered; the collective of step
+i runs on RCCL's stream while step i+1 scans.
+
+Workload (config.workload): BASELINE.json configs[1] shape -- 2048 patterns x 16 B over 8 KiB
+haystacks, alphabet abcdef, one planted hit per haystack -- scaled to 2^19 haystacks (4 GiB) per
+GPU, because the literal 256-haystack / 2 MiB batch is 0.3 us of HBM time, below launch latency.
+
+Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes of one scan launch
+(haystack bytes + 16 B per record + 8 B per haystack) / mean duration of the scan
+kernel measured with HIP events on the stream it runs on.  `cpu_baseline` = the reference's own
+MultiFast C (oracle/_ref, kind "reference") or our restatement (kind "port") timed on this box's
+host cores over a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+TILE_HAYSTACKS = 8192  # 64 MiB generated on the host, replicated on the device
+HAY_LEN = 8192
+
+
+def cpu_baseline(ds, seconds_target: float = 12.0):
+    """Reference CPU path over a bounded sample: 1 thread (the reference as shipped) and all cores
+    (one trie per thread -- AC_TRIE_t is not re-entrant, ahocorasick.h:49-65)."""
+    from oracle import pyoracle
+    kind = "reference" if pyoracle.have_reference() else "port"
+
+    def make():
+        o = pyoracle.Oracle(kind)
+        t0 = time.perf_counter()
+        o.add_patterns((ds.pat_blob, ds.pat_off))
+        o.finalize()
+        return o, time.perf_counter() - t0
+
+    o, build_s = make()
+    nh = 2048  # 16 MiB probe to size the sample
+    sub_off = ds.hay_off[:nh + 1]
+    sub_blob = ds.hay_blob[:int(sub_off[-1])]
+    t0 = time.perf_counter()
+    o.scan_checksum(sub_blob, sub_off)
+    probe = time.perf_counter() - t0
+    reps = max(1, int(seconds_target / max(probe, 1e-3)))
+    reps = min(reps, 64)
+    t0 = time.perf_counter()
+    n_rec = 0
+    for _ in range(reps):
+        n_rec, _ck = o.scan_checksum(sub_blob, sub_off)
+    dt = time.perf_counter() - t0
+    one = {"value": round(reps * len(sub_blob) / dt / 1e9, 5), "unit": "GB/s", "cores": 1, "kind": kind,
+           "sample": f"{reps} x {nh} haystacks x {HAY_LEN} B ({reps * len(sub_blob) >> 20} MiB) of the bench "
+                     f"workload, callback = count + checksum, {n_rec} records per pass",
+           "build_ms": round(build_s * 1e3, 2)}
+
+    cores = os.cpu_count() or 1
+    tries = [make()[0] for _ in range(cores)]
+    per = nh // cores
+    reps_mt = max(1, reps // 2)
+
+    def work(i):
+        lo, hi = i * per, (i + 1) * per
+        off = ds.hay_off[lo:hi + 1] - ds.hay_off[lo]
+        blob = ds.hay_blob[int(ds.hay_off[lo]):int(ds.hay_off[hi])]
+        for _ in range(reps_mt):
+            tries[i].scan_checksum(blob, off)  # ctypes releases the GIL
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    t0 = time.perf_counter()
+    [t.start() for t in th]
+    [t.join() for t in th]
+    dt = time.perf_counter() - t0
+    allc = {"value": round(reps_mt * per * cores * HAY_LEN / dt / 1e9, 5), "unit": "GB/s", "cores": cores,
+            "kind": kind, "sample": f"{reps_mt} x {per * cores} haystacks, one trie replica per thread"}
+    return one, allc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--haystacks", type=int, default=1 << 19, help="haystacks per GPU (8 KiB each)")
+    ap.add_argument("--ilp", type=int, default=int(os.environ.get("ACMI_ILP", "0")))
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    from php_aho_corasick_amd import synth
+    ds = synth.bench_batch(TILE_HAYSTACKS, HAY_LEN, seed=1, planted=True)
+
+    cpu1 = cpu_all = None
+    if rank == 0 and args.gpus == 1 and not args.no_cpu:
+        cpu1, cpu_all = cpu_baseline(ds)
+
+    import torch
+    import torch.distributed as dist
+    from php_aho_corasick_amd import api, batch
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- automaton (replicated on every rank) ----
+    t0 = time.perf_counter()
+    res = api.ahocorasick_init([{"id": k, "value": ds.pattern(k)} for k in range(ds.n_patterns)])
+    api.ahocorasick_finalize(res)
+    build_ms = (time.perf_counter() - t0) * 1e3
+    res.set_option("profile", 1)
+    if args.ilp:
+        res.set_option("ilp", args.ilp)
+
+    # ---- batch resident in HBM: the 64 MiB tile replicated to the requested size ----
+    nh = max(TILE_HAYSTACKS, (args.haystacks // TILE_HAYSTACKS) * TILE_HAYSTACKS)
+    reps = nh // TILE_HAYSTACKS
+    tile = torch.from_numpy(ds.hay_blob).to(dev)
+    d_blob = tile.repeat(reps).contiguous()
+    d_off = torch.arange(nh + 1, dtype=torch.int64, device=dev) * HAY_LEN
+    del tile
+    batch.bind_current_stream(res)
+    hay_base = rank * nh
+    bytes_per_step = nh * HAY_LEN
+
+    pending = []
+    scan_ms = []
+    records_per_step = 0
+
+    def step():
+        nonlocal records_per_step
+        total = batch.match_device(res, d_blob, d_off, True)
+        records_per_step = total
+        scan_ms.append(res.stat("scan_ms"))
+        if world > 1:
+            # all-gatherv of the match arrays, asynchronous: sizes, then padded payloads
+            prefix, rec = batch.result_tensors(res, nh, total, dev)
+            pending.append(batch.allgatherv_start(prefix[1:] - prefix[:-1], rec, hay_base))
+            while len(pending) > 1:
+                batch.allgatherv_finish(pending.pop(0))
+
+    for _ in range(args.warmup):
+        step()
+    while pending:
+        batch.allgatherv_finish(pending.pop(0))
+    scan_ms.clear()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    gathered = None
+    while pending:
+        gathered = batch.allgatherv_finish(pending.pop(0))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    # sanity: every haystack carries its planted record; the tile's count repeats
+    prefix, rec = batch.result_numpy(res, nh, records_per_step)
+    ok = records_per_step >= nh and int(prefix[-1]) == records_per_step
+    tile_count = int(prefix[TILE_HAYSTACKS])
+    ok = ok and records_per_step == tile_count * reps
+    if gathered is not None:
+        ok = ok and int(gathered[0][-1].item()) == gathered[1].shape[0]
+
+    if rank == 0:
+        kernel_ms = float(np.mean(scan_ms)) if scan_ms else float("nan")
+        algo_bytes = bytes_per_step + 16 * records_per_step + 8 * nh
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "haystack_GB_per_s", "value": round(world * bytes_per_step * args.steps / dt / 1e9, 2),
+            "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"2048 patterns x 16 B (abcdef, seed 1) over {nh} haystacks x {HAY_LEN} B per GPU "
+                                   f"({bytes_per_step >> 20} MiB), one planted hit per haystack; BASELINE configs[1] shape",
+                       "patterns": ds.n_patterns, "haystacks_per_gpu": nh, "haystack_bytes": HAY_LEN,
+                       "states": int(res.stat("states")), "hot_states": int(res.stat("hot_states")),
+                       "lds_tile_bytes": int(res.stat("lds_image_bytes")), "work_item_bytes": int(res.stat("chunk_bytes")),
+                       "ilp": args.ilp or 1, "sharding": f"{world} contiguous haystack ranges" if world > 1 else "none"},
+            "matches_per_s": round(world * records_per_step * args.steps / dt, 1),
+            "records_per_step_per_gpu": records_per_step, "check_ok": bool(ok),
+            "automaton_build_ms": round(build_ms, 2),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "k_scan_lds", "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes": algo_bytes},
+            "cpu_baseline": cpu1, "cpu_baseline_all_cores": cpu_all,
+        }
+        print(json.dumps(out), flush=True)
+    api.ahocorasick_deinit(res)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -63,18 +63,10 @@ def result_numpy(res: AhoResource, n_haystacks: int, total: int):
     return prefix, records[:total]
 
 
-def allgatherv_records(counts_local, records_local, hay_base: int, group=None):
-    """All-gatherv of match arrays: every rank ends with the concatenation, in rank order, of all
-    ranks' per-haystack counts and records (haystack ids made global with ``hay_base``).
-
-    RCCL has no native v-variant; sizes are exchanged first (fixed-size all_gather), then the
-    payloads are padded to the largest shard and exchanged with one all_gather each.  Match arrays
-    are tiny next to the haystacks on sparse workloads (16 B per record), so padding costs nothing
-    that matters; the dense adversarial case would rather gather to the caller's rank only.
-
-    ``counts_local``: int64[n_local] records per local haystack; ``records_local``: int32[n,4].
-    Returns (prefix int64[n_global+1], records int32[total,4]) on the same device as the inputs.
-    """
+def allgatherv_start(counts_local, records_local, hay_base: int, group=None):
+    """First half of the all-gatherv of match arrays (see ``allgatherv_records``): exchanges sizes
+    (blocking, 16 bytes per rank) and LAUNCHES the padded payload all_gathers asynchronously, so the
+    caller can start scanning its next batch while RCCL moves this one over xGMI."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -87,20 +79,44 @@ def allgatherv_records(counts_local, records_local, hay_base: int, group=None):
     dist.all_gather(all_sizes, sizes, group=group)
     all_sizes = torch.stack(all_sizes).cpu()
     max_rec, max_cnt = int(all_sizes[:, 0].max()), int(all_sizes[:, 1].max())
-
     rec_pad = torch.zeros((max(max_rec, 1), 4), dtype=torch.int32, device=dev)
     rec_pad[:rec.shape[0]] = rec
     cnt_pad = torch.zeros(max(max_cnt, 1), dtype=torch.int64, device=dev)
     cnt_pad[:counts_local.numel()] = counts_local
     rec_all = [torch.empty_like(rec_pad) for _ in range(world)]
     cnt_all = [torch.empty_like(cnt_pad) for _ in range(world)]
-    dist.all_gather(rec_all, rec_pad, group=group)
-    dist.all_gather(cnt_all, cnt_pad, group=group)
+    w1 = dist.all_gather(rec_all, rec_pad, group=group, async_op=True)
+    w2 = dist.all_gather(cnt_all, cnt_pad, group=group, async_op=True)
+    return all_sizes, rec_all, cnt_all, (w1, w2), (rec_pad, cnt_pad)
+
+
+def allgatherv_finish(state):
+    """Second half: wait for the payloads, drop the padding, concatenate in rank order."""
+    import torch
+    all_sizes, rec_all, cnt_all, works, _keep = state
+    for w in works:
+        w.wait()
+    world = len(rec_all)
     records = torch.cat([rec_all[r][:int(all_sizes[r, 0])] for r in range(world)])
     counts = torch.cat([cnt_all[r][:int(all_sizes[r, 1])] for r in range(world)])
-    prefix = torch.zeros(counts.numel() + 1, dtype=torch.int64, device=dev)
+    prefix = torch.zeros(counts.numel() + 1, dtype=torch.int64, device=records.device)
     prefix[1:] = torch.cumsum(counts, 0)
     return prefix, records
+
+
+def allgatherv_records(counts_local, records_local, hay_base: int, group=None):
+    """All-gatherv of match arrays: every rank ends with the concatenation, in rank order, of all
+    ranks' per-haystack counts and records (haystack ids made global with ``hay_base``).
+
+    RCCL has no native v-variant; sizes are exchanged first (fixed-size all_gather), then the
+    payloads are padded to the largest shard and exchanged with one all_gather each.  Match arrays
+    are tiny next to the haystacks on sparse workloads (16 B per record), so padding costs nothing
+    that matters; the dense adversarial case would rather gather to the caller's rank only.
+
+    ``counts_local``: int64[n_local] records per local haystack; ``records_local``: int32[n,4].
+    Returns (prefix int64[n_global+1], records int32[total,4]) on the same device as the inputs.
+    """
+    return allgatherv_finish(allgatherv_start(counts_local, records_local, hay_base, group))
 
 
 def sharded_match(res: AhoResource, d_blob_local, d_off_local, hay_base: int, find_all: bool = True, group=None):

@@ -21,6 +21,7 @@
 
 #include "device_types.hpp"
 #include "kernels.hpp"
+#include "scan_asm.inc"
 
 namespace acmi {
 
@@ -62,27 +63,21 @@ __device__ __forceinline__ bool is_final(const DevAutomaton &A, uint32_t s) {
 }
 
 // Per-item event sink.  Events, not records, are stored: one {pos, state} per arrival in a
-// final state; the per-state output list is expanded later (k_expand / k_refill).
-struct Sink {
-    uint2 *slab;
-    uint64_t n_rec;
-    uint32_t n_ev;
-    uint32_t cap;
-    uint32_t first_only;
-};
-
-__device__ __forceinline__ void on_event(const DevAutomaton &A, Sink &k, uint32_t pos, uint32_t s) {
-    if (k.first_only && k.n_ev) return;  // findAll=false: the first event only (php_ahocorasick.c:588)
-    k.n_rec += A.out_count[s];
-    if (k.n_ev < k.cap) k.slab[k.n_ev] = make_uint2(pos, s);
-    ++k.n_ev;
+// final state; the per-state output list is expanded later (k_expand / k_refill).  The
+// counters live in global memory (zeroed before the launch) rather than in registers: events
+// are rare on the hot path and the scan kernel needs its VGPRs for haystack lines.
+__device__ __forceinline__ void on_event(const DevAutomaton &A, const BatchArgs &B, uint64_t item, uint32_t pos,
+                                         uint32_t s) {
+    const uint32_t n = B.ev_count[item];
+    if (B.first_only && n) return;  // findAll=false: the first event only (php_ahocorasick.c:588)
+    B.rec_count[item] += A.out_count[s];
+    if (n < B.slab_events) B.slab[item * B.slab_events + n] = make_uint2(pos, s);
+    B.ev_count[item] = n + 1;
 }
 
-__device__ __forceinline__ void finish_item(const BatchArgs &B, const Sink &k, uint64_t i, uint32_t hay) {
-    B.item_hay[i] = hay;
-    B.ev_count[i] = k.n_ev;
-    B.rec_count[i] = k.n_rec;
-    if (k.n_ev > k.cap) B.overflow_list[atomicAdd(&B.counters[0], 1u)] = uint32_t(i);
+__device__ __forceinline__ void finish_item(const BatchArgs &B, uint64_t item, uint32_t hay) {
+    B.item_hay[item] = hay;
+    if (B.ev_count[item] > B.slab_events) B.overflow_list[atomicAdd(&B.counters[0], 1u)] = uint32_t(item);
 }
 
 // One exact transition.  `tile` (LDS) may be null; hot rows are read from it unless the
@@ -100,13 +95,13 @@ __device__ __forceinline__ uint32_t exact_step(const DevAutomaton &A, const uint
 
 // Walk bytes [j0, j1) of a stream one by one with full semantics (events, cold states).
 template <typename E>
-__device__ __forceinline__ uint32_t exact_bytes(const DevAutomaton &A, const uint8_t *tile, Sink &k,
-                                                const uint8_t *p, uint32_t j0, uint32_t j1, uint32_t warm,
-                                                uint32_t pos0, uint32_t s) {
+__device__ __forceinline__ uint32_t exact_bytes(const DevAutomaton &A, const BatchArgs &B, const uint8_t *tile,
+                                                uint64_t item, const uint8_t *p, uint32_t j0, uint32_t j1,
+                                                uint32_t warm, uint32_t pos0, uint32_t s) {
 #pragma unroll 1
     for (uint32_t j = j0; j < j1; ++j) {
         s = exact_step<E>(A, tile, s, p[j]);
-        if (j >= warm && is_final(A, s)) on_event(A, k, pos0 + (j - warm) + 1, s);
+        if (j >= warm && is_final(A, s)) on_event(A, B, item, pos0 + (j - warm) + 1, s);
     }
     return s;
 }
@@ -202,10 +197,9 @@ __global__ void k_scan_simple(DevAutomaton A, BatchArgs B) {
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     ItemDesc it;
     if (!decode_item(B, i, it)) return;
-    Sink k{B.slab + i * B.slab_events, 0, 0, B.slab_events, B.first_only};
     const uint8_t *p = B.blob + (it.begin - it.warm);
-    exact_bytes<E>(A, nullptr, k, p, 0, it.warm + it.len, it.warm, it.pos0, 0u);
-    finish_item(B, k, i, it.hay);
+    exact_bytes<E>(A, B, nullptr, i, p, 0, it.warm + it.len, it.warm, it.pos0, 0u);
+    finish_item(B, i, it.hay);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -214,12 +208,16 @@ __global__ void k_scan_simple(DevAutomaton A, BatchArgs B) {
 // * Workgroup = 1024 threads (16 waves, 4 per SIMD), one workgroup per CU; it stages the hot
 //   tile of the transition table (up to ~160 KiB: every state within the first few trie
 //   levels) into LDS once and then streams its work items.
-// * Each lane owns ILP independent work items (streams).  A lane reads its haystack in whole
-//   128-byte lines: eight 16-byte loads into a rolling register buffer, each slot re-loaded
-//   with the line after next as soon as it has been consumed, so every HBM line is fetched
-//   exactly once and ~100 byte-steps of work hide its latency.
+// * Each lane owns ILP independent work items (streams): the per-byte step is a dependent
+//   LDS lookup (~100+ cycles issue-to-use under load), so independent chains per lane are what
+//   fills the SIMD besides the 4 waves it can hold at this LDS footprint.
+// * A lane reads its haystack 64 bytes (4 x 16-byte loads, issued back to back) at a time into
+//   one of two register buffers; the group after the current one is in flight while the
+//   current one is scanned, so HBM latency hides behind 64 byte-steps.  Loads are
+//   unconditional (index clamped to the stream's last quad) so the compiler can count them
+//   with s_waitcnt vmcnt(N) instead of draining the queue.
 // * The inner step is optimistic: 16 bytes are pushed through the LDS tile with no branch at
-//   all (per byte: one bit-field extract, one multiply-add for the address, one ds_read, one
+//   all (per byte: extract the column, one multiply-add for the address, one ds_read, one
 //   max).  Transitions that would leave the tile land on an absorbing TRAP row and final states
 //   are numbered >= f1, so "max state seen >= f1" after the 16 bytes says the quad needs the
 //   exact path (an event to record, a cold state, a byte outside the alphabet); only then is
@@ -231,98 +229,160 @@ __global__ void k_scan_simple(DevAutomaton A, BatchArgs B) {
 //   v_perm_b32.  TABLE mode reads a 256-entry column-offset table from LDS instead.
 // ------------------------------------------------------------------------------------------
 constexpr int kLdsThreads = 1024;
-constexpr int kQuadsPerLine = 8;
+constexpr int kGroupQuads = 4;  // 16-byte quads fetched per lane per group (64 B)
 
-template <typename E>
-__device__ __forceinline__ uint32_t tile_read(const uint8_t *tile, uint32_t addr) {
-    return *reinterpret_cast<const E *>(tile + addr);
+// byte -> column offset inside a row, without touching global memory
+template <typename E, int MODE>
+__device__ __forceinline__ uint32_t class_offset(const DevAutomaton &A, const uint8_t *smem, uint32_t byte) {
+    if (MODE == 1) {
+        const uint32_t c = (byte >> A.swar_shift) & 7u;
+        // selector bytes 1..3 = 0x0c pick the constant 0x00
+        const uint32_t e = __builtin_amdgcn_perm(A.swar_expect_hi, A.swar_expect_lo, c | 0x0c0c0c00u);
+        return e == byte ? c * uint32_t(sizeof(E)) : A.swar_other_off;
+    }
+    return reinterpret_cast<const uint16_t *>(smem)[byte];
+}
+
+template <typename E, int MODE>
+__device__ __forceinline__ uint32_t exact_step_lds(const DevAutomaton &A, const uint8_t *smem, const uint8_t *tile,
+                                                   uint32_t s, uint32_t byte) {
+    const uint32_t coff = class_offset<E, MODE>(A, smem, byte);
+    if (s < A.trap) {
+        const uint32_t w = *reinterpret_cast<const E *>(tile + s * A.row_bytes + coff);
+        if (w < A.trap) return w;
+    }
+    return *reinterpret_cast<const E *>(static_cast<const uint8_t *>(A.table) + uint64_t(s) * A.row_bytes + coff);
+}
+
+// Exact replay of one 16-byte quad from its entry state: events, cold states, foreign bytes.
+template <typename E, int MODE>
+__device__ __forceinline__ uint32_t replay_quad(const DevAutomaton &A, const BatchArgs &B, const uint8_t *smem,
+                                                const uint8_t *tile, uint64_t item, uint4 cur, uint32_t s,
+                                                int32_t j0, int32_t warm_rel, uint32_t pos_bias) {
+    const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll 1
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t byte = (w[i] >> (8 * b)) & 0xffu;
+            s = exact_step_lds<E, MODE>(A, smem, tile, s, byte);
+            const int32_t j = j0 + 4 * i + b;
+            if (j >= warm_rel && is_final(A, s)) on_event(A, B, item, pos_bias + uint32_t(j), s);
+        }
+    }
+    return s;
 }
 
 template <typename E, int MODE, int ILP>
 __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchArgs B) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr uint32_t kTileOff = MODE == 1 ? 0u : 512u;  // TABLE mode: 256 x uint16 column offsets first
+    constexpr int G = kGroupQuads;
     const uint64_t first = uint64_t(blockIdx.x) * (kLdsThreads * ILP);
     if (first >= B.item_base[B.n_haystacks]) return;
 
-    {   // stage [class offsets +] hot tile into LDS
+    {   // stage [column offsets +] hot tile into LDS
         const uint4 *src = static_cast<const uint4 *>(A.lds_image);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
         const uint32_t n16 = (A.lds_image_bytes + 15u) >> 4;
         for (uint32_t t = threadIdx.x; t < n16; t += kLdsThreads) dst[t] = src[t];
     }
     __syncthreads();
-    const uint8_t *tile = smem + A.tile_offset;
+    // the hand-scheduled path addresses the tile with raw LDS offsets: the dynamic LDS block must
+    // start at LDS address 0 (true while this kernel declares no static __shared__ object)
+    if (uint32_t(reinterpret_cast<uintptr_t>(
+            (__attribute__((address_space(3))) uint8_t *)smem)) != 0u) __builtin_trap();
+    const uint8_t *tile = smem + kTileOff;
     const uint32_t row_bytes = A.row_bytes;
-    const uint32_t f1 = A.f1;
+    const uint32_t f1 = A.f1, trap = A.trap;
+    const uint64_t item0 = first + uint64_t(threadIdx.x) * ILP;
 
-    ItemDesc it[ILP];
-    bool valid[ILP];
-    Sink sink[ILP];
-    uint32_t s[ILP], head[ILP], nq[ILP], n[ILP];
-    const uint8_t *p[ILP];
+    // per-stream state kept across the main loop: 6 VGPRs + the line buffers
+    uint32_t s[ILP], nq[ILP], last[ILP], pos_bias[ILP];
+    int32_t warm_rel[ILP];
     const uint4 *qp[ILP];
     uint32_t nq_max = 0;
 #pragma unroll
     for (int k = 0; k < ILP; ++k) {
-        const uint64_t i = first + uint64_t(threadIdx.x) * ILP + k;
-        valid[k] = decode_item(B, i, it[k]);
-        sink[k] = Sink{B.slab + i * B.slab_events, 0, 0, B.slab_events, B.first_only};
-        s[k] = 0;
-        n[k] = 0; head[k] = 0; nq[k] = 0; p[k] = B.blob; qp[k] = nullptr;
-        if (valid[k]) {
-            p[k] = B.blob + (it[k].begin - it[k].warm);
-            n[k] = it[k].warm + it[k].len;
-            const uint32_t mis = uint32_t(-reinterpret_cast<uintptr_t>(p[k])) & 15u;
-            head[k] = mis < n[k] ? mis : n[k];
-            // unaligned head, byte by byte
-            s[k] = exact_bytes<E>(A, tile, sink[k], p[k], 0, head[k], it[k].warm, it[k].pos0, s[k]);
-            nq[k] = (n[k] - head[k]) >> 4;
-            qp[k] = reinterpret_cast<const uint4 *>(p[k] + head[k]);
+        ItemDesc it;
+        s[k] = 0; nq[k] = 0; last[k] = 0; pos_bias[k] = 0; warm_rel[k] = 0;
+        qp[k] = static_cast<const uint4 *>(A.lds_image);  // any readable 16-byte aligned address
+        if (decode_item(B, item0 + k, it)) {
+            const uint8_t *p = B.blob + (it.begin - it.warm);
+            const uint32_t n = it.warm + it.len;
+            const uint32_t mis = uint32_t(-reinterpret_cast<uintptr_t>(p)) & 15u;
+            const uint32_t head = mis < n ? mis : n;
+            s[k] = exact_bytes<E>(A, B, tile, item0 + k, p, 0, head, it.warm, it.pos0, 0u);  // unaligned head
+            nq[k] = (n - head) >> 4;
+            if (nq[k]) { qp[k] = reinterpret_cast<const uint4 *>(p + head); last[k] = nq[k] - 1; }
+            // byte j' (counted from the first quad) reports iff j' >= warm_rel, at pos_bias + j'
+            warm_rel[k] = int32_t(it.warm) - int32_t(head);
+            pos_bias[k] = it.pos0 + head + 1u - it.warm;
             nq_max = nq[k] > nq_max ? nq[k] : nq_max;
         }
     }
 
-    // rolling line buffer: slot r holds quad (base + r), re-loaded with quad (base + r + 8)
-    uint4 buf[ILP][kQuadsPerLine];
+    uint4 buf0[ILP][G], buf1[ILP][G];
+    auto load_group = [&](uint4 (&buf)[ILP][G], uint32_t g) {
 #pragma unroll
-    for (int k = 0; k < ILP; ++k)
+        for (int k = 0; k < ILP; ++k)
 #pragma unroll
-        for (int r = 0; r < kQuadsPerLine; ++r)
-            buf[k][r] = uint32_t(r) < nq[k] ? qp[k][r] : make_uint4(0, 0, 0, 0);
-
-    for (uint32_t base = 0; base < nq_max; base += kQuadsPerLine) {
+            for (int r = 0; r < G; ++r) {
+                const uint32_t q = g * G + r;
+                buf[k][r] = qp[k][q < last[k] ? q : last[k]];
+            }
+    };
+    auto scan_group = [&](const uint4 (&buf)[ILP][G], uint32_t g) {
 #pragma unroll
-        for (int r = 0; r < kQuadsPerLine; ++r) {
-            const uint32_t q = base + r;
+        for (int r = 0; r < G; ++r) {
+            const uint32_t q = g * G + r;
             if (q < nq_max) {
-                uint4 cur[ILP];
                 uint32_t s_in[ILP], m[ILP], bad[ILP];
 #pragma unroll
                 for (int k = 0; k < ILP; ++k) {
-                    cur[k] = buf[k][r];
-                    if (q + kQuadsPerLine < nq[k]) buf[k][r] = qp[k][q + kQuadsPerLine];
                     s_in[k] = s[k];
                     // a cold entry state has no row in the tile: enter through the absorbing trap
                     // row instead, which forces the exact replay below (from the true s_in)
-                    s[k] = s[k] < A.trap ? s[k] : A.trap;
+                    s[k] = s[k] < trap ? s[k] : trap;
                     m[k] = 0;
                     bad[k] = 0;
                 }
                 // ---- optimistic 16 byte-steps per stream, branch-free ----
+                if constexpr (MODE == 1 && sizeof(E) == 2 && (ILP == 1 || ILP == 2)) {
+                    // hand-scheduled gfx950 sequence (scan_asm.inc): streams interleaved per step with
+                    // counted lgkmcnt waits, address = one v_mad_u32_u24; tile starts at LDS address 0
+                    uint32_t w[ILP][4], t0[ILP], t1[ILP];
+#pragma unroll
+                    for (int k = 0; k < ILP; ++k) {
+                        const uint4 &cur = buf[k][r];
+                        const uint32_t d[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const uint32_t c4 = (d[i] >> A.swar_shift) & 0x07070707u;
+                            const uint32_t e4 = __builtin_amdgcn_perm(A.swar_expect_hi, A.swar_expect_lo, c4);
+                            bad[k] |= e4 ^ d[i];
+                            w[k][i] = c4 << 1;  // column * sizeof(uint16_t), one byte per haystack byte
+                        }
+                    }
+                    if constexpr (ILP == 1) ACMI_SCAN_QUAD_ASM_1(t0, t1, m, s, w, row_bytes);
+                    else ACMI_SCAN_QUAD_ASM_2(t0, t1, m, s, w, row_bytes);
+#pragma unroll
+                    for (int k = 0; k < ILP; ++k) s[k] = t1[k];
+                } else {
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
-                    uint32_t o4[ILP];
                     uint32_t o[ILP][4];
 #pragma unroll
                     for (int k = 0; k < ILP; ++k) {
-                        const uint32_t d = w == 0 ? cur[k].x : w == 1 ? cur[k].y : w == 2 ? cur[k].z : cur[k].w;
+                        const uint4 &cur = buf[k][r];
+                        const uint32_t d = w == 0 ? cur.x : w == 1 ? cur.y : w == 2 ? cur.z : cur.w;
                         if (MODE == 1) {
                             const uint32_t c4 = (d >> A.swar_shift) & 0x07070707u;
                             const uint32_t e4 = __builtin_amdgcn_perm(A.swar_expect_hi, A.swar_expect_lo, c4);
                             bad[k] |= e4 ^ d;
-                            o4[k] = c4 * uint32_t(sizeof(E));
+                            const uint32_t o4 = c4 * uint32_t(sizeof(E));
 #pragma unroll
-                            for (int b = 0; b < 4; ++b) o[k][b] = __builtin_amdgcn_ubfe(o4[k], 8 * b, 8);
+                            for (int b = 0; b < 4; ++b) o[k][b] = __builtin_amdgcn_ubfe(o4, 8 * b, 8);
                         } else {
                             const uint16_t *coff = reinterpret_cast<const uint16_t *>(smem);
 #pragma unroll
@@ -334,45 +394,46 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchA
 #pragma unroll
                         for (int k = 0; k < ILP; ++k) {
                             const uint32_t addr = __umul24(s[k], row_bytes) + o[k][b];
-                            s[k] = tile_read<E>(tile, addr);
+                            s[k] = *reinterpret_cast<const E *>(tile + addr);
                             m[k] = s[k] > m[k] ? s[k] : m[k];
                         }
                     }
+                }
                 }
                 // ---- rare: replay the quad exactly ----
 #pragma unroll
                 for (int k = 0; k < ILP; ++k) {
                     if (q < nq[k]) {
-                        if (m[k] >= f1 || bad[k] != 0) {
-                            uint32_t t = s_in[k];
-                            const uint32_t j0 = head[k] + (q << 4);
-#pragma unroll 1
-                            for (uint32_t b = 0; b < 16; ++b) {
-                                const uint32_t wsel = b >> 2;
-                                const uint32_t d = wsel == 0 ? cur[k].x : wsel == 1 ? cur[k].y : wsel == 2 ? cur[k].z : cur[k].w;
-                                const uint32_t byte = (d >> ((b & 3u) * 8u)) & 0xffu;
-                                t = exact_step<E>(A, tile, t, byte);
-                                const uint32_t j = j0 + b;
-                                if (j >= it[k].warm && is_final(A, t))
-                                    on_event(A, sink[k], it[k].pos0 + (j - it[k].warm) + 1, t);
-                            }
-                            s[k] = t;
-                        }
+                        if (m[k] >= f1 || bad[k] != 0)
+                            s[k] = replay_quad<E, MODE>(A, B, smem, tile, item0 + k, buf[k][r], s_in[k], int32_t(q << 4),
+                                                        warm_rel[k], pos_bias[k]);
                     } else {
                         s[k] = s_in[k];
                     }
                 }
             }
         }
+    };
+
+    load_group(buf0, 0);
+    for (uint32_t g = 0; g * G < nq_max; g += 2) {
+        load_group(buf1, g + 1);
+        scan_group(buf0, g);
+        load_group(buf0, g + 2);
+        scan_group(buf1, g + 1);
     }
 
     // tail (< 16 bytes) and bookkeeping
 #pragma unroll
     for (int k = 0; k < ILP; ++k) {
-        if (valid[k]) {
-            const uint32_t j0 = head[k] + (nq[k] << 4);
-            s[k] = exact_bytes<E>(A, tile, sink[k], p[k], j0, n[k], it[k].warm, it[k].pos0, s[k]);
-            finish_item(B, sink[k], first + uint64_t(threadIdx.x) * ILP + k, it[k].hay);
+        ItemDesc it;
+        if (decode_item(B, item0 + k, it)) {
+            const uint8_t *p = B.blob + (it.begin - it.warm);
+            const uint32_t n = it.warm + it.len;
+            const uint32_t mis = uint32_t(-reinterpret_cast<uintptr_t>(p)) & 15u;
+            const uint32_t head = mis < n ? mis : n;
+            exact_bytes<E>(A, B, tile, item0 + k, p, head + (nq[k] << 4), n, it.warm, it.pos0, s[k]);
+            finish_item(B, item0 + k, it.hay);
         }
     }
 }

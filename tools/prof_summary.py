@@ -1,0 +1,39 @@
+"""Condense rocprofv3 output directories (made by tools/prof.sh) into one text summary."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
+for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    with open(f) as fh:
+        rows = list(csv.DictReader(fh))
+    for r in rows:
+        print(f"{r.get('Name','')[:70]:70s} calls={r.get('Calls')} total_ns={r.get('TotalDurationNs')} "
+              f"avg_ns={r.get('AverageNs')} pct={r.get('Percentage')}")
+print()
+print("== PMC counters, summed over dispatches of each kernel (per-dispatch mean in brackets) ==")
+for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        acc = defaultdict(lambda: defaultdict(float))
+        cnt = defaultdict(set)
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                k = r.get("Kernel_Name", "")[:60]
+                acc[k][r.get("Counter_Name")] += float(r.get("Counter_Value", 0))
+                cnt[k].add(r.get("Dispatch_Id"))
+        for k, cs in acc.items():
+            if "k_scan_lds" not in k and "k_scan_simple" not in k and "k_expand" not in k and "k_refill" not in k:
+                continue
+            n = max(1, len(cnt[k]))
+            print(f"{k}: dispatches={n}")
+            for c, v in sorted(cs.items()):
+                print(f"    {c:28s} {v:18.0f}  [{v / n:16.1f}]")
+print()
+for f in sorted(glob.glob(os.path.join(out, "bench_*.log"))):
+    with open(f) as fh:
+        for line in fh:
+            if line.startswith("{"):
+                print(os.path.basename(f), line.strip()[:400])
