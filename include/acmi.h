@@ -166,6 +166,7 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
 /* Integer options, set before finalize unless noted:
  *   "lds_bytes"      LDS budget for the hot-state tile (default 160 KiB minus slack)
  *   "slab_events"    per work-item event slots before the overflow path (default 8)
+ *   "run_cap"        per work-item fix-up runs before the item is rescanned whole (default 8)
  *   "chunk_bytes"    force the work-item size (0 = automatic)            [any time]
  *   "kernel"         0 = plain global-table kernel, 1 = LDS-tile kernel  [any time]
  *   "ilp"            streams per lane in the LDS-tile kernel (1 or 2)    [any time]
@@ -174,7 +175,7 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value);
 
 /* Numeric facts about the automaton and the last match call, e.g. "states",
  * "hot_states", "columns", "entry_bytes", "lds_image_bytes", "table_bytes",
- * "max_pattern_length", "items", "overflow_items", "scan_ms", "total_ms". */
+ * "max_pattern_length", "items", "overflow_items", "scan_ms", "fixup_ms", "total_ms". */
 int acmi_get_stat(const acmi_handle *h, const char *key, double *value);
 
 /* Run subsequent launches on this hipStream_t (passed as void*); NULL = the

@@ -60,6 +60,7 @@ struct acmi_handle {
 
     // options
     uint32_t slab_events = 8;
+    uint32_t run_cap = 8;
     uint64_t chunk_opt = 0;
     int kernel = 1;
     int ilp = 1;
@@ -70,13 +71,13 @@ struct acmi_handle {
     int dev_id = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     DevAutomaton dA{};
     DevBuf d_table, d_lds, d_class, d_own, d_dict, d_cnt, d_plen;
 
     // workspace (grow-only)
     DevBuf d_blob, d_off, d_nitems, d_item_base, d_item_hay, d_ev, d_rec_cnt, d_rec_base, d_slab, d_ovf, d_counters,
-        d_scan_tmp, d_prefix, d_out;
+        d_scan_tmp, d_prefix, d_out, d_run_cnt, d_runs;
     uint64_t *pinned = nullptr;  // [0] total records, [1] overflow items
 
     // last result
@@ -87,7 +88,7 @@ struct acmi_handle {
     std::vector<uint64_t> h_prefix;
 
     // statistics of the last call
-    double scan_ms = 0, total_ms = 0;
+    double scan_ms = 0, fixup_ms = 0, total_ms = 0;
     uint64_t items = 0, chunk_used = 0;
     uint32_t overflow_items = 0;
 
@@ -224,7 +225,7 @@ uint32_t choose_chunk(const acmi_handle *h, uint64_t blob_bytes) {
 int run_batch(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, const uint64_t *d_off, size_t nh,
               int find_all) {
     h->have_result = false;
-    h->scan_ms = h->total_ms = 0;
+    h->scan_ms = h->fixup_ms = h->total_ms = 0;
     h->items = 0;
     h->overflow_items = 0;
     if (nh > 0xFFFFFFF0ull) { h->last_error = "too many haystacks"; return ACMI_E_TOO_LARGE; }
@@ -256,11 +257,15 @@ int run_batch(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, const 
     HIPCHK(h, h->d_slab.ensure(max_items * K * 8));
     HIPCHK(h, h->d_ovf.ensure(max_items * 4));
     HIPCHK(h, h->d_counters.ensure(64));
+    const uint32_t Q = std::max<uint32_t>(1, h->run_cap);
+    HIPCHK(h, h->d_run_cnt.ensure(max_items * 4));
+    HIPCHK(h, h->d_runs.ensure(max_items * Q * 8));
     HIPCHK(h, h->d_scan_tmp.ensure(scan_temp_elems(std::max<uint64_t>(max_items + 1, nh + 1)) * 8 * 2));
 
     HIPCHK(h, hipMemsetAsync(h->d_ev.p, 0, max_items * 4, st));
     HIPCHK(h, hipMemsetAsync(h->d_rec_cnt.p, 0, (max_items + 1) * 8, st));
     HIPCHK(h, hipMemsetAsync(h->d_counters.p, 0, 64, st));
+    if (h->kernel == 1) HIPCHK(h, hipMemsetAsync(h->d_run_cnt.p, 0, max_items * 4, st));
 
     BatchArgs B{};
     B.blob = d_blob;
@@ -277,6 +282,10 @@ int run_batch(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, const 
     B.slab = h->d_slab.as<uint2>();
     B.overflow_list = h->d_ovf.as<uint32_t>();
     B.counters = h->d_counters.as<uint32_t>();
+    B.run_count = h->d_run_cnt.as<uint32_t>();
+    B.runs = h->d_runs.as<uint2>();
+    B.run_cap = Q;
+    B.poison_quads = std::max<uint32_t>(1, (fa.max_pattern_length + 15) / 16);
 
     launch_count_items(d_off, uint32_t(nh), chunk, h->d_nitems.as<uint64_t>(), st);
     exclusive_scan_u64(h->d_nitems.as<uint64_t>(), h->d_item_base.as<uint64_t>(), nh + 1, h->d_scan_tmp.as<uint64_t>(), st);
@@ -284,6 +293,7 @@ int run_batch(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, const 
     if (h->profile) HIPCHK(h, hipEventRecord(h->ev[1], st));
     HIPCHK(h, launch_scan(h->dA, B, max_items, int(fa.entry_bytes), h->kernel, int(fa.class_mode), h->ilp, st));
     if (h->profile) HIPCHK(h, hipEventRecord(h->ev[2], st));
+    if (h->profile) HIPCHK(h, hipEventRecord(h->ev[3], st));
 
     if (!find_all) launch_first_only(B, st);
     exclusive_scan_u64(h->d_rec_cnt.as<uint64_t>(), h->d_rec_base.as<uint64_t>(), max_items + 1,
@@ -309,12 +319,14 @@ int run_batch(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, const 
     }
     HIPCHK(h, hipGetLastError());
     if (h->profile) {
-        HIPCHK(h, hipEventRecord(h->ev[3], st));
-        HIPCHK(h, hipEventSynchronize(h->ev[3]));
+        HIPCHK(h, hipEventRecord(h->ev[4], st));
+        HIPCHK(h, hipEventSynchronize(h->ev[4]));
         float ms = 0;
         HIPCHK(h, hipEventElapsedTime(&ms, h->ev[1], h->ev[2]));
         h->scan_ms = ms;
-        HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[3]));
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev[2], h->ev[3]));
+        h->fixup_ms = ms;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[4]));
         h->total_ms = ms;
     }
     h->last_total = total;
@@ -389,7 +401,7 @@ int acmi_destroy(acmi_handle *h) {
         if (h->stream) (void)hipStreamSynchronize(h->stream);
         for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_blob,
                           &h->d_off, &h->d_nitems, &h->d_item_base, &h->d_item_hay, &h->d_ev, &h->d_rec_cnt,
-                          &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_scan_tmp, &h->d_prefix, &h->d_out})
+                          &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_scan_tmp, &h->d_prefix, &h->d_out, &h->d_run_cnt, &h->d_runs})
             b->release();
         for (auto &evt : h->ev)
             if (evt) (void)hipEventDestroy(evt);
@@ -511,6 +523,9 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
     } else if (k == "slab_events") {
         if (value < 1 || value > 4096) return ACMI_E_ARG;
         h->slab_events = uint32_t(value);
+    } else if (k == "run_cap") {
+        if (value < 1 || value > 1024) return ACMI_E_ARG;
+        h->run_cap = uint32_t(value);
     } else if (k == "chunk_bytes") {
         if (value < 0) return ACMI_E_ARG;
         h->chunk_opt = uint64_t(value);
@@ -553,6 +568,7 @@ int acmi_get_stat(const acmi_handle *h, const char *key, double *value) {
     else if (k == "chunk_bytes") *value = double(h->chunk_used);
     else if (k == "overflow_items") *value = h->overflow_items;
     else if (k == "scan_ms") *value = h->scan_ms;
+    else if (k == "fixup_ms") *value = h->fixup_ms;
     else if (k == "total_ms") *value = h->total_ms;
     else if (k == "records") *value = double(h->last_total);
     else return ACMI_E_ARG;

@@ -216,20 +216,50 @@ __global__ void k_scan_simple(DevAutomaton A, BatchArgs B) {
 //   current one is scanned, so HBM latency hides behind 64 byte-steps.  Loads are
 //   unconditional (index clamped to the stream's last quad) so the compiler can count them
 //   with s_waitcnt vmcnt(N) instead of draining the queue.
-// * The inner step is optimistic: 16 bytes are pushed through the LDS tile with no branch at
-//   all (per byte: extract the column, one multiply-add for the address, one ds_read, one
-//   max).  Transitions that would leave the tile land on an absorbing TRAP row and final states
-//   are numbered >= f1, so "max state seen >= f1" after the 16 bytes says the quad needs the
-//   exact path (an event to record, a cold state, a byte outside the alphabet); only then is
-//   the quad replayed from its saved entry state with full semantics.  On sparse-match text
-//   (the headline workload) replays are rare and the wave runs branch-free.
-// * SWAR3 mode maps 4 haystack bytes to 4 table columns with three VALU ops when the
-//   pattern alphabet has <= 8 symbols distinguishable by a 3-bit window (abcdef, ACGT, ...):
+// * The kernel is PURELY optimistic and records no events itself.  16 bytes (a quad) are pushed
+//   through the LDS tile with no branch at all (per byte: extract the column, one multiply-add
+//   for the address, one ds_read, one max).  Transitions that would leave the tile land on an
+//   absorbing TRAP row and final states are numbered >= f1, so "max state seen >= f1" after the
+//   quad says it holds an event or lost the true state.  Such a quad is appended to the item's
+//   run list for the dense epilogue, which re-walks just those bytes exactly (with the (Lmax-1)-byte
+//   warm-up that makes a mid-text restart exact).  A stream that hit the trap restarts from the
+//   root and keeps flagging the next ceil(Lmax/16) quads: after Lmax bytes a walk from the root
+//   is in the true state again, and until then the epilogue owns the events.  SIMT cost of a rare
+//   event is therefore one short divergent append, not a 16-step replay by the whole wave.
+// * SWAR3 mode maps 4 haystack bytes to 4 table columns with a few VALU ops when the pattern
+//   alphabet has <= 8 symbols distinguishable by a 3-bit window (abcdef, ACGT, ...):
 //   column = (byte >> shift) & 7, validated against the expected byte of that bucket with one
-//   v_perm_b32.  TABLE mode reads a 256-entry column-offset table from LDS instead.
+//   v_perm_b32; bytes outside the alphabet are redirected to the "other" column.  TABLE mode
+//   reads a 256-entry column-offset table from LDS instead.
 // ------------------------------------------------------------------------------------------
 constexpr int kLdsThreads = 1024;
 constexpr int kGroupQuads = 4;  // 16-byte quads fetched per lane per group (64 B)
+
+// Append byte run [lo, hi) of `item` (scan coordinates) to its fix-up list; adjacent runs merge.
+__device__ __forceinline__ void append_run(const BatchArgs &B, uint64_t item, uint32_t lo, uint32_t hi) {
+    const uint32_t n = B.run_count[item];
+    if (n > B.run_cap) return;  // already "whole item"
+    uint2 *runs = B.runs + item * B.run_cap;
+    if (n > 0 && runs[n - 1].y == lo) { runs[n - 1].y = hi; return; }
+    if (n < B.run_cap) runs[n] = make_uint2(lo, hi);
+    B.run_count[item] = n + 1;
+}
+
+// 4 haystack bytes -> 4 column offsets (one per byte lane of the result), SWAR3 mode.
+template <typename E>
+__device__ __forceinline__ uint32_t swar_columns(const DevAutomaton &A, uint32_t d) {
+    uint32_t c4 = (d >> A.swar_shift) & 0x07070707u;
+    const uint32_t e4 = __builtin_amdgcn_perm(A.swar_expect_hi, A.swar_expect_lo, c4);
+    uint32_t x = e4 ^ d;
+    if (__builtin_expect(x != 0, 0)) {  // some byte is outside the alphabet -> "other" column
+        x |= x >> 4;
+        x |= x >> 2;
+        x |= x >> 1;
+        const uint32_t mask = (x & 0x01010101u) * 0xffu;
+        c4 = (c4 & ~mask) | (mask & (A.swar_other_off / uint32_t(sizeof(E)) * 0x01010101u));
+    }
+    return c4 * uint32_t(sizeof(E));
+}
 
 // byte -> column offset inside a row, without touching global memory
 template <typename E, int MODE>
@@ -243,32 +273,27 @@ __device__ __forceinline__ uint32_t class_offset(const DevAutomaton &A, const ui
     return reinterpret_cast<const uint16_t *>(smem)[byte];
 }
 
+// Exact walk of bytes [j0, j1) of one item with the LDS tile resident: hot rows from LDS, cold
+// rows from the global table, haystack bytes by aligned dword loads.  Reports (records an event)
+// for final states at byte index j >= rep_from, at position pos_bias + j.  Returns the state.
 template <typename E, int MODE>
-__device__ __forceinline__ uint32_t exact_step_lds(const DevAutomaton &A, const uint8_t *smem, const uint8_t *tile,
-                                                   uint32_t s, uint32_t byte) {
-    const uint32_t coff = class_offset<E, MODE>(A, smem, byte);
-    if (s < A.trap) {
-        const uint32_t w = *reinterpret_cast<const E *>(tile + s * A.row_bytes + coff);
-        if (w < A.trap) return w;
-    }
-    return *reinterpret_cast<const E *>(static_cast<const uint8_t *>(A.table) + uint64_t(s) * A.row_bytes + coff);
-}
-
-// Exact replay of one 16-byte quad from its entry state: events, cold states, foreign bytes.
-template <typename E, int MODE>
-__device__ __forceinline__ uint32_t replay_quad(const DevAutomaton &A, const BatchArgs &B, const uint8_t *smem,
-                                                const uint8_t *tile, uint64_t item, uint4 cur, uint32_t s,
-                                                int32_t j0, int32_t warm_rel, uint32_t pos_bias) {
-    const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
+__device__ __forceinline__ uint32_t exact_range(const DevAutomaton &A, const BatchArgs &B, const uint8_t *smem,
+                                                const uint8_t *tile, uint64_t item, const uint8_t *p, uint32_t j0,
+                                                uint32_t j1, uint32_t rep_from, uint32_t pos_bias, uint32_t s) {
+    const uintptr_t base = reinterpret_cast<uintptr_t>(p);
+    uint32_t word = 0;
 #pragma unroll 1
-        for (int b = 0; b < 4; ++b) {
-            const uint32_t byte = (w[i] >> (8 * b)) & 0xffu;
-            s = exact_step_lds<E, MODE>(A, smem, tile, s, byte);
-            const int32_t j = j0 + 4 * i + b;
-            if (j >= warm_rel && is_final(A, s)) on_event(A, B, item, pos_bias + uint32_t(j), s);
-        }
+    for (uint32_t j = j0; j < j1; ++j) {
+        const uintptr_t a = base + j;
+        if (j == j0 || (a & 3u) == 0) word = *reinterpret_cast<const uint32_t *>(a & ~uintptr_t(3));
+        const uint32_t byte = (word >> (8u * uint32_t(a & 3u))) & 0xffu;
+        const uint32_t coff = class_offset<E, MODE>(A, smem, byte);
+        uint32_t w = A.trap;
+        if (s < A.trap) w = *reinterpret_cast<const E *>(tile + s * A.row_bytes + coff);
+        if (w >= A.trap)
+            w = *reinterpret_cast<const E *>(static_cast<const uint8_t *>(A.table) + uint64_t(s) * A.row_bytes + coff);
+        s = w;
+        if (j >= rep_from && is_final(A, s)) on_event(A, B, item, pos_bias + j, s);
     }
     return s;
 }
@@ -297,27 +322,28 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchA
     const uint32_t f1 = A.f1, trap = A.trap;
     const uint64_t item0 = first + uint64_t(threadIdx.x) * ILP;
 
-    // per-stream state kept across the main loop: 6 VGPRs + the line buffers
-    uint32_t s[ILP], nq[ILP], last[ILP], pos_bias[ILP];
-    int32_t warm_rel[ILP];
+    // per-stream state kept across the main loop: 7 VGPRs + the line buffers
+    uint32_t s[ILP], nq[ILP], last[ILP], head[ILP], poison[ILP];
     const uint4 *qp[ILP];
     uint32_t nq_max = 0;
 #pragma unroll
     for (int k = 0; k < ILP; ++k) {
         ItemDesc it;
-        s[k] = 0; nq[k] = 0; last[k] = 0; pos_bias[k] = 0; warm_rel[k] = 0;
+        s[k] = 0; nq[k] = 0; last[k] = 0; head[k] = 0; poison[k] = 0;
         qp[k] = static_cast<const uint4 *>(A.lds_image);  // any readable 16-byte aligned address
         if (decode_item(B, item0 + k, it)) {
             const uint8_t *p = B.blob + (it.begin - it.warm);
             const uint32_t n = it.warm + it.len;
             const uint32_t mis = uint32_t(-reinterpret_cast<uintptr_t>(p)) & 15u;
-            const uint32_t head = mis < n ? mis : n;
-            s[k] = exact_bytes<E>(A, B, tile, item0 + k, p, 0, head, it.warm, it.pos0, 0u);  // unaligned head
-            nq[k] = (n - head) >> 4;
-            if (nq[k]) { qp[k] = reinterpret_cast<const uint4 *>(p + head); last[k] = nq[k] - 1; }
-            // byte j' (counted from the first quad) reports iff j' >= warm_rel, at pos_bias + j'
-            warm_rel[k] = int32_t(it.warm) - int32_t(head);
-            pos_bias[k] = it.pos0 + head + 1u - it.warm;
+            head[k] = mis < n ? mis : n;
+            if (head[k]) {  // unaligned head: exact state walk here, events left to the epilogue
+#pragma unroll 1
+                for (uint32_t j = 0; j < head[k]; ++j) s[k] = exact_step<E>(A, tile, s[k], p[j]);
+                append_run(B, item0 + k, 0, head[k]);
+                if (s[k] >= trap) { s[k] = 0; poison[k] = B.poison_quads; }
+            }
+            nq[k] = (n - head[k]) >> 4;
+            if (nq[k]) { qp[k] = reinterpret_cast<const uint4 *>(p + head[k]); last[k] = nq[k] - 1; }
             nq_max = nq[k] > nq_max ? nq[k] : nq_max;
         }
     }
@@ -337,16 +363,9 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchA
         for (int r = 0; r < G; ++r) {
             const uint32_t q = g * G + r;
             if (q < nq_max) {
-                uint32_t s_in[ILP], m[ILP], bad[ILP];
+                uint32_t s_in[ILP], m[ILP];
 #pragma unroll
-                for (int k = 0; k < ILP; ++k) {
-                    s_in[k] = s[k];
-                    // a cold entry state has no row in the tile: enter through the absorbing trap
-                    // row instead, which forces the exact replay below (from the true s_in)
-                    s[k] = s[k] < trap ? s[k] : trap;
-                    m[k] = 0;
-                    bad[k] = 0;
-                }
+                for (int k = 0; k < ILP; ++k) { s_in[k] = s[k]; m[k] = 0; }
                 // ---- optimistic 16 byte-steps per stream, branch-free ----
                 if constexpr (MODE == 1 && sizeof(E) == 2 && (ILP == 1 || ILP == 2)) {
                     // hand-scheduled gfx950 sequence (scan_asm.inc): streams interleaved per step with
@@ -355,14 +374,10 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchA
 #pragma unroll
                     for (int k = 0; k < ILP; ++k) {
                         const uint4 &cur = buf[k][r];
-                        const uint32_t d[4] = {cur.x, cur.y, cur.z, cur.w};
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const uint32_t c4 = (d[i] >> A.swar_shift) & 0x07070707u;
-                            const uint32_t e4 = __builtin_amdgcn_perm(A.swar_expect_hi, A.swar_expect_lo, c4);
-                            bad[k] |= e4 ^ d[i];
-                            w[k][i] = c4 << 1;  // column * sizeof(uint16_t), one byte per haystack byte
-                        }
+                        w[k][0] = swar_columns<E>(A, cur.x);
+                        w[k][1] = swar_columns<E>(A, cur.y);
+                        w[k][2] = swar_columns<E>(A, cur.z);
+                        w[k][3] = swar_columns<E>(A, cur.w);
                     }
                     if constexpr (ILP == 1) ACMI_SCAN_QUAD_ASM_1(t0, t1, m, s, w, row_bytes);
                     else ACMI_SCAN_QUAD_ASM_2(t0, t1, m, s, w, row_bytes);
@@ -370,43 +385,43 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchA
                     for (int k = 0; k < ILP; ++k) s[k] = t1[k];
                 } else {
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    uint32_t o[ILP][4];
-#pragma unroll
-                    for (int k = 0; k < ILP; ++k) {
-                        const uint4 &cur = buf[k][r];
-                        const uint32_t d = w == 0 ? cur.x : w == 1 ? cur.y : w == 2 ? cur.z : cur.w;
-                        if (MODE == 1) {
-                            const uint32_t c4 = (d >> A.swar_shift) & 0x07070707u;
-                            const uint32_t e4 = __builtin_amdgcn_perm(A.swar_expect_hi, A.swar_expect_lo, c4);
-                            bad[k] |= e4 ^ d;
-                            const uint32_t o4 = c4 * uint32_t(sizeof(E));
-#pragma unroll
-                            for (int b = 0; b < 4; ++b) o[k][b] = __builtin_amdgcn_ubfe(o4, 8 * b, 8);
-                        } else {
-                            const uint16_t *coff = reinterpret_cast<const uint16_t *>(smem);
-#pragma unroll
-                            for (int b = 0; b < 4; ++b) o[k][b] = coff[__builtin_amdgcn_ubfe(d, 8 * b, 8)];
-                        }
-                    }
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
+                    for (int w = 0; w < 4; ++w) {
+                        uint32_t o[ILP][4];
 #pragma unroll
                         for (int k = 0; k < ILP; ++k) {
-                            const uint32_t addr = __umul24(s[k], row_bytes) + o[k][b];
-                            s[k] = *reinterpret_cast<const E *>(tile + addr);
-                            m[k] = s[k] > m[k] ? s[k] : m[k];
+                            const uint4 &cur = buf[k][r];
+                            const uint32_t d = w == 0 ? cur.x : w == 1 ? cur.y : w == 2 ? cur.z : cur.w;
+                            if (MODE == 1) {
+                                const uint32_t o4 = swar_columns<E>(A, d);
+#pragma unroll
+                                for (int b = 0; b < 4; ++b) o[k][b] = __builtin_amdgcn_ubfe(o4, 8 * b, 8);
+                            } else {
+                                const uint16_t *coff = reinterpret_cast<const uint16_t *>(smem);
+#pragma unroll
+                                for (int b = 0; b < 4; ++b) o[k][b] = coff[__builtin_amdgcn_ubfe(d, 8 * b, 8)];
+                            }
+                        }
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+#pragma unroll
+                            for (int k = 0; k < ILP; ++k) {
+                                const uint32_t addr = __umul24(s[k], row_bytes) + o[k][b];
+                                s[k] = *reinterpret_cast<const E *>(tile + addr);
+                                m[k] = s[k] > m[k] ? s[k] : m[k];
+                            }
                         }
                     }
                 }
-                }
-                // ---- rare: replay the quad exactly ----
+                // ---- rare: hand the quad to the epilogue ----
 #pragma unroll
                 for (int k = 0; k < ILP; ++k) {
                     if (q < nq[k]) {
-                        if (m[k] >= f1 || bad[k] != 0)
-                            s[k] = replay_quad<E, MODE>(A, B, smem, tile, item0 + k, buf[k][r], s_in[k], int32_t(q << 4),
-                                                        warm_rel[k], pos_bias[k]);
+                        if (m[k] >= f1 || poison[k] != 0) {
+                            const uint32_t lo = head[k] + (q << 4);
+                            append_run(B, item0 + k, lo, lo + 16u);
+                            if (s[k] >= trap) { s[k] = 0; poison[k] = B.poison_quads; }  // lost the state: restart
+                            else if (poison[k]) --poison[k];
+                        }
                     } else {
                         s[k] = s_in[k];
                     }
@@ -423,17 +438,35 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchA
         scan_group(buf1, g + 1);
     }
 
-    // tail (< 16 bytes) and bookkeeping
+    // ---- dense epilogue: every lane now walks the flagged runs of its own items exactly ----
+    // (events only arise here, in ascending position order: head run, flagged quads, tail run).
+    // A run [lo, hi) is entered from the root Lmax-1 bytes earlier -- exact for every pattern
+    // ending inside the run -- and only events ending inside it (and inside the item's reporting
+    // range) are recorded.  The LDS tile is still resident, so hot steps stay on-chip.
 #pragma unroll
     for (int k = 0; k < ILP; ++k) {
         ItemDesc it;
         if (decode_item(B, item0 + k, it)) {
+            const uint64_t item = item0 + k;
             const uint8_t *p = B.blob + (it.begin - it.warm);
             const uint32_t n = it.warm + it.len;
-            const uint32_t mis = uint32_t(-reinterpret_cast<uintptr_t>(p)) & 15u;
-            const uint32_t head = mis < n ? mis : n;
-            exact_bytes<E>(A, B, tile, item0 + k, p, head + (nq[k] << 4), n, it.warm, it.pos0, s[k]);
-            finish_item(B, item0 + k, it.hay);
+            const uint32_t tail_lo = head[k] + (nq[k] << 4);
+            if (tail_lo < n) append_run(B, item, tail_lo, n);
+            const uint32_t nr = B.run_count[item];
+            if (nr > B.run_cap) {  // too many runs: the whole item, exactly
+                exact_range<E, MODE>(A, B, smem, tile, item, p, 0, n, it.warm, it.pos0 - it.warm + 1u, 0u);
+            } else {
+                const uint2 *runs = B.runs + item * B.run_cap;
+#pragma unroll 1
+                for (uint32_t r = 0; r < nr; ++r) {
+                    const uint32_t lo = runs[r].x, hi = runs[r].y;
+                    const uint32_t from = lo > B.warm_bytes ? lo - B.warm_bytes : 0u;
+                    const uint32_t st = exact_range<E, MODE>(A, B, smem, tile, item, p, from, lo, 0xFFFFFFFFu, 0u, 0u);
+                    exact_range<E, MODE>(A, B, smem, tile, item, p, lo, hi, lo > it.warm ? lo : it.warm,
+                                         it.pos0 - it.warm + 1u, st);
+                }
+            }
+            finish_item(B, item, it.hay);
         }
     }
 }
