@@ -290,6 +290,8 @@ int run_batch(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, const 
     launch_count_items(d_off, uint32_t(nh), chunk, h->d_nitems.as<uint64_t>(), st);
     exclusive_scan_u64(h->d_nitems.as<uint64_t>(), h->d_item_base.as<uint64_t>(), nh + 1, h->d_scan_tmp.as<uint64_t>(), st);
 
+    launch_build_items(B, max_items, st);
+
     if (h->profile) HIPCHK(h, hipEventRecord(h->ev[1], st));
     HIPCHK(h, launch_scan(h->dA, B, max_items, int(fa.entry_bytes), h->kernel, int(fa.class_mode), h->ilp, st));
     if (h->profile) HIPCHK(h, hipEventRecord(h->ev[2], st));

@@ -37,25 +37,36 @@ struct ItemDesc {
     uint32_t hay;
 };
 
-// Work item i -> (haystack, chunk).  item_base is non-decreasing; empty haystacks own no item.
-__device__ __forceinline__ bool decode_item(const BatchArgs &B, uint64_t i, ItemDesc &it) {
-    const uint64_t total = B.item_base[B.n_haystacks];
-    if (i >= total) return false;
+// Work item i -> haystack, by binary search.  item_base is non-decreasing; empty haystacks own
+// no item.  Done once per item by k_build_items; the scan kernels read item_hay[] instead.
+__device__ __forceinline__ uint32_t find_haystack(const BatchArgs &B, uint64_t i) {
     uint32_t lo = 0, hi = B.n_haystacks;  // item_base[lo] <= i < item_base[hi]
     while (hi - lo > 1) {
         const uint32_t mid = lo + ((hi - lo) >> 1);
         if (B.item_base[mid] <= i) lo = mid; else hi = mid;
     }
-    const uint64_t hb = B.offsets[lo], he = B.offsets[lo + 1];
-    const uint64_t k = i - B.item_base[lo];
+    return lo;
+}
+
+// Work item i -> (haystack, chunk) given its haystack index.
+__device__ __forceinline__ bool decode_item(const BatchArgs &B, uint64_t i, ItemDesc &it) {
+    if (i >= B.item_base[B.n_haystacks]) return false;
+    const uint32_t h = B.item_hay[i];
+    const uint64_t hb = B.offsets[h], he = B.offsets[h + 1];
+    const uint64_t k = i - B.item_base[h];
     const uint64_t p0 = k * B.chunk_bytes;
-    it.hay = lo;
+    it.hay = h;
     it.pos0 = uint32_t(p0);
     it.begin = hb + p0;
     const uint64_t rest = he - it.begin;
     it.len = rest < B.chunk_bytes ? uint32_t(rest) : B.chunk_bytes;
     it.warm = p0 < B.warm_bytes ? uint32_t(p0) : B.warm_bytes;
     return true;
+}
+
+__global__ void k_build_items(BatchArgs B) {
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < B.item_base[B.n_haystacks]) B.item_hay[i] = find_haystack(B, i);
 }
 
 __device__ __forceinline__ bool is_final(const DevAutomaton &A, uint32_t s) {
@@ -75,8 +86,7 @@ __device__ __forceinline__ void on_event(const DevAutomaton &A, const BatchArgs 
     B.ev_count[item] = n + 1;
 }
 
-__device__ __forceinline__ void finish_item(const BatchArgs &B, uint64_t item, uint32_t hay) {
-    B.item_hay[item] = hay;
+__device__ __forceinline__ void finish_item(const BatchArgs &B, uint64_t item) {
     if (B.ev_count[item] > B.slab_events) B.overflow_list[atomicAdd(&B.counters[0], 1u)] = uint32_t(item);
 }
 
@@ -199,7 +209,7 @@ __global__ void k_scan_simple(DevAutomaton A, BatchArgs B) {
     if (!decode_item(B, i, it)) return;
     const uint8_t *p = B.blob + (it.begin - it.warm);
     exact_bytes<E>(A, B, nullptr, i, p, 0, it.warm + it.len, it.warm, it.pos0, 0u);
-    finish_item(B, i, it.hay);
+    finish_item(B, i);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -466,7 +476,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchA
                                          it.pos0 - it.warm + 1u, st);
                 }
             }
-            finish_item(B, item, it.hay);
+            finish_item(B, item);
         }
     }
 }
@@ -534,6 +544,11 @@ __global__ void k_refill(DevAutomaton A, BatchArgs B, const uint64_t *rec_base, 
 // ------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------
+void launch_build_items(const BatchArgs &B, uint64_t max_items, hipStream_t st) {
+    if (max_items == 0) return;
+    hipLaunchKernelGGL(k_build_items, dim3(uint32_t((max_items + 255) / 256)), dim3(256), 0, st, B);
+}
+
 void launch_count_items(const uint64_t *offsets, uint32_t nh, uint32_t chunk, uint64_t *n_items, hipStream_t st) {
     hipLaunchKernelGGL(k_count_items, dim3((nh + 1 + 255) / 256), dim3(256), 0, st, offsets, nh, chunk, n_items);
 }

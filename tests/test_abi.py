@@ -1,0 +1,109 @@
+"""The C ABI: libacmi.so loads, exports every symbol include/acmi.h declares, and its host-side
+logic (lifecycle, status codes, pattern rules) behaves -- no GPU needed, no compute calls."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import ROOT
+from php_aho_corasick_amd import _native as N
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "acmi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(acmi_[a-z_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    names = _declared()
+    assert len(names) >= 20
+    raw = C.CDLL(N.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"{n} declared in include/acmi.h but not exported by libacmi.so"
+        assert n in N.SYMBOLS, f"{n} has no ctypes binding"
+    assert sorted(N.SYMBOLS) == names
+
+
+def test_header_cites_reference_lines():
+    text = open(os.path.join(ROOT, "include", "acmi.h")).read()
+    for cite in ("php_ahocorasick.c:664-746", "ahocorasick.c:91-131", "ahocorasick.c:143-155", "php_ahocorasick.c:542-589",
+                 "actypes.h:148", "php_ahocorasick.c:754-791"):
+        assert cite in text
+
+
+def _mk(patterns, **opts):
+    h = N.Handle()
+    assert N.lib.acmi_create(-1, C.byref(h)) == 0
+    for k, v in opts.items():
+        assert N.lib.acmi_set_option(h, k.encode(), v) == 0
+    arr = (N.Pattern * max(1, len(patterns)))()
+    keep = []
+    for k, p in enumerate(patterns):
+        buf = (C.c_uint8 * max(1, len(p))).from_buffer_copy(p or b"\0")
+        keep.append(buf)
+        arr[k].value = C.cast(buf, C.POINTER(C.c_uint8))
+        arr[k].length = len(p)
+        arr[k].id_type = N.ID_NUMBER
+        arr[k].id_number = 100 + k
+        arr[k].user = 7 * k
+    acc = C.c_size_t(0)
+    assert N.lib.acmi_add_patterns(h, arr, len(patterns), C.byref(acc)) == 0
+    return h, acc.value
+
+
+def test_lifecycle_and_status_codes():
+    h, acc = _mk([b"ab", b"ab", b"b", b"", b"x" * 1025, b"xab"])
+    assert acc == 3                                   # duplicate, empty and over-long dropped
+    assert N.lib.acmi_pattern_count(h) == 6           # ...but they keep their caller-order index
+    assert N.lib.acmi_is_valid(h) == 1
+    info = N.Pattern()
+    assert N.lib.acmi_pattern_info(h, 1, C.byref(info)) == 1      # accepted: the LAST duplicate wins
+    assert N.lib.acmi_pattern_info(h, 0, C.byref(info)) == 0      # the first "ab" lost
+    assert (info.length, info.id_number, info.user) == (2, 100, 0)
+    assert N.lib.acmi_pattern_info(h, 99, C.byref(info)) == N.E_ARG
+    assert N.lib.acmi_finalize(h) == 1                # first time
+    assert N.lib.acmi_finalize(h) == 0                # idempotent (php_ahocorasick.c:130-142)
+    arr = (N.Pattern * 1)()
+    assert N.lib.acmi_add_patterns(h, arr, 0, None) == N.E_FINALIZED
+    assert N.lib.acmi_set_option(h, b"lds_bytes", 4096) == N.E_FINALIZED
+    assert N.lib.acmi_set_option(h, b"no_such_option", 1) == N.E_ARG
+    v = C.c_double()
+    assert N.lib.acmi_get_stat(h, b"nodes", C.byref(v)) == 0 and v.value == 7   # 7 nodes
+    assert N.lib.acmi_get_stat(h, b"max_pattern_length", C.byref(v)) == 0 and v.value == 3
+    assert N.lib.acmi_destroy(h) == 0
+    assert N.lib.acmi_is_valid(h) == 0                # stale handle is recognised, not dereferenced
+    assert N.lib.acmi_destroy(h) == N.E_INVALID
+    assert N.lib.acmi_finalize(h) == N.E_INVALID
+    assert N.lib.acmi_destroy(None) == N.E_INVALID
+    assert N.lib.acmi_strerror(N.E_INVALID) == b"Invalid resource."
+    assert N.lib.acmi_strerror(N.E_NOT_INIT) == b"Not initialized."
+    assert N.lib.acmi_version() == b"0.1.0"
+
+
+def test_no_cpu_fallback_without_device():
+    """Without a GPU a match call must FAIL (ACMI_E_NO_DEVICE), never silently scan on the CPU."""
+    count = C.c_int(0)
+    hip = C.CDLL(None)
+    try:
+        rc = hip.hipGetDeviceCount(C.byref(count))
+    except AttributeError:
+        pytest.skip("hip runtime symbols not visible")
+    if rc == 0 and count.value > 0:
+        pytest.skip("a GPU is present")
+    h, _ = _mk([b"abc"])
+    recs = C.POINTER(N.Record)()
+    n = C.c_size_t(0)
+    buf = np.frombuffer(b"xxabcxx", dtype=np.uint8)
+    rc = N.lib.acmi_match(h, buf.ctypes.data, 7, 1, C.byref(recs), C.byref(n))
+    assert rc == N.E_NO_DEVICE
+    assert b"no CPU" in N.lib.acmi_last_error(h) or b"no HIP" in N.lib.acmi_last_error(h)
+    N.lib.acmi_destroy(h)
+
+
+def test_too_large_automaton_is_refused():
+    h, _ = _mk([bytes([i, j]) for i in range(64) for j in range(64)], max_table_bytes=4096)
+    assert N.lib.acmi_finalize(h) == N.E_TOO_LARGE
+    N.lib.acmi_destroy(h)

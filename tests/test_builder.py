@@ -1,0 +1,90 @@
+"""Host automaton builder (csrc/automaton.cpp) checked on the CPU: its flat tables are walked in
+numpy exactly as the device's exact path walks them and compared with the oracle."""
+import numpy as np
+import pytest
+
+from helpers import FlatTables
+from gpu_util import resource_for
+from oracle.pyoracle import Oracle
+from php_aho_corasick_amd import api, synth
+
+
+def _compare(ds, res, max_hay=6, calls=1):
+    ft = FlatTables(res)
+    o = Oracle("port")
+    pats = ds.patterns()
+    step = (len(pats) + calls - 1) // calls if pats else 1
+    for lo in range(0, max(len(pats), 1), step):
+        o.add_patterns(pats[lo:lo + step])
+    o.finalize()
+    assert ft.n_states == o.node_count() + 1
+    assert res.stat("accepted") == o.pattern_count()
+    plen = np.diff(ds.pat_off.astype(np.int64))
+    for h in range(min(ds.n_haystacks, max_hay)):
+        for find_all in (True, False):
+            exp = [tuple(int(x) for x in r) for r in o.match(ds.haystack(h), find_all, h)]
+            assert ft.walk(ds.haystack(h), plen, h, find_all) == exp, (ds.name, h, find_all)
+    return ft
+
+
+@pytest.mark.parametrize("name", ["G2", "G3", "G4", "G5", "R1", "R2", "R3"])
+@pytest.mark.parametrize("lds", [None, 2048])
+def test_tables_match_oracle(name, lds):
+    ds = synth.NAMED[name]()
+    opts = {"lds_bytes": lds} if lds else {}
+    res = resource_for(ds, **opts)
+    api.ahocorasick_finalize(res)
+    ft = _compare(ds, res, max_hay=3 if name in ("G2", "R3") else 6)
+    # numbering invariants the kernels rely on
+    assert 0 < ft.f1 <= ft.trap < ft.n_states and ft.trap < ft.f2 <= ft.n_states
+    assert np.all(ft.lds <= ft.trap)                      # tile never points outside itself
+    assert np.all(ft.table[ft.trap] == ft.trap)           # trap row is absorbing
+    assert np.all(ft.lds[:ft.trap][ft.table[:ft.trap] <= ft.trap] == ft.table[:ft.trap][ft.table[:ft.trap] <= ft.trap])
+    hot_final = np.arange(ft.f1, ft.trap)
+    assert np.all(ft.cnt[hot_final] > 0) and np.all(ft.cnt[:ft.f1] == 0)
+    assert np.all(ft.cnt[ft.f2:] > 0) and np.all(ft.cnt[ft.trap:ft.f2] == 0)
+    if lds:
+        assert (ft.trap + 1) * ft.n_columns * ft.entry_bytes <= lds
+    api.ahocorasick_deinit(res)
+
+
+def test_incremental_calls_and_duplicates():
+    ds = synth.r1()
+    res = resource_for(ds, calls=5)
+    api.ahocorasick_finalize(res)
+    _compare(ds, res, calls=5)
+    api.ahocorasick_deinit(res)
+
+
+def test_class_modes():
+    res = resource_for(synth.g1(8))
+    api.ahocorasick_finalize(res)
+    ft = FlatTables(res)
+    assert ft.class_mode == 1 and ft.swar_shift == 0 and ft.n_columns == 7    # abcdef -> buckets 1..6, other = 0
+    assert [int(ft.cls[b]) for b in b"abcdef"] == [1, 2, 3, 4, 5, 6] and ft.cls[ord("A")] == 0 and ft.cls[0x69] == 0
+    assert ft.n_states == 25581 and res.stat("nodes") == 25580                # 25,580 nodes
+    api.ahocorasick_deinit(res)
+    res = resource_for(synth.r2())
+    api.ahocorasick_finalize(res)
+    ft = FlatTables(res)
+    assert ft.class_mode == 0 and ft.n_columns == res.stat("used_bytes") + 1
+    api.ahocorasick_deinit(res)
+    pats = [{"value": bytes([b])} for b in range(256)]                        # all 256 bytes used: identity columns
+    res = api.ahocorasick_init(pats)
+    api.ahocorasick_finalize(res)
+    ft = FlatTables(res)
+    assert ft.n_columns == 256 and list(ft.cls) == list(range(256))
+    api.ahocorasick_deinit(res)
+    res = api.ahocorasick_init([{"value": "ACGT"}, {"value": "TTGACA"}])       # ACGT: 3-bit window exists
+    api.ahocorasick_finalize(res)
+    assert FlatTables(res).class_mode == 1
+    api.ahocorasick_deinit(res)
+
+
+def test_wide_entries_for_big_automata():
+    ds = synth.generate("W", 21, 12000, 8, 8, 1, 64, None)      # > 65535 states -> uint32 entries
+    res = resource_for(ds)
+    api.ahocorasick_finalize(res)
+    assert res.stat("states") > 65536 and res.stat("entry_bytes") == 4
+    _compare(ds, res, max_hay=1)
+    api.ahocorasick_deinit(res)
