@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--haystacks", type=int, default=1 << 19, help="haystacks per GPU (8 KiB each)")
     ap.add_argument("--ilp", type=int, default=int(os.environ.get("ACMI_ILP", "0")))
+    ap.add_argument("--group-quads", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
 
@@ -120,10 +121,17 @@ def main():
     import torch.distributed as dist
     from php_aho_corasick_amd import api, batch
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; ACMI_BENCH_BACKEND=gloo (+ ranks sharing a device) exists only to exercise the
+    # N > 1 code path on a single-GPU box -- the driver's multi-GPU runs use nccl (= RCCL over xGMI)
+    backend = os.environ.get("ACMI_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     # ---- automaton (replicated on every rank) ----
     t0 = time.perf_counter()
@@ -133,6 +141,8 @@ def main():
     res.set_option("profile", 1)
     if args.ilp:
         res.set_option("ilp", args.ilp)
+    if args.group_quads:
+        res.set_option("group_quads", args.group_quads)
 
     # ---- batch resident in HBM: the 64 MiB tile replicated to the requested size ----
     nh = max(TILE_HAYSTACKS, (args.haystacks // TILE_HAYSTACKS) * TILE_HAYSTACKS)
@@ -144,6 +154,14 @@ def main():
     batch.bind_current_stream(res)
     hay_base = rank * nh
     bytes_per_step = nh * HAY_LEN
+
+    # what a plain streaming read of the same buffer reaches on this chip (context for the roofline)
+    import ctypes as C
+    from php_aho_corasick_amd import _native as N
+    batch.match_device(res, d_blob[:TILE_HAYSTACKS * HAY_LEN], d_off[:TILE_HAYSTACKS + 1], True)  # device init
+    ms = C.c_double(0)
+    N.check(N.lib.acmi_debug_stream_read(res._h, C.c_void_p(d_blob.data_ptr()), d_blob.numel(), 3, C.byref(ms)), res._h)
+    stream_read_gbs = d_blob.numel() / (ms.value * 1e-3) / 1e9
 
     pending = []
     scan_ms = []
@@ -213,13 +231,15 @@ def main():
                        "patterns": ds.n_patterns, "haystacks_per_gpu": nh, "haystack_bytes": HAY_LEN,
                        "states": int(res.stat("states")), "hot_states": int(res.stat("hot_states")),
                        "lds_tile_bytes": int(res.stat("lds_image_bytes")), "work_item_bytes": int(res.stat("chunk_bytes")),
-                       "ilp": args.ilp or 1, "sharding": f"{world} contiguous haystack ranges" if world > 1 else "none"},
+                       "ilp": args.ilp or 1, "sharding": f"{world} contiguous haystack ranges, {backend} all-gatherv of match arrays" if world > 1 else "none"},
             "matches_per_s": round(world * records_per_step * args.steps / dt, 1),
             "records_per_step_per_gpu": records_per_step, "check_ok": bool(ok),
             "automaton_build_ms": round(build_ms, 2),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "k_scan_lds", "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes": algo_bytes},
+                         "kernel": "k_scan_lds", "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes": algo_bytes,
+                         "measured_stream_read_GBs": round(stream_read_gbs, 1),
+                         "frac_of_measured_stream_read": round(achieved / stream_read_gbs, 4)},
             "cpu_baseline": cpu1, "cpu_baseline_all_cores": cpu_all,
         }
         print(json.dumps(out), flush=True)

@@ -170,6 +170,7 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *   "chunk_bytes"    force the work-item size (0 = automatic)            [any time]
  *   "kernel"         0 = plain global-table kernel, 1 = LDS-tile kernel  [any time]
  *   "ilp"            streams per lane in the LDS-tile kernel (1 or 2)    [any time]
+ *   "group_quads"    16-byte loads per lane per fetch group, 4 or 8 (ILP 1) [any time]
  *   "profile"        1 = bracket the scan kernel with HIP events         [any time] */
 int acmi_set_option(acmi_handle *h, const char *key, int64_t value);
 
@@ -203,6 +204,11 @@ typedef struct acmi_tables {
     const uint32_t *out_count;    /* per state                                 */
 } acmi_tables;
 int acmi_debug_tables(const acmi_handle *h, acmi_tables *out);
+
+/* Measurement aid, not on the product path: time a plain coalesced streaming read of `bytes`
+ * of device memory (16 B per lane), `repeats` passes.  Gives the HBM read bandwidth a kernel can
+ * actually reach on this chip and a known byte count to calibrate FETCH_SIZE against. */
+int acmi_debug_stream_read(acmi_handle *h, const void *d_src, uint64_t bytes, int repeats, double *ms_per_pass);
 
 const char *acmi_strerror(int status);
 const char *acmi_last_error(const acmi_handle *h);

@@ -69,6 +69,7 @@ SYMBOLS = {
     "acmi_get_stat": (C.c_int, [Handle, C.c_char_p, C.POINTER(C.c_double)]),
     "acmi_set_stream": (C.c_int, [Handle, C.c_void_p]),
     "acmi_debug_tables": (C.c_int, [Handle, C.POINTER(Tables)]),
+    "acmi_debug_stream_read": (C.c_int, [Handle, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
     "acmi_strerror": (C.c_char_p, [C.c_int]),
     "acmi_last_error": (C.c_char_p, [Handle]),
     "acmi_version": (C.c_char_p, []),

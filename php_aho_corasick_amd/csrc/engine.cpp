@@ -64,6 +64,7 @@ struct acmi_handle {
     uint64_t chunk_opt = 0;
     int kernel = 1;
     int ilp = 1;
+    int group_quads = 8;
     int profile = 0;
 
     // device state
@@ -293,7 +294,7 @@ int run_batch(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, const 
     launch_build_items(B, max_items, st);
 
     if (h->profile) HIPCHK(h, hipEventRecord(h->ev[1], st));
-    HIPCHK(h, launch_scan(h->dA, B, max_items, int(fa.entry_bytes), h->kernel, int(fa.class_mode), h->ilp, st));
+    HIPCHK(h, launch_scan(h->dA, B, max_items, int(fa.entry_bytes), h->kernel, int(fa.class_mode), h->ilp, h->group_quads, st));
     if (h->profile) HIPCHK(h, hipEventRecord(h->ev[2], st));
     if (h->profile) HIPCHK(h, hipEventRecord(h->ev[3], st));
 
@@ -537,6 +538,9 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
     } else if (k == "ilp") {
         if (value != 1 && value != 2) return ACMI_E_ARG;
         h->ilp = int(value);
+    } else if (k == "group_quads") {
+        if (value != 4 && value != 8) return ACMI_E_ARG;
+        h->group_quads = int(value);
     } else if (k == "profile") {
         h->profile = value ? 1 : 0;
     } else if (k == "max_table_bytes") {
@@ -603,6 +607,23 @@ int acmi_debug_tables(const acmi_handle *h, acmi_tables *out) {
     out->own_pattern = fa.own_pattern.data();
     out->dict_link = fa.dict_link.data();
     out->out_count = fa.out_count.data();
+    return ACMI_OK;
+}
+
+int acmi_debug_stream_read(acmi_handle *h, const void *d_src, uint64_t bytes, int repeats, double *ms_per_pass) {
+    int rc = check_ready(h);
+    if (rc < 0) return rc;
+    if (!d_src || bytes < 16 || repeats < 1 || !ms_per_pass) return ACMI_E_ARG;
+    HIPCHK(h, h->d_counters.ensure(64));
+    hipStream_t st = h->stream;
+    launch_stream_read(d_src, bytes, h->d_counters.as<uint32_t>(), st);  // warm-up
+    HIPCHK(h, hipEventRecord(h->ev[0], st));
+    for (int i = 0; i < repeats; ++i) launch_stream_read(d_src, bytes, h->d_counters.as<uint32_t>(), st);
+    HIPCHK(h, hipEventRecord(h->ev[1], st));
+    HIPCHK(h, hipEventSynchronize(h->ev[1]));
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+    *ms_per_pass = double(ms) / repeats;
     return ACMI_OK;
 }
 

@@ -243,7 +243,6 @@ __global__ void k_scan_simple(DevAutomaton A, BatchArgs B) {
 //   reads a 256-entry column-offset table from LDS instead.
 // ------------------------------------------------------------------------------------------
 constexpr int kLdsThreads = 1024;
-constexpr int kGroupQuads = 4;  // 16-byte quads fetched per lane per group (64 B)
 
 // Append byte run [lo, hi) of `item` (scan coordinates) to its fix-up list; adjacent runs merge.
 __device__ __forceinline__ void append_run(const BatchArgs &B, uint64_t item, uint32_t lo, uint32_t hi) {
@@ -308,11 +307,10 @@ __device__ __forceinline__ uint32_t exact_range(const DevAutomaton &A, const Bat
     return s;
 }
 
-template <typename E, int MODE, int ILP>
+template <typename E, int MODE, int ILP, int G>
 __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchArgs B) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr uint32_t kTileOff = MODE == 1 ? 0u : 512u;  // TABLE mode: 256 x uint16 column offsets first
-    constexpr int G = kGroupQuads;
     const uint64_t first = uint64_t(blockIdx.x) * (kLdsThreads * ILP);
     if (first >= B.item_base[B.n_haystacks]) return;
 
@@ -542,6 +540,25 @@ __global__ void k_refill(DevAutomaton A, BatchArgs B, const uint64_t *rec_base, 
 }
 
 // ------------------------------------------------------------------------------------------
+// k_stream_read: plain coalesced 16 B/lane streaming read (xor-reduced so it cannot be elided).
+// Not on the product path: it measures what HBM read bandwidth a kernel can reach on this chip
+// and calibrates the FETCH_SIZE counter against a known byte count (MI355X_MICROARCH.md, HBM).
+// ------------------------------------------------------------------------------------------
+__global__ void k_stream_read(const uint4 *src, uint64_t n16, uint32_t *sink) {
+    uint32_t acc = 0;
+    const uint64_t stride = uint64_t(gridDim.x) * blockDim.x;
+    for (uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        const uint4 v = src[i];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x9e3779b9u) sink[0] = acc;  // practically never: keeps the loads alive
+}
+
+void launch_stream_read(const void *src, uint64_t bytes, uint32_t *sink, hipStream_t st) {
+    hipLaunchKernelGGL(k_stream_read, dim3(256 * 8), dim3(256), 0, st, static_cast<const uint4 *>(src), bytes / 16, sink);
+}
+
+// ------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------
 void launch_build_items(const BatchArgs &B, uint64_t max_items, hipStream_t st) {
@@ -553,10 +570,10 @@ void launch_count_items(const uint64_t *offsets, uint32_t nh, uint32_t chunk, ui
     hipLaunchKernelGGL(k_count_items, dim3((nh + 1 + 255) / 256), dim3(256), 0, st, offsets, nh, chunk, n_items);
 }
 
-template <typename E, int MODE, int ILP>
+template <typename E, int MODE, int ILP, int G>
 static hipError_t launch_lds_t(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, uint32_t lds_bytes,
                                hipStream_t st) {
-    auto fn = k_scan_lds<E, MODE, ILP>;
+    auto fn = k_scan_lds<E, MODE, ILP, G>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
     if (e != hipSuccess) return e;
@@ -566,8 +583,18 @@ static hipError_t launch_lds_t(const DevAutomaton &A, const BatchArgs &B, uint64
     return hipGetLastError();
 }
 
+template <typename E, int MODE>
+static hipError_t launch_lds_m(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, uint32_t lds, int ilp,
+                               int group_quads, hipStream_t st) {
+    // ILP 1 reads whole 128-byte lines per lane (8 quads, double-buffered = 64 VGPRs); ILP 2 has
+    // registers for 64-byte groups only
+    if (ilp == 2) return launch_lds_t<E, MODE, 2, 4>(A, B, max_items, lds, st);
+    if (group_quads == 4) return launch_lds_t<E, MODE, 1, 4>(A, B, max_items, lds, st);
+    return launch_lds_t<E, MODE, 1, 8>(A, B, max_items, lds, st);
+}
+
 hipError_t launch_scan(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes,
-                       int kernel, int class_mode, int ilp, hipStream_t st) {
+                       int kernel, int class_mode, int ilp, int group_quads, hipStream_t st) {
     if (max_items == 0) return hipSuccess;
     if (kernel == 0) {
         const uint32_t blocks = uint32_t((max_items + 255) / 256);
@@ -576,16 +603,11 @@ hipError_t launch_scan(const DevAutomaton &A, const BatchArgs &B, uint64_t max_i
         return hipGetLastError();
     }
     const uint32_t lds = ((A.lds_image_bytes + 15u) & ~15u) + 32u;
-    if (entry_bytes == 2) {
-        if (class_mode == 1) return ilp == 2 ? launch_lds_t<uint16_t, 1, 2>(A, B, max_items, lds, st)
-                                             : launch_lds_t<uint16_t, 1, 1>(A, B, max_items, lds, st);
-        return ilp == 2 ? launch_lds_t<uint16_t, 0, 2>(A, B, max_items, lds, st)
-                        : launch_lds_t<uint16_t, 0, 1>(A, B, max_items, lds, st);
-    }
-    if (class_mode == 1) return ilp == 2 ? launch_lds_t<uint32_t, 1, 2>(A, B, max_items, lds, st)
-                                         : launch_lds_t<uint32_t, 1, 1>(A, B, max_items, lds, st);
-    return ilp == 2 ? launch_lds_t<uint32_t, 0, 2>(A, B, max_items, lds, st)
-                    : launch_lds_t<uint32_t, 0, 1>(A, B, max_items, lds, st);
+    if (entry_bytes == 2)
+        return class_mode == 1 ? launch_lds_m<uint16_t, 1>(A, B, max_items, lds, ilp, group_quads, st)
+                               : launch_lds_m<uint16_t, 0>(A, B, max_items, lds, ilp, group_quads, st);
+    return class_mode == 1 ? launch_lds_m<uint32_t, 1>(A, B, max_items, lds, ilp, group_quads, st)
+                           : launch_lds_m<uint32_t, 0>(A, B, max_items, lds, ilp, group_quads, st);
 }
 
 void launch_first_only(const BatchArgs &B, hipStream_t st) {

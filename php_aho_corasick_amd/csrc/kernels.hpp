@@ -16,7 +16,7 @@ void exclusive_scan_u64(const uint64_t *in, uint64_t *out, uint64_t n, uint64_t 
 void launch_build_items(const BatchArgs &B, uint64_t max_items, hipStream_t st);
 void launch_count_items(const uint64_t *offsets, uint32_t nh, uint32_t chunk, uint64_t *n_items, hipStream_t st);
 hipError_t launch_scan(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int kernel,
-                       int class_mode, int ilp, hipStream_t st);
+                       int class_mode, int ilp, int group_quads, hipStream_t st);
 void launch_first_only(const BatchArgs &B, hipStream_t st);
 void launch_hay_prefix(const uint64_t *item_base, const uint64_t *rec_base, uint32_t nh, uint64_t *prefix,
                        hipStream_t st);
@@ -24,5 +24,7 @@ void launch_expand(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items
                    hipStream_t st);
 void launch_refill(const DevAutomaton &A, const BatchArgs &B, int entry_bytes, const uint64_t *rec_base, void *out,
                    uint32_t n_overflow, hipStream_t st);
+
+void launch_stream_read(const void *src, uint64_t bytes, uint32_t *sink, hipStream_t st);
 
 }  // namespace acmi
