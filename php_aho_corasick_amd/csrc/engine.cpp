@@ -77,8 +77,8 @@ struct acmi_handle {
     DevBuf d_table, d_lds, d_class, d_own, d_dict, d_cnt, d_plen;
 
     // workspace (grow-only)
-    DevBuf d_blob, d_off, d_nitems, d_item_base, d_item_hay, d_ev, d_rec_cnt, d_rec_base, d_slab, d_ovf, d_counters,
-        d_scan_tmp, d_prefix, d_out, d_run_cnt, d_runs;
+    DevBuf d_blob, d_off, d_nitems, d_item_base, d_item_hay, d_zero, d_rec_base, d_slab, d_ovf, d_counters,
+        d_scan_tmp, d_prefix, d_out, d_runs;
     uint64_t *pinned = nullptr;  // [0] total records, [1] overflow items
 
     // last result
@@ -252,21 +252,21 @@ int run_batch(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, const 
     HIPCHK(h, h->d_nitems.ensure((nh + 1) * 8));
     HIPCHK(h, h->d_item_base.ensure((nh + 1) * 8));
     HIPCHK(h, h->d_item_hay.ensure(max_items * 4));
-    HIPCHK(h, h->d_ev.ensure(max_items * 4));
-    HIPCHK(h, h->d_rec_cnt.ensure((max_items + 1) * 8));
-    HIPCHK(h, h->d_rec_base.ensure((max_items + 1) * 8));
+    // one zero-filled block per call: [counters 64 B | rec_count (items+1) x 8 | ev_count items x 4]
+    const size_t rec_cnt_off = 64, ev_off = rec_cnt_off + (max_items + 1) * 8;
+    const size_t zero_bytes = ev_off + max_items * 4;
+    HIPCHK(h, h->d_zero.ensure(zero_bytes));
+    HIPCHK(h, h->d_rec_base.ensure((max_items + 2) * 8));
     HIPCHK(h, h->d_slab.ensure(max_items * K * 8));
     HIPCHK(h, h->d_ovf.ensure(max_items * 4));
-    HIPCHK(h, h->d_counters.ensure(64));
     const uint32_t Q = std::max<uint32_t>(1, h->run_cap);
-    HIPCHK(h, h->d_run_cnt.ensure(max_items * 4));
-    HIPCHK(h, h->d_runs.ensure(max_items * Q * 8));
+    HIPCHK(h, h->d_runs.ensure(max_items * Q * 16));
     HIPCHK(h, h->d_scan_tmp.ensure(scan_temp_elems(std::max<uint64_t>(max_items + 1, nh + 1)) * 8 * 2));
-
-    HIPCHK(h, hipMemsetAsync(h->d_ev.p, 0, max_items * 4, st));
-    HIPCHK(h, hipMemsetAsync(h->d_rec_cnt.p, 0, (max_items + 1) * 8, st));
-    HIPCHK(h, hipMemsetAsync(h->d_counters.p, 0, 64, st));
-    if (h->kernel == 1) HIPCHK(h, hipMemsetAsync(h->d_run_cnt.p, 0, max_items * 4, st));
+    HIPCHK(h, hipMemsetAsync(h->d_zero.p, 0, zero_bytes, st));
+    uint8_t *zero = h->d_zero.as<uint8_t>();
+    uint32_t *d_counters = reinterpret_cast<uint32_t *>(zero);
+    uint64_t *d_rec_cnt = reinterpret_cast<uint64_t *>(zero + rec_cnt_off);
+    uint32_t *d_ev = reinterpret_cast<uint32_t *>(zero + ev_off);
 
     BatchArgs B{};
     B.blob = d_blob;
@@ -278,13 +278,13 @@ int run_batch(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, const 
     B.slab_events = K;
     B.first_only = find_all ? 0u : 1u;
     B.item_hay = h->d_item_hay.as<uint32_t>();
-    B.ev_count = h->d_ev.as<uint32_t>();
-    B.rec_count = h->d_rec_cnt.as<uint64_t>();
+    B.ev_count = d_ev;
+    B.rec_count = d_rec_cnt;
     B.slab = h->d_slab.as<uint2>();
     B.overflow_list = h->d_ovf.as<uint32_t>();
-    B.counters = h->d_counters.as<uint32_t>();
-    B.run_count = h->d_run_cnt.as<uint32_t>();
-    B.runs = h->d_runs.as<uint2>();
+    B.counters = d_counters;
+    B.run_count = nullptr;
+    B.runs = h->d_runs.as<uint4>();
     B.run_cap = Q;
     B.poison_quads = std::max<uint32_t>(1, (fa.max_pattern_length + 15) / 16);
 
@@ -299,26 +299,31 @@ int run_batch(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, const 
     if (h->profile) HIPCHK(h, hipEventRecord(h->ev[3], st));
 
     if (!find_all) launch_first_only(B, st);
-    exclusive_scan_u64(h->d_rec_cnt.as<uint64_t>(), h->d_rec_base.as<uint64_t>(), max_items + 1,
-                       h->d_scan_tmp.as<uint64_t>(), st);
+    exclusive_scan_u64(d_rec_cnt, h->d_rec_base.as<uint64_t>(), max_items + 1, h->d_scan_tmp.as<uint64_t>(), st);
+    // summary for the host, next to the overflow counter: counters[2..3] = total records, [4..5] = items
     launch_hay_prefix(h->d_item_base.as<uint64_t>(), h->d_rec_base.as<uint64_t>(), uint32_t(nh),
-                      h->d_prefix.as<uint64_t>(), st);
+                      h->d_prefix.as<uint64_t>(), reinterpret_cast<uint64_t *>(d_counters + 2), st);
 
-    // the one mid-pipeline host sync: how many records / overflowed items are there?
-    h->pinned[0] = h->pinned[1] = h->pinned[2] = 0;
-    HIPCHK(h, hipMemcpyAsync(&h->pinned[0], h->d_rec_base.as<uint64_t>() + max_items, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(h, hipMemcpyAsync(&h->pinned[1], h->d_counters.p, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(h, hipMemcpyAsync(&h->pinned[2], h->d_item_base.as<uint64_t>() + nh, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(h, hipStreamSynchronize(st));
-    const uint64_t total = h->pinned[0];
-    const uint32_t n_ovf = find_all ? uint32_t(h->pinned[1] & 0xFFFFFFFFu) : 0u;
-    h->items = h->pinned[2];
-    h->overflow_items = n_ovf;
-
-    HIPCHK(h, h->d_out.ensure(std::max<uint64_t>(16, total * 16)));
-    if (total) {
-        launch_expand(h->dA, B, max_items, h->d_rec_base.as<uint64_t>(), h->d_out.p, st);
-        launch_refill(h->dA, B, int(fa.entry_bytes), h->d_rec_base.as<uint64_t>(), h->d_out.p, n_ovf, st);
+    // Expansion is enqueued optimistically with the output capacity of the previous call, so the
+    // whole pipeline needs ONE host synchronisation (the read-back of the summary at the end).  Only
+    // when the batch produced more records than fit is the buffer grown and the expansion re-run.
+    HIPCHK(h, h->d_out.ensure(16));
+    uint64_t total = 0;
+    uint32_t n_ovf = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const uint64_t cap = h->d_out.cap / 16;
+        launch_expand(h->dA, B, max_items, h->d_rec_base.as<uint64_t>(), h->d_out.p, cap, st);
+        if (find_all) launch_refill(h->dA, B, max_items, int(fa.entry_bytes), h->d_rec_base.as<uint64_t>(), h->d_out.p, cap, st);
+        if (attempt == 0) {
+            HIPCHK(h, hipMemcpyAsync(h->pinned, d_counters, 24, hipMemcpyDeviceToHost, st));
+            HIPCHK(h, hipStreamSynchronize(st));
+            n_ovf = find_all ? reinterpret_cast<uint32_t *>(h->pinned)[0] : 0u;
+            total = h->pinned[1];
+            h->items = h->pinned[2];
+            h->overflow_items = n_ovf;
+            if (total <= cap) break;
+            HIPCHK(h, h->d_out.ensure(total * 16));
+        }
     }
     HIPCHK(h, hipGetLastError());
     if (h->profile) {
@@ -403,8 +408,8 @@ int acmi_destroy(acmi_handle *h) {
         (void)hipSetDevice(h->dev_id);
         if (h->stream) (void)hipStreamSynchronize(h->stream);
         for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_blob,
-                          &h->d_off, &h->d_nitems, &h->d_item_base, &h->d_item_hay, &h->d_ev, &h->d_rec_cnt,
-                          &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_scan_tmp, &h->d_prefix, &h->d_out, &h->d_run_cnt, &h->d_runs})
+                          &h->d_off, &h->d_nitems, &h->d_item_base, &h->d_item_hay, &h->d_zero,
+                          &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_scan_tmp, &h->d_prefix, &h->d_out, &h->d_runs})
             b->release();
         for (auto &evt : h->ev)
             if (evt) (void)hipEventDestroy(evt);

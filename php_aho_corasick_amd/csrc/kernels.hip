@@ -19,6 +19,8 @@
 // by LDS bank throughput of the table lookups.  Wave64, 1024-thread workgroups, one per CU.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "device_types.hpp"
 #include "kernels.hpp"
 #include "scan_asm.inc"
@@ -245,13 +247,21 @@ __global__ void k_scan_simple(DevAutomaton A, BatchArgs B) {
 constexpr int kLdsThreads = 1024;
 
 // Append byte run [lo, hi) of `item` (scan coordinates) to its fix-up list; adjacent runs merge.
-__device__ __forceinline__ void append_run(const BatchArgs &B, uint64_t item, uint32_t lo, uint32_t hi) {
-    const uint32_t n = B.run_count[item];
-    if (n > B.run_cap) return;  // already "whole item"
-    uint2 *runs = B.runs + item * B.run_cap;
-    if (n > 0 && runs[n - 1].y == lo) { runs[n - 1].y = hi; return; }
-    if (n < B.run_cap) runs[n] = make_uint2(lo, hi);
-    B.run_count[item] = n + 1;
+// `entry` is the exact automaton state at `lo` when the stream knew it (else ~0: the epilogue
+// re-derives it by walking the Lmax-1 bytes before `lo` from the root).  The list length and the
+// end of the last run live in registers (`n`, `last_hi`): an append is a fire-and-forget store,
+// never a load, so it does not stall the wave in the main loop.  n > run_cap == "whole item".
+__device__ __forceinline__ void append_run(const BatchArgs &B, uint64_t item, uint32_t lo, uint32_t hi,
+                                           uint32_t entry, uint32_t &n, uint32_t &last_hi) {
+    if (n > B.run_cap) return;
+    uint4 *runs = B.runs + item * B.run_cap;
+    if (n > 0 && last_hi == lo) {
+        runs[n - 1].y = hi;
+    } else {
+        if (n < B.run_cap) runs[n] = make_uint4(lo, hi, entry, 0u);
+        ++n;
+    }
+    last_hi = hi;
 }
 
 // 4 haystack bytes -> 4 column offsets (one per byte lane of the result), SWAR3 mode.
@@ -282,13 +292,20 @@ __device__ __forceinline__ uint32_t class_offset(const DevAutomaton &A, const ui
     return reinterpret_cast<const uint16_t *>(smem)[byte];
 }
 
+// Event counters of the item being walked by the epilogue, kept in registers and stored once.
+struct EventRegs {
+    uint64_t n_rec;
+    uint32_t n_ev;
+};
+
 // Exact walk of bytes [j0, j1) of one item with the LDS tile resident: hot rows from LDS, cold
 // rows from the global table, haystack bytes by aligned dword loads.  Reports (records an event)
 // for final states at byte index j >= rep_from, at position pos_bias + j.  Returns the state.
 template <typename E, int MODE>
 __device__ __forceinline__ uint32_t exact_range(const DevAutomaton &A, const BatchArgs &B, const uint8_t *smem,
                                                 const uint8_t *tile, uint64_t item, const uint8_t *p, uint32_t j0,
-                                                uint32_t j1, uint32_t rep_from, uint32_t pos_bias, uint32_t s) {
+                                                uint32_t j1, uint32_t rep_from, uint32_t pos_bias, uint32_t s,
+                                                EventRegs &ev) {
     const uintptr_t base = reinterpret_cast<uintptr_t>(p);
     uint32_t word = 0;
 #pragma unroll 1
@@ -302,7 +319,11 @@ __device__ __forceinline__ uint32_t exact_range(const DevAutomaton &A, const Bat
         if (w >= A.trap)
             w = *reinterpret_cast<const E *>(static_cast<const uint8_t *>(A.table) + uint64_t(s) * A.row_bytes + coff);
         s = w;
-        if (j >= rep_from && is_final(A, s)) on_event(A, B, item, pos_bias + j, s);
+        if (j >= rep_from && is_final(A, s) && !(B.first_only && ev.n_ev)) {
+            ev.n_rec += A.out_count[s];
+            if (ev.n_ev < B.slab_events) B.slab[item * B.slab_events + ev.n_ev] = make_uint2(pos_bias + j, s);
+            ++ev.n_ev;
+        }
     }
     return s;
 }
@@ -331,13 +352,13 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchA
     const uint64_t item0 = first + uint64_t(threadIdx.x) * ILP;
 
     // per-stream state kept across the main loop: 7 VGPRs + the line buffers
-    uint32_t s[ILP], nq[ILP], last[ILP], head[ILP], poison[ILP];
+    uint32_t s[ILP], nq[ILP], last[ILP], head[ILP], poison[ILP], nrun[ILP], run_hi[ILP];
     const uint4 *qp[ILP];
     uint32_t nq_max = 0;
 #pragma unroll
     for (int k = 0; k < ILP; ++k) {
         ItemDesc it;
-        s[k] = 0; nq[k] = 0; last[k] = 0; head[k] = 0; poison[k] = 0;
+        s[k] = 0; nq[k] = 0; last[k] = 0; head[k] = 0; poison[k] = 0; nrun[k] = 0; run_hi[k] = 0;
         qp[k] = static_cast<const uint4 *>(A.lds_image);  // any readable 16-byte aligned address
         if (decode_item(B, item0 + k, it)) {
             const uint8_t *p = B.blob + (it.begin - it.warm);
@@ -347,7 +368,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchA
             if (head[k]) {  // unaligned head: exact state walk here, events left to the epilogue
 #pragma unroll 1
                 for (uint32_t j = 0; j < head[k]; ++j) s[k] = exact_step<E>(A, tile, s[k], p[j]);
-                append_run(B, item0 + k, 0, head[k]);
+                append_run(B, item0 + k, 0, head[k], 0u, nrun[k], run_hi[k]);  // the scan range starts at the root
                 if (s[k] >= trap) { s[k] = 0; poison[k] = B.poison_quads; }
             }
             nq[k] = (n - head[k]) >> 4;
@@ -426,7 +447,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchA
                     if (q < nq[k]) {
                         if (m[k] >= f1 || poison[k] != 0) {
                             const uint32_t lo = head[k] + (q << 4);
-                            append_run(B, item0 + k, lo, lo + 16u);
+                            append_run(B, item0 + k, lo, lo + 16u, poison[k] ? 0xFFFFFFFFu : s_in[k], nrun[k], run_hi[k]);
                             if (s[k] >= trap) { s[k] = 0; poison[k] = B.poison_quads; }  // lost the state: restart
                             else if (poison[k]) --poison[k];
                         }
@@ -459,20 +480,30 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchA
             const uint8_t *p = B.blob + (it.begin - it.warm);
             const uint32_t n = it.warm + it.len;
             const uint32_t tail_lo = head[k] + (nq[k] << 4);
-            if (tail_lo < n) append_run(B, item, tail_lo, n);
-            const uint32_t nr = B.run_count[item];
+            if (tail_lo < n) append_run(B, item, tail_lo, n, poison[k] ? 0xFFFFFFFFu : s[k], nrun[k], run_hi[k]);
+            const uint32_t nr = nrun[k];
+            const uint32_t pos_bias = it.pos0 - it.warm + 1u;
+            EventRegs ev{0, 0};
             if (nr > B.run_cap) {  // too many runs: the whole item, exactly
-                exact_range<E, MODE>(A, B, smem, tile, item, p, 0, n, it.warm, it.pos0 - it.warm + 1u, 0u);
+                exact_range<E, MODE>(A, B, smem, tile, item, p, 0, n, it.warm, pos_bias, 0u, ev);
             } else {
-                const uint2 *runs = B.runs + item * B.run_cap;
+                const uint4 *runs = B.runs + item * B.run_cap;
 #pragma unroll 1
                 for (uint32_t r = 0; r < nr; ++r) {
-                    const uint32_t lo = runs[r].x, hi = runs[r].y;
-                    const uint32_t from = lo > B.warm_bytes ? lo - B.warm_bytes : 0u;
-                    const uint32_t st = exact_range<E, MODE>(A, B, smem, tile, item, p, from, lo, 0xFFFFFFFFu, 0u, 0u);
-                    exact_range<E, MODE>(A, B, smem, tile, item, p, lo, hi, lo > it.warm ? lo : it.warm,
-                                         it.pos0 - it.warm + 1u, st);
+                    const uint4 run = runs[r];
+                    const uint32_t lo = run.x, hi = run.y;
+                    uint32_t st = run.z;
+                    if (st == 0xFFFFFFFFu) {  // entry state unknown: Lmax-1 bytes of silent warm-up from the root
+                        EventRegs none{0, 0};
+                        const uint32_t from = lo > B.warm_bytes ? lo - B.warm_bytes : 0u;
+                        st = exact_range<E, MODE>(A, B, smem, tile, item, p, from, lo, 0xFFFFFFFFu, 0u, 0u, none);
+                    }
+                    exact_range<E, MODE>(A, B, smem, tile, item, p, lo, hi, lo > it.warm ? lo : it.warm, pos_bias, st, ev);
                 }
+            }
+            if (ev.n_ev) {
+                B.ev_count[item] = ev.n_ev;
+                B.rec_count[item] = ev.n_rec;
             }
             finish_item(B, item);
         }
@@ -492,9 +523,15 @@ __global__ void k_first_only(BatchArgs B) {
     }
 }
 
-__global__ void k_hay_prefix(const uint64_t *item_base, const uint64_t *rec_base, uint32_t nh, uint64_t *prefix) {
+// Per-haystack prefix of the record array; thread nh also publishes the batch summary
+// {total records, total work items} next to the overflow counter for the host's single read-back.
+__global__ void k_hay_prefix(const uint64_t *item_base, const uint64_t *rec_base, uint32_t nh, uint64_t *prefix,
+                             uint64_t *summary) {
     const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h <= nh) prefix[h] = rec_base[item_base[h]];
+    if (h > nh) return;
+    const uint64_t v = rec_base[item_base[h]];
+    prefix[h] = v;
+    if (h == nh) { summary[0] = v; summary[1] = item_base[nh]; }
 }
 
 // Expand one event into records, longest pattern first (node.c:424-441 order).
@@ -509,33 +546,38 @@ __device__ __forceinline__ uint64_t emit_event(const DevAutomaton &A, uint4 *out
     return w;
 }
 
-__global__ void k_expand(DevAutomaton A, BatchArgs B, const uint64_t *rec_base, uint4 *out) {
+// `cap` = records the output buffer can hold: the host launches this optimistically with the
+// capacity of the previous call and re-runs it after growing the buffer if the batch did not fit.
+__global__ void k_expand(DevAutomaton A, BatchArgs B, const uint64_t *rec_base, uint4 *out, uint64_t cap) {
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= B.item_base[B.n_haystacks]) return;
     const uint32_t n = B.ev_count[i];
     if (n == 0 || n > B.slab_events) return;  // overflowed items are k_refill's
+    if (rec_base[i + 1] > cap) return;
     const uint32_t hay = B.item_hay[i];
     uint64_t w = rec_base[i];
     const uint2 *ev = B.slab + i * B.slab_events;
     for (uint32_t e = 0; e < n; ++e) w = emit_event(A, out, w, hay, ev[e].x, ev[e].y);
 }
 
-// Overflowed items: scan again, writing records straight into their final slots.
+// Overflowed items: scan again, writing records straight into their final slots.  Grid-stride over
+// the overflow list, whose length the host does not need to know at launch time.
 template <typename E>
-__global__ void k_refill(DevAutomaton A, BatchArgs B, const uint64_t *rec_base, uint4 *out, uint32_t n_overflow) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_overflow) return;
-    const uint64_t i = B.overflow_list[t];
-    ItemDesc it;
-    if (!decode_item(B, i, it)) return;
-    uint64_t w = rec_base[i];
-    const uint8_t *p = B.blob + (it.begin - it.warm);
-    const uint32_t n = it.warm + it.len;
-    uint32_t s = 0;
+__global__ void k_refill(DevAutomaton A, BatchArgs B, const uint64_t *rec_base, uint4 *out, uint64_t cap) {
+    const uint32_t n_overflow = B.counters[0];
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_overflow; t += gridDim.x * blockDim.x) {
+        const uint64_t i = B.overflow_list[t];
+        ItemDesc it;
+        if (!decode_item(B, i, it) || rec_base[i + 1] > cap) continue;
+        uint64_t w = rec_base[i];
+        const uint8_t *p = B.blob + (it.begin - it.warm);
+        const uint32_t n = it.warm + it.len;
+        uint32_t s = 0;
 #pragma unroll 1
-    for (uint32_t j = 0; j < n; ++j) {
-        s = exact_step<E>(A, nullptr, s, p[j]);
-        if (j >= it.warm && is_final(A, s)) w = emit_event(A, out, w, it.hay, it.pos0 + (j - it.warm) + 1, s);
+        for (uint32_t j = 0; j < n; ++j) {
+            s = exact_step<E>(A, nullptr, s, p[j]);
+            if (j >= it.warm && is_final(A, s)) w = emit_event(A, out, w, it.hay, it.pos0 + (j - it.warm) + 1, s);
+        }
     }
 }
 
@@ -616,25 +658,26 @@ void launch_first_only(const BatchArgs &B, hipStream_t st) {
 }
 
 void launch_hay_prefix(const uint64_t *item_base, const uint64_t *rec_base, uint32_t nh, uint64_t *prefix,
-                       hipStream_t st) {
-    hipLaunchKernelGGL(k_hay_prefix, dim3((nh + 1 + 255) / 256), dim3(256), 0, st, item_base, rec_base, nh, prefix);
+                       uint64_t *summary, hipStream_t st) {
+    hipLaunchKernelGGL(k_hay_prefix, dim3((nh + 1 + 255) / 256), dim3(256), 0, st, item_base, rec_base, nh, prefix,
+                       summary);
 }
 
-void launch_expand(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, const uint64_t *rec_base,
-                   void *out, hipStream_t st) {
+void launch_expand(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, const uint64_t *rec_base, void *out,
+                   uint64_t cap, hipStream_t st) {
     if (max_items == 0) return;
     hipLaunchKernelGGL(k_expand, dim3(uint32_t((max_items + 255) / 256)), dim3(256), 0, st, A, B, rec_base,
-                       static_cast<uint4 *>(out));
+                       static_cast<uint4 *>(out), cap);
 }
 
-void launch_refill(const DevAutomaton &A, const BatchArgs &B, int entry_bytes, const uint64_t *rec_base, void *out,
-                   uint32_t n_overflow, hipStream_t st) {
-    if (n_overflow == 0) return;
-    const uint32_t blocks = (n_overflow + 63) / 64;
+void launch_refill(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes,
+                   const uint64_t *rec_base, void *out, uint64_t cap, hipStream_t st) {
+    if (max_items == 0) return;
+    const uint32_t blocks = uint32_t(std::min<uint64_t>((max_items + 63) / 64, 4096));
     if (entry_bytes == 2)
-        hipLaunchKernelGGL(k_refill<uint16_t>, dim3(blocks), dim3(64), 0, st, A, B, rec_base, static_cast<uint4 *>(out), n_overflow);
+        hipLaunchKernelGGL(k_refill<uint16_t>, dim3(blocks), dim3(64), 0, st, A, B, rec_base, static_cast<uint4 *>(out), cap);
     else
-        hipLaunchKernelGGL(k_refill<uint32_t>, dim3(blocks), dim3(64), 0, st, A, B, rec_base, static_cast<uint4 *>(out), n_overflow);
+        hipLaunchKernelGGL(k_refill<uint32_t>, dim3(blocks), dim3(64), 0, st, A, B, rec_base, static_cast<uint4 *>(out), cap);
 }
 
 }  // namespace acmi

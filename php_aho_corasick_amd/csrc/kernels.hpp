@@ -19,12 +19,11 @@ hipError_t launch_scan(const DevAutomaton &A, const BatchArgs &B, uint64_t max_i
                        int class_mode, int ilp, int group_quads, hipStream_t st);
 void launch_first_only(const BatchArgs &B, hipStream_t st);
 void launch_hay_prefix(const uint64_t *item_base, const uint64_t *rec_base, uint32_t nh, uint64_t *prefix,
-                       hipStream_t st);
+                       uint64_t *summary, hipStream_t st);
 void launch_expand(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, const uint64_t *rec_base, void *out,
-                   hipStream_t st);
-void launch_refill(const DevAutomaton &A, const BatchArgs &B, int entry_bytes, const uint64_t *rec_base, void *out,
-                   uint32_t n_overflow, hipStream_t st);
-
+                   uint64_t cap, hipStream_t st);
+void launch_refill(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes,
+                   const uint64_t *rec_base, void *out, uint64_t cap, hipStream_t st);
 void launch_stream_read(const void *src, uint64_t bytes, uint32_t *sink, hipStream_t st);
 
 }  // namespace acmi
