@@ -128,8 +128,13 @@ def main():
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
-        if backend == "nccl":
+    gather = world > 1 or os.environ.get("ACMI_BENCH_FORCE_GATHER") == "1"  # analysis: gather path at N=1
+    if gather:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group(backend, rank=0, world_size=1, **({"device_id": dev} if backend == "nccl" else {}))
+        elif backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
@@ -170,22 +175,25 @@ def main():
 
     def step():
         nonlocal records_per_step
-        total = batch.match_device(res, d_blob, d_off, True)
+        # enqueue the scan, then do the previous batches' gather bookkeeping while the GPU scans
+        batch.match_device_begin(res, d_blob, d_off, True)
+        while len(pending) > 1:
+            gatherer.finish(pending.pop(0))
+        total = batch.match_device_end(res)
         records_per_step = total
         scan_ms.append(res.stat("scan_ms"))
-        if world > 1:
-            # all-gatherv of the match arrays, asynchronous: sizes, then padded payloads
-            prefix, rec = batch.result_tensors(res, nh, total, dev)
-            pending.append(batch.allgatherv_start(prefix[1:] - prefix[:-1], rec, hay_base))
-            while len(pending) > 1:
-                batch.allgatherv_finish(pending.pop(0))
+        if gather:
+            # all-gatherv of the match arrays: one asynchronous fixed-capacity collective per step,
+            # in flight on RCCL's stream while the next step scans
+            pending.append(gatherer.start(batch.result_view(res, total), nh, hay_base))
 
+    gatherer = batch.RecordGatherer(None, dev, capacity=1 << 20) if gather else None
     for _ in range(args.warmup):
         step()
     while pending:
-        batch.allgatherv_finish(pending.pop(0))
+        gatherer.finish(pending.pop(0))
     scan_ms.clear()
-    if world > 1:
+    if gather:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -193,13 +201,13 @@ def main():
         step()
     gathered = None
     while pending:
-        gathered = batch.allgatherv_finish(pending.pop(0))
+        gathered = gatherer.finish(pending.pop(0))
     torch.cuda.synchronize()
-    if world > 1:
+    if gather:
         dist.barrier()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if gather:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
@@ -245,7 +253,7 @@ def main():
         }
         print(json.dumps(out), flush=True)
     api.ahocorasick_deinit(res)
-    if world > 1:
+    if gather:
         dist.destroy_process_group()
 
 

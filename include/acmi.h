@@ -140,6 +140,14 @@ int acmi_match_batch_device(acmi_handle *h, const void *d_blob, uint64_t blob_by
                             const void *d_offsets, size_t n_haystacks, int find_all,
                             uint64_t *n_records);
 
+/* The same call split in two, for callers that overlap host work (or a collective) with the
+ * scan: _begin enqueues the whole pipeline on the handle's stream and returns at once; _end waits
+ * for it (the pipeline's only host synchronisation) and reports the record count.  Exactly one
+ * _end per _begin; the input buffers must stay untouched in between. */
+int acmi_match_batch_device_begin(acmi_handle *h, const void *d_blob, uint64_t blob_bytes,
+                                  const void *d_offsets, size_t n_haystacks, int find_all);
+int acmi_match_batch_device_end(acmi_handle *h, uint64_t *n_records);
+
 /* Device pointers of the last result: prefix = uint64[n_haystacks+1],
  * records = acmi_record[n_records].  Valid until the next match call. */
 int acmi_result_device(acmi_handle *h, const void **d_prefix, const void **d_records,

@@ -59,6 +59,8 @@ SYMBOLS = {
                                    C.POINTER(C.c_size_t)]),
     "acmi_match_batch_device": (C.c_int, [Handle, C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t, C.c_int,
                                           C.POINTER(C.c_uint64)]),
+    "acmi_match_batch_device_begin": (C.c_int, [Handle, C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t, C.c_int]),
+    "acmi_match_batch_device_end": (C.c_int, [Handle, C.POINTER(C.c_uint64)]),
     "acmi_result_device": (C.c_int, [Handle, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                      C.POINTER(C.c_uint64)]),
     "acmi_result_to_host": (C.c_int, [Handle, C.c_void_p, C.c_void_p]),

@@ -45,6 +45,21 @@ def match_device(res: AhoResource, d_blob, d_off, find_all: bool = True) -> int:
     return int(total.value)
 
 
+def match_device_begin(res: AhoResource, d_blob, d_off, find_all: bool = True) -> None:
+    """Enqueue the scan of a resident batch and return immediately (see ``match_device_end``)."""
+    assert d_blob.is_cuda and d_off.is_cuda and d_blob.is_contiguous() and d_off.is_contiguous()
+    N.check(N.lib.acmi_match_batch_device_begin(res._h, C.c_void_p(d_blob.data_ptr()), d_blob.numel(),
+                                                C.c_void_p(d_off.data_ptr()), d_off.numel() - 1,
+                                                1 if find_all else 0), res._h)
+
+
+def match_device_end(res: AhoResource) -> int:
+    """Wait for the batch enqueued by ``match_device_begin``; returns its record count."""
+    total = C.c_uint64(0)
+    N.check(N.lib.acmi_match_batch_device_end(res._h, C.byref(total)), res._h)
+    return int(total.value)
+
+
 def result_tensors(res: AhoResource, n_haystacks: int, total: int, device=None):
     """Copy the last result into torch-owned CUDA tensors: (prefix int64[nh+1], records int32[n,4])."""
     import torch
@@ -61,6 +76,129 @@ def result_numpy(res: AhoResource, n_haystacks: int, total: int):
     records = np.zeros((max(total, 1), 4), dtype=np.uint32)
     N.check(N.lib.acmi_result_to_host(res._h, prefix.ctypes.data, records.ctypes.data), res._h)
     return prefix, records[:total]
+
+
+class _DevView:
+    """Zero-copy handle on library-owned device memory for ``torch.as_tensor``."""
+
+    def __init__(self, ptr: int, shape, typestr: str):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def result_view(res: AhoResource, total: int):
+    """The last result's record array as an int32 [total, 4] CUDA tensor WITHOUT a copy.  It aliases
+    the handle's buffer: valid until the next match call on ``res``."""
+    import torch
+    d_prefix, d_rec, n = C.c_void_p(), C.c_void_p(), C.c_uint64(0)
+    N.check(N.lib.acmi_result_device(res._h, C.byref(d_prefix), C.byref(d_rec), C.byref(n)), res._h)
+    if total == 0:
+        return torch.zeros((0, 4), dtype=torch.int32, device="cuda")
+    return torch.as_tensor(_DevView(d_rec.value, (total, 4), "<i4"), device="cuda")
+
+
+class RecordGatherer:
+    """All-gatherv of match arrays with ONE collective per batch and no blocking size exchange.
+
+    RCCL has no v-variant of all-gather.  Every rank sends a fixed-capacity buffer
+    ``[n_records, n_haystacks | records ...]``; the capacity is agreed implicitly (all ranks start
+    equal and grow it identically, from the headers everybody receives) and only a batch that
+    exceeds it costs a second, larger collective.  Per-haystack counts are not shipped: records
+    carry global haystack ids in ascending order, so the prefix array is a local ``bincount``.
+
+    ``start`` only enqueues (payload copy on the current stream, then the collective on the
+    backend's stream), so the caller can scan its next batch while this one travels over xGMI;
+    ``finish`` waits, reads the headers and returns ``(prefix int64[n_global+1], records int32[n,4])``.
+    Buffers are double-buffered by parity: at most two batches in flight.
+    """
+
+    def __init__(self, group=None, device=None, capacity: int = 1 << 16):
+        import torch.distributed as dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.device = device
+        self.cap = int(capacity)
+        self._bufs = {}
+        self._parity = 0
+
+    def _buffers(self, parity: int, cap: int):
+        import torch
+        key = (parity, cap)
+        if key not in self._bufs:
+            for k in [k for k in self._bufs if k[0] == parity]:
+                del self._bufs[k]
+            n = 2 + 2 * cap  # int64 words: header + 16 B per record
+            self._bufs[key] = (torch.zeros(n, dtype=torch.int64, device=self.device),
+                               torch.zeros(self.world * n, dtype=torch.int64, device=self.device))
+        return self._bufs[key]
+
+    def _launch(self, send, recv, async_op):
+        import torch.distributed as dist
+        return dist.all_gather(list(recv.view(self.world, -1).unbind(0)), send, group=self.group, async_op=async_op)
+
+    def start(self, records_local, n_haystacks_local: int, hay_base: int):
+        import torch
+        if self.device is None:
+            self.device = records_local.device
+        n = int(records_local.shape[0])
+        cap = self.cap
+        parity, self._parity = self._parity, self._parity ^ 1
+        send, recv = self._buffers(parity, cap)
+        send[:2] = torch.tensor([n, n_haystacks_local], dtype=torch.int64).to(self.device, non_blocking=True)
+        m = min(n, cap)
+        if m:
+            pay = send[2:2 + 2 * m].view(torch.int32).view(m, 4)
+            pay.copy_(records_local[:m])
+            pay[:, 0] += hay_base
+        spill = None
+        if n > cap:  # rare: keep everything for the second, larger collective
+            spill = records_local.clone()
+            spill[:, 0] += hay_base
+        work = self._launch(send, recv, True)
+        return {"work": work, "cap": cap, "parity": parity, "n": n, "nh": n_haystacks_local, "spill": spill}
+
+    def finish(self, st):
+        """Unpack on a side stream (CUDA) so that a scan already running on the main stream is not
+        delayed; the main stream is made to wait for the side stream before returning."""
+        import torch
+        if self.device is not None and torch.device(self.device).type == "cuda":
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            main = torch.cuda.current_stream(self.device)
+            # no side.wait_stream(main): the collective already ordered itself after the payload copy,
+            # and waiting for `main` here would serialise behind the scan that is running on it
+            with torch.cuda.stream(self._side):
+                out = self._finish(st)
+            main.wait_stream(self._side)
+            return out
+        return self._finish(st)
+
+    def _finish(self, st):
+        import torch
+        st["work"].wait()
+        send, recv = self._buffers(st["parity"], st["cap"])
+        rows = recv.view(self.world, -1)
+        hdr = rows[:, :2].cpu()
+        need = int(hdr[:, 0].max())
+        if need > st["cap"]:  # every rank sees the same headers and takes the same branch
+            cap = 1 << max(need - 1, 1).bit_length()
+            self.cap = max(self.cap, cap)
+            send2 = torch.zeros(2 + 2 * cap, dtype=torch.int64, device=self.device)
+            recv2 = torch.zeros(self.world * (2 + 2 * cap), dtype=torch.int64, device=self.device)
+            send2[:2] = send[:2]
+            n = st["n"]
+            if n:
+                src = st["spill"] if st["spill"] is not None else send[2:2 + 2 * n].view(torch.int32).view(n, 4)
+                send2[2:2 + 2 * n].view(torch.int32).view(n, 4).copy_(src)
+            self._launch(send2, recv2, False)
+            rows = recv2.view(self.world, -1)
+        parts = [rows[r, 2:2 + 2 * int(hdr[r, 0])].view(torch.int32).view(-1, 4) for r in range(self.world)]
+        records = torch.cat(parts) if parts else torch.zeros((0, 4), dtype=torch.int32, device=self.device)
+        nh_global = int(hdr[:, 1].sum())
+        counts = torch.bincount(records[:, 0].long(), minlength=nh_global) if records.shape[0] else \
+            torch.zeros(nh_global, dtype=torch.int64, device=self.device)
+        prefix = torch.zeros(nh_global + 1, dtype=torch.int64, device=self.device)
+        prefix[1:] = torch.cumsum(counts, 0)
+        return prefix, records
 
 
 def allgatherv_start(counts_local, records_local, hay_base: int, group=None):
@@ -119,11 +257,11 @@ def allgatherv_records(counts_local, records_local, hay_base: int, group=None):
     return allgatherv_finish(allgatherv_start(counts_local, records_local, hay_base, group))
 
 
-def sharded_match(res: AhoResource, d_blob_local, d_off_local, hay_base: int, find_all: bool = True, group=None):
+def sharded_match(res: AhoResource, d_blob_local, d_off_local, hay_base: int, find_all: bool = True, group=None,
+                  gatherer: RecordGatherer | None = None):
     """One rank's part of a sharded batch: scan the local contiguous haystack range on this GPU,
     then all-gatherv.  Returns the GLOBAL (prefix, records) on every rank."""
     nh = d_off_local.numel() - 1
     total = match_device(res, d_blob_local, d_off_local, find_all)
-    prefix, records = result_tensors(res, nh, total, d_blob_local.device)
-    counts = prefix[1:] - prefix[:-1]
-    return allgatherv_records(counts, records, hay_base, group)
+    g = gatherer or RecordGatherer(group, d_blob_local.device)
+    return g.finish(g.start(result_view(res, total), nh, hay_base))

@@ -88,6 +88,13 @@ struct acmi_handle {
     std::vector<acmi_record> h_records;
     std::vector<uint64_t> h_prefix;
 
+    // a batch whose pipeline is enqueued but not yet completed (acmi_match_batch_device_begin/_end)
+    bool in_flight = false;
+    BatchArgs fly_args{};
+    uint64_t fly_max_items = 0;
+    int fly_find_all = 1;
+    bool fly_trivial = false;
+
     // statistics of the last call
     double scan_ms = 0, fixup_ms = 0, total_ms = 0;
     uint64_t items = 0, chunk_used = 0;
@@ -222,8 +229,8 @@ uint32_t choose_chunk(const acmi_handle *h, uint64_t blob_bytes) {
     return uint32_t(std::min<uint64_t>(c, 1u << 30));
 }
 
-// The batch pipeline on device-resident input.
-int run_batch(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, const uint64_t *d_off, size_t nh,
+// The batch pipeline on device-resident input, first half: enqueue everything, no host wait.
+int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, const uint64_t *d_off, size_t nh,
               int find_all) {
     h->have_result = false;
     h->scan_ms = h->fixup_ms = h->total_ms = 0;
@@ -236,12 +243,14 @@ int run_batch(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, const 
     h->last_total = 0;
     if (h->profile) HIPCHK(h, hipEventRecord(h->ev[0], st));
 
+    h->in_flight = false;
     if (nh == 0 || h->aut.accepted_count() == 0) {  // empty batch / empty automaton -> no records
         HIPCHK(h, hipMemsetAsync(h->d_prefix.p, 0, (nh + 1) * 8, st));
-        HIPCHK(h, hipStreamSynchronize(st));
-        h->have_result = true;
+        h->fly_trivial = true;
+        h->in_flight = true;
         return ACMI_OK;
     }
+    h->fly_trivial = false;
 
     const FlatAutomaton &fa = h->aut.flat();
     const uint32_t chunk = choose_chunk(h, blob_bytes);
@@ -308,27 +317,35 @@ int run_batch(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, const 
     // whole pipeline needs ONE host synchronisation (the read-back of the summary at the end).  Only
     // when the batch produced more records than fit is the buffer grown and the expansion re-run.
     HIPCHK(h, h->d_out.ensure(16));
-    uint64_t total = 0;
-    uint32_t n_ovf = 0;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        const uint64_t cap = h->d_out.cap / 16;
-        launch_expand(h->dA, B, max_items, h->d_rec_base.as<uint64_t>(), h->d_out.p, cap, st);
-        if (find_all) launch_refill(h->dA, B, max_items, int(fa.entry_bytes), h->d_rec_base.as<uint64_t>(), h->d_out.p, cap, st);
-        if (attempt == 0) {
-            HIPCHK(h, hipMemcpyAsync(h->pinned, d_counters, 24, hipMemcpyDeviceToHost, st));
-            HIPCHK(h, hipStreamSynchronize(st));
-            n_ovf = find_all ? reinterpret_cast<uint32_t *>(h->pinned)[0] : 0u;
-            total = h->pinned[1];
-            h->items = h->pinned[2];
-            h->overflow_items = n_ovf;
-            if (total <= cap) break;
-            HIPCHK(h, h->d_out.ensure(total * 16));
-        }
-    }
+    const uint64_t cap = h->d_out.cap / 16;
+    launch_expand(h->dA, B, max_items, h->d_rec_base.as<uint64_t>(), h->d_out.p, cap, st);
+    if (find_all) launch_refill(h->dA, B, max_items, int(fa.entry_bytes), h->d_rec_base.as<uint64_t>(), h->d_out.p, cap, st);
+    HIPCHK(h, hipMemcpyAsync(h->pinned, d_counters, 24, hipMemcpyDeviceToHost, st));
+    if (h->profile) HIPCHK(h, hipEventRecord(h->ev[4], st));
     HIPCHK(h, hipGetLastError());
+    h->fly_args = B;
+    h->fly_max_items = max_items;
+    h->fly_find_all = find_all;
+    h->in_flight = true;
+    return ACMI_OK;
+}
+
+// Second half: the one host synchronisation, the capacity check and (rarely) the re-run.
+int run_batch_end(acmi_handle *h) {
+    if (!h->in_flight) { h->last_error = "no batch in flight"; return ACMI_E_ARG; }
+    h->in_flight = false;
+    hipStream_t st = h->stream;
+    HIPCHK(h, hipStreamSynchronize(st));
+    if (h->fly_trivial) {
+        h->have_result = true;
+        return ACMI_OK;
+    }
+    const FlatAutomaton &fa = h->aut.flat();
+    const uint32_t n_ovf = h->fly_find_all ? reinterpret_cast<uint32_t *>(h->pinned)[0] : 0u;
+    const uint64_t total = h->pinned[1];
+    h->items = h->pinned[2];
+    h->overflow_items = n_ovf;
     if (h->profile) {
-        HIPCHK(h, hipEventRecord(h->ev[4], st));
-        HIPCHK(h, hipEventSynchronize(h->ev[4]));
         float ms = 0;
         HIPCHK(h, hipEventElapsedTime(&ms, h->ev[1], h->ev[2]));
         h->scan_ms = ms;
@@ -337,9 +354,26 @@ int run_batch(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, const 
         HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[4]));
         h->total_ms = ms;
     }
+    if (total > h->d_out.cap / 16) {  // did not fit the optimistic capacity: grow, expand again
+        HIPCHK(h, h->d_out.ensure(total * 16));
+        const uint64_t cap = h->d_out.cap / 16;
+        launch_expand(h->dA, h->fly_args, h->fly_max_items, h->d_rec_base.as<uint64_t>(), h->d_out.p, cap, st);
+        if (h->fly_find_all)
+            launch_refill(h->dA, h->fly_args, h->fly_max_items, int(fa.entry_bytes), h->d_rec_base.as<uint64_t>(),
+                          h->d_out.p, cap, st);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipStreamSynchronize(st));
+    }
     h->last_total = total;
     h->have_result = true;
     return ACMI_OK;
+}
+
+int run_batch(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, const uint64_t *d_off, size_t nh,
+              int find_all) {
+    int rc = run_batch_begin(h, d_blob, blob_bytes, d_off, nh, find_all);
+    if (rc < 0) return rc;
+    return run_batch_end(h);
 }
 
 int check_ready(acmi_handle *h) {
@@ -427,6 +461,24 @@ int acmi_match_batch_device(acmi_handle *h, const void *d_blob, uint64_t blob_by
     if (n_haystacks && !d_offsets) return ACMI_E_ARG;
     rc = run_batch(h, static_cast<const uint8_t *>(d_blob), blob_bytes, static_cast<const uint64_t *>(d_offsets),
                    n_haystacks, find_all);
+    if (rc < 0) return rc;
+    if (n_records) *n_records = h->last_total;
+    return ACMI_OK;
+}
+
+int acmi_match_batch_device_begin(acmi_handle *h, const void *d_blob, uint64_t blob_bytes, const void *d_offsets,
+                                  size_t n_haystacks, int find_all) {
+    int rc = check_ready(h);
+    if (rc < 0) return rc;
+    if (n_haystacks && !d_offsets) return ACMI_E_ARG;
+    return run_batch_begin(h, static_cast<const uint8_t *>(d_blob), blob_bytes, static_cast<const uint64_t *>(d_offsets),
+                           n_haystacks, find_all);
+}
+
+int acmi_match_batch_device_end(acmi_handle *h, uint64_t *n_records) {
+    if (!live(h)) return ACMI_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->dev_id));
+    int rc = run_batch_end(h);
     if (rc < 0) return rc;
     if (n_records) *n_records = h->last_total;
     return ACMI_OK;

@@ -34,6 +34,7 @@ WORKER = textwrap.dedent("""
     from php_aho_corasick_amd import batch, synth
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    gatherers = dict()
     for name in ("R1", "G5", "R2"):
         ds = synth.NAMED[name]()
         o = Oracle("port"); o.add_patterns((ds.pat_blob, ds.pat_off))
@@ -45,14 +46,21 @@ WORKER = textwrap.dedent("""
             lp, lr = o.match_batch(blob, off, find_all)                         # this rank's shard, local ids
             counts = torch.from_numpy(np.diff(lp.astype(np.int64)))
             recs = torch.from_numpy(lr.astype(np.int32).reshape(-1, 4))
-            for use_async in (False, True):
-                if use_async:
+            for mode in ("padded", "padded-async", "gatherer-small", "gatherer"):
+                if mode == "padded-async":
                     st = batch.allgatherv_start(counts, recs, lo)
                     prefix, records = batch.allgatherv_finish(st)
-                else:
+                elif mode == "padded":
                     prefix, records = batch.allgatherv_records(counts, recs, lo)
-                assert np.array_equal(prefix.numpy().astype(np.uint64), gp), (name, find_all, rank)
-                assert np.array_equal(records.numpy().astype(np.uint32), gr), (name, find_all, rank)
+                else:  # fixed-capacity single collective; capacity 4 forces the grow-and-redo path
+                    g = gatherers.setdefault(mode, batch.RecordGatherer(None, torch.device("cpu"), 4 if mode.endswith("small") else 1 << 15))
+                    s1 = g.start(recs, hi - lo, lo)          # two batches in flight, as in bench.py
+                    s2 = g.start(recs, hi - lo, lo)
+                    prefix, records = g.finish(s1)
+                    p2, r2 = g.finish(s2)
+                    assert torch.equal(prefix, p2) and torch.equal(records, r2)
+                assert np.array_equal(prefix.numpy().astype(np.uint64), gp), (name, find_all, rank, mode)
+                assert np.array_equal(records.numpy().astype(np.uint32), gr), (name, find_all, rank, mode)
     dist.barrier()
     dist.destroy_process_group()
     print("rank", rank, "ok")
