@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--haystacks", type=int, default=1 << 19, help="haystacks per GPU (8 KiB each)")
     ap.add_argument("--ilp", type=int, default=int(os.environ.get("ACMI_ILP", "0")))
     ap.add_argument("--group-quads", type=int, default=0)
+    ap.add_argument("--kernel", type=int, default=-1, help="scan kernel: 1 LDS-tile table walk (default), 2 experimental anchor filter")
     ap.add_argument("--no-plant", action="store_true", help="analysis only: no planted hits (the reference's own benchmark has ~0 matches)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
@@ -149,6 +150,8 @@ def main():
         res.set_option("ilp", args.ilp)
     if args.group_quads:
         res.set_option("group_quads", args.group_quads)
+    if args.kernel >= 0:
+        res.set_option("kernel", args.kernel)
 
     # ---- batch resident in HBM: the 64 MiB tile replicated to the requested size ----
     nh = max(TILE_HAYSTACKS, (args.haystacks // TILE_HAYSTACKS) * TILE_HAYSTACKS)
@@ -246,7 +249,7 @@ def main():
             "automaton_build_ms": round(build_ms, 2),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "k_scan_lds", "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes": algo_bytes,
+                         "kernel": {1: "k_scan_lds", 2: "k_scan_anchor", 0: "k_scan_simple"}.get(int(res.stat("kernel_used")), "?"), "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes": algo_bytes,
                          "measured_stream_read_GBs": round(stream_read_gbs, 1),
                          "frac_of_measured_stream_read": round(achieved / stream_read_gbs, 4)},
             "cpu_baseline": cpu1, "cpu_baseline_all_cores": cpu_all,

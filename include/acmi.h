@@ -176,7 +176,9 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *   "slab_events"    per work-item event slots before the overflow path (default 8)
  *   "run_cap"        per work-item fix-up runs before the item is rescanned whole (default 8)
  *   "chunk_bytes"    force the work-item size (0 = automatic)            [any time]
- *   "kernel"         0 = plain global-table kernel, 1 = LDS-tile kernel  [any time]
+ *   "kernel"         0 = plain global-table walk, 1 = LDS-tile table walk (default), 2 =
+ *                    experimental anchor q-gram filter + exact walk of candidates (needs a
+ *                    shortest pattern >= 11 B, else falls back to 1)                    [any time]
  *   "ilp"            streams per lane in the LDS-tile kernel (1 or 2)    [any time]
  *   "group_quads"    16-byte loads per lane per fetch group, 4 or 8 (ILP 1) [any time]
  *   "profile"        1 = bracket the scan kernel with HIP events         [any time] */
@@ -210,6 +212,11 @@ typedef struct acmi_tables {
     const uint32_t *own_pattern;  /* per state, 0xFFFFFFFF = none              */
     const uint32_t *dict_link;    /* per state, 0xFFFFFFFF = none              */
     const uint32_t *out_count;    /* per state                                 */
+    uint32_t anchor_q;            /* anchor filter window in bytes, 0 = not eligible */
+    uint32_t anchor_mul;          /* hash multiplier                           */
+    uint32_t min_pattern_length;
+    uint32_t anchor_keys;
+    const uint16_t *anchor_table; /* 16384 buckets x 4 fingerprints            */
 } acmi_tables;
 int acmi_debug_tables(const acmi_handle *h, acmi_tables *out);
 

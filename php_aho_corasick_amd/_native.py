@@ -40,7 +40,9 @@ class Tables(C.Structure):
                 ("max_pattern_length", C.c_uint32),
                 ("table", C.c_void_p), ("lds_image", C.c_void_p), ("class_of_byte", C.POINTER(C.c_uint8)),
                 ("own_pattern", C.POINTER(C.c_uint32)), ("dict_link", C.POINTER(C.c_uint32)),
-                ("out_count", C.POINTER(C.c_uint32))]
+                ("out_count", C.POINTER(C.c_uint32)),
+                ("anchor_q", C.c_uint32), ("anchor_mul", C.c_uint32), ("min_pattern_length", C.c_uint32),
+                ("anchor_keys", C.c_uint32), ("anchor_table", C.POINTER(C.c_uint16))]
 
 
 Handle = C.c_void_p

@@ -2,6 +2,7 @@
 #include "automaton.hpp"
 
 #include <algorithm>
+#include <array>
 #include <cstring>
 
 namespace acmi {
@@ -271,6 +272,52 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
     for (size_t i = 0; i < patterns_.size(); ++i) {
         fa.pattern_length[i] = patterns_[i].length;
         if (patterns_[i].accepted) fa.max_pattern_length = std::max(fa.max_pattern_length, patterns_[i].length);
+    }
+
+    // ---- anchor filter table -------------------------------------------------------------------
+    fa.min_pattern_length = 0;
+    for (const PatternMeta &m : patterns_)
+        if (m.accepted && (fa.min_pattern_length == 0 || m.length < fa.min_pattern_length)) fa.min_pattern_length = m.length;
+    fa.anchor_q = 0;
+    fa.anchor_table.clear();
+    if (fa.min_pattern_length >= 11) {
+        const uint32_t q = fa.min_pattern_length >= 19 ? 16u : fa.min_pattern_length >= 15 ? 12u : 8u;
+        std::vector<std::array<uint32_t, 4>> keys;
+        for (const PatternMeta &m : patterns_) {
+            if (!m.accepted) continue;
+            for (uint32_t o = 0; o < 4; ++o) {
+                std::array<uint32_t, 4> k{0, 0, 0, 0};
+                std::memcpy(k.data(), pattern_bytes_.data() + m.byte_off + o, q);
+                keys.push_back(k);
+            }
+        }
+        std::sort(keys.begin(), keys.end());
+        keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+        fa.anchor_keys = uint32_t(keys.size());
+        if (keys.size() <= kAnchorMaxKeys) {
+            std::vector<uint16_t> tab(size_t(kAnchorBuckets) * 4);
+            uint32_t mul = 0x9E3779B1u;
+            for (int attempt = 0; attempt < 512 && fa.anchor_q == 0; ++attempt, mul = mul * 0x2545F491u + 0x6B43A9B5u) {
+                mul |= 1u;
+                std::fill(tab.begin(), tab.end(), uint16_t(0));
+                bool ok = true;
+                for (const auto &k : keys) {
+                    const uint32_t h = anchor_hash(k.data(), q / 4, mul);
+                    const uint16_t fp = uint16_t(h >> 16);   // fingerprint: high half
+                    if (fp == 0) { ok = false; break; }      // 0 means "empty slot": take another seed
+                    uint16_t *b = &tab[size_t((h >> 3) & (kAnchorBuckets - 1)) * 4];  // bucket: bits 3..16
+                    int slot = 0;
+                    while (slot < 4 && b[slot] != 0 && b[slot] != fp) ++slot;
+                    if (slot == 4) { ok = false; break; }
+                    b[slot] = fp;
+                }
+                if (ok) {
+                    fa.anchor_q = q;
+                    fa.anchor_mul = mul;
+                    fa.anchor_table = tab;
+                }
+            }
+        }
     }
 
     // the build-time trie is no longer needed

@@ -63,7 +63,33 @@ struct FlatAutomaton {
     std::vector<uint32_t> dict_link;    // per state: nearest failure ancestor owning a pattern
     std::vector<uint32_t> out_count;    // per state: records one event expands to
     std::vector<uint32_t> pattern_length;  // per caller-order pattern index
+
+    // ---- anchor filter (optional front end of the scan, see kernels.hip k_scan_anchor) ----
+    // Every occurrence of a pattern of length >= q + 3 contains a 4-byte-aligned text dword within
+    // its first 4 bytes; the q bytes from there are P[o, o+q) for o in 0..3.  anchor_table holds a
+    // 16-bit fingerprint of each such q-gram: kAnchorBuckets buckets x 4 slots, 0 = empty.
+    uint32_t min_pattern_length = 0;
+    uint32_t anchor_q = 0;        // 0 = not eligible; else 8, 12 or 16 bytes
+    uint32_t anchor_mul = 0;      // odd multiplier of the window hash (seed that gave no bucket overflow)
+    uint32_t anchor_keys = 0;
+    std::vector<uint16_t> anchor_table;
 };
+
+constexpr uint32_t kAnchorBucketBits = 14;
+constexpr uint32_t kAnchorBuckets = 1u << kAnchorBucketBits;  // x 4 slots x 2 B = 128 KiB of LDS
+constexpr uint32_t kAnchorMaxKeys = 12288;
+
+// Window hash shared by the host builder and the device kernel: `words` little-endian dwords of
+// the q-gram, each multiplied by `mul`, rotated by 11 bits per position and xor-ed together.
+inline uint32_t anchor_hash(const uint32_t *words, uint32_t n_words, uint32_t mul) {
+    uint32_t h = 0;
+    for (uint32_t i = 0; i < n_words; ++i) {
+        const uint32_t m = words[i] * mul;
+        const uint32_t r = (11u * i) & 31u;
+        h ^= r ? ((m << r) | (m >> (32u - r))) : m;
+    }
+    return h;
+}
 
 class Automaton {
 public:

@@ -23,6 +23,9 @@ struct DevAutomaton {
     uint32_t lds_image_bytes;    // bytes to stage into LDS (class offsets + tile)
     uint32_t tile_offset;        // byte offset of the tile inside the LDS image (0 or 512)
     uint32_t swar_shift, swar_expect_lo, swar_expect_hi, swar_other_off;  // other column * entry_bytes
+    // anchor filter (k_scan_anchor): 2^14 buckets x 4 x uint16 fingerprints, see automaton.hpp
+    const void *anchor_table;
+    uint32_t anchor_q, anchor_mul, min_pattern_length, max_pattern_length;
 };
 
 // One batch launch.

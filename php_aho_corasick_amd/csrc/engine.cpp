@@ -62,7 +62,7 @@ struct acmi_handle {
     uint32_t slab_events = 8;
     uint32_t run_cap = 8;
     uint64_t chunk_opt = 0;
-    int kernel = 1;
+    int kernel = 1;  // 0 plain global table, 1 LDS tile (default), 2 anchor filter (if eligible)
     int ilp = 1;
     int group_quads = 8;
     int profile = 0;
@@ -74,7 +74,7 @@ struct acmi_handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     DevAutomaton dA{};
-    DevBuf d_table, d_lds, d_class, d_own, d_dict, d_cnt, d_plen;
+    DevBuf d_table, d_lds, d_class, d_own, d_dict, d_cnt, d_plen, d_anchor;
 
     // workspace (grow-only)
     DevBuf d_blob, d_off, d_nitems, d_item_base, d_item_hay, d_zero, d_rec_base, d_slab, d_ovf, d_counters,
@@ -97,6 +97,7 @@ struct acmi_handle {
 
     // statistics of the last call
     double scan_ms = 0, fixup_ms = 0, total_ms = 0;
+    int kernel_used = 0;
     uint64_t items = 0, chunk_used = 0;
     uint32_t overflow_items = 0;
 
@@ -190,7 +191,17 @@ int ensure_device(acmi_handle *h) {
     if (!fa.pattern_length.empty())
         HIPCHK(h, hipMemcpy(h->d_plen.p, fa.pattern_length.data(), fa.pattern_length.size() * 4, hipMemcpyHostToDevice));
 
+    if (fa.anchor_q) {
+        HIPCHK(h, h->d_anchor.ensure(fa.anchor_table.size() * 2));
+        HIPCHK(h, hipMemcpy(h->d_anchor.p, fa.anchor_table.data(), fa.anchor_table.size() * 2, hipMemcpyHostToDevice));
+    }
+
     DevAutomaton &A = h->dA;
+    A.anchor_table = fa.anchor_q ? h->d_anchor.p : nullptr;
+    A.anchor_q = fa.anchor_q;
+    A.anchor_mul = fa.anchor_mul;
+    A.min_pattern_length = fa.min_pattern_length;
+    A.max_pattern_length = fa.max_pattern_length;
     A.table = h->d_table.p;
     A.lds_image = h->d_lds.p;
     A.class_off = h->d_class.as<uint16_t>();
@@ -303,7 +314,10 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
     launch_build_items(B, max_items, st);
 
     if (h->profile) HIPCHK(h, hipEventRecord(h->ev[1], st));
-    HIPCHK(h, launch_scan(h->dA, B, max_items, int(fa.entry_bytes), h->kernel, int(fa.class_mode), h->ilp, h->group_quads, st));
+    // the anchor filter needs a pattern set that allows it, else fall back to the LDS-tile table walk
+    const int kernel = (h->kernel == 2 && !fa.anchor_q) ? 1 : h->kernel;
+    h->kernel_used = kernel;
+    HIPCHK(h, launch_scan(h->dA, B, max_items, int(fa.entry_bytes), kernel, int(fa.class_mode), h->ilp, h->group_quads, st));
     if (h->profile) HIPCHK(h, hipEventRecord(h->ev[2], st));
     if (h->profile) HIPCHK(h, hipEventRecord(h->ev[3], st));
 
@@ -441,7 +455,7 @@ int acmi_destroy(acmi_handle *h) {
     if (h->dev_ready) {
         (void)hipSetDevice(h->dev_id);
         if (h->stream) (void)hipStreamSynchronize(h->stream);
-        for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_blob,
+        for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_blob,
                           &h->d_off, &h->d_nitems, &h->d_item_base, &h->d_item_hay, &h->d_zero,
                           &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_scan_tmp, &h->d_prefix, &h->d_out, &h->d_runs})
             b->release();
@@ -590,7 +604,7 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
         if (value < 0) return ACMI_E_ARG;
         h->chunk_opt = uint64_t(value);
     } else if (k == "kernel") {
-        if (value != 0 && value != 1) return ACMI_E_ARG;
+        if (value < 0 || value > 2) return ACMI_E_ARG;
         h->kernel = int(value);
     } else if (k == "ilp") {
         if (value != 1 && value != 2) return ACMI_E_ARG;
@@ -632,6 +646,10 @@ int acmi_get_stat(const acmi_handle *h, const char *key, double *value) {
     else if (k == "overflow_items") *value = h->overflow_items;
     else if (k == "scan_ms") *value = h->scan_ms;
     else if (k == "fixup_ms") *value = h->fixup_ms;
+    else if (k == "kernel_used") *value = h->kernel_used;
+    else if (k == "anchor_q") *value = fa.anchor_q;
+    else if (k == "anchor_keys") *value = fa.anchor_keys;
+    else if (k == "min_pattern_length") *value = fa.min_pattern_length;
     else if (k == "total_ms") *value = h->total_ms;
     else if (k == "records") *value = double(h->last_total);
     else return ACMI_E_ARG;
@@ -664,6 +682,11 @@ int acmi_debug_tables(const acmi_handle *h, acmi_tables *out) {
     out->own_pattern = fa.own_pattern.data();
     out->dict_link = fa.dict_link.data();
     out->out_count = fa.out_count.data();
+    out->anchor_q = fa.anchor_q;
+    out->anchor_mul = fa.anchor_mul;
+    out->min_pattern_length = fa.min_pattern_length;
+    out->anchor_keys = fa.anchor_keys;
+    out->anchor_table = fa.anchor_q ? fa.anchor_table.data() : nullptr;
     return ACMI_OK;
 }
 

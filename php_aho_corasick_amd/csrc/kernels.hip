@@ -66,6 +66,30 @@ __device__ __forceinline__ bool decode_item(const BatchArgs &B, uint64_t i, Item
     return true;
 }
 
+// Load through the constant address space: with a wave-uniform address hipcc then emits a scalar
+// s_load (counted by lgkmcnt) instead of a vector load whose wait would drain the haystack
+// prefetches queued on vmcnt.  Only for arrays this kernel never writes.
+template <typename T>
+__device__ __forceinline__ T const_load(const T *p) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) T *>(reinterpret_cast<uintptr_t>(p));
+}
+
+// decode_item for a wave-uniform item index, all loads scalar
+__device__ __forceinline__ bool decode_item_uniform(const BatchArgs &B, uint64_t i, ItemDesc &it) {
+    if (i >= const_load(B.item_base + B.n_haystacks)) return false;
+    const uint32_t h = const_load(B.item_hay + i);
+    const uint64_t hb = const_load(B.offsets + h), he = const_load(B.offsets + h + 1);
+    const uint64_t k = i - const_load(B.item_base + h);
+    const uint64_t p0 = k * B.chunk_bytes;
+    it.hay = h;
+    it.pos0 = uint32_t(p0);
+    it.begin = hb + p0;
+    const uint64_t rest = he - it.begin;
+    it.len = rest < B.chunk_bytes ? uint32_t(rest) : B.chunk_bytes;
+    it.warm = p0 < B.warm_bytes ? uint32_t(p0) : B.warm_bytes;
+    return true;
+}
+
 __global__ void k_build_items(BatchArgs B) {
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i < B.item_base[B.n_haystacks]) B.item_hay[i] = find_haystack(B, i);
@@ -280,16 +304,17 @@ __device__ __forceinline__ uint32_t swar_columns(const DevAutomaton &A, uint32_t
     return c4 * uint32_t(sizeof(E));
 }
 
-// byte -> column offset inside a row, without touching global memory
+// byte -> column offset inside a row.  SWAR3: pure arithmetic.  TABLE: the 256-entry table, from
+// LDS when the caller staged it there (`cls_lds`), else from global memory.
 template <typename E, int MODE>
-__device__ __forceinline__ uint32_t class_offset(const DevAutomaton &A, const uint8_t *smem, uint32_t byte) {
+__device__ __forceinline__ uint32_t class_offset(const DevAutomaton &A, const uint16_t *cls_lds, uint32_t byte) {
     if (MODE == 1) {
         const uint32_t c = (byte >> A.swar_shift) & 7u;
         // selector bytes 1..3 = 0x0c pick the constant 0x00
         const uint32_t e = __builtin_amdgcn_perm(A.swar_expect_hi, A.swar_expect_lo, c | 0x0c0c0c00u);
         return e == byte ? c * uint32_t(sizeof(E)) : A.swar_other_off;
     }
-    return reinterpret_cast<const uint16_t *>(smem)[byte];
+    return cls_lds ? cls_lds[byte] : A.class_off[byte];
 }
 
 // Event counters of the item being walked by the epilogue, kept in registers and stored once.
@@ -298,11 +323,12 @@ struct EventRegs {
     uint32_t n_ev;
 };
 
-// Exact walk of bytes [j0, j1) of one item with the LDS tile resident: hot rows from LDS, cold
-// rows from the global table, haystack bytes by aligned dword loads.  Reports (records an event)
-// for final states at byte index j >= rep_from, at position pos_bias + j.  Returns the state.
+// Exact walk of bytes [j0, j1) of one item: hot rows from the LDS tile when one is resident
+// (`tile`), everything else from the global table; haystack bytes by aligned dword loads.
+// Reports (records an event) for final states at byte index j >= rep_from, at position
+// pos_bias + j.  Returns the state.
 template <typename E, int MODE>
-__device__ __forceinline__ uint32_t exact_range(const DevAutomaton &A, const BatchArgs &B, const uint8_t *smem,
+__device__ __forceinline__ uint32_t exact_range(const DevAutomaton &A, const BatchArgs &B, const uint16_t *cls_lds,
                                                 const uint8_t *tile, uint64_t item, const uint8_t *p, uint32_t j0,
                                                 uint32_t j1, uint32_t rep_from, uint32_t pos_bias, uint32_t s,
                                                 EventRegs &ev) {
@@ -313,9 +339,9 @@ __device__ __forceinline__ uint32_t exact_range(const DevAutomaton &A, const Bat
         const uintptr_t a = base + j;
         if (j == j0 || (a & 3u) == 0) word = *reinterpret_cast<const uint32_t *>(a & ~uintptr_t(3));
         const uint32_t byte = (word >> (8u * uint32_t(a & 3u))) & 0xffu;
-        const uint32_t coff = class_offset<E, MODE>(A, smem, byte);
+        const uint32_t coff = class_offset<E, MODE>(A, cls_lds, byte);
         uint32_t w = A.trap;
-        if (s < A.trap) w = *reinterpret_cast<const E *>(tile + s * A.row_bytes + coff);
+        if (tile != nullptr && s < A.trap) w = *reinterpret_cast<const E *>(tile + s * A.row_bytes + coff);
         if (w >= A.trap)
             w = *reinterpret_cast<const E *>(static_cast<const uint8_t *>(A.table) + uint64_t(s) * A.row_bytes + coff);
         s = w;
@@ -326,6 +352,42 @@ __device__ __forceinline__ uint32_t exact_range(const DevAutomaton &A, const Bat
         }
     }
     return s;
+}
+
+// Dense epilogue of the scan kernels: walk the flagged byte runs of one item exactly.  Events only
+// arise here, in ascending position order (runs are disjoint and ascending).  A run [lo, hi) whose
+// entry state is unknown is entered from the root Lmax-1 bytes earlier -- exact for every pattern
+// ending inside the run -- and only events ending inside it (and inside the item's reporting range)
+// are recorded.  nr > run_cap means the run list overflowed: the whole item is walked.
+template <typename E, int MODE>
+__device__ __forceinline__ void run_epilogue(const DevAutomaton &A, const BatchArgs &B, const uint16_t *cls_lds,
+                                             const uint8_t *tile, uint64_t item, const ItemDesc &it, uint32_t nr) {
+    const uint8_t *p = B.blob + (it.begin - it.warm);
+    const uint32_t n = it.warm + it.len;
+    const uint32_t pos_bias = it.pos0 - it.warm + 1u;
+    EventRegs ev{0, 0};
+    if (nr > B.run_cap) {
+        exact_range<E, MODE>(A, B, cls_lds, tile, item, p, 0, n, it.warm, pos_bias, 0u, ev);
+    } else {
+        const uint4 *runs = B.runs + item * B.run_cap;
+#pragma unroll 1
+        for (uint32_t r = 0; r < nr; ++r) {
+            const uint4 run = runs[r];
+            const uint32_t lo = run.x, hi = run.y;
+            uint32_t st = run.z;
+            if (st == 0xFFFFFFFFu) {  // entry state unknown: Lmax-1 bytes of silent warm-up from the root
+                EventRegs none{0, 0};
+                const uint32_t from = lo > B.warm_bytes ? lo - B.warm_bytes : 0u;
+                st = exact_range<E, MODE>(A, B, cls_lds, tile, item, p, from, lo, 0xFFFFFFFFu, 0u, 0u, none);
+            }
+            exact_range<E, MODE>(A, B, cls_lds, tile, item, p, lo, hi, lo > it.warm ? lo : it.warm, pos_bias, st, ev);
+        }
+    }
+    if (ev.n_ev) {
+        B.ev_count[item] = ev.n_ev;
+        B.rec_count[item] = ev.n_rec;
+    }
+    finish_item(B, item);
 }
 
 template <typename E, int MODE, int ILP, int G>
@@ -468,46 +530,228 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchA
     }
 
     // ---- dense epilogue: every lane now walks the flagged runs of its own items exactly ----
-    // (events only arise here, in ascending position order: head run, flagged quads, tail run).
-    // A run [lo, hi) is entered from the root Lmax-1 bytes earlier -- exact for every pattern
-    // ending inside the run -- and only events ending inside it (and inside the item's reporting
-    // range) are recorded.  The LDS tile is still resident, so hot steps stay on-chip.
 #pragma unroll
     for (int k = 0; k < ILP; ++k) {
         ItemDesc it;
         if (decode_item(B, item0 + k, it)) {
-            const uint64_t item = item0 + k;
-            const uint8_t *p = B.blob + (it.begin - it.warm);
             const uint32_t n = it.warm + it.len;
             const uint32_t tail_lo = head[k] + (nq[k] << 4);
-            if (tail_lo < n) append_run(B, item, tail_lo, n, poison[k] ? 0xFFFFFFFFu : s[k], nrun[k], run_hi[k]);
-            const uint32_t nr = nrun[k];
-            const uint32_t pos_bias = it.pos0 - it.warm + 1u;
-            EventRegs ev{0, 0};
-            if (nr > B.run_cap) {  // too many runs: the whole item, exactly
-                exact_range<E, MODE>(A, B, smem, tile, item, p, 0, n, it.warm, pos_bias, 0u, ev);
-            } else {
-                const uint4 *runs = B.runs + item * B.run_cap;
-#pragma unroll 1
-                for (uint32_t r = 0; r < nr; ++r) {
-                    const uint4 run = runs[r];
-                    const uint32_t lo = run.x, hi = run.y;
-                    uint32_t st = run.z;
-                    if (st == 0xFFFFFFFFu) {  // entry state unknown: Lmax-1 bytes of silent warm-up from the root
-                        EventRegs none{0, 0};
-                        const uint32_t from = lo > B.warm_bytes ? lo - B.warm_bytes : 0u;
-                        st = exact_range<E, MODE>(A, B, smem, tile, item, p, from, lo, 0xFFFFFFFFu, 0u, 0u, none);
-                    }
-                    exact_range<E, MODE>(A, B, smem, tile, item, p, lo, hi, lo > it.warm ? lo : it.warm, pos_bias, st, ev);
-                }
-            }
-            if (ev.n_ev) {
-                B.ev_count[item] = ev.n_ev;
-                B.rec_count[item] = ev.n_rec;
-            }
-            finish_item(B, item);
+            if (tail_lo < n) append_run(B, item0 + k, tail_lo, n, poison[k] ? 0xFFFFFFFFu : s[k], nrun[k], run_hi[k]);
+            run_epilogue<E, MODE>(A, B, MODE == 1 ? nullptr : reinterpret_cast<const uint16_t *>(smem), tile, item0 + k, it,
+                                  nrun[k]);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_scan_anchor: sampled q-gram front end for pattern sets whose SHORTEST pattern is long.
+//
+// The per-byte table walk of k_scan_lds is bound by the LDS's random-lookup rate (one dependent
+// ds_read per byte).  When every pattern is at least q + 3 bytes long (q = 8, 12 or 16) the walk
+// can be skipped almost everywhere: an occurrence starting at text address x contains the
+// 4-byte-aligned dword at ceil4(x), i.e. within its first 4 bytes, and the q bytes from there are
+// one of <= 4 q-grams of that pattern (offsets 0..3).  So it suffices to test, for every ALIGNED
+// text dword, whether the q bytes starting there are such an "anchor" q-gram: one hash + one
+// ds_read_b64 (a 4-slot bucket of 16-bit fingerprints, 128 KiB table in LDS) per 4 bytes instead
+// of four dependent ds_read_u16.  No false negatives by construction; a hit (true anchor or
+// fingerprint collision) only flags the byte run in which a match could END, and the same exact
+// epilogue as k_scan_lds walks it through the Aho-Corasick table -- results are bit-identical.
+// Windows are independent (no state), so their LDS reads pipeline freely; the kernel is bound by
+// HBM.  Lines are read exactly like k_scan_lds (128 B per lane, double-buffered).
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kAnchorLdsBytes = 16384u * 8u;
+
+__device__ __forceinline__ uint32_t rotl32(uint32_t v, uint32_t r) { return __builtin_amdgcn_alignbit(v, v, 32u - r); }
+
+// Probe one window: bucket = bits 3..16 of the hash (so the LDS byte address is one v_and),
+// fingerprint = its high half.  Nonzero iff one of the bucket's four fingerprints equals the
+// window's: (v - 0x00010001) & ~v has bit 15 / 31 set where a halfword of v is zero.
+__device__ __forceinline__ uint32_t anchor_probe(const uint8_t *smem, uint32_t h) {
+    const uint2 b = *reinterpret_cast<const uint2 *>(smem + (h & 0x1FFF8u));
+    const uint32_t ff = __builtin_amdgcn_perm(h, h, 0x03020302u);  // fingerprint in both halves
+    const uint32_t x = b.x ^ ff, y = b.y ^ ff;
+    return ((x - 0x00010001u) & ~x) | ((y - 0x00010001u) & ~y);
+}
+
+// One wave streams one work item at a time, 8 KiB per step: lane l owns 128-byte line (chunk*64 + l)
+// of the item, so the wave's loads cover a contiguous 8 KiB of HBM (DRAM-page friendly, unlike
+// one-lane-per-haystack streaming where the 64 lines of a wave-load sit 8 KiB apart).  Windows that
+// begin in the previous lane's line get its last hashed dwords through a DPP wave shift.  A wave owns
+// 64 consecutive items; lane k remembers item k's run count for the lane-per-item epilogue.
+struct AnchorCursor {      // wave-uniform position in the wave's (item, chunk) task list
+    uint32_t k;            // item index inside the wave, 0..63
+    uint32_t c, chunks;    // current 8-KiB chunk of the item, number of chunks (>= 1)
+    uint32_t n, head, nq;  // scan bytes, unaligned head bytes, whole 16-byte quads after the head
+    const uint4 *qp;       // first quad
+    bool valid;
+};
+
+__device__ __forceinline__ void anchor_open(const DevAutomaton &A, const BatchArgs &B, uint64_t wave_first,
+                                            uint32_t k, AnchorCursor &cur) {
+    ItemDesc it;
+    cur.k = k;
+    cur.c = 0;
+    cur.chunks = 1;
+    cur.n = cur.head = cur.nq = 0;
+    cur.qp = static_cast<const uint4 *>(A.anchor_table);
+    cur.valid = k < 64u && decode_item_uniform(B, wave_first + k, it);
+    if (cur.valid) {
+        const uint8_t *p = B.blob + (it.begin - it.warm);
+        cur.n = it.warm + it.len;
+        const uint32_t mis = uint32_t(-reinterpret_cast<uintptr_t>(p)) & 15u;
+        cur.head = mis < cur.n ? mis : cur.n;
+        cur.nq = (cur.n - cur.head) >> 4;
+        if (cur.nq) cur.qp = reinterpret_cast<const uint4 *>(p + cur.head);
+        const uint32_t lines = (cur.nq + 7u) >> 3;
+        cur.chunks = lines ? (lines + 63u) >> 6 : 1u;
+    }
+}
+
+// advance to the next (item, chunk) task of the wave; false when the wave's 64 items are done
+__device__ __forceinline__ bool anchor_next(const DevAutomaton &A, const BatchArgs &B, uint64_t wave_first,
+                                            AnchorCursor &cur) {
+    if (!cur.valid) return false;
+    if (++cur.c < cur.chunks) return true;
+    anchor_open(A, B, wave_first, cur.k + 1u, cur);
+    return cur.valid;
+}
+
+template <typename E, int MODE, int QW>
+__global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, BatchArgs B) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int G = 8;
+    const uint64_t first = uint64_t(blockIdx.x) * kLdsThreads;
+    if (first >= B.item_base[B.n_haystacks]) return;
+    {
+        const uint4 *src = static_cast<const uint4 *>(A.anchor_table);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t t = threadIdx.x; t < kAnchorLdsBytes / 16u; t += kLdsThreads) dst[t] = src[t];
+    }
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave_first = first + __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u);
+    const uint32_t mul = A.anchor_mul;
+    const uint32_t q = QW * 4u, m_min = A.min_pattern_length, l_max = A.max_pattern_length;
+
+    AnchorCursor ld, sc;  // load cursor runs one task ahead of the scan cursor
+    anchor_open(A, B, wave_first, 0, ld);
+    if (!ld.valid) return;
+    sc = ld;
+    uint32_t nrun = 0, run_hi = 0;  // run list of the item being scanned (wave-uniform)
+    uint32_t nrun_vec = 0;          // lane k: run count of item wave_first + k
+    uint32_t prev_tail[QW - 1];     // hashed last dwords of the previous chunk's last line (uniform)
+#pragma unroll
+    for (int i = 0; i < QW - 1; ++i) prev_tail[i] = 0;
+    if (sc.head) append_run(B, wave_first + sc.k, 0, (sc.head + l_max) < sc.n ? sc.head + l_max : sc.n, 0u, nrun, run_hi);
+
+    uint4 buf0[G], buf1[G];
+    auto load_task = [&](uint4 (&buf)[G], const AnchorCursor &cur) {
+        const uint32_t line = cur.c * 64u + lane;
+        const uint32_t last = cur.nq ? cur.nq - 1u : 0u;
+#pragma unroll
+        for (int r = 0; r < G; ++r) {
+            const uint32_t qi = line * G + r;
+            buf[r] = cur.qp[qi < last ? qi : last];
+        }
+    };
+    auto scan_task = [&](const uint4 (&buf)[G]) {
+        const uint32_t line = sc.c * 64u + lane;
+        // hashed dwords of this lane's last quad feed the next lane's first windows
+        uint32_t carry[QW - 1];
+        {
+            const uint32_t t[3] = {buf[G - 1].y * mul, buf[G - 1].z * mul, buf[G - 1].w * mul};
+#pragma unroll
+            for (int i = 0; i < QW - 1; ++i) {
+                const uint32_t mine = t[3 - (QW - 1) + i];
+                const uint32_t from_left = __builtin_amdgcn_update_dpp(0u, mine, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                carry[i] = lane == 0 ? (sc.c ? prev_tail[i] : 0u) : from_left;
+                prev_tail[i] = __builtin_amdgcn_readlane(mine, 63);
+            }
+        }
+        uint32_t hits = 0;  // bit r: some window ENDING in quad r of this lane's line hit
+#pragma unroll
+        for (int r = 0; r < G; ++r) {
+            uint32_t m[QW + 3];
+#pragma unroll
+            for (int i = 0; i < QW - 1; ++i) m[i] = carry[i];
+            m[QW - 1] = buf[r].x * mul;
+            m[QW + 0] = buf[r].y * mul;
+            m[QW + 1] = buf[r].z * mul;
+            m[QW + 2] = buf[r].w * mul;
+#pragma unroll
+            for (int i = 0; i < QW - 1; ++i) carry[i] = m[4 + i];
+            uint32_t acc = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {  // window ending at dword w of this quad = m[w .. w+QW-1]
+                uint32_t h = m[w];
+#pragma unroll
+                for (int i = 1; i < QW; ++i) h ^= rotl32(m[w + i], (11u * i) & 31u);
+                acc |= anchor_probe(smem, h);
+            }
+            hits |= (acc & 0x80008000u) ? (1u << r) : 0u;
+        }
+        uint64_t who = __ballot(hits != 0);
+        while (__builtin_expect(who != 0, 0)) {  // rare, wave-uniform: flag where a match anchored there can end
+            const uint32_t l = uint32_t(__builtin_ctzll(who));
+            who &= who - 1;
+            const uint32_t hl = __builtin_amdgcn_readlane(hits, l);
+#pragma unroll 1
+            for (uint32_t r = 0; r < uint32_t(G); ++r) {
+                const uint32_t qi = (sc.c * 64u + l) * G + r;
+                if (((hl >> r) & 1u) && qi < sc.nq) {
+                    // first window of the group starts (QW-1) dwords before quad qi, the last one 12 B later
+                    const int32_t j_first = int32_t(sc.head + (qi << 4)) - int32_t(q - 4u);
+                    int32_t lo = j_first + int32_t(m_min) - 4;
+                    uint32_t hi = uint32_t(j_first + 12 + int32_t(l_max));
+                    if (lo < 0) lo = 0;
+                    if (hi > sc.n) hi = sc.n;
+                    if (nrun > 0 && uint32_t(lo) < run_hi) lo = int32_t(run_hi);  // keep runs disjoint and ascending
+                    if (uint32_t(lo) < hi) append_run(B, wave_first + sc.k, uint32_t(lo), hi, 0xFFFFFFFFu, nrun, run_hi);
+                }
+            }
+        }
+        (void)line;
+    };
+    auto close_or_advance = [&]() -> bool {  // scan cursor: next chunk, or finish the item and open the next
+        if (sc.c + 1u == sc.chunks) {
+            // anchors the main loop did not test start after head + 16*nq - q: what they could match
+            // ends at or after head + 16*nq - q + m_min
+            uint32_t lo = sc.head + (sc.nq << 4) + m_min;
+            lo = lo > q ? lo - q : 0u;
+            if (nrun > 0 && lo < run_hi) lo = run_hi;
+            if (lo < sc.n && sc.head + (sc.nq << 4) < sc.n) append_run(B, wave_first + sc.k, lo, sc.n, 0xFFFFFFFFu, nrun, run_hi);
+            nrun_vec = lane == sc.k ? nrun : nrun_vec;
+        }
+        const uint32_t k_before = sc.k;
+        const bool more = anchor_next(A, B, wave_first, sc);
+        if (more && sc.k != k_before) {
+            nrun = 0;
+            run_hi = 0;
+            if (sc.head) append_run(B, wave_first + sc.k, 0, (sc.head + l_max) < sc.n ? sc.head + l_max : sc.n, 0u, nrun, run_hi);
+        }
+        return more;
+    };
+
+    // Loads are issued unconditionally (past the last task the cursor is an invalid item whose
+    // loads fall on the anchor table): a load under a branch would make hipcc drain vmcnt(0) at
+    // every use of the other buffer instead of counting.
+    load_task(buf0, ld);
+    for (;;) {
+        anchor_next(A, B, wave_first, ld);
+        load_task(buf1, ld);
+        scan_task(buf0);
+        if (!close_or_advance()) break;
+        anchor_next(A, B, wave_first, ld);
+        load_task(buf0, ld);
+        scan_task(buf1);
+        if (!close_or_advance()) break;
+    }
+
+    // ---- dense epilogue: lane k walks the flagged runs of item k ----
+    ItemDesc it;
+    if (decode_item(B, wave_first + lane, it))
+        run_epilogue<E, MODE>(A, B, nullptr, nullptr, wave_first + lane, it, nrun_vec);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -635,9 +879,31 @@ static hipError_t launch_lds_m(const DevAutomaton &A, const BatchArgs &B, uint64
     return launch_lds_t<E, MODE, 1, 8>(A, B, max_items, lds, st);
 }
 
+template <typename E, int MODE>
+static hipError_t launch_anchor_m(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, hipStream_t st) {
+    const uint32_t blocks = uint32_t((max_items + kLdsThreads - 1) / kLdsThreads);
+    auto go = [&](auto fn) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(kAnchorLdsBytes));
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(fn, dim3(blocks), dim3(kLdsThreads), kAnchorLdsBytes, st, A, B);
+        return hipGetLastError();
+    };
+    if (A.anchor_q == 8) return go(k_scan_anchor<E, MODE, 2>);
+    if (A.anchor_q == 12) return go(k_scan_anchor<E, MODE, 3>);
+    return go(k_scan_anchor<E, MODE, 4>);
+}
+
 hipError_t launch_scan(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes,
                        int kernel, int class_mode, int ilp, int group_quads, hipStream_t st) {
     if (max_items == 0) return hipSuccess;
+    if (kernel == 2 && A.anchor_q != 0) {
+        if (entry_bytes == 2)
+            return class_mode == 1 ? launch_anchor_m<uint16_t, 1>(A, B, max_items, st)
+                                   : launch_anchor_m<uint16_t, 0>(A, B, max_items, st);
+        return class_mode == 1 ? launch_anchor_m<uint32_t, 1>(A, B, max_items, st)
+                               : launch_anchor_m<uint32_t, 0>(A, B, max_items, st);
+    }
     if (kernel == 0) {
         const uint32_t blocks = uint32_t((max_items + 255) / 256);
         if (entry_bytes == 2) hipLaunchKernelGGL(k_scan_simple<uint16_t>, dim3(blocks), dim3(256), 0, st, A, B);

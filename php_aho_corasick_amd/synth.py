@@ -215,4 +215,36 @@ def r3() -> Dataset:
     return ds
 
 
-NAMED = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "R1": r1, "R2": r2, "R3": r3}
+def _planted_ragged(name, seed, n_pat, lmin, lmax, n_hay, hmin, hmax, alphabet, plants_per_hay):
+    """Ragged haystacks with several planted patterns each: at the very start, at the very end and at
+    pseudo-random places (so matches straddle 16-byte quads, 128-byte lines and work-item chunks)."""
+    ds = ragged(name, seed, n_pat, lmin, lmax, n_hay, hmin, hmax, alphabet)
+    for h in range(ds.n_haystacks):
+        lo, hi = int(ds.hay_off[h]), int(ds.hay_off[h + 1])
+        for k in range(plants_per_hay):
+            pat = ds.pattern((7 * h + 13 * k + 1) % ds.n_patterns)
+            if hi - lo < len(pat):
+                continue
+            span = hi - lo - len(pat)
+            at = 0 if k == 0 else span if k == 1 else ((h * 2654435761 + k * 40503) >> 3) % (span + 1)
+            ds.hay_blob[lo + at:lo + at + len(pat)] = np.frombuffer(pat, dtype=np.uint8)
+    return ds
+
+
+def r4() -> Dataset:
+    """Anchor filter with 8-byte windows: 150 patterns of 11..30 B over {a,b,c,d}, planted."""
+    return _planted_ragged("R4", 14, 150, 11, 30, 61, 0, 6000, b"abcd", 5)
+
+
+def r5() -> Dataset:
+    """Anchor filter with 12-byte windows: 400 patterns of 15..40 B over Sigma=256, planted."""
+    return _planted_ragged("R5", 15, 400, 15, 40, 53, 0, 9000, None, 6)
+
+
+def r6() -> Dataset:
+    """Anchor filter with 16-byte windows: 120 patterns of 19..64 B over {0,1}, planted (binary text makes
+    accidental anchors common, so the candidate path is exercised hard)."""
+    return _planted_ragged("R6", 16, 120, 19, 64, 37, 0, 12000, b"01", 4)
+
+
+NAMED = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "R1": r1, "R2": r2, "R3": r3, "R4": r4, "R5": r5, "R6": r6}

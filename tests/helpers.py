@@ -62,6 +62,20 @@ class FlatTables:
         self.dict = np.ctypeslib.as_array(t.dict_link, shape=(t.n_states,)).astype(np.int64)
         self.cnt = np.ctypeslib.as_array(t.out_count, shape=(t.n_states,)).astype(np.int64)
         _ = dt
+        self.anchor_q, self.anchor_mul, self.min_pattern_length = t.anchor_q, t.anchor_mul, t.min_pattern_length
+        self.anchor_keys = t.anchor_keys
+        self.anchor = np.ctypeslib.as_array(t.anchor_table, shape=(16384, 4)).copy() if t.anchor_q else None
+
+    def anchor_probe(self, window: bytes) -> bool:
+        """The device's window test (k_scan_anchor), restated: hash q bytes, look the fingerprint up."""
+        q = self.anchor_q
+        words = np.frombuffer(window[:q], dtype="<u4").astype(np.uint64)
+        h = 0
+        for i, w in enumerate(words):
+            m = (int(w) * self.anchor_mul) & 0xFFFFFFFF
+            r = (11 * i) & 31
+            h ^= ((m << r) | (m >> (32 - r))) & 0xFFFFFFFF if r else m
+        return int(h >> 16) in [int(x) for x in self.anchor[(h >> 3) & 0x3FFF]]
 
     def is_final(self, s: int) -> bool:
         return (self.f1 <= s < self.trap) or s >= self.f2

@@ -88,3 +88,30 @@ def test_wide_entries_for_big_automata():
     assert res.stat("states") > 65536 and res.stat("entry_bytes") == 4
     _compare(ds, res, max_hay=1)
     api.ahocorasick_deinit(res)
+
+
+@pytest.mark.parametrize("name,q", [("G2", 12), ("R3", 16), ("R4", 8), ("R5", 12), ("R6", 16)])
+def test_anchor_table_has_no_false_negatives(name, q):
+    """Every pattern's q-grams at offsets 0..3 must probe positive (a miss would lose matches); random
+    windows almost never do."""
+    ds = synth.NAMED[name]()
+    res = resource_for(ds)
+    api.ahocorasick_finalize(res)
+    ft = FlatTables(res)
+    assert ft.anchor_q == q and ft.min_pattern_length >= q + 3
+    for k in range(ds.n_patterns):
+        p = ds.pattern(k)
+        for o in range(4):
+            assert ft.anchor_probe(p[o:o + q]), (name, k, o)
+    rng = np.random.default_rng(5)
+    fp = sum(ft.anchor_probe(rng.integers(0, 256, q, dtype=np.uint8).tobytes()) for _ in range(4000))
+    assert fp <= 8
+    api.ahocorasick_deinit(res)
+
+
+def test_anchor_not_offered_for_short_patterns():
+    for name in ("G4", "R1", "R2"):
+        res = resource_for(synth.NAMED[name]())
+        api.ahocorasick_finalize(res)
+        assert FlatTables(res).anchor_q == 0
+        api.ahocorasick_deinit(res)

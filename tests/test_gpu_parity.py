@@ -15,7 +15,7 @@ from php_aho_corasick_amd import api, synth
 
 pytestmark = pytest.mark.gpu
 
-SMALL = ["G1", "G2", "G3", "G4", "G5", "R1", "R2", "R3"]
+SMALL = ["G1", "G2", "G3", "G4", "G5", "R1", "R2", "R3", "R4", "R5", "R6"]
 
 
 def _check_golden(res, ds, golden, name, path=host_match):
@@ -55,14 +55,15 @@ def test_golden_g6_64k_patterns(golden):
     api.ahocorasick_deinit(res)
 
 
-VARIANTS = [dict(kernel=1, ilp=1, group_quads=4), dict(kernel=1, ilp=2, run_cap=1), dict(kernel=1, ilp=1, run_cap=2, chunk_bytes=512), dict(kernel=0), dict(kernel=1, ilp=1), dict(kernel=1, ilp=2),
+VARIANTS = [dict(kernel=2), dict(kernel=2, chunk_bytes=256), dict(kernel=2, run_cap=1, slab_events=1), dict(kernel=2, chunk_bytes=2048, run_cap=2),
+            dict(kernel=1, ilp=1), dict(kernel=1, ilp=1, group_quads=4), dict(kernel=1, ilp=2, run_cap=1), dict(kernel=1, ilp=1, run_cap=2, chunk_bytes=512), dict(kernel=0), dict(kernel=1, ilp=1), dict(kernel=1, ilp=2),
             dict(kernel=1, ilp=1, lds_bytes=4096), dict(kernel=1, ilp=2, lds_bytes=2048),
             dict(kernel=1, ilp=1, chunk_bytes=64), dict(kernel=1, ilp=2, chunk_bytes=256),
             dict(kernel=0, chunk_bytes=16), dict(kernel=1, ilp=1, chunk_bytes=4096, slab_events=1),
             dict(kernel=1, ilp=2, slab_events=1), dict(kernel=1, ilp=1, slab_events=3, chunk_bytes=128)]
 
 
-@pytest.mark.parametrize("name,variant", list(itertools.product(["G2", "G4", "G5", "R1", "R2", "R3"], range(len(VARIANTS)))))
+@pytest.mark.parametrize("name,variant", list(itertools.product(["G2", "G4", "G5", "R1", "R2", "R3", "R4", "R5", "R6"], range(len(VARIANTS)))))
 def test_golden_variants(name, variant, golden):
     """Every kernel / ILP / LDS-tile size (forces cold states + trap) / chunk size (forces warm-up
     overlap, R3 has 1 KiB patterns) / slab size (forces the overflow -> refill path)."""
@@ -202,7 +203,7 @@ def test_random_against_oracle():
         ds = synth.ragged(f"S{seed}", seed, 20 + 13 * (seed % 7), 1, 3 + seed % 9, 33 + seed, 0, 700 + 97 * (seed % 4), alpha)
         o = Oracle("port")
         o.add_patterns((ds.pat_blob, ds.pat_off))
-        res = resource_for(ds, kernel=1, ilp=1 + seed % 2, chunk_bytes=[0, 48, 512][seed % 3], slab_events=[8, 1, 2][seed % 3])
+        res = resource_for(ds, kernel=[1, 2, 0][seed % 3], ilp=1 + seed % 2, chunk_bytes=[0, 48, 512][seed % 3], slab_events=[8, 1, 2][seed % 3])
         for find_all in (True, False):
             pe, re_ = o.match_batch(ds.hay_blob, ds.hay_off, find_all)
             for path in (host_match, device_match):

@@ -1,0 +1,50 @@
+"""GPU fuzz: many seeded random automata / ragged batches through every kernel and entry point,
+each compared record-for-record with the oracle.  Usage: python tools/fuzz_gpu.py [n_cases] [seed0]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+from gpu_util import device_match, host_match, resource_for
+from oracle.pyoracle import Oracle
+from php_aho_corasick_amd import api, synth
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+alphabets = [b"ab", b"abc", b"abcdef", b"ACGT", b"01", b"abcdefgh", b"abcdefghij", b"xyz\x00\x01\x02\x03\x04\x05", None,
+             bytes(range(32, 127))]
+t0 = time.time()
+bad = 0
+for case in range(n_cases):
+    seed = seed0 + case
+    r = np.random.default_rng(seed)
+    alpha = alphabets[r.integers(len(alphabets))]
+    lmin = int(r.choice([1, 1, 2, 4, 8, 11, 15, 19, 40]))
+    lmax = int(min(1024, lmin + r.choice([0, 1, 3, 8, 20, 100, 900])))
+    n_pat = int(r.choice([1, 3, 17, 60, 300, 1500]))
+    n_hay = int(r.choice([1, 2, 9, 64, 65, 200]))
+    hmax = int(r.choice([0, 1, 15, 16, 17, 127, 128, 129, 1000, 5000, 20000]))
+    plants = int(r.choice([0, 1, 3, 10]))
+    ds = synth._planted_ragged(f"F{seed}", seed, n_pat, lmin, lmax, n_hay, 0, hmax, alpha, plants) if plants else \
+        synth.ragged(f"F{seed}", seed, n_pat, lmin, lmax, n_hay, 0, hmax, alpha)
+    o = Oracle("port")
+    calls = int(r.choice([1, 1, 2, 5]))
+    pats = ds.patterns()
+    step = (len(pats) + calls - 1) // calls
+    for lo in range(0, len(pats), step):
+        o.add_patterns(pats[lo:lo + step])
+    opts = dict(kernel=int(r.choice([0, 1, 1, 2, 2])), ilp=int(r.choice([1, 2])), group_quads=int(r.choice([4, 8])),
+                chunk_bytes=int(r.choice([0, 0, 16, 48, 256, 1024, 4096])), slab_events=int(r.choice([1, 2, 8])),
+                run_cap=int(r.choice([1, 2, 8])), lds_bytes=int(r.choice([2048, 8192, 65536, 163000])))
+    res = resource_for(ds, calls=calls, **opts)
+    for find_all in (True, False):
+        pe, re_ = o.match_batch(ds.hay_blob, ds.hay_off, find_all)
+        for path in (host_match, device_match):
+            p, rr = path(res, ds, find_all)
+            if not (np.array_equal(p, pe) and np.array_equal(rr, re_)):
+                bad += 1
+                print("MISMATCH", seed, opts, dict(alpha=alpha, lmin=lmin, lmax=lmax, n_pat=n_pat, n_hay=n_hay, hmax=hmax,
+                                                   plants=plants, calls=calls), find_all, path.__name__, len(rr), len(re_), flush=True)
+    api.ahocorasick_deinit(res)
+    o.close()
+print(f"fuzz: {n_cases} cases from seed {seed0}, {bad} mismatches, {time.time()-t0:.1f}s")
+sys.exit(1 if bad else 0)
