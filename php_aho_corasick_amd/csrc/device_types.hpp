@@ -49,6 +49,7 @@ struct BatchArgs {
     uint4 *runs;                 // per item: run_cap x {lo, hi, entry state or ~0, -}: bytes [lo, hi) in item scan coordinates
     uint32_t run_cap;
     uint32_t poison_quads;       // ceil(max_pattern_length / 16): quads flagged after a lost state
+    uint32_t persistent;         // 1: one workgroup per CU, waves pull item batches from counters[1]
 };
 
 }  // namespace acmi

@@ -394,8 +394,8 @@ template <typename E, int MODE, int ILP, int G>
 __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchArgs B) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr uint32_t kTileOff = MODE == 1 ? 0u : 512u;  // TABLE mode: 256 x uint16 column offsets first
-    const uint64_t first = uint64_t(blockIdx.x) * (kLdsThreads * ILP);
-    if (first >= B.item_base[B.n_haystacks]) return;
+    const uint64_t total_items = B.item_base[B.n_haystacks];
+    if (uint64_t(blockIdx.x) * (B.persistent ? 64u * ILP : kLdsThreads * ILP) >= total_items) return;  // no work
 
     {   // stage [column offsets +] hot tile into LDS
         const uint4 *src = static_cast<const uint4 *>(A.lds_image);
@@ -411,7 +411,19 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchA
     const uint8_t *tile = smem + kTileOff;
     const uint32_t row_bytes = A.row_bytes;
     const uint32_t f1 = A.f1, trap = A.trap;
-    const uint64_t item0 = first + uint64_t(threadIdx.x) * ILP;
+
+    // Persistent workgroups (one per CU, the tile is staged once): each WAVE pulls batches of
+    // 64 x ILP consecutive work items from a global counter until none are left.  Waves drift out
+    // of phase, so while one wave sits in its latency-bound exact epilogue the other 15 keep the
+    // LDS and HBM busy, and the tail of the launch is one wave-batch, not one workgroup.
+    for (;;) {
+    uint32_t batch_first = (blockIdx.x * (kLdsThreads / 64u) + (threadIdx.x >> 6)) * (64u * ILP);  // static split
+    if (B.persistent) {
+        if ((threadIdx.x & 63u) == 0) batch_first = atomicAdd(&B.counters[1], 64u * ILP);
+        batch_first = __builtin_amdgcn_readfirstlane(batch_first);
+    }
+    if (batch_first >= total_items) break;
+    const uint64_t item0 = uint64_t(batch_first) + uint64_t(threadIdx.x & 63u) * ILP;
 
     // per-stream state kept across the main loop: 7 VGPRs + the line buffers
     uint32_t s[ILP], nq[ILP], last[ILP], head[ILP], poison[ILP], nrun[ILP], run_hi[ILP];
@@ -541,6 +553,8 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchA
                                   nrun[k]);
         }
     }
+    if (!B.persistent) break;
+    }  // next batch of this wave
 }
 
 // ------------------------------------------------------------------------------------------
@@ -856,6 +870,16 @@ void launch_count_items(const uint64_t *offsets, uint32_t nh, uint32_t chunk, ui
     hipLaunchKernelGGL(k_count_items, dim3((nh + 1 + 255) / 256), dim3(256), 0, st, offsets, nh, chunk, n_items);
 }
 
+static int num_cus() {
+    static int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 256;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
+        return v;
+    }();
+    return n;
+}
+
 template <typename E, int MODE, int ILP, int G>
 static hipError_t launch_lds_t(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, uint32_t lds_bytes,
                                hipStream_t st) {
@@ -863,8 +887,10 @@ static hipError_t launch_lds_t(const DevAutomaton &A, const BatchArgs &B, uint64
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
     if (e != hipSuccess) return e;
+    // persistent: at most one workgroup per CU (the tile fills the CU's LDS), fewer for small batches
     const uint64_t per_block = uint64_t(kLdsThreads) * ILP;
-    const uint32_t blocks = uint32_t((max_items + per_block - 1) / per_block);
+    const uint64_t want = (max_items + per_block - 1) / per_block;
+    const uint32_t blocks = B.persistent ? uint32_t(std::min<uint64_t>(want, uint64_t(num_cus()))) : uint32_t(want);
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(kLdsThreads), lds_bytes, st, A, B);
     return hipGetLastError();
 }

@@ -55,7 +55,7 @@ def test_golden_g6_64k_patterns(golden):
     api.ahocorasick_deinit(res)
 
 
-VARIANTS = [dict(kernel=2), dict(kernel=2, chunk_bytes=256), dict(kernel=2, run_cap=1, slab_events=1), dict(kernel=2, chunk_bytes=2048, run_cap=2),
+VARIANTS = [dict(kernel=1, persistent=1, chunk_bytes=64), dict(kernel=1, persistent=0, ilp=2), dict(kernel=2), dict(kernel=2, chunk_bytes=256), dict(kernel=2, run_cap=1, slab_events=1), dict(kernel=2, chunk_bytes=2048, run_cap=2),
             dict(kernel=1, ilp=1), dict(kernel=1, ilp=1, group_quads=4), dict(kernel=1, ilp=2, run_cap=1), dict(kernel=1, ilp=1, run_cap=2, chunk_bytes=512), dict(kernel=0), dict(kernel=1, ilp=1), dict(kernel=1, ilp=2),
             dict(kernel=1, ilp=1, lds_bytes=4096), dict(kernel=1, ilp=2, lds_bytes=2048),
             dict(kernel=1, ilp=1, chunk_bytes=64), dict(kernel=1, ilp=2, chunk_bytes=256),

@@ -34,7 +34,7 @@ for case in range(n_cases):
         o.add_patterns(pats[lo:lo + step])
     opts = dict(kernel=int(r.choice([0, 1, 1, 2, 2])), ilp=int(r.choice([1, 2])), group_quads=int(r.choice([4, 8])),
                 chunk_bytes=int(r.choice([0, 0, 16, 48, 256, 1024, 4096])), slab_events=int(r.choice([1, 2, 8])),
-                run_cap=int(r.choice([1, 2, 8])), lds_bytes=int(r.choice([2048, 8192, 65536, 163000])))
+                run_cap=int(r.choice([1, 2, 8])), persistent=int(r.choice([-1, 0, 1])), lds_bytes=int(r.choice([2048, 8192, 65536, 163000])))
     res = resource_for(ds, calls=calls, **opts)
     for find_all in (True, False):
         pe, re_ = o.match_batch(ds.hay_blob, ds.hay_off, find_all)
