@@ -311,7 +311,7 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
     // persistent workgroups pay off once a CU would otherwise run several workgroups back to back
     // (measured: 1 KiB items -18 %, 2 x 8 KiB per lane +2.5 %)
     B.persistent = h->persistent >= 0 ? uint32_t(h->persistent != 0)
-                                      : uint32_t(max_items > 3ull * 256 * 1024 * uint64_t(h->ilp));
+                                      : uint32_t(blob_bytes / chunk > 3ull * 256 * 1024 * uint64_t(h->ilp));
 
     launch_count_items(d_off, uint32_t(nh), chunk, h->d_nitems.as<uint64_t>(), st);
     exclusive_scan_u64(h->d_nitems.as<uint64_t>(), h->d_item_base.as<uint64_t>(), nh + 1, h->d_scan_tmp.as<uint64_t>(), st);
