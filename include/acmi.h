@@ -188,7 +188,7 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value);
 
 /* Numeric facts about the automaton and the last match call, e.g. "states",
  * "hot_states", "columns", "entry_bytes", "lds_image_bytes", "table_bytes",
- * "max_pattern_length", "items", "overflow_items", "scan_ms", "fixup_ms", "total_ms". */
+ * "max_pattern_length", "items", "overflow_items", "kernel_used", "scan_ms", "total_ms". */
 int acmi_get_stat(const acmi_handle *h, const char *key, double *value);
 
 /* Run subsequent launches on this hipStream_t (passed as void*); NULL = the

@@ -45,7 +45,6 @@ struct BatchArgs {
     uint32_t *overflow_list;     // items whose events did not fit their slab
     uint32_t *counters;          // [0] = number of overflowed items
     // main loop -> epilogue hand-over inside k_scan_lds: byte runs of an item that need the exact path
-    uint32_t *run_count;         // per item; > run_cap means "rescan the whole item exactly"
     uint4 *runs;                 // per item: run_cap x {lo, hi, entry state or ~0, -}: bytes [lo, hi) in item scan coordinates
     uint32_t run_cap;
     uint32_t poison_quads;       // ceil(max_pattern_length / 16): quads flagged after a lost state

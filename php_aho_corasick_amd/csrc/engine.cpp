@@ -97,7 +97,7 @@ struct acmi_handle {
     bool fly_trivial = false;
 
     // statistics of the last call
-    double scan_ms = 0, fixup_ms = 0, total_ms = 0;
+    double scan_ms = 0, total_ms = 0;
     int kernel_used = 0;
     uint64_t items = 0, chunk_used = 0;
     uint32_t overflow_items = 0;
@@ -245,7 +245,7 @@ uint32_t choose_chunk(const acmi_handle *h, uint64_t blob_bytes) {
 int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, const uint64_t *d_off, size_t nh,
               int find_all) {
     h->have_result = false;
-    h->scan_ms = h->fixup_ms = h->total_ms = 0;
+    h->scan_ms = h->total_ms = 0;
     h->items = 0;
     h->overflow_items = 0;
     if (nh > 0xFFFFFFF0ull) { h->last_error = "too many haystacks"; return ACMI_E_TOO_LARGE; }
@@ -304,7 +304,6 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
     B.slab = h->d_slab.as<uint2>();
     B.overflow_list = h->d_ovf.as<uint32_t>();
     B.counters = d_counters;
-    B.run_count = nullptr;
     B.runs = h->d_runs.as<uint4>();
     B.run_cap = Q;
     B.poison_quads = std::max<uint32_t>(1, (fa.max_pattern_length + 15) / 16);
@@ -324,7 +323,6 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
     h->kernel_used = kernel;
     HIPCHK(h, launch_scan(h->dA, B, max_items, int(fa.entry_bytes), kernel, int(fa.class_mode), h->ilp, h->group_quads, st));
     if (h->profile) HIPCHK(h, hipEventRecord(h->ev[2], st));
-    if (h->profile) HIPCHK(h, hipEventRecord(h->ev[3], st));
 
     if (!find_all) launch_first_only(B, st);
     exclusive_scan_u64(d_rec_cnt, h->d_rec_base.as<uint64_t>(), max_items + 1, h->d_scan_tmp.as<uint64_t>(), st);
@@ -368,8 +366,6 @@ int run_batch_end(acmi_handle *h) {
         float ms = 0;
         HIPCHK(h, hipEventElapsedTime(&ms, h->ev[1], h->ev[2]));
         h->scan_ms = ms;
-        HIPCHK(h, hipEventElapsedTime(&ms, h->ev[2], h->ev[3]));
-        h->fixup_ms = ms;
         HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[4]));
         h->total_ms = ms;
     }
@@ -652,7 +648,6 @@ int acmi_get_stat(const acmi_handle *h, const char *key, double *value) {
     else if (k == "chunk_bytes") *value = double(h->chunk_used);
     else if (k == "overflow_items") *value = h->overflow_items;
     else if (k == "scan_ms") *value = h->scan_ms;
-    else if (k == "fixup_ms") *value = h->fixup_ms;
     else if (k == "kernel_used") *value = h->kernel_used;
     else if (k == "anchor_q") *value = fa.anchor_q;
     else if (k == "anchor_keys") *value = fa.anchor_keys;

@@ -5,18 +5,22 @@
 // search plus failure hops (~1.9 pointer-chased node visits per byte), every haystack byte
 // costs ONE lookup in a failure-free transition table whose hot rows live in LDS.
 //
-// Pipeline for one batch (all on one stream):
-//   k_count_items  -> exclusive scan                  work items per haystack
-//   k_scan_*                                          the hot kernel: events -> per-item slabs
-//   k_first_only   (findAll == false)                 keep only the first event per haystack
-//   exclusive scan of per-item record counts          -> record base of every item
-//   k_hay_prefix                                      -> per-haystack prefix array
-//   k_expand                                          slab events -> records (callback order)
-//   k_refill                                          overflowed items re-scanned straight into
-//                                                     their final slots (dense-match inputs)
+// Pipeline for one batch (all on one stream, one host synchronisation at the very end):
+//   k_count_items -> exclusive scan -> k_build_items   work items (haystack chunks) per haystack
+//   k_scan_lds                                         the hot kernel: optimistic LDS-tile walk, flagged
+//                                                      byte runs walked exactly in its dense epilogue,
+//                                                      events -> per-item slabs
+//   k_first_only   (findAll == false)                  keep only the first event per haystack
+//   exclusive scan of per-item record counts           -> record base of every item
+//   k_hay_prefix                                       -> per-haystack prefix array + batch summary
+//   k_expand                                           slab events -> records (callback order)
+//   k_refill                                           items whose events overflowed the slab re-scanned
+//                                                      straight into their final slots (dense inputs)
+// Alternatives to k_scan_lds: k_scan_simple (plain global-table walk, cross-check) and k_scan_anchor
+// (experimental q-gram front end).
 //
-// No MFMA anywhere: this is byte/integer indexing, bounded by HBM reads of the haystack and
-// by LDS bank throughput of the table lookups.  Wave64, 1024-thread workgroups, one per CU.
+// No MFMA anywhere: this is byte/integer indexing, bounded by the LDS's random-lookup rate and by
+// HBM reads of the haystack.  Wave64, 1024-thread workgroups, one per CU.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
