@@ -543,6 +543,12 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchA
         scan_group(buf0, g);
         load_group(buf0, g + 2);
         scan_group(buf1, g + 1);
+        // dense-match or mostly-cold inputs: once every stream of the wave has overflowed its run list
+        // (its whole item will be walked exactly anyway) the optimistic pass is pure waste -- leave it
+        bool alive = false;
+#pragma unroll
+        for (int k = 0; k < ILP; ++k) alive |= nrun[k] <= B.run_cap && (g + 2) * G < nq[k];
+        if (!__any(alive)) break;
     }
 
     // ---- dense epilogue: every lane now walks the flagged runs of its own items exactly ----
