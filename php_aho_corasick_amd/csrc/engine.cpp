@@ -312,7 +312,7 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
     B.persistent = h->persistent >= 0 ? uint32_t(h->persistent != 0)
                                       : uint32_t(blob_bytes / chunk > 3ull * 256 * 1024 * uint64_t(h->ilp));
 
-    launch_count_items(d_off, uint32_t(nh), chunk, h->d_nitems.as<uint64_t>(), st);
+    launch_count_items(d_off, uint32_t(nh), chunk, h->d_nitems.as<uint64_t>(), d_counters, st);
     exclusive_scan_u64(h->d_nitems.as<uint64_t>(), h->d_item_base.as<uint64_t>(), nh + 1, h->d_scan_tmp.as<uint64_t>(), st);
 
     launch_build_items(B, max_items, st);
@@ -337,7 +337,7 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
     const uint64_t cap = h->d_out.cap / 16;
     launch_expand(h->dA, B, max_items, h->d_rec_base.as<uint64_t>(), h->d_out.p, cap, st);
     if (find_all) launch_refill(h->dA, B, max_items, int(fa.entry_bytes), h->d_rec_base.as<uint64_t>(), h->d_out.p, cap, st);
-    HIPCHK(h, hipMemcpyAsync(h->pinned, d_counters, 24, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(h->pinned, d_counters, 32, hipMemcpyDeviceToHost, st));
     if (h->profile) HIPCHK(h, hipEventRecord(h->ev[4], st));
     HIPCHK(h, hipGetLastError());
     h->fly_args = B;
@@ -358,6 +358,10 @@ int run_batch_end(acmi_handle *h) {
         return ACMI_OK;
     }
     const FlatAutomaton &fa = h->aut.flat();
+    if (reinterpret_cast<uint32_t *>(h->pinned)[6] != 0u) {
+        h->last_error = "offsets must be non-decreasing and every haystack shorter than 4 GiB";
+        return ACMI_E_ARG;
+    }
     const uint32_t n_ovf = h->fly_find_all ? reinterpret_cast<uint32_t *>(h->pinned)[0] : 0u;
     const uint64_t total = h->pinned[1];
     h->items = h->pinned[2];

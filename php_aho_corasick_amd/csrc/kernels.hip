@@ -149,12 +149,20 @@ __device__ __forceinline__ uint32_t exact_bytes(const DevAutomaton &A, const Bat
 // ------------------------------------------------------------------------------------------
 // k_count_items: work items per haystack
 // ------------------------------------------------------------------------------------------
-__global__ void k_count_items(const uint64_t *offsets, uint32_t nh, uint32_t chunk, uint64_t *n_items) {
+// Also validates what the host cannot see for device-resident offsets: decreasing offsets or a
+// haystack of 4 GiB or more (positions are 32-bit) raise counters[6], and that haystack gets no item.
+__global__ void k_count_items(const uint64_t *offsets, uint32_t nh, uint32_t chunk, uint64_t *n_items,
+                              uint32_t *counters) {
     const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h > nh) return;
     if (h == nh) { n_items[h] = 0; return; }
-    const uint64_t len = offsets[h + 1] - offsets[h];
-    n_items[h] = (len + chunk - 1) / chunk;
+    const uint64_t lo = offsets[h], hi = offsets[h + 1];
+    if (hi < lo || hi - lo >= 0xFFFFFFFFull) {
+        counters[6] = 1u;
+        n_items[h] = 0;
+        return;
+    }
+    n_items[h] = (hi - lo + chunk - 1) / chunk;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -876,8 +884,9 @@ void launch_build_items(const BatchArgs &B, uint64_t max_items, hipStream_t st) 
     hipLaunchKernelGGL(k_build_items, dim3(uint32_t((max_items + 255) / 256)), dim3(256), 0, st, B);
 }
 
-void launch_count_items(const uint64_t *offsets, uint32_t nh, uint32_t chunk, uint64_t *n_items, hipStream_t st) {
-    hipLaunchKernelGGL(k_count_items, dim3((nh + 1 + 255) / 256), dim3(256), 0, st, offsets, nh, chunk, n_items);
+void launch_count_items(const uint64_t *offsets, uint32_t nh, uint32_t chunk, uint64_t *n_items, uint32_t *counters,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(k_count_items, dim3((nh + 1 + 255) / 256), dim3(256), 0, st, offsets, nh, chunk, n_items, counters);
 }
 
 static int num_cus() {

@@ -212,3 +212,21 @@ def test_random_against_oracle():
                 assert np.array_equal(r, re_), (seed, find_all, path.__name__)
         api.ahocorasick_deinit(res)
         o.close()
+
+
+def test_device_entry_rejects_bad_offsets():
+    """Device-resident offsets cannot be checked on the host: the pipeline flags them itself."""
+    import torch
+    from php_aho_corasick_amd import batch
+    from php_aho_corasick_amd._native import AcmiError, E_ARG
+    res = api.ahocorasick_init([{"value": "abc"}])
+    d_blob = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    batch.bind_current_stream(res)
+    good = torch.tensor([0, 100, 100, 4096], dtype=torch.int64, device="cuda")
+    assert batch.match_device(res, d_blob, good) == 0
+    bad = torch.tensor([0, 200, 100, 4096], dtype=torch.int64, device="cuda")
+    with pytest.raises(AcmiError) as e:
+        batch.match_device(res, d_blob, bad)
+    assert e.value.status == E_ARG
+    assert batch.match_device(res, d_blob, good) == 0      # the handle stays usable
+    api.ahocorasick_deinit(res)
