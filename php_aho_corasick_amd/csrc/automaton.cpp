@@ -298,7 +298,7 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
             std::vector<uint16_t> tab(size_t(kAnchorBuckets) * 4);
             uint32_t mul = 0x9E3779B1u;
             for (int attempt = 0; attempt < 512 && fa.anchor_q == 0; ++attempt, mul = mul * 0x2545F491u + 0x6B43A9B5u) {
-                mul |= 1u;
+                mul = (mul | 1u) & 0xFFFFFFu;
                 std::fill(tab.begin(), tab.end(), uint16_t(0));
                 bool ok = true;
                 for (const auto &k : keys) {

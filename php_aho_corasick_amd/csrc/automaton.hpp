@@ -79,12 +79,17 @@ constexpr uint32_t kAnchorBucketBits = 14;
 constexpr uint32_t kAnchorBuckets = 1u << kAnchorBucketBits;  // x 4 slots x 2 B = 128 KiB of LDS
 constexpr uint32_t kAnchorMaxKeys = 12288;
 
-// Window hash shared by the host builder and the device kernel: `words` little-endian dwords of
-// the q-gram, each multiplied by `mul`, rotated by 11 bits per position and xor-ed together.
+// Window hash shared by the host builder and the device kernel.  Each little-endian dword d of the
+// q-gram is folded to 24 bits (d ^ d >> 11) and multiplied by a 24-bit odd constant -- one
+// full-rate v_mul_u32_u24 on the device; a 32-bit v_mul_lo_u32 costs 8x as much and dominated the
+// kernel -- then the products are rotated by 11 bits per position and xor-ed together.
+inline uint32_t anchor_mix(uint32_t d, uint32_t mul) {
+    return ((d ^ (d >> 11)) & 0xFFFFFFu) * (mul & 0xFFFFFFu);  // low 32 bits of a 24 x 24 product
+}
 inline uint32_t anchor_hash(const uint32_t *words, uint32_t n_words, uint32_t mul) {
     uint32_t h = 0;
     for (uint32_t i = 0; i < n_words; ++i) {
-        const uint32_t m = words[i] * mul;
+        const uint32_t m = anchor_mix(words[i], mul);
         const uint32_t r = (11u * i) & 31u;
         h ^= r ? ((m << r) | (m >> (32u - r))) : m;
     }

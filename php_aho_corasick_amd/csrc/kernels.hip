@@ -595,6 +595,9 @@ constexpr uint32_t kAnchorLdsBytes = 16384u * 8u;
 
 __device__ __forceinline__ uint32_t rotl32(uint32_t v, uint32_t r) { return __builtin_amdgcn_alignbit(v, v, 32u - r); }
 
+// per-dword mixing of the window hash (automaton.hpp anchor_mix): fold to 24 bits, v_mul_u32_u24
+__device__ __forceinline__ uint32_t anchor_mix_dev(uint32_t d, uint32_t mul) { return __umul24(d ^ (d >> 11), mul); }
+
 // Probe one window: bucket = bits 3..16 of the hash (so the LDS byte address is one v_and),
 // fingerprint = its high half.  Nonzero iff one of the bucket's four fingerprints equals the
 // window's: (v - 0x00010001) & ~v has bit 15 / 31 set where a halfword of v is zero.
@@ -605,11 +608,10 @@ __device__ __forceinline__ uint32_t anchor_probe(const uint8_t *smem, uint32_t h
     return ((x - 0x00010001u) & ~x) | ((y - 0x00010001u) & ~y);
 }
 
-// One wave streams one work item at a time, 8 KiB per step: lane l owns 128-byte line (chunk*64 + l)
-// of the item, so the wave's loads cover a contiguous 8 KiB of HBM (DRAM-page friendly, unlike
-// one-lane-per-haystack streaming where the 64 lines of a wave-load sit 8 KiB apart).  Windows that
-// begin in the previous lane's line get its last hashed dwords through a DPP wave shift.  A wave owns
-// 64 consecutive items; lane k remembers item k's run count for the lane-per-item epilogue.
+// One wave streams one work item at a time, 8 KiB per step, with fully coalesced loads (lane l holds
+// quads r*64 + l).  Windows that begin in the previous quad get its last hashed dwords from the
+// neighbouring lane through a DPP wave shift.  A wave owns 64 consecutive items; lane k remembers
+// item k's run count for the lane-per-item epilogue.
 struct AnchorCursor {      // wave-uniform position in the wave's (item, chunk) task list
     uint32_t k;            // item index inside the wave, 0..63
     uint32_t c, chunks;    // current 8-KiB chunk of the item, number of chunks (>= 1)
@@ -634,8 +636,7 @@ __device__ __forceinline__ void anchor_open(const DevAutomaton &A, const BatchAr
         cur.head = mis < cur.n ? mis : cur.n;
         cur.nq = (cur.n - cur.head) >> 4;
         if (cur.nq) cur.qp = reinterpret_cast<const uint4 *>(p + cur.head);
-        const uint32_t lines = (cur.nq + 7u) >> 3;
-        cur.chunks = lines ? (lines + 63u) >> 6 : 1u;
+        cur.chunks = cur.nq ? (cur.nq + 511u) >> 9 : 1u;  // 8 KiB = 512 quads per wave step
     }
 }
 
@@ -678,41 +679,37 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     if (sc.head) append_run(B, wave_first + sc.k, 0, (sc.head + l_max) < sc.n ? sc.head + l_max : sc.n, 0u, nrun, run_hi);
 
     uint4 buf0[G], buf1[G];
+    // Lane l holds quads r*64 + l (r = 0..7) of the wave's current 8 KiB: every wave-load covers 1 KiB
+    // of contiguous memory (8 whole 128-byte lines).  A micro-benchmark of the access patterns alone
+    // (tools/micro/stream_pattern.hip) gives 4.6 TB/s when each lane reads its own 128-byte line --
+    // the line is split over 8 wave-instructions of 64 different lines each -- against 6.4 TB/s coalesced.
     auto load_task = [&](uint4 (&buf)[G], const AnchorCursor &cur) {
-        const uint32_t line = cur.c * 64u + lane;
         const uint32_t last = cur.nq ? cur.nq - 1u : 0u;
 #pragma unroll
         for (int r = 0; r < G; ++r) {
-            const uint32_t qi = line * G + r;
+            const uint32_t qi = cur.c * 512u + uint32_t(r) * 64u + lane;
             buf[r] = cur.qp[qi < last ? qi : last];
         }
     };
     auto scan_task = [&](const uint4 (&buf)[G]) {
-        const uint32_t line = sc.c * 64u + lane;
-        // hashed dwords of this lane's last quad feed the next lane's first windows
-        uint32_t carry[QW - 1];
-        {
-            const uint32_t t[3] = {buf[G - 1].y * mul, buf[G - 1].z * mul, buf[G - 1].w * mul};
-#pragma unroll
-            for (int i = 0; i < QW - 1; ++i) {
-                const uint32_t mine = t[3 - (QW - 1) + i];
-                const uint32_t from_left = __builtin_amdgcn_update_dpp(0u, mine, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-                carry[i] = lane == 0 ? (sc.c ? prev_tail[i] : 0u) : from_left;
-                prev_tail[i] = __builtin_amdgcn_readlane(mine, 63);
-            }
-        }
-        uint32_t hits = 0;  // bit r: some window ENDING in quad r of this lane's line hit
+        uint32_t hits = 0;  // bit r: some window ENDING in this lane's quad r hit
 #pragma unroll
         for (int r = 0; r < G; ++r) {
+            // hashed dwords: m[QW-1..QW+2] this quad's, m[0..QW-2] the end of the previous quad, which
+            // lives in lane l-1 (DPP wave shift) or, for lane 0, in lane 63 of the previous wave-load
             uint32_t m[QW + 3];
+            m[QW - 1] = anchor_mix_dev(buf[r].x, mul);
+            m[QW + 0] = anchor_mix_dev(buf[r].y, mul);
+            m[QW + 1] = anchor_mix_dev(buf[r].z, mul);
+            m[QW + 2] = anchor_mix_dev(buf[r].w, mul);
 #pragma unroll
-            for (int i = 0; i < QW - 1; ++i) m[i] = carry[i];
-            m[QW - 1] = buf[r].x * mul;
-            m[QW + 0] = buf[r].y * mul;
-            m[QW + 1] = buf[r].z * mul;
-            m[QW + 2] = buf[r].w * mul;
-#pragma unroll
-            for (int i = 0; i < QW - 1; ++i) carry[i] = m[4 + i];
+            for (int i = 0; i < QW - 1; ++i) {
+                const uint32_t mine = m[4 + i];  // one of this quad's last QW-1 hashed dwords
+                const uint32_t from_left = __builtin_amdgcn_update_dpp(0u, mine, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                const bool first_of_item = r == 0 && sc.c == 0;
+                m[i] = lane == 0 ? (first_of_item ? 0u : prev_tail[i]) : from_left;
+                prev_tail[i] = __builtin_amdgcn_readlane(mine, 63);
+            }
             uint32_t acc = 0;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {  // window ending at dword w of this quad = m[w .. w+QW-1]
@@ -723,27 +720,27 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
             }
             hits |= (acc & 0x80008000u) ? (1u << r) : 0u;
         }
-        uint64_t who = __ballot(hits != 0);
-        while (__builtin_expect(who != 0, 0)) {  // rare, wave-uniform: flag where a match anchored there can end
-            const uint32_t l = uint32_t(__builtin_ctzll(who));
-            who &= who - 1;
-            const uint32_t hl = __builtin_amdgcn_readlane(hits, l);
+        if (__builtin_expect(__any(hits != 0), 0)) {  // rare, wave-uniform: flag where a match anchored there can end
 #pragma unroll 1
-            for (uint32_t r = 0; r < uint32_t(G); ++r) {
-                const uint32_t qi = (sc.c * 64u + l) * G + r;
-                if (((hl >> r) & 1u) && qi < sc.nq) {
-                    // first window of the group starts (QW-1) dwords before quad qi, the last one 12 B later
-                    const int32_t j_first = int32_t(sc.head + (qi << 4)) - int32_t(q - 4u);
-                    int32_t lo = j_first + int32_t(m_min) - 4;
-                    uint32_t hi = uint32_t(j_first + 12 + int32_t(l_max));
-                    if (lo < 0) lo = 0;
-                    if (hi > sc.n) hi = sc.n;
-                    if (nrun > 0 && uint32_t(lo) < run_hi) lo = int32_t(run_hi);  // keep runs disjoint and ascending
-                    if (uint32_t(lo) < hi) append_run(B, wave_first + sc.k, uint32_t(lo), hi, 0xFFFFFFFFu, nrun, run_hi);
+            for (uint32_t r = 0; r < uint32_t(G); ++r) {  // r outer, lane inner: ascending quad order
+                uint64_t who = __ballot((hits >> r) & 1u);
+                while (who != 0) {
+                    const uint32_t l = uint32_t(__builtin_ctzll(who));
+                    who &= who - 1;
+                    const uint32_t qi = sc.c * 512u + r * 64u + l;
+                    if (qi < sc.nq) {
+                        // first window of the group starts (QW-1) dwords before quad qi, the last one 12 B later
+                        const int32_t j_first = int32_t(sc.head + (qi << 4)) - int32_t(q - 4u);
+                        int32_t lo = j_first + int32_t(m_min) - 4;
+                        uint32_t hi = uint32_t(j_first + 12 + int32_t(l_max));
+                        if (lo < 0) lo = 0;
+                        if (hi > sc.n) hi = sc.n;
+                        if (nrun > 0 && uint32_t(lo) < run_hi) lo = int32_t(run_hi);  // keep runs disjoint and ascending
+                        if (uint32_t(lo) < hi) append_run(B, wave_first + sc.k, uint32_t(lo), hi, 0xFFFFFFFFu, nrun, run_hi);
+                    }
                 }
             }
         }
-        (void)line;
     };
     auto close_or_advance = [&]() -> bool {  // scan cursor: next chunk, or finish the item and open the next
         if (sc.c + 1u == sc.chunks) {

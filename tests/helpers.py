@@ -72,7 +72,8 @@ class FlatTables:
         words = np.frombuffer(window[:q], dtype="<u4").astype(np.uint64)
         h = 0
         for i, w in enumerate(words):
-            m = (int(w) * self.anchor_mul) & 0xFFFFFFFF
+            d = int(w)
+            m = (((d ^ (d >> 11)) & 0xFFFFFF) * (self.anchor_mul & 0xFFFFFF)) & 0xFFFFFFFF
             r = (11 * i) & 31
             h ^= ((m << r) | (m >> (32 - r))) & 0xFFFFFFFF if r else m
         return int(h >> 16) in [int(x) for x in self.anchor[(h >> 3) & 0x3FFF]]
