@@ -101,7 +101,7 @@ def main():
     ap.add_argument("--haystacks", type=int, default=1 << 19, help="haystacks per GPU (8 KiB each)")
     ap.add_argument("--ilp", type=int, default=int(os.environ.get("ACMI_ILP", "0")))
     ap.add_argument("--group-quads", type=int, default=0)
-    ap.add_argument("--kernel", type=int, default=-1, help="scan kernel: 1 LDS-tile table walk (default), 2 experimental anchor filter")
+    ap.add_argument("--kernel", type=int, default=-1, help="scan kernel: 1 LDS-tile table walk, 2 anchor filter, default automatic")
     ap.add_argument("--no-plant", action="store_true", help="analysis only: no planted hits (the reference's own benchmark has ~0 matches)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()

@@ -176,9 +176,11 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *   "slab_events"    per work-item event slots before the overflow path (default 8)
  *   "run_cap"        per work-item fix-up runs before the item is rescanned whole (default 8)
  *   "chunk_bytes"    force the work-item size (0 = automatic)            [any time]
- *   "kernel"         0 = plain global-table walk, 1 = LDS-tile table walk (default), 2 =
- *                    experimental anchor q-gram filter + exact walk of candidates (needs a
- *                    shortest pattern >= 11 B, else falls back to 1)                    [any time]
+ *   "kernel"         0 = plain global-table walk, 1 = LDS-tile table walk, 2 = anchor q-gram
+ *                    filter + exact table walk of the candidates (needs a shortest pattern
+ *                    >= 11 B and <= 12288 anchor q-grams, else falls back to 1), 3 = automatic
+ *                    (default): 2 when eligible, and back to 1 for the rest of the handle's life
+ *                    if a batch shows the text defeats the filter                        [any time]
  *   "ilp"            streams per lane in the LDS-tile kernel (1 or 2)    [any time]
  *   "group_quads"    16-byte loads per lane per fetch group, 4 or 8 (ILP 1) [any time]
  *   "persistent"     1 = one workgroup per CU, waves pull item batches from a counter; 0 = one
@@ -188,7 +190,7 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value);
 
 /* Numeric facts about the automaton and the last match call, e.g. "states",
  * "hot_states", "columns", "entry_bytes", "lds_image_bytes", "table_bytes",
- * "max_pattern_length", "items", "overflow_items", "kernel_used", "scan_ms", "total_ms". */
+ * "max_pattern_length", "items", "overflow_items", "walked_bytes", "kernel_used", "scan_ms", "total_ms". */
 int acmi_get_stat(const acmi_handle *h, const char *key, double *value);
 
 /* Run subsequent launches on this hipStream_t (passed as void*); NULL = the

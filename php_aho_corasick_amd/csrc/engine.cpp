@@ -62,7 +62,8 @@ struct acmi_handle {
     uint32_t slab_events = 8;
     uint32_t run_cap = 8;
     uint64_t chunk_opt = 0;
-    int kernel = 1;  // 0 plain global table, 1 LDS tile (default), 2 anchor filter (if eligible)
+    int kernel = 3;  // 0 plain global table, 1 LDS-tile walk, 2 anchor filter (if eligible), 3 automatic
+    bool anchor_off = false;  // automatic mode: the anchor filter lost on this handle's data, stay on the table walk
     int ilp = 1;
     int group_quads = 8;
     int persistent = -1;  // -1 automatic, 0 one workgroup per 1024 x ILP items, 1 persistent workgroups
@@ -92,7 +93,7 @@ struct acmi_handle {
     // a batch whose pipeline is enqueued but not yet completed (acmi_match_batch_device_begin/_end)
     bool in_flight = false;
     BatchArgs fly_args{};
-    uint64_t fly_max_items = 0;
+    uint64_t fly_max_items = 0, fly_blob_bytes = 0;
     int fly_find_all = 1;
     bool fly_trivial = false;
 
@@ -101,6 +102,7 @@ struct acmi_handle {
     int kernel_used = 0;
     uint64_t items = 0, chunk_used = 0;
     uint32_t overflow_items = 0;
+    uint64_t walked_bytes = 0;
 
     std::string last_error;
 };
@@ -318,8 +320,10 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
     launch_build_items(B, max_items, st);
 
     if (h->profile) HIPCHK(h, hipEventRecord(h->ev[1], st));
-    // the anchor filter needs a pattern set that allows it, else fall back to the LDS-tile table walk
-    const int kernel = (h->kernel == 2 && !fa.anchor_q) ? 1 : h->kernel;
+    // the anchor filter needs a pattern set that allows it; automatic mode also leaves it once a batch
+    // showed that this handle's text makes most items overflow their run lists (see run_batch_end)
+    const int kernel = h->kernel == 3 ? ((fa.anchor_q && !h->anchor_off) ? 2 : 1)
+                                      : ((h->kernel == 2 && !fa.anchor_q) ? 1 : h->kernel);
     h->kernel_used = kernel;
     HIPCHK(h, launch_scan(h->dA, B, max_items, int(fa.entry_bytes), kernel, int(fa.class_mode), h->ilp, h->group_quads, st));
     if (h->profile) HIPCHK(h, hipEventRecord(h->ev[2], st));
@@ -342,6 +346,7 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
     HIPCHK(h, hipGetLastError());
     h->fly_args = B;
     h->fly_max_items = max_items;
+    h->fly_blob_bytes = blob_bytes;
     h->fly_find_all = find_all;
     h->in_flight = true;
     return ACMI_OK;
@@ -366,6 +371,9 @@ int run_batch_end(acmi_handle *h) {
     const uint64_t total = h->pinned[1];
     h->items = h->pinned[2];
     h->overflow_items = n_ovf;
+    h->walked_bytes = uint64_t(reinterpret_cast<uint32_t *>(h->pinned)[7]) * 16;
+    // automatic mode: a batch of which more than a quarter had to be walked exactly defeats the filter
+    if (h->kernel == 3 && h->kernel_used == 2 && h->walked_bytes * 4 > h->fly_blob_bytes) h->anchor_off = true;
     if (h->profile) {
         float ms = 0;
         HIPCHK(h, hipEventElapsedTime(&ms, h->ev[1], h->ev[2]));
@@ -609,8 +617,9 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
         if (value < 0) return ACMI_E_ARG;
         h->chunk_opt = uint64_t(value);
     } else if (k == "kernel") {
-        if (value < 0 || value > 2) return ACMI_E_ARG;
+        if (value < 0 || value > 3) return ACMI_E_ARG;
         h->kernel = int(value);
+        h->anchor_off = false;
     } else if (k == "ilp") {
         if (value != 1 && value != 2) return ACMI_E_ARG;
         h->ilp = int(value);
@@ -651,6 +660,7 @@ int acmi_get_stat(const acmi_handle *h, const char *key, double *value) {
     else if (k == "items") *value = double(h->items);
     else if (k == "chunk_bytes") *value = double(h->chunk_used);
     else if (k == "overflow_items") *value = h->overflow_items;
+    else if (k == "walked_bytes") *value = double(h->walked_bytes);
     else if (k == "scan_ms") *value = h->scan_ms;
     else if (k == "kernel_used") *value = h->kernel_used;
     else if (k == "anchor_q") *value = fa.anchor_q;

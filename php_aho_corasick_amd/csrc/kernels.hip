@@ -341,9 +341,9 @@ struct EventRegs {
 // pos_bias + j.  Returns the state.
 template <typename E, int MODE>
 __device__ __forceinline__ uint32_t exact_range(const DevAutomaton &A, const BatchArgs &B, const uint16_t *cls_lds,
-                                                const uint8_t *tile, uint64_t item, const uint8_t *p, uint32_t j0,
-                                                uint32_t j1, uint32_t rep_from, uint32_t pos_bias, uint32_t s,
-                                                EventRegs &ev) {
+                                                const uint8_t *tile, uint32_t tile_rows, uint64_t item,
+                                                const uint8_t *p, uint32_t j0, uint32_t j1, uint32_t rep_from,
+                                                uint32_t pos_bias, uint32_t s, EventRegs &ev) {
     const uintptr_t base = reinterpret_cast<uintptr_t>(p);
     uint32_t word = 0;
 #pragma unroll 1
@@ -353,7 +353,7 @@ __device__ __forceinline__ uint32_t exact_range(const DevAutomaton &A, const Bat
         const uint32_t byte = (word >> (8u * uint32_t(a & 3u))) & 0xffu;
         const uint32_t coff = class_offset<E, MODE>(A, cls_lds, byte);
         uint32_t w = A.trap;
-        if (tile != nullptr && s < A.trap) w = *reinterpret_cast<const E *>(tile + s * A.row_bytes + coff);
+        if (s < tile_rows) w = *reinterpret_cast<const E *>(tile + s * A.row_bytes + coff);  // LDS-resident row
         if (w >= A.trap)
             w = *reinterpret_cast<const E *>(static_cast<const uint8_t *>(A.table) + uint64_t(s) * A.row_bytes + coff);
         s = w;
@@ -371,15 +371,19 @@ __device__ __forceinline__ uint32_t exact_range(const DevAutomaton &A, const Bat
 // entry state is unknown is entered from the root Lmax-1 bytes earlier -- exact for every pattern
 // ending inside the run -- and only events ending inside it (and inside the item's reporting range)
 // are recorded.  nr > run_cap means the run list overflowed: the whole item is walked.
+// Returns the number of bytes it walked exactly (statistic for the kernel choice).
 template <typename E, int MODE>
-__device__ __forceinline__ void run_epilogue(const DevAutomaton &A, const BatchArgs &B, const uint16_t *cls_lds,
-                                             const uint8_t *tile, uint64_t item, const ItemDesc &it, uint32_t nr) {
+__device__ __forceinline__ uint32_t run_epilogue(const DevAutomaton &A, const BatchArgs &B, const uint16_t *cls_lds,
+                                                 const uint8_t *tile, uint32_t tile_rows, uint64_t item,
+                                                 const ItemDesc &it, uint32_t nr) {
     const uint8_t *p = B.blob + (it.begin - it.warm);
     const uint32_t n = it.warm + it.len;
     const uint32_t pos_bias = it.pos0 - it.warm + 1u;
     EventRegs ev{0, 0};
+    uint32_t walked = 0;
     if (nr > B.run_cap) {
-        exact_range<E, MODE>(A, B, cls_lds, tile, item, p, 0, n, it.warm, pos_bias, 0u, ev);
+        walked = n;
+        exact_range<E, MODE>(A, B, cls_lds, tile, tile_rows, item, p, 0, n, it.warm, pos_bias, 0u, ev);
     } else {
         const uint4 *runs = B.runs + item * B.run_cap;
 #pragma unroll 1
@@ -387,12 +391,13 @@ __device__ __forceinline__ void run_epilogue(const DevAutomaton &A, const BatchA
             const uint4 run = runs[r];
             const uint32_t lo = run.x, hi = run.y;
             uint32_t st = run.z;
+            walked += hi - lo;
             if (st == 0xFFFFFFFFu) {  // entry state unknown: Lmax-1 bytes of silent warm-up from the root
                 EventRegs none{0, 0};
                 const uint32_t from = lo > B.warm_bytes ? lo - B.warm_bytes : 0u;
-                st = exact_range<E, MODE>(A, B, cls_lds, tile, item, p, from, lo, 0xFFFFFFFFu, 0u, 0u, none);
+                st = exact_range<E, MODE>(A, B, cls_lds, tile, tile_rows, item, p, from, lo, 0xFFFFFFFFu, 0u, 0u, none);
             }
-            exact_range<E, MODE>(A, B, cls_lds, tile, item, p, lo, hi, lo > it.warm ? lo : it.warm, pos_bias, st, ev);
+            exact_range<E, MODE>(A, B, cls_lds, tile, tile_rows, item, p, lo, hi, lo > it.warm ? lo : it.warm, pos_bias, st, ev);
         }
     }
     if (ev.n_ev) {
@@ -400,6 +405,15 @@ __device__ __forceinline__ void run_epilogue(const DevAutomaton &A, const BatchA
         B.rec_count[item] = ev.n_rec;
     }
     finish_item(B, item);
+    return walked;
+}
+
+// Sum `v` over the wave and add it (in units of 16 bytes) to counters[7]: how much of the batch the
+// exact path had to walk.  Must be reached by all lanes of the wave.
+__device__ __forceinline__ void account_walked(const BatchArgs &B, uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&B.counters[7], (v + 15u) >> 4);
 }
 
 template <typename E, int MODE, int ILP, int G>
@@ -560,6 +574,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchA
     }
 
     // ---- dense epilogue: every lane now walks the flagged runs of its own items exactly ----
+    uint32_t walked = 0;
 #pragma unroll
     for (int k = 0; k < ILP; ++k) {
         ItemDesc it;
@@ -567,10 +582,11 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchA
             const uint32_t n = it.warm + it.len;
             const uint32_t tail_lo = head[k] + (nq[k] << 4);
             if (tail_lo < n) append_run(B, item0 + k, tail_lo, n, poison[k] ? 0xFFFFFFFFu : s[k], nrun[k], run_hi[k]);
-            run_epilogue<E, MODE>(A, B, MODE == 1 ? nullptr : reinterpret_cast<const uint16_t *>(smem), tile, item0 + k, it,
-                                  nrun[k]);
+            walked += run_epilogue<E, MODE>(A, B, MODE == 1 ? nullptr : reinterpret_cast<const uint16_t *>(smem), tile, trap,
+                                            item0 + k, it, nrun[k]);
         }
     }
+    account_walked(B, walked);
     if (!B.persistent) break;
     }  // next batch of this wave
 }
@@ -592,6 +608,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchA
 // HBM.  Lines are read exactly like k_scan_lds (128 B per lane, double-buffered).
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kAnchorLdsBytes = 16384u * 8u;
+constexpr uint32_t kAnchorTileBytes = 30u * 1024u;  // what is left of the CU's 160 KiB for transition rows
 
 __device__ __forceinline__ uint32_t rotl32(uint32_t v, uint32_t r) { return __builtin_amdgcn_alignbit(v, v, 32u - r); }
 
@@ -655,12 +672,20 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     constexpr int G = 8;
     const uint64_t first = uint64_t(blockIdx.x) * kLdsThreads;
     if (first >= B.item_base[B.n_haystacks]) return;
+    // LDS: [anchor table 128 KiB | first rows of the transition tile, as many as fit in the rest] -- the
+    // tile only serves the exact epilogue (shallow states of its warm-up walks)
+    const uint32_t tile_rows = A.row_bytes ? (kAnchorTileBytes / A.row_bytes < A.trap ? kAnchorTileBytes / A.row_bytes : A.trap) : 0u;
     {
         const uint4 *src = static_cast<const uint4 *>(A.anchor_table);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
         for (uint32_t t = threadIdx.x; t < kAnchorLdsBytes / 16u; t += kLdsThreads) dst[t] = src[t];
+        const uint4 *tsrc = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(A.lds_image) + A.tile_offset);
+        uint4 *tdst = reinterpret_cast<uint4 *>(smem + kAnchorLdsBytes);
+        const uint32_t n16 = (tile_rows * A.row_bytes + 15u) >> 4;
+        for (uint32_t t = threadIdx.x; t < n16; t += kLdsThreads) tdst[t] = tsrc[t];
     }
     __syncthreads();
+    const uint8_t *tile = smem + kAnchorLdsBytes;
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t wave_first = first + __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u);
@@ -779,8 +804,10 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
 
     // ---- dense epilogue: lane k walks the flagged runs of item k ----
     ItemDesc it;
+    uint32_t walked = 0;
     if (decode_item(B, wave_first + lane, it))
-        run_epilogue<E, MODE>(A, B, nullptr, nullptr, wave_first + lane, it, nrun_vec);
+        walked = run_epilogue<E, MODE>(A, B, nullptr, tile, tile_rows, wave_first + lane, it, nrun_vec);
+    account_walked(B, walked);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -925,10 +952,11 @@ template <typename E, int MODE>
 static hipError_t launch_anchor_m(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, hipStream_t st) {
     const uint32_t blocks = uint32_t((max_items + kLdsThreads - 1) / kLdsThreads);
     auto go = [&](auto fn) {
+        const uint32_t lds = kAnchorLdsBytes + kAnchorTileBytes + 32u;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(kAnchorLdsBytes));
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(fn, dim3(blocks), dim3(kLdsThreads), kAnchorLdsBytes, st, A, B);
+        hipLaunchKernelGGL(fn, dim3(blocks), dim3(kLdsThreads), lds, st, A, B);
         return hipGetLastError();
     };
     if (A.anchor_q == 8) return go(k_scan_anchor<E, MODE, 2>);

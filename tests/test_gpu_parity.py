@@ -203,7 +203,7 @@ def test_random_against_oracle():
         ds = synth.ragged(f"S{seed}", seed, 20 + 13 * (seed % 7), 1, 3 + seed % 9, 33 + seed, 0, 700 + 97 * (seed % 4), alpha)
         o = Oracle("port")
         o.add_patterns((ds.pat_blob, ds.pat_off))
-        res = resource_for(ds, kernel=[1, 2, 0][seed % 3], ilp=1 + seed % 2, chunk_bytes=[0, 48, 512][seed % 3], slab_events=[8, 1, 2][seed % 3])
+        res = resource_for(ds, kernel=[1, 2, 0, 3][seed % 4], ilp=1 + seed % 2, chunk_bytes=[0, 48, 512][seed % 3], slab_events=[8, 1, 2][seed % 3])
         for find_all in (True, False):
             pe, re_ = o.match_batch(ds.hay_blob, ds.hay_off, find_all)
             for path in (host_match, device_match):
@@ -229,4 +229,31 @@ def test_device_entry_rejects_bad_offsets():
         batch.match_device(res, d_blob, bad)
     assert e.value.status == E_ARG
     assert batch.match_device(res, d_blob, good) == 0      # the handle stays usable
+    api.ahocorasick_deinit(res)
+
+
+def test_automatic_kernel_choice_and_fallback():
+    """kernel=3 (default): anchor filter for long-pattern sets, LDS-tile walk otherwise, and a handle
+    leaves the filter for good once a batch defeats it (text made of pattern fragments)."""
+    ds = synth.g2()
+    res = resource_for(ds)
+    host_match(res, ds)
+    assert res.stat("kernel_used") == 2
+    api.ahocorasick_deinit(res)
+    res = resource_for(synth.r1())
+    host_match(res, synth.r1())
+    assert res.stat("kernel_used") == 1                  # short patterns: not eligible
+    api.ahocorasick_deinit(res)
+    # adversarial text: every haystack is a pattern's first 15 bytes repeated -> anchors everywhere
+    ds = synth.g2(64)
+    frag = np.frombuffer(ds.pattern(5)[:15] * 600, dtype=np.uint8)[:8192]
+    ds.hay_blob[:] = np.tile(frag, 64)
+    o = Oracle("port")
+    o.add_patterns((ds.pat_blob, ds.pat_off))
+    res = resource_for(ds)
+    for expect_kernel in (2, 1, 1):
+        p, r = host_match(res, ds)
+        pe, re_ = o.match_batch(ds.hay_blob, ds.hay_off)
+        assert np.array_equal(p, pe) and np.array_equal(r, re_)
+        assert res.stat("kernel_used") == expect_kernel
     api.ahocorasick_deinit(res)
