@@ -49,6 +49,7 @@ struct BatchArgs {
     uint32_t run_cap;
     uint32_t poison_quads;       // ceil(max_pattern_length / 16): quads flagged after a lost state
     uint32_t persistent;         // 1: one workgroup per CU, waves pull item batches from counters[1]
+    uint32_t wave_items;         // k_scan_anchor: items a wave takes per batch (1..64)
 };
 
 }  // namespace acmi

@@ -228,7 +228,7 @@ int ensure_device(acmi_handle *h) {
     return ACMI_OK;
 }
 
-uint32_t choose_chunk(const acmi_handle *h, uint64_t blob_bytes) {
+uint32_t choose_chunk(const acmi_handle *h, uint64_t blob_bytes, int kernel) {
     const uint32_t warm = h->aut.flat().max_pattern_length ? h->aut.flat().max_pattern_length - 1 : 0;
     if (h->chunk_opt) {
         uint64_t c = (h->chunk_opt + 15) & ~uint64_t(15);
@@ -239,6 +239,8 @@ uint32_t choose_chunk(const acmi_handle *h, uint64_t blob_bytes) {
     const uint64_t target_items = 256ull * 1024 * 2;
     uint64_t c0 = (blob_bytes + target_items - 1) / target_items;
     uint64_t cmin = std::max<uint64_t>(256, (uint64_t(warm) * 8 + 127) & ~uint64_t(127));
+    // the anchor kernel streams an item 8 KiB (one wave step) at a time: smaller items idle its lanes
+    if (kernel == 2) cmin = std::max<uint64_t>(cmin, 8192);
     uint64_t c = std::max<uint64_t>(cmin, (c0 + 127) & ~uint64_t(127));
     return uint32_t(std::min<uint64_t>(c, 1u << 30));
 }
@@ -267,7 +269,12 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
     h->fly_trivial = false;
 
     const FlatAutomaton &fa = h->aut.flat();
-    const uint32_t chunk = choose_chunk(h, blob_bytes);
+    // the anchor filter needs a pattern set that allows it; automatic mode also leaves it once a batch
+    // showed that this handle's text defeats it (see run_batch_end)
+    const int kernel = h->kernel == 3 ? ((fa.anchor_q && !h->anchor_off) ? 2 : 1)
+                                      : ((h->kernel == 2 && !fa.anchor_q) ? 1 : h->kernel);
+    h->kernel_used = kernel;
+    const uint32_t chunk = choose_chunk(h, blob_bytes, kernel);
     const uint64_t max_items = blob_bytes / chunk + nh;
     const uint32_t K = std::max<uint32_t>(1, h->slab_events);
     h->chunk_used = chunk;
@@ -311,6 +318,11 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
     B.poison_quads = std::max<uint32_t>(1, (fa.max_pattern_length + 15) / 16);
     // persistent workgroups pay off once a CU would otherwise run several workgroups back to back
     // (measured: 1 KiB items -18 %, 2 x 8 KiB per lane +2.5 %)
+    {   // anchor kernel: items per wave batch -- 64 when the batch can give every wave that many
+        const uint64_t est = std::max<uint64_t>(1, blob_bytes / chunk);
+        const uint64_t waves = 256ull * 16;
+        B.wave_items = uint32_t(std::min<uint64_t>(64, std::max<uint64_t>(1, est / waves)));
+    }
     B.persistent = h->persistent >= 0 ? uint32_t(h->persistent != 0)
                                       : uint32_t(blob_bytes / chunk > 3ull * 256 * 1024 * uint64_t(h->ilp));
 
@@ -320,11 +332,6 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
     launch_build_items(B, max_items, st);
 
     if (h->profile) HIPCHK(h, hipEventRecord(h->ev[1], st));
-    // the anchor filter needs a pattern set that allows it; automatic mode also leaves it once a batch
-    // showed that this handle's text makes most items overflow their run lists (see run_batch_end)
-    const int kernel = h->kernel == 3 ? ((fa.anchor_q && !h->anchor_off) ? 2 : 1)
-                                      : ((h->kernel == 2 && !fa.anchor_q) ? 1 : h->kernel);
-    h->kernel_used = kernel;
     HIPCHK(h, launch_scan(h->dA, B, max_items, int(fa.entry_bytes), kernel, int(fa.class_mode), h->ilp, h->group_quads, st));
     if (h->profile) HIPCHK(h, hipEventRecord(h->ev[2], st));
 

@@ -645,7 +645,7 @@ __device__ __forceinline__ void anchor_open(const DevAutomaton &A, const BatchAr
     cur.chunks = 1;
     cur.n = cur.head = cur.nq = 0;
     cur.qp = static_cast<const uint4 *>(A.anchor_table);
-    cur.valid = k < 64u && decode_item_uniform(B, wave_first + k, it);
+    cur.valid = k < B.wave_items && decode_item_uniform(B, wave_first + k, it);
     if (cur.valid) {
         const uint8_t *p = B.blob + (it.begin - it.warm);
         cur.n = it.warm + it.len;
@@ -670,8 +670,7 @@ template <typename E, int MODE, int QW>
 __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, BatchArgs B) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int G = 8;
-    const uint64_t first = uint64_t(blockIdx.x) * kLdsThreads;
-    if (first >= B.item_base[B.n_haystacks]) return;
+    if (uint64_t(blockIdx.x) * (B.persistent ? 1u : kLdsThreads / 64u) * B.wave_items >= B.item_base[B.n_haystacks]) return;
     // LDS: [anchor table 128 KiB | first rows of the transition tile, as many as fit in the rest] -- the
     // tile only serves the exact epilogue (shallow states of its warm-up walks)
     const uint32_t tile_rows = A.row_bytes ? (kAnchorTileBytes / A.row_bytes < A.trap ? kAnchorTileBytes / A.row_bytes : A.trap) : 0u;
@@ -688,13 +687,26 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     const uint8_t *tile = smem + kAnchorLdsBytes;
 
     const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t wave_first = first + __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u);
     const uint32_t mul = A.anchor_mul;
     const uint32_t q = QW * 4u, m_min = A.min_pattern_length, l_max = A.max_pattern_length;
+    const uint64_t total_items = B.item_base[B.n_haystacks];
+
+    // Persistent mode: waves pull batches of 64 items from counters[1] until none are left, so one
+    // wave's latency-bound epilogue overlaps the other waves' streaming.
+    for (;;) {
+    // a wave takes `wave_items` (1..64) consecutive items per batch: 64 for big batches, fewer when
+    // there are not enough items to give every wave of the chip 64 of them
+    uint32_t batch_first = (blockIdx.x * (kLdsThreads / 64u) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * B.wave_items;
+    if (B.persistent) {
+        if (lane == 0) batch_first = atomicAdd(&B.counters[1], B.wave_items);
+        batch_first = __builtin_amdgcn_readfirstlane(batch_first);
+    }
+    if (batch_first >= total_items) break;
+    const uint64_t wave_first = batch_first;
 
     AnchorCursor ld, sc;  // load cursor runs one task ahead of the scan cursor
     anchor_open(A, B, wave_first, 0, ld);
-    if (!ld.valid) return;
+    if (!ld.valid) break;
     sc = ld;
     uint32_t nrun = 0, run_hi = 0;  // run list of the item being scanned (wave-uniform)
     uint32_t nrun_vec = 0;          // lane k: run count of item wave_first + k
@@ -805,9 +817,11 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     // ---- dense epilogue: lane k walks the flagged runs of item k ----
     ItemDesc it;
     uint32_t walked = 0;
-    if (decode_item(B, wave_first + lane, it))
+    if (lane < B.wave_items && decode_item(B, wave_first + lane, it))
         walked = run_epilogue<E, MODE>(A, B, nullptr, tile, tile_rows, wave_first + lane, it, nrun_vec);
     account_walked(B, walked);
+    if (!B.persistent) break;
+    }  // next batch of this wave
 }
 
 // ------------------------------------------------------------------------------------------
@@ -950,7 +964,9 @@ static hipError_t launch_lds_m(const DevAutomaton &A, const BatchArgs &B, uint64
 
 template <typename E, int MODE>
 static hipError_t launch_anchor_m(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, hipStream_t st) {
-    const uint32_t blocks = uint32_t((max_items + kLdsThreads - 1) / kLdsThreads);
+    const uint64_t per_block = uint64_t(kLdsThreads / 64u) * B.wave_items;
+    const uint64_t want = (max_items + per_block - 1) / per_block;
+    const uint32_t blocks = B.persistent ? uint32_t(std::min<uint64_t>(want, uint64_t(num_cus()))) : uint32_t(want);
     auto go = [&](auto fn) {
         const uint32_t lds = kAnchorLdsBytes + kAnchorTileBytes + 32u;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
