@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libacmi.so")
+# ACMI_LIBRARY selects another build of the same ABI (A/B kernel comparisons inside one process launch)
+LIB_PATH = os.environ.get("ACMI_LIBRARY") or os.path.join(HERE, "libacmi.so")
 
 OK, E_INVALID, E_NOT_INIT, E_FINALIZED, E_ARG, E_NOMEM, E_DEVICE, E_NO_DEVICE, E_TOO_LARGE = \
     0, -1, -2, -3, -4, -5, -6, -7, -8

@@ -299,17 +299,18 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
             uint32_t mul = 0x9E3779B1u;
             for (int attempt = 0; attempt < 512 && fa.anchor_q == 0; ++attempt, mul = mul * 0x2545F491u + 0x6B43A9B5u) {
                 mul = (mul | 1u) & 0xFFFFFFu;
-                std::fill(tab.begin(), tab.end(), uint16_t(0));
+                std::vector<uint8_t> used(kAnchorBuckets, 0);
+                for (uint32_t b = 0; b < kAnchorBuckets; ++b) std::fill_n(&tab[size_t(b) * 4], 4, anchor_empty(b));
                 bool ok = true;
                 for (const auto &k : keys) {
                     const uint32_t h = anchor_hash(k.data(), q / 4, mul);
-                    const uint16_t fp = uint16_t(h >> 16);   // fingerprint: high half
-                    if (fp == 0) { ok = false; break; }      // 0 means "empty slot": take another seed
-                    uint16_t *b = &tab[size_t((h >> 3) & (kAnchorBuckets - 1)) * 4];  // bucket: bits 3..16
-                    int slot = 0;
-                    while (slot < 4 && b[slot] != 0 && b[slot] != fp) ++slot;
-                    if (slot == 4) { ok = false; break; }
-                    b[slot] = fp;
+                    const uint16_t fp = uint16_t(h >> 16);                   // fingerprint: high half
+                    const uint32_t bucket = (h >> 3) & (kAnchorBuckets - 1);  // bits 3..16
+                    uint16_t *b = &tab[size_t(bucket) * 4];
+                    uint32_t slot = 0;
+                    while (slot < used[bucket] && b[slot] != fp) ++slot;
+                    if (slot == 4) { ok = false; break; }  // bucket overflow: take another seed
+                    if (slot == used[bucket]) b[used[bucket]++] = fp;
                 }
                 if (ok) {
                     fa.anchor_q = q;

@@ -67,7 +67,7 @@ struct FlatAutomaton {
     // ---- anchor filter (optional front end of the scan, see kernels.hip k_scan_anchor) ----
     // Every occurrence of a pattern of length >= q + 3 contains a 4-byte-aligned text dword within
     // its first 4 bytes; the q bytes from there are P[o, o+q) for o in 0..3.  anchor_table holds a
-    // 16-bit fingerprint of each such q-gram: kAnchorBuckets buckets x 4 slots, 0 = empty.
+    // 16-bit fingerprint of each such q-gram: kAnchorBuckets buckets x 4 slots (empty: anchor_empty()).
     uint32_t min_pattern_length = 0;
     uint32_t anchor_q = 0;        // 0 = not eligible; else 8, 12 or 16 bytes
     uint32_t anchor_mul = 0;      // odd multiplier of the window hash (seed that gave no bucket overflow)
@@ -79,22 +79,20 @@ constexpr uint32_t kAnchorBucketBits = 14;
 constexpr uint32_t kAnchorBuckets = 1u << kAnchorBucketBits;  // x 4 slots x 2 B = 128 KiB of LDS
 constexpr uint32_t kAnchorMaxKeys = 12288;
 
-// Window hash shared by the host builder and the device kernel.  Each little-endian dword d of the
-// q-gram is folded to 24 bits (d ^ d >> 11) and multiplied by a 24-bit odd constant -- one
-// full-rate v_mul_u32_u24 on the device; a 32-bit v_mul_lo_u32 costs 8x as much and dominated the
-// kernel -- then the products are rotated by 11 bits per position and xor-ed together.
-inline uint32_t anchor_mix(uint32_t d, uint32_t mul) {
-    return ((d ^ (d >> 11)) & 0xFFFFFFu) * (mul & 0xFFFFFFu);  // low 32 bits of a 24 x 24 product
-}
+// Window hash shared by the host builder and the device kernel: fold each little-endian dword of
+// the q-gram (d ^ d >> 11, so that its top byte reaches the low 24 bits), then chain them with
+// 24-bit multiply-adds, h = (h mod 2^24) * mul + fold(next): one full-rate v_mad_u32_u24 per dword on
+// the device (a 32-bit v_mul_lo_u32 costs 8x as much and dominated the first version of the kernel).
+// mul odd makes every step a bijection of the 24 bits it keeps.  Bucket = bits 3..16, fingerprint =
+// bits 16..31: they share bit 16, so a slot value whose bit 0 differs from the bucket's top bit can
+// never equal a window's fingerprint there -- that is the "empty" marker (anchor_empty).
+inline uint32_t anchor_fold(uint32_t d) { return d ^ (d >> 11); }
 inline uint32_t anchor_hash(const uint32_t *words, uint32_t n_words, uint32_t mul) {
-    uint32_t h = 0;
-    for (uint32_t i = 0; i < n_words; ++i) {
-        const uint32_t m = anchor_mix(words[i], mul);
-        const uint32_t r = (11u * i) & 31u;
-        h ^= r ? ((m << r) | (m >> (32u - r))) : m;
-    }
+    uint32_t h = anchor_fold(words[0]);
+    for (uint32_t i = 1; i < n_words; ++i) h = (h & 0xFFFFFFu) * (mul & 0xFFFFFFu) + anchor_fold(words[i]);
     return h;
 }
+inline uint16_t anchor_empty(uint32_t bucket) { return uint16_t(((bucket >> (kAnchorBucketBits - 1)) & 1u) ^ 1u); }
 
 class Automaton {
 public:

@@ -39,6 +39,7 @@ struct BatchArgs {
     uint32_t slab_events;        // K: event slots per work item
     uint32_t first_only;         // findAll == false
     uint32_t *item_hay;          // per item: haystack index
+    uint4 *item_rec;             // per item: {scan offset lo, hi | warm << 16, scan bytes, pos0} (k_scan_anchor)
     uint32_t *ev_count;          // per item: events seen
     uint64_t *rec_count;         // per item: records those events expand to
     uint2 *slab;                 // per item: K x {pos, state}
@@ -47,6 +48,7 @@ struct BatchArgs {
     // main loop -> epilogue hand-over inside k_scan_lds: byte runs of an item that need the exact path
     uint4 *runs;                 // per item: run_cap x {lo, hi, entry state or ~0, -}: bytes [lo, hi) in item scan coordinates
     uint32_t run_cap;
+    uint32_t *run_count;         // per item: runs appended by k_scan_anchor, walked by k_walk_runs (> run_cap: whole item)
     uint32_t poison_quads;       // ceil(max_pattern_length / 16): quads flagged after a lost state
     uint32_t persistent;         // 1: one workgroup per CU, waves pull item batches from counters[1]
     uint32_t wave_items;         // k_scan_anchor: items a wave takes per batch (1..64)

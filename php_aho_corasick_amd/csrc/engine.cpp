@@ -66,6 +66,7 @@ struct acmi_handle {
     bool anchor_off = false;  // automatic mode: the anchor filter lost on this handle's data, stay on the table walk
     int ilp = 1;
     int group_quads = 8;
+    int wave_items = 0;   // 0 automatic, else 1..64 items per wave batch of the anchor kernel
     int persistent = -1;  // -1 automatic, 0 one workgroup per 1024 x ILP items, 1 persistent workgroups
     int profile = 0;
 
@@ -79,8 +80,8 @@ struct acmi_handle {
     DevBuf d_table, d_lds, d_class, d_own, d_dict, d_cnt, d_plen, d_anchor;
 
     // workspace (grow-only)
-    DevBuf d_blob, d_off, d_nitems, d_item_base, d_item_hay, d_zero, d_rec_base, d_slab, d_ovf, d_counters,
-        d_scan_tmp, d_prefix, d_out, d_runs;
+    DevBuf d_blob, d_off, d_nitems, d_item_base, d_item_hay, d_item_rec, d_zero, d_rec_base, d_slab, d_ovf, d_counters,
+        d_scan_tmp, d_prefix, d_out, d_runs, d_run_count;
     uint64_t *pinned = nullptr;  // [0] total records, [1] overflow items
 
     // last result
@@ -282,6 +283,7 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
     HIPCHK(h, h->d_nitems.ensure((nh + 1) * 8));
     HIPCHK(h, h->d_item_base.ensure((nh + 1) * 8));
     HIPCHK(h, h->d_item_hay.ensure(max_items * 4));
+    HIPCHK(h, h->d_item_rec.ensure(max_items * 16));
     // one zero-filled block per call: [counters 64 B | rec_count (items+1) x 8 | ev_count items x 4]
     const size_t rec_cnt_off = 64, ev_off = rec_cnt_off + (max_items + 1) * 8;
     const size_t zero_bytes = ev_off + max_items * 4;
@@ -291,6 +293,7 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
     HIPCHK(h, h->d_ovf.ensure(max_items * 4));
     const uint32_t Q = std::max<uint32_t>(1, h->run_cap);
     HIPCHK(h, h->d_runs.ensure(max_items * Q * 16));
+    HIPCHK(h, h->d_run_count.ensure(max_items * 4));
     HIPCHK(h, h->d_scan_tmp.ensure(scan_temp_elems(std::max<uint64_t>(max_items + 1, nh + 1)) * 8 * 2));
     HIPCHK(h, hipMemsetAsync(h->d_zero.p, 0, zero_bytes, st));
     uint8_t *zero = h->d_zero.as<uint8_t>();
@@ -308,12 +311,14 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
     B.slab_events = K;
     B.first_only = find_all ? 0u : 1u;
     B.item_hay = h->d_item_hay.as<uint32_t>();
+    B.item_rec = h->d_item_rec.as<uint4>();
     B.ev_count = d_ev;
     B.rec_count = d_rec_cnt;
     B.slab = h->d_slab.as<uint2>();
     B.overflow_list = h->d_ovf.as<uint32_t>();
     B.counters = d_counters;
     B.runs = h->d_runs.as<uint4>();
+    B.run_count = h->d_run_count.as<uint32_t>();
     B.run_cap = Q;
     B.poison_quads = std::max<uint32_t>(1, (fa.max_pattern_length + 15) / 16);
     // persistent workgroups pay off once a CU would otherwise run several workgroups back to back
@@ -322,6 +327,7 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
         const uint64_t est = std::max<uint64_t>(1, blob_bytes / chunk);
         const uint64_t waves = 256ull * 16;
         B.wave_items = uint32_t(std::min<uint64_t>(64, std::max<uint64_t>(1, est / waves)));
+        if (h->wave_items > 0) B.wave_items = uint32_t(h->wave_items);
     }
     B.persistent = h->persistent >= 0 ? uint32_t(h->persistent != 0)
                                       : uint32_t(blob_bytes / chunk > 3ull * 256 * 1024 * uint64_t(h->ilp));
@@ -334,6 +340,8 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
     if (h->profile) HIPCHK(h, hipEventRecord(h->ev[1], st));
     HIPCHK(h, launch_scan(h->dA, B, max_items, int(fa.entry_bytes), kernel, int(fa.class_mode), h->ilp, h->group_quads, st));
     if (h->profile) HIPCHK(h, hipEventRecord(h->ev[2], st));
+    // the anchor kernel only flags byte runs; their exact walk is a kernel of its own (one thread per item)
+    if (kernel == 2) HIPCHK(h, launch_walk_runs(h->dA, B, max_items, int(fa.entry_bytes), int(fa.class_mode), st));
 
     if (!find_all) launch_first_only(B, st);
     exclusive_scan_u64(d_rec_cnt, h->d_rec_base.as<uint64_t>(), max_items + 1, h->d_scan_tmp.as<uint64_t>(), st);
@@ -348,7 +356,7 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
     const uint64_t cap = h->d_out.cap / 16;
     launch_expand(h->dA, B, max_items, h->d_rec_base.as<uint64_t>(), h->d_out.p, cap, st);
     if (find_all) launch_refill(h->dA, B, max_items, int(fa.entry_bytes), h->d_rec_base.as<uint64_t>(), h->d_out.p, cap, st);
-    HIPCHK(h, hipMemcpyAsync(h->pinned, d_counters, 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(h->pinned, d_counters, 64, hipMemcpyDeviceToHost, st));
     if (h->profile) HIPCHK(h, hipEventRecord(h->ev[4], st));
     HIPCHK(h, hipGetLastError());
     h->fly_args = B;
@@ -378,7 +386,8 @@ int run_batch_end(acmi_handle *h) {
     const uint64_t total = h->pinned[1];
     h->items = h->pinned[2];
     h->overflow_items = n_ovf;
-    h->walked_bytes = uint64_t(reinterpret_cast<uint32_t *>(h->pinned)[7]) * 16;
+    h->walked_bytes = 0;  // counters[7..15]: k_scan_lds adds to [7], k_walk_runs spreads its workgroups over [8..15]
+    for (int i = 7; i < 16; ++i) h->walked_bytes += uint64_t(reinterpret_cast<uint32_t *>(h->pinned)[i]) * 16;
     // automatic mode: a batch of which more than a quarter had to be walked exactly defeats the filter
     if (h->kernel == 3 && h->kernel_used == 2 && h->walked_bytes * 4 > h->fly_blob_bytes) h->anchor_off = true;
     if (h->profile) {
@@ -476,8 +485,8 @@ int acmi_destroy(acmi_handle *h) {
         (void)hipSetDevice(h->dev_id);
         if (h->stream) (void)hipStreamSynchronize(h->stream);
         for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_blob,
-                          &h->d_off, &h->d_nitems, &h->d_item_base, &h->d_item_hay, &h->d_zero,
-                          &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_scan_tmp, &h->d_prefix, &h->d_out, &h->d_runs})
+                          &h->d_off, &h->d_nitems, &h->d_item_base, &h->d_item_hay, &h->d_item_rec, &h->d_zero,
+                          &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_scan_tmp, &h->d_prefix, &h->d_out, &h->d_runs, &h->d_run_count})
             b->release();
         for (auto &evt : h->ev)
             if (evt) (void)hipEventDestroy(evt);
@@ -633,6 +642,9 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
     } else if (k == "group_quads") {
         if (value != 4 && value != 8) return ACMI_E_ARG;
         h->group_quads = int(value);
+    } else if (k == "wave_items") {
+        if (value < 0 || value > 64) return ACMI_E_ARG;
+        h->wave_items = int(value);
     } else if (k == "persistent") {
         h->persistent = value < 0 ? -1 : (value ? 1 : 0);
     } else if (k == "profile") {

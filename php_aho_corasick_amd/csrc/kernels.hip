@@ -78,6 +78,16 @@ __device__ __forceinline__ T const_load(const T *p) {
     return *reinterpret_cast<const __attribute__((address_space(4))) T *>(reinterpret_cast<uintptr_t>(p));
 }
 
+// Haystack bytes are read exactly once: a non-temporal load (global_load ... nt) keeps them from
+// displacing the transition table in L2 and, measured, streams 11-13 % faster than a plain load
+// (k_scan_anchor 0.79 -> 0.69 ms per 4 GiB, k_stream_read 6.35 -> 7.07 TB/s).  Only for fully
+// coalesced accesses: a line that is fetched in pieces by several instructions is not retained.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 stream_load(const uint4 *p) {
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // decode_item for a wave-uniform item index, all loads scalar
 __device__ __forceinline__ bool decode_item_uniform(const BatchArgs &B, uint64_t i, ItemDesc &it) {
     if (i >= const_load(B.item_base + B.n_haystacks)) return false;
@@ -94,9 +104,29 @@ __device__ __forceinline__ bool decode_item_uniform(const BatchArgs &B, uint64_t
     return true;
 }
 
+// Packed work-item record for k_scan_anchor: everything its streaming loop and epilogue need about an
+// item in one 16-byte load, so that opening an item costs no chain of dependent loads
+// (item_hay -> offsets, item_base).  x, y[15:0]: blob offset of the first scanned byte (begin - warm);
+// y[31:16]: warm (<= 1023); z: scanned bytes (warm + len, >= 1); w: pos0.
+__device__ __forceinline__ uint4 pack_item(const ItemDesc &it) {
+    const uint64_t off = it.begin - it.warm;
+    return make_uint4(uint32_t(off), uint32_t(off >> 32) | (it.warm << 16), it.warm + it.len, it.pos0);
+}
+__device__ __forceinline__ void unpack_item(uint32_t x, uint32_t y, uint32_t z, uint32_t w, ItemDesc &it) {
+    it.warm = y >> 16;
+    it.begin = (uint64_t(y & 0xFFFFu) << 32 | x) + it.warm;
+    it.len = z - it.warm;
+    it.pos0 = w;
+    it.hay = 0;  // not carried: the scan kernels do not need it
+}
+
 __global__ void k_build_items(BatchArgs B) {
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i < B.item_base[B.n_haystacks]) B.item_hay[i] = find_haystack(B, i);
+    if (i >= B.item_base[B.n_haystacks]) return;
+    B.item_hay[i] = find_haystack(B, i);
+    ItemDesc it;
+    decode_item(B, i, it);
+    B.item_rec[i] = pack_item(it);
 }
 
 __device__ __forceinline__ bool is_final(const DevAutomaton &A, uint32_t s) {
@@ -484,7 +514,8 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchA
 #pragma unroll
             for (int r = 0; r < G; ++r) {
                 const uint32_t q = g * G + r;
-                buf[k][r] = qp[k][q < last[k] ? q : last[k]];
+                buf[k][r] = qp[k][q < last[k] ? q : last[k]];  // plain load: a lane takes its 128-byte line in 8 pieces, and
+                                                               // non-temporal lines are not kept for the later ones (2.3x slower)
             }
     };
     auto scan_group = [&](const uint4 (&buf)[ILP][G], uint32_t g) {
@@ -608,22 +639,34 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchA
 // HBM.  Lines are read exactly like k_scan_lds (128 B per lane, double-buffered).
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kAnchorLdsBytes = 16384u * 8u;
-constexpr uint32_t kAnchorTileBytes = 30u * 1024u;  // what is left of the CU's 160 KiB for transition rows
 
-__device__ __forceinline__ uint32_t rotl32(uint32_t v, uint32_t r) { return __builtin_amdgcn_alignbit(v, v, 32u - r); }
-
-// per-dword mixing of the window hash (automaton.hpp anchor_mix): fold to 24 bits, v_mul_u32_u24
-__device__ __forceinline__ uint32_t anchor_mix_dev(uint32_t d, uint32_t mul) { return __umul24(d ^ (d >> 11), mul); }
+// window hash (automaton.hpp anchor_hash): fold each dword, then a multiply-add chain in 24-bit
+// arithmetic -- one full-rate v_mad_u32_u24 per dword after the first
+__device__ __forceinline__ uint32_t anchor_fold_dev(uint32_t d) { return d ^ (d >> 11); }
+__device__ __forceinline__ uint32_t anchor_mad(uint32_t h, uint32_t mul, uint32_t f) {
+    uint32_t r;  // spelled out: from `__umul24(h, mul) + f` hipcc makes a quarter-rate v_mad_u64_u32 half of the time
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(h), "s"(mul), "v"(f));
+    return r;
+}
 
 // Probe one window: bucket = bits 3..16 of the hash (so the LDS byte address is one v_and),
-// fingerprint = its high half.  Nonzero iff one of the bucket's four fingerprints equals the
-// window's: (v - 0x00010001) & ~v has bit 15 / 31 set where a halfword of v is zero.
-__device__ __forceinline__ uint32_t anchor_probe(const uint8_t *smem, uint32_t h) {
-    const uint2 b = *reinterpret_cast<const uint2 *>(smem + (h & 0x1FFF8u));
-    const uint32_t ff = __builtin_amdgcn_perm(h, h, 0x03020302u);  // fingerprint in both halves
-    const uint32_t x = b.x ^ ff, y = b.y ^ ff;
-    return ((x - 0x00010001u) & ~x) | ((y - 0x00010001u) & ~y);
+// fingerprint = its high half.  The bucket's four 16-bit slots minus the fingerprint (packed
+// subtract, the fingerprint broadcast by op_sel) are folded into a running packed minimum: some
+// halfword of `z` is zero afterwards iff a slot equalled the fingerprint.
+// The table sits at LDS address 0 (the kernel has no other LDS object and checks it), so the masked
+// hash IS the ds_read address; going through the generic `smem` pointer costs a v_add per window.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) u32x2 *LdsU2Ptr;
+__device__ __forceinline__ u32x2 anchor_bucket(uint32_t h) { return *reinterpret_cast<LdsU2Ptr>(h & 0x1FFF8u); }
+__device__ __forceinline__ uint32_t anchor_compare(u32x2 b, uint32_t h, uint32_t z) {
+    uint32_t x, y;
+    asm("v_pk_sub_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(x) : "v"(b.x), "v"(h));
+    asm("v_pk_sub_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(y) : "v"(b.y), "v"(h));
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(z) : "v"(z), "v"(x));
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(z) : "v"(z), "v"(y));
+    return z;
 }
+__device__ __forceinline__ bool has_zero_half(uint32_t z) { return ((z - 0x00010001u) & ~z & 0x80008000u) != 0; }
 
 // One wave streams one work item at a time, 8 KiB per step, with fully coalesced loads (lane l holds
 // quads r*64 + l).  Windows that begin in the previous quad get its last hashed dwords from the
@@ -637,32 +680,35 @@ struct AnchorCursor {      // wave-uniform position in the wave's (item, chunk) 
     bool valid;
 };
 
-__device__ __forceinline__ void anchor_open(const DevAutomaton &A, const BatchArgs &B, uint64_t wave_first,
-                                            uint32_t k, AnchorCursor &cur) {
-    ItemDesc it;
+// `rec` = lane k's packed record of item wave_first + k (z == 0: no such item)
+__device__ __forceinline__ void anchor_open(const DevAutomaton &A, const BatchArgs &B, const uint4 &rec, uint32_t k,
+                                            AnchorCursor &cur) {
     cur.k = k;
     cur.c = 0;
     cur.chunks = 1;
     cur.n = cur.head = cur.nq = 0;
     cur.qp = static_cast<const uint4 *>(A.anchor_table);
-    cur.valid = k < B.wave_items && decode_item_uniform(B, wave_first + k, it);
-    if (cur.valid) {
-        const uint8_t *p = B.blob + (it.begin - it.warm);
-        cur.n = it.warm + it.len;
-        const uint32_t mis = uint32_t(-reinterpret_cast<uintptr_t>(p)) & 15u;
-        cur.head = mis < cur.n ? mis : cur.n;
-        cur.nq = (cur.n - cur.head) >> 4;
-        if (cur.nq) cur.qp = reinterpret_cast<const uint4 *>(p + cur.head);
-        cur.chunks = cur.nq ? (cur.nq + 511u) >> 9 : 1u;  // 8 KiB = 512 quads per wave step
-    }
+    cur.valid = false;
+    if (k >= B.wave_items) return;
+    ItemDesc it;
+    const uint32_t z = __builtin_amdgcn_readlane(rec.z, k);
+    if (z == 0) return;
+    unpack_item(__builtin_amdgcn_readlane(rec.x, k), __builtin_amdgcn_readlane(rec.y, k), z, 0u, it);
+    cur.valid = true;
+    const uint8_t *p = B.blob + (it.begin - it.warm);
+    cur.n = z;
+    const uint32_t mis = uint32_t(-reinterpret_cast<uintptr_t>(p)) & 15u;
+    cur.head = mis < cur.n ? mis : cur.n;
+    cur.nq = (cur.n - cur.head) >> 4;
+    if (cur.nq) cur.qp = reinterpret_cast<const uint4 *>(p + cur.head);
+    cur.chunks = cur.nq ? (cur.nq + 511u) >> 9 : 1u;  // 8 KiB = 512 quads per wave step
 }
 
-// advance to the next (item, chunk) task of the wave; false when the wave's 64 items are done
-__device__ __forceinline__ bool anchor_next(const DevAutomaton &A, const BatchArgs &B, uint64_t wave_first,
-                                            AnchorCursor &cur) {
+// advance to the next (item, chunk) task of the wave; false when the wave's items are done
+__device__ __forceinline__ bool anchor_next(const DevAutomaton &A, const BatchArgs &B, const uint4 &rec, AnchorCursor &cur) {
     if (!cur.valid) return false;
     if (++cur.c < cur.chunks) return true;
-    anchor_open(A, B, wave_first, cur.k + 1u, cur);
+    anchor_open(A, B, rec, cur.k + 1u, cur);
     return cur.valid;
 }
 
@@ -671,28 +717,20 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int G = 8;
     if (uint64_t(blockIdx.x) * (B.persistent ? 1u : kLdsThreads / 64u) * B.wave_items >= B.item_base[B.n_haystacks]) return;
-    // LDS: [anchor table 128 KiB | first rows of the transition tile, as many as fit in the rest] -- the
-    // tile only serves the exact epilogue (shallow states of its warm-up walks)
-    const uint32_t tile_rows = A.row_bytes ? (kAnchorTileBytes / A.row_bytes < A.trap ? kAnchorTileBytes / A.row_bytes : A.trap) : 0u;
-    {
+    {   // LDS: the anchor table, 128 KiB
         const uint4 *src = static_cast<const uint4 *>(A.anchor_table);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
         for (uint32_t t = threadIdx.x; t < kAnchorLdsBytes / 16u; t += kLdsThreads) dst[t] = src[t];
-        const uint4 *tsrc = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(A.lds_image) + A.tile_offset);
-        uint4 *tdst = reinterpret_cast<uint4 *>(smem + kAnchorLdsBytes);
-        const uint32_t n16 = (tile_rows * A.row_bytes + 15u) >> 4;
-        for (uint32_t t = threadIdx.x; t < n16; t += kLdsThreads) tdst[t] = tsrc[t];
     }
     __syncthreads();
-    const uint8_t *tile = smem + kAnchorLdsBytes;
+    if (static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint8_t *)smem)) != 0u) __builtin_trap();
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t mul = A.anchor_mul;
     const uint32_t q = QW * 4u, m_min = A.min_pattern_length, l_max = A.max_pattern_length;
     const uint64_t total_items = B.item_base[B.n_haystacks];
 
-    // Persistent mode: waves pull batches of 64 items from counters[1] until none are left, so one
-    // wave's latency-bound epilogue overlaps the other waves' streaming.
+    // Persistent mode: waves pull batches of items from counters[1] until none are left.
     for (;;) {
     // a wave takes `wave_items` (1..64) consecutive items per batch: 64 for big batches, fewer when
     // there are not enough items to give every wave of the chip 64 of them
@@ -704,15 +742,22 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     if (batch_first >= total_items) break;
     const uint64_t wave_first = batch_first;
 
+    // lane k holds the packed record of item wave_first + k for the whole batch: opening an item is
+    // three v_readlane, and the epilogue needs no table look-ups either
+    uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+    if (lane < B.wave_items && wave_first + lane < total_items) rec = B.item_rec[wave_first + lane];
     AnchorCursor ld, sc;  // load cursor runs one task ahead of the scan cursor
-    anchor_open(A, B, wave_first, 0, ld);
+    anchor_open(A, B, rec, 0, ld);
     if (!ld.valid) break;
     sc = ld;
     uint32_t nrun = 0, run_hi = 0;  // run list of the item being scanned (wave-uniform)
     uint32_t nrun_vec = 0;          // lane k: run count of item wave_first + k
-    uint32_t prev_tail[QW - 1];     // hashed last dwords of the previous chunk's last line (uniform)
+    // carry[n-1] = hash prefix over the LAST n dwords of a quad (n = 1..QW-1): what a window that
+    // begins there and ends in the next quad continues from.  `tail` = the carries of the previous
+    // wave-load (its lane 63 is the left neighbour of lane 0).
+    uint32_t tail[QW - 1];
 #pragma unroll
-    for (int i = 0; i < QW - 1; ++i) prev_tail[i] = 0;
+    for (int i = 0; i < QW - 1; ++i) tail[i] = 0;
     if (sc.head) append_run(B, wave_first + sc.k, 0, (sc.head + l_max) < sc.n ? sc.head + l_max : sc.n, 0u, nrun, run_hi);
 
     uint4 buf0[G], buf1[G];
@@ -720,42 +765,82 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     // of contiguous memory (8 whole 128-byte lines).  A micro-benchmark of the access patterns alone
     // (tools/micro/stream_pattern.hip) gives 4.6 TB/s when each lane reads its own 128-byte line --
     // the line is split over 8 wave-instructions of 64 different lines each -- against 6.4 TB/s coalesced.
-    auto load_task = [&](uint4 (&buf)[G], const AnchorCursor &cur) {
+    auto load_quad = [&](const AnchorCursor &cur, int r) -> uint4 {
         const uint32_t last = cur.nq ? cur.nq - 1u : 0u;
-#pragma unroll
-        for (int r = 0; r < G; ++r) {
-            const uint32_t qi = cur.c * 512u + uint32_t(r) * 64u + lane;
-            buf[r] = cur.qp[qi < last ? qi : last];
-        }
+        const uint32_t qi = cur.c * 512u + uint32_t(r) * 64u + lane;
+        return stream_load(cur.qp + (qi < last ? qi : last));
     };
-    auto scan_task = [&](const uint4 (&buf)[G]) {
+    auto load_task = [&](uint4 (&buf)[G], const AnchorCursor &cur) {
+#pragma unroll
+        for (int r = 0; r < G; ++r) buf[r] = load_quad(cur, r);
+    };
+    auto scan_task = [&](uint4 (&buf)[G]) {
+        uint32_t z[G];  // per quad: packed minimum of (slot - fingerprint) over the 4 windows ENDING in it
+        uint32_t zall = 0xFFFFFFFFu;
+        if (sc.c == 0) {  // first chunk of an item: nothing to the left of quad 0 (wave-uniform)
+#pragma unroll
+            for (int i = 0; i < QW - 1; ++i) tail[i] = 0;
+        }
+        // hashes of the 4 windows ending in quad r
+        auto hash_quad = [&](int r, uint32_t (&h4)[4]) {
+            uint32_t f[4];
+            f[0] = anchor_fold_dev(buf[r].x);
+            f[1] = anchor_fold_dev(buf[r].y);
+            f[2] = anchor_fold_dev(buf[r].z);
+            f[3] = anchor_fold_dev(buf[r].w);
+            uint32_t mine[QW - 1], left[QW - 1];
+#pragma unroll
+            for (int n = 1; n < QW; ++n) {  // prefix over this quad's last n dwords
+                uint32_t h = f[4 - n];
+#pragma unroll
+                for (int i = 4 - n + 1; i < 4; ++i) h = anchor_mad(h, mul, f[i]);
+                mine[n - 1] = h;
+                // lane 0 <- lane 63 of the previous wave-load (rotate), lanes 1..63 <- lane l-1 of this one
+                const uint32_t wrap = __builtin_amdgcn_mov_dpp(tail[n - 1], 0x13C /* wave_ror:1 */, 0xf, 0xf, false);
+                left[n - 1] = __builtin_amdgcn_update_dpp(wrap, h, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+            }
+#pragma unroll
+            for (int n = 1; n < QW; ++n) tail[n - 1] = mine[n - 1];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {  // window ending at dword w: QW-1-w dwords of the left quad, then f[..w]
+                const int need = QW - 1 - w;
+                uint32_t h;
+                int i0;
+                if (need > 0) { h = left[need - 1]; i0 = 0; } else { h = f[w - (QW - 1)]; i0 = w - (QW - 1) + 1; }
+#pragma unroll
+                for (int i = i0; i <= w; ++i) h = anchor_mad(h, mul, f[i]);
+                h4[w] = h;
+            }
+        };
+        // Software pipeline over the quads, pinned with sched_barriers: the four bucket reads of quad r
+        // are in flight while quad r-1's buckets are compared, so a wave never sits on LDS latency
+        // (hipcc on its own put an lgkmcnt(0) right behind every ds_read).
+        uint32_t hh[2][4];
+        u32x2 bb[2][4];
+#pragma unroll
+        for (int r = 0; r <= G; ++r) {
+            if (r < G) {
+                hash_quad(r, hh[r & 1]);
+                // the quad is consumed: reload its registers with the same quad of the task two steps
+                // ahead at once, so that the wave keeps close to 16 KiB of loads in flight
+                buf[r] = load_quad(ld, r);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) bb[r & 1][w] = anchor_bucket(hh[r & 1][w]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (r > 0) {
+                uint32_t zz = 0xFFFFFFFFu;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) zz = anchor_compare(bb[(r - 1) & 1][w], hh[(r - 1) & 1][w], zz);
+                z[r - 1] = zz;
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(zall) : "v"(zall), "v"(zz));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         uint32_t hits = 0;  // bit r: some window ENDING in this lane's quad r hit
+        if (__builtin_expect(__any(has_zero_half(zall)), 0)) {
 #pragma unroll
-        for (int r = 0; r < G; ++r) {
-            // hashed dwords: m[QW-1..QW+2] this quad's, m[0..QW-2] the end of the previous quad, which
-            // lives in lane l-1 (DPP wave shift) or, for lane 0, in lane 63 of the previous wave-load
-            uint32_t m[QW + 3];
-            m[QW - 1] = anchor_mix_dev(buf[r].x, mul);
-            m[QW + 0] = anchor_mix_dev(buf[r].y, mul);
-            m[QW + 1] = anchor_mix_dev(buf[r].z, mul);
-            m[QW + 2] = anchor_mix_dev(buf[r].w, mul);
-#pragma unroll
-            for (int i = 0; i < QW - 1; ++i) {
-                const uint32_t mine = m[4 + i];  // one of this quad's last QW-1 hashed dwords
-                const uint32_t from_left = __builtin_amdgcn_update_dpp(0u, mine, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-                const bool first_of_item = r == 0 && sc.c == 0;
-                m[i] = lane == 0 ? (first_of_item ? 0u : prev_tail[i]) : from_left;
-                prev_tail[i] = __builtin_amdgcn_readlane(mine, 63);
-            }
-            uint32_t acc = 0;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {  // window ending at dword w of this quad = m[w .. w+QW-1]
-                uint32_t h = m[w];
-#pragma unroll
-                for (int i = 1; i < QW; ++i) h ^= rotl32(m[w + i], (11u * i) & 31u);
-                acc |= anchor_probe(smem, h);
-            }
-            hits |= (acc & 0x80008000u) ? (1u << r) : 0u;
+            for (int r = 0; r < G; ++r) hits |= has_zero_half(z[r]) ? (1u << r) : 0u;
         }
         if (__builtin_expect(__any(hits != 0), 0)) {  // rare, wave-uniform: flag where a match anchored there can end
 #pragma unroll 1
@@ -790,7 +875,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
             nrun_vec = lane == sc.k ? nrun : nrun_vec;
         }
         const uint32_t k_before = sc.k;
-        const bool more = anchor_next(A, B, wave_first, sc);
+        const bool more = anchor_next(A, B, rec, sc);
         if (more && sc.k != k_before) {
             nrun = 0;
             run_hi = 0;
@@ -799,29 +884,103 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
         return more;
     };
 
-    // Loads are issued unconditionally (past the last task the cursor is an invalid item whose
-    // loads fall on the anchor table): a load under a branch would make hipcc drain vmcnt(0) at
-    // every use of the other buffer instead of counting.
+    // Two tasks are in flight: buf0 / buf1 hold tasks t and t+1, and each quad's registers are reloaded
+    // with task t+2 as soon as the quad has been hashed (scan_task).  Loads are unconditional -- past
+    // the last task the cursor is an invalid item whose loads fall on the anchor table -- because a load
+    // under a branch makes hipcc drain vmcnt(0) instead of counting.
     load_task(buf0, ld);
+    anchor_next(A, B, rec, ld);
+    load_task(buf1, ld);
     for (;;) {
-        anchor_next(A, B, wave_first, ld);
-        load_task(buf1, ld);
+        anchor_next(A, B, rec, ld);
         scan_task(buf0);
         if (!close_or_advance()) break;
-        anchor_next(A, B, wave_first, ld);
-        load_task(buf0, ld);
+        anchor_next(A, B, rec, ld);
         scan_task(buf1);
         if (!close_or_advance()) break;
     }
 
-    // ---- dense epilogue: lane k walks the flagged runs of item k ----
-    ItemDesc it;
-    uint32_t walked = 0;
-    if (lane < B.wave_items && decode_item(B, wave_first + lane, it))
-        walked = run_epilogue<E, MODE>(A, B, nullptr, tile, tile_rows, wave_first + lane, it, nrun_vec);
-    account_walked(B, walked);
+    // hand the run lists over to k_walk_runs (lane k: item wave_first + k)
+    if (rec.z != 0) B.run_count[wave_first + lane] = nrun_vec;
     if (!B.persistent) break;
     }  // next batch of this wave
+}
+
+// ------------------------------------------------------------------------------------------
+// k_walk_runs: exact walk of the byte runs k_scan_anchor flagged, one thread per work item.
+//
+// The anchor kernel used to do this itself, lane k walking item k after the wave had streamed its 64
+// items: a chain of ~26 dependent memory round trips (run list, haystack dwords, 11 cold table rows)
+// during which the wave streams nothing -- 0.15 ms of a 0.97 ms kernel for one hit per 8 KiB.  As a
+// kernel of its own the same walks run at full occupancy, all 2^19 of them at once, and the latency
+// chain is paid once instead of once per wave batch.  The first rows of the transition tile are
+// staged in LDS (same image as k_scan_lds uses) so that only deep states go to L2.  Items without runs
+// (run_count 0) cost one coalesced 4-byte load.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kWalkThreads = 1024;
+constexpr uint32_t kWalkTileBytes = 64u * 1024u;  // two workgroups per CU: every lane slot of the chip walks at once
+
+template <typename E, int MODE>
+__global__ __launch_bounds__(kWalkThreads) void k_walk_runs(DevAutomaton A, BatchArgs B) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint64_t total_items = B.item_base[B.n_haystacks];
+    if (uint64_t(blockIdx.x) * kWalkThreads >= total_items) return;
+    __shared__ uint32_t s_walked;
+    if (threadIdx.x == 0) s_walked = 0;
+    const uint64_t item = uint64_t(blockIdx.x) * kWalkThreads + threadIdx.x;
+    // issue the item's own loads first: they are in flight while the tile is staged
+    uint32_t nr = 0;
+    uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+    if (item < total_items) {
+        nr = B.run_count[item];
+        rec = B.item_rec[item];
+    }
+    const uint32_t tile_rows = A.row_bytes ? (kWalkTileBytes / A.row_bytes < A.trap ? kWalkTileBytes / A.row_bytes : A.trap) : 0u;
+    {
+        const uint4 *tsrc = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(A.lds_image) + A.tile_offset);
+        uint4 *tdst = reinterpret_cast<uint4 *>(smem);
+        const uint32_t n16 = (tile_rows * A.row_bytes + 15u) >> 4;  // <= 4096: at most 4 per thread, loaded back to back
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t t = threadIdx.x + uint32_t(u) * kWalkThreads;
+            v[u] = tsrc[t < n16 ? t : 0u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t t = threadIdx.x + uint32_t(u) * kWalkThreads;
+            if (t < n16) tdst[t] = v[u];
+        }
+    }
+    __syncthreads();
+    uint32_t walked = 0;
+    if (nr != 0) {
+        ItemDesc it;
+        unpack_item(rec.x, rec.y, rec.z, rec.w, it);
+        walked = run_epilogue<E, MODE>(A, B, nullptr, smem, tile_rows, item, it, nr);
+    }
+    // statistic: bytes walked, one atomic per workgroup (8192 same-address device atomics, one per
+    // wave, took 0.1 ms on their own: they serialise at ~12 ns each)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) walked += __shfl_xor(walked, d, 64);
+    if ((threadIdx.x & 63u) == 0 && walked) atomicAdd(&s_walked, (walked + 15u) >> 4);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_walked) atomicAdd(&B.counters[8u + (blockIdx.x & 7u)], s_walked);
+}
+
+hipError_t launch_walk_runs(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,
+                            hipStream_t st) {
+    if (max_items == 0) return hipSuccess;
+    const uint32_t blocks = uint32_t((max_items + kWalkThreads - 1) / kWalkThreads);
+    const uint32_t lds = kWalkTileBytes;
+    auto go = [&](auto fn) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(fn, dim3(blocks), dim3(kWalkThreads), lds, st, A, B);
+        return hipGetLastError();
+    };
+    if (entry_bytes == 2) return class_mode == 1 ? go(k_walk_runs<uint16_t, 1>) : go(k_walk_runs<uint16_t, 0>);
+    return class_mode == 1 ? go(k_walk_runs<uint32_t, 1>) : go(k_walk_runs<uint32_t, 0>);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -904,7 +1063,7 @@ __global__ void k_stream_read(const uint4 *src, uint64_t n16, uint32_t *sink) {
     uint32_t acc = 0;
     const uint64_t stride = uint64_t(gridDim.x) * blockDim.x;
     for (uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n16; i += stride) {
-        const uint4 v = src[i];
+        const uint4 v = stream_load(src + i);
         acc ^= v.x ^ v.y ^ v.z ^ v.w;
     }
     if (acc == 0x9e3779b9u) sink[0] = acc;  // practically never: keeps the loads alive
@@ -968,7 +1127,7 @@ static hipError_t launch_anchor_m(const DevAutomaton &A, const BatchArgs &B, uin
     const uint64_t want = (max_items + per_block - 1) / per_block;
     const uint32_t blocks = B.persistent ? uint32_t(std::min<uint64_t>(want, uint64_t(num_cus()))) : uint32_t(want);
     auto go = [&](auto fn) {
-        const uint32_t lds = kAnchorLdsBytes + kAnchorTileBytes + 32u;
+        const uint32_t lds = kAnchorLdsBytes + 32u;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return e;

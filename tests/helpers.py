@@ -70,12 +70,10 @@ class FlatTables:
         """The device's window test (k_scan_anchor), restated: hash q bytes, look the fingerprint up."""
         q = self.anchor_q
         words = np.frombuffer(window[:q], dtype="<u4").astype(np.uint64)
-        h = 0
-        for i, w in enumerate(words):
-            d = int(w)
-            m = (((d ^ (d >> 11)) & 0xFFFFFF) * (self.anchor_mul & 0xFFFFFF)) & 0xFFFFFFFF
-            r = (11 * i) & 31
-            h ^= ((m << r) | (m >> (32 - r))) & 0xFFFFFFFF if r else m
+        fold = [(int(w) ^ (int(w) >> 11)) & 0xFFFFFFFF for w in words]
+        h = fold[0]
+        for f in fold[1:]:
+            h = ((h & 0xFFFFFF) * (self.anchor_mul & 0xFFFFFF) + f) & 0xFFFFFFFF
         return int(h >> 16) in [int(x) for x in self.anchor[(h >> 3) & 0x3FFF]]
 
     def is_final(self, s: int) -> bool:

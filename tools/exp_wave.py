@@ -1,0 +1,21 @@
+"""Experiment: anchor kernel, items per wave batch x persistent workgroups (epilogue overlap)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from php_aho_corasick_amd import api, batch, synth
+plant = "--no-plant" not in sys.argv
+ds = synth.bench_batch(8192, planted=plant)
+res = api.ahocorasick_init([{"id": k, "value": ds.pattern(k)} for k in range(ds.n_patterns)])
+res.set_option("profile", 1)
+nh = 1 << 19
+d_blob = torch.from_numpy(ds.hay_blob).cuda().repeat(nh // 8192).contiguous()
+d_off = torch.arange(nh + 1, dtype=torch.int64, device="cuda") * 8192
+batch.bind_current_stream(res)
+for rep in range(2):
+    for pers, wi in ((0, 0), (1, 64), (1, 32), (1, 16), (1, 8), (1, 4), (0, 32), (0, 16)):
+        res.set_option("persistent", pers); res.set_option("wave_items", wi)
+        ms = []
+        for _ in range(8):
+            batch.match_device(res, d_blob, d_off)
+            ms.append(res.stat("scan_ms"))
+        print(f"rep {rep} plant {plant} persistent {pers} wave_items {wi}: kernel {np.mean(ms[2:]):.4f} ms  records {res.stat('records')}", flush=True)

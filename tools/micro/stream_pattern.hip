@@ -3,6 +3,9 @@
 // scan kernels' occupancy (1 block per CU).
 //   mode 0: lane-per-haystack  -- lane streams its own 8 KiB region, 128 B (8 x dwordx4) per step, D lines in flight
 //   mode 1: wave-per-haystack  -- lane l reads line l of the wave's current 8 KiB region (contiguous per wave)
+//   mode 2: wave-per-haystack, coalesced -- lane l reads quads r*64 + l; a wave owns 64 CONSECUTIVE items (k_scan_anchor)
+//   mode 3: as 2, but the wave's items are strided by the number of waves (all waves sweep one moving window)
+//   mode 4: as 2, persistent: 256 workgroups, waves pull batches of 64 items from a counter
 // build: hipcc --offload-arch=gfx950 -O3 -o stream_pattern stream_pattern.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -33,6 +36,28 @@ __global__ __launch_bounds__(1024) void k(const uint4 *src, uint64_t n_items, ui
                     acc ^= v.x ^ v.y ^ v.z ^ v.w;
                     const uint32_t nl = line + D + d;
                     buf[d][r] = p[(nl < 64 ? nl : 63) * 8 + r];
+                }
+            }
+        }
+    } else if (MODE == 2 || MODE == 3) {
+        const uint64_t wave_id = uint64_t(blockIdx.x) * 16 + (threadIdx.x >> 6);
+        const uint64_t n_waves = uint64_t(gridDim.x) * 16;
+        const uint64_t first = MODE == 2 ? wave_id * 64 : wave_id, step = MODE == 2 ? 1 : n_waves;
+        if (first >= n_items) return;
+        uint4 buf[D][8];
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) buf[d][r] = src[(first + d * step) * 512 + r * 64 + lane];
+        for (uint32_t it = 0; it < 64; it += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const uint4 v = buf[d][r];
+                    acc ^= v.x ^ v.y ^ v.z ^ v.w;
+                    const uint32_t ni = it + D + d;
+                    buf[d][r] = src[(first + (ni < 64 ? ni : 63) * step) * 512 + r * 64 + lane];
                 }
             }
         }
@@ -86,6 +111,10 @@ int main() {
         run<0, 2>(d, n_items, sink, lds);
         run<1, 1>(d, n_items, sink, lds);
         run<1, 2>(d, n_items, sink, lds);
+        run<2, 1>(d, n_items, sink, lds);
+        run<2, 2>(d, n_items, sink, lds);
+        run<3, 1>(d, n_items, sink, lds);
+        run<3, 2>(d, n_items, sink, lds);
     }
     return 0;
 }
