@@ -330,6 +330,46 @@ __device__ __forceinline__ void append_run(const BatchArgs &B, uint64_t item, ui
     last_hi = hi;
 }
 
+// Run hand-over of k_scan_anchor, where a wave handles ONE item together.  Runs are STAGED in LDS
+// (2 KiB per wave: 128 x {item k | index << 8, lo, hi, entry}) and written to the items' run lists
+// after the streaming loop.  A global store inside that loop cost 0.09 ms per 4 GiB with one hit per
+// 8 KiB: the store shares the in-order vmcnt queue with the haystack prefetches, and every wait behind it
+// sat out the store's round trip.
+struct RunStage {
+    uint4 *slots;        // this wave's 128 staging slots (LDS)
+    uint32_t count;      // staged entries (wave-uniform)
+    bool mergeable;      // the last staged entry is the current item's last run
+};
+constexpr uint32_t kStageSlots = 128;
+
+__device__ __forceinline__ void stage_flush(const BatchArgs &B, uint64_t wave_first, RunStage &st, uint32_t lane) {
+    for (uint32_t i = lane; i < st.count; i += 64u) {
+        const uint4 e = st.slots[i];
+        B.runs[(wave_first + (e.x & 0xffu)) * B.run_cap + (e.x >> 8)] = make_uint4(e.y, e.z, e.w, 0u);
+    }
+    st.count = 0;
+    st.mergeable = false;
+}
+
+// same bookkeeping as append_run (n, last_hi stay in scalar registers); k = item index inside the wave batch
+__device__ __forceinline__ void append_run_wave(const BatchArgs &B, uint64_t wave_first, RunStage &st, uint32_t k,
+                                                uint32_t lo, uint32_t hi, uint32_t entry, uint32_t &n,
+                                                uint32_t &last_hi, uint32_t lane) {
+    if (n > B.run_cap) return;
+    if (n > 0 && last_hi == lo && st.mergeable) {
+        if (lane == 0) st.slots[st.count - 1].z = hi;  // adjacent: extend the previous run
+    } else {
+        if (n < B.run_cap) {
+            if (st.count == kStageSlots) stage_flush(B, wave_first, st, lane);
+            if (lane == 0) st.slots[st.count] = make_uint4(k | (n << 8), lo, hi, entry);
+            ++st.count;
+            st.mergeable = true;
+        }
+        ++n;
+    }
+    last_hi = hi;
+}
+
 // 4 haystack bytes -> 4 column offsets (one per byte lane of the result), SWAR3 mode.
 template <typename E>
 __device__ __forceinline__ uint32_t swar_columns(const DevAutomaton &A, uint32_t d) {
@@ -374,12 +414,25 @@ __device__ __forceinline__ uint32_t exact_range(const DevAutomaton &A, const Bat
                                                 const uint8_t *tile, uint32_t tile_rows, uint64_t item,
                                                 const uint8_t *p, uint32_t j0, uint32_t j1, uint32_t rep_from,
                                                 uint32_t pos_bias, uint32_t s, EventRegs &ev) {
+    // Haystack bytes come in aligned 16-byte blocks, the next block requested one block ahead: one
+    // exposed memory round trip per call instead of one per dword (the walks are latency chains).
+    // A block is only touched when it holds a needed byte, so it lies inside a mapped page.
     const uintptr_t base = reinterpret_cast<uintptr_t>(p);
-    uint32_t word = 0;
+    if (j0 >= j1) return s;
+    uintptr_t blk = (base + j0) & ~uintptr_t(15);
+    const uintptr_t end = base + j1;
+    uint4 cur = *reinterpret_cast<const uint4 *>(blk), nxt = cur;
+    if (blk + 16 < end) nxt = *reinterpret_cast<const uint4 *>(blk + 16);
 #pragma unroll 1
     for (uint32_t j = j0; j < j1; ++j) {
         const uintptr_t a = base + j;
-        if (j == j0 || (a & 3u) == 0) word = *reinterpret_cast<const uint32_t *>(a & ~uintptr_t(3));
+        if (j != j0 && (a & 15u) == 0) {
+            cur = nxt;
+            blk += 16;
+            if (blk + 16 < end) nxt = *reinterpret_cast<const uint4 *>(blk + 16);
+        }
+        const uint32_t sel = uint32_t(a >> 2) & 3u;
+        const uint32_t word = sel == 0 ? cur.x : sel == 1 ? cur.y : sel == 2 ? cur.z : cur.w;
         const uint32_t byte = (word >> (8u * uint32_t(a & 3u))) & 0xffu;
         const uint32_t coff = class_offset<E, MODE>(A, cls_lds, byte);
         uint32_t w = A.trap;
@@ -717,7 +770,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int G = 8;
     if (uint64_t(blockIdx.x) * (B.persistent ? 1u : kLdsThreads / 64u) * B.wave_items >= B.item_base[B.n_haystacks]) return;
-    {   // LDS: the anchor table, 128 KiB
+    {   // LDS: the anchor table, 128 KiB; behind it 2 KiB of run staging per wave
         const uint4 *src = static_cast<const uint4 *>(A.anchor_table);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
         for (uint32_t t = threadIdx.x; t < kAnchorLdsBytes / 16u; t += kLdsThreads) dst[t] = src[t];
@@ -750,6 +803,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     anchor_open(A, B, rec, 0, ld);
     if (!ld.valid) break;
     sc = ld;
+    RunStage stage{reinterpret_cast<uint4 *>(smem + kAnchorLdsBytes) + (threadIdx.x >> 6) * kStageSlots, 0u, false};
     uint32_t nrun = 0, run_hi = 0;  // run list of the item being scanned (wave-uniform)
     uint32_t nrun_vec = 0;          // lane k: run count of item wave_first + k
     // carry[n-1] = hash prefix over the LAST n dwords of a quad (n = 1..QW-1): what a window that
@@ -758,7 +812,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     uint32_t tail[QW - 1];
 #pragma unroll
     for (int i = 0; i < QW - 1; ++i) tail[i] = 0;
-    if (sc.head) append_run(B, wave_first + sc.k, 0, (sc.head + l_max) < sc.n ? sc.head + l_max : sc.n, 0u, nrun, run_hi);
+    if (sc.head) append_run_wave(B, wave_first, stage, sc.k, 0, (sc.head + l_max) < sc.n ? sc.head + l_max : sc.n, 0u, nrun, run_hi, lane);
 
     uint4 buf0[G], buf1[G];
     // Lane l holds quads r*64 + l (r = 0..7) of the wave's current 8 KiB: every wave-load covers 1 KiB
@@ -837,28 +891,41 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        uint32_t hits = 0;  // bit r: some window ENDING in this lane's quad r hit
-        if (__builtin_expect(__any(has_zero_half(zall)), 0)) {
+        // Rare, wave-uniform: flag where a match anchored at a hit window can end.
+        const uint64_t cand = __ballot(has_zero_half(zall));
+        auto flag = [&](uint32_t r, uint32_t l) {
+            const uint32_t qi = sc.c * 512u + r * 64u + l;
+            if (qi >= sc.nq) return;
+            // first window of the group starts (QW-1) dwords before quad qi, the last one 12 B later
+            const int32_t j_first = int32_t(sc.head + (qi << 4)) - int32_t(q - 4u);
+            int32_t lo = j_first + int32_t(m_min) - 4;
+            uint32_t hi = uint32_t(j_first + 12 + int32_t(l_max));
+            if (lo < 0) lo = 0;
+            if (hi > sc.n) hi = sc.n;
+            if (nrun > 0 && uint32_t(lo) < run_hi) lo = int32_t(run_hi);  // keep runs disjoint and ascending
+            if (uint32_t(lo) < hi) append_run_wave(B, wave_first, stage, sc.k, uint32_t(lo), hi, 0xFFFFFFFFu, nrun, run_hi, lane);
+        };
+        if (__builtin_expect(cand != 0, 0)) {
+            if ((cand & (cand - 1)) == 0) {
+                // one lane hit (the usual case): its eight z values go through the scalar unit -- 8 v_readlane
+                // instead of ~40 vector instructions for the whole wave
+                const uint32_t l = uint32_t(__builtin_ctzll(cand));
 #pragma unroll
-            for (int r = 0; r < G; ++r) hits |= has_zero_half(z[r]) ? (1u << r) : 0u;
-        }
-        if (__builtin_expect(__any(hits != 0), 0)) {  // rare, wave-uniform: flag where a match anchored there can end
-#pragma unroll 1
-            for (uint32_t r = 0; r < uint32_t(G); ++r) {  // r outer, lane inner: ascending quad order
-                uint64_t who = __ballot((hits >> r) & 1u);
-                while (who != 0) {
-                    const uint32_t l = uint32_t(__builtin_ctzll(who));
-                    who &= who - 1;
-                    const uint32_t qi = sc.c * 512u + r * 64u + l;
-                    if (qi < sc.nq) {
-                        // first window of the group starts (QW-1) dwords before quad qi, the last one 12 B later
-                        const int32_t j_first = int32_t(sc.head + (qi << 4)) - int32_t(q - 4u);
-                        int32_t lo = j_first + int32_t(m_min) - 4;
-                        uint32_t hi = uint32_t(j_first + 12 + int32_t(l_max));
-                        if (lo < 0) lo = 0;
-                        if (hi > sc.n) hi = sc.n;
-                        if (nrun > 0 && uint32_t(lo) < run_hi) lo = int32_t(run_hi);  // keep runs disjoint and ascending
-                        if (uint32_t(lo) < hi) append_run(B, wave_first + sc.k, uint32_t(lo), hi, 0xFFFFFFFFu, nrun, run_hi);
+                for (int r = 0; r < G; ++r)
+                    if (has_zero_half(__builtin_amdgcn_readlane(z[r], l))) flag(uint32_t(r), l);
+            } else {
+                uint32_t hits = 0;  // bit r: some window ENDING in this lane's quad r hit
+#pragma unroll
+                for (int r = 0; r < G; ++r) hits |= has_zero_half(z[r]) ? (1u << r) : 0u;
+                uint32_t rmask = 0;
+                for (uint64_t w = cand; w != 0; w &= w - 1) rmask |= __builtin_amdgcn_readlane(hits, uint32_t(__builtin_ctzll(w)));
+                while (rmask != 0) {  // ascending quad order (r outer, lane inner) keeps the run list sorted
+                    const uint32_t r = uint32_t(__builtin_ctz(rmask));
+                    rmask &= rmask - 1;
+                    uint64_t who = __ballot((hits >> r) & 1u);
+                    while (who != 0) {
+                        flag(r, uint32_t(__builtin_ctzll(who)));
+                        who &= who - 1;
                     }
                 }
             }
@@ -871,7 +938,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
             uint32_t lo = sc.head + (sc.nq << 4) + m_min;
             lo = lo > q ? lo - q : 0u;
             if (nrun > 0 && lo < run_hi) lo = run_hi;
-            if (lo < sc.n && sc.head + (sc.nq << 4) < sc.n) append_run(B, wave_first + sc.k, lo, sc.n, 0xFFFFFFFFu, nrun, run_hi);
+            if (lo < sc.n && sc.head + (sc.nq << 4) < sc.n) append_run_wave(B, wave_first, stage, sc.k, lo, sc.n, 0xFFFFFFFFu, nrun, run_hi, lane);
             nrun_vec = lane == sc.k ? nrun : nrun_vec;
         }
         const uint32_t k_before = sc.k;
@@ -879,7 +946,8 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
         if (more && sc.k != k_before) {
             nrun = 0;
             run_hi = 0;
-            if (sc.head) append_run(B, wave_first + sc.k, 0, (sc.head + l_max) < sc.n ? sc.head + l_max : sc.n, 0u, nrun, run_hi);
+            stage.mergeable = false;
+            if (sc.head) append_run_wave(B, wave_first, stage, sc.k, 0, (sc.head + l_max) < sc.n ? sc.head + l_max : sc.n, 0u, nrun, run_hi, lane);
         }
         return more;
     };
@@ -901,6 +969,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     }
 
     // hand the run lists over to k_walk_runs (lane k: item wave_first + k)
+    stage_flush(B, wave_first, stage, lane);
     if (rec.z != 0) B.run_count[wave_first + lane] = nrun_vec;
     if (!B.persistent) break;
     }  // next batch of this wave
@@ -1127,7 +1196,7 @@ static hipError_t launch_anchor_m(const DevAutomaton &A, const BatchArgs &B, uin
     const uint64_t want = (max_items + per_block - 1) / per_block;
     const uint32_t blocks = B.persistent ? uint32_t(std::min<uint64_t>(want, uint64_t(num_cus()))) : uint32_t(want);
     auto go = [&](auto fn) {
-        const uint32_t lds = kAnchorLdsBytes + 32u;
+        const uint32_t lds = kAnchorLdsBytes + (kLdsThreads / 64u) * kStageSlots * 16u;  // table + run staging = 160 KiB
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return e;
