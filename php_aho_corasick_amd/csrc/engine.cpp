@@ -82,7 +82,7 @@ struct acmi_handle {
     // workspace (grow-only)
     DevBuf d_blob, d_off, d_nitems, d_item_base, d_item_hay, d_item_rec, d_zero, d_rec_base, d_slab, d_ovf, d_counters,
         d_scan_tmp, d_prefix, d_out, d_runs, d_run_count;
-    uint64_t *pinned = nullptr;  // [0] total records, [1] overflow items
+    uint64_t *pinned = nullptr;  // host copy of the device counters block (64 B)
 
     // last result
     uint64_t last_total = 0;
@@ -332,8 +332,8 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
     B.persistent = h->persistent >= 0 ? uint32_t(h->persistent != 0)
                                       : uint32_t(blob_bytes / chunk > 3ull * 256 * 1024 * uint64_t(h->ilp));
 
-    launch_count_items(d_off, uint32_t(nh), chunk, h->d_nitems.as<uint64_t>(), d_counters, st);
-    exclusive_scan_u64(h->d_nitems.as<uint64_t>(), h->d_item_base.as<uint64_t>(), nh + 1, h->d_scan_tmp.as<uint64_t>(), st);
+    launch_item_base(d_off, uint32_t(nh), chunk, h->d_nitems.as<uint64_t>(), h->d_item_base.as<uint64_t>(), d_counters,
+                     h->d_scan_tmp.as<uint64_t>(), st);
 
     launch_build_items(B, max_items, st);
 

@@ -253,17 +253,139 @@ size_t scan_temp_elems(uint64_t n) {
     return total + 2;
 }
 
-// out[i] = sum(in[0..i)) for i < n.  `temp` needs scan_temp_elems(n) uint64.
-void exclusive_scan_u64(const uint64_t *in, uint64_t *out, uint64_t n, uint64_t *temp, hipStream_t st) {
+// out[i] = sum(in[0..i)) for i < n.  `temp` needs scan_temp_elems(n) uint64.  General form: three
+// launches per level, recursive on the tile sums.
+static void exclusive_scan_recursive(const uint64_t *in, uint64_t *out, uint64_t n, uint64_t *temp, hipStream_t st) {
     if (n == 0) return;
     const uint64_t tiles = (n + kScanTile - 1) / kScanTile;
     uint64_t *sums = temp;
     hipLaunchKernelGGL(k_scan_tiles, dim3(uint32_t(tiles)), dim3(kScanThreads), 0, st, in, out, n, sums);
     if (tiles > 1) {
         uint64_t *sums_scanned = sums;  // scanned in place
-        exclusive_scan_u64(sums, sums_scanned, tiles, temp + tiles + 1, st);
+        exclusive_scan_recursive(sums, sums_scanned, tiles, temp + tiles + 1, st);
         hipLaunchKernelGGL(k_scan_add, dim3(uint32_t(tiles)), dim3(kScanThreads), 0, st, out, n, sums_scanned);
     }
+}
+
+// Two-launch form for up to kScanMaxTiles tiles (8.4 M elements): tile sums, then every tile adds up
+// the sums of the tiles before it on its own (at most 4096 values) and scans its elements.  The batch
+// pipeline is a chain of small dependent kernels, ~7 us each launch-to-launch; this form and the
+// fused item count below take 3 of them out.  Element i of the input is in[i], or, for COUNT, the
+// number of work items of haystack i computed from the offsets on the fly (k_count_items' rule).
+constexpr uint64_t kScanMaxTiles = 4096;
+
+struct ScanSource {
+    const uint64_t *in;        // plain input, or null
+    const uint64_t *offsets;   // COUNT: haystack offsets (n = n_haystacks + 1 elements, the last one 0)
+    uint32_t chunk;
+    uint32_t *counters;        // COUNT: counters[6] = 1 on a malformed offset
+};
+
+template <bool COUNT>
+__device__ __forceinline__ uint64_t scan_element(const ScanSource &S, uint64_t i, uint64_t n) {
+    if (i >= n) return 0;
+    if (!COUNT) return S.in[i];
+    if (i + 1 == n) return 0;  // element n_haystacks: sentinel
+    const uint64_t lo = S.offsets[i], hi = S.offsets[i + 1];
+    if (hi < lo || hi - lo >= 0xFFFFFFFFull) {
+        S.counters[6] = 1u;
+        return 0;
+    }
+    return (hi - lo + S.chunk - 1) / S.chunk;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(kScanThreads) void k_tile_sums(ScanSource S, uint64_t n, uint64_t *tile_sums) {
+    __shared__ uint64_t wave_sums[kScanThreads / 64];
+    const uint64_t base = uint64_t(blockIdx.x) * kScanTile + uint64_t(threadIdx.x) * kScanPerThread;
+    uint64_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < kScanPerThread; ++i) sum += scan_element<COUNT>(S, base + i, n);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    if ((threadIdx.x & 63) == 0) wave_sums[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t t = 0;
+        for (int w = 0; w < kScanThreads / 64; ++w) t += wave_sums[w];
+        tile_sums[blockIdx.x] = t;
+    }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(kScanThreads) void k_tile_scan(ScanSource S, uint64_t n, const uint64_t *tile_sums, uint64_t *out) {
+    __shared__ uint64_t wave_sums[kScanThreads / 64];
+    __shared__ uint64_t before;
+    // sum of the tiles before this one
+    uint64_t pre = 0;
+    for (uint32_t t = threadIdx.x; t < blockIdx.x; t += kScanThreads) pre += tile_sums[t];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) pre += __shfl_xor(pre, d, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_sums[wave] = pre;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t t = 0;
+        for (int w = 0; w < kScanThreads / 64; ++w) t += wave_sums[w];
+        before = t;
+    }
+    __syncthreads();
+    const uint64_t tile_base = before;
+    __syncthreads();
+    // the tile itself, as k_scan_tiles
+    const uint64_t base = uint64_t(blockIdx.x) * kScanTile + uint64_t(threadIdx.x) * kScanPerThread;
+    uint64_t v[kScanPerThread];
+    uint64_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < kScanPerThread; ++i) {
+        v[i] = scan_element<COUNT>(S, base + i, n);
+        sum += v[i];
+    }
+    uint64_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) wave_sums[wave] = inc;
+    __syncthreads();
+    uint64_t wave_base = 0;
+    for (int w = 0; w < wave; ++w) wave_base += wave_sums[w];
+    uint64_t run = tile_base + wave_base + inc - sum;
+#pragma unroll
+    for (int i = 0; i < kScanPerThread; ++i) {
+        if (base + i < n) out[base + i] = run;
+        run += v[i];
+    }
+}
+
+template <bool COUNT>
+static void scan_two_launch(const ScanSource &S, uint64_t *out, uint64_t n, uint64_t *temp, hipStream_t st) {
+    const uint64_t tiles = (n + kScanTile - 1) / kScanTile;
+    hipLaunchKernelGGL(k_tile_sums<COUNT>, dim3(uint32_t(tiles)), dim3(kScanThreads), 0, st, S, n, temp);
+    hipLaunchKernelGGL(k_tile_scan<COUNT>, dim3(uint32_t(tiles)), dim3(kScanThreads), 0, st, S, n, temp, out);
+}
+
+void exclusive_scan_u64(const uint64_t *in, uint64_t *out, uint64_t n, uint64_t *temp, hipStream_t st) {
+    if (n == 0) return;
+    if ((n + kScanTile - 1) / kScanTile <= kScanMaxTiles) {
+        scan_two_launch<false>(ScanSource{in, nullptr, 0u, nullptr}, out, n, temp, st);
+        return;
+    }
+    exclusive_scan_recursive(in, out, n, temp, st);
+}
+
+// item_base[h] = first work item of haystack h, h = 0..nh (item_base[nh] = number of items): item counts
+// from the offsets and their exclusive scan.  `n_items` is scratch for the general (recursive) form.
+void launch_item_base(const uint64_t *offsets, uint32_t nh, uint32_t chunk, uint64_t *n_items, uint64_t *item_base,
+                      uint32_t *counters, uint64_t *temp, hipStream_t st) {
+    const uint64_t n = uint64_t(nh) + 1;
+    if ((n + kScanTile - 1) / kScanTile <= kScanMaxTiles) {
+        scan_two_launch<true>(ScanSource{nullptr, offsets, chunk, counters}, item_base, n, temp, st);
+        return;
+    }
+    hipLaunchKernelGGL(k_count_items, dim3((nh + 1 + 255) / 256), dim3(256), 0, st, offsets, nh, chunk, n_items, counters);
+    exclusive_scan_recursive(n_items, item_base, n, temp, st);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -486,8 +608,9 @@ __device__ __forceinline__ uint32_t run_epilogue(const DevAutomaton &A, const Ba
     if (ev.n_ev) {
         B.ev_count[item] = ev.n_ev;
         B.rec_count[item] = ev.n_rec;
+        // events only arise here, so the overflow test needs no reload of ev_count (cf. finish_item)
+        if (ev.n_ev > B.slab_events) B.overflow_list[atomicAdd(&B.counters[0], 1u)] = uint32_t(item);
     }
-    finish_item(B, item);
     return walked;
 }
 
@@ -1150,10 +1273,6 @@ void launch_build_items(const BatchArgs &B, uint64_t max_items, hipStream_t st) 
     hipLaunchKernelGGL(k_build_items, dim3(uint32_t((max_items + 255) / 256)), dim3(256), 0, st, B);
 }
 
-void launch_count_items(const uint64_t *offsets, uint32_t nh, uint32_t chunk, uint64_t *n_items, uint32_t *counters,
-                        hipStream_t st) {
-    hipLaunchKernelGGL(k_count_items, dim3((nh + 1 + 255) / 256), dim3(256), 0, st, offsets, nh, chunk, n_items, counters);
-}
 
 static int num_cus() {
     static int n = [] {
