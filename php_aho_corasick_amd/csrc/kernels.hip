@@ -6,21 +6,26 @@
 // costs ONE lookup in a failure-free transition table whose hot rows live in LDS.
 //
 // Pipeline for one batch (all on one stream, one host synchronisation at the very end):
-//   k_count_items -> exclusive scan -> k_build_items   work items (haystack chunks) per haystack
-//   k_scan_lds                                         the hot kernel: optimistic LDS-tile walk, flagged
-//                                                      byte runs walked exactly in its dense epilogue,
+//   k_tile_sums<COUNT> + k_tile_scan<COUNT>            work items per haystack from the offsets, scanned
+//   k_build_items                                      item -> haystack, packed item records
+//   the scan kernel, by pattern set:
+//     k_scan_anchor + k_walk_runs                      every pattern >= 11 B: q-gram anchor filter at HBM
+//                                                      speed; the byte runs it flags are walked exactly
+//                                                      by a kernel of their own
+//     k_scan_lds                                       otherwise: optimistic LDS-tile table walk, flagged
+//                                                      byte runs walked exactly in its dense epilogue
 //                                                      events -> per-item slabs
 //   k_first_only   (findAll == false)                  keep only the first event per haystack
-//   exclusive scan of per-item record counts           -> record base of every item
+//   k_tile_sums + k_tile_scan of per-item record counts -> record base of every item
 //   k_hay_prefix                                       -> per-haystack prefix array + batch summary
 //   k_expand                                           slab events -> records (callback order)
 //   k_refill                                           items whose events overflowed the slab re-scanned
 //                                                      straight into their final slots (dense inputs)
-// Alternatives to k_scan_lds: k_scan_simple (plain global-table walk, cross-check) and k_scan_anchor
-// (experimental q-gram front end).
+// k_scan_simple (plain global-table walk) is the cross-check.  Every record comes out of the same exact
+// table walk (exact_range); the scan kernels only differ in how they find the bytes worth walking.
 //
-// No MFMA anywhere: this is byte/integer indexing, bounded by the LDS's random-lookup rate and by
-// HBM reads of the haystack.  Wave64, 1024-thread workgroups, one per CU.
+// No MFMA anywhere: this is byte/integer indexing, bounded by HBM reads of the haystack (anchor
+// path) or by the LDS's random-lookup rate (table walk).  Wave64, 1024-thread workgroups.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -809,10 +814,10 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchA
 // text dword, whether the q bytes starting there are such an "anchor" q-gram: one hash + one
 // ds_read_b64 (a 4-slot bucket of 16-bit fingerprints, 128 KiB table in LDS) per 4 bytes instead
 // of four dependent ds_read_u16.  No false negatives by construction; a hit (true anchor or
-// fingerprint collision) only flags the byte run in which a match could END, and the same exact
-// epilogue as k_scan_lds walks it through the Aho-Corasick table -- results are bit-identical.
-// Windows are independent (no state), so their LDS reads pipeline freely; the kernel is bound by
-// HBM.  Lines are read exactly like k_scan_lds (128 B per lane, double-buffered).
+// fingerprint collision) only flags the byte run in which a match could END, and k_walk_runs walks
+// it through the Aho-Corasick table with the same exact walk k_scan_lds uses -- results are
+// bit-identical.  Windows are independent (no state), so a wave can stream one item with fully
+// coalesced non-temporal loads and their LDS reads pipeline freely; the kernel is bound by HBM.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kAnchorLdsBytes = 16384u * 8u;
 
