@@ -469,6 +469,10 @@ struct RunStage {
 };
 constexpr uint32_t kStageSlots = 128;
 
+// `entry` of a run: the exact automaton state at `lo`, or one of
+constexpr uint32_t kEntryUnknown = 0xFFFFFFFFu;    // walk from the root Lmax-1 bytes before lo
+constexpr uint32_t kEntryShortWarm = 0xFFFFFFFEu;  // k_scan_anchor: m_min-1 bytes before lo suffice
+
 __device__ __forceinline__ void stage_flush(const BatchArgs &B, uint64_t wave_first, RunStage &st, uint32_t lane) {
     for (uint32_t i = lane; i < st.count; i += 64u) {
         const uint4 e = st.slots[i];
@@ -600,14 +604,16 @@ __device__ __forceinline__ uint32_t run_epilogue(const DevAutomaton &A, const Ba
         for (uint32_t r = 0; r < nr; ++r) {
             const uint4 run = runs[r];
             const uint32_t lo = run.x, hi = run.y;
-            uint32_t st = run.z;
+            uint32_t st = run.z, from = lo;
             walked += hi - lo;
-            if (st == 0xFFFFFFFFu) {  // entry state unknown: Lmax-1 bytes of silent warm-up from the root
-                EventRegs none{0, 0};
-                const uint32_t from = lo > B.warm_bytes ? lo - B.warm_bytes : 0u;
-                st = exact_range<E, MODE>(A, B, cls_lds, tile, tile_rows, item, p, from, lo, 0xFFFFFFFFu, 0u, 0u, none);
+            if (st >= kEntryShortWarm) {  // entry state unknown: silent warm-up from the root, Lmax-1 bytes
+                                          // (or m_min-1 where k_scan_anchor knows that this suffices)
+                const uint32_t warm = st == kEntryUnknown ? B.warm_bytes : A.min_pattern_length - 1u;
+                from = lo > warm ? lo - warm : 0u;
+                st = 0;
             }
-            exact_range<E, MODE>(A, B, cls_lds, tile, tile_rows, item, p, lo, hi, lo > it.warm ? lo : it.warm, pos_bias, st, ev);
+            // warm-up and run in one loop: nothing before `lo` is reported
+            exact_range<E, MODE>(A, B, cls_lds, tile, tile_rows, item, p, from, hi, lo > it.warm ? lo : it.warm, pos_bias, st, ev);
         }
     }
     if (ev.n_ev) {
@@ -957,8 +963,10 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
         for (int r = 0; r < G; ++r) buf[r] = load_quad(cur, r);
     };
     auto scan_task = [&](uint4 (&buf)[G]) {
-        uint32_t z[G];  // per quad: packed minimum of (slot - fingerprint) over the 4 windows ENDING in it
-        uint32_t zall = 0xFFFFFFFFu;
+        uint32_t z[G];  // per quad: bit w set = the window ENDING at dword w of the quad hit (written on hits only)
+#pragma unroll
+        for (int r = 0; r < G; ++r) z[r] = 0;
+        uint32_t zany = 0;
         if (sc.c == 0) {  // first chunk of an item: nothing to the left of quad 0 (wave-uniform)
 #pragma unroll
             for (int i = 0; i < QW - 1; ++i) tail[i] = 0;
@@ -1011,48 +1019,72 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
             }
             __builtin_amdgcn_sched_barrier(0);
             if (r > 0) {
+                const u32x2 *b4 = bb[(r - 1) & 1];
+                const uint32_t *h4 = hh[(r - 1) & 1];
                 uint32_t zz = 0xFFFFFFFFu;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) zz = anchor_compare(bb[(r - 1) & 1][w], hh[(r - 1) & 1][w], zz);
-                z[r - 1] = zz;
-                asm("v_pk_min_u16 %0, %1, %2" : "=v"(zall) : "v"(zall), "v"(zz));
+                for (int w = 0; w < 4; ++w) zz = anchor_compare(b4[w], h4[w], zz);
+                // Rare, wave-uniform: some lane's quad hit.  Which of its four windows is worked out here,
+                // while the buckets are still in registers: k_walk_runs then starts 3 bytes before the
+                // window instead of Lmax-1 bytes before the earliest end, and the walks of a wave are in
+                // phase to within 4 bytes (their cold-row accesses coincide).
+                if (__builtin_expect(__any(has_zero_half(zz)), 0)) {
+                    uint32_t m = 0;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) m |= has_zero_half(anchor_compare(b4[w], h4[w], 0xFFFFFFFFu)) ? (1u << w) : 0u;
+                    z[r - 1] = m;
+                    zany |= m;
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        // Rare, wave-uniform: flag where a match anchored at a hit window can end.
-        const uint64_t cand = __ballot(has_zero_half(zall));
-        auto flag = [&](uint32_t r, uint32_t l) {
+        // Rare, wave-uniform: flag where a match anchored at a hit window can end.  A pattern whose first
+        // aligned dword is the window starting at byte `start` begins in [start-3, start] and ends at byte
+        // index [start + m_min - 4, start + Lmax).
+        const uint64_t cand = __ballot(zany != 0);
+        auto flag = [&](uint32_t r, uint32_t l, uint32_t wmask) {
             const uint32_t qi = sc.c * 512u + r * 64u + l;
             if (qi >= sc.nq) return;
-            // first window of the group starts (QW-1) dwords before quad qi, the last one 12 B later
-            const int32_t j_first = int32_t(sc.head + (qi << 4)) - int32_t(q - 4u);
-            int32_t lo = j_first + int32_t(m_min) - 4;
-            uint32_t hi = uint32_t(j_first + 12 + int32_t(l_max));
-            if (lo < 0) lo = 0;
-            if (hi > sc.n) hi = sc.n;
-            if (nrun > 0 && uint32_t(lo) < run_hi) lo = int32_t(run_hi);  // keep runs disjoint and ascending
-            if (uint32_t(lo) < hi) append_run_wave(B, wave_first, stage, sc.k, uint32_t(lo), hi, 0xFFFFFFFFu, nrun, run_hi, lane);
+            for (; wmask != 0; wmask &= wmask - 1) {
+                const uint32_t w = uint32_t(__builtin_ctz(wmask));
+                // the window ending at dword w of quad qi starts QW-1 dwords earlier
+                const int32_t start = int32_t(sc.head + (qi << 4) + 4u * w) - int32_t(q - 4u);
+                int32_t lo = start + int32_t(m_min) - 4;
+                uint32_t hi = uint32_t(start + int32_t(l_max));
+                if (lo < 0) lo = 0;
+                if (hi > sc.n) hi = sc.n;
+                // a run that begins where no earlier window's range reaches needs only m_min-1 bytes of
+                // warm-up (everything ending in it starts at or after start-3); a clamped one the full Lmax-1
+                uint32_t entry = kEntryShortWarm;
+                if (nrun > 0 && uint32_t(lo) < run_hi) { lo = int32_t(run_hi); entry = kEntryUnknown; }  // disjoint, ascending
+                if (uint32_t(lo) < hi) append_run_wave(B, wave_first, stage, sc.k, uint32_t(lo), hi, entry, nrun, run_hi, lane);
+            }
         };
         if (__builtin_expect(cand != 0, 0)) {
             if ((cand & (cand - 1)) == 0) {
-                // one lane hit (the usual case): its eight z values go through the scalar unit -- 8 v_readlane
-                // instead of ~40 vector instructions for the whole wave
+                // one lane hit (the usual case): its eight masks go through the scalar unit
                 const uint32_t l = uint32_t(__builtin_ctzll(cand));
 #pragma unroll
-                for (int r = 0; r < G; ++r)
-                    if (has_zero_half(__builtin_amdgcn_readlane(z[r], l))) flag(uint32_t(r), l);
+                for (int r = 0; r < G; ++r) {
+                    const uint32_t m = __builtin_amdgcn_readlane(z[r], l);
+                    if (m) flag(uint32_t(r), l, m);
+                }
             } else {
                 uint32_t hits = 0;  // bit r: some window ENDING in this lane's quad r hit
 #pragma unroll
-                for (int r = 0; r < G; ++r) hits |= has_zero_half(z[r]) ? (1u << r) : 0u;
+                for (int r = 0; r < G; ++r) hits |= z[r] ? (1u << r) : 0u;
                 uint32_t rmask = 0;
                 for (uint64_t w = cand; w != 0; w &= w - 1) rmask |= __builtin_amdgcn_readlane(hits, uint32_t(__builtin_ctzll(w)));
                 while (rmask != 0) {  // ascending quad order (r outer, lane inner) keeps the run list sorted
                     const uint32_t r = uint32_t(__builtin_ctz(rmask));
                     rmask &= rmask - 1;
-                    uint64_t who = __ballot((hits >> r) & 1u);
+                    uint32_t zr = 0;
+#pragma unroll
+                    for (int i = 0; i < G; ++i) zr = uint32_t(i) == r ? z[i] : zr;
+                    uint64_t who = __ballot(zr != 0);
                     while (who != 0) {
-                        flag(r, uint32_t(__builtin_ctzll(who)));
+                        const uint32_t l = uint32_t(__builtin_ctzll(who));
+                        flag(r, l, __builtin_amdgcn_readlane(zr, l));
                         who &= who - 1;
                     }
                 }
