@@ -257,3 +257,36 @@ def test_automatic_kernel_choice_and_fallback():
         assert np.array_equal(p, pe) and np.array_equal(r, re_)
         assert res.stat("kernel_used") == expect_kernel
     api.ahocorasick_deinit(res)
+
+
+@pytest.mark.parametrize("chunk", [0, 256])
+def test_anchor_overlapping_occurrences_of_unequal_length(chunk):
+    """The anchor path starts a walk only m_min-1 bytes before a run where it can prove that enough, and
+    merges or clamps runs of neighbouring windows.  Long and short patterns that overlap, nest and share
+    suffixes, in periodic text where nearly every window hits, must still give the oracle's records."""
+    pats = [b"a" * 11, b"a" * 40 + b"b", b"ab" * 30, b"b" + b"a" * 25, b"abba" * 6, b"a" * 13 + b"ba" * 20,
+            b"bbbbbbbbbbbb", b"ab" * 8 + b"c" + b"ab" * 8, b"c" + b"a" * 60 + b"c", b"a" * 12 + b"c"]
+    rng = np.random.default_rng(7)
+    hays = []
+    for h in range(40):
+        parts = []
+        for _ in range(int(rng.integers(1, 30))):
+            k = int(rng.integers(0, 6))
+            parts.append([b"a" * int(rng.integers(1, 90)), b"b", b"ab" * int(rng.integers(1, 40)), b"c",
+                          pats[int(rng.integers(len(pats)))], b"ba" * int(rng.integers(1, 25))][k])
+        hays.append(b"".join(parts)[: int(rng.integers(0, 3000))])
+    pat_blob, pat_off = synth.pack(pats)
+    hay_blob, hay_off = synth.pack(hays)
+    ds = synth.Dataset("overlap", pat_blob, pat_off, hay_blob, hay_off)
+    o = Oracle("port")
+    o.add_patterns((ds.pat_blob, ds.pat_off))
+    for run_cap in (8, 2):
+        res = resource_for(ds, kernel=2, chunk_bytes=chunk, run_cap=run_cap, slab_events=2)
+        for find_all in (True, False):
+            pe, re_ = o.match_batch(ds.hay_blob, ds.hay_off, find_all)
+            for path in (host_match, device_match):
+                p, r = path(res, ds, find_all)
+                assert np.array_equal(p, pe) and np.array_equal(r, re_), (chunk, run_cap, find_all, path.__name__)
+        assert res.stat("kernel_used") == 2 and res.stat("anchor_q") == 8
+        api.ahocorasick_deinit(res)
+    o.close()
