@@ -85,3 +85,43 @@ def test_idempotent_and_chunk_invariant():
                 ref = out
             assert np.array_equal(out[0], ref[0]) and np.array_equal(out[1], ref[1])
         api.ahocorasick_deinit(res)
+
+
+def test_nine_million_tiny_haystacks():
+    """More haystacks than the two-launch prefix sum takes (4,096 tiles of 2,048): the recursive
+    three-kernel scan must give the same item table.  9.4 M haystacks of 0..3 bytes over {a,b}, patterns
+    a / ab / ba / bb: per-haystack counts against a vectorised restatement, a slice against the oracle."""
+    nh = 9_400_000
+    rng = np.random.default_rng(5)
+    lens = rng.integers(0, 4, nh, dtype=np.int64)
+    off = np.zeros(nh + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lens, dtype=np.uint64)
+    blob = rng.integers(0, 2, int(off[-1]), dtype=np.uint8) + ord("a")
+    pat_blob, pat_off = synth.pack([b"a", b"ab", b"ba", b"bb"])
+    ds = synth.Dataset("tiny", pat_blob, pat_off, blob, off)
+    res = resource_for(ds, slab_events=4)
+    d_blob, d_off = _device_batch(ds)
+    batch.bind_current_stream(res)
+    total = batch.match_device(res, d_blob, d_off)
+    prefix, rec = batch.result_numpy(res, nh, total)
+    # expected records per haystack: one per 'a', one per adjacent pair other than "aa"
+    is_a = (blob == ord("a")).astype(np.int64)
+    pair = np.zeros(len(blob), dtype=np.int64)
+    pair[1:] = 1 - is_a[1:] * is_a[:-1]
+    first = np.zeros(len(blob), dtype=bool)
+    first[off[:-1][lens > 0].astype(np.int64)] = True     # a pair must not straddle haystacks
+    pair[first] = 0
+    per_byte = is_a + pair
+    csum = np.concatenate([[0], np.cumsum(per_byte)])
+    expect = csum[off[1:].astype(np.int64)] - csum[off[:-1].astype(np.int64)]
+    assert total == int(expect.sum())
+    assert np.array_equal(np.diff(prefix.astype(np.int64)), expect)
+    o = Oracle("port")
+    o.add_patterns((ds.pat_blob, ds.pat_off))
+    lo, hi = 9_000_000, 9_002_000
+    sub_off = off[lo:hi + 1] - off[lo]
+    pe, re_ = o.match_batch(blob[int(off[lo]):int(off[hi])], sub_off)
+    re_[:, 0] += lo
+    assert np.array_equal(rec[int(prefix[lo]):int(prefix[hi])], re_)
+    api.ahocorasick_deinit(res)
+    o.close()
