@@ -178,7 +178,7 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *   "chunk_bytes"    force the work-item size (0 = automatic)            [any time]
  *   "kernel"         0 = plain global-table walk, 1 = LDS-tile table walk, 2 = anchor q-gram
  *                    filter + exact table walk of the candidates (needs a shortest pattern
- *                    >= 11 B and <= 12288 anchor q-grams, else falls back to 1), 3 = automatic
+ *                    >= 7 B and a collision-free table seed exists, else falls back to 1), 3 = automatic
  *                    (default): 2 when eligible, and back to 1 for the rest of the handle's life
  *                    if a batch shows the text defeats the filter                        [any time]
  *   "ilp"            streams per lane in the LDS-tile kernel (1 or 2)    [any time]
@@ -221,7 +221,10 @@ typedef struct acmi_tables {
     uint32_t anchor_mul;          /* hash multiplier                           */
     uint32_t min_pattern_length;
     uint32_t anchor_keys;
-    const uint16_t *anchor_table; /* 16384 buckets x 4 fingerprints            */
+    const uint16_t *anchor_table; /* mode 1: 16384 buckets x 4 fingerprints; mode 2: 2^bucket_bits x 8 */
+    uint32_t anchor_mode;         /* 0 none, 1 LDS table, 2 LDS bitmap + global table */
+    uint32_t anchor_bucket_bits;  /* mode 2                                    */
+    const uint32_t *anchor_bitmap;/* mode 2: 32768 words (2^20 bits)           */
 } acmi_tables;
 int acmi_debug_tables(const acmi_handle *h, acmi_tables *out);
 

@@ -43,7 +43,8 @@ class Tables(C.Structure):
                 ("own_pattern", C.POINTER(C.c_uint32)), ("dict_link", C.POINTER(C.c_uint32)),
                 ("out_count", C.POINTER(C.c_uint32)),
                 ("anchor_q", C.c_uint32), ("anchor_mul", C.c_uint32), ("min_pattern_length", C.c_uint32),
-                ("anchor_keys", C.c_uint32), ("anchor_table", C.POINTER(C.c_uint16))]
+                ("anchor_keys", C.c_uint32), ("anchor_table", C.POINTER(C.c_uint16)),
+                ("anchor_mode", C.c_uint32), ("anchor_bucket_bits", C.c_uint32), ("anchor_bitmap", C.POINTER(C.c_uint32))]
 
 
 Handle = C.c_void_p

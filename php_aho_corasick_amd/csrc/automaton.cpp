@@ -279,9 +279,12 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
     for (const PatternMeta &m : patterns_)
         if (m.accepted && (fa.min_pattern_length == 0 || m.length < fa.min_pattern_length)) fa.min_pattern_length = m.length;
     fa.anchor_q = 0;
+    fa.anchor_mode = 0;
     fa.anchor_table.clear();
-    if (fa.min_pattern_length >= 11) {
-        const uint32_t q = fa.min_pattern_length >= 19 ? 16u : fa.min_pattern_length >= 15 ? 12u : 8u;
+    fa.anchor_bitmap.clear();
+    if (fa.min_pattern_length >= 7) {
+        const uint32_t q = fa.min_pattern_length >= 19 ? 16u : fa.min_pattern_length >= 15 ? 12u
+                         : fa.min_pattern_length >= 11 ? 8u : 4u;
         std::vector<std::array<uint32_t, 4>> keys;
         for (const PatternMeta &m : patterns_) {
             if (!m.accepted) continue;
@@ -294,9 +297,9 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
         std::sort(keys.begin(), keys.end());
         keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
         fa.anchor_keys = uint32_t(keys.size());
+        uint32_t mul = 0x9E3779B1u;
         if (keys.size() <= kAnchorMaxKeys) {
             std::vector<uint16_t> tab(size_t(kAnchorBuckets) * 4);
-            uint32_t mul = 0x9E3779B1u;
             for (int attempt = 0; attempt < 512 && fa.anchor_q == 0; ++attempt, mul = mul * 0x2545F491u + 0x6B43A9B5u) {
                 mul = (mul | 1u) & 0xFFFFFFu;
                 std::vector<uint8_t> used(kAnchorBuckets, 0);
@@ -314,8 +317,45 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
                 }
                 if (ok) {
                     fa.anchor_q = q;
+                    fa.anchor_mode = 1;
                     fa.anchor_mul = mul;
                     fa.anchor_table = tab;
+                }
+            }
+        } else {
+            // mode 2: as many 8-slot buckets as q-grams (load 1: a bucket overflows with probability 1e-6)
+            uint32_t bits = 15;
+            while ((size_t(1) << bits) < keys.size() && bits < kAnchorMaxBucketBits) ++bits;
+            if ((size_t(1) << bits) >= keys.size()) {
+                const uint32_t nb = 1u << bits;
+                std::vector<uint16_t> tab;
+                std::vector<uint8_t> used;
+                for (int attempt = 0; attempt < 64 && fa.anchor_q == 0; ++attempt, mul = mul * 0x2545F491u + 0x6B43A9B5u) {
+                    mul = (mul | 1u) & 0xFFFFFFu;
+                    tab.assign(size_t(nb) * 8, uint16_t(0));
+                    used.assign(nb, 0);
+                    bool ok = true;
+                    for (const auto &k : keys) {
+                        const uint32_t h = anchor_hash(k.data(), q / 4, mul);
+                        const uint16_t fp = uint16_t((h >> 16) | 1u);
+                        const uint32_t bucket = h & (nb - 1);
+                        uint16_t *b = &tab[size_t(bucket) * 8];
+                        uint32_t slot = 0;
+                        while (slot < used[bucket] && b[slot] != fp) ++slot;
+                        if (slot == 8) { ok = false; break; }
+                        if (slot == used[bucket]) b[used[bucket]++] = fp;
+                    }
+                    if (!ok) continue;
+                    fa.anchor_q = q;
+                    fa.anchor_mode = 2;
+                    fa.anchor_mul = mul;
+                    fa.anchor_bucket_bits = bits;
+                    fa.anchor_table = tab;
+                    fa.anchor_bitmap.assign(kAnchorBitmapWords, 0u);
+                    for (const auto &k : keys) {
+                        const uint32_t h = anchor_hash(k.data(), q / 4, mul);
+                        fa.anchor_bitmap[h >> 17] |= 1u << ((h >> 12) & 31u);
+                    }
                 }
             }
         }

@@ -66,18 +66,27 @@ struct FlatAutomaton {
 
     // ---- anchor filter (optional front end of the scan, see kernels.hip k_scan_anchor) ----
     // Every occurrence of a pattern of length >= q + 3 contains a 4-byte-aligned text dword within
-    // its first 4 bytes; the q bytes from there are P[o, o+q) for o in 0..3.  anchor_table holds a
-    // 16-bit fingerprint of each such q-gram: kAnchorBuckets buckets x 4 slots (empty: anchor_empty()).
+    // its first 4 bytes; the q bytes from there are P[o, o+q) for o in 0..3 ("anchor q-grams").
+    //   mode 1 (<= kAnchorMaxKeys q-grams): anchor_table = kAnchorBuckets buckets x 4 slots of 16-bit
+    //     fingerprints, resident in LDS (empty slots: anchor_empty()).
+    //   mode 2 (more): anchor_bitmap = 2^20 bits in LDS (bit = top 20 bits of the hash) in front of a
+    //     fingerprint table in global memory / L2: 2^anchor_bucket_bits buckets x 8 slots, bucket = low
+    //     bits of the hash, fingerprint = (hash >> 16) | 1, 0 = empty slot.
     uint32_t min_pattern_length = 0;
-    uint32_t anchor_q = 0;        // 0 = not eligible; else 8, 12 or 16 bytes
+    uint32_t anchor_q = 0;        // 0 = not eligible; else 4, 8, 12 or 16 bytes
+    uint32_t anchor_mode = 0;     // 0 none, 1 LDS table, 2 LDS bitmap + global table
     uint32_t anchor_mul = 0;      // odd multiplier of the window hash (seed that gave no bucket overflow)
     uint32_t anchor_keys = 0;
+    uint32_t anchor_bucket_bits = 0;  // mode 2
     std::vector<uint16_t> anchor_table;
+    std::vector<uint32_t> anchor_bitmap;  // mode 2: 32768 words
 };
 
 constexpr uint32_t kAnchorBucketBits = 14;
 constexpr uint32_t kAnchorBuckets = 1u << kAnchorBucketBits;  // x 4 slots x 2 B = 128 KiB of LDS
-constexpr uint32_t kAnchorMaxKeys = 12288;
+constexpr uint32_t kAnchorMaxKeys = 12288;          // mode 1
+constexpr uint32_t kAnchorBitmapWords = 1u << 15;    // mode 2: 2^20 bits = 128 KiB of LDS
+constexpr uint32_t kAnchorMaxBucketBits = 21;        // mode 2: up to 2 M buckets x 16 B = 32 MiB
 
 // Window hash shared by the host builder and the device kernel: fold each little-endian dword of
 // the q-gram (d ^ d >> 11, so that its top byte reaches the low 24 bits), then chain them with
@@ -90,6 +99,7 @@ inline uint32_t anchor_fold(uint32_t d) { return d ^ (d >> 11); }
 inline uint32_t anchor_hash(const uint32_t *words, uint32_t n_words, uint32_t mul) {
     uint32_t h = anchor_fold(words[0]);
     for (uint32_t i = 1; i < n_words; ++i) h = (h & 0xFFFFFFu) * (mul & 0xFFFFFFu) + anchor_fold(words[i]);
+    if (n_words == 1) h = (h & 0xFFFFFFu) * (mul & 0xFFFFFFu) + (h >> 8);  // a lone dword still gets one multiply
     return h;
 }
 inline uint16_t anchor_empty(uint32_t bucket) { return uint16_t(((bucket >> (kAnchorBucketBits - 1)) & 1u) ^ 1u); }

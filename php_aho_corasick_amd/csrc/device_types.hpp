@@ -24,8 +24,10 @@ struct DevAutomaton {
     uint32_t tile_offset;        // byte offset of the tile inside the LDS image (0 or 512)
     uint32_t swar_shift, swar_expect_lo, swar_expect_hi, swar_other_off;  // other column * entry_bytes
     // anchor filter (k_scan_anchor): 2^14 buckets x 4 x uint16 fingerprints, see automaton.hpp
-    const void *anchor_table;
+    const void *anchor_table;    // mode 1: 128 KiB staged into LDS; mode 2: 2^bucket_bits x 8 x uint16, read through L2
+    const uint32_t *anchor_bitmap;  // mode 2: 2^20 bits staged into LDS
     uint32_t anchor_q, anchor_mul, min_pattern_length, max_pattern_length;
+    uint32_t anchor_mode, anchor_bucket_mask;
 };
 
 // One batch launch.

@@ -77,7 +77,7 @@ struct acmi_handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     DevAutomaton dA{};
-    DevBuf d_table, d_lds, d_class, d_own, d_dict, d_cnt, d_plen, d_anchor;
+    DevBuf d_table, d_lds, d_class, d_own, d_dict, d_cnt, d_plen, d_anchor, d_bitmap;
 
     // workspace (grow-only)
     DevBuf d_blob, d_off, d_nitems, d_item_base, d_item_hay, d_item_rec, d_zero, d_rec_base, d_slab, d_ovf, d_counters,
@@ -198,11 +198,18 @@ int ensure_device(acmi_handle *h) {
     if (fa.anchor_q) {
         HIPCHK(h, h->d_anchor.ensure(fa.anchor_table.size() * 2));
         HIPCHK(h, hipMemcpy(h->d_anchor.p, fa.anchor_table.data(), fa.anchor_table.size() * 2, hipMemcpyHostToDevice));
+        if (fa.anchor_mode == 2) {
+            HIPCHK(h, h->d_bitmap.ensure(fa.anchor_bitmap.size() * 4));
+            HIPCHK(h, hipMemcpy(h->d_bitmap.p, fa.anchor_bitmap.data(), fa.anchor_bitmap.size() * 4, hipMemcpyHostToDevice));
+        }
     }
 
     DevAutomaton &A = h->dA;
     A.anchor_table = fa.anchor_q ? h->d_anchor.p : nullptr;
     A.anchor_q = fa.anchor_q;
+    A.anchor_mode = fa.anchor_mode;
+    A.anchor_bitmap = fa.anchor_mode == 2 ? h->d_bitmap.as<uint32_t>() : nullptr;
+    A.anchor_bucket_mask = fa.anchor_mode == 2 ? (1u << fa.anchor_bucket_bits) - 1u : 0u;
     A.anchor_mul = fa.anchor_mul;
     A.min_pattern_length = fa.min_pattern_length;
     A.max_pattern_length = fa.max_pattern_length;
@@ -484,7 +491,7 @@ int acmi_destroy(acmi_handle *h) {
     if (h->dev_ready) {
         (void)hipSetDevice(h->dev_id);
         if (h->stream) (void)hipStreamSynchronize(h->stream);
-        for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_blob,
+        for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_blob,
                           &h->d_off, &h->d_nitems, &h->d_item_base, &h->d_item_hay, &h->d_item_rec, &h->d_zero,
                           &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_scan_tmp, &h->d_prefix, &h->d_out, &h->d_runs, &h->d_run_count})
             b->release();
@@ -684,6 +691,7 @@ int acmi_get_stat(const acmi_handle *h, const char *key, double *value) {
     else if (k == "kernel_used") *value = h->kernel_used;
     else if (k == "anchor_q") *value = fa.anchor_q;
     else if (k == "anchor_keys") *value = fa.anchor_keys;
+    else if (k == "anchor_mode") *value = fa.anchor_mode;
     else if (k == "min_pattern_length") *value = fa.min_pattern_length;
     else if (k == "total_ms") *value = h->total_ms;
     else if (k == "records") *value = double(h->last_total);
@@ -721,6 +729,9 @@ int acmi_debug_tables(const acmi_handle *h, acmi_tables *out) {
     out->anchor_mul = fa.anchor_mul;
     out->min_pattern_length = fa.min_pattern_length;
     out->anchor_keys = fa.anchor_keys;
+    out->anchor_mode = fa.anchor_mode;
+    out->anchor_bucket_bits = fa.anchor_bucket_bits;
+    out->anchor_bitmap = fa.anchor_mode == 2 ? fa.anchor_bitmap.data() : nullptr;
     out->anchor_table = fa.anchor_q ? fa.anchor_table.data() : nullptr;
     return ACMI_OK;
 }

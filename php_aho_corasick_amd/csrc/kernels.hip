@@ -844,6 +844,7 @@ __device__ __forceinline__ uint32_t anchor_mad(uint32_t h, uint32_t mul, uint32_
 // hash IS the ds_read address; going through the generic `smem` pointer costs a v_add per window.
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(3))) u32x2 *LdsU2Ptr;
+typedef const __attribute__((address_space(3))) uint32_t *LdsU1Ptr;
 __device__ __forceinline__ u32x2 anchor_bucket(uint32_t h) { return *reinterpret_cast<LdsU2Ptr>(h & 0x1FFF8u); }
 __device__ __forceinline__ uint32_t anchor_compare(u32x2 b, uint32_t h, uint32_t z) {
     uint32_t x, y;
@@ -899,13 +900,18 @@ __device__ __forceinline__ bool anchor_next(const DevAutomaton &A, const BatchAr
     return cur.valid;
 }
 
-template <typename E, int MODE, int QW>
+// BIG (anchor mode 2, more q-grams than the LDS table holds): LDS carries a 2^20-bit map of the hashes'
+// top 20 bits; a window whose bit is set (a fifth of them for 262,144 q-grams) is looked up in an
+// 8-slot fingerprint table in global memory, which L2 serves.  QW = 1 (4-byte windows, shortest pattern
+// 7..10 B) needs no hand-over between quads.
+template <typename E, int MODE, int QW, bool BIG>
 __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, BatchArgs B) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int G = 8;
+    constexpr int NC = QW > 1 ? QW - 1 : 1;  // carries between quads (none for QW == 1; arrays keep one element)
     if (uint64_t(blockIdx.x) * (B.persistent ? 1u : kLdsThreads / 64u) * B.wave_items >= B.item_base[B.n_haystacks]) return;
-    {   // LDS: the anchor table, 128 KiB; behind it 2 KiB of run staging per wave
-        const uint4 *src = static_cast<const uint4 *>(A.anchor_table);
+    {   // LDS: the anchor table (or bitmap), 128 KiB; behind it 2 KiB of run staging per wave
+        const uint4 *src = BIG ? reinterpret_cast<const uint4 *>(A.anchor_bitmap) : static_cast<const uint4 *>(A.anchor_table);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
         for (uint32_t t = threadIdx.x; t < kAnchorLdsBytes / 16u; t += kLdsThreads) dst[t] = src[t];
     }
@@ -943,9 +949,9 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     // carry[n-1] = hash prefix over the LAST n dwords of a quad (n = 1..QW-1): what a window that
     // begins there and ends in the next quad continues from.  `tail` = the carries of the previous
     // wave-load (its lane 63 is the left neighbour of lane 0).
-    uint32_t tail[QW - 1];
+    uint32_t tail[NC];
 #pragma unroll
-    for (int i = 0; i < QW - 1; ++i) tail[i] = 0;
+    for (int i = 0; i < NC; ++i) tail[i] = 0;
     if (sc.head) append_run_wave(B, wave_first, stage, sc.k, 0, (sc.head + l_max) < sc.n ? sc.head + l_max : sc.n, 0u, nrun, run_hi, lane);
 
     uint4 buf0[G], buf1[G];
@@ -969,7 +975,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
         uint32_t zany = 0;
         if (sc.c == 0) {  // first chunk of an item: nothing to the left of quad 0 (wave-uniform)
 #pragma unroll
-            for (int i = 0; i < QW - 1; ++i) tail[i] = 0;
+            for (int i = 0; i < NC; ++i) tail[i] = 0;
         }
         // hashes of the 4 windows ending in quad r
         auto hash_quad = [&](int r, uint32_t (&h4)[4]) {
@@ -978,7 +984,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
             f[1] = anchor_fold_dev(buf[r].y);
             f[2] = anchor_fold_dev(buf[r].z);
             f[3] = anchor_fold_dev(buf[r].w);
-            uint32_t mine[QW - 1], left[QW - 1];
+            uint32_t mine[NC], left[NC];
 #pragma unroll
             for (int n = 1; n < QW; ++n) {  // prefix over this quad's last n dwords
                 uint32_t h = f[4 - n];
@@ -999,6 +1005,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                 if (need > 0) { h = left[need - 1]; i0 = 0; } else { h = f[w - (QW - 1)]; i0 = w - (QW - 1) + 1; }
 #pragma unroll
                 for (int i = i0; i <= w; ++i) h = anchor_mad(h, mul, f[i]);
+                if (QW == 1) h = anchor_mad(h, mul, h >> 8);  // a lone dword still gets one multiply (anchor_hash)
                 h4[w] = h;
             }
         };
@@ -1006,38 +1013,72 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
         // are in flight while quad r-1's buckets are compared, so a wave never sits on LDS latency
         // (hipcc on its own put an lgkmcnt(0) right behind every ds_read).
         uint32_t hh[2][4];
-        u32x2 bb[2][4];
+        u32x2 bb[2][4];   // !BIG: the four fingerprint buckets of a quad; BIG: .x = the bitmap word
+        const uint32_t bucket_mask = A.anchor_bucket_mask;
+        const uint4 *big_table = static_cast<const uint4 *>(A.anchor_table);
 #pragma unroll
         for (int r = 0; r <= G; ++r) {
             if (r < G) {
                 hash_quad(r, hh[r & 1]);
                 // the quad is consumed: reload its registers with the same quad of the task two steps
-                // ahead at once, so that the wave keeps close to 16 KiB of loads in flight
-                buf[r] = load_quad(ld, r);
+                // ahead at once, so that the wave keeps close to 16 KiB of loads in flight.  (BIG reloads
+                // the whole task at the end instead: its table probes below share the in-order vmcnt queue
+                // with these loads, and each probe wait would sit out the newest reload's HBM round trip.)
+                if (!BIG) buf[r] = load_quad(ld, r);
 #pragma unroll
-                for (int w = 0; w < 4; ++w) bb[r & 1][w] = anchor_bucket(hh[r & 1][w]);
+                for (int w = 0; w < 4; ++w) {
+                    if (BIG) bb[r & 1][w].x = *reinterpret_cast<LdsU1Ptr>((hh[r & 1][w] >> 15) & 0x1FFFCu);
+                    else bb[r & 1][w] = anchor_bucket(hh[r & 1][w]);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             if (r > 0) {
                 const u32x2 *b4 = bb[(r - 1) & 1];
                 const uint32_t *h4 = hh[(r - 1) & 1];
-                uint32_t zz = 0xFFFFFFFFu;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) zz = anchor_compare(b4[w], h4[w], zz);
-                // Rare, wave-uniform: some lane's quad hit.  Which of its four windows is worked out here,
-                // while the buckets are still in registers: k_walk_runs then starts 3 bytes before the
-                // window instead of Lmax-1 bytes before the earliest end, and the walks of a wave are in
-                // phase to within 4 bytes (their cold-row accesses coincide).
-                if (__builtin_expect(__any(has_zero_half(zz)), 0)) {
+                if (BIG) {
+                    // bitmap says "maybe" for a fraction of the windows: those lanes fetch the 8-slot bucket
+                    // (16 B, through L2); the four loads are issued before the first compare
+                    bool maybe[4];
+                    uint4 tb[4];
                     uint32_t m = 0;
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) m |= has_zero_half(anchor_compare(b4[w], h4[w], 0xFFFFFFFFu)) ? (1u << w) : 0u;
+                    for (int w = 0; w < 4; ++w) {
+                        maybe[w] = (b4[w].x >> ((h4[w] >> 12) & 31u)) & 1u;
+                        tb[w] = make_uint4(0u, 0u, 0u, 0u);
+                        if (maybe[w]) tb[w] = big_table[h4[w] & bucket_mask];
+                    }
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        if (maybe[w]) {
+                            const uint32_t fp = h4[w] | 0x10000u;  // fingerprint = (h >> 16) | 1: never the empty 0
+                            uint32_t zz = 0xFFFFFFFFu;
+                            zz = anchor_compare(u32x2{tb[w].x, tb[w].y}, fp, zz);
+                            zz = anchor_compare(u32x2{tb[w].z, tb[w].w}, fp, zz);
+                            m |= has_zero_half(zz) ? (1u << w) : 0u;
+                        }
+                    }
                     z[r - 1] = m;
                     zany |= m;
+                } else {
+                    uint32_t zz = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) zz = anchor_compare(b4[w], h4[w], zz);
+                    // Rare, wave-uniform: some lane's quad hit.  Which of its four windows is worked out here,
+                    // while the buckets are still in registers: k_walk_runs then starts 3 bytes before the
+                    // window instead of Lmax-1 bytes before the earliest end, and the walks of a wave are in
+                    // phase to within 4 bytes (their cold-row accesses coincide).
+                    if (__builtin_expect(__any(has_zero_half(zz)), 0)) {
+                        uint32_t m = 0;
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) m |= has_zero_half(anchor_compare(b4[w], h4[w], 0xFFFFFFFFu)) ? (1u << w) : 0u;
+                        z[r - 1] = m;
+                        zany |= m;
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (BIG) load_task(buf, ld);
         // Rare, wave-uniform: flag where a match anchored at a hit window can end.  A pattern whose first
         // aligned dword is the window starting at byte `start` begins in [start-3, start] and ends at byte
         // index [start + m_min - 4, start + Lmax).
@@ -1359,9 +1400,16 @@ static hipError_t launch_anchor_m(const DevAutomaton &A, const BatchArgs &B, uin
         hipLaunchKernelGGL(fn, dim3(blocks), dim3(kLdsThreads), lds, st, A, B);
         return hipGetLastError();
     };
-    if (A.anchor_q == 8) return go(k_scan_anchor<E, MODE, 2>);
-    if (A.anchor_q == 12) return go(k_scan_anchor<E, MODE, 3>);
-    return go(k_scan_anchor<E, MODE, 4>);
+    if (A.anchor_mode == 2) {
+        if (A.anchor_q == 4) return go(k_scan_anchor<E, MODE, 1, true>);
+        if (A.anchor_q == 8) return go(k_scan_anchor<E, MODE, 2, true>);
+        if (A.anchor_q == 12) return go(k_scan_anchor<E, MODE, 3, true>);
+        return go(k_scan_anchor<E, MODE, 4, true>);
+    }
+    if (A.anchor_q == 4) return go(k_scan_anchor<E, MODE, 1, false>);
+    if (A.anchor_q == 8) return go(k_scan_anchor<E, MODE, 2, false>);
+    if (A.anchor_q == 12) return go(k_scan_anchor<E, MODE, 3, false>);
+    return go(k_scan_anchor<E, MODE, 4, false>);
 }
 
 hipError_t launch_scan(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes,

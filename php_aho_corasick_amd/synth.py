@@ -247,4 +247,15 @@ def r6() -> Dataset:
     return _planted_ragged("R6", 16, 120, 19, 64, 37, 0, 12000, b"01", 4)
 
 
-NAMED = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "R1": r1, "R2": r2, "R3": r3, "R4": r4, "R5": r5, "R6": r6}
+def r7() -> Dataset:
+    """Anchor filter with 4-byte windows (LDS table): 300 patterns of 7..12 B over Sigma=256, planted."""
+    return _planted_ragged("R7", 17, 300, 7, 12, 47, 0, 7000, None, 6)
+
+
+def r8() -> Dataset:
+    """Anchor filter for big sets (LDS bitmap + fingerprint table through L2): 5,000 patterns of 9..24 B
+    over a 16-letter alphabet (20,000 anchor q-grams of 4 bytes), planted."""
+    return _planted_ragged("R8", 18, 5000, 9, 24, 41, 0, 10000, b"abcdefghijklmnop", 8)
+
+
+NAMED = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "R1": r1, "R2": r2, "R3": r3, "R4": r4, "R5": r5, "R6": r6, "R7": r7, "R8": r8}

@@ -64,7 +64,13 @@ class FlatTables:
         _ = dt
         self.anchor_q, self.anchor_mul, self.min_pattern_length = t.anchor_q, t.anchor_mul, t.min_pattern_length
         self.anchor_keys = t.anchor_keys
-        self.anchor = np.ctypeslib.as_array(t.anchor_table, shape=(16384, 4)).copy() if t.anchor_q else None
+        self.anchor_mode, self.anchor_bucket_bits = t.anchor_mode, t.anchor_bucket_bits
+        self.anchor = self.anchor_bitmap = None
+        if t.anchor_mode == 1:
+            self.anchor = np.ctypeslib.as_array(t.anchor_table, shape=(16384, 4)).copy()
+        elif t.anchor_mode == 2:
+            self.anchor = np.ctypeslib.as_array(t.anchor_table, shape=(1 << t.anchor_bucket_bits, 8)).copy()
+            self.anchor_bitmap = np.ctypeslib.as_array(t.anchor_bitmap, shape=(1 << 15,)).copy()
 
     def anchor_probe(self, window: bytes) -> bool:
         """The device's window test (k_scan_anchor), restated: hash q bytes, look the fingerprint up."""
@@ -74,6 +80,12 @@ class FlatTables:
         h = fold[0]
         for f in fold[1:]:
             h = ((h & 0xFFFFFF) * (self.anchor_mul & 0xFFFFFF) + f) & 0xFFFFFFFF
+        if len(fold) == 1:
+            h = ((h & 0xFFFFFF) * (self.anchor_mul & 0xFFFFFF) + (h >> 8)) & 0xFFFFFFFF
+        if self.anchor_mode == 2:   # LDS bitmap in front of the 8-slot table read through L2
+            if not (int(self.anchor_bitmap[h >> 17]) >> ((h >> 12) & 31)) & 1:
+                return False
+            return int((h >> 16) | 1) in [int(x) for x in self.anchor[h & ((1 << self.anchor_bucket_bits) - 1)]]
         return int(h >> 16) in [int(x) for x in self.anchor[(h >> 3) & 0x3FFF]]
 
     def is_final(self, s: int) -> bool:

@@ -90,22 +90,23 @@ def test_wide_entries_for_big_automata():
     api.ahocorasick_deinit(res)
 
 
-@pytest.mark.parametrize("name,q", [("G2", 12), ("R3", 16), ("R4", 8), ("R5", 12), ("R6", 16)])
-def test_anchor_table_has_no_false_negatives(name, q):
+@pytest.mark.parametrize("name,q,mode", [("G2", 12, 1), ("R3", 16, 1), ("R4", 8, 1), ("R5", 12, 1), ("R6", 16, 1),
+                                         ("R7", 4, 1), ("R8", 4, 2), ("G6", 4, 2)])
+def test_anchor_table_has_no_false_negatives(name, q, mode):
     """Every pattern's q-grams at offsets 0..3 must probe positive (a miss would lose matches); random
     windows almost never do."""
     ds = synth.NAMED[name]()
     res = resource_for(ds)
     api.ahocorasick_finalize(res)
     ft = FlatTables(res)
-    assert ft.anchor_q == q and ft.min_pattern_length >= q + 3
-    for k in range(ds.n_patterns):
+    assert ft.anchor_q == q and ft.anchor_mode == mode and ft.min_pattern_length >= q + 3
+    for k in range(0, ds.n_patterns, 1 if ds.n_patterns <= 5000 else 37):
         p = ds.pattern(k)
         for o in range(4):
             assert ft.anchor_probe(p[o:o + q]), (name, k, o)
     rng = np.random.default_rng(5)
     fp = sum(ft.anchor_probe(rng.integers(0, 256, q, dtype=np.uint8).tobytes()) for _ in range(4000))
-    assert fp <= 8
+    assert fp <= 8   # q = 4 over G6's 262,144 q-grams: 6e-5 per random window
     api.ahocorasick_deinit(res)
 
 

@@ -15,7 +15,7 @@ from php_aho_corasick_amd import api, synth
 
 pytestmark = pytest.mark.gpu
 
-SMALL = ["G1", "G2", "G3", "G4", "G5", "R1", "R2", "R3", "R4", "R5", "R6"]
+SMALL = ["G1", "G2", "G3", "G4", "G5", "R1", "R2", "R3", "R4", "R5", "R6", "R7", "R8"]
 
 
 def _check_golden(res, ds, golden, name, path=host_match):
@@ -63,7 +63,7 @@ VARIANTS = [dict(kernel=1, persistent=1, chunk_bytes=64), dict(kernel=1, persist
             dict(kernel=1, ilp=2, slab_events=1), dict(kernel=1, ilp=1, slab_events=3, chunk_bytes=128)]
 
 
-@pytest.mark.parametrize("name,variant", list(itertools.product(["G2", "G4", "G5", "R1", "R2", "R3", "R4", "R5", "R6"], range(len(VARIANTS)))))
+@pytest.mark.parametrize("name,variant", list(itertools.product(["G2", "G4", "G5", "R1", "R2", "R3", "R4", "R5", "R6", "R7", "R8"], range(len(VARIANTS)))))
 def test_golden_variants(name, variant, golden):
     """Every kernel / ILP / LDS-tile size (forces cold states + trap) / chunk size (forces warm-up
     overlap, R3 has 1 KiB patterns) / slab size (forces the overflow -> refill path)."""
