@@ -125,7 +125,23 @@ int acmi_destroy(acmi_handle *h);
 int acmi_match(acmi_handle *h, const uint8_t *text, size_t length, int find_all,
                const acmi_record **records, size_t *n_records);
 
-/* Batch form of the above (NEW: the reference loops in PHP userland,
+/* Streaming search: MultiFast's keep=1 mode (ac_trie_search(..., keep=1, ...), ahocorasick.c:186-194,
+ * 220, 236-238: the next call continues in the node and at the stream offset the previous one ended).
+ * The PHP extension never uses it (keep=0 at php_ahocorasick.c:745); it is what a caller scanning one
+ * large input in pieces needs.  A stream carries the last max_pattern_length-1 bytes it was fed; every
+ * feed scans [carry | data] from the root and reports the events that END in `data` -- the same events,
+ * in the same order, that keep=1 reports, with pos / start counted from the start of the stream (hay = 0).
+ * Every event is reported (the findAll=false stop does not save the position in the reference either).
+ * Streams of 4 GiB or more are refused (ACMI_E_TOO_LARGE): record positions are 32-bit.
+ * *records / *n_records stay valid until the next feed or close of the same stream. */
+typedef struct acmi_stream acmi_stream;
+int acmi_stream_open(acmi_handle *h, acmi_stream **out);
+int acmi_stream_feed(acmi_handle *h, acmi_stream *s, const uint8_t *data, size_t length,
+                     const acmi_record **records, size_t *n_records);
+uint64_t acmi_stream_position(const acmi_stream *s);   /* bytes fed so far */
+void acmi_stream_close(acmi_stream *s);
+
+/* Batch form of acmi_match (NEW: the reference loops in PHP userland,
  * examples/benchmark.php:65-67).  `blob` holds the haystacks back to back,
  * `offsets[n_haystacks+1]` their byte offsets (non-decreasing).  On return
  * (*prefix)[k] .. (*prefix)[k+1] delimit haystack k's records in *records. */

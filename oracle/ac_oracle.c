@@ -45,6 +45,8 @@ struct orc_trie {
     size_t n, cap;
     int open;                   /* AC_TRIE_t.trie_open */
     size_t patterns_count;
+    uint32_t last_node;         /* AC_TRIE_t.last_node     (ahocorasick.h:55) */
+    size_t base_position;       /* AC_TRIE_t.base_position (ahocorasick.h:56) */
     /* pattern byte copies (the reference keeps them in its mpool) */
     uint8_t **copies;
     size_t ncopies, copies_cap;
@@ -260,15 +262,20 @@ void orc_finalize(orc_trie *t)
     t->open = 0;                                    /* :154 */
 }
 
-/* src/multifast/ahocorasick.c:175-241 with keep=0 and working mode SEARCH:
- * every call starts at the root with base_position 0 (:191-192, :330-335). */
-int orc_search(orc_trie *t, const uint8_t *text, size_t len, orc_callback cb, void *user)
+/* src/multifast/ahocorasick.c:175-241, working mode SEARCH.  keep == 0: the call starts at the root
+ * with base_position 0 (:191-192, :330-335).  keep != 0: it continues from the node and the stream
+ * offset the previous call left (:194, :220, :236-238); a call the callback stopped saves neither. */
+int orc_search_keep(orc_trie *t, const uint8_t *text, size_t len, int keep, orc_callback cb, void *user)
 {
     if (t->open)
         return -1;                                  /* :183-184 */
 
+    if (!keep) {                                    /* ac_trie_reset :330-335 */
+        t->last_node = 0;
+        t->base_position = 0;
+    }
     size_t position = 0;
-    uint32_t current = 0;
+    uint32_t current = t->last_node;                /* :194 */
     while (position < len) {                        /* :199 */
         uint32_t next = find_next_bs(t, current, (int8_t)text[position]);
         if (next == NONE) {
@@ -283,14 +290,21 @@ int orc_search(orc_trie *t, const uint8_t *text, size_t len, orc_callback cb, vo
         /* :214: report only after a goto transition, never after a failure hop */
         if (t->nodes[current].final && next != NONE) {
             orc_match m;
-            m.position = position;                  /* + base_position (0) :220 */
+            m.position = position + t->base_position;   /* :220 */
             m.size = t->nodes[current].m_n;
             m.patterns = t->nodes[current].matched;
             if (cb(&m, user))
                 return 1;                           /* :225-231 */
         }
     }
+    t->last_node = current;                         /* :236 */
+    t->base_position += position;                   /* :237 */
     return 0;
+}
+
+int orc_search(orc_trie *t, const uint8_t *text, size_t len, orc_callback cb, void *user)
+{
+    return orc_search_keep(t, text, len, 0, cb, user);
 }
 
 /* src/multifast/ahocorasick.c:288-296 */
@@ -363,6 +377,17 @@ size_t orc_php_match(orc_trie *t, const uint8_t *text, size_t len, int find_all,
         orc_finalize(t);                            /* lazy finalize :707 */
     php_payload p = { find_all ? 0 : 1, hay, out, cap, 0, 0 };   /* :742 */
     orc_search(t, text, len, php_handler, &p);      /* :745, keep=0 */
+    return p.n;
+}
+
+/* One chunk of a stream: ac_trie_search with keep = !first (ahocorasick.c:175-241); positions count
+ * from the start of the stream.  Every event is reported (the PHP layer has no streaming entry). */
+size_t orc_stream_feed(orc_trie *t, const uint8_t *text, size_t len, int first, uint32_t *out, size_t cap)
+{
+    if (t->open)
+        orc_finalize(t);
+    php_payload p = { 0, 0, out, cap, 0, 0 };
+    orc_search_keep(t, text, len, first ? 0 : 1, php_handler, &p);
     return p.n;
 }
 

@@ -68,6 +68,8 @@ int  orc_add(orc_trie *t, const uint8_t *p, size_t len,
 void orc_finalize(orc_trie *t);                                   /* ahocorasick.c:143-155 */
 int  orc_search(orc_trie *t, const uint8_t *text, size_t len,
                 orc_callback cb, void *user);                     /* ahocorasick.c:175-241 (keep=0) */
+int  orc_search_keep(orc_trie *t, const uint8_t *text, size_t len, int keep,
+                     orc_callback cb, void *user);                /* ahocorasick.c:175-241         */
 void orc_release(orc_trie *t);                                    /* ahocorasick.c:288-296 */
 
 size_t orc_node_count(const orc_trie *t);
@@ -92,6 +94,12 @@ size_t orc_php_add_patterns(orc_trie *t, const uint8_t *blob,
  * only the first `cap` are written to out. */
 size_t orc_php_match(orc_trie *t, const uint8_t *text, size_t len, int find_all,
                      uint32_t hay, uint32_t *out, size_t cap);
+
+/* One chunk of a stream (MultiFast's keep=1 mode, ahocorasick.c:186-194,220,236-238; not reachable from
+ * PHP, which always passes keep=0 at php_ahocorasick.c:745): first != 0 starts a new stream.  Records as
+ * orc_php_match with hay = 0 and positions counted from the start of the stream. */
+size_t orc_stream_feed(orc_trie *t, const uint8_t *text, size_t len, int first,
+                       uint32_t *out, size_t cap);
 
 /* Batch convenience used by goldens and by bench.py's cpu_baseline: runs
  * orc_php_match over nh haystacks (blob + nh+1 offsets), records appended in

@@ -64,6 +64,7 @@ class Oracle:
         f("php_match_batch", C.c_size_t, C.c_void_p, _u8p, _u64p, C.c_size_t, C.c_int, _u64p, _u32p,
           C.c_size_t)
         f("php_scan_checksum", C.c_size_t, C.c_void_p, _u8p, _u64p, C.c_size_t, _u64p)
+        f("stream_feed", C.c_size_t, C.c_void_p, _u8p, C.c_size_t, C.c_int, _u32p, C.c_size_t)
         self.t = self._c("create")()
         self.n_added = 0
 
@@ -122,6 +123,19 @@ class Oracle:
             if n <= cap:
                 return out[:n].copy()
             cap = int(n)
+
+    def stream_feed(self, chunk: bytes, first: bool) -> np.ndarray:
+        """One chunk through MultiFast's keep=1 mode (ahocorasick.c:186-194,236-238): records (n, 4) uint32
+        {0, pos, start, index} with positions counted from the start of the stream."""
+        buf = np.frombuffer(chunk, dtype=np.uint8) if len(chunk) else np.zeros(1, np.uint8)
+        cap = 64 + 4 * len(chunk)
+        while True:
+            out = np.zeros((cap, 4), dtype=np.uint32)
+            n = self._c("stream_feed")(self.t, _ptr(buf, _u8p), len(chunk), int(first), _ptr(out, _u32p), cap)
+            if n <= cap:
+                return out[:n].copy()
+            # the reference saved its state; a retry would double-count: size generously instead
+            raise RuntimeError("stream_feed: output capacity too small")
 
     def match_batch(self, blob: np.ndarray, off: np.ndarray, find_all: bool = True):
         """(counts_prefix[nh+1] uint64, records (n,4) uint32) over a batch, haystack order."""

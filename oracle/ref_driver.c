@@ -97,6 +97,20 @@ size_t ref_php_match(void *t, const uint8_t *text, size_t len, int find_all, uin
     return p.n;
 }
 
+/* one chunk of a stream through the reference's own keep=1 mode */
+size_t ref_stream_feed(void *t, const uint8_t *text, size_t len, int first, uint32_t *out, size_t cap)
+{
+    AC_TRIE_t *trie = (AC_TRIE_t *)t;
+    if (trie->trie_open)
+        ac_trie_finalize(trie);
+    AC_TEXT_t txt;
+    txt.astring = (const AC_ALPHABET_t *)text;
+    txt.length = len;
+    ref_payload p = { 0, 0, out, cap, 0, 0 };
+    ac_trie_search(trie, &txt, first ? 0 : 1, ref_handler, &p);
+    return p.n;
+}
+
 size_t ref_php_match_batch(void *t, const uint8_t *blob, const uint64_t *off, size_t nh,
                            int find_all, uint64_t *counts_prefix, uint32_t *out, size_t cap)
 {

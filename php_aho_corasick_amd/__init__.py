@@ -16,7 +16,7 @@ from __future__ import annotations
 
 _API = ("AhoException", "AhoWarning", "AhoResource", "ahocorasick_init", "ahocorasick_add_patterns",
         "ahocorasick_finalize", "ahocorasick_match", "ahocorasick_match_batch", "ahocorasick_isValid",
-        "ahocorasick_deinit", "match_arrays")
+        "ahocorasick_deinit", "match_arrays", "AhoStream")
 
 __version__ = "0.1.0"
 

@@ -58,6 +58,11 @@ SYMBOLS = {
     "acmi_destroy": (C.c_int, [Handle]),
     "acmi_match": (C.c_int, [Handle, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.POINTER(Record)),
                              C.POINTER(C.c_size_t)]),
+    "acmi_stream_open": (C.c_int, [Handle, C.POINTER(C.c_void_p)]),
+    "acmi_stream_feed": (C.c_int, [Handle, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.POINTER(Record)),
+                                   C.POINTER(C.c_size_t)]),
+    "acmi_stream_position": (C.c_uint64, [C.c_void_p]),
+    "acmi_stream_close": (None, [C.c_void_p]),
     "acmi_match_batch": (C.c_int, [Handle, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
                                    C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.POINTER(Record)),
                                    C.POINTER(C.c_size_t)]),

@@ -350,3 +350,48 @@ def match_arrays(res: AhoResource, blob: np.ndarray, off: np.ndarray, findAll: b
     else:
         records = np.zeros((0, 4), dtype=np.uint32)
     return prefix, records
+
+
+class AhoStream:
+    """Streaming search over one input fed in pieces: MultiFast's keep=1 mode
+    (src/multifast/ahocorasick.c:175-241 with keep != 0), which the PHP extension itself never uses
+    (keep=0 at src/php_ahocorasick.c:745).  Positions count from the start of the stream; a match that
+    straddles two pieces is reported by the feed that delivers its last byte.
+
+        s = AhoStream(res)
+        for piece in pieces:
+            records = s.feed(piece)        # uint32[n, 4] = {0, pos, start, pattern index}
+        s.close()
+    """
+
+    def __init__(self, res: AhoResource):
+        if not isinstance(res, AhoResource) or not res._h:
+            raise ValueError("Invalid resource.")
+        self._res = res
+        self._s = C.c_void_p()
+        N.check(N.lib.acmi_stream_open(res._h, C.byref(self._s)), res._h)
+
+    def feed(self, piece: bytes) -> np.ndarray:
+        buf = np.frombuffer(piece, dtype=np.uint8) if len(piece) else np.zeros(1, np.uint8)
+        rp = C.POINTER(N.Record)()
+        n = C.c_size_t(0)
+        N.check(N.lib.acmi_stream_feed(self._res._h, self._s, buf.ctypes.data, len(piece), C.byref(rp), C.byref(n)),
+                self._res._h)
+        if not n.value:
+            return np.zeros((0, 4), dtype=np.uint32)
+        return np.ctypeslib.as_array(C.cast(rp, C.POINTER(C.c_uint32)), shape=(n.value, 4)).copy()
+
+    @property
+    def position(self) -> int:
+        return int(N.lib.acmi_stream_position(self._s))
+
+    def close(self) -> None:
+        if self._s:
+            N.lib.acmi_stream_close(self._s)
+            self._s = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

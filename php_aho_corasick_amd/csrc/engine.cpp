@@ -52,6 +52,13 @@ std::unordered_set<const acmi_handle *> g_live;
 
 }  // namespace
 
+struct acmi_stream {
+    std::vector<uint8_t> carry;     // last max_pattern_length-1 bytes fed
+    std::vector<uint8_t> buf;       // carry + the chunk being scanned
+    std::vector<acmi_record> out;   // records of the last feed, stream offsets
+    uint64_t base = 0;              // bytes fed so far
+};
+
 struct acmi_handle {
     int init_ok = 0;
     int device_request = -1;
@@ -607,6 +614,52 @@ int acmi_match(acmi_handle *h, const uint8_t *text, size_t length, int find_all,
     if (length >= 0xFFFFFFFFull) return live(h) ? ACMI_E_ARG : ACMI_E_INVALID;
     return acmi_match_batch(h, text, off, 1, find_all, nullptr, records, n_records);
 }
+
+int acmi_stream_open(acmi_handle *h, acmi_stream **out) {
+    if (!live(h)) return ACMI_E_INVALID;
+    if (!out) return ACMI_E_ARG;
+    acmi_stream *s = new (std::nothrow) acmi_stream();
+    if (!s) return ACMI_E_NOMEM;
+    *out = s;
+    return ACMI_OK;
+}
+
+int acmi_stream_feed(acmi_handle *h, acmi_stream *s, const uint8_t *data, size_t length, const acmi_record **records,
+                     size_t *n_records) {
+    int rc = check_ready(h);
+    if (rc < 0) return rc;
+    if (!s || (length && !data)) return ACMI_E_ARG;
+    if (s->base + length >= 0xFFFFFFFFull) { h->last_error = "stream of 4 GiB or more"; return ACMI_E_TOO_LARGE; }
+    const size_t carry = s->carry.size();
+    s->buf.resize(carry + length);
+    if (carry) std::memcpy(s->buf.data(), s->carry.data(), carry);
+    if (length) std::memcpy(s->buf.data() + carry, data, length);
+    const acmi_record *recs = nullptr;
+    size_t n = 0;
+    rc = acmi_match(h, s->buf.data(), s->buf.size(), 1, &recs, &n);
+    if (rc < 0) return rc;
+    // events that end inside the carry were reported by the feed that delivered those bytes
+    s->out.clear();
+    const uint32_t shift = uint32_t(s->base - carry);  // buffer offset -> stream offset
+    for (size_t i = 0; i < n; ++i) {
+        if (recs[i].pos <= carry) continue;
+        acmi_record r = recs[i];
+        r.pos += shift;
+        r.start += shift;
+        s->out.push_back(r);
+    }
+    s->base += length;
+    const uint32_t lmax = h->aut.flat().max_pattern_length;
+    const size_t keep = std::min<size_t>(lmax ? lmax - 1 : 0, s->buf.size());
+    s->carry.assign(s->buf.end() - keep, s->buf.end());
+    if (records) *records = s->out.data();
+    if (n_records) *n_records = s->out.size();
+    return ACMI_OK;
+}
+
+uint64_t acmi_stream_position(const acmi_stream *s) { return s ? s->base : 0; }
+
+void acmi_stream_close(acmi_stream *s) { delete s; }
 
 size_t acmi_pattern_count(const acmi_handle *h) { return live(h) ? h->aut.patterns().size() : 0; }
 

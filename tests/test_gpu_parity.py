@@ -290,3 +290,35 @@ def test_anchor_overlapping_occurrences_of_unequal_length(chunk):
         assert res.stat("kernel_used") == 2 and res.stat("anchor_q") == 8
         api.ahocorasick_deinit(res)
     o.close()
+
+
+@pytest.mark.parametrize("name", ["R1", "R4", "R5", "G5"])
+def test_stream_feed_matches_keep_mode(name):
+    """acmi_stream_feed (carry of Lmax-1 bytes + scan from the root) against the oracle's keep=1 mode:
+    pieces shorter than the longest pattern, empty pieces, matches straddling several pieces."""
+    from php_aho_corasick_amd.api import AhoStream
+    ds = synth.NAMED[name]()
+    res = resource_for(ds)
+    o = Oracle("port")
+    o.add_patterns((ds.pat_blob, ds.pat_off))
+    rng = np.random.default_rng(11)
+    checked = 0
+    for h in range(min(ds.n_haystacks, 12)):
+        text = ds.haystack(h)
+        for sizes in ((1, 4), (1, 40), (200, 3000)):
+            s = AhoStream(res)
+            at, first = 0, True
+            while at < len(text) or first:
+                n = int(rng.integers(sizes[0], sizes[1] + 1)) if rng.integers(0, 8) else 0
+                piece = text[at:at + n]
+                want = o.stream_feed(piece, first)
+                got = s.feed(piece)
+                assert np.array_equal(got, want), (name, h, sizes, at, n)
+                checked += len(want)
+                at += n
+                first = False
+            assert s.position == len(text)
+            s.close()
+    assert checked > 0
+    api.ahocorasick_deinit(res)
+    o.close()

@@ -97,3 +97,24 @@ def test_duplicate_and_rejection_rules():
     o2.add_patterns([b"ab"])
     o2.add_patterns([b"ab"])
     assert [int(r[3]) for r in o2.match(b"ab")] == [0]
+
+
+@pytest.mark.parametrize("kind", ["port", "reference"])
+def test_stream_keep_mode_equals_one_shot(kind):
+    """MultiFast's keep=1 mode (ahocorasick.c:186-194,236-238): feeding a text in pieces reports the same
+    events with the same stream positions as one call over the whole text -- in the restatement and in the
+    reference's own C (and the two agree)."""
+    if kind == "reference" and not pyoracle.have_reference():
+        pytest.skip("oracle/_ref not built here")
+    ds = synth.r4()
+    rng = np.random.default_rng(3)
+    for h in (3, 17, 40):
+        text = ds.haystack(h)
+        o = Oracle(kind)
+        o.add_patterns((ds.pat_blob, ds.pat_off))
+        whole = o.match(text)
+        cuts = sorted(set(int(x) for x in rng.integers(0, len(text) + 1, 9)))
+        pieces = [text[a:b] for a, b in zip([0] + cuts, cuts + [len(text)])] + [b""]
+        got = np.concatenate([o.stream_feed(p, i == 0) for i, p in enumerate(pieces)])
+        assert np.array_equal(got[:, 1:], whole[:, 1:]) and len(whole) > 0
+        o.close()
