@@ -199,6 +199,8 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *                    if a batch shows the text defeats the filter                        [any time]
  *   "ilp"            streams per lane in the LDS-tile kernel (1 or 2)    [any time]
  *   "group_quads"    16-byte loads per lane per fetch group, 4 or 8 (ILP 1) [any time]
+ *   "small_path"     1 (default): host batches of <= 64 KiB in <= 1024 haystacks (every acmi_match of a few
+ *                    KiB) take one launch that reads / writes pinned host memory; 0 = always the pipeline
  *   "wave_items"     anchor kernel: items a wave takes per batch, 1..64 (0 = automatic)
  *   "persistent"     1 = one workgroup per CU, waves pull item batches from a counter; 0 = one
  *                    workgroup per 1024 x ILP items; -1 = automatic (default)   [any time]

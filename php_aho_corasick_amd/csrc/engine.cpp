@@ -73,6 +73,8 @@ struct acmi_handle {
     bool anchor_off = false;  // automatic mode: the anchor filter lost on this handle's data, stay on the table walk
     int ilp = 1;
     int group_quads = 8;
+    int small_path = 1;   // 1: host batches of <= 64 KiB / <= 1024 haystacks take the one-launch kernel
+    uint8_t *pin_small = nullptr;  // pinned host memory of the small path: [summary | prefix | records | offsets | bytes]
     int wave_items = 0;   // 0 automatic, else 1..64 items per wave batch of the anchor kernel
     int persistent = -1;  // -1 automatic, 0 one workgroup per 1024 x ILP items, 1 persistent workgroups
     int profile = 0;
@@ -433,6 +435,59 @@ int run_batch(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, const 
     return run_batch_end(h);
 }
 
+// Small host batches: one launch that reads and writes pinned host memory (k_match_small).  Returns 1 when
+// the batch does not qualify or its records do not fit, and the caller takes the general path.
+constexpr uint32_t kSmallCap = 8192;  // records
+constexpr size_t kSmallSummaryOff = 0, kSmallPrefixOff = 64, kSmallRecordsOff = kSmallPrefixOff + (kSmallPathMaxHay + 8) * 8,
+                 kSmallOffsetsOff = kSmallRecordsOff + size_t(kSmallCap) * 16, kSmallBytesOff = kSmallOffsetsOff + (kSmallPathMaxHay + 8) * 8,
+                 kSmallPinBytes = kSmallBytesOff + kSmallPathMaxBytes + 64;
+
+int run_small(acmi_handle *h, const uint8_t *blob, const uint64_t *offsets, size_t nh, int find_all) {
+    if (!h->small_path || nh == 0 || nh > kSmallPathMaxHay) return 1;
+    const uint64_t span = offsets[nh] - offsets[0];
+    if (span > kSmallPathMaxBytes) return 1;
+    if (!h->pin_small) {
+        if (hipHostMalloc(reinterpret_cast<void **>(&h->pin_small), kSmallPinBytes, hipHostMallocMapped) != hipSuccess) {
+            (void)hipGetLastError();
+            h->pin_small = nullptr;
+            return 1;
+        }
+    }
+    uint8_t *pin = h->pin_small;
+    std::memcpy(pin + kSmallOffsetsOff, offsets, (nh + 1) * 8);
+    if (span) std::memcpy(pin + kSmallBytesOff, blob + offsets[0], span);
+    void *dev = nullptr;
+    HIPCHK(h, hipHostGetDevicePointer(&dev, pin, 0));
+    uint8_t *d = static_cast<uint8_t *>(dev);
+    const FlatAutomaton &fa = h->aut.flat();
+    hipStream_t st = h->stream;
+    if (h->profile) HIPCHK(h, hipEventRecord(h->ev[0], st));
+    HIPCHK(h, launch_match_small(h->dA, reinterpret_cast<const uint64_t *>(d + kSmallOffsetsOff), d + kSmallBytesOff, uint32_t(nh),
+                                 find_all, fa.max_pattern_length, int(fa.entry_bytes), int(fa.class_mode),
+                                 reinterpret_cast<uint64_t *>(d + kSmallSummaryOff), reinterpret_cast<uint64_t *>(d + kSmallPrefixOff),
+                                 d + kSmallRecordsOff, kSmallCap, st));
+    if (h->profile) HIPCHK(h, hipEventRecord(h->ev[4], st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    const uint64_t *summary = reinterpret_cast<const uint64_t *>(pin + kSmallSummaryOff);
+    if (summary[2] != 0) return 1;  // more records than the pinned buffer holds: general path
+    const uint64_t total = summary[0];
+    h->items = summary[1];
+    h->h_prefix.assign(reinterpret_cast<const uint64_t *>(pin + kSmallPrefixOff), reinterpret_cast<const uint64_t *>(pin + kSmallPrefixOff) + nh + 1);
+    h->h_records.assign(reinterpret_cast<const acmi_record *>(pin + kSmallRecordsOff), reinterpret_cast<const acmi_record *>(pin + kSmallRecordsOff) + total);
+    h->last_total = total;
+    h->last_nh = uint32_t(nh);
+    h->have_result = false;  // the result lives in host memory only
+    h->kernel_used = 4;
+    h->overflow_items = 0;
+    h->walked_bytes = 0;
+    if (h->profile) {
+        float ms = 0;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[4]));
+        h->scan_ms = h->total_ms = ms;
+    }
+    return ACMI_OK;
+}
+
 int check_ready(acmi_handle *h) {
     if (!live(h)) return ACMI_E_INVALID;
     if (h->init_ok != 1) return ACMI_E_NOT_INIT;
@@ -505,6 +560,7 @@ int acmi_destroy(acmi_handle *h) {
         for (auto &evt : h->ev)
             if (evt) (void)hipEventDestroy(evt);
         if (h->pinned) (void)hipHostFree(h->pinned);
+        if (h->pin_small) (void)hipHostFree(h->pin_small);
         if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     }
     delete h;
@@ -588,6 +644,16 @@ int acmi_match_batch(acmi_handle *h, const uint8_t *blob, const uint64_t *offset
         }
         blob_bytes = offsets[n_haystacks];
         if (blob_bytes && !blob) return ACMI_E_ARG;
+    }
+    if (n_haystacks) {
+        rc = run_small(h, blob, offsets, n_haystacks, find_all);
+        if (rc < 0) return rc;
+        if (rc == ACMI_OK) {
+            if (prefix) *prefix = h->h_prefix.data();
+            if (records) *records = h->h_records.data();
+            if (n_records) *n_records = h->last_total;
+            return ACMI_OK;
+        }
     }
     hipStream_t st = h->stream;
     // stage the borrowed host buffers (php_ahocorasick.c:725-727 borrows the zend_string)
@@ -702,6 +768,8 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
     } else if (k == "group_quads") {
         if (value != 4 && value != 8) return ACMI_E_ARG;
         h->group_quads = int(value);
+    } else if (k == "small_path") {
+        h->small_path = value ? 1 : 0;
     } else if (k == "wave_items") {
         if (value < 0 || value > 64) return ACMI_E_ARG;
         h->wave_items = int(value);

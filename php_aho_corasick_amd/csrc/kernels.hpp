@@ -27,6 +27,11 @@ void launch_expand(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items
                    uint64_t cap, hipStream_t st);
 void launch_refill(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes,
                    const uint64_t *rec_base, void *out, uint64_t cap, hipStream_t st);
+// one-launch path for small host batches (<= 64 KiB, <= 1024 haystacks): reads / writes pinned host memory
+constexpr uint32_t kSmallPathMaxBytes = 64u * 1024u, kSmallPathMaxHay = 1024u;
+hipError_t launch_match_small(const DevAutomaton &A, const uint64_t *offsets, const uint8_t *blob, uint32_t nh, int find_all,
+                              uint32_t max_pattern_length, int entry_bytes, int class_mode, uint64_t *out_summary,
+                              uint64_t *out_prefix, void *out_records, uint32_t cap, hipStream_t st);
 void launch_stream_read(const void *src, uint64_t bytes, uint32_t *sink, hipStream_t st);
 
 }  // namespace acmi

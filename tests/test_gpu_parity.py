@@ -322,3 +322,39 @@ def test_stream_feed_matches_keep_mode(name):
     assert checked > 0
     api.ahocorasick_deinit(res)
     o.close()
+
+
+def _slice(ds, max_hay, max_bytes):
+    """First haystacks of a dataset that fit the one-launch path's limits."""
+    n = 0
+    while n < min(ds.n_haystacks, max_hay) and int(ds.hay_off[n + 1]) <= max_bytes:
+        n += 1
+    end = int(ds.hay_off[n])
+    return synth.Dataset(ds.name + "-slice", ds.pat_blob, ds.pat_off, ds.hay_blob[:end].copy(), ds.hay_off[:n + 1].copy())
+
+
+@pytest.mark.parametrize("name", ["G2", "G3", "G4", "G5", "R1", "R2", "R3", "R4", "R5", "R6", "R7", "R8"])
+def test_small_batch_one_launch_path(name):
+    """Host batches of <= 64 KiB take k_match_small (one launch on pinned memory); dense ones whose records
+    exceed its buffer fall back to the pipeline.  Both must give the oracle's records, and each other's."""
+    full = synth.NAMED[name]()
+    o = Oracle("port")
+    o.add_patterns((full.pat_blob, full.pat_off))
+    res = resource_for(full)
+    for max_hay, max_bytes in ((1024, 65536), (3, 65536), (1, 9000)):
+        ds = _slice(full, max_hay, max_bytes)
+        if ds.n_haystacks == 0:
+            continue
+        for find_all in (True, False):
+            pe, re_ = o.match_batch(ds.hay_blob, ds.hay_off, find_all)
+            res.set_option("small_path", 1)
+            p1, r1 = host_match(res, ds, find_all)
+            used = res.stat("kernel_used")
+            res.set_option("small_path", 0)
+            p0, r0 = host_match(res, ds, find_all)
+            assert res.stat("kernel_used") != 4
+            assert np.array_equal(p1, pe) and np.array_equal(r1, re_), (name, max_hay, find_all, "small", used)
+            assert np.array_equal(p0, pe) and np.array_equal(r0, re_), (name, max_hay, find_all, "pipeline")
+            assert used == (4 if len(re_) <= 8192 else used)
+    api.ahocorasick_deinit(res)
+    o.close()
