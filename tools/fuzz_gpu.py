@@ -18,9 +18,9 @@ for case in range(n_cases):
     seed = seed0 + case
     r = np.random.default_rng(seed)
     alpha = alphabets[r.integers(len(alphabets))]
-    lmin = int(r.choice([1, 1, 2, 4, 8, 11, 15, 19, 40]))
+    lmin = int(r.choice([1, 1, 2, 4, 7, 8, 11, 15, 19, 40]))
     lmax = int(min(1024, lmin + r.choice([0, 1, 3, 8, 20, 100, 900])))
-    n_pat = int(r.choice([1, 3, 17, 60, 300, 1500]))
+    n_pat = int(r.choice([1, 3, 17, 60, 300, 1500, 4000]))   # 4000 x 4 offsets: the big-set anchor tables
     n_hay = int(r.choice([1, 2, 9, 64, 65, 200]))
     hmax = int(r.choice([0, 1, 15, 16, 17, 127, 128, 129, 1000, 5000, 20000]))
     plants = int(r.choice([0, 1, 3, 10]))
@@ -34,7 +34,8 @@ for case in range(n_cases):
         o.add_patterns(pats[lo:lo + step])
     opts = dict(kernel=int(r.choice([0, 1, 2, 2, 3, 3])), ilp=int(r.choice([1, 2])), group_quads=int(r.choice([4, 8])),
                 chunk_bytes=int(r.choice([0, 0, 16, 48, 256, 1024, 4096])), slab_events=int(r.choice([1, 2, 8])),
-                run_cap=int(r.choice([1, 2, 8])), persistent=int(r.choice([-1, 0, 1])), lds_bytes=int(r.choice([2048, 8192, 65536, 163000])))
+                run_cap=int(r.choice([1, 2, 8])), persistent=int(r.choice([-1, 0, 1])), lds_bytes=int(r.choice([2048, 8192, 65536, 163000])),
+                small_path=int(r.choice([0, 1])))
     res = resource_for(ds, calls=calls, **opts)
     for find_all in (True, False):
         pe, re_ = o.match_batch(ds.hay_blob, ds.hay_off, find_all)
