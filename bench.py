@@ -190,7 +190,9 @@ def main():
             # in flight on RCCL's stream while the next step scans
             pending.append(gatherer.start(batch.result_view(res, total), nh, hay_base))
 
-    gatherer = batch.RecordGatherer(None, dev, capacity=1 << 20) if gather else None
+    # capacity of the fixed-size collective: the planted workload yields one record per haystack (+ slack;
+    # a batch that exceeds it costs one more, larger collective and the capacity stays grown)
+    gatherer = batch.RecordGatherer(None, dev, capacity=max(1 << 16, nh + nh // 8)) if gather else None
     for _ in range(args.warmup):
         step()
     while pending:

@@ -118,6 +118,7 @@ class RecordGatherer:
         self.device = device
         self.cap = int(capacity)
         self._bufs = {}
+        self._hdr, self._base, self._base_val = {}, {}, {}
         self._parity = 0
 
     def _buffers(self, parity: int, cap: int):
@@ -143,12 +144,23 @@ class RecordGatherer:
         cap = self.cap
         parity, self._parity = self._parity, self._parity ^ 1
         send, recv = self._buffers(parity, cap)
-        send[:2] = torch.tensor([n, n_haystacks_local], dtype=torch.int64).to(self.device, non_blocking=True)
+        # header from a per-parity pinned tensor (one async copy), payload with the haystack base added in
+        # the same kernel that copies it: start() runs between two scans, so its host time is exposed
+        cuda = torch.device(self.device).type == "cuda"
+        if parity not in self._hdr:
+            self._hdr[parity] = torch.zeros(2, dtype=torch.int64, pin_memory=cuda)
+            self._base[parity] = torch.zeros((1, 4), dtype=torch.int32, device=self.device)
+        hdr = self._hdr[parity]
+        hdr[0], hdr[1] = n, n_haystacks_local
+        send[:2].copy_(hdr, non_blocking=True)
         m = min(n, cap)
         if m:
+            base = self._base[parity]
+            if self._base_val.get(parity) != hay_base:
+                base[0, 0] = hay_base
+                self._base_val[parity] = hay_base
             pay = send[2:2 + 2 * m].view(torch.int32).view(m, 4)
-            pay.copy_(records_local[:m])
-            pay[:, 0] += hay_base
+            torch.add(records_local[:m], base, out=pay)
         spill = None
         if n > cap:  # rare: keep everything for the second, larger collective
             spill = records_local.clone()
