@@ -109,7 +109,7 @@ __device__ __forceinline__ bool decode_item_uniform(const BatchArgs &B, uint64_t
     return true;
 }
 
-// Packed work-item record for k_scan_anchor: everything its streaming loop and epilogue need about an
+// Packed work-item record for k_scan_anchor and k_walk_runs: everything they need about an
 // item in one 16-byte load, so that opening an item costs no chain of dependent loads
 // (item_hay -> offsets, item_base).  x, y[15:0]: blob offset of the first scanned byte (begin - warm);
 // y[31:16]: warm (<= 1023); z: scanned bytes (warm + len, >= 1); w: pos0.
@@ -580,7 +580,7 @@ __device__ __forceinline__ uint32_t exact_range(const DevAutomaton &A, const Bat
     return s;
 }
 
-// Dense epilogue of the scan kernels: walk the flagged byte runs of one item exactly.  Events only
+// Exact walk of one item's flagged byte runs (k_scan_lds' in-kernel epilogue, k_walk_runs).  Events only
 // arise here, in ascending position order (runs are disjoint and ascending).  A run [lo, hi) whose
 // entry state is unknown is entered from the root Lmax-1 bytes earlier -- exact for every pattern
 // ending inside the run -- and only events ending inside it (and inside the item's reporting range)
@@ -859,7 +859,7 @@ __device__ __forceinline__ bool has_zero_half(uint32_t z) { return ((z - 0x00010
 // One wave streams one work item at a time, 8 KiB per step, with fully coalesced loads (lane l holds
 // quads r*64 + l).  Windows that begin in the previous quad get its last hashed dwords from the
 // neighbouring lane through a DPP wave shift.  A wave owns 64 consecutive items; lane k remembers
-// item k's run count for the lane-per-item epilogue.
+// item k's run count, handed to k_walk_runs when the batch is done.
 struct AnchorCursor {      // wave-uniform position in the wave's (item, chunk) task list
     uint32_t k;            // item index inside the wave, 0..63
     uint32_t c, chunks;    // current 8-KiB chunk of the item, number of chunks (>= 1)
@@ -936,7 +936,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     const uint64_t wave_first = batch_first;
 
     // lane k holds the packed record of item wave_first + k for the whole batch: opening an item is
-    // three v_readlane, and the epilogue needs no table look-ups either
+    // three v_readlane and no memory access
     uint4 rec = make_uint4(0u, 0u, 0u, 0u);
     if (lane < B.wave_items && wave_first + lane < total_items) rec = B.item_rec[wave_first + lane];
     AnchorCursor ld, sc;  // load cursor runs one task ahead of the scan cursor
