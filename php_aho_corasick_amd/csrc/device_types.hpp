@@ -48,7 +48,10 @@ struct BatchArgs {
     uint32_t *overflow_list;     // items whose events did not fit their slab
     uint32_t *counters;          // [0] = number of overflowed items
     // main loop -> epilogue hand-over inside k_scan_lds: byte runs of an item that need the exact path
-    uint4 *runs;                 // per item: run_cap x {lo, hi, entry state or ~0, -}: bytes [lo, hi) in item scan coordinates
+    uint4 *runs;                 // run r of item i at runs[r * run_stride + i]: {lo, hi, entry state or marker, -}, bytes
+                                 // [lo, hi) in item scan coordinates.  Run-major, so that the usual single run per item is
+                                 // written and read as whole lines (item-major: 16 B of every 128-byte line)
+    uint64_t run_stride;         // >= number of items
     uint32_t run_cap;
     uint32_t *run_count;         // per item: runs appended by k_scan_anchor, walked by k_walk_runs (> run_cap: whole item)
     uint32_t poison_quads;       // ceil(max_pattern_length / 16): quads flagged after a lost state

@@ -336,6 +336,7 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
     B.runs = h->d_runs.as<uint4>();
     B.run_count = h->d_run_count.as<uint32_t>();
     B.run_cap = Q;
+    B.run_stride = max_items;
     B.poison_quads = std::max<uint32_t>(1, (fa.max_pattern_length + 15) / 16);
     // persistent workgroups pay off once a CU would otherwise run several workgroups back to back
     // (measured: 1 KiB items -18 %, 2 x 8 KiB per lane +2.5 %)

@@ -447,11 +447,11 @@ constexpr int kLdsThreads = 1024;
 __device__ __forceinline__ void append_run(const BatchArgs &B, uint64_t item, uint32_t lo, uint32_t hi,
                                            uint32_t entry, uint32_t &n, uint32_t &last_hi) {
     if (n > B.run_cap) return;
-    uint4 *runs = B.runs + item * B.run_cap;
+    uint4 *runs = B.runs + item;
     if (n > 0 && last_hi == lo) {
-        runs[n - 1].y = hi;
+        runs[uint64_t(n - 1) * B.run_stride].y = hi;
     } else {
-        if (n < B.run_cap) runs[n] = make_uint4(lo, hi, entry, 0u);
+        if (n < B.run_cap) runs[uint64_t(n) * B.run_stride] = make_uint4(lo, hi, entry, 0u);
         ++n;
     }
     last_hi = hi;
@@ -476,7 +476,7 @@ constexpr uint32_t kEntryShortWarm = 0xFFFFFFFEu;  // k_scan_anchor: m_min-1 byt
 __device__ __forceinline__ void stage_flush(const BatchArgs &B, uint64_t wave_first, RunStage &st, uint32_t lane) {
     for (uint32_t i = lane; i < st.count; i += 64u) {
         const uint4 e = st.slots[i];
-        B.runs[(wave_first + (e.x & 0xffu)) * B.run_cap + (e.x >> 8)] = make_uint4(e.y, e.z, e.w, 0u);
+        B.runs[uint64_t(e.x >> 8) * B.run_stride + wave_first + (e.x & 0xffu)] = make_uint4(e.y, e.z, e.w, 0u);
     }
     st.count = 0;
     st.mergeable = false;
@@ -599,10 +599,10 @@ __device__ __forceinline__ uint32_t run_epilogue(const DevAutomaton &A, const Ba
         walked = n;
         exact_range<E, MODE>(A, B, cls_lds, tile, tile_rows, item, p, 0, n, it.warm, pos_bias, 0u, ev);
     } else {
-        const uint4 *runs = B.runs + item * B.run_cap;
+        const uint4 *runs = B.runs + item;
 #pragma unroll 1
         for (uint32_t r = 0; r < nr; ++r) {
-            const uint4 run = runs[r];
+            const uint4 run = runs[uint64_t(r) * B.run_stride];
             const uint32_t lo = run.x, hi = run.y;
             uint32_t st = run.z, from = lo;
             walked += hi - lo;
