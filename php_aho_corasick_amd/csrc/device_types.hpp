@@ -44,7 +44,7 @@ struct BatchArgs {
     uint4 *item_rec;             // per item: {scan offset lo, hi | warm << 16, scan bytes, pos0} (k_scan_anchor)
     uint32_t *ev_count;          // per item: events seen
     uint64_t *rec_count;         // per item: records those events expand to
-    uint2 *slab;                 // per item: K x {pos, state}
+    uint2 *slab;                 // event e of item i at slab[e * run_stride + i]: {pos, state}; K events per item
     uint32_t *overflow_list;     // items whose events did not fit their slab
     uint32_t *counters;          // [0] = number of overflowed items
     // main loop -> epilogue hand-over inside k_scan_lds: byte runs of an item that need the exact path

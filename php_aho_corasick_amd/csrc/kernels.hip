@@ -147,7 +147,7 @@ __device__ __forceinline__ void on_event(const DevAutomaton &A, const BatchArgs 
     const uint32_t n = B.ev_count[item];
     if (B.first_only && n) return;  // findAll=false: the first event only (php_ahocorasick.c:588)
     B.rec_count[item] += A.out_count[s];
-    if (n < B.slab_events) B.slab[item * B.slab_events + n] = make_uint2(pos, s);
+    if (n < B.slab_events) B.slab[uint64_t(n) * B.run_stride + item] = make_uint2(pos, s);
     B.ev_count[item] = n + 1;
 }
 
@@ -573,7 +573,7 @@ __device__ __forceinline__ uint32_t exact_range(const DevAutomaton &A, const Bat
         s = w;
         if (j >= rep_from && is_final(A, s) && !(B.first_only && ev.n_ev)) {
             ev.n_rec += A.out_count[s];
-            if (ev.n_ev < B.slab_events) B.slab[item * B.slab_events + ev.n_ev] = make_uint2(pos_bias + j, s);
+            if (ev.n_ev < B.slab_events) B.slab[uint64_t(ev.n_ev) * B.run_stride + item] = make_uint2(pos_bias + j, s);
             ++ev.n_ev;
         }
     }
@@ -1299,8 +1299,10 @@ __global__ void k_expand(DevAutomaton A, BatchArgs B, const uint64_t *rec_base, 
     if (rec_base[i + 1] > cap) return;
     const uint32_t hay = B.item_hay[i];
     uint64_t w = rec_base[i];
-    const uint2 *ev = B.slab + i * B.slab_events;
-    for (uint32_t e = 0; e < n; ++e) w = emit_event(A, out, w, hay, ev[e].x, ev[e].y);
+    for (uint32_t e = 0; e < n; ++e) {
+        const uint2 ev = B.slab[uint64_t(e) * B.run_stride + i];  // event-major, like the run lists
+        w = emit_event(A, out, w, hay, ev.x, ev.y);
+    }
 }
 
 // Overflowed items: scan again, writing records straight into their final slots.  Grid-stride over
