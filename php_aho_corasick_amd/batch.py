@@ -134,7 +134,8 @@ class RecordGatherer:
 
     def _launch(self, send, recv, async_op):
         import torch.distributed as dist
-        return dist.all_gather(list(recv.view(self.world, -1).unbind(0)), send, group=self.group, async_op=async_op)
+        # one flat output buffer: the list form makes the backend gather into a temporary and copy out
+        return dist.all_gather_into_tensor(recv, send, group=self.group, async_op=async_op)
 
     def start(self, records_local, n_haystacks_local: int, hay_base: int):
         import torch
