@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--kernel", type=int, default=-1, help="scan kernel: 1 LDS-tile table walk, 2 anchor filter, default automatic")
     ap.add_argument("--no-plant", action="store_true", help="analysis only: no planted hits (the reference's own benchmark has ~0 matches)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--phase-times", action="store_true", help="analysis: add the host time per step phase to the JSON")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -176,37 +177,63 @@ def main():
     scan_ms = []
     records_per_step = 0
 
+    ready = []   # (records view, count) of the batch collected last: shipped after the next scan is enqueued
+
+    phase = {"begin": 0.0, "gather_finish": 0.0, "gather_start": 0.0, "end": 0.0}   # host seconds, --phase-times
+
     def step():
         nonlocal records_per_step
-        # enqueue the scan, then do the previous batches' gather bookkeeping while the GPU scans
+        # enqueue the scan first, then do the gather bookkeeping of the previous batches while the GPU scans:
+        # a batch's records stay valid while the next one runs (acmi_result_device)
+        t_a = time.perf_counter()
         batch.match_device_begin(res, d_blob, d_off, True)
-        while len(pending) > 1:
+        t_b = time.perf_counter()
+        while len(pending) > 2:  # three collectives in flight: the oldest has long finished, finish() does not block
             gatherer.finish(pending.pop(0))
+        t_c = time.perf_counter()
+        if ready:
+            # all-gatherv of the match arrays: one asynchronous fixed-capacity collective per step,
+            # in flight on RCCL's stream while later steps scan
+            pending.append(gatherer.start(ready.pop(0), nh, hay_base))
+        t_d = time.perf_counter()
         total = batch.match_device_end(res)
+        t_e = time.perf_counter()
+        phase["begin"] += t_b - t_a
+        phase["gather_finish"] += t_c - t_b
+        phase["gather_start"] += t_d - t_c
+        phase["end"] += t_e - t_d
         records_per_step = total
         scan_ms.append(res.stat("scan_ms"))
         if gather:
-            # all-gatherv of the match arrays: one asynchronous fixed-capacity collective per step,
-            # in flight on RCCL's stream while the next step scans
-            pending.append(gatherer.start(batch.result_view(res, total), nh, hay_base))
+            ready.append(batch.result_view(res, total))
 
     # capacity of the fixed-size collective: the planted workload yields one record per haystack (+ slack;
     # a batch that exceeds it costs one more, larger collective and the capacity stays grown)
-    gatherer = batch.RecordGatherer(None, dev, capacity=max(1 << 16, nh + nh // 8)) if gather else None
+    gatherer = batch.RecordGatherer(None, dev, capacity=max(1 << 16, nh + nh // 8), depth=3) if gather else None
+
+    def drain():
+        out = None
+        while ready:
+            while len(pending) > 2:
+                out = gatherer.finish(pending.pop(0))
+            pending.append(gatherer.start(ready.pop(0), nh, hay_base))
+        while pending:
+            out = gatherer.finish(pending.pop(0))
+        return out
+
     for _ in range(args.warmup):
         step()
-    while pending:
-        gatherer.finish(pending.pop(0))
+    drain()
     scan_ms.clear()
+    for k_ in phase:
+        phase[k_] = 0.0
     if gather:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    gathered = None
-    while pending:
-        gathered = gatherer.finish(pending.pop(0))
+    gathered = drain()
     torch.cuda.synchronize()
     if gather:
         dist.barrier()
@@ -256,6 +283,8 @@ def main():
                          "frac_of_measured_stream_read": round(achieved / stream_read_gbs, 4)},
             "cpu_baseline": cpu1, "cpu_baseline_all_cores": cpu_all,
         }
+        if args.phase_times:
+            out["host_us_per_step"] = {k: round(v / args.steps * 1e6, 1) for k, v in phase.items()}
         print(json.dumps(out), flush=True)
     api.ahocorasick_deinit(res)
     if gather:

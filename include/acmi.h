@@ -165,7 +165,9 @@ int acmi_match_batch_device_begin(acmi_handle *h, const void *d_blob, uint64_t b
 int acmi_match_batch_device_end(acmi_handle *h, uint64_t *n_records);
 
 /* Device pointers of the last result: prefix = uint64[n_haystacks+1],
- * records = acmi_record[n_records].  Valid until the next match call. */
+ * records = acmi_record[n_records].  The memory stays valid until the SECOND next match call on the
+ * handle (results alternate between two buffers), so a caller may enqueue the next batch first and ship
+ * this result while it runs. */
 int acmi_result_device(acmi_handle *h, const void **d_prefix, const void **d_records,
                        uint64_t *n_records);
 

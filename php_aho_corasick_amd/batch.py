@@ -108,10 +108,12 @@ class RecordGatherer:
     ``start`` only enqueues (payload copy on the current stream, then the collective on the
     backend's stream), so the caller can scan its next batch while this one travels over xGMI;
     ``finish`` waits, reads the headers and returns ``(prefix int64[n_global+1], records int32[n,4])``.
-    Buffers are double-buffered by parity: at most two batches in flight.
+    Buffers rotate over ``depth`` slots (default 2): at most ``depth`` batches between start and finish.
+    With the scan kernel holding every CU's LDS, a collective started during step t only gets CUs when that
+    step's scan lets go, so a caller that must not block in ``finish`` keeps three in flight.
     """
 
-    def __init__(self, group=None, device=None, capacity: int = 1 << 16):
+    def __init__(self, group=None, device=None, capacity: int = 1 << 16, depth: int = 2):
         import torch.distributed as dist
         self.group = group
         self.world = dist.get_world_size(group)
@@ -120,6 +122,7 @@ class RecordGatherer:
         self._bufs = {}
         self._hdr, self._base, self._base_val = {}, {}, {}
         self._parity = 0
+        self.depth = max(2, int(depth))
 
     def _buffers(self, parity: int, cap: int):
         import torch
@@ -143,7 +146,7 @@ class RecordGatherer:
             self.device = records_local.device
         n = int(records_local.shape[0])
         cap = self.cap
-        parity, self._parity = self._parity, self._parity ^ 1
+        parity, self._parity = self._parity, (self._parity + 1) % self.depth
         send, recv = self._buffers(parity, cap)
         # header from a per-parity pinned tensor (one async copy), payload with the haystack base added in
         # the same kernel that copies it: start() runs between two scans, so its host time is exposed
@@ -175,7 +178,9 @@ class RecordGatherer:
         import torch
         if self.device is not None and torch.device(self.device).type == "cuda":
             if getattr(self, "_side", None) is None:
-                self._side = torch.cuda.Stream(device=self.device)
+                # high priority: its own hardware queue (HIP maps streams onto a few; behind the scan kernel's
+                # queue the unpack would wait for the whole scan)
+                self._side = torch.cuda.Stream(device=self.device, priority=-1)
             main = torch.cuda.current_stream(self.device)
             # no side.wait_stream(main): the collective already ordered itself after the payload copy,
             # and waiting for `main` here would serialise behind the scan that is running on it
@@ -207,10 +212,14 @@ class RecordGatherer:
         parts = [rows[r, 2:2 + 2 * int(hdr[r, 0])].view(torch.int32).view(-1, 4) for r in range(self.world)]
         records = torch.cat(parts) if parts else torch.zeros((0, 4), dtype=torch.int32, device=self.device)
         nh_global = int(hdr[:, 1].sum())
-        counts = torch.bincount(records[:, 0].long(), minlength=nh_global) if records.shape[0] else \
-            torch.zeros(nh_global, dtype=torch.int64, device=self.device)
-        prefix = torch.zeros(nh_global + 1, dtype=torch.int64, device=self.device)
-        prefix[1:] = torch.cumsum(counts, 0)
+        # records are sorted by global haystack id, so prefix[h] = first record with id >= h: one binary-search
+        # kernel.  (bincount + cumsum use LDS, which the scan kernel holds on every CU: queued on the side
+        # stream they only ran once a scan let go, and the next finish() blocked behind them.)
+        if records.shape[0]:
+            prefix = torch.searchsorted(records[:, 0].contiguous(),
+                                        torch.arange(nh_global + 1, dtype=torch.int32, device=self.device))
+        else:
+            prefix = torch.zeros(nh_global + 1, dtype=torch.int64, device=self.device)
         return prefix, records
 
 

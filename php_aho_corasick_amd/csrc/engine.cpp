@@ -90,7 +90,8 @@ struct acmi_handle {
 
     // workspace (grow-only)
     DevBuf d_blob, d_off, d_nitems, d_item_base, d_item_hay, d_item_rec, d_zero, d_rec_base, d_slab, d_ovf, d_counters,
-        d_scan_tmp, d_prefix, d_out, d_runs, d_run_count;
+        d_scan_tmp, d_prefix, d_out, d_runs, d_run_count,
+        d_prefix_alt, d_out_alt;  // result buffers alternate: a batch's records stay valid while the next one runs
     uint64_t *pinned = nullptr;  // host copy of the device counters block (64 B)
 
     // last result
@@ -266,6 +267,10 @@ uint32_t choose_chunk(const acmi_handle *h, uint64_t blob_bytes, int kernel) {
 int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, const uint64_t *d_off, size_t nh,
               int find_all) {
     h->have_result = false;
+    // The previous batch's prefix array and records stay untouched by this one (they are valid until the
+    // begin after this): a caller can enqueue the next scan first and ship the last result meanwhile.
+    std::swap(h->d_out, h->d_out_alt);
+    std::swap(h->d_prefix, h->d_prefix_alt);
     h->scan_ms = h->total_ms = 0;
     h->items = 0;
     h->overflow_items = 0;
@@ -556,7 +561,7 @@ int acmi_destroy(acmi_handle *h) {
         if (h->stream) (void)hipStreamSynchronize(h->stream);
         for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_blob,
                           &h->d_off, &h->d_nitems, &h->d_item_base, &h->d_item_hay, &h->d_item_rec, &h->d_zero,
-                          &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_scan_tmp, &h->d_prefix, &h->d_out, &h->d_runs, &h->d_run_count})
+                          &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_scan_tmp, &h->d_prefix, &h->d_out, &h->d_runs, &h->d_run_count, &h->d_prefix_alt, &h->d_out_alt})
             b->release();
         for (auto &evt : h->ev)
             if (evt) (void)hipEventDestroy(evt);
