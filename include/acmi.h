@@ -206,6 +206,12 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *   "wave_items"     anchor kernel: items a wave takes per batch, 1..64 (0 = automatic)
  *   "persistent"     1 = one workgroup per CU, waves pull item batches from a counter; 0 = one
  *                    workgroup per 1024 x ILP items; -1 = automatic (default)   [any time]
+ *   "max_flat_outputs"  per-state output lists are also stored flat ({pattern, length}, longest first) for the
+ *                    dense-match drain when they total at most this many entries (default 2^25);
+ *                    0 = dictionary links only                                  [before finalize]
+ *   "refill"         drain of work items whose events overflowed their slab (dense-match inputs):
+ *                    1 = one thread per item, 2 = one wave per item with whole-row record stores,
+ *                    0 = automatic (default): 2 unless the longest pattern exceeds 64 B   [any time]
  *   "profile"        1 = bracket the scan kernel with HIP events         [any time] */
 int acmi_set_option(acmi_handle *h, const char *key, int64_t value);
 

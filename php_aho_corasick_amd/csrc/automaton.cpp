@@ -274,6 +274,33 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
         if (patterns_[i].accepted) fa.max_pattern_length = std::max(fa.max_pattern_length, patterns_[i].length);
     }
 
+    // ---- flat output lists (matched[] of the reference's nodes) ------------------------------------
+    fa.out_off.clear();
+    fa.out_list.clear();
+    fa.max_out_count = 0;
+    {
+        uint64_t total = 0;
+        for (uint32_t s = 0; s < fa.n_states; ++s) {
+            total += fa.out_count[s];
+            fa.max_out_count = std::max(fa.max_out_count, fa.out_count[s]);
+        }
+        if (total <= opt.max_flat_outputs) {
+            fa.out_off.assign(fa.n_states, 0);
+            fa.out_list.resize(size_t(total) * 2);
+            uint32_t at = 0;
+            for (uint32_t s = 0; s < fa.n_states; ++s) {
+                if (fa.out_count[s] == 0) continue;
+                fa.out_off[s] = at;
+                for (uint32_t t = fa.own_pattern[s] != kNone ? s : fa.dict_link[s]; t != kNone; t = fa.dict_link[t]) {
+                    const uint32_t pat = fa.own_pattern[t];
+                    fa.out_list[size_t(at) * 2] = pat;
+                    fa.out_list[size_t(at) * 2 + 1] = fa.pattern_length[pat];
+                    ++at;
+                }
+            }
+        }
+    }
+
     // ---- anchor filter table -------------------------------------------------------------------
     fa.min_pattern_length = 0;
     for (const PatternMeta &m : patterns_)

@@ -37,6 +37,7 @@ struct PatternMeta {
 struct BuildOptions {
     uint32_t lds_bytes = 160 * 1024 - 512;  // budget for class table + hot tile
     uint64_t max_table_bytes = 64ull << 30; // refuse automata whose table exceeds this
+    uint64_t max_flat_outputs = 1ull << 25; // flat output lists up to this many entries (256 MiB), else dictionary links only
 };
 
 enum ClassMode : uint32_t { kClassTable = 0, kClassSwar3 = 1 };
@@ -63,6 +64,14 @@ struct FlatAutomaton {
     std::vector<uint32_t> dict_link;    // per state: nearest failure ancestor owning a pattern
     std::vector<uint32_t> out_count;    // per state: records one event expands to
     std::vector<uint32_t> pattern_length;  // per caller-order pattern index
+    // The same output lists flattened the way the reference keeps them per node (matched[], node.h:49-51,
+    // filled by node_collect_matches, node.c:424-441): entries out_off[s] .. out_off[s] + out_count[s] are
+    // {pattern index, pattern length} of state s's event, longest first.  The dense-match drain reads them
+    // with independent loads instead of chasing dict_link.  Left empty (the drain then follows the links)
+    // when the lists would exceed BuildOptions::max_flat_outputs entries -- nested pattern families can square.
+    std::vector<uint32_t> out_off;      // per state (valid where out_count > 0)
+    std::vector<uint32_t> out_list;     // 2 words per entry: pattern, length
+    uint32_t max_out_count = 0;
 
     // ---- anchor filter (optional front end of the scan, see kernels.hip k_scan_anchor) ----
     // Every occurrence of a pattern of length >= q + 3 contains a 4-byte-aligned text dword within

@@ -16,6 +16,9 @@ struct DevAutomaton {
     const uint32_t *dict_link;   // per state
     const uint32_t *out_count;   // per state
     const uint32_t *pattern_length;  // per pattern
+    const uint32_t *out_off;     // per state: first entry of its flat output list (null: follow dict_link)
+    const uint2 *out_list;       // {pattern, length}, longest first
+    uint32_t max_out_count;      // longest output list
     uint32_t n_states;
     uint32_t n_columns;
     uint32_t row_bytes;          // n_columns * entry_bytes

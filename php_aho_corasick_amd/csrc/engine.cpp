@@ -77,6 +77,7 @@ struct acmi_handle {
     uint8_t *pin_small = nullptr;  // pinned host memory of the small path: [summary | prefix | records | offsets | bytes]
     int wave_items = 0;   // 0 automatic, else 1..64 items per wave batch of the anchor kernel
     int persistent = -1;  // -1 automatic, 0 one workgroup per 1024 x ILP items, 1 persistent workgroups
+    int refill = 0;       // 0 automatic, 1 one thread per overflowed item (k_refill), 2 one wave (k_refill_wave)
     int profile = 0;
 
     // device state
@@ -86,7 +87,7 @@ struct acmi_handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     DevAutomaton dA{};
-    DevBuf d_table, d_lds, d_class, d_own, d_dict, d_cnt, d_plen, d_anchor, d_bitmap;
+    DevBuf d_table, d_lds, d_class, d_own, d_dict, d_cnt, d_plen, d_anchor, d_bitmap, d_out_off, d_out_list;
 
     // workspace (grow-only)
     DevBuf d_blob, d_off, d_nitems, d_item_base, d_item_hay, d_item_rec, d_zero, d_rec_base, d_slab, d_ovf, d_counters,
@@ -205,6 +206,14 @@ int ensure_device(acmi_handle *h) {
     if (!fa.pattern_length.empty())
         HIPCHK(h, hipMemcpy(h->d_plen.p, fa.pattern_length.data(), fa.pattern_length.size() * 4, hipMemcpyHostToDevice));
 
+    if (!fa.out_off.empty()) {
+        HIPCHK(h, h->d_out_off.ensure(ns4));
+        HIPCHK(h, hipMemcpy(h->d_out_off.p, fa.out_off.data(), ns4, hipMemcpyHostToDevice));
+        HIPCHK(h, h->d_out_list.ensure(std::max<size_t>(8, fa.out_list.size() * 4)));
+        if (!fa.out_list.empty())
+            HIPCHK(h, hipMemcpy(h->d_out_list.p, fa.out_list.data(), fa.out_list.size() * 4, hipMemcpyHostToDevice));
+    }
+
     if (fa.anchor_q) {
         HIPCHK(h, h->d_anchor.ensure(fa.anchor_table.size() * 2));
         HIPCHK(h, hipMemcpy(h->d_anchor.p, fa.anchor_table.data(), fa.anchor_table.size() * 2, hipMemcpyHostToDevice));
@@ -230,6 +239,9 @@ int ensure_device(acmi_handle *h) {
     A.dict_link = h->d_dict.as<uint32_t>();
     A.out_count = h->d_cnt.as<uint32_t>();
     A.pattern_length = h->d_plen.as<uint32_t>();
+    A.out_off = fa.out_off.empty() ? nullptr : h->d_out_off.as<uint32_t>();
+    A.out_list = fa.out_off.empty() ? nullptr : h->d_out_list.as<uint2>();
+    A.max_out_count = fa.max_out_count;
     A.n_states = fa.n_states;
     A.n_columns = fa.n_columns;
     A.row_bytes = fa.n_columns * fa.entry_bytes;
@@ -377,7 +389,7 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
     HIPCHK(h, h->d_out.ensure(16));
     const uint64_t cap = h->d_out.cap / 16;
     launch_expand(h->dA, B, max_items, h->d_rec_base.as<uint64_t>(), h->d_out.p, cap, st);
-    if (find_all) launch_refill(h->dA, B, max_items, int(fa.entry_bytes), h->d_rec_base.as<uint64_t>(), h->d_out.p, cap, st);
+    if (find_all) launch_refill(h->dA, B, max_items, int(fa.entry_bytes), h->d_rec_base.as<uint64_t>(), h->d_out.p, cap, h->refill, st);
     HIPCHK(h, hipMemcpyAsync(h->pinned, d_counters, 64, hipMemcpyDeviceToHost, st));
     if (h->profile) HIPCHK(h, hipEventRecord(h->ev[4], st));
     HIPCHK(h, hipGetLastError());
@@ -425,7 +437,7 @@ int run_batch_end(acmi_handle *h) {
         launch_expand(h->dA, h->fly_args, h->fly_max_items, h->d_rec_base.as<uint64_t>(), h->d_out.p, cap, st);
         if (h->fly_find_all)
             launch_refill(h->dA, h->fly_args, h->fly_max_items, int(fa.entry_bytes), h->d_rec_base.as<uint64_t>(),
-                          h->d_out.p, cap, st);
+                          h->d_out.p, cap, h->refill, st);
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipStreamSynchronize(st));
     }
@@ -559,7 +571,7 @@ int acmi_destroy(acmi_handle *h) {
     if (h->dev_ready) {
         (void)hipSetDevice(h->dev_id);
         if (h->stream) (void)hipStreamSynchronize(h->stream);
-        for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_blob,
+        for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_out_off, &h->d_out_list, &h->d_blob,
                           &h->d_off, &h->d_nitems, &h->d_item_base, &h->d_item_hay, &h->d_item_rec, &h->d_zero,
                           &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_scan_tmp, &h->d_prefix, &h->d_out, &h->d_runs, &h->d_run_count, &h->d_prefix_alt, &h->d_out_alt})
             b->release();
@@ -781,8 +793,15 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
         h->wave_items = int(value);
     } else if (k == "persistent") {
         h->persistent = value < 0 ? -1 : (value ? 1 : 0);
+    } else if (k == "refill") {
+        if (value < 0 || value > 2) return ACMI_E_ARG;
+        h->refill = int(value);
     } else if (k == "profile") {
         h->profile = value ? 1 : 0;
+    } else if (k == "max_flat_outputs") {
+        if (h->aut.finalized()) return ACMI_E_FINALIZED;
+        if (value < 0) return ACMI_E_ARG;
+        h->bopt.max_flat_outputs = uint64_t(value);
     } else if (k == "max_table_bytes") {
         if (h->aut.finalized()) return ACMI_E_FINALIZED;
         if (value < 1024) return ACMI_E_ARG;
@@ -822,6 +841,8 @@ int acmi_get_stat(const acmi_handle *h, const char *key, double *value) {
     else if (k == "min_pattern_length") *value = fa.min_pattern_length;
     else if (k == "total_ms") *value = h->total_ms;
     else if (k == "records") *value = double(h->last_total);
+    else if (k == "flat_outputs") *value = double(fa.out_list.size() / 2);
+    else if (k == "max_out_count") *value = fa.max_out_count;
     else return ACMI_E_ARG;
     return ACMI_OK;
 }

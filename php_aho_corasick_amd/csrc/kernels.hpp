@@ -26,7 +26,7 @@ void launch_hay_prefix(const uint64_t *item_base, const uint64_t *rec_base, uint
 void launch_expand(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, const uint64_t *rec_base, void *out,
                    uint64_t cap, hipStream_t st);
 void launch_refill(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes,
-                   const uint64_t *rec_base, void *out, uint64_t cap, hipStream_t st);
+                   const uint64_t *rec_base, void *out, uint64_t cap, int mode, hipStream_t st);
 // one-launch path for small host batches (<= 64 KiB, <= 1024 haystacks): reads / writes pinned host memory
 constexpr uint32_t kSmallPathMaxBytes = 64u * 1024u, kSmallPathMaxHay = 1024u;
 hipError_t launch_match_small(const DevAutomaton &A, const uint64_t *offsets, const uint8_t *blob, uint32_t nh, int find_all,

@@ -60,7 +60,11 @@ VARIANTS = [dict(kernel=1, persistent=1, chunk_bytes=64), dict(kernel=1, persist
             dict(kernel=1, ilp=1, lds_bytes=4096), dict(kernel=1, ilp=2, lds_bytes=2048),
             dict(kernel=1, ilp=1, chunk_bytes=64), dict(kernel=1, ilp=2, chunk_bytes=256),
             dict(kernel=0, chunk_bytes=16), dict(kernel=1, ilp=1, chunk_bytes=4096, slab_events=1),
-            dict(kernel=1, ilp=2, slab_events=1), dict(kernel=1, ilp=1, slab_events=3, chunk_bytes=128)]
+            dict(kernel=1, ilp=2, slab_events=1), dict(kernel=1, ilp=1, slab_events=3, chunk_bytes=128),
+            # both drains of overflowed items on every dataset: one thread per item / one wave per item
+            dict(kernel=1, slab_events=1, refill=2, chunk_bytes=512), dict(kernel=2, slab_events=1, refill=1),
+            dict(kernel=0, slab_events=1, refill=2, chunk_bytes=48), dict(kernel=2, slab_events=2, refill=2, chunk_bytes=1000),
+            dict(kernel=1, slab_events=1, refill=2, max_flat_outputs=0)]
 
 
 @pytest.mark.parametrize("name,variant", list(itertools.product(["G2", "G4", "G5", "R1", "R2", "R3", "R4", "R5", "R6", "R7", "R8"], range(len(VARIANTS)))))
@@ -73,10 +77,12 @@ def test_golden_variants(name, variant, golden):
     api.ahocorasick_deinit(res)
 
 
-def test_overflow_path_is_taken():
+@pytest.mark.parametrize("refill,flat", [(0, 1), (1, 1), (2, 1), (2, 0)])
+def test_overflow_path_is_taken(refill, flat):
     ds = synth.g3(n_hay=3, hay_len=4096)
-    res = resource_for(ds, slab_events=2)
+    res = resource_for(ds, slab_events=2, refill=refill, **({} if flat else {"max_flat_outputs": 0}))
     prefix, rec = host_match(res, ds)
+    assert (res.stat("flat_outputs") > 0) == bool(flat)
     assert res.stat("overflow_items") > 0
     assert len(rec) == 3 * (16 * 4096 - 120)  # NH * (K*HL - K(K-1)/2), SURVEY.md 8d config 5
     o = Oracle("port")
