@@ -206,6 +206,10 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *   "wave_items"     anchor kernel: items a wave takes per batch, 1..64 (0 = automatic)
  *   "persistent"     1 = one workgroup per CU, waves pull item batches from a counter; 0 = one
  *                    workgroup per 1024 x ILP items; -1 = automatic (default)   [any time]
+ *   "cold_chains"    states outside the LDS tile that are non-final and have one trie child (the inside of a
+ *                    long pattern) get consecutive ids along the pattern and a 4-byte edge word, so that the
+ *                    exact walk of a candidate reads one line per 32 steps instead of one table row per step:
+ *                    1 = always, 0 = never, -1 (default) = when the table exceeds 16 MiB   [before finalize]
  *   "max_flat_outputs"  per-state output lists are also stored flat ({pattern, length}, longest first) for the
  *                    dense-match drain when they total at most this many entries (default 2^25);
  *                    0 = dictionary links only                                  [before finalize]
@@ -251,6 +255,11 @@ typedef struct acmi_tables {
     uint32_t anchor_mode;         /* 0 none, 1 LDS table, 2 LDS bitmap + global table */
     uint32_t anchor_bucket_bits;  /* mode 2                                    */
     const uint32_t *anchor_bitmap;/* mode 2: 32768 words (2^20 bits)           */
+    uint32_t chain_lo;            /* states [chain_lo, first_cold_final): cold, non-final, one trie child, in trie preorder */
+    uint32_t n_flat_outputs;      /* entries of out_list (0: dictionary links only) */
+    const uint32_t *chain;        /* per such state: child id << 8 | edge byte (null: none) */
+    const uint32_t *out_off;      /* per state: first entry of its flat output list */
+    const uint32_t *out_list;     /* 2 words per entry: pattern index, pattern length; longest first */
 } acmi_tables;
 int acmi_debug_tables(const acmi_handle *h, acmi_tables *out);
 

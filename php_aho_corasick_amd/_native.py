@@ -44,7 +44,9 @@ class Tables(C.Structure):
                 ("out_count", C.POINTER(C.c_uint32)),
                 ("anchor_q", C.c_uint32), ("anchor_mul", C.c_uint32), ("min_pattern_length", C.c_uint32),
                 ("anchor_keys", C.c_uint32), ("anchor_table", C.POINTER(C.c_uint16)),
-                ("anchor_mode", C.c_uint32), ("anchor_bucket_bits", C.c_uint32), ("anchor_bitmap", C.POINTER(C.c_uint32))]
+                ("anchor_mode", C.c_uint32), ("anchor_bucket_bits", C.c_uint32), ("anchor_bitmap", C.POINTER(C.c_uint32)),
+                ("chain_lo", C.c_uint32), ("n_flat_outputs", C.c_uint32), ("chain", C.POINTER(C.c_uint32)),
+                ("out_off", C.POINTER(C.c_uint32)), ("out_list", C.POINTER(C.c_uint32))]
 
 
 Handle = C.c_void_p

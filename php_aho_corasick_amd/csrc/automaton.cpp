@@ -236,20 +236,49 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
     if (max_rows < 2) max_rows = 2;  // root + trap always fit (row <= 1 KiB)
     const uint32_t hot = uint32_t(std::min<uint64_t>(ns, max_rows - 1));
     std::vector<uint32_t> newid(ns);
-    uint32_t hot_nf = 0, cold_nf = 0;
+    // Cold non-final states with exactly one trie child ("chain" states: the inside of a long pattern) can
+    // be numbered last among the cold non-final ones, in trie preorder, so that a chain s1 -> s2 -> ... has
+    // consecutive ids and chain[] (one word per such state: child id << 8 | edge byte) is read sequentially.
+    // A walk along a pattern then touches one 128-byte line per 32 steps instead of one table row per step.
+    const bool chains = opt.cold_chains > 0 || (opt.cold_chains < 0 && table_bytes > (16ull << 20));
+    const bool use_chains = chains && fa.n_states < (1u << 24);
+    std::vector<uint8_t> in_chain(use_chains ? ns : 0, 0);
+    uint32_t hot_nf = 0, cold_nf = 0, cold_chain = 0;
     for (uint32_t i = 0; i < ns; ++i) {
         const uint32_t u = order[i];
-        if (!is_final[u]) (i < hot ? hot_nf : cold_nf)++;
+        if (!is_final[u]) {
+            (i < hot ? hot_nf : cold_nf)++;
+            if (use_chains && i >= hot && child_off[u + 1] - child_off[u] == 1) { in_chain[u] = 1; ++cold_chain; }
+        }
     }
     fa.f1 = hot_nf;
     fa.trap = hot;
     fa.f2 = hot + 1 + cold_nf;
+    fa.chain_lo = fa.f2 - cold_chain;
     {
         uint32_t a = 0, b = hot_nf, c = hot + 1, d = fa.f2;
         for (uint32_t i = 0; i < ns; ++i) {
             const uint32_t u = order[i];
             if (i < hot) newid[u] = is_final[u] ? b++ : a++;
-            else newid[u] = is_final[u] ? d++ : c++;
+            else if (is_final[u]) newid[u] = d++;
+            else if (!use_chains || !in_chain[u]) newid[u] = c++;
+        }
+    }
+    fa.chain.clear();
+    if (cold_chain) {
+        uint32_t c = fa.chain_lo;
+        std::vector<uint32_t> stack{0};
+        while (!stack.empty()) {  // trie preorder; children pushed in reverse so they pop in byte order
+            const uint32_t u = stack.back();
+            stack.pop_back();
+            if (in_chain[u]) newid[u] = c++;
+            for (uint32_t e = child_off[u + 1]; e > child_off[u]; --e) stack.push_back(child_list[e - 1]);
+        }
+        fa.chain.assign(cold_chain, 0xFFFFFFFFu);
+        for (uint32_t u = 0; u < ns; ++u) {
+            if (!in_chain[u]) continue;
+            const uint32_t v = child_list[child_off[u]];
+            fa.chain[newid[u] - fa.chain_lo] = (newid[v] << 8) | in_byte_[v];
         }
     }
 

@@ -37,6 +37,7 @@ struct PatternMeta {
 struct BuildOptions {
     uint32_t lds_bytes = 160 * 1024 - 512;  // budget for class table + hot tile
     uint64_t max_table_bytes = 64ull << 30; // refuse automata whose table exceeds this
+    int cold_chains = -1;                   // chain[] for cold single-child states: -1 = when the table exceeds 16 MiB, 0 = never, 1 = always
     uint64_t max_flat_outputs = 1ull << 25; // flat output lists up to this many entries (256 MiB), else dictionary links only
 };
 
@@ -50,6 +51,7 @@ struct FlatAutomaton {
     uint32_t f1 = 0;             // [0,f1) hot non-final, [f1,trap) hot final
     uint32_t trap = 0;           // id of the trap row == number of hot states
     uint32_t f2 = 0;             // (trap,f2) cold non-final, [f2,n_states) cold final
+    uint32_t chain_lo = 0;       // [chain_lo,f2): cold non-final states with one trie child, in trie preorder (== f2: none)
     uint32_t class_mode = kClassTable;
     uint32_t swar_shift = 0;     // class = (byte >> shift) & 7 when byte is in the alphabet
     uint32_t swar_other = 0;     // column of every byte outside the alphabet
@@ -64,6 +66,7 @@ struct FlatAutomaton {
     std::vector<uint32_t> dict_link;    // per state: nearest failure ancestor owning a pattern
     std::vector<uint32_t> out_count;    // per state: records one event expands to
     std::vector<uint32_t> pattern_length;  // per caller-order pattern index
+    std::vector<uint32_t> chain;        // per state of [chain_lo,f2): child id << 8 | edge byte
     // The same output lists flattened the way the reference keeps them per node (matched[], node.h:49-51,
     // filled by node_collect_matches, node.c:424-441): entries out_off[s] .. out_off[s] + out_count[s] are
     // {pattern index, pattern length} of state s's event, longest first.  The dense-match drain reads them

@@ -19,6 +19,8 @@ struct DevAutomaton {
     const uint32_t *out_off;     // per state: first entry of its flat output list (null: follow dict_link)
     const uint2 *out_list;       // {pattern, length}, longest first
     uint32_t max_out_count;      // longest output list
+    const uint32_t *chain;       // states [chain_lo,f2) (cold, non-final, one trie child): child << 8 | edge byte; null: none
+    uint32_t chain_lo;
     uint32_t n_states;
     uint32_t n_columns;
     uint32_t row_bytes;          // n_columns * entry_bytes

@@ -87,7 +87,7 @@ struct acmi_handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     DevAutomaton dA{};
-    DevBuf d_table, d_lds, d_class, d_own, d_dict, d_cnt, d_plen, d_anchor, d_bitmap, d_out_off, d_out_list;
+    DevBuf d_table, d_lds, d_class, d_own, d_dict, d_cnt, d_plen, d_anchor, d_bitmap, d_out_off, d_out_list, d_chain;
 
     // workspace (grow-only)
     DevBuf d_blob, d_off, d_nitems, d_item_base, d_item_hay, d_item_rec, d_zero, d_rec_base, d_slab, d_ovf, d_counters,
@@ -214,6 +214,11 @@ int ensure_device(acmi_handle *h) {
             HIPCHK(h, hipMemcpy(h->d_out_list.p, fa.out_list.data(), fa.out_list.size() * 4, hipMemcpyHostToDevice));
     }
 
+    if (!fa.chain.empty()) {
+        HIPCHK(h, h->d_chain.ensure(fa.chain.size() * 4));
+        HIPCHK(h, hipMemcpy(h->d_chain.p, fa.chain.data(), fa.chain.size() * 4, hipMemcpyHostToDevice));
+    }
+
     if (fa.anchor_q) {
         HIPCHK(h, h->d_anchor.ensure(fa.anchor_table.size() * 2));
         HIPCHK(h, hipMemcpy(h->d_anchor.p, fa.anchor_table.data(), fa.anchor_table.size() * 2, hipMemcpyHostToDevice));
@@ -242,6 +247,8 @@ int ensure_device(acmi_handle *h) {
     A.out_off = fa.out_off.empty() ? nullptr : h->d_out_off.as<uint32_t>();
     A.out_list = fa.out_off.empty() ? nullptr : h->d_out_list.as<uint2>();
     A.max_out_count = fa.max_out_count;
+    A.chain = fa.chain.empty() ? nullptr : h->d_chain.as<uint32_t>();
+    A.chain_lo = fa.chain_lo;
     A.n_states = fa.n_states;
     A.n_columns = fa.n_columns;
     A.row_bytes = fa.n_columns * fa.entry_bytes;
@@ -571,7 +578,7 @@ int acmi_destroy(acmi_handle *h) {
     if (h->dev_ready) {
         (void)hipSetDevice(h->dev_id);
         if (h->stream) (void)hipStreamSynchronize(h->stream);
-        for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_out_off, &h->d_out_list, &h->d_blob,
+        for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_out_off, &h->d_out_list, &h->d_chain, &h->d_blob,
                           &h->d_off, &h->d_nitems, &h->d_item_base, &h->d_item_hay, &h->d_item_rec, &h->d_zero,
                           &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_scan_tmp, &h->d_prefix, &h->d_out, &h->d_runs, &h->d_run_count, &h->d_prefix_alt, &h->d_out_alt})
             b->release();
@@ -798,6 +805,9 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
         h->refill = int(value);
     } else if (k == "profile") {
         h->profile = value ? 1 : 0;
+    } else if (k == "cold_chains") {
+        if (h->aut.finalized()) return ACMI_E_FINALIZED;
+        h->bopt.cold_chains = value < 0 ? -1 : (value ? 1 : 0);
     } else if (k == "max_flat_outputs") {
         if (h->aut.finalized()) return ACMI_E_FINALIZED;
         if (value < 0) return ACMI_E_ARG;
@@ -843,6 +853,7 @@ int acmi_get_stat(const acmi_handle *h, const char *key, double *value) {
     else if (k == "records") *value = double(h->last_total);
     else if (k == "flat_outputs") *value = double(fa.out_list.size() / 2);
     else if (k == "max_out_count") *value = fa.max_out_count;
+    else if (k == "chain_states") *value = double(fa.chain.size());
     else return ACMI_E_ARG;
     return ACMI_OK;
 }
@@ -881,6 +892,11 @@ int acmi_debug_tables(const acmi_handle *h, acmi_tables *out) {
     out->anchor_bucket_bits = fa.anchor_bucket_bits;
     out->anchor_bitmap = fa.anchor_mode == 2 ? fa.anchor_bitmap.data() : nullptr;
     out->anchor_table = fa.anchor_q ? fa.anchor_table.data() : nullptr;
+    out->chain_lo = fa.chain_lo;
+    out->n_flat_outputs = uint32_t(fa.out_list.size() / 2);
+    out->chain = fa.chain.empty() ? nullptr : fa.chain.data();
+    out->out_off = fa.out_off.empty() ? nullptr : fa.out_off.data();
+    out->out_list = fa.out_list.empty() ? nullptr : fa.out_list.data();
     return ACMI_OK;
 }
 

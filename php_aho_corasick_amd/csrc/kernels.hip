@@ -570,8 +570,16 @@ __device__ __forceinline__ uint32_t exact_range(const DevAutomaton &A, const Bat
         const uint32_t coff = class_offset<E, MODE>(A, cls_lds, byte);
         uint32_t w = A.trap;
         if (s < tile_rows) w = *reinterpret_cast<const E *>(tile + s * A.row_bytes + coff);  // LDS-resident row
-        if (w >= A.trap)
-            w = *reinterpret_cast<const E *>(static_cast<const uint8_t *>(A.table) + uint64_t(s) * A.row_bytes + coff);
+        if (w >= A.trap) {
+            // cold row.  Inside a long pattern the state has one trie child: its edge is in chain[], which is
+            // laid out along the pattern (32 steps per 128-byte line; the table costs one line per step)
+            uint32_t cw = 0xFFFFFFFFu;
+            if (A.chain != nullptr && s >= A.chain_lo && s < A.f2) cw = A.chain[s - A.chain_lo];
+            if ((cw & 0xffu) == byte && cw != 0xFFFFFFFFu)
+                w = cw >> 8;
+            else
+                w = *reinterpret_cast<const E *>(static_cast<const uint8_t *>(A.table) + uint64_t(s) * A.row_bytes + coff);
+        }
         s = w;
         if (j >= rep_from && is_final(A, s) && !(B.first_only && ev.n_ev)) {
             ev.n_rec += A.out_count[s];

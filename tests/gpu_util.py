@@ -14,13 +14,13 @@ def resource_for(ds, calls: int = 1, **options):
     res = api.ahocorasick_init(pats[:step] if calls > 1 else pats)
     assert res is not False
     for k, v in options.items():
-        if k in ("lds_bytes", "max_table_bytes", "max_flat_outputs"):
+        if k in ("lds_bytes", "max_table_bytes", "max_flat_outputs", "cold_chains"):
             res.set_option(k, v)
     for lo in range(step, len(pats), step):
         if calls > 1:
             assert api.ahocorasick_add_patterns(res, pats[lo:lo + step])
     for k, v in options.items():
-        if k not in ("lds_bytes", "max_table_bytes", "max_flat_outputs"):
+        if k not in ("lds_bytes", "max_table_bytes", "max_flat_outputs", "cold_chains"):
             res.set_option(k, v)
     return res
 

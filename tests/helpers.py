@@ -62,6 +62,12 @@ class FlatTables:
         self.dict = np.ctypeslib.as_array(t.dict_link, shape=(t.n_states,)).astype(np.int64)
         self.cnt = np.ctypeslib.as_array(t.out_count, shape=(t.n_states,)).astype(np.int64)
         _ = dt
+        self.chain_lo = t.chain_lo
+        self.chain = np.ctypeslib.as_array(t.chain, shape=(self.f2 - t.chain_lo,)).astype(np.int64) if t.chain else None
+        self.out_off = self.out_list = None
+        if t.out_off:
+            self.out_off = np.ctypeslib.as_array(t.out_off, shape=(t.n_states,)).astype(np.int64)
+            self.out_list = np.ctypeslib.as_array(t.out_list, shape=(max(t.n_flat_outputs, 1), 2)).astype(np.int64)[:t.n_flat_outputs]
         self.anchor_q, self.anchor_mul, self.min_pattern_length = t.anchor_q, t.anchor_mul, t.min_pattern_length
         self.anchor_keys = t.anchor_keys
         self.anchor_mode, self.anchor_bucket_bits = t.anchor_mode, t.anchor_bucket_bits
@@ -99,11 +105,18 @@ class FlatTables:
         tab, lds, cls, trap = self.table, self.lds, self.cls, self.trap
         for j, b in enumerate(text):
             c = cls[b]
+            w = trap
             if use_lds and s < trap:
-                w = lds[s, c]
-                s = int(w) if w < trap else int(tab[s, c])
-            else:
-                s = int(tab[s, c])
+                w = int(lds[s, c])
+            if w >= trap:
+                # cold row: the chain word of a single-child state first (kernels.hip exact_range)
+                cw = int(self.chain[s - self.chain_lo]) if self.chain is not None and self.chain_lo <= s < self.f2 else NONE
+                if cw != NONE and (cw & 0xFF) == b:
+                    w = cw >> 8
+                    assert w == int(tab[s, c]), "chain edge disagrees with the table"
+                else:
+                    w = int(tab[s, c])
+            s = w
             if self.is_final(s):
                 pos = j + 1
                 t = s if self.own[s] != NONE else int(self.dict[s])
@@ -113,6 +126,10 @@ class FlatTables:
                     recs.append((hay, pos, pos - int(pat_len[pat]), pat))
                     t = int(self.dict[t])
                 assert len(recs) - n0 == self.cnt[s]
+                if self.out_off is not None:  # the flat list says the same, in the same order
+                    o = int(self.out_off[s])
+                    flat = [(hay, pos, pos - int(l), int(p)) for p, l in self.out_list[o:o + int(self.cnt[s])]]
+                    assert flat == recs[n0:], "flat output list disagrees with the dictionary links"
                 if not find_all:
                     break
         return recs

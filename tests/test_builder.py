@@ -28,13 +28,22 @@ def _compare(ds, res, max_hay=6, calls=1):
 
 
 @pytest.mark.parametrize("name", ["G2", "G3", "G4", "G5", "R1", "R2", "R3"])
-@pytest.mark.parametrize("lds", [None, 2048])
-def test_tables_match_oracle(name, lds):
+@pytest.mark.parametrize("lds,chains", [(None, -1), (2048, 0), (2048, 1)])
+def test_tables_match_oracle(name, lds, chains):
     ds = synth.NAMED[name]()
     opts = {"lds_bytes": lds} if lds else {}
-    res = resource_for(ds, **opts)
+    res = resource_for(ds, cold_chains=chains, **opts)
     api.ahocorasick_finalize(res)
     ft = _compare(ds, res, max_hay=3 if name in ("G2", "R3") else 6)
+    assert ft.out_off is not None
+    if chains == 1 and name in ("G2", "R2", "R3"):
+        # long patterns outside a 2 KiB tile: chain states exist, are numbered along their pattern ...
+        assert ft.chain is not None and ft.trap < ft.chain_lo < ft.f2
+        nxt = ft.chain >> 8
+        inside = (nxt >= ft.chain_lo) & (nxt < ft.f2)
+        assert np.all(nxt[inside] == np.arange(ft.chain_lo, ft.f2)[inside] + 1)  # ... child of a chain state = next id
+    if chains == 0:
+        assert ft.chain is None and ft.chain_lo == ft.f2
     # numbering invariants the kernels rely on
     assert 0 < ft.f1 <= ft.trap < ft.n_states and ft.trap < ft.f2 <= ft.n_states
     assert np.all(ft.lds <= ft.trap)                      # tile never points outside itself

@@ -64,7 +64,10 @@ VARIANTS = [dict(kernel=1, persistent=1, chunk_bytes=64), dict(kernel=1, persist
             # both drains of overflowed items on every dataset: one thread per item / one wave per item
             dict(kernel=1, slab_events=1, refill=2, chunk_bytes=512), dict(kernel=2, slab_events=1, refill=1),
             dict(kernel=0, slab_events=1, refill=2, chunk_bytes=48), dict(kernel=2, slab_events=2, refill=2, chunk_bytes=1000),
-            dict(kernel=1, slab_events=1, refill=2, max_flat_outputs=0)]
+            dict(kernel=1, slab_events=1, refill=2, max_flat_outputs=0),
+            # chain words for cold single-child states (forced; automatic only for tables > 16 MiB)
+            dict(kernel=1, lds_bytes=2048, cold_chains=1), dict(kernel=2, lds_bytes=4096, cold_chains=1, chunk_bytes=256),
+            dict(kernel=0, cold_chains=1), dict(kernel=3, cold_chains=1, lds_bytes=8192, run_cap=1)]
 
 
 @pytest.mark.parametrize("name,variant", list(itertools.product(["G2", "G4", "G5", "R1", "R2", "R3", "R4", "R5", "R6", "R7", "R8"], range(len(VARIANTS)))))

@@ -11,10 +11,15 @@ ds = synth.g6(n_hay=4096, hay_len=4096)
 t0 = time.time()
 res = api.ahocorasick_init([{"id": k, "value": ds.pattern(k)} for k in range(ds.n_patterns)])
 t1 = time.time()
+BUILD_OPTS = ("lds_bytes", "max_table_bytes", "max_flat_outputs", "cold_chains")
+for k, v in opts.items():
+    if k in BUILD_OPTS:
+        res.set_option(k, int(v))
 api.ahocorasick_finalize(res)
 t2 = time.time()
 for k, v in opts.items():
-    res.set_option(k, int(v))
+    if k not in BUILD_OPTS:
+        res.set_option(k, int(v))
 res.set_option("profile", 1)
 print(f"add {t1-t0:.2f}s finalize {t2-t1:.2f}s states {int(res.stat('states'))} table {res.stat('table_bytes')/1e9:.2f} GB "
       f"hot {int(res.stat('hot_states'))} cols {int(res.stat('columns'))} mode {int(res.stat('class_mode'))}")
@@ -32,4 +37,5 @@ for _ in range(3):
     total = batch.match_device(res, d_blob, d_off)
     torch.cuda.synchronize()
     dt = time.time() - t0
-    print(f"scan {d_blob.numel()/dt/1e9:.2f} GB/s whole-job, kernel {res.stat('scan_ms'):.2f} ms = {d_blob.numel()/res.stat('scan_ms')/1e6:.2f} GB/s, records {total}")
+    print(f"scan {d_blob.numel()/dt/1e9:.2f} GB/s whole-job ({dt*1e3:.2f} ms), kernel {res.stat('scan_ms'):.2f} ms = {d_blob.numel()/res.stat('scan_ms')/1e6:.2f} GB/s, "
+          f"records {total}, chain states {int(res.stat('chain_states'))}")
