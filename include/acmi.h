@@ -209,7 +209,8 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *   "cold_chains"    states outside the LDS tile that are non-final and have one trie child (the inside of a
  *                    long pattern) get consecutive ids along the pattern and a 4-byte edge word, so that the
  *                    exact walk of a candidate reads one line per 32 steps instead of one table row per step:
- *                    1 = always, 0 = never, -1 (default) = when the table exceeds 16 MiB   [before finalize]
+ *                    1 = always, 0 = never (default: the walks are bound by far-memory latency in SIMT
+ *                    lockstep, not by lines fetched -- no gain measured), -1 = when the table exceeds 16 MiB   [before finalize]
  *   "max_flat_outputs"  per-state output lists are also stored flat ({pattern, length}, longest first) for the
  *                    dense-match drain when they total at most this many entries (default 2^25);
  *                    0 = dictionary links only                                  [before finalize]

@@ -37,7 +37,7 @@ struct PatternMeta {
 struct BuildOptions {
     uint32_t lds_bytes = 160 * 1024 - 512;  // budget for class table + hot tile
     uint64_t max_table_bytes = 64ull << 30; // refuse automata whose table exceeds this
-    int cold_chains = -1;                   // chain[] for cold single-child states: -1 = when the table exceeds 16 MiB, 0 = never, 1 = always
+    int cold_chains = 0;                    // chain[] for cold single-child states: 0 = never (default: measured no gain), 1 = always, -1 = when the table exceeds 16 MiB
     uint64_t max_flat_outputs = 1ull << 25; // flat output lists up to this many entries (256 MiB), else dictionary links only
 };
 

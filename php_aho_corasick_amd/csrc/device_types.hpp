@@ -21,6 +21,7 @@ struct DevAutomaton {
     uint32_t max_out_count;      // longest output list
     const uint32_t *chain;       // states [chain_lo,f2) (cold, non-final, one trie child): child << 8 | edge byte; null: none
     uint32_t chain_lo;
+    uint32_t class_identity;     // TABLE mode with 256 columns: class(byte) == byte
     uint32_t n_states;
     uint32_t n_columns;
     uint32_t row_bytes;          // n_columns * entry_bytes

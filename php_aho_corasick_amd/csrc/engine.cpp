@@ -249,6 +249,7 @@ int ensure_device(acmi_handle *h) {
     A.max_out_count = fa.max_out_count;
     A.chain = fa.chain.empty() ? nullptr : h->d_chain.as<uint32_t>();
     A.chain_lo = fa.chain_lo;
+    A.class_identity = (fa.class_mode == kClassTable && fa.n_columns == 256) ? 1u : 0u;
     A.n_states = fa.n_states;
     A.n_columns = fa.n_columns;
     A.row_bytes = fa.n_columns * fa.entry_bytes;

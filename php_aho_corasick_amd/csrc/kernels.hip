@@ -529,6 +529,7 @@ __device__ __forceinline__ uint32_t class_offset(const DevAutomaton &A, const ui
         const uint32_t e = __builtin_amdgcn_perm(A.swar_expect_hi, A.swar_expect_lo, c | 0x0c0c0c00u);
         return e == byte ? c * uint32_t(sizeof(E)) : A.swar_other_off;
     }
+    if (A.class_identity) return byte * uint32_t(sizeof(E));  // all 256 byte values in use: no lookup (one dependent load less per step)
     return cls_lds ? cls_lds[byte] : A.class_off[byte];
 }
 
