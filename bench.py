@@ -93,7 +93,7 @@ def cpu_baseline(ds, seconds_target: float = 12.0):
     return one, allc
 
 
-def dense_leg(torch, api, batch, synth, dev, nh=2048, k=16):
+def dense_leg(torch, api, batch, synth, dev, nh=4096, k=16):
     """Secondary figure, outside the timed region: BASELINE configs[4], the adversarial high-hit-rate set
     (patterns a^1..a^16 over haystacks of 'a': 16 records = 256 B written per byte read), whole calls of
     acmi_match_batch_device on a resident batch.  Write-bound: the rate is set against the same 8 TB/s."""
