@@ -306,7 +306,7 @@ def main():
             "automaton_build_ms": round(build_ms, 2),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": {1: "k_scan_lds", 2: "k_scan_anchor", 0: "k_scan_simple"}.get(int(res.stat("kernel_used")), "?"), "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes": algo_bytes,
+                         "kernel": {1: "k_scan_lds", 2: "k_scan_anchor", 0: "k_scan_simple", 4: "k_walk_items"}.get(int(res.stat("kernel_used")), "?"), "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes": algo_bytes,
                          "measured_stream_read_GBs": round(stream_read_gbs, 1),
                          "frac_of_measured_stream_read": round(achieved / stream_read_gbs, 4)},
             "cpu_baseline": cpu1, "cpu_baseline_all_cores": cpu_all,

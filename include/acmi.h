@@ -198,7 +198,10 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *                    filter + exact table walk of the candidates (needs a shortest pattern
  *                    >= 7 B and a collision-free table seed exists, else falls back to 1), 3 = automatic
  *                    (default): 2 when eligible, and back to 1 for the rest of the handle's life
- *                    if a batch shows the text defeats the filter                        [any time]
+ *                    if a batch shows the text defeats the filter; from 1 on to 4 if a batch shows
+ *                    that its optimistic pass flags most bytes anyway; 4 = exact table walk of whole
+ *                    work items only (keyword-like and dense-match text)                 [any time]
+ *   "walk_ilp"       work items per thread of kernel 4: 1 (default), 2 or 4             [any time]
  *   "ilp"            streams per lane in the LDS-tile kernel (1 or 2)    [any time]
  *   "group_quads"    16-byte loads per lane per fetch group, 4 or 8 (ILP 1) [any time]
  *   "small_path"     1 (default): host batches of <= 64 KiB in <= 1024 haystacks (every acmi_match of a few
@@ -222,7 +225,8 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value);
 
 /* Numeric facts about the automaton and the last match call, e.g. "states",
  * "hot_states", "columns", "entry_bytes", "lds_image_bytes", "table_bytes",
- * "max_pattern_length", "items", "overflow_items", "walked_bytes", "kernel_used", "scan_ms", "total_ms". */
+ * "max_pattern_length", "items", "overflow_items", "walked_bytes", "kernel_used" (0, 1, 2, 4 as the "kernel"
+ * option; 5 = the one-launch small-batch path), "scan_ms", "total_ms". */
 int acmi_get_stat(const acmi_handle *h, const char *key, double *value);
 
 /* Run subsequent launches on this hipStream_t (passed as void*); NULL = the

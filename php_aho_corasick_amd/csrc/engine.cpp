@@ -71,12 +71,14 @@ struct acmi_handle {
     uint64_t chunk_opt = 0;
     int kernel = 3;  // 0 plain global table, 1 LDS-tile walk, 2 anchor filter (if eligible), 3 automatic
     bool anchor_off = false;  // automatic mode: the anchor filter lost on this handle's data, stay on the table walk
+    bool exact_only = false;  // automatic mode: k_scan_lds' optimistic pass flagged most of a batch, walk exactly from now on
     int ilp = 1;
     int group_quads = 8;
     int small_path = 1;   // 1: host batches of <= 64 KiB / <= 1024 haystacks take the one-launch kernel
     uint8_t *pin_small = nullptr;  // pinned host memory of the small path: [summary | prefix | records | offsets | bytes]
     int wave_items = 0;   // 0 automatic, else 1..64 items per wave batch of the anchor kernel
     int persistent = -1;  // -1 automatic, 0 one workgroup per 1024 x ILP items, 1 persistent workgroups
+    int walk_ilp = 1;     // k_walk_items: work items per thread (1, 2 or 4; hipcc serialises the streams: 1 is fastest)
     int refill = 0;       // 0 automatic, 1 one thread per overflowed item (k_refill), 2 one wave (k_refill_wave)
     int profile = 0;
 
@@ -313,8 +315,9 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
     const FlatAutomaton &fa = h->aut.flat();
     // the anchor filter needs a pattern set that allows it; automatic mode also leaves it once a batch
     // showed that this handle's text defeats it (see run_batch_end)
-    const int kernel = h->kernel == 3 ? ((fa.anchor_q && !h->anchor_off) ? 2 : 1)
-                                      : ((h->kernel == 2 && !fa.anchor_q) ? 1 : h->kernel);
+    int kernel = h->kernel == 3 ? ((fa.anchor_q && !h->anchor_off) ? 2 : 1)
+                                : ((h->kernel == 2 && !fa.anchor_q) ? 1 : h->kernel);
+    if (h->kernel == 3 && kernel == 1 && h->exact_only) kernel = 4;
     h->kernel_used = kernel;
     const uint32_t chunk = choose_chunk(h, blob_bytes, kernel);
     const uint64_t max_items = blob_bytes / chunk + nh;
@@ -380,7 +383,13 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
     launch_build_items(B, max_items, st);
 
     if (h->profile) HIPCHK(h, hipEventRecord(h->ev[1], st));
-    HIPCHK(h, launch_scan(h->dA, B, max_items, int(fa.entry_bytes), kernel, int(fa.class_mode), h->ilp, h->group_quads, st));
+    if (kernel == 4) {
+        // exact walk only (k_walk_items, `walk_ilp` items per thread): for text on which k_scan_lds' optimistic
+        // pass flags everything anyway (events in every wave-quad)
+        HIPCHK(h, launch_walk_items(h->dA, B, max_items, int(fa.entry_bytes), int(fa.class_mode), h->walk_ilp, st));
+    } else {
+        HIPCHK(h, launch_scan(h->dA, B, max_items, int(fa.entry_bytes), kernel, int(fa.class_mode), h->ilp, h->group_quads, st));
+    }
     if (h->profile) HIPCHK(h, hipEventRecord(h->ev[2], st));
     // the anchor kernel only flags byte runs; their exact walk is a kernel of its own (one thread per item)
     if (kernel == 2) HIPCHK(h, launch_walk_runs(h->dA, B, max_items, int(fa.entry_bytes), int(fa.class_mode), st));
@@ -432,6 +441,9 @@ int run_batch_end(acmi_handle *h) {
     for (int i = 7; i < 16; ++i) h->walked_bytes += uint64_t(reinterpret_cast<uint32_t *>(h->pinned)[i]) * 16;
     // automatic mode: a batch of which more than a quarter had to be walked exactly defeats the filter
     if (h->kernel == 3 && h->kernel_used == 2 && h->walked_bytes * 4 > h->fly_blob_bytes) h->anchor_off = true;
+    // ... and one of which more than half was flagged by the LDS-tile kernel's optimistic pass (events or tile
+    // exits in most wave-quads: keyword-like and dense-match text) is walked exactly right away from now on
+    if (h->kernel == 3 && h->kernel_used == 1 && h->walked_bytes * 2 > h->fly_blob_bytes) h->exact_only = true;
     if (h->profile) {
         float ms = 0;
         HIPCHK(h, hipEventElapsedTime(&ms, h->ev[1], h->ev[2]));
@@ -503,7 +515,7 @@ int run_small(acmi_handle *h, const uint8_t *blob, const uint64_t *offsets, size
     h->last_total = total;
     h->last_nh = uint32_t(nh);
     h->have_result = false;  // the result lives in host memory only
-    h->kernel_used = 4;
+    h->kernel_used = 5;  // k_match_small
     h->overflow_items = 0;
     h->walked_bytes = 0;
     if (h->profile) {
@@ -785,9 +797,10 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
         if (value < 0) return ACMI_E_ARG;
         h->chunk_opt = uint64_t(value);
     } else if (k == "kernel") {
-        if (value < 0 || value > 3) return ACMI_E_ARG;
+        if (value < 0 || value > 4) return ACMI_E_ARG;
         h->kernel = int(value);
         h->anchor_off = false;
+        h->exact_only = false;
     } else if (k == "ilp") {
         if (value != 1 && value != 2) return ACMI_E_ARG;
         h->ilp = int(value);
@@ -801,6 +814,9 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
         h->wave_items = int(value);
     } else if (k == "persistent") {
         h->persistent = value < 0 ? -1 : (value ? 1 : 0);
+    } else if (k == "walk_ilp") {
+        if (value != 1 && value != 2 && value != 4) return ACMI_E_ARG;
+        h->walk_ilp = int(value);
     } else if (k == "refill") {
         if (value < 0 || value > 2) return ACMI_E_ARG;
         h->refill = int(value);

@@ -1265,6 +1265,141 @@ hipError_t launch_walk_runs(const DevAutomaton &A, const BatchArgs &B, uint64_t 
 }
 
 // ------------------------------------------------------------------------------------------
+// k_walk_items: exact walk of WHOLE work items, ILP items per thread (kernel 4).
+//
+// For text on which k_scan_lds' optimistic pass flags everything anyway -- keyword-like sets with events
+// in every wave-quad, the dense sets of BASELINE configs[4] -- the table walk is all there is, and one
+// walk per thread is a chain of dependent lookups of which, in a wave of 64, some lane always goes to L2:
+// ~1 us per lockstep step at full occupancy.  Here a thread walks ILP items in one loop, so that the
+// lookups of its streams are issued back to back and wait together.  Same tile, same event rule and slab
+// layout as run_epilogue; byte classes staged in LDS next to the tile.
+// ------------------------------------------------------------------------------------------
+template <typename E, int MODE, int ILP>
+__global__ __launch_bounds__(kWalkThreads) void k_walk_items(DevAutomaton A, BatchArgs B) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint64_t total_items = B.item_base[B.n_haystacks];
+    const uint64_t first = uint64_t(blockIdx.x) * (kWalkThreads * ILP);
+    if (first >= total_items) return;
+    __shared__ uint32_t s_walked;
+    if (threadIdx.x == 0) s_walked = 0;
+    uint64_t item[ILP];
+    uint4 rec[ILP];
+#pragma unroll
+    for (int k = 0; k < ILP; ++k) {
+        item[k] = first + uint64_t(k) * kWalkThreads + threadIdx.x;
+        rec[k] = item[k] < total_items ? B.item_rec[item[k]] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    // LDS: [512 B byte classes (TABLE mode)] [tile rows]
+    const uint32_t cls_bytes = (MODE == 0) ? 512u : 0u;
+    const uint32_t tile_rows = A.row_bytes ? (kWalkTileBytes / A.row_bytes < A.trap ? kWalkTileBytes / A.row_bytes : A.trap) : 0u;
+    const uint16_t *cls_lds = (MODE == 0) ? reinterpret_cast<const uint16_t *>(smem) : nullptr;
+    const uint8_t *tile = smem + cls_bytes;
+    {
+        if (MODE == 0 && threadIdx.x < 256) reinterpret_cast<uint16_t *>(smem)[threadIdx.x] = A.class_off[threadIdx.x];
+        const uint4 *tsrc = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(A.lds_image) + A.tile_offset);
+        uint4 *tdst = reinterpret_cast<uint4 *>(smem + cls_bytes);
+        const uint32_t n16 = (tile_rows * A.row_bytes + 15u) >> 4;
+        for (uint32_t t = threadIdx.x; t < n16; t += kWalkThreads) tdst[t] = tsrc[t];
+    }
+    __syncthreads();
+
+    uintptr_t base[ILP], blk[ILP];
+    uint32_t n[ILP], warm[ILP], pos_bias[ILP], st[ILP];
+    uint4 cur[ILP], nxt[ILP];
+    EventRegs ev[ILP];
+    uint32_t n_max = 0;
+#pragma unroll
+    for (int k = 0; k < ILP; ++k) {
+        ItemDesc it;
+        unpack_item(rec[k].x, rec[k].y, rec[k].z, rec[k].w, it);
+        n[k] = rec[k].z;  // 0 for lanes past the end
+        warm[k] = it.warm;
+        pos_bias[k] = it.pos0 - it.warm + 1u;
+        base[k] = reinterpret_cast<uintptr_t>(B.blob + (it.begin - it.warm));
+        st[k] = 0;
+        ev[k] = EventRegs{0, 0};
+        blk[k] = base[k] & ~uintptr_t(15);
+        cur[k] = nxt[k] = make_uint4(0u, 0u, 0u, 0u);
+        if (n[k]) {
+            cur[k] = *reinterpret_cast<const uint4 *>(blk[k]);
+            nxt[k] = cur[k];
+            if (blk[k] + 16 < base[k] + n[k]) nxt[k] = *reinterpret_cast<const uint4 *>(blk[k] + 16);
+        }
+        n_max = n[k] > n_max ? n[k] : n_max;
+    }
+#pragma unroll 1
+    for (uint32_t j = 0; j < n_max; ++j) {
+        uint32_t coff[ILP], w[ILP], byte_k[ILP];
+#pragma unroll
+        for (int k = 0; k < ILP; ++k) {  // bytes and their columns (no memory access but the block refill)
+            const uintptr_t a = base[k] + j;
+            if (j < n[k] && j != 0 && (a & 15u) == 0) {
+                cur[k] = nxt[k];
+                blk[k] += 16;
+                if (blk[k] + 16 < base[k] + n[k]) nxt[k] = *reinterpret_cast<const uint4 *>(blk[k] + 16);
+            }
+            const uint32_t sel = uint32_t(a >> 2) & 3u;
+            const uint32_t word = sel == 0 ? cur[k].x : sel == 1 ? cur[k].y : sel == 2 ? cur[k].z : cur[k].w;
+            byte_k[k] = (word >> (8u * uint32_t(a & 3u))) & 0xffu;
+            coff[k] = class_offset<E, MODE>(A, cls_lds, byte_k[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < ILP; ++k) {  // LDS rows first ...
+            w[k] = A.trap;
+            if (st[k] < tile_rows) w[k] = *reinterpret_cast<const E *>(tile + st[k] * A.row_bytes + coff[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < ILP; ++k)  // ... then the cold rows of all streams together
+            if (w[k] >= A.trap && j < n[k])
+                w[k] = *reinterpret_cast<const E *>(static_cast<const uint8_t *>(A.table) + uint64_t(st[k]) * A.row_bytes + coff[k]);
+#pragma unroll
+        for (int k = 0; k < ILP; ++k) {
+            if (j >= n[k]) continue;
+            st[k] = w[k];
+            if (j >= warm[k] && is_final(A, st[k]) && !(B.first_only && ev[k].n_ev)) {
+                ev[k].n_rec += A.out_count[st[k]];
+                if (ev[k].n_ev < B.slab_events) B.slab[uint64_t(ev[k].n_ev) * B.run_stride + item[k]] = make_uint2(pos_bias[k] + j, st[k]);
+                ++ev[k].n_ev;
+            }
+        }
+    }
+    uint32_t walked = 0;
+#pragma unroll
+    for (int k = 0; k < ILP; ++k) {
+        walked += n[k];
+        if (ev[k].n_ev) {
+            B.ev_count[item[k]] = ev[k].n_ev;
+            B.rec_count[item[k]] = ev[k].n_rec;
+            if (ev[k].n_ev > B.slab_events) B.overflow_list[atomicAdd(&B.counters[0], 1u)] = uint32_t(item[k]);
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) walked += __shfl_xor(walked, d, 64);
+    if ((threadIdx.x & 63u) == 0 && walked) atomicAdd(&s_walked, (walked + 15u) >> 4);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_walked) atomicAdd(&B.counters[8u + (blockIdx.x & 7u)], s_walked);
+}
+
+hipError_t launch_walk_items(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,
+                             int ilp, hipStream_t st) {
+    if (max_items == 0) return hipSuccess;
+    const uint32_t lds = kWalkTileBytes + 512u;
+    auto go = [&](auto fn, uint32_t per_block) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        if (e != hipSuccess) return e;
+        const uint32_t blocks = uint32_t((max_items + per_block - 1) / per_block);
+        hipLaunchKernelGGL(fn, dim3(blocks), dim3(kWalkThreads), lds, st, A, B);
+        return hipGetLastError();
+    };
+#define ACMI_WALK_ITEMS(E, M)                                                       \
+    (ilp >= 4 ? go(k_walk_items<E, M, 4>, kWalkThreads * 4u)                         \
+              : ilp == 2 ? go(k_walk_items<E, M, 2>, kWalkThreads * 2u) : go(k_walk_items<E, M, 1>, kWalkThreads))
+    if (entry_bytes == 2) return class_mode == 1 ? ACMI_WALK_ITEMS(uint16_t, 1) : ACMI_WALK_ITEMS(uint16_t, 0);
+    return class_mode == 1 ? ACMI_WALK_ITEMS(uint32_t, 1) : ACMI_WALK_ITEMS(uint32_t, 0);
+#undef ACMI_WALK_ITEMS
+}
+
+// ------------------------------------------------------------------------------------------
 // findAll == false: keep the first event of the first item (per haystack) that has one
 // ------------------------------------------------------------------------------------------
 __global__ void k_first_only(BatchArgs B) {

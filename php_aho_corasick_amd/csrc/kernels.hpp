@@ -20,6 +20,8 @@ hipError_t launch_scan(const DevAutomaton &A, const BatchArgs &B, uint64_t max_i
                        int class_mode, int ilp, int group_quads, hipStream_t st);
 hipError_t launch_walk_runs(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,
                             hipStream_t st);
+hipError_t launch_walk_items(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,
+                             int ilp, hipStream_t st);
 void launch_first_only(const BatchArgs &B, hipStream_t st);
 void launch_hay_prefix(const uint64_t *item_base, const uint64_t *rec_base, uint32_t nh, uint64_t *prefix,
                        uint64_t *summary, hipStream_t st);

@@ -67,7 +67,10 @@ VARIANTS = [dict(kernel=1, persistent=1, chunk_bytes=64), dict(kernel=1, persist
             dict(kernel=1, slab_events=1, refill=2, max_flat_outputs=0),
             # chain words for cold single-child states (forced; automatic only for tables > 16 MiB)
             dict(kernel=1, lds_bytes=2048, cold_chains=1), dict(kernel=2, lds_bytes=4096, cold_chains=1, chunk_bytes=256),
-            dict(kernel=0, cold_chains=1), dict(kernel=3, cold_chains=1, lds_bytes=8192, run_cap=1)]
+            dict(kernel=0, cold_chains=1), dict(kernel=3, cold_chains=1, lds_bytes=8192, run_cap=1),
+            # exact walk of whole items, 1 / 2 / 4 items per thread
+            dict(kernel=4, walk_ilp=1), dict(kernel=4, walk_ilp=2, chunk_bytes=48, slab_events=1), dict(kernel=4, walk_ilp=4, chunk_bytes=256, lds_bytes=4096),
+            dict(kernel=4, walk_ilp=4, slab_events=2, refill=2)]
 
 
 @pytest.mark.parametrize("name,variant", list(itertools.product(["G2", "G4", "G5", "R1", "R2", "R3", "R4", "R5", "R6", "R7", "R8"], range(len(VARIANTS)))))
@@ -92,6 +95,20 @@ def test_overflow_path_is_taken(refill, flat):
     o.add_patterns((ds.pat_blob, ds.pat_off))
     _, exp = o.match_batch(ds.hay_blob, ds.hay_off)
     assert np.array_equal(rec, exp)
+    api.ahocorasick_deinit(res)
+
+
+def test_automatic_switch_to_exact_walk(golden):
+    """Automatic kernel choice: a batch whose bytes were mostly flagged by the LDS-tile kernel's optimistic
+    pass (dense matches) moves the handle to the exact whole-item walk; results do not change."""
+    ds = synth.g4()
+    res = resource_for(ds)
+    first = device_match(res, ds)
+    assert res.stat("kernel_used") == 1
+    second = device_match(res, ds)
+    assert res.stat("kernel_used") == 4
+    assert np.array_equal(first[0], second[0]) and np.array_equal(first[1], second[1])
+    _check_golden(res, ds, golden, "G4")
     api.ahocorasick_deinit(res)
 
 
@@ -260,7 +277,7 @@ def test_automatic_kernel_choice_and_fallback():
     o = Oracle("port")
     o.add_patterns((ds.pat_blob, ds.pat_off))
     res = resource_for(ds)
-    for expect_kernel in (2, 1, 1):
+    for expect_kernel in (2, 1, 4):  # the same text defeats the LDS kernel's optimistic pass too -> exact walk
         p, r = host_match(res, ds)
         pe, re_ = o.match_batch(ds.hay_blob, ds.hay_off)
         assert np.array_equal(p, pe) and np.array_equal(r, re_)
@@ -361,9 +378,9 @@ def test_small_batch_one_launch_path(name):
             used = res.stat("kernel_used")
             res.set_option("small_path", 0)
             p0, r0 = host_match(res, ds, find_all)
-            assert res.stat("kernel_used") != 4
+            assert res.stat("kernel_used") != 5
             assert np.array_equal(p1, pe) and np.array_equal(r1, re_), (name, max_hay, find_all, "small", used)
             assert np.array_equal(p0, pe) and np.array_equal(r0, re_), (name, max_hay, find_all, "pipeline")
-            assert used == (4 if len(re_) <= 8192 else used)
+            assert used == (5 if len(re_) <= 8192 else used)
     api.ahocorasick_deinit(res)
     o.close()

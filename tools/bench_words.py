@@ -15,10 +15,10 @@ nh = 1 << 17
 d_blob = torch.from_numpy(ds.hay_blob).cuda().repeat(nh // 8192).contiguous()
 d_off = torch.arange(nh + 1, dtype=torch.int64, device="cuda") * 8192
 batch.bind_current_stream(res)
-for slab, refill in ((8, 1), (8, 2), (16, 0), (32, 0)):
-    res.set_option("slab_events", slab); res.set_option("refill", refill)
+for slab, refill, kern, wilp in ((8, 2, 1, 1), (16, 0, 1, 1), (16, 0, 4, 1), (16, 0, 4, 2), (8, 0, 3, 1)):
+    res.set_option("slab_events", slab); res.set_option("refill", refill); res.set_option("kernel", kern); res.set_option("walk_ilp", wilp)
     ms, tot = [], []
     for _ in range(6):
         total = batch.match_device(res, d_blob, d_off)
         ms.append(res.stat("scan_ms")); tot.append(res.stat("total_ms"))
-    print(f"slab {slab} refill {refill}: scan kernel {np.mean(ms[2:]):.3f} ms, whole call {np.mean(tot[2:]):.3f} ms = {d_blob.numel()/np.mean(tot[2:])/1e6:.0f} GB/s, records {total} ({total/nh:.1f}/haystack), overflow items {int(res.stat('overflow_items'))} of {int(res.stat('items'))}, walked bytes {int(res.stat('walked_bytes'))}", flush=True)
+    print(f"kernel {kern} walk_ilp {wilp} slab {slab} refill {refill}: scan kernel {np.mean(ms[2:]):.3f} ms, whole call {np.mean(tot[2:]):.3f} ms = {d_blob.numel()/np.mean(tot[2:])/1e6:.0f} GB/s, records {total} ({total/nh:.1f}/haystack), overflow items {int(res.stat('overflow_items'))} of {int(res.stat('items'))}, walked bytes {int(res.stat('walked_bytes'))}", flush=True)
