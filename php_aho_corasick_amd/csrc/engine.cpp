@@ -78,7 +78,7 @@ struct acmi_handle {
     uint8_t *pin_small = nullptr;  // pinned host memory of the small path: [summary | prefix | records | offsets | bytes]
     int wave_items = 0;   // 0 automatic, else 1..64 items per wave batch of the anchor kernel
     int persistent = -1;  // -1 automatic, 0 one workgroup per 1024 x ILP items, 1 persistent workgroups
-    int walk_ilp = 1;     // k_walk_items: work items per thread (1, 2 or 4; hipcc serialises the streams: 1 is fastest)
+    int walk_ilp = 1;     // accepted for compatibility: k_walk_items walks one item per thread (more measured slower)
     int refill = 0;       // 0 automatic, 1 one thread per overflowed item (k_refill), 2 one wave (k_refill_wave)
     int profile = 0;
 

@@ -1265,30 +1265,26 @@ hipError_t launch_walk_runs(const DevAutomaton &A, const BatchArgs &B, uint64_t 
 }
 
 // ------------------------------------------------------------------------------------------
-// k_walk_items: exact walk of WHOLE work items, ILP items per thread (kernel 4).
+// k_walk_items: exact walk of WHOLE work items, one per thread (kernel 4).
 //
 // For text on which k_scan_lds' optimistic pass flags everything anyway -- keyword-like sets with events
-// in every wave-quad, the dense sets of BASELINE configs[4] -- the table walk is all there is, and one
-// walk per thread is a chain of dependent lookups of which, in a wave of 64, some lane always goes to L2:
-// ~1 us per lockstep step at full occupancy.  Here a thread walks ILP items in one loop, so that the
-// lookups of its streams are issued back to back and wait together.  Same tile, same event rule and slab
-// layout as run_epilogue; byte classes staged in LDS next to the tile.
+// in every wave-quad, the dense sets of BASELINE configs[4] -- the table walk is all there is.  At full
+// occupancy (2,048 walks per CU) it is bound by instruction issue, not by the L2 round trips of the cold
+// rows: two or four walks per thread, whether with conditional loads (hipcc waits in front of each) or
+// branch-free with unconditional ones, measured 1.4-2.8 x SLOWER.  So the step is kept short instead:
+// haystack bytes as aligned 16-byte blocks requested two ahead (sixteen unrolled steps, no per-byte select), byte
+// classes and the tile's first 64 KiB in LDS, the cold-row load and the event block the only branches.
+// Same event rule and slab layout as run_epilogue.
 // ------------------------------------------------------------------------------------------
-template <typename E, int MODE, int ILP>
+template <typename E, int MODE>
 __global__ __launch_bounds__(kWalkThreads) void k_walk_items(DevAutomaton A, BatchArgs B) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint64_t total_items = B.item_base[B.n_haystacks];
-    const uint64_t first = uint64_t(blockIdx.x) * (kWalkThreads * ILP);
-    if (first >= total_items) return;
+    const uint64_t item = uint64_t(blockIdx.x) * kWalkThreads + threadIdx.x;
+    if (uint64_t(blockIdx.x) * kWalkThreads >= total_items) return;
     __shared__ uint32_t s_walked;
     if (threadIdx.x == 0) s_walked = 0;
-    uint64_t item[ILP];
-    uint4 rec[ILP];
-#pragma unroll
-    for (int k = 0; k < ILP; ++k) {
-        item[k] = first + uint64_t(k) * kWalkThreads + threadIdx.x;
-        rec[k] = item[k] < total_items ? B.item_rec[item[k]] : make_uint4(0u, 0u, 0u, 0u);
-    }
+    const uint4 rec = item < total_items ? B.item_rec[item] : make_uint4(0u, 0u, 0u, 0u);
     // LDS: [512 B byte classes (TABLE mode)] [tile rows]
     const uint32_t cls_bytes = (MODE == 0) ? 512u : 0u;
     const uint32_t tile_rows = A.row_bytes ? (kWalkTileBytes / A.row_bytes < A.trap ? kWalkTileBytes / A.row_bytes : A.trap) : 0u;
@@ -1303,75 +1299,61 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_items(DevAutomaton A, Bat
     }
     __syncthreads();
 
-    uintptr_t base[ILP], blk[ILP];
-    uint32_t n[ILP], warm[ILP], pos_bias[ILP], st[ILP];
-    uint4 cur[ILP], nxt[ILP];
-    EventRegs ev[ILP];
-    uint32_t n_max = 0;
-#pragma unroll
-    for (int k = 0; k < ILP; ++k) {
-        ItemDesc it;
-        unpack_item(rec[k].x, rec[k].y, rec[k].z, rec[k].w, it);
-        n[k] = rec[k].z;  // 0 for lanes past the end
-        warm[k] = it.warm;
-        pos_bias[k] = it.pos0 - it.warm + 1u;
-        base[k] = reinterpret_cast<uintptr_t>(B.blob + (it.begin - it.warm));
-        st[k] = 0;
-        ev[k] = EventRegs{0, 0};
-        blk[k] = base[k] & ~uintptr_t(15);
-        cur[k] = nxt[k] = make_uint4(0u, 0u, 0u, 0u);
-        if (n[k]) {
-            cur[k] = *reinterpret_cast<const uint4 *>(blk[k]);
-            nxt[k] = cur[k];
-            if (blk[k] + 16 < base[k] + n[k]) nxt[k] = *reinterpret_cast<const uint4 *>(blk[k] + 16);
+    ItemDesc it;
+    unpack_item(rec.x, rec.y, rec.z, rec.w, it);
+    const uint32_t n = rec.z;  // 0 for threads past the last item
+    const uint8_t *p = B.blob + (n ? it.begin - it.warm : 0);
+    const uint32_t warm = it.warm, pos_bias = it.pos0 - it.warm + 1u;
+    const uint8_t *table = static_cast<const uint8_t *>(A.table);
+    uint32_t st = 0;
+    EventRegs ev{0, 0};
+    // one exact transition on byte `byte` = scan index j; the cold-row load and the event block are the only
+    // branches, both rare per lane (the loads are skipped by the wave when no lane needs them)
+    auto step = [&](uint32_t byte, uint32_t j) {
+        const uint32_t coff = class_offset<E, MODE>(A, cls_lds, byte);
+        uint32_t w = A.trap;
+        if (st < tile_rows) w = *reinterpret_cast<const E *>(tile + st * A.row_bytes + coff);
+        if (w >= A.trap) w = *reinterpret_cast<const E *>(table + uint64_t(st) * A.row_bytes + coff);
+        st = w;
+        if (j >= warm && is_final(A, st) && !(B.first_only && ev.n_ev)) {
+            ev.n_rec += A.out_count[st];
+            if (ev.n_ev < B.slab_events) B.slab[uint64_t(ev.n_ev) * B.run_stride + item] = make_uint2(pos_bias + j, st);
+            ++ev.n_ev;
         }
-        n_max = n[k] > n_max ? n[k] : n_max;
-    }
+    };
+    uint32_t j = 0;
+    // head: single bytes up to the first aligned 16-byte block
+    for (; j < n && (reinterpret_cast<uintptr_t>(p + j) & 15u) != 0; ++j) step(p[j], j);
+    // body: aligned 16-byte blocks, requested two ahead (the index is clamped, so the load is unconditional).
+    // Wide loads matter: a lane's bytes share a line with no other lane's, and fetched as dwords the same walk
+    // ran 2.7 x slower -- four times the requests to L2.
+    const uint32_t nb = (n - j) >> 4;
+    if (nb) {
+        const uint4 *q = reinterpret_cast<const uint4 *>(p + j);
+        uint4 cur = q[0], nxt = q[nb > 1u ? 1u : 0u];
 #pragma unroll 1
-    for (uint32_t j = 0; j < n_max; ++j) {
-        uint32_t coff[ILP], w[ILP], byte_k[ILP];
+        for (uint32_t d = 0; d < nb; ++d) {
+            const uint4 blk = cur;
+            cur = nxt;
+            nxt = q[d + 2u < nb ? d + 2u : nb - 1u];
+            const uint32_t words[4] = {blk.x, blk.y, blk.z, blk.w};
 #pragma unroll
-        for (int k = 0; k < ILP; ++k) {  // bytes and their columns (no memory access but the block refill)
-            const uintptr_t a = base[k] + j;
-            if (j < n[k] && j != 0 && (a & 15u) == 0) {
-                cur[k] = nxt[k];
-                blk[k] += 16;
-                if (blk[k] + 16 < base[k] + n[k]) nxt[k] = *reinterpret_cast<const uint4 *>(blk[k] + 16);
+            for (uint32_t i = 0; i < 4u; ++i) {
+                step(words[i] & 0xffu, j + 4u * i);
+                step((words[i] >> 8) & 0xffu, j + 4u * i + 1u);
+                step((words[i] >> 16) & 0xffu, j + 4u * i + 2u);
+                step(words[i] >> 24, j + 4u * i + 3u);
             }
-            const uint32_t sel = uint32_t(a >> 2) & 3u;
-            const uint32_t word = sel == 0 ? cur[k].x : sel == 1 ? cur[k].y : sel == 2 ? cur[k].z : cur[k].w;
-            byte_k[k] = (word >> (8u * uint32_t(a & 3u))) & 0xffu;
-            coff[k] = class_offset<E, MODE>(A, cls_lds, byte_k[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < ILP; ++k) {  // LDS rows first ...
-            w[k] = A.trap;
-            if (st[k] < tile_rows) w[k] = *reinterpret_cast<const E *>(tile + st[k] * A.row_bytes + coff[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < ILP; ++k)  // ... then the cold rows of all streams together
-            if (w[k] >= A.trap && j < n[k])
-                w[k] = *reinterpret_cast<const E *>(static_cast<const uint8_t *>(A.table) + uint64_t(st[k]) * A.row_bytes + coff[k]);
-#pragma unroll
-        for (int k = 0; k < ILP; ++k) {
-            if (j >= n[k]) continue;
-            st[k] = w[k];
-            if (j >= warm[k] && is_final(A, st[k]) && !(B.first_only && ev[k].n_ev)) {
-                ev[k].n_rec += A.out_count[st[k]];
-                if (ev[k].n_ev < B.slab_events) B.slab[uint64_t(ev[k].n_ev) * B.run_stride + item[k]] = make_uint2(pos_bias[k] + j, st[k]);
-                ++ev[k].n_ev;
-            }
+            j += 16u;
         }
     }
-    uint32_t walked = 0;
-#pragma unroll
-    for (int k = 0; k < ILP; ++k) {
-        walked += n[k];
-        if (ev[k].n_ev) {
-            B.ev_count[item[k]] = ev[k].n_ev;
-            B.rec_count[item[k]] = ev[k].n_rec;
-            if (ev[k].n_ev > B.slab_events) B.overflow_list[atomicAdd(&B.counters[0], 1u)] = uint32_t(item[k]);
-        }
+    for (; j < n; ++j) step(p[j], j);  // tail
+
+    uint32_t walked = n;
+    if (ev.n_ev) {
+        B.ev_count[item] = ev.n_ev;
+        B.rec_count[item] = ev.n_rec;
+        if (ev.n_ev > B.slab_events) B.overflow_list[atomicAdd(&B.counters[0], 1u)] = uint32_t(item);
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) walked += __shfl_xor(walked, d, 64);
@@ -1391,12 +1373,9 @@ hipError_t launch_walk_items(const DevAutomaton &A, const BatchArgs &B, uint64_t
         hipLaunchKernelGGL(fn, dim3(blocks), dim3(kWalkThreads), lds, st, A, B);
         return hipGetLastError();
     };
-#define ACMI_WALK_ITEMS(E, M)                                                       \
-    (ilp >= 4 ? go(k_walk_items<E, M, 4>, kWalkThreads * 4u)                         \
-              : ilp == 2 ? go(k_walk_items<E, M, 2>, kWalkThreads * 2u) : go(k_walk_items<E, M, 1>, kWalkThreads))
-    if (entry_bytes == 2) return class_mode == 1 ? ACMI_WALK_ITEMS(uint16_t, 1) : ACMI_WALK_ITEMS(uint16_t, 0);
-    return class_mode == 1 ? ACMI_WALK_ITEMS(uint32_t, 1) : ACMI_WALK_ITEMS(uint32_t, 0);
-#undef ACMI_WALK_ITEMS
+    (void)ilp;
+    if (entry_bytes == 2) return class_mode == 1 ? go(k_walk_items<uint16_t, 1>, kWalkThreads) : go(k_walk_items<uint16_t, 0>, kWalkThreads);
+    return class_mode == 1 ? go(k_walk_items<uint32_t, 1>, kWalkThreads) : go(k_walk_items<uint32_t, 0>, kWalkThreads);
 }
 
 // ------------------------------------------------------------------------------------------
