@@ -78,7 +78,7 @@ struct acmi_handle {
     uint8_t *pin_small = nullptr;  // pinned host memory of the small path: [summary | prefix | records | offsets | bytes]
     int wave_items = 0;   // 0 automatic, else 1..64 items per wave batch of the anchor kernel
     int persistent = -1;  // -1 automatic, 0 one workgroup per 1024 x ILP items, 1 persistent workgroups
-    int walk_ilp = 1;     // accepted for compatibility: k_walk_items walks one item per thread (more measured slower)
+    int walk_ilp = 0;     // k_walk_items: 0 / 1 = one item per thread + 64 KiB tile (default), 2 = two items + whole hot tile
     int refill = 0;       // 0 automatic, 1 one thread per overflowed item (k_refill), 2 one wave (k_refill_wave)
     int profile = 0;
 
@@ -815,7 +815,7 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
     } else if (k == "persistent") {
         h->persistent = value < 0 ? -1 : (value ? 1 : 0);
     } else if (k == "walk_ilp") {
-        if (value != 1 && value != 2 && value != 4) return ACMI_E_ARG;
+        if (value < 0 || value > 2) return ACMI_E_ARG;
         h->walk_ilp = int(value);
     } else if (k == "refill") {
         if (value < 0 || value > 2) return ACMI_E_ARG;

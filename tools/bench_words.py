@@ -15,7 +15,7 @@ nh = 1 << 17
 d_blob = torch.from_numpy(ds.hay_blob).cuda().repeat(nh // 8192).contiguous()
 d_off = torch.arange(nh + 1, dtype=torch.int64, device="cuda") * 8192
 batch.bind_current_stream(res)
-for slab, refill, kern, wilp in ((16, 0, 1, 1), (16, 0, 4, 1), (8, 0, 3, 1)):
+for slab, refill, kern, wilp in ((16, 0, 4, 1), (16, 0, 4, 2), (8, 0, 3, 0)):
     res.set_option("slab_events", slab); res.set_option("refill", refill); res.set_option("kernel", kern); res.set_option("walk_ilp", wilp)
     ms, tot = [], []
     for _ in range(6):
