@@ -201,8 +201,8 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *                    if a batch shows the text defeats the filter; from 1 on to 4 if a batch shows
  *                    that its optimistic pass flags most bytes anyway; 4 = exact table walk of whole
  *                    work items only (keyword-like and dense-match text)                 [any time]
- *   "walk_ilp"       kernel 4: 0 / 1 = one work item per thread, 64 KiB of the tile in LDS (default);
- *                    2 = two per thread and the whole hot tile                           [any time]
+ *   "walk_group"     kernel 4: 16-byte haystack blocks a lane requests back to back: 1, 4 (default: half a
+ *                    line, the most that fits 8 waves per SIMD) or 8 (a whole 128-byte line)  [any time]
  *   "ilp"            streams per lane in the LDS-tile kernel (1 or 2)    [any time]
  *   "group_quads"    16-byte loads per lane per fetch group, 4 or 8 (ILP 1) [any time]
  *   "small_path"     1 (default): host batches of <= 64 KiB in <= 1024 haystacks (every acmi_match of a few

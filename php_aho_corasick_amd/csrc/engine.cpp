@@ -78,7 +78,7 @@ struct acmi_handle {
     uint8_t *pin_small = nullptr;  // pinned host memory of the small path: [summary | prefix | records | offsets | bytes]
     int wave_items = 0;   // 0 automatic, else 1..64 items per wave batch of the anchor kernel
     int persistent = -1;  // -1 automatic, 0 one workgroup per 1024 x ILP items, 1 persistent workgroups
-    int walk_ilp = 0;     // k_walk_items: 0 / 1 = one item per thread + 64 KiB tile (default), 2 = two items + whole hot tile
+    int walk_group = 4;   // k_walk_items: 16-byte haystack blocks a lane requests back to back (1, 4 or 8 = a whole line)
     int refill = 0;       // 0 automatic, 1 one thread per overflowed item (k_refill), 2 one wave (k_refill_wave)
     int profile = 0;
 
@@ -384,9 +384,9 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
 
     if (h->profile) HIPCHK(h, hipEventRecord(h->ev[1], st));
     if (kernel == 4) {
-        // exact walk only (k_walk_items, `walk_ilp` items per thread): for text on which k_scan_lds' optimistic
+        // exact walk only (k_walk_items): for text on which k_scan_lds' optimistic
         // pass flags everything anyway (events in every wave-quad)
-        HIPCHK(h, launch_walk_items(h->dA, B, max_items, int(fa.entry_bytes), int(fa.class_mode), h->walk_ilp, st));
+        HIPCHK(h, launch_walk_items(h->dA, B, max_items, int(fa.entry_bytes), int(fa.class_mode), h->walk_group, st));
     } else {
         HIPCHK(h, launch_scan(h->dA, B, max_items, int(fa.entry_bytes), kernel, int(fa.class_mode), h->ilp, h->group_quads, st));
     }
@@ -814,9 +814,9 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
         h->wave_items = int(value);
     } else if (k == "persistent") {
         h->persistent = value < 0 ? -1 : (value ? 1 : 0);
-    } else if (k == "walk_ilp") {
-        if (value < 0 || value > 2) return ACMI_E_ARG;
-        h->walk_ilp = int(value);
+    } else if (k == "walk_group") {
+        if (value != 1 && value != 4 && value != 8) return ACMI_E_ARG;
+        h->walk_group = int(value);
     } else if (k == "refill") {
         if (value < 0 || value > 2) return ACMI_E_ARG;
         h->refill = int(value);

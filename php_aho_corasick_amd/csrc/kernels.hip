@@ -1268,31 +1268,31 @@ hipError_t launch_walk_runs(const DevAutomaton &A, const BatchArgs &B, uint64_t 
 // k_walk_items: exact walk of WHOLE work items, one per thread (kernel 4).
 //
 // For text on which k_scan_lds' optimistic pass flags everything anyway -- keyword-like sets with events
-// in every wave-quad, the dense sets of BASELINE configs[4] -- the table walk is all there is.  The step is
-// kept short: haystack bytes as aligned 16-byte blocks requested two ahead (sixteen unrolled steps, no
-// per-byte select; as dwords the same walk ran 2.7 x slower -- four times the requests to L2), byte classes
-// and the first rows of the tile in LDS, the cold-row load and the event block the only branches.
-// ILP == 2 walks two items per thread with their blocks side by side (see launch_walk_items for what it
-// measured).  Same event rule and slab layout as run_epilogue.
+// in every wave-quad, the dense sets of BASELINE configs[4] -- the table walk is all there is.  One item per
+// thread, 2,048 walks per CU.  What bounded the first version was HBM, not the walk: a lane's bytes share a
+// 128-byte line with no other lane's, 2^19 lanes hold 64 MiB of such lines open at once -- twice the L2 --
+// and with one 16-byte block requested at a time every line was fetched from HBM again for each of its
+// blocks (TCC_MISS x 128 B = 8.5 x the haystack bytes, 6.3 TB/s of HBM traffic for 0.74 TB/s of text).  So a
+// lane requests LB blocks of one line back to back, one group ahead, and walks the group it holds: LB x 16
+// unrolled steps, no per-byte select.  LB = 4 (64 bytes) is the most that fits the 64 VGPRs of 8 waves per
+// SIMD and is the default: 1.16 ms per GiB of the keyword set of tools/bench_words.py against 1.42 ms with
+// single blocks; LB = 8 (whole lines, 96 VGPRs, 4 waves per SIMD) 1.59 ms.  Byte classes and the first 64 KiB of
+// the tile are in LDS; the cold-row load and the event block are the only branches.  Two items per thread
+// (their blocks side by side, conditional or unconditional cold loads) measured equal or slower and was dropped.
+// Same event rule and slab layout as run_epilogue.
 // ------------------------------------------------------------------------------------------
-template <typename E, int MODE, int ILP>
-__global__ __launch_bounds__(kWalkThreads) void k_walk_items(DevAutomaton A, BatchArgs B, uint32_t tile_bytes) {
+template <typename E, int MODE, int LB>
+__global__ __launch_bounds__(kWalkThreads, (LB <= 4 ? 8 : 4)) void k_walk_items(DevAutomaton A, BatchArgs B) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint64_t total_items = B.item_base[B.n_haystacks];
-    const uint64_t first = uint64_t(blockIdx.x) * (kWalkThreads * ILP);
-    if (first >= total_items) return;
+    if (uint64_t(blockIdx.x) * kWalkThreads >= total_items) return;
+    const uint64_t item = uint64_t(blockIdx.x) * kWalkThreads + threadIdx.x;
     __shared__ uint32_t s_walked;
     if (threadIdx.x == 0) s_walked = 0;
-    uint64_t item[ILP];
-    uint4 rec[ILP];
-#pragma unroll
-    for (int k = 0; k < ILP; ++k) {
-        item[k] = first + uint64_t(k) * kWalkThreads + threadIdx.x;
-        rec[k] = item[k] < total_items ? B.item_rec[item[k]] : make_uint4(0u, 0u, 0u, 0u);
-    }
+    const uint4 rec = item < total_items ? B.item_rec[item] : make_uint4(0u, 0u, 0u, 0u);
     // LDS: [512 B byte classes (TABLE mode)] [tile rows]
     const uint32_t cls_bytes = (MODE == 0) ? 512u : 0u;
-    const uint32_t tile_rows = A.row_bytes ? (tile_bytes / A.row_bytes < A.trap ? tile_bytes / A.row_bytes : A.trap) : 0u;
+    const uint32_t tile_rows = A.row_bytes ? (kWalkTileBytes / A.row_bytes < A.trap ? kWalkTileBytes / A.row_bytes : A.trap) : 0u;
     const uint16_t *cls_lds = (MODE == 0) ? reinterpret_cast<const uint16_t *>(smem) : nullptr;
     const uint8_t *tile = smem + cls_bytes;
     {
@@ -1304,140 +1304,67 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_items(DevAutomaton A, Bat
     }
     __syncthreads();
 
+    ItemDesc it;
+    unpack_item(rec.x, rec.y, rec.z, rec.w, it);
+    const uint32_t n = rec.z;  // 0 for threads past the last item
+    const uint8_t *p = B.blob + (n ? it.begin - it.warm : 0);
+    const uint32_t warm = it.warm, pos_bias = it.pos0 - it.warm + 1u;
     const uint8_t *table = static_cast<const uint8_t *>(A.table);
-    const uint8_t *p[ILP];
-    uint32_t n[ILP], warm[ILP], pos_bias[ILP], st[ILP], j[ILP];
-    EventRegs ev[ILP];
-#pragma unroll
-    for (int k = 0; k < ILP; ++k) {
-        ItemDesc it;
-        unpack_item(rec[k].x, rec[k].y, rec[k].z, rec[k].w, it);
-        n[k] = rec[k].z;  // 0 for threads past the last item
-        p[k] = B.blob + (n[k] ? it.begin - it.warm : 0);
-        warm[k] = it.warm;
-        pos_bias[k] = it.pos0 - it.warm + 1u;
-        st[k] = 0;
-        j[k] = 0;
-        ev[k] = EventRegs{0, 0};
-    }
-    auto on_final = [&](int k, uint32_t jj) {
-        if (!(B.first_only && ev[k].n_ev)) {
-            ev[k].n_rec += A.out_count[st[k]];
-            if (ev[k].n_ev < B.slab_events) B.slab[uint64_t(ev[k].n_ev) * B.run_stride + item[k]] = make_uint2(pos_bias[k] + jj, st[k]);
-            ++ev[k].n_ev;
-        }
-    };
-    // one exact transition of stream k on byte `byte` = scan index jj; the cold-row load and the event block are
-    // the only branches, both rare per lane (the wave skips the loads when no lane needs them)
-    auto step = [&](int k, uint32_t byte, uint32_t jj) {
+    uint32_t st = 0;
+    EventRegs ev{0, 0};
+    auto step = [&](uint32_t byte, uint32_t jj) __attribute__((always_inline)) {
         const uint32_t coff = class_offset<E, MODE>(A, cls_lds, byte);
         uint32_t w = A.trap;
-        if (st[k] < tile_rows) w = *reinterpret_cast<const E *>(tile + __umul24(st[k], A.row_bytes) + coff);
-        if (w >= A.trap) w = *reinterpret_cast<const E *>(table + uint64_t(st[k]) * A.row_bytes + coff);
-        st[k] = w;
-        if (jj >= warm[k] && is_final(A, st[k])) on_final(k, jj);
+        if (st < tile_rows) w = *reinterpret_cast<const E *>(tile + __umul24(st, A.row_bytes) + coff);
+        if (w >= A.trap) w = *reinterpret_cast<const E *>(table + uint64_t(st) * A.row_bytes + coff);
+        st = w;
+        if (jj >= warm && is_final(A, st) && !(B.first_only && ev.n_ev)) {
+            ev.n_rec += A.out_count[st];
+            if (ev.n_ev < B.slab_events) B.slab[uint64_t(ev.n_ev) * B.run_stride + item] = make_uint2(pos_bias + jj, st);
+            ++ev.n_ev;
+        }
     };
-    // head: single bytes up to the first aligned 16-byte block
+    // (written out: as a loop over an array of the four words hipcc kept the array in scratch memory)
+#define ACMI_STEP4(wd, jj) \
+    step((wd) & 0xffu, (jj)); step(((wd) >> 8) & 0xffu, (jj) + 1u); step(((wd) >> 16) & 0xffu, (jj) + 2u); step((wd) >> 24, (jj) + 3u);
+    auto step_block = [&](const uint4 &blk, uint32_t jj) __attribute__((always_inline)) {
+        ACMI_STEP4(blk.x, jj) ACMI_STEP4(blk.y, jj + 4u) ACMI_STEP4(blk.z, jj + 8u) ACMI_STEP4(blk.w, jj + 12u)
+    };
+#undef ACMI_STEP4
+    uint32_t j = 0;
+    // head: single bytes up to a 16-byte boundary, single blocks up to a group boundary
+    for (; j < n && (reinterpret_cast<uintptr_t>(p + j) & 15u) != 0; ++j) step(p[j], j);
+    for (; j + 16u <= n && (reinterpret_cast<uintptr_t>(p + j) & (16u * LB - 1u)) != 0; j += 16u)
+        step_block(*reinterpret_cast<const uint4 *>(p + j), j);
+    // body: groups of LB blocks of one line, the next group requested (back to back, clamped index) while this
+    // one is walked
+    const uint32_t ng = (n - j) / (16u * LB);
+    if (ng) {
+        const uint4 *q = reinterpret_cast<const uint4 *>(p + j);
+        uint4 cur[LB], nxt[LB];
 #pragma unroll
-    for (int k = 0; k < ILP; ++k)
-        for (; j[k] < n[k] && (reinterpret_cast<uintptr_t>(p[k] + j[k]) & 15u) != 0; ++j[k]) step(k, p[k][j[k]], j[k]);
-
-    if (ILP > 1) {
-        // joint body: the streams' aligned 16-byte blocks side by side, no branch per byte but "some stream
-        // needs a cold row" (then all streams load, the ones that do not from the table's first line) and
-        // "some stream is in a final state" -- the lookups of the streams are issued back to back
-        uint32_t nbj = 0xFFFFFFFFu;
-#pragma unroll
-        for (int k = 0; k < ILP; ++k) nbj = min(nbj, (n[k] - j[k]) >> 4);
-        if (nbj) {
-            const uint4 *q[ILP];
-            uint4 cur[ILP], nxt[ILP];
-#pragma unroll
-            for (int k = 0; k < ILP; ++k) {
-                q[k] = reinterpret_cast<const uint4 *>(p[k] + j[k]);
-                cur[k] = q[k][0];
-                nxt[k] = q[k][nbj > 1u ? 1u : 0u];
-            }
+        for (int i = 0; i < LB; ++i) cur[i] = q[i];
 #pragma unroll 1
-            for (uint32_t d = 0; d < nbj; ++d) {
-                uint32_t words[ILP][4];
+        for (uint32_t g = 0; g < ng; ++g) {
+            const uint4 *qn = q + (g + 1u < ng ? g + 1u : g) * LB;
 #pragma unroll
-                for (int k = 0; k < ILP; ++k) {
-                    words[k][0] = cur[k].x; words[k][1] = cur[k].y; words[k][2] = cur[k].z; words[k][3] = cur[k].w;
-                    cur[k] = nxt[k];
-                    nxt[k] = q[k][d + 2u < nbj ? d + 2u : nbj - 1u];
-                }
+            for (int i = 0; i < LB; ++i) nxt[i] = qn[i];
 #pragma unroll
-                for (uint32_t b = 0; b < 16u; ++b) {
-                    uint32_t coff[ILP], w[ILP];
-                    bool need[ILP], any_need = false, fin[ILP], any_fin = false;
+            for (int i = 0; i < LB; ++i) step_block(cur[i], j + 16u * uint32_t(i));
 #pragma unroll
-                    for (int k = 0; k < ILP; ++k) {
-                        const uint32_t byte = (words[k][b >> 2] >> (8u * (b & 3u))) & 0xffu;
-                        coff[k] = class_offset<E, MODE>(A, cls_lds, byte);
-                        const bool hot = st[k] < tile_rows;
-                        w[k] = *reinterpret_cast<const E *>(tile + __umul24(hot ? st[k] : 0u, A.row_bytes) + coff[k]);
-                        need[k] = !hot || w[k] >= A.trap;
-                        any_need |= need[k];
-                    }
-                    if (any_need) {
-                        uint32_t g[ILP];
-#pragma unroll
-                        for (int k = 0; k < ILP; ++k)
-                            g[k] = *reinterpret_cast<const E *>(table + (need[k] ? uint64_t(st[k]) * A.row_bytes + coff[k] : uint64_t(coff[k])));
-#pragma unroll
-                        for (int k = 0; k < ILP; ++k) w[k] = need[k] ? g[k] : w[k];
-                    }
-#pragma unroll
-                    for (int k = 0; k < ILP; ++k) {
-                        st[k] = w[k];
-                        fin[k] = j[k] + b >= warm[k] && is_final(A, st[k]);
-                        any_fin |= fin[k];
-                    }
-                    if (__builtin_expect(any_fin, 0)) {
-#pragma unroll
-                        for (int k = 0; k < ILP; ++k)
-                            if (fin[k]) on_final(k, j[k] + b);
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < ILP; ++k) j[k] += 16u;
-            }
+            for (int i = 0; i < LB; ++i) cur[i] = nxt[i];
+            j += 16u * LB;
         }
     }
+    // what is left: whole blocks, then bytes
+    for (; j + 16u <= n; j += 16u) step_block(*reinterpret_cast<const uint4 *>(p + j), j);
+    for (; j < n; ++j) step(p[j], j);
 
-    // what is left of each stream (everything when ILP == 1): aligned 16-byte blocks requested two ahead (the
-    // index is clamped, so the load is unconditional), then the tail bytes.  Wide loads matter: a lane's bytes
-    // share a line with no other lane's, and fetched as dwords the same walk ran 2.7 x slower -- four times the
-    // requests to L2.
-#pragma unroll
-    for (int k = 0; k < ILP; ++k) {
-        const uint32_t nb = (n[k] - j[k]) >> 4;
-        if (nb) {
-            const uint4 *q = reinterpret_cast<const uint4 *>(p[k] + j[k]);
-            uint4 cur = q[0], nxt = q[nb > 1u ? 1u : 0u];
-#pragma unroll 1
-            for (uint32_t d = 0; d < nb; ++d) {
-                const uint32_t words[4] = {cur.x, cur.y, cur.z, cur.w};
-                cur = nxt;
-                nxt = q[d + 2u < nb ? d + 2u : nb - 1u];
-#pragma unroll
-                for (uint32_t b = 0; b < 16u; ++b) step(k, (words[b >> 2] >> (8u * (b & 3u))) & 0xffu, j[k] + b);
-                j[k] += 16u;
-            }
-        }
-        for (; j[k] < n[k]; ++j[k]) step(k, p[k][j[k]], j[k]);
-    }
-
-    uint32_t walked = 0;
-#pragma unroll
-    for (int k = 0; k < ILP; ++k) {
-        walked += n[k];
-        if (ev[k].n_ev) {
-            B.ev_count[item[k]] = ev[k].n_ev;
-            B.rec_count[item[k]] = ev[k].n_rec;
-            if (ev[k].n_ev > B.slab_events) B.overflow_list[atomicAdd(&B.counters[0], 1u)] = uint32_t(item[k]);
-        }
+    uint32_t walked = n;
+    if (ev.n_ev) {
+        B.ev_count[item] = ev.n_ev;
+        B.rec_count[item] = ev.n_rec;
+        if (ev.n_ev > B.slab_events) B.overflow_list[atomicAdd(&B.counters[0], 1u)] = uint32_t(item);
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) walked += __shfl_xor(walked, d, 64);
@@ -1447,26 +1374,18 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_items(DevAutomaton A, Bat
 }
 
 hipError_t launch_walk_items(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,
-                             int ilp, hipStream_t st) {
+                             int group, hipStream_t st) {
     if (max_items == 0) return hipSuccess;
-    // Two shapes: 64 KiB of the tile, two workgroups per CU, one item per thread (default); or the whole hot
-    // tile (up to 159.5 KiB, one workgroup per CU) and two items per thread, their 16-byte blocks walked side by
-    // side (ilp 2).  Same 2,048 walks per CU either way, and measured the same to within 4 % on a keyword set of
-    // which 1,170 / 2,906 of 12,749 states are in the tile (1.45 / 1.51 ms per GiB): neither the L2 round trips
-    // nor the number of cold lookups is what bounds this walk.
-    const uint32_t cls = class_mode == 0 ? 512u : 0u;
-    const uint32_t full = A.trap * A.row_bytes;
-    const bool big = ilp >= 2;
-    const uint32_t tile_bytes = big ? std::min<uint32_t>(full, 160u * 1024u - 64u - cls) : kWalkTileBytes;
-    const uint32_t lds = ((tile_bytes + 15u) & ~15u) + cls;
-    auto go = [&](auto fn, uint32_t per_block) {
+    const uint32_t lds = kWalkTileBytes + (class_mode == 0 ? 512u : 0u);
+    auto go = [&](auto fn) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return e;
-        const uint32_t blocks = uint32_t((max_items + per_block - 1) / per_block);
-        hipLaunchKernelGGL(fn, dim3(blocks), dim3(kWalkThreads), lds, st, A, B, tile_bytes);
+        const uint32_t blocks = uint32_t((max_items + kWalkThreads - 1) / kWalkThreads);
+        hipLaunchKernelGGL(fn, dim3(blocks), dim3(kWalkThreads), lds, st, A, B);
         return hipGetLastError();
     };
-#define ACMI_WALK_ITEMS(E, M) (big ? go(k_walk_items<E, M, 2>, kWalkThreads * 2u) : go(k_walk_items<E, M, 1>, kWalkThreads))
+    // group = 16-byte blocks a lane requests back to back: 1 (the first version), 4 or 8 (a whole line)
+#define ACMI_WALK_ITEMS(E, M) (group >= 8 ? go(k_walk_items<E, M, 8>) : group >= 4 ? go(k_walk_items<E, M, 4>) : go(k_walk_items<E, M, 1>))
     if (entry_bytes == 2) return class_mode == 1 ? ACMI_WALK_ITEMS(uint16_t, 1) : ACMI_WALK_ITEMS(uint16_t, 0);
     return class_mode == 1 ? ACMI_WALK_ITEMS(uint32_t, 1) : ACMI_WALK_ITEMS(uint32_t, 0);
 #undef ACMI_WALK_ITEMS

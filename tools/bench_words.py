@@ -15,10 +15,11 @@ nh = 1 << 17
 d_blob = torch.from_numpy(ds.hay_blob).cuda().repeat(nh // 8192).contiguous()
 d_off = torch.arange(nh + 1, dtype=torch.int64, device="cuda") * 8192
 batch.bind_current_stream(res)
-for slab, refill, kern, wilp in ((16, 0, 4, 1), (16, 0, 4, 2), (8, 0, 3, 0)):
-    res.set_option("slab_events", slab); res.set_option("refill", refill); res.set_option("kernel", kern); res.set_option("walk_ilp", wilp)
+light = len(sys.argv) > 1 and sys.argv[1] == "light"   # counter passes: the exact walk only
+for slab, refill, kern, wilp in (((16, 0, 4, 4),) if light else ((16, 0, 1, 8), (16, 0, 4, 1), (16, 0, 4, 4), (16, 0, 4, 8), (8, 0, 3, 4))):
+    res.set_option("slab_events", slab); res.set_option("refill", refill); res.set_option("kernel", kern); res.set_option("walk_group", wilp)
     ms, tot = [], []
-    for _ in range(6):
+    for _ in range(3 if light else 6):
         total = batch.match_device(res, d_blob, d_off)
         ms.append(res.stat("scan_ms")); tot.append(res.stat("total_ms"))
-    print(f"kernel {kern} walk_ilp {wilp} slab {slab} refill {refill}: scan kernel {np.mean(ms[2:]):.3f} ms, whole call {np.mean(tot[2:]):.3f} ms = {d_blob.numel()/np.mean(tot[2:])/1e6:.0f} GB/s, records {total} ({total/nh:.1f}/haystack), overflow items {int(res.stat('overflow_items'))} of {int(res.stat('items'))}, walked bytes {int(res.stat('walked_bytes'))}", flush=True)
+    print(f"kernel {kern} walk_group {wilp} slab {slab} refill {refill}: scan kernel {np.mean(ms[2:]):.3f} ms, whole call {np.mean(tot[2:]):.3f} ms = {d_blob.numel()/np.mean(tot[2:])/1e6:.0f} GB/s, records {total} ({total/nh:.1f}/haystack), overflow items {int(res.stat('overflow_items'))} of {int(res.stat('items'))}, walked bytes {int(res.stat('walked_bytes'))}", flush=True)
