@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libacmi.so")
 SOURCES = ["automaton.cpp", "engine.cpp", "kernels.hip"]
-HEADERS = ["automaton.hpp", "device_types.hpp", "kernels.hpp", os.path.join("..", "..", "include", "acmi.h")]
+HEADERS = ["automaton.hpp", "device_types.hpp", "kernels.hpp", "scan_asm.inc", os.path.join("..", "..", "include", "acmi.h")]
 
 
 def _hipcc() -> str:

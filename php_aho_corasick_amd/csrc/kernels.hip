@@ -1281,6 +1281,9 @@ hipError_t launch_walk_runs(const DevAutomaton &A, const BatchArgs &B, uint64_t 
 // (their blocks side by side, conditional or unconditional cold loads) measured equal or slower and was dropped.
 // Same event rule and slab layout as run_epilogue.
 // ------------------------------------------------------------------------------------------
+// two workgroups per CU share the 160 KiB: 79 KiB each, 512 B of it the byte classes
+constexpr uint32_t kItemsTileBytes = 78u * 1024u;
+
 template <typename E, int MODE, int LB>
 __global__ __launch_bounds__(kWalkThreads, (LB <= 4 ? 8 : 4)) void k_walk_items(DevAutomaton A, BatchArgs B) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1292,7 +1295,7 @@ __global__ __launch_bounds__(kWalkThreads, (LB <= 4 ? 8 : 4)) void k_walk_items(
     const uint4 rec = item < total_items ? B.item_rec[item] : make_uint4(0u, 0u, 0u, 0u);
     // LDS: [512 B byte classes (TABLE mode)] [tile rows]
     const uint32_t cls_bytes = (MODE == 0) ? 512u : 0u;
-    const uint32_t tile_rows = A.row_bytes ? (kWalkTileBytes / A.row_bytes < A.trap ? kWalkTileBytes / A.row_bytes : A.trap) : 0u;
+    const uint32_t tile_rows = A.row_bytes ? (kItemsTileBytes / A.row_bytes < A.trap ? kItemsTileBytes / A.row_bytes : A.trap) : 0u;
     const uint16_t *cls_lds = (MODE == 0) ? reinterpret_cast<const uint16_t *>(smem) : nullptr;
     const uint8_t *tile = smem + cls_bytes;
     {
@@ -1376,7 +1379,7 @@ __global__ __launch_bounds__(kWalkThreads, (LB <= 4 ? 8 : 4)) void k_walk_items(
 hipError_t launch_walk_items(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,
                              int group, hipStream_t st) {
     if (max_items == 0) return hipSuccess;
-    const uint32_t lds = kWalkTileBytes + (class_mode == 0 ? 512u : 0u);
+    const uint32_t lds = kItemsTileBytes + (class_mode == 0 ? 512u : 0u);
     auto go = [&](auto fn) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return e;
