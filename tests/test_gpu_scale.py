@@ -74,7 +74,8 @@ def test_idempotent_and_chunk_invariant():
     """Same batch, different work-item sizes / kernels -> byte-identical result arrays."""
     ds = synth.bench_batch(1 << 12)
     ref = None
-    for opts in (dict(kernel=1, ilp=1), dict(kernel=1, ilp=2, chunk_bytes=1024), dict(kernel=0, chunk_bytes=2048)):
+    for opts in (dict(kernel=1, ilp=1), dict(kernel=1, ilp=2, chunk_bytes=1024), dict(kernel=0, chunk_bytes=2048),
+                 dict(kernel=4), dict(kernel=4, walk_group=8, chunk_bytes=3000), dict(kernel=2)):
         res = resource_for(ds, **opts)
         d_blob, d_off = _device_batch(ds)
         batch.bind_current_stream(res)
