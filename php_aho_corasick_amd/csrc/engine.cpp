@@ -251,7 +251,11 @@ int ensure_device(acmi_handle *h) {
     A.max_out_count = fa.max_out_count;
     A.chain = fa.chain.empty() ? nullptr : h->d_chain.as<uint32_t>();
     A.chain_lo = fa.chain_lo;
+    // identity byte classes (all 256 byte values occur in patterns); 255 used values also give 256 columns, but
+    // with column 0 = "other" -- so test the map itself
     A.class_identity = (fa.class_mode == kClassTable && fa.n_columns == 256) ? 1u : 0u;
+    for (int b = 0; b < 256 && A.class_identity; ++b)
+        if (fa.class_of_byte[b] != b) A.class_identity = 0u;
     A.n_states = fa.n_states;
     A.n_columns = fa.n_columns;
     A.row_bytes = fa.n_columns * fa.entry_bytes;

@@ -384,3 +384,28 @@ def test_small_batch_one_launch_path(name):
             assert used == (5 if len(re_) <= 8192 else used)
     api.ahocorasick_deinit(res)
     o.close()
+
+
+def test_255_used_byte_values_are_not_identity_classes():
+    """255 distinct byte values in the patterns give 256 table columns with column 0 = "every other byte":
+    the byte -> column map is NOT the identity there (found by tools/fuzz_gpu.py seed 50771)."""
+    missing = 0x41
+    vals = [b for b in range(256) if b != missing]
+    pats = [bytes(vals[i:i + 16]) for i in range(0, 255 - 15, 7)] + [bytes(vals[-16:])]
+    hay = bytes([missing]) * 5 + pats[3] + bytes([missing, 0, 255]) + pats[-1] + pats[0][:9] + bytes([missing]) + pats[10]
+    pat_blob, pat_off = synth.pack(pats)
+    hay_blob, hay_off = synth.pack([hay, hay[::-1], hay * 3])
+    ds = synth.Dataset("c255", pat_blob, pat_off, hay_blob, hay_off)
+    o = Oracle("port")
+    o.add_patterns(pats)
+    for opts in (dict(), dict(kernel=1), dict(kernel=4), dict(kernel=0), dict(small_path=0)):
+        res = resource_for(ds, **opts)
+        for find_all in (True, False):
+            pe, re_ = o.match_batch(ds.hay_blob, ds.hay_off, find_all)
+            assert len(re_) > 0
+            for path in (host_match, device_match):
+                p, r = path(res, ds, find_all)
+                assert np.array_equal(p, pe) and np.array_equal(r, re_), (opts, find_all, path.__name__)
+        assert res.stat("columns") == 256
+        api.ahocorasick_deinit(res)
+    o.close()

@@ -1,0 +1,47 @@
+"""Replay one case of tools/fuzz_gpu.py by seed and show the first differing record.
+python tools/repro_fuzz.py <seed> [key=value ...]   (overrides of the drawn options)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+from gpu_util import device_match, host_match, resource_for
+from oracle.pyoracle import Oracle
+from php_aho_corasick_amd import api, synth
+
+seed = int(sys.argv[1])
+over = dict(a.split("=") for a in sys.argv[2:])
+alphabets = [b"ab", b"abc", b"abcdef", b"ACGT", b"01", b"abcdefgh", b"abcdefghij", b"xyz\x00\x01\x02\x03\x04\x05", None,
+             bytes(range(32, 127))]
+r = np.random.default_rng(seed)
+alpha = alphabets[r.integers(len(alphabets))]
+lmin = int(r.choice([1, 1, 2, 4, 7, 8, 11, 15, 19, 40]))
+lmax = int(min(1024, lmin + r.choice([0, 1, 3, 8, 20, 100, 900])))
+n_pat = int(r.choice([1, 3, 17, 60, 300, 1500, 4000]))
+n_hay = int(r.choice([1, 2, 9, 64, 65, 200]))
+hmax = int(r.choice([0, 1, 15, 16, 17, 127, 128, 129, 1000, 5000, 20000]))
+plants = int(r.choice([0, 1, 3, 10]))
+ds = synth._planted_ragged(f"F{seed}", seed, n_pat, lmin, lmax, n_hay, 0, hmax, alpha, plants) if plants else \
+    synth.ragged(f"F{seed}", seed, n_pat, lmin, lmax, n_hay, 0, hmax, alpha)
+o = Oracle("port")
+calls = int(r.choice([1, 1, 2, 5]))
+pats = ds.patterns()
+step = (len(pats) + calls - 1) // calls
+for lo in range(0, len(pats), step):
+    o.add_patterns(pats[lo:lo + step])
+opts = dict(kernel=int(r.choice([0, 1, 2, 2, 3, 3, 4, 4])), walk_group=int(r.choice([1, 4, 8])), ilp=int(r.choice([1, 2])), group_quads=int(r.choice([4, 8])),
+            chunk_bytes=int(r.choice([0, 0, 16, 48, 256, 1024, 4096])), slab_events=int(r.choice([1, 2, 8])),
+            run_cap=int(r.choice([1, 2, 8])), persistent=int(r.choice([-1, 0, 1])), lds_bytes=int(r.choice([2048, 8192, 65536, 163000])),
+            small_path=int(r.choice([0, 1])), refill=int(r.choice([0, 1, 2, 2])), max_flat_outputs=int(r.choice([0, 1 << 25, 1 << 25])), cold_chains=int(r.choice([-1, 0, 1, 1])))
+opts.update({k: int(v) for k, v in over.items()})
+print(dict(alpha=alpha, lmin=lmin, lmax=lmax, n_pat=n_pat, n_hay=n_hay, hmax=hmax, plants=plants, calls=calls), opts)
+print("haystack lengths", np.diff(ds.hay_off.astype(np.int64))[:10], "pattern lengths min/max", np.diff(ds.pat_off.astype(np.int64)).min(), np.diff(ds.pat_off.astype(np.int64)).max())
+res = resource_for(ds, calls=calls, **opts)
+for find_all in (True, False):
+    pe, re_ = o.match_batch(ds.hay_blob, ds.hay_off, find_all)
+    for path in (host_match, device_match):
+        p, rr = path(res, ds, find_all)
+        ok = np.array_equal(p, pe) and np.array_equal(rr, re_)
+        print(path.__name__, find_all, "ok" if ok else "MISMATCH", "got", len(rr), "expected", len(re_), "kernel_used", res.stat("kernel_used"), "anchor_q", res.stat("anchor_q"), "min/max len", res.stat("min_pattern_length"), res.stat("max_pattern_length"))
+        if not ok:
+            print("  expected", re_[:12].tolist())
+            print("  got     ", rr[:12].tolist())
