@@ -255,6 +255,25 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
     fa.trap = hot;
     fa.f2 = hot + 1 + cold_nf;
     fa.chain_lo = fa.f2 - cold_chain;
+    // Non-final states of trie depth <= 2 are a prefix of their id class (ids follow BFS order within a class):
+    // [0, shallow_hot) and (trap, shallow_cold_end).  The exact walk of an anchor candidate stops on them (see
+    // run_epilogue): no pattern begun at the candidate's window can still be alive there.
+    {
+        std::vector<uint8_t> depth(ns, 0);
+        for (uint32_t i = 1; i < ns; ++i) {
+            const uint32_t u = order[i];
+            depth[u] = uint8_t(std::min<uint32_t>(depth[parent_[u]] + 1u, 255u));
+        }
+        uint32_t sh = 0, sc = 0;
+        for (uint32_t i = 0; i < ns; ++i) {
+            const uint32_t u = order[i];
+            if (is_final[u] || depth[u] > 2) continue;
+            if (i < hot) ++sh;
+            else if (!use_chains || !in_chain[u]) ++sc;
+        }
+        fa.shallow_hot = sh;
+        fa.shallow_cold_end = hot + 1 + sc;
+    }
     {
         uint32_t a = 0, b = hot_nf, c = hot + 1, d = fa.f2;
         for (uint32_t i = 0; i < ns; ++i) {

@@ -21,6 +21,8 @@ struct DevAutomaton {
     uint32_t max_out_count;      // longest output list
     const uint32_t *chain;       // states [chain_lo,f2) (cold, non-final, one trie child): child << 8 | edge byte; null: none
     uint32_t chain_lo;
+    uint32_t shallow_hot, shallow_cold_end;  // non-final states of trie depth <= 2: [0,shallow_hot), (trap,shallow_cold_end)
+    uint32_t early_stop;         // 1: walks of anchor candidates stop on them (run_epilogue)
     uint32_t class_identity;     // TABLE mode with 256 columns: class(byte) == byte
     uint32_t n_states;
     uint32_t n_columns;

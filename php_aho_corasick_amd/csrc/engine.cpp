@@ -79,6 +79,7 @@ struct acmi_handle {
     int wave_items = 0;   // 0 automatic, else 1..64 items per wave batch of the anchor kernel
     int persistent = -1;  // -1 automatic, 0 one workgroup per 1024 x ILP items, 1 persistent workgroups
     int walk_group = 4;   // k_walk_items: 16-byte haystack blocks a lane requests back to back (1, 4 or 8 = a whole line)
+    int early_stop = 1;   // walks of anchor candidates end once no pattern begun at the hit window can be alive
     int refill = 0;       // 0 automatic, 1 one thread per overflowed item (k_refill), 2 one wave (k_refill_wave)
     int profile = 0;
 
@@ -251,6 +252,9 @@ int ensure_device(acmi_handle *h) {
     A.max_out_count = fa.max_out_count;
     A.chain = fa.chain.empty() ? nullptr : h->d_chain.as<uint32_t>();
     A.chain_lo = fa.chain_lo;
+    A.shallow_hot = fa.shallow_hot;
+    A.shallow_cold_end = fa.shallow_cold_end;
+    A.early_stop = h->early_stop ? 1u : 0u;
     // identity byte classes (all 256 byte values occur in patterns); 255 used values also give 256 columns, but
     // with column 0 = "other" -- so test the map itself
     A.class_identity = (fa.class_mode == kClassTable && fa.n_columns == 256) ? 1u : 0u;
@@ -821,6 +825,9 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
     } else if (k == "walk_group") {
         if (value != 1 && value != 4 && value != 8) return ACMI_E_ARG;
         h->walk_group = int(value);
+    } else if (k == "early_stop") {
+        h->early_stop = value ? 1 : 0;
+        h->dA.early_stop = h->early_stop ? 1u : 0u;
     } else if (k == "refill") {
         if (value < 0 || value > 2) return ACMI_E_ARG;
         h->refill = int(value);

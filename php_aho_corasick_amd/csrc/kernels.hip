@@ -474,6 +474,7 @@ constexpr uint32_t kStageSlots = 128;
 // `entry` of a run: the exact automaton state at `lo`, or one of
 constexpr uint32_t kEntryUnknown = 0xFFFFFFFFu;    // walk from the root Lmax-1 bytes before lo
 constexpr uint32_t kEntryShortWarm = 0xFFFFFFFEu;  // k_scan_anchor: m_min-1 bytes before lo suffice
+constexpr uint32_t kEntryShortWarmMerged = 0xFFFFFFFDu;  // the same, and later windows' ranges were merged into the run
 
 __device__ __forceinline__ void stage_flush(const BatchArgs &B, uint64_t wave_first, RunStage &st, uint32_t lane) {
     for (uint32_t i = lane; i < st.count; i += 64u) {
@@ -490,7 +491,10 @@ __device__ __forceinline__ void append_run_wave(const BatchArgs &B, uint64_t wav
                                                 uint32_t &last_hi, uint32_t lane) {
     if (n > B.run_cap) return;
     if (n > 0 && last_hi == lo && st.mergeable) {
-        if (lane == 0) st.slots[st.count - 1].z = hi;  // adjacent: extend the previous run
+        if (lane == 0) {  // adjacent: extend the previous run; it then serves more than one hit window
+            st.slots[st.count - 1].z = hi;
+            if (st.slots[st.count - 1].w == kEntryShortWarm) st.slots[st.count - 1].w = kEntryShortWarmMerged;
+        }
     } else {
         if (n < B.run_cap) {
             if (st.count == kStageSlots) stage_flush(B, wave_first, st, lane);
@@ -547,7 +551,8 @@ template <typename E, int MODE>
 __device__ __forceinline__ uint32_t exact_range(const DevAutomaton &A, const BatchArgs &B, const uint16_t *cls_lds,
                                                 const uint8_t *tile, uint32_t tile_rows, uint64_t item,
                                                 const uint8_t *p, uint32_t j0, uint32_t j1, uint32_t rep_from,
-                                                uint32_t pos_bias, uint32_t s, EventRegs &ev) {
+                                                uint32_t pos_bias, uint32_t s, EventRegs &ev,
+                                                uint32_t stop_from = 0xFFFFFFFFu) {
     // Haystack bytes come in aligned 16-byte blocks, the next block requested one block ahead: one
     // exposed memory round trip per call instead of one per dword (the walks are latency chains).
     // A block is only touched when it holds a needed byte, so it lies inside a mapped page.
@@ -587,6 +592,9 @@ __device__ __forceinline__ uint32_t exact_range(const DevAutomaton &A, const Bat
             if (ev.n_ev < B.slab_events) B.slab[uint64_t(ev.n_ev) * B.run_stride + item] = make_uint2(pos_bias + j, s);
             ++ev.n_ev;
         }
+        // an anchor candidate's walk: from byte stop_from on, a non-final state of trie depth <= 2 means that
+        // no pattern begun at or before the hit window is still alive -- nothing more can end in this run
+        if (j >= stop_from && (s < A.shallow_hot || (s > A.trap && s < A.shallow_cold_end))) break;
     }
     return s;
 }
@@ -616,15 +624,23 @@ __device__ __forceinline__ uint32_t run_epilogue(const DevAutomaton &A, const Ba
             const uint4 run = runs[uint64_t(r) * B.run_stride];
             const uint32_t lo = run.x, hi = run.y;
             uint32_t st = run.z, from = lo;
+            uint32_t stop_from = 0xFFFFFFFFu;
             walked += hi - lo;
-            if (st >= kEntryShortWarm) {  // entry state unknown: silent warm-up from the root, Lmax-1 bytes
+            if (st >= kEntryShortWarmMerged) {  // entry state unknown: silent warm-up from the root, Lmax-1 bytes
                                           // (or m_min-1 where k_scan_anchor knows that this suffices)
                 const uint32_t warm = st == kEntryUnknown ? B.warm_bytes : A.min_pattern_length - 1u;
+                // A run of ONE hit window (short warm-up; lo = window start + m_min - 4) whose range no later
+                // window's run was clamped against: every pattern it can report begins in [start-3, start], so
+                // once the state's depth is <= j - start nothing is alive.  Depth <= 2 is what the state ids
+                // tell for free: stop from byte start + 2 on.
+                if (st == kEntryShortWarm && A.early_stop && lo + 6u >= A.min_pattern_length &&
+                    (r + 1u == nr || runs[uint64_t(r + 1u) * B.run_stride].x != hi))
+                    stop_from = lo + 6u - A.min_pattern_length;
                 from = lo > warm ? lo - warm : 0u;
                 st = 0;
             }
             // warm-up and run in one loop: nothing before `lo` is reported
-            exact_range<E, MODE>(A, B, cls_lds, tile, tile_rows, item, p, from, hi, lo > it.warm ? lo : it.warm, pos_bias, st, ev);
+            exact_range<E, MODE>(A, B, cls_lds, tile, tile_rows, item, p, from, hi, lo > it.warm ? lo : it.warm, pos_bias, st, ev, stop_from);
         }
     }
     if (ev.n_ev) {
@@ -956,6 +972,18 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     sc = ld;
     RunStage stage{reinterpret_cast<uint4 *>(smem + kAnchorLdsBytes) + (threadIdx.x >> 6) * kStageSlots, 0u, false};
     uint32_t nrun = 0, run_hi = 0;  // run list of the item being scanned (wave-uniform)
+    uint32_t run_entry = 0;         // entry word of its last run as stored (wave-uniform)
+    // The last run is about to serve a second hit window (a later window's range was clamped against it, or
+    // swallowed by it): if it is a single-window run (kEntryShortWarm) its walk may no longer stop early.
+    auto mark_prev = [&]() {
+        if (run_entry != kEntryShortWarm || nrun == 0 || nrun > B.run_cap) return;
+        if (stage.mergeable) {
+            if (lane == 0) stage.slots[stage.count - 1].w = kEntryShortWarmMerged;
+        } else if (lane == 0) {
+            B.runs[uint64_t(nrun - 1u) * B.run_stride + wave_first + sc.k].z = kEntryShortWarmMerged;
+        }
+        run_entry = kEntryShortWarmMerged;
+    };
     uint32_t nrun_vec = 0;          // lane k: run count of item wave_first + k
     // carry[n-1] = hash prefix over the LAST n dwords of a quad (n = 1..QW-1): what a window that
     // begins there and ends in the next quad continues from.  `tail` = the carries of the previous
@@ -1108,8 +1136,13 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                 // a run that begins where no earlier window's range reaches needs only m_min-1 bytes of
                 // warm-up (everything ending in it starts at or after start-3); a clamped one the full Lmax-1
                 uint32_t entry = kEntryShortWarm;
-                if (nrun > 0 && uint32_t(lo) < run_hi) { lo = int32_t(run_hi); entry = kEntryUnknown; }  // disjoint, ascending
-                if (uint32_t(lo) < hi) append_run_wave(B, wave_first, stage, sc.k, uint32_t(lo), hi, entry, nrun, run_hi, lane);
+                if (nrun > 0 && uint32_t(lo) < run_hi) { lo = int32_t(run_hi); entry = kEntryUnknown; mark_prev(); }  // disjoint, ascending
+                if (uint32_t(lo) < hi) {
+                    const bool extends = nrun > 0 && run_hi == uint32_t(lo) && stage.mergeable;
+                    append_run_wave(B, wave_first, stage, sc.k, uint32_t(lo), hi, entry, nrun, run_hi, lane);
+                    if (!extends) run_entry = entry;
+                    else if (run_entry == kEntryShortWarm) run_entry = kEntryShortWarmMerged;  // append_run_wave marked the slot
+                }
             }
         };
         if (__builtin_expect(cand != 0, 0)) {
@@ -1149,7 +1182,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
             // ends at or after head + 16*nq - q + m_min
             uint32_t lo = sc.head + (sc.nq << 4) + m_min;
             lo = lo > q ? lo - q : 0u;
-            if (nrun > 0 && lo < run_hi) lo = run_hi;
+            if (nrun > 0 && lo < run_hi) { lo = run_hi; if (sc.head + (sc.nq << 4) < sc.n) mark_prev(); }
             if (lo < sc.n && sc.head + (sc.nq << 4) < sc.n) append_run_wave(B, wave_first, stage, sc.k, lo, sc.n, 0xFFFFFFFFu, nrun, run_hi, lane);
             nrun_vec = lane == sc.k ? nrun : nrun_vec;
         }
@@ -1158,6 +1191,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
         if (more && sc.k != k_before) {
             nrun = 0;
             run_hi = 0;
+            run_entry = 0;
             stage.mergeable = false;
             if (sc.head) append_run_wave(B, wave_first, stage, sc.k, 0, (sc.head + l_max) < sc.n ? sc.head + l_max : sc.n, 0u, nrun, run_hi, lane);
         }
