@@ -218,6 +218,10 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *   "max_flat_outputs"  per-state output lists are also stored flat ({pattern, length}, longest first) for the
  *                    dense-match drain when they total at most this many entries (default 2^25);
  *                    0 = dictionary links only                                  [before finalize]
+ *   "early_stop"     exact walks of single-window anchor candidates end once the state is a non-final state of
+ *                    trie depth <= 2 two bytes past the window start: 0 = off, 1 (default) = when some 3-gram
+ *                    over the patterns' first-byte alphabet is not a trie path (else it cannot fire on
+ *                    in-alphabet text), 2 = always                                        [any time]
  *   "refill"         drain of work items whose events overflowed their slab (dense-match inputs):
  *                    1 = one thread per item, 2 = one wave per item with whole-row record stores,
  *                    0 = automatic (default): 2 unless the longest pattern exceeds 64 B   [any time]

@@ -273,6 +273,11 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
         }
         fa.shallow_hot = sh;
         fa.shallow_cold_end = hot + 1 + sc;
+        // When every 3-gram over the first-byte alphabet is a trie path (2048 x 16 B over 6 letters: 216 of 216)
+        // a walk on in-alphabet text never falls back to depth <= 2 and the test would only cost time.
+        uint64_t d1 = 0, d3 = 0;
+        for (uint32_t u = 1; u < ns; ++u) { d1 += depth[u] == 1; d3 += depth[u] == 3; }
+        fa.early_stop_useful = d3 < d1 * d1 * d1;
     }
     {
         uint32_t a = 0, b = hot_nf, c = hot + 1, d = fa.f2;

@@ -53,6 +53,7 @@ struct FlatAutomaton {
     uint32_t f2 = 0;             // (trap,f2) cold non-final, [f2,n_states) cold final
     uint32_t shallow_hot = 0;    // [0,shallow_hot) and (trap,shallow_cold_end): non-final states of trie depth <= 2
     uint32_t shallow_cold_end = 0;
+    bool early_stop_useful = false;  // some 3-gram over the first-byte alphabet is not a trie path
     uint32_t chain_lo = 0;       // [chain_lo,f2): cold non-final states with one trie child, in trie preorder (== f2: none)
     uint32_t class_mode = kClassTable;
     uint32_t swar_shift = 0;     // class = (byte >> shift) & 7 when byte is in the alphabet

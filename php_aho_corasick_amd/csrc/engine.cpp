@@ -79,7 +79,8 @@ struct acmi_handle {
     int wave_items = 0;   // 0 automatic, else 1..64 items per wave batch of the anchor kernel
     int persistent = -1;  // -1 automatic, 0 one workgroup per 1024 x ILP items, 1 persistent workgroups
     int walk_group = 4;   // k_walk_items: 16-byte haystack blocks a lane requests back to back (1, 4 or 8 = a whole line)
-    int early_stop = 1;   // walks of anchor candidates end once no pattern begun at the hit window can be alive
+    int early_stop = 1;   // walks of anchor candidates end once no pattern begun at the hit window can be alive: 0 off,
+                          // 1 when the automaton can fall back to shallow states at all (default), 2 always
     int refill = 0;       // 0 automatic, 1 one thread per overflowed item (k_refill), 2 one wave (k_refill_wave)
     int profile = 0;
 
@@ -254,7 +255,7 @@ int ensure_device(acmi_handle *h) {
     A.chain_lo = fa.chain_lo;
     A.shallow_hot = fa.shallow_hot;
     A.shallow_cold_end = fa.shallow_cold_end;
-    A.early_stop = h->early_stop ? 1u : 0u;
+    A.early_stop = (h->early_stop == 2 || (h->early_stop == 1 && fa.early_stop_useful)) ? 1u : 0u;
     // identity byte classes (all 256 byte values occur in patterns); 255 used values also give 256 columns, but
     // with column 0 = "other" -- so test the map itself
     A.class_identity = (fa.class_mode == kClassTable && fa.n_columns == 256) ? 1u : 0u;
@@ -826,8 +827,10 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
         if (value != 1 && value != 4 && value != 8) return ACMI_E_ARG;
         h->walk_group = int(value);
     } else if (k == "early_stop") {
-        h->early_stop = value ? 1 : 0;
-        h->dA.early_stop = h->early_stop ? 1u : 0u;
+        if (value < 0 || value > 2) return ACMI_E_ARG;
+        h->early_stop = int(value);
+        if (h->aut.finalized())
+            h->dA.early_stop = (value == 2 || (value == 1 && h->aut.flat().early_stop_useful)) ? 1u : 0u;
     } else if (k == "refill") {
         if (value < 0 || value > 2) return ACMI_E_ARG;
         h->refill = int(value);

@@ -543,11 +543,13 @@ struct EventRegs {
     uint32_t n_ev;
 };
 
+// EXTRA compiles in what only some automata use -- chain words for cold single-child states, the early stop of
+// single-window anchor runs: without them the headline's k_walk_runs takes 65 us, with the tests in the loop 72.
 // Exact walk of bytes [j0, j1) of one item: hot rows from the LDS tile when one is resident
 // (`tile`), everything else from the global table; haystack bytes by aligned dword loads.
 // Reports (records an event) for final states at byte index j >= rep_from, at position
 // pos_bias + j.  Returns the state.
-template <typename E, int MODE>
+template <typename E, int MODE, bool EXTRA = false>
 __device__ __forceinline__ uint32_t exact_range(const DevAutomaton &A, const BatchArgs &B, const uint16_t *cls_lds,
                                                 const uint8_t *tile, uint32_t tile_rows, uint64_t item,
                                                 const uint8_t *p, uint32_t j0, uint32_t j1, uint32_t rep_from,
@@ -580,7 +582,7 @@ __device__ __forceinline__ uint32_t exact_range(const DevAutomaton &A, const Bat
             // cold row.  Inside a long pattern the state has one trie child: its edge is in chain[], which is
             // laid out along the pattern (32 steps per 128-byte line; the table costs one line per step)
             uint32_t cw = 0xFFFFFFFFu;
-            if (A.chain != nullptr && s >= A.chain_lo && s < A.f2) cw = A.chain[s - A.chain_lo];
+            if (EXTRA && A.chain != nullptr && s >= A.chain_lo && s < A.f2) cw = A.chain[s - A.chain_lo];
             if ((cw & 0xffu) == byte && cw != 0xFFFFFFFFu)
                 w = cw >> 8;
             else
@@ -594,7 +596,7 @@ __device__ __forceinline__ uint32_t exact_range(const DevAutomaton &A, const Bat
         }
         // an anchor candidate's walk: from byte stop_from on, a non-final state of trie depth <= 2 means that
         // no pattern begun at or before the hit window is still alive -- nothing more can end in this run
-        if (j >= stop_from && (s < A.shallow_hot || (s > A.trap && s < A.shallow_cold_end))) break;
+        if (EXTRA && j >= stop_from && (s < A.shallow_hot || (s > A.trap && s < A.shallow_cold_end))) break;
     }
     return s;
 }
@@ -605,7 +607,7 @@ __device__ __forceinline__ uint32_t exact_range(const DevAutomaton &A, const Bat
 // ending inside the run -- and only events ending inside it (and inside the item's reporting range)
 // are recorded.  nr > run_cap means the run list overflowed: the whole item is walked.
 // Returns the number of bytes it walked exactly (statistic for the kernel choice).
-template <typename E, int MODE>
+template <typename E, int MODE, bool EXTRA = false>
 __device__ __forceinline__ uint32_t run_epilogue(const DevAutomaton &A, const BatchArgs &B, const uint16_t *cls_lds,
                                                  const uint8_t *tile, uint32_t tile_rows, uint64_t item,
                                                  const ItemDesc &it, uint32_t nr) {
@@ -616,7 +618,7 @@ __device__ __forceinline__ uint32_t run_epilogue(const DevAutomaton &A, const Ba
     uint32_t walked = 0;
     if (nr > B.run_cap) {
         walked = n;
-        exact_range<E, MODE>(A, B, cls_lds, tile, tile_rows, item, p, 0, n, it.warm, pos_bias, 0u, ev);
+        exact_range<E, MODE, EXTRA>(A, B, cls_lds, tile, tile_rows, item, p, 0, n, it.warm, pos_bias, 0u, ev);
     } else {
         const uint4 *runs = B.runs + item;
 #pragma unroll 1
@@ -633,14 +635,14 @@ __device__ __forceinline__ uint32_t run_epilogue(const DevAutomaton &A, const Ba
                 // window's run was clamped against: every pattern it can report begins in [start-3, start], so
                 // once the state's depth is <= j - start nothing is alive.  Depth <= 2 is what the state ids
                 // tell for free: stop from byte start + 2 on.
-                if (st == kEntryShortWarm && A.early_stop && lo + 6u >= A.min_pattern_length &&
+                if (EXTRA && st == kEntryShortWarm && A.early_stop && lo + 6u >= A.min_pattern_length &&
                     (r + 1u == nr || runs[uint64_t(r + 1u) * B.run_stride].x != hi))
                     stop_from = lo + 6u - A.min_pattern_length;
                 from = lo > warm ? lo - warm : 0u;
                 st = 0;
             }
             // warm-up and run in one loop: nothing before `lo` is reported
-            exact_range<E, MODE>(A, B, cls_lds, tile, tile_rows, item, p, from, hi, lo > it.warm ? lo : it.warm, pos_bias, st, ev, stop_from);
+            exact_range<E, MODE, EXTRA>(A, B, cls_lds, tile, tile_rows, item, p, from, hi, lo > it.warm ? lo : it.warm, pos_bias, st, ev, stop_from);
         }
     }
     if (ev.n_ev) {
@@ -1235,7 +1237,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
 constexpr uint32_t kWalkThreads = 1024;
 constexpr uint32_t kWalkTileBytes = 64u * 1024u;  // two workgroups per CU: every lane slot of the chip walks at once
 
-template <typename E, int MODE>
+template <typename E, int MODE, bool EXTRA>
 __global__ __launch_bounds__(kWalkThreads) void k_walk_runs(DevAutomaton A, BatchArgs B) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint64_t total_items = B.item_base[B.n_haystacks];
@@ -1272,7 +1274,7 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_runs(DevAutomaton A, Batc
     if (nr != 0) {
         ItemDesc it;
         unpack_item(rec.x, rec.y, rec.z, rec.w, it);
-        walked = run_epilogue<E, MODE>(A, B, nullptr, smem, tile_rows, item, it, nr);
+        walked = run_epilogue<E, MODE, EXTRA>(A, B, nullptr, smem, tile_rows, item, it, nr);
     }
     // statistic: bytes walked, one atomic per workgroup (8192 same-address device atomics, one per
     // wave, took 0.1 ms on their own: they serialise at ~12 ns each)
@@ -1294,8 +1296,11 @@ hipError_t launch_walk_runs(const DevAutomaton &A, const BatchArgs &B, uint64_t 
         hipLaunchKernelGGL(fn, dim3(blocks), dim3(kWalkThreads), lds, st, A, B);
         return hipGetLastError();
     };
-    if (entry_bytes == 2) return class_mode == 1 ? go(k_walk_runs<uint16_t, 1>) : go(k_walk_runs<uint16_t, 0>);
-    return class_mode == 1 ? go(k_walk_runs<uint32_t, 1>) : go(k_walk_runs<uint32_t, 0>);
+    const bool extra = A.chain != nullptr || A.early_stop != 0u;
+#define ACMI_WALK_RUNS(E, M) (extra ? go(k_walk_runs<E, M, true>) : go(k_walk_runs<E, M, false>))
+    if (entry_bytes == 2) return class_mode == 1 ? ACMI_WALK_RUNS(uint16_t, 1) : ACMI_WALK_RUNS(uint16_t, 0);
+    return class_mode == 1 ? ACMI_WALK_RUNS(uint32_t, 1) : ACMI_WALK_RUNS(uint32_t, 0);
+#undef ACMI_WALK_RUNS
 }
 
 // ------------------------------------------------------------------------------------------

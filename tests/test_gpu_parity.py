@@ -70,7 +70,9 @@ VARIANTS = [dict(kernel=1, persistent=1, chunk_bytes=64), dict(kernel=1, persist
             dict(kernel=0, cold_chains=1), dict(kernel=3, cold_chains=1, lds_bytes=8192, run_cap=1),
             # exact walk of whole items, 1 / 2 / 4 items per thread
             dict(kernel=4, walk_group=1), dict(kernel=4, walk_group=4, chunk_bytes=48, slab_events=1), dict(kernel=4, walk_group=8, chunk_bytes=256, lds_bytes=4096),
-            dict(kernel=4, walk_group=8, slab_events=2, refill=2)]
+            dict(kernel=4, walk_group=8, slab_events=2, refill=2),
+            # early stop of single-window anchor walks: forced on / off
+            dict(kernel=2, early_stop=2), dict(kernel=2, early_stop=2, chunk_bytes=256, cold_chains=1), dict(kernel=2, early_stop=0)]
 
 
 @pytest.mark.parametrize("name,variant", list(itertools.product(["G2", "G4", "G5", "R1", "R2", "R3", "R4", "R5", "R6", "R7", "R8"], range(len(VARIANTS)))))
