@@ -210,11 +210,14 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *   "wave_items"     anchor kernel: items a wave takes per batch, 1..64 (0 = automatic)
  *   "persistent"     1 = one workgroup per CU, waves pull item batches from a counter; 0 = one
  *                    workgroup per 1024 x ILP items; -1 = automatic (default)   [any time]
- *   "cold_chains"    states outside the LDS tile that are non-final and have one trie child (the inside of a
- *                    long pattern) get consecutive ids along the pattern and a 4-byte edge word, so that the
- *                    exact walk of a candidate reads one line per 32 steps instead of one table row per step:
- *                    1 = always, 0 = never (default: the walks are bound by far-memory latency in SIMT
- *                    lockstep, not by lines fetched -- no gain measured), -1 = when the table exceeds 16 MiB   [before finalize]
+ *   "compact"        automaton form for the states outside the first trie levels: dense failure-free rows
+ *                    (one lookup per byte, 1 KiB per state at 256 byte classes) or 8-byte goto / failure records
+ *                    laid out along the patterns (the reference's node form, node.h:37-67, flattened): 1 = compact,
+ *                    0 = dense, -1 (default) = compact when the dense table would exceed 64 MiB   [before finalize]
+ *   "dense_bytes"    compact: dense rows are kept for the LDS tile, trie depth <= 1 and further states in BFS order
+ *                    up to this many bytes (default 4 MiB)                                        [before finalize]
+ *   "keep_host_tables"  1 = keep the host copies of the tables after they were uploaded (acmi_debug_tables after a
+ *                    match call); default 0: they are freed by the first match call               [before the first match]
  *   "max_flat_outputs"  per-state output lists are also stored flat ({pattern, length}, longest first) for the
  *                    dense-match drain when they total at most this many entries (default 2^25);
  *                    0 = dictionary links only                                  [before finalize]
@@ -251,7 +254,7 @@ typedef struct acmi_tables {
     uint32_t swar_shift;
     uint32_t swar_other;
     uint32_t max_pattern_length;
-    const void *table;       /* n_states x n_columns transitions               */
+    const void *table;       /* n_states (compact: n_dense_rows) x n_columns transitions */
     const void *lds_image;   /* (trap+1) x n_columns, cold targets -> trap     */
     const uint8_t *class_of_byte; /* 256 entries                               */
     const uint32_t *own_pattern;  /* per state, 0xFFFFFFFF = none              */
@@ -265,9 +268,12 @@ typedef struct acmi_tables {
     uint32_t anchor_mode;         /* 0 none, 1 LDS table, 2 LDS bitmap + global table */
     uint32_t anchor_bucket_bits;  /* mode 2                                    */
     const uint32_t *anchor_bitmap;/* mode 2: 32768 words (2^20 bits)           */
-    uint32_t chain_lo;            /* states [chain_lo, first_cold_final): cold, non-final, one trie child, in trie preorder */
     uint32_t n_flat_outputs;      /* entries of out_list (0: dictionary links only) */
-    const uint32_t *chain;        /* per such state: child id << 8 | edge byte (null: none) */
+    uint32_t compact;             /* 1: `table` holds n_dense_rows rows only, for ids [0, dense_nf_end) and [first_cold_final, dense_f_end) */
+    uint32_t dense_nf_end, dense_f_end, n_dense_rows, n_cold_edges;
+    const uint32_t *cold_rec;     /* compact: 2 words per state id {x, failure id | code << 24}; code 0 no child, 1: x = child << 8 | byte,
+                                     2..254: that many edges at cold_edges[x], 255: cold_edges[x] = count, edges behind it */
+    const uint32_t *cold_edges;   /* child << 8 | byte, ascending byte */
     const uint32_t *out_off;      /* per state: first entry of its flat output list */
     const uint32_t *out_list;     /* 2 words per entry: pattern index, pattern length; longest first */
 } acmi_tables;

@@ -240,7 +240,7 @@ def ahocorasick_add_patterns(res, patterns) -> bool:
     if r is None or not N.lib.acmi_is_valid(r._h):
         _warn("Cannot add a new pattern, not initialized")
         return False
-    if r.stat("states") > 0:  # finalized: the flat automaton exists
+    if r.stat("finalized") > 0:  # php_ahocorasick.c:914-917 (ac_finalized)
         _warn("Cannot add a new pattern to finalized search structure")
         return False
     if not isinstance(patterns, (list, tuple, dict)):

@@ -26,6 +26,9 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: libacmi.so cannot be built (there is no CPU-only build)")
 
 
+OBJ_DIR = os.path.join(CSRC, "build")
+
+
 def stale() -> bool:
     if not os.path.exists(LIB):
         return True
@@ -34,13 +37,30 @@ def stale() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """One object per source (compiled in parallel, only when it or a header changed), then the link."""
     if not force and not stale():
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function",
-           *[os.path.join(CSRC, f) for f in SOURCES], "-o", LIB]
+    hipcc = _hipcc()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hdr_time = max(os.path.getmtime(os.path.join(CSRC, f)) for f in HEADERS)
+    procs, objs = [], []
+    for src in SOURCES:
+        obj = os.path.join(OBJ_DIR, src + ".o")
+        objs.append(obj)
+        path = os.path.join(CSRC, src)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_time):
+            continue
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+               "-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", LIB]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     return LIB
 

@@ -13,18 +13,23 @@ inline uint64_t mix(uint64_t k) {
     return k ^ (k >> 29);
 }
 
+// Dense rows.  `dense` = how many states, in BFS order, get a row (all of them when not compact); a state's row
+// index is its id below dense_nf_end and dense_nf_end + id - f2 for the dense cold final ones.
 template <typename E>
-void build_tables(FlatAutomaton &fa, const std::vector<uint32_t> &order,
+void build_tables(FlatAutomaton &fa, const std::vector<uint32_t> &order, uint32_t dense,
                   const std::vector<uint32_t> &fail, const std::vector<uint32_t> &newid,
                   const std::vector<uint32_t> &child_off, const std::vector<uint32_t> &child_list,
                   const std::vector<uint8_t> &in_byte) {
     const size_t nc = fa.n_columns;
-    fa.table.assign(size_t(fa.n_states) * nc * sizeof(E), 0);
+    fa.table.assign(size_t(fa.n_dense_rows) * nc * sizeof(E), 0);
+    fa.table_bytes = fa.table.size();
     E *tab = reinterpret_cast<E *>(fa.table.data());
-    for (uint32_t u : order) {  // BFS order: the failure state's row is already complete
-        E *row = tab + size_t(newid[u]) * nc;
+    auto row_of = [&](uint32_t id) { return size_t(id < fa.dense_nf_end ? id : fa.dense_nf_end + (id - fa.f2)); };
+    for (uint32_t i = 0; i < dense; ++i) {  // BFS order: the failure state's row is already complete
+        const uint32_t u = order[i];
+        E *row = tab + row_of(newid[u]) * nc;
         if (u != 0)
-            std::memcpy(row, tab + size_t(newid[fail[u]]) * nc, nc * sizeof(E));
+            std::memcpy(row, tab + row_of(newid[fail[u]]) * nc, nc * sizeof(E));
         // (root row stays all-zero: every byte without a goto edge returns to the root)
         for (uint32_t e = child_off[u]; e < child_off[u + 1]; ++e) {
             uint32_t c = child_list[e];
@@ -226,50 +231,63 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
     fa.n_states = ns + 1;
     fa.entry_bytes = ns <= 65535 ? 2 : 4;
     const uint64_t row_bytes = uint64_t(fa.n_columns) * fa.entry_bytes;
-    const uint64_t table_bytes = row_bytes * fa.n_states;
-    if (table_bytes > opt.max_table_bytes) {
-        if (error) *error = "transition table of " + std::to_string(table_bytes) + " bytes exceeds the limit";
+    const uint64_t full_table_bytes = row_bytes * fa.n_states;
+    const bool compact = (opt.compact > 0 || (opt.compact < 0 && full_table_bytes > (64ull << 20))) && fa.n_states < (1u << 24);
+    if (!compact && full_table_bytes > opt.max_table_bytes) {
+        if (error) *error = "transition table of " + std::to_string(full_table_bytes) + " bytes exceeds the limit";
         return false;
     }
+    fa.compact = compact ? 1u : 0u;
     const uint64_t class_tab = fa.class_mode == kClassTable ? 512 : 0;  // uint16 column offsets
     uint64_t max_rows = opt.lds_bytes > class_tab ? (opt.lds_bytes - class_tab) / row_bytes : 0;
     if (max_rows < 2) max_rows = 2;  // root + trap always fit (row <= 1 KiB)
     const uint32_t hot = uint32_t(std::min<uint64_t>(ns, max_rows - 1));
     std::vector<uint32_t> newid(ns);
-    // Cold non-final states with exactly one trie child ("chain" states: the inside of a long pattern) can
-    // be numbered last among the cold non-final ones, in trie preorder, so that a chain s1 -> s2 -> ... has
-    // consecutive ids and chain[] (one word per such state: child id << 8 | edge byte) is read sequentially.
-    // A walk along a pattern then touches one 128-byte line per 32 steps instead of one table row per step.
-    const bool chains = opt.cold_chains > 0 || (opt.cold_chains < 0 && table_bytes > (16ull << 20));
-    const bool use_chains = chains && fa.n_states < (1u << 24);
-    std::vector<uint8_t> in_chain(use_chains ? ns : 0, 0);
-    uint32_t hot_nf = 0, cold_nf = 0, cold_chain = 0;
+    std::vector<uint8_t> depth(ns, 0);
+    uint32_t n_shallow1 = 0;  // states of trie depth <= 1
+    for (uint32_t i = 0; i < ns; ++i) {
+        const uint32_t u = order[i];
+        if (i) depth[u] = uint8_t(std::min<uint32_t>(depth[parent_[u]] + 1u, 255u));
+        n_shallow1 += depth[u] <= 1;
+    }
+    // Dense set = a prefix of the BFS order (closed under failure links, so that a row can be copied from the
+    // failure state's): everything when not compact; else the LDS tile, trie depth <= 1 (the failure walk of a
+    // compact state then always ends on a dense row after at most one record per level) and what the budget allows.
+    uint32_t dense = ns;
+    if (compact) {
+        const uint64_t by_budget = opt.dense_bytes / row_bytes;
+        dense = uint32_t(std::min<uint64_t>(ns, std::max<uint64_t>(std::max<uint64_t>(hot, n_shallow1), by_budget)));
+    }
+    // Compact: cold non-final states with exactly one trie child (the inside of a long pattern) are numbered last
+    // among the cold non-final ones, in trie preorder: a chain s1 -> s2 -> ... has consecutive ids and its 8-byte
+    // records are read sequentially, 16 steps per 128-byte line.  Depth <= 2 keeps BFS numbering (the early stop
+    // of candidate walks tests "non-final, depth <= 2" as an id range).
+    std::vector<uint8_t> in_chain(compact ? ns : 0, 0);
+    uint32_t hot_nf = 0, cold_nf = 0, cold_chain = 0, dense_cold_nf = 0, dense_cold_f = 0;
     for (uint32_t i = 0; i < ns; ++i) {
         const uint32_t u = order[i];
         if (!is_final[u]) {
             (i < hot ? hot_nf : cold_nf)++;
-            if (use_chains && i >= hot && child_off[u + 1] - child_off[u] == 1) { in_chain[u] = 1; ++cold_chain; }
+            if (compact && i >= dense && depth[u] >= 3 && child_off[u + 1] - child_off[u] == 1) { in_chain[u] = 1; ++cold_chain; }
         }
+        if (i >= hot && i < dense) (is_final[u] ? dense_cold_f : dense_cold_nf)++;
     }
     fa.f1 = hot_nf;
     fa.trap = hot;
     fa.f2 = hot + 1 + cold_nf;
-    fa.chain_lo = fa.f2 - cold_chain;
+    fa.dense_nf_end = compact ? hot + 1 + dense_cold_nf : fa.n_states;
+    fa.dense_f_end = compact ? fa.f2 + dense_cold_f : fa.n_states;
+    fa.n_dense_rows = compact ? fa.dense_nf_end + dense_cold_f : fa.n_states;
+    const uint32_t chain_lo = fa.f2 - cold_chain;
     // Non-final states of trie depth <= 2 are a prefix of their id class (ids follow BFS order within a class):
     // [0, shallow_hot) and (trap, shallow_cold_end).  The exact walk of an anchor candidate stops on them (see
     // run_epilogue): no pattern begun at the candidate's window can still be alive there.
     {
-        std::vector<uint8_t> depth(ns, 0);
-        for (uint32_t i = 1; i < ns; ++i) {
-            const uint32_t u = order[i];
-            depth[u] = uint8_t(std::min<uint32_t>(depth[parent_[u]] + 1u, 255u));
-        }
         uint32_t sh = 0, sc = 0;
         for (uint32_t i = 0; i < ns; ++i) {
             const uint32_t u = order[i];
             if (is_final[u] || depth[u] > 2) continue;
-            if (i < hot) ++sh;
-            else if (!use_chains || !in_chain[u]) ++sc;
+            if (i < hot) ++sh; else ++sc;
         }
         fa.shallow_hot = sh;
         fa.shallow_cold_end = hot + 1 + sc;
@@ -285,12 +303,11 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
             const uint32_t u = order[i];
             if (i < hot) newid[u] = is_final[u] ? b++ : a++;
             else if (is_final[u]) newid[u] = d++;
-            else if (!use_chains || !in_chain[u]) newid[u] = c++;
+            else if (!compact || !in_chain[u]) newid[u] = c++;
         }
     }
-    fa.chain.clear();
     if (cold_chain) {
-        uint32_t c = fa.chain_lo;
+        uint32_t c = chain_lo;
         std::vector<uint32_t> stack{0};
         while (!stack.empty()) {  // trie preorder; children pushed in reverse so they pop in byte order
             const uint32_t u = stack.back();
@@ -298,19 +315,43 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
             if (in_chain[u]) newid[u] = c++;
             for (uint32_t e = child_off[u + 1]; e > child_off[u]; --e) stack.push_back(child_list[e - 1]);
         }
-        fa.chain.assign(cold_chain, 0xFFFFFFFFu);
-        for (uint32_t u = 0; u < ns; ++u) {
-            if (!in_chain[u]) continue;
-            const uint32_t v = child_list[child_off[u]];
-            fa.chain[newid[u] - fa.chain_lo] = (newid[v] << 8) | in_byte_[v];
-        }
     }
 
     // ---- tables ----------------------------------------------------------------------------------
     if (fa.entry_bytes == 2)
-        build_tables<uint16_t>(fa, order, fail, newid, child_off, child_list, in_byte_);
+        build_tables<uint16_t>(fa, order, dense, fail, newid, child_off, child_list, in_byte_);
     else
-        build_tables<uint32_t>(fa, order, fail, newid, child_off, child_list, in_byte_);
+        build_tables<uint32_t>(fa, order, dense, fail, newid, child_off, child_list, in_byte_);
+
+    // ---- compact records of the states without a dense row ------------------------------------------
+    fa.cold_rec.clear();
+    fa.cold_edges.clear();
+    if (compact) {
+        fa.cold_rec.assign(size_t(fa.n_states) * 2, 0u);
+        std::vector<uint32_t> tmp;
+        for (uint32_t i = dense; i < ns; ++i) {
+            const uint32_t u = order[i];
+            const uint32_t nk = child_off[u + 1] - child_off[u];
+            uint32_t x = 0, code = 0;
+            if (nk == 1) {
+                const uint32_t v = child_list[child_off[u]];
+                x = (newid[v] << 8) | in_byte_[v];
+                code = 1;
+            } else if (nk >= 2) {
+                tmp.clear();
+                for (uint32_t e = child_off[u]; e < child_off[u + 1]; ++e) {
+                    const uint32_t v = child_list[e];
+                    tmp.push_back((newid[v] << 8) | in_byte_[v]);
+                }
+                std::sort(tmp.begin(), tmp.end(), [](uint32_t p, uint32_t q) { return (p & 0xffu) < (q & 0xffu); });
+                x = uint32_t(fa.cold_edges.size());
+                if (nk >= 255) { code = 255; fa.cold_edges.push_back(nk); } else code = nk;
+                fa.cold_edges.insert(fa.cold_edges.end(), tmp.begin(), tmp.end());
+            }
+            fa.cold_rec[size_t(newid[u]) * 2] = x;
+            fa.cold_rec[size_t(newid[u]) * 2 + 1] = newid[fail[u]] | (code << 24);
+        }
+    }
 
     fa.own_pattern.assign(fa.n_states, kNone);
     fa.dict_link.assign(fa.n_states, kNone);
@@ -330,6 +371,7 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
     // ---- flat output lists (matched[] of the reference's nodes) ------------------------------------
     fa.out_off.clear();
     fa.out_list.clear();
+    fa.n_flat_outputs = 0;
     fa.max_out_count = 0;
     {
         uint64_t total = 0;
@@ -340,6 +382,7 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
         if (total <= opt.max_flat_outputs) {
             fa.out_off.assign(fa.n_states, 0);
             fa.out_list.resize(size_t(total) * 2);
+            fa.n_flat_outputs = total;
             uint32_t at = 0;
             for (uint32_t s = 0; s < fa.n_states; ++s) {
                 if (fa.out_count[s] == 0) continue;

@@ -36,8 +36,11 @@ struct PatternMeta {
 
 struct BuildOptions {
     uint32_t lds_bytes = 160 * 1024 - 512;  // budget for class table + hot tile
-    uint64_t max_table_bytes = 64ull << 30; // refuse automata whose table exceeds this
-    int cold_chains = 0;                    // chain[] for cold single-child states: 0 = never (default: measured no gain), 1 = always, -1 = when the table exceeds 16 MiB
+    uint64_t max_table_bytes = 8ull << 30;  // refuse automata whose dense table would exceed this (and that cannot go compact)
+    int compact = -1;                       // goto/failure records instead of dense rows for states outside the first
+                                            // BFS levels: 1 = always, 0 = never, -1 = when the dense table exceeds 64 MiB
+    uint64_t dense_bytes = 4ull << 20;      // compact: dense rows are kept for the LDS tile, every state of trie depth <= 1
+                                            // and further BFS-first states up to this many bytes of rows
     uint64_t max_flat_outputs = 1ull << 25; // flat output lists up to this many entries (256 MiB), else dictionary links only
 };
 
@@ -54,7 +57,23 @@ struct FlatAutomaton {
     uint32_t shallow_hot = 0;    // [0,shallow_hot) and (trap,shallow_cold_end): non-final states of trie depth <= 2
     uint32_t shallow_cold_end = 0;
     bool early_stop_useful = false;  // some 3-gram over the first-byte alphabet is not a trie path
-    uint32_t chain_lo = 0;       // [chain_lo,f2): cold non-final states with one trie child, in trie preorder (== f2: none)
+    // Compact form (BuildOptions::compact).  The reference keeps 88-byte nodes with sorted edge arrays and a failure
+    // pointer (node.h:37-67); a dense failure-free row per state is 1 KiB at 256 columns -- 2.3 GB for the
+    // 2.27 M states of a 64K-pattern set, every deep step of a walk a far-memory access.  Compact keeps dense rows
+    // for the first BFS levels only (where random text spends 99.9 % of its steps) and, for every other state, one
+    // 8-byte record {edge, failure}: states with one trie child (96 % of a big random set: the inside of a
+    // pattern) carry the edge in the record and are numbered along their pattern, so a walk down a pattern reads
+    // 16 states per 128-byte line; states with several children point into a sorted edge array.  A miss follows
+    // the failure link until it reaches a dense row -- the same transition function, computed the MultiFast way
+    // where that is cheap and by one lookup where it is hot.
+    uint32_t compact = 0;
+    uint32_t dense_nf_end = 0;   // dense rows exist for ids [0,dense_nf_end) (hot, trap, BFS-first cold non-final) ...
+    uint32_t dense_f_end = 0;    // ... and [f2,dense_f_end) (BFS-first cold final), the latter at row dense_nf_end + id - f2
+    uint32_t n_dense_rows = 0;   // rows in `table` (== n_states when not compact)
+    std::vector<uint32_t> cold_rec;    // compact: 2 words per state id {x, y}: y = failure id | code << 24;
+                                       //   code 0: no child; 1: x = child id << 8 | byte; 2..254: that many edges at
+                                       //   cold_edges[x..]; 255: cold_edges[x] = count, edges behind it
+    std::vector<uint32_t> cold_edges;  // child id << 8 | byte, ascending byte
     uint32_t class_mode = kClassTable;
     uint32_t swar_shift = 0;     // class = (byte >> shift) & 7 when byte is in the alphabet
     uint32_t swar_other = 0;     // column of every byte outside the alphabet
@@ -62,14 +81,14 @@ struct FlatAutomaton {
     uint32_t swar_expect_hi = 0; // expected byte of buckets 4..7
     uint32_t max_pattern_length = 0;
     uint32_t n_used_bytes = 0;
-    std::vector<uint8_t> table;      // n_states x n_columns entries, true transitions
+    uint64_t table_bytes = 0;        // size of `table` (kept when the host copy is released)
+    std::vector<uint8_t> table;      // n_dense_rows x n_columns entries, true transitions
     std::vector<uint8_t> lds_image;  // (trap+1) x n_columns entries, cold targets -> trap
     uint8_t class_of_byte[256] = {0};
     std::vector<uint32_t> own_pattern;  // per state
     std::vector<uint32_t> dict_link;    // per state: nearest failure ancestor owning a pattern
     std::vector<uint32_t> out_count;    // per state: records one event expands to
     std::vector<uint32_t> pattern_length;  // per caller-order pattern index
-    std::vector<uint32_t> chain;        // per state of [chain_lo,f2): child id << 8 | edge byte
     // The same output lists flattened the way the reference keeps them per node (matched[], node.h:49-51,
     // filled by node_collect_matches, node.c:424-441): entries out_off[s] .. out_off[s] + out_count[s] are
     // {pattern index, pattern length} of state s's event, longest first.  The dense-match drain reads them
@@ -77,6 +96,7 @@ struct FlatAutomaton {
     // when the lists would exceed BuildOptions::max_flat_outputs entries -- nested pattern families can square.
     std::vector<uint32_t> out_off;      // per state (valid where out_count > 0)
     std::vector<uint32_t> out_list;     // 2 words per entry: pattern, length
+    uint64_t n_flat_outputs = 0;        // entries of out_list (kept when the host copy is released)
     uint32_t max_out_count = 0;
 
     // ---- anchor filter (optional front end of the scan, see kernels.hip k_scan_anchor) ----
@@ -137,6 +157,16 @@ public:
     const std::vector<PatternMeta> &patterns() const { return patterns_; }
     const std::vector<uint8_t> &pattern_bytes() const { return pattern_bytes_; }
     const FlatAutomaton &flat() const { return flat_; }
+    // drop the host copies of the big arrays once they live on the device (acmi_debug_tables then has nothing to show)
+    void release_host_tables() {
+        std::vector<uint8_t>().swap(flat_.table);
+        std::vector<uint8_t>().swap(flat_.lds_image);
+        std::vector<uint32_t>().swap(flat_.cold_rec);
+        std::vector<uint32_t>().swap(flat_.cold_edges);
+        std::vector<uint32_t>().swap(flat_.out_list);
+        host_tables_released_ = true;
+    }
+    bool host_tables_released() const { return host_tables_released_; }
 
 private:
     uint32_t find_child(uint32_t node, uint8_t byte) const;
@@ -157,6 +187,7 @@ private:
     std::vector<uint8_t> pattern_bytes_;
     size_t accepted_ = 0;
     bool finalized_ = false;
+    bool host_tables_released_ = false;
     FlatAutomaton flat_;
 };
 

@@ -19,8 +19,12 @@ struct DevAutomaton {
     const uint32_t *out_off;     // per state: first entry of its flat output list (null: follow dict_link)
     const uint2 *out_list;       // {pattern, length}, longest first
     uint32_t max_out_count;      // longest output list
-    const uint32_t *chain;       // states [chain_lo,f2) (cold, non-final, one trie child): child << 8 | edge byte; null: none
-    uint32_t chain_lo;
+    // compact form (automaton.hpp): dense rows for ids [0,dense_nf_end) and [f2,dense_f_end) (the latter at row
+    // dense_nf_end + id - f2); every other state has a record {x, failure | code << 24} and maybe sorted edges
+    uint32_t compact;
+    uint32_t dense_nf_end, dense_f_end;
+    const uint2 *cold_rec;
+    const uint32_t *cold_edges;
     uint32_t shallow_hot, shallow_cold_end;  // non-final states of trie depth <= 2: [0,shallow_hot), (trap,shallow_cold_end)
     uint32_t early_stop;         // 1: walks of anchor candidates stop on them (run_epilogue)
     uint32_t class_identity;     // TABLE mode with 256 columns: class(byte) == byte

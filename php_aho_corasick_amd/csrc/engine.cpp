@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <unordered_set>
 #include <vector>
@@ -83,15 +85,17 @@ struct acmi_handle {
                           // 1 when the automaton can fall back to shallow states at all (default), 2 always
     int refill = 0;       // 0 automatic, 1 one thread per overflowed item (k_refill), 2 one wave (k_refill_wave)
     int profile = 0;
+    int keep_host_tables = 0;  // 1: the host copies of table / tile / records stay after the upload (acmi_debug_tables)
 
     // device state
     bool dev_ready = false;
+    bool dev_touched = false;  // some device resource may exist (ensure_device got as far as picking the device)
     int dev_id = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     DevAutomaton dA{};
-    DevBuf d_table, d_lds, d_class, d_own, d_dict, d_cnt, d_plen, d_anchor, d_bitmap, d_out_off, d_out_list, d_chain;
+    DevBuf d_table, d_lds, d_class, d_own, d_dict, d_cnt, d_plen, d_anchor, d_bitmap, d_out_off, d_out_list, d_cold_rec, d_cold_edges;
 
     // workspace (grow-only)
     DevBuf d_blob, d_off, d_nitems, d_item_base, d_item_hay, d_item_rec, d_zero, d_rec_base, d_slab, d_ovf, d_counters,
@@ -114,7 +118,7 @@ struct acmi_handle {
     bool fly_trivial = false;
 
     // statistics of the last call
-    double scan_ms = 0, total_ms = 0;
+    double scan_ms = 0, walk_ms = 0, total_ms = 0;
     int kernel_used = 0;
     uint64_t items = 0, chunk_used = 0;
     uint32_t overflow_items = 0;
@@ -177,10 +181,14 @@ int ensure_device(acmi_handle *h) {
         return ACMI_E_NO_DEVICE;
     }
     h->dev_id = dev;
-    HIPCHK(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->dev_touched = true;
+    // a call that fails further down (e.g. out of device memory for a large table) leaves dev_ready false and is
+    // retried by the next match call: create every resource once only
+    if (!h->own_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     if (!h->stream) h->stream = h->own_stream;
-    for (auto &evt : h->ev) HIPCHK(h, hipEventCreate(&evt));
-    HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->pinned), 64, hipHostMallocDefault));
+    for (auto &evt : h->ev)
+        if (!evt) HIPCHK(h, hipEventCreate(&evt));
+    if (!h->pinned) HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->pinned), 64, hipHostMallocDefault));
 
     // upload the flat automaton
     const FlatAutomaton &fa = h->aut.flat();
@@ -218,9 +226,12 @@ int ensure_device(acmi_handle *h) {
             HIPCHK(h, hipMemcpy(h->d_out_list.p, fa.out_list.data(), fa.out_list.size() * 4, hipMemcpyHostToDevice));
     }
 
-    if (!fa.chain.empty()) {
-        HIPCHK(h, h->d_chain.ensure(fa.chain.size() * 4));
-        HIPCHK(h, hipMemcpy(h->d_chain.p, fa.chain.data(), fa.chain.size() * 4, hipMemcpyHostToDevice));
+    if (fa.compact) {
+        HIPCHK(h, h->d_cold_rec.ensure(std::max<size_t>(8, fa.cold_rec.size() * 4)));
+        HIPCHK(h, hipMemcpy(h->d_cold_rec.p, fa.cold_rec.data(), fa.cold_rec.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(h, h->d_cold_edges.ensure(std::max<size_t>(8, fa.cold_edges.size() * 4)));
+        if (!fa.cold_edges.empty())
+            HIPCHK(h, hipMemcpy(h->d_cold_edges.p, fa.cold_edges.data(), fa.cold_edges.size() * 4, hipMemcpyHostToDevice));
     }
 
     if (fa.anchor_q) {
@@ -251,8 +262,11 @@ int ensure_device(acmi_handle *h) {
     A.out_off = fa.out_off.empty() ? nullptr : h->d_out_off.as<uint32_t>();
     A.out_list = fa.out_off.empty() ? nullptr : h->d_out_list.as<uint2>();
     A.max_out_count = fa.max_out_count;
-    A.chain = fa.chain.empty() ? nullptr : h->d_chain.as<uint32_t>();
-    A.chain_lo = fa.chain_lo;
+    A.compact = fa.compact;
+    A.dense_nf_end = fa.dense_nf_end;
+    A.dense_f_end = fa.dense_f_end;
+    A.cold_rec = fa.compact ? h->d_cold_rec.as<uint2>() : nullptr;
+    A.cold_edges = fa.compact ? h->d_cold_edges.as<uint32_t>() : nullptr;
     A.shallow_hot = fa.shallow_hot;
     A.shallow_cold_end = fa.shallow_cold_end;
     A.early_stop = (h->early_stop == 2 || (h->early_stop == 1 && fa.early_stop_useful)) ? 1u : 0u;
@@ -274,6 +288,9 @@ int ensure_device(acmi_handle *h) {
     A.swar_expect_hi = fa.swar_expect_hi;
     A.swar_other_off = fa.swar_other * fa.entry_bytes;
     h->dev_ready = true;
+    // the device has everything now; the host copies (up to GiBs for a dense table) are only of interest to
+    // acmi_debug_tables
+    if (!h->keep_host_tables) h->aut.release_host_tables();
     return ACMI_OK;
 }
 
@@ -302,7 +319,7 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
     // begin after this): a caller can enqueue the next scan first and ship the last result meanwhile.
     std::swap(h->d_out, h->d_out_alt);
     std::swap(h->d_prefix, h->d_prefix_alt);
-    h->scan_ms = h->total_ms = 0;
+    h->scan_ms = h->walk_ms = h->total_ms = 0;
     h->items = 0;
     h->overflow_items = 0;
     if (nh > 0xFFFFFFF0ull) { h->last_error = "too many haystacks"; return ACMI_E_TOO_LARGE; }
@@ -386,7 +403,7 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
     B.persistent = h->persistent >= 0 ? uint32_t(h->persistent != 0)
                                       : uint32_t(blob_bytes / chunk > 3ull * 256 * 1024 * uint64_t(h->ilp));
 
-    launch_item_base(d_off, uint32_t(nh), chunk, h->d_nitems.as<uint64_t>(), h->d_item_base.as<uint64_t>(), d_counters,
+    launch_item_base(d_off, uint32_t(nh), chunk, blob_bytes, h->d_nitems.as<uint64_t>(), h->d_item_base.as<uint64_t>(), d_counters,
                      h->d_scan_tmp.as<uint64_t>(), st);
 
     launch_build_items(B, max_items, st);
@@ -402,6 +419,7 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
     if (h->profile) HIPCHK(h, hipEventRecord(h->ev[2], st));
     // the anchor kernel only flags byte runs; their exact walk is a kernel of its own (one thread per item)
     if (kernel == 2) HIPCHK(h, launch_walk_runs(h->dA, B, max_items, int(fa.entry_bytes), int(fa.class_mode), st));
+    if (h->profile) HIPCHK(h, hipEventRecord(h->ev[3], st));
 
     if (!find_all) launch_first_only(B, st);
     exclusive_scan_u64(d_rec_cnt, h->d_rec_base.as<uint64_t>(), max_items + 1, h->d_scan_tmp.as<uint64_t>(), st);
@@ -439,7 +457,7 @@ int run_batch_end(acmi_handle *h) {
     }
     const FlatAutomaton &fa = h->aut.flat();
     if (reinterpret_cast<uint32_t *>(h->pinned)[6] != 0u) {
-        h->last_error = "offsets must be non-decreasing and every haystack shorter than 4 GiB";
+        h->last_error = "offsets must be non-decreasing, inside the blob, and every haystack shorter than 4 GiB";
         return ACMI_E_ARG;
     }
     const uint32_t n_ovf = h->fly_find_all ? reinterpret_cast<uint32_t *>(h->pinned)[0] : 0u;
@@ -457,6 +475,8 @@ int run_batch_end(acmi_handle *h) {
         float ms = 0;
         HIPCHK(h, hipEventElapsedTime(&ms, h->ev[1], h->ev[2]));
         h->scan_ms = ms;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev[2], h->ev[3]));
+        h->walk_ms = h->kernel_used == 2 ? ms : 0.0;
         HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[4]));
         h->total_ms = ms;
     }
@@ -543,231 +563,278 @@ int check_ready(acmi_handle *h) {
     return ensure_device(h);
 }
 
+// No C++ exception may cross the C ABI (the callers are ctypes, cgo-style FFIs and the Zend engine):
+// std::bad_alloc from the builder's vectors or the result buffers becomes ACMI_E_NOMEM, anything else
+// ACMI_E_DEVICE, with the text kept for acmi_last_error().
+template <typename F>
+int guarded(const acmi_handle *hc, F &&f) noexcept {
+    acmi_handle *h = const_cast<acmi_handle *>(hc);
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        try { if (live(h)) h->last_error = "out of host memory"; } catch (...) {}
+        return ACMI_E_NOMEM;
+    } catch (const std::exception &e) {
+        try { if (live(h)) h->last_error = std::string("internal error: ") + e.what(); } catch (...) {}
+        return ACMI_E_DEVICE;
+    } catch (...) {
+        return ACMI_E_DEVICE;
+    }
+}
+
 }  // namespace
 
 extern "C" {
 
 int acmi_create(int device, acmi_handle **out) {
-    if (!out) return ACMI_E_ARG;
-    acmi_handle *h = new (std::nothrow) acmi_handle();
-    if (!h) return ACMI_E_NOMEM;
-    h->device_request = device;
-    h->init_ok = 1;
-    {
-        std::lock_guard<std::mutex> g(g_live_mutex);
-        g_live.insert(h);
-    }
-    *out = h;
-    return ACMI_OK;
+    return guarded(nullptr, [&]() -> int {
+        if (!out) return ACMI_E_ARG;
+        acmi_handle *h = new (std::nothrow) acmi_handle();
+        if (!h) return ACMI_E_NOMEM;
+        h->device_request = device;
+        h->init_ok = 1;
+        {
+            std::lock_guard<std::mutex> g(g_live_mutex);
+            g_live.insert(h);
+        }
+        *out = h;
+        return ACMI_OK;
+    });
 }
 
 int acmi_add_patterns(acmi_handle *h, const acmi_pattern *patterns, size_t n, size_t *accepted) {
-    if (!live(h)) return ACMI_E_INVALID;
-    if (h->init_ok != 1) return ACMI_E_NOT_INIT;
-    if (h->aut.finalized()) return ACMI_E_FINALIZED;
-    if (n && !patterns) return ACMI_E_ARG;
-    std::vector<const uint8_t *> vals(n);
-    std::vector<uint32_t> lens(n), types(n);
-    std::vector<int64_t> ids(n);
-    std::vector<uint64_t> users(n);
-    for (size_t k = 0; k < n; ++k) {
-        if (patterns[k].length && !patterns[k].value) return ACMI_E_ARG;
-        vals[k] = patterns[k].value;
-        lens[k] = patterns[k].length;
-        types[k] = patterns[k].id_type;
-        ids[k] = patterns[k].id_number;
-        users[k] = patterns[k].user;
-    }
-    size_t acc = h->aut.add_batch(vals.data(), lens.data(), types.data(), ids.data(), users.data(), n);
-    if (accepted) *accepted = acc;
-    return ACMI_OK;
+    return guarded(h, [&]() -> int {
+        if (!live(h)) return ACMI_E_INVALID;
+        if (h->init_ok != 1) return ACMI_E_NOT_INIT;
+        if (h->aut.finalized()) return ACMI_E_FINALIZED;
+        if (n && !patterns) return ACMI_E_ARG;
+        std::vector<const uint8_t *> vals(n);
+        std::vector<uint32_t> lens(n), types(n);
+        std::vector<int64_t> ids(n);
+        std::vector<uint64_t> users(n);
+        for (size_t k = 0; k < n; ++k) {
+            if (patterns[k].length && !patterns[k].value) return ACMI_E_ARG;
+            vals[k] = patterns[k].value;
+            lens[k] = patterns[k].length;
+            types[k] = patterns[k].id_type;
+            ids[k] = patterns[k].id_number;
+            users[k] = patterns[k].user;
+        }
+        size_t acc = h->aut.add_batch(vals.data(), lens.data(), types.data(), ids.data(), users.data(), n);
+        if (accepted) *accepted = acc;
+        return ACMI_OK;
+    });
 }
 
 int acmi_finalize(acmi_handle *h) {
-    if (!live(h)) return ACMI_E_INVALID;
-    if (h->init_ok != 1) return ACMI_E_NOT_INIT;
-    return ensure_finalized(h);
+    return guarded(h, [&]() -> int {
+        if (!live(h)) return ACMI_E_INVALID;
+        if (h->init_ok != 1) return ACMI_E_NOT_INIT;
+        return ensure_finalized(h);
+    });
 }
 
 int acmi_is_valid(const acmi_handle *h) { return live(h) && h->init_ok == 1 ? 1 : 0; }
 
 int acmi_destroy(acmi_handle *h) {
-    {
-        std::lock_guard<std::mutex> g(g_live_mutex);
-        if (!h || !g_live.erase(h)) return ACMI_E_INVALID;
-    }
-    h->init_ok = 0;
-    if (h->dev_ready) {
-        (void)hipSetDevice(h->dev_id);
-        if (h->stream) (void)hipStreamSynchronize(h->stream);
-        for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_out_off, &h->d_out_list, &h->d_chain, &h->d_blob,
-                          &h->d_off, &h->d_nitems, &h->d_item_base, &h->d_item_hay, &h->d_item_rec, &h->d_zero,
-                          &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_scan_tmp, &h->d_prefix, &h->d_out, &h->d_runs, &h->d_run_count, &h->d_prefix_alt, &h->d_out_alt})
-            b->release();
-        for (auto &evt : h->ev)
-            if (evt) (void)hipEventDestroy(evt);
-        if (h->pinned) (void)hipHostFree(h->pinned);
-        if (h->pin_small) (void)hipHostFree(h->pin_small);
-        if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
-    }
-    delete h;
-    return ACMI_OK;
+    return guarded(h, [&]() -> int {
+        {
+            std::lock_guard<std::mutex> g(g_live_mutex);
+            if (!h || !g_live.erase(h)) return ACMI_E_INVALID;
+        }
+        h->init_ok = 0;
+        if (h->dev_touched) {  // also after a failed upload: release whatever was created
+            (void)hipSetDevice(h->dev_id);
+            if (h->stream) (void)hipStreamSynchronize(h->stream);
+            for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_out_off, &h->d_out_list, &h->d_cold_rec, &h->d_cold_edges, &h->d_blob,
+                              &h->d_off, &h->d_nitems, &h->d_item_base, &h->d_item_hay, &h->d_item_rec, &h->d_zero,
+                              &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_scan_tmp, &h->d_prefix, &h->d_out, &h->d_runs, &h->d_run_count, &h->d_prefix_alt, &h->d_out_alt})
+                b->release();
+            for (auto &evt : h->ev)
+                if (evt) (void)hipEventDestroy(evt);
+            if (h->pinned) (void)hipHostFree(h->pinned);
+            if (h->pin_small) (void)hipHostFree(h->pin_small);
+            if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+        }
+        delete h;
+        return ACMI_OK;
+    });
 }
 
 int acmi_match_batch_device(acmi_handle *h, const void *d_blob, uint64_t blob_bytes, const void *d_offsets,
                             size_t n_haystacks, int find_all, uint64_t *n_records) {
-    int rc = check_ready(h);
-    if (rc < 0) return rc;
-    if (n_haystacks && !d_offsets) return ACMI_E_ARG;
-    rc = run_batch(h, static_cast<const uint8_t *>(d_blob), blob_bytes, static_cast<const uint64_t *>(d_offsets),
-                   n_haystacks, find_all);
-    if (rc < 0) return rc;
-    if (n_records) *n_records = h->last_total;
-    return ACMI_OK;
+    return guarded(h, [&]() -> int {
+        int rc = check_ready(h);
+        if (rc < 0) return rc;
+        if (n_haystacks && !d_offsets) return ACMI_E_ARG;
+        rc = run_batch(h, static_cast<const uint8_t *>(d_blob), blob_bytes, static_cast<const uint64_t *>(d_offsets),
+                       n_haystacks, find_all);
+        if (rc < 0) return rc;
+        if (n_records) *n_records = h->last_total;
+        return ACMI_OK;
+    });
 }
 
 int acmi_match_batch_device_begin(acmi_handle *h, const void *d_blob, uint64_t blob_bytes, const void *d_offsets,
                                   size_t n_haystacks, int find_all) {
-    int rc = check_ready(h);
-    if (rc < 0) return rc;
-    if (n_haystacks && !d_offsets) return ACMI_E_ARG;
-    return run_batch_begin(h, static_cast<const uint8_t *>(d_blob), blob_bytes, static_cast<const uint64_t *>(d_offsets),
-                           n_haystacks, find_all);
+    return guarded(h, [&]() -> int {
+        int rc = check_ready(h);
+        if (rc < 0) return rc;
+        if (n_haystacks && !d_offsets) return ACMI_E_ARG;
+        return run_batch_begin(h, static_cast<const uint8_t *>(d_blob), blob_bytes, static_cast<const uint64_t *>(d_offsets),
+                               n_haystacks, find_all);
+    });
 }
 
 int acmi_match_batch_device_end(acmi_handle *h, uint64_t *n_records) {
-    if (!live(h)) return ACMI_E_INVALID;
-    HIPCHK(h, hipSetDevice(h->dev_id));
-    int rc = run_batch_end(h);
-    if (rc < 0) return rc;
-    if (n_records) *n_records = h->last_total;
-    return ACMI_OK;
+    return guarded(h, [&]() -> int {
+        if (!live(h)) return ACMI_E_INVALID;
+        HIPCHK(h, hipSetDevice(h->dev_id));
+        int rc = run_batch_end(h);
+        if (rc < 0) return rc;
+        if (n_records) *n_records = h->last_total;
+        return ACMI_OK;
+    });
 }
 
 int acmi_result_device(acmi_handle *h, const void **d_prefix, const void **d_records, uint64_t *n_records) {
-    if (!live(h)) return ACMI_E_INVALID;
-    if (!h->have_result) return ACMI_E_ARG;
-    if (d_prefix) *d_prefix = h->d_prefix.p;
-    if (d_records) *d_records = h->d_out.p;
-    if (n_records) *n_records = h->last_total;
-    return ACMI_OK;
+    return guarded(h, [&]() -> int {
+        if (!live(h)) return ACMI_E_INVALID;
+        if (!h->have_result) return ACMI_E_ARG;
+        if (d_prefix) *d_prefix = h->d_prefix.p;
+        if (d_records) *d_records = h->d_out.p;
+        if (n_records) *n_records = h->last_total;
+        return ACMI_OK;
+    });
 }
 
 int acmi_result_to_host(acmi_handle *h, uint64_t *prefix, acmi_record *records) {
-    if (!live(h)) return ACMI_E_INVALID;
-    if (!h->have_result) return ACMI_E_ARG;
-    HIPCHK(h, hipSetDevice(h->dev_id));
-    hipStream_t st = h->stream;
-    if (prefix) HIPCHK(h, hipMemcpyAsync(prefix, h->d_prefix.p, (size_t(h->last_nh) + 1) * 8, hipMemcpyDeviceToHost, st));
-    if (records && h->last_total)
-        HIPCHK(h, hipMemcpyAsync(records, h->d_out.p, h->last_total * sizeof(acmi_record), hipMemcpyDeviceToHost, st));
-    HIPCHK(h, hipStreamSynchronize(st));
-    return ACMI_OK;
+    return guarded(h, [&]() -> int {
+        if (!live(h)) return ACMI_E_INVALID;
+        if (!h->have_result) return ACMI_E_ARG;
+        HIPCHK(h, hipSetDevice(h->dev_id));
+        hipStream_t st = h->stream;
+        if (prefix) HIPCHK(h, hipMemcpyAsync(prefix, h->d_prefix.p, (size_t(h->last_nh) + 1) * 8, hipMemcpyDeviceToHost, st));
+        if (records && h->last_total)
+            HIPCHK(h, hipMemcpyAsync(records, h->d_out.p, h->last_total * sizeof(acmi_record), hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        return ACMI_OK;
+    });
 }
 
 int acmi_result_to_device(acmi_handle *h, void *d_prefix_dst, void *d_records_dst) {
-    if (!live(h)) return ACMI_E_INVALID;
-    if (!h->have_result) return ACMI_E_ARG;
-    HIPCHK(h, hipSetDevice(h->dev_id));
-    hipStream_t st = h->stream;
-    if (d_prefix_dst)
-        HIPCHK(h, hipMemcpyAsync(d_prefix_dst, h->d_prefix.p, (size_t(h->last_nh) + 1) * 8, hipMemcpyDeviceToDevice, st));
-    if (d_records_dst && h->last_total)
-        HIPCHK(h, hipMemcpyAsync(d_records_dst, h->d_out.p, h->last_total * sizeof(acmi_record), hipMemcpyDeviceToDevice, st));
-    HIPCHK(h, hipStreamSynchronize(st));
-    return ACMI_OK;
+    return guarded(h, [&]() -> int {
+        if (!live(h)) return ACMI_E_INVALID;
+        if (!h->have_result) return ACMI_E_ARG;
+        HIPCHK(h, hipSetDevice(h->dev_id));
+        hipStream_t st = h->stream;
+        if (d_prefix_dst)
+            HIPCHK(h, hipMemcpyAsync(d_prefix_dst, h->d_prefix.p, (size_t(h->last_nh) + 1) * 8, hipMemcpyDeviceToDevice, st));
+        if (d_records_dst && h->last_total)
+            HIPCHK(h, hipMemcpyAsync(d_records_dst, h->d_out.p, h->last_total * sizeof(acmi_record), hipMemcpyDeviceToDevice, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        return ACMI_OK;
+    });
 }
 
 int acmi_match_batch(acmi_handle *h, const uint8_t *blob, const uint64_t *offsets, size_t n_haystacks, int find_all,
                      const uint64_t **prefix, const acmi_record **records, size_t *n_records) {
-    int rc = check_ready(h);
-    if (rc < 0) return rc;
-    if (n_haystacks && !offsets) return ACMI_E_ARG;
-    uint64_t blob_bytes = 0;
-    if (n_haystacks) {
-        for (size_t k = 0; k < n_haystacks; ++k) {
-            if (offsets[k + 1] < offsets[k]) { h->last_error = "offsets must be non-decreasing"; return ACMI_E_ARG; }
-            if (offsets[k + 1] - offsets[k] >= 0xFFFFFFFFull) { h->last_error = "haystack of 4 GiB or more"; return ACMI_E_ARG; }
-        }
-        blob_bytes = offsets[n_haystacks];
-        if (blob_bytes && !blob) return ACMI_E_ARG;
-    }
-    if (n_haystacks) {
-        rc = run_small(h, blob, offsets, n_haystacks, find_all);
+    return guarded(h, [&]() -> int {
+        int rc = check_ready(h);
         if (rc < 0) return rc;
-        if (rc == ACMI_OK) {
-            if (prefix) *prefix = h->h_prefix.data();
-            if (records) *records = h->h_records.data();
-            if (n_records) *n_records = h->last_total;
-            return ACMI_OK;
+        if (n_haystacks && !offsets) return ACMI_E_ARG;
+        uint64_t blob_bytes = 0;
+        if (n_haystacks) {
+            for (size_t k = 0; k < n_haystacks; ++k) {
+                if (offsets[k + 1] < offsets[k]) { h->last_error = "offsets must be non-decreasing"; return ACMI_E_ARG; }
+                if (offsets[k + 1] - offsets[k] >= 0xFFFFFFFFull) { h->last_error = "haystack of 4 GiB or more"; return ACMI_E_ARG; }
+            }
+            blob_bytes = offsets[n_haystacks];
+            if (blob_bytes && !blob) return ACMI_E_ARG;
         }
-    }
-    hipStream_t st = h->stream;
-    // stage the borrowed host buffers (php_ahocorasick.c:725-727 borrows the zend_string)
-    HIPCHK(h, h->d_blob.ensure(blob_bytes + 64));
-    HIPCHK(h, h->d_off.ensure((n_haystacks + 1) * 8));
-    if (blob_bytes) HIPCHK(h, hipMemcpyAsync(h->d_blob.p, blob, blob_bytes, hipMemcpyHostToDevice, st));
-    if (n_haystacks) HIPCHK(h, hipMemcpyAsync(h->d_off.p, offsets, (n_haystacks + 1) * 8, hipMemcpyHostToDevice, st));
-    rc = run_batch(h, h->d_blob.as<uint8_t>(), blob_bytes, h->d_off.as<uint64_t>(), n_haystacks, find_all);
-    if (rc < 0) return rc;
-    // drain: device match buffer -> host records
-    h->h_prefix.assign(n_haystacks + 1, 0);
-    h->h_records.resize(h->last_total);
-    rc = acmi_result_to_host(h, h->h_prefix.data(), h->h_records.data());
-    if (rc < 0) return rc;
-    if (prefix) *prefix = h->h_prefix.data();
-    if (records) *records = h->h_records.data();
-    if (n_records) *n_records = h->last_total;
-    return ACMI_OK;
+        if (n_haystacks) {
+            rc = run_small(h, blob, offsets, n_haystacks, find_all);
+            if (rc < 0) return rc;
+            if (rc == ACMI_OK) {
+                if (prefix) *prefix = h->h_prefix.data();
+                if (records) *records = h->h_records.data();
+                if (n_records) *n_records = h->last_total;
+                return ACMI_OK;
+            }
+        }
+        hipStream_t st = h->stream;
+        // stage the borrowed host buffers (php_ahocorasick.c:725-727 borrows the zend_string)
+        HIPCHK(h, h->d_blob.ensure(blob_bytes + 64));
+        HIPCHK(h, h->d_off.ensure((n_haystacks + 1) * 8));
+        if (blob_bytes) HIPCHK(h, hipMemcpyAsync(h->d_blob.p, blob, blob_bytes, hipMemcpyHostToDevice, st));
+        if (n_haystacks) HIPCHK(h, hipMemcpyAsync(h->d_off.p, offsets, (n_haystacks + 1) * 8, hipMemcpyHostToDevice, st));
+        rc = run_batch(h, h->d_blob.as<uint8_t>(), blob_bytes, h->d_off.as<uint64_t>(), n_haystacks, find_all);
+        if (rc < 0) return rc;
+        // drain: device match buffer -> host records
+        h->h_prefix.assign(n_haystacks + 1, 0);
+        h->h_records.resize(h->last_total);
+        rc = acmi_result_to_host(h, h->h_prefix.data(), h->h_records.data());
+        if (rc < 0) return rc;
+        if (prefix) *prefix = h->h_prefix.data();
+        if (records) *records = h->h_records.data();
+        if (n_records) *n_records = h->last_total;
+        return ACMI_OK;
+    });
 }
 
 int acmi_match(acmi_handle *h, const uint8_t *text, size_t length, int find_all, const acmi_record **records,
                size_t *n_records) {
-    const uint64_t off[2] = {0, length};
-    if (length >= 0xFFFFFFFFull) return live(h) ? ACMI_E_ARG : ACMI_E_INVALID;
-    return acmi_match_batch(h, text, off, 1, find_all, nullptr, records, n_records);
+    return guarded(h, [&]() -> int {
+        const uint64_t off[2] = {0, length};
+        if (length >= 0xFFFFFFFFull) return live(h) ? ACMI_E_ARG : ACMI_E_INVALID;
+        return acmi_match_batch(h, text, off, 1, find_all, nullptr, records, n_records);
+    });
 }
 
 int acmi_stream_open(acmi_handle *h, acmi_stream **out) {
-    if (!live(h)) return ACMI_E_INVALID;
-    if (!out) return ACMI_E_ARG;
-    acmi_stream *s = new (std::nothrow) acmi_stream();
-    if (!s) return ACMI_E_NOMEM;
-    *out = s;
-    return ACMI_OK;
+    return guarded(h, [&]() -> int {
+        if (!live(h)) return ACMI_E_INVALID;
+        if (!out) return ACMI_E_ARG;
+        acmi_stream *s = new (std::nothrow) acmi_stream();
+        if (!s) return ACMI_E_NOMEM;
+        *out = s;
+        return ACMI_OK;
+    });
 }
 
 int acmi_stream_feed(acmi_handle *h, acmi_stream *s, const uint8_t *data, size_t length, const acmi_record **records,
                      size_t *n_records) {
-    int rc = check_ready(h);
-    if (rc < 0) return rc;
-    if (!s || (length && !data)) return ACMI_E_ARG;
-    if (s->base + length >= 0xFFFFFFFFull) { h->last_error = "stream of 4 GiB or more"; return ACMI_E_TOO_LARGE; }
-    const size_t carry = s->carry.size();
-    s->buf.resize(carry + length);
-    if (carry) std::memcpy(s->buf.data(), s->carry.data(), carry);
-    if (length) std::memcpy(s->buf.data() + carry, data, length);
-    const acmi_record *recs = nullptr;
-    size_t n = 0;
-    rc = acmi_match(h, s->buf.data(), s->buf.size(), 1, &recs, &n);
-    if (rc < 0) return rc;
-    // events that end inside the carry were reported by the feed that delivered those bytes
-    s->out.clear();
-    const uint32_t shift = uint32_t(s->base - carry);  // buffer offset -> stream offset
-    for (size_t i = 0; i < n; ++i) {
-        if (recs[i].pos <= carry) continue;
-        acmi_record r = recs[i];
-        r.pos += shift;
-        r.start += shift;
-        s->out.push_back(r);
-    }
-    s->base += length;
-    const uint32_t lmax = h->aut.flat().max_pattern_length;
-    const size_t keep = std::min<size_t>(lmax ? lmax - 1 : 0, s->buf.size());
-    s->carry.assign(s->buf.end() - keep, s->buf.end());
-    if (records) *records = s->out.data();
-    if (n_records) *n_records = s->out.size();
-    return ACMI_OK;
+    return guarded(h, [&]() -> int {
+        int rc = check_ready(h);
+        if (rc < 0) return rc;
+        if (!s || (length && !data)) return ACMI_E_ARG;
+        if (s->base + length >= 0xFFFFFFFFull) { h->last_error = "stream of 4 GiB or more"; return ACMI_E_TOO_LARGE; }
+        const size_t carry = s->carry.size();
+        s->buf.resize(carry + length);
+        if (carry) std::memcpy(s->buf.data(), s->carry.data(), carry);
+        if (length) std::memcpy(s->buf.data() + carry, data, length);
+        const acmi_record *recs = nullptr;
+        size_t n = 0;
+        rc = acmi_match(h, s->buf.data(), s->buf.size(), 1, &recs, &n);
+        if (rc < 0) return rc;
+        // events that end inside the carry were reported by the feed that delivered those bytes
+        s->out.clear();
+        const uint32_t shift = uint32_t(s->base - carry);  // buffer offset -> stream offset
+        for (size_t i = 0; i < n; ++i) {
+            if (recs[i].pos <= carry) continue;
+            acmi_record r = recs[i];
+            r.pos += shift;
+            r.start += shift;
+            s->out.push_back(r);
+        }
+        s->base += length;
+        const uint32_t lmax = h->aut.flat().max_pattern_length;
+        const size_t keep = std::min<size_t>(lmax ? lmax - 1 : 0, s->buf.size());
+        s->carry.assign(s->buf.end() - keep, s->buf.end());
+        if (records) *records = s->out.data();
+        if (n_records) *n_records = s->out.size();
+        return ACMI_OK;
+    });
 }
 
 uint64_t acmi_stream_position(const acmi_stream *s) { return s ? s->base : 0; }
@@ -777,175 +844,204 @@ void acmi_stream_close(acmi_stream *s) { delete s; }
 size_t acmi_pattern_count(const acmi_handle *h) { return live(h) ? h->aut.patterns().size() : 0; }
 
 int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out) {
-    if (!live(h)) return ACMI_E_INVALID;
-    if (!out || index >= h->aut.patterns().size()) return ACMI_E_ARG;
-    const PatternMeta &m = h->aut.patterns()[index];
-    out->value = h->aut.pattern_bytes().data() + m.byte_off;
-    out->length = m.length;
-    out->id_type = m.id_type;
-    out->id_number = m.id_number;
-    out->user = m.user;
-    return m.accepted ? 1 : 0;
+    return guarded(h, [&]() -> int {
+        if (!live(h)) return ACMI_E_INVALID;
+        if (!out || index >= h->aut.patterns().size()) return ACMI_E_ARG;
+        const PatternMeta &m = h->aut.patterns()[index];
+        out->value = h->aut.pattern_bytes().data() + m.byte_off;
+        out->length = m.length;
+        out->id_type = m.id_type;
+        out->id_number = m.id_number;
+        out->user = m.user;
+        return m.accepted ? 1 : 0;
+    });
 }
 
 int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
-    if (!live(h)) return ACMI_E_INVALID;
-    if (!key) return ACMI_E_ARG;
-    const std::string k(key);
-    if (k == "lds_bytes") {
-        if (h->aut.finalized()) return ACMI_E_FINALIZED;
-        if (value < 2048 || value > 160 * 1024 - 64) return ACMI_E_ARG;
-        h->bopt.lds_bytes = uint32_t(value);
-    } else if (k == "slab_events") {
-        if (value < 1 || value > 4096) return ACMI_E_ARG;
-        h->slab_events = uint32_t(value);
-    } else if (k == "run_cap") {
-        if (value < 1 || value > 1024) return ACMI_E_ARG;
-        h->run_cap = uint32_t(value);
-    } else if (k == "chunk_bytes") {
-        if (value < 0) return ACMI_E_ARG;
-        h->chunk_opt = uint64_t(value);
-    } else if (k == "kernel") {
-        if (value < 0 || value > 4) return ACMI_E_ARG;
-        h->kernel = int(value);
-        h->anchor_off = false;
-        h->exact_only = false;
-    } else if (k == "ilp") {
-        if (value != 1 && value != 2) return ACMI_E_ARG;
-        h->ilp = int(value);
-    } else if (k == "group_quads") {
-        if (value != 4 && value != 8) return ACMI_E_ARG;
-        h->group_quads = int(value);
-    } else if (k == "small_path") {
-        h->small_path = value ? 1 : 0;
-    } else if (k == "wave_items") {
-        if (value < 0 || value > 64) return ACMI_E_ARG;
-        h->wave_items = int(value);
-    } else if (k == "persistent") {
-        h->persistent = value < 0 ? -1 : (value ? 1 : 0);
-    } else if (k == "walk_group") {
-        if (value != 1 && value != 4 && value != 8) return ACMI_E_ARG;
-        h->walk_group = int(value);
-    } else if (k == "early_stop") {
-        if (value < 0 || value > 2) return ACMI_E_ARG;
-        h->early_stop = int(value);
-        if (h->aut.finalized())
-            h->dA.early_stop = (value == 2 || (value == 1 && h->aut.flat().early_stop_useful)) ? 1u : 0u;
-    } else if (k == "refill") {
-        if (value < 0 || value > 2) return ACMI_E_ARG;
-        h->refill = int(value);
-    } else if (k == "profile") {
-        h->profile = value ? 1 : 0;
-    } else if (k == "cold_chains") {
-        if (h->aut.finalized()) return ACMI_E_FINALIZED;
-        h->bopt.cold_chains = value < 0 ? -1 : (value ? 1 : 0);
-    } else if (k == "max_flat_outputs") {
-        if (h->aut.finalized()) return ACMI_E_FINALIZED;
-        if (value < 0) return ACMI_E_ARG;
-        h->bopt.max_flat_outputs = uint64_t(value);
-    } else if (k == "max_table_bytes") {
-        if (h->aut.finalized()) return ACMI_E_FINALIZED;
-        if (value < 1024) return ACMI_E_ARG;
-        h->bopt.max_table_bytes = uint64_t(value);
-    } else {
-        return ACMI_E_ARG;
-    }
-    return ACMI_OK;
+    return guarded(h, [&]() -> int {
+        if (!live(h)) return ACMI_E_INVALID;
+        if (!key) return ACMI_E_ARG;
+        const std::string k(key);
+        if (k == "lds_bytes") {
+            if (h->aut.finalized()) return ACMI_E_FINALIZED;
+            if (value < 2048 || value > 160 * 1024 - 64) return ACMI_E_ARG;
+            h->bopt.lds_bytes = uint32_t(value);
+        } else if (k == "slab_events") {
+            if (value < 1 || value > 4096) return ACMI_E_ARG;
+            h->slab_events = uint32_t(value);
+        } else if (k == "run_cap") {
+            if (value < 1 || value > 1024) return ACMI_E_ARG;
+            h->run_cap = uint32_t(value);
+        } else if (k == "chunk_bytes") {
+            if (value < 0) return ACMI_E_ARG;
+            h->chunk_opt = uint64_t(value);
+        } else if (k == "kernel") {
+            if (value < 0 || value > 4) return ACMI_E_ARG;
+            h->kernel = int(value);
+            h->anchor_off = false;
+            h->exact_only = false;
+        } else if (k == "ilp") {
+            if (value != 1 && value != 2) return ACMI_E_ARG;
+            h->ilp = int(value);
+        } else if (k == "group_quads") {
+            if (value != 4 && value != 8) return ACMI_E_ARG;
+            h->group_quads = int(value);
+        } else if (k == "small_path") {
+            h->small_path = value ? 1 : 0;
+        } else if (k == "wave_items") {
+            if (value < 0 || value > 64) return ACMI_E_ARG;
+            h->wave_items = int(value);
+        } else if (k == "persistent") {
+            h->persistent = value < 0 ? -1 : (value ? 1 : 0);
+        } else if (k == "walk_group") {
+            if (value != 1 && value != 4 && value != 8) return ACMI_E_ARG;
+            h->walk_group = int(value);
+        } else if (k == "early_stop") {
+            if (value < 0 || value > 2) return ACMI_E_ARG;
+            h->early_stop = int(value);
+            if (h->aut.finalized())
+                h->dA.early_stop = (value == 2 || (value == 1 && h->aut.flat().early_stop_useful)) ? 1u : 0u;
+        } else if (k == "refill") {
+            if (value < 0 || value > 2) return ACMI_E_ARG;
+            h->refill = int(value);
+        } else if (k == "profile") {
+            h->profile = value ? 1 : 0;
+        } else if (k == "compact") {
+            if (h->aut.finalized()) return ACMI_E_FINALIZED;
+            h->bopt.compact = value < 0 ? -1 : (value ? 1 : 0);
+        } else if (k == "dense_bytes") {
+            if (h->aut.finalized()) return ACMI_E_FINALIZED;
+            if (value < 0) return ACMI_E_ARG;
+            h->bopt.dense_bytes = uint64_t(value);
+        } else if (k == "keep_host_tables") {
+            h->keep_host_tables = value ? 1 : 0;
+        } else if (k == "max_flat_outputs") {
+            if (h->aut.finalized()) return ACMI_E_FINALIZED;
+            if (value < 0) return ACMI_E_ARG;
+            h->bopt.max_flat_outputs = uint64_t(value);
+        } else if (k == "max_table_bytes") {
+            if (h->aut.finalized()) return ACMI_E_FINALIZED;
+            if (value < 1024) return ACMI_E_ARG;
+            h->bopt.max_table_bytes = uint64_t(value);
+        } else {
+            return ACMI_E_ARG;
+        }
+        return ACMI_OK;
+    });
 }
 
 int acmi_get_stat(const acmi_handle *h, const char *key, double *value) {
-    if (!live(h)) return ACMI_E_INVALID;
-    if (!key || !value) return ACMI_E_ARG;
-    const std::string k(key);
-    const FlatAutomaton &fa = h->aut.flat();
-    if (k == "nodes") *value = double(h->aut.node_count());
-    else if (k == "accepted") *value = double(h->aut.accepted_count());
-    else if (k == "patterns") *value = double(h->aut.patterns().size());
-    else if (k == "states") *value = fa.n_states;
-    else if (k == "hot_states") *value = fa.trap;
-    else if (k == "columns") *value = fa.n_columns;
-    else if (k == "entry_bytes") *value = fa.entry_bytes;
-    else if (k == "class_mode") *value = fa.class_mode;
-    else if (k == "lds_image_bytes") *value = double(fa.lds_image.size() + (fa.class_mode == kClassTable ? 512 : 0));
-    else if (k == "table_bytes") *value = double(fa.table.size());
-    else if (k == "max_pattern_length") *value = fa.max_pattern_length;
-    else if (k == "used_bytes") *value = fa.n_used_bytes;
-    else if (k == "items") *value = double(h->items);
-    else if (k == "chunk_bytes") *value = double(h->chunk_used);
-    else if (k == "overflow_items") *value = h->overflow_items;
-    else if (k == "walked_bytes") *value = double(h->walked_bytes);
-    else if (k == "scan_ms") *value = h->scan_ms;
-    else if (k == "kernel_used") *value = h->kernel_used;
-    else if (k == "anchor_q") *value = fa.anchor_q;
-    else if (k == "anchor_keys") *value = fa.anchor_keys;
-    else if (k == "anchor_mode") *value = fa.anchor_mode;
-    else if (k == "min_pattern_length") *value = fa.min_pattern_length;
-    else if (k == "total_ms") *value = h->total_ms;
-    else if (k == "records") *value = double(h->last_total);
-    else if (k == "flat_outputs") *value = double(fa.out_list.size() / 2);
-    else if (k == "max_out_count") *value = fa.max_out_count;
-    else if (k == "chain_states") *value = double(fa.chain.size());
-    else return ACMI_E_ARG;
-    return ACMI_OK;
+    return guarded(h, [&]() -> int {
+        if (!live(h)) return ACMI_E_INVALID;
+        if (!key || !value) return ACMI_E_ARG;
+        const std::string k(key);
+        const FlatAutomaton &fa = h->aut.flat();
+        if (k == "nodes") *value = double(h->aut.node_count());
+        else if (k == "accepted") *value = double(h->aut.accepted_count());
+        else if (k == "patterns") *value = double(h->aut.patterns().size());
+        else if (k == "finalized") *value = h->aut.finalized() ? 1 : 0;
+        else if (k == "states") *value = fa.n_states;
+        else if (k == "hot_states") *value = fa.trap;
+        else if (k == "columns") *value = fa.n_columns;
+        else if (k == "entry_bytes") *value = fa.entry_bytes;
+        else if (k == "class_mode") *value = fa.class_mode;
+        else if (k == "lds_image_bytes") *value = double(fa.lds_image.size() + (fa.class_mode == kClassTable ? 512 : 0));
+        else if (k == "table_bytes") *value = double(fa.table_bytes);
+        else if (k == "automaton_bytes") *value = double(fa.table_bytes + (fa.compact ? uint64_t(fa.n_states) * 8 : 0));
+        else if (k == "max_pattern_length") *value = fa.max_pattern_length;
+        else if (k == "used_bytes") *value = fa.n_used_bytes;
+        else if (k == "items") *value = double(h->items);
+        else if (k == "chunk_bytes") *value = double(h->chunk_used);
+        else if (k == "overflow_items") *value = h->overflow_items;
+        else if (k == "walked_bytes") *value = double(h->walked_bytes);
+        else if (k == "scan_ms") *value = h->scan_ms;
+        else if (k == "walk_ms") *value = h->walk_ms;
+        else if (k == "kernel_used") *value = h->kernel_used;
+        else if (k == "anchor_q") *value = fa.anchor_q;
+        else if (k == "anchor_keys") *value = fa.anchor_keys;
+        else if (k == "anchor_mode") *value = fa.anchor_mode;
+        else if (k == "min_pattern_length") *value = fa.min_pattern_length;
+        else if (k == "total_ms") *value = h->total_ms;
+        else if (k == "records") *value = double(h->last_total);
+        else if (k == "flat_outputs") *value = double(fa.n_flat_outputs);
+        else if (k == "max_out_count") *value = fa.max_out_count;
+        else if (k == "compact") *value = fa.compact;
+        else if (k == "dense_rows") *value = fa.n_dense_rows;
+        else if (k == "cold_edges") *value = double(fa.cold_edges.size());
+        else return ACMI_E_ARG;
+        return ACMI_OK;
+    });
 }
 
 int acmi_set_stream(acmi_handle *h, void *hip_stream) {
-    if (!live(h)) return ACMI_E_INVALID;
-    h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
-    return ACMI_OK;
+    return guarded(h, [&]() -> int {
+        if (!live(h)) return ACMI_E_INVALID;
+        h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+        return ACMI_OK;
+    });
 }
 
 int acmi_debug_tables(const acmi_handle *h, acmi_tables *out) {
-    if (!live(h)) return ACMI_E_INVALID;
-    if (!out || !h->aut.finalized()) return ACMI_E_ARG;
-    const FlatAutomaton &fa = h->aut.flat();
-    out->n_states = fa.n_states;
-    out->n_columns = fa.n_columns;
-    out->entry_bytes = fa.entry_bytes;
-    out->first_hot_final = fa.f1;
-    out->trap = fa.trap;
-    out->first_cold_final = fa.f2;
-    out->class_mode = fa.class_mode;
-    out->swar_shift = fa.swar_shift;
-    out->swar_other = fa.swar_other;
-    out->max_pattern_length = fa.max_pattern_length;
-    out->table = fa.table.data();
-    out->lds_image = fa.lds_image.data();
-    out->class_of_byte = fa.class_of_byte;
-    out->own_pattern = fa.own_pattern.data();
-    out->dict_link = fa.dict_link.data();
-    out->out_count = fa.out_count.data();
-    out->anchor_q = fa.anchor_q;
-    out->anchor_mul = fa.anchor_mul;
-    out->min_pattern_length = fa.min_pattern_length;
-    out->anchor_keys = fa.anchor_keys;
-    out->anchor_mode = fa.anchor_mode;
-    out->anchor_bucket_bits = fa.anchor_bucket_bits;
-    out->anchor_bitmap = fa.anchor_mode == 2 ? fa.anchor_bitmap.data() : nullptr;
-    out->anchor_table = fa.anchor_q ? fa.anchor_table.data() : nullptr;
-    out->chain_lo = fa.chain_lo;
-    out->n_flat_outputs = uint32_t(fa.out_list.size() / 2);
-    out->chain = fa.chain.empty() ? nullptr : fa.chain.data();
-    out->out_off = fa.out_off.empty() ? nullptr : fa.out_off.data();
-    out->out_list = fa.out_list.empty() ? nullptr : fa.out_list.data();
-    return ACMI_OK;
+    return guarded(h, [&]() -> int {
+        if (!live(h)) return ACMI_E_INVALID;
+        if (!out || !h->aut.finalized()) return ACMI_E_ARG;
+        if (h->aut.host_tables_released()) return ACMI_E_ARG;  // uploaded and dropped: set "keep_host_tables" before the first match
+        const FlatAutomaton &fa = h->aut.flat();
+        out->n_states = fa.n_states;
+        out->n_columns = fa.n_columns;
+        out->entry_bytes = fa.entry_bytes;
+        out->first_hot_final = fa.f1;
+        out->trap = fa.trap;
+        out->first_cold_final = fa.f2;
+        out->class_mode = fa.class_mode;
+        out->swar_shift = fa.swar_shift;
+        out->swar_other = fa.swar_other;
+        out->max_pattern_length = fa.max_pattern_length;
+        out->table = fa.table.data();
+        out->lds_image = fa.lds_image.data();
+        out->class_of_byte = fa.class_of_byte;
+        out->own_pattern = fa.own_pattern.data();
+        out->dict_link = fa.dict_link.data();
+        out->out_count = fa.out_count.data();
+        out->anchor_q = fa.anchor_q;
+        out->anchor_mul = fa.anchor_mul;
+        out->min_pattern_length = fa.min_pattern_length;
+        out->anchor_keys = fa.anchor_keys;
+        out->anchor_mode = fa.anchor_mode;
+        out->anchor_bucket_bits = fa.anchor_bucket_bits;
+        out->anchor_bitmap = fa.anchor_mode == 2 ? fa.anchor_bitmap.data() : nullptr;
+        out->anchor_table = fa.anchor_q ? fa.anchor_table.data() : nullptr;
+        out->compact = fa.compact;
+        out->dense_nf_end = fa.dense_nf_end;
+        out->dense_f_end = fa.dense_f_end;
+        out->n_dense_rows = fa.n_dense_rows;
+        out->n_cold_edges = uint32_t(fa.cold_edges.size());
+        out->cold_rec = fa.cold_rec.empty() ? nullptr : fa.cold_rec.data();
+        out->cold_edges = fa.cold_edges.empty() ? nullptr : fa.cold_edges.data();
+        out->n_flat_outputs = uint32_t(fa.out_list.size() / 2);
+        out->out_off = fa.out_off.empty() ? nullptr : fa.out_off.data();
+        out->out_list = fa.out_list.empty() ? nullptr : fa.out_list.data();
+        return ACMI_OK;
+    });
 }
 
 int acmi_debug_stream_read(acmi_handle *h, const void *d_src, uint64_t bytes, int repeats, double *ms_per_pass) {
-    int rc = check_ready(h);
-    if (rc < 0) return rc;
-    if (!d_src || bytes < 16 || repeats < 1 || !ms_per_pass) return ACMI_E_ARG;
-    HIPCHK(h, h->d_counters.ensure(64));
-    hipStream_t st = h->stream;
-    launch_stream_read(d_src, bytes, h->d_counters.as<uint32_t>(), st);  // warm-up
-    HIPCHK(h, hipEventRecord(h->ev[0], st));
-    for (int i = 0; i < repeats; ++i) launch_stream_read(d_src, bytes, h->d_counters.as<uint32_t>(), st);
-    HIPCHK(h, hipEventRecord(h->ev[1], st));
-    HIPCHK(h, hipEventSynchronize(h->ev[1]));
-    float ms = 0;
-    HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
-    *ms_per_pass = double(ms) / repeats;
-    return ACMI_OK;
+    return guarded(h, [&]() -> int {
+        int rc = check_ready(h);
+        if (rc < 0) return rc;
+        if (!d_src || bytes < 16 || repeats < 1 || !ms_per_pass) return ACMI_E_ARG;
+        HIPCHK(h, h->d_counters.ensure(64));
+        hipStream_t st = h->stream;
+        launch_stream_read(d_src, bytes, h->d_counters.as<uint32_t>(), st);  // warm-up
+        HIPCHK(h, hipEventRecord(h->ev[0], st));
+        for (int i = 0; i < repeats; ++i) launch_stream_read(d_src, bytes, h->d_counters.as<uint32_t>(), st);
+        HIPCHK(h, hipEventRecord(h->ev[1], st));
+        HIPCHK(h, hipEventSynchronize(h->ev[1]));
+        float ms = 0;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+        *ms_per_pass = double(ms) / repeats;
+        return ACMI_OK;
+    });
 }
 
 const char *acmi_strerror(int status) {

@@ -157,6 +157,40 @@ __device__ __forceinline__ void finish_item(const BatchArgs &B, uint64_t item) {
     if (B.ev_count[item] > B.slab_events) B.overflow_list[atomicAdd(&B.counters[0], 1u)] = uint32_t(item);
 }
 
+// One transition from a state whose row is not in LDS: the dense global table, or -- compact automata -- the
+// goto / failure records of the states that have no dense row (ahocorasick.c:199-211 does the same walk per byte:
+// edge search, else failure link; here it only happens below the first trie levels, where text rarely is, and it
+// ends on the first dense row, whose entry already has the rest of the failure chain folded in).
+template <typename E>
+__device__ __forceinline__ uint32_t cold_step(const DevAutomaton &A, uint32_t s, uint32_t byte, uint32_t coff) {
+    const uint8_t *table = static_cast<const uint8_t *>(A.table);
+    if (!A.compact) return *reinterpret_cast<const E *>(table + uint64_t(s) * A.row_bytes + coff);
+    for (;;) {
+        if (s < A.dense_nf_end) return *reinterpret_cast<const E *>(table + uint64_t(s) * A.row_bytes + coff);
+        if (s >= A.f2 && s < A.dense_f_end)
+            return *reinterpret_cast<const E *>(table + uint64_t(A.dense_nf_end + (s - A.f2)) * A.row_bytes + coff);
+        const uint2 r = A.cold_rec[s];
+        const uint32_t code = r.y >> 24;
+        if (code == 1u) {  // one trie child: the inside of a pattern
+            if ((r.x & 0xffu) == byte) return r.x >> 8;
+        } else if (code >= 2u) {  // several: sorted by byte
+            const uint32_t *e = A.cold_edges + r.x;
+            uint32_t n = code;
+            if (code == 255u) n = *e++;
+            uint32_t lo = 0, hi = n;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if ((e[mid] & 0xffu) < byte) lo = mid + 1; else hi = mid;
+            }
+            if (lo < n) {
+                const uint32_t w = e[lo];
+                if ((w & 0xffu) == byte) return w >> 8;
+            }
+        }
+        s = r.y & 0xFFFFFFu;  // failure link: strictly shallower, the root's row is dense
+    }
+}
+
 // One exact transition.  `tile` (LDS) may be null; hot rows are read from it unless the
 // stored target is the trap row, which stands for "the real target is cold".
 template <typename E>
@@ -167,7 +201,7 @@ __device__ __forceinline__ uint32_t exact_step(const DevAutomaton &A, const uint
         const uint32_t w = *reinterpret_cast<const E *>(tile + s * A.row_bytes + coff);
         if (w < A.trap) return w;
     }
-    return *reinterpret_cast<const E *>(static_cast<const uint8_t *>(A.table) + uint64_t(s) * A.row_bytes + coff);
+    return cold_step<E>(A, s, byte, coff);
 }
 
 // Walk bytes [j0, j1) of a stream one by one with full semantics (events, cold states).
@@ -186,15 +220,16 @@ __device__ __forceinline__ uint32_t exact_bytes(const DevAutomaton &A, const Bat
 // ------------------------------------------------------------------------------------------
 // k_count_items: work items per haystack
 // ------------------------------------------------------------------------------------------
-// Also validates what the host cannot see for device-resident offsets: decreasing offsets or a
-// haystack of 4 GiB or more (positions are 32-bit) raise counters[6], and that haystack gets no item.
-__global__ void k_count_items(const uint64_t *offsets, uint32_t nh, uint32_t chunk, uint64_t *n_items,
+// Also validates what the host cannot see for device-resident offsets: decreasing offsets, a haystack of
+// 4 GiB or more (positions are 32-bit) or one that ends past the blob (every per-item workspace is sized
+// from blob_bytes) raise counters[6], and that haystack gets no item.
+__global__ void k_count_items(const uint64_t *offsets, uint32_t nh, uint32_t chunk, uint64_t blob_bytes, uint64_t *n_items,
                               uint32_t *counters) {
     const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h > nh) return;
     if (h == nh) { n_items[h] = 0; return; }
     const uint64_t lo = offsets[h], hi = offsets[h + 1];
-    if (hi < lo || hi - lo >= 0xFFFFFFFFull) {
+    if (hi < lo || hi - lo >= 0xFFFFFFFFull || hi > blob_bytes) {
         counters[6] = 1u;
         n_items[h] = 0;
         return;
@@ -286,6 +321,7 @@ struct ScanSource {
     const uint64_t *offsets;   // COUNT: haystack offsets (n = n_haystacks + 1 elements, the last one 0)
     uint32_t chunk;
     uint32_t *counters;        // COUNT: counters[6] = 1 on a malformed offset
+    uint64_t blob_bytes;       // COUNT: no haystack may end past the blob
 };
 
 template <bool COUNT>
@@ -294,7 +330,7 @@ __device__ __forceinline__ uint64_t scan_element(const ScanSource &S, uint64_t i
     if (!COUNT) return S.in[i];
     if (i + 1 == n) return 0;  // element n_haystacks: sentinel
     const uint64_t lo = S.offsets[i], hi = S.offsets[i + 1];
-    if (hi < lo || hi - lo >= 0xFFFFFFFFull) {
+    if (hi < lo || hi - lo >= 0xFFFFFFFFull || hi > S.blob_bytes) {
         S.counters[6] = 1u;
         return 0;
     }
@@ -376,7 +412,7 @@ static void scan_two_launch(const ScanSource &S, uint64_t *out, uint64_t n, uint
 void exclusive_scan_u64(const uint64_t *in, uint64_t *out, uint64_t n, uint64_t *temp, hipStream_t st) {
     if (n == 0) return;
     if ((n + kScanTile - 1) / kScanTile <= kScanMaxTiles) {
-        scan_two_launch<false>(ScanSource{in, nullptr, 0u, nullptr}, out, n, temp, st);
+        scan_two_launch<false>(ScanSource{in, nullptr, 0u, nullptr, 0ull}, out, n, temp, st);
         return;
     }
     exclusive_scan_recursive(in, out, n, temp, st);
@@ -384,14 +420,14 @@ void exclusive_scan_u64(const uint64_t *in, uint64_t *out, uint64_t n, uint64_t 
 
 // item_base[h] = first work item of haystack h, h = 0..nh (item_base[nh] = number of items): item counts
 // from the offsets and their exclusive scan.  `n_items` is scratch for the general (recursive) form.
-void launch_item_base(const uint64_t *offsets, uint32_t nh, uint32_t chunk, uint64_t *n_items, uint64_t *item_base,
-                      uint32_t *counters, uint64_t *temp, hipStream_t st) {
+void launch_item_base(const uint64_t *offsets, uint32_t nh, uint32_t chunk, uint64_t blob_bytes, uint64_t *n_items,
+                      uint64_t *item_base, uint32_t *counters, uint64_t *temp, hipStream_t st) {
     const uint64_t n = uint64_t(nh) + 1;
     if ((n + kScanTile - 1) / kScanTile <= kScanMaxTiles) {
-        scan_two_launch<true>(ScanSource{nullptr, offsets, chunk, counters}, item_base, n, temp, st);
+        scan_two_launch<true>(ScanSource{nullptr, offsets, chunk, counters, blob_bytes}, item_base, n, temp, st);
         return;
     }
-    hipLaunchKernelGGL(k_count_items, dim3((nh + 1 + 255) / 256), dim3(256), 0, st, offsets, nh, chunk, n_items, counters);
+    hipLaunchKernelGGL(k_count_items, dim3((nh + 1 + 255) / 256), dim3(256), 0, st, offsets, nh, chunk, blob_bytes, n_items, counters);
     exclusive_scan_recursive(n_items, item_base, n, temp, st);
 }
 
@@ -543,8 +579,8 @@ struct EventRegs {
     uint32_t n_ev;
 };
 
-// EXTRA compiles in what only some automata use -- chain words for cold single-child states, the early stop of
-// single-window anchor runs: without them the headline's k_walk_runs takes 65 us, with the tests in the loop 72.
+// EXTRA compiles in what only some automata use -- the early stop of single-window anchor runs: without it the
+// headline's k_walk_runs takes 65 us, with the test in the loop 72.
 // Exact walk of bytes [j0, j1) of one item: hot rows from the LDS tile when one is resident
 // (`tile`), everything else from the global table; haystack bytes by aligned dword loads.
 // Reports (records an event) for final states at byte index j >= rep_from, at position
@@ -578,16 +614,7 @@ __device__ __forceinline__ uint32_t exact_range(const DevAutomaton &A, const Bat
         const uint32_t coff = class_offset<E, MODE>(A, cls_lds, byte);
         uint32_t w = A.trap;
         if (s < tile_rows) w = *reinterpret_cast<const E *>(tile + s * A.row_bytes + coff);  // LDS-resident row
-        if (w >= A.trap) {
-            // cold row.  Inside a long pattern the state has one trie child: its edge is in chain[], which is
-            // laid out along the pattern (32 steps per 128-byte line; the table costs one line per step)
-            uint32_t cw = 0xFFFFFFFFu;
-            if (EXTRA && A.chain != nullptr && s >= A.chain_lo && s < A.f2) cw = A.chain[s - A.chain_lo];
-            if ((cw & 0xffu) == byte && cw != 0xFFFFFFFFu)
-                w = cw >> 8;
-            else
-                w = *reinterpret_cast<const E *>(static_cast<const uint8_t *>(A.table) + uint64_t(s) * A.row_bytes + coff);
-        }
+        if (w >= A.trap) w = cold_step<E>(A, s, byte, coff);  // row not in LDS
         s = w;
         if (j >= rep_from && is_final(A, s) && !(B.first_only && ev.n_ev)) {
             ev.n_rec += A.out_count[s];
@@ -1296,7 +1323,7 @@ hipError_t launch_walk_runs(const DevAutomaton &A, const BatchArgs &B, uint64_t 
         hipLaunchKernelGGL(fn, dim3(blocks), dim3(kWalkThreads), lds, st, A, B);
         return hipGetLastError();
     };
-    const bool extra = A.chain != nullptr || A.early_stop != 0u;
+    const bool extra = A.early_stop != 0u;
 #define ACMI_WALK_RUNS(E, M) (extra ? go(k_walk_runs<E, M, true>) : go(k_walk_runs<E, M, false>))
     if (entry_bytes == 2) return class_mode == 1 ? ACMI_WALK_RUNS(uint16_t, 1) : ACMI_WALK_RUNS(uint16_t, 0);
     return class_mode == 1 ? ACMI_WALK_RUNS(uint32_t, 1) : ACMI_WALK_RUNS(uint32_t, 0);
@@ -1351,14 +1378,13 @@ __global__ __launch_bounds__(kWalkThreads, (LB <= 4 ? 8 : 4)) void k_walk_items(
     const uint32_t n = rec.z;  // 0 for threads past the last item
     const uint8_t *p = B.blob + (n ? it.begin - it.warm : 0);
     const uint32_t warm = it.warm, pos_bias = it.pos0 - it.warm + 1u;
-    const uint8_t *table = static_cast<const uint8_t *>(A.table);
     uint32_t st = 0;
     EventRegs ev{0, 0};
     auto step = [&](uint32_t byte, uint32_t jj) __attribute__((always_inline)) {
         const uint32_t coff = class_offset<E, MODE>(A, cls_lds, byte);
         uint32_t w = A.trap;
         if (st < tile_rows) w = *reinterpret_cast<const E *>(tile + __umul24(st, A.row_bytes) + coff);
-        if (w >= A.trap) w = *reinterpret_cast<const E *>(table + uint64_t(st) * A.row_bytes + coff);
+        if (w >= A.trap) w = cold_step<E>(A, st, byte, coff);
         st = w;
         if (jj >= warm && is_final(A, st) && !(B.first_only && ev.n_ev)) {
             ev.n_rec += A.out_count[st];
@@ -1744,7 +1770,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_match_small(DevAutomaton A, c
         const uint32_t coff = class_offset<E, MODE>(A, cls, byte);
         uint32_t w = A.trap;
         if (s < tile_rows) w = *reinterpret_cast<const E *>(tile + s * A.row_bytes + coff);
-        if (w >= A.trap) w = *reinterpret_cast<const E *>(static_cast<const uint8_t *>(A.table) + uint64_t(s) * A.row_bytes + coff);
+        if (w >= A.trap) w = cold_step<E>(A, s, byte, coff);
         return w;
     };
     // item i -> (haystack, first byte, bytes, warm-up bytes, position of its first byte)

@@ -14,8 +14,8 @@ size_t scan_temp_elems(uint64_t n);
 void exclusive_scan_u64(const uint64_t *in, uint64_t *out, uint64_t n, uint64_t *temp, hipStream_t st);
 
 void launch_build_items(const BatchArgs &B, uint64_t max_items, hipStream_t st);
-void launch_item_base(const uint64_t *offsets, uint32_t nh, uint32_t chunk, uint64_t *n_items, uint64_t *item_base,
-                      uint32_t *counters, uint64_t *temp, hipStream_t st);
+void launch_item_base(const uint64_t *offsets, uint32_t nh, uint32_t chunk, uint64_t blob_bytes, uint64_t *n_items,
+                      uint64_t *item_base, uint32_t *counters, uint64_t *temp, hipStream_t st);
 hipError_t launch_scan(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int kernel,
                        int class_mode, int ilp, int group_quads, hipStream_t st);
 hipError_t launch_walk_runs(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,

@@ -49,6 +49,22 @@ typedef struct acmi_php_master {
 static int le_acmi_master;
 static zend_class_entry *aho_exception_ce;
 
+/* zend_array_is_list() exists from PHP 8.1 on; older versions get the same test spelled out
+ * (keys must be exactly 0..n-1 in order). */
+static int acmi_array_is_list(HashTable *ht)
+{
+#if PHP_VERSION_ID >= 80100
+    return zend_array_is_list(ht);
+#else
+    zend_ulong expect = 0, idx;
+    zend_string *key;
+    ZEND_HASH_FOREACH_KEY(ht, idx, key) {
+        if (key != NULL || idx != expect++) return 0;
+    } ZEND_HASH_FOREACH_END();
+    return 1;
+#endif
+}
+
 static void master_free(acmi_php_master *m)
 {
     size_t i;
@@ -149,7 +165,7 @@ static int process_patterns(acmi_php_master *m, HashTable *ht)
     zval *elem;
     int rc = 0;
     if (n == 0) return 0;
-    if (!zend_array_is_list(ht)) {   /* the reference NULL-derefs here */
+    if (!acmi_array_is_list(ht)) {   /* the reference NULL-derefs here */
         php_error_docref(NULL, E_WARNING, "Invalid pattern structure! Cannot initialize.");
         return -4;
     }
@@ -180,7 +196,11 @@ static int process_patterns(acmi_php_master *m, HashTable *ht)
     }
     rc = acmi_add_patterns(m->h, abi, n, NULL);         /* ac_trie_add loop: php_ahocorasick.c:484 */
     efree(abi);
-    if (rc != ACMI_OK) { efree(tmp); return -6; }
+    if (rc != ACMI_OK) {                                /* the zvals were ZVAL_COPY'd by parse_pattern: release them */
+        for (i = 0; i < n; i++) { zval_ptr_dtor(&tmp[i].key); zval_ptr_dtor(&tmp[i].value); zval_ptr_dtor(&tmp[i].aux); }
+        efree(tmp);
+        return -6;
+    }
     if (m->n_patterns + n > m->cap) {
         m->cap = (m->n_patterns + n) * 2;
         m->patterns = erealloc(m->patterns, m->cap * sizeof(*m->patterns));

@@ -6,6 +6,9 @@ import numpy as np
 from php_aho_corasick_amd import api
 
 
+BUILD_OPTIONS = ("lds_bytes", "max_table_bytes", "max_flat_outputs", "compact", "dense_bytes", "keep_host_tables")
+
+
 def resource_for(ds, calls: int = 1, **options):
     """ahocorasick_init() over the dataset's patterns (id => caller index), optionally split into
     `calls` add_patterns() calls; options are acmi_set_option() knobs applied before finalize."""
@@ -14,13 +17,13 @@ def resource_for(ds, calls: int = 1, **options):
     res = api.ahocorasick_init(pats[:step] if calls > 1 else pats)
     assert res is not False
     for k, v in options.items():
-        if k in ("lds_bytes", "max_table_bytes", "max_flat_outputs", "cold_chains"):
+        if k in BUILD_OPTIONS:
             res.set_option(k, v)
     for lo in range(step, len(pats), step):
         if calls > 1:
             assert api.ahocorasick_add_patterns(res, pats[lo:lo + step])
     for k, v in options.items():
-        if k not in ("lds_bytes", "max_table_bytes", "max_flat_outputs", "cold_chains"):
+        if k not in BUILD_OPTIONS:
             res.set_option(k, v)
     return res
 

@@ -51,9 +51,16 @@ class FlatTables:
         self.class_mode, self.swar_shift, self.swar_other = t.class_mode, t.swar_shift, t.swar_other
         self.max_pattern_length = t.max_pattern_length
         dt = np.uint16 if t.entry_bytes == 2 else np.uint32
-        n = t.n_states * t.n_columns
+        self.compact, self.dense_nf_end, self.dense_f_end = t.compact, t.dense_nf_end, t.dense_f_end
+        self.n_dense_rows = t.n_dense_rows if t.compact else t.n_states
+        n = self.n_dense_rows * t.n_columns
         self.table = np.ctypeslib.as_array(C.cast(t.table, C.POINTER(C.c_uint16 if t.entry_bytes == 2 else C.c_uint32)),
-                                           shape=(n,)).astype(np.int64).reshape(t.n_states, t.n_columns)
+                                           shape=(n,)).astype(np.int64).reshape(self.n_dense_rows, t.n_columns)
+        self.cold_rec = self.cold_edges = None
+        if t.compact:
+            self.cold_rec = np.ctypeslib.as_array(t.cold_rec, shape=(t.n_states, 2)).astype(np.int64)
+            self.cold_edges = (np.ctypeslib.as_array(t.cold_edges, shape=(t.n_cold_edges,)).astype(np.int64)
+                               if t.n_cold_edges else np.zeros(0, np.int64))
         m = (t.trap + 1) * t.n_columns
         self.lds = np.ctypeslib.as_array(C.cast(t.lds_image, C.POINTER(C.c_uint16 if t.entry_bytes == 2 else C.c_uint32)),
                                          shape=(m,)).astype(np.int64).reshape(t.trap + 1, t.n_columns)
@@ -62,8 +69,6 @@ class FlatTables:
         self.dict = np.ctypeslib.as_array(t.dict_link, shape=(t.n_states,)).astype(np.int64)
         self.cnt = np.ctypeslib.as_array(t.out_count, shape=(t.n_states,)).astype(np.int64)
         _ = dt
-        self.chain_lo = t.chain_lo
-        self.chain = np.ctypeslib.as_array(t.chain, shape=(self.f2 - t.chain_lo,)).astype(np.int64) if t.chain else None
         self.out_off = self.out_list = None
         if t.out_off:
             self.out_off = np.ctypeslib.as_array(t.out_off, shape=(t.n_states,)).astype(np.int64)
@@ -94,6 +99,31 @@ class FlatTables:
             return int((h >> 16) | 1) in [int(x) for x in self.anchor[h & ((1 << self.anchor_bucket_bits) - 1)]]
         return int(h >> 16) in [int(x) for x in self.anchor[(h >> 3) & 0x3FFF]]
 
+    def cold_step(self, s: int, b: int) -> int:
+        """kernels.hip cold_step(): dense row, or goto / failure records until a dense row is reached."""
+        c = int(self.cls[b])
+        if not self.compact:
+            return int(self.table[s, c])
+        while True:
+            if s < self.dense_nf_end:
+                return int(self.table[s, c])
+            if self.f2 <= s < self.dense_f_end:
+                return int(self.table[self.dense_nf_end + s - self.f2, c])
+            x, y = int(self.cold_rec[s, 0]), int(self.cold_rec[s, 1])
+            code = y >> 24
+            if code == 1:
+                if (x & 0xFF) == b:
+                    return x >> 8
+            elif code >= 2:
+                n, at = (code, x) if code != 255 else (int(self.cold_edges[x]), x + 1)
+                edges = self.cold_edges[at:at + n]
+                assert np.all(np.diff(edges & 0xFF) > 0), "edges must ascend by byte"
+                hit = edges[(edges & 0xFF) == b]
+                if hit.size:
+                    return int(hit[0]) >> 8
+            assert (y & 0xFFFFFF) != s
+            s = y & 0xFFFFFF
+
     def is_final(self, s: int) -> bool:
         return (self.f1 <= s < self.trap) or s >= self.f2
 
@@ -102,20 +132,14 @@ class FlatTables:
         NONE = 0xFFFFFFFF
         recs = []
         s = 0
-        tab, lds, cls, trap = self.table, self.lds, self.cls, self.trap
+        lds, cls, trap = self.lds, self.cls, self.trap
         for j, b in enumerate(text):
             c = cls[b]
             w = trap
             if use_lds and s < trap:
                 w = int(lds[s, c])
             if w >= trap:
-                # cold row: the chain word of a single-child state first (kernels.hip exact_range)
-                cw = int(self.chain[s - self.chain_lo]) if self.chain is not None and self.chain_lo <= s < self.f2 else NONE
-                if cw != NONE and (cw & 0xFF) == b:
-                    w = cw >> 8
-                    assert w == int(tab[s, c]), "chain edge disagrees with the table"
-                else:
-                    w = int(tab[s, c])
+                w = self.cold_step(s, b)  # row not in the LDS tile
             s = w
             if self.is_final(s):
                 pos = j + 1

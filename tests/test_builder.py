@@ -28,26 +28,35 @@ def _compare(ds, res, max_hay=6, calls=1):
 
 
 @pytest.mark.parametrize("name", ["G2", "G3", "G4", "G5", "R1", "R2", "R3"])
-@pytest.mark.parametrize("lds,chains", [(None, -1), (2048, 0), (2048, 1)])
-def test_tables_match_oracle(name, lds, chains):
+@pytest.mark.parametrize("lds,compact", [(None, -1), (2048, 0), (2048, 1), (None, 1)])
+def test_tables_match_oracle(name, lds, compact):
     ds = synth.NAMED[name]()
     opts = {"lds_bytes": lds} if lds else {}
-    res = resource_for(ds, cold_chains=chains, **opts)
+    if compact == 1:
+        opts["dense_bytes"] = 0   # dense rows for the LDS tile and trie depth <= 1 only
+    res = resource_for(ds, compact=compact, **opts)
     api.ahocorasick_finalize(res)
     ft = _compare(ds, res, max_hay=3 if name in ("G2", "R3") else 6)
     assert ft.out_off is not None
-    if chains == 1 and name in ("G2", "R2", "R3"):
-        # long patterns outside a 2 KiB tile: chain states exist, are numbered along their pattern ...
-        assert ft.chain is not None and ft.trap < ft.chain_lo < ft.f2
-        nxt = ft.chain >> 8
-        inside = (nxt >= ft.chain_lo) & (nxt < ft.f2)
-        assert np.all(nxt[inside] == np.arange(ft.chain_lo, ft.f2)[inside] + 1)  # ... child of a chain state = next id
-    if chains == 0:
-        assert ft.chain is None and ft.chain_lo == ft.f2
+    assert ft.compact == (1 if compact == 1 else 0)
+    if compact == 1:
+        assert ft.n_dense_rows == ft.dense_nf_end + (ft.dense_f_end - ft.f2) and ft.trap < ft.dense_nf_end <= ft.f2
+        code = ft.cold_rec[:, 1] >> 24
+        cold = np.ones(ft.n_states, bool)
+        cold[:ft.dense_nf_end] = False
+        cold[ft.f2:ft.dense_f_end] = False
+        assert np.all(code[~cold] == 0)
+        if name in ("G2", "R3") and lds:
+            # long patterns outside a 2 KiB tile: the insides of patterns are numbered along the pattern, so the
+            # child of most single-child states is the next id (one 128-byte line per 16 steps of a walk)
+            single = np.nonzero(cold & (code == 1))[0]
+            assert single.size > 0
+            nxt = ft.cold_rec[single, 0] >> 8
+            assert np.mean(nxt == single + 1) > 0.5
     # numbering invariants the kernels rely on
     assert 0 < ft.f1 <= ft.trap < ft.n_states and ft.trap < ft.f2 <= ft.n_states
     assert np.all(ft.lds <= ft.trap)                      # tile never points outside itself
-    assert np.all(ft.table[ft.trap] == ft.trap)           # trap row is absorbing
+    assert np.all(ft.table[ft.trap] == ft.trap)           # trap row is absorbing (its row index is its id: trap < dense_nf_end)
     assert np.all(ft.lds[:ft.trap][ft.table[:ft.trap] <= ft.trap] == ft.table[:ft.trap][ft.table[:ft.trap] <= ft.trap])
     hot_final = np.arange(ft.f1, ft.trap)
     assert np.all(ft.cnt[hot_final] > 0) and np.all(ft.cnt[:ft.f1] == 0)

@@ -52,6 +52,25 @@ def test_golden_g6_64k_patterns(golden):
     _check_golden(res, ds, golden, "G6")
     assert res.stat("nodes") == golden[("G6", True)]["nodes"]
     assert res.stat("entry_bytes") == 4
+    assert res.stat("compact") == 1 and res.stat("automaton_bytes") < 64 << 20   # 2.3 GB as dense rows
+    api.ahocorasick_deinit(res)
+
+
+@pytest.mark.parametrize("kernel", [0, 1, 4])
+def test_golden_g6_compact_other_kernels(golden, kernel):
+    """The same automaton through the table-walk kernels: every cold step is a goto / failure record."""
+    ds = synth.g6()
+    res = resource_for(ds, kernel=kernel)
+    _check_golden(res, ds, golden, "G6")
+    api.ahocorasick_deinit(res)
+
+
+def test_g6_dense_equals_compact(golden):
+    """Dense rows for all 2.27 M states (2.3 GB, the round-1 layout) give the same records."""
+    ds = synth.g6()
+    res = resource_for(ds, compact=0)
+    _check_golden(res, ds, golden, "G6")
+    assert res.stat("compact") == 0 and res.stat("table_bytes") > 2e9
     api.ahocorasick_deinit(res)
 
 
@@ -65,14 +84,17 @@ VARIANTS = [dict(kernel=1, persistent=1, chunk_bytes=64), dict(kernel=1, persist
             dict(kernel=1, slab_events=1, refill=2, chunk_bytes=512), dict(kernel=2, slab_events=1, refill=1),
             dict(kernel=0, slab_events=1, refill=2, chunk_bytes=48), dict(kernel=2, slab_events=2, refill=2, chunk_bytes=1000),
             dict(kernel=1, slab_events=1, refill=2, max_flat_outputs=0),
-            # chain words for cold single-child states (forced; automatic only for tables > 16 MiB)
-            dict(kernel=1, lds_bytes=2048, cold_chains=1), dict(kernel=2, lds_bytes=4096, cold_chains=1, chunk_bytes=256),
-            dict(kernel=0, cold_chains=1), dict(kernel=3, cold_chains=1, lds_bytes=8192, run_cap=1),
+            # compact automaton (goto / failure records outside the first trie levels) forced on small sets; automatic
+            # only when the dense table would exceed 64 MiB.  dense_bytes=0: dense rows for the tile and depth <= 1 only
+            dict(kernel=1, lds_bytes=2048, compact=1, dense_bytes=0), dict(kernel=2, lds_bytes=4096, compact=1, chunk_bytes=256, dense_bytes=0),
+            dict(kernel=0, compact=1, dense_bytes=0), dict(kernel=3, compact=1, lds_bytes=8192, run_cap=1, dense_bytes=4096),
+            dict(kernel=4, compact=1, dense_bytes=0, lds_bytes=2048, chunk_bytes=128), dict(kernel=1, compact=1, dense_bytes=0, slab_events=1, refill=2, lds_bytes=2048),
+            dict(kernel=1, compact=1, dense_bytes=0, slab_events=1, refill=1, lds_bytes=4096, small_path=0),
             # exact walk of whole items, 1 / 2 / 4 items per thread
             dict(kernel=4, walk_group=1), dict(kernel=4, walk_group=4, chunk_bytes=48, slab_events=1), dict(kernel=4, walk_group=8, chunk_bytes=256, lds_bytes=4096),
             dict(kernel=4, walk_group=8, slab_events=2, refill=2),
             # early stop of single-window anchor walks: forced on / off
-            dict(kernel=2, early_stop=2), dict(kernel=2, early_stop=2, chunk_bytes=256, cold_chains=1), dict(kernel=2, early_stop=0)]
+            dict(kernel=2, early_stop=2), dict(kernel=2, early_stop=2, chunk_bytes=256, compact=1, dense_bytes=0, lds_bytes=2048), dict(kernel=2, early_stop=0)]
 
 
 @pytest.mark.parametrize("name,variant", list(itertools.product(["G2", "G4", "G5", "R1", "R2", "R3", "R4", "R5", "R6", "R7", "R8"], range(len(VARIANTS)))))
