@@ -242,7 +242,8 @@ static void collect_matches(orc_trie *t, uint32_t n)
         if (t->nodes[f].final)
             t->nodes[n].final = 1;
     }
-    qsort(t->nodes[n].out, t->nodes[n].out_n, sizeof(edge_t), edge_cmp);
+    if (t->nodes[n].out_n)  /* (the reference calls qsort on a NULL vector of 0 edges too; UBSan objects) */
+        qsort(t->nodes[n].out, t->nodes[n].out_n, sizeof(edge_t), edge_cmp);
 }
 
 /* src/multifast/ahocorasick.c:407-422 ac_trie_traverse_action, top_down=1. */

@@ -1,0 +1,65 @@
+"""include/acmi.h consumed as C: tests/abi_c/driver.c is compiled with gcc -std=c99 -pedantic -Wall -Werror,
+linked against libacmi.so and run (the reference's MultiFast API is plain C too: src/multifast/ahocorasick.h:73-87)."""
+import ctypes as C
+import ctypes.util
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from helpers import ROOT
+from php_aho_corasick_amd import _native as N
+
+SRC = os.path.join(ROOT, "tests", "abi_c", "driver.c")
+EXE = os.path.join(ROOT, "tests", "abi_c", "driver")
+PKG = os.path.join(ROOT, "php_aho_corasick_amd")
+
+
+def _hip_lib_dir():
+    """Directory of the HIP runtime libacmi.so was linked against (torch's copy is only preferred inside python)."""
+    for d in ("/opt/rocm/lib", os.path.join(os.path.dirname(C.util.find_library("amdhip64") or ""), "")):
+        if d and os.path.exists(os.path.join(d, "libamdhip64.so")):
+            return d
+    return "/opt/rocm/lib"
+
+
+@pytest.fixture(scope="module")
+def driver():
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(SRC), os.path.getmtime(N.LIB_PATH),
+                                                               os.path.getmtime(os.path.join(ROOT, "include", "acmi.h"))):
+        subprocess.run([gcc, "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-O1", "-I" + os.path.join(ROOT, "include"), SRC,
+                        "-L" + PKG, "-lacmi", "-Wl,-rpath," + PKG, "-Wl,-rpath-link," + _hip_lib_dir(), "-o", EXE], check=True)
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = _hip_lib_dir() + ":" + env.get("LD_LIBRARY_PATH", "")
+
+    def run(mode):
+        return subprocess.run([EXE, mode], env=env, capture_output=True, text=True, timeout=300)
+    return run
+
+
+def test_header_compiles_as_c99_and_layout_matches_ctypes(driver):
+    out = driver("layout")
+    assert out.returncode == 0, out.stderr
+    facts = dict(line.rsplit(" ", 1) for line in out.stdout.strip().splitlines())
+    assert int(facts["acmi_record"]) == C.sizeof(N.Record) == 16
+    assert int(facts["acmi_pattern"]) == C.sizeof(N.Pattern) == 32
+    assert int(facts["acmi_tables"]) == C.sizeof(N.Tables)
+    for key, val in facts.items():
+        if key.startswith("acmi_tables."):
+            assert getattr(N.Tables, key.split(".", 1)[1]).offset == int(val), key
+
+
+def test_lifecycle_status_codes_and_metadata_from_c(driver):
+    out = driver("cpu")
+    assert out.returncode == 0 and out.stdout.strip().endswith("cpu ok"), out.stderr + out.stdout
+
+
+@pytest.mark.gpu
+def test_kat1_through_acmi_match_from_c(driver):
+    """tests/test1.phpt through acmi_match(), no python in the call path."""
+    out = driver("kat")
+    assert out.returncode == 0 and out.stdout.strip().endswith("kat ok"), out.stderr + out.stdout
