@@ -296,6 +296,19 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
         uint64_t d1 = 0, d3 = 0;
         for (uint32_t u = 1; u < ns; ++u) { d1 += depth[u] == 1; d3 += depth[u] == 3; }
         fa.early_stop_useful = d3 < d1 * d1 * d1;
+        // events + tile exits per byte of uniform text over the used alphabet (see est_flag_rate)
+        std::vector<double> w(256, 0.0);
+        w[0] = 1.0;
+        for (int d = 1; d < 256; ++d) w[d] = w[d - 1] / double(std::max<uint32_t>(nused, 1));
+        std::vector<uint32_t> bfs_pos(ns);
+        for (uint32_t i = 0; i < ns; ++i) bfs_pos[order[i]] = i;
+        double rate = 0;
+        for (uint32_t i = 1; i < ns; ++i) {
+            const uint32_t u = order[i];
+            if (is_final[u]) rate += w[depth[u]];
+            else if (i >= hot && bfs_pos[parent_[u]] < hot) rate += w[depth[u]];  // first cold state on its path
+        }
+        fa.est_flag_rate = rate;
     }
     {
         uint32_t a = 0, b = hot_nf, c = hot + 1, d = fa.f2;

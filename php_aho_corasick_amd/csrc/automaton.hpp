@@ -57,6 +57,11 @@ struct FlatAutomaton {
     uint32_t shallow_hot = 0;    // [0,shallow_hot) and (trap,shallow_cold_end): non-final states of trie depth <= 2
     uint32_t shallow_cold_end = 0;
     bool early_stop_useful = false;  // some 3-gram over the first-byte alphabet is not a trie path
+    // Expected flagged positions per text byte of k_scan_lds' optimistic pass on text drawn uniformly from the
+    // patterns' own alphabet: arrivals in final states (events) plus transitions that leave the LDS tile, each
+    // state weighed |alphabet|^-depth.  The engine starts keyword-like and dense sets on the exact whole-item
+    // walk instead of finding out on their first batch.
+    double est_flag_rate = 0;
     // Compact form (BuildOptions::compact).  The reference keeps 88-byte nodes with sorted edge arrays and a failure
     // pointer (node.h:37-67); a dense failure-free row per state is 1 KiB at 256 columns -- 2.3 GB for the
     // 2.27 M states of a 64K-pattern set, every deep step of a walk a far-memory access.  Compact keeps dense rows

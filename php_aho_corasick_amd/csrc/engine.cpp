@@ -72,8 +72,12 @@ struct acmi_handle {
     uint32_t run_cap = 8;
     uint64_t chunk_opt = 0;
     int kernel = 3;  // 0 plain global table, 1 LDS-tile walk, 2 anchor filter (if eligible), 3 automatic
-    bool anchor_off = false;  // automatic mode: the anchor filter lost on this handle's data, stay on the table walk
-    bool exact_only = false;  // automatic mode: k_scan_lds' optimistic pass flagged most of a batch, walk exactly from now on
+    // automatic mode: a batch on which the fast kernel lost (most bytes had to be walked exactly anyway) moves the
+    // handle to the slower, safer kernel -- for `*_left` batches, then the fast one is probed again; every further
+    // loss doubles the span (16 .. 1024 batches), a win resets it.  Batches under kAutoMinBytes decide nothing.
+    bool anchor_off = false;  // the anchor filter lost on this handle's data: table walk meanwhile
+    bool exact_only = false;  // k_scan_lds' optimistic pass flagged most of a batch: exact whole-item walk meanwhile
+    uint32_t anchor_left = 0, anchor_span = 16, exact_left = 0, exact_span = 16;
     int ilp = 1;
     int group_quads = 8;
     int small_path = 1;   // 1: host batches of <= 64 KiB / <= 1024 haystacks take the one-launch kernel
@@ -146,12 +150,23 @@ int fail_hip(acmi_handle *h, hipError_t e, const char *what) {
         if (_e != hipSuccess) return fail_hip(h, _e, #call); \
     } while (0)
 
+constexpr uint64_t kAutoMinBytes = 1ull << 20;
+
 int ensure_finalized(acmi_handle *h) {
     if (h->aut.finalized()) return 0;
     std::string err;
     if (!h->aut.finalize(h->bopt, &err)) {
         h->last_error = err;
         return ACMI_E_TOO_LARGE;
+    }
+    // Automatic kernel choice, seeded from the automaton instead of from a first slow batch: when uniform text over
+    // the patterns' alphabet would flag more positions of an 8 KiB work item than its run list holds, the optimistic
+    // LDS-tile pass ends up walking whole items anyway (keyword lists, dense sets) -- start on the exact walk.  The
+    // usual probing applies from there (the fast kernel gets its chance after `exact_left` batches).
+    const FlatAutomaton &fa = h->aut.flat();
+    if (fa.est_flag_rate * 8192.0 > double(h->run_cap)) {
+        h->exact_only = true;
+        h->exact_left = h->exact_span;
     }
     return 1;
 }
@@ -341,6 +356,10 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
     const FlatAutomaton &fa = h->aut.flat();
     // the anchor filter needs a pattern set that allows it; automatic mode also leaves it once a batch
     // showed that this handle's text defeats it (see run_batch_end)
+    if (h->kernel == 3 && blob_bytes >= kAutoMinBytes) {  // time to probe the fast kernel again?
+        if (h->anchor_off && h->anchor_left-- == 0) h->anchor_off = false;
+        else if (h->exact_only && !(fa.anchor_q && !h->anchor_off) && h->exact_left-- == 0) h->exact_only = false;
+    }
     int kernel = h->kernel == 3 ? ((fa.anchor_q && !h->anchor_off) ? 2 : 1)
                                 : ((h->kernel == 2 && !fa.anchor_q) ? 1 : h->kernel);
     if (h->kernel == 3 && kernel == 1 && h->exact_only) kernel = 4;
@@ -467,10 +486,27 @@ int run_batch_end(acmi_handle *h) {
     h->walked_bytes = 0;  // counters[7..15]: k_scan_lds adds to [7], k_walk_runs spreads its workgroups over [8..15]
     for (int i = 7; i < 16; ++i) h->walked_bytes += uint64_t(reinterpret_cast<uint32_t *>(h->pinned)[i]) * 16;
     // automatic mode: a batch of which more than a quarter had to be walked exactly defeats the filter
-    if (h->kernel == 3 && h->kernel_used == 2 && h->walked_bytes * 4 > h->fly_blob_bytes) h->anchor_off = true;
+    const bool decisive = h->kernel == 3 && h->fly_blob_bytes >= kAutoMinBytes;
+    if (decisive && h->kernel_used == 2) {
+        if (h->walked_bytes * 4 > h->fly_blob_bytes) {
+            h->anchor_off = true;
+            h->anchor_left = h->anchor_span;
+            h->anchor_span = std::min<uint32_t>(h->anchor_span * 2, 1024);
+        } else {
+            h->anchor_span = 16;
+        }
+    }
     // ... and one of which more than half was flagged by the LDS-tile kernel's optimistic pass (events or tile
-    // exits in most wave-quads: keyword-like and dense-match text) is walked exactly right away from now on
-    if (h->kernel == 3 && h->kernel_used == 1 && h->walked_bytes * 2 > h->fly_blob_bytes) h->exact_only = true;
+    // exits in most wave-quads: keyword-like and dense-match text) is walked exactly right away
+    if (decisive && h->kernel_used == 1) {
+        if (h->walked_bytes * 2 > h->fly_blob_bytes) {
+            h->exact_only = true;
+            h->exact_left = h->exact_span;
+            h->exact_span = std::min<uint32_t>(h->exact_span * 2, 1024);
+        } else {
+            h->exact_span = 16;
+        }
+    }
     if (h->profile) {
         float ms = 0;
         HIPCHK(h, hipEventElapsedTime(&ms, h->ev[1], h->ev[2]));
@@ -880,6 +916,7 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
             h->kernel = int(value);
             h->anchor_off = false;
             h->exact_only = false;
+            h->anchor_span = h->exact_span = 16;
         } else if (k == "ilp") {
             if (value != 1 && value != 2) return ACMI_E_ARG;
             h->ilp = int(value);
@@ -940,6 +977,7 @@ int acmi_get_stat(const acmi_handle *h, const char *key, double *value) {
         else if (k == "accepted") *value = double(h->aut.accepted_count());
         else if (k == "patterns") *value = double(h->aut.patterns().size());
         else if (k == "finalized") *value = h->aut.finalized() ? 1 : 0;
+        else if (k == "est_flag_rate") *value = fa.est_flag_rate;
         else if (k == "states") *value = fa.n_states;
         else if (k == "hot_states") *value = fa.trap;
         else if (k == "columns") *value = fa.n_columns;

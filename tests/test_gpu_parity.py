@@ -122,17 +122,41 @@ def test_overflow_path_is_taken(refill, flat):
     api.ahocorasick_deinit(res)
 
 
-def test_automatic_switch_to_exact_walk(golden):
-    """Automatic kernel choice: a batch whose bytes were mostly flagged by the LDS-tile kernel's optimistic
-    pass (dense matches) moves the handle to the exact whole-item walk; results do not change."""
+def test_automatic_choice_of_exact_walk(golden):
+    """Automatic kernel choice.  Dense sets (all strings <= 4 over {a,b}) start on the exact whole-item walk:
+    the builder's estimate says the LDS-tile kernel's optimistic pass would flag every work item.  A sparse set
+    starts on the optimistic kernel, leaves it when a batch of >= 1 MiB shows that most bytes were walked exactly
+    anyway, and probes it again later; results never change."""
     ds = synth.g4()
     res = resource_for(ds)
+    api.ahocorasick_finalize(res)
+    assert res.stat("est_flag_rate") > 1
     first = device_match(res, ds)
-    assert res.stat("kernel_used") == 1
-    second = device_match(res, ds)
     assert res.stat("kernel_used") == 4
-    assert np.array_equal(first[0], second[0]) and np.array_equal(first[1], second[1])
     _check_golden(res, ds, golden, "G4")
+    api.ahocorasick_deinit(res)
+
+    # 8 patterns of 6 letters: sparse on uniform text (8 / 26^6 events per byte), but this text is ALL pattern
+    ds = synth.generate("sw", 77, 8, 6, 6, 1, 64, bytes(range(97, 123)))
+    res = resource_for(ds)
+    api.ahocorasick_finalize(res)
+    assert res.stat("est_flag_rate") * 8192 < 1 and res.stat("anchor_q") == 0
+    o = Oracle("port")
+    o.add_patterns((ds.pat_blob, ds.pat_off))
+    hay = np.frombuffer(b"".join(ds.pattern(k % 8) for k in range(8192 // 6 * 256 + 300)), dtype=np.uint8)[:256 * 8192].copy()
+    off = (np.arange(257, dtype=np.uint64) * 8192)
+    pe, re_ = o.match_batch(hay, off, True)
+    import torch
+    from php_aho_corasick_amd import batch
+    d_blob, d_off = torch.from_numpy(hay).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()
+    batch.bind_current_stream(res)
+    used = []
+    for _ in range(3):
+        total = batch.match_device(res, d_blob, d_off, True)
+        used.append(int(res.stat("kernel_used")))
+        p, r = batch.result_numpy(res, 256, total)
+        assert np.array_equal(p, pe) and np.array_equal(r, re_)
+    assert used[0] == 1 and used[1] == 4 and used[2] == 4, used
     api.ahocorasick_deinit(res)
 
 
@@ -292,12 +316,13 @@ def test_automatic_kernel_choice_and_fallback():
     api.ahocorasick_deinit(res)
     res = resource_for(synth.r1())
     host_match(res, synth.r1())
-    assert res.stat("kernel_used") == 1                  # short patterns: not eligible
+    assert res.stat("kernel_used") == 4                  # short patterns: not eligible, and dense by the builder's estimate
     api.ahocorasick_deinit(res)
     # adversarial text: every haystack is a pattern's first 15 bytes repeated -> anchors everywhere
-    ds = synth.g2(64)
+    # (2 MiB: batches under 1 MiB decide nothing)
+    ds = synth.g2(256)
     frag = np.frombuffer(ds.pattern(5)[:15] * 600, dtype=np.uint8)[:8192]
-    ds.hay_blob[:] = np.tile(frag, 64)
+    ds.hay_blob[:] = np.tile(frag, 256)
     o = Oracle("port")
     o.add_patterns((ds.pat_blob, ds.pat_off))
     res = resource_for(ds)
@@ -306,6 +331,12 @@ def test_automatic_kernel_choice_and_fallback():
         pe, re_ = o.match_batch(ds.hay_blob, ds.hay_off)
         assert np.array_equal(p, pe) and np.array_equal(r, re_)
         assert res.stat("kernel_used") == expect_kernel
+    # ... not for good: after 16 batches on the exact walk the LDS kernel is probed again, loses again (span doubles)
+    used = []
+    for _ in range(18):
+        host_match(res, ds)
+        used.append(int(res.stat("kernel_used")))
+    assert used.count(1) == 1 and used[16] == 1 and used[17] == 4, used
     api.ahocorasick_deinit(res)
 
 
