@@ -216,6 +216,9 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *                    0 = dense, -1 (default) = compact when the dense table would exceed 64 MiB   [before finalize]
  *   "dense_bytes"    compact: dense rows are kept for the LDS tile, trie depth <= 1 and further states in BFS order
  *                    up to this many bytes (default 4 MiB)                                        [before finalize]
+ *   "verify"         1 (default): a candidate of the anchor filter whose q-gram belongs to exactly one (pattern, offset)
+ *                    pair is decided by comparing that pattern's text with the haystack; 0: every candidate is walked
+ *                    through the automaton.  Same records either way                              [before the first match]
  *   "keep_host_tables"  1 = keep the host copies of the tables after they were uploaded (acmi_debug_tables after a
  *                    match call); default 0: they are freed by the first match call               [before the first match]
  *   "max_flat_outputs"  per-state output lists are also stored flat ({pattern, length}, longest first) for the
@@ -274,6 +277,9 @@ typedef struct acmi_tables {
     const uint32_t *cold_rec;     /* compact: 2 words per state id {x, failure id | code << 24}; code 0 no child, 1: x = child << 8 | byte,
                                      2..254: that many edges at cold_edges[x], 255: cold_edges[x] = count, edges behind it */
     const uint32_t *cold_edges;   /* child << 8 | byte, ascending byte */
+    uint32_t chain_lo;            /* compact: ids [chain_lo, first_cold_final) are single-child states numbered along their patterns */
+    const uint8_t *chain_byte;    /* per such state: its edge byte (null: none) */
+    const uint8_t *chain_run;     /* per such state: how many steps from it on lead to id + 1, again such a state (capped at 255) */
     const uint32_t *out_off;      /* per state: first entry of its flat output list */
     const uint32_t *out_list;     /* 2 words per entry: pattern index, pattern length; longest first */
 } acmi_tables;

@@ -42,6 +42,7 @@ void build_tables(FlatAutomaton &fa, const std::vector<uint32_t> &order, uint32_
     // LDS tile: hot rows only; a transition that leaves the tile lands on the trap row
     const size_t hot_rows = size_t(fa.trap) + 1;
     fa.lds_image.resize(hot_rows * nc * sizeof(E));
+    fa.lds_image_bytes = fa.lds_image.size();
     E *img = reinterpret_cast<E *>(fa.lds_image.data());
     for (size_t i = 0; i < hot_rows * nc; ++i) img[i] = tab[i] > E(fa.trap) ? E(fa.trap) : tab[i];
 }
@@ -279,6 +280,7 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
     fa.dense_f_end = compact ? fa.f2 + dense_cold_f : fa.n_states;
     fa.n_dense_rows = compact ? fa.dense_nf_end + dense_cold_f : fa.n_states;
     const uint32_t chain_lo = fa.f2 - cold_chain;
+    fa.chain_lo = chain_lo;
     // Non-final states of trie depth <= 2 are a prefix of their id class (ids follow BFS order within a class):
     // [0, shallow_hot) and (trap, shallow_cold_end).  The exact walk of an anchor candidate stops on them (see
     // run_epilogue): no pattern begun at the candidate's window can still be alive there.
@@ -365,6 +367,21 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
             fa.cold_rec[size_t(newid[u]) * 2 + 1] = newid[fail[u]] | (code << 24);
         }
     }
+    fa.chain_byte.clear();
+    fa.chain_run.clear();
+    if (compact && cold_chain) {
+        fa.chain_byte.assign(size_t(cold_chain) + 16, 0);
+        fa.chain_run.assign(size_t(cold_chain) + 16, 0);
+        for (uint32_t id = fa.f2; id-- > chain_lo;) {  // backwards: a state's run extends its successor's
+            const uint32_t x = fa.cold_rec[size_t(id) * 2];
+            const uint32_t k = id - chain_lo;
+            fa.chain_byte[k] = uint8_t(x & 0xffu);
+            // steps that can be taken blindly: the states they LAND on must be of this kind too (non-final, deeper
+            // than 2: no event, no early stop to test); a child numbered elsewhere or a final one ends the run
+            if ((x >> 8) != id + 1 || id + 1 >= fa.f2) continue;
+            fa.chain_run[k] = uint8_t(std::min<uint32_t>(255u, 1u + fa.chain_run[k + 1]));
+        }
+    }
 
     fa.own_pattern.assign(fa.n_states, kNone);
     fa.dict_link.assign(fa.n_states, kNone);
@@ -410,6 +427,11 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
         }
     }
 
+    // final state of every accepted pattern (the state whose own pattern it is)
+    std::vector<uint32_t> pattern_state(patterns_.size(), kNone);
+    for (uint32_t u = 0; u < ns; ++u)
+        if (own_[u] != kNone) pattern_state[own_[u]] = newid[u];
+
     // ---- anchor filter table -------------------------------------------------------------------
     fa.min_pattern_length = 0;
     for (const PatternMeta &m : patterns_)
@@ -421,41 +443,70 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
     if (fa.min_pattern_length >= 7) {
         const uint32_t q = fa.min_pattern_length >= 19 ? 16u : fa.min_pattern_length >= 15 ? 12u
                          : fa.min_pattern_length >= 11 ? 8u : 4u;
-        std::vector<std::array<uint32_t, 4>> keys;
-        for (const PatternMeta &m : patterns_) {
+        // (q-gram, pattern, offset) triples, sorted by q-gram: the distinct q-grams are the filter's keys, and a key
+        // that stands for exactly ONE (pattern, offset) pair lets k_walk_runs verify a candidate by comparing the
+        // pattern's text instead of walking the automaton (anchor_pairs below)
+        struct Triple { std::array<uint32_t, 4> key; uint32_t pattern, offset; };
+        std::vector<Triple> triples;
+        for (size_t pi = 0; pi < patterns_.size(); ++pi) {
+            const PatternMeta &m = patterns_[pi];
             if (!m.accepted) continue;
             for (uint32_t o = 0; o < 4; ++o) {
-                std::array<uint32_t, 4> k{0, 0, 0, 0};
-                std::memcpy(k.data(), pattern_bytes_.data() + m.byte_off + o, q);
-                keys.push_back(k);
+                Triple t{{0, 0, 0, 0}, uint32_t(pi), o};
+                std::memcpy(t.key.data(), pattern_bytes_.data() + m.byte_off + o, q);
+                triples.push_back(t);
             }
         }
-        std::sort(keys.begin(), keys.end());
-        keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+        std::sort(triples.begin(), triples.end(), [](const Triple &a, const Triple &b) {
+            return a.key != b.key ? a.key < b.key : (a.pattern != b.pattern ? a.pattern < b.pattern : a.offset < b.offset);
+        });
+        std::vector<std::array<uint32_t, 4>> keys;
+        std::vector<uint32_t> key_pair;  // per key: index into anchor_pairs, or kNone when several pairs share the q-gram
+        fa.anchor_pairs.clear();
+        for (size_t i = 0; i < triples.size();) {
+            size_t e = i + 1;
+            while (e < triples.size() && triples[e].key == triples[i].key) ++e;
+            keys.push_back(triples[i].key);
+            if (e - i == 1) {
+                const PatternMeta &m = patterns_[triples[i].pattern];
+                key_pair.push_back(uint32_t(fa.anchor_pairs.size() / 4));
+                fa.anchor_pairs.insert(fa.anchor_pairs.end(), {triples[i].pattern, triples[i].offset | (m.length << 8),
+                                                               uint32_t(m.byte_off), pattern_state[triples[i].pattern]});
+            } else {
+                key_pair.push_back(kNone);
+            }
+            i = e;
+        }
+        std::vector<Triple>().swap(triples);
+        fa.anchor_pairs_count = fa.anchor_pairs.size() / 4;
         fa.anchor_keys = uint32_t(keys.size());
+        fa.anchor_slot_pair.clear();
         uint32_t mul = 0x9E3779B1u;
         if (keys.size() <= kAnchorMaxKeys) {
             std::vector<uint16_t> tab(size_t(kAnchorBuckets) * 4);
             for (int attempt = 0; attempt < 512 && fa.anchor_q == 0; ++attempt, mul = mul * 0x2545F491u + 0x6B43A9B5u) {
                 mul = (mul | 1u) & 0xFFFFFFu;
                 std::vector<uint8_t> used(kAnchorBuckets, 0);
+                std::vector<uint32_t> slot_pair(size_t(kAnchorBuckets) * 4, kNone);
                 for (uint32_t b = 0; b < kAnchorBuckets; ++b) std::fill_n(&tab[size_t(b) * 4], 4, anchor_empty(b));
                 bool ok = true;
-                for (const auto &k : keys) {
-                    const uint32_t h = anchor_hash(k.data(), q / 4, mul);
+                for (size_t ki = 0; ki < keys.size(); ++ki) {
+                    const uint32_t h = anchor_hash(keys[ki].data(), q / 4, mul);
                     const uint16_t fp = uint16_t(h >> 16);                   // fingerprint: high half
                     const uint32_t bucket = (h >> 3) & (kAnchorBuckets - 1);  // bits 3..16
                     uint16_t *b = &tab[size_t(bucket) * 4];
                     uint32_t slot = 0;
                     while (slot < used[bucket] && b[slot] != fp) ++slot;
                     if (slot == 4) { ok = false; break; }  // bucket overflow: take another seed
-                    if (slot == used[bucket]) b[used[bucket]++] = fp;
+                    if (slot == used[bucket]) { b[used[bucket]++] = fp; slot_pair[size_t(bucket) * 4 + slot] = key_pair[ki]; }
+                    else slot_pair[size_t(bucket) * 4 + slot] = kNone;  // two q-grams, one fingerprint: not verifiable
                 }
                 if (ok) {
                     fa.anchor_q = q;
                     fa.anchor_mode = 1;
                     fa.anchor_mul = mul;
                     fa.anchor_table = tab;
+                    fa.anchor_slot_pair = slot_pair;
                 }
             }
         } else {
@@ -470,18 +521,21 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
                     mul = (mul | 1u) & 0xFFFFFFu;
                     tab.assign(size_t(nb) * 8, uint16_t(0));
                     used.assign(nb, 0);
+                    std::vector<uint32_t> slot_pair(size_t(nb) * 8, kNone);
                     bool ok = true;
-                    for (const auto &k : keys) {
-                        const uint32_t h = anchor_hash(k.data(), q / 4, mul);
+                    for (size_t ki = 0; ki < keys.size(); ++ki) {
+                        const uint32_t h = anchor_hash(keys[ki].data(), q / 4, mul);
                         const uint16_t fp = uint16_t((h >> 16) | 1u);
                         const uint32_t bucket = h & (nb - 1);
                         uint16_t *b = &tab[size_t(bucket) * 8];
                         uint32_t slot = 0;
                         while (slot < used[bucket] && b[slot] != fp) ++slot;
                         if (slot == 8) { ok = false; break; }
-                        if (slot == used[bucket]) b[used[bucket]++] = fp;
+                        if (slot == used[bucket]) { b[used[bucket]++] = fp; slot_pair[size_t(bucket) * 8 + slot] = key_pair[ki]; }
+                        else slot_pair[size_t(bucket) * 8 + slot] = kNone;
                     }
                     if (!ok) continue;
+                    fa.anchor_slot_pair.swap(slot_pair);
                     fa.anchor_q = q;
                     fa.anchor_mode = 2;
                     fa.anchor_mul = mul;

@@ -79,6 +79,12 @@ struct FlatAutomaton {
                                        //   code 0: no child; 1: x = child id << 8 | byte; 2..254: that many edges at
                                        //   cold_edges[x..]; 255: cold_edges[x] = count, edges behind it
     std::vector<uint32_t> cold_edges;  // child id << 8 | byte, ascending byte
+    // The single-child states that are numbered along their patterns, ids [chain_lo, f2): edge byte per state and
+    // how many steps from this state on lead to the next id, which is again such a state (capped at 255).  A candidate walk that
+    // reaches such a state compares up to 16 text bytes against 16 edge bytes at once instead of taking 16
+    // dependent steps (kernels.hip walk_fast).  Both arrays carry 16 bytes of padding.
+    uint32_t chain_lo = 0;
+    std::vector<uint8_t> chain_byte, chain_run;
     uint32_t class_mode = kClassTable;
     uint32_t swar_shift = 0;     // class = (byte >> shift) & 7 when byte is in the alphabet
     uint32_t swar_other = 0;     // column of every byte outside the alphabet
@@ -87,6 +93,7 @@ struct FlatAutomaton {
     uint32_t max_pattern_length = 0;
     uint32_t n_used_bytes = 0;
     uint64_t table_bytes = 0;        // size of `table` (kept when the host copy is released)
+    uint64_t lds_image_bytes = 0;    // size of `lds_image` (likewise)
     std::vector<uint8_t> table;      // n_dense_rows x n_columns entries, true transitions
     std::vector<uint8_t> lds_image;  // (trap+1) x n_columns entries, cold targets -> trap
     uint8_t class_of_byte[256] = {0};
@@ -120,6 +127,15 @@ struct FlatAutomaton {
     uint32_t anchor_bucket_bits = 0;  // mode 2
     std::vector<uint16_t> anchor_table;
     std::vector<uint32_t> anchor_bitmap;  // mode 2: 32768 words
+    // Candidate verification by text compare (k_walk_runs).  A hit window whose q-gram belongs to exactly one
+    // (pattern, offset) pair can only be the anchor of that pattern: comparing the pattern's bytes with the text
+    // decides the candidate without a single automaton step.  anchor_slot_pair[bucket * slots + slot] = index of
+    // the 4-word record {pattern, offset | length << 8, byte offset in pattern_bytes, final state} in anchor_pairs,
+    // or kNone when the slot stands for several pairs (patterns sharing a q-gram, two q-grams sharing a fingerprint):
+    // those candidates are walked.
+    std::vector<uint32_t> anchor_slot_pair;
+    std::vector<uint32_t> anchor_pairs;
+    uint64_t anchor_pairs_count = 0;
 };
 
 constexpr uint32_t kAnchorBucketBits = 14;
@@ -168,6 +184,10 @@ public:
         std::vector<uint8_t>().swap(flat_.lds_image);
         std::vector<uint32_t>().swap(flat_.cold_rec);
         std::vector<uint32_t>().swap(flat_.cold_edges);
+        std::vector<uint8_t>().swap(flat_.chain_byte);
+        std::vector<uint8_t>().swap(flat_.chain_run);
+        std::vector<uint32_t>().swap(flat_.anchor_slot_pair);
+        std::vector<uint32_t>().swap(flat_.anchor_pairs);
         std::vector<uint32_t>().swap(flat_.out_list);
         host_tables_released_ = true;
     }

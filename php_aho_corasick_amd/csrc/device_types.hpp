@@ -25,6 +25,11 @@ struct DevAutomaton {
     uint32_t dense_nf_end, dense_f_end;
     const uint2 *cold_rec;
     const uint32_t *cold_edges;
+    // ids [chain_lo, f2): single-child states numbered along their pattern -- edge byte and length of the run of
+    // "child == id + 1" states from here on (automaton.hpp); null when there are none
+    uint32_t chain_lo;
+    const uint8_t *chain_byte, *chain_run;
+    const uint8_t *pad16;        // 16 readable bytes: where unconditional loads of lanes with nothing to load go
     uint32_t shallow_hot, shallow_cold_end;  // non-final states of trie depth <= 2: [0,shallow_hot), (trap,shallow_cold_end)
     uint32_t early_stop;         // 1: walks of anchor candidates stop on them (run_epilogue)
     uint32_t class_identity;     // TABLE mode with 256 columns: class(byte) == byte
@@ -38,6 +43,10 @@ struct DevAutomaton {
     // anchor filter (k_scan_anchor): 2^14 buckets x 4 x uint16 fingerprints, see automaton.hpp
     const void *anchor_table;    // mode 1: 128 KiB staged into LDS; mode 2: 2^bucket_bits x 8 x uint16, read through L2
     const uint32_t *anchor_bitmap;  // mode 2: 2^20 bits staged into LDS
+    // candidate verification by text compare (automaton.hpp anchor_pairs); null: every candidate is walked
+    const uint32_t *anchor_slot_pair;
+    const uint4 *anchor_pairs;   // {pattern, offset | length << 8, byte offset in pattern_bytes, final state}
+    const uint8_t *pattern_bytes;
     uint32_t anchor_q, anchor_mul, min_pattern_length, max_pattern_length;
     uint32_t anchor_mode, anchor_bucket_mask;
 };

@@ -89,6 +89,7 @@ struct acmi_handle {
                           // 1 when the automaton can fall back to shallow states at all (default), 2 always
     int refill = 0;       // 0 automatic, 1 one thread per overflowed item (k_refill), 2 one wave (k_refill_wave)
     int profile = 0;
+    int verify = 1;            // 1: anchor candidates whose q-gram names one pattern are decided by comparing its text
     int keep_host_tables = 0;  // 1: the host copies of table / tile / records stay after the upload (acmi_debug_tables)
 
     // device state
@@ -99,7 +100,7 @@ struct acmi_handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     DevAutomaton dA{};
-    DevBuf d_table, d_lds, d_class, d_own, d_dict, d_cnt, d_plen, d_anchor, d_bitmap, d_out_off, d_out_list, d_cold_rec, d_cold_edges;
+    DevBuf d_table, d_lds, d_class, d_own, d_dict, d_cnt, d_plen, d_anchor, d_bitmap, d_out_off, d_out_list, d_cold_rec, d_cold_edges, d_chain_byte, d_chain_run, d_slot_pair, d_pairs, d_pat_bytes;
 
     // workspace (grow-only)
     DevBuf d_blob, d_off, d_nitems, d_item_base, d_item_hay, d_item_rec, d_zero, d_rec_base, d_slab, d_ovf, d_counters,
@@ -247,6 +248,12 @@ int ensure_device(acmi_handle *h) {
         HIPCHK(h, h->d_cold_edges.ensure(std::max<size_t>(8, fa.cold_edges.size() * 4)));
         if (!fa.cold_edges.empty())
             HIPCHK(h, hipMemcpy(h->d_cold_edges.p, fa.cold_edges.data(), fa.cold_edges.size() * 4, hipMemcpyHostToDevice));
+        if (!fa.chain_byte.empty()) {
+            HIPCHK(h, h->d_chain_byte.ensure(fa.chain_byte.size()));
+            HIPCHK(h, hipMemcpy(h->d_chain_byte.p, fa.chain_byte.data(), fa.chain_byte.size(), hipMemcpyHostToDevice));
+            HIPCHK(h, h->d_chain_run.ensure(fa.chain_run.size()));
+            HIPCHK(h, hipMemcpy(h->d_chain_run.p, fa.chain_run.data(), fa.chain_run.size(), hipMemcpyHostToDevice));
+        }
     }
 
     if (fa.anchor_q) {
@@ -258,7 +265,22 @@ int ensure_device(acmi_handle *h) {
         }
     }
 
+    const bool verify = fa.anchor_q && h->verify && !fa.anchor_pairs.empty() && !fa.anchor_slot_pair.empty();
+    if (verify) {
+        const std::vector<uint8_t> &pb = h->aut.pattern_bytes();
+        HIPCHK(h, h->d_pat_bytes.ensure(pb.size() + 32));
+        HIPCHK(h, hipMemset(h->d_pat_bytes.p, 0, pb.size() + 32));
+        HIPCHK(h, hipMemcpy(h->d_pat_bytes.p, pb.data(), pb.size(), hipMemcpyHostToDevice));
+        HIPCHK(h, h->d_slot_pair.ensure(fa.anchor_slot_pair.size() * 4));
+        HIPCHK(h, hipMemcpy(h->d_slot_pair.p, fa.anchor_slot_pair.data(), fa.anchor_slot_pair.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(h, h->d_pairs.ensure(fa.anchor_pairs.size() * 4));
+        HIPCHK(h, hipMemcpy(h->d_pairs.p, fa.anchor_pairs.data(), fa.anchor_pairs.size() * 4, hipMemcpyHostToDevice));
+    }
+
     DevAutomaton &A = h->dA;
+    A.anchor_slot_pair = verify ? h->d_slot_pair.as<uint32_t>() : nullptr;
+    A.anchor_pairs = verify ? h->d_pairs.as<uint4>() : nullptr;
+    A.pattern_bytes = verify ? h->d_pat_bytes.as<uint8_t>() : nullptr;
     A.anchor_table = fa.anchor_q ? h->d_anchor.p : nullptr;
     A.anchor_q = fa.anchor_q;
     A.anchor_mode = fa.anchor_mode;
@@ -282,6 +304,10 @@ int ensure_device(acmi_handle *h) {
     A.dense_f_end = fa.dense_f_end;
     A.cold_rec = fa.compact ? h->d_cold_rec.as<uint2>() : nullptr;
     A.cold_edges = fa.compact ? h->d_cold_edges.as<uint32_t>() : nullptr;
+    A.chain_lo = fa.chain_lo;
+    A.chain_byte = fa.chain_byte.empty() ? nullptr : h->d_chain_byte.as<uint8_t>();
+    A.chain_run = fa.chain_byte.empty() ? nullptr : h->d_chain_run.as<uint8_t>();
+    A.pad16 = h->d_class.as<uint8_t>();  // (512 bytes, always present)
     A.shallow_hot = fa.shallow_hot;
     A.shallow_cold_end = fa.shallow_cold_end;
     A.early_stop = (h->early_stop == 2 || (h->early_stop == 1 && fa.early_stop_useful)) ? 1u : 0u;
@@ -682,7 +708,7 @@ int acmi_destroy(acmi_handle *h) {
         if (h->dev_touched) {  // also after a failed upload: release whatever was created
             (void)hipSetDevice(h->dev_id);
             if (h->stream) (void)hipStreamSynchronize(h->stream);
-            for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_out_off, &h->d_out_list, &h->d_cold_rec, &h->d_cold_edges, &h->d_blob,
+            for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_out_off, &h->d_out_list, &h->d_cold_rec, &h->d_cold_edges, &h->d_chain_byte, &h->d_chain_run, &h->d_slot_pair, &h->d_pairs, &h->d_pat_bytes, &h->d_blob,
                               &h->d_off, &h->d_nitems, &h->d_item_base, &h->d_item_hay, &h->d_item_rec, &h->d_zero,
                               &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_scan_tmp, &h->d_prefix, &h->d_out, &h->d_runs, &h->d_run_count, &h->d_prefix_alt, &h->d_out_alt})
                 b->release();
@@ -950,6 +976,9 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
             if (h->aut.finalized()) return ACMI_E_FINALIZED;
             if (value < 0) return ACMI_E_ARG;
             h->bopt.dense_bytes = uint64_t(value);
+        } else if (k == "verify") {
+            if (h->dev_ready) return ACMI_E_FINALIZED;  // the tables are uploaded (or not) by the first match call
+            h->verify = value ? 1 : 0;
         } else if (k == "keep_host_tables") {
             h->keep_host_tables = value ? 1 : 0;
         } else if (k == "max_flat_outputs") {
@@ -983,7 +1012,7 @@ int acmi_get_stat(const acmi_handle *h, const char *key, double *value) {
         else if (k == "columns") *value = fa.n_columns;
         else if (k == "entry_bytes") *value = fa.entry_bytes;
         else if (k == "class_mode") *value = fa.class_mode;
-        else if (k == "lds_image_bytes") *value = double(fa.lds_image.size() + (fa.class_mode == kClassTable ? 512 : 0));
+        else if (k == "lds_image_bytes") *value = double(fa.lds_image_bytes + (fa.class_mode == kClassTable ? 512 : 0));
         else if (k == "table_bytes") *value = double(fa.table_bytes);
         else if (k == "automaton_bytes") *value = double(fa.table_bytes + (fa.compact ? uint64_t(fa.n_states) * 8 : 0));
         else if (k == "max_pattern_length") *value = fa.max_pattern_length;
@@ -1003,6 +1032,7 @@ int acmi_get_stat(const acmi_handle *h, const char *key, double *value) {
         else if (k == "records") *value = double(h->last_total);
         else if (k == "flat_outputs") *value = double(fa.n_flat_outputs);
         else if (k == "max_out_count") *value = fa.max_out_count;
+        else if (k == "anchor_pairs") *value = double(fa.anchor_pairs_count);
         else if (k == "compact") *value = fa.compact;
         else if (k == "dense_rows") *value = fa.n_dense_rows;
         else if (k == "cold_edges") *value = double(fa.cold_edges.size());
@@ -1056,6 +1086,9 @@ int acmi_debug_tables(const acmi_handle *h, acmi_tables *out) {
         out->n_cold_edges = uint32_t(fa.cold_edges.size());
         out->cold_rec = fa.cold_rec.empty() ? nullptr : fa.cold_rec.data();
         out->cold_edges = fa.cold_edges.empty() ? nullptr : fa.cold_edges.data();
+        out->chain_lo = fa.chain_lo;
+        out->chain_byte = fa.chain_byte.empty() ? nullptr : fa.chain_byte.data();
+        out->chain_run = fa.chain_run.empty() ? nullptr : fa.chain_run.data();
         out->n_flat_outputs = uint32_t(fa.out_list.size() / 2);
         out->out_off = fa.out_off.empty() ? nullptr : fa.out_off.data();
         out->out_list = fa.out_list.empty() ? nullptr : fa.out_list.data();

@@ -127,6 +127,15 @@ __device__ __forceinline__ void unpack_item(uint32_t x, uint32_t y, uint32_t z, 
     it.hay = 0;  // not carried: the scan kernels do not need it
 }
 
+// window hash (automaton.hpp anchor_hash): fold each dword, then a multiply-add chain in 24-bit
+// arithmetic -- one full-rate v_mad_u32_u24 per dword after the first
+__device__ __forceinline__ uint32_t anchor_fold_dev(uint32_t d) { return d ^ (d >> 11); }
+__device__ __forceinline__ uint32_t anchor_mad(uint32_t h, uint32_t mul, uint32_t f) {
+    uint32_t r;  // spelled out: from `__umul24(h, mul) + f` hipcc makes a quarter-rate v_mad_u64_u32 half of the time
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(h), "s"(mul), "v"(f));
+    return r;
+}
+
 __global__ void k_build_items(BatchArgs B) {
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= B.item_base[B.n_haystacks]) return;
@@ -503,14 +512,17 @@ __device__ __forceinline__ void append_run(const BatchArgs &B, uint64_t item, ui
 struct RunStage {
     uint4 *slots;        // this wave's 128 staging slots (LDS)
     uint32_t count;      // staged entries (wave-uniform)
-    bool mergeable;      // the last staged entry is the current item's last run
 };
 constexpr uint32_t kStageSlots = 128;
 
-// `entry` of a run: the exact automaton state at `lo`, or one of
+// `entry` of a run: the exact automaton state at `lo` (< 2^24), or
 constexpr uint32_t kEntryUnknown = 0xFFFFFFFFu;    // walk from the root Lmax-1 bytes before lo
-constexpr uint32_t kEntryShortWarm = 0xFFFFFFFEu;  // k_scan_anchor: m_min-1 bytes before lo suffice
-constexpr uint32_t kEntryShortWarmMerged = 0xFFFFFFFDu;  // the same, and later windows' ranges were merged into the run
+// ... or, from k_scan_anchor, kEntryWindow | start of the hit window the run belongs to (item scan coordinates):
+// every pattern anchored there ends in [start + m_min - 4, start + Lmax); the stored `lo` is that lower bound unless
+// an earlier window's run reached further (then it was clamped to that run's end: the two are adjacent).  Runs
+// are never merged, one per hit window: k_walk_runs sees which runs touch and what every run was flagged for.
+constexpr uint32_t kEntryWindow = 0x80000000u;
+__device__ __forceinline__ bool entry_is_window(uint32_t e) { return (e & kEntryWindow) != 0u && e != kEntryUnknown; }
 
 __device__ __forceinline__ void stage_flush(const BatchArgs &B, uint64_t wave_first, RunStage &st, uint32_t lane) {
     for (uint32_t i = lane; i < st.count; i += 64u) {
@@ -518,28 +530,20 @@ __device__ __forceinline__ void stage_flush(const BatchArgs &B, uint64_t wave_fi
         B.runs[uint64_t(e.x >> 8) * B.run_stride + wave_first + (e.x & 0xffu)] = make_uint4(e.y, e.z, e.w, 0u);
     }
     st.count = 0;
-    st.mergeable = false;
 }
 
-// same bookkeeping as append_run (n, last_hi stay in scalar registers); k = item index inside the wave batch
+// Bookkeeping as in append_run (n, last_hi stay in scalar registers), but runs are never merged: adjacent runs
+// stay separate entries (k_walk_runs joins them); k = item index inside the wave batch
 __device__ __forceinline__ void append_run_wave(const BatchArgs &B, uint64_t wave_first, RunStage &st, uint32_t k,
                                                 uint32_t lo, uint32_t hi, uint32_t entry, uint32_t &n,
                                                 uint32_t &last_hi, uint32_t lane) {
     if (n > B.run_cap) return;
-    if (n > 0 && last_hi == lo && st.mergeable) {
-        if (lane == 0) {  // adjacent: extend the previous run; it then serves more than one hit window
-            st.slots[st.count - 1].z = hi;
-            if (st.slots[st.count - 1].w == kEntryShortWarm) st.slots[st.count - 1].w = kEntryShortWarmMerged;
-        }
-    } else {
-        if (n < B.run_cap) {
-            if (st.count == kStageSlots) stage_flush(B, wave_first, st, lane);
-            if (lane == 0) st.slots[st.count] = make_uint4(k | (n << 8), lo, hi, entry);
-            ++st.count;
-            st.mergeable = true;
-        }
-        ++n;
+    if (n < B.run_cap) {
+        if (st.count == kStageSlots) stage_flush(B, wave_first, st, lane);
+        if (lane == 0) st.slots[st.count] = make_uint4(k | (n << 8), lo, hi, entry);
+        ++st.count;
     }
+    ++n;
     last_hi = hi;
 }
 
@@ -653,29 +657,300 @@ __device__ __forceinline__ uint32_t run_epilogue(const DevAutomaton &A, const Ba
             const uint4 run = runs[uint64_t(r) * B.run_stride];
             const uint32_t lo = run.x, hi = run.y;
             uint32_t st = run.z, from = lo;
-            uint32_t stop_from = 0xFFFFFFFFu;
             walked += hi - lo;
-            if (st >= kEntryShortWarmMerged) {  // entry state unknown: silent warm-up from the root, Lmax-1 bytes
-                                          // (or m_min-1 where k_scan_anchor knows that this suffices)
-                const uint32_t warm = st == kEntryUnknown ? B.warm_bytes : A.min_pattern_length - 1u;
-                // A run of ONE hit window (short warm-up; lo = window start + m_min - 4) whose range no later
-                // window's run was clamped against: every pattern it can report begins in [start-3, start], so
-                // once the state's depth is <= j - start nothing is alive.  Depth <= 2 is what the state ids
-                // tell for free: stop from byte start + 2 on.
-                if (EXTRA && st == kEntryShortWarm && A.early_stop && lo + 6u >= A.min_pattern_length &&
-                    (r + 1u == nr || runs[uint64_t(r + 1u) * B.run_stride].x != hi))
-                    stop_from = lo + 6u - A.min_pattern_length;
-                from = lo > warm ? lo - warm : 0u;
+            if (st == kEntryUnknown) {  // entry state unknown: silent warm-up from the root, Lmax-1 bytes
+                from = lo > B.warm_bytes ? lo - B.warm_bytes : 0u;
                 st = 0;
             }
             // warm-up and run in one loop: nothing before `lo` is reported
-            exact_range<E, MODE, EXTRA>(A, B, cls_lds, tile, tile_rows, item, p, from, hi, lo > it.warm ? lo : it.warm, pos_bias, st, ev, stop_from);
+            exact_range<E, MODE, EXTRA>(A, B, cls_lds, tile, tile_rows, item, p, from, hi, lo > it.warm ? lo : it.warm, pos_bias, st, ev);
         }
     }
     if (ev.n_ev) {
         B.ev_count[item] = ev.n_ev;
         B.rec_count[item] = ev.n_rec;
         // events only arise here, so the overflow test needs no reload of ev_count (cf. finish_item)
+        if (ev.n_ev > B.slab_events) B.overflow_list[atomicAdd(&B.counters[0], 1u)] = uint32_t(item);
+    }
+    return walked;
+}
+
+// ------------------------------------------------------------------------------------------
+// walk_fast: the exact walk of ONE candidate run, built for k_walk_runs.
+//
+// exact_range above costs ~200 wave-instructions per byte-step once 64 lanes diverge over its branches (block
+// reloads, per-byte dword selects, cold-row loop), and a wave takes as many steps as its longest walk has bytes:
+// k_walk_runs was bound by instruction issue, not by memory (config 3: 6,200 VALU + 7,000 SALU per wave for ~67
+// lockstep steps).  Here every lane has its own cursor and every loop iteration is useful work for every lane
+// that is still walking:
+//   * a lane holds 16 text bytes in registers, read by ONE unaligned 16-byte load at its cursor (byte k of the
+//     window = a dword select and a shift, no memory access);
+//   * a state inside a pattern (compact automata: ids [chain_lo, f2) are numbered along the patterns) is not
+//     stepped through byte by byte with dependent loads: its next 16 edge bytes are compared with the 16 text
+//     bytes at the cursor in one go and the cursor jumps over what matched -- no event test on the way (such
+//     states are non-final and deeper than 2).  A 36-byte pattern is ~10 iterations instead of ~40;
+//   * events, the early stop and the cold step keep the semantics of exact_range, which also finishes the last
+//     bytes of an item (where a 16-byte load would cross its end).
+// ------------------------------------------------------------------------------------------
+typedef u32x4 u32x4_u __attribute__((aligned(1)));
+// (explicitly global: through a generic pointer hipcc emits flat_load, whose wait also drains the LDS queue)
+__device__ __forceinline__ uint4 load16u(const uint8_t *a) {
+    const u32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) u32x4_u *>(reinterpret_cast<uintptr_t>(a));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint32_t load8g(const uint8_t *a) {
+    return *reinterpret_cast<const __attribute__((address_space(1))) uint8_t *>(reinterpret_cast<uintptr_t>(a));
+}
+
+// The loop body is written as straight-line predicated code (three loads issued together, one wait, selects):
+// as nested divergent branches the same logic compiled to ~120 scalar branch / exec-mask sequences and a
+// vmcnt(0) behind every load, and the kernel was bound by instruction issue again.
+template <typename E, int MODE, bool EXTRA>
+__device__ __forceinline__ uint32_t walk_fast(const DevAutomaton &A, const BatchArgs &B, const uint8_t *tile,
+                                              uint32_t tile_rows, uint64_t item, const uint8_t *p, uint32_t from,
+                                              uint32_t hi, uint32_t safe_end, uint32_t rep_from, uint32_t pos_bias,
+                                              uint32_t s, EventRegs &ev, uint32_t stop_from) {
+    uint32_t j = from;
+    uint32_t jbase = from;  // text[jbase .. jbase+16) is what the window load fetches
+    const bool chains = A.chain_byte != nullptr;
+    const uint32_t chain_lo = A.chain_lo, f2 = A.f2, trap = A.trap, row_bytes = A.row_bytes;
+    // 16-byte loads must stay inside the item: the last bytes are walked with single loads
+    const uint32_t fast_hi = safe_end >= 16u ? (hi < safe_end - 15u ? hi : safe_end - 15u) : 0u;
+#pragma unroll 1
+    while (j < fast_hi) {
+        const bool in_chain = chains && s >= chain_lo && s < f2;
+        uint32_t k = j - jbase;
+        if (k >= 16u || (in_chain && k != 0u)) { jbase = j; k = 0; }
+        const uint32_t idx = in_chain ? s - chain_lo : 0u;
+        const uint4 t = load16u(p + jbase);           // (a line this lane has touched before, unless the window moved)
+        const uint4 cb = load16u((chains ? A.chain_byte : A.pad16) + idx);
+        const uint32_t run = load8g((chains ? A.chain_run : A.pad16) + idx);
+        // the 16 text bytes at the cursor against the 16 edge bytes from this state on
+        uint32_t m = 16u;
+        uint32_t x = t.w ^ cb.w;
+        m = x ? 12u + (uint32_t(__builtin_ctz(x)) >> 3) : m;
+        x = t.z ^ cb.z;
+        m = x ? 8u + (uint32_t(__builtin_ctz(x)) >> 3) : m;
+        x = t.y ^ cb.y;
+        m = x ? 4u + (uint32_t(__builtin_ctz(x)) >> 3) : m;
+        x = t.x ^ cb.x;
+        m = x ? (uint32_t(__builtin_ctz(x)) >> 3) : m;
+        m = m < run ? m : run;
+        m = m < hi - j ? m : hi - j;
+        m = in_chain ? m : 0u;                        // m steps along the pattern: states s+1 .. s+m are of this kind too
+        // one ordinary step (taken when m == 0)
+        const uint32_t word = k < 8u ? (k < 4u ? t.x : t.y) : (k < 12u ? t.z : t.w);
+        const uint32_t byte = (word >> (8u * (k & 3u))) & 0xffu;
+        const uint32_t coff = class_offset<E, MODE>(A, nullptr, byte);
+        const uint32_t row = s < tile_rows ? s : 0u;
+        uint32_t w = *reinterpret_cast<const E *>(tile + row * row_bytes + coff);
+        w = s < tile_rows ? w : trap;
+        if (m == 0u && w >= trap) w = cold_step<E>(A, s, byte, coff);
+        const bool stepped = m == 0u;
+        s = stepped ? w : s + m;
+        if (stepped && j >= rep_from && is_final(A, s) && !(B.first_only && ev.n_ev)) {
+            ev.n_rec += A.out_count[s];
+            if (ev.n_ev < B.slab_events) B.slab[uint64_t(ev.n_ev) * B.run_stride + item] = make_uint2(pos_bias + j, s);
+            ++ev.n_ev;
+        }
+        if (EXTRA && stepped && j >= stop_from && (s < A.shallow_hot || (s > trap && s < A.shallow_cold_end))) return s;
+        j += stepped ? 1u : m;
+    }
+    if (j < hi) s = exact_range<E, MODE, EXTRA>(A, B, nullptr, tile, tile_rows, item, p, j, hi, rep_from, pos_bias, s, ev, stop_from);
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------
+// verify_candidate: decide a single-window candidate of the anchor filter WITHOUT walking.
+//
+// A run that serves one hit window (the case the early stop is also built on: nothing anchored at another window
+// can end inside it) can only contain occurrences of patterns whose anchor q-gram is the window's.  When that
+// q-gram belongs to exactly one (pattern, offset) pair -- every q-gram of a random signature set, most of any
+// real one -- the run holds one event or none: the pattern's text either is there or is not.  So: hash the
+// window again, find its slot in the filter's own fingerprint table, fetch the pair, compare the pattern's bytes
+// with the text in 16-byte pieces, and on equality report the occurrence with the pattern's final state (its output
+// list carries the shorter patterns that end there too, exactly as after a walk).  Four dependent memory round
+// trips and ~100 instructions, the same for every lane of a wave, against one round trip and ~200 lockstep
+// instructions per BYTE of the pattern for the walk.  Returns false when the slot stands for several pairs
+// (patterns sharing a q-gram, fingerprint twins): the caller walks.
+// ------------------------------------------------------------------------------------------
+// Result of verify_candidate for one window
+struct Verified {
+    uint32_t j;      // index of the occurrence's last byte, 0xFFFFFFFF: the pattern is not there
+    uint32_t state;  // its final state
+};
+
+typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+typedef u32x2v u32x2_u __attribute__((aligned(1)));
+typedef uint32_t u32_u __attribute__((aligned(1)));
+__device__ __forceinline__ uint2 load8u(const uint8_t *a) {
+    const u32x2v v = *reinterpret_cast<const __attribute__((address_space(1))) u32x2_u *>(reinterpret_cast<uintptr_t>(a));
+    return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ uint32_t load4u(const uint8_t *a) {
+    return *reinterpret_cast<const __attribute__((address_space(1))) u32_u *>(reinterpret_cast<uintptr_t>(a));
+}
+
+__device__ __forceinline__ bool verify_candidate(const DevAutomaton &A, const uint8_t *p, uint32_t n, uint32_t w, Verified &out) {
+    out = Verified{0xFFFFFFFFu, 0u};
+    if (w + A.anchor_q > n) return false;
+    // the window's hash (automaton.hpp anchor_hash; the window lies inside the item: the filter tested it)
+    const uint32_t nw = A.anchor_q >> 2;
+    uint32_t h = anchor_fold_dev(load4u(p + w));
+#pragma unroll 1
+    for (uint32_t i = 1; i < nw; ++i) h = anchor_mad(h, A.anchor_mul, anchor_fold_dev(load4u(p + w + 4u * i)));
+    if (nw == 1u) h = anchor_mad(h, A.anchor_mul, h >> 8);
+    // its slot in the fingerprint table
+    uint32_t slot = 0xFFFFFFFFu;
+    if (A.anchor_mode == 2u) {
+        const uint32_t bucket = h & A.anchor_bucket_mask;
+        const uint4 b = static_cast<const uint4 *>(A.anchor_table)[bucket];
+        const uint32_t fp = (h >> 16) | 1u;
+        const uint32_t v[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int i = 3; i >= 0; --i) {
+            if ((v[i] >> 16) == fp) slot = bucket * 8u + uint32_t(i) * 2u + 1u;
+            if ((v[i] & 0xffffu) == fp) slot = bucket * 8u + uint32_t(i) * 2u;
+        }
+    } else {
+        const uint32_t bucket = (h >> 3) & 0x3FFFu;
+        const uint2 b = static_cast<const uint2 *>(A.anchor_table)[bucket];
+        const uint32_t fp = h >> 16;
+        const uint32_t v[2] = {b.x, b.y};
+#pragma unroll
+        for (int i = 1; i >= 0; --i) {
+            if ((v[i] >> 16) == fp) slot = bucket * 4u + uint32_t(i) * 2u + 1u;
+            if ((v[i] & 0xffffu) == fp) slot = bucket * 4u + uint32_t(i) * 2u;
+        }
+    }
+    if (slot == 0xFFFFFFFFu) return false;  // (cannot happen for a window the filter flagged; walk to be safe)
+    const uint32_t pair = A.anchor_slot_pair[slot];
+    if (pair == 0xFFFFFFFFu) return false;
+    const uint4 rec = A.anchor_pairs[pair];
+    const uint32_t o = rec.y & 0xffu, len = rec.y >> 8;
+    if (w < o || w - o + len > n) return true;  // the pattern would begin before / end after this item's bytes: no occurrence
+    const uint8_t *tp = p + (w - o), *pp = A.pattern_bytes + rec.z;
+    uint32_t diff = 0;
+    if (len >= 16u) {
+#pragma unroll 1
+        for (uint32_t c = 0; c + 16u <= len; c += 16u) {
+            const uint4 a = load16u(tp + c), b = load16u(pp + c);
+            diff |= (a.x ^ b.x) | (a.y ^ b.y) | (a.z ^ b.z) | (a.w ^ b.w);
+        }
+        const uint4 a = load16u(tp + len - 16u), b = load16u(pp + len - 16u);  // the last 16 bytes (may overlap)
+        diff |= (a.x ^ b.x) | (a.y ^ b.y) | (a.z ^ b.z) | (a.w ^ b.w);
+    } else if (len >= 8u) {
+        const uint2 a0 = load8u(tp), b0 = load8u(pp), a1 = load8u(tp + len - 8u), b1 = load8u(pp + len - 8u);
+        diff = (a0.x ^ b0.x) | (a0.y ^ b0.y) | (a1.x ^ b1.x) | (a1.y ^ b1.y);
+    } else {  // 7 bytes (patterns shorter than that are not anchor-eligible)
+        diff = (load4u(tp) ^ load4u(pp)) | (load4u(tp + len - 4u) ^ load4u(pp + len - 4u));
+    }
+    if (diff) return true;
+    out.j = w - o + len - 1u;  // index of the occurrence's last byte
+    out.state = rec.w;
+    return true;
+}
+
+// run_epilogue for k_walk_runs.  k_scan_anchor leaves one run per hit window, ascending and disjoint, a run that
+// begins where its predecessor ends being adjacent to it.  Runs that touch form a CLUSTER: everything that ends
+// inside a cluster is an occurrence of a pattern anchored at one of the cluster's windows (an occurrence anchored
+// elsewhere would have flagged a run of its own, overlapping this range, hence in the cluster).  So a cluster of
+// window runs is decided by verifying its windows (verify_candidate) and emitting the occurrences found in
+// position order -- of two that end at the same byte only the longer is an event, the shorter is in its output
+// list.  Clusters with a run that names no window (unaligned head, tail, a swallowed window), with a window whose
+// q-gram names several patterns, or with more than kClusterMax windows are walked as one range.
+constexpr uint32_t kClusterMax = 4;
+
+template <typename E, int MODE, bool EXTRA>
+__device__ __forceinline__ uint32_t run_epilogue_fast(const DevAutomaton &A, const BatchArgs &B, const uint8_t *tile,
+                                                      uint32_t tile_rows, uint64_t item, const ItemDesc &it, uint32_t nr) {
+    const uint8_t *p = B.blob + (it.begin - it.warm);
+    const uint32_t n = it.warm + it.len;
+    const uint32_t pos_bias = it.pos0 - it.warm + 1u;
+    EventRegs ev{0, 0};
+    uint32_t walked = 0;
+    if (nr > B.run_cap) {
+        walked = n;
+        exact_range<E, MODE, EXTRA>(A, B, nullptr, tile, tile_rows, item, p, 0, n, it.warm, pos_bias, 0u, ev);
+    } else {
+        const uint4 *runs = B.runs + item;
+        uint32_t r = 0;
+        uint4 run = nr ? runs[0] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll 1
+        while (r < nr) {
+            // the cluster that starts with run r
+            const uint4 first = run;
+            uint32_t hi = first.y, count = 1;
+            bool windows = entry_is_window(first.z) && A.anchor_pairs != nullptr;
+            Verified v[kClusterMax];
+#pragma unroll
+            for (uint32_t i = 0; i < kClusterMax; ++i) v[i] = Verified{0xFFFFFFFFu, 0u};
+            if (windows) windows = verify_candidate(A, p, n, first.z & ~kEntryWindow, v[0]);
+#pragma unroll 1
+            for (;;) {
+                ++r;
+                if (r >= nr) break;
+                run = runs[uint64_t(r) * B.run_stride];
+                if (run.x != hi) break;  // not adjacent: the next cluster
+                hi = run.y;
+                windows = windows && entry_is_window(run.z) && count < kClusterMax;
+                if (windows) {
+                    Verified vv;
+                    windows = verify_candidate(A, p, n, run.z & ~kEntryWindow, vv);
+                    // (kept in registers: the slot index is wave-divergent, so a select chain instead of v[count])
+#pragma unroll
+                    for (uint32_t i = 1; i < kClusterMax; ++i) if (i == count) v[i] = vv;
+                }
+                ++count;
+            }
+            const uint32_t lo = first.x;
+            const uint32_t rep_from = lo > it.warm ? lo : it.warm;
+            walked += hi - lo;
+            if (windows) {
+                // occurrences in position order; windows ascend, so do pattern starts per window, ends need not
+#pragma unroll
+                for (uint32_t a = 0; a + 1 < kClusterMax; ++a)
+#pragma unroll
+                    for (uint32_t b = 0; b + 1 < kClusterMax - a; ++b)
+                        if (v[b + 1].j < v[b].j) { const Verified t = v[b]; v[b] = v[b + 1]; v[b + 1] = t; }
+#pragma unroll
+                for (uint32_t i = 0; i < kClusterMax; ++i) {
+                    const uint32_t j = v[i].j;
+                    if (j == 0xFFFFFFFFu) continue;
+                    // same end as the next one: the longer pattern is the one from the EARLIER window; after the sort
+                    // equal ends are neighbours, and the event belongs to the deepest final state among them
+                    if (i + 1 < kClusterMax && v[i + 1].j == j) {
+                        if (A.out_count[v[i + 1].state] < A.out_count[v[i].state]) v[i + 1].state = v[i].state;
+                        continue;
+                    }
+                    if (j >= rep_from && j < hi && !(B.first_only && ev.n_ev)) {
+                        const uint32_t s = v[i].state;
+                        ev.n_rec += A.out_count[s];
+                        if (ev.n_ev < B.slab_events) B.slab[uint64_t(ev.n_ev) * B.run_stride + item] = make_uint2(pos_bias + j, s);
+                        ++ev.n_ev;
+                    }
+                }
+                continue;
+            }
+            // walk the cluster as one range: from the root, m_min-1 bytes before a window's own lower bound (every
+            // pattern that ends in the cluster begins at or after the first window - 3), Lmax-1 bytes otherwise
+            uint32_t st = 0, from = lo, stop_from = 0xFFFFFFFFu;
+            if (entry_is_window(first.z) && lo + 4u == (first.z & ~kEntryWindow) + A.min_pattern_length) {
+                const uint32_t warm = A.min_pattern_length - 1u;
+                from = lo > warm ? lo - warm : 0u;
+                // a lone window: nothing is alive once the state is shallow two bytes past the window start
+                if (EXTRA && A.early_stop && count == 1u && lo + 6u >= A.min_pattern_length) stop_from = lo + 6u - A.min_pattern_length;
+            } else if (first.z == 0u && lo == 0u) {
+                from = 0;  // the item's first bytes: the scan begins in the root
+            } else {
+                from = lo > B.warm_bytes ? lo - B.warm_bytes : 0u;
+            }
+            walk_fast<E, MODE, EXTRA>(A, B, tile, tile_rows, item, p, from, hi, n, rep_from, pos_bias, st, ev, stop_from);
+        }
+    }
+    if (ev.n_ev) {
+        B.ev_count[item] = ev.n_ev;
+        B.rec_count[item] = ev.n_rec;
         if (ev.n_ev > B.slab_events) B.overflow_list[atomicAdd(&B.counters[0], 1u)] = uint32_t(item);
     }
     return walked;
@@ -883,14 +1158,6 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchA
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kAnchorLdsBytes = 16384u * 8u;
 
-// window hash (automaton.hpp anchor_hash): fold each dword, then a multiply-add chain in 24-bit
-// arithmetic -- one full-rate v_mad_u32_u24 per dword after the first
-__device__ __forceinline__ uint32_t anchor_fold_dev(uint32_t d) { return d ^ (d >> 11); }
-__device__ __forceinline__ uint32_t anchor_mad(uint32_t h, uint32_t mul, uint32_t f) {
-    uint32_t r;  // spelled out: from `__umul24(h, mul) + f` hipcc makes a quarter-rate v_mad_u64_u32 half of the time
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(h), "s"(mul), "v"(f));
-    return r;
-}
 
 // Probe one window: bucket = bits 3..16 of the hash (so the LDS byte address is one v_and),
 // fingerprint = its high half.  The bucket's four 16-bit slots minus the fingerprint (packed
@@ -999,20 +1266,8 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     anchor_open(A, B, rec, 0, ld);
     if (!ld.valid) break;
     sc = ld;
-    RunStage stage{reinterpret_cast<uint4 *>(smem + kAnchorLdsBytes) + (threadIdx.x >> 6) * kStageSlots, 0u, false};
+    RunStage stage{reinterpret_cast<uint4 *>(smem + kAnchorLdsBytes) + (threadIdx.x >> 6) * kStageSlots, 0u};
     uint32_t nrun = 0, run_hi = 0;  // run list of the item being scanned (wave-uniform)
-    uint32_t run_entry = 0;         // entry word of its last run as stored (wave-uniform)
-    // The last run is about to serve a second hit window (a later window's range was clamped against it, or
-    // swallowed by it): if it is a single-window run (kEntryShortWarm) its walk may no longer stop early.
-    auto mark_prev = [&]() {
-        if (run_entry != kEntryShortWarm || nrun == 0 || nrun > B.run_cap) return;
-        if (stage.mergeable) {
-            if (lane == 0) stage.slots[stage.count - 1].w = kEntryShortWarmMerged;
-        } else if (lane == 0) {
-            B.runs[uint64_t(nrun - 1u) * B.run_stride + wave_first + sc.k].z = kEntryShortWarmMerged;
-        }
-        run_entry = kEntryShortWarmMerged;
-    };
     uint32_t nrun_vec = 0;          // lane k: run count of item wave_first + k
     // carry[n-1] = hash prefix over the LAST n dwords of a quad (n = 1..QW-1): what a window that
     // begins there and ends in the next quad continues from.  `tail` = the carries of the previous
@@ -1162,15 +1417,18 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                 uint32_t hi = uint32_t(start + int32_t(l_max));
                 if (lo < 0) lo = 0;
                 if (hi > sc.n) hi = sc.n;
-                // a run that begins where no earlier window's range reaches needs only m_min-1 bytes of
-                // warm-up (everything ending in it starts at or after start-3); a clamped one the full Lmax-1
-                uint32_t entry = kEntryShortWarm;
-                if (nrun > 0 && uint32_t(lo) < run_hi) { lo = int32_t(run_hi); entry = kEntryUnknown; mark_prev(); }  // disjoint, ascending
+                // one run per hit window, tagged with the window's start; where an earlier window's run reaches
+                // into this one's range the run starts at that run's end (disjoint, ascending, adjacent)
+                if (nrun > 0 && uint32_t(lo) < run_hi) lo = int32_t(run_hi);
+                // (a window that begins before the item's first quad was hashed over zeros: not a real window)
+                const uint32_t entry = start >= 0 ? (kEntryWindow | uint32_t(start)) : kEntryUnknown;
                 if (uint32_t(lo) < hi) {
-                    const bool extends = nrun > 0 && run_hi == uint32_t(lo) && stage.mergeable;
                     append_run_wave(B, wave_first, stage, sc.k, uint32_t(lo), hi, entry, nrun, run_hi, lane);
-                    if (!extends) run_entry = entry;
-                    else if (run_entry == kEntryShortWarm) run_entry = kEntryShortWarmMerged;  // append_run_wave marked the slot
+                } else if (nrun > 0 && nrun <= B.run_cap) {
+                    // its whole range lies inside the previous run (both end with the item): that run now stands for
+                    // a window it does not name and must be walked.  The previous run is the last staged entry:
+                    // the stage is only flushed right before an append.
+                    if (lane == 0) stage.slots[stage.count - 1].w = kEntryUnknown;
                 }
             }
         };
@@ -1211,8 +1469,16 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
             // ends at or after head + 16*nq - q + m_min
             uint32_t lo = sc.head + (sc.nq << 4) + m_min;
             lo = lo > q ? lo - q : 0u;
-            if (nrun > 0 && lo < run_hi) { lo = run_hi; if (sc.head + (sc.nq << 4) < sc.n) mark_prev(); }
-            if (lo < sc.n && sc.head + (sc.nq << 4) < sc.n) append_run_wave(B, wave_first, stage, sc.k, lo, sc.n, 0xFFFFFFFFu, nrun, run_hi, lane);
+            if (nrun > 0 && lo < run_hi) lo = run_hi;
+            if (sc.head + (sc.nq << 4) < sc.n) {
+                if (lo < sc.n) {
+                    append_run_wave(B, wave_first, stage, sc.k, lo, sc.n, kEntryUnknown, nrun, run_hi, lane);
+                } else if (nrun > 0 && nrun <= B.run_cap) {
+                    // the previous run already reaches the item's end: it now also stands for the untested windows
+                    // of the tail and must be walked (it is the last staged entry, see flag())
+                    if (lane == 0) stage.slots[stage.count - 1].w = kEntryUnknown;
+                }
+            }
             nrun_vec = lane == sc.k ? nrun : nrun_vec;
         }
         const uint32_t k_before = sc.k;
@@ -1220,8 +1486,6 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
         if (more && sc.k != k_before) {
             nrun = 0;
             run_hi = 0;
-            run_entry = 0;
-            stage.mergeable = false;
             if (sc.head) append_run_wave(B, wave_first, stage, sc.k, 0, (sc.head + l_max) < sc.n ? sc.head + l_max : sc.n, 0u, nrun, run_hi, lane);
         }
         return more;
@@ -1301,7 +1565,7 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_runs(DevAutomaton A, Batc
     if (nr != 0) {
         ItemDesc it;
         unpack_item(rec.x, rec.y, rec.z, rec.w, it);
-        walked = run_epilogue<E, MODE, EXTRA>(A, B, nullptr, smem, tile_rows, item, it, nr);
+        walked = run_epilogue_fast<E, MODE, EXTRA>(A, B, smem, tile_rows, item, it, nr);
     }
     // statistic: bytes walked, one atomic per workgroup (8192 same-address device atomics, one per
     // wave, took 0.1 ms on their own: they serialise at ~12 ns each)

@@ -69,6 +69,12 @@ class FlatTables:
         self.dict = np.ctypeslib.as_array(t.dict_link, shape=(t.n_states,)).astype(np.int64)
         self.cnt = np.ctypeslib.as_array(t.out_count, shape=(t.n_states,)).astype(np.int64)
         _ = dt
+        self.chain_lo = t.chain_lo
+        self.chain_byte = self.chain_run = None
+        if t.compact and t.chain_byte:
+            nchain = self.f2 - t.chain_lo
+            self.chain_byte = np.ctypeslib.as_array(t.chain_byte, shape=(nchain + 16,)).astype(np.int64)
+            self.chain_run = np.ctypeslib.as_array(t.chain_run, shape=(nchain + 16,)).astype(np.int64)
         self.out_off = self.out_list = None
         if t.out_off:
             self.out_off = np.ctypeslib.as_array(t.out_off, shape=(t.n_states,)).astype(np.int64)

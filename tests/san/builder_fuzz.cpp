@@ -106,6 +106,23 @@ void walk(const FlatAutomaton &fa, const uint8_t *text, size_t n, int find_all, 
     }
 }
 
+// slot of a window in the fingerprint table (as kernels.hip verify_candidate finds it), or -1
+long anchor_slot(const FlatAutomaton &fa, const uint8_t *window) {
+    uint32_t words[4] = {0, 0, 0, 0};
+    std::memcpy(words, window, fa.anchor_q);
+    const uint32_t h = anchor_hash(words, fa.anchor_q / 4, fa.anchor_mul);
+    if (fa.anchor_mode == 2) {
+        const uint16_t fp = uint16_t((h >> 16) | 1u);
+        const size_t bucket = h & ((1u << fa.anchor_bucket_bits) - 1u);
+        for (int i = 0; i < 8; ++i) if (fa.anchor_table[bucket * 8 + i] == fp) return long(bucket * 8 + i);
+        return -1;
+    }
+    const uint16_t fp = uint16_t(h >> 16);
+    const size_t bucket = (h >> 3) & (kAnchorBuckets - 1);
+    for (int i = 0; i < 4; ++i) if (fa.anchor_table[bucket * 4 + i] == fp) return long(bucket * 4 + i);
+    return -1;
+}
+
 bool anchor_probe(const FlatAutomaton &fa, const uint8_t *window) {
     uint32_t words[4] = {0, 0, 0, 0};
     std::memcpy(words, window, fa.anchor_q);
@@ -205,6 +222,31 @@ int run_case(uint64_t seed, bool verbose) {
                     std::fprintf(stderr, "seed %llu: anchor false negative\n", (unsigned long long)seed);
                     bad = 1;
                 }
+        }
+        // verification pairs: a slot either names exactly the (pattern, offset) whose q-gram it holds, or nothing
+        size_t named = 0;
+        for (size_t pi = 0; pi < aut.patterns().size() && !fa.anchor_slot_pair.empty(); ++pi) {
+            const PatternMeta &m = aut.patterns()[pi];
+            if (!m.accepted) continue;
+            for (uint32_t off = 0; off < 4; ++off) {
+                const long slot = anchor_slot(fa, aut.pattern_bytes().data() + m.byte_off + off);
+                if (slot < 0) { std::fprintf(stderr, "seed %llu: no slot\n", (unsigned long long)seed); bad = 1; continue; }
+                const uint32_t pair = fa.anchor_slot_pair[size_t(slot)];
+                if (pair == kNone) continue;
+                const uint32_t *rec = &fa.anchor_pairs[size_t(pair) * 4];
+                const uint32_t st = rec[3];
+                // the slot's pair must be THIS pattern at THIS offset (else some other pattern shares the q-gram and
+                // the slot had to be unnamed), with its length, bytes and final state
+                if (rec[0] != pi || (rec[1] & 0xffu) != off || (rec[1] >> 8) != m.length || rec[2] != m.byte_off ||
+                    st >= fa.n_states || fa.own_pattern[st] != pi) {
+                    std::fprintf(stderr, "seed %llu: verification pair of pattern %zu offset %u is wrong\n", (unsigned long long)seed, pi, off);
+                    bad = 1;
+                }
+                ++named;
+            }
+        }
+        (void)named;
+        {
         }
     }
     // haystacks: alphabet text (sometimes with bytes outside it) with planted patterns

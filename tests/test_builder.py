@@ -53,6 +53,16 @@ def test_tables_match_oracle(name, lds, compact):
             assert single.size > 0
             nxt = ft.cold_rec[single, 0] >> 8
             assert np.mean(nxt == single + 1) > 0.5
+        if ft.chain_byte is not None:
+            # the bulk-compare arrays restate the records: edge byte, and the run of "child == id + 1" states
+            ids = np.arange(ft.chain_lo, ft.f2)
+            assert np.all(code[ids] == 1) and np.all((ft.cold_rec[ids, 0] & 0xFF) == ft.chain_byte[:ids.size])
+            consecutive = ((ft.cold_rec[ids, 0] >> 8) == ids + 1) & (ids + 1 < ft.f2)
+            run = np.zeros(ids.size + 1, np.int64)
+            for k in range(ids.size - 1, -1, -1):
+                run[k] = min(255, 1 + run[k + 1]) if consecutive[k] else 0
+            assert np.array_equal(run[:-1], ft.chain_run[:ids.size])
+            assert np.all(ft.chain_byte[ids.size:] == 0) and np.all(ft.chain_run[ids.size:] == 0)
     # numbering invariants the kernels rely on
     assert 0 < ft.f1 <= ft.trap < ft.n_states and ft.trap < ft.f2 <= ft.n_states
     assert np.all(ft.lds <= ft.trap)                      # tile never points outside itself

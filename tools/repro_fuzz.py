@@ -31,7 +31,7 @@ for lo in range(0, len(pats), step):
 opts = dict(kernel=int(r.choice([0, 1, 2, 2, 3, 3, 4, 4])), walk_group=int(r.choice([1, 4, 8])), ilp=int(r.choice([1, 2])), group_quads=int(r.choice([4, 8])),
             chunk_bytes=int(r.choice([0, 0, 16, 48, 256, 1024, 4096])), slab_events=int(r.choice([1, 2, 8])),
             run_cap=int(r.choice([1, 2, 8])), persistent=int(r.choice([-1, 0, 1])), lds_bytes=int(r.choice([2048, 8192, 65536, 163000])),
-            small_path=int(r.choice([0, 1])), refill=int(r.choice([0, 1, 2, 2])), max_flat_outputs=int(r.choice([0, 1 << 25, 1 << 25])), compact=int(r.choice([-1, 0, 1, 1])), early_stop=int(r.choice([0, 1, 2, 2])))
+            small_path=int(r.choice([0, 1])), refill=int(r.choice([0, 1, 2, 2])), max_flat_outputs=int(r.choice([0, 1 << 25, 1 << 25])), compact=int(r.choice([-1, 0, 1, 1])), early_stop=int(r.choice([0, 1, 2, 2])), verify=int(r.choice([0, 1, 1])), dense_bytes=int(r.choice([0, 4096, 1 << 22])))
 opts.update({k: int(v) for k, v in over.items()})
 print(dict(alpha=alpha, lmin=lmin, lmax=lmax, n_pat=n_pat, n_hay=n_hay, hmax=hmax, plants=plants, calls=calls), opts)
 print("haystack lengths", np.diff(ds.hay_off.astype(np.int64))[:10], "pattern lengths min/max", np.diff(ds.pat_off.astype(np.int64)).min(), np.diff(ds.pat_off.astype(np.int64)).max())
