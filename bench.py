@@ -99,7 +99,7 @@ def dense_leg(torch, api, batch, synth, dev, nh=4096, k=16):
     acmi_match_batch_device on a resident batch.  Write-bound: the rate is set against the same 8 TB/s."""
     ds = synth.g3(n_hay=1, hay_len=HAY_LEN, k=k)
     res = api.ahocorasick_init([{"id": i, "value": ds.pattern(i)} for i in range(ds.n_patterns)])
-    res.set_option("profile", 1)
+    res.set_option("profile", 2)
     d_blob = torch.from_numpy(ds.hay_blob).to(dev).repeat(nh).contiguous()
     d_off = torch.arange(nh + 1, dtype=torch.int64, device=dev) * HAY_LEN
     batch.bind_current_stream(res)
@@ -120,6 +120,160 @@ def dense_leg(torch, api, batch, synth, dev, nh=4096, k=16):
     return out
 
 
+def _timed_calls(torch, batch, res, d_blob, d_off, calls=6, skip=2):
+    """Whole acmi_match_batch_device calls on a resident batch: (mean host ms per call, mean scan-kernel ms, mean
+    walk-kernel ms, records) over the calls after `skip` (the first ones grow workspaces and probe kernels)."""
+    ms, scan, walk, total = [], [], [], 0
+    for i in range(calls):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        total = batch.match_device(res, d_blob, d_off, True)
+        dt = time.perf_counter() - t0
+        if i >= skip:
+            ms.append(dt * 1e3)
+            scan.append(res.stat("scan_ms"))
+            walk.append(res.stat("walk_ms"))
+    return float(np.mean(ms)), float(np.mean(scan)), float(np.mean(walk)), total
+
+
+KERNEL_NAMES = {0: "k_scan_simple", 1: "k_scan_lds", 2: "k_scan_anchor", 4: "k_walk_items", 5: "k_match_small"}
+
+
+def _leg_summary(workload, blob_bytes, nh, total, ms, scan, walk, res, ok):
+    algo = blob_bytes + 16 * total + 8 * nh  # SURVEY 8(d): 1 B per haystack byte + 16 B per record + 8 B per haystack
+    return {"workload": workload, "kernel": KERNEL_NAMES.get(int(res.stat("kernel_used")), "?"),
+            "ms_per_call": round(ms, 4), "scan_kernel_ms": round(scan, 4), "walk_kernel_ms": round(walk, 4),
+            "haystack_GB_per_s": round(blob_bytes / ms / 1e6, 1), "records": int(total), "check_ok": bool(ok),
+            "algorithmic_bytes": int(algo), "frac_scan_kernel": round(algo / (scan * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "frac_scan_plus_walk": round(algo / ((scan + walk) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "frac_whole_call": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+
+def config3_leg(torch, api, batch, synth, dev, nh=1 << 20):
+    """BASELINE configs[2]: 65,536 patterns of 8..64 B over Sigma=256 (2.27 M states, seed 7: the G6 automaton),
+    2^20 haystacks x 4 KiB = 4 GiB resident, one planted pattern per haystack.  Check: every haystack's plant is
+    reported at its place (pattern, start and end), and the tile's record count repeats."""
+    tile_h, hl = 4096, 4096
+    ds = synth.g6(n_hay=tile_h, hay_len=hl)
+    t0 = time.perf_counter()
+    res = api.ahocorasick_init([{"id": k, "value": ds.pattern(k)} for k in range(ds.n_patterns)])
+    api.ahocorasick_finalize(res)
+    build_ms = (time.perf_counter() - t0) * 1e3
+    res.set_option("profile", 2)
+    reps = max(1, nh // tile_h)
+    nh = reps * tile_h
+    d_blob = torch.from_numpy(ds.hay_blob).to(dev).repeat(reps).contiguous()
+    d_off = torch.arange(nh + 1, dtype=torch.int64, device=dev) * hl
+    batch.bind_current_stream(res)
+    ms, scan, walk, total = _timed_calls(torch, batch, res, d_blob, d_off)
+    prefix, rec = batch.result_numpy(res, nh, total)
+    # plants of synth.g6: hay[h][(37 h + 11) mod (hl - 64) ...) = pattern (1021 h + 17) mod 65536, h within the tile
+    h = np.arange(tile_h, dtype=np.int64)
+    pat = (1021 * h + 17) % ds.n_patterns
+    start = (37 * h + 11) % (hl - 64)
+    plen = np.diff(ds.pat_off.astype(np.int64))[pat]
+    want = np.stack([h, start + plen, start, pat], axis=1).astype(np.uint32)
+    first_tile = rec[:int(prefix[tile_h])]
+    have = set(map(tuple, first_tile.tolist()))
+    ok = all(tuple(w) in have for w in want.tolist()) and total == int(prefix[tile_h]) * reps and int(prefix[-1]) == total
+    out = _leg_summary(f"65,536 patterns of 8..64 B (Sigma=256, seed 7: 2,269,830 states) over {nh} haystacks x {hl} B "
+                       f"({nh * hl >> 20} MiB), one planted pattern per haystack; BASELINE configs[2] shape",
+                       nh * hl, nh, total, ms, scan, walk, res, ok)
+    out.update({"automaton_build_ms": round(build_ms, 1), "automaton_bytes": int(res.stat("automaton_bytes")),
+                "compact": int(res.stat("compact")), "anchor_keys": int(res.stat("anchor_keys"))})
+    api.ahocorasick_deinit(res)
+    del d_blob
+    return out
+
+
+def general_leg(torch, api, batch, res_patterns, d_blob, d_off, nh, expect_records):
+    """The headline batch through the general path north_star describes (LDS-tile table walk, k_scan_lds):
+    what a pattern set that is not eligible for the anchor filter gets."""
+    res = api.ahocorasick_init(res_patterns)
+    res.set_option("kernel", 1)
+    res.set_option("profile", 2)
+    batch.bind_current_stream(res)
+    ms, scan, walk, total = _timed_calls(torch, batch, res, d_blob, d_off, calls=5, skip=2)
+    out = _leg_summary("the headline batch with kernel=1 (LDS-tile table walk)", d_blob.numel(), nh, total, ms, scan, walk, res,
+                       total == expect_records)
+    api.ahocorasick_deinit(res)
+    return out
+
+
+def keywords_leg(torch, api, batch, synth, dev, nh=1 << 17):
+    """Keyword-like set (the use the reference's README sells): 2,048 patterns of 4..12 letters over text of letters
+    and spaces, 2^17 haystacks x 8 KiB = 1 GiB; automatic kernel choice.  Check against the CPU oracle on the first
+    64 haystacks of the tile."""
+    alpha = bytes(range(ord("a"), ord("z") + 1)) + b"     "
+    ds = synth.generate("words", 33, 2048, 4, 12, 8192, HAY_LEN, alpha)
+    res = api.ahocorasick_init([{"id": k, "value": p} for k, p in enumerate(ds.patterns())])
+    res.set_option("profile", 2)
+    d_blob = torch.from_numpy(ds.hay_blob).to(dev).repeat(nh // 8192).contiguous()
+    d_off = torch.arange(nh + 1, dtype=torch.int64, device=dev) * HAY_LEN
+    batch.bind_current_stream(res)
+    first_kernel = None
+    ms, scan, walk, total = [], [], [], 0
+    for i in range(5):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        total = batch.match_device(res, d_blob, d_off, True)
+        dt = time.perf_counter() - t0
+        if first_kernel is None:
+            first_kernel = int(res.stat("kernel_used"))
+        if i >= 2:
+            ms.append(dt * 1e3); scan.append(res.stat("scan_ms")); walk.append(res.stat("walk_ms"))
+    prefix, rec = batch.result_numpy(res, nh, total)
+    from oracle import pyoracle
+    o = pyoracle.Oracle("port")
+    o.add_patterns((ds.pat_blob, ds.pat_off))
+    n_chk = 64
+    pe, re_ = o.match_batch(ds.hay_blob[:int(ds.hay_off[n_chk])], ds.hay_off[:n_chk + 1], True)
+    ok = np.array_equal(prefix[:n_chk + 1], pe) and np.array_equal(rec[:int(pe[-1])], re_) and total == int(prefix[8192]) * (nh // 8192)
+    out = _leg_summary(f"2,048 patterns of 4..12 letters over letters + spaces, {nh} haystacks x {HAY_LEN} B ({nh * HAY_LEN >> 20} MiB)",
+                       nh * HAY_LEN, nh, total, float(np.mean(ms)), float(np.mean(scan)), float(np.mean(walk)), res, ok)
+    out["first_batch_kernel"] = KERNEL_NAMES.get(first_kernel, "?")
+    out["records_per_haystack"] = round(total / nh, 2)
+    api.ahocorasick_deinit(res)
+    return out
+
+
+def host_leg(api, synth, ds, expect_per_tile):
+    """The host-buffer entry the Zend shim calls (acmi_match_batch: borrowed host memory in, host records out):
+    PCIe-inclusive rate on a 512 MiB batch, the literal 256 x 8 KiB batch of BASELINE configs[1] as ONE call, and
+    single ahocorasick_match calls of 8 KiB (examples/benchmark.php:65-67 loops over these)."""
+    res = api.ahocorasick_init([{"id": k, "value": ds.pattern(k)} for k in range(ds.n_patterns)])
+    nh = 1 << 16
+    blob = np.tile(ds.hay_blob, nh // TILE_HAYSTACKS)
+    off = np.arange(nh + 1, dtype=np.uint64) * HAY_LEN
+    api.match_arrays(res, blob, off)
+    best = 1e9
+    n_rec = 0
+    for _ in range(3):
+        t0 = time.perf_counter()
+        prefix, rec = api.match_arrays(res, blob, off)
+        best = min(best, time.perf_counter() - t0)
+        n_rec = len(rec)
+    lit_blob, lit_off = ds.hay_blob[:256 * HAY_LEN], off[:257]
+    api.match_arrays(res, lit_blob, lit_off)
+    lit = []
+    for _ in range(20):
+        t0 = time.perf_counter()
+        p2, r2 = api.match_arrays(res, lit_blob, lit_off)
+        lit.append(time.perf_counter() - t0)
+    one = ds.haystack(3)
+    api.ahocorasick_match(one, res)
+    t0 = time.perf_counter()
+    for _ in range(200):
+        api.ahocorasick_match(one, res)
+    single = (time.perf_counter() - t0) / 200
+    out = {"batch_512MiB": {"GB_per_s_pcie_inclusive": round(blob.nbytes / best / 1e9, 2), "ms": round(best * 1e3, 2), "records": n_rec,
+                            "check_ok": bool(n_rec == expect_per_tile * (nh // TILE_HAYSTACKS))},
+           "literal_256x8KiB_one_call_ms": round(float(np.median(lit)) * 1e3, 4), "literal_records": len(r2),
+           "single_match_8KiB_us": round(single * 1e6, 1)}
+    api.ahocorasick_deinit(res)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,6 +286,7 @@ def main():
     ap.add_argument("--no-plant", action="store_true", help="analysis only: no planted hits (the reference's own benchmark has ~0 matches)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-dense", action="store_true", help="skip the secondary BASELINE configs[4] (dense-match) measurement")
+    ap.add_argument("--no-legs", action="store_true", help="skip the other secondary legs (config 3, general path, keyword set, host-buffer entry)")
     ap.add_argument("--phase-times", action="store_true", help="analysis: add the host time per step phase to the JSON")
     args = ap.parse_args()
 
@@ -203,6 +358,7 @@ def main():
 
     pending = []
     scan_ms = []
+    walk_ms = []
     records_per_step = 0
 
     ready = []   # (records view, count) of the batch collected last: shipped after the next scan is enqueued
@@ -253,6 +409,7 @@ def main():
         step()
     drain()
     scan_ms.clear()
+    walk_ms.clear()
     for k_ in phase:
         phase[k_] = 0.0
     if gather:
@@ -271,6 +428,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
+    # the candidate walk (second kernel of a step) timed with its own events on a few extra, untimed steps: every
+    # event is a barrier on the stream, the timed region carries only the two around the scan kernel
+    res.set_option("profile", 2)
+    for _ in range(5):
+        batch.match_device(res, d_blob, d_off, True)
+        walk_ms.append(res.stat("walk_ms"))
+    res.set_option("profile", 1)
+
     # sanity: every haystack carries its planted record; the tile's count repeats
     prefix, rec = batch.result_numpy(res, nh, records_per_step)
     ok = (args.no_plant or records_per_step >= nh) and int(prefix[-1]) == records_per_step
@@ -281,6 +446,7 @@ def main():
 
     if rank == 0:
         kernel_ms = float(np.mean(scan_ms)) if scan_ms else float("nan")
+        walk_kernel_ms = float(np.mean(walk_ms)) if walk_ms else 0.0
         algo_bytes = bytes_per_step + 16 * records_per_step + 8 * nh
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
@@ -307,12 +473,25 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": {1: "k_scan_lds", 2: "k_scan_anchor", 0: "k_scan_simple", 4: "k_walk_items"}.get(int(res.stat("kernel_used")), "?"), "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes": algo_bytes,
+                         "walk_kernel_ms": round(walk_kernel_ms, 4),
+                         "frac_scan_plus_walk": round(algo_bytes / ((kernel_ms + walk_kernel_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "frac_whole_step": round(algo_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                         "step_minus_kernels_us": round((dt / args.steps * 1e3 - kernel_ms - walk_kernel_ms) * 1e3, 1),
                          "measured_stream_read_GBs": round(stream_read_gbs, 1),
                          "frac_of_measured_stream_read": round(achieved / stream_read_gbs, 4)},
             "cpu_baseline": cpu1, "cpu_baseline_all_cores": cpu_all,
         }
         if world == 1 and not args.no_dense:
             out["config5_dense"] = dense_leg(torch, api, batch, synth, dev)
+        if world == 1 and not args.no_legs:
+            # secondary figures, measured outside the timed region on the same GPU, same process
+            pats = [{"id": k, "value": ds.pattern(k)} for k in range(ds.n_patterns)]
+            out["general_path"] = general_leg(torch, api, batch, pats, d_blob, d_off, nh, records_per_step)
+            out["host_entry"] = host_leg(api, synth, ds, tile_count)
+            del d_blob
+            torch.cuda.empty_cache()
+            out["keyword_set"] = keywords_leg(torch, api, batch, synth, dev)
+            out["config3"] = config3_leg(torch, api, batch, synth, dev)
         if args.phase_times:
             out["host_us_per_step"] = {k: round(v / args.steps * 1e6, 1) for k, v in phase.items()}
         print(json.dumps(out), flush=True)

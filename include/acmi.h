@@ -231,7 +231,8 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *   "refill"         drain of work items whose events overflowed their slab (dense-match inputs):
  *                    1 = one thread per item, 2 = one wave per item with whole-row record stores,
  *                    0 = automatic (default): 2 unless the longest pattern exceeds 64 B   [any time]
- *   "profile"        1 = bracket the scan kernel with HIP events         [any time] */
+ *   "profile"        1 = bracket the scan kernel with HIP events ("scan_ms"); 2 = also the candidate walk ("walk_ms")
+ *                    and the whole pipeline ("total_ms") -- every event is a barrier on the stream   [any time] */
 int acmi_set_option(acmi_handle *h, const char *key, int64_t value);
 
 /* Numeric facts about the automaton and the last match call, e.g. "states",

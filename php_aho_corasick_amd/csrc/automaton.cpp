@@ -487,7 +487,6 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
             for (int attempt = 0; attempt < 512 && fa.anchor_q == 0; ++attempt, mul = mul * 0x2545F491u + 0x6B43A9B5u) {
                 mul = (mul | 1u) & 0xFFFFFFu;
                 std::vector<uint8_t> used(kAnchorBuckets, 0);
-                std::vector<uint32_t> slot_pair(size_t(kAnchorBuckets) * 4, kNone);
                 for (uint32_t b = 0; b < kAnchorBuckets; ++b) std::fill_n(&tab[size_t(b) * 4], 4, anchor_empty(b));
                 bool ok = true;
                 for (size_t ki = 0; ki < keys.size(); ++ki) {
@@ -498,8 +497,22 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
                     uint32_t slot = 0;
                     while (slot < used[bucket] && b[slot] != fp) ++slot;
                     if (slot == 4) { ok = false; break; }  // bucket overflow: take another seed
-                    if (slot == used[bucket]) { b[used[bucket]++] = fp; slot_pair[size_t(bucket) * 4 + slot] = key_pair[ki]; }
-                    else slot_pair[size_t(bucket) * 4 + slot] = kNone;  // two q-grams, one fingerprint: not verifiable
+                    if (slot == used[bucket]) b[used[bucket]++] = fp;
+                }
+                std::vector<uint32_t> slot_pair;
+                if (ok) {  // which slot names which pair: the same insertion replayed (only for the seed that is kept)
+                    slot_pair.assign(size_t(kAnchorBuckets) * 4, kNone);
+                    std::vector<uint8_t> seen(size_t(kAnchorBuckets) * 4, 0);
+                    for (size_t ki = 0; ki < keys.size(); ++ki) {
+                        const uint32_t h = anchor_hash(keys[ki].data(), q / 4, mul);
+                        const uint16_t fp = uint16_t(h >> 16);
+                        const uint32_t bucket = (h >> 3) & (kAnchorBuckets - 1);
+                        uint32_t slot = 0;
+                        while (tab[size_t(bucket) * 4 + slot] != fp) ++slot;
+                        const size_t at = size_t(bucket) * 4 + slot;
+                        slot_pair[at] = seen[at] ? kNone : key_pair[ki];  // two q-grams, one fingerprint: not verifiable
+                        seen[at] = 1;
+                    }
                 }
                 if (ok) {
                     fa.anchor_q = q;

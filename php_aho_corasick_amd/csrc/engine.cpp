@@ -103,10 +103,11 @@ struct acmi_handle {
     DevBuf d_table, d_lds, d_class, d_own, d_dict, d_cnt, d_plen, d_anchor, d_bitmap, d_out_off, d_out_list, d_cold_rec, d_cold_edges, d_chain_byte, d_chain_run, d_slot_pair, d_pairs, d_pat_bytes;
 
     // workspace (grow-only)
-    DevBuf d_blob, d_off, d_nitems, d_item_base, d_item_hay, d_item_rec, d_zero, d_rec_base, d_slab, d_ovf, d_counters,
-        d_scan_tmp, d_prefix, d_out, d_runs, d_run_count,
+    DevBuf d_blob, d_off, d_item_base, d_item_hay, d_item_rec, d_zero, d_rec_base, d_slab, d_ovf, d_counters,
+        d_prefix, d_out, d_runs, d_run_count,
         d_prefix_alt, d_out_alt;  // result buffers alternate: a batch's records stay valid while the next one runs
-    uint64_t *pinned = nullptr;  // host copy of the device counters block (64 B)
+    uint64_t *pinned = nullptr;  // host copy of the device counters block (64 B), written by k_expand through pinned_dev
+    uint32_t *pinned_dev = nullptr;
 
     // last result
     uint64_t last_total = 0;
@@ -121,6 +122,10 @@ struct acmi_handle {
     uint64_t fly_max_items = 0, fly_blob_bytes = 0;
     int fly_find_all = 1;
     bool fly_trivial = false;
+    uint32_t *fly_sync_next = nullptr;
+    uint32_t fly_sync_words = 0;
+    DevBuf d_sync[2];          // counters, scan tickets and status words: two copies that take turns (run_batch_begin)
+    uint32_t sync_tiles = 0, sync_turn = 0;
 
     // statistics of the last call
     double scan_ms = 0, walk_ms = 0, total_ms = 0;
@@ -204,7 +209,12 @@ int ensure_device(acmi_handle *h) {
     if (!h->stream) h->stream = h->own_stream;
     for (auto &evt : h->ev)
         if (!evt) HIPCHK(h, hipEventCreate(&evt));
-    if (!h->pinned) HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->pinned), 64, hipHostMallocDefault));
+    if (!h->pinned) {
+        HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->pinned), 64, hipHostMallocMapped));
+        void *dp = nullptr;
+        HIPCHK(h, hipHostGetDevicePointer(&dp, h->pinned, 0));
+        h->pinned_dev = static_cast<uint32_t *>(dp);
+    }
 
     // upload the flat automaton
     const FlatAutomaton &fa = h->aut.flat();
@@ -353,8 +363,19 @@ uint32_t choose_chunk(const acmi_handle *h, uint64_t blob_bytes, int kernel) {
 }
 
 // The batch pipeline on device-resident input, first half: enqueue everything, no host wait.
+int run_batch_begin_impl(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, const uint64_t *d_off, size_t nh,
+                         int find_all);
+
 int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, const uint64_t *d_off, size_t nh,
-              int find_all) {
+                    int find_all) {
+    const int rc = run_batch_begin_impl(h, d_blob, blob_bytes, d_off, nh, find_all);
+    // a pipeline that was not enqueued to its end has not zeroed the next batch's sync block: have both zeroed again
+    if (rc < 0) h->sync_tiles = 0;
+    return rc;
+}
+
+int run_batch_begin_impl(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, const uint64_t *d_off, size_t nh,
+                         int find_all) {
     h->have_result = false;
     // The previous batch's prefix array and records stay untouched by this one (they are valid until the
     // begin after this): a caller can enqueue the next scan first and ship the last result meanwhile.
@@ -368,7 +389,7 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
     HIPCHK(h, h->d_prefix.ensure((nh + 1) * 8));
     h->last_nh = uint32_t(nh);
     h->last_total = 0;
-    if (h->profile) HIPCHK(h, hipEventRecord(h->ev[0], st));
+    if (h->profile > 1) HIPCHK(h, hipEventRecord(h->ev[0], st));
 
     h->in_flight = false;
     if (nh == 0 || h->aut.accepted_count() == 0) {  // empty batch / empty automaton -> no records
@@ -395,24 +416,36 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
     const uint32_t K = std::max<uint32_t>(1, h->slab_events);
     h->chunk_used = chunk;
 
-    HIPCHK(h, h->d_nitems.ensure((nh + 1) * 8));
     HIPCHK(h, h->d_item_base.ensure((nh + 1) * 8));
     HIPCHK(h, h->d_item_hay.ensure(max_items * 4));
     HIPCHK(h, h->d_item_rec.ensure(max_items * 16));
-    // one zero-filled block per call: [counters 64 B | rec_count (items+1) x 8 | ev_count items x 4]
-    const size_t rec_cnt_off = 64, ev_off = rec_cnt_off + (max_items + 1) * 8;
-    const size_t zero_bytes = ev_off + max_items * 4;
-    HIPCHK(h, h->d_zero.ensure(zero_bytes));
+    // per-item counters [rec_count (items+1) x 8 | ev_count items x 4]: zeroed per item by k_items
+    const size_t rec_cnt_off = 0, ev_off = rec_cnt_off + (max_items + 1) * 8;
+    HIPCHK(h, h->d_zero.ensure(ev_off + max_items * 4));
+    // sync block of this batch: [counters 16 x u32 | tickets 2 x u32 | pad | status words of the two scans], one of
+    // two copies that take turns; this batch's k_expand zeroes the other one.  (Re)allocation zeroes both.
+    const uint32_t tiles = std::max(scan_tiles(nh + 1), scan_tiles(max_items + 1)) + 1u;
+    if (tiles > h->sync_tiles || !h->d_sync[0].p) {
+        const uint32_t want = tiles + tiles / 4 + 16;
+        for (DevBuf &b : h->d_sync) {
+            HIPCHK(h, b.ensure(128 + size_t(want) * 16));
+            HIPCHK(h, hipMemsetAsync(b.p, 0, b.cap, st));
+        }
+        h->sync_tiles = want;
+    }
+    const uint32_t sync_words = uint32_t(32 + size_t(h->sync_tiles) * 4);
+    uint32_t *sync_cur = h->d_sync[h->sync_turn & 1].as<uint32_t>();
+    uint32_t *sync_next = h->d_sync[(h->sync_turn + 1) & 1].as<uint32_t>();
+    ++h->sync_turn;
+    uint64_t *status0 = reinterpret_cast<uint64_t *>(sync_cur + 32), *status1 = status0 + h->sync_tiles;
     HIPCHK(h, h->d_rec_base.ensure((max_items + 2) * 8));
     HIPCHK(h, h->d_slab.ensure(max_items * K * 8));
     HIPCHK(h, h->d_ovf.ensure(max_items * 4));
     const uint32_t Q = std::max<uint32_t>(1, h->run_cap);
     HIPCHK(h, h->d_runs.ensure(max_items * Q * 16));
     HIPCHK(h, h->d_run_count.ensure(max_items * 4));
-    HIPCHK(h, h->d_scan_tmp.ensure(scan_temp_elems(std::max<uint64_t>(max_items + 1, nh + 1)) * 8 * 2));
-    HIPCHK(h, hipMemsetAsync(h->d_zero.p, 0, zero_bytes, st));
     uint8_t *zero = h->d_zero.as<uint8_t>();
-    uint32_t *d_counters = reinterpret_cast<uint32_t *>(zero);
+    uint32_t *d_counters = sync_cur;
     uint64_t *d_rec_cnt = reinterpret_cast<uint64_t *>(zero + rec_cnt_off);
     uint32_t *d_ev = reinterpret_cast<uint32_t *>(zero + ev_off);
 
@@ -448,10 +481,8 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
     B.persistent = h->persistent >= 0 ? uint32_t(h->persistent != 0)
                                       : uint32_t(blob_bytes / chunk > 3ull * 256 * 1024 * uint64_t(h->ilp));
 
-    launch_item_base(d_off, uint32_t(nh), chunk, blob_bytes, h->d_nitems.as<uint64_t>(), h->d_item_base.as<uint64_t>(), d_counters,
-                     h->d_scan_tmp.as<uint64_t>(), st);
-
-    launch_build_items(B, max_items, st);
+    // item counts, their scan, the item table, zeroed per-item counters: one launch
+    launch_items(B, blob_bytes, h->d_item_base.as<uint64_t>(), sync_cur + 16, status0, st);
 
     if (h->profile) HIPCHK(h, hipEventRecord(h->ev[1], st));
     if (kernel == 4) {
@@ -464,23 +495,24 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
     if (h->profile) HIPCHK(h, hipEventRecord(h->ev[2], st));
     // the anchor kernel only flags byte runs; their exact walk is a kernel of its own (one thread per item)
     if (kernel == 2) HIPCHK(h, launch_walk_runs(h->dA, B, max_items, int(fa.entry_bytes), int(fa.class_mode), st));
-    if (h->profile) HIPCHK(h, hipEventRecord(h->ev[3], st));
+    if (h->profile > 1) HIPCHK(h, hipEventRecord(h->ev[3], st));
 
     if (!find_all) launch_first_only(B, st);
-    exclusive_scan_u64(d_rec_cnt, h->d_rec_base.as<uint64_t>(), max_items + 1, h->d_scan_tmp.as<uint64_t>(), st);
-    // summary for the host, next to the overflow counter: counters[2..3] = total records, [4..5] = items
-    launch_hay_prefix(h->d_item_base.as<uint64_t>(), h->d_rec_base.as<uint64_t>(), uint32_t(nh),
-                      h->d_prefix.as<uint64_t>(), reinterpret_cast<uint64_t *>(d_counters + 2), st);
+    launch_rec_scan(B, max_items, h->d_rec_base.as<uint64_t>(), sync_cur + 17, status1, st);
 
     // Expansion is enqueued optimistically with the output capacity of the previous call, so the
     // whole pipeline needs ONE host synchronisation (the read-back of the summary at the end).  Only
     // when the batch produced more records than fit is the buffer grown and the expansion re-run.
     HIPCHK(h, h->d_out.ensure(16));
     const uint64_t cap = h->d_out.cap / 16;
-    launch_expand(h->dA, B, max_items, h->d_rec_base.as<uint64_t>(), h->d_out.p, cap, st);
+    // (also: per-haystack prefix, the summary for the host next to the overflow counter -- counters[2..3] = total
+    // records, [4..5] = items -- and the zeroing of the next batch's sync block)
+    launch_expand(h->dA, B, max_items, h->d_rec_base.as<uint64_t>(), h->d_out.p, cap, h->d_prefix.as<uint64_t>(),
+                  h->pinned_dev, sync_next, sync_words, st);
     if (find_all) launch_refill(h->dA, B, max_items, int(fa.entry_bytes), h->d_rec_base.as<uint64_t>(), h->d_out.p, cap, h->refill, st);
-    HIPCHK(h, hipMemcpyAsync(h->pinned, d_counters, 64, hipMemcpyDeviceToHost, st));
-    if (h->profile) HIPCHK(h, hipEventRecord(h->ev[4], st));
+    h->fly_sync_next = sync_next;
+    h->fly_sync_words = sync_words;
+    if (h->profile > 1) HIPCHK(h, hipEventRecord(h->ev[4], st));
     HIPCHK(h, hipGetLastError());
     h->fly_args = B;
     h->fly_max_items = max_items;
@@ -495,7 +527,10 @@ int run_batch_end(acmi_handle *h) {
     if (!h->in_flight) { h->last_error = "no batch in flight"; return ACMI_E_ARG; }
     h->in_flight = false;
     hipStream_t st = h->stream;
-    HIPCHK(h, hipStreamSynchronize(st));
+    {
+        const hipError_t e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { h->sync_tiles = 0; return fail_hip(h, e, "hipStreamSynchronize"); }
+    }
     if (h->fly_trivial) {
         h->have_result = true;
         return ACMI_OK;
@@ -537,15 +572,18 @@ int run_batch_end(acmi_handle *h) {
         float ms = 0;
         HIPCHK(h, hipEventElapsedTime(&ms, h->ev[1], h->ev[2]));
         h->scan_ms = ms;
-        HIPCHK(h, hipEventElapsedTime(&ms, h->ev[2], h->ev[3]));
-        h->walk_ms = h->kernel_used == 2 ? ms : 0.0;
-        HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[4]));
-        h->total_ms = ms;
+        if (h->profile > 1) {
+            HIPCHK(h, hipEventElapsedTime(&ms, h->ev[2], h->ev[3]));
+            h->walk_ms = h->kernel_used == 2 ? ms : 0.0;
+            HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[4]));
+            h->total_ms = ms;
+        }
     }
     if (total > h->d_out.cap / 16) {  // did not fit the optimistic capacity: grow, expand again
         HIPCHK(h, h->d_out.ensure(total * 16));
         const uint64_t cap = h->d_out.cap / 16;
-        launch_expand(h->dA, h->fly_args, h->fly_max_items, h->d_rec_base.as<uint64_t>(), h->d_out.p, cap, st);
+        launch_expand(h->dA, h->fly_args, h->fly_max_items, h->d_rec_base.as<uint64_t>(), h->d_out.p, cap, h->d_prefix.as<uint64_t>(),
+                      h->pinned_dev, h->fly_sync_next, h->fly_sync_words, st);
         if (h->fly_find_all)
             launch_refill(h->dA, h->fly_args, h->fly_max_items, int(fa.entry_bytes), h->d_rec_base.as<uint64_t>(),
                           h->d_out.p, cap, h->refill, st);
@@ -709,8 +747,8 @@ int acmi_destroy(acmi_handle *h) {
             (void)hipSetDevice(h->dev_id);
             if (h->stream) (void)hipStreamSynchronize(h->stream);
             for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_out_off, &h->d_out_list, &h->d_cold_rec, &h->d_cold_edges, &h->d_chain_byte, &h->d_chain_run, &h->d_slot_pair, &h->d_pairs, &h->d_pat_bytes, &h->d_blob,
-                              &h->d_off, &h->d_nitems, &h->d_item_base, &h->d_item_hay, &h->d_item_rec, &h->d_zero,
-                              &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_scan_tmp, &h->d_prefix, &h->d_out, &h->d_runs, &h->d_run_count, &h->d_prefix_alt, &h->d_out_alt})
+                              &h->d_off, &h->d_sync[0], &h->d_sync[1], &h->d_item_base, &h->d_item_hay, &h->d_item_rec, &h->d_zero,
+                              &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_prefix, &h->d_out, &h->d_runs, &h->d_run_count, &h->d_prefix_alt, &h->d_out_alt})
                 b->release();
             for (auto &evt : h->ev)
                 if (evt) (void)hipEventDestroy(evt);
@@ -968,7 +1006,8 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
             if (value < 0 || value > 2) return ACMI_E_ARG;
             h->refill = int(value);
         } else if (k == "profile") {
-            h->profile = value ? 1 : 0;
+            if (value < 0 || value > 2) return ACMI_E_ARG;
+            h->profile = int(value);
         } else if (k == "compact") {
             if (h->aut.finalized()) return ACMI_E_FINALIZED;
             h->bopt.compact = value < 0 ? -1 : (value ? 1 : 0);

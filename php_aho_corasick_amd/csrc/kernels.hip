@@ -48,19 +48,6 @@ struct ItemDesc {
     uint32_t hay;
 };
 
-// Work item i -> haystack, by binary search.  item_base is non-decreasing; empty haystacks own
-// no item.  Done once per item by k_build_items; the scan kernels read item_hay[] instead.
-__device__ __forceinline__ uint32_t find_haystack(const BatchArgs &B, uint64_t i) {
-    // one item per haystack and no empty ones before it (the usual batch): haystack i, two loads instead of ~20
-    if (i < B.n_haystacks && B.item_base[i] <= i && i < B.item_base[i + 1]) return uint32_t(i);
-    uint32_t lo = 0, hi = B.n_haystacks;  // item_base[lo] <= i < item_base[hi]
-    while (hi - lo > 1) {
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        if (B.item_base[mid] <= i) lo = mid; else hi = mid;
-    }
-    return lo;
-}
-
 // Work item i -> (haystack, chunk) given its haystack index.
 __device__ __forceinline__ bool decode_item(const BatchArgs &B, uint64_t i, ItemDesc &it) {
     if (i >= B.item_base[B.n_haystacks]) return false;
@@ -134,15 +121,6 @@ __device__ __forceinline__ uint32_t anchor_mad(uint32_t h, uint32_t mul, uint32_
     uint32_t r;  // spelled out: from `__umul24(h, mul) + f` hipcc makes a quarter-rate v_mad_u64_u32 half of the time
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(h), "s"(mul), "v"(f));
     return r;
-}
-
-__global__ void k_build_items(BatchArgs B) {
-    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= B.item_base[B.n_haystacks]) return;
-    B.item_hay[i] = find_haystack(B, i);
-    ItemDesc it;
-    decode_item(B, i, it);
-    B.item_rec[i] = pack_item(it);
 }
 
 __device__ __forceinline__ bool is_final(const DevAutomaton &A, uint32_t s) {
@@ -227,173 +205,80 @@ __device__ __forceinline__ uint32_t exact_bytes(const DevAutomaton &A, const Bat
 }
 
 // ------------------------------------------------------------------------------------------
-// k_count_items: work items per haystack
-// ------------------------------------------------------------------------------------------
-// Also validates what the host cannot see for device-resident offsets: decreasing offsets, a haystack of
-// 4 GiB or more (positions are 32-bit) or one that ends past the blob (every per-item workspace is sized
-// from blob_bytes) raise counters[6], and that haystack gets no item.
-__global__ void k_count_items(const uint64_t *offsets, uint32_t nh, uint32_t chunk, uint64_t blob_bytes, uint64_t *n_items,
-                              uint32_t *counters) {
-    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h > nh) return;
-    if (h == nh) { n_items[h] = 0; return; }
-    const uint64_t lo = offsets[h], hi = offsets[h + 1];
-    if (hi < lo || hi - lo >= 0xFFFFFFFFull || hi > blob_bytes) {
-        counters[6] = 1u;
-        n_items[h] = 0;
-        return;
-    }
-    n_items[h] = (hi - lo + chunk - 1) / chunk;
-}
-
-// ------------------------------------------------------------------------------------------
-// exclusive scan of uint64 (three small kernels, recursive on the block sums)
+// Single-pass prefix sums (decoupled look-back) for the two scans of the pipeline.
+//
+// The batch pipeline used to open with five launches (zero block, tile sums, tile scan, item table) and close
+// with four more (tile sums, tile scan, haystack prefix, expansion): 5-9 us each, dependent, host-paced -- 10 %
+// of a 0.86 ms step and all of a small batch.  Now
+//   k_items      item counts per haystack from the offsets (validated), their exclusive scan, the item table
+//                (item -> haystack, packed item records) and the zeroed per-item counters: one launch;
+//   k_rec_scan   exclusive scan of the per-item record counts: one launch;
+//   k_expand     also writes the per-haystack prefix array, the batch summary, and zeroes the NEXT batch's sync block.
+// A tile (2048 elements, one workgroup) takes a ticket, sums its elements, publishes {aggregate}, adds up the
+// tiles before it by looking back until it meets a published {inclusive prefix}, publishes its own, and writes
+// its results.  Status words are 64-bit {flag:2 | value:62}, written and read with relaxed agent-scope atomics
+// (8-byte atomics on both sides need no further ordering; tickets make the look-back deadlock-free whatever the
+// dispatch order).  The sync block -- counters, tickets, status words -- alternates between two copies; the
+// last pipeline kernel of a batch zeroes the other copy, so no memset is launched.
 // ------------------------------------------------------------------------------------------
 constexpr int kScanThreads = 256;
 constexpr int kScanPerThread = 8;
 constexpr int kScanTile = kScanThreads * kScanPerThread;
+constexpr uint64_t kChainAgg = 1ull << 62, kChainInc = 2ull << 62, kChainVal = (1ull << 62) - 1;
 
-__global__ void k_scan_tiles(const uint64_t *in, uint64_t *out, uint64_t n, uint64_t *tile_sums) {
-    __shared__ uint64_t wave_sums[kScanThreads / 64];
-    const uint64_t base = uint64_t(blockIdx.x) * kScanTile + uint64_t(threadIdx.x) * kScanPerThread;
-    uint64_t v[kScanPerThread];
-    uint64_t sum = 0;
-#pragma unroll
-    for (int i = 0; i < kScanPerThread; ++i) {
-        v[i] = base + i < n ? in[base + i] : 0;
-        sum += v[i];
-    }
-    // inclusive scan of `sum` across the wave, then across the block's 4 waves
-    uint64_t inc = sum;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint64_t t = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += t;
-    }
-    if (lane == 63) wave_sums[wave] = inc;
-    __syncthreads();
-    uint64_t wave_base = 0;
-    for (int w = 0; w < wave; ++w) wave_base += wave_sums[w];
-    uint64_t run = wave_base + inc - sum;
-#pragma unroll
-    for (int i = 0; i < kScanPerThread; ++i) {
-        if (base + i < n) out[base + i] = run;
-        run += v[i];
-    }
-    if (threadIdx.x == kScanThreads - 1) tile_sums[blockIdx.x] = wave_base + inc;
+__device__ __forceinline__ uint64_t chain_load(const uint64_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void chain_store(uint64_t *p, uint64_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ void k_scan_add(uint64_t *out, uint64_t n, const uint64_t *tile_base) {
-    const uint64_t i = uint64_t(blockIdx.x) * kScanTile + threadIdx.x;
-    const uint64_t add = tile_base[blockIdx.x];
-#pragma unroll
-    for (int r = 0; r < kScanPerThread; ++r) {
-        const uint64_t j = i + uint64_t(r) * kScanThreads;
-        if (j < n) out[j] += add;
-    }
-}
-
-size_t scan_temp_elems(uint64_t n) {
-    size_t total = 0;
-    while (n > 1) {
-        n = (n + kScanTile - 1) / kScanTile;
-        total += n + 1;
-        if (n == 1) break;
-    }
-    return total + 2;
-}
-
-// out[i] = sum(in[0..i)) for i < n.  `temp` needs scan_temp_elems(n) uint64.  General form: three
-// launches per level, recursive on the tile sums.
-static void exclusive_scan_recursive(const uint64_t *in, uint64_t *out, uint64_t n, uint64_t *temp, hipStream_t st) {
-    if (n == 0) return;
-    const uint64_t tiles = (n + kScanTile - 1) / kScanTile;
-    uint64_t *sums = temp;
-    hipLaunchKernelGGL(k_scan_tiles, dim3(uint32_t(tiles)), dim3(kScanThreads), 0, st, in, out, n, sums);
-    if (tiles > 1) {
-        uint64_t *sums_scanned = sums;  // scanned in place
-        exclusive_scan_recursive(sums, sums_scanned, tiles, temp + tiles + 1, st);
-        hipLaunchKernelGGL(k_scan_add, dim3(uint32_t(tiles)), dim3(kScanThreads), 0, st, out, n, sums_scanned);
-    }
-}
-
-// Two-launch form for up to kScanMaxTiles tiles (8.4 M elements): tile sums, then every tile adds up
-// the sums of the tiles before it on its own (at most 4096 values) and scans its elements.  The batch
-// pipeline is a chain of small dependent kernels, ~7 us each launch-to-launch; this form and the
-// fused item count below take 3 of them out.  Element i of the input is in[i], or, for COUNT, the
-// number of work items of haystack i computed from the offsets on the fly (k_count_items' rule).
-constexpr uint64_t kScanMaxTiles = 4096;
-
-struct ScanSource {
-    const uint64_t *in;        // plain input, or null
-    const uint64_t *offsets;   // COUNT: haystack offsets (n = n_haystacks + 1 elements, the last one 0)
-    uint32_t chunk;
-    uint32_t *counters;        // COUNT: counters[6] = 1 on a malformed offset
-    uint64_t blob_bytes;       // COUNT: no haystack may end past the blob
-};
-
-template <bool COUNT>
-__device__ __forceinline__ uint64_t scan_element(const ScanSource &S, uint64_t i, uint64_t n) {
-    if (i >= n) return 0;
-    if (!COUNT) return S.in[i];
-    if (i + 1 == n) return 0;  // element n_haystacks: sentinel
-    const uint64_t lo = S.offsets[i], hi = S.offsets[i + 1];
-    if (hi < lo || hi - lo >= 0xFFFFFFFFull || hi > S.blob_bytes) {
-        S.counters[6] = 1u;
+// The first WAVE of a workgroup (all 64 lanes call): publish this tile's sum, return the sum of all tiles before it.
+// Look-back 64 tiles at a time: the lanes read the status words of the 64 tiles before the window's end, the
+// nearest published inclusive prefix closes the sum (everything nearer must at least have its aggregate out, else
+// the window is read again).  A single thread walking back one word per L2 round trip made the 257 tiles of a
+// 2^19-item batch a 17 us serial chain.
+__device__ __forceinline__ uint64_t chain_exclusive(uint64_t *status, uint32_t tile, uint64_t tile_sum) {
+    const uint32_t lane = threadIdx.x & 63u;
+    if (tile == 0) {
+        if (lane == 0) chain_store(status, kChainInc | tile_sum);
         return 0;
     }
-    return (hi - lo + S.chunk - 1) / S.chunk;
+    if (lane == 0) chain_store(status + tile, kChainAgg | tile_sum);
+    uint64_t before = 0;
+    uint32_t end = tile;  // tiles [.., end) are still to be added
+    for (;;) {
+        const bool mine = lane < end;
+        uint64_t v = 0;
+        if (mine) v = chain_load(status + (end - 1u - lane));  // lane 0 = the nearest tile
+        const uint64_t inc = __ballot(mine && (v >> 62) == 2u);
+        const uint64_t missing = __ballot(mine && (v >> 62) == 0u);
+        const uint32_t stop = inc ? uint32_t(__builtin_ctzll(inc)) : 64u;             // first lane holding an inclusive prefix
+        const uint32_t gap = missing ? uint32_t(__builtin_ctzll(missing)) : 64u;      // first lane with nothing published
+        if (gap < stop && gap < 64u) {  // a nearer tile has not published yet: look again
+            __builtin_amdgcn_s_sleep(1);
+            continue;
+        }
+        uint64_t part = (mine && lane <= stop) ? (v & kChainVal) : 0ull;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+        before += part;
+        if (stop < 64u) break;
+        if (end <= 64u) break;  // (cannot happen: tile 0 publishes an inclusive prefix)
+        end -= 64u;
+    }
+    if (lane == 0) chain_store(status + tile, kChainInc | (before + tile_sum));
+    return before;
 }
 
-template <bool COUNT>
-__global__ __launch_bounds__(kScanThreads) void k_tile_sums(ScanSource S, uint64_t n, uint64_t *tile_sums) {
-    __shared__ uint64_t wave_sums[kScanThreads / 64];
-    const uint64_t base = uint64_t(blockIdx.x) * kScanTile + uint64_t(threadIdx.x) * kScanPerThread;
+// Block-wide exclusive scan of kScanPerThread values per thread; returns this thread's exclusive base inside the
+// tile and, through tile_sum (valid in every thread), the tile total.
+__device__ __forceinline__ uint64_t tile_exclusive(const uint64_t (&v)[kScanPerThread], uint64_t *wave_sums, uint64_t &tile_sum) {
     uint64_t sum = 0;
 #pragma unroll
-    for (int i = 0; i < kScanPerThread; ++i) sum += scan_element<COUNT>(S, base + i, n);
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
-    if ((threadIdx.x & 63) == 0) wave_sums[threadIdx.x >> 6] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t t = 0;
-        for (int w = 0; w < kScanThreads / 64; ++w) t += wave_sums[w];
-        tile_sums[blockIdx.x] = t;
-    }
-}
-
-template <bool COUNT>
-__global__ __launch_bounds__(kScanThreads) void k_tile_scan(ScanSource S, uint64_t n, const uint64_t *tile_sums, uint64_t *out) {
-    __shared__ uint64_t wave_sums[kScanThreads / 64];
-    __shared__ uint64_t before;
-    // sum of the tiles before this one
-    uint64_t pre = 0;
-    for (uint32_t t = threadIdx.x; t < blockIdx.x; t += kScanThreads) pre += tile_sums[t];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) pre += __shfl_xor(pre, d, 64);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) wave_sums[wave] = pre;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t t = 0;
-        for (int w = 0; w < kScanThreads / 64; ++w) t += wave_sums[w];
-        before = t;
-    }
-    __syncthreads();
-    const uint64_t tile_base = before;
-    __syncthreads();
-    // the tile itself, as k_scan_tiles
-    const uint64_t base = uint64_t(blockIdx.x) * kScanTile + uint64_t(threadIdx.x) * kScanPerThread;
-    uint64_t v[kScanPerThread];
-    uint64_t sum = 0;
-#pragma unroll
-    for (int i = 0; i < kScanPerThread; ++i) {
-        v[i] = scan_element<COUNT>(S, base + i, n);
-        sum += v[i];
-    }
+    for (int i = 0; i < kScanPerThread; ++i) sum += v[i];
     uint64_t inc = sum;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const uint64_t t = __shfl_up(inc, d, 64);
@@ -401,44 +286,117 @@ __global__ __launch_bounds__(kScanThreads) void k_tile_scan(ScanSource S, uint64
     }
     if (lane == 63) wave_sums[wave] = inc;
     __syncthreads();
-    uint64_t wave_base = 0;
-    for (int w = 0; w < wave; ++w) wave_base += wave_sums[w];
-    uint64_t run = tile_base + wave_base + inc - sum;
+    uint64_t wave_base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kScanThreads / 64; ++w) {
+        const uint64_t x = wave_sums[w];
+        if (w < wave) wave_base += x;
+        total += x;
+    }
+    tile_sum = total;
+    return wave_base + inc - sum;
+}
+
+// item_base[h] = first work item of haystack h (h = 0..nh; item_base[nh] = number of items), the item table and
+// the zeroed per-item counters.  Validates what the host cannot see for device-resident offsets: decreasing
+// offsets, a haystack of 4 GiB or more (positions are 32-bit) or one that ends past the blob (every per-item
+// workspace is sized from blob_bytes) raise counters[6], and that haystack gets no item.
+__global__ __launch_bounds__(kScanThreads) void k_items(BatchArgs B, uint64_t blob_bytes, uint64_t *item_base_out, uint32_t *ticket,
+                                                        uint64_t *status) {
+    __shared__ uint64_t wave_sums[kScanThreads / 64];
+    __shared__ uint64_t s_before;
+    __shared__ uint32_t s_tile;
+    __shared__ uint64_t local[kScanTile + 1];  // exclusive item prefix inside the tile
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint64_t n = uint64_t(B.n_haystacks) + 1;  // elements: one per haystack + the closing one
+    const uint64_t base = uint64_t(tile) * kScanTile + uint64_t(threadIdx.x) * kScanPerThread;
+    uint64_t v[kScanPerThread];
 #pragma unroll
     for (int i = 0; i < kScanPerThread; ++i) {
-        if (base + i < n) out[base + i] = run;
+        const uint64_t h = base + i;
+        v[i] = 0;
+        if (h + 1 < n) {
+            const uint64_t lo = B.offsets[h], hi = B.offsets[h + 1];
+            if (hi < lo || hi - lo >= 0xFFFFFFFFull || hi > blob_bytes) B.counters[6] = 1u;
+            else v[i] = (hi - lo + B.chunk_bytes - 1) / B.chunk_bytes;
+        }
+    }
+    uint64_t tile_sum;
+    uint64_t run = tile_exclusive(v, wave_sums, tile_sum);
+    if (threadIdx.x < 64) {
+        const uint64_t bf = chain_exclusive(status, tile, tile_sum);
+        if (threadIdx.x == 0) s_before = bf;
+    }
+#pragma unroll
+    for (int i = 0; i < kScanPerThread; ++i) {
+        local[threadIdx.x * kScanPerThread + i] = run;
+        run += v[i];
+    }
+    if (threadIdx.x == kScanThreads - 1) local[kScanTile] = run;
+    __syncthreads();
+    const uint64_t before = s_before;
+#pragma unroll
+    for (int i = 0; i < kScanPerThread; ++i)
+        if (base + i < n) item_base_out[base + i] = before + local[threadIdx.x * kScanPerThread + i];
+    // the tile's work items, shared out over the workgroup whatever their distribution over its haystacks
+    for (uint64_t k = threadIdx.x; k < tile_sum; k += kScanThreads) {
+        uint32_t lo = 0, hi = kScanTile;  // local[lo] <= k < local[hi]
+        // one item per haystack so far (the usual batch): haystack k, two LDS reads instead of eleven
+        if (k < kScanTile && local[k] == k && local[k + 1] == k + 1) { lo = uint32_t(k); hi = lo + 1; }
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (local[mid] <= k) lo = mid; else hi = mid;
+        }
+        const uint64_t h = uint64_t(tile) * kScanTile + lo;
+        const uint64_t hb = B.offsets[h], he = B.offsets[h + 1];
+        const uint64_t p0 = (k - local[lo]) * B.chunk_bytes;
+        ItemDesc it;
+        it.hay = uint32_t(h);
+        it.pos0 = uint32_t(p0);
+        it.begin = hb + p0;
+        const uint64_t rest = he - it.begin;
+        it.len = rest < B.chunk_bytes ? uint32_t(rest) : B.chunk_bytes;
+        it.warm = p0 < B.warm_bytes ? uint32_t(p0) : B.warm_bytes;
+        const uint64_t g = before + k;
+        B.item_hay[g] = uint32_t(h);
+        B.item_rec[g] = pack_item(it);
+        B.ev_count[g] = 0u;
+        B.rec_count[g] = 0ull;
+    }
+}
+
+// rec_base[i] = records of all items before item i, i = 0..items (the per-item record counts' exclusive scan)
+__global__ __launch_bounds__(kScanThreads) void k_rec_scan(BatchArgs B, uint64_t *rec_base, uint32_t *ticket, uint64_t *status) {
+    __shared__ uint64_t wave_sums[kScanThreads / 64];
+    __shared__ uint64_t s_before;
+    __shared__ uint32_t s_tile;
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint64_t items = B.item_base[B.n_haystacks];
+    const uint64_t base = uint64_t(tile) * kScanTile + uint64_t(threadIdx.x) * kScanPerThread;
+    if (uint64_t(tile) * kScanTile > items) return;  // (so does every later tile: nobody looks back at this one)
+    uint64_t v[kScanPerThread];
+#pragma unroll
+    for (int i = 0; i < kScanPerThread; ++i) v[i] = base + i < items ? B.rec_count[base + i] : 0ull;
+    uint64_t tile_sum;
+    uint64_t run = tile_exclusive(v, wave_sums, tile_sum);
+    if (threadIdx.x < 64) {
+        const uint64_t bf = chain_exclusive(status, tile, tile_sum);
+        if (threadIdx.x == 0) s_before = bf;
+    }
+    __syncthreads();
+    run += s_before;
+#pragma unroll
+    for (int i = 0; i < kScanPerThread; ++i) {
+        if (base + i <= items) rec_base[base + i] = run;
         run += v[i];
     }
 }
 
-template <bool COUNT>
-static void scan_two_launch(const ScanSource &S, uint64_t *out, uint64_t n, uint64_t *temp, hipStream_t st) {
-    const uint64_t tiles = (n + kScanTile - 1) / kScanTile;
-    hipLaunchKernelGGL(k_tile_sums<COUNT>, dim3(uint32_t(tiles)), dim3(kScanThreads), 0, st, S, n, temp);
-    hipLaunchKernelGGL(k_tile_scan<COUNT>, dim3(uint32_t(tiles)), dim3(kScanThreads), 0, st, S, n, temp, out);
-}
-
-void exclusive_scan_u64(const uint64_t *in, uint64_t *out, uint64_t n, uint64_t *temp, hipStream_t st) {
-    if (n == 0) return;
-    if ((n + kScanTile - 1) / kScanTile <= kScanMaxTiles) {
-        scan_two_launch<false>(ScanSource{in, nullptr, 0u, nullptr, 0ull}, out, n, temp, st);
-        return;
-    }
-    exclusive_scan_recursive(in, out, n, temp, st);
-}
-
-// item_base[h] = first work item of haystack h, h = 0..nh (item_base[nh] = number of items): item counts
-// from the offsets and their exclusive scan.  `n_items` is scratch for the general (recursive) form.
-void launch_item_base(const uint64_t *offsets, uint32_t nh, uint32_t chunk, uint64_t blob_bytes, uint64_t *n_items,
-                      uint64_t *item_base, uint32_t *counters, uint64_t *temp, hipStream_t st) {
-    const uint64_t n = uint64_t(nh) + 1;
-    if ((n + kScanTile - 1) / kScanTile <= kScanMaxTiles) {
-        scan_two_launch<true>(ScanSource{nullptr, offsets, chunk, counters, blob_bytes}, item_base, n, temp, st);
-        return;
-    }
-    hipLaunchKernelGGL(k_count_items, dim3((nh + 1 + 255) / 256), dim3(256), 0, st, offsets, nh, chunk, blob_bytes, n_items, counters);
-    exclusive_scan_recursive(n_items, item_base, n, temp, st);
-}
+uint32_t scan_tiles(uint64_t n) { return uint32_t((n + kScanTile - 1) / kScanTile); }
 
 // ------------------------------------------------------------------------------------------
 // k_scan_simple: one thread per work item, every lookup from the global table.  The plain,
@@ -510,10 +468,13 @@ __device__ __forceinline__ void append_run(const BatchArgs &B, uint64_t item, ui
 // 8 KiB: the store shares the in-order vmcnt queue with the haystack prefetches, and every wait behind it
 // sat out the store's round trip.
 struct RunStage {
-    uint4 *slots;        // this wave's 128 staging slots (LDS)
+    uint4 *slots;        // this wave's staging slots (LDS)
     uint32_t count;      // staged entries (wave-uniform)
+    uint32_t cap;        // slots: 128 (2 KiB per wave), or 48 in the big-set kernel, whose probe queue shares the 2 KiB
 };
 constexpr uint32_t kStageSlots = 128;
+constexpr uint32_t kStageSlotsBig = 48;   // 768 B behind 1 KiB of probe queue and 256 B of hit masks
+constexpr uint32_t kProbeQueue = 128;     // entries {hash, window | lane << 5} per wave
 
 // `entry` of a run: the exact automaton state at `lo` (< 2^24), or
 constexpr uint32_t kEntryUnknown = 0xFFFFFFFFu;    // walk from the root Lmax-1 bytes before lo
@@ -539,7 +500,7 @@ __device__ __forceinline__ void append_run_wave(const BatchArgs &B, uint64_t wav
                                                 uint32_t &last_hi, uint32_t lane) {
     if (n > B.run_cap) return;
     if (n < B.run_cap) {
-        if (st.count == kStageSlots) stage_flush(B, wave_first, st, lane);
+        if (st.count == st.cap) stage_flush(B, wave_first, st, lane);
         if (lane == 0) st.slots[st.count] = make_uint4(k | (n << 8), lo, hi, entry);
         ++st.count;
     }
@@ -1266,7 +1227,12 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     anchor_open(A, B, rec, 0, ld);
     if (!ld.valid) break;
     sc = ld;
-    RunStage stage{reinterpret_cast<uint4 *>(smem + kAnchorLdsBytes) + (threadIdx.x >> 6) * kStageSlots, 0u};
+    // per wave, behind the table: 2 KiB of run staging -- BIG: [1 KiB probe queue | 256 B hit masks | 768 B run staging]
+    uint8_t *wave_lds = smem + kAnchorLdsBytes + (threadIdx.x >> 6) * 2048u;
+    RunStage stage{reinterpret_cast<uint4 *>(wave_lds + (BIG ? 1280u : 0u)), 0u, BIG ? kStageSlotsBig : kStageSlots};
+    uint2 *const queue = reinterpret_cast<uint2 *>(wave_lds);           // BIG only
+    uint32_t *const hitmask = reinterpret_cast<uint32_t *>(wave_lds + 1024u);
+    if (BIG) hitmask[lane] = 0u;
     uint32_t nrun = 0, run_hi = 0;  // run list of the item being scanned (wave-uniform)
     uint32_t nrun_vec = 0;          // lane k: run count of item wave_first + k
     // carry[n-1] = hash prefix over the LAST n dwords of a quad (n = 1..QW-1): what a window that
@@ -1332,76 +1298,124 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                 h4[w] = h;
             }
         };
+        const uint32_t bucket_mask = A.anchor_bucket_mask;
+        const uint4 *big_table = static_cast<const uint4 *>(A.anchor_table);
+        if constexpr (BIG) {
+            // Big sets.  The LDS bitmap passes a fifth of all windows (262,144 q-grams in 2^20 bits); each of those
+            // needs its 16-byte fingerprint bucket from the table behind L2.  Probing where the window is found --
+            // four predicated loads and compares per quad, 14 of 64 lanes active in each, the wave waiting for every
+            // quad's round trip -- made the kernel both VALU-bound (52 wave-instructions per window) and
+            // latency-bound (2.1 ms per 4 GiB).  Instead the "maybes" of a wave are COMPACTED: {hash, position} goes
+            // into a 128-entry LDS ring (ballot + mbcnt give the slot), and whenever 64 are queued the wave probes
+            // them as one dense round: one 16-byte load and one compare per LANE, the load consumed one round later.
+            // A fingerprint match sets the window's bit in the owner lane's hit mask (ds_or); the masks are read
+            // back when the task is done and flagged in text order exactly as in the small-set kernel.
+            uint32_t qhead = 0, qcount = 0;   // ring state (wave-uniform)
+            uint32_t ph = 0, ppos = 0xFFFFFFFFu;  // the probe round in flight: hash, position (0xFFFFFFFF: idle lane)
+            uint4 ptb = make_uint4(0u, 0u, 0u, 0u);
+            bool pending = false;             // wave-uniform
+            // (two rounds in flight were tried: no faster -- 1.71 against 1.75 ms per 4 GiB -- and the 12 registers
+            // they hold spilled inside the loop: the kernel is bound by the L2's request rate, 70 M probes per GiB)
+            auto consume = [&]() {
+                if (!pending) return;
+                uint32_t zz = 0xFFFFFFFFu;
+                const uint32_t fp = ph | 0x10000u;  // fingerprint = (h >> 16) | 1: never the empty 0
+                zz = anchor_compare(u32x2{ptb.x, ptb.y}, fp, zz);
+                zz = anchor_compare(u32x2{ptb.z, ptb.w}, fp, zz);
+                const bool hit = ppos != 0xFFFFFFFFu && has_zero_half(zz);
+                if (__builtin_expect(__any(hit), 0)) {
+                    if (hit) atomicOr(&hitmask[ppos >> 5], 1u << (ppos & 31u));
+                }
+                pending = false;
+            };
+            auto probe_round = [&]() {  // the oldest (up to) 64 queued windows
+                consume();
+                const uint32_t nq_ = qcount < 64u ? qcount : 64u;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                ppos = 0xFFFFFFFFu;
+                ph = 0;
+                if (lane < nq_) {
+                    const uint2 e = queue[(qhead + lane) & (kProbeQueue - 1u)];
+                    ph = e.x;
+                    ppos = e.y;
+                }
+                ptb = big_table[ph & bucket_mask];  // (idle lanes read bucket 0: no branch around the load)
+                qhead += nq_;
+                qcount -= nq_;
+                pending = true;
+            };
+            // quads of this task that exist (an item of 4 KiB fills half a task: the rest is skipped, wave-uniform)
+            const uint32_t task_quads = sc.nq - sc.c * 512u < 512u ? sc.nq - sc.c * 512u : 512u;
+#pragma unroll
+            for (int r = 0; r < G; ++r) {
+                if (uint32_t(r) * 64u >= task_quads) break;
+                uint32_t h4[4], wd[4];
+                hash_quad(r, h4);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) wd[w] = *reinterpret_cast<LdsU1Ptr>((h4[w] >> 15) & 0x1FFFCu);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const bool maybe = (wd[w] >> ((h4[w] >> 12) & 31u)) & 1u;
+                    const uint64_t mm = __ballot(maybe);
+                    if (mm != 0) {
+                        const uint32_t at = __builtin_amdgcn_mbcnt_hi(uint32_t(mm >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mm), 0u));
+                        if (maybe) queue[(qhead + qcount + at) & (kProbeQueue - 1u)] = make_uint2(h4[w], uint32_t(r * 4 + w) | (lane << 5));
+                        qcount += uint32_t(__builtin_popcountll(mm));
+                        if (qcount >= 64u) probe_round();
+                    }
+                }
+            }
+            while (qcount != 0) probe_round();
+            load_task(buf, ld);  // the next task (issued behind the last probe round, which is consumed without waiting for it)
+            consume();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t m = hitmask[lane];
+            if (__builtin_expect(__any(m != 0), 0)) {
+                hitmask[lane] = 0u;
+#pragma unroll
+                for (int r = 0; r < G; ++r) z[r] = (m >> (4 * r)) & 15u;
+                zany = m;
+            }
+        } else {
         // Software pipeline over the quads, pinned with sched_barriers: the four bucket reads of quad r
         // are in flight while quad r-1's buckets are compared, so a wave never sits on LDS latency
         // (hipcc on its own put an lgkmcnt(0) right behind every ds_read).
         uint32_t hh[2][4];
-        u32x2 bb[2][4];   // !BIG: the four fingerprint buckets of a quad; BIG: .x = the bitmap word
-        const uint32_t bucket_mask = A.anchor_bucket_mask;
-        const uint4 *big_table = static_cast<const uint4 *>(A.anchor_table);
+        u32x2 bb[2][4];   // the four fingerprint buckets of a quad
 #pragma unroll
         for (int r = 0; r <= G; ++r) {
             if (r < G) {
                 hash_quad(r, hh[r & 1]);
                 // the quad is consumed: reload its registers with the same quad of the task two steps
-                // ahead at once, so that the wave keeps close to 16 KiB of loads in flight.  (BIG reloads
-                // the whole task at the end instead: its table probes below share the in-order vmcnt queue
-                // with these loads, and each probe wait would sit out the newest reload's HBM round trip.)
-                if (!BIG) buf[r] = load_quad(ld, r);
+                // ahead at once, so that the wave keeps close to 16 KiB of loads in flight
+                buf[r] = load_quad(ld, r);
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    if (BIG) bb[r & 1][w].x = *reinterpret_cast<LdsU1Ptr>((hh[r & 1][w] >> 15) & 0x1FFFCu);
-                    else bb[r & 1][w] = anchor_bucket(hh[r & 1][w]);
-                }
+                for (int w = 0; w < 4; ++w) bb[r & 1][w] = anchor_bucket(hh[r & 1][w]);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (r > 0) {
                 const u32x2 *b4 = bb[(r - 1) & 1];
                 const uint32_t *h4 = hh[(r - 1) & 1];
-                if (BIG) {
-                    // bitmap says "maybe" for a fraction of the windows: those lanes fetch the 8-slot bucket
-                    // (16 B, through L2); the four loads are issued before the first compare
-                    bool maybe[4];
-                    uint4 tb[4];
+                uint32_t zz = 0xFFFFFFFFu;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) zz = anchor_compare(b4[w], h4[w], zz);
+                // Rare, wave-uniform: some lane's quad hit.  Which of its four windows is worked out here,
+                // while the buckets are still in registers: k_walk_runs then knows the window of every run.
+                if (__builtin_expect(__any(has_zero_half(zz)), 0)) {
                     uint32_t m = 0;
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        maybe[w] = (b4[w].x >> ((h4[w] >> 12) & 31u)) & 1u;
-                        tb[w] = make_uint4(0u, 0u, 0u, 0u);
-                        if (maybe[w]) tb[w] = big_table[h4[w] & bucket_mask];
-                    }
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        if (maybe[w]) {
-                            const uint32_t fp = h4[w] | 0x10000u;  // fingerprint = (h >> 16) | 1: never the empty 0
-                            uint32_t zz = 0xFFFFFFFFu;
-                            zz = anchor_compare(u32x2{tb[w].x, tb[w].y}, fp, zz);
-                            zz = anchor_compare(u32x2{tb[w].z, tb[w].w}, fp, zz);
-                            m |= has_zero_half(zz) ? (1u << w) : 0u;
-                        }
-                    }
+                    for (int w = 0; w < 4; ++w) m |= has_zero_half(anchor_compare(b4[w], h4[w], 0xFFFFFFFFu)) ? (1u << w) : 0u;
                     z[r - 1] = m;
                     zany |= m;
-                } else {
-                    uint32_t zz = 0xFFFFFFFFu;
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) zz = anchor_compare(b4[w], h4[w], zz);
-                    // Rare, wave-uniform: some lane's quad hit.  Which of its four windows is worked out here,
-                    // while the buckets are still in registers: k_walk_runs then starts 3 bytes before the
-                    // window instead of Lmax-1 bytes before the earliest end, and the walks of a wave are in
-                    // phase to within 4 bytes (their cold-row accesses coincide).
-                    if (__builtin_expect(__any(has_zero_half(zz)), 0)) {
-                        uint32_t m = 0;
-#pragma unroll
-                        for (int w = 0; w < 4; ++w) m |= has_zero_half(anchor_compare(b4[w], h4[w], 0xFFFFFFFFu)) ? (1u << w) : 0u;
-                        z[r - 1] = m;
-                        zany |= m;
-                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (BIG) load_task(buf, ld);
+        }
         // Rare, wave-uniform: flag where a match anchored at a hit window can end.  A pattern whose first
         // aligned dword is the window starting at byte `start` begins in [start-3, start] and ends at byte
         // index [start + m_min - 4, start + Lmax).
@@ -1495,6 +1509,17 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     // with task t+2 as soon as the quad has been hashed (scan_task).  Loads are unconditional -- past
     // the last task the cursor is an invalid item whose loads fall on the anchor table -- because a load
     // under a branch makes hipcc drain vmcnt(0) instead of counting.
+    if constexpr (BIG) {
+        // One task buffer: the kernel is bound by instruction issue, not by bytes in flight, and the second buffer's
+        // 32 registers were what spilled.  A task's loads are issued when the scan of the previous one ends; the wave
+        // then waits for them while the CU's other 15 waves keep its SIMDs busy.
+        load_task(buf0, ld);
+        for (;;) {
+            anchor_next(A, B, rec, ld);
+            scan_task(buf0);   // (ends by loading the next task into buf0)
+            if (!close_or_advance()) break;
+        }
+    } else {
     load_task(buf0, ld);
     anchor_next(A, B, rec, ld);
     load_task(buf1, ld);
@@ -1505,6 +1530,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
         anchor_next(A, B, rec, ld);
         scan_task(buf1);
         if (!close_or_advance()) break;
+    }
     }
 
     // hand the run lists over to k_walk_runs (lane k: item wave_first + k)
@@ -1736,17 +1762,6 @@ __global__ void k_first_only(BatchArgs B) {
     }
 }
 
-// Per-haystack prefix of the record array; thread nh also publishes the batch summary
-// {total records, total work items} next to the overflow counter for the host's single read-back.
-__global__ void k_hay_prefix(const uint64_t *item_base, const uint64_t *rec_base, uint32_t nh, uint64_t *prefix,
-                             uint64_t *summary) {
-    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h > nh) return;
-    const uint64_t v = rec_base[item_base[h]];
-    prefix[h] = v;
-    if (h == nh) { summary[0] = v; summary[1] = item_base[nh]; }
-}
-
 // Expand one event into records, longest pattern first (node.c:424-441 order).
 __device__ __forceinline__ uint64_t emit_event(const DevAutomaton &A, uint4 *out, uint64_t w, uint32_t hay,
                                                uint32_t pos, uint32_t state) {
@@ -1761,9 +1776,29 @@ __device__ __forceinline__ uint64_t emit_event(const DevAutomaton &A, uint4 *out
 
 // `cap` = records the output buffer can hold: the host launches this optimistically with the
 // capacity of the previous call and re-runs it after growing the buffer if the batch did not fit.
-__global__ void k_expand(DevAutomaton A, BatchArgs B, const uint64_t *rec_base, uint4 *out, uint64_t cap) {
+// Thread h <= n_haystacks also writes the per-haystack prefix of the record array (thread n_haystacks: the batch
+// summary {total records, work items} next to the overflow counter, for the host's single read-back), and the
+// first workgroup zeroes the sync block of the NEXT batch (counters, tickets, scan status words).
+__global__ void k_expand(DevAutomaton A, BatchArgs B, const uint64_t *rec_base, uint4 *out, uint64_t cap, uint64_t *prefix,
+                         uint32_t *host_counters, uint32_t *next_sync, uint32_t next_sync_words) {
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= B.item_base[B.n_haystacks]) return;
+    if (blockIdx.x == 0) {
+        for (uint32_t k = threadIdx.x; k < next_sync_words; k += blockDim.x) next_sync[k] = 0u;
+        // the batch's counters straight into the host's pinned block (words 2..5, the summary, come from the thread
+        // of haystack n below): no copy command behind the pipeline
+        if (threadIdx.x < 16u && (threadIdx.x < 2u || threadIdx.x > 5u)) host_counters[threadIdx.x] = B.counters[threadIdx.x];
+    }
+    const uint64_t items = B.item_base[B.n_haystacks];
+    if (i <= B.n_haystacks) {
+        const uint64_t v = rec_base[B.item_base[i]];
+        prefix[i] = v;
+        if (i == B.n_haystacks) {
+            uint64_t *summary = reinterpret_cast<uint64_t *>(host_counters + 2);
+            summary[0] = v;
+            summary[1] = items;
+        }
+    }
+    if (i >= items) return;
     const uint32_t n = B.ev_count[i];
     if (n == 0 || n > B.slab_events) return;  // overflowed items are k_refill's
     if (rec_base[i + 1] > cap) return;
@@ -2152,11 +2187,13 @@ void launch_stream_read(const void *src, uint64_t bytes, uint32_t *sink, hipStre
 // ------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------
-void launch_build_items(const BatchArgs &B, uint64_t max_items, hipStream_t st) {
-    if (max_items == 0) return;
-    hipLaunchKernelGGL(k_build_items, dim3(uint32_t((max_items + 255) / 256)), dim3(256), 0, st, B);
+void launch_items(const BatchArgs &B, uint64_t blob_bytes, uint64_t *item_base, uint32_t *ticket, uint64_t *status, hipStream_t st) {
+    hipLaunchKernelGGL(k_items, dim3(scan_tiles(uint64_t(B.n_haystacks) + 1)), dim3(kScanThreads), 0, st, B, blob_bytes, item_base, ticket, status);
 }
 
+void launch_rec_scan(const BatchArgs &B, uint64_t max_items, uint64_t *rec_base, uint32_t *ticket, uint64_t *status, hipStream_t st) {
+    hipLaunchKernelGGL(k_rec_scan, dim3(scan_tiles(max_items + 1)), dim3(kScanThreads), 0, st, B, rec_base, ticket, status);
+}
 
 static int num_cus() {
     static int n = [] {
@@ -2247,17 +2284,11 @@ void launch_first_only(const BatchArgs &B, hipStream_t st) {
     hipLaunchKernelGGL(k_first_only, dim3((B.n_haystacks + 255) / 256), dim3(256), 0, st, B);
 }
 
-void launch_hay_prefix(const uint64_t *item_base, const uint64_t *rec_base, uint32_t nh, uint64_t *prefix,
-                       uint64_t *summary, hipStream_t st) {
-    hipLaunchKernelGGL(k_hay_prefix, dim3((nh + 1 + 255) / 256), dim3(256), 0, st, item_base, rec_base, nh, prefix,
-                       summary);
-}
-
 void launch_expand(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, const uint64_t *rec_base, void *out,
-                   uint64_t cap, hipStream_t st) {
-    if (max_items == 0) return;
-    hipLaunchKernelGGL(k_expand, dim3(uint32_t((max_items + 255) / 256)), dim3(256), 0, st, A, B, rec_base,
-                       static_cast<uint4 *>(out), cap);
+                   uint64_t cap, uint64_t *prefix, uint32_t *host_counters, uint32_t *next_sync, uint32_t next_sync_words, hipStream_t st) {
+    const uint64_t threads = std::max<uint64_t>(max_items, uint64_t(B.n_haystacks) + 1);
+    hipLaunchKernelGGL(k_expand, dim3(uint32_t((threads + 255) / 256)), dim3(256), 0, st, A, B, rec_base,
+                       static_cast<uint4 *>(out), cap, prefix, host_counters, next_sync, next_sync_words);
 }
 
 void launch_refill(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes,

@@ -18,7 +18,7 @@ light = len(sys.argv) > 3 and sys.argv[3] == "light"   # counter passes: default
 def run(name, ds, expect_total, refill=0):
     res = api.ahocorasick_init([{"id": k, "value": ds.pattern(k)} for k in range(ds.n_patterns)])
     api.ahocorasick_finalize(res)
-    res.set_option("profile", 1)
+    res.set_option("profile", 2)
     res.set_option("refill", refill)
     reps = nh // ds.n_haystacks
     d_blob = torch.from_numpy(ds.hay_blob).cuda().repeat(reps).contiguous()

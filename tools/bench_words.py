@@ -9,7 +9,7 @@ ds = synth.generate("words", 33, 2048, 4, 12, 8192, 8192, alpha)
 pats = [p for p in ds.patterns()]
 res = api.ahocorasick_init([{"id": k, "value": p} for k, p in enumerate(pats)])
 api.ahocorasick_finalize(res)
-res.set_option("profile", 1)
+res.set_option("profile", 2)
 print({k: res.stat(k) for k in ("states", "hot_states", "columns", "class_mode", "entry_bytes", "lds_image_bytes", "max_pattern_length")})
 nh = 1 << 17
 d_blob = torch.from_numpy(ds.hay_blob).cuda().repeat(nh // 8192).contiguous()

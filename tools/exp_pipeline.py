@@ -12,7 +12,7 @@ streams = [torch.cuda.Stream(), torch.cuda.Stream()]
 handles = []
 for s in streams:
     h = api.ahocorasick_init(pats)
-    h.set_option("profile", 1)
+    h.set_option("profile", 2)
     with torch.cuda.stream(s):
         batch.bind_current_stream(h)
     handles.append(h)

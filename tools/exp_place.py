@@ -16,7 +16,7 @@ for i in range(3):
     blobs.append(tile.repeat(nh // 8192).contiguous())
 handles = [api.ahocorasick_init(pats) for _ in range(2)]
 for h in handles:
-    h.set_option("profile", 1)
+    h.set_option("profile", 2)
     batch.bind_current_stream(h)
 for rep in range(2):
     for hi, h in enumerate(handles):

@@ -6,7 +6,7 @@ import numpy as np, torch
 from php_aho_corasick_amd import api, batch, synth
 ds = synth.bench_batch(8192)
 res = api.ahocorasick_init([{"id": k, "value": ds.pattern(k)} for k in range(ds.n_patterns)])
-res.set_option("profile", 1)
+res.set_option("profile", 2)
 nh = 1 << 19
 tile = torch.from_numpy(ds.hay_blob).cuda().view(8192, 8192)
 batch.bind_current_stream(res)

@@ -6,7 +6,7 @@ from php_aho_corasick_amd import api, batch, synth
 plant = "--no-plant" not in sys.argv
 ds = synth.bench_batch(8192, planted=plant)
 res = api.ahocorasick_init([{"id": k, "value": ds.pattern(k)} for k in range(ds.n_patterns)])
-res.set_option("profile", 1)
+res.set_option("profile", 2)
 nh = 1 << 19
 d_blob = torch.from_numpy(ds.hay_blob).cuda().repeat(nh // 8192).contiguous()
 d_off = torch.arange(nh + 1, dtype=torch.int64, device="cuda") * 8192

@@ -17,7 +17,7 @@ for lds in (4096, 16384, 32768, 65536, 98304, 131072, 163328):
     res = api.ahocorasick_init(pats)
     res.set_option("lds_bytes", lds)
     api.ahocorasick_finalize(res)
-    res.set_option("profile", 1)
+    res.set_option("profile", 2)
     batch.bind_current_stream(res)
     ms = []
     for _ in range(5):
