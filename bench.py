@@ -280,6 +280,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--haystacks", type=int, default=1 << 19, help="haystacks per GPU (8 KiB each)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default, what the driver's scaling runs use): --haystacks per GPU; strong: --haystacks in total, split into contiguous shards")
     ap.add_argument("--ilp", type=int, default=int(os.environ.get("ACMI_ILP", "0")))
     ap.add_argument("--group-quads", type=int, default=0)
     ap.add_argument("--kernel", type=int, default=-1, help="scan kernel: 1 LDS-tile table walk, 2 anchor filter, default automatic")
@@ -338,7 +340,8 @@ def main():
         res.set_option("kernel", args.kernel)
 
     # ---- batch resident in HBM: the 64 MiB tile replicated to the requested size ----
-    nh = max(TILE_HAYSTACKS, (args.haystacks // TILE_HAYSTACKS) * TILE_HAYSTACKS)
+    per_gpu = args.haystacks // world if args.scaling == "strong" else args.haystacks
+    nh = max(TILE_HAYSTACKS, (per_gpu // TILE_HAYSTACKS) * TILE_HAYSTACKS)
     reps = nh // TILE_HAYSTACKS
     tile = torch.from_numpy(ds.hay_blob).to(dev)
     d_blob = tile.repeat(reps).contiguous()
@@ -459,7 +462,7 @@ def main():
         out = {
             "metric": "haystack_GB_per_s", "value": round(world * bytes_per_step * args.steps / dt / 1e9, 2),
             "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"2048 patterns x 16 B (abcdef, seed 1) over {nh} haystacks x {HAY_LEN} B per GPU "
                                    f"({bytes_per_step >> 20} MiB), one planted hit per haystack; BASELINE configs[1] shape",

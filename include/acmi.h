@@ -181,6 +181,33 @@ int acmi_result_to_host(acmi_handle *h, uint64_t *prefix, acmi_record *records);
  * synchronized before returning. */
 int acmi_result_to_device(acmi_handle *h, void *d_prefix_dst, void *d_records_dst);
 
+/* ---- multi-GPU: a batch sharded over the GPUs of one node (NEW; the reference is single-threaded) --------------
+ * Haystacks are independent (keep=0, php_ahocorasick.c:745; tests/test6.phpt), so a batch is cut into contiguous
+ * haystack ranges, one per rank (one process or thread per GPU, each with its own handle built from the same
+ * patterns).  Every rank scans its range with acmi_match_batch_device(); the one exchange step is the all-gatherv
+ * that concatenates the per-rank match arrays in rank order -- the reference's global order, because the ranges
+ * are contiguous.  The collective is RCCL's ncclAllGather over xGMI, bound at run time from librccl.so (no
+ * link-time dependency; a process that already has torch's copy loaded reuses it). */
+typedef struct acmi_comm acmi_comm;
+typedef struct acmi_comm_id { char internal[128]; } acmi_comm_id;   /* ncclUniqueId */
+
+/* Rank 0 makes an id and hands it to the other ranks out of band (a file, a socket, MPI, torch.distributed). */
+int acmi_comm_get_id(acmi_comm_id *id);
+/* Joins rank `rank` of `world` (<= 64) on the handle's device; world == 1 needs no id and no RCCL. */
+int acmi_comm_create(acmi_handle *h, int rank, int world, const acmi_comm_id *id, acmi_comm **out);
+int acmi_comm_destroy(acmi_comm *c);
+/* After acmi_match_batch_device() on this rank's `n_haystacks_local` haystacks: all-gatherv of the results.  On
+ * return every rank holds the GLOBAL arrays in device memory owned by the communicator (valid until its next call):
+ * prefix = uint64[*n_haystacks + 1], records = acmi_record[*n_records] with hay counted over all ranks.  Two
+ * collectives: 16 bytes per rank of sizes, then one payload padded to the largest shard. */
+int acmi_comm_allgather_result(acmi_comm *c, acmi_handle *h, uint64_t n_haystacks_local, const void **d_prefix,
+                               const void **d_records, uint64_t *n_records, uint64_t *n_haystacks);
+/* Test aid: the unpacking half alone, on n_payloads payloads [prefix (nh_cap+1) x u64 | records] of `stride` bytes
+ * laid out by the caller; sizes = n_payloads x {records, haystacks} (host). */
+int acmi_comm_debug_compact(acmi_comm *c, acmi_handle *h, int n_payloads, const void *d_payloads, uint64_t stride, uint64_t nh_cap,
+                            const uint64_t *sizes, const void **d_prefix, const void **d_records, uint64_t *n_records,
+                            uint64_t *n_haystacks);
+
 /* ---- pattern metadata for the shim's zval pack (php_ahocorasick.c:562-583) ---- */
 
 size_t acmi_pattern_count(const acmi_handle *h);

@@ -80,4 +80,16 @@ struct BatchArgs {
     uint32_t wave_items;         // k_scan_anchor: items a wave takes per batch (1..64)
 };
 
+// all-gatherv unpacking (k_gather_compact); at most kMaxRanks ranks
+constexpr uint32_t kMaxRanks = 64;
+struct GatherArgs {
+    const uint8_t *recv;         // world payloads of `stride` bytes: [prefix (nh_cap+1) x u64 | records rec_cap x 16 B]
+    uint64_t stride, nh_cap;
+    uint32_t world;
+    uint64_t total_rec, total_hay;
+    uint64_t rec_base[kMaxRanks + 1], hay_base[kMaxRanks + 1];  // exclusive prefix sums over ranks
+    uint4 *out_records;
+    uint64_t *out_prefix;
+};
+
 }  // namespace acmi

@@ -7,9 +7,11 @@
 // matching path in this library: without a usable gfx950 device every match call fails with
 // ACMI_E_NO_DEVICE / ACMI_E_DEVICE.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -1172,5 +1174,207 @@ const char *acmi_strerror(int status) {
 const char *acmi_last_error(const acmi_handle *h) { return live(h) ? h->last_error.c_str() : "Invalid resource."; }
 
 const char *acmi_version(void) { return ACMI_VERSION; }
+
+}  // extern "C"
+
+// ---- multi-GPU: contiguous haystack shards, one exchange step ------------------------------------------
+// RCCL is bound at run time (dlopen): libacmi.so has no link-time dependency on it, a host without RCCL simply gets
+// ACMI_E_NO_DEVICE from acmi_comm_*.  torch.distributed's "nccl" backend is the same library: a process that has
+// torch loaded reuses its copy.
+namespace {
+
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, acmi_comm_id, int) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string error;
+};
+
+Rccl &rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *env = std::getenv("ACMI_RCCL_LIBRARY");
+        const char *names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) {  // a copy that is already in the process first (torch's)
+            if (n && (r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;
+        }
+        for (const char *n : names) {
+            if (r.lib) break;
+            if (n) r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        }
+        if (!r.lib) { r.error = "librccl.so not found (set ACMI_RCCL_LIBRARY)"; return; }
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+        if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) r.error = "librccl.so lacks a needed symbol";
+    });
+    return r;
+}
+
+constexpr int kNcclUint8 = 1;  // ncclDataType_t (rccl.h:460)
+
+}  // namespace
+
+struct acmi_comm {
+    void *comm = nullptr;  // ncclComm_t; null for a world of one
+    int rank = 0, world = 1, dev = 0;
+    DevBuf d_hdr, d_send, d_recv, d_prefix, d_records;
+    uint64_t *h_hdr = nullptr;  // pinned: world x {records, haystacks}
+    uint64_t total_rec = 0, total_hay = 0;
+    std::string last_error;
+};
+
+namespace {
+
+// Unpack `world` payloads (see GatherArgs) into the comm's global prefix / record arrays.
+int comm_compact(acmi_comm *c, int world, const uint8_t *d_recv, uint64_t stride, uint64_t nh_cap, const uint64_t *hdr, hipStream_t st) {
+    GatherArgs G{};
+    G.recv = d_recv;
+    G.stride = stride;
+    G.nh_cap = nh_cap;
+    G.world = uint32_t(world);
+    for (int r = 0; r < world; ++r) {
+        G.rec_base[r + 1] = G.rec_base[r] + hdr[2 * r];
+        G.hay_base[r + 1] = G.hay_base[r] + hdr[2 * r + 1];
+    }
+    G.total_rec = G.rec_base[world];
+    G.total_hay = G.hay_base[world];
+    if (c->d_prefix.ensure((G.total_hay + 1) * 8) != hipSuccess || c->d_records.ensure(std::max<uint64_t>(16, G.total_rec * 16)) != hipSuccess)
+        return ACMI_E_NOMEM;
+    G.out_prefix = c->d_prefix.as<uint64_t>();
+    G.out_records = c->d_records.as<uint4>();
+    launch_gather_compact(G, st);
+    c->total_rec = G.total_rec;
+    c->total_hay = G.total_hay;
+    return hipGetLastError() == hipSuccess ? ACMI_OK : ACMI_E_DEVICE;
+}
+
+}  // namespace
+
+extern "C" {
+
+int acmi_comm_get_id(acmi_comm_id *id) {
+    return guarded(nullptr, [&]() -> int {
+        if (!id) return ACMI_E_ARG;
+        Rccl &R = rccl();
+        if (!R.error.empty()) return ACMI_E_NO_DEVICE;
+        return R.GetUniqueId(id) == 0 ? ACMI_OK : ACMI_E_DEVICE;
+    });
+}
+
+int acmi_comm_create(acmi_handle *h, int rank, int world, const acmi_comm_id *id, acmi_comm **out) {
+    return guarded(h, [&]() -> int {
+        int rc = check_ready(h);  // the communicator lives on the handle's device
+        if (rc < 0) return rc;
+        if (!out || world < 1 || world > int(kMaxRanks) || rank < 0 || rank >= world || (world > 1 && !id)) return ACMI_E_ARG;
+        acmi_comm *c = new acmi_comm();
+        c->rank = rank;
+        c->world = world;
+        c->dev = h->dev_id;
+        if (world > 1) {
+            Rccl &R = rccl();
+            if (!R.error.empty()) { h->last_error = R.error; delete c; return ACMI_E_NO_DEVICE; }
+            const int e = R.CommInitRank(&c->comm, world, *id, rank);
+            if (e != 0) {
+                h->last_error = std::string("ncclCommInitRank: ") + (R.GetErrorString ? R.GetErrorString(e) : "error");
+                delete c;
+                return ACMI_E_DEVICE;
+            }
+        }
+        if (hipHostMalloc(reinterpret_cast<void **>(&c->h_hdr), size_t(world) * 16, hipHostMallocDefault) != hipSuccess) {
+            if (c->comm) rccl().CommDestroy(c->comm);
+            delete c;
+            return ACMI_E_NOMEM;
+        }
+        *out = c;
+        return ACMI_OK;
+    });
+}
+
+int acmi_comm_destroy(acmi_comm *c) {
+    return guarded(nullptr, [&]() -> int {
+        if (!c) return ACMI_E_INVALID;
+        (void)hipSetDevice(c->dev);
+        if (c->comm) rccl().CommDestroy(c->comm);
+        for (DevBuf *b : {&c->d_hdr, &c->d_send, &c->d_recv, &c->d_prefix, &c->d_records}) b->release();
+        if (c->h_hdr) (void)hipHostFree(c->h_hdr);
+        delete c;
+        return ACMI_OK;
+    });
+}
+
+int acmi_comm_allgather_result(acmi_comm *c, acmi_handle *h, uint64_t n_haystacks_local, const void **d_prefix,
+                               const void **d_records, uint64_t *n_records, uint64_t *n_haystacks) {
+    return guarded(h, [&]() -> int {
+        if (!c) return ACMI_E_ARG;
+        if (!live(h)) return ACMI_E_INVALID;
+        if (!h->have_result || n_haystacks_local != h->last_nh) return ACMI_E_ARG;
+        HIPCHK(h, hipSetDevice(h->dev_id));
+        hipStream_t st = h->stream;
+        Rccl &R = rccl();
+        const int W = c->world;
+        // round 1: sizes (16 bytes per rank) -- RCCL has no all-gatherv, the payload round is padded to the largest shard
+        HIPCHK(h, c->d_hdr.ensure(size_t(W + 1) * 16));
+        uint64_t *d_mine = c->d_hdr.as<uint64_t>(), *d_all = d_mine + 2;
+        const uint64_t mine[2] = {h->last_total, h->last_nh};
+        HIPCHK(h, hipMemcpyAsync(d_mine, mine, 16, hipMemcpyHostToDevice, st));
+        if (W > 1) {
+            const int e = R.AllGather(d_mine, d_all, 16, kNcclUint8, c->comm, st);
+            if (e != 0) { h->last_error = std::string("ncclAllGather: ") + (R.GetErrorString ? R.GetErrorString(e) : "error"); return ACMI_E_DEVICE; }
+        } else {
+            HIPCHK(h, hipMemcpyAsync(d_all, d_mine, 16, hipMemcpyDeviceToDevice, st));
+        }
+        HIPCHK(h, hipMemcpyAsync(c->h_hdr, d_all, size_t(W) * 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        uint64_t rec_cap = 0, nh_cap = 0;
+        for (int r = 0; r < W; ++r) { rec_cap = std::max(rec_cap, c->h_hdr[2 * r]); nh_cap = std::max(nh_cap, c->h_hdr[2 * r + 1]); }
+        // round 2: [prefix (nh_cap+1) | records rec_cap], every rank the same size
+        const uint64_t stride = (nh_cap + 1) * 8 + rec_cap * 16;
+        HIPCHK(h, c->d_send.ensure(stride));
+        HIPCHK(h, c->d_recv.ensure(stride * uint64_t(W)));
+        uint8_t *send = c->d_send.as<uint8_t>();
+        HIPCHK(h, hipMemcpyAsync(send, h->d_prefix.p, (size_t(h->last_nh) + 1) * 8, hipMemcpyDeviceToDevice, st));
+        if (h->last_total)
+            HIPCHK(h, hipMemcpyAsync(send + (nh_cap + 1) * 8, h->d_out.p, h->last_total * 16, hipMemcpyDeviceToDevice, st));
+        const uint8_t *recv = send;
+        if (W > 1) {
+            const int e = R.AllGather(send, c->d_recv.p, stride, kNcclUint8, c->comm, st);
+            if (e != 0) { h->last_error = std::string("ncclAllGather: ") + (R.GetErrorString ? R.GetErrorString(e) : "error"); return ACMI_E_DEVICE; }
+            recv = c->d_recv.as<uint8_t>();
+        }
+        int rc = comm_compact(c, W, recv, stride, nh_cap, c->h_hdr, st);
+        if (rc < 0) return rc;
+        HIPCHK(h, hipStreamSynchronize(st));
+        if (d_prefix) *d_prefix = c->d_prefix.p;
+        if (d_records) *d_records = c->d_records.p;
+        if (n_records) *n_records = c->total_rec;
+        if (n_haystacks) *n_haystacks = c->total_hay;
+        return ACMI_OK;
+    });
+}
+
+int acmi_comm_debug_compact(acmi_comm *c, acmi_handle *h, int n_payloads, const void *d_payloads, uint64_t stride, uint64_t nh_cap,
+                            const uint64_t *sizes, const void **d_prefix, const void **d_records, uint64_t *n_records,
+                            uint64_t *n_haystacks) {
+    return guarded(h, [&]() -> int {
+        if (!c || !sizes || !d_payloads || n_payloads < 1 || n_payloads > int(kMaxRanks)) return ACMI_E_ARG;
+        int rc = check_ready(h);
+        if (rc < 0) return rc;
+        rc = comm_compact(c, n_payloads, static_cast<const uint8_t *>(d_payloads), stride, nh_cap, sizes, h->stream);
+        if (rc < 0) return rc;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (d_prefix) *d_prefix = c->d_prefix.p;
+        if (d_records) *d_records = c->d_records.p;
+        if (n_records) *n_records = c->total_rec;
+        if (n_haystacks) *n_haystacks = c->total_hay;
+        return ACMI_OK;
+    });
+}
 
 }  // extern "C"

@@ -2185,6 +2185,37 @@ void launch_stream_read(const void *src, uint64_t bytes, uint32_t *sink, hipStre
 }
 
 // ------------------------------------------------------------------------------------------
+// k_gather_compact: the unpacking half of the all-gatherv of match arrays (engine.cpp acmi_comm_allgather_result).
+// After the exchange every rank holds, per rank r, a payload [prefix (nh_cap + 1) x u64 | records rec_cap x 16 B]
+// of which n_hay[r] + 1 prefix words and n_rec[r] records are meaningful.  Ranks own contiguous haystack ranges in
+// rank order, so concatenating the payloads in rank order IS the reference's global order: thread g copies global
+// record g (haystack id made global) and, for g <= total haystacks, writes the global prefix word g.
+// ------------------------------------------------------------------------------------------
+__global__ void k_gather_compact(GatherArgs G) {
+    const uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (g < G.total_rec) {
+        uint32_t r = 0;
+        while (r + 1 < G.world && g >= G.rec_base[r + 1]) ++r;
+        const uint8_t *pay = G.recv + uint64_t(r) * G.stride;
+        const uint4 *recs = reinterpret_cast<const uint4 *>(pay + (G.nh_cap + 1) * 8);
+        uint4 v = recs[g - G.rec_base[r]];
+        v.x += uint32_t(G.hay_base[r]);
+        G.out_records[g] = v;
+    }
+    if (g <= G.total_hay) {
+        uint32_t r = 0;
+        while (r + 1 < G.world && g >= G.hay_base[r + 1]) ++r;  // (g == total_hay lands on the last rank's closing word)
+        const uint64_t *pre = reinterpret_cast<const uint64_t *>(G.recv + uint64_t(r) * G.stride);
+        G.out_prefix[g] = G.rec_base[r] + pre[g - G.hay_base[r]];
+    }
+}
+
+void launch_gather_compact(const GatherArgs &G, hipStream_t st) {
+    const uint64_t threads = std::max<uint64_t>(G.total_rec, G.total_hay + 1);
+    hipLaunchKernelGGL(k_gather_compact, dim3(uint32_t((threads + 255) / 256)), dim3(256), 0, st, G);
+}
+
+// ------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------
 void launch_items(const BatchArgs &B, uint64_t blob_bytes, uint64_t *item_base, uint32_t *ticket, uint64_t *status, hipStream_t st) {
