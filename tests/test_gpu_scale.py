@@ -126,3 +126,43 @@ def test_nine_million_tiny_haystacks():
     assert np.array_equal(rec[int(prefix[lo]):int(prefix[hi])], re_)
     api.ahocorasick_deinit(res)
     o.close()
+
+
+def test_config3_full_size_planted_hits():
+    """BASELINE configs[2] at its full size: 65,536 patterns of 8..64 B over 2^20 haystacks x 4 KiB (4 GiB resident).
+    Size-independent properties: every haystack reports its planted pattern at its place, records are ordered by
+    (haystack, position), the count repeats tile by tile, verify=1 (text compare) and verify=0 (automaton walk) agree;
+    and the first 64 haystacks ARE the G6 golden (same generator, same plants), compared record for record."""
+    import torch
+    from helpers import load_json, sha
+    tile_h, hl, nh = 4096, 4096, 1 << 20
+    ds = synth.g6(n_hay=tile_h, hay_len=hl)
+    reps = nh // tile_h
+    d_blob = torch.from_numpy(ds.hay_blob).cuda().repeat(reps).contiguous()
+    d_off = torch.arange(nh + 1, dtype=torch.int64, device="cuda") * hl
+    results = []
+    for verify in (1, 0):
+        res = resource_for(ds, verify=verify)
+        batch.bind_current_stream(res)
+        total = batch.match_device(res, d_blob, d_off)
+        assert res.stat("kernel_used") == 2 and res.stat("compact") == 1
+        prefix, rec = batch.result_numpy(res, nh, total)
+        results.append((total, sha(prefix), sha(rec)))
+        if verify == 1:
+            h = np.arange(tile_h, dtype=np.int64)
+            pat = (1021 * h + 17) % ds.n_patterns
+            start = (37 * h + 11) % (hl - 64)
+            plen = np.diff(ds.pat_off.astype(np.int64))[pat]
+            keys = rec[:, 0].astype(np.int64) * (1 << 32) + rec[:, 1]
+            assert np.all(np.diff(keys) >= 0), "records must be ordered by (haystack, pos)"
+            per_tile = int(prefix[tile_h])
+            assert total == per_tile * reps and int(prefix[-1]) == total
+            for t in (0, reps // 2, reps - 1):  # the same tile wherever it lies in the batch
+                lo, hi = int(prefix[t * tile_h]), int(prefix[(t + 1) * tile_h])
+                got = {(int(a) - t * tile_h, int(b), int(c), int(d)) for a, b, c, d in rec[lo:hi]}
+                assert all((int(hh), int(s + l), int(s), int(p)) in got for hh, s, l, p in zip(h, start, plen, pat))
+            g = {(c["dataset"], c["find_all"]): c for c in load_json("golden.json")["cases"]}[("G6", True)]
+            n64 = int(prefix[64])
+            assert n64 == g["n_records"] and sha(rec[:n64]) == g["sha256"]
+        api.ahocorasick_deinit(res)
+    assert results[0] == results[1]
