@@ -47,6 +47,7 @@ extern "C" {
 #define ACMI_E_DEVICE     (-6)   /* a HIP call failed; acmi_last_error() has text */
 #define ACMI_E_NO_DEVICE  (-7)   /* no usable gfx950 device: matching is refused, there is NO CPU fallback */
 #define ACMI_E_TOO_LARGE  (-8)   /* automaton or result exceeds a hard limit      */
+#define ACMI_E_NO_REPLACEMENT (-9) /* acmi_replace_batch: no pattern carries a replacement text (multifast_replace's -2) */
 
 /* Pattern identifier kinds: src/multifast/actypes.h:57-62 (enum ac_pattid_type). */
 #define ACMI_ID_DEFAULT 0
@@ -180,6 +181,27 @@ int acmi_result_to_host(acmi_handle *h, uint64_t *prefix, acmi_record *records);
  * send buffers of the multi-GPU all-gather.  Ordered on the handle's stream and
  * synchronized before returning. */
 int acmi_result_to_device(acmi_handle *h, void *d_prefix_dst, void *d_records_dst);
+
+/* ---- search and replace (MultiFast's multifast_replace; compiled into the reference, config.m4:9, but not exposed
+ * by its PHP layer: rtext is always NULL at php_ahocorasick.c:469-470) ---------------------------------------------- */
+
+#define ACMI_REPLACE_NORMAL 1   /* MF_REPLACE_MODE_NORMAL (replace.h:34-46; 0 = DEFAULT behaves the same): a pattern swallows
+                                   the factors found inside it; other overlapping patterns are all replaced */
+#define ACMI_REPLACE_LAZY   2   /* MF_REPLACE_MODE_LAZY: whichever pattern comes first is replaced, what overlaps it is dropped */
+
+/* AC_PATTERN_t.rtext (actypes.h:88-94) of caller-order pattern `pattern_index`, set between the acmi_add_patterns()
+ * call that brought the pattern and finalize.  The text is kept as the reference keeps it (node.c:248-251 through
+ * mpool_strndup, mpool.c:165-178): copied up to its first NUL byte, zero-filled from there to `length`.  text == NULL:
+ * the pattern is matched but not replaced. */
+int acmi_set_replacement(acmi_handle *h, uint32_t pattern_index, const uint8_t *text, uint32_t length);
+
+/* multifast_replace() + multifast_rep_flush(keep=0) (replace.c:469-568) over every haystack of a batch: per event the
+ * longest pattern with a replacement text is the nominee (node.c:337-362), nominees are kept or dropped by `mode`
+ * (replace.c:222-272), and each output text is the input with the kept nominees replaced left to right (:402-455).
+ * *out_blob holds the output texts back to back, (*out_offsets)[n_haystacks + 1] their offsets; both are owned by the
+ * handle until its next call.  ACMI_E_NO_REPLACEMENT when no accepted pattern has a replacement text. */
+int acmi_replace_batch(acmi_handle *h, const uint8_t *blob, const uint64_t *offsets, size_t n_haystacks, int mode,
+                       const uint8_t **out_blob, const uint64_t **out_offsets);
 
 /* ---- multi-GPU: a batch sharded over the GPUs of one node (NEW; the reference is single-threaded) --------------
  * Haystacks are independent (keep=0, php_ahocorasick.c:745; tests/test6.phpt), so a batch is cut into contiguous

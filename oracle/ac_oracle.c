@@ -50,6 +50,10 @@ struct orc_trie {
     /* pattern byte copies (the reference keeps them in its mpool) */
     uint8_t **copies;
     size_t ncopies, copies_cap;
+    /* replacement texts (AC_PATTERN_t.rtext, actypes.h:88-94), by caller-order pattern index */
+    uint8_t **rep;
+    uint32_t *rep_len;
+    size_t rep_n;
 };
 
 static uint32_t node_new(orc_trie *t)
@@ -320,12 +324,168 @@ void orc_release(orc_trie *t)
     for (size_t i = 0; i < t->ncopies; i++)
         free(t->copies[i]);
     free(t->copies);
+    for (size_t i = 0; i < t->rep_n; i++)
+        free(t->rep[i]);
+    free(t->rep);
+    free(t->rep_len);
     free(t->nodes);
     free(t);
 }
 
 size_t orc_node_count(const orc_trie *t) { return t->n; }
 size_t orc_pattern_count(const orc_trie *t) { return t->patterns_count; }
+
+/* ------------------------- search and replace ----------------------------- */
+
+/* AC_PATTERN_t.rtext as ac_trie_add keeps it with copy=1 (node.c:238-251): the bytes go through
+ * mpool_strndup (mpool.c:165-178), i.e. strncpy -- copied up to the first NUL, zero-filled after it --
+ * while rtext.length stays the caller's.  NULL means "not to be replaced". */
+void orc_set_replacement(orc_trie *t, uint32_t index, const uint8_t *r, size_t rlen)
+{
+    if (index >= t->rep_n) {
+        size_t n = (size_t)index + 1;
+        t->rep = (uint8_t **)realloc(t->rep, n * sizeof(uint8_t *));
+        t->rep_len = (uint32_t *)realloc(t->rep_len, n * sizeof(uint32_t));
+        for (size_t i = t->rep_n; i < n; i++) { t->rep[i] = NULL; t->rep_len[i] = 0; }
+        t->rep_n = n;
+    }
+    free(t->rep[index]);
+    t->rep[index] = NULL;
+    t->rep_len[index] = 0;
+    if (!r)
+        return;
+    uint8_t *c = (uint8_t *)calloc(rlen + 1, 1);
+    strncpy((char *)c, (const char *)r, rlen);
+    t->rep[index] = c;
+    t->rep_len[index] = (uint32_t)rlen;
+}
+
+static const orc_pattern *to_be_replaced(const orc_trie *t, const node_t *nd)
+{
+    /* node.c:337-362 node_book_replacement: the longest matched pattern that has a replacement */
+    const orc_pattern *longest = NULL;
+    if (!nd->final)
+        return NULL;
+    for (uint32_t j = 0; j < nd->m_n; j++) {
+        const orc_pattern *p = &nd->matched[j];
+        if (p->index < t->rep_n && t->rep[p->index] != NULL) {
+            if (!longest || p->length > longest->length)
+                longest = p;
+        }
+    }
+    return longest;
+}
+
+typedef struct { const orc_pattern *pattern; size_t position; } nominee_t;   /* replace.h:57-61 */
+
+typedef struct {
+    nominee_t *noms;
+    size_t n, cap;
+    size_t curser;                                  /* replace.h:84 */
+    uint8_t *out;
+    size_t out_n, out_cap;
+} repdata_t;
+
+static void rep_append(repdata_t *rd, const uint8_t *p, size_t n)   /* replace.c:279-305, unbuffered */
+{
+    for (size_t i = 0; i < n; i++) {
+        if (rd->out_n < rd->out_cap)
+            rd->out[rd->out_n] = p[i];
+        rd->out_n++;
+    }
+}
+
+/* replace.c:222-272 mf_repdata_booknominee */
+static void book_nominee(repdata_t *rd, int mode, const orc_pattern *pat, size_t position)
+{
+    if (!pat)
+        return;
+    size_t new_start = position - pat->length;
+    if (mode == 2) {                                /* MF_REPLACE_MODE_LAZY :236-250 */
+        if (new_start < rd->curser)
+            return;
+        if (rd->n > 0 && new_start < rd->noms[rd->n - 1].position)
+            return;
+    } else {                                        /* DEFAULT / NORMAL :252-268 */
+        while (rd->n > 0) {
+            const nominee_t *prev = &rd->noms[rd->n - 1];
+            size_t prev_start = prev->position - prev->pattern->length;
+            if (new_start <= prev_start)
+                rd->n--;                            /* a factor of the new nominee */
+            else
+                break;
+        }
+    }
+    if (rd->n == rd->cap) {
+        rd->cap = rd->cap ? rd->cap * 2 : 64;
+        rd->noms = (nominee_t *)realloc(rd->noms, rd->cap * sizeof(nominee_t));
+    }
+    rd->noms[rd->n].pattern = pat;
+    rd->noms[rd->n].position = position;
+    rd->n++;
+}
+
+/* replace.c:402-455 mf_repdata_do_replace for a text that is wholly in memory (base_position 0: every
+ * factor comes from the input, mf_repdata_appendfactor :314-351 first branch; `to < from` appends nothing) */
+static void do_replace(const orc_trie *t, repdata_t *rd, const uint8_t *text, size_t to_position)
+{
+    size_t index = 0;
+    for (; index < rd->n; index++) {
+        const nominee_t *nom = &rd->noms[index];
+        size_t start = nom->position - nom->pattern->length;
+        if (to_position <= start)
+            break;
+        if (start >= rd->curser)
+            rep_append(rd, text + rd->curser, start - rd->curser);
+        rep_append(rd, t->rep[nom->pattern->index], t->rep_len[nom->pattern->index]);
+        rd->curser = nom->position;
+    }
+    memmove(rd->noms, rd->noms + index, (rd->n - index) * sizeof(nominee_t));
+    rd->n -= index;
+    if (to_position > rd->curser) {
+        rep_append(rd, text + rd->curser, to_position - rd->curser);
+        rd->curser = to_position;
+    }
+}
+
+/* One whole text: multifast_replace (replace.c:469-542) followed by multifast_rep_flush(keep=0) (:552-568).
+ * mode 0/1 = DEFAULT/NORMAL, 2 = LAZY (replace.h:34-46).  Writes at most `cap` bytes, returns the length of the
+ * result, or (size_t)-2 when no pattern has a replacement (multifast_replace returns -2 and emits nothing, :482-483)
+ * and (size_t)-1 on an open trie (:479-480). */
+size_t orc_replace(orc_trie *t, const uint8_t *text, size_t len, int mode, uint8_t *out, size_t cap)
+{
+    if (t->open)
+        return (size_t)-1;
+    int any = 0;
+    for (size_t i = 0; i < t->n && !any; i++)       /* rd->has_replacement, replace.c:95-131 */
+        any = to_be_replaced(t, &t->nodes[i]) != NULL;
+    if (!any)
+        return (size_t)-2;
+    repdata_t rd;
+    memset(&rd, 0, sizeof(rd));
+    rd.out = out;
+    rd.out_cap = cap;
+    size_t position = 0;
+    uint32_t current = 0;
+    while (position < len) {                        /* :498-522: the same walk as ac_trie_search */
+        uint32_t next = find_next_bs(t, current, (int8_t)text[position]);
+        if (next == NONE) {
+            if (t->nodes[current].failure != NONE)
+                current = t->nodes[current].failure;
+            else
+                position++;
+        } else {
+            current = next;
+            position++;
+        }
+        if (t->nodes[current].final && next != NONE)
+            book_nominee(&rd, mode, to_be_replaced(t, &t->nodes[current]), position);
+    }
+    do_replace(t, &rd, text, len - t->nodes[current].depth);   /* :529-532: up to the backlog position */
+    do_replace(t, &rd, text, len);                             /* multifast_rep_flush(keep=0) :556-558 */
+    free(rd.noms);
+    return rd.out_n;
+}
 
 /* ------------------------- PHP-layer emulation --------------------------- */
 

@@ -72,6 +72,12 @@ int  orc_search_keep(orc_trie *t, const uint8_t *text, size_t len, int keep,
                      orc_callback cb, void *user);                /* ahocorasick.c:175-241         */
 void orc_release(orc_trie *t);                                    /* ahocorasick.c:288-296 */
 
+/* Search and replace (not reachable from the PHP surface: rtext is always NULL there, php_ahocorasick.c:469-470).
+ * orc_set_replacement before orc_add / orc_php_add_patterns of that index; r == NULL: not to be replaced. */
+void orc_set_replacement(orc_trie *t, uint32_t index, const uint8_t *r, size_t rlen);   /* actypes.h:88-94 rtext, node.c:248-251 */
+size_t orc_replace(orc_trie *t, const uint8_t *text, size_t len, int mode,
+                   uint8_t *out, size_t cap);                     /* replace.c:469-542 + :552-568 (keep=0) */
+
 size_t orc_node_count(const orc_trie *t);
 size_t orc_pattern_count(const orc_trie *t);                      /* AC_TRIE_t.patterns_count */
 

@@ -65,6 +65,8 @@ class Oracle:
           C.c_size_t)
         f("php_scan_checksum", C.c_size_t, C.c_void_p, _u8p, _u64p, C.c_size_t, _u64p)
         f("stream_feed", C.c_size_t, C.c_void_p, _u8p, C.c_size_t, C.c_int, _u32p, C.c_size_t)
+        f("set_replacement", None, C.c_void_p, C.c_uint32, C.c_char_p, C.c_size_t)
+        f("replace", C.c_size_t, C.c_void_p, _u8p, C.c_size_t, C.c_int, _u8p, C.c_size_t)
         self.t = self._c("create")()
         self.n_added = 0
 
@@ -150,6 +152,25 @@ class Oracle:
         self._c("php_match_batch")(self.t, _ptr(keep, _u8p), _ptr(off, _u64p), nh, int(find_all),
                                    _ptr(prefix, _u64p), _ptr(out, _u32p), int(total))
         return prefix, out[:int(total)]
+
+    # -- search and replace (replace.c; not reachable from the PHP surface) --------------------
+    def set_replacement(self, index: int, text: bytes | None) -> None:
+        """Replacement text of caller-order pattern ``index``; call BEFORE the add_patterns that brings the pattern."""
+        self._c("set_replacement")(self.t, index, text, len(text) if text is not None else 0)
+
+    def replace(self, text: bytes, mode: int = 1) -> bytes | None:
+        """multifast_replace + multifast_rep_flush(keep=0) over one whole text; None when no pattern has a replacement."""
+        self.finalize()
+        buf = np.frombuffer(bytes(text) or b"\0", dtype=np.uint8)
+        cap = len(text) + 64
+        while True:
+            out = np.zeros(max(cap, 1), dtype=np.uint8)
+            n = self._c("replace")(self.t, _ptr(buf, _u8p), len(text), mode, _ptr(out, _u8p), cap)
+            if n >= (1 << 63):   # (size_t)-1 / -2
+                return None
+            if n <= cap:
+                return out[:n].tobytes()
+            cap = int(n)
 
     def scan_checksum(self, blob: np.ndarray, off: np.ndarray):
         """(record count, checksum) without materialising records (cpu_baseline timing leg)."""

@@ -53,6 +53,23 @@ static int ref_handler(AC_MATCH_t *m, void *param)
     return p->ret_val == 0 ? 0 : 1;
 }
 
+/* replacement texts waiting for their pattern's ac_trie_add (the reference takes rtext with the pattern) */
+typedef struct ref_rep { void *trie; uint32_t index; uint8_t *bytes; size_t len; struct ref_rep *next; } ref_rep;
+static ref_rep *ref_reps = NULL;
+
+void ref_set_replacement(void *t, uint32_t index, const uint8_t *r, size_t rlen)
+{
+    if (!r)
+        return;
+    ref_rep *e = (ref_rep *)malloc(sizeof(ref_rep));
+    e->trie = t; e->index = index; e->len = rlen;
+    e->bytes = (uint8_t *)malloc(rlen + 1);
+    memcpy(e->bytes, r, rlen);
+    e->bytes[rlen] = 0;
+    e->next = ref_reps;
+    ref_reps = e;
+}
+
 void *ref_create(void) { return ac_trie_create(); }
 
 int ref_add(void *t, const uint8_t *p, size_t len, uint32_t index)
@@ -62,6 +79,12 @@ int ref_add(void *t, const uint8_t *p, size_t len, uint32_t index)
     patt.ptext.length = len;
     patt.rtext.astring = NULL;
     patt.rtext.length = 0;
+    for (ref_rep *e = ref_reps; e; e = e->next)
+        if (e->trie == t && e->index == index) {
+            patt.rtext.astring = (const AC_ALPHABET_t *)e->bytes;
+            patt.rtext.length = e->len;
+            break;
+        }
     patt.id.type = AC_PATTID_TYPE_NUMBER;
     patt.id.u.number = (long)index;
     patt.aux = NULL;
@@ -69,7 +92,14 @@ int ref_add(void *t, const uint8_t *p, size_t len, uint32_t index)
 }
 
 void ref_finalize(void *t) { ac_trie_finalize((AC_TRIE_t *)t); }
-void ref_release(void *t) { ac_trie_release((AC_TRIE_t *)t); }
+void ref_release(void *t)
+{
+    for (ref_rep **pp = &ref_reps; *pp;) {   /* drop this trie's pending replacement texts */
+        if ((*pp)->trie == t) { ref_rep *e = *pp; *pp = e->next; free(e->bytes); free(e); }
+        else pp = &(*pp)->next;
+    }
+    ac_trie_release((AC_TRIE_t *)t);
+}
 size_t ref_pattern_count(const void *t) { return ((const AC_TRIE_t *)t)->patterns_count; }
 
 size_t ref_php_add_patterns(void *t, const uint8_t *blob, const uint64_t *off, size_t n,
@@ -145,6 +175,34 @@ size_t ref_php_scan_checksum(void *t, const uint8_t *blob, const uint64_t *off, 
     if (checksum)
         *checksum = p.checksum;
     return p.n;
+}
+
+/* multifast_replace + multifast_rep_flush(keep=0) over one whole text, the callback's chunks concatenated */
+typedef struct { uint8_t *out; size_t cap, n; } ref_rep_out;
+static void ref_rep_cb(AC_TEXT_t *txt, void *param)
+{
+    ref_rep_out *o = (ref_rep_out *)param;
+    for (size_t i = 0; i < txt->length; i++) {
+        if (o->n < o->cap)
+            o->out[o->n] = (uint8_t)txt->astring[i];
+        o->n++;
+    }
+}
+
+size_t ref_replace(void *t, const uint8_t *text, size_t len, int mode, uint8_t *out, size_t cap)
+{
+    AC_TRIE_t *trie = (AC_TRIE_t *)t;
+    if (trie->trie_open)
+        return (size_t)-1;
+    AC_TEXT_t txt;
+    txt.astring = (const AC_ALPHABET_t *)text;
+    txt.length = len;
+    ref_rep_out o = { out, cap, 0 };
+    int rc = multifast_replace(trie, &txt, (MF_REPLACE_MODE_t)mode, ref_rep_cb, &o);
+    if (rc < 0)
+        return (size_t)(long)rc;
+    multifast_rep_flush(trie, 0);
+    return o.n;
 }
 
 /* Node count = 1 + number of edges, by DFS over the reference's own structs. */

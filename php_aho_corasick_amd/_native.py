@@ -13,8 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # ACMI_LIBRARY selects another build of the same ABI (A/B kernel comparisons inside one process launch)
 LIB_PATH = os.environ.get("ACMI_LIBRARY") or os.path.join(HERE, "libacmi.so")
 
-OK, E_INVALID, E_NOT_INIT, E_FINALIZED, E_ARG, E_NOMEM, E_DEVICE, E_NO_DEVICE, E_TOO_LARGE = \
-    0, -1, -2, -3, -4, -5, -6, -7, -8
+OK, E_INVALID, E_NOT_INIT, E_FINALIZED, E_ARG, E_NOMEM, E_DEVICE, E_NO_DEVICE, E_TOO_LARGE, E_NO_REPLACEMENT = \
+    0, -1, -2, -3, -4, -5, -6, -7, -8, -9
 ID_DEFAULT, ID_NUMBER, ID_STRING = 0, 1, 2
 
 
@@ -79,6 +79,9 @@ SYMBOLS = {
                                      C.POINTER(C.c_uint64)]),
     "acmi_result_to_host": (C.c_int, [Handle, C.c_void_p, C.c_void_p]),
     "acmi_result_to_device": (C.c_int, [Handle, C.c_void_p, C.c_void_p]),
+    "acmi_set_replacement": (C.c_int, [Handle, C.c_uint32, C.c_char_p, C.c_uint32]),
+    "acmi_replace_batch": (C.c_int, [Handle, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.POINTER(C.c_uint8)),
+                                     C.POINTER(C.POINTER(C.c_uint64))]),
     "acmi_comm_get_id": (C.c_int, [C.c_void_p]),
     "acmi_comm_create": (C.c_int, [Handle, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "acmi_comm_destroy": (C.c_int, [C.c_void_p]),

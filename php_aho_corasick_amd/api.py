@@ -352,6 +352,27 @@ def match_arrays(res: AhoResource, blob: np.ndarray, off: np.ndarray, findAll: b
     return prefix, records
 
 
+def set_replacement(res: AhoResource, index: int, text: bytes | None) -> None:
+    """AC_PATTERN_t.rtext of caller-order pattern ``index`` (before finalize); None: matched but not replaced."""
+    N.check(N.lib.acmi_set_replacement(res._h, index, text, len(text) if text is not None else 0), res._h)
+
+
+def replace_arrays(res: AhoResource, blob: np.ndarray, off: np.ndarray, mode: int = 1):
+    """multifast_replace + flush over a batch of host haystacks (src/multifast/replace.c:469-568; not part of the PHP
+    surface).  Returns (out_blob uint8[], out_off uint64[nh+1]); raises AcmiError(E_NO_REPLACEMENT) when no pattern
+    has a replacement text."""
+    blob = np.ascontiguousarray(blob, dtype=np.uint8)
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    nh = len(off) - 1
+    bp = C.POINTER(C.c_uint8)()
+    op = C.POINTER(C.c_uint64)()
+    N.check(N.lib.acmi_replace_batch(res._h, blob.ctypes.data, off.ctypes.data, nh, mode, C.byref(bp), C.byref(op)), res._h)
+    out_off = np.ctypeslib.as_array(op, shape=(nh + 1,)).copy()
+    total = int(out_off[-1])
+    out = np.ctypeslib.as_array(bp, shape=(total,)).copy() if total else np.zeros(0, np.uint8)
+    return out, out_off
+
+
 class AhoStream:
     """Streaming search over one input fed in pieces: MultiFast's keep=1 mode
     (src/multifast/ahocorasick.c:175-241 with keep != 0), which the PHP extension itself never uses

@@ -97,6 +97,23 @@ uint32_t Automaton::add_child(uint32_t node, uint8_t byte) {
     return child;
 }
 
+void Automaton::set_replacement(uint32_t index, const uint8_t *text, uint32_t length) {
+    if (rep_off_.size() <= index) rep_off_.resize(size_t(index) + 1, ~0ull);
+    if (!text) { rep_off_[index] = ~0ull; return; }
+    const uint64_t at = rep_bytes_.size();
+    uint32_t n = 0;
+    while (n < length && text[n] != 0) ++n;          // strncpy: up to the first NUL ...
+    rep_bytes_.insert(rep_bytes_.end(), text, text + n);
+    rep_bytes_.insert(rep_bytes_.end(), length - n, uint8_t(0));   // ... zero-filled to the caller's length
+    rep_off_[index] = (at << 32) | length;
+}
+
+bool Automaton::has_replacement() const {
+    for (size_t i = 0; i < patterns_.size() && i < rep_off_.size(); ++i)
+        if (patterns_[i].accepted && rep_off_[i] != ~0ull) return true;
+    return false;
+}
+
 size_t Automaton::add_batch(const uint8_t *const *values, const uint32_t *lengths,
                             const uint32_t *id_types, const int64_t *id_numbers,
                             const uint64_t *users, size_t n) {

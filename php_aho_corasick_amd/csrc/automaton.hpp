@@ -172,6 +172,14 @@ public:
     // Returns false (and sets error) when the automaton cannot be represented.
     bool finalize(const BuildOptions &opt, std::string *error);
 
+    // search and replace (AC_PATTERN_t.rtext, actypes.h:88-94): replacement text of caller-order pattern `index`, kept as
+    // the reference keeps it -- through strncpy (mpool_strndup, mpool.c:165-178): bytes up to the first NUL, zeros after
+    // it, the length the caller's.  text == nullptr: the pattern is not to be replaced.  Before finalize.
+    void set_replacement(uint32_t index, const uint8_t *text, uint32_t length);
+    const std::vector<uint8_t> &replacement_bytes() const { return rep_bytes_; }
+    const std::vector<uint64_t> &replacement_off() const { return rep_off_; }   // per pattern index: offset << 32 | length, ~0 = none
+    bool has_replacement() const;  // some ACCEPTED pattern carries one (rd->has_replacement, replace.c:95-131)
+
     bool finalized() const { return finalized_; }
     size_t node_count() const { return parent_.size(); }
     size_t accepted_count() const { return accepted_; }
@@ -211,6 +219,8 @@ private:
     std::vector<PatternMeta> patterns_;
     std::vector<uint8_t> pattern_bytes_;
     size_t accepted_ = 0;
+    std::vector<uint8_t> rep_bytes_;
+    std::vector<uint64_t> rep_off_;
     bool finalized_ = false;
     bool host_tables_released_ = false;
     FlatAutomaton flat_;

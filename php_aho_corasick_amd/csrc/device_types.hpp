@@ -80,6 +80,24 @@ struct BatchArgs {
     uint32_t wave_items;         // k_scan_anchor: items a wave takes per batch (1..64)
 };
 
+// search and replace over a matched batch (k_replace_plan / k_replace_emit)
+struct ReplaceArgs {
+    const uint8_t *blob;         // haystacks
+    const uint64_t *offsets;     // n_haystacks + 1
+    uint32_t n_haystacks;
+    uint32_t mode;               // 1 normal, 2 lazy
+    const uint64_t *prefix;      // per-haystack prefix of the record array
+    const uint4 *records;        // {hay, pos, start, pattern}
+    const uint32_t *pattern_length;
+    const uint64_t *rep_off;     // per pattern: offset << 32 | length of its replacement text, ~0: none
+    const uint8_t *rep_bytes;
+    uint2 *plan;                 // nominees {end, pattern}, haystack h's from plan[prefix[h]]
+    uint32_t *nom_count;         // per haystack
+    uint64_t *out_len;           // per haystack
+    const uint64_t *out_off;     // per haystack (k_replace_emit)
+    uint8_t *out_blob;
+};
+
 // all-gatherv unpacking (k_gather_compact); at most kMaxRanks ranks
 constexpr uint32_t kMaxRanks = 64;
 struct GatherArgs {

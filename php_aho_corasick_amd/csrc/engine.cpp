@@ -117,6 +117,11 @@ struct acmi_handle {
     bool have_result = false;
     std::vector<acmi_record> h_records;
     std::vector<uint64_t> h_prefix;
+    // search and replace
+    DevBuf d_rep_off, d_rep_bytes, d_plan, d_nom_count, d_out_len, d_rep_out_off, d_rep_out;
+    bool rep_uploaded = false;
+    std::vector<uint8_t> h_rep_blob;
+    std::vector<uint64_t> h_rep_off;
 
     // a batch whose pipeline is enqueued but not yet completed (acmi_match_batch_device_begin/_end)
     bool in_flight = false;
@@ -748,7 +753,7 @@ int acmi_destroy(acmi_handle *h) {
         if (h->dev_touched) {  // also after a failed upload: release whatever was created
             (void)hipSetDevice(h->dev_id);
             if (h->stream) (void)hipStreamSynchronize(h->stream);
-            for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_out_off, &h->d_out_list, &h->d_cold_rec, &h->d_cold_edges, &h->d_chain_byte, &h->d_chain_run, &h->d_slot_pair, &h->d_pairs, &h->d_pat_bytes, &h->d_blob,
+            for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_out_off, &h->d_out_list, &h->d_cold_rec, &h->d_cold_edges, &h->d_chain_byte, &h->d_chain_run, &h->d_slot_pair, &h->d_pairs, &h->d_pat_bytes, &h->d_rep_off, &h->d_rep_bytes, &h->d_plan, &h->d_nom_count, &h->d_out_len, &h->d_rep_out_off, &h->d_rep_out, &h->d_blob,
                               &h->d_off, &h->d_sync[0], &h->d_sync[1], &h->d_item_base, &h->d_item_hay, &h->d_item_rec, &h->d_zero,
                               &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_prefix, &h->d_out, &h->d_runs, &h->d_run_count, &h->d_prefix_alt, &h->d_out_alt})
                 b->release();
@@ -1167,6 +1172,7 @@ const char *acmi_strerror(int status) {
     case ACMI_E_DEVICE: return "HIP error";
     case ACMI_E_NO_DEVICE: return "no usable gfx950 device (no CPU fallback)";
     case ACMI_E_TOO_LARGE: return "automaton or result too large";
+    case ACMI_E_NO_REPLACEMENT: return "no pattern has a replacement text";
     default: return status > 0 ? "ok" : "unknown error";
     }
 }
@@ -1373,6 +1379,106 @@ int acmi_comm_debug_compact(acmi_comm *c, acmi_handle *h, int n_payloads, const 
         if (d_records) *d_records = c->d_records.p;
         if (n_records) *n_records = c->total_rec;
         if (n_haystacks) *n_haystacks = c->total_hay;
+        return ACMI_OK;
+    });
+}
+
+}  // extern "C"
+
+// ---- search and replace (multifast_replace, reference src/multifast/replace.c) ------------------------------------
+extern "C" {
+
+int acmi_set_replacement(acmi_handle *h, uint32_t pattern_index, const uint8_t *text, uint32_t length) {
+    return guarded(h, [&]() -> int {
+        if (!live(h)) return ACMI_E_INVALID;
+        if (h->init_ok != 1) return ACMI_E_NOT_INIT;
+        if (h->aut.finalized()) return ACMI_E_FINALIZED;
+        if (pattern_index >= h->aut.patterns().size() || (length && !text)) return ACMI_E_ARG;
+        h->aut.set_replacement(pattern_index, text, length);
+        return ACMI_OK;
+    });
+}
+
+int acmi_replace_batch(acmi_handle *h, const uint8_t *blob, const uint64_t *offsets, size_t n_haystacks, int mode,
+                       const uint8_t **out_blob, const uint64_t **out_offsets) {
+    return guarded(h, [&]() -> int {
+        int rc = check_ready(h);
+        if (rc < 0) return rc;
+        if (mode < 0 || mode > 2 || (n_haystacks && !offsets)) return ACMI_E_ARG;
+        if (!h->aut.has_replacement()) {  // multifast_replace returns -2 and emits nothing (replace.c:482-483)
+            h->last_error = "no pattern has a replacement text";
+            return ACMI_E_NO_REPLACEMENT;
+        }
+        uint64_t blob_bytes = 0;
+        for (size_t k = 0; k < n_haystacks; ++k) {
+            if (offsets[k + 1] < offsets[k] || offsets[k + 1] - offsets[k] >= 0xFFFFFFFFull) return ACMI_E_ARG;
+        }
+        if (n_haystacks) blob_bytes = offsets[n_haystacks];
+        if (blob_bytes && !blob) return ACMI_E_ARG;
+        hipStream_t st = h->stream;
+        if (!h->rep_uploaded) {
+            std::vector<uint64_t> off = h->aut.replacement_off();
+            off.resize(std::max<size_t>(1, h->aut.patterns().size()), ~0ull);
+            for (size_t i = 0; i < h->aut.patterns().size(); ++i)
+                if (!h->aut.patterns()[i].accepted) off[i] = ~0ull;
+            HIPCHK(h, h->d_rep_off.ensure(off.size() * 8));
+            HIPCHK(h, hipMemcpy(h->d_rep_off.p, off.data(), off.size() * 8, hipMemcpyHostToDevice));
+            const std::vector<uint8_t> &rb = h->aut.replacement_bytes();
+            HIPCHK(h, h->d_rep_bytes.ensure(rb.size() + 16));
+            if (!rb.empty()) HIPCHK(h, hipMemcpy(h->d_rep_bytes.p, rb.data(), rb.size(), hipMemcpyHostToDevice));
+            h->rep_uploaded = true;
+        }
+        // 1. every match of the batch (the pipeline of acmi_match_batch, results left on the device)
+        HIPCHK(h, h->d_blob.ensure(blob_bytes + 64));
+        HIPCHK(h, h->d_off.ensure((n_haystacks + 1) * 8));
+        if (blob_bytes) HIPCHK(h, hipMemcpyAsync(h->d_blob.p, blob, blob_bytes, hipMemcpyHostToDevice, st));
+        h->h_rep_off.assign(n_haystacks + 1, 0);
+        if (n_haystacks == 0) {
+            h->h_rep_blob.clear();
+            if (out_blob) *out_blob = h->h_rep_blob.data();
+            if (out_offsets) *out_offsets = h->h_rep_off.data();
+            return ACMI_OK;
+        }
+        HIPCHK(h, hipMemcpyAsync(h->d_off.p, offsets, (n_haystacks + 1) * 8, hipMemcpyHostToDevice, st));
+        rc = run_batch(h, h->d_blob.as<uint8_t>(), blob_bytes, h->d_off.as<uint64_t>(), n_haystacks, 1);
+        if (rc < 0) return rc;
+        // 2. nominees and output lengths per haystack
+        HIPCHK(h, h->d_plan.ensure(std::max<uint64_t>(8, h->last_total * 8)));
+        HIPCHK(h, h->d_nom_count.ensure(n_haystacks * 4));
+        HIPCHK(h, h->d_out_len.ensure(n_haystacks * 8));
+        HIPCHK(h, h->d_rep_out_off.ensure((n_haystacks + 1) * 8));
+        ReplaceArgs R{};
+        R.blob = h->d_blob.as<uint8_t>();
+        R.offsets = h->d_off.as<uint64_t>();
+        R.n_haystacks = uint32_t(n_haystacks);
+        R.mode = mode == 2 ? 2u : 1u;   // MF_REPLACE_MODE_DEFAULT behaves as NORMAL (replace.c:252-254)
+        R.prefix = h->d_prefix.as<uint64_t>();
+        R.records = h->d_out.as<uint4>();
+        R.pattern_length = h->dA.pattern_length;
+        R.rep_off = h->d_rep_off.as<uint64_t>();
+        R.rep_bytes = h->d_rep_bytes.as<uint8_t>();
+        R.plan = h->d_plan.as<uint2>();
+        R.nom_count = h->d_nom_count.as<uint32_t>();
+        R.out_len = h->d_out_len.as<uint64_t>();
+        launch_replace_plan(R, st);
+        // 3. output offsets: exclusive scan of the lengths (nh words: on the host)
+        std::vector<uint64_t> lens(n_haystacks);
+        HIPCHK(h, hipMemcpyAsync(lens.data(), h->d_out_len.p, n_haystacks * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        for (size_t k = 0; k < n_haystacks; ++k) h->h_rep_off[k + 1] = h->h_rep_off[k] + lens[k];
+        const uint64_t total = h->h_rep_off[n_haystacks];
+        HIPCHK(h, hipMemcpyAsync(h->d_rep_out_off.p, h->h_rep_off.data(), (n_haystacks + 1) * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(h, h->d_rep_out.ensure(total + 16));
+        // 4. the output texts
+        R.out_off = h->d_rep_out_off.as<uint64_t>();
+        R.out_blob = h->d_rep_out.as<uint8_t>();
+        launch_replace_emit(R, st);
+        h->h_rep_blob.resize(total);
+        if (total) HIPCHK(h, hipMemcpyAsync(h->h_rep_blob.data(), h->d_rep_out.p, total, hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        HIPCHK(h, hipGetLastError());
+        if (out_blob) *out_blob = h->h_rep_blob.data();
+        if (out_offsets) *out_offsets = h->h_rep_off.data();
         return ACMI_OK;
     });
 }

@@ -2185,6 +2185,99 @@ void launch_stream_read(const void *src, uint64_t bytes, uint32_t *sink, hipStre
 }
 
 // ------------------------------------------------------------------------------------------
+// Search and replace: multifast_replace + multifast_rep_flush(keep=0) (reference src/multifast/replace.c:469-568) as a
+// post-pass over the match records of a batch.
+//
+// The reference books a NOMINEE per event -- the longest pattern of the node's list that has a replacement text
+// (node.c:337-362) -- and keeps or drops nominees by mode (replace.c:222-272): NORMAL lets a nominee swallow the
+// earlier ones that start at or after its own start (its factors), overlapping ones all stay; LAZY drops a nominee
+// that starts before the previous one ends.  The output is then one left-to-right pass (replace.c:402-455): the text
+// between the cursor and a nominee's start (nothing if the nominee starts before the cursor), its replacement, the
+// cursor moved to the nominee's end; the rest of the text at the end.  The match records already hold every event
+// in that order with the patterns of an event longest first, so:
+//   k_replace_plan  one thread per haystack: nominees from its records, the booking rule, the output length;
+//   (host)          exclusive scan of the output lengths -> output offsets;
+//   k_replace_emit  one wave per haystack: the pass above, every copy 64 bytes at a time.
+// ------------------------------------------------------------------------------------------
+__global__ void k_replace_plan(ReplaceArgs R) {
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= R.n_haystacks) return;
+    const uint64_t lo = R.prefix[h], hi = R.prefix[h + 1];
+    const uint32_t len = uint32_t(R.offsets[h + 1] - R.offsets[h]);
+    uint2 *plan = R.plan + lo;   // {end position, pattern}: at most one nominee per record
+    uint32_t n = 0, last_pos = 0xFFFFFFFFu;
+    for (uint64_t i = lo; i < hi; ++i) {
+        const uint4 rec = R.records[i];  // {hay, pos, start, pattern}
+        if (rec.y == last_pos) continue;              // this event has its nominee (records of one event: longest first)
+        const uint64_t ro = R.rep_off[rec.w];
+        if (ro == ~0ull) continue;                    // not a to-be-replaced pattern: maybe a shorter one of the event is
+        last_pos = rec.y;
+        const uint32_t new_start = rec.z;
+        if (R.mode == 2) {                            // MF_REPLACE_MODE_LAZY (replace.c:236-250; the cursor is 0 while one text is scanned)
+            if (n > 0 && new_start < plan[n - 1].x) continue;
+        } else {                                      // DEFAULT / NORMAL (:252-268)
+            while (n > 0) {
+                const uint2 prev = plan[n - 1];
+                const uint32_t prev_start = prev.x - uint32_t(R.pattern_length[prev.y]);
+                if (new_start <= prev_start) --n; else break;
+            }
+        }
+        plan[n++] = make_uint2(rec.y, rec.w);
+    }
+    uint64_t out = 0;
+    uint32_t cursor = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint2 nom = plan[k];
+        const uint32_t start = nom.x - R.pattern_length[nom.y];
+        if (start >= cursor) out += start - cursor;
+        out += uint32_t(R.rep_off[nom.y]);
+        cursor = nom.x;
+    }
+    if (len > cursor) out += len - cursor;
+    R.nom_count[h] = n;
+    R.out_len[h] = out;
+}
+
+__device__ __forceinline__ void wave_copy(uint8_t *dst, const uint8_t *src, uint64_t n, uint32_t lane) {
+    for (uint64_t i = lane; i < n; i += 64u) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(256) void k_replace_emit(ReplaceArgs R) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t waves = gridDim.x * (blockDim.x / 64u);
+    for (uint32_t h = blockIdx.x * (blockDim.x / 64u) + (threadIdx.x >> 6); h < R.n_haystacks; h += waves) {
+        const uint8_t *text = R.blob + R.offsets[h];
+        const uint32_t len = uint32_t(R.offsets[h + 1] - R.offsets[h]);
+        const uint2 *plan = R.plan + R.prefix[h];
+        const uint32_t n = R.nom_count[h];
+        uint8_t *out = R.out_blob + R.out_off[h];
+        uint32_t cursor = 0;
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint2 nom = plan[k];
+            const uint32_t start = nom.x - R.pattern_length[nom.y];
+            if (start >= cursor) {
+                wave_copy(out, text + cursor, start - cursor, lane);
+                out += start - cursor;
+            }
+            const uint64_t ro = R.rep_off[nom.y];
+            wave_copy(out, R.rep_bytes + (ro >> 32), uint32_t(ro), lane);
+            out += uint32_t(ro);
+            cursor = nom.x;
+        }
+        if (len > cursor) wave_copy(out, text + cursor, len - cursor, lane);
+    }
+}
+
+void launch_replace_plan(const ReplaceArgs &R, hipStream_t st) {
+    if (R.n_haystacks) hipLaunchKernelGGL(k_replace_plan, dim3((R.n_haystacks + 255) / 256), dim3(256), 0, st, R);
+}
+void launch_replace_emit(const ReplaceArgs &R, hipStream_t st) {
+    if (!R.n_haystacks) return;
+    const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(R.n_haystacks) + 3) / 4, 256ull * 8));
+    hipLaunchKernelGGL(k_replace_emit, dim3(blocks), dim3(256), 0, st, R);
+}
+
+// ------------------------------------------------------------------------------------------
 // k_gather_compact: the unpacking half of the all-gatherv of match arrays (engine.cpp acmi_comm_allgather_result).
 // After the exchange every rank holds, per rank r, a payload [prefix (nh_cap + 1) x u64 | records rec_cap x 16 B]
 // of which n_hay[r] + 1 prefix words and n_rec[r] records are meaningful.  Ranks own contiguous haystack ranges in

@@ -120,6 +120,18 @@ def plant(ds: Dataset, pos_mul: int, pos_add: int, pos_mod: int, pat_mul: int, p
         ds.hay_blob[at:at + len(p)] = np.frombuffer(p, dtype=np.uint8)
 
 
+def replacement(k: int, pattern: bytes):
+    """Deterministic replacement text of pattern k for the search-and-replace fixtures (None: the pattern is
+    matched but not replaced): a third of the patterns keep their text, some are deleted, some reversed."""
+    if k % 3 == 2:
+        return None
+    if k % 7 == 0:
+        return b""
+    if k % 5 == 1:
+        return pattern[::-1] + b"!"
+    return b"<" + str(k).encode() + b">"
+
+
 # ---- the named datasets of SURVEY.md section 8c/8d ---------------------------------------
 
 def g1(n_hay: int = 256) -> Dataset:

@@ -103,10 +103,13 @@ static int run_cpu(void)
     CHECK(acmi_add_patterns(h, &extra, 1, &accepted) == ACMI_OK && accepted == 0);
     CHECK(acmi_pattern_info(h, KAT1_N, &info) == 0);   /* known to the handle, not accepted */
     CHECK(acmi_get_stat(h, "finalized", &v) == ACMI_OK && v == 0);
+    CHECK(acmi_set_replacement(h, 0, (const uint8_t *)"ALFA", 4) == ACMI_OK);           /* AC_PATTERN_t.rtext, actypes.h:88-94 */
+    CHECK(acmi_set_replacement(h, 1000, (const uint8_t *)"x", 1) == ACMI_E_ARG);
     CHECK(acmi_finalize(h) == 1);                       /* php_ahocorasick.c:130-142: 1 the first time ... */
     CHECK(acmi_finalize(h) == 0);                       /* ... 0 after */
     CHECK(acmi_get_stat(h, "finalized", &v) == ACMI_OK && v == 1);
     CHECK(acmi_add_patterns(h, &extra, 1, NULL) == ACMI_E_FINALIZED);   /* :914-917 */
+    CHECK(acmi_set_replacement(h, 0, NULL, 0) == ACMI_E_FINALIZED);
     CHECK(acmi_get_stat(h, "nodes", &v) == ACMI_OK && v == 1 + 4 + 4 + 5 + 5 + 4 + 5 + 3);  /* no shared prefixes */
     CHECK(acmi_get_stat(h, "no such stat", &v) == ACMI_E_ARG);
     CHECK(acmi_set_option(h, "kernel", 99) == ACMI_E_ARG);

@@ -118,3 +118,39 @@ def test_stream_keep_mode_equals_one_shot(kind):
         got = np.concatenate([o.stream_feed(p, i == 0) for i, p in enumerate(pieces)])
         assert np.array_equal(got[:, 1:], whole[:, 1:]) and len(whole) > 0
         o.close()
+
+
+def _replace_stream(o, ds, mode):
+    outs = [o.replace(ds.haystack(h), mode) for h in range(ds.n_haystacks)]
+    prefix = np.zeros(len(outs) + 1, dtype=np.uint64)
+    prefix[1:] = np.cumsum([len(x) for x in outs], dtype=np.uint64)
+    return prefix.tobytes() + b"".join(outs), int(prefix[-1])
+
+
+@pytest.mark.parametrize("name", ["G3", "G4", "G5", "R1", "R2", "R4", "R7"])
+def test_replace_restatement_matches_reference_goldens(name):
+    """orc_replace (oracle/ac_oracle.c, restating src/multifast/replace.c:222-272, 402-455, 469-568 and
+    node.c:337-362) against tests/golden/replace_golden.json, made by the reference's own replace.c."""
+    import hashlib
+    from helpers import load_json
+    from php_aho_corasick_amd import synth
+    cases = {(c["dataset"], c["mode"]): c for c in load_json("replace_golden.json")["cases"]}
+    ds = synth.NAMED[name]()
+    kinds = ["port"] + (["reference"] if pyoracle.have_reference() else [])
+    for kind in kinds:
+        o = pyoracle.Oracle(kind)
+        for k, p in enumerate(ds.patterns()):
+            o.set_replacement(k, synth.replacement(k, p))
+        o.add_patterns((ds.pat_blob, ds.pat_off))
+        for mode in (1, 2):
+            stream, total = _replace_stream(o, ds, mode)
+            g = cases[(name, mode)]
+            assert total == g["out_bytes"] and hashlib.sha256(stream).hexdigest() == g["sha256"], (kind, name, mode)
+        o.close()
+
+
+def test_replace_without_replacement_texts_emits_nothing():
+    """multifast_replace returns -2 when no pattern carries a replacement (replace.c:482-483)."""
+    o = pyoracle.Oracle("port")
+    o.add_patterns([b"abc", b"bc"])
+    assert o.replace(b"xxabcxx", 1) is None
