@@ -263,6 +263,10 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *                    (one lookup per byte, 1 KiB per state at 256 byte classes) or 8-byte goto / failure records
  *                    laid out along the patterns (the reference's node form, node.h:37-67, flattened): 1 = compact,
  *                    0 = dense, -1 (default) = compact when the dense table would exceed 64 MiB   [before finalize]
+ *   "anchor_choice"  big pattern sets (anchor mode 2): which aligned window of a pattern is its anchor is chosen so that the
+ *                    anchors share bits of the LDS bitmap (greedy set cover: 9 % of the bits set instead of 22 % for 65,536
+ *                    patterns, as many fewer probes of the fingerprint table): -1 / 1 = yes (default), 0 = always the
+ *                    pattern's first aligned window                                               [before finalize]
  *   "dense_bytes"    compact: dense rows are kept for the LDS tile, trie depth <= 1 and further states in BFS order
  *                    up to this many bytes (default 4 MiB)                                        [before finalize]
  *   "verify"         1 (default): a candidate of the anchor filter whose q-gram belongs to exactly one (pattern, offset)
@@ -321,6 +325,8 @@ typedef struct acmi_tables {
     uint32_t anchor_mode;         /* 0 none, 1 LDS table, 2 LDS bitmap + global table */
     uint32_t anchor_bucket_bits;  /* mode 2                                    */
     const uint32_t *anchor_bitmap;/* mode 2: 32768 words (2^20 bits)           */
+    uint32_t anchor_choice;       /* 1: anchor windows chosen among the aligned windows of a pattern (mode 2) */
+    const uint8_t *anchor_offsets;/* [pattern * 4 + a]: offset of the anchor window when the first aligned text dword lies a bytes into the pattern */
     uint32_t n_flat_outputs;      /* entries of out_list (0: dictionary links only) */
     uint32_t compact;             /* 1: `table` holds n_dense_rows rows only, for ids [0, dense_nf_end) and [first_cold_final, dense_f_end) */
     uint32_t dense_nf_end, dense_f_end, n_dense_rows, n_cold_edges;

@@ -455,6 +455,8 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
         if (m.accepted && (fa.min_pattern_length == 0 || m.length < fa.min_pattern_length)) fa.min_pattern_length = m.length;
     fa.anchor_q = 0;
     fa.anchor_mode = 0;
+    fa.anchor_choice = 0;
+    fa.anchor_offsets.clear();
     fa.anchor_table.clear();
     fa.anchor_bitmap.clear();
     if (fa.min_pattern_length >= 7) {
@@ -464,39 +466,133 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
         // that stands for exactly ONE (pattern, offset) pair lets k_walk_runs verify a candidate by comparing the
         // pattern's text instead of walking the automaton (anchor_pairs below)
         struct Triple { std::array<uint32_t, 4> key; uint32_t pattern, offset; };
-        std::vector<Triple> triples;
-        for (size_t pi = 0; pi < patterns_.size(); ++pi) {
-            const PatternMeta &m = patterns_[pi];
-            if (!m.accepted) continue;
-            for (uint32_t o = 0; o < 4; ++o) {
-                Triple t{{0, 0, 0, 0}, uint32_t(pi), o};
-                std::memcpy(t.key.data(), pattern_bytes_.data() + m.byte_off + o, q);
-                triples.push_back(t);
-            }
-        }
-        std::sort(triples.begin(), triples.end(), [](const Triple &a, const Triple &b) {
-            return a.key != b.key ? a.key < b.key : (a.pattern != b.pattern ? a.pattern < b.pattern : a.offset < b.offset);
-        });
         std::vector<std::array<uint32_t, 4>> keys;
-        std::vector<uint32_t> key_pair;  // per key: index into anchor_pairs, or kNone when several pairs share the q-gram
-        fa.anchor_pairs.clear();
-        for (size_t i = 0; i < triples.size();) {
-            size_t e = i + 1;
-            while (e < triples.size() && triples[e].key == triples[i].key) ++e;
-            keys.push_back(triples[i].key);
-            if (e - i == 1) {
-                const PatternMeta &m = patterns_[triples[i].pattern];
-                key_pair.push_back(uint32_t(fa.anchor_pairs.size() / 4));
-                fa.anchor_pairs.insert(fa.anchor_pairs.end(), {triples[i].pattern, triples[i].offset | (m.length << 8),
-                                                               uint32_t(m.byte_off), pattern_state[triples[i].pattern]});
-            } else {
-                key_pair.push_back(kNone);
+        std::vector<uint32_t> key_first;                         // key k stands for key_trip[key_first[k] .. key_first[k+1])
+        std::vector<std::pair<uint32_t, uint32_t>> key_trip;     // (pattern, offset)
+        // anchor offset of pattern pi for alignment class a (the pattern begins a bytes before an aligned text dword
+        // ... no: its first aligned dword is at offset a): a itself, unless a later aligned window was chosen (below)
+        fa.anchor_offsets.assign(patterns_.size() * 4, 0);
+        for (size_t pi = 0; pi < patterns_.size(); ++pi)
+            for (uint32_t a = 0; a < 4; ++a) fa.anchor_offsets[pi * 4 + a] = uint8_t(a);
+        auto build_keys = [&]() {
+            std::vector<Triple> triples;
+            for (size_t pi = 0; pi < patterns_.size(); ++pi) {
+                const PatternMeta &m = patterns_[pi];
+                if (!m.accepted) continue;
+                for (uint32_t a = 0; a < 4; ++a) {
+                    const uint32_t o = fa.anchor_offsets[pi * 4 + a];
+                    Triple t{{0, 0, 0, 0}, uint32_t(pi), o};
+                    std::memcpy(t.key.data(), pattern_bytes_.data() + m.byte_off + o, q);
+                    triples.push_back(t);
+                }
             }
-            i = e;
-        }
-        std::vector<Triple>().swap(triples);
-        fa.anchor_pairs_count = fa.anchor_pairs.size() / 4;
-        fa.anchor_keys = uint32_t(keys.size());
+            std::sort(triples.begin(), triples.end(), [](const Triple &a, const Triple &b) {
+                return a.key != b.key ? a.key < b.key : (a.pattern != b.pattern ? a.pattern < b.pattern : a.offset < b.offset);
+            });
+            keys.clear();
+            key_first.clear();
+            key_trip.clear();
+            for (size_t i = 0; i < triples.size();) {
+                size_t e = i + 1;
+                while (e < triples.size() && triples[e].key == triples[i].key) ++e;
+                keys.push_back(triples[i].key);
+                key_first.push_back(uint32_t(key_trip.size()));
+                for (size_t k = i; k < e; ++k) key_trip.emplace_back(triples[k].pattern, triples[k].offset);
+                i = e;
+            }
+            key_first.push_back(uint32_t(key_trip.size()));
+            fa.anchor_keys = uint32_t(keys.size());
+        };
+        // Once every key has its slot in the fingerprint table: the (pattern, offset) pairs a slot stands for -- those of
+        // its q-gram, and of any other q-gram that shares bucket and fingerprint -- contiguous in anchor_pairs,
+        // anchor_slot_pair[slot] = first | (count - 1) << 28.  More than 8 pairs: kNone (such candidates are walked).
+        auto make_slot_pairs = [&](size_t n_slots, const std::vector<size_t> &slot_of_key) {
+            struct Entry { size_t slot; uint32_t pattern, offset; };
+            std::vector<Entry> all;
+            all.reserve(key_trip.size());
+            for (size_t ki = 0; ki < keys.size(); ++ki)
+                for (uint32_t t = key_first[ki]; t < key_first[ki + 1]; ++t) all.push_back({slot_of_key[ki], key_trip[t].first, key_trip[t].second});
+            std::sort(all.begin(), all.end(), [](const Entry &a, const Entry &b) {
+                return a.slot != b.slot ? a.slot < b.slot : (a.pattern != b.pattern ? a.pattern < b.pattern : a.offset < b.offset);
+            });
+            fa.anchor_slot_pair.assign(n_slots, kNone);
+            fa.anchor_pairs.clear();
+            for (size_t i = 0; i < all.size();) {
+                size_t e = i + 1;
+                while (e < all.size() && all[e].slot == all[i].slot) ++e;
+                if (e - i <= 8 && fa.anchor_pairs.size() / 4 < (1u << 28)) {
+                    fa.anchor_slot_pair[all[i].slot] = uint32_t(fa.anchor_pairs.size() / 4) | uint32_t(e - i - 1) << 28;
+                    for (size_t k = i; k < e; ++k) {
+                        const PatternMeta &m = patterns_[all[k].pattern];
+                        fa.anchor_pairs.insert(fa.anchor_pairs.end(), {all[k].pattern, all[k].offset | (m.length << 8), uint32_t(m.byte_off),
+                                                                       pattern_state[all[k].pattern]});
+                    }
+                }
+                i = e;
+            }
+            fa.anchor_pairs_count = fa.anchor_pairs.size() / 4;
+        };
+        build_keys();
+        // Big sets: WHICH aligned window of a pattern is its anchor is free -- an occurrence whose first aligned text
+        // dword lies a bytes into the pattern contains the windows at a, a+4, a+8, ... -- and the LDS bitmap passes a
+        // window when ANY key shares its bit, so the (pattern, class) pairs are covered with as few distinct bits as
+        // possible: greedy set cover over the candidates' bits.  65,536 patterns of 8..64 B: 9.4 % of the 2^20 bits
+        // instead of 22 %, i.e. 2.3 x fewer probes of the fingerprint table, which is what bounds the filter (L2 request
+        // rate).  The chosen offset travels in the pair record (verification) and the run of a hit window becomes
+        // [w + q - 1, w + Lmax): a pattern anchored at w ends there whatever its offset.
+        auto choose_offsets = [&](uint32_t mul_) {
+            constexpr uint32_t kBits = 1u << 20;
+            std::vector<uint32_t> pair_begin{0}, cand_bit;
+            std::vector<uint8_t> cand_off;
+            std::vector<uint32_t> pair_id;  // pattern * 4 + class
+            for (size_t pi = 0; pi < patterns_.size(); ++pi) {
+                const PatternMeta &m = patterns_[pi];
+                if (!m.accepted) continue;
+                for (uint32_t a = 0; a < 4; ++a) {
+                    for (uint32_t o = a; o + q <= m.length && o <= 252u; o += 4) {
+                        uint32_t words[4] = {0, 0, 0, 0};
+                        std::memcpy(words, pattern_bytes_.data() + m.byte_off + o, q);
+                        cand_bit.push_back(anchor_hash(words, q / 4, mul_) >> 12);
+                        cand_off.push_back(uint8_t(o));
+                    }
+                    pair_begin.push_back(uint32_t(cand_bit.size()));
+                    pair_id.push_back(uint32_t(pi * 4 + a));
+                }
+            }
+            const uint32_t n_pairs = uint32_t(pair_id.size());
+            // bit -> the pairs it is a candidate of (CSR)
+            std::vector<uint32_t> bit_off(kBits + 1, 0), bit_pairs(cand_bit.size());
+            for (uint32_t b : cand_bit) ++bit_off[b + 1];
+            for (uint32_t b = 0; b < kBits; ++b) bit_off[b + 1] += bit_off[b];
+            {
+                std::vector<uint32_t> cur(bit_off.begin(), bit_off.end() - 1);
+                for (uint32_t pr = 0; pr < n_pairs; ++pr)
+                    for (uint32_t c = pair_begin[pr]; c < pair_begin[pr + 1]; ++c) bit_pairs[cur[cand_bit[c]]++] = pr;
+            }
+            std::vector<uint8_t> covered(n_pairs, 0), bit_chosen(kBits, 0);
+            std::vector<std::pair<uint32_t, uint32_t>> heap;  // (uncovered pairs the bit would cover when last counted, bit)
+            for (uint32_t b = 0; b < kBits; ++b)
+                if (bit_off[b + 1] > bit_off[b]) heap.emplace_back(bit_off[b + 1] - bit_off[b], b);
+            std::make_heap(heap.begin(), heap.end());
+            while (!heap.empty()) {
+                std::pop_heap(heap.begin(), heap.end());
+                const auto top = heap.back();
+                heap.pop_back();
+                uint32_t now = 0;
+                for (uint32_t e = bit_off[top.second]; e < bit_off[top.second + 1]; ++e) now += !covered[bit_pairs[e]];
+                if (now == 0) continue;
+                if (now < top.first) {  // stale count: back into the heap with the fresh one
+                    heap.emplace_back(now, top.second);
+                    std::push_heap(heap.begin(), heap.end());
+                    continue;
+                }
+                bit_chosen[top.second] = 1;
+                for (uint32_t e = bit_off[top.second]; e < bit_off[top.second + 1]; ++e) covered[bit_pairs[e]] = 1;
+            }
+            for (uint32_t pr = 0; pr < n_pairs; ++pr)
+                for (uint32_t c = pair_begin[pr]; c < pair_begin[pr + 1]; ++c)
+                    if (bit_chosen[cand_bit[c]]) { fa.anchor_offsets[pair_id[pr]] = cand_off[c]; break; }
+        };
         fa.anchor_slot_pair.clear();
         uint32_t mul = 0x9E3779B1u;
         if (keys.size() <= kAnchorMaxKeys) {
@@ -516,27 +612,23 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
                     if (slot == 4) { ok = false; break; }  // bucket overflow: take another seed
                     if (slot == used[bucket]) b[used[bucket]++] = fp;
                 }
-                std::vector<uint32_t> slot_pair;
-                if (ok) {  // which slot names which pair: the same insertion replayed (only for the seed that is kept)
-                    slot_pair.assign(size_t(kAnchorBuckets) * 4, kNone);
-                    std::vector<uint8_t> seen(size_t(kAnchorBuckets) * 4, 0);
+                if (ok) {  // which slot each key went to (only for the seed that is kept)
+                    std::vector<size_t> slot_of(keys.size());
                     for (size_t ki = 0; ki < keys.size(); ++ki) {
                         const uint32_t h = anchor_hash(keys[ki].data(), q / 4, mul);
                         const uint16_t fp = uint16_t(h >> 16);
                         const uint32_t bucket = (h >> 3) & (kAnchorBuckets - 1);
                         uint32_t slot = 0;
                         while (tab[size_t(bucket) * 4 + slot] != fp) ++slot;
-                        const size_t at = size_t(bucket) * 4 + slot;
-                        slot_pair[at] = seen[at] ? kNone : key_pair[ki];  // two q-grams, one fingerprint: not verifiable
-                        seen[at] = 1;
+                        slot_of[ki] = size_t(bucket) * 4 + slot;
                     }
+                    make_slot_pairs(size_t(kAnchorBuckets) * 4, slot_of);
                 }
                 if (ok) {
                     fa.anchor_q = q;
                     fa.anchor_mode = 1;
                     fa.anchor_mul = mul;
                     fa.anchor_table = tab;
-                    fa.anchor_slot_pair = slot_pair;
                 }
             }
         } else {
@@ -549,9 +641,14 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
                 std::vector<uint8_t> used;
                 for (int attempt = 0; attempt < 64 && fa.anchor_q == 0; ++attempt, mul = mul * 0x2545F491u + 0x6B43A9B5u) {
                     mul = (mul | 1u) & 0xFFFFFFu;
+                    if (opt.anchor_choice != 0) {
+                        choose_offsets(mul);
+                        build_keys();
+                        fa.anchor_choice = 1;
+                    }
                     tab.assign(size_t(nb) * 8, uint16_t(0));
                     used.assign(nb, 0);
-                    std::vector<uint32_t> slot_pair(size_t(nb) * 8, kNone);
+                    std::vector<size_t> slot_of(keys.size());
                     bool ok = true;
                     for (size_t ki = 0; ki < keys.size(); ++ki) {
                         const uint32_t h = anchor_hash(keys[ki].data(), q / 4, mul);
@@ -561,11 +658,11 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
                         uint32_t slot = 0;
                         while (slot < used[bucket] && b[slot] != fp) ++slot;
                         if (slot == 8) { ok = false; break; }
-                        if (slot == used[bucket]) { b[used[bucket]++] = fp; slot_pair[size_t(bucket) * 8 + slot] = key_pair[ki]; }
-                        else slot_pair[size_t(bucket) * 8 + slot] = kNone;
+                        if (slot == used[bucket]) b[used[bucket]++] = fp;
+                        slot_of[ki] = size_t(bucket) * 8 + slot;
                     }
                     if (!ok) continue;
-                    fa.anchor_slot_pair.swap(slot_pair);
+                    make_slot_pairs(size_t(nb) * 8, slot_of);
                     fa.anchor_q = q;
                     fa.anchor_mode = 2;
                     fa.anchor_mul = mul;

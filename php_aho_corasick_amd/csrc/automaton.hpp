@@ -39,6 +39,8 @@ struct BuildOptions {
     uint64_t max_table_bytes = 8ull << 30;  // refuse automata whose dense table would exceed this (and that cannot go compact)
     int compact = -1;                       // goto/failure records instead of dense rows for states outside the first
                                             // BFS levels: 1 = always, 0 = never, -1 = when the dense table exceeds 64 MiB
+    int anchor_choice = -1;                 // big-set anchor filter: pick each pattern's anchor windows so that they share
+                                            // bitmap bits (-1 / 1 = yes, 0 = the first aligned window as in the small-set table)
     uint64_t dense_bytes = 4ull << 20;      // compact: dense rows are kept for the LDS tile, every state of trie depth <= 1
                                             // and further BFS-first states up to this many bytes of rows
     uint64_t max_flat_outputs = 1ull << 25; // flat output lists up to this many entries (256 MiB), else dictionary links only
@@ -136,6 +138,10 @@ struct FlatAutomaton {
     std::vector<uint32_t> anchor_slot_pair;
     std::vector<uint32_t> anchor_pairs;
     uint64_t anchor_pairs_count = 0;
+    // anchor_offsets[pattern * 4 + a]: offset of the anchor window of an occurrence whose first aligned text dword lies
+    // a bytes into the pattern (a itself; with anchor_choice a + 4j, see automaton.cpp)
+    uint32_t anchor_choice = 0;
+    std::vector<uint8_t> anchor_offsets;
 };
 
 constexpr uint32_t kAnchorBucketBits = 14;

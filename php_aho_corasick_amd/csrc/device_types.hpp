@@ -49,6 +49,7 @@ struct DevAutomaton {
     const uint8_t *pattern_bytes;
     uint32_t anchor_q, anchor_mul, min_pattern_length, max_pattern_length;
     uint32_t anchor_mode, anchor_bucket_mask;
+    uint32_t anchor_choice;      // 1: a pattern's anchor window may lie deeper than its first aligned dword (offset in the pair record)
 };
 
 // One batch launch.

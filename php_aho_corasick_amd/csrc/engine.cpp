@@ -140,6 +140,7 @@ struct acmi_handle {
     uint64_t items = 0, chunk_used = 0;
     uint32_t overflow_items = 0;
     uint64_t walked_bytes = 0;
+    uint64_t fallback_bytes = 0;  // anchor path: bytes of candidate clusters that were walked because verification could not decide
 
     std::string last_error;
 };
@@ -303,6 +304,7 @@ int ensure_device(acmi_handle *h) {
     A.anchor_mode = fa.anchor_mode;
     A.anchor_bitmap = fa.anchor_mode == 2 ? h->d_bitmap.as<uint32_t>() : nullptr;
     A.anchor_bucket_mask = fa.anchor_mode == 2 ? (1u << fa.anchor_bucket_bits) - 1u : 0u;
+    A.anchor_choice = fa.anchor_choice;
     A.anchor_mul = fa.anchor_mul;
     A.min_pattern_length = fa.min_pattern_length;
     A.max_pattern_length = fa.max_pattern_length;
@@ -553,6 +555,8 @@ int run_batch_end(acmi_handle *h) {
     h->overflow_items = n_ovf;
     h->walked_bytes = 0;  // counters[7..15]: k_scan_lds adds to [7], k_walk_runs spreads its workgroups over [8..15]
     for (int i = 7; i < 16; ++i) h->walked_bytes += uint64_t(reinterpret_cast<uint32_t *>(h->pinned)[i]) * 16;
+    h->fallback_bytes = h->kernel_used == 2 ? uint64_t(reinterpret_cast<uint32_t *>(h->pinned)[7]) * 16 : 0;
+    if (h->kernel_used == 2) h->walked_bytes -= h->fallback_bytes;  // (counters[7] is k_scan_lds' own share otherwise)
     // automatic mode: a batch of which more than a quarter had to be walked exactly defeats the filter
     const bool decisive = h->kernel == 3 && h->fly_blob_bytes >= kAutoMinBytes;
     if (decisive && h->kernel_used == 2) {
@@ -1018,6 +1022,9 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
         } else if (k == "compact") {
             if (h->aut.finalized()) return ACMI_E_FINALIZED;
             h->bopt.compact = value < 0 ? -1 : (value ? 1 : 0);
+        } else if (k == "anchor_choice") {
+            if (h->aut.finalized()) return ACMI_E_FINALIZED;
+            h->bopt.anchor_choice = value < 0 ? -1 : (value ? 1 : 0);
         } else if (k == "dense_bytes") {
             if (h->aut.finalized()) return ACMI_E_FINALIZED;
             if (value < 0) return ACMI_E_ARG;
@@ -1067,6 +1074,7 @@ int acmi_get_stat(const acmi_handle *h, const char *key, double *value) {
         else if (k == "chunk_bytes") *value = double(h->chunk_used);
         else if (k == "overflow_items") *value = h->overflow_items;
         else if (k == "walked_bytes") *value = double(h->walked_bytes);
+        else if (k == "fallback_bytes") *value = double(h->fallback_bytes);
         else if (k == "scan_ms") *value = h->scan_ms;
         else if (k == "walk_ms") *value = h->walk_ms;
         else if (k == "kernel_used") *value = h->kernel_used;
@@ -1079,6 +1087,7 @@ int acmi_get_stat(const acmi_handle *h, const char *key, double *value) {
         else if (k == "flat_outputs") *value = double(fa.n_flat_outputs);
         else if (k == "max_out_count") *value = fa.max_out_count;
         else if (k == "anchor_pairs") *value = double(fa.anchor_pairs_count);
+        else if (k == "anchor_choice") *value = fa.anchor_choice;
         else if (k == "compact") *value = fa.compact;
         else if (k == "dense_rows") *value = fa.n_dense_rows;
         else if (k == "cold_edges") *value = double(fa.cold_edges.size());
@@ -1125,6 +1134,8 @@ int acmi_debug_tables(const acmi_handle *h, acmi_tables *out) {
         out->anchor_bucket_bits = fa.anchor_bucket_bits;
         out->anchor_bitmap = fa.anchor_mode == 2 ? fa.anchor_bitmap.data() : nullptr;
         out->anchor_table = fa.anchor_q ? fa.anchor_table.data() : nullptr;
+        out->anchor_choice = fa.anchor_choice;
+        out->anchor_offsets = fa.anchor_offsets.empty() ? nullptr : fa.anchor_offsets.data();
         out->compact = fa.compact;
         out->dense_nf_end = fa.dense_nf_end;
         out->dense_f_end = fa.dense_f_end;

@@ -752,8 +752,12 @@ __device__ __forceinline__ uint32_t load4u(const uint8_t *a) {
     return *reinterpret_cast<const __attribute__((address_space(1))) u32_u *>(reinterpret_cast<uintptr_t>(a));
 }
 
-__device__ __forceinline__ bool verify_candidate(const DevAutomaton &A, const uint8_t *p, uint32_t n, uint32_t w, Verified &out) {
-    out = Verified{0xFFFFFFFFu, 0u};
+constexpr uint32_t kClusterMax = 6;   // occurrences a cluster of candidate windows may hold (more: the cluster is walked)
+
+// Appends the occurrences anchored at window w to v[0 .. nv) (kept in registers: the index is lane-divergent, hence the
+// select chain).  False when the window cannot be decided here.
+__device__ __forceinline__ bool verify_candidate(const DevAutomaton &A, const uint8_t *p, uint32_t n, uint32_t w,
+                                                 Verified (&v)[kClusterMax], uint32_t &nv) {
     if (w + A.anchor_q > n) return false;
     // the window's hash (automaton.hpp anchor_hash; the window lies inside the item: the filter tested it)
     const uint32_t nw = A.anchor_q >> 2;
@@ -767,48 +771,56 @@ __device__ __forceinline__ bool verify_candidate(const DevAutomaton &A, const ui
         const uint32_t bucket = h & A.anchor_bucket_mask;
         const uint4 b = static_cast<const uint4 *>(A.anchor_table)[bucket];
         const uint32_t fp = (h >> 16) | 1u;
-        const uint32_t v[4] = {b.x, b.y, b.z, b.w};
+        const uint32_t bv[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
         for (int i = 3; i >= 0; --i) {
-            if ((v[i] >> 16) == fp) slot = bucket * 8u + uint32_t(i) * 2u + 1u;
-            if ((v[i] & 0xffffu) == fp) slot = bucket * 8u + uint32_t(i) * 2u;
+            if ((bv[i] >> 16) == fp) slot = bucket * 8u + uint32_t(i) * 2u + 1u;
+            if ((bv[i] & 0xffffu) == fp) slot = bucket * 8u + uint32_t(i) * 2u;
         }
     } else {
         const uint32_t bucket = (h >> 3) & 0x3FFFu;
         const uint2 b = static_cast<const uint2 *>(A.anchor_table)[bucket];
         const uint32_t fp = h >> 16;
-        const uint32_t v[2] = {b.x, b.y};
+        const uint32_t bv[2] = {b.x, b.y};
 #pragma unroll
         for (int i = 1; i >= 0; --i) {
-            if ((v[i] >> 16) == fp) slot = bucket * 4u + uint32_t(i) * 2u + 1u;
-            if ((v[i] & 0xffffu) == fp) slot = bucket * 4u + uint32_t(i) * 2u;
+            if ((bv[i] >> 16) == fp) slot = bucket * 4u + uint32_t(i) * 2u + 1u;
+            if ((bv[i] & 0xffffu) == fp) slot = bucket * 4u + uint32_t(i) * 2u;
         }
     }
     if (slot == 0xFFFFFFFFu) return false;  // (cannot happen for a window the filter flagged; walk to be safe)
-    const uint32_t pair = A.anchor_slot_pair[slot];
-    if (pair == 0xFFFFFFFFu) return false;
-    const uint4 rec = A.anchor_pairs[pair];
-    const uint32_t o = rec.y & 0xffu, len = rec.y >> 8;
-    if (w < o || w - o + len > n) return true;  // the pattern would begin before / end after this item's bytes: no occurrence
-    const uint8_t *tp = p + (w - o), *pp = A.pattern_bytes + rec.z;
-    uint32_t diff = 0;
-    if (len >= 16u) {
+    const uint32_t sp = A.anchor_slot_pair[slot];
+    if (sp == 0xFFFFFFFFu) return false;    // too many pairs behind this slot
+    const uint32_t first = sp & 0x0FFFFFFFu, count = (sp >> 28) + 1u;
+    // every (pattern, offset) pair the slot stands for: the q-gram's own, those of q-grams that share its fingerprint
 #pragma unroll 1
-        for (uint32_t c = 0; c + 16u <= len; c += 16u) {
-            const uint4 a = load16u(tp + c), b = load16u(pp + c);
+    for (uint32_t k = 0; k < count; ++k) {
+        const uint4 rec = A.anchor_pairs[first + k];
+        const uint32_t o = rec.y & 0xffu, len = rec.y >> 8;
+        if (w < o || w - o + len > n) continue;  // would begin before / end after this item's bytes: no occurrence here
+        const uint8_t *tp = p + (w - o), *pp = A.pattern_bytes + rec.z;
+        uint32_t diff = 0;
+        if (len >= 16u) {
+#pragma unroll 1
+            for (uint32_t c = 0; c + 16u <= len; c += 16u) {
+                const uint4 a = load16u(tp + c), b = load16u(pp + c);
+                diff |= (a.x ^ b.x) | (a.y ^ b.y) | (a.z ^ b.z) | (a.w ^ b.w);
+            }
+            const uint4 a = load16u(tp + len - 16u), b = load16u(pp + len - 16u);  // the last 16 bytes (may overlap)
             diff |= (a.x ^ b.x) | (a.y ^ b.y) | (a.z ^ b.z) | (a.w ^ b.w);
+        } else if (len >= 8u) {
+            const uint2 a0 = load8u(tp), b0 = load8u(pp), a1 = load8u(tp + len - 8u), b1 = load8u(pp + len - 8u);
+            diff = (a0.x ^ b0.x) | (a0.y ^ b0.y) | (a1.x ^ b1.x) | (a1.y ^ b1.y);
+        } else {  // 7 bytes (patterns shorter than that are not anchor-eligible)
+            diff = (load4u(tp) ^ load4u(pp)) | (load4u(tp + len - 4u) ^ load4u(pp + len - 4u));
         }
-        const uint4 a = load16u(tp + len - 16u), b = load16u(pp + len - 16u);  // the last 16 bytes (may overlap)
-        diff |= (a.x ^ b.x) | (a.y ^ b.y) | (a.z ^ b.z) | (a.w ^ b.w);
-    } else if (len >= 8u) {
-        const uint2 a0 = load8u(tp), b0 = load8u(pp), a1 = load8u(tp + len - 8u), b1 = load8u(pp + len - 8u);
-        diff = (a0.x ^ b0.x) | (a0.y ^ b0.y) | (a1.x ^ b1.x) | (a1.y ^ b1.y);
-    } else {  // 7 bytes (patterns shorter than that are not anchor-eligible)
-        diff = (load4u(tp) ^ load4u(pp)) | (load4u(tp + len - 4u) ^ load4u(pp + len - 4u));
+        if (diff) continue;
+        if (nv >= kClusterMax) return false;
+        const Verified vv{w - o + len - 1u, rec.w};  // index of the occurrence's last byte, the pattern's final state
+#pragma unroll
+        for (uint32_t i = 0; i < kClusterMax; ++i) if (i == nv) v[i] = vv;
+        ++nv;
     }
-    if (diff) return true;
-    out.j = w - o + len - 1u;  // index of the occurrence's last byte
-    out.state = rec.w;
     return true;
 }
 
@@ -818,10 +830,8 @@ __device__ __forceinline__ bool verify_candidate(const DevAutomaton &A, const ui
 // elsewhere would have flagged a run of its own, overlapping this range, hence in the cluster).  So a cluster of
 // window runs is decided by verifying its windows (verify_candidate) and emitting the occurrences found in
 // position order -- of two that end at the same byte only the longer is an event, the shorter is in its output
-// list.  Clusters with a run that names no window (unaligned head, tail, a swallowed window), with a window whose
-// q-gram names several patterns, or with more than kClusterMax windows are walked as one range.
-constexpr uint32_t kClusterMax = 4;
-
+// list.  Clusters with a run that names no window (unaligned head, tail, a swallowed window), with a fingerprint slot
+// that stands for more than 8 pairs, or with more than kClusterMax occurrences are walked as one range.
 template <typename E, int MODE, bool EXTRA>
 __device__ __forceinline__ uint32_t run_epilogue_fast(const DevAutomaton &A, const BatchArgs &B, const uint8_t *tile,
                                                       uint32_t tile_rows, uint64_t item, const ItemDesc &it, uint32_t nr) {
@@ -841,12 +851,12 @@ __device__ __forceinline__ uint32_t run_epilogue_fast(const DevAutomaton &A, con
         while (r < nr) {
             // the cluster that starts with run r
             const uint4 first = run;
-            uint32_t hi = first.y, count = 1;
+            uint32_t hi = first.y, count = 1, nv = 0;
             bool windows = entry_is_window(first.z) && A.anchor_pairs != nullptr;
             Verified v[kClusterMax];
 #pragma unroll
             for (uint32_t i = 0; i < kClusterMax; ++i) v[i] = Verified{0xFFFFFFFFu, 0u};
-            if (windows) windows = verify_candidate(A, p, n, first.z & ~kEntryWindow, v[0]);
+            if (windows) windows = verify_candidate(A, p, n, first.z & ~kEntryWindow, v, nv);
 #pragma unroll 1
             for (;;) {
                 ++r;
@@ -854,14 +864,8 @@ __device__ __forceinline__ uint32_t run_epilogue_fast(const DevAutomaton &A, con
                 run = runs[uint64_t(r) * B.run_stride];
                 if (run.x != hi) break;  // not adjacent: the next cluster
                 hi = run.y;
-                windows = windows && entry_is_window(run.z) && count < kClusterMax;
-                if (windows) {
-                    Verified vv;
-                    windows = verify_candidate(A, p, n, run.z & ~kEntryWindow, vv);
-                    // (kept in registers: the slot index is wave-divergent, so a select chain instead of v[count])
-#pragma unroll
-                    for (uint32_t i = 1; i < kClusterMax; ++i) if (i == count) v[i] = vv;
-                }
+                windows = windows && entry_is_window(run.z);
+                if (windows) windows = verify_candidate(A, p, n, run.z & ~kEntryWindow, v, nv);
                 ++count;
             }
             const uint32_t lo = first.x;
@@ -896,7 +900,7 @@ __device__ __forceinline__ uint32_t run_epilogue_fast(const DevAutomaton &A, con
             // walk the cluster as one range: from the root, m_min-1 bytes before a window's own lower bound (every
             // pattern that ends in the cluster begins at or after the first window - 3), Lmax-1 bytes otherwise
             uint32_t st = 0, from = lo, stop_from = 0xFFFFFFFFu;
-            if (entry_is_window(first.z) && lo + 4u == (first.z & ~kEntryWindow) + A.min_pattern_length) {
+            if (!A.anchor_choice && entry_is_window(first.z) && lo + 4u == (first.z & ~kEntryWindow) + A.min_pattern_length) {
                 const uint32_t warm = A.min_pattern_length - 1u;
                 from = lo > warm ? lo - warm : 0u;
                 // a lone window: nothing is alive once the state is shallow two bytes past the window start
@@ -907,6 +911,7 @@ __device__ __forceinline__ uint32_t run_epilogue_fast(const DevAutomaton &A, con
                 from = lo > B.warm_bytes ? lo - B.warm_bytes : 0u;
             }
             walk_fast<E, MODE, EXTRA>(A, B, tile, tile_rows, item, p, from, hi, n, rep_from, pos_bias, st, ev, stop_from);
+            atomicAdd(&B.counters[7], (hi - from + 15u) >> 4);  // statistic: bytes walked because verification could not decide
         }
     }
     if (ev.n_ev) {
@@ -1205,6 +1210,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t mul = A.anchor_mul;
     const uint32_t q = QW * 4u, m_min = A.min_pattern_length, l_max = A.max_pattern_length;
+    const uint32_t lo_bias = A.anchor_choice ? q - 1u : m_min - 4u;
     const uint64_t total_items = B.item_base[B.n_haystacks];
 
     // Persistent mode: waves pull batches of items from counters[1] until none are left.
@@ -1427,7 +1433,9 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                 const uint32_t w = uint32_t(__builtin_ctz(wmask));
                 // the window ending at dword w of quad qi starts QW-1 dwords earlier
                 const int32_t start = int32_t(sc.head + (qi << 4) + 4u * w) - int32_t(q - 4u);
-                int32_t lo = start + int32_t(m_min) - 4;
+                // the end of a pattern anchored here: at least m_min - 4 past the window start when the window is the
+                // pattern's FIRST aligned dword, at least q - 1 when the builder chose a deeper window (anchor_choice)
+                int32_t lo = start + int32_t(lo_bias);
                 uint32_t hi = uint32_t(start + int32_t(l_max));
                 if (lo < 0) lo = 0;
                 if (hi > sc.n) hi = sc.n;
@@ -1481,7 +1489,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
         if (sc.c + 1u == sc.chunks) {
             // anchors the main loop did not test start after head + 16*nq - q: what they could match
             // ends at or after head + 16*nq - q + m_min
-            uint32_t lo = sc.head + (sc.nq << 4) + m_min;
+            uint32_t lo = sc.head + (sc.nq << 4) + (A.anchor_choice ? q : m_min);
             lo = lo > q ? lo - q : 0u;
             if (nrun > 0 && lo < run_hi) lo = run_hi;
             if (sc.head + (sc.nq << 4) < sc.n) {

@@ -82,12 +82,18 @@ class FlatTables:
         self.anchor_q, self.anchor_mul, self.min_pattern_length = t.anchor_q, t.anchor_mul, t.min_pattern_length
         self.anchor_keys = t.anchor_keys
         self.anchor_mode, self.anchor_bucket_bits = t.anchor_mode, t.anchor_bucket_bits
+        self.anchor_choice = t.anchor_choice
+        self.anchor_offsets = None   # filled by test code that knows the pattern count
+        self._anchor_offsets_ptr = t.anchor_offsets
         self.anchor = self.anchor_bitmap = None
         if t.anchor_mode == 1:
             self.anchor = np.ctypeslib.as_array(t.anchor_table, shape=(16384, 4)).copy()
         elif t.anchor_mode == 2:
             self.anchor = np.ctypeslib.as_array(t.anchor_table, shape=(1 << t.anchor_bucket_bits, 8)).copy()
             self.anchor_bitmap = np.ctypeslib.as_array(t.anchor_bitmap, shape=(1 << 15,)).copy()
+
+    def anchor_offset(self, pattern: int, a: int) -> int:
+        return int(self._anchor_offsets_ptr[pattern * 4 + a]) if self._anchor_offsets_ptr else a
 
     def anchor_probe(self, window: bytes) -> bool:
         """The device's window test (k_scan_anchor), restated: hash q bytes, look the fingerprint up."""

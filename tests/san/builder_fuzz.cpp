@@ -217,29 +217,40 @@ int run_case(uint64_t seed, bool verbose) {
     if (fa.anchor_q) {
         for (const PatternMeta &m : aut.patterns()) {
             if (!m.accepted) continue;
-            for (uint32_t off = 0; off < 4; ++off)
+            for (uint32_t a = 0; a < 4; ++a) {
+                const uint32_t off = fa.anchor_offsets[size_t(&m - aut.patterns().data()) * 4 + a];
+                if (off % 4 != a || off + fa.anchor_q > m.length) { std::fprintf(stderr, "seed %llu: bad anchor offset\n", (unsigned long long)seed); bad = 1; continue; }
                 if (!anchor_probe(fa, aut.pattern_bytes().data() + m.byte_off + off)) {
                     std::fprintf(stderr, "seed %llu: anchor false negative\n", (unsigned long long)seed);
                     bad = 1;
                 }
+            }
         }
         // verification pairs: a slot either names exactly the (pattern, offset) whose q-gram it holds, or nothing
         size_t named = 0;
         for (size_t pi = 0; pi < aut.patterns().size() && !fa.anchor_slot_pair.empty(); ++pi) {
             const PatternMeta &m = aut.patterns()[pi];
             if (!m.accepted) continue;
-            for (uint32_t off = 0; off < 4; ++off) {
+            for (uint32_t a = 0; a < 4; ++a) {
+                const uint32_t off = fa.anchor_offsets[pi * 4 + a];
                 const long slot = anchor_slot(fa, aut.pattern_bytes().data() + m.byte_off + off);
                 if (slot < 0) { std::fprintf(stderr, "seed %llu: no slot\n", (unsigned long long)seed); bad = 1; continue; }
-                const uint32_t pair = fa.anchor_slot_pair[size_t(slot)];
-                if (pair == kNone) continue;
-                const uint32_t *rec = &fa.anchor_pairs[size_t(pair) * 4];
-                const uint32_t st = rec[3];
-                // the slot's pair must be THIS pattern at THIS offset (else some other pattern shares the q-gram and
-                // the slot had to be unnamed), with its length, bytes and final state
-                if (rec[0] != pi || (rec[1] & 0xffu) != off || (rec[1] >> 8) != m.length || rec[2] != m.byte_off ||
-                    st >= fa.n_states || fa.own_pattern[st] != pi) {
-                    std::fprintf(stderr, "seed %llu: verification pair of pattern %zu offset %u is wrong\n", (unsigned long long)seed, pi, off);
+                const uint32_t sp = fa.anchor_slot_pair[size_t(slot)];
+                if (sp == kNone) continue;
+                // the slot's pair list must hold THIS pattern at THIS offset with its length, bytes and final state
+                bool found = false;
+                for (uint32_t k = 0; k <= (sp >> 28); ++k) {
+                    const uint32_t *rec = &fa.anchor_pairs[(size_t(sp & 0x0FFFFFFFu) + k) * 4];
+                    const uint32_t st = rec[3];
+                    if (st >= fa.n_states || fa.own_pattern[st] != rec[0] || (rec[1] >> 8) != aut.patterns()[rec[0]].length ||
+                        rec[2] != aut.patterns()[rec[0]].byte_off) {
+                        std::fprintf(stderr, "seed %llu: malformed verification pair\n", (unsigned long long)seed);
+                        bad = 1;
+                    }
+                    found = found || (rec[0] == pi && (rec[1] & 0xffu) == off);
+                }
+                if (!found) {
+                    std::fprintf(stderr, "seed %llu: verification pairs of pattern %zu offset %u are missing\n", (unsigned long long)seed, pi, off);
                     bad = 1;
                 }
                 ++named;

@@ -130,8 +130,10 @@ def test_anchor_table_has_no_false_negatives(name, q, mode):
     assert ft.anchor_q == q and ft.anchor_mode == mode and ft.min_pattern_length >= q + 3
     for k in range(0, ds.n_patterns, 1 if ds.n_patterns <= 5000 else 37):
         p = ds.pattern(k)
-        for o in range(4):
-            assert ft.anchor_probe(p[o:o + q]), (name, k, o)
+        for a in range(4):
+            o = ft.anchor_offset(k, a)   # the anchor window of an occurrence whose first aligned dword lies a bytes in
+            assert o % 4 == a and o + q <= len(p) and (o == a or ft.anchor_choice == 1)
+            assert ft.anchor_probe(p[o:o + q]), (name, k, a, o)
     rng = np.random.default_rng(5)
     fp = sum(ft.anchor_probe(rng.integers(0, 256, q, dtype=np.uint8).tobytes()) for _ in range(4000))
     assert fp <= 8   # q = 4 over G6's 262,144 q-grams: 6e-5 per random window

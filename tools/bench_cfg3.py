@@ -11,7 +11,7 @@ ds = synth.g6(n_hay=4096, hay_len=4096)
 t0 = time.time()
 res = api.ahocorasick_init([{"id": k, "value": ds.pattern(k)} for k in range(ds.n_patterns)])
 t1 = time.time()
-BUILD_OPTS = ("lds_bytes", "max_table_bytes", "max_flat_outputs", "compact", "dense_bytes")
+BUILD_OPTS = ("lds_bytes", "max_table_bytes", "max_flat_outputs", "compact", "dense_bytes", "anchor_choice", "verify")
 for k, v in opts.items():
     if k in BUILD_OPTS:
         res.set_option(k, int(v))
@@ -38,4 +38,4 @@ for _ in range(3):
     torch.cuda.synchronize()
     dt = time.time() - t0
     print(f"scan {d_blob.numel()/dt/1e9:.2f} GB/s whole-job ({dt*1e3:.2f} ms), kernel {res.stat('scan_ms'):.2f} ms = {d_blob.numel()/res.stat('scan_ms')/1e6:.2f} GB/s, "
-          f"walk {res.stat('walk_ms'):.3f} ms, records {total}, compact {int(res.stat('compact'))} dense rows {int(res.stat('dense_rows'))}")
+          f"walk {res.stat('walk_ms'):.3f} ms, fallback {int(res.stat('fallback_bytes'))} B of {int(res.stat('walked_bytes'))} flagged, records {total}, compact {int(res.stat('compact'))} dense rows {int(res.stat('dense_rows'))}")
