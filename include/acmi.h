@@ -272,6 +272,10 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *   "verify"         1 (default): a candidate of the anchor filter whose q-gram belongs to exactly one (pattern, offset)
  *                    pair is decided by comparing that pattern's text with the haystack; 0: every candidate is walked
  *                    through the automaton.  Same records either way                              [before the first match]
+ *   "device_build"   the level-synchronous part of the build -- failure links (ahocorasick.c:344-368) and per-state outputs
+ *                    (node.c:424-441), one kernel launch per trie depth -- on the device: 1 = always (when a gfx950 device
+ *                    is there), 0 = never, -1 (default) = from 200,000 trie nodes.  Same tables either way ("built_on_device")
+ *                                                                                                  [before finalize]
  *   "keep_host_tables"  1 = keep the host copies of the tables after they were uploaded (acmi_debug_tables after a
  *                    match call); default 0: they are freed by the first match call               [before the first match]
  *   "max_flat_outputs"  per-state output lists are also stored flat ({pattern, length}, longest first) for the
@@ -324,6 +328,7 @@ typedef struct acmi_tables {
     const uint16_t *anchor_table; /* mode 1: 16384 buckets x 4 fingerprints; mode 2: 2^bucket_bits x 8 */
     uint32_t anchor_mode;         /* 0 none, 1 LDS table, 2 LDS bitmap + global table */
     uint32_t anchor_bucket_bits;  /* mode 2                                    */
+    uint32_t anchor_bucket_shift; /* mode 2: bucket = (hash >> shift) & (2^bits - 1) */
     const uint32_t *anchor_bitmap;/* mode 2: 32768 words (2^20 bits)           */
     uint32_t anchor_choice;       /* 1: anchor windows chosen among the aligned windows of a pattern (mode 2) */
     const uint8_t *anchor_offsets;/* [pattern * 4 + a]: offset of the anchor window when the first aligned text dword lies a bytes into the pattern */

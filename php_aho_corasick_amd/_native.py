@@ -44,7 +44,8 @@ class Tables(C.Structure):
                 ("out_count", C.POINTER(C.c_uint32)),
                 ("anchor_q", C.c_uint32), ("anchor_mul", C.c_uint32), ("min_pattern_length", C.c_uint32),
                 ("anchor_keys", C.c_uint32), ("anchor_table", C.POINTER(C.c_uint16)),
-                ("anchor_mode", C.c_uint32), ("anchor_bucket_bits", C.c_uint32), ("anchor_bitmap", C.POINTER(C.c_uint32)),
+                ("anchor_mode", C.c_uint32), ("anchor_bucket_bits", C.c_uint32), ("anchor_bucket_shift", C.c_uint32),
+                ("anchor_bitmap", C.POINTER(C.c_uint32)),
                 ("anchor_choice", C.c_uint32), ("anchor_offsets", C.POINTER(C.c_uint8)),
                 ("n_flat_outputs", C.c_uint32), ("compact", C.c_uint32), ("dense_nf_end", C.c_uint32),
                 ("dense_f_end", C.c_uint32), ("n_dense_rows", C.c_uint32), ("n_cold_edges", C.c_uint32),

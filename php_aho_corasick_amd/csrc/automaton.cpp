@@ -3,6 +3,9 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace acmi {
@@ -149,8 +152,17 @@ size_t Automaton::add_batch(const uint8_t *const *values, const uint32_t *length
     return accepted;
 }
 
-bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
+bool Automaton::finalize(const BuildOptions &opt, std::string *error, const BuildAccel *accel) {
     if (finalized_) return true;
+    // ACMI_BUILD_TRACE=1: phase times on stderr
+    const bool trace = std::getenv("ACMI_BUILD_TRACE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[acmi build] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     const uint32_t ns = uint32_t(parent_.size());
     FlatAutomaton &fa = flat_;
 
@@ -170,31 +182,53 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
         for (uint32_t e = child_off[u]; e < child_off[u + 1]; ++e) order.push_back(child_list[e]);
     }
 
-    // ---- failure links (textbook BFS; same function as ahocorasick.c:344-368 defines) ----
+    // ---- failure links (textbook BFS; same function as ahocorasick.c:344-368 defines) and per-state output:
+    // final flag, record count, dictionary link (node.c:424-441).  Level-synchronous: on the device when the engine
+    // offers it (one launch per trie depth), else here.
     std::vector<uint32_t> fail(ns, 0);
-    for (uint32_t u : order) {
-        if (u == 0) continue;
-        const uint32_t p = parent_[u];
-        if (p == 0) continue;
-        const uint8_t b = in_byte_[u];
-        uint32_t f = fail[p];
-        for (;;) {
-            const uint32_t c = find_child(f, b);
-            if (c != kNone) { fail[u] = c; break; }
-            if (f == 0) break;
-            f = fail[f];
-        }
-    }
-
-    // ---- per-state output: final flag, record count, dictionary link (node.c:424-441) ----
     std::vector<uint8_t> is_final(ns, 0);
     std::vector<uint32_t> cnt(ns, 0), dict(ns, kNone);
-    for (uint32_t u : order) {
-        if (u == 0) continue;
-        const uint32_t f = fail[u];
-        is_final[u] = (own_[u] != kNone) || is_final[f];
-        cnt[u] = (own_[u] != kNone ? 1u : 0u) + cnt[f];
-        dict[u] = own_[f] != kNone ? f : dict[f];
+    bool done = false;
+    if (accel && accel->fail_and_outputs) {
+        std::vector<uint32_t> level_off{0};
+        {   // BFS order is depth order: a level ends where a node's parent lies in the current level
+            std::vector<uint32_t> depth_of(ns, 0);
+            uint32_t cur = 0;
+            for (uint32_t i = 1; i < ns; ++i) {
+                const uint32_t u = order[i];
+                depth_of[u] = depth_of[parent_[u]] + 1;
+                if (depth_of[u] != cur) { level_off.push_back(i); cur = depth_of[u]; }
+            }
+            level_off.push_back(ns);
+        }
+        TrieView tv{ns, parent_.data(), in_byte_.data(), own_.data(), order.data(), level_off.data(), uint32_t(level_off.size() - 1),
+                    map_keys_.data(), map_vals_.data(), map_keys_.size()};
+        done = accel->fail_and_outputs(accel->ctx, tv, fail.data(), is_final.data(), cnt.data(), dict.data());
+        built_on_device_ = done;
+        lap(done ? "failure links + outputs (device)" : "device build declined");
+    }
+    if (!done) {
+        for (uint32_t u : order) {
+            if (u == 0) continue;
+            const uint32_t p = parent_[u];
+            if (p == 0) continue;
+            const uint8_t b = in_byte_[u];
+            uint32_t f = fail[p];
+            for (;;) {
+                const uint32_t c = find_child(f, b);
+                if (c != kNone) { fail[u] = c; break; }
+                if (f == 0) break;
+                f = fail[f];
+            }
+        }
+        lap("children CSR + failure links");
+        for (uint32_t u : order) {
+            if (u == 0) continue;
+            const uint32_t f = fail[u];
+            is_final[u] = (own_[u] != kNone) || is_final[f];
+            cnt[u] = (own_[u] != kNone ? 1u : 0u) + cnt[f];
+            dict[u] = own_[f] != kNone ? f : dict[f];
+        }
     }
 
     // ---- byte classes ----------------------------------------------------------------------
@@ -349,6 +383,7 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
         }
     }
 
+    lap("outputs, classes, numbering");
     // ---- tables ----------------------------------------------------------------------------------
     if (fa.entry_bytes == 2)
         build_tables<uint16_t>(fa, order, dense, fail, newid, child_off, child_list, in_byte_);
@@ -444,6 +479,7 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
         }
     }
 
+    lap("rows, records, output lists");
     // final state of every accepted pattern (the state whose own pattern it is)
     std::vector<uint32_t> pattern_state(patterns_.size(), kNone);
     for (uint32_t u = 0; u < ns; ++u)
@@ -533,6 +569,7 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
             fa.anchor_pairs_count = fa.anchor_pairs.size() / 4;
         };
         build_keys();
+        lap("anchor keys");
         // Big sets: WHICH aligned window of a pattern is its anchor is free -- an occurrence whose first aligned text
         // dword lies a bytes into the pattern contains the windows at a, a+4, a+8, ... -- and the LDS bitmap passes a
         // window when ANY key shares its bit, so the (pattern, class) pairs are covered with as few distinct bits as
@@ -639,12 +676,21 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
                 const uint32_t nb = 1u << bits;
                 std::vector<uint16_t> tab;
                 std::vector<uint8_t> used;
-                for (int attempt = 0; attempt < 64 && fa.anchor_q == 0; ++attempt, mul = mul * 0x2545F491u + 0x6B43A9B5u) {
-                    mul = (mul | 1u) & 0xFFFFFFu;
-                    if (opt.anchor_choice != 0) {
-                        choose_offsets(mul);
-                        build_keys();
-                        fa.anchor_choice = 1;
+                // A bucket overflows with probability ~ 1e-6 (load 1 of 8): 0.3 per seed for 262,144 buckets.  The first
+                // retries only move the bucket index to other hash bits (anchor_bucket_shift) -- the hash itself, and with
+                // it the anchor-window choice and the bitmap (0.35 s for 65,536 patterns), stay; then a new multiplier.
+                for (int attempt = 0; attempt < 64 && fa.anchor_q == 0; ++attempt) {
+                    const uint32_t shift = uint32_t(attempt) % 7u;
+                    if (shift == 0) {
+                        if (attempt) mul = mul * 0x2545F491u + 0x6B43A9B5u;
+                        mul = (mul | 1u) & 0xFFFFFFu;
+                        if (opt.anchor_choice != 0) {
+                            choose_offsets(mul);
+                            lap("anchor window choice");
+                            build_keys();
+                            fa.anchor_choice = 1;
+                            lap("anchor keys again");
+                        }
                     }
                     tab.assign(size_t(nb) * 8, uint16_t(0));
                     used.assign(nb, 0);
@@ -653,7 +699,7 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
                     for (size_t ki = 0; ki < keys.size(); ++ki) {
                         const uint32_t h = anchor_hash(keys[ki].data(), q / 4, mul);
                         const uint16_t fp = uint16_t((h >> 16) | 1u);
-                        const uint32_t bucket = h & (nb - 1);
+                        const uint32_t bucket = (h >> shift) & (nb - 1);
                         uint16_t *b = &tab[size_t(bucket) * 8];
                         uint32_t slot = 0;
                         while (slot < used[bucket] && b[slot] != fp) ++slot;
@@ -667,6 +713,7 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
                     fa.anchor_mode = 2;
                     fa.anchor_mul = mul;
                     fa.anchor_bucket_bits = bits;
+                    fa.anchor_bucket_shift = shift;
                     fa.anchor_table = tab;
                     fa.anchor_bitmap.assign(kAnchorBitmapWords, 0u);
                     for (const auto &k : keys) {
@@ -678,6 +725,7 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error) {
         }
     }
 
+    lap("anchor table + pairs");
     // the build-time trie is no longer needed
     std::vector<uint64_t>().swap(map_keys_);
     std::vector<uint32_t>().swap(map_vals_);

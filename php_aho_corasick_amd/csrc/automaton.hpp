@@ -46,6 +46,27 @@ struct BuildOptions {
     uint64_t max_flat_outputs = 1ull << 25; // flat output lists up to this many entries (256 MiB), else dictionary links only
 };
 
+// The part of finalize() that a device can take over (engine.cpp / kernels.hip k_build_level): failure links and
+// per-state outputs are level-synchronous -- a node needs only shallower nodes' results -- so one kernel launch per
+// trie depth computes them for all nodes of that depth at once, walking the same open-addressing child map.
+struct TrieView {
+    uint32_t n_nodes;
+    const uint32_t *parent;        // per node
+    const uint8_t *in_byte;        // per node
+    const uint32_t *own;           // per node: pattern index or kNone
+    const uint32_t *order;         // nodes in BFS order (order[0] = root)
+    const uint32_t *level_off;     // n_levels + 1 offsets into `order`: level d = [level_off[d], level_off[d+1])
+    uint32_t n_levels;
+    const uint64_t *map_keys;      // (parent << 8 | byte) + 1, 0 = empty; linear probing from mix(key) & (map_size - 1)
+    const uint32_t *map_vals;
+    uint64_t map_size;
+};
+struct BuildAccel {
+    void *ctx = nullptr;
+    // fills fail / is_final / cnt / dict (all n_nodes entries); false: not done, the host computes them
+    bool (*fail_and_outputs)(void *ctx, const TrieView &tv, uint32_t *fail, uint8_t *is_final, uint32_t *cnt, uint32_t *dict) = nullptr;
+};
+
 enum ClassMode : uint32_t { kClassTable = 0, kClassSwar3 = 1 };
 
 // Everything the device needs, in host memory, after finalize().
@@ -120,13 +141,14 @@ struct FlatAutomaton {
     //     fingerprints, resident in LDS (empty slots: anchor_empty()).
     //   mode 2 (more): anchor_bitmap = 2^20 bits in LDS (bit = top 20 bits of the hash) in front of a
     //     fingerprint table in global memory / L2: 2^anchor_bucket_bits buckets x 8 slots, bucket = low
-    //     bits of the hash, fingerprint = (hash >> 16) | 1, 0 = empty slot.
+    //     bits of the hash (from bit anchor_bucket_shift on), fingerprint = (hash >> 16) | 1, 0 = empty slot.
     uint32_t min_pattern_length = 0;
     uint32_t anchor_q = 0;        // 0 = not eligible; else 4, 8, 12 or 16 bytes
     uint32_t anchor_mode = 0;     // 0 none, 1 LDS table, 2 LDS bitmap + global table
     uint32_t anchor_mul = 0;      // odd multiplier of the window hash (seed that gave no bucket overflow)
     uint32_t anchor_keys = 0;
     uint32_t anchor_bucket_bits = 0;  // mode 2
+    uint32_t anchor_bucket_shift = 0; // mode 2: bucket = (hash >> shift) & (2^bits - 1)
     std::vector<uint16_t> anchor_table;
     std::vector<uint32_t> anchor_bitmap;  // mode 2: 32768 words
     // Candidate verification by text compare (k_walk_runs).  A hit window whose q-gram belongs to exactly one
@@ -176,7 +198,8 @@ public:
                      const uint64_t *users, size_t n);
 
     // Returns false (and sets error) when the automaton cannot be represented.
-    bool finalize(const BuildOptions &opt, std::string *error);
+    bool finalize(const BuildOptions &opt, std::string *error, const BuildAccel *accel = nullptr);
+    bool built_on_device() const { return built_on_device_; }
 
     // search and replace (AC_PATTERN_t.rtext, actypes.h:88-94): replacement text of caller-order pattern `index`, kept as
     // the reference keeps it -- through strncpy (mpool_strndup, mpool.c:165-178): bytes up to the first NUL, zeros after
@@ -228,6 +251,7 @@ private:
     std::vector<uint8_t> rep_bytes_;
     std::vector<uint64_t> rep_off_;
     bool finalized_ = false;
+    bool built_on_device_ = false;
     bool host_tables_released_ = false;
     FlatAutomaton flat_;
 };

@@ -48,7 +48,7 @@ struct DevAutomaton {
     const uint4 *anchor_pairs;   // {pattern, offset | length << 8, byte offset in pattern_bytes, final state}
     const uint8_t *pattern_bytes;
     uint32_t anchor_q, anchor_mul, min_pattern_length, max_pattern_length;
-    uint32_t anchor_mode, anchor_bucket_mask;
+    uint32_t anchor_mode, anchor_bucket_mask, anchor_bucket_shift;   // mode 2: bucket = (hash >> shift) & mask
     uint32_t anchor_choice;      // 1: a pattern's anchor window may lie deeper than its first aligned dword (offset in the pair record)
 };
 
@@ -79,6 +79,19 @@ struct BatchArgs {
     uint32_t poison_quads;       // ceil(max_pattern_length / 16): quads flagged after a lost state
     uint32_t persistent;         // 1: one workgroup per CU, waves pull item batches from counters[1]
     uint32_t wave_items;         // k_scan_anchor: items a wave takes per batch (1..64)
+};
+
+// one trie depth of the automaton build (k_build_level); all pointers are device pointers
+struct BuildArgs {
+    const uint32_t *parent;
+    const uint8_t *in_byte;
+    const uint32_t *own;
+    const uint32_t *order;
+    const uint64_t *map_keys;
+    const uint32_t *map_vals;
+    uint64_t map_size;
+    uint32_t *fail, *cnt, *dict;
+    uint8_t *is_final;
 };
 
 // search and replace over a matched batch (k_replace_plan / k_replace_emit)

@@ -92,6 +92,7 @@ struct acmi_handle {
     int refill = 0;       // 0 automatic, 1 one thread per overflowed item (k_refill), 2 one wave (k_refill_wave)
     int profile = 0;
     int verify = 1;            // 1: anchor candidates whose q-gram names one pattern are decided by comparing its text
+    int device_build = -1;     // failure links + outputs of the build on the device: -1 from 200,000 trie nodes, 0 never, 1 always
     int keep_host_tables = 0;  // 1: the host copies of table / tile / records stay after the upload (acmi_debug_tables)
 
     // device state
@@ -166,10 +167,55 @@ int fail_hip(acmi_handle *h, hipError_t e, const char *what) {
 
 constexpr uint64_t kAutoMinBytes = 1ull << 20;
 
+// Failure links and per-state outputs on the device, one launch per trie depth (kernels.hip k_build_level).  Used for
+// big tries when a gfx950 device is there ("device_build": -1 automatic from 200,000 nodes, 0 never, 1 always);
+// anything that goes wrong hands the work back to the host loop -- the results are the same words either way.
+bool device_fail_and_outputs(void *ctx, const TrieView &tv, uint32_t *fail, uint8_t *is_final, uint32_t *cnt, uint32_t *dict) {
+    acmi_handle *h = static_cast<acmi_handle *>(ctx);
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return false; }
+    int dev = h->device_request;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return false;
+    if (dev >= count || hipSetDevice(dev) != hipSuccess) return false;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return false;
+    const size_t n = tv.n_nodes;
+    DevBuf d_parent, d_byte, d_own, d_order, d_keys, d_vals, d_fail, d_cnt, d_dict, d_final;
+    auto up = [&](DevBuf &b, const void *src, size_t bytes) {
+        return b.ensure(bytes) == hipSuccess && hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+    };
+    bool ok = up(d_parent, tv.parent, n * 4) && up(d_byte, tv.in_byte, n) && up(d_own, tv.own, n * 4) && up(d_order, tv.order, n * 4) &&
+              up(d_keys, tv.map_keys, tv.map_size * 8) && up(d_vals, tv.map_vals, tv.map_size * 4) &&
+              d_fail.ensure(n * 4) == hipSuccess && d_cnt.ensure(n * 4) == hipSuccess && d_dict.ensure(n * 4) == hipSuccess &&
+              d_final.ensure(n) == hipSuccess;
+    if (ok) {
+        // the root: no failure link, no output (the level loop starts at depth 1 and reads these)
+        ok = hipMemset(d_fail.p, 0, 4) == hipSuccess && hipMemset(d_cnt.p, 0, 4) == hipSuccess &&
+             hipMemset(d_dict.p, 0xFF, 4) == hipSuccess && hipMemset(d_final.p, 0, 1) == hipSuccess;
+    }
+    if (ok) {
+        BuildArgs T{d_parent.as<uint32_t>(), d_byte.as<uint8_t>(), d_own.as<uint32_t>(), d_order.as<uint32_t>(), d_keys.as<uint64_t>(),
+                    d_vals.as<uint32_t>(), tv.map_size, d_fail.as<uint32_t>(), d_cnt.as<uint32_t>(), d_dict.as<uint32_t>(), d_final.as<uint8_t>()};
+        for (uint32_t d = 1; d < tv.n_levels; ++d) launch_build_level(T, tv.level_off[d], tv.level_off[d + 1], nullptr);
+        ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+             hipMemcpy(fail, d_fail.p, n * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+             hipMemcpy(cnt, d_cnt.p, n * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+             hipMemcpy(dict, d_dict.p, n * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+             hipMemcpy(is_final, d_final.p, n, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    if (!ok) (void)hipGetLastError();
+    for (DevBuf *b : {&d_parent, &d_byte, &d_own, &d_order, &d_keys, &d_vals, &d_fail, &d_cnt, &d_dict, &d_final}) b->release();
+    return ok;
+}
+
 int ensure_finalized(acmi_handle *h) {
     if (h->aut.finalized()) return 0;
     std::string err;
-    if (!h->aut.finalize(h->bopt, &err)) {
+    BuildAccel accel;
+    accel.ctx = h;
+    accel.fail_and_outputs = device_fail_and_outputs;
+    const bool use_device = h->device_build > 0 || (h->device_build < 0 && h->aut.node_count() >= 200000);
+    if (!h->aut.finalize(h->bopt, &err, use_device ? &accel : nullptr)) {
         h->last_error = err;
         return ACMI_E_TOO_LARGE;
     }
@@ -305,6 +351,7 @@ int ensure_device(acmi_handle *h) {
     A.anchor_bitmap = fa.anchor_mode == 2 ? h->d_bitmap.as<uint32_t>() : nullptr;
     A.anchor_bucket_mask = fa.anchor_mode == 2 ? (1u << fa.anchor_bucket_bits) - 1u : 0u;
     A.anchor_choice = fa.anchor_choice;
+    A.anchor_bucket_shift = fa.anchor_bucket_shift;
     A.anchor_mul = fa.anchor_mul;
     A.min_pattern_length = fa.min_pattern_length;
     A.max_pattern_length = fa.max_pattern_length;
@@ -1032,6 +1079,9 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
         } else if (k == "verify") {
             if (h->dev_ready) return ACMI_E_FINALIZED;  // the tables are uploaded (or not) by the first match call
             h->verify = value ? 1 : 0;
+        } else if (k == "device_build") {
+            if (h->aut.finalized()) return ACMI_E_FINALIZED;
+            h->device_build = value < 0 ? -1 : (value ? 1 : 0);
         } else if (k == "keep_host_tables") {
             h->keep_host_tables = value ? 1 : 0;
         } else if (k == "max_flat_outputs") {
@@ -1088,6 +1138,7 @@ int acmi_get_stat(const acmi_handle *h, const char *key, double *value) {
         else if (k == "max_out_count") *value = fa.max_out_count;
         else if (k == "anchor_pairs") *value = double(fa.anchor_pairs_count);
         else if (k == "anchor_choice") *value = fa.anchor_choice;
+        else if (k == "built_on_device") *value = h->aut.built_on_device() ? 1 : 0;
         else if (k == "compact") *value = fa.compact;
         else if (k == "dense_rows") *value = fa.n_dense_rows;
         else if (k == "cold_edges") *value = double(fa.cold_edges.size());
@@ -1132,6 +1183,7 @@ int acmi_debug_tables(const acmi_handle *h, acmi_tables *out) {
         out->anchor_keys = fa.anchor_keys;
         out->anchor_mode = fa.anchor_mode;
         out->anchor_bucket_bits = fa.anchor_bucket_bits;
+        out->anchor_bucket_shift = fa.anchor_bucket_shift;
         out->anchor_bitmap = fa.anchor_mode == 2 ? fa.anchor_bitmap.data() : nullptr;
         out->anchor_table = fa.anchor_q ? fa.anchor_table.data() : nullptr;
         out->anchor_choice = fa.anchor_choice;

@@ -768,7 +768,7 @@ __device__ __forceinline__ bool verify_candidate(const DevAutomaton &A, const ui
     // its slot in the fingerprint table
     uint32_t slot = 0xFFFFFFFFu;
     if (A.anchor_mode == 2u) {
-        const uint32_t bucket = h & A.anchor_bucket_mask;
+        const uint32_t bucket = (h >> A.anchor_bucket_shift) & A.anchor_bucket_mask;
         const uint4 b = static_cast<const uint4 *>(A.anchor_table)[bucket];
         const uint32_t fp = (h >> 16) | 1u;
         const uint32_t bv[4] = {b.x, b.y, b.z, b.w};
@@ -1347,7 +1347,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                     ph = e.x;
                     ppos = e.y;
                 }
-                ptb = big_table[ph & bucket_mask];  // (idle lanes read bucket 0: no branch around the load)
+                ptb = big_table[(ph >> A.anchor_bucket_shift) & bucket_mask];  // (idle lanes read bucket 0: no branch around the load)
                 qhead += nq_;
                 qcount -= nq_;
                 pending = true;
@@ -1363,7 +1363,9 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                 for (int w = 0; w < 4; ++w) wd[w] = *reinterpret_cast<LdsU1Ptr>((h4[w] >> 15) & 0x1FFFCu);
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
-                    const bool maybe = (wd[w] >> ((h4[w] >> 12) & 31u)) & 1u;
+                    // (one bit-field extract feeds both the ballot and the predicated append: written as a shift and a
+                    // mask hipcc computed the bit twice, 7 VALU instead of 3)
+                    const bool maybe = __builtin_amdgcn_ubfe(wd[w], __builtin_amdgcn_ubfe(h4[w], 12u, 5u), 1u) != 0u;
                     const uint64_t mm = __ballot(maybe);
                     if (mm != 0) {
                         const uint32_t at = __builtin_amdgcn_mbcnt_hi(uint32_t(mm >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mm), 0u));
@@ -2190,6 +2192,56 @@ __global__ void k_stream_read(const uint4 *src, uint64_t n16, uint32_t *sink) {
 
 void launch_stream_read(const void *src, uint64_t bytes, uint32_t *sink, hipStream_t st) {
     hipLaunchKernelGGL(k_stream_read, dim3(256 * 8), dim3(256), 0, st, static_cast<const uint4 *>(src), bytes / 16, sink);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_build_level: one trie depth of the automaton build on the device (automaton.hpp TrieView / BuildAccel).
+//
+// The reference computes a node's failure link by re-walking every suffix of its path from the root
+// (ac_trie_set_failure, ahocorasick.c:344-368: 8.3 s for 65,536 patterns); the textbook recurrence -- follow the
+// parent's failure chain until a node has a child on the node's byte -- needs only SHALLOWER nodes' links, so all
+// nodes of one depth are independent: one thread per node, one launch per depth, the child lookups in the builder's
+// own open-addressing map.  The per-state outputs (final flag, record count, dictionary link: node_collect_matches,
+// node.c:424-441, folded into three words per node) depend on the node's failure target only and ride along.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t build_find_child(const BuildArgs &T, uint32_t node, uint32_t byte) {
+    const uint64_t key = ((uint64_t(node) << 8) | byte) + 1;
+    uint64_t k = key * 0x9E3779B97F4A7C15ull;
+    k ^= k >> 29;
+    uint64_t slot = k & (T.map_size - 1);
+    for (;;) {
+        const uint64_t have = T.map_keys[slot];
+        if (have == key) return T.map_vals[slot];
+        if (have == 0) return 0xFFFFFFFFu;
+        slot = (slot + 1) & (T.map_size - 1);
+    }
+}
+
+__global__ void k_build_level(BuildArgs T, uint32_t lo, uint32_t hi) {
+    const uint32_t i = lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hi) return;
+    const uint32_t u = T.order[i];
+    const uint32_t p = T.parent[u];
+    uint32_t fl = 0;
+    if (p != 0) {
+        const uint32_t b = T.in_byte[u];
+        uint32_t f = T.fail[p];
+        for (;;) {
+            const uint32_t c = build_find_child(T, f, b);
+            if (c != 0xFFFFFFFFu) { fl = c; break; }
+            if (f == 0) break;
+            f = T.fail[f];
+        }
+    }
+    T.fail[u] = fl;
+    const bool owns = T.own[u] != 0xFFFFFFFFu;
+    T.is_final[u] = (owns || T.is_final[fl]) ? 1 : 0;
+    T.cnt[u] = (owns ? 1u : 0u) + T.cnt[fl];
+    T.dict[u] = T.own[fl] != 0xFFFFFFFFu ? fl : T.dict[fl];
+}
+
+void launch_build_level(const BuildArgs &T, uint32_t lo, uint32_t hi, hipStream_t st) {
+    if (hi > lo) hipLaunchKernelGGL(k_build_level, dim3((hi - lo + 255) / 256), dim3(256), 0, st, T, lo, hi);
 }
 
 // ------------------------------------------------------------------------------------------

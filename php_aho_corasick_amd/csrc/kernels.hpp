@@ -30,6 +30,7 @@ constexpr uint32_t kSmallPathMaxBytes = 64u * 1024u, kSmallPathMaxHay = 1024u;
 hipError_t launch_match_small(const DevAutomaton &A, const uint64_t *offsets, const uint8_t *blob, uint32_t nh, int find_all,
                               uint32_t max_pattern_length, int entry_bytes, int class_mode, uint64_t *out_summary,
                               uint64_t *out_prefix, void *out_records, uint32_t cap, hipStream_t st);
+void launch_build_level(const BuildArgs &T, uint32_t lo, uint32_t hi, hipStream_t st);
 void launch_replace_plan(const ReplaceArgs &R, hipStream_t st);
 void launch_replace_emit(const ReplaceArgs &R, hipStream_t st);
 void launch_gather_compact(const GatherArgs &G, hipStream_t st);

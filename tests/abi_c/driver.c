@@ -66,7 +66,7 @@ static int run_layout(void)
     printf("acmi_record %zu\nacmi_pattern %zu\nacmi_tables %zu\n", sizeof(acmi_record), sizeof(acmi_pattern), sizeof(acmi_tables));
 #define OFF(f) printf("acmi_tables.%s %zu\n", #f, offsetof(acmi_tables, f))
     OFF(n_states); OFF(max_pattern_length); OFF(table); OFF(lds_image); OFF(class_of_byte); OFF(own_pattern); OFF(dict_link);
-    OFF(out_count); OFF(anchor_q); OFF(anchor_keys); OFF(anchor_table); OFF(anchor_mode); OFF(anchor_bucket_bits);
+    OFF(out_count); OFF(anchor_q); OFF(anchor_keys); OFF(anchor_table); OFF(anchor_mode); OFF(anchor_bucket_bits); OFF(anchor_bucket_shift);
     OFF(anchor_bitmap); OFF(anchor_choice); OFF(anchor_offsets); OFF(n_flat_outputs); OFF(compact); OFF(dense_nf_end); OFF(n_cold_edges); OFF(cold_rec);
     OFF(cold_edges); OFF(chain_lo); OFF(chain_byte); OFF(chain_run); OFF(out_off); OFF(out_list);
 #undef OFF

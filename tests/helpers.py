@@ -82,6 +82,7 @@ class FlatTables:
         self.anchor_q, self.anchor_mul, self.min_pattern_length = t.anchor_q, t.anchor_mul, t.min_pattern_length
         self.anchor_keys = t.anchor_keys
         self.anchor_mode, self.anchor_bucket_bits = t.anchor_mode, t.anchor_bucket_bits
+        self.anchor_bucket_shift = t.anchor_bucket_shift
         self.anchor_choice = t.anchor_choice
         self.anchor_offsets = None   # filled by test code that knows the pattern count
         self._anchor_offsets_ptr = t.anchor_offsets
@@ -108,7 +109,7 @@ class FlatTables:
         if self.anchor_mode == 2:   # LDS bitmap in front of the 8-slot table read through L2
             if not (int(self.anchor_bitmap[h >> 17]) >> ((h >> 12) & 31)) & 1:
                 return False
-            return int((h >> 16) | 1) in [int(x) for x in self.anchor[h & ((1 << self.anchor_bucket_bits) - 1)]]
+            return int((h >> 16) | 1) in [int(x) for x in self.anchor[(h >> self.anchor_bucket_shift) & ((1 << self.anchor_bucket_bits) - 1)]]
         return int(h >> 16) in [int(x) for x in self.anchor[(h >> 3) & 0x3FFF]]
 
     def cold_step(self, s: int, b: int) -> int:

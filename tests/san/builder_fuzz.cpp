@@ -113,7 +113,7 @@ long anchor_slot(const FlatAutomaton &fa, const uint8_t *window) {
     const uint32_t h = anchor_hash(words, fa.anchor_q / 4, fa.anchor_mul);
     if (fa.anchor_mode == 2) {
         const uint16_t fp = uint16_t((h >> 16) | 1u);
-        const size_t bucket = h & ((1u << fa.anchor_bucket_bits) - 1u);
+        const size_t bucket = (h >> fa.anchor_bucket_shift) & ((1u << fa.anchor_bucket_bits) - 1u);
         for (int i = 0; i < 8; ++i) if (fa.anchor_table[bucket * 8 + i] == fp) return long(bucket * 8 + i);
         return -1;
     }
@@ -130,7 +130,7 @@ bool anchor_probe(const FlatAutomaton &fa, const uint8_t *window) {
     if (fa.anchor_mode == 2) {
         if (!((fa.anchor_bitmap[h >> 17] >> ((h >> 12) & 31u)) & 1u)) return false;
         const uint16_t fp = uint16_t((h >> 16) | 1u);
-        const uint16_t *b = &fa.anchor_table[size_t(h & ((1u << fa.anchor_bucket_bits) - 1u)) * 8];
+        const uint16_t *b = &fa.anchor_table[size_t((h >> fa.anchor_bucket_shift) & ((1u << fa.anchor_bucket_bits) - 1u)) * 8];
         for (int i = 0; i < 8; ++i) if (b[i] == fp) return true;
         return false;
     }
