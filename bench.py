@@ -5,7 +5,10 @@
 
 One "step" = one pass of the hot path over one batch that is already resident in HBM:
 acmi_match_batch_device() = work-item table, LDS-tile scan kernel, record-base scan, expansion of
-events into the final {hay,pos,start,pattern} array (left on the device).  With N > 1 (launched by
+events into the final {hay,pos,start,pattern} array (left on the device).  K steps = K batches begun
+and ended inside the timed region, up to two of them in flight (acmi_match_batch_device_begin/_end:
+the second batch's kernels queue behind the first one's, the host's turn-around is hidden;
+`roofline.one_at_a_time_ms_per_step` is the same step without that).  With N > 1 (launched by
 torch.distributed.run, one rank per GPU, backend "nccl" == RCCL) every rank scans its own shard of
 the same size (weak scaling) and the per-rank match arrays are all-gathered; the collective of step
 i runs on RCCL's stream while step i+1 scans.
@@ -122,18 +125,41 @@ def dense_leg(torch, api, batch, synth, dev, nh=4096, k=16):
 
 def _timed_calls(torch, batch, res, d_blob, d_off, calls=6, skip=2):
     """Whole acmi_match_batch_device calls on a resident batch: (mean host ms per call, mean scan-kernel ms, mean
-    walk-kernel ms, records) over the calls after `skip` (the first ones grow workspaces and probe kernels)."""
+    walk-kernel ms, records).  Kernel times come from calls at profile level 2 (five events on the stream, each one a
+    barrier between two kernels), the whole-call time from further calls at level 0; the first `skip` calls grow
+    workspaces and probe kernels and are not counted."""
     ms, scan, walk, total = [], [], [], 0
+    res.set_option("profile", 2)
+    for i in range(calls):
+        total = batch.match_device(res, d_blob, d_off, True)
+        if i >= skip:
+            scan.append(res.stat("scan_ms"))
+            walk.append(res.stat("walk_ms"))
+    res.set_option("profile", 0)
     for i in range(calls):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         total = batch.match_device(res, d_blob, d_off, True)
-        dt = time.perf_counter() - t0
-        if i >= skip:
-            ms.append(dt * 1e3)
-            scan.append(res.stat("scan_ms"))
-            walk.append(res.stat("walk_ms"))
+        ms.append((time.perf_counter() - t0) * 1e3)
+    _two_in_flight(torch, batch, res, d_blob, d_off)
+    res.set_option("profile", 2)
     return float(np.mean(ms)), float(np.mean(scan)), float(np.mean(walk)), total
+
+
+def _two_in_flight(torch, batch, res, d_blob, d_off, n=8):
+    """The same batch with two calls in flight (begin, begin, end, begin, end, ...): the rate a caller of the split
+    entry points gets.  Leaves the figure where _leg_summary picks it up."""
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    began = ended = 0
+    while ended < n:
+        while began < n and began - ended < 2:
+            batch.match_device_begin(res, d_blob, d_off, True)
+            began += 1
+        batch.match_device_end(res)
+        ended += 1
+    torch.cuda.synchronize()
+    _timed_calls.two_in_flight_ms = (time.perf_counter() - t0) / n * 1e3
 
 
 KERNEL_NAMES = {0: "k_scan_simple", 1: "k_scan_lds", 2: "k_scan_anchor", 4: "k_walk_items", 5: "k_match_small"}
@@ -144,9 +170,12 @@ def _leg_summary(workload, blob_bytes, nh, total, ms, scan, walk, res, ok):
     return {"workload": workload, "kernel": KERNEL_NAMES.get(int(res.stat("kernel_used")), "?"),
             "ms_per_call": round(ms, 4), "scan_kernel_ms": round(scan, 4), "walk_kernel_ms": round(walk, 4),
             "haystack_GB_per_s": round(blob_bytes / ms / 1e6, 1), "records": int(total), "check_ok": bool(ok),
+            "ms_per_call_two_in_flight": round(_timed_calls.two_in_flight_ms, 4),
+            "haystack_GB_per_s_two_in_flight": round(blob_bytes / _timed_calls.two_in_flight_ms / 1e6, 1),
             "algorithmic_bytes": int(algo), "frac_scan_kernel": round(algo / (scan * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "frac_scan_plus_walk": round(algo / ((scan + walk) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "frac_whole_call": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            "frac_whole_call": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "frac_whole_call_two_in_flight": round(algo / (_timed_calls.two_in_flight_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
 
 def config3_leg(torch, api, batch, synth, dev, nh=1 << 20):
@@ -212,16 +241,9 @@ def keywords_leg(torch, api, batch, synth, dev, nh=1 << 17):
     d_off = torch.arange(nh + 1, dtype=torch.int64, device=dev) * HAY_LEN
     batch.bind_current_stream(res)
     first_kernel = None
-    ms, scan, walk, total = [], [], [], 0
-    for i in range(5):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        total = batch.match_device(res, d_blob, d_off, True)
-        dt = time.perf_counter() - t0
-        if first_kernel is None:
-            first_kernel = int(res.stat("kernel_used"))
-        if i >= 2:
-            ms.append(dt * 1e3); scan.append(res.stat("scan_ms")); walk.append(res.stat("walk_ms"))
+    total = batch.match_device(res, d_blob, d_off, True)
+    first_kernel = int(res.stat("kernel_used"))
+    ms, scan, walk, total = _timed_calls(torch, batch, res, d_blob, d_off, calls=4, skip=1)
     prefix, rec = batch.result_numpy(res, nh, total)
     from oracle import pyoracle
     o = pyoracle.Oracle("port")
@@ -230,7 +252,7 @@ def keywords_leg(torch, api, batch, synth, dev, nh=1 << 17):
     pe, re_ = o.match_batch(ds.hay_blob[:int(ds.hay_off[n_chk])], ds.hay_off[:n_chk + 1], True)
     ok = np.array_equal(prefix[:n_chk + 1], pe) and np.array_equal(rec[:int(pe[-1])], re_) and total == int(prefix[8192]) * (nh // 8192)
     out = _leg_summary(f"2,048 patterns of 4..12 letters over letters + spaces, {nh} haystacks x {HAY_LEN} B ({nh * HAY_LEN >> 20} MiB)",
-                       nh * HAY_LEN, nh, total, float(np.mean(ms)), float(np.mean(scan)), float(np.mean(walk)), res, ok)
+                       nh * HAY_LEN, nh, total, ms, scan, walk, res, ok)
     out["first_batch_kernel"] = KERNEL_NAMES.get(first_kernel, "?")
     out["records_per_haystack"] = round(total / nh, 2)
     api.ahocorasick_deinit(res)
@@ -302,6 +324,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-dense", action="store_true", help="skip the secondary BASELINE configs[4] (dense-match) measurement")
     ap.add_argument("--no-legs", action="store_true", help="skip the other secondary legs (config 3, general path, keyword set, host-buffer entry)")
+    ap.add_argument("--in-flight", type=int, default=2, help="batches begun before the oldest is ended (1 or 2)")
     ap.add_argument("--phase-times", action="store_true", help="analysis: add the host time per step phase to the JSON")
     args = ap.parse_args()
 
@@ -377,35 +400,43 @@ def main():
     walk_ms = []
     records_per_step = 0
 
-    ready = []   # (records view, count) of the batch collected last: shipped after the next scan is enqueued
+    phase = {"begin": 0.0, "gather": 0.0, "end": 0.0}   # host seconds, --phase-times
 
-    phase = {"begin": 0.0, "gather_finish": 0.0, "gather_start": 0.0, "end": 0.0}   # host seconds, --phase-times
+    # A step is one batch through the whole pipeline.  Up to `in_flight` (default 2) batches are begun before the oldest
+    # is ended: the second one's kernels are queued behind the first one's, so the device does not idle while the host
+    # turns around (acmi.h, acmi_match_batch_device_begin).  K steps = K batches begun and ended inside the timed region.
+    depth = max(1, min(2, args.in_flight))
 
-    def step():
-        nonlocal records_per_step
-        # enqueue the scan first, then do the gather bookkeeping of the previous batches while the GPU scans:
-        # a batch's records stay valid while the next one runs (acmi_result_device)
+    def begin_one():
         t_a = time.perf_counter()
         batch.match_device_begin(res, d_blob, d_off, True)
-        t_b = time.perf_counter()
-        while len(pending) > 2:  # three collectives in flight: the oldest has long finished, finish() does not block
-            gatherer.finish(pending.pop(0))
-        t_c = time.perf_counter()
-        if ready:
-            # all-gatherv of the match arrays: one asynchronous fixed-capacity collective per step,
-            # in flight on RCCL's stream while later steps scan
-            pending.append(gatherer.start(ready.pop(0), nh, hay_base))
-        t_d = time.perf_counter()
+        phase["begin"] += time.perf_counter() - t_a
+
+    def end_one():
+        nonlocal records_per_step
+        t_a = time.perf_counter()
         total = batch.match_device_end(res)
-        t_e = time.perf_counter()
-        phase["begin"] += t_b - t_a
-        phase["gather_finish"] += t_c - t_b
-        phase["gather_start"] += t_d - t_c
-        phase["end"] += t_e - t_d
+        t_b = time.perf_counter()
         records_per_step = total
         scan_ms.append(res.stat("scan_ms"))
         if gather:
-            ready.append(batch.result_view(res, total))
+            # all-gatherv of the match arrays: one asynchronous fixed-capacity collective per step, in flight on RCCL's
+            # stream while later steps scan.  The payload copy is enqueued here, on the scan's stream, BEFORE the next
+            # begin: that begin reuses this result's buffers (valid until the second begin after its own).
+            while len(pending) > 2:  # three collectives in flight: the oldest has long finished, finish() does not block
+                gatherer.finish(pending.pop(0))
+            pending.append(gatherer.start(batch.result_view(res, total), nh, hay_base))
+        phase["end"] += t_b - t_a
+        phase["gather"] += time.perf_counter() - t_b
+
+    def run_steps(k, in_flight):
+        began = ended = 0
+        while ended < k:
+            while began < k and began - ended < in_flight:
+                begin_one()
+                began += 1
+            end_one()
+            ended += 1
 
     # capacity of the fixed-size collective: the planted workload yields one record per haystack (+ slack;
     # a batch that exceeds it costs one more, larger collective and the capacity stays grown)
@@ -413,16 +444,11 @@ def main():
 
     def drain():
         out = None
-        while ready:
-            while len(pending) > 2:
-                out = gatherer.finish(pending.pop(0))
-            pending.append(gatherer.start(ready.pop(0), nh, hay_base))
         while pending:
             out = gatherer.finish(pending.pop(0))
         return out
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup, depth)
     drain()
     scan_ms.clear()
     walk_ms.clear()
@@ -432,8 +458,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps, depth)
     gathered = drain()
     torch.cuda.synchronize()
     if gather:
@@ -443,6 +468,17 @@ def main():
     if gather:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+
+    # the same steps one at a time (begin, end, begin, ...): what a caller that cannot keep two batches in flight sees
+    n_sync = min(args.steps, 20)
+    scan_keep = list(scan_ms)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    run_steps(n_sync, 1)
+    drain()
+    torch.cuda.synchronize()
+    sync_ms_per_step = (time.perf_counter() - t1) / n_sync * 1e3
+    scan_ms[:] = scan_keep
 
     # the candidate walk (second kernel of a step) timed with its own events on a few extra, untimed steps: every
     # event is a barrier on the stream, the timed region carries only the two around the scan kernel
@@ -493,6 +529,8 @@ def main():
                          "frac_scan_plus_walk": round(algo_bytes / ((kernel_ms + walk_kernel_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "frac_whole_step": round(algo_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
                          "step_minus_kernels_us": round((dt / args.steps * 1e3 - kernel_ms - walk_kernel_ms) * 1e3, 1),
+                         "batches_in_flight": depth, "one_at_a_time_ms_per_step": round(sync_ms_per_step, 4),
+                         "one_at_a_time_step_minus_kernels_us": round((sync_ms_per_step - kernel_ms - walk_kernel_ms) * 1e3, 1),
                          "measured_stream_read_GBs": round(stream_read_gbs, 1),
                          "frac_of_measured_stream_read": round(achieved / stream_read_gbs, 4)},
             "cpu_baseline": cpu1, "cpu_baseline_all_cores": cpu_all,

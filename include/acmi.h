@@ -159,8 +159,13 @@ int acmi_match_batch_device(acmi_handle *h, const void *d_blob, uint64_t blob_by
 
 /* The same call split in two, for callers that overlap host work (or a collective) with the
  * scan: _begin enqueues the whole pipeline on the handle's stream and returns at once; _end waits
- * for it (the pipeline's only host synchronisation) and reports the record count.  Exactly one
- * _end per _begin; the input buffers must stay untouched in between. */
+ * for it (the pipeline's only host synchronisation) and reports the record count.  Up to TWO
+ * batches may be in flight: a second _begin before the first _end queues its kernels behind the
+ * first batch's, so the device does not idle while the host turns around (a third _begin returns
+ * ACMI_E_ARG).  _end completes the OLDEST batch in flight; one _end per _begin; a batch's input
+ * buffers must stay untouched until its _end.  The result acmi_result_* refer to is that of the
+ * last _end; its device buffers stay valid until the second _begin after its own.  A synchronous
+ * call (acmi_match*, acmi_match_batch_device) drops batches that were begun and never ended. */
 int acmi_match_batch_device_begin(acmi_handle *h, const void *d_blob, uint64_t blob_bytes,
                                   const void *d_offsets, size_t n_haystacks, int find_all);
 int acmi_match_batch_device_end(acmi_handle *h, uint64_t *n_records);

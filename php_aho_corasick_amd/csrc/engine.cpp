@@ -107,9 +107,8 @@ struct acmi_handle {
 
     // workspace (grow-only)
     DevBuf d_blob, d_off, d_item_base, d_item_hay, d_item_rec, d_zero, d_rec_base, d_slab, d_ovf, d_counters,
-        d_prefix, d_out, d_runs, d_run_count,
-        d_prefix_alt, d_out_alt;  // result buffers alternate: a batch's records stay valid while the next one runs
-    uint64_t *pinned = nullptr;  // host copy of the device counters block (64 B), written by k_expand through pinned_dev
+        d_runs, d_run_count;
+    uint64_t *pinned = nullptr;  // host copy of the device counters blocks (2 x 64 B), written by k_expand through pinned_dev
     uint32_t *pinned_dev = nullptr;
 
     // last result
@@ -124,14 +123,36 @@ struct acmi_handle {
     std::vector<uint8_t> h_rep_blob;
     std::vector<uint64_t> h_rep_off;
 
-    // a batch whose pipeline is enqueued but not yet completed (acmi_match_batch_device_begin/_end)
-    bool in_flight = false;
-    BatchArgs fly_args{};
-    uint64_t fly_max_items = 0, fly_blob_bytes = 0;
-    int fly_find_all = 1;
-    bool fly_trivial = false;
-    uint32_t *fly_sync_next = nullptr;
-    uint32_t fly_sync_words = 0;
+    // Batches whose pipeline is enqueued but not yet completed (acmi_match_batch_device_begin/_end): up to TWO, ended in
+    // the order they were begun.  The second one's kernels are already queued on the stream when the first one's last
+    // kernel retires, so the device does not idle through the host's turn-around (stream wake-up, the caller, the next
+    // begin's launches: ~35 us of a 0.8 ms step).  Each slot owns what the host reads or hands out after the end --
+    // result buffers, the pinned summary, the events -- while the intermediate buffers are shared: the pipelines run
+    // one after the other on the stream.  (Only the rare re-expansion of a batch whose records outgrew the optimistic
+    // capacity needs intermediates that a later begin has overwritten: that batch is then run again as a whole.)
+    struct FlySlot {
+        uint64_t seq = 0;              // 1-based begin number
+        BatchArgs args{};
+        uint64_t max_items = 0, blob_bytes = 0;
+        const uint8_t *d_blob = nullptr;
+        const uint64_t *d_off = nullptr;
+        size_t nh = 0;
+        int find_all = 1;
+        bool trivial = false;
+        uint32_t *sync_next = nullptr;
+        uint32_t sync_words = 0;
+        int kernel_used = 0;
+        uint64_t chunk_used = 0;
+        hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        DevBuf d_prefix, d_out;        // valid from this batch's end until the second begin after its own
+    };
+    FlySlot fly[2];
+    uint64_t begin_seq = 0, end_seq = 0;  // batches begun / ended; begin_seq - end_seq (0..2) are in flight
+    uint64_t enqueue_seq = 0;             // seq of the batch whose pipeline was enqueued last (it owns the intermediates)
+    size_t out_want = 0;                  // bytes of records the largest batch so far produced: both slots' optimistic capacity
+    int cur = 0;                          // slot of the last completed result (have_result)
+    DevBuf &d_prefix() { return fly[cur].d_prefix; }
+    DevBuf &d_out() { return fly[cur].d_out; }
     DevBuf d_sync[2];          // counters, scan tickets and status words: two copies that take turns (run_batch_begin)
     uint32_t sync_tiles = 0, sync_turn = 0;
 
@@ -263,8 +284,11 @@ int ensure_device(acmi_handle *h) {
     if (!h->stream) h->stream = h->own_stream;
     for (auto &evt : h->ev)
         if (!evt) HIPCHK(h, hipEventCreate(&evt));
+    for (auto &slot : h->fly)
+        for (auto &evt : slot.ev)
+            if (!evt) HIPCHK(h, hipEventCreate(&evt));
     if (!h->pinned) {
-        HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->pinned), 64, hipHostMallocMapped));
+        HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->pinned), 128, hipHostMallocMapped));
         void *dp = nullptr;
         HIPCHK(h, hipHostGetDevicePointer(&dp, h->pinned, 0));
         h->pinned_dev = static_cast<uint32_t *>(dp);
@@ -419,42 +443,51 @@ uint32_t choose_chunk(const acmi_handle *h, uint64_t blob_bytes, int kernel) {
 }
 
 // The batch pipeline on device-resident input, first half: enqueue everything, no host wait.
-int run_batch_begin_impl(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, const uint64_t *d_off, size_t nh,
-                         int find_all);
+int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob, uint64_t blob_bytes, const uint64_t *d_off,
+                  size_t nh, int find_all);
 
 int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, const uint64_t *d_off, size_t nh,
                     int find_all) {
-    const int rc = run_batch_begin_impl(h, d_blob, blob_bytes, d_off, nh, find_all);
+    if (h->begin_seq - h->end_seq >= 2) {
+        h->last_error = "two batches are in flight already: end the older one first";
+        return ACMI_E_ARG;
+    }
+    if (nh > 0xFFFFFFF0ull) { h->last_error = "too many haystacks"; return ACMI_E_TOO_LARGE; }
+    // This batch takes the slot of the batch before the previous one, whose prefix array and records end here: a
+    // result is valid from its batch's end until the SECOND begin after its own.
+    acmi_handle::FlySlot &F = h->fly[(h->begin_seq + 1) & 1];
+    h->have_result = false;
+    const int rc = enqueue_batch(h, F, d_blob, blob_bytes, d_off, nh, find_all);
     // a pipeline that was not enqueued to its end has not zeroed the next batch's sync block: have both zeroed again
-    if (rc < 0) h->sync_tiles = 0;
+    if (rc < 0) { h->sync_tiles = 0; return rc; }
+    F.seq = ++h->begin_seq;
+    h->enqueue_seq = F.seq;
     return rc;
 }
 
-int run_batch_begin_impl(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, const uint64_t *d_off, size_t nh,
-                         int find_all) {
-    h->have_result = false;
-    // The previous batch's prefix array and records stay untouched by this one (they are valid until the
-    // begin after this): a caller can enqueue the next scan first and ship the last result meanwhile.
-    std::swap(h->d_out, h->d_out_alt);
-    std::swap(h->d_prefix, h->d_prefix_alt);
-    h->scan_ms = h->walk_ms = h->total_ms = 0;
-    h->items = 0;
-    h->overflow_items = 0;
-    if (nh > 0xFFFFFFF0ull) { h->last_error = "too many haystacks"; return ACMI_E_TOO_LARGE; }
+int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob, uint64_t blob_bytes, const uint64_t *d_off,
+                  size_t nh, int find_all) {
     hipStream_t st = h->stream;
-    HIPCHK(h, h->d_prefix.ensure((nh + 1) * 8));
-    h->last_nh = uint32_t(nh);
-    h->last_total = 0;
-    if (h->profile > 1) HIPCHK(h, hipEventRecord(h->ev[0], st));
+    HIPCHK(h, F.d_prefix.ensure((nh + 1) * 8));
+    F.d_blob = d_blob;
+    F.d_off = d_off;
+    F.nh = nh;
+    F.blob_bytes = blob_bytes;
+    F.find_all = find_all;
+    F.kernel_used = 0;
+    F.chunk_used = 0;
+    F.max_items = 0;
+    if (h->profile > 1) HIPCHK(h, hipEventRecord(F.ev[0], st));
+    const int slot_index = int(&F - h->fly);
+    uint32_t *const pinned_dev = h->pinned_dev + 16 * slot_index;
 
-    h->in_flight = false;
     if (nh == 0 || h->aut.accepted_count() == 0) {  // empty batch / empty automaton -> no records
-        HIPCHK(h, hipMemsetAsync(h->d_prefix.p, 0, (nh + 1) * 8, st));
-        h->fly_trivial = true;
-        h->in_flight = true;
+        HIPCHK(h, hipMemsetAsync(F.d_prefix.p, 0, (nh + 1) * 8, st));
+        HIPCHK(h, hipEventRecord(F.ev[4], st));
+        F.trivial = true;
         return ACMI_OK;
     }
-    h->fly_trivial = false;
+    F.trivial = false;
 
     const FlatAutomaton &fa = h->aut.flat();
     // the anchor filter needs a pattern set that allows it; automatic mode also leaves it once a batch
@@ -466,11 +499,11 @@ int run_batch_begin_impl(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_by
     int kernel = h->kernel == 3 ? ((fa.anchor_q && !h->anchor_off) ? 2 : 1)
                                 : ((h->kernel == 2 && !fa.anchor_q) ? 1 : h->kernel);
     if (h->kernel == 3 && kernel == 1 && h->exact_only) kernel = 4;
-    h->kernel_used = kernel;
+    F.kernel_used = kernel;
     const uint32_t chunk = choose_chunk(h, blob_bytes, kernel);
     const uint64_t max_items = blob_bytes / chunk + nh;
     const uint32_t K = std::max<uint32_t>(1, h->slab_events);
-    h->chunk_used = chunk;
+    F.chunk_used = chunk;
 
     HIPCHK(h, h->d_item_base.ensure((nh + 1) * 8));
     HIPCHK(h, h->d_item_hay.ensure(max_items * 4));
@@ -540,7 +573,7 @@ int run_batch_begin_impl(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_by
     // item counts, their scan, the item table, zeroed per-item counters: one launch
     launch_items(B, blob_bytes, h->d_item_base.as<uint64_t>(), sync_cur + 16, status0, st);
 
-    if (h->profile) HIPCHK(h, hipEventRecord(h->ev[1], st));
+    if (h->profile) HIPCHK(h, hipEventRecord(F.ev[1], st));
     if (kernel == 4) {
         // exact walk only (k_walk_items): for text on which k_scan_lds' optimistic
         // pass flags everything anyway (events in every wave-quad)
@@ -548,10 +581,10 @@ int run_batch_begin_impl(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_by
     } else {
         HIPCHK(h, launch_scan(h->dA, B, max_items, int(fa.entry_bytes), kernel, int(fa.class_mode), h->ilp, h->group_quads, st));
     }
-    if (h->profile) HIPCHK(h, hipEventRecord(h->ev[2], st));
+    if (h->profile) HIPCHK(h, hipEventRecord(F.ev[2], st));
     // the anchor kernel only flags byte runs; their exact walk is a kernel of its own (one thread per item)
     if (kernel == 2) HIPCHK(h, launch_walk_runs(h->dA, B, max_items, int(fa.entry_bytes), int(fa.class_mode), st));
-    if (h->profile > 1) HIPCHK(h, hipEventRecord(h->ev[3], st));
+    if (h->profile > 1) HIPCHK(h, hipEventRecord(F.ev[3], st));
 
     if (!find_all) launch_first_only(B, st);
     launch_rec_scan(B, max_items, h->d_rec_base.as<uint64_t>(), sync_cur + 17, status1, st);
@@ -559,55 +592,65 @@ int run_batch_begin_impl(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_by
     // Expansion is enqueued optimistically with the output capacity of the previous call, so the
     // whole pipeline needs ONE host synchronisation (the read-back of the summary at the end).  Only
     // when the batch produced more records than fit is the buffer grown and the expansion re-run.
-    HIPCHK(h, h->d_out.ensure(16));
-    const uint64_t cap = h->d_out.cap / 16;
+    HIPCHK(h, F.d_out.ensure(std::max<size_t>(16, h->out_want)));  // (at least what any earlier batch of this handle needed)
+    const uint64_t cap = F.d_out.cap / 16;
     // (also: per-haystack prefix, the summary for the host next to the overflow counter -- counters[2..3] = total
     // records, [4..5] = items -- and the zeroing of the next batch's sync block)
-    launch_expand(h->dA, B, max_items, h->d_rec_base.as<uint64_t>(), h->d_out.p, cap, h->d_prefix.as<uint64_t>(),
-                  h->pinned_dev, sync_next, sync_words, st);
-    if (find_all) launch_refill(h->dA, B, max_items, int(fa.entry_bytes), h->d_rec_base.as<uint64_t>(), h->d_out.p, cap, h->refill, st);
-    h->fly_sync_next = sync_next;
-    h->fly_sync_words = sync_words;
-    if (h->profile > 1) HIPCHK(h, hipEventRecord(h->ev[4], st));
+    launch_expand(h->dA, B, max_items, h->d_rec_base.as<uint64_t>(), F.d_out.p, cap, F.d_prefix.as<uint64_t>(),
+                  pinned_dev, sync_next, sync_words, st);
+    if (find_all) launch_refill(h->dA, B, max_items, int(fa.entry_bytes), h->d_rec_base.as<uint64_t>(), F.d_out.p, cap, h->refill, st);
+    F.sync_next = sync_next;
+    F.sync_words = sync_words;
+    HIPCHK(h, hipEventRecord(F.ev[4], st));  // (always: the end waits for THIS batch, not for the one queued behind it)
     HIPCHK(h, hipGetLastError());
-    h->fly_args = B;
-    h->fly_max_items = max_items;
-    h->fly_blob_bytes = blob_bytes;
-    h->fly_find_all = find_all;
-    h->in_flight = true;
+    F.args = B;
+    F.max_items = max_items;
     return ACMI_OK;
 }
 
-// Second half: the one host synchronisation, the capacity check and (rarely) the re-run.
+// Second half, for the OLDEST batch in flight: the one host synchronisation, the capacity check and (rarely) the re-run.
 int run_batch_end(acmi_handle *h) {
-    if (!h->in_flight) { h->last_error = "no batch in flight"; return ACMI_E_ARG; }
-    h->in_flight = false;
+    if (h->begin_seq == h->end_seq) { h->last_error = "no batch in flight"; return ACMI_E_ARG; }
+    acmi_handle::FlySlot &F = h->fly[(h->end_seq + 1) & 1];
+    ++h->end_seq;
+    const int slot_index = int(&F - h->fly);
+    const uint64_t *const pinned = h->pinned + 8 * slot_index;
+    const uint32_t *const pinned32 = reinterpret_cast<const uint32_t *>(pinned);
     hipStream_t st = h->stream;
     {
-        const hipError_t e = hipStreamSynchronize(st);
-        if (e != hipSuccess) { h->sync_tiles = 0; return fail_hip(h, e, "hipStreamSynchronize"); }
+        // (with a second batch queued behind this one the wait is for this batch's last kernel only)
+        const hipError_t e = h->begin_seq != h->end_seq ? hipEventSynchronize(F.ev[4]) : hipStreamSynchronize(st);
+        if (e != hipSuccess) { h->sync_tiles = 0; h->end_seq = h->begin_seq; return fail_hip(h, e, "hipStreamSynchronize"); }
     }
-    if (h->fly_trivial) {
+    h->cur = slot_index;
+    h->last_nh = uint32_t(F.nh);
+    h->last_total = 0;
+    h->scan_ms = h->walk_ms = h->total_ms = 0;
+    h->items = 0;
+    h->overflow_items = 0;
+    h->kernel_used = F.kernel_used;
+    h->chunk_used = F.chunk_used;
+    if (F.trivial) {
         h->have_result = true;
         return ACMI_OK;
     }
     const FlatAutomaton &fa = h->aut.flat();
-    if (reinterpret_cast<uint32_t *>(h->pinned)[6] != 0u) {
+    if (pinned32[6] != 0u) {
         h->last_error = "offsets must be non-decreasing, inside the blob, and every haystack shorter than 4 GiB";
         return ACMI_E_ARG;
     }
-    const uint32_t n_ovf = h->fly_find_all ? reinterpret_cast<uint32_t *>(h->pinned)[0] : 0u;
-    const uint64_t total = h->pinned[1];
-    h->items = h->pinned[2];
+    const uint32_t n_ovf = F.find_all ? pinned32[0] : 0u;
+    uint64_t total = pinned[1];
+    h->items = pinned[2];
     h->overflow_items = n_ovf;
     h->walked_bytes = 0;  // counters[7..15]: k_scan_lds adds to [7], k_walk_runs spreads its workgroups over [8..15]
-    for (int i = 7; i < 16; ++i) h->walked_bytes += uint64_t(reinterpret_cast<uint32_t *>(h->pinned)[i]) * 16;
-    h->fallback_bytes = h->kernel_used == 2 ? uint64_t(reinterpret_cast<uint32_t *>(h->pinned)[7]) * 16 : 0;
-    if (h->kernel_used == 2) h->walked_bytes -= h->fallback_bytes;  // (counters[7] is k_scan_lds' own share otherwise)
+    for (int i = 7; i < 16; ++i) h->walked_bytes += uint64_t(pinned32[i]) * 16;
+    h->fallback_bytes = F.kernel_used == 2 ? uint64_t(pinned32[7]) * 16 : 0;
+    if (F.kernel_used == 2) h->walked_bytes -= h->fallback_bytes;  // (counters[7] is k_scan_lds' own share otherwise)
     // automatic mode: a batch of which more than a quarter had to be walked exactly defeats the filter
-    const bool decisive = h->kernel == 3 && h->fly_blob_bytes >= kAutoMinBytes;
-    if (decisive && h->kernel_used == 2) {
-        if (h->walked_bytes * 4 > h->fly_blob_bytes) {
+    const bool decisive = h->kernel == 3 && F.blob_bytes >= kAutoMinBytes;
+    if (decisive && F.kernel_used == 2) {
+        if (h->walked_bytes * 4 > F.blob_bytes) {
             h->anchor_off = true;
             h->anchor_left = h->anchor_span;
             h->anchor_span = std::min<uint32_t>(h->anchor_span * 2, 1024);
@@ -617,8 +660,8 @@ int run_batch_end(acmi_handle *h) {
     }
     // ... and one of which more than half was flagged by the LDS-tile kernel's optimistic pass (events or tile
     // exits in most wave-quads: keyword-like and dense-match text) is walked exactly right away
-    if (decisive && h->kernel_used == 1) {
-        if (h->walked_bytes * 2 > h->fly_blob_bytes) {
+    if (decisive && F.kernel_used == 1) {
+        if (h->walked_bytes * 2 > F.blob_bytes) {
             h->exact_only = true;
             h->exact_left = h->exact_span;
             h->exact_span = std::min<uint32_t>(h->exact_span * 2, 1024);
@@ -628,25 +671,42 @@ int run_batch_end(acmi_handle *h) {
     }
     if (h->profile) {
         float ms = 0;
-        HIPCHK(h, hipEventElapsedTime(&ms, h->ev[1], h->ev[2]));
+        HIPCHK(h, hipEventElapsedTime(&ms, F.ev[1], F.ev[2]));
         h->scan_ms = ms;
         if (h->profile > 1) {
-            HIPCHK(h, hipEventElapsedTime(&ms, h->ev[2], h->ev[3]));
-            h->walk_ms = h->kernel_used == 2 ? ms : 0.0;
-            HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[4]));
+            HIPCHK(h, hipEventElapsedTime(&ms, F.ev[2], F.ev[3]));
+            h->walk_ms = F.kernel_used == 2 ? ms : 0.0;
+            HIPCHK(h, hipEventElapsedTime(&ms, F.ev[0], F.ev[4]));
             h->total_ms = ms;
         }
     }
-    if (total > h->d_out.cap / 16) {  // did not fit the optimistic capacity: grow, expand again
-        HIPCHK(h, h->d_out.ensure(total * 16));
-        const uint64_t cap = h->d_out.cap / 16;
-        launch_expand(h->dA, h->fly_args, h->fly_max_items, h->d_rec_base.as<uint64_t>(), h->d_out.p, cap, h->d_prefix.as<uint64_t>(),
-                      h->pinned_dev, h->fly_sync_next, h->fly_sync_words, st);
-        if (h->fly_find_all)
-            launch_refill(h->dA, h->fly_args, h->fly_max_items, int(fa.entry_bytes), h->d_rec_base.as<uint64_t>(),
-                          h->d_out.p, cap, h->refill, st);
-        HIPCHK(h, hipGetLastError());
-        HIPCHK(h, hipStreamSynchronize(st));
+    h->out_want = std::max<size_t>(h->out_want, size_t(total) * 16);
+    if (total > F.d_out.cap / 16) {  // did not fit the optimistic capacity: grow, expand again
+        if (h->enqueue_seq == F.seq) {
+            HIPCHK(h, F.d_out.ensure(total * 16));
+            const uint64_t cap = F.d_out.cap / 16;
+            launch_expand(h->dA, F.args, F.max_items, h->d_rec_base.as<uint64_t>(), F.d_out.p, cap, F.d_prefix.as<uint64_t>(),
+                          h->pinned_dev + 16 * slot_index, F.sync_next, F.sync_words, st);
+            if (F.find_all)
+                launch_refill(h->dA, F.args, F.max_items, int(fa.entry_bytes), h->d_rec_base.as<uint64_t>(),
+                              F.d_out.p, cap, h->refill, st);
+            HIPCHK(h, hipGetLastError());
+            HIPCHK(h, hipStreamSynchronize(st));
+        } else {
+            // a later begin has reused the item table, slabs and record bases: this batch runs again as a whole, into a
+            // buffer of the size it is now known to need (the later batch's own result and summary are its slot's)
+            {
+                const hipError_t e = hipStreamSynchronize(st);
+                if (e != hipSuccess) { h->sync_tiles = 0; return fail_hip(h, e, "hipStreamSynchronize"); }
+            }
+            HIPCHK(h, F.d_out.ensure(total * 16));
+            const int rc = enqueue_batch(h, F, F.d_blob, F.blob_bytes, F.d_off, F.nh, F.find_all);
+            if (rc < 0) { h->sync_tiles = 0; return rc; }
+            h->enqueue_seq = F.seq;
+            HIPCHK(h, hipStreamSynchronize(st));
+            total = pinned[1];
+            if (total > F.d_out.cap / 16) { h->last_error = "record count changed between two runs of one batch"; return ACMI_E_DEVICE; }
+        }
     }
     h->last_total = total;
     h->have_result = true;
@@ -655,6 +715,10 @@ int run_batch_end(acmi_handle *h) {
 
 int run_batch(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, const uint64_t *d_off, size_t nh,
               int find_all) {
+    if (h->begin_seq != h->end_seq) {  // a synchronous call drops batches that were begun and never ended
+        (void)hipStreamSynchronize(h->stream);
+        h->end_seq = h->begin_seq;
+    }
     int rc = run_batch_begin(h, d_blob, blob_bytes, d_off, nh, find_all);
     if (rc < 0) return rc;
     return run_batch_end(h);
@@ -806,10 +870,13 @@ int acmi_destroy(acmi_handle *h) {
             if (h->stream) (void)hipStreamSynchronize(h->stream);
             for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_out_off, &h->d_out_list, &h->d_cold_rec, &h->d_cold_edges, &h->d_chain_byte, &h->d_chain_run, &h->d_slot_pair, &h->d_pairs, &h->d_pat_bytes, &h->d_rep_off, &h->d_rep_bytes, &h->d_plan, &h->d_nom_count, &h->d_out_len, &h->d_rep_out_off, &h->d_rep_out, &h->d_blob,
                               &h->d_off, &h->d_sync[0], &h->d_sync[1], &h->d_item_base, &h->d_item_hay, &h->d_item_rec, &h->d_zero,
-                              &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_prefix, &h->d_out, &h->d_runs, &h->d_run_count, &h->d_prefix_alt, &h->d_out_alt})
+                              &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->fly[0].d_prefix, &h->fly[0].d_out, &h->fly[1].d_prefix, &h->fly[1].d_out, &h->d_runs, &h->d_run_count})
                 b->release();
             for (auto &evt : h->ev)
                 if (evt) (void)hipEventDestroy(evt);
+            for (auto &slot : h->fly)
+                for (auto &evt : slot.ev)
+                    if (evt) (void)hipEventDestroy(evt);
             if (h->pinned) (void)hipHostFree(h->pinned);
             if (h->pin_small) (void)hipHostFree(h->pin_small);
             if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -859,8 +926,8 @@ int acmi_result_device(acmi_handle *h, const void **d_prefix, const void **d_rec
     return guarded(h, [&]() -> int {
         if (!live(h)) return ACMI_E_INVALID;
         if (!h->have_result) return ACMI_E_ARG;
-        if (d_prefix) *d_prefix = h->d_prefix.p;
-        if (d_records) *d_records = h->d_out.p;
+        if (d_prefix) *d_prefix = h->d_prefix().p;
+        if (d_records) *d_records = h->d_out().p;
         if (n_records) *n_records = h->last_total;
         return ACMI_OK;
     });
@@ -872,9 +939,9 @@ int acmi_result_to_host(acmi_handle *h, uint64_t *prefix, acmi_record *records) 
         if (!h->have_result) return ACMI_E_ARG;
         HIPCHK(h, hipSetDevice(h->dev_id));
         hipStream_t st = h->stream;
-        if (prefix) HIPCHK(h, hipMemcpyAsync(prefix, h->d_prefix.p, (size_t(h->last_nh) + 1) * 8, hipMemcpyDeviceToHost, st));
+        if (prefix) HIPCHK(h, hipMemcpyAsync(prefix, h->d_prefix().p, (size_t(h->last_nh) + 1) * 8, hipMemcpyDeviceToHost, st));
         if (records && h->last_total)
-            HIPCHK(h, hipMemcpyAsync(records, h->d_out.p, h->last_total * sizeof(acmi_record), hipMemcpyDeviceToHost, st));
+            HIPCHK(h, hipMemcpyAsync(records, h->d_out().p, h->last_total * sizeof(acmi_record), hipMemcpyDeviceToHost, st));
         HIPCHK(h, hipStreamSynchronize(st));
         return ACMI_OK;
     });
@@ -887,9 +954,9 @@ int acmi_result_to_device(acmi_handle *h, void *d_prefix_dst, void *d_records_ds
         HIPCHK(h, hipSetDevice(h->dev_id));
         hipStream_t st = h->stream;
         if (d_prefix_dst)
-            HIPCHK(h, hipMemcpyAsync(d_prefix_dst, h->d_prefix.p, (size_t(h->last_nh) + 1) * 8, hipMemcpyDeviceToDevice, st));
+            HIPCHK(h, hipMemcpyAsync(d_prefix_dst, h->d_prefix().p, (size_t(h->last_nh) + 1) * 8, hipMemcpyDeviceToDevice, st));
         if (d_records_dst && h->last_total)
-            HIPCHK(h, hipMemcpyAsync(d_records_dst, h->d_out.p, h->last_total * sizeof(acmi_record), hipMemcpyDeviceToDevice, st));
+            HIPCHK(h, hipMemcpyAsync(d_records_dst, h->d_out().p, h->last_total * sizeof(acmi_record), hipMemcpyDeviceToDevice, st));
         HIPCHK(h, hipStreamSynchronize(st));
         return ACMI_OK;
     });
@@ -1408,9 +1475,9 @@ int acmi_comm_allgather_result(acmi_comm *c, acmi_handle *h, uint64_t n_haystack
         HIPCHK(h, c->d_send.ensure(stride));
         HIPCHK(h, c->d_recv.ensure(stride * uint64_t(W)));
         uint8_t *send = c->d_send.as<uint8_t>();
-        HIPCHK(h, hipMemcpyAsync(send, h->d_prefix.p, (size_t(h->last_nh) + 1) * 8, hipMemcpyDeviceToDevice, st));
+        HIPCHK(h, hipMemcpyAsync(send, h->d_prefix().p, (size_t(h->last_nh) + 1) * 8, hipMemcpyDeviceToDevice, st));
         if (h->last_total)
-            HIPCHK(h, hipMemcpyAsync(send + (nh_cap + 1) * 8, h->d_out.p, h->last_total * 16, hipMemcpyDeviceToDevice, st));
+            HIPCHK(h, hipMemcpyAsync(send + (nh_cap + 1) * 8, h->d_out().p, h->last_total * 16, hipMemcpyDeviceToDevice, st));
         const uint8_t *recv = send;
         if (W > 1) {
             const int e = R.AllGather(send, c->d_recv.p, stride, kNcclUint8, c->comm, st);
@@ -1515,8 +1582,8 @@ int acmi_replace_batch(acmi_handle *h, const uint8_t *blob, const uint64_t *offs
         R.offsets = h->d_off.as<uint64_t>();
         R.n_haystacks = uint32_t(n_haystacks);
         R.mode = mode == 2 ? 2u : 1u;   // MF_REPLACE_MODE_DEFAULT behaves as NORMAL (replace.c:252-254)
-        R.prefix = h->d_prefix.as<uint64_t>();
-        R.records = h->d_out.as<uint4>();
+        R.prefix = h->d_prefix().as<uint64_t>();
+        R.records = h->d_out().as<uint4>();
         R.pattern_length = h->dA.pattern_length;
         R.rep_off = h->d_rep_off.as<uint64_t>();
         R.rep_bytes = h->d_rep_bytes.as<uint8_t>();

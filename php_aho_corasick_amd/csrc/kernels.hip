@@ -1158,6 +1158,7 @@ struct AnchorCursor {      // wave-uniform position in the wave's (item, chunk) 
 };
 
 // `rec` = lane k's packed record of item wave_first + k (z == 0: no such item)
+template <uint32_t TQ>  // quads per task (a wave step): 512 = 8 KiB, or 256 for the BIG filter
 __device__ __forceinline__ void anchor_open(const DevAutomaton &A, const BatchArgs &B, const uint4 &rec, uint32_t k,
                                             AnchorCursor &cur) {
     cur.k = k;
@@ -1178,14 +1179,15 @@ __device__ __forceinline__ void anchor_open(const DevAutomaton &A, const BatchAr
     cur.head = mis < cur.n ? mis : cur.n;
     cur.nq = (cur.n - cur.head) >> 4;
     if (cur.nq) cur.qp = reinterpret_cast<const uint4 *>(p + cur.head);
-    cur.chunks = cur.nq ? (cur.nq + 511u) >> 9 : 1u;  // 8 KiB = 512 quads per wave step
+    cur.chunks = cur.nq ? (cur.nq + TQ - 1u) / TQ : 1u;
 }
 
 // advance to the next (item, chunk) task of the wave; false when the wave's items are done
+template <uint32_t TQ>
 __device__ __forceinline__ bool anchor_next(const DevAutomaton &A, const BatchArgs &B, const uint4 &rec, AnchorCursor &cur) {
     if (!cur.valid) return false;
     if (++cur.c < cur.chunks) return true;
-    anchor_open(A, B, rec, cur.k + 1u, cur);
+    anchor_open<TQ>(A, B, rec, cur.k + 1u, cur);
     return cur.valid;
 }
 
@@ -1196,7 +1198,8 @@ __device__ __forceinline__ bool anchor_next(const DevAutomaton &A, const BatchAr
 template <typename E, int MODE, int QW, bool BIG>
 __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, BatchArgs B) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    constexpr int G = 8;
+    constexpr int G = BIG ? 4 : 8;  // 16-byte quads per lane and task
+    constexpr uint32_t TQ = G * 64u;  // quads per task: 8 KiB, BIG 4 KiB (two tasks in flight in the registers of one)
     constexpr int NC = QW > 1 ? QW - 1 : 1;  // carries between quads (none for QW == 1; arrays keep one element)
     if (uint64_t(blockIdx.x) * (B.persistent ? 1u : kLdsThreads / 64u) * B.wave_items >= B.item_base[B.n_haystacks]) return;
     {   // LDS: the anchor table (or bitmap), 128 KiB; behind it 2 KiB of run staging per wave
@@ -1230,7 +1233,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     uint4 rec = make_uint4(0u, 0u, 0u, 0u);
     if (lane < B.wave_items && wave_first + lane < total_items) rec = B.item_rec[wave_first + lane];
     AnchorCursor ld, sc;  // load cursor runs one task ahead of the scan cursor
-    anchor_open(A, B, rec, 0, ld);
+    anchor_open<TQ>(A, B, rec, 0, ld);
     if (!ld.valid) break;
     sc = ld;
     // per wave, behind the table: 2 KiB of run staging -- BIG: [1 KiB probe queue | 256 B hit masks | 768 B run staging]
@@ -1256,7 +1259,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     // the line is split over 8 wave-instructions of 64 different lines each -- against 6.4 TB/s coalesced.
     auto load_quad = [&](const AnchorCursor &cur, int r) -> uint4 {
         const uint32_t last = cur.nq ? cur.nq - 1u : 0u;
-        const uint32_t qi = cur.c * 512u + uint32_t(r) * 64u + lane;
+        const uint32_t qi = cur.c * TQ + uint32_t(r) * 64u + lane;
         return stream_load(cur.qp + (qi < last ? qi : last));
     };
     auto load_task = [&](uint4 (&buf)[G], const AnchorCursor &cur) {
@@ -1353,14 +1356,24 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                 pending = true;
             };
             // quads of this task that exist (an item of 4 KiB fills half a task: the rest is skipped, wave-uniform)
-            const uint32_t task_quads = sc.nq - sc.c * 512u < 512u ? sc.nq - sc.c * 512u : 512u;
+            const uint32_t task_quads = sc.nq - sc.c * TQ < TQ ? sc.nq - sc.c * TQ : TQ;
+            // The bitmap words of quad r+1 are requested before quad r's are tested (sched_barrier keeps hipcc from
+            // sinking the reads to their use): a wave never sits on the LDS round trip of its own four reads.
+            typedef __attribute__((address_space(3))) u32x2 *RingPtr;
+            const uint32_t ring_base = kAnchorLdsBytes + (threadIdx.x >> 6) * 2048u;  // 1-KiB aligned: slot address = base | offset
+            uint32_t hh[2][4], ww[2][4];
+            auto fetch_quad = [&](int r) {
+                hash_quad(r, hh[r & 1]);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) ww[r & 1][w] = *reinterpret_cast<LdsU1Ptr>((hh[r & 1][w] >> 15) & 0x1FFFCu);
+            };
+            fetch_quad(0);
 #pragma unroll
             for (int r = 0; r < G; ++r) {
                 if (uint32_t(r) * 64u >= task_quads) break;
-                uint32_t h4[4], wd[4];
-                hash_quad(r, h4);
-#pragma unroll
-                for (int w = 0; w < 4; ++w) wd[w] = *reinterpret_cast<LdsU1Ptr>((h4[w] >> 15) & 0x1FFFCu);
+                if (r + 1 < G) fetch_quad(r + 1);  // (of a quad past the item's end: hashed, never tested)
+                __builtin_amdgcn_sched_barrier(0);
+                const uint32_t *h4 = hh[r & 1], *wd = ww[r & 1];
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
                     // (one bit-field extract feeds both the ballot and the predicated append: written as a shift and a
@@ -1369,11 +1382,15 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                     const uint64_t mm = __ballot(maybe);
                     if (mm != 0) {
                         const uint32_t at = __builtin_amdgcn_mbcnt_hi(uint32_t(mm >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mm), 0u));
-                        if (maybe) queue[(qhead + qcount + at) & (kProbeQueue - 1u)] = make_uint2(h4[w], uint32_t(r * 4 + w) | (lane << 5));
+                        if (maybe) {
+                            const uint32_t slot = ((((qhead + qcount) << 3) + (at << 3)) & (kProbeQueue * 8u - 8u)) | ring_base;
+                            *reinterpret_cast<RingPtr>(slot) = u32x2{h4[w], uint32_t(r * 4 + w) | (lane << 5)};
+                        }
                         qcount += uint32_t(__builtin_popcountll(mm));
                         if (qcount >= 64u) probe_round();
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
             while (qcount != 0) probe_round();
             load_task(buf, ld);  // the next task (issued behind the last probe round, which is consumed without waiting for it)
@@ -1429,7 +1446,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
         // index [start + m_min - 4, start + Lmax).
         const uint64_t cand = __ballot(zany != 0);
         auto flag = [&](uint32_t r, uint32_t l, uint32_t wmask) {
-            const uint32_t qi = sc.c * 512u + r * 64u + l;
+            const uint32_t qi = sc.c * TQ + r * 64u + l;
             if (qi >= sc.nq) return;
             for (; wmask != 0; wmask &= wmask - 1) {
                 const uint32_t w = uint32_t(__builtin_ctz(wmask));
@@ -1506,7 +1523,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
             nrun_vec = lane == sc.k ? nrun : nrun_vec;
         }
         const uint32_t k_before = sc.k;
-        const bool more = anchor_next(A, B, rec, sc);
+        const bool more = anchor_next<TQ>(A, B, rec, sc);
         if (more && sc.k != k_before) {
             nrun = 0;
             run_hi = 0;
@@ -1519,28 +1536,20 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     // with task t+2 as soon as the quad has been hashed (scan_task).  Loads are unconditional -- past
     // the last task the cursor is an invalid item whose loads fall on the anchor table -- because a load
     // under a branch makes hipcc drain vmcnt(0) instead of counting.
-    if constexpr (BIG) {
-        // One task buffer: the kernel is bound by instruction issue, not by bytes in flight, and the second buffer's
-        // 32 registers were what spilled.  A task's loads are issued when the scan of the previous one ends; the wave
-        // then waits for them while the CU's other 15 waves keep its SIMDs busy.
-        load_task(buf0, ld);
-        for (;;) {
-            anchor_next(A, B, rec, ld);
-            scan_task(buf0);   // (ends by loading the next task into buf0)
-            if (!close_or_advance()) break;
-        }
-    } else {
+    // (BIG: tasks are 4 KiB, so the two buffers take the 32 registers one 8-KiB task would.  The version with a
+    // single buffer loaded at the end of each scan left every task's HBM latency exposed at its first quad; now the
+    // loads of task t+1 are a whole scan old when it begins, and the probe loads -- whose in-order vmcnt wait also
+    // drains whatever was issued before them -- come two thirds into a task at a 10 % pass rate.)
     load_task(buf0, ld);
-    anchor_next(A, B, rec, ld);
+    anchor_next<TQ>(A, B, rec, ld);
     load_task(buf1, ld);
     for (;;) {
-        anchor_next(A, B, rec, ld);
+        anchor_next<TQ>(A, B, rec, ld);
         scan_task(buf0);
         if (!close_or_advance()) break;
-        anchor_next(A, B, rec, ld);
+        anchor_next<TQ>(A, B, rec, ld);
         scan_task(buf1);
         if (!close_or_advance()) break;
-    }
     }
 
     // hand the run lists over to k_walk_runs (lane k: item wave_first + k)
@@ -1562,7 +1571,10 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
 // (run_count 0) cost one coalesced 4-byte load.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kWalkThreads = 1024;
-constexpr uint32_t kWalkTileBytes = 64u * 1024u;  // two workgroups per CU: every lane slot of the chip walks at once
+constexpr uint32_t kWalkTileBytes = 64u * 1024u;
+// (k_walk_runs keeps 79 registers, so a CU holds ONE of its 16-wave workgroups.  Measured alternatives on config 3 /
+// the headline batch: 64 registers forced (24 spilled) 0.183 / 0.077 ms, three 8-wave workgroups with 48 KiB tiles
+// 0.160 / 0.084 ms, against 0.163 / 0.077 ms as it is: occupancy is not what bounds the kernel.)
 
 template <typename E, int MODE, bool EXTRA>
 __global__ __launch_bounds__(kWalkThreads) void k_walk_runs(DevAutomaton A, BatchArgs B) {

@@ -464,3 +464,58 @@ def test_255_used_byte_values_are_not_identity_classes():
         assert res.stat("columns") == 256
         api.ahocorasick_deinit(res)
     o.close()
+
+
+@pytest.mark.parametrize("kernel", [1, 2, 3])
+def test_two_batches_in_flight(kernel):
+    """acmi_match_batch_device_begin twice before the first _end: the batches end in the order they were begun, each
+    with its own records (== oracle), a third begin is refused, and a batch whose records outgrow the capacity the
+    handle expected -- after a later begin has reused the pipeline's intermediates -- still comes back whole."""
+    import torch
+    from php_aho_corasick_amd import batch
+    from php_aho_corasick_amd._native import AcmiError, E_ARG
+    sets = [synth.ragged(f"F{seed}", seed, 40, 12, 20, 300 + 50 * seed, 100, 3000, b"abcd") for seed in (1, 2, 3)]
+    # one pattern set for all batches: batch k is scanned with the patterns of set 0
+    base = sets[0]
+    o = Oracle("port")
+    o.add_patterns((base.pat_blob, base.pat_off))
+    res = resource_for(base, kernel=kernel)
+    batch.bind_current_stream(res)
+    dev, want = [], []
+    for ds in sets:
+        dev.append((torch.from_numpy(ds.hay_blob.copy()).cuda(), torch.from_numpy(ds.hay_off.astype(np.int64)).cuda(), len(ds.hay_off) - 1))
+        want.append(o.match_batch(ds.hay_blob, ds.hay_off, True))
+    # a dense batch: far more records than the first batches made the handle expect (capacity grows at its end)
+    nh_d = 64
+    dense_blob = np.frombuffer(bytes(base.pattern(0)) * (nh_d * 4096 // 12 + 1), dtype=np.uint8)[:nh_d * 4096].copy()
+    dense_off = (np.arange(nh_d + 1, dtype=np.uint64) * 4096)
+    dev.append((torch.from_numpy(dense_blob).cuda(), torch.from_numpy(dense_off.astype(np.int64)).cuda(), nh_d))
+    want.append(o.match_batch(dense_blob, dense_off, True))
+
+    def check(k, total):
+        p, r = batch.result_numpy(res, dev[k][2], total)
+        assert total == len(want[k][1]), k
+        assert np.array_equal(p, want[k][0]), k
+        assert np.array_equal(r, want[k][1]), k
+
+    order = [0, 1, 2, 3, 0, 3, 3, 1]
+    began = ended = 0
+    while ended < len(order):
+        while began < len(order) and began - ended < 2:
+            batch.match_device_begin(res, dev[order[began]][0], dev[order[began]][1], True)
+            began += 1
+        if began - ended == 2:
+            with pytest.raises(AcmiError) as e:   # a third batch is refused, the two in flight are not disturbed
+                batch.match_device_begin(res, dev[0][0], dev[0][1], True)
+            assert e.value.status == E_ARG
+        check(order[ended], batch.match_device_end(res))
+        ended += 1
+    with pytest.raises(AcmiError):
+        batch.match_device_end(res)               # nothing left in flight
+    # a synchronous call drops what was begun and never ended
+    batch.match_device_begin(res, dev[1][0], dev[1][1], True)
+    check(2, batch.match_device(res, dev[2][0], dev[2][1], True))
+    with pytest.raises(AcmiError):
+        batch.match_device_end(res)
+    api.ahocorasick_deinit(res)
+    o.close()

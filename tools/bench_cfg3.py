@@ -17,10 +17,10 @@ for k, v in opts.items():
         res.set_option(k, int(v))
 api.ahocorasick_finalize(res)
 t2 = time.time()
+res.set_option("profile", 2)
 for k, v in opts.items():
     if k not in BUILD_OPTS:
         res.set_option(k, int(v))
-res.set_option("profile", 2)
 print(f"add {t1-t0:.2f}s finalize {t2-t1:.2f}s states {int(res.stat('states'))} table {res.stat('table_bytes')/1e9:.2f} GB "
       f"hot {int(res.stat('hot_states'))} cols {int(res.stat('columns'))} mode {int(res.stat('class_mode'))}")
 tile = torch.from_numpy(ds.hay_blob).cuda()
