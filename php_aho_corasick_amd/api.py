@@ -175,6 +175,10 @@ def _process_pattern(pidx: int, elem) -> _Pattern | None:
     return p
 
 
+_PATTERN_DTYPE = np.dtype([("value", "<u8"), ("length", "<u4"), ("id_type", "<u4"), ("id_number", "<i8"), ("user", "<u8")])
+assert _PATTERN_DTYPE.itemsize == C.sizeof(N.Pattern)
+
+
 def _process_patterns(res: AhoResource, data) -> int:
     """php_ahocorasick_process_patterns (php_ahocorasick.c:389-489): 0 on success, <0 on failure."""
     if isinstance(data, dict):
@@ -195,16 +199,19 @@ def _process_patterns(res: AhoResource, data) -> int:
     if not parsed:
         return 0
     n = len(parsed)
-    arr = (N.Pattern * n)()
-    keep = []
-    for k, p in enumerate(parsed):
-        buf = (C.c_uint8 * max(1, len(p.value_bytes))).from_buffer_copy(p.value_bytes or b"\0")
-        keep.append(buf)
-        arr[k].value = C.cast(buf, C.POINTER(C.c_uint8))
-        arr[k].length = len(p.value_bytes)
-        arr[k].id_type = p.key_type
-        arr[k].id_number = p.key_id if p.key_type == N.ID_NUMBER else 0
-        arr[k].user = len(res._patterns) + k
+    # acmi_pattern array filled column-wise (65,536 patterns: 20 ms instead of 0.3 s of per-field ctypes stores): all
+    # values back to back in one buffer, `value` = its address + the pattern's offset
+    lengths = np.fromiter((len(p.value_bytes) for p in parsed), dtype=np.uint32, count=n)
+    blob = np.frombuffer(b"".join(p.value_bytes for p in parsed) + b"\0", dtype=np.uint8)
+    offs = np.zeros(n, dtype=np.uint64)
+    np.cumsum(lengths[:-1], out=offs[1:])
+    rec = np.zeros(n, dtype=_PATTERN_DTYPE)
+    rec["value"] = np.uint64(blob.ctypes.data) + offs
+    rec["length"] = lengths
+    rec["id_type"] = np.fromiter((p.key_type for p in parsed), dtype=np.uint32, count=n)
+    rec["id_number"] = np.fromiter((p.key_id if p.key_type == N.ID_NUMBER else 0 for p in parsed), dtype=np.int64, count=n)
+    rec["user"] = np.arange(len(res._patterns), len(res._patterns) + n, dtype=np.uint64)
+    arr = rec.ctypes.data_as(C.POINTER(N.Pattern))
     N.check(N.lib.acmi_add_patterns(res._h, arr, n, None), res._h)
     res._patterns.extend(parsed)
     return 0

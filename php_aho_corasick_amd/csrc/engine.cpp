@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -188,11 +189,32 @@ int fail_hip(acmi_handle *h, hipError_t e, const char *what) {
 
 constexpr uint64_t kAutoMinBytes = 1ull << 20;
 
+// Synchronous upload of a host array, registered for the duration of the copy when it is big (40-55 GB/s against
+// the staged path's 20-45 GB/s; registration costs 0.3-2 ms; tools/micro/upload_cost.hip).  The FIRST copy of a process
+// takes ~ 30 ms more whatever is done here, and ~ 140 ms in a process that has libacmi.so's code object to load: the
+// runtime's own start, paid once, by whichever call touches the device first (the device-side build, or the first match).
+hipError_t copy_h2d(void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) return hipSuccess;
+    const bool pin = bytes >= (256u << 10) && hipHostRegister(const_cast<void *>(src), bytes, hipHostRegisterDefault) == hipSuccess;
+    if (!pin) (void)hipGetLastError();
+    const hipError_t e = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+    if (pin) (void)hipHostUnregister(const_cast<void *>(src));
+    return e;
+}
+
 // Failure links and per-state outputs on the device, one launch per trie depth (kernels.hip k_build_level).  Used for
 // big tries when a gfx950 device is there ("device_build": -1 automatic from 200,000 nodes, 0 never, 1 always);
 // anything that goes wrong hands the work back to the host loop -- the results are the same words either way.
 bool device_fail_and_outputs(void *ctx, const TrieView &tv, uint32_t *fail, uint8_t *is_final, uint32_t *cnt, uint32_t *dict) {
     acmi_handle *h = static_cast<acmi_handle *>(ctx);
+    const bool trace = std::getenv("ACMI_BUILD_TRACE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[acmi build]   device: %-20s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return false; }
     int dev = h->device_request;
@@ -200,10 +222,11 @@ bool device_fail_and_outputs(void *ctx, const TrieView &tv, uint32_t *fail, uint
     if (dev >= count || hipSetDevice(dev) != hipSuccess) return false;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return false;
+    lap("runtime + device");
     const size_t n = tv.n_nodes;
     DevBuf d_parent, d_byte, d_own, d_order, d_keys, d_vals, d_fail, d_cnt, d_dict, d_final;
     auto up = [&](DevBuf &b, const void *src, size_t bytes) {
-        return b.ensure(bytes) == hipSuccess && hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+        return b.ensure(bytes) == hipSuccess && copy_h2d(b.p, src, bytes) == hipSuccess;
     };
     bool ok = up(d_parent, tv.parent, n * 4) && up(d_byte, tv.in_byte, n) && up(d_own, tv.own, n * 4) && up(d_order, tv.order, n * 4) &&
               up(d_keys, tv.map_keys, tv.map_size * 8) && up(d_vals, tv.map_vals, tv.map_size * 4) &&
@@ -214,18 +237,22 @@ bool device_fail_and_outputs(void *ctx, const TrieView &tv, uint32_t *fail, uint
         ok = hipMemset(d_fail.p, 0, 4) == hipSuccess && hipMemset(d_cnt.p, 0, 4) == hipSuccess &&
              hipMemset(d_dict.p, 0xFF, 4) == hipSuccess && hipMemset(d_final.p, 0, 1) == hipSuccess;
     }
+    lap("trie upload (+ first use of the device)");
     if (ok) {
         BuildArgs T{d_parent.as<uint32_t>(), d_byte.as<uint8_t>(), d_own.as<uint32_t>(), d_order.as<uint32_t>(), d_keys.as<uint64_t>(),
                     d_vals.as<uint32_t>(), tv.map_size, d_fail.as<uint32_t>(), d_cnt.as<uint32_t>(), d_dict.as<uint32_t>(), d_final.as<uint8_t>()};
         for (uint32_t d = 1; d < tv.n_levels; ++d) launch_build_level(T, tv.level_off[d], tv.level_off[d + 1], nullptr);
-        ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
-             hipMemcpy(fail, d_fail.p, n * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+        ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+        lap("level kernels");
+        ok = ok && hipMemcpy(fail, d_fail.p, n * 4, hipMemcpyDeviceToHost) == hipSuccess &&
              hipMemcpy(cnt, d_cnt.p, n * 4, hipMemcpyDeviceToHost) == hipSuccess &&
              hipMemcpy(dict, d_dict.p, n * 4, hipMemcpyDeviceToHost) == hipSuccess &&
              hipMemcpy(is_final, d_final.p, n, hipMemcpyDeviceToHost) == hipSuccess;
     }
     if (!ok) (void)hipGetLastError();
+    lap("download");
     for (DevBuf *b : {&d_parent, &d_byte, &d_own, &d_order, &d_keys, &d_vals, &d_fail, &d_cnt, &d_dict, &d_final}) b->release();
+    lap("release");
     return ok;
 }
 
@@ -305,51 +332,51 @@ int ensure_device(acmi_handle *h) {
     while (image.size() % 16) image.push_back(0);
 
     HIPCHK(h, h->d_table.ensure(fa.table.size()));
-    HIPCHK(h, hipMemcpy(h->d_table.p, fa.table.data(), fa.table.size(), hipMemcpyHostToDevice));
+    HIPCHK(h, copy_h2d(h->d_table.p, fa.table.data(), fa.table.size()));
     HIPCHK(h, h->d_lds.ensure(image.size()));
-    HIPCHK(h, hipMemcpy(h->d_lds.p, image.data(), image.size(), hipMemcpyHostToDevice));
+    HIPCHK(h, copy_h2d(h->d_lds.p, image.data(), image.size()));
     HIPCHK(h, h->d_class.ensure(512));
-    HIPCHK(h, hipMemcpy(h->d_class.p, class_off, 512, hipMemcpyHostToDevice));
+    HIPCHK(h, copy_h2d(h->d_class.p, class_off, 512));
     const size_t ns4 = size_t(fa.n_states) * 4;
     HIPCHK(h, h->d_own.ensure(ns4));
-    HIPCHK(h, hipMemcpy(h->d_own.p, fa.own_pattern.data(), ns4, hipMemcpyHostToDevice));
+    HIPCHK(h, copy_h2d(h->d_own.p, fa.own_pattern.data(), ns4));
     HIPCHK(h, h->d_dict.ensure(ns4));
-    HIPCHK(h, hipMemcpy(h->d_dict.p, fa.dict_link.data(), ns4, hipMemcpyHostToDevice));
+    HIPCHK(h, copy_h2d(h->d_dict.p, fa.dict_link.data(), ns4));
     HIPCHK(h, h->d_cnt.ensure(ns4));
-    HIPCHK(h, hipMemcpy(h->d_cnt.p, fa.out_count.data(), ns4, hipMemcpyHostToDevice));
+    HIPCHK(h, copy_h2d(h->d_cnt.p, fa.out_count.data(), ns4));
     const size_t np4 = std::max<size_t>(4, fa.pattern_length.size() * 4);
     HIPCHK(h, h->d_plen.ensure(np4));
     if (!fa.pattern_length.empty())
-        HIPCHK(h, hipMemcpy(h->d_plen.p, fa.pattern_length.data(), fa.pattern_length.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(h, copy_h2d(h->d_plen.p, fa.pattern_length.data(), fa.pattern_length.size() * 4));
 
     if (!fa.out_off.empty()) {
         HIPCHK(h, h->d_out_off.ensure(ns4));
-        HIPCHK(h, hipMemcpy(h->d_out_off.p, fa.out_off.data(), ns4, hipMemcpyHostToDevice));
+        HIPCHK(h, copy_h2d(h->d_out_off.p, fa.out_off.data(), ns4));
         HIPCHK(h, h->d_out_list.ensure(std::max<size_t>(8, fa.out_list.size() * 4)));
         if (!fa.out_list.empty())
-            HIPCHK(h, hipMemcpy(h->d_out_list.p, fa.out_list.data(), fa.out_list.size() * 4, hipMemcpyHostToDevice));
+            HIPCHK(h, copy_h2d(h->d_out_list.p, fa.out_list.data(), fa.out_list.size() * 4));
     }
 
     if (fa.compact) {
         HIPCHK(h, h->d_cold_rec.ensure(std::max<size_t>(8, fa.cold_rec.size() * 4)));
-        HIPCHK(h, hipMemcpy(h->d_cold_rec.p, fa.cold_rec.data(), fa.cold_rec.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(h, copy_h2d(h->d_cold_rec.p, fa.cold_rec.data(), fa.cold_rec.size() * 4));
         HIPCHK(h, h->d_cold_edges.ensure(std::max<size_t>(8, fa.cold_edges.size() * 4)));
         if (!fa.cold_edges.empty())
-            HIPCHK(h, hipMemcpy(h->d_cold_edges.p, fa.cold_edges.data(), fa.cold_edges.size() * 4, hipMemcpyHostToDevice));
+            HIPCHK(h, copy_h2d(h->d_cold_edges.p, fa.cold_edges.data(), fa.cold_edges.size() * 4));
         if (!fa.chain_byte.empty()) {
             HIPCHK(h, h->d_chain_byte.ensure(fa.chain_byte.size()));
-            HIPCHK(h, hipMemcpy(h->d_chain_byte.p, fa.chain_byte.data(), fa.chain_byte.size(), hipMemcpyHostToDevice));
+            HIPCHK(h, copy_h2d(h->d_chain_byte.p, fa.chain_byte.data(), fa.chain_byte.size()));
             HIPCHK(h, h->d_chain_run.ensure(fa.chain_run.size()));
-            HIPCHK(h, hipMemcpy(h->d_chain_run.p, fa.chain_run.data(), fa.chain_run.size(), hipMemcpyHostToDevice));
+            HIPCHK(h, copy_h2d(h->d_chain_run.p, fa.chain_run.data(), fa.chain_run.size()));
         }
     }
 
     if (fa.anchor_q) {
         HIPCHK(h, h->d_anchor.ensure(fa.anchor_table.size() * 2));
-        HIPCHK(h, hipMemcpy(h->d_anchor.p, fa.anchor_table.data(), fa.anchor_table.size() * 2, hipMemcpyHostToDevice));
+        HIPCHK(h, copy_h2d(h->d_anchor.p, fa.anchor_table.data(), fa.anchor_table.size() * 2));
         if (fa.anchor_mode == 2) {
             HIPCHK(h, h->d_bitmap.ensure(fa.anchor_bitmap.size() * 4));
-            HIPCHK(h, hipMemcpy(h->d_bitmap.p, fa.anchor_bitmap.data(), fa.anchor_bitmap.size() * 4, hipMemcpyHostToDevice));
+            HIPCHK(h, copy_h2d(h->d_bitmap.p, fa.anchor_bitmap.data(), fa.anchor_bitmap.size() * 4));
         }
     }
 
@@ -358,11 +385,11 @@ int ensure_device(acmi_handle *h) {
         const std::vector<uint8_t> &pb = h->aut.pattern_bytes();
         HIPCHK(h, h->d_pat_bytes.ensure(pb.size() + 32));
         HIPCHK(h, hipMemset(h->d_pat_bytes.p, 0, pb.size() + 32));
-        HIPCHK(h, hipMemcpy(h->d_pat_bytes.p, pb.data(), pb.size(), hipMemcpyHostToDevice));
+        HIPCHK(h, copy_h2d(h->d_pat_bytes.p, pb.data(), pb.size()));
         HIPCHK(h, h->d_slot_pair.ensure(fa.anchor_slot_pair.size() * 4));
-        HIPCHK(h, hipMemcpy(h->d_slot_pair.p, fa.anchor_slot_pair.data(), fa.anchor_slot_pair.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(h, copy_h2d(h->d_slot_pair.p, fa.anchor_slot_pair.data(), fa.anchor_slot_pair.size() * 4));
         HIPCHK(h, h->d_pairs.ensure(fa.anchor_pairs.size() * 4));
-        HIPCHK(h, hipMemcpy(h->d_pairs.p, fa.anchor_pairs.data(), fa.anchor_pairs.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(h, copy_h2d(h->d_pairs.p, fa.anchor_pairs.data(), fa.anchor_pairs.size() * 4));
     }
 
     DevAutomaton &A = h->dA;
@@ -1552,10 +1579,10 @@ int acmi_replace_batch(acmi_handle *h, const uint8_t *blob, const uint64_t *offs
             for (size_t i = 0; i < h->aut.patterns().size(); ++i)
                 if (!h->aut.patterns()[i].accepted) off[i] = ~0ull;
             HIPCHK(h, h->d_rep_off.ensure(off.size() * 8));
-            HIPCHK(h, hipMemcpy(h->d_rep_off.p, off.data(), off.size() * 8, hipMemcpyHostToDevice));
+            HIPCHK(h, copy_h2d(h->d_rep_off.p, off.data(), off.size() * 8));
             const std::vector<uint8_t> &rb = h->aut.replacement_bytes();
             HIPCHK(h, h->d_rep_bytes.ensure(rb.size() + 16));
-            if (!rb.empty()) HIPCHK(h, hipMemcpy(h->d_rep_bytes.p, rb.data(), rb.size(), hipMemcpyHostToDevice));
+            if (!rb.empty()) HIPCHK(h, copy_h2d(h->d_rep_bytes.p, rb.data(), rb.size()));
             h->rep_uploaded = true;
         }
         // 1. every match of the batch (the pipeline of acmi_match_batch, results left on the device)
