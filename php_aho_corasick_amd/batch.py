@@ -46,7 +46,8 @@ def match_device(res: AhoResource, d_blob, d_off, find_all: bool = True) -> int:
 
 
 def match_device_begin(res: AhoResource, d_blob, d_off, find_all: bool = True) -> None:
-    """Enqueue the scan of a resident batch and return immediately (see ``match_device_end``)."""
+    """Enqueue the scan of a resident batch and return immediately (see ``match_device_end``).  Up to two batches may
+    be in flight per resource: the second one's kernels queue behind the first one's (acmi.h)."""
     assert d_blob.is_cuda and d_off.is_cuda and d_blob.is_contiguous() and d_off.is_contiguous()
     N.check(N.lib.acmi_match_batch_device_begin(res._h, C.c_void_p(d_blob.data_ptr()), d_blob.numel(),
                                                 C.c_void_p(d_off.data_ptr()), d_off.numel() - 1,
@@ -54,7 +55,8 @@ def match_device_begin(res: AhoResource, d_blob, d_off, find_all: bool = True) -
 
 
 def match_device_end(res: AhoResource) -> int:
-    """Wait for the batch enqueued by ``match_device_begin``; returns its record count."""
+    """Wait for the OLDEST batch enqueued by ``match_device_begin``; returns its record count.  Its result
+    (``result_view`` / ``result_numpy`` / ...) stays valid until the second begin after its own."""
     total = C.c_uint64(0)
     N.check(N.lib.acmi_match_batch_device_end(res._h, C.byref(total)), res._h)
     return int(total.value)
