@@ -739,6 +739,7 @@ __device__ __forceinline__ uint32_t walk_fast(const DevAutomaton &A, const Batch
 struct Verified {
     uint32_t j;      // index of the occurrence's last byte, 0xFFFFFFFF: the pattern is not there
     uint32_t state;  // its final state
+    uint32_t cnt;    // out_count[state], requested together with the texts that are compared (one round trip less)
 };
 
 typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
@@ -799,8 +800,12 @@ __device__ __forceinline__ bool verify_candidate(const DevAutomaton &A, const ui
         const uint32_t o = rec.y & 0xffu, len = rec.y >> 8;
         if (w < o || w - o + len > n) continue;  // would begin before / end after this item's bytes: no occurrence here
         const uint8_t *tp = p + (w - o), *pp = A.pattern_bytes + rec.z;
+        const uint32_t oc = A.out_count[rec.w];
         uint32_t diff = 0;
         if (len >= 16u) {
+            // (requesting four clamped 16-byte pieces of both texts up front -- one round trip whatever the length -- was
+            // measured and is slower, 0.166 against 0.162 ms on config 3: the kernel is bound by the number of divergent
+            // requests a CU's vector memory path takes per clock, ~ 15 per candidate, not by the length of the chain)
 #pragma unroll 1
             for (uint32_t c = 0; c + 16u <= len; c += 16u) {
                 const uint4 a = load16u(tp + c), b = load16u(pp + c);
@@ -816,7 +821,7 @@ __device__ __forceinline__ bool verify_candidate(const DevAutomaton &A, const ui
         }
         if (diff) continue;
         if (nv >= kClusterMax) return false;
-        const Verified vv{w - o + len - 1u, rec.w};  // index of the occurrence's last byte, the pattern's final state
+        const Verified vv{w - o + len - 1u, rec.w, oc};  // index of the occurrence's last byte, the pattern's final state
 #pragma unroll
         for (uint32_t i = 0; i < kClusterMax; ++i) if (i == nv) v[i] = vv;
         ++nv;
@@ -855,7 +860,7 @@ __device__ __forceinline__ uint32_t run_epilogue_fast(const DevAutomaton &A, con
             bool windows = entry_is_window(first.z) && A.anchor_pairs != nullptr;
             Verified v[kClusterMax];
 #pragma unroll
-            for (uint32_t i = 0; i < kClusterMax; ++i) v[i] = Verified{0xFFFFFFFFu, 0u};
+            for (uint32_t i = 0; i < kClusterMax; ++i) v[i] = Verified{0xFFFFFFFFu, 0u, 0u};
             if (windows) windows = verify_candidate(A, p, n, first.z & ~kEntryWindow, v, nv);
 #pragma unroll 1
             for (;;) {
@@ -885,12 +890,12 @@ __device__ __forceinline__ uint32_t run_epilogue_fast(const DevAutomaton &A, con
                     // same end as the next one: the longer pattern is the one from the EARLIER window; after the sort
                     // equal ends are neighbours, and the event belongs to the deepest final state among them
                     if (i + 1 < kClusterMax && v[i + 1].j == j) {
-                        if (A.out_count[v[i + 1].state] < A.out_count[v[i].state]) v[i + 1].state = v[i].state;
+                        if (v[i + 1].cnt < v[i].cnt) { v[i + 1].state = v[i].state; v[i + 1].cnt = v[i].cnt; }
                         continue;
                     }
                     if (j >= rep_from && j < hi && !(B.first_only && ev.n_ev)) {
                         const uint32_t s = v[i].state;
-                        ev.n_rec += A.out_count[s];
+                        ev.n_rec += v[i].cnt;
                         if (ev.n_ev < B.slab_events) B.slab[uint64_t(ev.n_ev) * B.run_stride + item] = make_uint2(pos_bias + j, s);
                         ++ev.n_ev;
                     }
