@@ -60,6 +60,8 @@ struct BatchArgs {
     uint32_t n_haystacks;
     uint32_t chunk_bytes;        // reporting bytes per work item
     uint32_t warm_bytes;         // max_pattern_length - 1
+    uint32_t align_warm;         // 1: k_items lengthens the warm-up of a chunk that does not start its haystack so that
+                                 // the scan begins on a 128-byte boundary (anchor kernel: no unaligned head to flag, whole lines per wave-load)
     uint32_t slab_events;        // K: event slots per work item
     uint32_t first_only;         // findAll == false
     uint32_t *item_hay;          // per item: haystack index

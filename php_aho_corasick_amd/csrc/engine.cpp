@@ -188,6 +188,7 @@ int fail_hip(acmi_handle *h, hipError_t e, const char *what) {
     } while (0)
 
 constexpr uint64_t kAutoMinBytes = 1ull << 20;
+constexpr uint64_t kSmallItemBytes = 3072;  // automatic mode: average haystack size under which the anchor kernel is not used
 
 // Synchronous upload of a host array, registered for the duration of the copy when it is big (40-55 GB/s against
 // the staged path's 20-45 GB/s; registration costs 0.3-2 ms; tools/micro/upload_cost.hip).  The FIRST copy of a process
@@ -452,7 +453,7 @@ int ensure_device(acmi_handle *h) {
     return ACMI_OK;
 }
 
-uint32_t choose_chunk(const acmi_handle *h, uint64_t blob_bytes, int kernel) {
+uint32_t choose_chunk(const acmi_handle *h, uint64_t blob_bytes, size_t nh, int kernel) {
     const uint32_t warm = h->aut.flat().max_pattern_length ? h->aut.flat().max_pattern_length - 1 : 0;
     if (h->chunk_opt) {
         uint64_t c = (h->chunk_opt + 15) & ~uint64_t(15);
@@ -464,7 +465,17 @@ uint32_t choose_chunk(const acmi_handle *h, uint64_t blob_bytes, int kernel) {
     uint64_t c0 = (blob_bytes + target_items - 1) / target_items;
     uint64_t cmin = std::max<uint64_t>(256, (uint64_t(warm) * 8 + 127) & ~uint64_t(127));
     // the anchor kernel streams an item 8 KiB (one wave step) at a time: smaller items idle its lanes
-    if (kernel == 2) cmin = std::max<uint64_t>(cmin, 8192);
+    if (kernel == 2) {
+        cmin = std::max<uint64_t>(cmin, 8192);
+        // ... and where haystacks are longer than that (they get chunked), a chunk inside its haystack must fit one step
+        // WITH its warm-up, which k_items rounds up to a 128-byte boundary (align_warm): 8 KiB chunks were 513-514 quads,
+        // i.e. a second, almost empty step per item (24-KiB haystacks: scan kernel 0.83 instead of 0.67 ms per 4 GiB)
+        if (nh && blob_bytes / nh > 8192 && uint64_t(warm) + 32 < 4096) {
+            const uint64_t steps = std::max<uint64_t>(1, (c0 + 8191) / 8192);  // whole steps per chunk, less the warm-up's room
+            const uint64_t c = steps * 8192 - ((uint64_t(warm) + 128 + 127) & ~uint64_t(127));  // (warm-up rounded to a whole line)
+            return uint32_t(std::min<uint64_t>(c, 1u << 30));
+        }
+    }
     uint64_t c = std::max<uint64_t>(cmin, (c0 + 127) & ~uint64_t(127));
     return uint32_t(std::min<uint64_t>(c, 1u << 30));
 }
@@ -525,9 +536,16 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     }
     int kernel = h->kernel == 3 ? ((fa.anchor_q && !h->anchor_off) ? 2 : 1)
                                 : ((h->kernel == 2 && !fa.anchor_q) ? 1 : h->kernel);
+    // Small haystacks: the anchor kernel gives a wave one work item per 8-KiB step whatever the item's size, so its
+    // rate falls with the item size (headline patterns over 4 GiB: 5.4 TB/s at 8 KiB, 3.8 at 4 KiB, 2.1 at 2 KiB, 1.1 at
+    // 1 KiB, 0.6 at 512 B), while the LDS-tile walk gives every LANE its own items (3.3 / 2.9 / 2.3 / 1.7 TB/s).  Under
+    // 3 KiB per haystack on average automatic mode takes the tile walk -- unless the automaton's estimate or an earlier
+    // batch says its optimistic pass does not work on this handle's data (exact_only).  (Batches under 1 MiB are
+    // launch-bound either way and keep the kernel the pattern set asks for.)
+    if (h->kernel == 3 && kernel == 2 && !h->exact_only && blob_bytes >= kAutoMinBytes && blob_bytes / nh < kSmallItemBytes) kernel = 1;
     if (h->kernel == 3 && kernel == 1 && h->exact_only) kernel = 4;
     F.kernel_used = kernel;
-    const uint32_t chunk = choose_chunk(h, blob_bytes, kernel);
+    const uint32_t chunk = choose_chunk(h, blob_bytes, nh, kernel);
     const uint64_t max_items = blob_bytes / chunk + nh;
     const uint32_t K = std::max<uint32_t>(1, h->slab_events);
     F.chunk_used = chunk;
@@ -572,6 +590,7 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     B.n_haystacks = uint32_t(nh);
     B.chunk_bytes = chunk;
     B.warm_bytes = fa.max_pattern_length ? fa.max_pattern_length - 1 : 0;
+    B.align_warm = kernel == 2 ? 1u : 0u;
     B.slab_events = K;
     B.first_only = find_all ? 0u : 1u;
     B.item_hay = h->d_item_hay.as<uint32_t>();
@@ -596,9 +615,18 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     }
     B.persistent = h->persistent >= 0 ? uint32_t(h->persistent != 0)
                                       : uint32_t(blob_bytes / chunk > 3ull * 256 * 1024 * uint64_t(h->ilp));
+    if (h->persistent < 0 && kernel == 2) {
+        // The anchor kernel's static split gives a workgroup 16 x wave_items items: fine when the workgroups are a
+        // multiple of the 256 CUs (the headline batch: 512, and 2.5 % faster than pulling batches from a counter), but
+        // 528 of them -- 1 MiB haystacks in 7,936-byte chunks -- are three rounds of which the last is almost empty
+        // (0.87 instead of 0.67 ms per 4 GiB).  Any other count: persistent workgroups.
+        const uint64_t per_group = 16ull * B.wave_items;
+        const uint64_t groups = (blob_bytes / chunk + per_group - 1) / per_group;
+        if (groups > 256 && groups % 256 != 0) B.persistent = 1u;
+    }
 
     // item counts, their scan, the item table, zeroed per-item counters: one launch
-    launch_items(B, blob_bytes, h->d_item_base.as<uint64_t>(), sync_cur + 16, status0, st);
+    launch_items(B, blob_bytes, max_items, h->d_item_base.as<uint64_t>(), sync_cur + 16, status0, st);
 
     if (h->profile) HIPCHK(h, hipEventRecord(F.ev[1], st));
     if (kernel == 4) {

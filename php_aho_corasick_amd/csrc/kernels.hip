@@ -297,12 +297,37 @@ __device__ __forceinline__ uint64_t tile_exclusive(const uint64_t (&v)[kScanPerT
     return wave_base + inc - sum;
 }
 
+// Work item `g` = chunk `c` of haystack `h`: its table entries and zeroed counters.
+__device__ __forceinline__ void fill_item(const BatchArgs &B, uint64_t h, uint64_t c, uint64_t g) {
+    const uint64_t hb = B.offsets[h], he = B.offsets[h + 1];
+    const uint64_t p0 = c * B.chunk_bytes;
+    ItemDesc it;
+    it.hay = uint32_t(h);
+    it.pos0 = uint32_t(p0);
+    it.begin = hb + p0;
+    const uint64_t rest = he - it.begin;
+    it.len = rest < B.chunk_bytes ? uint32_t(rest) : B.chunk_bytes;
+    it.warm = p0 < B.warm_bytes ? uint32_t(p0) : B.warm_bytes;
+    if (B.align_warm && p0 > it.warm) {
+        // a chunk inside its haystack: the bytes in front of its warm-up are the same haystack's, so the scan may as
+        // well begin on the aligned boundary below -- the anchor kernel then has no unaligned head to flag wholesale
+        // (such heads, walked from the root by k_walk_runs, were 0.3 ms per 4 GiB of 24-KiB haystacks)
+        // (a whole 128-byte line below, in fact: wave-loads that straddle lines cost the anchor kernel a quarter of its rate)
+        const uint64_t extra = (reinterpret_cast<uintptr_t>(B.blob) + it.begin - it.warm) & 127u;
+        it.warm += uint32_t(extra < p0 - it.warm ? extra : p0 - it.warm);
+    }
+    B.item_hay[g] = uint32_t(h);
+    B.item_rec[g] = pack_item(it);
+    B.ev_count[g] = 0u;
+    B.rec_count[g] = 0ull;
+}
+
 // item_base[h] = first work item of haystack h (h = 0..nh; item_base[nh] = number of items), the item table and
 // the zeroed per-item counters.  Validates what the host cannot see for device-resident offsets: decreasing
 // offsets, a haystack of 4 GiB or more (positions are 32-bit) or one that ends past the blob (every per-item
 // workspace is sized from blob_bytes) raise counters[6], and that haystack gets no item.
 __global__ __launch_bounds__(kScanThreads) void k_items(BatchArgs B, uint64_t blob_bytes, uint64_t *item_base_out, uint32_t *ticket,
-                                                        uint64_t *status) {
+                                                        uint64_t *status, bool fill_later) {
     __shared__ uint64_t wave_sums[kScanThreads / 64];
     __shared__ uint64_t s_before;
     __shared__ uint32_t s_tile;
@@ -340,7 +365,9 @@ __global__ __launch_bounds__(kScanThreads) void k_items(BatchArgs B, uint64_t bl
 #pragma unroll
     for (int i = 0; i < kScanPerThread; ++i)
         if (base + i < n) item_base_out[base + i] = before + local[threadIdx.x * kScanPerThread + i];
-    // the tile's work items, shared out over the workgroup whatever their distribution over its haystacks
+    // the tile's work items, shared out over the workgroup whatever their distribution over its haystacks (when haystacks
+    // are long -- many items each -- a tile of 2,048 of them is too much for one workgroup: k_item_fill does it instead)
+    if (fill_later) return;
     for (uint64_t k = threadIdx.x; k < tile_sum; k += kScanThreads) {
         uint32_t lo = 0, hi = kScanTile;  // local[lo] <= k < local[hi]
         // one item per haystack so far (the usual batch): haystack k, two LDS reads instead of eleven
@@ -349,21 +376,21 @@ __global__ __launch_bounds__(kScanThreads) void k_items(BatchArgs B, uint64_t bl
             const uint32_t mid = (lo + hi) >> 1;
             if (local[mid] <= k) lo = mid; else hi = mid;
         }
-        const uint64_t h = uint64_t(tile) * kScanTile + lo;
-        const uint64_t hb = B.offsets[h], he = B.offsets[h + 1];
-        const uint64_t p0 = (k - local[lo]) * B.chunk_bytes;
-        ItemDesc it;
-        it.hay = uint32_t(h);
-        it.pos0 = uint32_t(p0);
-        it.begin = hb + p0;
-        const uint64_t rest = he - it.begin;
-        it.len = rest < B.chunk_bytes ? uint32_t(rest) : B.chunk_bytes;
-        it.warm = p0 < B.warm_bytes ? uint32_t(p0) : B.warm_bytes;
-        const uint64_t g = before + k;
-        B.item_hay[g] = uint32_t(h);
-        B.item_rec[g] = pack_item(it);
-        B.ev_count[g] = 0u;
-        B.rec_count[g] = 0ull;
+        fill_item(B, uint64_t(tile) * kScanTile + lo, k - local[lo], before + k);
+    }
+}
+
+// The item table when haystacks are long (4,096 haystacks of 1 MiB: 129 items each -- two workgroups of k_items took
+// 1 ms to write 528,384 records): one thread per item, its haystack found by binary search in item_base.
+__global__ __launch_bounds__(256) void k_item_fill(BatchArgs B) {
+    const uint64_t items = B.item_base[B.n_haystacks];
+    for (uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; g < items; g += uint64_t(gridDim.x) * blockDim.x) {
+        uint64_t lo = 0, hi = B.n_haystacks;  // item_base[lo] <= g < item_base[hi]; the LAST such lo (empty haystacks share a base)
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (B.item_base[mid] <= g) lo = mid; else hi = mid;
+        }
+        fill_item(B, lo, g - B.item_base[lo], g);
     }
 }
 
@@ -2388,8 +2415,14 @@ void launch_gather_compact(const GatherArgs &G, hipStream_t st) {
 // ------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------
-void launch_items(const BatchArgs &B, uint64_t blob_bytes, uint64_t *item_base, uint32_t *ticket, uint64_t *status, hipStream_t st) {
-    hipLaunchKernelGGL(k_items, dim3(scan_tiles(uint64_t(B.n_haystacks) + 1)), dim3(kScanThreads), 0, st, B, blob_bytes, item_base, ticket, status);
+void launch_items(const BatchArgs &B, uint64_t blob_bytes, uint64_t max_items, uint64_t *item_base, uint32_t *ticket, uint64_t *status, hipStream_t st) {
+    // long haystacks (more than two items each on average): the item table is written by a kernel of its own
+    const bool fill_later = B.n_haystacks && blob_bytes / B.n_haystacks > 2ull * B.chunk_bytes;
+    hipLaunchKernelGGL(k_items, dim3(scan_tiles(uint64_t(B.n_haystacks) + 1)), dim3(kScanThreads), 0, st, B, blob_bytes, item_base, ticket, status, fill_later);
+    if (fill_later) {
+        const uint64_t blocks = std::min<uint64_t>((max_items + 255) / 256, 256u * 32u);
+        hipLaunchKernelGGL(k_item_fill, dim3(uint32_t(blocks)), dim3(256), 0, st, B);
+    }
 }
 
 void launch_rec_scan(const BatchArgs &B, uint64_t max_items, uint64_t *rec_base, uint32_t *ticket, uint64_t *status, hipStream_t st) {

@@ -12,7 +12,7 @@ namespace acmi {
 
 // single-pass scans (kernels.hip): tiles of 2048 elements, one status word per tile
 uint32_t scan_tiles(uint64_t n);
-void launch_items(const BatchArgs &B, uint64_t blob_bytes, uint64_t *item_base, uint32_t *ticket, uint64_t *status, hipStream_t st);
+void launch_items(const BatchArgs &B, uint64_t blob_bytes, uint64_t max_items, uint64_t *item_base, uint32_t *ticket, uint64_t *status, hipStream_t st);
 void launch_rec_scan(const BatchArgs &B, uint64_t max_items, uint64_t *rec_base, uint32_t *ticket, uint64_t *status, hipStream_t st);
 hipError_t launch_scan(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int kernel,
                        int class_mode, int ilp, int group_quads, hipStream_t st);

@@ -519,3 +519,26 @@ def test_two_batches_in_flight(kernel):
         batch.match_device_end(res)
     api.ahocorasick_deinit(res)
     o.close()
+
+
+def test_automatic_choice_small_haystacks():
+    """Automatic mode takes the LDS-tile walk instead of the anchor filter when haystacks average under 3 KiB (the anchor
+    kernel spends an 8-KiB wave step per work item): same records, other kernel; big haystacks keep the filter."""
+    import torch
+    from php_aho_corasick_amd import batch
+    ds = synth.generate("SH", 5, 256, 16, 16, 4096, 512, b"abcdef")        # 2 MiB of 512-byte haystacks
+    big = synth.generate("SB", 5, 256, 16, 16, 256, 8192, b"abcdef")       # 2 MiB of 8-KiB haystacks, same patterns
+    o = Oracle("port")
+    o.add_patterns((ds.pat_blob, ds.pat_off))
+    res = resource_for(ds)
+    batch.bind_current_stream(res)
+    for data, kernel in ((ds, 1), (big, 2), (ds, 1)):
+        d_blob = torch.from_numpy(data.hay_blob.copy()).cuda()
+        d_off = torch.from_numpy(data.hay_off.astype(np.int64)).cuda()
+        total = batch.match_device(res, d_blob, d_off, True)
+        assert int(res.stat("kernel_used")) == kernel
+        p, r = batch.result_numpy(res, len(data.hay_off) - 1, total)
+        pe, re_ = o.match_batch(data.hay_blob, data.hay_off, True)
+        assert np.array_equal(p, pe) and np.array_equal(r, re_)
+    api.ahocorasick_deinit(res)
+    o.close()
