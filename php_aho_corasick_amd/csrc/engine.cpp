@@ -190,17 +190,14 @@ int fail_hip(acmi_handle *h, hipError_t e, const char *what) {
 constexpr uint64_t kAutoMinBytes = 1ull << 20;
 constexpr uint64_t kSmallItemBytes = 3072;  // automatic mode: average haystack size under which the anchor kernel is not used
 
-// Synchronous upload of a host array, registered for the duration of the copy when it is big (40-55 GB/s against
-// the staged path's 20-45 GB/s; registration costs 0.3-2 ms; tools/micro/upload_cost.hip).  The FIRST copy of a process
-// takes ~ 30 ms more whatever is done here, and ~ 140 ms in a process that has libacmi.so's code object to load: the
-// runtime's own start, paid once, by whichever call touches the device first (the device-side build, or the first match).
+// Synchronous upload of a host array: a plain pageable hipMemcpy (20-55 GB/s on the MI355X box, tools/micro/upload_cost.hip).
+// The FIRST copy of a process takes ~ 30 ms more, and ~ 140 ms in a process that has libacmi.so's code object to load:
+// the runtime's own start, paid once, by whichever call touches the device first (the device-side build, or the first
+// match).  (Registering the source for the duration of the copy was tried: no faster once the runtime is up, and long test
+// runs then aborted inside later pageable copies of other libraries from address ranges that had once been registered.)
 hipError_t copy_h2d(void *dst, const void *src, size_t bytes) {
     if (bytes == 0) return hipSuccess;
-    const bool pin = bytes >= (256u << 10) && hipHostRegister(const_cast<void *>(src), bytes, hipHostRegisterDefault) == hipSuccess;
-    if (!pin) (void)hipGetLastError();
-    const hipError_t e = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
-    if (pin) (void)hipHostUnregister(const_cast<void *>(src));
-    return e;
+    return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
 }
 
 // Failure links and per-state outputs on the device, one launch per trie depth (kernels.hip k_build_level).  Used for
@@ -591,6 +588,7 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     B.chunk_bytes = chunk;
     B.warm_bytes = fa.max_pattern_length ? fa.max_pattern_length - 1 : 0;
     B.align_warm = kernel == 2 ? 1u : 0u;
+    B.short_items = (kernel == 2 && blob_bytes / nh < 6144) ? 1u : 0u;
     B.slab_events = K;
     B.first_only = find_all ? 0u : 1u;
     B.item_hay = h->d_item_hay.as<uint32_t>();

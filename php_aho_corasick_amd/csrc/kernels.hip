@@ -1227,7 +1227,9 @@ __device__ __forceinline__ bool anchor_next(const DevAutomaton &A, const BatchAr
 // top 20 bits; a window whose bit is set (a fifth of them for 262,144 q-grams) is looked up in an
 // 8-slot fingerprint table in global memory, which L2 serves.  QW = 1 (4-byte windows, shortest pattern
 // 7..10 B) needs no hand-over between quads.
-template <typename E, int MODE, int QW, bool BIG>
+// SHORT (small-set kernel only): items may be shorter than a task -- the rows a task does not have are not hashed.
+// A variant of its own because the test, one scalar branch per row, costs the 8-KiB-item kernel its schedule.
+template <int QW, bool BIG, bool SHORT>
 __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, BatchArgs B) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int G = BIG ? 4 : 8;  // 16-byte quads per lane and task
@@ -1443,18 +1445,22 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
         // (hipcc on its own put an lgkmcnt(0) right behind every ds_read).
         uint32_t hh[2][4];
         u32x2 bb[2][4];   // the four fingerprint buckets of a quad
+        // SHORT: rows of 64 quads this task has (an item of 4 KiB fills half a task); the others are only reloaded
+        const uint32_t rows = SHORT ? ((sc.nq - sc.c * TQ < TQ ? sc.nq - sc.c * TQ : TQ) + 63u) >> 6 : uint32_t(G);
 #pragma unroll
         for (int r = 0; r <= G; ++r) {
             if (r < G) {
-                hash_quad(r, hh[r & 1]);
+                if (!SHORT || uint32_t(r) < rows) hash_quad(r, hh[r & 1]);
                 // the quad is consumed: reload its registers with the same quad of the task two steps
                 // ahead at once, so that the wave keeps close to 16 KiB of loads in flight
                 buf[r] = load_quad(ld, r);
+                if (!SHORT || uint32_t(r) < rows) {
 #pragma unroll
-                for (int w = 0; w < 4; ++w) bb[r & 1][w] = anchor_bucket(hh[r & 1][w]);
+                    for (int w = 0; w < 4; ++w) bb[r & 1][w] = anchor_bucket(hh[r & 1][w]);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (r > 0) {
+            if (r > 0 && (!SHORT || uint32_t(r - 1) < rows)) {
                 const u32x2 *b4 = bb[(r - 1) & 1];
                 const uint32_t *h4 = hh[(r - 1) & 1];
                 uint32_t zz = 0xFFFFFFFFu;
@@ -2464,8 +2470,7 @@ static hipError_t launch_lds_m(const DevAutomaton &A, const BatchArgs &B, uint64
     return launch_lds_t<E, MODE, 1, 8>(A, B, max_items, lds, st);
 }
 
-template <typename E, int MODE>
-static hipError_t launch_anchor_m(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, hipStream_t st) {
+static hipError_t launch_anchor(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, hipStream_t st) {
     const uint64_t per_block = uint64_t(kLdsThreads / 64u) * B.wave_items;
     const uint64_t want = (max_items + per_block - 1) / per_block;
     const uint32_t blocks = B.persistent ? uint32_t(std::min<uint64_t>(want, uint64_t(num_cus()))) : uint32_t(want);
@@ -2478,27 +2483,27 @@ static hipError_t launch_anchor_m(const DevAutomaton &A, const BatchArgs &B, uin
         return hipGetLastError();
     };
     if (A.anchor_mode == 2) {
-        if (A.anchor_q == 4) return go(k_scan_anchor<E, MODE, 1, true>);
-        if (A.anchor_q == 8) return go(k_scan_anchor<E, MODE, 2, true>);
-        if (A.anchor_q == 12) return go(k_scan_anchor<E, MODE, 3, true>);
-        return go(k_scan_anchor<E, MODE, 4, true>);
+        if (A.anchor_q == 4) return go(k_scan_anchor<1, true, false>);
+        if (A.anchor_q == 8) return go(k_scan_anchor<2, true, false>);
+        if (A.anchor_q == 12) return go(k_scan_anchor<3, true, false>);
+        return go(k_scan_anchor<4, true, false>);
     }
-    if (A.anchor_q == 4) return go(k_scan_anchor<E, MODE, 1, false>);
-    if (A.anchor_q == 8) return go(k_scan_anchor<E, MODE, 2, false>);
-    if (A.anchor_q == 12) return go(k_scan_anchor<E, MODE, 3, false>);
-    return go(k_scan_anchor<E, MODE, 4, false>);
+    if (B.short_items) {
+        if (A.anchor_q == 4) return go(k_scan_anchor<1, false, true>);
+        if (A.anchor_q == 8) return go(k_scan_anchor<2, false, true>);
+        if (A.anchor_q == 12) return go(k_scan_anchor<3, false, true>);
+        return go(k_scan_anchor<4, false, true>);
+    }
+    if (A.anchor_q == 4) return go(k_scan_anchor<1, false, false>);
+    if (A.anchor_q == 8) return go(k_scan_anchor<2, false, false>);
+    if (A.anchor_q == 12) return go(k_scan_anchor<3, false, false>);
+    return go(k_scan_anchor<4, false, false>);
 }
 
 hipError_t launch_scan(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes,
                        int kernel, int class_mode, int ilp, int group_quads, hipStream_t st) {
     if (max_items == 0) return hipSuccess;
-    if (kernel == 2 && A.anchor_q != 0) {
-        if (entry_bytes == 2)
-            return class_mode == 1 ? launch_anchor_m<uint16_t, 1>(A, B, max_items, st)
-                                   : launch_anchor_m<uint16_t, 0>(A, B, max_items, st);
-        return class_mode == 1 ? launch_anchor_m<uint32_t, 1>(A, B, max_items, st)
-                               : launch_anchor_m<uint32_t, 0>(A, B, max_items, st);
-    }
+    if (kernel == 2 && A.anchor_q != 0) return launch_anchor(A, B, max_items, st);
     if (kernel == 0) {
         const uint32_t blocks = uint32_t((max_items + 255) / 256);
         if (entry_bytes == 2) hipLaunchKernelGGL(k_scan_simple<uint16_t>, dim3(blocks), dim3(256), 0, st, A, B);
