@@ -188,7 +188,7 @@ int fail_hip(acmi_handle *h, hipError_t e, const char *what) {
     } while (0)
 
 constexpr uint64_t kAutoMinBytes = 1ull << 20;
-constexpr uint64_t kSmallItemBytes = 3072;  // automatic mode: average haystack size under which the anchor kernel is not used
+constexpr uint64_t kSmallItemBytes = 1024;  // automatic mode: average haystack size under which the anchor kernel is not used
 
 // Synchronous upload of a host array: a plain pageable hipMemcpy (20-55 GB/s on the MI355X box, tools/micro/upload_cost.hip).
 // The FIRST copy of a process takes ~ 30 ms more, and ~ 140 ms in a process that has libacmi.so's code object to load:
@@ -533,12 +533,13 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     }
     int kernel = h->kernel == 3 ? ((fa.anchor_q && !h->anchor_off) ? 2 : 1)
                                 : ((h->kernel == 2 && !fa.anchor_q) ? 1 : h->kernel);
-    // Small haystacks: the anchor kernel gives a wave one work item per 8-KiB step whatever the item's size, so its
-    // rate falls with the item size (headline patterns over 4 GiB: 5.4 TB/s at 8 KiB, 3.8 at 4 KiB, 2.1 at 2 KiB, 1.1 at
-    // 1 KiB, 0.6 at 512 B), while the LDS-tile walk gives every LANE its own items (3.3 / 2.9 / 2.3 / 1.7 TB/s).  Under
-    // 3 KiB per haystack on average automatic mode takes the tile walk -- unless the automaton's estimate or an earlier
-    // batch says its optimistic pass does not work on this handle's data (exact_only).  (Batches under 1 MiB are
-    // launch-bound either way and keep the kernel the pattern set asks for.)
+    // Small haystacks: the anchor kernel gives a wave one work item per step whatever the item's size (its short-item
+    // variant skips the 1-KiB rows an item lacks, not the step), so its rate falls with the item size -- headline patterns
+    // over 4 GiB: 5.4 TB/s at 8 KiB, 4.65 at 4 KiB, 3.5 at 2 KiB, 2.2 at 1 KiB, 1.2 at 512 B -- while the LDS-tile walk
+    // gives every LANE its own items (3.3 / 2.9 / 2.3 / 1.7 TB/s at 4 KiB / 2 KiB / 1 KiB / 512 B).  Under 1 KiB per
+    // haystack on average automatic mode takes the tile walk -- unless the automaton's estimate or an earlier batch says
+    // its optimistic pass does not work on this handle's data (exact_only).  (Batches under 1 MiB are launch-bound
+    // either way and keep the kernel the pattern set asks for.)
     if (h->kernel == 3 && kernel == 2 && !h->exact_only && blob_bytes >= kAutoMinBytes && blob_bytes / nh < kSmallItemBytes) kernel = 1;
     if (h->kernel == 3 && kernel == 1 && h->exact_only) kernel = 4;
     F.kernel_used = kernel;

@@ -522,8 +522,8 @@ def test_two_batches_in_flight(kernel):
 
 
 def test_automatic_choice_small_haystacks():
-    """Automatic mode takes the LDS-tile walk instead of the anchor filter when haystacks average under 3 KiB (the anchor
-    kernel spends an 8-KiB wave step per work item): same records, other kernel; big haystacks keep the filter."""
+    """Automatic mode takes the LDS-tile walk instead of the anchor filter when haystacks average under 1 KiB (the anchor
+    kernel spends a wave step per work item): same records, other kernel; big haystacks keep the filter."""
     import torch
     from php_aho_corasick_amd import batch
     ds = synth.generate("SH", 5, 256, 16, 16, 4096, 512, b"abcdef")        # 2 MiB of 512-byte haystacks
