@@ -60,7 +60,7 @@ struct BatchArgs {
     uint32_t n_haystacks;
     uint32_t chunk_bytes;        // reporting bytes per work item
     uint32_t warm_bytes;         // max_pattern_length - 1
-    uint32_t short_items;        // anchor kernel: haystacks average under 6 KiB -- the variant that skips the rows a task lacks
+    uint32_t short_items;        // anchor kernel: not every task is full -- the variant that skips the rows a task lacks
     uint32_t align_warm;         // 1: k_items lengthens the warm-up of a chunk that does not start its haystack so that
                                  // the scan begins on a 128-byte boundary (anchor kernel: no unaligned head to flag, whole lines per wave-load)
     uint32_t slab_events;        // K: event slots per work item

@@ -43,7 +43,9 @@ namespace acmi {
 struct ItemDesc {
     uint64_t begin;   // blob offset of the first byte this item REPORTS on
     uint32_t len;     // bytes it reports on
-    uint32_t warm;    // bytes before `begin` (same haystack) consumed silently from the root
+    uint32_t warm;    // bytes before `begin` consumed silently from the root: the same haystack's, except the first ...
+    uint32_t floor;   // ... `floor` of them (anchor path, haystacks that start unaligned: the scan begins on the 16-byte
+                      // boundary below the haystack, in ANOTHER haystack's bytes -- hashed, never part of an occurrence)
     uint32_t pos0;    // begin - haystack begin
     uint32_t hay;
 };
@@ -61,6 +63,7 @@ __device__ __forceinline__ bool decode_item(const BatchArgs &B, uint64_t i, Item
     const uint64_t rest = he - it.begin;
     it.len = rest < B.chunk_bytes ? uint32_t(rest) : B.chunk_bytes;
     it.warm = p0 < B.warm_bytes ? uint32_t(p0) : B.warm_bytes;
+    it.floor = 0;
     return true;
 }
 
@@ -95,6 +98,7 @@ __device__ __forceinline__ bool decode_item_uniform(const BatchArgs &B, uint64_t
     const uint64_t rest = he - it.begin;
     it.len = rest < B.chunk_bytes ? uint32_t(rest) : B.chunk_bytes;
     it.warm = p0 < B.warm_bytes ? uint32_t(p0) : B.warm_bytes;
+    it.floor = 0;
     return true;
 }
 
@@ -104,10 +108,11 @@ __device__ __forceinline__ bool decode_item_uniform(const BatchArgs &B, uint64_t
 // y[31:16]: warm (<= 1023); z: scanned bytes (warm + len, >= 1); w: pos0.
 __device__ __forceinline__ uint4 pack_item(const ItemDesc &it) {
     const uint64_t off = it.begin - it.warm;
-    return make_uint4(uint32_t(off), uint32_t(off >> 32) | (it.warm << 16), it.warm + it.len, it.pos0);
+    return make_uint4(uint32_t(off), uint32_t(off >> 32) | ((it.warm | it.floor << 12) << 16), it.warm + it.len, it.pos0);  // warm < 2^12
 }
 __device__ __forceinline__ void unpack_item(uint32_t x, uint32_t y, uint32_t z, uint32_t w, ItemDesc &it) {
-    it.warm = y >> 16;
+    it.warm = (y >> 16) & 0xFFFu;
+    it.floor = y >> 28;
     it.begin = (uint64_t(y & 0xFFFFu) << 32 | x) + it.warm;
     it.len = z - it.warm;
     it.pos0 = w;
@@ -308,13 +313,23 @@ __device__ __forceinline__ void fill_item(const BatchArgs &B, uint64_t h, uint64
     const uint64_t rest = he - it.begin;
     it.len = rest < B.chunk_bytes ? uint32_t(rest) : B.chunk_bytes;
     it.warm = p0 < B.warm_bytes ? uint32_t(p0) : B.warm_bytes;
-    if (B.align_warm && p0 > it.warm) {
-        // a chunk inside its haystack: the bytes in front of its warm-up are the same haystack's, so the scan may as
-        // well begin on the aligned boundary below -- the anchor kernel then has no unaligned head to flag wholesale
-        // (such heads, walked from the root by k_walk_runs, were 0.3 ms per 4 GiB of 24-KiB haystacks)
-        // (a whole 128-byte line below, in fact: wave-loads that straddle lines cost the anchor kernel a quarter of its rate)
-        const uint64_t extra = (reinterpret_cast<uintptr_t>(B.blob) + it.begin - it.warm) & 127u;
-        it.warm += uint32_t(extra < p0 - it.warm ? extra : p0 - it.warm);
+    it.floor = 0;
+    if (B.align_warm) {
+        // Anchor kernel: the scan begins on an aligned address, so that there is no unaligned head to flag wholesale and
+        // walk from the root (0.3-0.4 ms per 4 GiB of unaligned items).  A chunk inside its haystack has the haystack's own
+        // bytes in front of its warm-up: it takes them up to the 128-byte line below (whole lines per wave-load).  Where the
+        // haystack itself begins unaligned the bytes below are ANOTHER haystack's (or none of the blob's: the aligned
+        // 16-byte block of a valid byte is in that byte's page): they are hashed, and `floor` keeps them out of matches.
+        uint64_t avail = p0 - it.warm;
+        const uintptr_t base = reinterpret_cast<uintptr_t>(B.blob);
+        const uint64_t extra = (base + it.begin - it.warm) & 127u;
+        const uint64_t e = extra < avail ? extra : avail;
+        it.warm += uint32_t(e);
+        const uint32_t mis = uint32_t((base + it.begin - it.warm) & 15u);  // non-zero only when the haystack's start was reached
+        if (it.begin >= uint64_t(it.warm) + mis) {  // (not below the blob's own first byte: that item keeps an unaligned head)
+            it.floor = mis;
+            it.warm += mis;
+        }
     }
     B.item_hay[g] = uint32_t(h);
     B.item_rec[g] = pack_item(it);
@@ -784,9 +799,9 @@ constexpr uint32_t kClusterMax = 6;   // occurrences a cluster of candidate wind
 
 // Appends the occurrences anchored at window w to v[0 .. nv) (kept in registers: the index is lane-divergent, hence the
 // select chain).  False when the window cannot be decided here.
-__device__ __forceinline__ bool verify_candidate(const DevAutomaton &A, const uint8_t *p, uint32_t n, uint32_t w,
+__device__ __forceinline__ bool verify_candidate(const DevAutomaton &A, const uint8_t *p, uint32_t n, uint32_t floor, uint32_t w,
                                                  Verified (&v)[kClusterMax], uint32_t &nv) {
-    if (w + A.anchor_q > n) return false;
+    if (w + A.anchor_q > n) return true;   // the window reaches past the item's end: no pattern anchored there fits
     // the window's hash (automaton.hpp anchor_hash; the window lies inside the item: the filter tested it)
     const uint32_t nw = A.anchor_q >> 2;
     uint32_t h = anchor_fold_dev(load4u(p + w));
@@ -825,7 +840,7 @@ __device__ __forceinline__ bool verify_candidate(const DevAutomaton &A, const ui
     for (uint32_t k = 0; k < count; ++k) {
         const uint4 rec = A.anchor_pairs[first + k];
         const uint32_t o = rec.y & 0xffu, len = rec.y >> 8;
-        if (w < o || w - o + len > n) continue;  // would begin before / end after this item's bytes: no occurrence here
+        if (w < o + floor || w - o + len > n) continue;  // would begin before / end after this item's bytes: no occurrence here
         const uint8_t *tp = p + (w - o), *pp = A.pattern_bytes + rec.z;
         const uint32_t oc = A.out_count[rec.w];
         uint32_t diff = 0;
@@ -874,7 +889,7 @@ __device__ __forceinline__ uint32_t run_epilogue_fast(const DevAutomaton &A, con
     uint32_t walked = 0;
     if (nr > B.run_cap) {
         walked = n;
-        exact_range<E, MODE, EXTRA>(A, B, nullptr, tile, tile_rows, item, p, 0, n, it.warm, pos_bias, 0u, ev);
+        exact_range<E, MODE, EXTRA>(A, B, nullptr, tile, tile_rows, item, p, it.floor, n, it.warm, pos_bias, 0u, ev);
     } else {
         const uint4 *runs = B.runs + item;
         uint32_t r = 0;
@@ -888,7 +903,7 @@ __device__ __forceinline__ uint32_t run_epilogue_fast(const DevAutomaton &A, con
             Verified v[kClusterMax];
 #pragma unroll
             for (uint32_t i = 0; i < kClusterMax; ++i) v[i] = Verified{0xFFFFFFFFu, 0u, 0u};
-            if (windows) windows = verify_candidate(A, p, n, first.z & ~kEntryWindow, v, nv);
+            if (windows) windows = verify_candidate(A, p, n, it.floor, first.z & ~kEntryWindow, v, nv);
 #pragma unroll 1
             for (;;) {
                 ++r;
@@ -897,7 +912,7 @@ __device__ __forceinline__ uint32_t run_epilogue_fast(const DevAutomaton &A, con
                 if (run.x != hi) break;  // not adjacent: the next cluster
                 hi = run.y;
                 windows = windows && entry_is_window(run.z);
-                if (windows) windows = verify_candidate(A, p, n, run.z & ~kEntryWindow, v, nv);
+                if (windows) windows = verify_candidate(A, p, n, it.floor, run.z & ~kEntryWindow, v, nv);
                 ++count;
             }
             const uint32_t lo = first.x;
@@ -942,6 +957,7 @@ __device__ __forceinline__ uint32_t run_epilogue_fast(const DevAutomaton &A, con
             } else {
                 from = lo > B.warm_bytes ? lo - B.warm_bytes : 0u;
             }
+            if (from < it.floor) from = it.floor;  // (the bytes below are another haystack's)
             walk_fast<E, MODE, EXTRA>(A, B, tile, tile_rows, item, p, from, hi, n, rep_from, pos_bias, st, ev, stop_from);
             atomicAdd(&B.counters[7], (hi - from + 15u) >> 4);  // statistic: bytes walked because verification could not decide
         }
@@ -1209,7 +1225,10 @@ __device__ __forceinline__ void anchor_open(const DevAutomaton &A, const BatchAr
     cur.n = z;
     const uint32_t mis = uint32_t(-reinterpret_cast<uintptr_t>(p)) & 15u;
     cur.head = mis < cur.n ? mis : cur.n;
-    cur.nq = (cur.n - cur.head) >> 4;
+    // whole quads after the head; with aligned items (align_warm) also the last, partial one: its windows are tested like
+    // any other (the bytes behind the item's end are another haystack's, or the rest of the blob's last aligned block),
+    // what they yield past the end is clipped or rejected, and there is no tail left to flag wholesale
+    cur.nq = (cur.n - cur.head + (B.align_warm && cur.head == 0u ? 15u : 0u)) >> 4;
     if (cur.nq) cur.qp = reinterpret_cast<const uint4 *>(p + cur.head);
     cur.chunks = cur.nq ? (cur.nq + TQ - 1u) / TQ : 1u;
 }

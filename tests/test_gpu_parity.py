@@ -542,3 +542,47 @@ def test_automatic_choice_small_haystacks():
         assert np.array_equal(p, pe) and np.array_equal(r, re_)
     api.ahocorasick_deinit(res)
     o.close()
+
+
+@pytest.mark.parametrize("short_rows", [0, 1])
+@pytest.mark.parametrize("plen", [7, 11, 16, 24])
+def test_anchor_occurrences_at_and_across_haystack_borders(plen, short_rows):
+    """The anchor path scans from the aligned address BELOW an unaligned haystack (bytes of the haystack before it) and
+    through the aligned block behind its end: a pattern that straddles two haystacks must not be reported, one that
+    begins with a haystack's first byte or ends with its last must be."""
+    rng = np.random.default_rng(plen)
+    pats = [bytes(rng.integers(97, 103, plen, dtype=np.uint8)) for _ in range(40)]
+    hays = []
+    for k in range(300):
+        n = int(rng.integers(0, 700))
+        body = bytearray(rng.integers(97, 103, n, dtype=np.uint8).tobytes())
+        p = pats[k % len(pats)]
+        mode = k % 6
+        if mode == 0 and n >= plen:
+            body[:plen] = p                      # begins with the haystack
+        elif mode == 1 and n >= plen:
+            body[n - plen:] = p                  # ends with the haystack
+        elif mode == 2 and n >= plen // 2:
+            body[n - plen // 2:] = p[:plen // 2]  # first half at the end: the next haystack gets the rest
+        if hays and (k - 1) % 6 == 2 and n >= plen - plen // 2:
+            q = pats[(k - 1) % len(pats)]
+            body[:plen - plen // 2] = q[plen // 2:]
+        hays.append(bytes(body))
+    blob = np.frombuffer(b"".join(hays), dtype=np.uint8).copy()
+    off = np.zeros(len(hays) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(h) for h in hays])
+    pat_blob, pat_off = synth.pack(pats)
+    ds = synth.Dataset("borders", pat_blob, pat_off, blob, off)
+    o = Oracle("port")
+    o.add_patterns((pat_blob, pat_off))
+    res = resource_for(ds, kernel=2, short_rows=short_rows)
+    api.ahocorasick_finalize(res)
+    assert int(res.stat("anchor_q")) > 0
+    for find_all in (True, False):
+        pe, re_ = o.match_batch(blob, off, find_all)
+        assert len(re_) > 50
+        for path in (host_match, device_match):
+            p, r = path(res, ds, find_all)
+            assert np.array_equal(p, pe) and np.array_equal(r, re_), (find_all, path.__name__)
+    api.ahocorasick_deinit(res)
+    o.close()
