@@ -40,6 +40,7 @@ struct DevAutomaton {
     uint32_t lds_image_bytes;    // bytes to stage into LDS (class offsets + tile)
     uint32_t tile_offset;        // byte offset of the tile inside the LDS image (0 or 512)
     uint32_t swar_shift, swar_expect_lo, swar_expect_hi, swar_other_off;  // other column * entry_bytes
+    uint32_t other_byte;         // a byte value no pattern uses (its column leads every state to the root), 0x100: there is none
     // anchor filter (k_scan_anchor): 2^14 buckets x 4 x uint16 fingerprints, see automaton.hpp
     const void *anchor_table;    // mode 1: 128 KiB staged into LDS; mode 2: 2^bucket_bits x 8 x uint16, read through L2
     const uint32_t *anchor_bitmap;  // mode 2: 2^20 bits staged into LDS
@@ -61,8 +62,9 @@ struct BatchArgs {
     uint32_t chunk_bytes;        // reporting bytes per work item
     uint32_t warm_bytes;         // max_pattern_length - 1
     uint32_t short_items;        // anchor kernel: not every task is full -- the variant that skips the rows a task lacks
-    uint32_t align_warm;         // 1: k_items lengthens the warm-up of a chunk that does not start its haystack so that
-                                 // the scan begins on a 128-byte boundary (anchor kernel: no unaligned head to flag, whole lines per wave-load)
+    uint32_t align_warm;         // k_items: 1 (anchor kernel) a chunk inside its haystack lengthens its warm-up to the 128-byte line
+                                 // below, a haystack that starts unaligned is scanned from the 16-byte boundary below (ItemDesc::floor);
+                                 // 2 (LDS-tile walk) both from the 128-byte line below, the bytes under `floor` masked
     uint32_t slab_events;        // K: event slots per work item
     uint32_t first_only;         // findAll == false
     uint32_t *item_hay;          // per item: haystack index

@@ -444,6 +444,12 @@ int ensure_device(acmi_handle *h) {
     A.swar_expect_lo = fa.swar_expect_lo;
     A.swar_expect_hi = fa.swar_expect_hi;
     A.swar_other_off = fa.swar_other * fa.entry_bytes;
+    A.other_byte = 0x100u;
+    if (fa.n_used_bytes < 256) {
+        const uint32_t other_class = fa.class_mode == kClassSwar3 ? fa.swar_other : 0u;
+        for (int b = 255; b >= 0; --b)
+            if (fa.class_of_byte[b] == other_class) A.other_byte = uint32_t(b);
+    }
     h->dev_ready = true;
     // the device has everything now; the host copies (up to GiBs for a dense table) are only of interest to
     // acmi_debug_tables
@@ -589,7 +595,7 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     B.n_haystacks = uint32_t(nh);
     B.chunk_bytes = chunk;
     B.warm_bytes = fa.max_pattern_length ? fa.max_pattern_length - 1 : 0;
-    B.align_warm = kernel == 2 ? 1u : 0u;
+    B.align_warm = kernel == 2 ? 1u : (kernel == 1 && h->dA.other_byte < 0x100u ? 2u : 0u);
     // anchor kernel: the variant that skips the 1-KiB rows a task lacks costs the perfectly regular batch -- haystacks of
     // exactly k x 8 KiB on an aligned blob, every task full: the bench's shape -- 4 % (0.704 vs 0.677 ms) and gains up to 2 x
     // on everything else (short items, last chunks, the 513th quad of an 8-KiB haystack that starts unaligned)

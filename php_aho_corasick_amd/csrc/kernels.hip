@@ -108,12 +108,13 @@ __device__ __forceinline__ bool decode_item_uniform(const BatchArgs &B, uint64_t
 // y[31:16]: warm (<= 1023); z: scanned bytes (warm + len, >= 1); w: pos0.
 __device__ __forceinline__ uint4 pack_item(const ItemDesc &it) {
     const uint64_t off = it.begin - it.warm;
-    return make_uint4(uint32_t(off), uint32_t(off >> 32) | ((it.warm | it.floor << 12) << 16), it.warm + it.len, it.pos0);  // warm < 2^12
+    // y = offset bits 32..45 | warm (< 2^11) << 14 | floor (< 2^7) << 25
+    return make_uint4(uint32_t(off), (uint32_t(off >> 32) & 0x3FFFu) | it.warm << 14 | it.floor << 25, it.warm + it.len, it.pos0);
 }
 __device__ __forceinline__ void unpack_item(uint32_t x, uint32_t y, uint32_t z, uint32_t w, ItemDesc &it) {
-    it.warm = (y >> 16) & 0xFFFu;
-    it.floor = y >> 28;
-    it.begin = (uint64_t(y & 0xFFFFu) << 32 | x) + it.warm;
+    it.warm = (y >> 14) & 0x7FFu;
+    it.floor = y >> 25;
+    it.begin = (uint64_t(y & 0x3FFFu) << 32 | x) + it.warm;
     it.len = z - it.warm;
     it.pos0 = w;
     it.hay = 0;  // not carried: the scan kernels do not need it
@@ -325,7 +326,8 @@ __device__ __forceinline__ void fill_item(const BatchArgs &B, uint64_t h, uint64
         const uint64_t extra = (base + it.begin - it.warm) & 127u;
         const uint64_t e = extra < avail ? extra : avail;
         it.warm += uint32_t(e);
-        const uint32_t mis = uint32_t((base + it.begin - it.warm) & 15u);  // non-zero only when the haystack's start was reached
+        // (non-zero only when the haystack's start was reached; the tile walk, mode 2, wants whole lines here too)
+        const uint32_t mis = uint32_t((base + it.begin - it.warm) & (B.align_warm == 2u ? 127u : 15u));
         if (it.begin >= uint64_t(it.warm) + mis) {  // (not below the blob's own first byte: that item keeps an unaligned head)
             it.floor = mis;
             it.warm += mis;
@@ -652,7 +654,7 @@ __device__ __forceinline__ uint32_t run_epilogue(const DevAutomaton &A, const Ba
     uint32_t walked = 0;
     if (nr > B.run_cap) {
         walked = n;
-        exact_range<E, MODE, EXTRA>(A, B, cls_lds, tile, tile_rows, item, p, 0, n, it.warm, pos_bias, 0u, ev);
+        exact_range<E, MODE, EXTRA>(A, B, cls_lds, tile, tile_rows, item, p, it.floor, n, it.warm, pos_bias, 0u, ev);
     } else {
         const uint4 *runs = B.runs + item;
 #pragma unroll 1
@@ -663,6 +665,7 @@ __device__ __forceinline__ uint32_t run_epilogue(const DevAutomaton &A, const Ba
             walked += hi - lo;
             if (st == kEntryUnknown) {  // entry state unknown: silent warm-up from the root, Lmax-1 bytes
                 from = lo > B.warm_bytes ? lo - B.warm_bytes : 0u;
+                if (from < it.floor) from = it.floor;  // (the bytes below are another haystack's)
                 st = 0;
             }
             // warm-up and run in one loop: nothing before `lo` is reported
@@ -978,6 +981,38 @@ __device__ __forceinline__ void account_walked(const BatchArgs &B, uint32_t v) {
     if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&B.counters[7], (v + 15u) >> 4);
 }
 
+// Work item of k_scan_lds: from the item table when k_items aligned the items (the record carries the lengthened
+// warm-up and the floor), else recomputed from the offsets.
+__device__ __forceinline__ bool lds_item(const BatchArgs &B, uint64_t i, ItemDesc &it) {
+    if (B.align_warm != 2u) return decode_item(B, i, it);
+    if (i >= B.item_base[B.n_haystacks]) return false;
+    const uint4 rec = B.item_rec[i];
+    unpack_item(rec.x, rec.y, rec.z, rec.w, it);
+    it.hay = B.item_hay[i];
+    return true;
+}
+
+// The quad a stream feeds the automaton: bytes below the item's floor (quads of an aligned item that lie in front of its
+// haystack) and behind its end (last quad) replaced by A.other_byte.  hf = head | floor << 8 | valid bytes of the last
+// quad << 16; the test is two compares for every quad, the masking runs for the first and the last quads of an item only.
+__device__ __forceinline__ uint4 masked_quad(const DevAutomaton &A, const uint4 &v, uint32_t q, uint32_t hf, uint32_t last) {
+    const uint32_t floor = (hf >> 8) & 0xffu, tv = hf >> 16;
+    if (__builtin_expect((q << 4) >= floor && !(q == last && tv < 16u), 1)) return v;
+    const uint32_t other4 = A.other_byte * 0x01010101u;
+    const int lead = int(floor) - int(q << 4);                       // bytes of this quad below the floor
+    const int keep = q == last ? int(tv) : 16;                        // bytes of this quad inside the item
+    uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int l = lead - 4 * w, t = 4 * w + 4 - keep;             // leading / trailing bytes of dword w to replace
+        uint32_t m = 0;
+        if (l > 0) m |= l >= 4 ? 0xFFFFFFFFu : (1u << (8 * l)) - 1u;
+        if (t > 0) m |= t >= 4 ? 0xFFFFFFFFu : ~((1u << (8 * (4 - t))) - 1u);
+        d[w] = (d[w] & ~m) | (other4 & m);
+    }
+    return make_uint4(d[0], d[1], d[2], d[3]);
+}
+
 template <typename E, int MODE, int ILP, int G>
 __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchArgs B) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1022,7 +1057,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchA
         ItemDesc it;
         s[k] = 0; nq[k] = 0; last[k] = 0; head[k] = 0; poison[k] = 0; nrun[k] = 0; run_hi[k] = 0;
         qp[k] = static_cast<const uint4 *>(A.lds_image);  // any readable 16-byte aligned address
-        if (decode_item(B, item0 + k, it)) {
+        if (lds_item(B, item0 + k, it)) {
             const uint8_t *p = B.blob + (it.begin - it.warm);
             const uint32_t n = it.warm + it.len;
             const uint32_t mis = uint32_t(-reinterpret_cast<uintptr_t>(p)) & 15u;
@@ -1032,9 +1067,22 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchA
                 for (uint32_t j = 0; j < head[k]; ++j) s[k] = exact_step<E>(A, tile, s[k], p[j]);
                 append_run(B, item0 + k, 0, head[k], 0u, nrun[k], run_hi[k]);  // the scan range starts at the root
                 if (s[k] >= trap) { s[k] = 0; poison[k] = B.poison_quads; }
+                nq[k] = (n - head[k]) >> 4;
+                head[k] |= 16u << 16;  // (every quad is whole; the tail is a run of its own)
+            } else if (B.align_warm == 2u) {
+                // Aligned item (k_items, align_warm 2: the scan begins on a 128-byte line, so that a lane's 8-quad groups
+                // are whole lines -- unaligned, every line was fetched by two groups and ragged batches ran at half the
+                // rate).  The `floor` bytes in front of a haystack that starts unaligned are another haystack's and the
+                // bytes behind the item's end likewise: both are replaced by a byte no pattern uses before they reach
+                // the automaton (every state goes to the root on it), so the item needs neither a head walked exactly
+                // nor a tail flagged.  head[k] = 0 | floor << 8 | valid bytes of the last quad << 16.
+                nq[k] = (n + 15u) >> 4;
+                head[k] = it.floor << 8 | (((n - 1u) & 15u) + 1u) << 16;
+            } else {
+                nq[k] = n >> 4;
+                head[k] = 16u << 16;
             }
-            nq[k] = (n - head[k]) >> 4;
-            if (nq[k]) { qp[k] = reinterpret_cast<const uint4 *>(p + head[k]); last[k] = nq[k] - 1; }
+            if (nq[k]) { qp[k] = reinterpret_cast<const uint4 *>(p + (head[k] & 0xffu)); last[k] = nq[k] - 1; }
             nq_max = nq[k] > nq_max ? nq[k] : nq_max;
         }
     }
@@ -1065,7 +1113,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchA
                     uint32_t w[ILP][4], t0[ILP], t1[ILP];
 #pragma unroll
                     for (int k = 0; k < ILP; ++k) {
-                        const uint4 &cur = buf[k][r];
+                        const uint4 cur = masked_quad(A, buf[k][r], q, head[k], last[k]);
                         w[k][0] = swar_columns<E>(A, cur.x);
                         w[k][1] = swar_columns<E>(A, cur.y);
                         w[k][2] = swar_columns<E>(A, cur.z);
@@ -1081,7 +1129,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchA
                         uint32_t o[ILP][4];
 #pragma unroll
                         for (int k = 0; k < ILP; ++k) {
-                            const uint4 &cur = buf[k][r];
+                            const uint4 cur = masked_quad(A, buf[k][r], q, head[k], last[k]);
                             const uint32_t d = w == 0 ? cur.x : w == 1 ? cur.y : w == 2 ? cur.z : cur.w;
                             if (MODE == 1) {
                                 const uint32_t o4 = swar_columns<E>(A, d);
@@ -1109,8 +1157,12 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchA
                 for (int k = 0; k < ILP; ++k) {
                     if (q < nq[k]) {
                         if (m[k] >= f1 || poison[k] != 0) {
-                            const uint32_t lo = head[k] + (q << 4);
-                            append_run(B, item0 + k, lo, lo + 16u, poison[k] ? 0xFFFFFFFFu : s_in[k], nrun[k], run_hi[k]);
+                            // (clipped to the item's own bytes: below `floor` the automaton saw masked bytes and is in the root)
+                            const uint32_t fl = (head[k] >> 8) & 0xffu;
+                            uint32_t lo = (head[k] & 0xffu) + (q << 4), hi = lo + (q == last[k] ? head[k] >> 16 : 16u);
+                            uint32_t entry = poison[k] ? 0xFFFFFFFFu : s_in[k];
+                            if (lo < fl) { lo = fl; entry = poison[k] ? 0xFFFFFFFFu : 0u; }
+                            if (lo < hi) append_run(B, item0 + k, lo, hi, entry, nrun[k], run_hi[k]);
                             if (s[k] >= trap) { s[k] = 0; poison[k] = B.poison_quads; }  // lost the state: restart
                             else if (poison[k]) --poison[k];
                         }
@@ -1141,9 +1193,9 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchA
 #pragma unroll
     for (int k = 0; k < ILP; ++k) {
         ItemDesc it;
-        if (decode_item(B, item0 + k, it)) {
+        if (lds_item(B, item0 + k, it)) {
             const uint32_t n = it.warm + it.len;
-            const uint32_t tail_lo = head[k] + (nq[k] << 4);
+            const uint32_t tail_lo = (head[k] & 0xffu) + (nq[k] << 4);
             if (tail_lo < n) append_run(B, item0 + k, tail_lo, n, poison[k] ? 0xFFFFFFFFu : s[k], nrun[k], run_hi[k]);
             walked += run_epilogue<E, MODE>(A, B, MODE == 1 ? nullptr : reinterpret_cast<const uint16_t *>(smem), tile, trap,
                                             item0 + k, it, nrun[k]);
