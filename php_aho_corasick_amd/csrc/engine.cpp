@@ -465,9 +465,12 @@ uint32_t choose_chunk(const acmi_handle *h, uint64_t blob_bytes, size_t nh, int 
     }
     // enough work items to fill 256 CUs x 1024 lanes x 2 streams, but never so small that the
     // (Lmax-1)-byte warm-up of a chunk costs more than 1/8 of its work
-    const uint64_t target_items = 256ull * 1024 * 2;
+    // (the exact whole-item walk, kernel 4, has every lane slot of the chip take ONE item and no persistent mode: four rounds of
+    // smaller items (not under 1 KiB), so that an item count just above a multiple of the slots costs a quarter of the
+    // kernel, not all of it again)
+    const uint64_t target_items = 256ull * 1024 * 2 * (kernel == 4 ? 4 : 1);
     uint64_t c0 = (blob_bytes + target_items - 1) / target_items;
-    uint64_t cmin = std::max<uint64_t>(256, (uint64_t(warm) * 8 + 127) & ~uint64_t(127));
+    uint64_t cmin = std::max<uint64_t>(kernel == 4 ? 1024 : 256, (uint64_t(warm) * 8 + 127) & ~uint64_t(127));
     // the anchor kernel streams an item 8 KiB (one wave step) at a time: smaller items idle its lanes
     if (kernel == 2) {
         cmin = std::max<uint64_t>(cmin, 8192);
@@ -625,14 +628,19 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     }
     B.persistent = h->persistent >= 0 ? uint32_t(h->persistent != 0)
                                       : uint32_t(blob_bytes / chunk > 3ull * 256 * 1024 * uint64_t(h->ilp));
-    if (h->persistent < 0 && kernel == 2) {
-        // The anchor kernel's static split gives a workgroup 16 x wave_items items: fine when the workgroups are a
-        // multiple of the 256 CUs (the headline batch: 512, and 2.5 % faster than pulling batches from a counter), but
-        // 528 of them -- 1 MiB haystacks in 7,936-byte chunks -- are three rounds of which the last is almost empty
-        // (0.87 instead of 0.67 ms per 4 GiB).  Any other count: persistent workgroups.
-        const uint64_t per_group = 16ull * B.wave_items;
-        const uint64_t groups = (blob_bytes / chunk + per_group - 1) / per_group;
-        if (groups > 256 && groups % 256 != 0) B.persistent = 1u;
+    if (h->persistent < 0 && (kernel == 1 || kernel == 2)) {
+        // A static split gives a workgroup 16 x wave_items items (anchor kernel) or 1,024 x ILP (tile walk), and a CU runs
+        // one workgroup at a time: fine when the workgroups are a multiple of the 256 CUs (the headline batch: 512, and
+        // 2.5 % faster than pulling batches from a counter), but 528 of them -- 1 MiB haystacks in 7,936-byte chunks -- are
+        // three rounds of which the last is almost empty (0.87 instead of 0.67 ms per 4 GiB), and 513 -- 524,352
+        // haystacks through the tile walk -- end with ONE workgroup that lasts as long as the others (1.50 vs 1.25 ms).
+        // The item count is only known here when all haystacks have one length: any other batch, and any uneven count,
+        // gets persistent workgroups.
+        const uint64_t per_group = kernel == 2 ? 16ull * B.wave_items : 1024ull * uint64_t(std::max(1, h->ilp));
+        const uint64_t hay_len = blob_bytes / nh;
+        const uint64_t items = nh * ((hay_len + chunk - 1) / chunk);
+        const uint64_t groups = (items + per_group - 1) / per_group;
+        if (blob_bytes % nh != 0 || (groups > 256 && groups % 256 != 0)) B.persistent = 1u;
     }
 
     // item counts, their scan, the item table, zeroed per-item counters: one launch
