@@ -7,7 +7,8 @@ from php_aho_corasick_amd import api, batch, synth, _native as N
 
 nh = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 16
 opts = dict(a.split("=") for a in sys.argv[2:])
-ds = synth.g6(n_hay=4096, hay_len=4096)
+HL = int(opts.pop("hay_len", 4096))   # hay_len=4001: every haystack starts unaligned
+ds = synth.g6(n_hay=4096, hay_len=HL)
 t0 = time.time()
 res = api.ahocorasick_init([{"id": k, "value": ds.pattern(k)} for k in range(ds.n_patterns)])
 t1 = time.time()
@@ -26,7 +27,7 @@ print(f"add {t1-t0:.2f}s finalize {t2-t1:.2f}s states {int(res.stat('states'))} 
 tile = torch.from_numpy(ds.hay_blob).cuda()
 reps = max(1, nh // 4096)
 d_blob = tile.repeat(reps).contiguous()
-d_off = torch.arange(reps * 4096 + 1, dtype=torch.int64, device="cuda") * 4096
+d_off = torch.arange(reps * 4096 + 1, dtype=torch.int64, device="cuda") * HL
 batch.bind_current_stream(res)
 t0 = time.time()
 total = batch.match_device(res, d_blob, d_off)
