@@ -1695,8 +1695,8 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_runs(DevAutomaton A, Batc
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint64_t total_items = B.item_base[B.n_haystacks];
     if (uint64_t(blockIdx.x) * kWalkThreads >= total_items) return;
-    __shared__ uint32_t s_walked;
-    if (threadIdx.x == 0) s_walked = 0;
+    __shared__ uint32_t s_walked, s_done;
+    if (threadIdx.x == 0) { s_walked = 0; s_done = 0; }
     const uint64_t item = uint64_t(blockIdx.x) * kWalkThreads + threadIdx.x;
     // issue the item's own loads first: they are in flight while the tile is staged
     uint32_t nr = 0;
@@ -1729,13 +1729,22 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_runs(DevAutomaton A, Batc
         unpack_item(rec.x, rec.y, rec.z, rec.w, it);
         walked = run_epilogue_fast<E, MODE, EXTRA>(A, B, smem, tile_rows, item, it, nr);
     }
-    // statistic: bytes walked, one atomic per workgroup (8192 same-address device atomics, one per
-    // wave, took 0.1 ms on their own: they serialise at ~12 ns each)
+    // statistic: bytes walked, one device atomic per WORKGROUP (8,192 same-address device atomics took 0.1 ms on their own,
+    // and per-wave atomics spread over eight words of one line doubled this kernel's time), handed in by the workgroup's
+    // LAST wave to finish -- no barrier: a barrier made every wave of a workgroup wait for its slowest lane (a cluster that
+    // has to be WALKED takes ~ 100 us) and kept the CU from starting the next workgroup; with one such item in a thousand
+    // almost every workgroup had one (0.66 ms instead of 0.16 on such a batch; 0.39 without the barrier).
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) walked += __shfl_xor(walked, d, 64);
-    if ((threadIdx.x & 63u) == 0 && walked) atomicAdd(&s_walked, (walked + 15u) >> 4);
-    __syncthreads();
-    if (threadIdx.x == 0 && s_walked) atomicAdd(&B.counters[8u + (blockIdx.x & 7u)], s_walked);
+    if ((threadIdx.x & 63u) == 0) {
+        if (walked) atomicAdd(&s_walked, (walked + 15u) >> 4);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (atomicAdd(&s_done, 1u) == kWalkThreads / 64u - 1u) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const uint32_t total = atomicAdd(&s_walked, 0u);
+            if (total) atomicAdd(&B.counters[8u + (blockIdx.x & 7u)], total);
+        }
+    }
 }
 
 hipError_t launch_walk_runs(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,
