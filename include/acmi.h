@@ -251,11 +251,13 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *   "kernel"         0 = plain global-table walk, 1 = LDS-tile table walk, 2 = anchor q-gram
  *                    filter + exact table walk of the candidates (needs a shortest pattern
  *                    >= 7 B and a collision-free table seed exists, else falls back to 1), 3 = automatic
- *                    (default): 2 when eligible -- 1 for batches of haystacks under 1 KiB on average --
+ *                    (default): 2 when eligible -- 1 for batches of haystacks under 192 B on average --
  *                    and back to 1 for a while if a batch shows the text defeats the filter (the fast
  *                    kernel is probed again after 16, 32, ... batches); from 1 on to 4 if a batch shows
  *                    that its optimistic pass flags most bytes anyway; 4 = exact table walk of whole
  *                    work items only (keyword-like and dense-match text)                 [any time]
+ *   "tiny_rows"      kernel 2: 1 (default) batches of haystacks of <= 1 KiB on average take the variant whose
+ *                    waves pack one-row work items eight to a step, 0 never                [any time]
  *   "short_rows"     kernel 2: the variant that skips the 1-KiB rows a work item lacks: -1 (default)
  *                    unless every haystack is a multiple of 8 KiB on an aligned blob, 0 never, 1 always [any time]
  *   "walk_group"     kernel 4: 16-byte haystack blocks a lane requests back to back: 1, 4 (default: half a

@@ -62,6 +62,7 @@ struct BatchArgs {
     uint32_t chunk_bytes;        // reporting bytes per work item
     uint32_t warm_bytes;         // max_pattern_length - 1
     uint32_t short_items;        // anchor kernel: not every task is full -- the variant that skips the rows a task lacks
+    uint32_t tiny_items;         // anchor kernel: haystacks average 1 KiB or less -- the variant that packs one-row items G to a task
     uint32_t align_warm;         // k_items: 1 (anchor kernel) a chunk inside its haystack lengthens its warm-up to the 128-byte line
                                  // below, a haystack that starts unaligned is scanned from the 16-byte boundary below (ItemDesc::floor);
                                  // 2 (LDS-tile walk) both from the 128-byte line below, the bytes under `floor` masked

@@ -87,6 +87,7 @@ struct acmi_handle {
     uint8_t *pin_small = nullptr;  // pinned host memory of the small path: [summary | prefix | records | offsets | bytes]
     int wave_items = 0;   // 0 automatic, else 1..64 items per wave batch of the anchor kernel
     int persistent = -1;  // -1 automatic, 0 one workgroup per 1024 x ILP items, 1 persistent workgroups
+    int tiny_rows = 1;    // anchor kernel: 1 (default) haystacks of <= 1 KiB on average take the variant that packs one-row items
     int short_rows = -1;  // anchor kernel variant that skips the rows a task lacks: -1 automatic, 0 never, 1 always
     int walk_group = 4;   // k_walk_items: 16-byte haystack blocks a lane requests back to back (1, 4 or 8 = a whole line)
     int early_stop = 1;   // walks of anchor candidates end once no pattern begun at the hit window can be alive: 0 off,
@@ -189,7 +190,7 @@ int fail_hip(acmi_handle *h, hipError_t e, const char *what) {
     } while (0)
 
 constexpr uint64_t kAutoMinBytes = 1ull << 20;
-constexpr uint64_t kSmallItemBytes = 1024;  // automatic mode: average haystack size under which the anchor kernel is not used
+constexpr uint64_t kSmallItemBytes = 192;  // automatic mode: average haystack size under which the anchor kernel is not used
 
 // Synchronous upload of a host array: a plain pageable hipMemcpy (20-55 GB/s on the MI355X box, tools/micro/upload_cost.hip).
 // The FIRST copy of a process takes ~ 30 ms more, and ~ 140 ms in a process that has libacmi.so's code object to load:
@@ -543,13 +544,14 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     }
     int kernel = h->kernel == 3 ? ((fa.anchor_q && !h->anchor_off) ? 2 : 1)
                                 : ((h->kernel == 2 && !fa.anchor_q) ? 1 : h->kernel);
-    // Small haystacks: the anchor kernel gives a wave one work item per step whatever the item's size (its short-item
-    // variant skips the 1-KiB rows an item lacks, not the step), so its rate falls with the item size -- headline patterns
-    // over 4 GiB: 5.4 TB/s at 8 KiB, 4.65 at 4 KiB, 3.5 at 2 KiB, 2.2 at 1 KiB, 1.2 at 512 B -- while the LDS-tile walk
-    // gives every LANE its own items (3.3 / 2.9 / 2.3 / 1.7 TB/s at 4 KiB / 2 KiB / 1 KiB / 512 B).  Under 1 KiB per
-    // haystack on average automatic mode takes the tile walk -- unless the automaton's estimate or an earlier batch says
-    // its optimistic pass does not work on this handle's data (exact_only).  (Batches under 1 MiB are launch-bound
-    // either way and keep the kernel the pattern set asks for.)
+    // Small haystacks: the anchor kernel gives a wave one work item per step (its short-item variant skips the 1-KiB rows
+    // an item lacks; its tiny-item variant, from 1 KiB per haystack down, packs one-row items eight to a step), so its
+    // rate falls with the item size -- headline patterns over 4 GiB: 5.4 TB/s at 8 KiB, 4.8 at 4 KiB, 3.5 at 2 KiB, 3.95 at
+    // 1 KiB, 2.6 at 512 B, 1.44 at 256 B, 0.75 at 128 B -- while the LDS-tile walk gives every LANE its own items (2.3 /
+    // 1.75 / 1.27 / 0.84 TB/s at 1 KiB / 512 / 256 / 128 B).  Under 192 B per haystack on average automatic mode takes
+    // the tile walk -- unless the automaton's estimate or an earlier batch says its optimistic pass does not work on this
+    // handle's data (exact_only).  (Batches under 1 MiB are launch-bound either way and keep the kernel the pattern set
+    // asks for.)
     if (h->kernel == 3 && kernel == 2 && !h->exact_only && blob_bytes >= kAutoMinBytes && blob_bytes / nh < kSmallItemBytes) kernel = 1;
     if (h->kernel == 3 && kernel == 1 && h->exact_only) kernel = 4;
     F.kernel_used = kernel;
@@ -604,6 +606,7 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     // on everything else (short items, last chunks, the 513th quad of an 8-KiB haystack that starts unaligned)
     const bool regular = blob_bytes % nh == 0 && (blob_bytes / nh) % 8192 == 0 && (reinterpret_cast<uintptr_t>(d_blob) & 15u) == 0;
     B.short_items = kernel != 2 ? 0u : h->short_rows >= 0 ? uint32_t(h->short_rows) : (regular ? 0u : 1u);
+    B.tiny_items = (kernel == 2 && h->tiny_rows != 0 && blob_bytes / nh <= 1024) ? 1u : 0u;
     B.slab_events = K;
     B.first_only = find_all ? 0u : 1u;
     B.item_hay = h->d_item_hay.as<uint32_t>();
@@ -1192,6 +1195,8 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
             h->wave_items = int(value);
         } else if (k == "persistent") {
             h->persistent = value < 0 ? -1 : (value ? 1 : 0);
+        } else if (k == "tiny_rows") {
+            h->tiny_rows = value ? 1 : 0;
         } else if (k == "short_rows") {
             h->short_rows = value < 0 ? -1 : (value ? 1 : 0);
         } else if (k == "walk_group") {

@@ -1300,7 +1300,9 @@ __device__ __forceinline__ bool anchor_next(const DevAutomaton &A, const BatchAr
 // 7..10 B) needs no hand-over between quads.
 // SHORT (small-set kernel only): items may be shorter than a task -- the rows a task does not have are not hashed.
 // A variant of its own because the test, one scalar branch per row, costs the 8-KiB-item kernel its schedule.
-template <int QW, bool BIG, bool SHORT>
+// TINY: a wave whose items are all at most one row (1 KiB, aligned: haystacks of a few hundred bytes) takes them G to a task,
+// ROW r of the task = item t*G + r, instead of spending a whole step on each (512-byte haystacks: 8 x fewer steps).
+template <int QW, bool BIG, bool SHORT, bool TINY = false>
 __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, BatchArgs B) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int G = BIG ? 4 : 8;  // 16-byte quads per lane and task
@@ -1337,6 +1339,14 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     // three v_readlane and no memory access
     uint4 rec = make_uint4(0u, 0u, 0u, 0u);
     if (lane < B.wave_items && wave_first + lane < total_items) rec = B.item_rec[wave_first + lane];
+    // TINY: every item of this batch is one aligned row at most?  (wave-uniform; else the wave takes the usual path)
+    bool tiny_on = false;
+    uint32_t tcnt = 0, tscan = 0, tload = 0;  // items of the batch; task being scanned / being loaded (G items each)
+    if constexpr (TINY) {
+        const bool fits = rec.z == 0u || (((reinterpret_cast<uintptr_t>(B.blob) + rec.x) & 15u) == 0u && rec.z <= 1024u);
+        tiny_on = B.align_warm == 1u && __all(fits);
+        tcnt = uint32_t(__builtin_popcountll(__ballot(rec.z != 0u)));
+    }
     AnchorCursor ld, sc;  // load cursor runs one task ahead of the scan cursor
     anchor_open<TQ>(A, B, rec, 0, ld);
     if (!ld.valid) break;
@@ -1363,9 +1373,20 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     // (tools/micro/stream_pattern.hip) gives 4.6 TB/s when each lane reads its own 128-byte line --
     // the line is split over 8 wave-instructions of 64 different lines each -- against 6.4 TB/s coalesced.
     auto load_quad = [&](const AnchorCursor &cur, int r) -> uint4 {
-        const uint32_t last = cur.nq ? cur.nq - 1u : 0u;
-        const uint32_t qi = cur.c * TQ + uint32_t(r) * 64u + lane;
-        return stream_load(cur.qp + (qi < last ? qi : last));
+        const uint4 *base = cur.qp;
+        uint32_t last = cur.nq ? cur.nq - 1u : 0u;
+        uint32_t qi = cur.c * TQ + uint32_t(r) * 64u + lane;
+        if constexpr (TINY) {
+            if (tiny_on) {  // row r of task `tload` = item tload * G + r (a row that is not there repeats the last item)
+                uint32_t k = tload * uint32_t(G) + uint32_t(r);
+                k = k < tcnt ? k : tcnt - 1u;
+                const uint32_t x = __builtin_amdgcn_readlane(rec.x, k), y = __builtin_amdgcn_readlane(rec.y, k);
+                base = reinterpret_cast<const uint4 *>(B.blob + (uint64_t(y & 0x3FFFu) << 32 | x));
+                last = ((__builtin_amdgcn_readlane(rec.z, k) + 15u) >> 4) - 1u;
+                qi = lane;
+            }
+        }
+        return stream_load(base + (qi < last ? qi : last));  // (one load instruction either way: only the address differs)
     };
     auto load_task = [&](uint4 (&buf)[G], const AnchorCursor &cur) {
 #pragma unroll
@@ -1382,6 +1403,12 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
         }
         // hashes of the 4 windows ending in quad r
         auto hash_quad = [&](int r, uint32_t (&h4)[4]) {
+            if constexpr (TINY && QW > 1) {
+                if (tiny_on) {  // every row begins an item: nothing to the left of its quad 0
+#pragma unroll
+                    for (int i = 0; i < NC; ++i) tail[i] = 0;
+                }
+            }
             uint32_t f[4];
             f[0] = anchor_fold_dev(buf[r].x);
             f[1] = anchor_fold_dev(buf[r].y);
@@ -1461,7 +1488,10 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                 pending = true;
             };
             // quads of this task that exist (an item of 4 KiB fills half a task: the rest is skipped, wave-uniform)
-            const uint32_t task_quads = sc.nq - sc.c * TQ < TQ ? sc.nq - sc.c * TQ : TQ;
+            uint32_t task_quads = sc.nq - sc.c * TQ < TQ ? sc.nq - sc.c * TQ : TQ;
+            if constexpr (TINY) {
+                if (tiny_on) task_quads = (tcnt - tscan * uint32_t(G) < uint32_t(G) ? tcnt - tscan * uint32_t(G) : uint32_t(G)) * 64u;
+            }
             // The bitmap words of quad r+1 are requested before quad r's are tested (sched_barrier keeps hipcc from
             // sinking the reads to their use): a wave never sits on the LDS round trip of its own four reads.
             typedef __attribute__((address_space(3))) u32x2 *RingPtr;
@@ -1517,7 +1547,10 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
         uint32_t hh[2][4];
         u32x2 bb[2][4];   // the four fingerprint buckets of a quad
         // SHORT: rows of 64 quads this task has (an item of 4 KiB fills half a task); the others are only reloaded
-        const uint32_t rows = SHORT ? ((sc.nq - sc.c * TQ < TQ ? sc.nq - sc.c * TQ : TQ) + 63u) >> 6 : uint32_t(G);
+        uint32_t rows = SHORT ? ((sc.nq - sc.c * TQ < TQ ? sc.nq - sc.c * TQ : TQ) + 63u) >> 6 : uint32_t(G);
+        if constexpr (TINY) {
+            if (tiny_on) rows = tcnt - tscan * uint32_t(G) < uint32_t(G) ? tcnt - tscan * uint32_t(G) : uint32_t(G);
+        }
 #pragma unroll
         for (int r = 0; r <= G; ++r) {
             if (r < G) {
@@ -1553,7 +1586,6 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
         // Rare, wave-uniform: flag where a match anchored at a hit window can end.  A pattern whose first
         // aligned dword is the window starting at byte `start` begins in [start-3, start] and ends at byte
         // index [start + m_min - 4, start + Lmax).
-        const uint64_t cand = __ballot(zany != 0);
         auto flag = [&](uint32_t r, uint32_t l, uint32_t wmask) {
             const uint32_t qi = sc.c * TQ + r * 64u + l;
             if (qi >= sc.nq) return;
@@ -1587,6 +1619,29 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                 }
             }
         };
+        if constexpr (TINY) {
+            if (tiny_on) {  // row r is item tscan * G + r: its hits in lane order, its run count handed to its lane
+                if (__any(zany != 0)) {
+#pragma unroll
+                    for (int r = 0; r < G; ++r) {
+                        uint64_t who = __ballot(z[r] != 0);
+                        const uint32_t k = tscan * uint32_t(G) + uint32_t(r);
+                        if (who == 0 || k >= tcnt) continue;
+                        anchor_open<TQ>(A, B, rec, k, sc);
+                        nrun = 0;
+                        run_hi = 0;
+                        while (who != 0) {
+                            const uint32_t l = uint32_t(__builtin_ctzll(who));
+                            flag(0u, l, __builtin_amdgcn_readlane(z[r], l));
+                            who &= who - 1;
+                        }
+                        nrun_vec = lane == k ? nrun : nrun_vec;
+                    }
+                }
+                return;
+            }
+        }
+        const uint64_t cand = __ballot(zany != 0);
         if (__builtin_expect(cand != 0, 0)) {
             if ((cand & (cand - 1)) == 0) {
                 // one lane hit (the usual case): its eight masks go through the scalar unit
@@ -1654,6 +1709,25 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     // single buffer loaded at the end of each scan left every task's HBM latency exposed at its first quad; now the
     // loads of task t+1 are a whole scan old when it begins, and the probe loads -- whose in-order vmcnt wait also
     // drains whatever was issued before them -- come two thirds into a task at a 10 % pass rate.)
+    bool done_tiny = false;
+    if constexpr (TINY) {
+        if (tiny_on) {
+            tload = 0;
+            load_task(buf0, ld);
+            tload = 1;
+            load_task(buf1, ld);
+            for (;;) {
+                tload = tscan + 2u;
+                scan_task(buf0);
+                if (++tscan * uint32_t(G) >= tcnt) break;
+                tload = tscan + 2u;
+                scan_task(buf1);
+                if (++tscan * uint32_t(G) >= tcnt) break;
+            }
+            done_tiny = true;
+        }
+    }
+    if (!done_tiny) {
     load_task(buf0, ld);
     anchor_next<TQ>(A, B, rec, ld);
     load_task(buf1, ld);
@@ -1664,6 +1738,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
         anchor_next<TQ>(A, B, rec, ld);
         scan_task(buf1);
         if (!close_or_advance()) break;
+    }
     }
 
     // hand the run lists over to k_walk_runs (lane k: item wave_first + k)
@@ -2567,6 +2642,18 @@ static hipError_t launch_anchor(const DevAutomaton &A, const BatchArgs &B, uint6
         hipLaunchKernelGGL(fn, dim3(blocks), dim3(kLdsThreads), lds, st, A, B);
         return hipGetLastError();
     };
+    if (B.tiny_items) {  // haystacks of a few hundred bytes: the variants whose waves pack one-row items G to a task
+        if (A.anchor_mode == 2) {
+            if (A.anchor_q == 4) return go(k_scan_anchor<1, true, false, true>);
+            if (A.anchor_q == 8) return go(k_scan_anchor<2, true, false, true>);
+            if (A.anchor_q == 12) return go(k_scan_anchor<3, true, false, true>);
+            return go(k_scan_anchor<4, true, false, true>);
+        }
+        if (A.anchor_q == 4) return go(k_scan_anchor<1, false, true, true>);
+        if (A.anchor_q == 8) return go(k_scan_anchor<2, false, true, true>);
+        if (A.anchor_q == 12) return go(k_scan_anchor<3, false, true, true>);
+        return go(k_scan_anchor<4, false, true, true>);
+    }
     if (A.anchor_mode == 2) {
         if (A.anchor_q == 4) return go(k_scan_anchor<1, true, false>);
         if (A.anchor_q == 8) return go(k_scan_anchor<2, true, false>);

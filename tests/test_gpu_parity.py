@@ -522,11 +522,11 @@ def test_two_batches_in_flight(kernel):
 
 
 def test_automatic_choice_small_haystacks():
-    """Automatic mode takes the LDS-tile walk instead of the anchor filter when haystacks average under 1 KiB (the anchor
-    kernel spends a wave step per work item): same records, other kernel; big haystacks keep the filter."""
+    """Automatic mode takes the LDS-tile walk instead of the anchor filter when haystacks average under 192 B (the anchor
+    kernel spends a row of 64 lanes per work item at least): same records, other kernel; big haystacks keep the filter."""
     import torch
     from php_aho_corasick_amd import batch
-    ds = synth.generate("SH", 5, 256, 16, 16, 4096, 512, b"abcdef")        # 2 MiB of 512-byte haystacks
+    ds = synth.generate("SH", 5, 256, 16, 16, 16384, 128, b"abcdef")       # 2 MiB of 128-byte haystacks
     big = synth.generate("SB", 5, 256, 16, 16, 256, 8192, b"abcdef")       # 2 MiB of 8-KiB haystacks, same patterns
     o = Oracle("port")
     o.add_patterns((ds.pat_blob, ds.pat_off))
