@@ -313,12 +313,207 @@ def host_leg(api, synth, ds, expect_per_tile):
     return out
 
 
+
+def _sclk_mhz():
+    """Shader clock of every GPU the kernel driver exposes right now (sysfs pp_dpm_sclk: the level marked '*'), so that a
+    reader can tell which clock level a run sat on; {} when the files are not there."""
+    import glob
+    out = {}
+    for path in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+        try:
+            for line in open(path).read().splitlines():
+                if line.rstrip().endswith("*"):
+                    out[path.split("/")[4]] = int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
+        except Exception:
+            pass
+    return out
+
+
+def _stats(xs):
+    xs = [float(x) for x in xs]
+    if not xs:
+        return None
+    return {"min": round(min(xs), 4), "median": round(float(np.median(xs)), 4), "max": round(max(xs), 4), "n": len(xs)}
+
+
+class Workload:
+    """What a step scans: a pattern set and a 64-MiB-ish tile of haystacks that is replicated on the device."""
+
+    def __init__(self, name, synth, planted=True):
+        self.name = name
+        if name == "config3":
+            # BASELINE configs[2] / [3]: 65,536 patterns of 8..64 B over Sigma=256 (seed 7: the G6 automaton), 4 KiB haystacks
+            self.tile_h, self.hay_len, self.default_nh = 4096, 4096, 1 << 20
+            self.ds = synth.g6(n_hay=self.tile_h, hay_len=self.hay_len)
+            self.label = "65,536 patterns of 8..64 B (Sigma=256, seed 7: 2,269,830 states)"
+            self.shape = "BASELINE configs[2] shape (configs[3] when sharded)"
+        else:
+            self.tile_h, self.hay_len, self.default_nh = TILE_HAYSTACKS, HAY_LEN, 1 << 19
+            self.ds = synth.bench_batch(self.tile_h, self.hay_len, seed=1, planted=planted)
+            self.label = "2048 patterns x 16 B (abcdef, seed 1)"
+            self.shape = "BASELINE configs[1] shape"
+        self.planted = planted
+
+    def patterns(self):
+        return [{"id": k, "value": self.ds.pattern(k)} for k in range(self.ds.n_patterns)]
+
+    def check(self, prefix, rec, nh, total):
+        """Every haystack carries its planted record; the tile's record count repeats over the replicas."""
+        reps = nh // self.tile_h
+        tile_count = int(prefix[self.tile_h])
+        ok = int(prefix[-1]) == total and total == tile_count * reps
+        if not self.planted:
+            return ok, tile_count
+        ok = ok and total >= nh
+        if self.name == "config3":
+            ds = self.ds
+            h = np.arange(self.tile_h, dtype=np.int64)
+            pat = (1021 * h + 17) % ds.n_patterns
+            start = (37 * h + 11) % (self.hay_len - 64)
+            plen = np.diff(ds.pat_off.astype(np.int64))[pat]
+            want = np.stack([h, start + plen, start, pat], axis=1).astype(np.uint32)
+            have = set(map(tuple, rec[:tile_count].tolist()))
+            ok = ok and all(tuple(w) in have for w in want.tolist())
+        return ok, tile_count
+
+
+def short_haystacks_leg(torch, api, batch, synth, dev):
+    """The headline pattern set over 1 GiB of SHORT haystacks (work items shorter than the anchor kernel's 8-KiB wave step):
+    256 B and 1 KiB regular, 4,001 B back to back (every start unaligned).  Which template ran is in `anchor_variant`
+    (window dwords | 8 big set | 16 short rows | 32 tiny items) and `tiny_waves`; the first 64 haystacks are checked
+    against the oracle."""
+    from oracle import pyoracle
+    out = []
+    for hl in (256, 1024, 4001):
+        n_tile = max(1, (32 << 20) // hl)
+        ds = synth.generate("L", 1, 2048, 16, 16, n_tile, hl, b"abcdef")
+        synth.plant(ds, 31, 5, hl - 16, 7, 3)
+        res = api.ahocorasick_init([{"id": k, "value": ds.pattern(k)} for k in range(ds.n_patterns)])
+        reps = max(1, (1 << 30) // (n_tile * hl))
+        nh = reps * n_tile
+        d_blob = torch.from_numpy(ds.hay_blob).to(dev).repeat(reps).contiguous()
+        d_off = torch.arange(nh + 1, dtype=torch.int64, device=dev) * hl
+        batch.bind_current_stream(res)
+        ms, scan, walk, total = _timed_calls(torch, batch, res, d_blob, d_off, calls=5, skip=2)
+        prefix, rec = batch.result_numpy(res, nh, total)
+        o = pyoracle.Oracle("port")
+        o.add_patterns((ds.pat_blob, ds.pat_off))
+        n_chk = 64
+        pe, re_ = o.match_batch(ds.hay_blob[:int(ds.hay_off[n_chk])], ds.hay_off[:n_chk + 1], True)
+        ok = np.array_equal(prefix[:n_chk + 1], pe) and np.array_equal(rec[:int(pe[-1])], re_) and total == int(prefix[n_tile]) * reps and total >= nh
+        leg = _leg_summary(f"headline patterns over {nh} haystacks x {hl} B ({nh * hl >> 20} MiB){', every start unaligned' if hl % 16 else ''}",
+                           nh * hl, nh, total, ms, scan, walk, res, ok)
+        leg.update({"haystack_bytes": hl, "anchor_variant": int(res.stat("anchor_variant")), "tiny_waves": int(res.stat("tiny_waves")),
+                    "work_item_bytes": int(res.stat("chunk_bytes"))})
+        out.append(leg)
+        api.ahocorasick_deinit(res)
+        del d_blob, d_off
+        torch.cuda.empty_cache()
+    return out
+
+
+def replace_leg(torch, api, batch, synth, dev, nh=1 << 17):
+    """multifast_replace on the device (reference src/multifast/replace.c:469-568): the headline batch shape
+    (one planted pattern per 8 KiB haystack, every pattern with a replacement text "<k>"), input and output resident in HBM:
+    acmi_replace_batch_device = the match pipeline + nominee plan + device prefix sum of the output lengths + the copy.
+    Rate = (bytes read + bytes written) per second against the 8 TB/s; the first 32 haystacks against the oracle."""
+    from oracle import pyoracle
+    ds = synth.bench_batch(TILE_HAYSTACKS, HAY_LEN, seed=1, planted=True)
+    res = api.ahocorasick_init([{"id": k, "value": ds.pattern(k)} for k in range(ds.n_patterns)])
+    o = pyoracle.Oracle("port")
+    for k in range(ds.n_patterns):
+        r = b"<%d>" % k
+        api.set_replacement(res, k, r)
+        o.set_replacement(k, r)
+    o.add_patterns((ds.pat_blob, ds.pat_off))
+    reps = nh // TILE_HAYSTACKS
+    d_blob = torch.from_numpy(ds.hay_blob).to(dev).repeat(reps).contiguous()
+    d_off = torch.arange(nh + 1, dtype=torch.int64, device=dev) * HAY_LEN
+    batch.bind_current_stream(res)
+    ms = []
+    for i in range(6):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out, off = batch.replace_device(res, d_blob, d_off, 1)
+        if i >= 2:
+            ms.append((time.perf_counter() - t0) * 1e3)
+    t = float(np.mean(ms))
+    off_h = off[:33].cpu().numpy()
+    out_h = out[:int(off_h[-1])].cpu().numpy()
+    ok = int(off[-1].item()) == out.numel()
+    for h in range(32):
+        ok = ok and out_h[int(off_h[h]):int(off_h[h + 1])].tobytes() == o.replace(ds.haystack(h), 1)
+    moved = d_blob.numel() + out.numel()
+    leg = {"workload": f"headline patterns, each with a replacement text, over {nh} haystacks x {HAY_LEN} B ({nh * HAY_LEN >> 20} MiB), "
+                       f"one replacement per haystack; input and output resident",
+           "ms_per_call": round(t, 4), "bytes_in": int(d_blob.numel()), "bytes_out": int(out.numel()),
+           "in_plus_out_GB_per_s": round(moved / t / 1e6, 1), "frac_of_hbm_peak": round(moved / t / 1e6 / HBM_PEAK_GBS, 4), "check_ok": bool(ok)}
+    api.ahocorasick_deinit(res)
+    return leg
+
+
+def _spawn(args):
+    """`python bench.py --gpus N` without a launcher: become N ranks under torch.distributed.run (one per GPU, RCCL).
+    Fewer than N GPUs is an error, not a silent single-GPU run (ACMI_BENCH_BACKEND=gloo, ranks sharing GPU 0, exists to
+    exercise this very path on a one-GPU box)."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus and os.environ.get("ACMI_BENCH_BACKEND", "nccl") == "nccl":
+        print(f"bench.py: --gpus {args.gpus} but this box has {have} GPU(s); refusing to run a smaller job under that name", file=sys.stderr)
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def _c_abi_gather_check(torch, dist, api, batch, res, rank, world, dev, d_blob, d_off, nh, expect_total):
+    """One all-gatherv of a step's match arrays through the C ABI's own communicator (acmi_comm_*: RCCL bound by
+    libacmi.so; the id travels over the process group): the library-level exchange a non-Python host would use."""
+    import ctypes as C
+    from php_aho_corasick_amd import _native as N
+    ident = torch.zeros(128, dtype=torch.uint8, device=dev if dist.get_backend() == "nccl" else "cpu")
+    if rank == 0:
+        buf = (C.c_char * 128)()
+        N.check(N.lib.acmi_comm_get_id(buf))
+        ident.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
+    dist.broadcast(ident, 0)
+    raw = (C.c_char * 128).from_buffer_copy(ident.cpu().numpy().tobytes())
+    comm = C.c_void_p()
+    N.check(N.lib.acmi_comm_create(res._h, rank, world, raw, C.byref(comm)), res._h)
+    total = batch.match_device(res, d_blob, d_off, True)
+    dp, dr, nr, nhg = C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_uint64()
+    ms = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        N.check(N.lib.acmi_comm_allgather_result(comm, res._h, nh, C.byref(dp), C.byref(dr), C.byref(nr), C.byref(nhg)), res._h)
+        ms.append((time.perf_counter() - t0) * 1e3)
+    v = C.c_double()
+    stat = {}
+    for key in ("backend_ranks", "transport", "rounds", "bytes_sent", "bytes_received"):
+        N.lib.acmi_comm_get_stat(comm, key.encode(), C.byref(v))
+        stat[key] = int(v.value)
+    ok = nr.value == expect_total * world and nhg.value == nh * world and total == expect_total
+    N.lib.acmi_comm_destroy(comm)
+    return {"ok": bool(ok), "ms": round(min(ms), 3), "records": int(nr.value), "haystacks": int(nhg.value), **stat}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--haystacks", type=int, default=1 << 19, help="haystacks per GPU (8 KiB each)")
+    ap.add_argument("--workload", choices=("headline", "config3"), default="headline",
+                    help="headline: 2048 x 16 B over 8 KiB haystacks (BASELINE configs[1], the metric's config); config3: 65,536 patterns over "
+                         "4 KiB haystacks (configs[2]; with --gpus N > 1 that is configs[3])")
+    ap.add_argument("--haystacks", type=int, default=0, help="haystacks per GPU (default: 2^19 x 8 KiB headline, 2^20 x 4 KiB config3)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak (default, what the driver's scaling runs use): --haystacks per GPU; strong: --haystacks in total, split into contiguous shards")
     ap.add_argument("--ilp", type=int, default=int(os.environ.get("ACMI_ILP", "0")))
@@ -327,11 +522,17 @@ def main():
     ap.add_argument("--no-plant", action="store_true", help="analysis only: no planted hits (the reference's own benchmark has ~0 matches)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-dense", action="store_true", help="skip the secondary BASELINE configs[4] (dense-match) measurement")
-    ap.add_argument("--no-legs", action="store_true", help="skip the other secondary legs (config 3, general path, keyword set, host-buffer entry)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the other secondary legs (config 3, general path, keyword set, host-buffer entry, ...)")
+    ap.add_argument("--legs", default="", help="comma-separated subset of the secondary legs to run (default: all)")
     ap.add_argument("--events", type=int, default=1, help="analysis: 0 = no HIP events around the scan kernel in the timed region (roofline fields are then meaningless)")
     ap.add_argument("--in-flight", type=int, default=2, help="batches begun before the oldest is ended (1 or 2)")
     ap.add_argument("--phase-times", action="store_true", help="analysis: add the host time per step phase to the JSON")
+    ap.add_argument("--no-c-abi-gather", action="store_true", help="N > 1: skip the untimed exchange through acmi_comm_* after the timed steps")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` on its own: N ranks under torch.distributed.run (the driver launches that itself for N > 1)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(_spawn(args))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -340,10 +541,11 @@ def main():
         args.gpus = world
 
     from php_aho_corasick_amd import synth
-    ds = synth.bench_batch(TILE_HAYSTACKS, HAY_LEN, seed=1, planted=not args.no_plant)
+    wl = Workload(args.workload, synth, planted=not args.no_plant)
+    ds = wl.ds
 
     cpu1 = cpu_all = None
-    if rank == 0 and args.gpus == 1 and not args.no_cpu:
+    if rank == 0 and args.gpus == 1 and not args.no_cpu and args.workload == "headline":
         cpu1, cpu_all = cpu_baseline(ds)
 
     import torch
@@ -353,7 +555,10 @@ def main():
     # one rank per GPU; ACMI_BENCH_BACKEND=gloo (+ ranks sharing a device) exists only to exercise the
     # N > 1 code path on a single-GPU box -- the driver's multi-GPU runs use nccl (= RCCL over xGMI)
     backend = os.environ.get("ACMI_BENCH_BACKEND", "nccl")
-    dev_index = local_rank % torch.cuda.device_count()
+    n_dev = torch.cuda.device_count()
+    if world > n_dev and backend == "nccl":
+        raise SystemExit(f"bench.py: {world} ranks but {n_dev} GPU(s): RCCL wants one GPU per rank")
+    dev_index = local_rank % n_dev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     gather = world > 1 or os.environ.get("ACMI_BENCH_FORCE_GATHER") == "1"  # analysis: gather path at N=1
@@ -366,10 +571,11 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    clocks_start = _sclk_mhz()
 
     # ---- automaton (replicated on every rank) ----
     t0 = time.perf_counter()
-    res = api.ahocorasick_init([{"id": k, "value": ds.pattern(k)} for k in range(ds.n_patterns)])
+    res = api.ahocorasick_init(wl.patterns())
     api.ahocorasick_finalize(res)
     build_ms = (time.perf_counter() - t0) * 1e3
     res.set_option("profile", 1 if args.events else 0)
@@ -380,17 +586,18 @@ def main():
     if args.kernel >= 0:
         res.set_option("kernel", args.kernel)
 
-    # ---- batch resident in HBM: the 64 MiB tile replicated to the requested size ----
-    per_gpu = args.haystacks // world if args.scaling == "strong" else args.haystacks
-    nh = max(TILE_HAYSTACKS, (per_gpu // TILE_HAYSTACKS) * TILE_HAYSTACKS)
-    reps = nh // TILE_HAYSTACKS
+    # ---- batch resident in HBM: the tile replicated to the requested size ----
+    want = args.haystacks or wl.default_nh
+    per_gpu = want // world if args.scaling == "strong" else want
+    nh = max(wl.tile_h, (per_gpu // wl.tile_h) * wl.tile_h)
+    reps = nh // wl.tile_h
     tile = torch.from_numpy(ds.hay_blob).to(dev)
     d_blob = tile.repeat(reps).contiguous()
-    d_off = torch.arange(nh + 1, dtype=torch.int64, device=dev) * HAY_LEN
+    d_off = torch.arange(nh + 1, dtype=torch.int64, device=dev) * wl.hay_len
     del tile
     batch.bind_current_stream(res)
     hay_base = rank * nh
-    bytes_per_step = nh * HAY_LEN
+    bytes_per_step = nh * wl.hay_len
 
     # what a plain streaming read of the same buffer reaches on this chip (context for the roofline)
     import ctypes as C
@@ -403,6 +610,7 @@ def main():
     pending = []
     scan_ms = []
     walk_ms = []
+    end_stamps = []
     records_per_step = 0
 
     phase = {"begin": 0.0, "gather": 0.0, "end": 0.0}   # host seconds, --phase-times
@@ -422,6 +630,7 @@ def main():
         t_a = time.perf_counter()
         total = batch.match_device_end(res)
         t_b = time.perf_counter()
+        end_stamps.append(t_b)
         records_per_step = total
         scan_ms.append(res.stat("scan_ms"))
         if gather:
@@ -457,6 +666,7 @@ def main():
     drain()
     scan_ms.clear()
     walk_ms.clear()
+    end_stamps.clear()
     for k_ in phase:
         phase[k_] = 0.0
     if gather:
@@ -470,9 +680,15 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    ranks_in_collective = 1
     if gather:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        one = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(one)                          # how many ranks the backend's collective really joined
+        ranks_in_collective = int(one.item())
     dt = float(t.item())
+    clocks_end = _sclk_mhz()
+    step_gaps = [(b - a) * 1e3 for a, b in zip(end_stamps[:-1], end_stamps[1:])]   # host time between consecutive ends
 
     # the same steps one at a time (begin, end, begin, ...): what a caller that cannot keep two batches in flight sees
     n_sync = min(args.steps, 20)
@@ -495,11 +711,31 @@ def main():
 
     # sanity: every haystack carries its planted record; the tile's count repeats
     prefix, rec = batch.result_numpy(res, nh, records_per_step)
-    ok = (args.no_plant or records_per_step >= nh) and int(prefix[-1]) == records_per_step
-    tile_count = int(prefix[TILE_HAYSTACKS])
-    ok = ok and records_per_step == tile_count * reps
+    ok, tile_count = wl.check(prefix, rec, nh, records_per_step)
+    gathered_records = gathered_haystacks = None
     if gathered is not None:
-        ok = ok and int(gathered[0][-1].item()) == gathered[1].shape[0]
+        gathered_records, gathered_haystacks = int(gathered[1].shape[0]), int(gathered[0].shape[0]) - 1
+        # the gathered GLOBAL arrays: every rank's shard in rank order (weak scaling: the same shard `world` times)
+        ok = ok and int(gathered[0][-1].item()) == gathered_records == records_per_step * world and gathered_haystacks == nh * world
+        ok = ok and bool((gathered[0][::nh][:world + 1].cpu() == torch.arange(world + 1) * records_per_step).all())
+
+    # N > 1: one more exchange of the same step's result, untimed, through the C ABI's own communicator (acmi_comm_*)
+    c_abi = None
+    if world > 1 and backend == "nccl" and not args.no_c_abi_gather:
+        import threading
+        done = threading.Event()
+
+        def watchdog():  # a stuck collective must not take the measured line with it
+            if not done.wait(120):
+                if rank == 0:
+                    print(json.dumps({"error": "acmi_comm_allgather_result did not return within 120 s", "n_gpus": world}), file=sys.stderr, flush=True)
+                os._exit(3)
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            c_abi = _c_abi_gather_check(torch, dist, api, batch, res, rank, world, dev, d_blob, d_off, nh, records_per_step)
+        except Exception as e:  # reported, not fatal: the timed figure stands on the torch.distributed exchange
+            c_abi = {"ok": False, "error": str(e)[:300]}
+        done.set()
 
     if rank == 0:
         kernel_ms = float(np.mean(scan_ms)) if scan_ms else float("nan")
@@ -510,7 +746,7 @@ def main():
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.workload == "headline":
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
@@ -520,18 +756,24 @@ def main():
             "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"2048 patterns x 16 B (abcdef, seed 1) over {nh} haystacks x {HAY_LEN} B per GPU "
-                                   f"({bytes_per_step >> 20} MiB), one planted hit per haystack; BASELINE configs[1] shape",
-                       "patterns": ds.n_patterns, "haystacks_per_gpu": nh, "haystack_bytes": HAY_LEN,
+            "config": {"workload": f"{wl.label} over {nh} haystacks x {wl.hay_len} B per GPU "
+                                   f"({bytes_per_step >> 20} MiB), one planted hit per haystack; {wl.shape}",
+                       "patterns": ds.n_patterns, "haystacks_per_gpu": nh, "haystack_bytes": wl.hay_len,
                        "states": int(res.stat("states")), "hot_states": int(res.stat("hot_states")),
                        "lds_tile_bytes": int(res.stat("lds_image_bytes")), "work_item_bytes": int(res.stat("chunk_bytes")),
                        "ilp": args.ilp or 1, "sharding": f"{world} contiguous haystack ranges, {backend} all-gatherv of match arrays" if world > 1 else "none"},
+            "ranks": {"launched": world, "process_group": (dist.get_world_size() if gather else 1), "joined_a_collective": ranks_in_collective,
+                      "backend": backend if gather else None, "gpus_on_box": n_dev,
+                      "gathered_records": gathered_records, "gathered_haystacks": gathered_haystacks, "c_abi_exchange": c_abi,
+                      "note": "one line per N: no scaling curve is measured by a single run (the driver's SCALE run over N = 1, 2, 4, 8 computes efficiency)"},
             "matches_per_s": round(world * records_per_step * args.steps / dt, 1),
             "records_per_step_per_gpu": records_per_step, "check_ok": bool(ok),
             "automaton_build_ms": round(build_ms, 2),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": {1: "k_scan_lds", 2: "k_scan_anchor", 0: "k_scan_simple", 4: "k_walk_items"}.get(int(res.stat("kernel_used")), "?"), "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes": algo_bytes,
+                         "kernel": KERNEL_NAMES.get(int(res.stat("kernel_used")), "?"), "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes": algo_bytes,
+                         "kernel_ms_per_step": _stats(scan_ms), "host_ms_between_step_ends": _stats(step_gaps),
+                         "anchor_variant": int(res.stat("anchor_variant")),
                          "walk_kernel_ms": round(walk_kernel_ms, 4),
                          "frac_scan_plus_walk": round(algo_bytes / ((kernel_ms + walk_kernel_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "frac_whole_step": round(algo_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
@@ -539,25 +781,35 @@ def main():
                          "batches_in_flight": depth, "one_at_a_time_ms_per_step": round(sync_ms_per_step, 4),
                          "one_at_a_time_step_minus_kernels_us": round((sync_ms_per_step - kernel_ms - walk_kernel_ms) * 1e3, 1),
                          "measured_stream_read_GBs": round(stream_read_gbs, 1),
-                         "frac_of_measured_stream_read": round(achieved / stream_read_gbs, 4)},
+                         "frac_of_measured_stream_read": round(achieved / stream_read_gbs, 4),
+                         "sclk_mhz_start": clocks_start, "sclk_mhz_end": clocks_end},
             "cpu_baseline": cpu1, "cpu_baseline_all_cores": cpu_all,
         }
-        if world == 1 and not args.no_dense:
+        legs = set(x for x in args.legs.split(",") if x)
+        want_leg = lambda name: world == 1 and not args.no_legs and (not legs or name in legs)  # noqa: E731
+        if world == 1 and not args.no_dense and (not legs or "config5_dense" in legs):
             out["config5_dense"] = dense_leg(torch, api, batch, synth, dev)
-        if world == 1 and not args.no_legs:
-            # secondary figures, measured outside the timed region on the same GPU, same process
-            pats = [{"id": k, "value": ds.pattern(k)} for k in range(ds.n_patterns)]
-            out["general_path"] = general_leg(torch, api, batch, pats, d_blob, d_off, nh, records_per_step)
+        # secondary figures, measured outside the timed region on the same GPU, same process
+        if want_leg("general_path") and args.workload == "headline":
+            out["general_path"] = general_leg(torch, api, batch, wl.patterns(), d_blob, d_off, nh, records_per_step)
+        if want_leg("host_entry") and args.workload == "headline":
             out["host_entry"] = host_leg(api, synth, ds, tile_count)
-            del d_blob
-            torch.cuda.empty_cache()
+        del d_blob
+        torch.cuda.empty_cache()
+        if want_leg("short_haystacks"):
+            out["short_haystacks"] = short_haystacks_leg(torch, api, batch, synth, dev)
+        if want_leg("replace"):
+            out["replace"] = replace_leg(torch, api, batch, synth, dev)
+        if want_leg("keyword_set"):
             out["keyword_set"] = keywords_leg(torch, api, batch, synth, dev)
+        if want_leg("config3") and args.workload == "headline":
             out["config3"] = config3_leg(torch, api, batch, synth, dev)
         if args.phase_times:
             out["host_us_per_step"] = {k: round(v / args.steps * 1e6, 1) for k, v in phase.items()}
         print(json.dumps(out), flush=True)
     api.ahocorasick_deinit(res)
     if gather:
+        dist.barrier()
         dist.destroy_process_group()
 
 

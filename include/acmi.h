@@ -30,7 +30,10 @@
 extern "C" {
 #endif
 
-#define ACMI_VERSION "0.1.0"
+/* 0.3.0: acmi_tables reshuffled in 0.2 (fields inserted mid-struct) -- a consumer checks acmi_version() against the header it
+ * was compiled with; _end completes the OLDEST batch; acmi_comm_* exchange is size-proportional (acmi_comm_debug_compact is
+ * gone, acmi_comm_create_local / acmi_comm_get_stat / acmi_comm_last_error are new); acmi_replace_batch_device is new. */
+#define ACMI_VERSION "0.3.0"
 
 /* ---- status codes (negative = error; never aborts) ------------------------
  * The Zend shim maps them onto the reference's PHP-level behaviour:
@@ -208,6 +211,14 @@ int acmi_set_replacement(acmi_handle *h, uint32_t pattern_index, const uint8_t *
 int acmi_replace_batch(acmi_handle *h, const uint8_t *blob, const uint64_t *offsets, size_t n_haystacks, int mode,
                        const uint8_t **out_blob, const uint64_t **out_offsets);
 
+/* The same with input and output RESIDENT in device memory: `d_blob` / `d_offsets` as for acmi_match_batch_device; on return
+ * *d_out_blob (device) holds the *out_bytes bytes of output text and *d_out_offsets (device) the uint64[n_haystacks + 1]
+ * offsets, both owned by the handle until its next call.  One host wait for the matching, one for the whole replace pass
+ * (nominees, a device prefix sum of the output lengths, the copy cut by 32 KiB of OUTPUT per wave: one huge haystack is
+ * spread over the chip). */
+int acmi_replace_batch_device(acmi_handle *h, const void *d_blob, uint64_t blob_bytes, const void *d_offsets, size_t n_haystacks,
+                              int mode, const void **d_out_blob, const void **d_out_offsets, uint64_t *out_bytes);
+
 /* ---- multi-GPU: a batch sharded over the GPUs of one node (NEW; the reference is single-threaded) --------------
  * Haystacks are independent (keep=0, php_ahocorasick.c:745; tests/test6.phpt), so a batch is cut into contiguous
  * haystack ranges, one per rank (one process or thread per GPU, each with its own handle built from the same
@@ -222,18 +233,28 @@ typedef struct acmi_comm_id { char internal[128]; } acmi_comm_id;   /* ncclUniqu
 int acmi_comm_get_id(acmi_comm_id *id);
 /* Joins rank `rank` of `world` (<= 64) on the handle's device; world == 1 needs no id and no RCCL. */
 int acmi_comm_create(acmi_handle *h, int rank, int world, const acmi_comm_id *id, acmi_comm **out);
+/* The same communicators for ONE process that drives several handles (one per GPU, or several on one GPU) from one thread
+ * each: out[r] is rank r's, on handles[r]'s device.  No RCCL: ranks meet in process memory and copy device to device.
+ * Every acmi_comm_allgather_result is a rendezvous of all `world` threads.  (Also how the W > 1 logic is tested on a box
+ * with one GPU, where RCCL refuses several ranks per device.) */
+int acmi_comm_create_local(acmi_handle *const *handles, int world, acmi_comm **out);
 int acmi_comm_destroy(acmi_comm *c);
 /* After acmi_match_batch_device() on this rank's `n_haystacks_local` haystacks: all-gatherv of the results.  On
  * return every rank holds the GLOBAL arrays in device memory owned by the communicator (valid until its next call):
- * prefix = uint64[*n_haystacks + 1], records = acmi_record[*n_records] with hay counted over all ranks.  Two
- * collectives: 16 bytes per rank of sizes, then one payload padded to the largest shard. */
+ * prefix = uint64[*n_haystacks + 1], records = acmi_record[*n_records] with hay counted over all ranks.
+ * Collectives: 32 bytes per rank of sizes and status (the call's one host wait), then ONE group of per-rank broadcasts,
+ * each exactly its shard's size, received in place -- nothing is padded to the largest shard, staged or unpacked.  A rank
+ * that cannot take part (no result for the count it gave, out of memory) reports it in the size round, which it still
+ * joins: every rank then returns an error (ACMI_E_ARG / ACMI_E_NOMEM on the rank at fault, ACMI_E_DEVICE on its peers)
+ * instead of waiting inside a collective.  When the global arrays have to grow, a second 32-byte round confirms that every
+ * rank could allocate.  EXPERIMENTAL for world > 1 over RCCL until it has run on a multi-GPU node (the build box has one
+ * GPU); the process-local transport runs the same code on one. */
 int acmi_comm_allgather_result(acmi_comm *c, acmi_handle *h, uint64_t n_haystacks_local, const void **d_prefix,
                                const void **d_records, uint64_t *n_records, uint64_t *n_haystacks);
-/* Test aid: the unpacking half alone, on n_payloads payloads [prefix (nh_cap+1) x u64 | records] of `stride` bytes
- * laid out by the caller; sizes = n_payloads x {records, haystacks} (host). */
-int acmi_comm_debug_compact(acmi_comm *c, acmi_handle *h, int n_payloads, const void *d_payloads, uint64_t stride, uint64_t nh_cap,
-                            const uint64_t *sizes, const void **d_prefix, const void **d_records, uint64_t *n_records,
-                            uint64_t *n_haystacks);
+/* "world", "rank", "backend_ranks" (what ncclCommCount reports), "transport" (0 none, 1 RCCL, 2 process-local), and of the
+ * last exchange: "rounds" (collectives), "bytes_sent", "bytes_received", "records", "haystacks". */
+int acmi_comm_get_stat(const acmi_comm *c, const char *key, double *value);
+const char *acmi_comm_last_error(const acmi_comm *c);
 
 /* ---- pattern metadata for the shim's zval pack (php_ahocorasick.c:562-583) ---- */
 
@@ -304,12 +325,15 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value);
 
 /* Numeric facts about the automaton and the last match call, e.g. "states",
  * "hot_states", "columns", "entry_bytes", "lds_image_bytes", "table_bytes",
- * "max_pattern_length", "items", "overflow_items", "walked_bytes", "kernel_used" (0, 1, 2, 4 as the "kernel"
- * option; 5 = the one-launch small-batch path), "scan_ms", "total_ms". */
+ * "max_pattern_length", "items", "overflow_items", "walked_bytes", "fallback_bytes", "kernel_used" (0, 1, 2, 4 as the
+ * "kernel" option; 5 = the one-launch small-batch path), "anchor_variant" (the k_scan_anchor template the last batch ran:
+ * window dwords in bits 0-2 | 8 big set (LDS bitmap + L2 table) | 16 short-row variant | 32 tiny-item variant | 64 windows
+ * at every byte offset; 0 = another kernel), "tiny_waves" (wave batches that took the tiny-item path), "scan_ms",
+ * "total_ms". */
 int acmi_get_stat(const acmi_handle *h, const char *key, double *value);
 
 /* Run subsequent launches on this hipStream_t (passed as void*); NULL = the
- * handle's own stream. */
+ * handle's own stream.  ACMI_E_ARG while a begun batch has not been ended. */
 int acmi_set_stream(acmi_handle *h, void *hip_stream);
 
 /* Flat host tables of the finalized automaton, for CPU-side inspection by

@@ -18,7 +18,7 @@ _API = ("AhoException", "AhoWarning", "AhoResource", "ahocorasick_init", "ahocor
         "ahocorasick_finalize", "ahocorasick_match", "ahocorasick_match_batch", "ahocorasick_isValid",
         "ahocorasick_deinit", "match_arrays", "AhoStream")
 
-__version__ = "0.1.0"
+__version__ = "0.3.0"
 
 
 def __getattr__(name):

@@ -84,13 +84,16 @@ SYMBOLS = {
     "acmi_set_replacement": (C.c_int, [Handle, C.c_uint32, C.c_char_p, C.c_uint32]),
     "acmi_replace_batch": (C.c_int, [Handle, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.POINTER(C.c_uint8)),
                                      C.POINTER(C.POINTER(C.c_uint64))]),
+    "acmi_replace_batch_device": (C.c_int, [Handle, C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p),
+                                            C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "acmi_comm_get_id": (C.c_int, [C.c_void_p]),
     "acmi_comm_create": (C.c_int, [Handle, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "acmi_comm_destroy": (C.c_int, [C.c_void_p]),
     "acmi_comm_allgather_result": (C.c_int, [C.c_void_p, Handle, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                              C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
-    "acmi_comm_debug_compact": (C.c_int, [C.c_void_p, Handle, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.POINTER(C.c_void_p),
-                                          C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "acmi_comm_create_local": (C.c_int, [C.POINTER(Handle), C.c_int, C.POINTER(C.c_void_p)]),
+    "acmi_comm_get_stat": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]),
+    "acmi_comm_last_error": (C.c_char_p, [C.c_void_p]),
     "acmi_pattern_count": (C.c_size_t, [Handle]),
     "acmi_pattern_info": (C.c_int, [Handle, C.c_uint32, C.POINTER(Pattern)]),
     "acmi_set_option": (C.c_int, [Handle, C.c_char_p, C.c_int64]),

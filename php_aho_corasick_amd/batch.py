@@ -98,6 +98,22 @@ def result_view(res: AhoResource, total: int):
     return torch.as_tensor(_DevView(d_rec.value, (total, 4), "<i4"), device="cuda")
 
 
+def replace_device(res: AhoResource, d_blob, d_off, mode: int = 1):
+    """Search and replace over a batch resident in HBM (acmi_replace_batch_device: multifast_replace + flush,
+    reference src/multifast/replace.c:469-568).  Returns (out_blob uint8[total], out_off int64[n+1]) as CUDA tensors
+    that ALIAS the handle's buffers: valid until the next call on ``res``."""
+    import torch
+    assert d_blob.is_cuda and d_off.is_cuda and d_blob.is_contiguous() and d_off.is_contiguous()
+    nh = d_off.numel() - 1
+    d_out, d_oo, total = C.c_void_p(), C.c_void_p(), C.c_uint64(0)
+    N.check(N.lib.acmi_replace_batch_device(res._h, C.c_void_p(d_blob.data_ptr()), d_blob.numel(), C.c_void_p(d_off.data_ptr()), nh,
+                                            mode, C.byref(d_out), C.byref(d_oo), C.byref(total)), res._h)
+    off = torch.as_tensor(_DevView(d_oo.value, (nh + 1,), "<i8"), device="cuda")
+    if total.value == 0:
+        return torch.zeros(0, dtype=torch.uint8, device="cuda"), off
+    return torch.as_tensor(_DevView(d_out.value, (total.value,), "|u1"), device="cuda"), off
+
+
 class RecordGatherer:
     """All-gatherv of match arrays with ONE collective per batch and no blocking size exchange.
 

@@ -112,22 +112,15 @@ struct ReplaceArgs {
     const uint64_t *rep_off;     // per pattern: offset << 32 | length of its replacement text, ~0: none
     const uint8_t *rep_bytes;
     uint2 *plan;                 // nominees {end, pattern}, haystack h's from plan[prefix[h]]
+    uint64_t *plan_out;          // per kept nominee: where its piece (the text before it + its replacement) begins in the haystack's output
+    uint64_t *tail_out;          // per haystack: where the text behind its last nominee begins in its output
     uint32_t *nom_count;         // per haystack
     uint64_t *out_len;           // per haystack
     const uint64_t *out_off;     // per haystack (k_replace_emit)
     uint8_t *out_blob;
 };
 
-// all-gatherv unpacking (k_gather_compact); at most kMaxRanks ranks
+// multi-GPU exchange (engine.cpp acmi_comm_*): at most kMaxRanks ranks
 constexpr uint32_t kMaxRanks = 64;
-struct GatherArgs {
-    const uint8_t *recv;         // world payloads of `stride` bytes: [prefix (nh_cap+1) x u64 | records rec_cap x 16 B]
-    uint64_t stride, nh_cap;
-    uint32_t world;
-    uint64_t total_rec, total_hay;
-    uint64_t rec_base[kMaxRanks + 1], hay_base[kMaxRanks + 1];  // exclusive prefix sums over ranks
-    uint4 *out_records;
-    uint64_t *out_prefix;
-};
 
 }  // namespace acmi

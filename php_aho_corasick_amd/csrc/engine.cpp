@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -41,6 +42,20 @@ struct DevBuf {
         size_t want = bytes + bytes / 8 + 256;  // grow-only workspace with a little slack
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) { p = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    // Growth while kernels that use the old allocation may still be queued (a second batch begun while the first is in
+    // flight): the old block is parked in `retired` and freed when nothing is in flight -- hipFree synchronises the whole
+    // device, which would serialise the two batches, and the older batch's arguments keep pointing at live memory.
+    hipError_t ensure_keep(size_t bytes, std::vector<void *> &retired) {
+        if (bytes <= cap) return hipSuccess;
+        void *fresh = nullptr;
+        const size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&fresh, want);
+        if (e != hipSuccess) return e;
+        if (p) retired.push_back(p);
+        p = fresh;
         cap = want;
         return hipSuccess;
     }
@@ -111,7 +126,7 @@ struct acmi_handle {
     // workspace (grow-only)
     DevBuf d_blob, d_off, d_item_base, d_item_hay, d_item_rec, d_zero, d_rec_base, d_slab, d_ovf, d_counters,
         d_runs, d_run_count;
-    uint64_t *pinned = nullptr;  // host copy of the device counters blocks (2 x 64 B), written by k_expand through pinned_dev
+    uint64_t *pinned = nullptr;  // host copy of the device counters blocks (2 x 128 B, one per batch in flight), written by k_expand through pinned_dev
     uint32_t *pinned_dev = nullptr;
 
     // last result
@@ -121,7 +136,8 @@ struct acmi_handle {
     std::vector<acmi_record> h_records;
     std::vector<uint64_t> h_prefix;
     // search and replace
-    DevBuf d_rep_off, d_rep_bytes, d_plan, d_nom_count, d_out_len, d_rep_out_off, d_rep_out;
+    DevBuf d_rep_off, d_rep_bytes, d_plan, d_plan_out, d_tail_out, d_nom_count, d_out_len, d_rep_out_off, d_rep_out, d_rep_sync;
+    uint64_t rep_cap = 0;  // bytes of replace output the largest batch so far produced: the optimistic capacity
     bool rep_uploaded = false;
     std::vector<uint8_t> h_rep_blob;
     std::vector<uint64_t> h_rep_off;
@@ -147,6 +163,8 @@ struct acmi_handle {
         int kernel_used = 0;
         uint64_t chunk_used = 0;
         hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        hipStream_t stream = nullptr;  // the stream this batch was enqueued on (acmi_set_stream is refused while batches are in flight)
+        uint32_t anchor_variant = 0;   // template of k_scan_anchor that ran (acmi_get_stat "anchor_variant")
         DevBuf d_prefix, d_out;        // valid from this batch's end until the second begin after its own
     };
     FlySlot fly[2];
@@ -158,12 +176,15 @@ struct acmi_handle {
     DevBuf &d_out() { return fly[cur].d_out; }
     DevBuf d_sync[2];          // counters, scan tickets and status words: two copies that take turns (run_batch_begin)
     uint32_t sync_tiles = 0, sync_turn = 0;
+    std::vector<void *> retired;   // device blocks outgrown while a batch was in flight: freed when none is (DevBuf::ensure_keep)
 
     // statistics of the last call
     double scan_ms = 0, walk_ms = 0, total_ms = 0;
     int kernel_used = 0;
     uint64_t items = 0, chunk_used = 0;
     uint32_t overflow_items = 0;
+    uint32_t anchor_variant = 0;  // k_scan_anchor template of the last batch: QW (bits 0-2) | BIG 8 | SHORT 16 | TINY 32 | DENSE 64; 0: another kernel
+    uint32_t tiny_waves = 0;      // wave batches of the last call that took the TINY path (items of one row, eight to a step)
     uint64_t walked_bytes = 0;
     uint64_t fallback_bytes = 0;  // anchor path: bytes of candidate clusters that were walked because verification could not decide
 
@@ -190,6 +211,7 @@ int fail_hip(acmi_handle *h, hipError_t e, const char *what) {
     } while (0)
 
 constexpr uint64_t kAutoMinBytes = 1ull << 20;
+constexpr uint32_t kPinWords = 32;  // 32-bit words of a batch's sync block that k_expand mirrors into pinned host memory
 constexpr uint64_t kSmallItemBytes = 192;  // automatic mode: average haystack size under which the anchor kernel is not used
 
 // Synchronous upload of a host array: a plain pageable hipMemcpy (20-55 GB/s on the MI355X box, tools/micro/upload_cost.hip).
@@ -217,11 +239,26 @@ bool device_fail_and_outputs(void *ctx, const TrieView &tv, uint32_t *fail, uint
     };
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return false; }
+    // The caller's current device is put back on every way out, and the work runs on a private non-blocking stream:
+    // a host such as torch is neither serialised against its blocking streams (the NULL stream would be) nor left on
+    // another device.
+    int caller_dev = -1;
+    if (hipGetDevice(&caller_dev) != hipSuccess) { (void)hipGetLastError(); return false; }
     int dev = h->device_request;
-    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return false;
+    if (dev < 0) dev = caller_dev;
+    struct Restore {
+        int dev;
+        hipStream_t st = nullptr;
+        ~Restore() {
+            if (st) (void)hipStreamDestroy(st);
+            (void)hipSetDevice(dev);
+        }
+    } restore{caller_dev};
     if (dev >= count || hipSetDevice(dev) != hipSuccess) return false;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return false;
+    if (hipStreamCreateWithFlags(&restore.st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); restore.st = nullptr; return false; }
+    hipStream_t st = restore.st;
     lap("runtime + device");
     const size_t n = tv.n_nodes;
     DevBuf d_parent, d_byte, d_own, d_order, d_keys, d_vals, d_fail, d_cnt, d_dict, d_final;
@@ -234,15 +271,15 @@ bool device_fail_and_outputs(void *ctx, const TrieView &tv, uint32_t *fail, uint
               d_final.ensure(n) == hipSuccess;
     if (ok) {
         // the root: no failure link, no output (the level loop starts at depth 1 and reads these)
-        ok = hipMemset(d_fail.p, 0, 4) == hipSuccess && hipMemset(d_cnt.p, 0, 4) == hipSuccess &&
-             hipMemset(d_dict.p, 0xFF, 4) == hipSuccess && hipMemset(d_final.p, 0, 1) == hipSuccess;
+        ok = hipMemsetAsync(d_fail.p, 0, 4, st) == hipSuccess && hipMemsetAsync(d_cnt.p, 0, 4, st) == hipSuccess &&
+             hipMemsetAsync(d_dict.p, 0xFF, 4, st) == hipSuccess && hipMemsetAsync(d_final.p, 0, 1, st) == hipSuccess;
     }
     lap("trie upload (+ first use of the device)");
     if (ok) {
         BuildArgs T{d_parent.as<uint32_t>(), d_byte.as<uint8_t>(), d_own.as<uint32_t>(), d_order.as<uint32_t>(), d_keys.as<uint64_t>(),
                     d_vals.as<uint32_t>(), tv.map_size, d_fail.as<uint32_t>(), d_cnt.as<uint32_t>(), d_dict.as<uint32_t>(), d_final.as<uint8_t>()};
-        for (uint32_t d = 1; d < tv.n_levels; ++d) launch_build_level(T, tv.level_off[d], tv.level_off[d + 1], nullptr);
-        ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+        for (uint32_t d = 1; d < tv.n_levels; ++d) launch_build_level(T, tv.level_off[d], tv.level_off[d + 1], st);
+        ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
         lap("level kernels");
         ok = ok && hipMemcpy(fail, d_fail.p, n * 4, hipMemcpyDeviceToHost) == hipSuccess &&
              hipMemcpy(cnt, d_cnt.p, n * 4, hipMemcpyDeviceToHost) == hipSuccess &&
@@ -315,7 +352,7 @@ int ensure_device(acmi_handle *h) {
         for (auto &evt : slot.ev)
             if (!evt) HIPCHK(h, hipEventCreate(&evt));
     if (!h->pinned) {
-        HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->pinned), 128, hipHostMallocMapped));
+        HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->pinned), 2 * kPinWords * 4, hipHostMallocMapped));
         void *dp = nullptr;
         HIPCHK(h, hipHostGetDevicePointer(&dp, h->pinned, 0));
         h->pinned_dev = static_cast<uint32_t *>(dp);
@@ -502,7 +539,8 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
     // This batch takes the slot of the batch before the previous one, whose prefix array and records end here: a
     // result is valid from its batch's end until the SECOND begin after its own.
     acmi_handle::FlySlot &F = h->fly[(h->begin_seq + 1) & 1];
-    h->have_result = false;
+    // (the last completed result lives in slot `cur`: it stays readable through ONE further begin, as acmi.h says)
+    if (int(&F - h->fly) == h->cur) h->have_result = false;
     const int rc = enqueue_batch(h, F, d_blob, blob_bytes, d_off, nh, find_all);
     // a pipeline that was not enqueued to its end has not zeroed the next batch's sync block: have both zeroed again
     if (rc < 0) { h->sync_tiles = 0; return rc; }
@@ -514,6 +552,8 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
 int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob, uint64_t blob_bytes, const uint64_t *d_off,
                   size_t nh, int find_all) {
     hipStream_t st = h->stream;
+    F.stream = st;
+    F.anchor_variant = 0;
     HIPCHK(h, F.d_prefix.ensure((nh + 1) * 8));
     F.d_blob = d_blob;
     F.d_off = d_off;
@@ -525,7 +565,7 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     F.max_items = 0;
     if (h->profile > 1) HIPCHK(h, hipEventRecord(F.ev[0], st));
     const int slot_index = int(&F - h->fly);
-    uint32_t *const pinned_dev = h->pinned_dev + 16 * slot_index;
+    uint32_t *const pinned_dev = h->pinned_dev + kPinWords * slot_index;
 
     if (nh == 0 || h->aut.accepted_count() == 0) {  // empty batch / empty automaton -> no records
         HIPCHK(h, hipMemsetAsync(F.d_prefix.p, 0, (nh + 1) * 8, st));
@@ -560,19 +600,19 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     const uint32_t K = std::max<uint32_t>(1, h->slab_events);
     F.chunk_used = chunk;
 
-    HIPCHK(h, h->d_item_base.ensure((nh + 1) * 8));
-    HIPCHK(h, h->d_item_hay.ensure(max_items * 4));
-    HIPCHK(h, h->d_item_rec.ensure(max_items * 16));
+    HIPCHK(h, h->d_item_base.ensure_keep((nh + 1) * 8, h->retired));
+    HIPCHK(h, h->d_item_hay.ensure_keep(max_items * 4, h->retired));
+    HIPCHK(h, h->d_item_rec.ensure_keep(max_items * 16, h->retired));
     // per-item counters [rec_count (items+1) x 8 | ev_count items x 4]: zeroed per item by k_items
     const size_t rec_cnt_off = 0, ev_off = rec_cnt_off + (max_items + 1) * 8;
-    HIPCHK(h, h->d_zero.ensure(ev_off + max_items * 4));
+    HIPCHK(h, h->d_zero.ensure_keep(ev_off + max_items * 4, h->retired));
     // sync block of this batch: [counters 16 x u32 | tickets 2 x u32 | pad | status words of the two scans], one of
     // two copies that take turns; this batch's k_expand zeroes the other one.  (Re)allocation zeroes both.
     const uint32_t tiles = std::max(scan_tiles(nh + 1), scan_tiles(max_items + 1)) + 1u;
     if (tiles > h->sync_tiles || !h->d_sync[0].p) {
         const uint32_t want = tiles + tiles / 4 + 16;
         for (DevBuf &b : h->d_sync) {
-            HIPCHK(h, b.ensure(128 + size_t(want) * 16));
+            HIPCHK(h, b.ensure_keep(128 + size_t(want) * 16, h->retired));
             HIPCHK(h, hipMemsetAsync(b.p, 0, b.cap, st));
         }
         h->sync_tiles = want;
@@ -582,12 +622,12 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     uint32_t *sync_next = h->d_sync[(h->sync_turn + 1) & 1].as<uint32_t>();
     ++h->sync_turn;
     uint64_t *status0 = reinterpret_cast<uint64_t *>(sync_cur + 32), *status1 = status0 + h->sync_tiles;
-    HIPCHK(h, h->d_rec_base.ensure((max_items + 2) * 8));
-    HIPCHK(h, h->d_slab.ensure(max_items * K * 8));
-    HIPCHK(h, h->d_ovf.ensure(max_items * 4));
+    HIPCHK(h, h->d_rec_base.ensure_keep((max_items + 2) * 8, h->retired));
+    HIPCHK(h, h->d_slab.ensure_keep(max_items * K * 8, h->retired));
+    HIPCHK(h, h->d_ovf.ensure_keep(max_items * 4, h->retired));
     const uint32_t Q = std::max<uint32_t>(1, h->run_cap);
-    HIPCHK(h, h->d_runs.ensure(max_items * Q * 16));
-    HIPCHK(h, h->d_run_count.ensure(max_items * 4));
+    HIPCHK(h, h->d_runs.ensure_keep(max_items * Q * 16, h->retired));
+    HIPCHK(h, h->d_run_count.ensure_keep(max_items * 4, h->retired));
     uint8_t *zero = h->d_zero.as<uint8_t>();
     uint32_t *d_counters = sync_cur;
     uint64_t *d_rec_cnt = reinterpret_cast<uint64_t *>(zero + rec_cnt_off);
@@ -655,7 +695,7 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
         // pass flags everything anyway (events in every wave-quad)
         HIPCHK(h, launch_walk_items(h->dA, B, max_items, int(fa.entry_bytes), int(fa.class_mode), h->walk_group, st));
     } else {
-        HIPCHK(h, launch_scan(h->dA, B, max_items, int(fa.entry_bytes), kernel, int(fa.class_mode), h->ilp, h->group_quads, st));
+        HIPCHK(h, launch_scan(h->dA, B, max_items, int(fa.entry_bytes), kernel, int(fa.class_mode), h->ilp, h->group_quads, st, &F.anchor_variant));
     }
     if (h->profile) HIPCHK(h, hipEventRecord(F.ev[2], st));
     // the anchor kernel only flags byte runs; their exact walk is a kernel of its own (one thread per item)
@@ -690,13 +730,18 @@ int run_batch_end(acmi_handle *h) {
     acmi_handle::FlySlot &F = h->fly[(h->end_seq + 1) & 1];
     ++h->end_seq;
     const int slot_index = int(&F - h->fly);
-    const uint64_t *const pinned = h->pinned + 8 * slot_index;
+    const uint64_t *const pinned = h->pinned + (kPinWords / 2) * slot_index;
     const uint32_t *const pinned32 = reinterpret_cast<const uint32_t *>(pinned);
-    hipStream_t st = h->stream;
+    hipStream_t st = F.stream;
     {
-        // (with a second batch queued behind this one the wait is for this batch's last kernel only)
-        const hipError_t e = h->begin_seq != h->end_seq ? hipEventSynchronize(F.ev[4]) : hipStreamSynchronize(st);
-        if (e != hipSuccess) { h->sync_tiles = 0; h->end_seq = h->begin_seq; return fail_hip(h, e, "hipStreamSynchronize"); }
+        // the wait is for THIS batch's last kernel (its own event, on the stream it was enqueued on), not for whatever
+        // else the stream holds -- a second batch queued behind it, the caller's own work
+        const hipError_t e = hipEventSynchronize(F.ev[4]);
+        if (e != hipSuccess) { h->sync_tiles = 0; h->end_seq = h->begin_seq; return fail_hip(h, e, "hipEventSynchronize"); }
+    }
+    if (h->begin_seq == h->end_seq && !h->retired.empty()) {  // nothing in flight: blocks outgrown meanwhile can go
+        for (void *q : h->retired) (void)hipFree(q);
+        h->retired.clear();
     }
     h->cur = slot_index;
     h->last_nh = uint32_t(F.nh);
@@ -706,6 +751,8 @@ int run_batch_end(acmi_handle *h) {
     h->overflow_items = 0;
     h->kernel_used = F.kernel_used;
     h->chunk_used = F.chunk_used;
+    h->anchor_variant = F.anchor_variant;
+    h->tiny_waves = 0;
     if (F.trivial) {
         h->have_result = true;
         return ACMI_OK;
@@ -723,10 +770,14 @@ int run_batch_end(acmi_handle *h) {
     for (int i = 7; i < 16; ++i) h->walked_bytes += uint64_t(pinned32[i]) * 16;
     h->fallback_bytes = F.kernel_used == 2 ? uint64_t(pinned32[7]) * 16 : 0;
     if (F.kernel_used == 2) h->walked_bytes -= h->fallback_bytes;  // (counters[7] is k_scan_lds' own share otherwise)
-    // automatic mode: a batch of which more than a quarter had to be walked exactly defeats the filter
+    h->tiny_waves = pinned32[18];
+    // automatic mode: a batch of which more than a quarter had to be WALKED through the automaton defeats the filter --
+    // `fallback_bytes`: clusters verification could not decide, head / tail / unknown runs, items whose run list
+    // overflowed.  (Clusters decided by the text compare are in walked_bytes but cost no walk: text with many true
+    // matches keeps the anchor kernel.)
     const bool decisive = h->kernel == 3 && F.blob_bytes >= kAutoMinBytes;
     if (decisive && F.kernel_used == 2) {
-        if (h->walked_bytes * 4 > F.blob_bytes) {
+        if (h->fallback_bytes * 4 > F.blob_bytes) {
             h->anchor_off = true;
             h->anchor_left = h->anchor_span;
             h->anchor_span = std::min<uint32_t>(h->anchor_span * 2, 1024);
@@ -762,7 +813,7 @@ int run_batch_end(acmi_handle *h) {
             HIPCHK(h, F.d_out.ensure(total * 16));
             const uint64_t cap = F.d_out.cap / 16;
             launch_expand(h->dA, F.args, F.max_items, h->d_rec_base.as<uint64_t>(), F.d_out.p, cap, F.d_prefix.as<uint64_t>(),
-                          h->pinned_dev + 16 * slot_index, F.sync_next, F.sync_words, st);
+                          h->pinned_dev + kPinWords * slot_index, F.sync_next, F.sync_words, st);
             if (F.find_all)
                 launch_refill(h->dA, F.args, F.max_items, int(fa.entry_bytes), h->d_rec_base.as<uint64_t>(),
                               F.d_out.p, cap, h->refill, st);
@@ -792,8 +843,10 @@ int run_batch_end(acmi_handle *h) {
 int run_batch(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, const uint64_t *d_off, size_t nh,
               int find_all) {
     if (h->begin_seq != h->end_seq) {  // a synchronous call drops batches that were begun and never ended
-        (void)hipStreamSynchronize(h->stream);
+        for (auto &slot : h->fly)
+            if (slot.stream) (void)hipStreamSynchronize(slot.stream);
         h->end_seq = h->begin_seq;
+        h->have_result = false;
     }
     int rc = run_batch_begin(h, d_blob, blob_bytes, d_off, nh, find_all);
     if (rc < 0) return rc;
@@ -944,10 +997,11 @@ int acmi_destroy(acmi_handle *h) {
         if (h->dev_touched) {  // also after a failed upload: release whatever was created
             (void)hipSetDevice(h->dev_id);
             if (h->stream) (void)hipStreamSynchronize(h->stream);
-            for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_out_off, &h->d_out_list, &h->d_cold_rec, &h->d_cold_edges, &h->d_chain_byte, &h->d_chain_run, &h->d_slot_pair, &h->d_pairs, &h->d_pat_bytes, &h->d_rep_off, &h->d_rep_bytes, &h->d_plan, &h->d_nom_count, &h->d_out_len, &h->d_rep_out_off, &h->d_rep_out, &h->d_blob,
+            for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_out_off, &h->d_out_list, &h->d_cold_rec, &h->d_cold_edges, &h->d_chain_byte, &h->d_chain_run, &h->d_slot_pair, &h->d_pairs, &h->d_pat_bytes, &h->d_rep_off, &h->d_rep_bytes, &h->d_plan, &h->d_plan_out, &h->d_tail_out, &h->d_rep_sync, &h->d_nom_count, &h->d_out_len, &h->d_rep_out_off, &h->d_rep_out, &h->d_blob,
                               &h->d_off, &h->d_sync[0], &h->d_sync[1], &h->d_item_base, &h->d_item_hay, &h->d_item_rec, &h->d_zero,
                               &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->fly[0].d_prefix, &h->fly[0].d_out, &h->fly[1].d_prefix, &h->fly[1].d_out, &h->d_runs, &h->d_run_count})
                 b->release();
+            for (void *q : h->retired) (void)hipFree(q);
             for (auto &evt : h->ev)
                 if (evt) (void)hipEventDestroy(evt);
             for (auto &slot : h->fly)
@@ -1275,6 +1329,8 @@ int acmi_get_stat(const acmi_handle *h, const char *key, double *value) {
         else if (k == "scan_ms") *value = h->scan_ms;
         else if (k == "walk_ms") *value = h->walk_ms;
         else if (k == "kernel_used") *value = h->kernel_used;
+        else if (k == "anchor_variant") *value = h->anchor_variant;
+        else if (k == "tiny_waves") *value = h->tiny_waves;
         else if (k == "anchor_q") *value = fa.anchor_q;
         else if (k == "anchor_keys") *value = fa.anchor_keys;
         else if (k == "anchor_mode") *value = fa.anchor_mode;
@@ -1297,6 +1353,10 @@ int acmi_get_stat(const acmi_handle *h, const char *key, double *value) {
 int acmi_set_stream(acmi_handle *h, void *hip_stream) {
     return guarded(h, [&]() -> int {
         if (!live(h)) return ACMI_E_INVALID;
+        if (h->begin_seq != h->end_seq) {  // a begun batch is ended on the stream it was enqueued on
+            h->last_error = "acmi_set_stream while a batch is in flight";
+            return ACMI_E_ARG;
+        }
         h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
         return ACMI_OK;
     });
@@ -1397,6 +1457,18 @@ const char *acmi_version(void) { return ACMI_VERSION; }
 // RCCL is bound at run time (dlopen): libacmi.so has no link-time dependency on it, a host without RCCL simply gets
 // ACMI_E_NO_DEVICE from acmi_comm_*.  torch.distributed's "nccl" backend is the same library: a process that has
 // torch loaded reuses its copy.
+//
+// The exchange is SIZE-PROPORTIONAL: after a 32-byte header per rank (records, haystacks, status) every rank knows every
+// shard's size, writes its own shard -- haystack ids and prefix words already global -- into ITS slice of the global
+// arrays, and one group of per-rank ncclBroadcast calls (root r, exactly r's bytes, in place for the root) fills in the
+// other slices: no padding to the largest shard, no staging copy, no unpacking kernel.  A rank that cannot take part (no
+// result, wrong haystack count, out of memory) says so IN THE HEADER and still joins the header round, so that every rank
+// returns an error together instead of leaving its peers inside a collective.
+//
+// The collectives sit behind a small transport interface with two implementations: RCCL (one process or thread per GPU),
+// and a process-local fabric (acmi_comm_create_local: W communicators of one process, each used by its own thread, copies
+// instead of collectives) -- the same packing / offset logic runs on a box with ONE GPU, which is how the W > 1 layout is
+// tested where RCCL refuses several ranks per device.
 namespace {
 
 struct Rccl {
@@ -1404,6 +1476,10 @@ struct Rccl {
     int (*GetUniqueId)(void *) = nullptr;
     int (*CommInitRank)(void **, int, acmi_comm_id, int) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*CommCount)(void *, int *) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     std::string error;
@@ -1426,49 +1502,165 @@ Rccl &rccl() {
         r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
         r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
+        r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(dlsym(r.lib, "ncclBroadcast"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(r.lib, "ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(r.lib, "ncclGroupEnd"));
+        r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.lib, "ncclCommCount"));
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
-        if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) r.error = "librccl.so lacks a needed symbol";
+        if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.Broadcast || !r.GroupStart || !r.GroupEnd || !r.CommDestroy)
+            r.error = "librccl.so lacks a needed symbol";
     });
     return r;
 }
 
 constexpr int kNcclUint8 = 1;  // ncclDataType_t (rccl.h:460)
 
+// One broadcast of a group: `bytes` from rank `root`'s `send` into every rank's `recv` (the root passes send == recv).
+struct BcastOp {
+    const void *send;
+    void *recv;
+    size_t bytes;
+    int root;
+};
+
+// The process-local fabric: W communicators of one process meet here.  Every collective is a rendezvous (all ranks
+// post their buffers, wait for each other, copy what they receive on their own stream, synchronise it, meet again):
+// as blocking as can be, which is all a test transport and a single-process multi-GPU host need.
+struct LocalFabric {
+    std::mutex m;
+    std::condition_variable cv;
+    int world = 0, refs = 0;
+    int arrived = 0;
+    uint64_t generation = 0;
+    std::vector<const void *> send;                 // all-gather: per rank
+    std::vector<std::vector<BcastOp>> ops;          // broadcast group: per rank
+    std::vector<hipEvent_t> ready;                  // per rank: its send data is complete on its stream
+    void barrier() {
+        std::unique_lock<std::mutex> g(m);
+        const uint64_t gen = generation;
+        if (++arrived == world) { arrived = 0; ++generation; cv.notify_all(); }
+        else cv.wait(g, [&] { return generation != gen; });
+    }
+};
+
 }  // namespace
 
 struct acmi_comm {
-    void *comm = nullptr;  // ncclComm_t; null for a world of one
+    void *comm = nullptr;           // ncclComm_t (RCCL transport)
+    LocalFabric *fabric = nullptr;  // process-local transport
     int rank = 0, world = 1, dev = 0;
-    DevBuf d_hdr, d_send, d_recv, d_prefix, d_records;
-    uint64_t *h_hdr = nullptr;  // pinned: world x {records, haystacks}
+    int backend_ranks = 1;          // ranks the backend itself reports (ncclCommCount)
+    DevBuf d_hdr, d_prefix, d_records;
+    uint64_t *h_hdr = nullptr;      // pinned: [mine 4 | all world x 4] words
+    // capacities every rank holds, kept identical on all ranks (they grow by the same rule from the same headers)
+    uint64_t cap_rec = 0, cap_hay = 0;
+    bool cap_ok = true;             // this rank's buffers really have that capacity
     uint64_t total_rec = 0, total_hay = 0;
+    uint64_t bytes_sent = 0, bytes_received = 0, rounds = 0;  // of the last exchange (statistics)
     std::string last_error;
 };
 
 namespace {
 
-// Unpack `world` payloads (see GatherArgs) into the comm's global prefix / record arrays.
-int comm_compact(acmi_comm *c, int world, const uint8_t *d_recv, uint64_t stride, uint64_t nh_cap, const uint64_t *hdr, hipStream_t st) {
-    GatherArgs G{};
-    G.recv = d_recv;
-    G.stride = stride;
-    G.nh_cap = nh_cap;
-    G.world = uint32_t(world);
-    for (int r = 0; r < world; ++r) {
-        G.rec_base[r + 1] = G.rec_base[r] + hdr[2 * r];
-        G.hay_base[r + 1] = G.hay_base[r] + hdr[2 * r + 1];
+constexpr uint64_t kHdrWords = 4;  // {records, haystacks, status, reserved}
+enum : uint64_t { kCommOk = 0, kCommNoResult = 1, kCommNoMemory = 2, kCommDevice = 3 };
+
+int comm_fail(acmi_handle *h, acmi_comm *c, int code, const std::string &text) {
+    c->last_error = text;
+    if (h && live(h)) h->last_error = text;
+    return code;
+}
+
+// all-gather of `bytes` per rank (device buffers), enqueued on `st`
+int comm_allgather(acmi_comm *c, const void *send, void *recv, size_t bytes, hipStream_t st) {
+    if (c->world == 1) {
+        if (send != recv && hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return ACMI_E_DEVICE;
+        return ACMI_OK;
     }
-    G.total_rec = G.rec_base[world];
-    G.total_hay = G.hay_base[world];
-    if (c->d_prefix.ensure((G.total_hay + 1) * 8) != hipSuccess || c->d_records.ensure(std::max<uint64_t>(16, G.total_rec * 16)) != hipSuccess)
-        return ACMI_E_NOMEM;
-    G.out_prefix = c->d_prefix.as<uint64_t>();
-    G.out_records = c->d_records.as<uint4>();
-    launch_gather_compact(G, st);
-    c->total_rec = G.total_rec;
-    c->total_hay = G.total_hay;
-    return hipGetLastError() == hipSuccess ? ACMI_OK : ACMI_E_DEVICE;
+    if (c->fabric) {
+        LocalFabric &F = *c->fabric;
+        if (hipEventRecord(F.ready[size_t(c->rank)], st) != hipSuccess) return ACMI_E_DEVICE;
+        F.send[size_t(c->rank)] = send;
+        F.barrier();
+        int rc = ACMI_OK;
+        for (int r = 0; r < c->world && rc == ACMI_OK; ++r) {
+            if (hipStreamWaitEvent(st, F.ready[size_t(r)], 0) != hipSuccess ||
+                hipMemcpyAsync(static_cast<uint8_t *>(recv) + size_t(r) * bytes, F.send[size_t(r)], bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
+                rc = ACMI_E_DEVICE;
+        }
+        if (hipStreamSynchronize(st) != hipSuccess) rc = ACMI_E_DEVICE;
+        F.barrier();  // nobody reuses its send buffer before everybody has copied it
+        return rc;
+    }
+    Rccl &R = rccl();
+    const int e = R.AllGather(send, recv, bytes, kNcclUint8, c->comm, st);
+    if (e != 0) { c->last_error = std::string("ncclAllGather: ") + (R.GetErrorString ? R.GetErrorString(e) : "error"); return ACMI_E_DEVICE; }
+    return ACMI_OK;
+}
+
+// one group of broadcasts; every rank passes the same list (same order, sizes and roots)
+int comm_bcast_group(acmi_comm *c, const std::vector<BcastOp> &ops, hipStream_t st) {
+    if (c->world == 1 || ops.empty()) return ACMI_OK;
+    if (c->fabric) {
+        LocalFabric &F = *c->fabric;
+        if (hipEventRecord(F.ready[size_t(c->rank)], st) != hipSuccess) return ACMI_E_DEVICE;
+        F.ops[size_t(c->rank)] = ops;
+        F.barrier();
+        int rc = ACMI_OK;
+        for (size_t i = 0; i < ops.size() && rc == ACMI_OK; ++i) {
+            const BcastOp &mine = ops[i];
+            if (mine.root == c->rank || mine.bytes == 0) continue;
+            const BcastOp &theirs = F.ops[size_t(mine.root)][i];
+            if (hipStreamWaitEvent(st, F.ready[size_t(mine.root)], 0) != hipSuccess ||
+                hipMemcpyAsync(mine.recv, theirs.send, mine.bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
+                rc = ACMI_E_DEVICE;
+        }
+        if (hipStreamSynchronize(st) != hipSuccess) rc = ACMI_E_DEVICE;
+        F.barrier();
+        return rc;
+    }
+    Rccl &R = rccl();
+    int e = R.GroupStart();
+    for (size_t i = 0; i < ops.size() && e == 0; ++i)
+        if (ops[i].bytes) e = R.Broadcast(ops[i].send, ops[i].recv, ops[i].bytes, kNcclUint8, ops[i].root, c->comm, st);
+    const int e2 = R.GroupEnd();
+    if (e == 0) e = e2;
+    if (e != 0) { c->last_error = std::string("ncclBroadcast: ") + (R.GetErrorString ? R.GetErrorString(e) : "error"); return ACMI_E_DEVICE; }
+    return ACMI_OK;
+}
+
+// header round: every rank's {records, haystacks, status} -> c->h_hdr[4 ..]; the exchange's one host wait
+int comm_headers(acmi_comm *c, uint64_t n_rec, uint64_t n_hay, uint64_t status, hipStream_t st) {
+    const int W = c->world;
+    uint64_t *mine = c->h_hdr, *all = c->h_hdr + kHdrWords;
+    mine[0] = n_rec; mine[1] = n_hay; mine[2] = status; mine[3] = 0;
+    uint64_t *d_mine = c->d_hdr.as<uint64_t>(), *d_all = d_mine + kHdrWords;
+    if (hipMemcpyAsync(d_mine, mine, kHdrWords * 8, hipMemcpyHostToDevice, st) != hipSuccess) return ACMI_E_DEVICE;
+    int rc = comm_allgather(c, d_mine, d_all, kHdrWords * 8, st);
+    if (rc < 0) return rc;
+    if (hipMemcpyAsync(all, d_all, size_t(W) * kHdrWords * 8, hipMemcpyDeviceToHost, st) != hipSuccess) return ACMI_E_DEVICE;
+    if (hipStreamSynchronize(st) != hipSuccess) return ACMI_E_DEVICE;
+    ++c->rounds;
+    return ACMI_OK;
+}
+
+acmi_comm *comm_new(acmi_handle *h, int rank, int world) {
+    acmi_comm *c = new acmi_comm();
+    c->rank = rank;
+    c->world = world;
+    c->dev = h->dev_id;
+    c->backend_ranks = world;
+    // the header buffers exist from the start: the header round itself must not be able to fail on an allocation
+    if (hipHostMalloc(reinterpret_cast<void **>(&c->h_hdr), size_t(world + 1) * kHdrWords * 8, hipHostMallocDefault) != hipSuccess ||
+        c->d_hdr.ensure(size_t(world + 1) * kHdrWords * 8) != hipSuccess) {
+        (void)hipGetLastError();
+        if (c->h_hdr) (void)hipHostFree(c->h_hdr);
+        c->d_hdr.release();
+        delete c;
+        return nullptr;
+    }
+    return c;
 }
 
 }  // namespace
@@ -1489,26 +1681,54 @@ int acmi_comm_create(acmi_handle *h, int rank, int world, const acmi_comm_id *id
         int rc = check_ready(h);  // the communicator lives on the handle's device
         if (rc < 0) return rc;
         if (!out || world < 1 || world > int(kMaxRanks) || rank < 0 || rank >= world || (world > 1 && !id)) return ACMI_E_ARG;
-        acmi_comm *c = new acmi_comm();
-        c->rank = rank;
-        c->world = world;
-        c->dev = h->dev_id;
+        acmi_comm *c = comm_new(h, rank, world);
+        if (!c) return ACMI_E_NOMEM;
         if (world > 1) {
             Rccl &R = rccl();
-            if (!R.error.empty()) { h->last_error = R.error; delete c; return ACMI_E_NO_DEVICE; }
+            if (!R.error.empty()) { h->last_error = R.error; acmi_comm_destroy(c); return ACMI_E_NO_DEVICE; }
             const int e = R.CommInitRank(&c->comm, world, *id, rank);
             if (e != 0) {
                 h->last_error = std::string("ncclCommInitRank: ") + (R.GetErrorString ? R.GetErrorString(e) : "error");
-                delete c;
+                c->comm = nullptr;
+                acmi_comm_destroy(c);
                 return ACMI_E_DEVICE;
             }
-        }
-        if (hipHostMalloc(reinterpret_cast<void **>(&c->h_hdr), size_t(world) * 16, hipHostMallocDefault) != hipSuccess) {
-            if (c->comm) rccl().CommDestroy(c->comm);
-            delete c;
-            return ACMI_E_NOMEM;
+            int n = 0;
+            if (R.CommCount && R.CommCount(c->comm, &n) == 0) c->backend_ranks = n;
         }
         *out = c;
+        return ACMI_OK;
+    });
+}
+
+int acmi_comm_create_local(acmi_handle *const *handles, int world, acmi_comm **out) {
+    return guarded(nullptr, [&]() -> int {
+        if (!handles || !out || world < 1 || world > int(kMaxRanks)) return ACMI_E_ARG;
+        for (int r = 0; r < world; ++r) {
+            const int rc = check_ready(handles[r]);
+            if (rc < 0) return rc;
+        }
+        LocalFabric *F = new LocalFabric();
+        F->world = world;
+        F->send.assign(size_t(world), nullptr);
+        F->ops.resize(size_t(world));
+        F->ready.assign(size_t(world), nullptr);
+        int made = 0;
+        for (int r = 0; r < world; ++r) {
+            acmi_comm *c = nullptr;
+            if (hipSetDevice(handles[r]->dev_id) == hipSuccess && hipEventCreateWithFlags(&F->ready[size_t(r)], hipEventDisableTiming) == hipSuccess)
+                c = comm_new(handles[r], r, world);
+            if (!c) {
+                for (int k = 0; k < made; ++k) { out[k]->fabric = nullptr; acmi_comm_destroy(out[k]); out[k] = nullptr; }
+                for (hipEvent_t e : F->ready) if (e) (void)hipEventDestroy(e);
+                delete F;
+                return ACMI_E_NOMEM;
+            }
+            c->fabric = F;
+            ++F->refs;
+            out[r] = c;
+            ++made;
+        }
         return ACMI_OK;
     });
 }
@@ -1518,7 +1738,18 @@ int acmi_comm_destroy(acmi_comm *c) {
         if (!c) return ACMI_E_INVALID;
         (void)hipSetDevice(c->dev);
         if (c->comm) rccl().CommDestroy(c->comm);
-        for (DevBuf *b : {&c->d_hdr, &c->d_send, &c->d_recv, &c->d_prefix, &c->d_records}) b->release();
+        if (c->fabric) {
+            bool last;
+            {
+                std::lock_guard<std::mutex> g(c->fabric->m);
+                last = --c->fabric->refs == 0;
+            }
+            if (last) {
+                for (hipEvent_t e : c->fabric->ready) if (e) (void)hipEventDestroy(e);
+                delete c->fabric;
+            }
+        }
+        for (DevBuf *b : {&c->d_hdr, &c->d_prefix, &c->d_records}) b->release();
         if (c->h_hdr) (void)hipHostFree(c->h_hdr);
         delete c;
         return ACMI_OK;
@@ -1529,69 +1760,96 @@ int acmi_comm_allgather_result(acmi_comm *c, acmi_handle *h, uint64_t n_haystack
                                const void **d_records, uint64_t *n_records, uint64_t *n_haystacks) {
     return guarded(h, [&]() -> int {
         if (!c) return ACMI_E_ARG;
-        if (!live(h)) return ACMI_E_INVALID;
-        if (!h->have_result || n_haystacks_local != h->last_nh) return ACMI_E_ARG;
+        if (!live(h)) return ACMI_E_INVALID;   // (no stream to join a collective on: the caller broke the contract)
         HIPCHK(h, hipSetDevice(h->dev_id));
         hipStream_t st = h->stream;
-        Rccl &R = rccl();
         const int W = c->world;
-        // round 1: sizes (16 bytes per rank) -- RCCL has no all-gatherv, the payload round is padded to the largest shard
-        HIPCHK(h, c->d_hdr.ensure(size_t(W + 1) * 16));
-        uint64_t *d_mine = c->d_hdr.as<uint64_t>(), *d_all = d_mine + 2;
-        const uint64_t mine[2] = {h->last_total, h->last_nh};
-        HIPCHK(h, hipMemcpyAsync(d_mine, mine, 16, hipMemcpyHostToDevice, st));
-        if (W > 1) {
-            const int e = R.AllGather(d_mine, d_all, 16, kNcclUint8, c->comm, st);
-            if (e != 0) { h->last_error = std::string("ncclAllGather: ") + (R.GetErrorString ? R.GetErrorString(e) : "error"); return ACMI_E_DEVICE; }
-        } else {
-            HIPCHK(h, hipMemcpyAsync(d_all, d_mine, 16, hipMemcpyDeviceToDevice, st));
+        c->rounds = c->bytes_sent = c->bytes_received = 0;
+        // what is wrong on THIS rank travels in the header; the rank joins the header round all the same
+        uint64_t status = kCommOk;
+        if (!h->have_result || n_haystacks_local != h->last_nh) status = kCommNoResult;
+        else if (!c->cap_ok) status = kCommNoMemory;
+        const uint64_t my_rec = status == kCommOk ? h->last_total : 0, my_hay = status == kCommOk ? h->last_nh : 0;
+        int rc = comm_headers(c, my_rec, my_hay, status, st);
+        if (rc < 0) return comm_fail(h, c, rc, c->last_error.empty() ? "header exchange failed" : c->last_error);
+        const uint64_t *all = c->h_hdr + kHdrWords;
+        uint64_t rec_base[kMaxRanks + 1] = {0}, hay_base[kMaxRanks + 1] = {0};
+        int bad = -1;
+        for (int r = 0; r < W; ++r) {
+            rec_base[r + 1] = rec_base[r] + all[size_t(r) * kHdrWords];
+            hay_base[r + 1] = hay_base[r] + all[size_t(r) * kHdrWords + 1];
+            if (all[size_t(r) * kHdrWords + 2] != kCommOk && bad < 0) bad = r;
         }
-        HIPCHK(h, hipMemcpyAsync(c->h_hdr, d_all, size_t(W) * 16, hipMemcpyDeviceToHost, st));
-        HIPCHK(h, hipStreamSynchronize(st));
-        uint64_t rec_cap = 0, nh_cap = 0;
-        for (int r = 0; r < W; ++r) { rec_cap = std::max(rec_cap, c->h_hdr[2 * r]); nh_cap = std::max(nh_cap, c->h_hdr[2 * r + 1]); }
-        // round 2: [prefix (nh_cap+1) | records rec_cap], every rank the same size
-        const uint64_t stride = (nh_cap + 1) * 8 + rec_cap * 16;
-        HIPCHK(h, c->d_send.ensure(stride));
-        HIPCHK(h, c->d_recv.ensure(stride * uint64_t(W)));
-        uint8_t *send = c->d_send.as<uint8_t>();
-        HIPCHK(h, hipMemcpyAsync(send, h->d_prefix().p, (size_t(h->last_nh) + 1) * 8, hipMemcpyDeviceToDevice, st));
-        if (h->last_total)
-            HIPCHK(h, hipMemcpyAsync(send + (nh_cap + 1) * 8, h->d_out().p, h->last_total * 16, hipMemcpyDeviceToDevice, st));
-        const uint8_t *recv = send;
-        if (W > 1) {
-            const int e = R.AllGather(send, c->d_recv.p, stride, kNcclUint8, c->comm, st);
-            if (e != 0) { h->last_error = std::string("ncclAllGather: ") + (R.GetErrorString ? R.GetErrorString(e) : "error"); return ACMI_E_DEVICE; }
-            recv = c->d_recv.as<uint8_t>();
+        if (bad >= 0) {  // every rank sees the same headers and leaves here together
+            const uint64_t why = all[size_t(bad) * kHdrWords + 2];
+            const std::string text = "rank " + std::to_string(bad) + (why == kCommNoResult ? " has no result for the haystack count it gave"
+                                                                      : why == kCommNoMemory ? " is out of device memory" : " reported a device error");
+            return comm_fail(h, c, bad == c->rank ? (why == kCommNoMemory ? ACMI_E_NOMEM : ACMI_E_ARG) : ACMI_E_DEVICE, text);
         }
-        int rc = comm_compact(c, W, recv, stride, nh_cap, c->h_hdr, st);
-        if (rc < 0) return rc;
+        const uint64_t total_rec = rec_base[W], total_hay = hay_base[W];
+        // Global arrays: grown by the same rule on every rank (the totals are the same everywhere), and a rank whose
+        // allocation fails tells the others in a second, tiny round -- taken by all ranks or by none.
+        if (total_rec > c->cap_rec || total_hay > c->cap_hay || !c->d_prefix.p) {
+            c->cap_rec = std::max(c->cap_rec, total_rec + total_rec / 4);
+            c->cap_hay = std::max(c->cap_hay, total_hay + total_hay / 4);
+            c->cap_ok = c->d_prefix.ensure((c->cap_hay + 1) * 8) == hipSuccess && c->d_records.ensure(std::max<uint64_t>(16, c->cap_rec * 16)) == hipSuccess;
+            if (!c->cap_ok) (void)hipGetLastError();
+            rc = comm_headers(c, 0, 0, c->cap_ok ? kCommOk : kCommNoMemory, st);
+            if (rc < 0) return comm_fail(h, c, rc, c->last_error.empty() ? "status exchange failed" : c->last_error);
+            for (int r = 0; r < W; ++r)
+                if (all[size_t(r) * kHdrWords + 2] != kCommOk) {
+                    c->cap_rec = c->cap_hay = 0;   // (every rank: the next call tries again from scratch)
+                    return comm_fail(h, c, r == c->rank ? ACMI_E_NOMEM : ACMI_E_DEVICE, "rank " + std::to_string(r) + " is out of device memory");
+                }
+        }
+        // this rank's slice, already global: haystack ids + hay_base, prefix words + rec_base (and the closing word)
+        uint64_t *g_prefix = c->d_prefix.as<uint64_t>();
+        uint4 *g_records = c->d_records.as<uint4>();
+        launch_gather_pack(h->d_prefix().as<uint64_t>(), h->d_out().as<uint4>(), my_hay, my_rec, hay_base[c->rank], rec_base[c->rank],
+                           g_prefix + hay_base[c->rank], g_records + rec_base[c->rank], g_prefix + total_hay, total_rec, st);
+        HIPCHK(h, hipGetLastError());
+        // one group: rank r's slices from rank r, exactly their size
+        std::vector<BcastOp> ops;
+        for (int r = 0; r < W; ++r) {
+            const uint64_t nr = rec_base[r + 1] - rec_base[r], nh = hay_base[r + 1] - hay_base[r];
+            ops.push_back({g_records + rec_base[r], g_records + rec_base[r], size_t(nr) * 16, r});
+            ops.push_back({g_prefix + hay_base[r], g_prefix + hay_base[r], size_t(nh) * 8, r});
+            if (r == c->rank) c->bytes_sent = (W > 1 ? nr * 16 + nh * 8 : 0);
+            else c->bytes_received += nr * 16 + nh * 8;
+        }
+        rc = comm_bcast_group(c, ops, st);
+        if (rc < 0) return comm_fail(h, c, rc, c->last_error.empty() ? "payload exchange failed" : c->last_error);
+        ++c->rounds;
         HIPCHK(h, hipStreamSynchronize(st));
+        c->total_rec = total_rec;
+        c->total_hay = total_hay;
         if (d_prefix) *d_prefix = c->d_prefix.p;
         if (d_records) *d_records = c->d_records.p;
-        if (n_records) *n_records = c->total_rec;
-        if (n_haystacks) *n_haystacks = c->total_hay;
+        if (n_records) *n_records = total_rec;
+        if (n_haystacks) *n_haystacks = total_hay;
         return ACMI_OK;
     });
 }
 
-int acmi_comm_debug_compact(acmi_comm *c, acmi_handle *h, int n_payloads, const void *d_payloads, uint64_t stride, uint64_t nh_cap,
-                            const uint64_t *sizes, const void **d_prefix, const void **d_records, uint64_t *n_records,
-                            uint64_t *n_haystacks) {
-    return guarded(h, [&]() -> int {
-        if (!c || !sizes || !d_payloads || n_payloads < 1 || n_payloads > int(kMaxRanks)) return ACMI_E_ARG;
-        int rc = check_ready(h);
-        if (rc < 0) return rc;
-        rc = comm_compact(c, n_payloads, static_cast<const uint8_t *>(d_payloads), stride, nh_cap, sizes, h->stream);
-        if (rc < 0) return rc;
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        if (d_prefix) *d_prefix = c->d_prefix.p;
-        if (d_records) *d_records = c->d_records.p;
-        if (n_records) *n_records = c->total_rec;
-        if (n_haystacks) *n_haystacks = c->total_hay;
+int acmi_comm_get_stat(const acmi_comm *c, const char *key, double *value) {
+    return guarded(nullptr, [&]() -> int {
+        if (!c || !key || !value) return ACMI_E_ARG;
+        const std::string k(key);
+        if (k == "world") *value = c->world;
+        else if (k == "rank") *value = c->rank;
+        else if (k == "backend_ranks") *value = c->backend_ranks;          // ncclCommCount (RCCL transport)
+        else if (k == "transport") *value = c->world == 1 ? 0 : (c->fabric ? 2 : 1);  // 0 none, 1 RCCL, 2 process-local
+        else if (k == "rounds") *value = double(c->rounds);                // collectives of the last exchange
+        else if (k == "bytes_sent") *value = double(c->bytes_sent);
+        else if (k == "bytes_received") *value = double(c->bytes_received);
+        else if (k == "records") *value = double(c->total_rec);
+        else if (k == "haystacks") *value = double(c->total_hay);
+        else return ACMI_E_ARG;
         return ACMI_OK;
     });
 }
+
+const char *acmi_comm_last_error(const acmi_comm *c) { return c ? c->last_error.c_str() : "no communicator"; }
 
 }  // extern "C"
 
@@ -1609,16 +1867,125 @@ int acmi_set_replacement(acmi_handle *h, uint32_t pattern_index, const uint8_t *
     });
 }
 
+namespace {
+
+// multifast_replace over a batch that is resident in device memory; the output stays there (h->d_rep_out / d_rep_out_off).
+// One host wait: the match pipeline's own, then plan -> scan -> emit are enqueued behind it with an OPTIMISTIC output
+// capacity (the largest output so far, at least the input's size plus a quarter) and the total read back at the end; only
+// an output that outgrew the buffer costs a second emit.
+int replace_on_device(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, const uint64_t *d_off, size_t nh, int mode,
+                      uint64_t *out_bytes) {
+    hipStream_t st = h->stream;
+    if (!h->rep_uploaded) {
+        std::vector<uint64_t> off = h->aut.replacement_off();
+        off.resize(std::max<size_t>(1, h->aut.patterns().size()), ~0ull);
+        for (size_t i = 0; i < h->aut.patterns().size(); ++i)
+            if (!h->aut.patterns()[i].accepted) off[i] = ~0ull;
+        HIPCHK(h, h->d_rep_off.ensure(off.size() * 8));
+        HIPCHK(h, copy_h2d(h->d_rep_off.p, off.data(), off.size() * 8));
+        const std::vector<uint8_t> &rb = h->aut.replacement_bytes();
+        HIPCHK(h, h->d_rep_bytes.ensure(rb.size() + 16));
+        if (!rb.empty()) HIPCHK(h, copy_h2d(h->d_rep_bytes.p, rb.data(), rb.size()));
+        h->rep_uploaded = true;
+    }
+    *out_bytes = 0;
+    if (nh == 0) {
+        HIPCHK(h, h->d_rep_out_off.ensure(8));
+        HIPCHK(h, hipMemsetAsync(h->d_rep_out_off.p, 0, 8, st));
+        HIPCHK(h, h->d_rep_out.ensure(16));
+        HIPCHK(h, hipStreamSynchronize(st));
+        return ACMI_OK;
+    }
+    // 1. every match of the batch (results left on the device)
+    int rc = run_batch(h, d_blob, blob_bytes, d_off, nh, 1);
+    if (rc < 0) return rc;
+    // 2. nominees and output lengths per haystack, 3. output offsets, 4. the output texts
+    HIPCHK(h, h->d_plan.ensure(std::max<uint64_t>(8, h->last_total * 8)));
+    HIPCHK(h, h->d_plan_out.ensure(std::max<uint64_t>(8, h->last_total * 8)));
+    HIPCHK(h, h->d_tail_out.ensure(nh * 8));
+    HIPCHK(h, h->d_nom_count.ensure(nh * 4));
+    HIPCHK(h, h->d_out_len.ensure(nh * 8));
+    HIPCHK(h, h->d_rep_out_off.ensure((nh + 1) * 8));
+    const size_t sync_bytes = 8 + size_t(scan_tiles(nh + 1) + 1) * 8;
+    HIPCHK(h, h->d_rep_sync.ensure(sync_bytes));
+    HIPCHK(h, hipMemsetAsync(h->d_rep_sync.p, 0, sync_bytes, st));
+    h->rep_cap = std::max<uint64_t>(h->rep_cap, blob_bytes + blob_bytes / 4 + 4096);
+    HIPCHK(h, h->d_rep_out.ensure(h->rep_cap + 16));
+    ReplaceArgs R{};
+    R.blob = d_blob;
+    R.offsets = d_off;
+    R.n_haystacks = uint32_t(nh);
+    R.mode = mode == 2 ? 2u : 1u;   // MF_REPLACE_MODE_DEFAULT behaves as NORMAL (replace.c:252-254)
+    R.prefix = h->d_prefix().as<uint64_t>();
+    R.records = h->d_out().as<uint4>();
+    R.pattern_length = h->dA.pattern_length;
+    R.rep_off = h->d_rep_off.as<uint64_t>();
+    R.rep_bytes = h->d_rep_bytes.as<uint8_t>();
+    R.plan = h->d_plan.as<uint2>();
+    R.plan_out = h->d_plan_out.as<uint64_t>();
+    R.tail_out = h->d_tail_out.as<uint64_t>();
+    R.nom_count = h->d_nom_count.as<uint32_t>();
+    R.out_len = h->d_out_len.as<uint64_t>();
+    R.out_off = h->d_rep_out_off.as<uint64_t>();
+    R.out_blob = h->d_rep_out.as<uint8_t>();
+    // the total travels through the pinned block of the slot the match result does not use
+    uint64_t *total_host = h->pinned + (kPinWords / 2) * (h->cur ^ 1);
+    uint64_t *total_dev = reinterpret_cast<uint64_t *>(h->pinned_dev + kPinWords * (h->cur ^ 1));
+    launch_replace_plan(R, st);
+    launch_scan_u64(R.out_len, nh, h->d_rep_out_off.as<uint64_t>(), h->d_rep_sync.as<uint32_t>(), total_dev, st);
+    launch_replace_emit(R, h->rep_cap, st);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(st));
+    const uint64_t total = *total_host;
+    if (total > h->rep_cap) {
+        h->rep_cap = total + total / 8;
+        HIPCHK(h, h->d_rep_out.ensure(h->rep_cap + 16));
+        R.out_blob = h->d_rep_out.as<uint8_t>();
+        launch_replace_emit(R, h->rep_cap, st);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipStreamSynchronize(st));
+    }
+    *out_bytes = total;
+    return ACMI_OK;
+}
+
+int replace_args_ok(acmi_handle *h, int mode) {
+    if (mode < 0 || mode > 2) return ACMI_E_ARG;
+    if (!h->aut.has_replacement()) {  // multifast_replace returns -2 and emits nothing (replace.c:482-483)
+        h->last_error = "no pattern has a replacement text";
+        return ACMI_E_NO_REPLACEMENT;
+    }
+    return ACMI_OK;
+}
+
+}  // namespace
+
+int acmi_replace_batch_device(acmi_handle *h, const void *d_blob, uint64_t blob_bytes, const void *d_offsets, size_t n_haystacks,
+                              int mode, const void **d_out_blob, const void **d_out_offsets, uint64_t *out_bytes) {
+    return guarded(h, [&]() -> int {
+        int rc = check_ready(h);
+        if (rc < 0) return rc;
+        if (n_haystacks && !d_offsets) return ACMI_E_ARG;
+        rc = replace_args_ok(h, mode);
+        if (rc < 0) return rc;
+        uint64_t total = 0;
+        rc = replace_on_device(h, static_cast<const uint8_t *>(d_blob), blob_bytes, static_cast<const uint64_t *>(d_offsets), n_haystacks, mode, &total);
+        if (rc < 0) return rc;
+        if (d_out_blob) *d_out_blob = h->d_rep_out.p;
+        if (d_out_offsets) *d_out_offsets = h->d_rep_out_off.p;
+        if (out_bytes) *out_bytes = total;
+        return ACMI_OK;
+    });
+}
+
 int acmi_replace_batch(acmi_handle *h, const uint8_t *blob, const uint64_t *offsets, size_t n_haystacks, int mode,
                        const uint8_t **out_blob, const uint64_t **out_offsets) {
     return guarded(h, [&]() -> int {
         int rc = check_ready(h);
         if (rc < 0) return rc;
-        if (mode < 0 || mode > 2 || (n_haystacks && !offsets)) return ACMI_E_ARG;
-        if (!h->aut.has_replacement()) {  // multifast_replace returns -2 and emits nothing (replace.c:482-483)
-            h->last_error = "no pattern has a replacement text";
-            return ACMI_E_NO_REPLACEMENT;
-        }
+        if (n_haystacks && !offsets) return ACMI_E_ARG;
+        rc = replace_args_ok(h, mode);
+        if (rc < 0) return rc;
         uint64_t blob_bytes = 0;
         for (size_t k = 0; k < n_haystacks; ++k) {
             if (offsets[k + 1] < offsets[k] || offsets[k + 1] - offsets[k] >= 0xFFFFFFFFull) return ACMI_E_ARG;
@@ -1626,67 +1993,18 @@ int acmi_replace_batch(acmi_handle *h, const uint8_t *blob, const uint64_t *offs
         if (n_haystacks) blob_bytes = offsets[n_haystacks];
         if (blob_bytes && !blob) return ACMI_E_ARG;
         hipStream_t st = h->stream;
-        if (!h->rep_uploaded) {
-            std::vector<uint64_t> off = h->aut.replacement_off();
-            off.resize(std::max<size_t>(1, h->aut.patterns().size()), ~0ull);
-            for (size_t i = 0; i < h->aut.patterns().size(); ++i)
-                if (!h->aut.patterns()[i].accepted) off[i] = ~0ull;
-            HIPCHK(h, h->d_rep_off.ensure(off.size() * 8));
-            HIPCHK(h, copy_h2d(h->d_rep_off.p, off.data(), off.size() * 8));
-            const std::vector<uint8_t> &rb = h->aut.replacement_bytes();
-            HIPCHK(h, h->d_rep_bytes.ensure(rb.size() + 16));
-            if (!rb.empty()) HIPCHK(h, copy_h2d(h->d_rep_bytes.p, rb.data(), rb.size()));
-            h->rep_uploaded = true;
-        }
-        // 1. every match of the batch (the pipeline of acmi_match_batch, results left on the device)
         HIPCHK(h, h->d_blob.ensure(blob_bytes + 64));
         HIPCHK(h, h->d_off.ensure((n_haystacks + 1) * 8));
         if (blob_bytes) HIPCHK(h, hipMemcpyAsync(h->d_blob.p, blob, blob_bytes, hipMemcpyHostToDevice, st));
-        h->h_rep_off.assign(n_haystacks + 1, 0);
-        if (n_haystacks == 0) {
-            h->h_rep_blob.clear();
-            if (out_blob) *out_blob = h->h_rep_blob.data();
-            if (out_offsets) *out_offsets = h->h_rep_off.data();
-            return ACMI_OK;
-        }
-        HIPCHK(h, hipMemcpyAsync(h->d_off.p, offsets, (n_haystacks + 1) * 8, hipMemcpyHostToDevice, st));
-        rc = run_batch(h, h->d_blob.as<uint8_t>(), blob_bytes, h->d_off.as<uint64_t>(), n_haystacks, 1);
+        if (n_haystacks) HIPCHK(h, hipMemcpyAsync(h->d_off.p, offsets, (n_haystacks + 1) * 8, hipMemcpyHostToDevice, st));
+        uint64_t total = 0;
+        rc = replace_on_device(h, h->d_blob.as<uint8_t>(), blob_bytes, h->d_off.as<uint64_t>(), n_haystacks, mode, &total);
         if (rc < 0) return rc;
-        // 2. nominees and output lengths per haystack
-        HIPCHK(h, h->d_plan.ensure(std::max<uint64_t>(8, h->last_total * 8)));
-        HIPCHK(h, h->d_nom_count.ensure(n_haystacks * 4));
-        HIPCHK(h, h->d_out_len.ensure(n_haystacks * 8));
-        HIPCHK(h, h->d_rep_out_off.ensure((n_haystacks + 1) * 8));
-        ReplaceArgs R{};
-        R.blob = h->d_blob.as<uint8_t>();
-        R.offsets = h->d_off.as<uint64_t>();
-        R.n_haystacks = uint32_t(n_haystacks);
-        R.mode = mode == 2 ? 2u : 1u;   // MF_REPLACE_MODE_DEFAULT behaves as NORMAL (replace.c:252-254)
-        R.prefix = h->d_prefix().as<uint64_t>();
-        R.records = h->d_out().as<uint4>();
-        R.pattern_length = h->dA.pattern_length;
-        R.rep_off = h->d_rep_off.as<uint64_t>();
-        R.rep_bytes = h->d_rep_bytes.as<uint8_t>();
-        R.plan = h->d_plan.as<uint2>();
-        R.nom_count = h->d_nom_count.as<uint32_t>();
-        R.out_len = h->d_out_len.as<uint64_t>();
-        launch_replace_plan(R, st);
-        // 3. output offsets: exclusive scan of the lengths (nh words: on the host)
-        std::vector<uint64_t> lens(n_haystacks);
-        HIPCHK(h, hipMemcpyAsync(lens.data(), h->d_out_len.p, n_haystacks * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(h, hipStreamSynchronize(st));
-        for (size_t k = 0; k < n_haystacks; ++k) h->h_rep_off[k + 1] = h->h_rep_off[k] + lens[k];
-        const uint64_t total = h->h_rep_off[n_haystacks];
-        HIPCHK(h, hipMemcpyAsync(h->d_rep_out_off.p, h->h_rep_off.data(), (n_haystacks + 1) * 8, hipMemcpyHostToDevice, st));
-        HIPCHK(h, h->d_rep_out.ensure(total + 16));
-        // 4. the output texts
-        R.out_off = h->d_rep_out_off.as<uint64_t>();
-        R.out_blob = h->d_rep_out.as<uint8_t>();
-        launch_replace_emit(R, st);
+        h->h_rep_off.assign(n_haystacks + 1, 0);
         h->h_rep_blob.resize(total);
+        HIPCHK(h, hipMemcpyAsync(h->h_rep_off.data(), h->d_rep_out_off.p, (n_haystacks + 1) * 8, hipMemcpyDeviceToHost, st));
         if (total) HIPCHK(h, hipMemcpyAsync(h->h_rep_blob.data(), h->d_rep_out.p, total, hipMemcpyDeviceToHost, st));
         HIPCHK(h, hipStreamSynchronize(st));
-        HIPCHK(h, hipGetLastError());
         if (out_blob) *out_blob = h->h_rep_blob.data();
         if (out_offsets) *out_offsets = h->h_rep_off.data();
         return ACMI_OK;

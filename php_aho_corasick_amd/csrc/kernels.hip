@@ -36,6 +36,8 @@
 
 namespace acmi {
 
+int num_cus();
+
 // ------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------
@@ -893,6 +895,7 @@ __device__ __forceinline__ uint32_t run_epilogue_fast(const DevAutomaton &A, con
     if (nr > B.run_cap) {
         walked = n;
         exact_range<E, MODE, EXTRA>(A, B, nullptr, tile, tile_rows, item, p, it.floor, n, it.warm, pos_bias, 0u, ev);
+        atomicAdd(&B.counters[7], (n + 15u) >> 4);  // statistic: walked through the automaton, not decided by a text compare
     } else {
         const uint4 *runs = B.runs + item;
         uint32_t r = 0;
@@ -1346,6 +1349,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
         const bool fits = rec.z == 0u || (((reinterpret_cast<uintptr_t>(B.blob) + rec.x) & 15u) == 0u && rec.z <= 1024u);
         tiny_on = B.align_warm == 1u && __all(fits);
         tcnt = uint32_t(__builtin_popcountll(__ballot(rec.z != 0u)));
+        if (tiny_on && lane == 0) atomicAdd(&B.counters[18], 1u);  // statistic ("tiny_waves"): which path the batch's waves took
     }
     AnchorCursor ld, sc;  // load cursor runs one task ahead of the scan cursor
     anchor_open<TQ>(A, B, rec, 0, ld);
@@ -2006,7 +2010,8 @@ __global__ void k_expand(DevAutomaton A, BatchArgs B, const uint64_t *rec_base, 
         for (uint32_t k = threadIdx.x; k < next_sync_words; k += blockDim.x) next_sync[k] = 0u;
         // the batch's counters straight into the host's pinned block (words 2..5, the summary, come from the thread
         // of haystack n below): no copy command behind the pipeline
-        if (threadIdx.x < 16u && (threadIdx.x < 2u || threadIdx.x > 5u)) host_counters[threadIdx.x] = B.counters[threadIdx.x];
+        // (words 16..31: the scans' tickets and, word 18, the wave batches k_scan_anchor's TINY path took)
+        if (threadIdx.x < 32u && (threadIdx.x < 2u || threadIdx.x > 5u)) host_counters[threadIdx.x] = B.counters[threadIdx.x];
     }
     const uint64_t items = B.item_base[B.n_haystacks];
     if (i <= B.n_haystacks) {
@@ -2465,9 +2470,13 @@ void launch_build_level(const BuildArgs &T, uint32_t lo, uint32_t hi, hipStream_
 // between the cursor and a nominee's start (nothing if the nominee starts before the cursor), its replacement, the
 // cursor moved to the nominee's end; the rest of the text at the end.  The match records already hold every event
 // in that order with the patterns of an event longest first, so:
-//   k_replace_plan  one thread per haystack: nominees from its records, the booking rule, the output length;
-//   (host)          exclusive scan of the output lengths -> output offsets;
-//   k_replace_emit  one wave per haystack: the pass above, every copy 64 bytes at a time.
+//   k_replace_plan  one thread per haystack: nominees from its records, the booking rule, where in the haystack's output
+//                   every kept nominee's piece (gap + replacement) begins, the output length;
+//   k_scan_u64      exclusive scan of the output lengths -> output offsets, on the device (single pass, look-back);
+//   k_replace_emit  the copy, cut by OUTPUT bytes, not by haystack: a wave takes 32 KiB of the output blob at a time,
+//                   finds the haystack and the piece its range begins in by binary search and copies pieces -- 16 bytes
+//                   per lane, stores aligned -- until the range is full.  One huge haystack (the README's "one big file")
+//                   is spread over the whole chip, thousands of tiny ones do not get a wave each.
 // ------------------------------------------------------------------------------------------
 __global__ void k_replace_plan(ReplaceArgs R) {
     const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2494,88 +2503,181 @@ __global__ void k_replace_plan(ReplaceArgs R) {
         }
         plan[n++] = make_uint2(rec.y, rec.w);
     }
+    // piece k = [text between the cursor and nominee k's start][its replacement], beginning at plan_out[k] of the output
     uint64_t out = 0;
     uint32_t cursor = 0;
+    uint64_t *pout = R.plan_out + lo;
     for (uint32_t k = 0; k < n; ++k) {
         const uint2 nom = plan[k];
         const uint32_t start = nom.x - R.pattern_length[nom.y];
+        pout[k] = out;
         if (start >= cursor) out += start - cursor;
         out += uint32_t(R.rep_off[nom.y]);
         cursor = nom.x;
     }
+    R.tail_out[h] = out;
     if (len > cursor) out += len - cursor;
     R.nom_count[h] = n;
     R.out_len[h] = out;
 }
 
-__device__ __forceinline__ void wave_copy(uint8_t *dst, const uint8_t *src, uint64_t n, uint32_t lane) {
-    for (uint64_t i = lane; i < n; i += 64u) dst[i] = src[i];
+// Exclusive scan of n 64-bit values into out[0..n] (out[n] = the total, also written to *total_host when that is not
+// null: mapped host memory).  Same single-pass scheme as k_items / k_rec_scan; `sync` = {ticket, pad, status words},
+// zeroed before the launch.
+__global__ __launch_bounds__(kScanThreads) void k_scan_u64(const uint64_t *in, uint64_t n, uint64_t *out, uint32_t *ticket,
+                                                           uint64_t *status, uint64_t *total_host) {
+    __shared__ uint64_t wave_sums[kScanThreads / 64];
+    __shared__ uint64_t s_before;
+    __shared__ uint32_t s_tile;
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint64_t base = uint64_t(tile) * kScanTile + uint64_t(threadIdx.x) * kScanPerThread;
+    if (uint64_t(tile) * kScanTile > n) return;
+    uint64_t v[kScanPerThread];
+#pragma unroll
+    for (int i = 0; i < kScanPerThread; ++i) v[i] = base + i < n ? in[base + i] : 0ull;
+    uint64_t tile_sum;
+    uint64_t run = tile_exclusive(v, wave_sums, tile_sum);
+    if (threadIdx.x < 64) {
+        const uint64_t bf = chain_exclusive(status, tile, tile_sum);
+        if (threadIdx.x == 0) s_before = bf;
+    }
+    __syncthreads();
+    run += s_before;
+#pragma unroll
+    for (int i = 0; i < kScanPerThread; ++i) {
+        if (base + i <= n) out[base + i] = run;
+        if (base + i == n && total_host) *total_host = run;
+        run += v[i];
+    }
 }
 
-__global__ __launch_bounds__(256) void k_replace_emit(ReplaceArgs R) {
+// `n` bytes from src to dst by one wave: single bytes up to dst's 16-byte boundary, then 16 bytes per lane (the load may be
+// unaligned: gaps move by the difference between pattern and replacement lengths), then the last bytes.
+__device__ __forceinline__ void wave_copy(uint8_t *dst, const uint8_t *src, uint64_t n, uint32_t lane) {
+    const uint64_t head = (16u - uint32_t(reinterpret_cast<uintptr_t>(dst) & 15u)) & 15u;
+    if (n < 64u + head) {
+        for (uint64_t i = lane; i < n; i += 64u) dst[i] = src[i];
+        return;
+    }
+    if (lane < head) dst[lane] = src[lane];
+    const uint64_t body = (n - head) >> 4;
+    uint4 *d16 = reinterpret_cast<uint4 *>(dst + head);
+    const uint8_t *s = src + head;
+    for (uint64_t i = lane; i < body; i += 64u) d16[i] = load16u(s + (i << 4));
+    const uint64_t done = head + (body << 4);
+    if (done + lane < n) dst[done + lane] = src[done + lane];
+}
+
+constexpr uint64_t kEmitRange = 32u * 1024u;   // output bytes a wave takes at a time
+
+__global__ __launch_bounds__(256) void k_replace_emit(ReplaceArgs R, uint64_t cap) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t waves = gridDim.x * (blockDim.x / 64u);
-    for (uint32_t h = blockIdx.x * (blockDim.x / 64u) + (threadIdx.x >> 6); h < R.n_haystacks; h += waves) {
-        const uint8_t *text = R.blob + R.offsets[h];
-        const uint32_t len = uint32_t(R.offsets[h + 1] - R.offsets[h]);
-        const uint2 *plan = R.plan + R.prefix[h];
-        const uint32_t n = R.nom_count[h];
-        uint8_t *out = R.out_blob + R.out_off[h];
-        uint32_t cursor = 0;
-        for (uint32_t k = 0; k < n; ++k) {
-            const uint2 nom = plan[k];
-            const uint32_t start = nom.x - R.pattern_length[nom.y];
-            if (start >= cursor) {
-                wave_copy(out, text + cursor, start - cursor, lane);
-                out += start - cursor;
-            }
-            const uint64_t ro = R.rep_off[nom.y];
-            wave_copy(out, R.rep_bytes + (ro >> 32), uint32_t(ro), lane);
-            out += uint32_t(ro);
-            cursor = nom.x;
+    const uint64_t waves = uint64_t(gridDim.x) * (blockDim.x / 64u);
+    const uint64_t total = R.out_off[R.n_haystacks];
+    if (total > cap) return;   // the optimistic output buffer is too small: the host grows it and launches again
+    for (uint64_t g = uint64_t(blockIdx.x) * (blockDim.x / 64u) + (threadIdx.x >> 6); g * kEmitRange < total; g += waves) {
+        uint64_t a = g * kEmitRange;
+        const uint64_t b = a + kEmitRange < total ? a + kEmitRange : total;
+        // the haystack whose output holds byte a: the LAST h with out_off[h] <= a (haystacks with empty outputs share an offset)
+        uint64_t lo = 0, hi = R.n_haystacks;
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (R.out_off[mid] <= a) lo = mid; else hi = mid;
         }
-        if (len > cursor) wave_copy(out, text + cursor, len - cursor, lane);
+        uint32_t h = uint32_t(lo);
+        while (a < b) {
+            const uint64_t hb = R.out_off[h], he = R.out_off[h + 1];
+            if (he <= a) { ++h; continue; }
+            const uint64_t seg_end = b < he ? b : he;
+            const uint64_t la = a - hb, le = seg_end - hb;      // this range inside haystack h's output
+            const uint8_t *text = R.blob + R.offsets[h];
+            const uint32_t len = uint32_t(R.offsets[h + 1] - R.offsets[h]);
+            const uint32_t n = R.nom_count[h];
+            const uint2 *plan = R.plan + R.prefix[h];
+            const uint64_t *pout = R.plan_out + R.prefix[h];
+            uint8_t *out = R.out_blob + hb;
+            // first piece that reaches past la: the last k <= n with begin(k) <= la (begin(n) = the tail's)
+            const uint64_t tail_at = R.tail_out[h];
+            uint32_t k = 0;
+            if (n) {
+                uint32_t klo = 0, khi = n + 1u;   // begin(klo) <= la < begin(khi)
+                while (khi - klo > 1u) {
+                    const uint32_t mid = (klo + khi) >> 1;
+                    const uint64_t at = mid < n ? pout[mid] : tail_at;
+                    if (at <= la) klo = mid; else khi = mid;
+                }
+                k = klo;
+            }
+            for (; k <= n; ++k) {
+                const uint64_t at = k < n ? pout[k] : tail_at;
+                if (at >= le) break;
+                const uint32_t cursor = k ? plan[k - 1].x : 0u;
+                uint64_t gap_len, rep_len = 0;
+                const uint8_t *rep = nullptr;
+                if (k < n) {
+                    const uint2 nom = plan[k];
+                    const uint32_t start = nom.x - R.pattern_length[nom.y];
+                    gap_len = start >= cursor ? start - cursor : 0u;
+                    const uint64_t ro = R.rep_off[nom.y];
+                    rep = R.rep_bytes + (ro >> 32);
+                    rep_len = uint32_t(ro);
+                } else {
+                    gap_len = len > cursor ? len - cursor : 0u;
+                }
+                // the gap [at, at + gap_len) and the replacement behind it, both clipped to [la, le)
+                {
+                    const uint64_t p0 = at > la ? at : la, p1 = at + gap_len < le ? at + gap_len : le;
+                    if (p0 < p1) wave_copy(out + p0, text + cursor + (p0 - at), p1 - p0, lane);
+                }
+                if (rep_len) {
+                    const uint64_t r0 = at + gap_len;
+                    const uint64_t p0 = r0 > la ? r0 : la, p1 = r0 + rep_len < le ? r0 + rep_len : le;
+                    if (p0 < p1) wave_copy(out + p0, rep + (p0 - r0), p1 - p0, lane);
+                }
+            }
+            a = seg_end;
+            if (a == he) ++h;
+        }
     }
 }
 
 void launch_replace_plan(const ReplaceArgs &R, hipStream_t st) {
     if (R.n_haystacks) hipLaunchKernelGGL(k_replace_plan, dim3((R.n_haystacks + 255) / 256), dim3(256), 0, st, R);
 }
-void launch_replace_emit(const ReplaceArgs &R, hipStream_t st) {
+void launch_scan_u64(const uint64_t *in, uint64_t n, uint64_t *out, uint32_t *sync, uint64_t *total_host, hipStream_t st) {
+    hipLaunchKernelGGL(k_scan_u64, dim3(scan_tiles(n + 1)), dim3(kScanThreads), 0, st, in, n, out, sync, reinterpret_cast<uint64_t *>(sync + 2), total_host);
+}
+void launch_replace_emit(const ReplaceArgs &R, uint64_t cap, hipStream_t st) {
     if (!R.n_haystacks) return;
-    const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(R.n_haystacks) + 3) / 4, 256ull * 8));
-    hipLaunchKernelGGL(k_replace_emit, dim3(blocks), dim3(256), 0, st, R);
+    hipLaunchKernelGGL(k_replace_emit, dim3(uint32_t(num_cus()) * 8u), dim3(256), 0, st, R, cap);
 }
 
 // ------------------------------------------------------------------------------------------
-// k_gather_compact: the unpacking half of the all-gatherv of match arrays (engine.cpp acmi_comm_allgather_result).
-// After the exchange every rank holds, per rank r, a payload [prefix (nh_cap + 1) x u64 | records rec_cap x 16 B]
-// of which n_hay[r] + 1 prefix words and n_rec[r] records are meaningful.  Ranks own contiguous haystack ranges in
-// rank order, so concatenating the payloads in rank order IS the reference's global order: thread g copies global
-// record g (haystack id made global) and, for g <= total haystacks, writes the global prefix word g.
+// k_gather_pack: this rank's half of the all-gatherv of match arrays (engine.cpp acmi_comm_allgather_result).
+// Ranks own contiguous haystack ranges in rank order, so the global arrays are the ranks' arrays back to back: a rank
+// writes its own slice of them -- haystack ids made global, prefix words moved by the records of the ranks before it --
+// and the per-rank broadcasts that follow fill in the other slices, each exactly its size.  Nothing is unpacked
+// afterwards.  `closing` = the global prefix array's last word (the total), written by every rank for itself.
 // ------------------------------------------------------------------------------------------
-__global__ void k_gather_compact(GatherArgs G) {
+__global__ void k_gather_pack(const uint64_t *prefix, const uint4 *records, uint64_t nh, uint64_t nrec, uint64_t hay_base,
+                              uint64_t rec_base, uint64_t *out_prefix, uint4 *out_records, uint64_t *closing, uint64_t total_rec) {
     const uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (g < G.total_rec) {
-        uint32_t r = 0;
-        while (r + 1 < G.world && g >= G.rec_base[r + 1]) ++r;
-        const uint8_t *pay = G.recv + uint64_t(r) * G.stride;
-        const uint4 *recs = reinterpret_cast<const uint4 *>(pay + (G.nh_cap + 1) * 8);
-        uint4 v = recs[g - G.rec_base[r]];
-        v.x += uint32_t(G.hay_base[r]);
-        G.out_records[g] = v;
+    if (g < nrec) {
+        uint4 v = records[g];
+        v.x += uint32_t(hay_base);
+        out_records[g] = v;
     }
-    if (g <= G.total_hay) {
-        uint32_t r = 0;
-        while (r + 1 < G.world && g >= G.hay_base[r + 1]) ++r;  // (g == total_hay lands on the last rank's closing word)
-        const uint64_t *pre = reinterpret_cast<const uint64_t *>(G.recv + uint64_t(r) * G.stride);
-        G.out_prefix[g] = G.rec_base[r] + pre[g - G.hay_base[r]];
-    }
+    if (g < nh) out_prefix[g] = prefix[g] + rec_base;
+    if (g == 0) *closing = total_rec;
 }
 
-void launch_gather_compact(const GatherArgs &G, hipStream_t st) {
-    const uint64_t threads = std::max<uint64_t>(G.total_rec, G.total_hay + 1);
-    hipLaunchKernelGGL(k_gather_compact, dim3(uint32_t((threads + 255) / 256)), dim3(256), 0, st, G);
+void launch_gather_pack(const uint64_t *prefix, const uint4 *records, uint64_t nh, uint64_t nrec, uint64_t hay_base, uint64_t rec_base,
+                        uint64_t *out_prefix, uint4 *out_records, uint64_t *closing, uint64_t total_rec, hipStream_t st) {
+    const uint64_t threads = std::max<uint64_t>(1, std::max(nrec, nh));
+    hipLaunchKernelGGL(k_gather_pack, dim3(uint32_t((threads + 255) / 256)), dim3(256), 0, st, prefix, records, nh, nrec, hay_base,
+                       rec_base, out_prefix, out_records, closing, total_rec);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2595,7 +2697,7 @@ void launch_rec_scan(const BatchArgs &B, uint64_t max_items, uint64_t *rec_base,
     hipLaunchKernelGGL(k_rec_scan, dim3(scan_tiles(max_items + 1)), dim3(kScanThreads), 0, st, B, rec_base, ticket, status);
 }
 
-static int num_cus() {
+int num_cus() {
     static int n = [] {
         int dev = 0, v = 0;
         if (hipGetDevice(&dev) != hipSuccess) return 256;
@@ -2630,7 +2732,13 @@ static hipError_t launch_lds_m(const DevAutomaton &A, const BatchArgs &B, uint64
     return launch_lds_t<E, MODE, 1, 8>(A, B, max_items, lds, st);
 }
 
-static hipError_t launch_anchor(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, hipStream_t st) {
+// *variant (acmi_get_stat "anchor_variant"): the template that ran -- QW | BIG << 3 | SHORT << 4 | TINY << 5
+static hipError_t launch_anchor(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, hipStream_t st, uint32_t *variant) {
+    if (variant) {
+        const bool big = A.anchor_mode == 2, tiny = B.tiny_items != 0;
+        const bool shrt = !big && (tiny || B.short_items != 0);
+        *variant = (A.anchor_q / 4u) | (big ? 8u : 0u) | (shrt ? 16u : 0u) | (tiny ? 32u : 0u);
+    }
     const uint64_t per_block = uint64_t(kLdsThreads / 64u) * B.wave_items;
     const uint64_t want = (max_items + per_block - 1) / per_block;
     const uint32_t blocks = B.persistent ? uint32_t(std::min<uint64_t>(want, uint64_t(num_cus()))) : uint32_t(want);
@@ -2673,9 +2781,10 @@ static hipError_t launch_anchor(const DevAutomaton &A, const BatchArgs &B, uint6
 }
 
 hipError_t launch_scan(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes,
-                       int kernel, int class_mode, int ilp, int group_quads, hipStream_t st) {
+                       int kernel, int class_mode, int ilp, int group_quads, hipStream_t st, uint32_t *anchor_variant) {
+    if (anchor_variant) *anchor_variant = 0;
     if (max_items == 0) return hipSuccess;
-    if (kernel == 2 && A.anchor_q != 0) return launch_anchor(A, B, max_items, st);
+    if (kernel == 2 && A.anchor_q != 0) return launch_anchor(A, B, max_items, st, anchor_variant);
     if (kernel == 0) {
         const uint32_t blocks = uint32_t((max_items + 255) / 256);
         if (entry_bytes == 2) hipLaunchKernelGGL(k_scan_simple<uint16_t>, dim3(blocks), dim3(256), 0, st, A, B);

@@ -15,7 +15,7 @@ uint32_t scan_tiles(uint64_t n);
 void launch_items(const BatchArgs &B, uint64_t blob_bytes, uint64_t max_items, uint64_t *item_base, uint32_t *ticket, uint64_t *status, hipStream_t st);
 void launch_rec_scan(const BatchArgs &B, uint64_t max_items, uint64_t *rec_base, uint32_t *ticket, uint64_t *status, hipStream_t st);
 hipError_t launch_scan(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int kernel,
-                       int class_mode, int ilp, int group_quads, hipStream_t st);
+                       int class_mode, int ilp, int group_quads, hipStream_t st, uint32_t *anchor_variant = nullptr);
 hipError_t launch_walk_runs(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,
                             hipStream_t st);
 hipError_t launch_walk_items(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,
@@ -32,8 +32,11 @@ hipError_t launch_match_small(const DevAutomaton &A, const uint64_t *offsets, co
                               uint64_t *out_prefix, void *out_records, uint32_t cap, hipStream_t st);
 void launch_build_level(const BuildArgs &T, uint32_t lo, uint32_t hi, hipStream_t st);
 void launch_replace_plan(const ReplaceArgs &R, hipStream_t st);
-void launch_replace_emit(const ReplaceArgs &R, hipStream_t st);
-void launch_gather_compact(const GatherArgs &G, hipStream_t st);
+void launch_replace_emit(const ReplaceArgs &R, uint64_t cap, hipStream_t st);
+// exclusive scan of n 64-bit values into out[0..n]; sync = {ticket, pad, scan_tiles(n + 1) status words}, zeroed; total_host (mapped, may be null) receives out[n]
+void launch_scan_u64(const uint64_t *in, uint64_t n, uint64_t *out, uint32_t *sync, uint64_t *total_host, hipStream_t st);
+void launch_gather_pack(const uint64_t *prefix, const uint4 *records, uint64_t nh, uint64_t nrec, uint64_t hay_base, uint64_t rec_base,
+                        uint64_t *out_prefix, uint4 *out_records, uint64_t *closing, uint64_t total_rec, hipStream_t st);
 void launch_stream_read(const void *src, uint64_t bytes, uint32_t *sink, hipStream_t st);
 
 }  // namespace acmi

@@ -270,4 +270,75 @@ def r8() -> Dataset:
     return _planted_ragged("R8", 18, 5000, 9, 24, 41, 0, 10000, b"abcdefghijklmnop", 8)
 
 
+# ---- targeted datasets for the anchor kernel's item-shape variants (tests/test_gpu_variants.py) -------------------------
+# k_scan_anchor has a template per item shape: TINY (items of one 1-KiB row at most, eight to a wave step), SHORT (the rows
+# an item lacks are skipped) and BIG (pattern sets of more than 12,288 anchor q-grams: LDS bitmap + L2 table), which also
+# combines with TINY.  The haystacks here have exactly those shapes, with plants that BEGIN at a row start, END at a row /
+# item end and STRADDLE a row border (rows are the 1-KiB pieces a wave-load covers).
+
+def _regular(name, seed, n_pat, lmin, lmax, n_hay, hay_len, alphabet, plant_at):
+    """Regular haystacks; haystack h gets patterns planted at plant_at[(h + j) % len] for j = 0, 1 (skipped when None)."""
+    ds = generate(name, seed, n_pat, lmin, lmax, n_hay, hay_len, alphabet)
+    for h in range(n_hay):
+        for j in range(2):
+            at = plant_at[(h + 3 * j) % len(plant_at)]
+            if at is None:
+                continue
+            pat = ds.pattern((11 * h + 5 * j + 2) % ds.n_patterns)
+            a = at if at >= 0 else hay_len + at - len(pat) + 1   # negative: the pattern ENDS |at| - 1 bytes before the end
+            a = max(0, min(a, hay_len - len(pat)))
+            lo = int(ds.hay_off[h])
+            ds.hay_blob[lo + a:lo + a + len(pat)] = np.frombuffer(pat, dtype=np.uint8)
+    return ds
+
+
+def t256() -> Dataset:
+    """TINY: 2,048 patterns x 16 B over 640 haystacks of 256 B (regular, 16-byte aligned starts)."""
+    return _regular("T256", 21, 2048, 16, 16, 640, 256, b"abcdef", [0, -1, 120, None, 233, 7])
+
+
+def t512() -> Dataset:
+    """TINY: the same pattern shape over 400 haystacks of 512 B."""
+    return _regular("T512", 22, 2048, 16, 16, 400, 512, b"abcdef", [0, -1, 250, None, 496, 129])
+
+
+def t1k() -> Dataset:
+    """TINY at its limit: 288 haystacks of exactly one row (1,024 B)."""
+    return _regular("T1K", 23, 2048, 16, 16, 288, 1024, b"abcdef", [0, -1, 504, 1001, None, 16])
+
+
+def trag() -> Dataset:
+    """TINY on ragged haystacks of 0..1,024 B (unaligned starts: scanned from the aligned address below, `floor`), plants at the
+    very start and the very end of every haystack; some items exceed a row once the floor is added (the wave's usual path)."""
+    return _planted_ragged("TRAG", 24, 2048, 16, 16, 700, 0, 1024, b"abcdef", 3)
+
+
+def s3k() -> Dataset:
+    """SHORT: 128 haystacks of three rows (3,072 B): plants that straddle a row border, begin at a row start, end at a row end."""
+    return _regular("S3K", 25, 2048, 16, 16, 128, 3072, b"abcdef", [1016, 1024, 2032, -1, 0, 2040, 1008, None])
+
+
+def s2k5() -> Dataset:
+    """SHORT, unaligned: 150 haystacks of 2,500 B back to back (starts at every residue mod 16 that is a multiple of 4)."""
+    return _regular("S2K5", 26, 2048, 16, 16, 150, 2500, b"abcdef", [0, -1, 1018, 1024, 2040, None, 2484])
+
+
+def b512() -> Dataset:
+    """BIG x TINY: 4,000 patterns of 9..24 B over 16 letters (16,000 anchor q-grams of 4 bytes: LDS bitmap + L2 table) over 360
+    haystacks of 512 B."""
+    return _regular("B512", 27, 4000, 9, 24, 360, 512, b"abcdefghijklmnop", [0, -1, 250, None, 488, 3])
+
+
+def brag() -> Dataset:
+    """BIG x TINY on ragged haystacks of 0..1,024 B."""
+    return _planted_ragged("BRAG", 28, 4000, 9, 24, 500, 0, 1024, b"abcdefghijklmnop", 3)
+
+
+def b3k() -> Dataset:
+    """BIG with items of three rows (its tasks are 4 KiB: the quads an item lacks are skipped)."""
+    return _regular("B3K", 29, 4000, 9, 24, 100, 3072, b"abcdefghijklmnop", [1016, 1024, 2030, -1, 0, None])
+
+
+TARGETED = {"T256": t256, "T512": t512, "T1K": t1k, "TRAG": trag, "S3K": s3k, "S2K5": s2k5, "B512": b512, "BRAG": brag, "B3K": b3k}
+
 NAMED = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "R1": r1, "R2": r2, "R3": r3, "R4": r4, "R5": r5, "R6": r6, "R7": r7, "R8": r8}

@@ -80,7 +80,7 @@ def test_lifecycle_and_status_codes():
     assert N.lib.acmi_destroy(None) == N.E_INVALID
     assert N.lib.acmi_strerror(N.E_INVALID) == b"Invalid resource."
     assert N.lib.acmi_strerror(N.E_NOT_INIT) == b"Not initialized."
-    assert N.lib.acmi_version() == b"0.1.0"
+    assert N.lib.acmi_version() == b"0.3.0"
 
 
 def test_no_cpu_fallback_without_device():

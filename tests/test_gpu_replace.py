@@ -74,3 +74,58 @@ def test_replace_quirks_and_errors():
         api.replace_arrays(res, blob, off, 1)
     assert e.value.status == N.E_NO_REPLACEMENT
     api.ahocorasick_deinit(res)
+
+
+@pytest.mark.parametrize("name", ["G2", "R1", "R2", "R5"])
+def test_replace_device_entry_goldens(name):
+    """acmi_replace_batch_device: haystacks resident in HBM, output left there (device prefix sum of the output lengths,
+    copy cut by output bytes) -- same bytes and offsets as the reference's replace.c (goldens)."""
+    import torch
+    from php_aho_corasick_amd import batch
+    cases = {(c["dataset"], c["mode"]): c for c in load_json("replace_golden.json")["cases"]}
+    ds = synth.NAMED[name]()
+    res = _resource(ds)
+    d_blob = torch.from_numpy(ds.hay_blob if ds.hay_blob.size else np.zeros(16, np.uint8)).cuda()
+    d_off = torch.from_numpy(ds.hay_off.astype(np.int64)).cuda()
+    batch.bind_current_stream(res)
+    for mode in (1, 2, 1):   # (the third call reuses buffers sized by the first two)
+        out, off = batch.replace_device(res, d_blob, d_off, mode)
+        out, off = out.cpu().numpy(), off.cpu().numpy().astype(np.uint64)
+        g = cases[(name, mode)]
+        assert int(off[-1]) == g["out_bytes"] == len(out)
+        assert hashlib.sha256(off.tobytes() + out.tobytes()).hexdigest() == g["sha256"], (name, mode)
+    api.ahocorasick_deinit(res)
+
+
+@pytest.mark.parametrize("n_plants", [0, 3, 5000])
+def test_replace_one_big_haystack(n_plants):
+    """The README's one-big-file case: ONE haystack of 6 MiB (its output is cut into 32-KiB ranges over the whole chip),
+    with no, a few and thousands of replacements, output longer and shorter than the input; empty haystacks around it."""
+    import torch
+    from php_aho_corasick_amd import batch
+    rng = np.random.default_rng(5)
+    pats = [b"needle-%03d" % k for k in range(40)] + [b"ndl"]
+    big = rng.integers(97, 123, size=6 << 20, dtype=np.uint8)
+    for k in range(n_plants):
+        p = np.frombuffer(pats[k % len(pats)], dtype=np.uint8)
+        at = int(rng.integers(0, len(big) - 16))
+        big[at:at + len(p)] = p
+    small = np.frombuffer(b"xx needle-007 yy ndl", dtype=np.uint8)
+    blob = np.concatenate([small, big, small])
+    off = np.array([0, 0, len(small), len(small), len(small) + len(big), len(blob), len(blob)], dtype=np.uint64)
+    res = api.ahocorasick_init([{"value": p} for p in pats])
+    o = Oracle("port")
+    for k, p in enumerate(pats):
+        r = None if k % 9 == 4 else (b"" if k % 5 == 0 else (p * 3 if k % 2 else b"#"))
+        api.set_replacement(res, k, r)
+        o.set_replacement(k, r)
+    o.add_patterns(pats)
+    batch.bind_current_stream(res)
+    d_blob, d_off = torch.from_numpy(blob).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()
+    for mode in (1, 2):
+        out, ooff = batch.replace_device(res, d_blob, d_off, mode)
+        out, ooff = out.cpu().numpy(), ooff.cpu().numpy()
+        for h in range(len(off) - 1):
+            want = o.replace(blob[int(off[h]):int(off[h + 1])].tobytes(), mode)
+            assert out[int(ooff[h]):int(ooff[h + 1])].tobytes() == want, (h, mode, n_plants)
+    api.ahocorasick_deinit(res)
