@@ -314,16 +314,21 @@ def host_leg(api, synth, ds, expect_per_tile):
 
 
 
-def _sclk_mhz():
-    """Shader clock of every GPU the kernel driver exposes right now (sysfs pp_dpm_sclk: the level marked '*'), so that a
-    reader can tell which clock level a run sat on; {} when the files are not there."""
+def _sclk_mhz(pci_bus=None):
+    """Shader clock right now (sysfs pp_dpm_sclk: the level marked '*') of the GPU on PCI bus `pci_bus` -- the one this rank
+    runs on -- or of every GPU the kernel driver exposes when the bus is unknown, so that a reader can tell which clock
+    level a run sat on; {} when the files are not there."""
     import glob
     out = {}
     for path in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
         try:
+            card = path.split("/")[4]
+            bus = int(os.path.realpath(os.path.dirname(path)).split("/")[-1].split(":")[1], 16)
+            if pci_bus is not None and bus != pci_bus:
+                continue
             for line in open(path).read().splitlines():
                 if line.rstrip().endswith("*"):
-                    out[path.split("/")[4]] = int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
+                    out[card] = int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
         except Exception:
             pass
     return out
@@ -387,7 +392,11 @@ def short_haystacks_leg(torch, api, batch, synth, dev):
     for hl in (256, 1024, 4001):
         n_tile = max(1, (32 << 20) // hl)
         ds = synth.generate("L", 1, 2048, 16, 16, n_tile, hl, b"abcdef")
-        synth.plant(ds, 31, 5, hl - 16, 7, 3)
+        every = max(1, HAY_LEN // hl)   # the headline's hit density: one planted pattern per 8 KiB of text
+        for h in range(0, n_tile, every):
+            p = np.frombuffer(ds.pattern((7 * h + 3) % ds.n_patterns), dtype=np.uint8)
+            at = int(ds.hay_off[h]) + (31 * h + 5) % (hl - 16)
+            ds.hay_blob[at:at + 16] = p
         res = api.ahocorasick_init([{"id": k, "value": ds.pattern(k)} for k in range(ds.n_patterns)])
         reps = max(1, (1 << 30) // (n_tile * hl))
         nh = reps * n_tile
@@ -400,8 +409,8 @@ def short_haystacks_leg(torch, api, batch, synth, dev):
         o.add_patterns((ds.pat_blob, ds.pat_off))
         n_chk = 64
         pe, re_ = o.match_batch(ds.hay_blob[:int(ds.hay_off[n_chk])], ds.hay_off[:n_chk + 1], True)
-        ok = np.array_equal(prefix[:n_chk + 1], pe) and np.array_equal(rec[:int(pe[-1])], re_) and total == int(prefix[n_tile]) * reps and total >= nh
-        leg = _leg_summary(f"headline patterns over {nh} haystacks x {hl} B ({nh * hl >> 20} MiB){', every start unaligned' if hl % 16 else ''}",
+        ok = np.array_equal(prefix[:n_chk + 1], pe) and np.array_equal(rec[:int(pe[-1])], re_) and total == int(prefix[n_tile]) * reps and total >= nh // every
+        leg = _leg_summary(f"headline patterns over {nh} haystacks x {hl} B ({nh * hl >> 20} MiB){', every start unaligned' if hl % 16 else ''}, one planted pattern per 8 KiB of text",
                            nh * hl, nh, total, ms, scan, walk, res, ok)
         leg.update({"haystack_bytes": hl, "anchor_variant": int(res.stat("anchor_variant")), "tiny_waves": int(res.stat("tiny_waves")),
                     "work_item_bytes": int(res.stat("chunk_bytes"))})
@@ -571,7 +580,11 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    clocks_start = _sclk_mhz()
+    try:
+        pci_bus = int(torch.cuda.get_device_properties(dev_index).pci_bus_id)
+    except Exception:
+        pci_bus = None
+    clocks_start = _sclk_mhz(pci_bus)
 
     # ---- automaton (replicated on every rank) ----
     t0 = time.perf_counter()
@@ -687,7 +700,7 @@ def main():
         dist.all_reduce(one)                          # how many ranks the backend's collective really joined
         ranks_in_collective = int(one.item())
     dt = float(t.item())
-    clocks_end = _sclk_mhz()
+    clocks_end = _sclk_mhz(pci_bus)
     step_gaps = [(b - a) * 1e3 for a, b in zip(end_stamps[:-1], end_stamps[1:])]   # host time between consecutive ends
 
     # the same steps one at a time (begin, end, begin, ...): what a caller that cannot keep two batches in flight sees
