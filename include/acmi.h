@@ -267,7 +267,7 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
 /* Integer options, set before finalize unless noted:
  *   "lds_bytes"      LDS budget for the hot-state tile (default 160 KiB minus slack)
  *   "slab_events"    per work-item event slots before the overflow path (default 8)
- *   "run_cap"        per work-item fix-up runs before the item is rescanned whole (default 8)
+ *   "run_cap"        per work-item fix-up runs before the item is rescanned whole (default 8; 64 with the dense anchor form)
  *   "chunk_bytes"    force the work-item size (0 = automatic)            [any time]
  *   "kernel"         0 = plain global-table walk, 1 = LDS-tile table walk, 2 = anchor q-gram
  *                    filter + exact table walk of the candidates (needs a shortest pattern
@@ -294,6 +294,10 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *                    (one lookup per byte, 1 KiB per state at 256 byte classes) or 8-byte goto / failure records
  *                    laid out along the patterns (the reference's node form, node.h:37-67, flattened): 1 = compact,
  *                    0 = dense, -1 (default) = compact when the dense table would exceed 64 MiB   [before finalize]
+ *   "anchor_dense"   pattern sets whose shortest pattern is 4..6 B (keyword lists): the anchor filter in its dense form -- every
+ *                    pattern anchored by its first four bytes, the window tested at every byte offset of the text: -1 (default)
+ *                    when at most ~ 48 windows per 8 KiB are expected to hit on text that looks like the patterns, 0 never,
+ *                    1 whenever the shortest pattern allows                                         [before finalize]
  *   "anchor_choice"  big pattern sets (anchor mode 2): which aligned window of a pattern is its anchor is chosen so that the
  *                    anchors share bits of the LDS bitmap (greedy set cover: 9 % of the bits set instead of 22 % for 65,536
  *                    patterns, as many fewer probes of the fingerprint table): -1 / 1 = yes (default), 0 = always the
@@ -377,6 +381,8 @@ typedef struct acmi_tables {
     const uint8_t *chain_run;     /* per such state: how many steps from it on lead to id + 1, again such a state (capped at 255) */
     const uint32_t *out_off;      /* per state: first entry of its flat output list */
     const uint32_t *out_list;     /* 2 words per entry: pattern index, pattern length; longest first */
+    uint32_t anchor_dense;        /* 1: the filter tests the 4-byte window at EVERY byte offset against the patterns' first four bytes
+                                     (shortest pattern 4..6 B); anchor_q = 4, anchor_mode = 1, one key per pattern */
 } acmi_tables;
 int acmi_debug_tables(const acmi_handle *h, acmi_tables *out);
 

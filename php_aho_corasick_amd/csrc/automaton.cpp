@@ -518,8 +518,36 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
     fa.anchor_offsets.clear();
     fa.anchor_table.clear();
     fa.anchor_bitmap.clear();
-    if (fa.min_pattern_length >= 7) {
-        const uint32_t q = fa.min_pattern_length >= 19 ? 16u : fa.min_pattern_length >= 15 ? 12u
+    fa.anchor_dense = 0;
+    fa.anchor_dense_rate = 0;
+    // Dense form: the shortest pattern is 4..6 B, so not every occurrence holds an aligned dword to anchor on -- every
+    // pattern is anchored by its first 4 bytes instead and the kernel tests the window at every byte offset.  Worth it only
+    // when few text windows are keys: the estimate draws text from the patterns' own byte frequencies (keyword lists over
+    // letters: 2,048 words / 26^4 = 0.4 % of the windows; 2,048 patterns over six letters: every window -- not eligible).
+    bool every_offset = false;
+    if (fa.min_pattern_length >= 4 && fa.min_pattern_length < 7 && opt.anchor_dense != 0) {
+        std::vector<uint32_t> prefixes;
+        double freq[256] = {0};
+        uint64_t total_bytes = 0;
+        for (const PatternMeta &m : patterns_) {
+            if (!m.accepted) continue;
+            uint32_t w;
+            std::memcpy(&w, pattern_bytes_.data() + m.byte_off, 4);
+            prefixes.push_back(w);
+            for (uint32_t i = 0; i < m.length; ++i) freq[pattern_bytes_[m.byte_off + i]] += 1.0;
+            total_bytes += m.length;
+        }
+        std::sort(prefixes.begin(), prefixes.end());
+        prefixes.erase(std::unique(prefixes.begin(), prefixes.end()), prefixes.end());
+        double rate = 0;
+        for (uint32_t w : prefixes)
+            rate += (freq[w & 0xff] / total_bytes) * (freq[(w >> 8) & 0xff] / total_bytes) * (freq[(w >> 16) & 0xff] / total_bytes) * (freq[w >> 24] / total_bytes);
+        fa.anchor_dense_rate = rate;
+        // up to ~ 48 candidate windows per 8 KiB work item (its run list holds 64)
+        every_offset = prefixes.size() <= kAnchorMaxKeys && (opt.anchor_dense > 0 || rate * 8192.0 <= 48.0);
+    }
+    if (fa.min_pattern_length >= 7 || every_offset) {
+        const uint32_t q = every_offset ? 4u : fa.min_pattern_length >= 19 ? 16u : fa.min_pattern_length >= 15 ? 12u
                          : fa.min_pattern_length >= 11 ? 8u : 4u;
         // (q-gram, pattern, offset) triples, sorted by q-gram: the distinct q-grams are the filter's keys, and a key
         // that stands for exactly ONE (pattern, offset) pair lets k_walk_runs verify a candidate by comparing the
@@ -538,7 +566,7 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
             for (size_t pi = 0; pi < patterns_.size(); ++pi) {
                 const PatternMeta &m = patterns_[pi];
                 if (!m.accepted) continue;
-                for (uint32_t a = 0; a < 4; ++a) {
+                for (uint32_t a = 0; a < (every_offset ? 1u : 4u); ++a) {
                     const uint32_t o = fa.anchor_offsets[pi * 4 + a];
                     Triple t{{0, 0, 0, 0}, uint32_t(pi), o};
                     std::memcpy(t.key.data(), pattern_bytes_.data() + m.byte_off + o, q);
@@ -657,6 +685,8 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
         };
         fa.anchor_slot_pair.clear();
         uint32_t mul = 0x9E3779B1u;
+        // (every_offset: the window is hashed raw, see anchor_hash_dense)
+        auto key_hash = [&](const std::array<uint32_t, 4> &k, uint32_t mul_) { return every_offset ? anchor_hash_dense(k[0], mul_) : anchor_hash(k.data(), q / 4, mul_); };
         if (keys.size() <= kAnchorMaxKeys) {
             std::vector<uint16_t> tab(size_t(kAnchorBuckets) * 4);
             for (int attempt = 0; attempt < 512 && fa.anchor_q == 0; ++attempt, mul = mul * 0x2545F491u + 0x6B43A9B5u) {
@@ -665,7 +695,7 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
                 for (uint32_t b = 0; b < kAnchorBuckets; ++b) std::fill_n(&tab[size_t(b) * 4], 4, anchor_empty(b));
                 bool ok = true;
                 for (size_t ki = 0; ki < keys.size(); ++ki) {
-                    const uint32_t h = anchor_hash(keys[ki].data(), q / 4, mul);
+                    const uint32_t h = key_hash(keys[ki], mul);
                     const uint16_t fp = uint16_t(h >> 16);                   // fingerprint: high half
                     const uint32_t bucket = (h >> 3) & (kAnchorBuckets - 1);  // bits 3..16
                     uint16_t *b = &tab[size_t(bucket) * 4];
@@ -677,7 +707,7 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
                 if (ok) {  // which slot each key went to (only for the seed that is kept)
                     std::vector<size_t> slot_of(keys.size());
                     for (size_t ki = 0; ki < keys.size(); ++ki) {
-                        const uint32_t h = anchor_hash(keys[ki].data(), q / 4, mul);
+                        const uint32_t h = key_hash(keys[ki], mul);
                         const uint16_t fp = uint16_t(h >> 16);
                         const uint32_t bucket = (h >> 3) & (kAnchorBuckets - 1);
                         uint32_t slot = 0;
@@ -691,6 +721,7 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
                     fa.anchor_mode = 1;
                     fa.anchor_mul = mul;
                     fa.anchor_table = tab;
+                    fa.anchor_dense = every_offset ? 1u : 0u;
                 }
             }
         } else {

@@ -39,6 +39,9 @@ struct BuildOptions {
     uint64_t max_table_bytes = 8ull << 30;  // refuse automata whose dense table would exceed this (and that cannot go compact)
     int compact = -1;                       // goto/failure records instead of dense rows for states outside the first
                                             // BFS levels: 1 = always, 0 = never, -1 = when the dense table exceeds 64 MiB
+    int anchor_dense = -1;                  // pattern sets whose shortest pattern is 4..6 B: anchor filter over the 4-byte window at EVERY
+                                            // byte offset, keys = the patterns' first 4 bytes (-1 = when the keys are selective enough
+                                            // on text that looks like the patterns, 0 = never, 1 = whenever the shortest pattern is >= 4 B)
     int anchor_choice = -1;                 // big-set anchor filter: pick each pattern's anchor windows so that they share
                                             // bitmap bits (-1 / 1 = yes, 0 = the first aligned window as in the small-set table)
     uint64_t dense_bytes = 4ull << 20;      // compact: dense rows are kept for the LDS tile, every state of trie depth <= 1
@@ -144,6 +147,11 @@ struct FlatAutomaton {
     //     bits of the hash (from bit anchor_bucket_shift on), fingerprint = (hash >> 16) | 1, 0 = empty slot.
     uint32_t min_pattern_length = 0;
     uint32_t anchor_q = 0;        // 0 = not eligible; else 4, 8, 12 or 16 bytes
+    // "dense" form (mode 1 only, q = 4): every pattern is anchored by its FIRST four bytes and the kernel tests the window at
+    // every byte offset of the text, not only the aligned ones -- for sets whose shortest pattern is 4..6 B (keyword lists),
+    // which have no aligned dword inside every occurrence.  One key per pattern instead of four, hash anchor_hash_dense.
+    uint32_t anchor_dense = 0;
+    double anchor_dense_rate = 0; // expected hit windows per text byte, text drawn from the patterns' own byte frequencies
     uint32_t anchor_mode = 0;     // 0 none, 1 LDS table, 2 LDS bitmap + global table
     uint32_t anchor_mul = 0;      // odd multiplier of the window hash (seed that gave no bucket overflow)
     uint32_t anchor_keys = 0;
@@ -186,6 +194,9 @@ inline uint32_t anchor_hash(const uint32_t *words, uint32_t n_words, uint32_t mu
     if (n_words == 1) h = (h & 0xFFFFFFu) * (mul & 0xFFFFFFu) + (h >> 8);  // a lone dword still gets one multiply
     return h;
 }
+// dense form: ONE multiply-add on the raw window (v_lshrrev + v_mad_u32_u24 on the device): its low three bytes times
+// the multiplier plus its high three bytes -- every byte reaches bucket and fingerprint bits
+inline uint32_t anchor_hash_dense(uint32_t w, uint32_t mul) { return (w & 0xFFFFFFu) * (mul & 0xFFFFFFu) + (w >> 8); }
 inline uint16_t anchor_empty(uint32_t bucket) { return uint16_t(((bucket >> (kAnchorBucketBits - 1)) & 1u) ^ 1u); }
 
 class Automaton {

@@ -51,6 +51,7 @@ struct DevAutomaton {
     uint32_t anchor_q, anchor_mul, min_pattern_length, max_pattern_length;
     uint32_t anchor_mode, anchor_bucket_mask, anchor_bucket_shift;   // mode 2: bucket = (hash >> shift) & mask
     uint32_t anchor_choice;      // 1: a pattern's anchor window may lie deeper than its first aligned dword (offset in the pair record)
+    uint32_t anchor_dense;       // 1: windows at every byte offset, keys = the patterns' first four bytes (automaton.hpp)
 };
 
 // One batch launch.

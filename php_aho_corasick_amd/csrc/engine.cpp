@@ -88,6 +88,7 @@ struct acmi_handle {
     // options
     uint32_t slab_events = 8;
     uint32_t run_cap = 8;
+    bool run_cap_set = false;  // by the caller; else the dense anchor form takes 64 (a work item has tens of candidate windows there)
     uint64_t chunk_opt = 0;
     int kernel = 3;  // 0 plain global table, 1 LDS-tile walk, 2 anchor filter (if eligible), 3 automatic
     // automatic mode: a batch on which the fast kernel lost (most bytes had to be walked exactly anyway) moves the
@@ -439,6 +440,7 @@ int ensure_device(acmi_handle *h) {
     A.anchor_bitmap = fa.anchor_mode == 2 ? h->d_bitmap.as<uint32_t>() : nullptr;
     A.anchor_bucket_mask = fa.anchor_mode == 2 ? (1u << fa.anchor_bucket_bits) - 1u : 0u;
     A.anchor_choice = fa.anchor_choice;
+    A.anchor_dense = fa.anchor_dense;
     A.anchor_bucket_shift = fa.anchor_bucket_shift;
     A.anchor_mul = fa.anchor_mul;
     A.min_pattern_length = fa.min_pattern_length;
@@ -625,7 +627,7 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     HIPCHK(h, h->d_rec_base.ensure_keep((max_items + 2) * 8, h->retired));
     HIPCHK(h, h->d_slab.ensure_keep(max_items * K * 8, h->retired));
     HIPCHK(h, h->d_ovf.ensure_keep(max_items * 4, h->retired));
-    const uint32_t Q = std::max<uint32_t>(1, h->run_cap);
+    const uint32_t Q = (!h->run_cap_set && kernel == 2 && fa.anchor_dense) ? 64u : std::max<uint32_t>(1, h->run_cap);
     HIPCHK(h, h->d_runs.ensure_keep(max_items * Q * 16, h->retired));
     HIPCHK(h, h->d_run_count.ensure_keep(max_items * 4, h->retired));
     uint8_t *zero = h->d_zero.as<uint8_t>();
@@ -1227,6 +1229,7 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
         } else if (k == "run_cap") {
             if (value < 1 || value > 1024) return ACMI_E_ARG;
             h->run_cap = uint32_t(value);
+            h->run_cap_set = true;
         } else if (k == "chunk_bytes") {
             if (value < 0) return ACMI_E_ARG;
             h->chunk_opt = uint64_t(value);
@@ -1270,6 +1273,9 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
         } else if (k == "compact") {
             if (h->aut.finalized()) return ACMI_E_FINALIZED;
             h->bopt.compact = value < 0 ? -1 : (value ? 1 : 0);
+        } else if (k == "anchor_dense") {
+            if (h->aut.finalized()) return ACMI_E_FINALIZED;
+            h->bopt.anchor_dense = value < 0 ? -1 : (value ? 1 : 0);
         } else if (k == "anchor_choice") {
             if (h->aut.finalized()) return ACMI_E_FINALIZED;
             h->bopt.anchor_choice = value < 0 ? -1 : (value ? 1 : 0);
@@ -1341,6 +1347,8 @@ int acmi_get_stat(const acmi_handle *h, const char *key, double *value) {
         else if (k == "max_out_count") *value = fa.max_out_count;
         else if (k == "anchor_pairs") *value = double(fa.anchor_pairs_count);
         else if (k == "anchor_choice") *value = fa.anchor_choice;
+        else if (k == "anchor_dense") *value = fa.anchor_dense;
+        else if (k == "anchor_dense_rate") *value = fa.anchor_dense_rate;
         else if (k == "built_on_device") *value = h->aut.built_on_device() ? 1 : 0;
         else if (k == "compact") *value = fa.compact;
         else if (k == "dense_rows") *value = fa.n_dense_rows;
@@ -1408,6 +1416,7 @@ int acmi_debug_tables(const acmi_handle *h, acmi_tables *out) {
         out->n_flat_outputs = uint32_t(fa.out_list.size() / 2);
         out->out_off = fa.out_off.empty() ? nullptr : fa.out_off.data();
         out->out_list = fa.out_list.empty() ? nullptr : fa.out_list.data();
+        out->anchor_dense = fa.anchor_dense;
         return ACMI_OK;
     });
 }

@@ -809,10 +809,16 @@ __device__ __forceinline__ bool verify_candidate(const DevAutomaton &A, const ui
     if (w + A.anchor_q > n) return true;   // the window reaches past the item's end: no pattern anchored there fits
     // the window's hash (automaton.hpp anchor_hash; the window lies inside the item: the filter tested it)
     const uint32_t nw = A.anchor_q >> 2;
-    uint32_t h = anchor_fold_dev(load4u(p + w));
+    uint32_t h;
+    if (A.anchor_dense) {  // the raw window, one multiply-add (automaton.hpp anchor_hash_dense)
+        const uint32_t t4 = load4u(p + w);
+        h = anchor_mad(t4, A.anchor_mul, t4 >> 8);
+    } else {
+        h = anchor_fold_dev(load4u(p + w));
 #pragma unroll 1
-    for (uint32_t i = 1; i < nw; ++i) h = anchor_mad(h, A.anchor_mul, anchor_fold_dev(load4u(p + w + 4u * i)));
-    if (nw == 1u) h = anchor_mad(h, A.anchor_mul, h >> 8);
+        for (uint32_t i = 1; i < nw; ++i) h = anchor_mad(h, A.anchor_mul, anchor_fold_dev(load4u(p + w + 4u * i)));
+        if (nw == 1u) h = anchor_mad(h, A.anchor_mul, h >> 8);
+    }
     // its slot in the fingerprint table
     uint32_t slot = 0xFFFFFFFFu;
     if (A.anchor_mode == 2u) {
@@ -863,7 +869,7 @@ __device__ __forceinline__ bool verify_candidate(const DevAutomaton &A, const ui
         } else if (len >= 8u) {
             const uint2 a0 = load8u(tp), b0 = load8u(pp), a1 = load8u(tp + len - 8u), b1 = load8u(pp + len - 8u);
             diff = (a0.x ^ b0.x) | (a0.y ^ b0.y) | (a1.x ^ b1.x) | (a1.y ^ b1.y);
-        } else {  // 7 bytes (patterns shorter than that are not anchor-eligible)
+        } else {  // 4..7 bytes (the dense form anchors patterns from 4 B on)
             diff = (load4u(tp) ^ load4u(pp)) | (load4u(tp + len - 4u) ^ load4u(pp + len - 4u));
         }
         if (diff) continue;
@@ -915,8 +921,8 @@ __device__ __forceinline__ uint32_t run_epilogue_fast(const DevAutomaton &A, con
                 ++r;
                 if (r >= nr) break;
                 run = runs[uint64_t(r) * B.run_stride];
-                if (run.x != hi) break;  // not adjacent: the next cluster
-                hi = run.y;
+                if (run.x > hi) break;  // neither adjacent nor overlapping (the dense form does not clamp its runs): the next cluster
+                hi = run.y > hi ? run.y : hi;
                 windows = windows && entry_is_window(run.z);
                 if (windows) windows = verify_candidate(A, p, n, it.floor, run.z & ~kEntryWindow, v, nv);
                 ++count;
@@ -953,7 +959,10 @@ __device__ __forceinline__ uint32_t run_epilogue_fast(const DevAutomaton &A, con
             // walk the cluster as one range: from the root, m_min-1 bytes before a window's own lower bound (every
             // pattern that ends in the cluster begins at or after the first window - 3), Lmax-1 bytes otherwise
             uint32_t st = 0, from = lo, stop_from = 0xFFFFFFFFu;
-            if (!A.anchor_choice && entry_is_window(first.z) && lo + 4u == (first.z & ~kEntryWindow) + A.min_pattern_length) {
+            if (A.anchor_dense && entry_is_window(first.z)) {
+                // dense form: every pattern BEGINS at its window, and the cluster's first window is its leftmost
+                from = first.z & ~kEntryWindow;
+            } else if (!A.anchor_choice && entry_is_window(first.z) && lo + 4u == (first.z & ~kEntryWindow) + A.min_pattern_length) {
                 const uint32_t warm = A.min_pattern_length - 1u;
                 from = lo > warm ? lo - warm : 0u;
                 // a lone window: nothing is alive once the state is shallow two bytes past the window start
@@ -974,6 +983,19 @@ __device__ __forceinline__ uint32_t run_epilogue_fast(const DevAutomaton &A, con
         if (ev.n_ev > B.slab_events) B.overflow_list[atomicAdd(&B.counters[0], 1u)] = uint32_t(item);
     }
     return walked;
+}
+
+// Inclusive prefix sum over the 64 lanes of a wave in registers (DPP): within the rows of 16 lanes by shifts of 1, 2, 4, 8,
+// then row 0's total into row 1 and row 2's into row 3 (row_bcast:15), then the first half's total into the second
+// (row_bcast:31).  All lanes must be active.
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
+    x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x111 /* row_shr:1 */, 0xf, 0xf, true));
+    x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x112 /* row_shr:2 */, 0xf, 0xf, true));
+    x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x114 /* row_shr:4 */, 0xf, 0xf, true));
+    x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x118 /* row_shr:8 */, 0xf, 0xf, true));
+    x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x142 /* row_bcast:15 */, 0xa, 0xf, false));
+    x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x143 /* row_bcast:31 */, 0xc, 0xf, false));
+    return x;
 }
 
 // Sum `v` over the wave and add it (in units of 16 bytes) to counters[7]: how much of the batch the
@@ -1305,8 +1327,16 @@ __device__ __forceinline__ bool anchor_next(const DevAutomaton &A, const BatchAr
 // A variant of its own because the test, one scalar branch per row, costs the 8-KiB-item kernel its schedule.
 // TINY: a wave whose items are all at most one row (1 KiB, aligned: haystacks of a few hundred bytes) takes them G to a task,
 // ROW r of the task = item t*G + r, instead of spending a whole step on each (512-byte haystacks: 8 x fewer steps).
-template <int QW, bool BIG, bool SHORT, bool TINY = false>
+// DENSE (QW == 1, small sets): pattern sets whose shortest pattern is 4..6 B (keyword lists) have no aligned dword inside
+// every occurrence, so every pattern is anchored by its FIRST four bytes and the 4-byte window at EVERY byte offset is
+// tested -- 16 windows per quad instead of 4, hashed raw (anchor_hash_dense: a shift and a multiply-add).  Hit windows are
+// an order of magnitude more frequent than with aligned anchors (a keyword list: ~ 20 per 8 KiB of text), so they are
+// turned into runs by VECTOR code -- a wave prefix sum over the lanes' hit counts gives every hit its slot in the item's
+// run list -- not one by one through the scalar unit; runs keep their natural bounds (they may overlap: k_walk_runs joins
+// them into clusters).
+template <int QW, bool BIG, bool SHORT, bool TINY = false, bool DENSE = false>
 __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, BatchArgs B) {
+    static_assert(!DENSE || (QW == 1 && !BIG), "the dense form exists for 4-byte windows and the LDS table only");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int G = BIG ? 4 : 8;  // 16-byte quads per lane and task
     constexpr uint32_t TQ = G * 64u;  // quads per task: 8 KiB, BIG 4 KiB (two tasks in flight in the registers of one)
@@ -1323,7 +1353,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t mul = A.anchor_mul;
     const uint32_t q = QW * 4u, m_min = A.min_pattern_length, l_max = A.max_pattern_length;
-    const uint32_t lo_bias = A.anchor_choice ? q - 1u : m_min - 4u;
+    const uint32_t lo_bias = DENSE ? m_min - 1u : (A.anchor_choice ? q - 1u : m_min - 4u);
     const uint64_t total_items = B.item_base[B.n_haystacks];
 
     // Persistent mode: waves pull batches of items from counters[1] until none are left.
@@ -1544,6 +1574,66 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                 for (int r = 0; r < G; ++r) z[r] = (m >> (4 * r)) & 15u;
                 zany = m;
             }
+        } else if constexpr (DENSE) {
+        // 16 windows per quad, four at a time: step t = 4 r + j takes dword j of row r -- the three windows that begin in
+        // dword j-1 and end in dword j, and dword j itself -- i.e. the windows ENDING at bytes 4j .. 4j+3 of the quad (bit e
+        // of z[r] = the window ending at byte e).  Same software pipeline as below: the four bucket reads of step t are in
+        // flight while step t-1's are compared.  The dword to the left of a quad's first is the neighbouring lane's last
+        // (DPP), lane 0's the last dword of lane 63 in the previous row (tail[0]: raw text here, not a hash prefix).
+        uint32_t hh[2][4];
+        u32x2 bb[2][4];
+        uint32_t rows = SHORT ? ((sc.nq - sc.c * TQ < TQ ? sc.nq - sc.c * TQ : TQ) + 63u) >> 6 : uint32_t(G);
+        if constexpr (TINY) {
+            if (tiny_on) rows = tcnt - tscan * uint32_t(G) < uint32_t(G) ? tcnt - tscan * uint32_t(G) : uint32_t(G);
+        }
+        uint32_t left = 0;  // the dword in front of the current row's quad
+#pragma unroll
+        for (int t = 0; t <= 4 * G; ++t) {
+            const int r = t >> 2, j = t & 3;
+            if (t < 4 * G) {
+                const bool live = !SHORT || uint32_t(r) < rows;
+                if (j == 0 && live) {
+                    if constexpr (TINY) {
+                        if (tiny_on) tail[0] = 0;  // every row begins an item: nothing to the left of its quad 0
+                    }
+                    const uint32_t wrap = __builtin_amdgcn_mov_dpp(tail[0], 0x13C /* wave_ror:1 */, 0xf, 0xf, false);
+                    left = __builtin_amdgcn_update_dpp(wrap, buf[r].w, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                    tail[0] = buf[r].w;
+                }
+                if (live) {
+                    const uint32_t dj = j == 0 ? buf[r].x : j == 1 ? buf[r].y : j == 2 ? buf[r].z : buf[r].w;
+                    const uint32_t dm = j == 0 ? left : j == 1 ? buf[r].x : j == 2 ? buf[r].y : buf[r].z;
+                    uint32_t *h4 = hh[t & 1];
+                    const uint32_t w1 = __builtin_amdgcn_alignbyte(dj, dm, 1), w2 = __builtin_amdgcn_alignbyte(dj, dm, 2), w3 = __builtin_amdgcn_alignbyte(dj, dm, 3);
+                    h4[0] = anchor_mad(w1, mul, w1 >> 8);
+                    h4[1] = anchor_mad(w2, mul, w2 >> 8);
+                    h4[2] = anchor_mad(w3, mul, w3 >> 8);
+                    h4[3] = anchor_mad(dj, mul, dj >> 8);
+                }
+                // the row is consumed: reload its registers with the same row of the task two steps ahead
+                if (j == 3) buf[r] = load_quad(ld, r);
+                if (live) {
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) bb[t & 1][w] = anchor_bucket(hh[t & 1][w]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (t > 0 && (!SHORT || uint32_t((t - 1) >> 2) < rows)) {
+                const u32x2 *b4 = bb[(t - 1) & 1];
+                const uint32_t *h4 = hh[(t - 1) & 1];
+                uint32_t zz = 0xFFFFFFFFu;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) zz = anchor_compare(b4[w], h4[w], zz);
+                if (__builtin_expect(__any(has_zero_half(zz)), 0)) {
+                    uint32_t m = 0;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) m |= has_zero_half(anchor_compare(b4[w], h4[w], 0xFFFFFFFFu)) ? (1u << w) : 0u;
+                    z[(t - 1) >> 2] |= m << (4 * ((t - 1) & 3));
+                    zany |= m;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         } else {
         // Software pipeline over the quads, pinned with sched_barriers: the four bucket reads of quad r
         // are in flight while quad r-1's buckets are compared, so a wave never sits on LDS latency
@@ -1623,6 +1713,65 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                 }
             }
         };
+        if constexpr (DENSE) {
+            // Hits -> runs by vector code.  Per row (its quads ascend with the lane, so (row, lane, byte) order is text
+            // order): a lane keeps the hit windows that can hold a pattern at all -- they begin inside the item and a pattern
+            // of the shortest length would end inside it -- counts them, a wave prefix sum gives each its index in the
+            // item's run list, and the lanes write their own entries into the LDS stage (flushed to the run lists in bulk).
+            // Runs are not clamped against each other: [start + m_min - 1, start + Lmax) each, possibly overlapping.
+            if (__any(zany != 0)) {
+#pragma unroll
+                for (int r = 0; r < G; ++r) {
+                    if (__ballot(z[r] != 0) == 0) continue;
+                    uint32_t k_item = sc.k, n_item = sc.n, head = sc.head, qi = sc.c * TQ + uint32_t(r) * 64u + lane, nq_item = sc.nq;
+                    if constexpr (TINY) {
+                        if (tiny_on) {  // row r is item tscan * G + r
+                            k_item = tscan * uint32_t(G) + uint32_t(r);
+                            if (k_item >= tcnt) continue;
+                            n_item = __builtin_amdgcn_readlane(rec.z, k_item);
+                            head = 0;
+                            qi = lane;
+                            nq_item = (n_item + 15u) >> 4;
+                            nrun = 0;
+                        }
+                    }
+                    // windows that cannot anchor anything: begin before the item's first byte, or too near its end
+                    uint32_t zr = qi < nq_item ? z[r] : 0u;
+                    const uint32_t pos0 = head + (qi << 4);            // scan coordinate of the quad's first byte
+                    if (pos0 < 3u) zr &= ~((1u << (3u - pos0)) - 1u);   // start = pos0 + e - 3 >= 0
+                    {
+                        // start + m_min <= n_item  <=>  e <= n_item + 3 - m_min - pos0
+                        const int32_t emax = int32_t(n_item + 3u) - int32_t(m_min) - int32_t(pos0);
+                        if (emax < 15) zr = emax < 0 ? 0u : (zr & ((2u << emax) - 1u));
+                    }
+                    const uint32_t cnt = uint32_t(__builtin_popcount(zr));
+                    const uint32_t incl = wave_inclusive_sum(cnt);
+                    const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+                    if (total != 0) {
+                        if (nrun <= B.run_cap && nrun + total <= B.run_cap && total <= stage.cap) {
+                            if (stage.count + total > stage.cap) stage_flush(B, wave_first, stage, lane);
+                            uint32_t at = stage.count + incl - cnt, idx = nrun + incl - cnt;
+                            for (uint32_t m = zr; m != 0; m &= m - 1, ++at, ++idx) {
+                                const uint32_t start = pos0 + uint32_t(__builtin_ctz(m)) - 3u;
+                                const uint32_t hi = start + l_max < n_item ? start + l_max : n_item;
+                                stage.slots[at] = make_uint4(k_item | (idx << 8), start + lo_bias, hi, kEntryWindow | start);
+                            }
+                            stage.count += total;
+                            nrun += total;
+                        } else {
+                            nrun = B.run_cap + 1u;  // more windows than the run list holds: the whole item is walked
+                        }
+                    }
+                    if constexpr (TINY) {
+                        if (tiny_on) nrun_vec = lane == k_item ? nrun : nrun_vec;
+                    }
+                }
+            }
+            if constexpr (TINY) {
+                if (tiny_on) return;
+            }
+            return;
+        }
         if constexpr (TINY) {
             if (tiny_on) {  // row r is item tscan * G + r: its hits in lane order, its run count handed to its lane
                 if (__any(zany != 0)) {
@@ -2737,7 +2886,7 @@ static hipError_t launch_anchor(const DevAutomaton &A, const BatchArgs &B, uint6
     if (variant) {
         const bool big = A.anchor_mode == 2, tiny = B.tiny_items != 0;
         const bool shrt = !big && (tiny || B.short_items != 0);
-        *variant = (A.anchor_q / 4u) | (big ? 8u : 0u) | (shrt ? 16u : 0u) | (tiny ? 32u : 0u);
+        *variant = (A.anchor_q / 4u) | (big ? 8u : 0u) | (shrt ? 16u : 0u) | (tiny ? 32u : 0u) | (A.anchor_dense ? 64u : 0u);
     }
     const uint64_t per_block = uint64_t(kLdsThreads / 64u) * B.wave_items;
     const uint64_t want = (max_items + per_block - 1) / per_block;
@@ -2750,6 +2899,11 @@ static hipError_t launch_anchor(const DevAutomaton &A, const BatchArgs &B, uint6
         hipLaunchKernelGGL(fn, dim3(blocks), dim3(kLdsThreads), lds, st, A, B);
         return hipGetLastError();
     };
+    if (A.anchor_dense) {  // windows at every byte offset (shortest pattern 4..6 B)
+        if (B.tiny_items) return go(k_scan_anchor<1, false, true, true, true>);
+        if (B.short_items) return go(k_scan_anchor<1, false, true, false, true>);
+        return go(k_scan_anchor<1, false, false, false, true>);
+    }
     if (B.tiny_items) {  // haystacks of a few hundred bytes: the variants whose waves pack one-row items G to a task
         if (A.anchor_mode == 2) {
             if (A.anchor_q == 4) return go(k_scan_anchor<1, true, false, true>);

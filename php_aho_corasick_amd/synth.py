@@ -339,6 +339,32 @@ def b3k() -> Dataset:
     return _regular("B3K", 29, 4000, 9, 24, 100, 3072, b"abcdefghijklmnop", [1016, 1024, 2030, -1, 0, None])
 
 
-TARGETED = {"T256": t256, "T512": t512, "T1K": t1k, "TRAG": trag, "S3K": s3k, "S2K5": s2k5, "B512": b512, "BRAG": brag, "B3K": b3k}
+# ---- pattern sets whose shortest pattern is 4..6 B: the anchor filter's dense form (windows at every byte offset) ----------
+
+def k1() -> Dataset:
+    """Keyword list: 600 words of 4..12 letters over text of letters and spaces, ragged haystacks, planted (at the very start,
+    the very end and inside): a few candidate windows per KiB, most of them true 4-letter prefixes of longer words."""
+    return _planted_ragged("K1", 31, 600, 4, 12, 70, 0, 9000, bytes(range(97, 123)) + b"     ", 6)
+
+
+def k2() -> Dataset:
+    """Binary signatures of 4..9 B over Sigma=256, 2,500 of them; long ragged haystacks."""
+    return _planted_ragged("K2", 32, 2500, 4, 9, 40, 0, 20000, None, 8)
+
+
+def k3() -> Dataset:
+    """80 patterns of exactly 5..6 B over 12 letters, nested plants (overlapping candidate windows: clusters), short haystacks
+    (the tiny-item path of the dense form)."""
+    ds = _planted_ragged("K3", 33, 80, 5, 6, 500, 0, 700, b"abcdefghijkl", 4)
+    for h in range(0, ds.n_haystacks, 3):   # two patterns overlapping by two bytes, and one right behind the other
+        lo, hi = int(ds.hay_off[h]), int(ds.hay_off[h + 1])
+        a, b = ds.pattern((5 * h + 1) % ds.n_patterns), ds.pattern((7 * h + 2) % ds.n_patterns)
+        if hi - lo >= 40:
+            t = np.frombuffer(a + b[2:] + a + b, dtype=np.uint8)
+            ds.hay_blob[lo + 9:lo + 9 + len(t)] = t
+    return ds
+
+
+TARGETED = {"T256": t256, "T512": t512, "T1K": t1k, "TRAG": trag, "S3K": s3k, "S2K5": s2k5, "B512": b512, "BRAG": brag, "B3K": b3k, "K1": k1, "K2": k2, "K3": k3}
 
 NAMED = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "R1": r1, "R2": r2, "R3": r3, "R4": r4, "R5": r5, "R6": r6, "R7": r7, "R8": r8}

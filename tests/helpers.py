@@ -84,6 +84,7 @@ class FlatTables:
         self.anchor_mode, self.anchor_bucket_bits = t.anchor_mode, t.anchor_bucket_bits
         self.anchor_bucket_shift = t.anchor_bucket_shift
         self.anchor_choice = t.anchor_choice
+        self.anchor_dense = t.anchor_dense
         self.anchor_offsets = None   # filled by test code that knows the pattern count
         self._anchor_offsets_ptr = t.anchor_offsets
         self.anchor = self.anchor_bitmap = None
@@ -99,6 +100,10 @@ class FlatTables:
     def anchor_probe(self, window: bytes) -> bool:
         """The device's window test (k_scan_anchor), restated: hash q bytes, look the fingerprint up."""
         q = self.anchor_q
+        if getattr(self, "anchor_dense", 0):   # the raw window, one multiply-add (automaton.hpp anchor_hash_dense)
+            w = int.from_bytes(window[:4], "little")
+            h = ((w & 0xFFFFFF) * (self.anchor_mul & 0xFFFFFF) + (w >> 8)) & 0xFFFFFFFF
+            return int(h >> 16) in [int(x) for x in self.anchor[(h >> 3) & 0x3FFF]]
         words = np.frombuffer(window[:q], dtype="<u4").astype(np.uint64)
         fold = [(int(w) ^ (int(w) >> 11)) & 0xFFFFFFFF for w in words]
         h = fold[0]

@@ -110,7 +110,7 @@ void walk(const FlatAutomaton &fa, const uint8_t *text, size_t n, int find_all, 
 long anchor_slot(const FlatAutomaton &fa, const uint8_t *window) {
     uint32_t words[4] = {0, 0, 0, 0};
     std::memcpy(words, window, fa.anchor_q);
-    const uint32_t h = anchor_hash(words, fa.anchor_q / 4, fa.anchor_mul);
+    const uint32_t h = fa.anchor_dense ? anchor_hash_dense(words[0], fa.anchor_mul) : anchor_hash(words, fa.anchor_q / 4, fa.anchor_mul);
     if (fa.anchor_mode == 2) {
         const uint16_t fp = uint16_t((h >> 16) | 1u);
         const size_t bucket = (h >> fa.anchor_bucket_shift) & ((1u << fa.anchor_bucket_bits) - 1u);
@@ -126,7 +126,7 @@ long anchor_slot(const FlatAutomaton &fa, const uint8_t *window) {
 bool anchor_probe(const FlatAutomaton &fa, const uint8_t *window) {
     uint32_t words[4] = {0, 0, 0, 0};
     std::memcpy(words, window, fa.anchor_q);
-    const uint32_t h = anchor_hash(words, fa.anchor_q / 4, fa.anchor_mul);
+    const uint32_t h = fa.anchor_dense ? anchor_hash_dense(words[0], fa.anchor_mul) : anchor_hash(words, fa.anchor_q / 4, fa.anchor_mul);
     if (fa.anchor_mode == 2) {
         if (!((fa.anchor_bitmap[h >> 17] >> ((h >> 12) & 31u)) & 1u)) return false;
         const uint16_t fp = uint16_t((h >> 16) | 1u);
@@ -154,7 +154,7 @@ int run_case(uint64_t seed, bool verbose) {
     }
     const uint32_t shape = r.below(8);
     const uint32_t np = shape == 7 ? 1 + r.below(4) : 1 + r.below(shape == 6 ? 3000 : 300);
-    const uint32_t lmin = shape == 3 ? 7 + r.below(12) : 1, lmax = shape == 0 ? 4 : shape == 1 ? 16 : shape == 2 ? 64 : shape == 3 ? lmin + r.below(40) : shape == 7 ? 1024 : 12;
+    const uint32_t lmin = shape == 3 ? 7 + r.below(12) : (shape == 4 || shape == 5) ? 4 + r.below(3) : 1 /* shapes 4, 5: 4..6 B shortest, the dense anchor form */, lmax = shape == 0 ? 4 : shape == 1 ? 16 : shape == 2 ? 64 : shape == 3 ? lmin + r.below(40) : shape == 7 ? 1024 : 12;
     const uint32_t calls = 1 + r.below(3);
     // patterns (caller order), with empties / over-long / duplicates mixed in
     std::vector<std::vector<uint8_t>> pats;
@@ -182,6 +182,7 @@ int run_case(uint64_t seed, bool verbose) {
     static const uint64_t dense_opts[] = {0, 4096, 65536, 4ull << 20};
     opt.dense_bytes = dense_opts[r.below(4)];
     opt.max_flat_outputs = r.below(4) == 0 ? 0 : (1ull << 25);
+    opt.anchor_dense = int(r.below(3)) - 1;   // the dense anchor form (shortest pattern 4..6 B): automatic, never, whenever possible
 
     Automaton aut;
     orc_trie *o = orc_create();
@@ -217,7 +218,7 @@ int run_case(uint64_t seed, bool verbose) {
     if (fa.anchor_q) {
         for (const PatternMeta &m : aut.patterns()) {
             if (!m.accepted) continue;
-            for (uint32_t a = 0; a < 4; ++a) {
+            for (uint32_t a = 0; a < (fa.anchor_dense ? 1u : 4u); ++a) /* dense form: one key per pattern, its first four bytes */ {
                 const uint32_t off = fa.anchor_offsets[size_t(&m - aut.patterns().data()) * 4 + a];
                 if (off % 4 != a || off + fa.anchor_q > m.length) { std::fprintf(stderr, "seed %llu: bad anchor offset\n", (unsigned long long)seed); bad = 1; continue; }
                 if (!anchor_probe(fa, aut.pattern_bytes().data() + m.byte_off + off)) {
@@ -231,7 +232,7 @@ int run_case(uint64_t seed, bool verbose) {
         for (size_t pi = 0; pi < aut.patterns().size() && !fa.anchor_slot_pair.empty(); ++pi) {
             const PatternMeta &m = aut.patterns()[pi];
             if (!m.accepted) continue;
-            for (uint32_t a = 0; a < 4; ++a) {
+            for (uint32_t a = 0; a < (fa.anchor_dense ? 1u : 4u); ++a) /* dense form: one key per pattern, its first four bytes */ {
                 const uint32_t off = fa.anchor_offsets[pi * 4 + a];
                 const long slot = anchor_slot(fa, aut.pattern_bytes().data() + m.byte_off + off);
                 if (slot < 0) { std::fprintf(stderr, "seed %llu: no slot\n", (unsigned long long)seed); bad = 1; continue; }

@@ -146,3 +146,42 @@ def test_anchor_not_offered_for_short_patterns():
         api.ahocorasick_finalize(res)
         assert FlatTables(res).anchor_q == 0
         api.ahocorasick_deinit(res)
+
+
+@pytest.mark.parametrize("name", ["K1", "K2", "K3"])
+def test_dense_anchor_form_has_no_false_negatives(name):
+    """Shortest pattern 4..6 B: the filter's dense form -- one key per pattern, its first four bytes, hashed raw -- must probe
+    positive for every accepted pattern; random windows almost never do."""
+    ds = synth.TARGETED[name]()
+    res = resource_for(ds, keep_host_tables=1)
+    api.ahocorasick_finalize(res)
+    ft = FlatTables(res)
+    assert ft.anchor_dense == 1 and ft.anchor_q == 4 and ft.anchor_mode == 1 and 4 <= ft.min_pattern_length <= 6
+    assert res.stat("anchor_dense_rate") * 8192 <= 48
+    for k in range(ds.n_patterns):
+        assert ft.anchor_probe(ds.pattern(k)[:4]), (name, k)
+    rng = np.random.default_rng(6)
+    fp = sum(ft.anchor_probe(rng.integers(0, 256, 4, dtype=np.uint8).tobytes()) for _ in range(4000))
+    assert fp <= 4
+    api.ahocorasick_deinit(res)
+
+
+def test_dense_anchor_form_only_when_selective():
+    """2,048 patterns over six letters plus one of five bytes: every 4-letter window is some pattern's prefix -- the estimate
+    says so and the dense form is not chosen (the table walk is); it can be forced."""
+    base = synth.g1(1)
+    pats = base.patterns() + [b"abcde"]
+    res = api.ahocorasick_init([{"value": p} for p in pats])
+    api.ahocorasick_finalize(res)
+    assert res.stat("anchor_q") == 0 and res.stat("anchor_dense") == 0 and res.stat("anchor_dense_rate") * 8192 > 48
+    api.ahocorasick_deinit(res)
+    res = api.ahocorasick_init([{"value": p} for p in pats])
+    res.set_option("anchor_dense", 1)
+    api.ahocorasick_finalize(res)
+    assert res.stat("anchor_q") == 4 and res.stat("anchor_dense") == 1
+    api.ahocorasick_deinit(res)
+    res = api.ahocorasick_init([{"value": p} for p in synth.k1().patterns()])
+    res.set_option("anchor_dense", 0)
+    api.ahocorasick_finalize(res)
+    assert res.stat("anchor_q") == 0
+    api.ahocorasick_deinit(res)

@@ -3,7 +3,8 @@ rows an item lacks are skipped), BIG (LDS bitmap + L2 fingerprint table) and BIG
 shapes (synth.TARGETED: regular 256 B / 512 B / 1 KiB, ragged <= 1 KiB, 3 KiB and 2,500 B; plants that begin at a row start,
 end at a row / item end and straddle a row border), against goldens made by the compiled reference
 (tests/golden/golden_targeted.json, tests/golden/make_golden.py).  `anchor_variant` and `tiny_waves` (acmi_get_stat) prove
-which template and which wave path ran."""
+which template and which wave path ran.  K1..K3: pattern sets whose shortest pattern is 4..6 B -- the filter's dense form
+(bit 64)."""
 import numpy as np
 import pytest
 
@@ -13,7 +14,7 @@ from php_aho_corasick_amd import api, synth
 
 pytestmark = pytest.mark.gpu
 
-BIG, SHORT, TINY = 8, 16, 32
+BIG, SHORT, TINY, DENSE = 8, 16, 32, 64
 
 
 @pytest.fixture(scope="module")
@@ -33,7 +34,9 @@ def _check(res, ds, golden, name, path):
 # dataset -> (bits the automatic choice must set, bits it must not set, tiny waves expected)
 EXPECT = {"T256": (TINY | SHORT, BIG, True), "T512": (TINY | SHORT, BIG, True), "T1K": (TINY | SHORT, BIG, True), "TRAG": (TINY | SHORT, BIG, True),
           "S3K": (SHORT, BIG | TINY, False), "S2K5": (SHORT, BIG | TINY, False),
-          "B512": (BIG | TINY, 0, True), "BRAG": (BIG | TINY, 0, True), "B3K": (BIG, TINY, False)}
+          "B512": (BIG | TINY, 0, True), "BRAG": (BIG | TINY, 0, True), "B3K": (BIG, TINY, False),
+          # shortest pattern 4..6 B: the dense form (windows at every byte offset), on long, ragged and tiny haystacks
+          "K1": (DENSE | SHORT | 1, BIG | TINY, False), "K2": (DENSE | SHORT | 1, BIG | TINY, False), "K3": (DENSE | SHORT | TINY | 1, BIG, True)}
 
 
 @pytest.mark.parametrize("name", list(EXPECT))
@@ -51,7 +54,8 @@ def test_targeted_goldens_automatic_variant(name, path, targeted):
 
 OPTIONS = [dict(tiny_rows=0), dict(tiny_rows=0, short_rows=0), dict(short_rows=1), dict(wave_items=1), dict(wave_items=7, persistent=1),
            dict(wave_items=64, persistent=0), dict(chunk_bytes=512), dict(chunk_bytes=1024, run_cap=1), dict(slab_events=1, refill=2),
-           dict(verify=0), dict(kernel=1), dict(kernel=4), dict(kernel=0)]
+           dict(verify=0), dict(kernel=1), dict(kernel=4), dict(kernel=0), dict(run_cap=3), dict(run_cap=200, chunk_bytes=256), dict(anchor_dense=0),
+           dict(short_rows=0, tiny_rows=0, persistent=1), dict(early_stop=2, compact=1, dense_bytes=0, lds_bytes=4096)]
 
 
 @pytest.mark.parametrize("name", list(EXPECT))
