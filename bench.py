@@ -240,6 +240,8 @@ def keywords_leg(torch, api, batch, synth, dev, nh=1 << 17):
     alpha = bytes(range(ord("a"), ord("z") + 1)) + b"     "
     ds = synth.generate("words", 33, 2048, 4, 12, 8192, HAY_LEN, alpha)
     res = api.ahocorasick_init([{"id": k, "value": p} for k, p in enumerate(ds.patterns())])
+    for kv in filter(None, os.environ.get("ACMI_KW_OPTS", "").split(",")):   # analysis: e.g. ACMI_KW_OPTS=anchor_dense=0
+        res.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     res.set_option("profile", 2)
     d_blob = torch.from_numpy(ds.hay_blob).to(dev).repeat(nh // 8192).contiguous()
     d_off = torch.arange(nh + 1, dtype=torch.int64, device=dev) * HAY_LEN
@@ -259,6 +261,8 @@ def keywords_leg(torch, api, batch, synth, dev, nh=1 << 17):
                        nh * HAY_LEN, nh, total, ms, scan, walk, res, ok)
     out["first_batch_kernel"] = KERNEL_NAMES.get(first_kernel, "?")
     out["records_per_haystack"] = round(total / nh, 2)
+    out.update({"anchor_variant": int(res.stat("anchor_variant")), "anchor_dense_rate_per_8KiB": round(res.stat("anchor_dense_rate") * 8192, 1),
+                "fallback_bytes": int(res.stat("fallback_bytes")), "walked_bytes": int(res.stat("walked_bytes")), "overflow_items": int(res.stat("overflow_items"))})
     api.ahocorasick_deinit(res)
     return out
 

@@ -266,8 +266,8 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
 
 /* Integer options, set before finalize unless noted:
  *   "lds_bytes"      LDS budget for the hot-state tile (default 160 KiB minus slack)
- *   "slab_events"    per work-item event slots before the overflow path (default 8)
- *   "run_cap"        per work-item fix-up runs before the item is rescanned whole (default 8; 64 with the dense anchor form)
+ *   "slab_events"    per work-item event slots before the overflow path (default 8; 32 with the dense anchor form)
+ *   "run_cap"        per work-item fix-up runs before the item is rescanned whole (default 8; the dense anchor form: 256 entries of 4 bytes)
  *   "chunk_bytes"    force the work-item size (0 = automatic)            [any time]
  *   "kernel"         0 = plain global-table walk, 1 = LDS-tile table walk, 2 = anchor q-gram
  *                    filter + exact table walk of the candidates (needs a shortest pattern
@@ -296,7 +296,7 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *                    0 = dense, -1 (default) = compact when the dense table would exceed 64 MiB   [before finalize]
  *   "anchor_dense"   pattern sets whose shortest pattern is 4..6 B (keyword lists): the anchor filter in its dense form -- every
  *                    pattern anchored by its first four bytes, the window tested at every byte offset of the text: -1 (default)
- *                    when at most ~ 48 windows per 8 KiB are expected to hit on text that looks like the patterns, 0 never,
+ *                    when at most ~ 160 windows per 8 KiB are expected to hit on text that looks like the patterns, 0 never,
  *                    1 whenever the shortest pattern allows                                         [before finalize]
  *   "anchor_choice"  big pattern sets (anchor mode 2): which aligned window of a pattern is its anchor is chosen so that the
  *                    anchors share bits of the LDS bitmap (greedy set cover: 9 % of the bits set instead of 22 % for 65,536

@@ -543,8 +543,8 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
         for (uint32_t w : prefixes)
             rate += (freq[w & 0xff] / total_bytes) * (freq[(w >> 8) & 0xff] / total_bytes) * (freq[(w >> 16) & 0xff] / total_bytes) * (freq[w >> 24] / total_bytes);
         fa.anchor_dense_rate = rate;
-        // up to ~ 48 candidate windows per 8 KiB work item (its run list holds 64)
-        every_offset = prefixes.size() <= kAnchorMaxKeys && (opt.anchor_dense > 0 || rate * 8192.0 <= 48.0);
+        // up to ~ 160 candidate windows per 8 KiB work item (its run list holds 256)
+        every_offset = prefixes.size() <= kAnchorMaxKeys && (opt.anchor_dense > 0 || rate * 8192.0 <= 160.0);
     }
     if (fa.min_pattern_length >= 7 || every_offset) {
         const uint32_t q = every_offset ? 4u : fa.min_pattern_length >= 19 ? 16u : fa.min_pattern_length >= 15 ? 12u
@@ -777,6 +777,75 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
                         fa.anchor_bitmap[h >> 17] |= 1u << ((h >> 12) & 31u);
                     }
                 }
+            }
+        }
+    }
+
+    // ---- dense form: the LDS image of the verification data (automaton.hpp dense_image) ---------------------------
+    fa.dense_image.clear();
+    if (fa.anchor_dense && fa.anchor_q) {
+        struct Rec { uint32_t window, state, length, pattern; };
+        std::vector<Rec> recs;
+        bool fits = fa.max_pattern_length <= 16 && fa.n_states < (1u << 24);
+        for (size_t pi = 0; pi < patterns_.size() && fits; ++pi) {
+            const PatternMeta &m = patterns_[pi];
+            if (!m.accepted) continue;
+            Rec r{0, pattern_state[pi], m.length, uint32_t(pi)};
+            std::memcpy(&r.window, pattern_bytes_.data() + m.byte_off, 4);
+            recs.push_back(r);
+        }
+        fits = fits && recs.size() <= 4096;
+        if (fits) {
+            std::sort(recs.begin(), recs.end(), [](const Rec &a, const Rec &b) {
+                return a.window != b.window ? a.window < b.window : (a.length != b.length ? a.length > b.length : a.pattern < b.pattern);
+            });
+            uint32_t n_keys = 0;
+            for (size_t i = 0; i < recs.size(); ++i) n_keys += i == 0 || recs[i].window != recs[i - 1].window;
+            uint32_t slots = 64;
+            while (slots < 2 * n_keys) slots *= 2;
+            std::vector<uint32_t> tails;   // words
+            std::vector<uint32_t> rec_words;
+            for (const Rec &r : recs) {
+                const uint32_t toff = uint32_t(tails.size());
+                const uint32_t tail_len = r.length - 4u;
+                const uint8_t *tb = pattern_bytes_.data() + patterns_[r.pattern].byte_off + 4;
+                for (uint32_t i = 0; i < tail_len; i += 4) {
+                    uint32_t wv = 0;
+                    std::memcpy(&wv, tb + i, std::min<uint32_t>(4u, tail_len - i));
+                    tails.push_back(wv);
+                }
+                if (tail_len == 0) tails.push_back(0u);   // (every record has a readable tail word)
+                const uint32_t oc = std::min<uint32_t>(65535u, fa.out_count[r.state]);
+                rec_words.push_back(r.state | (r.length << 24));
+                rec_words.push_back(toff | (oc << 16));
+                if (toff >= 65536u || fa.out_count[r.state] > 65535u) fits = false;
+            }
+            tails.resize(tails.size() + 4, 0u);   // (three tail words are read unconditionally)
+            fits = fits && n_keys <= 4096 && tails.size() * 4 <= 32768 + 16;
+            if (fits) {
+                const uint32_t mul = 0x9E3779B1u;
+                std::vector<uint32_t> ht(size_t(slots) * 2, 0xFFFFFFFFu);
+                for (size_t i = 0; i < recs.size();) {
+                    size_t e = i + 1;
+                    while (e < recs.size() && recs[e].window == recs[i].window) ++e;
+                    uint32_t slot = ((recs[i].window * mul) >> 16) & (slots - 1);
+                    while (ht[size_t(slot) * 2 + 1] != 0xFFFFFFFFu) slot = (slot + 1) & (slots - 1);
+                    ht[size_t(slot) * 2] = recs[i].window;
+                    ht[size_t(slot) * 2 + 1] = uint32_t(i) | (uint32_t(std::min<size_t>(e - i, 0xFFFEu)) << 16);
+                    i = e;
+                }
+                std::vector<uint32_t> &img = fa.dense_image;
+                img.assign(8, 0u);
+                img[0] = slots - 1;
+                img[1] = 8;
+                img[2] = img[1] + uint32_t(ht.size());
+                img[3] = img[2] + uint32_t(rec_words.size());
+                img[5] = mul;
+                img.insert(img.end(), ht.begin(), ht.end());
+                img.insert(img.end(), rec_words.begin(), rec_words.end());
+                img.insert(img.end(), tails.begin(), tails.end());
+                while (img.size() % 4) img.push_back(0u);
+                img[4] = uint32_t(img.size());
             }
         }
     }

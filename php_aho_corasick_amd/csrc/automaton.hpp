@@ -152,6 +152,17 @@ struct FlatAutomaton {
     // which have no aligned dword inside every occurrence.  One key per pattern instead of four, hash anchor_hash_dense.
     uint32_t anchor_dense = 0;
     double anchor_dense_rate = 0; // expected hit windows per text byte, text drawn from the patterns' own byte frequencies
+    // Dense form, small sets: everything the verification of a hit window needs, laid out to be staged into LDS by
+    // k_verify_dense (a hit is decided without a single table access in global memory; the dense form has tens of hits per
+    // work item).  Words: [0] hash-table mask (slots - 1), [1] word offset of the hash table, [2] of the pattern records,
+    // [3] of the tail bytes, [4] total words, [5] multiplier of the slot hash, [6..7] reserved; then
+    //   hash table   slots x {window (the pattern's first four bytes), first record | count << 16}   (0xFFFFFFFF in the
+    //                second word: empty; open addressing, linear probing from (window * mul) >> 16 & mask);
+    //   records      per pattern with that prefix {final state | length << 24, tail word offset | min(out_count, 65535) << 16};
+    //   tails        the patterns' bytes from the fifth on, each padded to a whole word.
+    // Empty when the set is too big for it (more than 4,096 keys or patterns, 32 KiB of tails, a state id of 2^24 or more, a
+    // pattern longer than 16 B): candidates are then verified through the tables in global memory.
+    std::vector<uint32_t> dense_image;
     uint32_t anchor_mode = 0;     // 0 none, 1 LDS table, 2 LDS bitmap + global table
     uint32_t anchor_mul = 0;      // odd multiplier of the window hash (seed that gave no bucket overflow)
     uint32_t anchor_keys = 0;
@@ -237,6 +248,7 @@ public:
         std::vector<uint32_t>().swap(flat_.anchor_slot_pair);
         std::vector<uint32_t>().swap(flat_.anchor_pairs);
         std::vector<uint32_t>().swap(flat_.out_list);
+        std::vector<uint32_t>().swap(flat_.dense_image);
         host_tables_released_ = true;
     }
     bool host_tables_released() const { return host_tables_released_; }

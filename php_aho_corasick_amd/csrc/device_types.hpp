@@ -52,6 +52,8 @@ struct DevAutomaton {
     uint32_t anchor_mode, anchor_bucket_mask, anchor_bucket_shift;   // mode 2: bucket = (hash >> shift) & mask
     uint32_t anchor_choice;      // 1: a pattern's anchor window may lie deeper than its first aligned dword (offset in the pair record)
     uint32_t anchor_dense;       // 1: windows at every byte offset, keys = the patterns' first four bytes (automaton.hpp)
+    const uint32_t *dense_image; // dense form, small sets: the verification data k_verify_dense stages into LDS (automaton.hpp), or null
+    uint32_t dense_image_words;
 };
 
 // One batch launch.
@@ -83,6 +85,8 @@ struct BatchArgs {
     uint64_t run_stride;         // >= number of items
     uint32_t run_cap;
     uint32_t *run_count;         // per item: runs appended by k_scan_anchor, walked by k_walk_runs (> run_cap: whole item)
+    uint32_t run_dense;          // 1 (dense anchor form): `runs` holds 4-byte entries, the hit windows' start offsets, ITEM-major --
+                                 // entry r of item i at ((uint32_t *)runs)[i * run_cap + r]; a run's bounds follow from its start
     uint32_t poison_quads;       // ceil(max_pattern_length / 16): quads flagged after a lost state
     uint32_t persistent;         // 1: one workgroup per CU, waves pull item batches from counters[1]
     uint32_t wave_items;         // k_scan_anchor: items a wave takes per batch (1..64)

@@ -88,6 +88,7 @@ struct acmi_handle {
     // options
     uint32_t slab_events = 8;
     uint32_t run_cap = 8;
+    bool slab_set = false;     // "slab_events" set by the caller; else the dense anchor form takes 32
     bool run_cap_set = false;  // by the caller; else the dense anchor form takes 64 (a work item has tens of candidate windows there)
     uint64_t chunk_opt = 0;
     int kernel = 3;  // 0 plain global table, 1 LDS-tile walk, 2 anchor filter (if eligible), 3 automatic
@@ -122,7 +123,7 @@ struct acmi_handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     DevAutomaton dA{};
-    DevBuf d_table, d_lds, d_class, d_own, d_dict, d_cnt, d_plen, d_anchor, d_bitmap, d_out_off, d_out_list, d_cold_rec, d_cold_edges, d_chain_byte, d_chain_run, d_slot_pair, d_pairs, d_pat_bytes;
+    DevBuf d_table, d_lds, d_class, d_own, d_dict, d_cnt, d_plen, d_anchor, d_bitmap, d_out_off, d_out_list, d_cold_rec, d_cold_edges, d_chain_byte, d_chain_run, d_slot_pair, d_pairs, d_pat_bytes, d_dense_img;
 
     // workspace (grow-only)
     DevBuf d_blob, d_off, d_item_base, d_item_hay, d_item_rec, d_zero, d_rec_base, d_slab, d_ovf, d_counters,
@@ -418,6 +419,15 @@ int ensure_device(acmi_handle *h) {
         }
     }
 
+    if (fa.anchor_dense && !fa.dense_image.empty() && h->verify) {
+        HIPCHK(h, h->d_dense_img.ensure(fa.dense_image.size() * 4));
+        HIPCHK(h, copy_h2d(h->d_dense_img.p, fa.dense_image.data(), fa.dense_image.size() * 4));
+        h->dA.dense_image = h->d_dense_img.as<uint32_t>();
+        h->dA.dense_image_words = uint32_t(fa.dense_image.size());
+    } else {
+        h->dA.dense_image = nullptr;
+        h->dA.dense_image_words = 0;
+    }
     const bool verify = fa.anchor_q && h->verify && !fa.anchor_pairs.empty() && !fa.anchor_slot_pair.empty();
     if (verify) {
         const std::vector<uint8_t> &pb = h->aut.pattern_bytes();
@@ -599,7 +609,8 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     F.kernel_used = kernel;
     const uint32_t chunk = choose_chunk(h, blob_bytes, nh, kernel);
     const uint64_t max_items = blob_bytes / chunk + nh;
-    const uint32_t K = std::max<uint32_t>(1, h->slab_events);
+    // (event slots per item: the dense anchor form is for sets with a few matches per KiB of text)
+    const uint32_t K = (!h->slab_set && kernel == 2 && fa.anchor_dense) ? 32u : std::max<uint32_t>(1, h->slab_events);
     F.chunk_used = chunk;
 
     HIPCHK(h, h->d_item_base.ensure_keep((nh + 1) * 8, h->retired));
@@ -627,8 +638,10 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     HIPCHK(h, h->d_rec_base.ensure_keep((max_items + 2) * 8, h->retired));
     HIPCHK(h, h->d_slab.ensure_keep(max_items * K * 8, h->retired));
     HIPCHK(h, h->d_ovf.ensure_keep(max_items * 4, h->retired));
-    const uint32_t Q = (!h->run_cap_set && kernel == 2 && fa.anchor_dense) ? 64u : std::max<uint32_t>(1, h->run_cap);
-    HIPCHK(h, h->d_runs.ensure_keep(max_items * Q * 16, h->retired));
+    // dense anchor form: hit windows per item by the dozen -- 4-byte entries, 256 of them unless the caller says otherwise
+    const bool dense = kernel == 2 && fa.anchor_dense != 0;
+    const uint32_t Q = (!h->run_cap_set && dense) ? 256u : std::max<uint32_t>(1, h->run_cap);
+    HIPCHK(h, h->d_runs.ensure_keep(max_items * Q * (dense ? 4 : 16), h->retired));
     HIPCHK(h, h->d_run_count.ensure_keep(max_items * 4, h->retired));
     uint8_t *zero = h->d_zero.as<uint8_t>();
     uint32_t *d_counters = sync_cur;
@@ -661,6 +674,7 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     B.runs = h->d_runs.as<uint4>();
     B.run_count = h->d_run_count.as<uint32_t>();
     B.run_cap = Q;
+    B.run_dense = dense ? 1u : 0u;
     B.run_stride = max_items;
     B.poison_quads = std::max<uint32_t>(1, (fa.max_pattern_length + 15) / 16);
     // persistent workgroups pay off once a CU would otherwise run several workgroups back to back
@@ -999,7 +1013,7 @@ int acmi_destroy(acmi_handle *h) {
         if (h->dev_touched) {  // also after a failed upload: release whatever was created
             (void)hipSetDevice(h->dev_id);
             if (h->stream) (void)hipStreamSynchronize(h->stream);
-            for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_out_off, &h->d_out_list, &h->d_cold_rec, &h->d_cold_edges, &h->d_chain_byte, &h->d_chain_run, &h->d_slot_pair, &h->d_pairs, &h->d_pat_bytes, &h->d_rep_off, &h->d_rep_bytes, &h->d_plan, &h->d_plan_out, &h->d_tail_out, &h->d_rep_sync, &h->d_nom_count, &h->d_out_len, &h->d_rep_out_off, &h->d_rep_out, &h->d_blob,
+            for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_out_off, &h->d_out_list, &h->d_cold_rec, &h->d_cold_edges, &h->d_chain_byte, &h->d_chain_run, &h->d_slot_pair, &h->d_pairs, &h->d_pat_bytes, &h->d_dense_img, &h->d_rep_off, &h->d_rep_bytes, &h->d_plan, &h->d_plan_out, &h->d_tail_out, &h->d_rep_sync, &h->d_nom_count, &h->d_out_len, &h->d_rep_out_off, &h->d_rep_out, &h->d_blob,
                               &h->d_off, &h->d_sync[0], &h->d_sync[1], &h->d_item_base, &h->d_item_hay, &h->d_item_rec, &h->d_zero,
                               &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->fly[0].d_prefix, &h->fly[0].d_out, &h->fly[1].d_prefix, &h->fly[1].d_out, &h->d_runs, &h->d_run_count})
                 b->release();
@@ -1226,6 +1240,7 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
         } else if (k == "slab_events") {
             if (value < 1 || value > 4096) return ACMI_E_ARG;
             h->slab_events = uint32_t(value);
+            h->slab_set = true;
         } else if (k == "run_cap") {
             if (value < 1 || value > 1024) return ACMI_E_ARG;
             h->run_cap = uint32_t(value);
@@ -1349,6 +1364,7 @@ int acmi_get_stat(const acmi_handle *h, const char *key, double *value) {
         else if (k == "anchor_choice") *value = fa.anchor_choice;
         else if (k == "anchor_dense") *value = fa.anchor_dense;
         else if (k == "anchor_dense_rate") *value = fa.anchor_dense_rate;
+        else if (k == "dense_image_bytes") *value = double(h->dA.dense_image_words) * 4;
         else if (k == "built_on_device") *value = h->aut.built_on_device() ? 1 : 0;
         else if (k == "compact") *value = fa.compact;
         else if (k == "dense_rows") *value = fa.n_dense_rows;

@@ -539,6 +539,17 @@ __device__ __forceinline__ void stage_flush(const BatchArgs &B, uint64_t wave_fi
     st.count = 0;
 }
 
+constexpr uint32_t kDenseStage = 256;   // 8-byte entries in the wave's 2 KiB
+__device__ __forceinline__ void dense_flush(const BatchArgs &B, uint64_t wave_first, RunStage &st, uint32_t lane) {
+    const uint2 *slots2 = reinterpret_cast<const uint2 *>(st.slots);
+    uint32_t *runs32 = reinterpret_cast<uint32_t *>(B.runs);
+    for (uint32_t i = lane; i < st.count; i += 64u) {
+        const uint2 e = slots2[i];
+        runs32[(wave_first + (e.x & 0xffu)) * uint64_t(B.run_cap) + (e.x >> 8)] = e.y;
+    }
+    st.count = 0;
+}
+
 // Bookkeeping as in append_run (n, last_hi stay in scalar registers), but runs are never merged: adjacent runs
 // stay separate entries (k_walk_runs joins them); k = item index inside the wave batch
 __device__ __forceinline__ void append_run_wave(const BatchArgs &B, uint64_t wave_first, RunStage &st, uint32_t k,
@@ -882,6 +893,34 @@ __device__ __forceinline__ bool verify_candidate(const DevAutomaton &A, const ui
     return true;
 }
 
+// The events of a cluster whose windows were all decided by verification: the occurrences in position order (windows
+// ascend, so do pattern starts per window, ends need not); of several that end at the same byte one event, the deepest
+// final state among them (the longest pattern: its output list carries the others).
+__device__ __forceinline__ void emit_verified(const BatchArgs &B, uint64_t item, Verified (&v)[kClusterMax], uint32_t rep_from,
+                                              uint32_t hi, uint32_t pos_bias, EventRegs &ev) {
+#pragma unroll
+    for (uint32_t a = 0; a + 1 < kClusterMax; ++a)
+#pragma unroll
+        for (uint32_t b = 0; b + 1 < kClusterMax - a; ++b)
+            if (v[b + 1].j < v[b].j) { const Verified t = v[b]; v[b] = v[b + 1]; v[b + 1] = t; }
+#pragma unroll
+    for (uint32_t i = 0; i < kClusterMax; ++i) {
+        const uint32_t j = v[i].j;
+        if (j == 0xFFFFFFFFu) continue;
+        // same end as the next one: after the sort equal ends are neighbours
+        if (i + 1 < kClusterMax && v[i + 1].j == j) {
+            if (v[i + 1].cnt < v[i].cnt) { v[i + 1].state = v[i].state; v[i + 1].cnt = v[i].cnt; }
+            continue;
+        }
+        if (j >= rep_from && j < hi && !(B.first_only && ev.n_ev)) {
+            const uint32_t s = v[i].state;
+            ev.n_rec += v[i].cnt;
+            if (ev.n_ev < B.slab_events) B.slab[uint64_t(ev.n_ev) * B.run_stride + item] = make_uint2(pos_bias + j, s);
+            ++ev.n_ev;
+        }
+    }
+}
+
 // run_epilogue for k_walk_runs.  k_scan_anchor leaves one run per hit window, ascending and disjoint, a run that
 // begins where its predecessor ends being adjacent to it.  Runs that touch form a CLUSTER: everything that ends
 // inside a cluster is an occurrence of a pattern anchored at one of the cluster's windows (an occurrence anchored
@@ -931,29 +970,7 @@ __device__ __forceinline__ uint32_t run_epilogue_fast(const DevAutomaton &A, con
             const uint32_t rep_from = lo > it.warm ? lo : it.warm;
             walked += hi - lo;
             if (windows) {
-                // occurrences in position order; windows ascend, so do pattern starts per window, ends need not
-#pragma unroll
-                for (uint32_t a = 0; a + 1 < kClusterMax; ++a)
-#pragma unroll
-                    for (uint32_t b = 0; b + 1 < kClusterMax - a; ++b)
-                        if (v[b + 1].j < v[b].j) { const Verified t = v[b]; v[b] = v[b + 1]; v[b + 1] = t; }
-#pragma unroll
-                for (uint32_t i = 0; i < kClusterMax; ++i) {
-                    const uint32_t j = v[i].j;
-                    if (j == 0xFFFFFFFFu) continue;
-                    // same end as the next one: the longer pattern is the one from the EARLIER window; after the sort
-                    // equal ends are neighbours, and the event belongs to the deepest final state among them
-                    if (i + 1 < kClusterMax && v[i + 1].j == j) {
-                        if (v[i + 1].cnt < v[i].cnt) { v[i + 1].state = v[i].state; v[i + 1].cnt = v[i].cnt; }
-                        continue;
-                    }
-                    if (j >= rep_from && j < hi && !(B.first_only && ev.n_ev)) {
-                        const uint32_t s = v[i].state;
-                        ev.n_rec += v[i].cnt;
-                        if (ev.n_ev < B.slab_events) B.slab[uint64_t(ev.n_ev) * B.run_stride + item] = make_uint2(pos_bias + j, s);
-                        ++ev.n_ev;
-                    }
-                }
+                emit_verified(B, item, v, rep_from, hi, pos_bias, ev);
                 continue;
             }
             // walk the cluster as one range: from the root, m_min-1 bytes before a window's own lower bound (every
@@ -1399,7 +1416,12 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     uint32_t tail[NC];
 #pragma unroll
     for (int i = 0; i < NC; ++i) tail[i] = 0;
-    if (sc.head) append_run_wave(B, wave_first, stage, sc.k, 0, (sc.head + l_max) < sc.n ? sc.head + l_max : sc.n, 0u, nrun, run_hi, lane);
+    if (sc.head) {
+        // (dense form: its run lists hold window starts only -- an item with an unaligned head, the first haystack of an unaligned
+        // blob, is walked whole)
+        if constexpr (DENSE) nrun = B.run_cap + 1u;
+        else append_run_wave(B, wave_first, stage, sc.k, 0, (sc.head + l_max) < sc.n ? sc.head + l_max : sc.n, 0u, nrun, run_hi, lane);
+    }
 
     uint4 buf0[G], buf1[G];
     // Lane l holds quads r*64 + l (r = 0..7) of the wave's current 8 KiB: every wave-load covers 1 KiB
@@ -1748,14 +1770,14 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                     const uint32_t incl = wave_inclusive_sum(cnt);
                     const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
                     if (total != 0) {
-                        if (nrun <= B.run_cap && nrun + total <= B.run_cap && total <= stage.cap) {
-                            if (stage.count + total > stage.cap) stage_flush(B, wave_first, stage, lane);
+                        if (nrun <= B.run_cap && nrun + total <= B.run_cap && total <= kDenseStage) {
+                            // (dense stage: 256 entries of 8 bytes {item in the wave | run index << 8, window start}, flushed to
+                            // the items' run lists -- 4 bytes per hit, item-major: an item's hits are one contiguous piece)
+                            uint2 *slots2 = reinterpret_cast<uint2 *>(stage.slots);
+                            if (stage.count + total > kDenseStage) dense_flush(B, wave_first, stage, lane);
                             uint32_t at = stage.count + incl - cnt, idx = nrun + incl - cnt;
-                            for (uint32_t m = zr; m != 0; m &= m - 1, ++at, ++idx) {
-                                const uint32_t start = pos0 + uint32_t(__builtin_ctz(m)) - 3u;
-                                const uint32_t hi = start + l_max < n_item ? start + l_max : n_item;
-                                stage.slots[at] = make_uint4(k_item | (idx << 8), start + lo_bias, hi, kEntryWindow | start);
-                            }
+                            for (uint32_t m = zr; m != 0; m &= m - 1, ++at, ++idx)
+                                slots2[at] = make_uint2(k_item | (idx << 8), pos0 + uint32_t(__builtin_ctz(m)) - 3u);
                             stage.count += total;
                             nrun += total;
                         } else {
@@ -1833,7 +1855,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
             uint32_t lo = sc.head + (sc.nq << 4) + (A.anchor_choice ? q : m_min);
             lo = lo > q ? lo - q : 0u;
             if (nrun > 0 && lo < run_hi) lo = run_hi;
-            if (sc.head + (sc.nq << 4) < sc.n) {
+            if (!DENSE && sc.head + (sc.nq << 4) < sc.n) {
                 if (lo < sc.n) {
                     append_run_wave(B, wave_first, stage, sc.k, lo, sc.n, kEntryUnknown, nrun, run_hi, lane);
                 } else if (nrun > 0 && nrun <= B.run_cap) {
@@ -1849,7 +1871,12 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
         if (more && sc.k != k_before) {
             nrun = 0;
             run_hi = 0;
-            if (sc.head) append_run_wave(B, wave_first, stage, sc.k, 0, (sc.head + l_max) < sc.n ? sc.head + l_max : sc.n, 0u, nrun, run_hi, lane);
+            if (sc.head) {
+        // (dense form: its run lists hold window starts only -- an item with an unaligned head, the first haystack of an unaligned
+        // blob, is walked whole)
+        if constexpr (DENSE) nrun = B.run_cap + 1u;
+        else append_run_wave(B, wave_first, stage, sc.k, 0, (sc.head + l_max) < sc.n ? sc.head + l_max : sc.n, 0u, nrun, run_hi, lane);
+    }
         }
         return more;
     };
@@ -1895,7 +1922,8 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     }
 
     // hand the run lists over to k_walk_runs (lane k: item wave_first + k)
-    stage_flush(B, wave_first, stage, lane);
+    if constexpr (DENSE) dense_flush(B, wave_first, stage, lane);
+    else stage_flush(B, wave_first, stage, lane);
     if (rec.z != 0) B.run_count[wave_first + lane] = nrun_vec;
     if (!B.persistent) break;
     }  // next batch of this wave
@@ -1975,9 +2003,13 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_runs(DevAutomaton A, Batc
     }
 }
 
+static hipError_t launch_verify_dense(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,
+                                      hipStream_t st);
+
 hipError_t launch_walk_runs(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,
                             hipStream_t st) {
     if (max_items == 0) return hipSuccess;
+    if (B.run_dense) return launch_verify_dense(A, B, max_items, entry_bytes, class_mode, st);
     const uint32_t blocks = uint32_t((max_items + kWalkThreads - 1) / kWalkThreads);
     const uint32_t lds = kWalkTileBytes;
     auto go = [&](auto fn) {
@@ -1991,6 +2023,176 @@ hipError_t launch_walk_runs(const DevAutomaton &A, const BatchArgs &B, uint64_t 
     if (entry_bytes == 2) return class_mode == 1 ? ACMI_WALK_RUNS(uint16_t, 1) : ACMI_WALK_RUNS(uint16_t, 0);
     return class_mode == 1 ? ACMI_WALK_RUNS(uint32_t, 1) : ACMI_WALK_RUNS(uint32_t, 0);
 #undef ACMI_WALK_RUNS
+}
+
+// ------------------------------------------------------------------------------------------
+// k_verify_dense: k_walk_runs for the dense anchor form (windows at every byte offset, shortest pattern 4..6 B).
+//
+// A work item has tens of hit windows there (a keyword list: ~ 100 per 8 KiB), and deciding each through the tables in
+// global memory -- fingerprint bucket, slot, pair record, pattern text: five dependent round trips, ~ 15 divergent
+// requests -- made this step three times the filter's own time.  For small sets (<= 4,096 patterns of <= 16 B) everything
+// the decision needs is staged into LDS instead (automaton.hpp dense_image: a hash table keyed by the window itself, a
+// record per pattern, the patterns' bytes from the fifth on), and a hit costs ONE global access, the 16 text bytes at the
+// window, requested a hit ahead.  The run list is the 4-byte window starts of the item, contiguous (item-major); a run's
+// bounds follow from its start: patterns BEGIN at their window, so everything anchored at `start` ends in
+// [start + m_min - 1, start + Lmax).  Runs that touch or overlap form a cluster, decided as in run_epilogue_fast: its
+// occurrences in position order, or -- more than six of them, a text load that would cross the item's end -- one exact
+// walk from the cluster's first window.  Bigger sets verify through the global tables (VLDS = false).
+// ------------------------------------------------------------------------------------------
+template <bool VLDS>
+__device__ __forceinline__ bool verify_dense(const DevAutomaton &A, const uint32_t *img, const uint8_t *p, uint32_t n, uint32_t floor,
+                                             uint32_t start, const uint4 &t, Verified (&v)[kClusterMax], uint32_t &nv) {
+    if (start + 4u > n) return true;   // no pattern fits
+    if constexpr (!VLDS) {
+        return verify_candidate(A, p, n, floor, start, v, nv);
+    } else {
+        if (start + 16u > n) return false;   // (the 16 text bytes were not loaded: the cluster is walked)
+        const uint32_t mask = img[0];
+        const uint32_t *ht = img + img[1], *recs = img + img[2], *tails = img + img[3];
+        uint32_t slot = ((t.x * img[5]) >> 16) & mask;
+        uint32_t e1;
+        for (;;) {
+            e1 = ht[2u * slot + 1u];
+            if (e1 == 0xFFFFFFFFu) return true;   // not a key at all: a fingerprint twin
+            if (ht[2u * slot] == t.x) break;
+            slot = (slot + 1u) & mask;
+        }
+        const uint32_t first = e1 & 0xFFFFu, count = e1 >> 16;
+#pragma unroll 1
+        for (uint32_t k = 0; k < count; ++k) {
+            const uint32_t r0 = recs[2u * (first + k)], r1 = recs[2u * (first + k) + 1u];
+            const uint32_t len = r0 >> 24, state = r0 & 0xFFFFFFu, toff = r1 & 0xFFFFu;
+            if (start < floor || start + len > n) continue;   // would begin before / end after this item's bytes
+            const uint32_t tl = len - 4u;                      // 0..12 bytes behind the window
+            const uint32_t m0 = tl >= 4u ? 0xFFFFFFFFu : (1u << (8u * tl)) - 1u;
+            const uint32_t m1 = tl >= 8u ? 0xFFFFFFFFu : tl > 4u ? (1u << (8u * (tl - 4u))) - 1u : 0u;
+            const uint32_t m2 = tl >= 12u ? 0xFFFFFFFFu : tl > 8u ? (1u << (8u * (tl - 8u))) - 1u : 0u;
+            const uint32_t diff = ((t.y ^ tails[toff]) & m0) | ((t.z ^ tails[toff + 1u]) & m1) | ((t.w ^ tails[toff + 2u]) & m2);
+            if (diff) continue;
+            if (nv >= kClusterMax) return false;
+            uint32_t oc = r1 >> 16;
+            if (oc == 65535u) oc = A.out_count[state];
+            const Verified vv{start + len - 1u, state, oc};
+#pragma unroll
+            for (uint32_t i = 0; i < kClusterMax; ++i) if (i == nv) v[i] = vv;
+            ++nv;
+        }
+        return true;
+    }
+}
+
+template <typename E, int MODE, bool VLDS>
+__global__ __launch_bounds__(kWalkThreads) void k_verify_dense(DevAutomaton A, BatchArgs B) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint64_t total_items = B.item_base[B.n_haystacks];
+    if (uint64_t(blockIdx.x) * kWalkThreads >= total_items) return;
+    __shared__ uint32_t s_walked, s_done;
+    if (threadIdx.x == 0) { s_walked = 0; s_done = 0; }
+    const uint64_t item = uint64_t(blockIdx.x) * kWalkThreads + threadIdx.x;
+    uint32_t nr = 0;
+    uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+    if (item < total_items) {
+        nr = B.run_count[item];
+        rec = B.item_rec[item];
+    }
+    if constexpr (VLDS) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(A.dense_image);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        const uint32_t n16 = A.dense_image_words >> 2;
+        for (uint32_t t = threadIdx.x; t < n16; t += kWalkThreads) dst[t] = src[t];
+    }
+    __syncthreads();
+    const uint32_t *img = reinterpret_cast<const uint32_t *>(smem);
+    uint32_t walked = 0;
+    if (nr != 0) {
+        ItemDesc it;
+        unpack_item(rec.x, rec.y, rec.z, rec.w, it);
+        const uint8_t *p = B.blob + (it.begin - it.warm);
+        const uint32_t n = it.warm + it.len;
+        const uint32_t pos_bias = it.pos0 - it.warm + 1u;
+        const uint32_t m_min = A.min_pattern_length, l_max = A.max_pattern_length;
+        EventRegs ev{0, 0};
+        if (nr > B.run_cap) {   // more hit windows than the list holds (or an unaligned head): the whole item, exactly
+            walked = n;
+            exact_range<E, MODE, false>(A, B, nullptr, nullptr, 0u, item, p, it.floor, n, it.warm, pos_bias, 0u, ev);
+            atomicAdd(&B.counters[7], (n + 15u) >> 4);
+        } else {
+            const uint32_t *starts = reinterpret_cast<const uint32_t *>(B.runs) + item * uint64_t(B.run_cap);
+            uint32_t r = 0;
+            uint32_t cur = starts[0];
+            // the 16 text bytes at a window, requested one window ahead (where they lie inside the item)
+            auto text_at = [&](uint32_t st) -> uint4 { return (VLDS && st + 16u <= n) ? load16u(p + st) : make_uint4(0u, 0u, 0u, 0u); };
+            uint4 t_cur = text_at(cur);
+#pragma unroll 1
+            while (r < nr) {
+                const uint32_t first = cur;
+                uint32_t hi = first + l_max < n ? first + l_max : n, nv = 0;
+                Verified v[kClusterMax];
+#pragma unroll
+                for (uint32_t i = 0; i < kClusterMax; ++i) v[i] = Verified{0xFFFFFFFFu, 0u, 0u};
+                bool windows = true;
+#pragma unroll 1
+                for (;;) {
+                    const uint32_t st = cur;
+                    const uint4 t = t_cur;
+                    ++r;
+                    if (r < nr) {   // (the next window's text is in flight while this one is decided)
+                        cur = starts[r];
+                        t_cur = text_at(cur);
+                    }
+                    if (windows) windows = verify_dense<VLDS>(A, img, p, n, it.floor, st, t, v, nv);
+                    if (r >= nr || cur + m_min - 1u > hi) break;   // neither adjacent nor overlapping: the next cluster
+                    const uint32_t h2 = cur + l_max < n ? cur + l_max : n;
+                    hi = h2 > hi ? h2 : hi;
+                }
+                const uint32_t lo = first + m_min - 1u;
+                if (lo >= n) continue;
+                const uint32_t rep_from = lo > it.warm ? lo : it.warm;
+                walked += hi - lo;
+                if (windows) {
+                    emit_verified(B, item, v, rep_from, hi, pos_bias, ev);
+                    continue;
+                }
+                // every pattern that ends in the cluster begins at one of its windows, the first being the leftmost
+                const uint32_t from = first > it.floor ? first : it.floor;
+                exact_range<E, MODE, false>(A, B, nullptr, nullptr, 0u, item, p, from, hi, rep_from, pos_bias, 0u, ev);
+                atomicAdd(&B.counters[7], (hi - from + 15u) >> 4);
+            }
+        }
+        if (ev.n_ev) {
+            B.ev_count[item] = ev.n_ev;
+            B.rec_count[item] = ev.n_rec;
+            if (ev.n_ev > B.slab_events) B.overflow_list[atomicAdd(&B.counters[0], 1u)] = uint32_t(item);
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) walked += __shfl_xor(walked, d, 64);
+    if ((threadIdx.x & 63u) == 0) {
+        if (walked) atomicAdd(&s_walked, (walked + 15u) >> 4);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (atomicAdd(&s_done, 1u) == kWalkThreads / 64u - 1u) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const uint32_t total = atomicAdd(&s_walked, 0u);
+            if (total) atomicAdd(&B.counters[8u + (blockIdx.x & 7u)], total);
+        }
+    }
+}
+
+static hipError_t launch_verify_dense(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,
+                                      hipStream_t st) {
+    const uint32_t blocks = uint32_t((max_items + kWalkThreads - 1) / kWalkThreads);
+    const bool vlds = A.dense_image != nullptr;
+    const uint32_t lds = vlds ? A.dense_image_words * 4u : 16u;
+    auto go = [&](auto fn) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(fn, dim3(blocks), dim3(kWalkThreads), lds, st, A, B);
+        return hipGetLastError();
+    };
+#define ACMI_VERIFY_DENSE(E, M) (vlds ? go(k_verify_dense<E, M, true>) : go(k_verify_dense<E, M, false>))
+    if (entry_bytes == 2) return class_mode == 1 ? ACMI_VERIFY_DENSE(uint16_t, 1) : ACMI_VERIFY_DENSE(uint16_t, 0);
+    return class_mode == 1 ? ACMI_VERIFY_DENSE(uint32_t, 1) : ACMI_VERIFY_DENSE(uint32_t, 0);
+#undef ACMI_VERIFY_DENSE
 }
 
 // ------------------------------------------------------------------------------------------
