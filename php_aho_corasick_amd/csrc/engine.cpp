@@ -641,7 +641,7 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     // dense anchor form: hit windows per item by the dozen -- 4-byte entries, 256 of them unless the caller says otherwise
     const bool dense = kernel == 2 && fa.anchor_dense != 0;
     const uint32_t Q = (!h->run_cap_set && dense) ? 256u : std::max<uint32_t>(1, h->run_cap);
-    HIPCHK(h, h->d_runs.ensure_keep(max_items * Q * (dense ? 4 : 16), h->retired));
+    HIPCHK(h, h->d_runs.ensure_keep(max_items * Q * (dense ? 8 : 16), h->retired));   // (dense: window starts, then k_dense_decide's results)
     HIPCHK(h, h->d_run_count.ensure_keep(max_items * 4, h->retired));
     uint8_t *zero = h->d_zero.as<uint8_t>();
     uint32_t *d_counters = sync_cur;

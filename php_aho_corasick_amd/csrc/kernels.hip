@@ -2044,6 +2044,7 @@ __device__ __forceinline__ bool verify_dense(const DevAutomaton &A, const uint32
                                              uint32_t start, const uint4 &t, Verified (&v)[kClusterMax], uint32_t &nv) {
     if (start + 4u > n) return true;   // no pattern fits
     if constexpr (!VLDS) {
+        if (A.anchor_pairs == nullptr) return false;   // "verify" 0: every candidate is walked
         return verify_candidate(A, p, n, floor, start, v, nv);
     } else {
         if (start + 16u > n) return false;   // (the 16 text bytes were not loaded: the cluster is walked)
@@ -2178,18 +2179,195 @@ __global__ __launch_bounds__(kWalkThreads) void k_verify_dense(DevAutomaton A, B
     }
 }
 
+// With the LDS image the decision is split in two kernels, because what bounds it is memory LATENCY, not work: one thread per
+// item deciding its ~ 100 windows one after the other waits for a window-list load and a text load per window, a few
+// microseconds each (k_verify_dense<.., true> as first written: 0.89 ms per GiB of keyword text, more than the filter).
+//   k_dense_decide   one thread per HIT WINDOW (thread t: item t / run_cap, window t % run_cap -- a wave's 64 windows belong
+//                    to one item, so the item's record is a scalar load, the window list one coalesced 256-byte read and the
+//                    text loads fall into a few neighbouring lines): the LDS lookup of verify_dense, result written next to
+//                    the window list -- the record index of the occurrence found, kDenseNone, or kDenseMany (several
+//                    patterns with that prefix are there, or the text load would cross the item's end);
+//   k_dense_emit     one thread per item: reads the results in order (contiguous, no dependent loads), clusters windows
+//                    whose ranges touch, emits the events in position order; only kDenseMany windows are looked at again.
+constexpr uint32_t kDenseNone = 0xFFFFFFFFu, kDenseMany = 0xFFFFFFFEu;
+
+__global__ __launch_bounds__(1024) void k_dense_decide(DevAutomaton A, BatchArgs B, uint32_t *results) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint64_t total_items = B.item_base[B.n_haystacks];
+    const uint32_t Q = B.run_cap;                       // a multiple of 64 (the host sees to it)
+    if (uint64_t(blockIdx.x) * 1024u / Q >= total_items) return;
+    {   // the image is staged once per workgroup; the workgroups are persistent (a few per CU) and stride over the windows
+        const uint4 *src = reinterpret_cast<const uint4 *>(A.dense_image);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        const uint32_t n16 = A.dense_image_words >> 2;
+        for (uint32_t t = threadIdx.x; t < n16; t += 1024u) dst[t] = src[t];
+    }
+    __syncthreads();
+    const uint32_t *img = reinterpret_cast<const uint32_t *>(smem);
+    for (uint64_t t = uint64_t(blockIdx.x) * 1024u + threadIdx.x; t / Q < total_items; t += uint64_t(gridDim.x) * 1024u) {
+    const uint64_t item = t / Q;
+    const uint32_t r = uint32_t(t % Q);
+    const uint32_t nr = B.run_count[item];
+    if (nr > Q || r >= nr) continue;
+    const uint4 rec = B.item_rec[item];
+    ItemDesc it;
+    unpack_item(rec.x, rec.y, rec.z, rec.w, it);
+    const uint8_t *p = B.blob + (it.begin - it.warm);
+    const uint32_t n = it.warm + it.len;
+    const uint32_t start = reinterpret_cast<const uint32_t *>(B.runs)[item * Q + r];
+    uint32_t out = kDenseNone;
+    if (start + 16u > n) {
+        out = start + 4u <= n ? kDenseMany : kDenseNone;   // (decided by k_dense_emit, which may read single bytes)
+    } else {
+        const uint4 tx = load16u(p + start);
+        const uint32_t mask = img[0];
+        const uint32_t *ht = img + img[1], *recs = img + img[2], *tails = img + img[3];
+        uint32_t slot = ((tx.x * img[5]) >> 16) & mask, e1;
+        for (;;) {
+            e1 = ht[2u * slot + 1u];
+            if (e1 == 0xFFFFFFFFu || ht[2u * slot] == tx.x) break;
+            slot = (slot + 1u) & mask;
+        }
+        if (e1 != 0xFFFFFFFFu) {
+            const uint32_t first = e1 & 0xFFFFu, count = e1 >> 16;
+#pragma unroll 1
+            for (uint32_t k = 0; k < count; ++k) {
+                const uint32_t r0 = recs[2u * (first + k)], r1 = recs[2u * (first + k) + 1u];
+                const uint32_t len = r0 >> 24, toff = r1 & 0xFFFFu;
+                if (start < it.floor || start + len > n) continue;
+                const uint32_t tl = len - 4u;
+                const uint32_t m0 = tl >= 4u ? 0xFFFFFFFFu : (1u << (8u * tl)) - 1u;
+                const uint32_t m1 = tl >= 8u ? 0xFFFFFFFFu : tl > 4u ? (1u << (8u * (tl - 4u))) - 1u : 0u;
+                const uint32_t m2 = tl >= 12u ? 0xFFFFFFFFu : tl > 8u ? (1u << (8u * (tl - 8u))) - 1u : 0u;
+                const uint32_t diff = ((tx.y ^ tails[toff]) & m0) | ((tx.z ^ tails[toff + 1u]) & m1) | ((tx.w ^ tails[toff + 2u]) & m2);
+                if (diff) continue;
+                out = out == kDenseNone ? first + k : kDenseMany;
+            }
+        }
+    }
+    results[item * Q + r] = out;
+    }
+}
+
+template <typename E, int MODE>
+__global__ __launch_bounds__(256) void k_dense_emit(DevAutomaton A, BatchArgs B, const uint32_t *results) {
+    const uint64_t total_items = B.item_base[B.n_haystacks];
+    const uint64_t item = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    __shared__ uint32_t s_walked;
+    if (threadIdx.x == 0) s_walked = 0;
+    __syncthreads();
+    uint32_t walked = 0;
+    const uint32_t nr = item < total_items ? B.run_count[item] : 0u;
+    if (nr != 0) {
+        const uint4 rec = B.item_rec[item];
+        ItemDesc it;
+        unpack_item(rec.x, rec.y, rec.z, rec.w, it);
+        const uint8_t *p = B.blob + (it.begin - it.warm);
+        const uint32_t n = it.warm + it.len;
+        const uint32_t pos_bias = it.pos0 - it.warm + 1u;
+        const uint32_t m_min = A.min_pattern_length, l_max = A.max_pattern_length;
+        const uint32_t *img = A.dense_image;              // (records read through the cache: a few KiB, shared by everyone)
+        const uint32_t *recs = img + img[2];
+        EventRegs ev{0, 0};
+        if (nr > B.run_cap) {
+            walked = n;
+            exact_range<E, MODE, false>(A, B, nullptr, nullptr, 0u, item, p, it.floor, n, it.warm, pos_bias, 0u, ev);
+            atomicAdd(&B.counters[7], (n + 15u) >> 4);
+        } else {
+            const uint32_t *starts = reinterpret_cast<const uint32_t *>(B.runs) + item * uint64_t(B.run_cap);
+            const uint32_t *res = results + item * uint64_t(B.run_cap);
+            uint32_t r = 0;
+#pragma unroll 1
+            while (r < nr) {
+                const uint32_t first = starts[r];
+                uint32_t hi = first + l_max < n ? first + l_max : n, nv = 0;
+                Verified v[kClusterMax];
+#pragma unroll
+                for (uint32_t i = 0; i < kClusterMax; ++i) v[i] = Verified{0xFFFFFFFFu, 0u, 0u};
+                bool windows = true;
+                uint32_t st = first;
+#pragma unroll 1
+                for (;;) {
+                    const uint32_t got = res[r];
+                    if (got == kDenseMany) {
+                        // several patterns with this prefix, or a window in the item's last bytes: decided here
+                        if (windows) windows = A.anchor_pairs != nullptr && verify_candidate(A, p, n, it.floor, st, v, nv);
+                    } else if (got != kDenseNone && windows) {
+                        if (nv >= kClusterMax) windows = false;
+                        else {
+                            const uint32_t r0 = recs[2u * got], r1 = recs[2u * got + 1u];
+                            uint32_t oc = r1 >> 16;
+                            if (oc == 65535u) oc = A.out_count[r0 & 0xFFFFFFu];
+                            const Verified vv{st + (r0 >> 24) - 1u, r0 & 0xFFFFFFu, oc};
+#pragma unroll
+                            for (uint32_t i = 0; i < kClusterMax; ++i) if (i == nv) v[i] = vv;
+                            ++nv;
+                        }
+                    }
+                    ++r;
+                    if (r >= nr) break;
+                    st = starts[r];
+                    if (st + m_min - 1u > hi) break;   // neither adjacent nor overlapping: the next cluster
+                    const uint32_t h2 = st + l_max < n ? st + l_max : n;
+                    hi = h2 > hi ? h2 : hi;
+                }
+                const uint32_t lo = first + m_min - 1u;
+                if (lo >= n) continue;
+                const uint32_t rep_from = lo > it.warm ? lo : it.warm;
+                walked += hi - lo;
+                if (windows) {
+                    if (nv) emit_verified(B, item, v, rep_from, hi, pos_bias, ev);
+                    continue;
+                }
+                const uint32_t from = first > it.floor ? first : it.floor;
+                exact_range<E, MODE, false>(A, B, nullptr, nullptr, 0u, item, p, from, hi, rep_from, pos_bias, 0u, ev);
+                atomicAdd(&B.counters[7], (hi - from + 15u) >> 4);
+            }
+        }
+        if (ev.n_ev) {
+            B.ev_count[item] = ev.n_ev;
+            B.rec_count[item] = ev.n_rec;
+            if (ev.n_ev > B.slab_events) B.overflow_list[atomicAdd(&B.counters[0], 1u)] = uint32_t(item);
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) walked += __shfl_xor(walked, d, 64);
+    if ((threadIdx.x & 63u) == 0 && walked) atomicAdd(&s_walked, (walked + 15u) >> 4);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_walked) atomicAdd(&B.counters[8u + (blockIdx.x & 7u)], s_walked);
+}
+
 static hipError_t launch_verify_dense(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,
                                       hipStream_t st) {
     const uint32_t blocks = uint32_t((max_items + kWalkThreads - 1) / kWalkThreads);
-    const bool vlds = A.dense_image != nullptr;
-    const uint32_t lds = vlds ? A.dense_image_words * 4u : 16u;
+    if (A.dense_image != nullptr && B.run_cap % 64u == 0 && B.run_cap <= 1024u) {
+        // results live behind the window lists in the same buffer (engine.cpp sizes it: 8 bytes per window slot)
+        uint32_t *results = reinterpret_cast<uint32_t *>(B.runs) + B.run_stride * uint64_t(B.run_cap);
+        const uint32_t lds1 = A.dense_image_words * 4u;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_decide), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds1));
+        if (e != hipSuccess) return e;
+        const uint64_t threads = max_items * uint64_t(B.run_cap);
+        const uint32_t per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(2u, (160u * 1024u) / std::max<uint32_t>(lds1, 1u)));
+        const uint64_t blocks1 = std::min<uint64_t>((threads + 1023) / 1024, uint64_t(num_cus()) * per_cu);
+        hipLaunchKernelGGL(k_dense_decide, dim3(uint32_t(blocks1)), dim3(1024), lds1, st, A, B, results);
+        const uint32_t blocks2 = uint32_t((max_items + 255) / 256);
+        if (entry_bytes == 2) {
+            if (class_mode == 1) hipLaunchKernelGGL((k_dense_emit<uint16_t, 1>), dim3(blocks2), dim3(256), 0, st, A, B, results);
+            else hipLaunchKernelGGL((k_dense_emit<uint16_t, 0>), dim3(blocks2), dim3(256), 0, st, A, B, results);
+        } else {
+            if (class_mode == 1) hipLaunchKernelGGL((k_dense_emit<uint32_t, 1>), dim3(blocks2), dim3(256), 0, st, A, B, results);
+            else hipLaunchKernelGGL((k_dense_emit<uint32_t, 0>), dim3(blocks2), dim3(256), 0, st, A, B, results);
+        }
+        return hipGetLastError();
+    }
+    const uint32_t lds = 16u;   // (no image: candidates are verified through the tables in global memory)
     auto go = [&](auto fn) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(fn, dim3(blocks), dim3(kWalkThreads), lds, st, A, B);
         return hipGetLastError();
     };
-#define ACMI_VERIFY_DENSE(E, M) (vlds ? go(k_verify_dense<E, M, true>) : go(k_verify_dense<E, M, false>))
+#define ACMI_VERIFY_DENSE(E, M) go(k_verify_dense<E, M, false>)
     if (entry_bytes == 2) return class_mode == 1 ? ACMI_VERIFY_DENSE(uint16_t, 1) : ACMI_VERIFY_DENSE(uint16_t, 0);
     return class_mode == 1 ? ACMI_VERIFY_DENSE(uint32_t, 1) : ACMI_VERIFY_DENSE(uint32_t, 0);
 #undef ACMI_VERIFY_DENSE
