@@ -298,6 +298,9 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *                    pattern anchored by its first four bytes, the window tested at every byte offset of the text: -1 (default)
  *                    when at most ~ 160 windows per 8 KiB are expected to hit on text that looks like the patterns, 0 never,
  *                    1 whenever the shortest pattern allows                                         [before finalize]
+ *   "dense_hot"      dense anchor form: the scan variant that works out which windows hit in every step, branch-free (+ 10 VALU per
+ *                    dword) instead of behind a rarely-taken branch: -1 (default) when a dozen or more hit windows are expected
+ *                    per 8 KiB, 0 never, 1 always                                                  [before the first match]
  *   "anchor_choice"  big pattern sets (anchor mode 2): which aligned window of a pattern is its anchor is chosen so that the
  *                    anchors share bits of the LDS bitmap (greedy set cover: 9 % of the bits set instead of 22 % for 65,536
  *                    patterns, as many fewer probes of the fingerprint table): -1 / 1 = yes (default), 0 = always the
@@ -332,7 +335,7 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value);
  * "max_pattern_length", "items", "overflow_items", "walked_bytes", "fallback_bytes", "kernel_used" (0, 1, 2, 4 as the
  * "kernel" option; 5 = the one-launch small-batch path), "anchor_variant" (the k_scan_anchor template the last batch ran:
  * window dwords in bits 0-2 | 8 big set (LDS bitmap + L2 table) | 16 short-row variant | 32 tiny-item variant | 64 windows
- * at every byte offset; 0 = another kernel), "tiny_waves" (wave batches that took the tiny-item path), "scan_ms",
+ * at every byte offset | 128 its many-hits variant; 0 = another kernel), "tiny_waves" (wave batches that took the tiny-item path), "scan_ms",
  * "total_ms". */
 int acmi_get_stat(const acmi_handle *h, const char *key, double *value);
 

@@ -112,6 +112,7 @@ struct acmi_handle {
     int refill = 0;       // 0 automatic, 1 one thread per overflowed item (k_refill), 2 one wave (k_refill_wave)
     int profile = 0;
     int verify = 1;            // 1: anchor candidates whose q-gram names one pattern are decided by comparing its text
+    int dense_hot = -1;        // dense anchor form: the scan variant that works out every step's hits branch-free: -1 by the expected hit rate, 0 never, 1 always
     int device_build = -1;     // failure links + outputs of the build on the device: -1 from 200,000 trie nodes, 0 never, 1 always
     int keep_host_tables = 0;  // 1: the host copies of table / tile / records stay after the upload (acmi_debug_tables)
 
@@ -451,6 +452,7 @@ int ensure_device(acmi_handle *h) {
     A.anchor_bucket_mask = fa.anchor_mode == 2 ? (1u << fa.anchor_bucket_bits) - 1u : 0u;
     A.anchor_choice = fa.anchor_choice;
     A.anchor_dense = fa.anchor_dense;
+    A.anchor_dense_hot = (h->dense_hot > 0 || (h->dense_hot < 0 && fa.anchor_dense_rate * 8192.0 > 12.0)) ? 1u : 0u;
     A.anchor_bucket_shift = fa.anchor_bucket_shift;
     A.anchor_mul = fa.anchor_mul;
     A.min_pattern_length = fa.min_pattern_length;
@@ -1301,6 +1303,9 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
         } else if (k == "verify") {
             if (h->dev_ready) return ACMI_E_FINALIZED;  // the tables are uploaded (or not) by the first match call
             h->verify = value ? 1 : 0;
+        } else if (k == "dense_hot") {
+            if (h->dev_ready) return ACMI_E_FINALIZED;
+            h->dense_hot = value < 0 ? -1 : (value ? 1 : 0);
         } else if (k == "device_build") {
             if (h->aut.finalized()) return ACMI_E_FINALIZED;
             h->device_build = value < 0 ? -1 : (value ? 1 : 0);

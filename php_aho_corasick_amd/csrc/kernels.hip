@@ -1351,7 +1351,10 @@ __device__ __forceinline__ bool anchor_next(const DevAutomaton &A, const BatchAr
 // turned into runs by VECTOR code -- a wave prefix sum over the lanes' hit counts gives every hit its slot in the item's
 // run list -- not one by one through the scalar unit; runs keep their natural bounds (they may overlap: k_walk_runs joins
 // them into clusters).
-template <int QW, bool BIG, bool SHORT, bool TINY = false, bool DENSE = false>
+// HOT (dense form): many hit windows expected (a dozen or more per 8 KiB) -- which of a step's four windows hit is worked out
+// for every step, branch-free (31 VALU), instead of a cheap any-hit test (21) with the exact one behind a branch (+ 35 when
+// taken: with three hits per step that was most of the kernel's instructions).
+template <int QW, bool BIG, bool SHORT, bool TINY = false, bool DENSE = false, bool HOT = false>
 __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, BatchArgs B) {
     static_assert(!DENSE || (QW == 1 && !BIG), "the dense form exists for 4-byte windows and the LDS table only");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1643,6 +1646,23 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
             if (t > 0 && (!SHORT || uint32_t((t - 1) >> 2) < rows)) {
                 const u32x2 *b4 = bb[(t - 1) & 1];
                 const uint32_t *h4 = hh[(t - 1) & 1];
+                if constexpr (HOT) {
+                    // per window: the bucket's four slots minus the fingerprint, their minimum per halfword pair, the
+                    // zero-halfword test (bits 15 / 31), shifted to the window's own bit positions and merged
+                    uint32_t dd = 0;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        uint32_t x, y, tm;
+                        asm("v_pk_sub_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(x) : "v"(b4[w].x), "v"(h4[w]));
+                        asm("v_pk_sub_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(y) : "v"(b4[w].y), "v"(h4[w]));
+                        asm("v_pk_min_u16 %0, %1, %2" : "=v"(tm) : "v"(x), "v"(y));
+                        const uint32_t d = (tm - 0x00010001u) & ~tm;
+                        dd |= (d >> (3 - w)) & (0x80008000u >> (3 - w));   // window w at bits 12 + w and 28 + w
+                    }
+                    const uint32_t m = __builtin_amdgcn_ubfe(dd | (dd >> 16), 12u, 4u);   // bit w: window w hit
+                    z[(t - 1) >> 2] |= m << (4 * ((t - 1) & 3));
+                    zany |= m;
+                } else {
                 uint32_t zz = 0xFFFFFFFFu;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) zz = anchor_compare(b4[w], h4[w], zz);
@@ -1652,6 +1672,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                     for (int w = 0; w < 4; ++w) m |= has_zero_half(anchor_compare(b4[w], h4[w], 0xFFFFFFFFu)) ? (1u << w) : 0u;
                     z[(t - 1) >> 2] |= m << (4 * ((t - 1) & 3));
                     zany |= m;
+                }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -2191,12 +2212,18 @@ __global__ __launch_bounds__(kWalkThreads) void k_verify_dense(DevAutomaton A, B
 //                    whose ranges touch, emits the events in position order; only kDenseMany windows are looked at again.
 constexpr uint32_t kDenseNone = 0xFFFFFFFFu, kDenseMany = 0xFFFFFFFEu;
 
-__global__ __launch_bounds__(1024) void k_dense_decide(DevAutomaton A, BatchArgs B, uint32_t *results) {
+// One WAVE per item, 64 hit windows per step: the window starts in one coalesced read, the text loads (they fall into the
+// item's own few lines), the LDS lookup, and the windows that hold an occurrence COMPACTED (ballot + mbcnt, running base):
+// found[item * Q + i] = start of the i-th such window (written over the window list: i never exceeds the index read) and
+// its record index -- or kDenseMany -- behind the lists; run_count[item] becomes the number found.  Most hit windows hold
+// nothing (a keyword list: nine in ten are a word's first four letters and no more), so k_dense_emit is left with a
+// handful of entries per item.
+__global__ __launch_bounds__(1024) void k_dense_decide(DevAutomaton A, BatchArgs B, uint32_t *found_idx) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint64_t total_items = B.item_base[B.n_haystacks];
-    const uint32_t Q = B.run_cap;                       // a multiple of 64 (the host sees to it)
-    if (uint64_t(blockIdx.x) * 1024u / Q >= total_items) return;
-    {   // the image is staged once per workgroup; the workgroups are persistent (a few per CU) and stride over the windows
+    const uint32_t Q = B.run_cap;
+    if (uint64_t(blockIdx.x) * 16u >= total_items) return;
+    {   // the image is staged once per workgroup; the workgroups are persistent (a few per CU) and stride over the items
         const uint4 *src = reinterpret_cast<const uint4 *>(A.dense_image);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
         const uint32_t n16 = A.dense_image_words >> 2;
@@ -2204,61 +2231,81 @@ __global__ __launch_bounds__(1024) void k_dense_decide(DevAutomaton A, BatchArgs
     }
     __syncthreads();
     const uint32_t *img = reinterpret_cast<const uint32_t *>(smem);
-    for (uint64_t t = uint64_t(blockIdx.x) * 1024u + threadIdx.x; t / Q < total_items; t += uint64_t(gridDim.x) * 1024u) {
-    const uint64_t item = t / Q;
-    const uint32_t r = uint32_t(t % Q);
-    const uint32_t nr = B.run_count[item];
-    if (nr > Q || r >= nr) continue;
-    const uint4 rec = B.item_rec[item];
-    ItemDesc it;
-    unpack_item(rec.x, rec.y, rec.z, rec.w, it);
-    const uint8_t *p = B.blob + (it.begin - it.warm);
-    const uint32_t n = it.warm + it.len;
-    const uint32_t start = reinterpret_cast<const uint32_t *>(B.runs)[item * Q + r];
-    uint32_t out = kDenseNone;
-    if (start + 16u > n) {
-        out = start + 4u <= n ? kDenseMany : kDenseNone;   // (decided by k_dense_emit, which may read single bytes)
-    } else {
-        const uint4 tx = load16u(p + start);
-        const uint32_t mask = img[0];
-        const uint32_t *ht = img + img[1], *recs = img + img[2], *tails = img + img[3];
-        uint32_t slot = ((tx.x * img[5]) >> 16) & mask, e1;
-        for (;;) {
-            e1 = ht[2u * slot + 1u];
-            if (e1 == 0xFFFFFFFFu || ht[2u * slot] == tx.x) break;
-            slot = (slot + 1u) & mask;
-        }
-        if (e1 != 0xFFFFFFFFu) {
-            const uint32_t first = e1 & 0xFFFFu, count = e1 >> 16;
+    const uint32_t mask = img[0];
+    const uint32_t *ht = img + img[1], *recs = img + img[2], *tails = img + img[3];
+    const uint32_t hmul = img[5];
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t *starts_all = reinterpret_cast<uint32_t *>(B.runs);
+    for (uint64_t item = uint64_t(blockIdx.x) * 16u + (threadIdx.x >> 6); item < total_items; item += uint64_t(gridDim.x) * 16u) {
+        const uint32_t nr = __builtin_amdgcn_readfirstlane(B.run_count[item]);
+        if (nr == 0 || nr > Q) continue;   // (more windows than the list holds: k_dense_emit walks the whole item)
+        const uint4 rec = B.item_rec[item];
+        ItemDesc it;
+        unpack_item(rec.x, rec.y, rec.z, rec.w, it);
+        const uint8_t *p = B.blob + (it.begin - it.warm);
+        const uint32_t n = it.warm + it.len;
+        uint32_t *starts = starts_all + item * uint64_t(Q), *fidx = found_idx + item * uint64_t(Q);
+        uint32_t base = 0;
 #pragma unroll 1
-            for (uint32_t k = 0; k < count; ++k) {
-                const uint32_t r0 = recs[2u * (first + k)], r1 = recs[2u * (first + k) + 1u];
-                const uint32_t len = r0 >> 24, toff = r1 & 0xFFFFu;
-                if (start < it.floor || start + len > n) continue;
-                const uint32_t tl = len - 4u;
-                const uint32_t m0 = tl >= 4u ? 0xFFFFFFFFu : (1u << (8u * tl)) - 1u;
-                const uint32_t m1 = tl >= 8u ? 0xFFFFFFFFu : tl > 4u ? (1u << (8u * (tl - 4u))) - 1u : 0u;
-                const uint32_t m2 = tl >= 12u ? 0xFFFFFFFFu : tl > 8u ? (1u << (8u * (tl - 8u))) - 1u : 0u;
-                const uint32_t diff = ((tx.y ^ tails[toff]) & m0) | ((tx.z ^ tails[toff + 1u]) & m1) | ((tx.w ^ tails[toff + 2u]) & m2);
-                if (diff) continue;
-                out = out == kDenseNone ? first + k : kDenseMany;
+        for (uint32_t c = 0; c < nr; c += 64u) {
+            const uint32_t r = c + lane;
+            const bool active = r < nr;
+            const uint32_t start = active ? starts[r] : 0u;
+            uint32_t out = kDenseNone;
+            if (active) {
+                if (start + 16u > n) {
+                    out = start + 4u <= n ? kDenseMany : kDenseNone;   // (decided by k_dense_emit, which reads single bytes)
+                } else {
+                    const uint4 tx = load16u(p + start);
+                    uint32_t slot = ((tx.x * hmul) >> 16) & mask, e1;
+                    for (;;) {
+                        e1 = ht[2u * slot + 1u];
+                        if (e1 == 0xFFFFFFFFu || ht[2u * slot] == tx.x) break;
+                        slot = (slot + 1u) & mask;
+                    }
+                    if (e1 != 0xFFFFFFFFu) {
+                        const uint32_t first = e1 & 0xFFFFu, count = e1 >> 16;
+#pragma unroll 1
+                        for (uint32_t k = 0; k < count; ++k) {
+                            const uint32_t r0 = recs[2u * (first + k)], r1 = recs[2u * (first + k) + 1u];
+                            const uint32_t len = r0 >> 24, toff = r1 & 0xFFFFu;
+                            if (start < it.floor || start + len > n) continue;
+                            const uint32_t tl = len - 4u;
+                            const uint32_t m0 = tl >= 4u ? 0xFFFFFFFFu : (1u << (8u * tl)) - 1u;
+                            const uint32_t m1 = tl >= 8u ? 0xFFFFFFFFu : tl > 4u ? (1u << (8u * (tl - 4u))) - 1u : 0u;
+                            const uint32_t m2 = tl >= 12u ? 0xFFFFFFFFu : tl > 8u ? (1u << (8u * (tl - 8u))) - 1u : 0u;
+                            const uint32_t diff = ((tx.y ^ tails[toff]) & m0) | ((tx.z ^ tails[toff + 1u]) & m1) | ((tx.w ^ tails[toff + 2u]) & m2);
+                            if (diff) continue;
+                            out = out == kDenseNone ? first + k : kDenseMany;
+                        }
+                    }
+                }
+            }
+            const bool keep = out != kDenseNone;
+            const uint64_t km = __ballot(keep);
+            if (km != 0) {
+                const uint32_t at = base + __builtin_amdgcn_mbcnt_hi(uint32_t(km >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(km), 0u));
+                if (keep) {
+                    starts[at] = start;   // at <= r: every lane of this step has read its start, earlier steps' are consumed
+                    fidx[at] = out;
+                }
+                base += uint32_t(__builtin_popcountll(km));
             }
         }
-    }
-    results[item * Q + r] = out;
+        if (lane == 0) B.run_count[item] = base;
     }
 }
 
 template <typename E, int MODE>
-__global__ __launch_bounds__(256) void k_dense_emit(DevAutomaton A, BatchArgs B, const uint32_t *results) {
+__global__ __launch_bounds__(256) void k_dense_emit(DevAutomaton A, BatchArgs B, const uint32_t *found_idx) {
     const uint64_t total_items = B.item_base[B.n_haystacks];
     const uint64_t item = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     __shared__ uint32_t s_walked;
     if (threadIdx.x == 0) s_walked = 0;
     __syncthreads();
     uint32_t walked = 0;
-    const uint32_t nr = item < total_items ? B.run_count[item] : 0u;
-    if (nr != 0) {
+    const uint32_t nf = item < total_items ? B.run_count[item] : 0u;   // occurrences found (> run_cap: the window list overflowed)
+    if (nf != 0) {
         const uint4 rec = B.item_rec[item];
         ItemDesc it;
         unpack_item(rec.x, rec.y, rec.z, rec.w, it);
@@ -2269,16 +2316,17 @@ __global__ __launch_bounds__(256) void k_dense_emit(DevAutomaton A, BatchArgs B,
         const uint32_t *img = A.dense_image;              // (records read through the cache: a few KiB, shared by everyone)
         const uint32_t *recs = img + img[2];
         EventRegs ev{0, 0};
-        if (nr > B.run_cap) {
+        if (nf > B.run_cap) {
             walked = n;
             exact_range<E, MODE, false>(A, B, nullptr, nullptr, 0u, item, p, it.floor, n, it.warm, pos_bias, 0u, ev);
             atomicAdd(&B.counters[7], (n + 15u) >> 4);
         } else {
             const uint32_t *starts = reinterpret_cast<const uint32_t *>(B.runs) + item * uint64_t(B.run_cap);
-            const uint32_t *res = results + item * uint64_t(B.run_cap);
+            const uint32_t *fidx = found_idx + item * uint64_t(B.run_cap);
             uint32_t r = 0;
 #pragma unroll 1
-            while (r < nr) {
+            while (r < nf) {
+                // a cluster: occurrences whose possible ranges [start + m_min - 1, start + Lmax) touch or overlap
                 const uint32_t first = starts[r];
                 uint32_t hi = first + l_max < n ? first + l_max : n, nv = 0;
                 Verified v[kClusterMax];
@@ -2288,11 +2336,11 @@ __global__ __launch_bounds__(256) void k_dense_emit(DevAutomaton A, BatchArgs B,
                 uint32_t st = first;
 #pragma unroll 1
                 for (;;) {
-                    const uint32_t got = res[r];
+                    const uint32_t got = fidx[r];
                     if (got == kDenseMany) {
                         // several patterns with this prefix, or a window in the item's last bytes: decided here
                         if (windows) windows = A.anchor_pairs != nullptr && verify_candidate(A, p, n, it.floor, st, v, nv);
-                    } else if (got != kDenseNone && windows) {
+                    } else if (windows) {
                         if (nv >= kClusterMax) windows = false;
                         else {
                             const uint32_t r0 = recs[2u * got], r1 = recs[2u * got + 1u];
@@ -2305,7 +2353,7 @@ __global__ __launch_bounds__(256) void k_dense_emit(DevAutomaton A, BatchArgs B,
                         }
                     }
                     ++r;
-                    if (r >= nr) break;
+                    if (r >= nf) break;
                     st = starts[r];
                     if (st + m_min - 1u > hi) break;   // neither adjacent nor overlapping: the next cluster
                     const uint32_t h2 = st + l_max < n ? st + l_max : n;
@@ -2319,6 +2367,7 @@ __global__ __launch_bounds__(256) void k_dense_emit(DevAutomaton A, BatchArgs B,
                     if (nv) emit_verified(B, item, v, rep_from, hi, pos_bias, ev);
                     continue;
                 }
+                // every occurrence that ends in the cluster begins at one of its windows, the first being the leftmost
                 const uint32_t from = first > it.floor ? first : it.floor;
                 exact_range<E, MODE, false>(A, B, nullptr, nullptr, 0u, item, p, from, hi, rep_from, pos_bias, 0u, ev);
                 atomicAdd(&B.counters[7], (hi - from + 15u) >> 4);
@@ -2340,15 +2389,14 @@ __global__ __launch_bounds__(256) void k_dense_emit(DevAutomaton A, BatchArgs B,
 static hipError_t launch_verify_dense(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,
                                       hipStream_t st) {
     const uint32_t blocks = uint32_t((max_items + kWalkThreads - 1) / kWalkThreads);
-    if (A.dense_image != nullptr && B.run_cap % 64u == 0 && B.run_cap <= 1024u) {
+    if (A.dense_image != nullptr) {
         // results live behind the window lists in the same buffer (engine.cpp sizes it: 8 bytes per window slot)
         uint32_t *results = reinterpret_cast<uint32_t *>(B.runs) + B.run_stride * uint64_t(B.run_cap);
         const uint32_t lds1 = A.dense_image_words * 4u;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_decide), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds1));
         if (e != hipSuccess) return e;
-        const uint64_t threads = max_items * uint64_t(B.run_cap);
         const uint32_t per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(2u, (160u * 1024u) / std::max<uint32_t>(lds1, 1u)));
-        const uint64_t blocks1 = std::min<uint64_t>((threads + 1023) / 1024, uint64_t(num_cus()) * per_cu);
+        const uint64_t blocks1 = std::min<uint64_t>((max_items + 15) / 16, uint64_t(num_cus()) * per_cu);
         hipLaunchKernelGGL(k_dense_decide, dim3(uint32_t(blocks1)), dim3(1024), lds1, st, A, B, results);
         const uint32_t blocks2 = uint32_t((max_items + 255) / 256);
         if (entry_bytes == 2) {
@@ -3266,7 +3314,7 @@ static hipError_t launch_anchor(const DevAutomaton &A, const BatchArgs &B, uint6
     if (variant) {
         const bool big = A.anchor_mode == 2, tiny = B.tiny_items != 0;
         const bool shrt = !big && (tiny || B.short_items != 0);
-        *variant = (A.anchor_q / 4u) | (big ? 8u : 0u) | (shrt ? 16u : 0u) | (tiny ? 32u : 0u) | (A.anchor_dense ? 64u : 0u);
+        *variant = (A.anchor_q / 4u) | (big ? 8u : 0u) | (shrt ? 16u : 0u) | (tiny ? 32u : 0u) | (A.anchor_dense ? 64u : 0u) | (A.anchor_dense && A.anchor_dense_hot ? 128u : 0u);
     }
     const uint64_t per_block = uint64_t(kLdsThreads / 64u) * B.wave_items;
     const uint64_t want = (max_items + per_block - 1) / per_block;
@@ -3280,6 +3328,11 @@ static hipError_t launch_anchor(const DevAutomaton &A, const BatchArgs &B, uint6
         return hipGetLastError();
     };
     if (A.anchor_dense) {  // windows at every byte offset (shortest pattern 4..6 B)
+        if (A.anchor_dense_hot) {
+            if (B.tiny_items) return go(k_scan_anchor<1, false, true, true, true, true>);
+            if (B.short_items) return go(k_scan_anchor<1, false, true, false, true, true>);
+            return go(k_scan_anchor<1, false, false, false, true, true>);
+        }
         if (B.tiny_items) return go(k_scan_anchor<1, false, true, true, true>);
         if (B.short_items) return go(k_scan_anchor<1, false, true, false, true>);
         return go(k_scan_anchor<1, false, false, false, true>);
