@@ -138,7 +138,7 @@ def test_automatic_choice_of_exact_walk(golden):
 
     # 8 patterns of 6 letters: sparse on uniform text (8 / 26^6 events per byte), but this text is ALL pattern
     ds = synth.generate("sw", 77, 8, 6, 6, 1, 64, bytes(range(97, 123)))
-    res = resource_for(ds)
+    res = resource_for(ds, anchor_dense=0)   # (with the dense anchor form these patterns take kernel 2: second half of the test)
     api.ahocorasick_finalize(res)
     assert res.stat("est_flag_rate") * 8192 < 1 and res.stat("anchor_q") == 0
     o = Oracle("port")
@@ -157,6 +157,20 @@ def test_automatic_choice_of_exact_walk(golden):
         p, r = batch.result_numpy(res, 256, total)
         assert np.array_equal(p, pe) and np.array_equal(r, re_)
     assert used[0] == 1 and used[1] == 4 and used[2] == 4, used
+    api.ahocorasick_deinit(res)
+    # the same set with the dense anchor form (shortest pattern 6 B: windows at every byte offset): this text has a hit window
+    # every six bytes, the window lists overflow, whole items are walked -- the handle leaves the filter after the first batch
+    res = resource_for(ds)
+    api.ahocorasick_finalize(res)
+    assert res.stat("anchor_q") == 4 and res.stat("anchor_dense") == 1
+    batch.bind_current_stream(res)
+    used = []
+    for _ in range(3):
+        total = batch.match_device(res, d_blob, d_off, True)
+        used.append(int(res.stat("kernel_used")))
+        p, r = batch.result_numpy(res, 256, total)
+        assert np.array_equal(p, pe) and np.array_equal(r, re_)
+    assert used[0] == 2 and used[1] != 2, used
     api.ahocorasick_deinit(res)
 
 
