@@ -95,6 +95,10 @@ struct acmi_handle {
     // automatic mode: a batch on which the fast kernel lost (most bytes had to be walked exactly anyway) moves the
     // handle to the slower, safer kernel -- for `*_left` batches, then the fast one is probed again; every further
     // loss doubles the span (16 .. 1024 batches), a win resets it.  Batches under kAutoMinBytes decide nothing.
+    // The drain of items whose events overflowed their slab (k_refill_wave) is a launch of its own, ~ 8 us with its kernel
+    // boundary even when there is nothing to drain: it is enqueued with the pipeline only while batches need it (the batch
+    // before did, or the pattern set is a dense one); a batch that needs it unexpectedly gets it at its end.
+    bool refill_armed = false;
     bool anchor_off = false;  // the anchor filter lost on this handle's data: table walk meanwhile
     bool exact_only = false;  // k_scan_lds' optimistic pass flagged most of a batch: exact whole-item walk meanwhile
     uint32_t anchor_left = 0, anchor_span = 16, exact_left = 0, exact_span = 16;
@@ -168,6 +172,7 @@ struct acmi_handle {
         hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
         hipStream_t stream = nullptr;  // the stream this batch was enqueued on (acmi_set_stream is refused while batches are in flight)
         uint32_t anchor_variant = 0;   // template of k_scan_anchor that ran (acmi_get_stat "anchor_variant")
+        bool refill_launched = false;  // the drain of overflowed items was enqueued with the pipeline (else: only if the batch turns out to need it)
         DevBuf d_prefix, d_out;        // valid from this batch's end until the second begin after its own
     };
     FlySlot fly[2];
@@ -315,6 +320,7 @@ int ensure_finalized(acmi_handle *h) {
     if (fa.est_flag_rate * 8192.0 > double(h->run_cap)) {
         h->exact_only = true;
         h->exact_left = h->exact_span;
+        h->refill_armed = true;   // (dense sets: the first batch will want its overflowed items drained)
     }
     return 1;
 }
@@ -721,7 +727,6 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     if (h->profile > 1) HIPCHK(h, hipEventRecord(F.ev[3], st));
 
     if (!find_all) launch_first_only(B, st);
-    launch_rec_scan(B, max_items, h->d_rec_base.as<uint64_t>(), sync_cur + 17, status1, st);
 
     // Expansion is enqueued optimistically with the output capacity of the previous call, so the
     // whole pipeline needs ONE host synchronisation (the read-back of the summary at the end).  Only
@@ -731,8 +736,9 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     // (also: per-haystack prefix, the summary for the host next to the overflow counter -- counters[2..3] = total
     // records, [4..5] = items -- and the zeroing of the next batch's sync block)
     launch_expand(h->dA, B, max_items, h->d_rec_base.as<uint64_t>(), F.d_out.p, cap, F.d_prefix.as<uint64_t>(),
-                  pinned_dev, sync_next, sync_words, st);
-    if (find_all) launch_refill(h->dA, B, max_items, int(fa.entry_bytes), h->d_rec_base.as<uint64_t>(), F.d_out.p, cap, h->refill, st);
+                  pinned_dev, sync_next, sync_words, sync_cur + 17, status1, true, st);
+    F.refill_launched = find_all && h->refill_armed;
+    if (F.refill_launched) launch_refill(h->dA, B, max_items, int(fa.entry_bytes), h->d_rec_base.as<uint64_t>(), F.d_out.p, cap, h->refill, st);
     F.sync_next = sync_next;
     F.sync_words = sync_words;
     HIPCHK(h, hipEventRecord(F.ev[4], st));  // (always: the end waits for THIS batch, not for the one queued behind it)
@@ -826,12 +832,16 @@ int run_batch_end(acmi_handle *h) {
         }
     }
     h->out_want = std::max<size_t>(h->out_want, size_t(total) * 16);
-    if (total > F.d_out.cap / 16) {  // did not fit the optimistic capacity: grow, expand again
+    const bool too_small = total > F.d_out.cap / 16;             // did not fit the optimistic capacity: grow, expand again
+    const bool undrained = n_ovf > 0 && !F.refill_launched;      // items overflowed their slabs and the drain was not enqueued
+    h->refill_armed = n_ovf > 0;
+    if (too_small || undrained) {
         if (h->enqueue_seq == F.seq) {
-            HIPCHK(h, F.d_out.ensure(total * 16));
+            if (too_small) HIPCHK(h, F.d_out.ensure(total * 16));
             const uint64_t cap = F.d_out.cap / 16;
-            launch_expand(h->dA, F.args, F.max_items, h->d_rec_base.as<uint64_t>(), F.d_out.p, cap, F.d_prefix.as<uint64_t>(),
-                          h->pinned_dev + kPinWords * slot_index, F.sync_next, F.sync_words, st);
+            if (too_small)
+                launch_expand(h->dA, F.args, F.max_items, h->d_rec_base.as<uint64_t>(), F.d_out.p, cap, F.d_prefix.as<uint64_t>(),
+                              h->pinned_dev + kPinWords * slot_index, F.sync_next, F.sync_words, nullptr, nullptr, false, st);
             if (F.find_all)
                 launch_refill(h->dA, F.args, F.max_items, int(fa.entry_bytes), h->d_rec_base.as<uint64_t>(),
                               F.d_out.p, cap, h->refill, st);
@@ -844,7 +854,8 @@ int run_batch_end(acmi_handle *h) {
                 const hipError_t e = hipStreamSynchronize(st);
                 if (e != hipSuccess) { h->sync_tiles = 0; return fail_hip(h, e, "hipStreamSynchronize"); }
             }
-            HIPCHK(h, F.d_out.ensure(total * 16));
+            if (too_small) HIPCHK(h, F.d_out.ensure(total * 16));
+            h->refill_armed = true;
             const int rc = enqueue_batch(h, F, F.d_blob, F.blob_bytes, F.d_off, F.nh, F.find_all);
             if (rc < 0) { h->sync_tiles = 0; return rc; }
             h->enqueue_seq = F.seq;

@@ -413,35 +413,6 @@ __global__ __launch_bounds__(256) void k_item_fill(BatchArgs B) {
     }
 }
 
-// rec_base[i] = records of all items before item i, i = 0..items (the per-item record counts' exclusive scan)
-__global__ __launch_bounds__(kScanThreads) void k_rec_scan(BatchArgs B, uint64_t *rec_base, uint32_t *ticket, uint64_t *status) {
-    __shared__ uint64_t wave_sums[kScanThreads / 64];
-    __shared__ uint64_t s_before;
-    __shared__ uint32_t s_tile;
-    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
-    __syncthreads();
-    const uint32_t tile = s_tile;
-    const uint64_t items = B.item_base[B.n_haystacks];
-    const uint64_t base = uint64_t(tile) * kScanTile + uint64_t(threadIdx.x) * kScanPerThread;
-    if (uint64_t(tile) * kScanTile > items) return;  // (so does every later tile: nobody looks back at this one)
-    uint64_t v[kScanPerThread];
-#pragma unroll
-    for (int i = 0; i < kScanPerThread; ++i) v[i] = base + i < items ? B.rec_count[base + i] : 0ull;
-    uint64_t tile_sum;
-    uint64_t run = tile_exclusive(v, wave_sums, tile_sum);
-    if (threadIdx.x < 64) {
-        const uint64_t bf = chain_exclusive(status, tile, tile_sum);
-        if (threadIdx.x == 0) s_before = bf;
-    }
-    __syncthreads();
-    run += s_before;
-#pragma unroll
-    for (int i = 0; i < kScanPerThread; ++i) {
-        if (base + i <= items) rec_base[base + i] = run;
-        run += v[i];
-    }
-}
-
 uint32_t scan_tiles(uint64_t n) { return uint32_t((n + kScanTile - 1) / kScanTile); }
 
 // ------------------------------------------------------------------------------------------
@@ -2577,38 +2548,112 @@ __device__ __forceinline__ uint64_t emit_event(const DevAutomaton &A, uint4 *out
 
 // `cap` = records the output buffer can hold: the host launches this optimistically with the
 // capacity of the previous call and re-runs it after growing the buffer if the batch did not fit.
-// Thread h <= n_haystacks also writes the per-haystack prefix of the record array (thread n_haystacks: the batch
-// summary {total records, work items} next to the overflow counter, for the host's single read-back), and the
-// first workgroup zeroes the sync block of the NEXT batch (counters, tickets, scan status words).
-__global__ void k_expand(DevAutomaton A, BatchArgs B, const uint64_t *rec_base, uint4 *out, uint64_t cap, uint64_t *prefix,
-                         uint32_t *host_counters, uint32_t *next_sync, uint32_t next_sync_words) {
-    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+//
+// SCAN = true (the pipeline's launch): the exclusive scan of the per-item record counts is done HERE, single pass with
+// look-back like k_items -- a tile of 2,048 items per workgroup, two per thread -- so that the record base of an item is known
+// in the kernel that expands it (k_rec_scan used to be a launch of its own: 14 us + a kernel boundary per batch).  rec_base[]
+// is still written (the drain of overflowed items and a re-expansion read it).  The per-haystack prefix of the record array
+// comes from the items too: the thread of a haystack's FIRST item writes that haystack's word -- and those of the empty
+// haystacks right in front of it --, the workgroup that holds the closing element the words behind the last item, the batch
+// summary {total records, work items} for the host's single read-back next to the overflow counter; and the first workgroup
+// zeroes the sync block of the NEXT batch (counters, tickets, scan status words).
+// SCAN = false (re-expansion into a grown buffer): rec_base[] is read.
+constexpr int kExpandThreads = 1024;
+constexpr int kExpandPerThread = kScanTile / kExpandThreads;   // 2
+
+template <bool SCAN>
+__global__ __launch_bounds__(kExpandThreads) void k_expand(DevAutomaton A, BatchArgs B, uint64_t *rec_base, uint4 *out, uint64_t cap,
+                                                            uint64_t *prefix, uint32_t *host_counters, uint32_t *next_sync,
+                                                            uint32_t next_sync_words, uint32_t *ticket, uint64_t *status) {
+    __shared__ uint64_t wave_sums[kExpandThreads / 64];
+    __shared__ uint64_t s_before, s_total;
+    __shared__ uint32_t s_tile, s_closing;
     if (blockIdx.x == 0) {
         for (uint32_t k = threadIdx.x; k < next_sync_words; k += blockDim.x) next_sync[k] = 0u;
-        // the batch's counters straight into the host's pinned block (words 2..5, the summary, come from the thread
-        // of haystack n below): no copy command behind the pipeline
+        // the batch's counters straight into the host's pinned block (words 2..5, the summary, come from the closing element
+        // below): no copy command behind the pipeline
         // (words 16..31: the scans' tickets and, word 18, the wave batches k_scan_anchor's TINY path took)
         if (threadIdx.x < 32u && (threadIdx.x < 2u || threadIdx.x > 5u)) host_counters[threadIdx.x] = B.counters[threadIdx.x];
     }
+    if (threadIdx.x == 0) { s_tile = SCAN ? atomicAdd(ticket, 1u) : blockIdx.x; s_closing = 0u; }
+    __syncthreads();
+    const uint32_t tile = s_tile;
     const uint64_t items = B.item_base[B.n_haystacks];
-    if (i <= B.n_haystacks) {
-        const uint64_t v = rec_base[B.item_base[i]];
-        prefix[i] = v;
-        if (i == B.n_haystacks) {
+    if (uint64_t(tile) * kScanTile > items) return;  // (so does every later tile: nobody looks back at this one)
+    const uint64_t base = uint64_t(tile) * kScanTile + uint64_t(threadIdx.x) * kExpandPerThread;
+    uint64_t v[kExpandPerThread], rb[kExpandPerThread + 1];
+#pragma unroll
+    for (int i = 0; i < kExpandPerThread; ++i) v[i] = base + i < items ? B.rec_count[base + i] : 0ull;
+    if constexpr (SCAN) {
+        uint64_t sum = 0;
+#pragma unroll
+        for (int i = 0; i < kExpandPerThread; ++i) sum += v[i];
+        uint64_t inc = sum;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t t = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += t;
+        }
+        if (lane == 63) wave_sums[wave] = inc;
+        __syncthreads();
+        uint64_t wave_base = 0, tile_sum = 0;
+#pragma unroll
+        for (int w = 0; w < kExpandThreads / 64; ++w) {
+            const uint64_t x = wave_sums[w];
+            if (w < wave) wave_base += x;
+            tile_sum += x;
+        }
+        if (threadIdx.x < 64) {
+            const uint64_t bf = chain_exclusive(status, tile, tile_sum);
+            if (threadIdx.x == 0) s_before = bf;
+        }
+        __syncthreads();
+        uint64_t run = s_before + wave_base + inc - sum;
+#pragma unroll
+        for (int i = 0; i <= kExpandPerThread; ++i) {
+            rb[i] = run;
+            if (i < kExpandPerThread) {
+                if (base + i <= items) rec_base[base + i] = run;
+                run += v[i];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i <= kExpandPerThread; ++i) rb[i] = base + i <= items ? rec_base[base + i] : 0ull;
+    }
+    // prefix words and the events of this thread's items
+#pragma unroll
+    for (int i = 0; i < kExpandPerThread; ++i) {
+        const uint64_t g = base + i;
+        if (g > items) break;
+        if (g == items) {  // the closing element: the total; the haystacks behind the last item are this workgroup's (below)
             uint64_t *summary = reinterpret_cast<uint64_t *>(host_counters + 2);
-            summary[0] = v;
+            summary[0] = rb[i];
             summary[1] = items;
+            s_total = rb[i];
+            s_closing = 1u;
+            break;
+        }
+        const uint32_t hay = B.item_hay[g];
+        const uint32_t prev = g ? B.item_hay[g - 1] : 0xFFFFFFFFu;
+        if (prev != hay) {  // the haystack's first item: its prefix word, and those of the empty haystacks right before it
+            for (uint32_t hh = prev + 1u; hh != hay + 1u; ++hh) prefix[hh] = rb[i];
+        }
+        const uint32_t n = B.ev_count[g];
+        if (n == 0 || n > B.slab_events) continue;  // overflowed items are k_refill's
+        if (rb[i + 1] > cap) continue;
+        uint64_t w = rb[i];
+        for (uint32_t e = 0; e < n; ++e) {
+            const uint2 ev = B.slab[uint64_t(e) * B.run_stride + g];  // event-major, like the run lists
+            w = emit_event(A, out, w, hay, ev.x, ev.y);
         }
     }
-    if (i >= items) return;
-    const uint32_t n = B.ev_count[i];
-    if (n == 0 || n > B.slab_events) return;  // overflowed items are k_refill's
-    if (rec_base[i + 1] > cap) return;
-    const uint32_t hay = B.item_hay[i];
-    uint64_t w = rec_base[i];
-    for (uint32_t e = 0; e < n; ++e) {
-        const uint2 ev = B.slab[uint64_t(e) * B.run_stride + i];  // event-major, like the run lists
-        w = emit_event(A, out, w, hay, ev.x, ev.y);
+    __syncthreads();
+    if (s_closing) {  // prefix words of the haystacks behind the last item (all of them when the batch has no item), the closing word
+        const uint64_t total = s_total;
+        const uint32_t from = items ? B.item_hay[items - 1] + 1u : 0u;
+        for (uint64_t hh = uint64_t(from) + threadIdx.x; hh <= B.n_haystacks; hh += blockDim.x) prefix[hh] = total;
     }
 }
 
@@ -3270,10 +3315,6 @@ void launch_items(const BatchArgs &B, uint64_t blob_bytes, uint64_t max_items, u
     }
 }
 
-void launch_rec_scan(const BatchArgs &B, uint64_t max_items, uint64_t *rec_base, uint32_t *ticket, uint64_t *status, hipStream_t st) {
-    hipLaunchKernelGGL(k_rec_scan, dim3(scan_tiles(max_items + 1)), dim3(kScanThreads), 0, st, B, rec_base, ticket, status);
-}
-
 int num_cus() {
     static int n = [] {
         int dev = 0, v = 0;
@@ -3391,11 +3432,16 @@ void launch_first_only(const BatchArgs &B, hipStream_t st) {
     hipLaunchKernelGGL(k_first_only, dim3((B.n_haystacks + 255) / 256), dim3(256), 0, st, B);
 }
 
-void launch_expand(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, const uint64_t *rec_base, void *out,
-                   uint64_t cap, uint64_t *prefix, uint32_t *host_counters, uint32_t *next_sync, uint32_t next_sync_words, hipStream_t st) {
-    const uint64_t threads = std::max<uint64_t>(max_items, uint64_t(B.n_haystacks) + 1);
-    hipLaunchKernelGGL(k_expand, dim3(uint32_t((threads + 255) / 256)), dim3(256), 0, st, A, B, rec_base,
-                       static_cast<uint4 *>(out), cap, prefix, host_counters, next_sync, next_sync_words);
+void launch_expand(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, uint64_t *rec_base, void *out,
+                   uint64_t cap, uint64_t *prefix, uint32_t *host_counters, uint32_t *next_sync, uint32_t next_sync_words,
+                   uint32_t *ticket, uint64_t *status, bool scan, hipStream_t st) {
+    const uint32_t blocks = scan_tiles(max_items + 1);
+    if (scan)
+        hipLaunchKernelGGL(k_expand<true>, dim3(blocks), dim3(kExpandThreads), 0, st, A, B, rec_base, static_cast<uint4 *>(out), cap, prefix,
+                           host_counters, next_sync, next_sync_words, ticket, status);
+    else
+        hipLaunchKernelGGL(k_expand<false>, dim3(blocks), dim3(kExpandThreads), 0, st, A, B, rec_base, static_cast<uint4 *>(out), cap, prefix,
+                           host_counters, next_sync, next_sync_words, ticket, status);
 }
 
 void launch_refill(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes,
