@@ -131,8 +131,14 @@ struct acmi_handle {
     DevBuf d_table, d_lds, d_class, d_own, d_dict, d_cnt, d_plen, d_anchor, d_bitmap, d_out_off, d_out_list, d_cold_rec, d_cold_edges, d_chain_byte, d_chain_run, d_slot_pair, d_pairs, d_pat_bytes, d_dense_img;
 
     // workspace (grow-only)
-    DevBuf d_blob, d_off, d_item_base, d_item_hay, d_item_rec, d_zero, d_rec_base, d_slab, d_ovf, d_counters,
-        d_runs, d_run_count;
+    DevBuf d_blob, d_off, d_rec_base, d_slab, d_ovf, d_counters, d_runs, d_run_count;
+    // The item table of a batch (item_base, item -> haystack, packed item records, zeroed per-item counters, k_items' own sync
+    // words) exists once per slot: k_items needs nothing from the batch before, so with "items_ahead" it runs on a side stream
+    // while that batch's scan is still on the chip, and the pipeline proper waits for its event.
+    DevBuf d_item_base[2], d_item_hay[2], d_item_rec[2], d_zero[2], d_isync[2];
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_items[2] = {nullptr, nullptr};
+    int items_ahead = 0;
     uint64_t *pinned = nullptr;  // host copy of the device counters blocks (2 x 128 B, one per batch in flight), written by k_expand through pinned_dev
     uint32_t *pinned_dev = nullptr;
 
@@ -354,6 +360,9 @@ int ensure_device(acmi_handle *h) {
     // a call that fails further down (e.g. out of device memory for a large table) leaves dev_ready false and is
     // retried by the next match call: create every resource once only
     if (!h->own_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    if (!h->side_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+    for (auto &evt : h->ev_items)
+        if (!evt) HIPCHK(h, hipEventCreateWithFlags(&evt, hipEventDisableTiming));
     if (!h->stream) h->stream = h->own_stream;
     for (auto &evt : h->ev)
         if (!evt) HIPCHK(h, hipEventCreate(&evt));
@@ -621,12 +630,16 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     const uint32_t K = (!h->slab_set && kernel == 2 && fa.anchor_dense) ? 32u : std::max<uint32_t>(1, h->slab_events);
     F.chunk_used = chunk;
 
-    HIPCHK(h, h->d_item_base.ensure_keep((nh + 1) * 8, h->retired));
-    HIPCHK(h, h->d_item_hay.ensure_keep(max_items * 4, h->retired));
-    HIPCHK(h, h->d_item_rec.ensure_keep(max_items * 16, h->retired));
+    DevBuf &d_item_base = h->d_item_base[slot_index], &d_item_hay = h->d_item_hay[slot_index], &d_item_rec = h->d_item_rec[slot_index],
+           &d_zero = h->d_zero[slot_index], &d_isync = h->d_isync[slot_index];
+    HIPCHK(h, d_item_base.ensure_keep((nh + 1) * 8, h->retired));
+    HIPCHK(h, d_item_hay.ensure_keep(max_items * 4, h->retired));
+    HIPCHK(h, d_item_rec.ensure_keep(max_items * 16, h->retired));
     // per-item counters [rec_count (items+1) x 8 | ev_count items x 4]: zeroed per item by k_items
     const size_t rec_cnt_off = 0, ev_off = rec_cnt_off + (max_items + 1) * 8;
-    HIPCHK(h, h->d_zero.ensure_keep(ev_off + max_items * 4, h->retired));
+    HIPCHK(h, d_zero.ensure_keep(ev_off + max_items * 4, h->retired));
+    const size_t isync_bytes = 8 + size_t(scan_tiles(nh + 1) + 1) * 8;
+    HIPCHK(h, d_isync.ensure_keep(isync_bytes, h->retired));
     // sync block of this batch: [counters 16 x u32 | tickets 2 x u32 | pad | status words of the two scans], one of
     // two copies that take turns; this batch's k_expand zeroes the other one.  (Re)allocation zeroes both.
     const uint32_t tiles = std::max(scan_tiles(nh + 1), scan_tiles(max_items + 1)) + 1u;
@@ -651,7 +664,7 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     const uint32_t Q = (!h->run_cap_set && dense) ? 256u : std::max<uint32_t>(1, h->run_cap);
     HIPCHK(h, h->d_runs.ensure_keep(max_items * Q * (dense ? 8 : 16), h->retired));   // (dense: window starts, then k_dense_decide's results)
     HIPCHK(h, h->d_run_count.ensure_keep(max_items * 4, h->retired));
-    uint8_t *zero = h->d_zero.as<uint8_t>();
+    uint8_t *zero = d_zero.as<uint8_t>();
     uint32_t *d_counters = sync_cur;
     uint64_t *d_rec_cnt = reinterpret_cast<uint64_t *>(zero + rec_cnt_off);
     uint32_t *d_ev = reinterpret_cast<uint32_t *>(zero + ev_off);
@@ -659,7 +672,7 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     BatchArgs B{};
     B.blob = d_blob;
     B.offsets = d_off;
-    B.item_base = h->d_item_base.as<uint64_t>();
+    B.item_base = d_item_base.as<uint64_t>();
     B.n_haystacks = uint32_t(nh);
     B.chunk_bytes = chunk;
     B.warm_bytes = fa.max_pattern_length ? fa.max_pattern_length - 1 : 0;
@@ -672,8 +685,8 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     B.tiny_items = (kernel == 2 && h->tiny_rows != 0 && blob_bytes / nh <= 1024) ? 1u : 0u;
     B.slab_events = K;
     B.first_only = find_all ? 0u : 1u;
-    B.item_hay = h->d_item_hay.as<uint32_t>();
-    B.item_rec = h->d_item_rec.as<uint4>();
+    B.item_hay = d_item_hay.as<uint32_t>();
+    B.item_rec = d_item_rec.as<uint4>();
     B.ev_count = d_ev;
     B.rec_count = d_rec_cnt;
     B.slab = h->d_slab.as<uint2>();
@@ -711,7 +724,17 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     }
 
     // item counts, their scan, the item table, zeroed per-item counters: one launch
-    launch_items(B, blob_bytes, max_items, h->d_item_base.as<uint64_t>(), sync_cur + 16, status0, st);
+    {
+        // "items_ahead": on the side stream -- it starts at once, next to the batch before (whose slot this is not), and the
+        // pipeline waits for it.  The caller vouches that offsets and blob are complete when the batch is begun.
+        hipStream_t ist = (h->items_ahead && h->side_stream) ? h->side_stream : st;
+        HIPCHK(h, hipMemsetAsync(d_isync.p, 0, isync_bytes, ist));
+        launch_items(B, blob_bytes, max_items, d_item_base.as<uint64_t>(), d_isync.as<uint32_t>(), ist);
+        if (ist != st) {
+            HIPCHK(h, hipEventRecord(h->ev_items[slot_index], ist));
+            HIPCHK(h, hipStreamWaitEvent(st, h->ev_items[slot_index], 0));
+        }
+    }
 
     if (h->profile) HIPCHK(h, hipEventRecord(F.ev[1], st));
     if (kernel == 4) {
@@ -736,7 +759,7 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     // (also: per-haystack prefix, the summary for the host next to the overflow counter -- counters[2..3] = total
     // records, [4..5] = items -- and the zeroing of the next batch's sync block)
     launch_expand(h->dA, B, max_items, h->d_rec_base.as<uint64_t>(), F.d_out.p, cap, F.d_prefix.as<uint64_t>(),
-                  pinned_dev, sync_next, sync_words, sync_cur + 17, status1, true, st);
+                  pinned_dev, sync_next, sync_words, sync_cur + 17, status1, d_isync.as<uint32_t>() + 1, true, st);
     F.refill_launched = find_all && h->refill_armed;
     if (F.refill_launched) launch_refill(h->dA, B, max_items, int(fa.entry_bytes), h->d_rec_base.as<uint64_t>(), F.d_out.p, cap, h->refill, st);
     F.sync_next = sync_next;
@@ -841,7 +864,8 @@ int run_batch_end(acmi_handle *h) {
             const uint64_t cap = F.d_out.cap / 16;
             if (too_small)
                 launch_expand(h->dA, F.args, F.max_items, h->d_rec_base.as<uint64_t>(), F.d_out.p, cap, F.d_prefix.as<uint64_t>(),
-                              h->pinned_dev + kPinWords * slot_index, F.sync_next, F.sync_words, nullptr, nullptr, false, st);
+                              h->pinned_dev + kPinWords * slot_index, F.sync_next, F.sync_words, nullptr, nullptr,
+                              h->d_isync[slot_index].as<uint32_t>() + 1, false, st);
             if (F.find_all)
                 launch_refill(h->dA, F.args, F.max_items, int(fa.entry_bytes), h->d_rec_base.as<uint64_t>(),
                               F.d_out.p, cap, h->refill, st);
@@ -1027,7 +1051,8 @@ int acmi_destroy(acmi_handle *h) {
             (void)hipSetDevice(h->dev_id);
             if (h->stream) (void)hipStreamSynchronize(h->stream);
             for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_out_off, &h->d_out_list, &h->d_cold_rec, &h->d_cold_edges, &h->d_chain_byte, &h->d_chain_run, &h->d_slot_pair, &h->d_pairs, &h->d_pat_bytes, &h->d_dense_img, &h->d_rep_off, &h->d_rep_bytes, &h->d_plan, &h->d_plan_out, &h->d_tail_out, &h->d_rep_sync, &h->d_nom_count, &h->d_out_len, &h->d_rep_out_off, &h->d_rep_out, &h->d_blob,
-                              &h->d_off, &h->d_sync[0], &h->d_sync[1], &h->d_item_base, &h->d_item_hay, &h->d_item_rec, &h->d_zero,
+                              &h->d_off, &h->d_sync[0], &h->d_sync[1], &h->d_item_base[0], &h->d_item_hay[0], &h->d_item_rec[0], &h->d_zero[0], &h->d_isync[0],
+                              &h->d_item_base[1], &h->d_item_hay[1], &h->d_item_rec[1], &h->d_zero[1], &h->d_isync[1],
                               &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->fly[0].d_prefix, &h->fly[0].d_out, &h->fly[1].d_prefix, &h->fly[1].d_out, &h->d_runs, &h->d_run_count})
                 b->release();
             for (void *q : h->retired) (void)hipFree(q);
@@ -1039,6 +1064,9 @@ int acmi_destroy(acmi_handle *h) {
             if (h->pinned) (void)hipHostFree(h->pinned);
             if (h->pin_small) (void)hipHostFree(h->pin_small);
             if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+            if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+            for (auto &evt : h->ev_items)
+                if (evt) (void)hipEventDestroy(evt);
         }
         delete h;
         return ACMI_OK;
@@ -1314,6 +1342,8 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
         } else if (k == "verify") {
             if (h->dev_ready) return ACMI_E_FINALIZED;  // the tables are uploaded (or not) by the first match call
             h->verify = value ? 1 : 0;
+        } else if (k == "items_ahead") {
+            h->items_ahead = value ? 1 : 0;
         } else if (k == "dense_hot") {
             if (h->dev_ready) return ACMI_E_FINALIZED;
             h->dense_hot = value < 0 ? -1 : (value ? 1 : 0);

@@ -344,9 +344,10 @@ __device__ __forceinline__ void fill_item(const BatchArgs &B, uint64_t h, uint64
 // item_base[h] = first work item of haystack h (h = 0..nh; item_base[nh] = number of items), the item table and
 // the zeroed per-item counters.  Validates what the host cannot see for device-resident offsets: decreasing
 // offsets, a haystack of 4 GiB or more (positions are 32-bit) or one that ends past the blob (every per-item
-// workspace is sized from blob_bytes) raise counters[6], and that haystack gets no item.
+// workspace is sized from blob_bytes) raise *bad_offsets (k_expand hands it to the host as counters[6]), and that haystack gets no
+// item.  The kernel touches nothing of the batch's sync block: it may run on another stream, ahead of the batch before.
 __global__ __launch_bounds__(kScanThreads) void k_items(BatchArgs B, uint64_t blob_bytes, uint64_t *item_base_out, uint32_t *ticket,
-                                                        uint64_t *status, bool fill_later) {
+                                                        uint32_t *bad_offsets, uint64_t *status, bool fill_later) {
     __shared__ uint64_t wave_sums[kScanThreads / 64];
     __shared__ uint64_t s_before;
     __shared__ uint32_t s_tile;
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(kScanThreads) void k_items(BatchArgs B, uint64_t bl
         v[i] = 0;
         if (h + 1 < n) {
             const uint64_t lo = B.offsets[h], hi = B.offsets[h + 1];
-            if (hi < lo || hi - lo >= 0xFFFFFFFFull || hi > blob_bytes) B.counters[6] = 1u;
+            if (hi < lo || hi - lo >= 0xFFFFFFFFull || hi > blob_bytes) *bad_offsets = 1u;
             else v[i] = (hi - lo + B.chunk_bytes - 1) / B.chunk_bytes;
         }
     }
@@ -2564,7 +2565,8 @@ constexpr int kExpandPerThread = kScanTile / kExpandThreads;   // 2
 template <bool SCAN>
 __global__ __launch_bounds__(kExpandThreads) void k_expand(DevAutomaton A, BatchArgs B, uint64_t *rec_base, uint4 *out, uint64_t cap,
                                                             uint64_t *prefix, uint32_t *host_counters, uint32_t *next_sync,
-                                                            uint32_t next_sync_words, uint32_t *ticket, uint64_t *status) {
+                                                            uint32_t next_sync_words, uint32_t *ticket, uint64_t *status,
+                                                            const uint32_t *bad_offsets) {
     __shared__ uint64_t wave_sums[kExpandThreads / 64];
     __shared__ uint64_t s_before, s_total;
     __shared__ uint32_t s_tile, s_closing;
@@ -2573,7 +2575,8 @@ __global__ __launch_bounds__(kExpandThreads) void k_expand(DevAutomaton A, Batch
         // the batch's counters straight into the host's pinned block (words 2..5, the summary, come from the closing element
         // below): no copy command behind the pipeline
         // (words 16..31: the scans' tickets and, word 18, the wave batches k_scan_anchor's TINY path took)
-        if (threadIdx.x < 32u && (threadIdx.x < 2u || threadIdx.x > 5u)) host_counters[threadIdx.x] = B.counters[threadIdx.x];
+        if (threadIdx.x < 32u && (threadIdx.x < 2u || threadIdx.x > 5u))
+            host_counters[threadIdx.x] = threadIdx.x == 6u ? *bad_offsets : B.counters[threadIdx.x];   // ([6]: k_items' verdict on the offsets)
     }
     if (threadIdx.x == 0) { s_tile = SCAN ? atomicAdd(ticket, 1u) : blockIdx.x; s_closing = 0u; }
     __syncthreads();
@@ -3305,10 +3308,13 @@ void launch_gather_pack(const uint64_t *prefix, const uint4 *records, uint64_t n
 // ------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------
-void launch_items(const BatchArgs &B, uint64_t blob_bytes, uint64_t max_items, uint64_t *item_base, uint32_t *ticket, uint64_t *status, hipStream_t st) {
+void launch_items(const BatchArgs &B, uint64_t blob_bytes, uint64_t max_items, uint64_t *item_base, uint32_t *isync, hipStream_t st) {
+    // isync (zeroed by the caller): {ticket, bad-offsets flag, status words of the scan}
+    uint32_t *ticket = isync, *bad = isync + 1;
+    uint64_t *status = reinterpret_cast<uint64_t *>(isync + 2);
     // long haystacks (more than two items each on average): the item table is written by a kernel of its own
     const bool fill_later = B.n_haystacks && blob_bytes / B.n_haystacks > 2ull * B.chunk_bytes;
-    hipLaunchKernelGGL(k_items, dim3(scan_tiles(uint64_t(B.n_haystacks) + 1)), dim3(kScanThreads), 0, st, B, blob_bytes, item_base, ticket, status, fill_later);
+    hipLaunchKernelGGL(k_items, dim3(scan_tiles(uint64_t(B.n_haystacks) + 1)), dim3(kScanThreads), 0, st, B, blob_bytes, item_base, ticket, bad, status, fill_later);
     if (fill_later) {
         const uint64_t blocks = std::min<uint64_t>((max_items + 255) / 256, 256u * 32u);
         hipLaunchKernelGGL(k_item_fill, dim3(uint32_t(blocks)), dim3(256), 0, st, B);
@@ -3434,14 +3440,14 @@ void launch_first_only(const BatchArgs &B, hipStream_t st) {
 
 void launch_expand(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, uint64_t *rec_base, void *out,
                    uint64_t cap, uint64_t *prefix, uint32_t *host_counters, uint32_t *next_sync, uint32_t next_sync_words,
-                   uint32_t *ticket, uint64_t *status, bool scan, hipStream_t st) {
+                   uint32_t *ticket, uint64_t *status, const uint32_t *bad_offsets, bool scan, hipStream_t st) {
     const uint32_t blocks = scan_tiles(max_items + 1);
     if (scan)
         hipLaunchKernelGGL(k_expand<true>, dim3(blocks), dim3(kExpandThreads), 0, st, A, B, rec_base, static_cast<uint4 *>(out), cap, prefix,
-                           host_counters, next_sync, next_sync_words, ticket, status);
+                           host_counters, next_sync, next_sync_words, ticket, status, bad_offsets);
     else
         hipLaunchKernelGGL(k_expand<false>, dim3(blocks), dim3(kExpandThreads), 0, st, A, B, rec_base, static_cast<uint4 *>(out), cap, prefix,
-                           host_counters, next_sync, next_sync_words, ticket, status);
+                           host_counters, next_sync, next_sync_words, ticket, status, bad_offsets);
 }
 
 void launch_refill(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes,

@@ -12,7 +12,8 @@ namespace acmi {
 
 // single-pass scans (kernels.hip): tiles of 2048 elements, one status word per tile
 uint32_t scan_tiles(uint64_t n);
-void launch_items(const BatchArgs &B, uint64_t blob_bytes, uint64_t max_items, uint64_t *item_base, uint32_t *ticket, uint64_t *status, hipStream_t st);
+// isync: 8 + 8 x scan_tiles(n_haystacks + 1) zeroed bytes {ticket, bad-offsets flag, status words}
+void launch_items(const BatchArgs &B, uint64_t blob_bytes, uint64_t max_items, uint64_t *item_base, uint32_t *isync, hipStream_t st);
 hipError_t launch_scan(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int kernel,
                        int class_mode, int ilp, int group_quads, hipStream_t st, uint32_t *anchor_variant = nullptr);
 hipError_t launch_walk_runs(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,
@@ -23,7 +24,7 @@ void launch_first_only(const BatchArgs &B, hipStream_t st);
 // scan = true: also the exclusive scan of the per-item record counts (ticket / status: zeroed sync words); false: rec_base is read
 void launch_expand(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, uint64_t *rec_base, void *out,
                    uint64_t cap, uint64_t *prefix, uint32_t *host_counters, uint32_t *next_sync, uint32_t next_sync_words,
-                   uint32_t *ticket, uint64_t *status, bool scan, hipStream_t st);
+                   uint32_t *ticket, uint64_t *status, const uint32_t *bad_offsets, bool scan, hipStream_t st);
 void launch_refill(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes,
                    const uint64_t *rec_base, void *out, uint64_t cap, int mode, hipStream_t st);
 // one-launch path for small host batches (<= 64 KiB, <= 1024 haystacks): reads / writes pinned host memory

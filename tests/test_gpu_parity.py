@@ -480,8 +480,8 @@ def test_255_used_byte_values_are_not_identity_classes():
     o.close()
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 3])
-def test_two_batches_in_flight(kernel):
+@pytest.mark.parametrize("kernel,items_ahead", [(1, 0), (2, 0), (3, 0), (2, 1), (3, 1), (4, 1)])
+def test_two_batches_in_flight(kernel, items_ahead):
     """acmi_match_batch_device_begin twice before the first _end: the batches end in the order they were begun, each
     with its own records (== oracle), a third begin is refused, and a batch whose records outgrow the capacity the
     handle expected -- after a later begin has reused the pipeline's intermediates -- still comes back whole."""
@@ -493,7 +493,8 @@ def test_two_batches_in_flight(kernel):
     base = sets[0]
     o = Oracle("port")
     o.add_patterns((base.pat_blob, base.pat_off))
-    res = resource_for(base, kernel=kernel)
+    # items_ahead: every batch's work-item table is built on the handle's side stream, next to the batch begun before it
+    res = resource_for(base, kernel=kernel, items_ahead=items_ahead)
     batch.bind_current_stream(res)
     dev, want = [], []
     for ds in sets:
