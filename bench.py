@@ -540,7 +540,7 @@ def main():
     ap.add_argument("--events", type=int, default=1, help="analysis: 0 = no HIP events around the scan kernel in the timed region (roofline fields are then meaningless)")
     ap.add_argument("--in-flight", type=int, default=2, help="batches begun before the oldest is ended (1 or 2)")
     ap.add_argument("--phase-times", action="store_true", help="analysis: add the host time per step phase to the JSON")
-    ap.add_argument("--no-items-ahead", action="store_true", help="analysis: every batch's item table in stream order (acmi.h \"items_ahead\" 0)")
+    ap.add_argument("--items-ahead", action="store_true", help="analysis: every batch's item table on the handle's side stream (acmi.h \"items_ahead\" 1; measured: no gain)")
     ap.add_argument("--no-c-abi-gather", action="store_true", help="N > 1: skip the untimed exchange through acmi_comm_* after the timed steps")
     args = ap.parse_args()
 
@@ -603,8 +603,8 @@ def main():
         res.set_option("group_quads", args.group_quads)
     if args.kernel >= 0:
         res.set_option("kernel", args.kernel)
-    # the batches of the timed steps are resident and complete before they are begun: their work-item tables may be built ahead
-    res.set_option("items_ahead", 0 if args.no_items_ahead else 1)
+    if args.items_ahead:   # analysis: every batch's work-item table built on the handle's side stream (acmi.h "items_ahead")
+        res.set_option("items_ahead", 1)
 
     # ---- batch resident in HBM: the tile replicated to the requested size ----
     want = args.haystacks or wl.default_nh
@@ -781,7 +781,7 @@ def main():
                        "patterns": ds.n_patterns, "haystacks_per_gpu": nh, "haystack_bytes": wl.hay_len,
                        "states": int(res.stat("states")), "hot_states": int(res.stat("hot_states")),
                        "lds_tile_bytes": int(res.stat("lds_image_bytes")), "work_item_bytes": int(res.stat("chunk_bytes")),
-                       "ilp": args.ilp or 1, "items_ahead": 0 if args.no_items_ahead else 1, "sharding": f"{world} contiguous haystack ranges, {backend} all-gatherv of match arrays" if world > 1 else "none"},
+                       "ilp": args.ilp or 1, "items_ahead": int(args.items_ahead), "sharding": f"{world} contiguous haystack ranges, {backend} all-gatherv of match arrays" if world > 1 else "none"},
             "ranks": {"launched": world, "process_group": (dist.get_world_size() if gather else 1), "joined_a_collective": ranks_in_collective,
                       "backend": backend if gather else None, "gpus_on_box": n_dev,
                       "gathered_records": gathered_records, "gathered_haystacks": gathered_haystacks, "c_abi_exchange": c_abi,

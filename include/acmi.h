@@ -327,8 +327,9 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *                    1 = one thread per item, 2 = one wave per item with whole-row record stores,
  *                    0 = automatic (default): 2 unless the longest pattern exceeds 64 B   [any time]
  *   "items_ahead"    1: a batch's work-item table (k_items: it needs the offsets only) is built on a second stream of the handle,
- *                    at once -- next to the scan of the batch begun before it -- and the batch's pipeline waits for it: 20 us
- *                    less per batch with two batches in flight.  The caller vouches that a batch's offsets and blob are COMPLETE
+ *                    behind the scan kernel of the batch begun before it, next to that batch's candidate walk and expansion,
+ *                    and the batch's pipeline waits for it.  (Measured on the headline batch: no gain -- the small kernels do
+ *                    not overlap in practice; kept for experiments.)  The caller vouches that a batch's offsets and blob are COMPLETE
  *                    in device memory when it is begun (not pending on the stream).  0 (default): in stream order   [any time]
  *   "profile"        1 = bracket the scan kernel with HIP events ("scan_ms"); 2 = also the candidate walk ("walk_ms")
  *                    and the whole pipeline ("total_ms") -- every event is a barrier on the stream   [any time] */

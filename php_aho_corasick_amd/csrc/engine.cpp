@@ -138,6 +138,7 @@ struct acmi_handle {
     DevBuf d_item_base[2], d_item_hay[2], d_item_rec[2], d_zero[2], d_isync[2];
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_items[2] = {nullptr, nullptr};
+    hipEvent_t ev_scanned[2] = {nullptr, nullptr};   // behind a batch's scan kernel: the NEXT batch's k_items waits for it (not for the batch)
     int items_ahead = 0;
     uint64_t *pinned = nullptr;  // host copy of the device counters blocks (2 x 128 B, one per batch in flight), written by k_expand through pinned_dev
     uint32_t *pinned_dev = nullptr;
@@ -360,8 +361,16 @@ int ensure_device(acmi_handle *h) {
     // a call that fails further down (e.g. out of device memory for a large table) leaves dev_ready false and is
     // retried by the next match call: create every resource once only
     if (!h->own_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
-    if (!h->side_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+    if (!h->side_stream) {
+        // lowest priority: its workgroups (k_items of the NEXT batch) take the compute units the current batch's scan leaves
+        // free at its tail, not the ones it is about to use -- at equal priority the scan got 2.5 % slower and nothing was won
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        HIPCHK(h, hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, least));
+    }
     for (auto &evt : h->ev_items)
+        if (!evt) HIPCHK(h, hipEventCreateWithFlags(&evt, hipEventDisableTiming));
+    for (auto &evt : h->ev_scanned)
         if (!evt) HIPCHK(h, hipEventCreateWithFlags(&evt, hipEventDisableTiming));
     if (!h->stream) h->stream = h->own_stream;
     for (auto &evt : h->ev)
@@ -728,6 +737,9 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
         // "items_ahead": on the side stream -- it starts at once, next to the batch before (whose slot this is not), and the
         // pipeline waits for it.  The caller vouches that offsets and blob are complete when the batch is begun.
         hipStream_t ist = (h->items_ahead && h->side_stream) ? h->side_stream : st;
+        // ... but not next to that batch's SCAN, which wants every compute unit to itself (k_items' workgroups, placed first,
+        // kept the scan's off their units: scan + 24 us for 14 us saved): behind it, next to its candidate walk and expansion
+        if (ist != st && h->begin_seq != h->end_seq) HIPCHK(h, hipStreamWaitEvent(ist, h->ev_scanned[slot_index ^ 1], 0));
         HIPCHK(h, hipMemsetAsync(d_isync.p, 0, isync_bytes, ist));
         launch_items(B, blob_bytes, max_items, d_item_base.as<uint64_t>(), d_isync.as<uint32_t>(), ist);
         if (ist != st) {
@@ -745,6 +757,7 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
         HIPCHK(h, launch_scan(h->dA, B, max_items, int(fa.entry_bytes), kernel, int(fa.class_mode), h->ilp, h->group_quads, st, &F.anchor_variant));
     }
     if (h->profile) HIPCHK(h, hipEventRecord(F.ev[2], st));
+    if (h->items_ahead) HIPCHK(h, hipEventRecord(h->ev_scanned[slot_index], st));
     // the anchor kernel only flags byte runs; their exact walk is a kernel of its own (one thread per item)
     if (kernel == 2) HIPCHK(h, launch_walk_runs(h->dA, B, max_items, int(fa.entry_bytes), int(fa.class_mode), st));
     if (h->profile > 1) HIPCHK(h, hipEventRecord(F.ev[3], st));
@@ -1066,6 +1079,8 @@ int acmi_destroy(acmi_handle *h) {
             if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
             if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
             for (auto &evt : h->ev_items)
+                if (evt) (void)hipEventDestroy(evt);
+            for (auto &evt : h->ev_scanned)
                 if (evt) (void)hipEventDestroy(evt);
         }
         delete h;
