@@ -140,6 +140,7 @@ struct acmi_handle {
     hipEvent_t ev_items[2] = {nullptr, nullptr};
     hipEvent_t ev_scanned[2] = {nullptr, nullptr};   // behind a batch's scan kernel: the NEXT batch's k_items waits for it (not for the batch)
     int items_ahead = 0;
+    bool isync_clean[2] = {false, false};   // slot's k_items sync words are zero (the batch before zeroed them in its k_expand)
     uint64_t *pinned = nullptr;  // host copy of the device counters blocks (2 x 128 B, one per batch in flight), written by k_expand through pinned_dev
     uint32_t *pinned_dev = nullptr;
 
@@ -581,7 +582,7 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
     if (int(&F - h->fly) == h->cur) h->have_result = false;
     const int rc = enqueue_batch(h, F, d_blob, blob_bytes, d_off, nh, find_all);
     // a pipeline that was not enqueued to its end has not zeroed the next batch's sync block: have both zeroed again
-    if (rc < 0) { h->sync_tiles = 0; return rc; }
+    if (rc < 0) { h->sync_tiles = 0; h->isync_clean[0] = h->isync_clean[1] = false; return rc; }
     F.seq = ++h->begin_seq;
     h->enqueue_seq = F.seq;
     return rc;
@@ -647,8 +648,11 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     // per-item counters [rec_count (items+1) x 8 | ev_count items x 4]: zeroed per item by k_items
     const size_t rec_cnt_off = 0, ev_off = rec_cnt_off + (max_items + 1) * 8;
     HIPCHK(h, d_zero.ensure_keep(ev_off + max_items * 4, h->retired));
-    const size_t isync_bytes = 8 + size_t(scan_tiles(nh + 1) + 1) * 8;
-    HIPCHK(h, d_isync.ensure_keep(isync_bytes, h->retired));
+    const size_t isync_bytes = (8 + size_t(scan_tiles(nh + 1) + 1) * 8 + 15) & ~size_t(15);
+    if (isync_bytes > d_isync.cap) {
+        HIPCHK(h, d_isync.ensure_keep(isync_bytes, h->retired));
+        h->isync_clean[slot_index] = false;
+    }
     // sync block of this batch: [counters 16 x u32 | tickets 2 x u32 | pad | status words of the two scans], one of
     // two copies that take turns; this batch's k_expand zeroes the other one.  (Re)allocation zeroes both.
     const uint32_t tiles = std::max(scan_tiles(nh + 1), scan_tiles(max_items + 1)) + 1u;
@@ -740,7 +744,10 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
         // ... but not next to that batch's SCAN, which wants every compute unit to itself (k_items' workgroups, placed first,
         // kept the scan's off their units: scan + 24 us for 14 us saved): behind it, next to its candidate walk and expansion
         if (ist != st && h->begin_seq != h->end_seq) HIPCHK(h, hipStreamWaitEvent(ist, h->ev_scanned[slot_index ^ 1], 0));
-        HIPCHK(h, hipMemsetAsync(d_isync.p, 0, isync_bytes, ist));
+        // (the sync words of k_items are zeroed by the k_expand of the batch before -- no fill launch per batch -- unless that
+        // batch had no pipeline, failed, or this k_items runs ahead of it)
+        if (!h->isync_clean[slot_index] || ist != st) HIPCHK(h, hipMemsetAsync(d_isync.p, 0, d_isync.cap & ~size_t(15), ist));
+        h->isync_clean[slot_index] = false;
         launch_items(B, blob_bytes, max_items, d_item_base.as<uint64_t>(), d_isync.as<uint32_t>(), ist);
         if (ist != st) {
             HIPCHK(h, hipEventRecord(h->ev_items[slot_index], ist));
@@ -772,7 +779,9 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     // (also: per-haystack prefix, the summary for the host next to the overflow counter -- counters[2..3] = total
     // records, [4..5] = items -- and the zeroing of the next batch's sync block)
     launch_expand(h->dA, B, max_items, h->d_rec_base.as<uint64_t>(), F.d_out.p, cap, F.d_prefix.as<uint64_t>(),
-                  pinned_dev, sync_next, sync_words, sync_cur + 17, status1, d_isync.as<uint32_t>() + 1, true, st);
+                  pinned_dev, sync_next, sync_words, sync_cur + 17, status1, d_isync.as<uint32_t>() + 1, true, st,
+                  h->d_isync[slot_index ^ 1].as<uint32_t>(), uint32_t((h->d_isync[slot_index ^ 1].cap & ~size_t(15)) / 4));
+    h->isync_clean[slot_index ^ 1] = h->d_isync[slot_index ^ 1].p != nullptr;
     F.refill_launched = find_all && h->refill_armed;
     if (F.refill_launched) launch_refill(h->dA, B, max_items, int(fa.entry_bytes), h->d_rec_base.as<uint64_t>(), F.d_out.p, cap, h->refill, st);
     F.sync_next = sync_next;

@@ -2566,12 +2566,13 @@ template <bool SCAN>
 __global__ __launch_bounds__(kExpandThreads) void k_expand(DevAutomaton A, BatchArgs B, uint64_t *rec_base, uint4 *out, uint64_t cap,
                                                             uint64_t *prefix, uint32_t *host_counters, uint32_t *next_sync,
                                                             uint32_t next_sync_words, uint32_t *ticket, uint64_t *status,
-                                                            const uint32_t *bad_offsets) {
+                                                            const uint32_t *bad_offsets, uint32_t *next_isync, uint32_t next_isync_words) {
     __shared__ uint64_t wave_sums[kExpandThreads / 64];
     __shared__ uint64_t s_before, s_total;
     __shared__ uint32_t s_tile, s_closing;
     if (blockIdx.x == 0) {
         for (uint32_t k = threadIdx.x; k < next_sync_words; k += blockDim.x) next_sync[k] = 0u;
+        for (uint32_t k = threadIdx.x; k < next_isync_words; k += blockDim.x) next_isync[k] = 0u;   // (the next batch's k_items: ticket, flag, status)
         // the batch's counters straight into the host's pinned block (words 2..5, the summary, come from the closing element
         // below): no copy command behind the pipeline
         // (words 16..31: the scans' tickets and, word 18, the wave batches k_scan_anchor's TINY path took)
@@ -3440,14 +3441,15 @@ void launch_first_only(const BatchArgs &B, hipStream_t st) {
 
 void launch_expand(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, uint64_t *rec_base, void *out,
                    uint64_t cap, uint64_t *prefix, uint32_t *host_counters, uint32_t *next_sync, uint32_t next_sync_words,
-                   uint32_t *ticket, uint64_t *status, const uint32_t *bad_offsets, bool scan, hipStream_t st) {
+                   uint32_t *ticket, uint64_t *status, const uint32_t *bad_offsets, bool scan, hipStream_t st,
+                   uint32_t *next_isync, uint32_t next_isync_words) {
     const uint32_t blocks = scan_tiles(max_items + 1);
     if (scan)
         hipLaunchKernelGGL(k_expand<true>, dim3(blocks), dim3(kExpandThreads), 0, st, A, B, rec_base, static_cast<uint4 *>(out), cap, prefix,
-                           host_counters, next_sync, next_sync_words, ticket, status, bad_offsets);
+                           host_counters, next_sync, next_sync_words, ticket, status, bad_offsets, next_isync, next_isync_words);
     else
         hipLaunchKernelGGL(k_expand<false>, dim3(blocks), dim3(kExpandThreads), 0, st, A, B, rec_base, static_cast<uint4 *>(out), cap, prefix,
-                           host_counters, next_sync, next_sync_words, ticket, status, bad_offsets);
+                           host_counters, next_sync, next_sync_words, ticket, status, bad_offsets, next_isync, next_isync_words);
 }
 
 void launch_refill(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes,

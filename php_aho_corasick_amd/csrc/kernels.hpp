@@ -24,7 +24,8 @@ void launch_first_only(const BatchArgs &B, hipStream_t st);
 // scan = true: also the exclusive scan of the per-item record counts (ticket / status: zeroed sync words); false: rec_base is read
 void launch_expand(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, uint64_t *rec_base, void *out,
                    uint64_t cap, uint64_t *prefix, uint32_t *host_counters, uint32_t *next_sync, uint32_t next_sync_words,
-                   uint32_t *ticket, uint64_t *status, const uint32_t *bad_offsets, bool scan, hipStream_t st);
+                   uint32_t *ticket, uint64_t *status, const uint32_t *bad_offsets, bool scan, hipStream_t st,
+                   uint32_t *next_isync = nullptr, uint32_t next_isync_words = 0);
 void launch_refill(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes,
                    const uint64_t *rec_base, void *out, uint64_t cap, int mode, hipStream_t st);
 // one-launch path for small host batches (<= 64 KiB, <= 1024 haystacks): reads / writes pinned host memory
