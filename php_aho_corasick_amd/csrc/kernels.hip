@@ -793,14 +793,13 @@ __device__ __forceinline__ bool verify_candidate(const DevAutomaton &A, const ui
     // the window's hash (automaton.hpp anchor_hash; the window lies inside the item: the filter tested it)
     const uint32_t nw = A.anchor_q >> 2;
     uint32_t h;
-    if (A.anchor_dense) {  // the raw window, one multiply-add (automaton.hpp anchor_hash_dense)
+    if (nw == 1u) {  // the raw window, one multiply-add (automaton.hpp anchor_hash)
         const uint32_t t4 = load4u(p + w);
         h = anchor_mad(t4, A.anchor_mul, t4 >> 8);
     } else {
         h = anchor_fold_dev(load4u(p + w));
 #pragma unroll 1
         for (uint32_t i = 1; i < nw; ++i) h = anchor_mad(h, A.anchor_mul, anchor_fold_dev(load4u(p + w + 4u * i)));
-        if (nw == 1u) h = anchor_mad(h, A.anchor_mul, h >> 8);
     }
     // its slot in the fingerprint table
     uint32_t slot = 0xFFFFFFFFu;
@@ -1440,6 +1439,13 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                     for (int i = 0; i < NC; ++i) tail[i] = 0;
                 }
             }
+            if constexpr (QW == 1) {  // lone dwords are hashed raw (automaton.hpp anchor_hash): a shift and a multiply-add
+                h4[0] = anchor_mad(buf[r].x, mul, buf[r].x >> 8);
+                h4[1] = anchor_mad(buf[r].y, mul, buf[r].y >> 8);
+                h4[2] = anchor_mad(buf[r].z, mul, buf[r].z >> 8);
+                h4[3] = anchor_mad(buf[r].w, mul, buf[r].w >> 8);
+                return;
+            }
             uint32_t f[4];
             f[0] = anchor_fold_dev(buf[r].x);
             f[1] = anchor_fold_dev(buf[r].y);
@@ -1466,7 +1472,6 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                 if (need > 0) { h = left[need - 1]; i0 = 0; } else { h = f[w - (QW - 1)]; i0 = w - (QW - 1) + 1; }
 #pragma unroll
                 for (int i = i0; i <= w; ++i) h = anchor_mad(h, mul, f[i]);
-                if (QW == 1) h = anchor_mad(h, mul, h >> 8);  // a lone dword still gets one multiply (anchor_hash)
                 h4[w] = h;
             }
         };

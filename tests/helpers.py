@@ -100,17 +100,15 @@ class FlatTables:
     def anchor_probe(self, window: bytes) -> bool:
         """The device's window test (k_scan_anchor), restated: hash q bytes, look the fingerprint up."""
         q = self.anchor_q
-        if getattr(self, "anchor_dense", 0):   # the raw window, one multiply-add (automaton.hpp anchor_hash_dense)
-            w = int.from_bytes(window[:4], "little")
-            h = ((w & 0xFFFFFF) * (self.anchor_mul & 0xFFFFFF) + (w >> 8)) & 0xFFFFFFFF
-            return int(h >> 16) in [int(x) for x in self.anchor[(h >> 3) & 0x3FFF]]
         words = np.frombuffer(window[:q], dtype="<u4").astype(np.uint64)
-        fold = [(int(w) ^ (int(w) >> 11)) & 0xFFFFFFFF for w in words]
-        h = fold[0]
-        for f in fold[1:]:
-            h = ((h & 0xFFFFFF) * (self.anchor_mul & 0xFFFFFF) + f) & 0xFFFFFFFF
-        if len(fold) == 1:
-            h = ((h & 0xFFFFFF) * (self.anchor_mul & 0xFFFFFF) + (h >> 8)) & 0xFFFFFFFF
+        if len(words) == 1:   # a lone dword is hashed raw, one multiply-add (automaton.hpp anchor_hash)
+            w = int(words[0])
+            h = ((w & 0xFFFFFF) * (self.anchor_mul & 0xFFFFFF) + (w >> 8)) & 0xFFFFFFFF
+        else:
+            fold = [(int(w) ^ (int(w) >> 11)) & 0xFFFFFFFF for w in words]
+            h = fold[0]
+            for f in fold[1:]:
+                h = ((h & 0xFFFFFF) * (self.anchor_mul & 0xFFFFFF) + f) & 0xFFFFFFFF
         if self.anchor_mode == 2:   # LDS bitmap in front of the 8-slot table read through L2
             if not (int(self.anchor_bitmap[h >> 17]) >> ((h >> 12) & 31)) & 1:
                 return False

@@ -110,7 +110,7 @@ void walk(const FlatAutomaton &fa, const uint8_t *text, size_t n, int find_all, 
 long anchor_slot(const FlatAutomaton &fa, const uint8_t *window) {
     uint32_t words[4] = {0, 0, 0, 0};
     std::memcpy(words, window, fa.anchor_q);
-    const uint32_t h = fa.anchor_dense ? anchor_hash_dense(words[0], fa.anchor_mul) : anchor_hash(words, fa.anchor_q / 4, fa.anchor_mul);
+    const uint32_t h = anchor_hash(words, fa.anchor_q / 4, fa.anchor_mul);
     if (fa.anchor_mode == 2) {
         const uint16_t fp = uint16_t((h >> 16) | 1u);
         const size_t bucket = (h >> fa.anchor_bucket_shift) & ((1u << fa.anchor_bucket_bits) - 1u);
@@ -126,7 +126,7 @@ long anchor_slot(const FlatAutomaton &fa, const uint8_t *window) {
 bool anchor_probe(const FlatAutomaton &fa, const uint8_t *window) {
     uint32_t words[4] = {0, 0, 0, 0};
     std::memcpy(words, window, fa.anchor_q);
-    const uint32_t h = fa.anchor_dense ? anchor_hash_dense(words[0], fa.anchor_mul) : anchor_hash(words, fa.anchor_q / 4, fa.anchor_mul);
+    const uint32_t h = anchor_hash(words, fa.anchor_q / 4, fa.anchor_mul);
     if (fa.anchor_mode == 2) {
         if (!((fa.anchor_bitmap[h >> 17] >> ((h >> 12) & 31u)) & 1u)) return false;
         const uint16_t fp = uint16_t((h >> 16) | 1u);
