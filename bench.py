@@ -233,12 +233,21 @@ def general_leg(torch, api, batch, res_patterns, d_blob, d_off, nh, expect_recor
     return out
 
 
-def keywords_leg(torch, api, batch, synth, dev, nh=1 << 17):
-    """Keyword-like set (the use the reference's README sells): 2,048 patterns of 4..12 letters over text of letters
-    and spaces, 2^17 haystacks x 8 KiB = 1 GiB; automatic kernel choice.  Check against the CPU oracle on the first
-    64 haystacks of the tile."""
+def keywords_leg(torch, api, batch, synth, dev, nh=1 << 17, words_only=False):
+    """Keyword-like set (the use the reference's README sells): 2,048 patterns of 4..12 bytes over text of letters and spaces,
+    2^17 haystacks x 8 KiB = 1 GiB; automatic kernel choice.  `words_only` False (the leg of rounds 1 and 2, kept for
+    comparison): the patterns are drawn from the text's own alphabet, spaces included (5 of 31 symbols) -- 115 windows per 8 KiB
+    are some pattern's first four bytes; True: the patterns are WORDS, letters only -- 18 per 8 KiB.  Check against the CPU
+    oracle on the first 64 haystacks of the tile."""
     alpha = bytes(range(ord("a"), ord("z") + 1)) + b"     "
     ds = synth.generate("words", 33, 2048, 4, 12, 8192, HAY_LEN, alpha)
+    if words_only:
+        pats = synth.generate("words", 34, 2048, 4, 12, 1, 16, bytes(range(ord("a"), ord("z") + 1)))
+        ds = synth.Dataset("words", pats.pat_blob, pats.pat_off, ds.hay_blob, ds.hay_off)
+        for h in range(0, 8192, 2):   # a planted word in every second haystack (random text holds the 4-letter ones only)
+            p = np.frombuffer(ds.pattern((13 * h + 5) % 2048), dtype=np.uint8)
+            at = int(ds.hay_off[h]) + (131 * h + 7) % (HAY_LEN - 16)
+            ds.hay_blob[at:at + len(p)] = p
     res = api.ahocorasick_init([{"id": k, "value": p} for k, p in enumerate(ds.patterns())])
     for kv in filter(None, os.environ.get("ACMI_KW_OPTS", "").split(",")):   # analysis: e.g. ACMI_KW_OPTS=anchor_dense=0
         res.set_option(kv.split("=")[0], int(kv.split("=")[1]))
@@ -257,13 +266,46 @@ def keywords_leg(torch, api, batch, synth, dev, nh=1 << 17):
     n_chk = 64
     pe, re_ = o.match_batch(ds.hay_blob[:int(ds.hay_off[n_chk])], ds.hay_off[:n_chk + 1], True)
     ok = np.array_equal(prefix[:n_chk + 1], pe) and np.array_equal(rec[:int(pe[-1])], re_) and total == int(prefix[8192]) * (nh // 8192)
-    out = _leg_summary(f"2,048 patterns of 4..12 letters over letters + spaces, {nh} haystacks x {HAY_LEN} B ({nh * HAY_LEN >> 20} MiB)",
+    what = "2,048 words of 4..12 letters" if words_only else "2,048 patterns of 4..12 letters and spaces (the text's alphabet)"
+    out = _leg_summary(f"{what} over letters + spaces, {nh} haystacks x {HAY_LEN} B ({nh * HAY_LEN >> 20} MiB)",
                        nh * HAY_LEN, nh, total, ms, scan, walk, res, ok)
     out["first_batch_kernel"] = KERNEL_NAMES.get(first_kernel, "?")
     out["records_per_haystack"] = round(total / nh, 2)
-    out.update({"anchor_variant": int(res.stat("anchor_variant")), "anchor_dense_rate_per_8KiB": round(res.stat("anchor_dense_rate") * 8192, 1),
+    out.update({"anchor_variant": int(res.stat("anchor_variant")), "hit_windows_expected_per_8KiB": round(res.stat("anchor_dense_rate") * 8192, 1),
                 "fallback_bytes": int(res.stat("fallback_bytes")), "walked_bytes": int(res.stat("walked_bytes")), "overflow_items": int(res.stat("overflow_items"))})
     api.ahocorasick_deinit(res)
+    return out
+
+
+def short_patterns_leg(torch, api, batch, synth, dev, ds, nh=1 << 17):
+    """The headline pattern set (2,048 x 16 B over abcdef) PLUS eight patterns of 2..6 B -- the reference takes any length from
+    1 to 1,024 B in one trie (src/multifast/ahocorasick.c:101-105); here a pattern under 7 B takes the whole set off the
+    aligned-anchor filter (and, over this six-letter alphabet, off the dense form too: every 4-letter window is some pattern's
+    prefix).  Two cases over 1 GiB of the headline text: the short patterns over letters the text does not hold (no match: what
+    the set costs), and over the text's own alphabet (a 2-byte pattern then matches every 36 bytes: dense output)."""
+    from oracle import pyoracle
+    out = {}
+    reps = nh // TILE_HAYSTACKS
+    d_blob = torch.from_numpy(ds.hay_blob).to(dev).repeat(reps).contiguous()
+    d_off = torch.arange(nh + 1, dtype=torch.int64, device=dev) * HAY_LEN
+    for name, alpha in (("absent_letters", b"uvwxyz"), ("same_alphabet", b"abcdef")):
+        sp = synth.generate("short", 41, 8, 2, 6, 1, 16, alpha)
+        pats = ds.patterns() + sp.patterns()
+        res = api.ahocorasick_init([{"id": k, "value": p} for k, p in enumerate(pats)])
+        batch.bind_current_stream(res)
+        batch.match_device(res, d_blob, d_off, True)
+        ms, scan, walk, total = _timed_calls(torch, batch, res, d_blob, d_off, calls=4, skip=1)
+        prefix, rec = batch.result_numpy(res, nh, total)
+        o = pyoracle.Oracle("port")
+        o.add_patterns(pats)
+        n_chk = 32
+        pe, re_ = o.match_batch(ds.hay_blob[:int(ds.hay_off[n_chk])], ds.hay_off[:n_chk + 1], True)
+        ok = np.array_equal(prefix[:n_chk + 1], pe) and np.array_equal(rec[:int(pe[-1])], re_) and total == int(prefix[TILE_HAYSTACKS]) * reps
+        leg = _leg_summary(f"headline patterns + {[p.decode() for p in sp.patterns()]} over {nh} haystacks x {HAY_LEN} B", nh * HAY_LEN, nh, total, ms, scan, walk, res, ok)
+        leg["records_per_haystack"] = round(total / nh, 2)
+        out[name] = leg
+        api.ahocorasick_deinit(res)
+    del d_blob
     return out
 
 
@@ -822,6 +864,10 @@ def main():
             out["replace"] = replace_leg(torch, api, batch, synth, dev)
         if want_leg("keyword_set"):
             out["keyword_set"] = keywords_leg(torch, api, batch, synth, dev)
+        if want_leg("keyword_words"):
+            out["keyword_words"] = keywords_leg(torch, api, batch, synth, dev, words_only=True)
+        if want_leg("short_patterns") and args.workload == "headline":
+            out["short_patterns"] = short_patterns_leg(torch, api, batch, synth, dev, ds)
         if want_leg("config3") and args.workload == "headline":
             out["config3"] = config3_leg(torch, api, batch, synth, dev)
         if args.phase_times:
