@@ -331,6 +331,11 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *                    and the batch's pipeline waits for it.  (Measured on the headline batch: no gain -- the small kernels do
  *                    not overlap in practice; kept for experiments.)  The caller vouches that a batch's offsets and blob are COMPLETE
  *                    in device memory when it is begun (not pending on the stream).  0 (default): in stream order   [any time]
+ *   "split"          a set that is not eligible for the anchor filter only because of a FEW patterns under 7 B is matched as two
+ *                    automata over the same batch -- the long patterns through the filter, the rest through the table walk -- and
+ *                    the two match arrays are merged per haystack (position ascending, longer pattern first): -1 (default) when
+ *                    the short patterns are at most 256 and a sixteenth of the long ones, 0 never, 1 whenever both kinds exist.
+ *                    Same records either way ("split", "split_long_patterns", "split_short_patterns")   [before finalize]
  *   "profile"        1 = bracket the scan kernel with HIP events ("scan_ms"); 2 = also the candidate walk ("walk_ms")
  *                    and the whole pipeline ("total_ms") -- every event is a barrier on the stream   [any time] */
 int acmi_set_option(acmi_handle *h, const char *key, int64_t value);

@@ -85,6 +85,16 @@ struct acmi_handle {
     Automaton aut;
     BuildOptions bopt;
 
+    // Split pattern set (ensure_finalized): a set that is not eligible for the anchor filter as a whole because of a FEW short
+    // patterns -- the reference takes any length from 1 to 1,024 B in one trie (ahocorasick.c:101-105) -- is matched as two
+    // automata over the same batch: part[0] the accepted patterns of >= 7 B (the filter), part[1] the rest (the table walk),
+    // both with the caller-order pattern indices of this handle; their match arrays are merged per haystack (k_merge_parts).
+    acmi_handle *part[2] = {nullptr, nullptr};
+    bool is_part = false;
+    int split_opt = -1;   // -1 automatic, 0 never, 1 whenever there are patterns on both sides of 7 B
+    std::vector<std::pair<std::string, int64_t>> option_log;   // every option set on this handle: replayed on the parts
+    DevBuf d_merge_counts, d_merge_sync;
+
     // options
     uint32_t slab_events = 8;
     uint32_t run_cap = 8;
@@ -309,6 +319,45 @@ bool device_fail_and_outputs(void *ctx, const TrieView &tv, uint32_t *fail, uint
     return ok;
 }
 
+int ensure_finalized(acmi_handle *h);
+
+// The two parts of a split set: handles of their own (automaton, device tables, pipeline buffers), built from this handle's
+// ACCEPTED patterns -- the others, and those of the other part, are passed with length 0, which add_batch drops while keeping
+// the caller-order index (duplicates were settled when this handle took the patterns: first inserted wins across calls).
+int build_parts(acmi_handle *h) {
+    const std::vector<PatternMeta> &pats = h->aut.patterns();
+    const uint8_t *bytes = h->aut.pattern_bytes().data();
+    for (int side = 0; side < 2; ++side) {
+        acmi_handle *c = new (std::nothrow) acmi_handle();
+        if (!c) return ACMI_E_NOMEM;
+        c->device_request = h->device_request;
+        c->init_ok = 1;
+        c->is_part = true;
+        {
+            std::lock_guard<std::mutex> g(g_live_mutex);
+            g_live.insert(c);
+        }
+        h->part[side] = c;
+        for (const auto &kv : h->option_log) (void)acmi_set_option(c, kv.first.c_str(), kv.second);
+        std::vector<const uint8_t *> vals(pats.size());
+        std::vector<uint32_t> lens(pats.size()), types(pats.size());
+        std::vector<int64_t> ids(pats.size());
+        std::vector<uint64_t> users(pats.size());
+        for (size_t i = 0; i < pats.size(); ++i) {
+            const bool mine = pats[i].accepted && ((pats[i].length >= 7) == (side == 0));
+            vals[i] = bytes + pats[i].byte_off;
+            lens[i] = mine ? pats[i].length : 0u;
+            types[i] = pats[i].id_type;
+            ids[i] = pats[i].id_number;
+            users[i] = pats[i].user;
+        }
+        c->aut.add_batch(vals.data(), lens.data(), types.data(), ids.data(), users.data(), pats.size());
+        const int rc = ensure_finalized(c);
+        if (rc < 0) { h->last_error = c->last_error; return rc; }
+    }
+    return ACMI_OK;
+}
+
 int ensure_finalized(acmi_handle *h) {
     if (h->aut.finalized()) return 0;
     std::string err;
@@ -330,6 +379,17 @@ int ensure_finalized(acmi_handle *h) {
         h->exact_left = h->exact_span;
         h->refill_armed = true;   // (dense sets: the first batch will want its overflowed items drained)
     }
+    // Split?  The set as a whole cannot use the anchor filter, but without its few short patterns it could.
+    if (!h->is_part && h->split_opt != 0 && fa.anchor_q == 0 && h->kernel == 3) {
+        size_t n_long = 0, n_short = 0;
+        for (const PatternMeta &m : h->aut.patterns())
+            if (m.accepted) (m.length >= 7 ? n_long : n_short)++;
+        const bool want = n_long > 0 && n_short > 0 && (h->split_opt > 0 || (n_short <= 256 && n_long >= 16 * n_short));
+        if (want) {
+            const int rc = build_parts(h);
+            if (rc < 0) return rc;
+        }
+    }
     return 1;
 }
 
@@ -337,6 +397,12 @@ int ensure_device(acmi_handle *h) {
     if (h->dev_ready) {
         HIPCHK(h, hipSetDevice(h->dev_id));
         return ACMI_OK;
+    }
+    if (h->part[0]) {   // a split set: the parts hold the device tables; this handle the stream, the merged results
+        for (acmi_handle *c : h->part) {
+            const int rc = ensure_device(c);
+            if (rc < 0) { h->last_error = c->last_error; return rc; }
+        }
     }
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -386,6 +452,20 @@ int ensure_device(acmi_handle *h) {
         h->pinned_dev = static_cast<uint32_t *>(dp);
     }
 
+    if (h->part[0]) {
+        // (of its own automaton the handle needs the pattern lengths only: search and replace)
+        const FlatAutomaton &fp = h->aut.flat();
+        const size_t np4 = std::max<size_t>(4, fp.pattern_length.size() * 4);
+        HIPCHK(h, h->d_plen.ensure(np4));
+        if (!fp.pattern_length.empty()) HIPCHK(h, copy_h2d(h->d_plen.p, fp.pattern_length.data(), fp.pattern_length.size() * 4));
+        h->dA = DevAutomaton{};
+        h->dA.pattern_length = h->d_plen.as<uint32_t>();
+        h->dA.max_pattern_length = fp.max_pattern_length;
+        for (acmi_handle *c : h->part) c->stream = h->stream;
+        h->dev_ready = true;
+        if (!h->keep_host_tables) h->aut.release_host_tables();
+        return ACMI_OK;
+    }
     // upload the flat automaton
     const FlatAutomaton &fa = h->aut.flat();
     const bool table_mode = fa.class_mode == kClassTable;
@@ -568,6 +648,8 @@ uint32_t choose_chunk(const acmi_handle *h, uint64_t blob_bytes, size_t nh, int 
 int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob, uint64_t blob_bytes, const uint64_t *d_off,
                   size_t nh, int find_all);
 
+int run_batch_end(acmi_handle *h);
+
 int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, const uint64_t *d_off, size_t nh,
                     int find_all) {
     if (h->begin_seq - h->end_seq >= 2) {
@@ -575,6 +657,28 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
         return ACMI_E_ARG;
     }
     if (nh > 0xFFFFFFF0ull) { h->last_error = "too many haystacks"; return ACMI_E_TOO_LARGE; }
+    if (h->part[0]) {   // split set: both parts scan the batch, one after the other on the stream; merged at the end
+        acmi_handle::FlySlot &F = h->fly[(h->begin_seq + 1) & 1];
+        if (int(&F - h->fly) == h->cur) h->have_result = false;
+        for (acmi_handle *c : h->part) {
+            c->stream = h->stream;
+            c->profile = h->profile;
+            const int rc = run_batch_begin(c, d_blob, blob_bytes, d_off, nh, find_all);
+            if (rc < 0) {
+                h->last_error = c->last_error;
+                if (c == h->part[1]) (void)run_batch_end(h->part[0]);   // (the first part's batch is not left in flight)
+                return rc;
+            }
+        }
+        F.nh = nh;
+        F.find_all = find_all;
+        F.blob_bytes = blob_bytes;
+        F.stream = h->stream;
+        F.trivial = false;
+        F.seq = ++h->begin_seq;
+        h->enqueue_seq = F.seq;
+        return ACMI_OK;
+    }
     // This batch takes the slot of the batch before the previous one, whose prefix array and records end here: a
     // result is valid from its batch's end until the SECOND begin after its own.
     acmi_handle::FlySlot &F = h->fly[(h->begin_seq + 1) & 1];
@@ -794,8 +898,59 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
 }
 
 // Second half, for the OLDEST batch in flight: the one host synchronisation, the capacity check and (rarely) the re-run.
+// The end of a split set's batch: both parts' ends, then the merge of their match arrays into this handle's result buffers.
+int run_split_end(acmi_handle *h) {
+    acmi_handle::FlySlot &F = h->fly[(h->end_seq + 1) & 1];
+    ++h->end_seq;
+    acmi_handle *a = h->part[0], *b = h->part[1];
+    int rc = run_batch_end(a);
+    const int rc2 = run_batch_end(b);
+    if (rc < 0 || rc2 < 0) { h->last_error = rc < 0 ? a->last_error : b->last_error; return rc < 0 ? rc : rc2; }
+    hipStream_t st = F.stream;
+    const uint32_t nh = uint32_t(F.nh), first_only = F.find_all ? 0u : 1u;
+    const uint64_t ta = a->last_total, tb = b->last_total;
+    HIPCHK(h, F.d_prefix.ensure((size_t(nh) + 1) * 8));
+    HIPCHK(h, F.d_out.ensure(std::max<uint64_t>(16, (ta + tb) * 16)));
+    const uint64_t *pa = a->d_prefix().as<uint64_t>(), *pb = b->d_prefix().as<uint64_t>();
+    uint64_t total = ta + tb;
+    if (!first_only) {
+        launch_merge_prefix_sum(pa, pb, nh, F.d_prefix.as<uint64_t>(), st);
+    } else {
+        // findAll = false: a haystack keeps the earlier of the parts' first events (both at equal positions): counts, then their scan
+        HIPCHK(h, h->d_merge_counts.ensure(std::max<size_t>(8, size_t(nh) * 8)));
+        const size_t sync_bytes = 8 + size_t(scan_tiles(uint64_t(nh) + 1) + 1) * 8;
+        HIPCHK(h, h->d_merge_sync.ensure(sync_bytes));
+        HIPCHK(h, hipMemsetAsync(h->d_merge_sync.p, 0, sync_bytes, st));
+        launch_merge_counts(pa, a->d_out().p, pb, b->d_out().p, nh, 1u, h->d_merge_counts.as<uint64_t>(), st);
+        const int slot_index = int(&F - h->fly);
+        launch_scan_u64(h->d_merge_counts.as<uint64_t>(), nh, F.d_prefix.as<uint64_t>(), h->d_merge_sync.as<uint32_t>(),
+                        reinterpret_cast<uint64_t *>(h->pinned_dev + kPinWords * slot_index), st);
+    }
+    launch_merge_parts(pa, a->d_out().p, ta, pb, b->d_out().p, tb, nh, first_only, F.d_prefix.as<uint64_t>(), F.d_out.p, st);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(st));
+    if (first_only) total = h->pinned[(kPinWords / 2) * int(&F - h->fly)];
+    h->cur = int(&F - h->fly);
+    h->last_nh = nh;
+    h->last_total = total;
+    h->have_result = true;
+    h->kernel_used = a->kernel_used;
+    h->anchor_variant = a->anchor_variant;
+    h->tiny_waves = a->tiny_waves;
+    h->chunk_used = a->chunk_used;
+    h->items = a->items + b->items;
+    h->overflow_items = a->overflow_items + b->overflow_items;
+    h->walked_bytes = a->walked_bytes + b->walked_bytes;
+    h->fallback_bytes = a->fallback_bytes + b->fallback_bytes;
+    h->scan_ms = a->scan_ms + b->scan_ms;
+    h->walk_ms = a->walk_ms + b->walk_ms;
+    h->total_ms = a->total_ms + b->total_ms;
+    return ACMI_OK;
+}
+
 int run_batch_end(acmi_handle *h) {
     if (h->begin_seq == h->end_seq) { h->last_error = "no batch in flight"; return ACMI_E_ARG; }
+    if (h->part[0]) return run_split_end(h);
     acmi_handle::FlySlot &F = h->fly[(h->end_seq + 1) & 1];
     ++h->end_seq;
     const int slot_index = int(&F - h->fly);
@@ -922,6 +1077,8 @@ int run_batch(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, const 
             if (slot.stream) (void)hipStreamSynchronize(slot.stream);
         h->end_seq = h->begin_seq;
         h->have_result = false;
+        for (acmi_handle *c : h->part)
+            if (c) { c->end_seq = c->begin_seq; c->have_result = false; }
     }
     int rc = run_batch_begin(h, d_blob, blob_bytes, d_off, nh, find_all);
     if (rc < 0) return rc;
@@ -936,7 +1093,7 @@ constexpr size_t kSmallSummaryOff = 0, kSmallPrefixOff = 64, kSmallRecordsOff = 
                  kSmallPinBytes = kSmallBytesOff + kSmallPathMaxBytes + 64;
 
 int run_small(acmi_handle *h, const uint8_t *blob, const uint64_t *offsets, size_t nh, int find_all) {
-    if (!h->small_path || nh == 0 || nh > kSmallPathMaxHay) return 1;
+    if (!h->small_path || nh == 0 || nh > kSmallPathMaxHay || h->part[0]) return 1;   // (a split set has two automata: the pipeline)
     const uint64_t span = offsets[nh] - offsets[0];
     if (span > kSmallPathMaxBytes) return 1;
     if (!h->pin_small) {
@@ -1069,10 +1226,12 @@ int acmi_destroy(acmi_handle *h) {
             if (!h || !g_live.erase(h)) return ACMI_E_INVALID;
         }
         h->init_ok = 0;
+        for (acmi_handle *&c : h->part)
+            if (c) { (void)acmi_destroy(c); c = nullptr; }
         if (h->dev_touched) {  // also after a failed upload: release whatever was created
             (void)hipSetDevice(h->dev_id);
             if (h->stream) (void)hipStreamSynchronize(h->stream);
-            for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_out_off, &h->d_out_list, &h->d_cold_rec, &h->d_cold_edges, &h->d_chain_byte, &h->d_chain_run, &h->d_slot_pair, &h->d_pairs, &h->d_pat_bytes, &h->d_dense_img, &h->d_rep_off, &h->d_rep_bytes, &h->d_plan, &h->d_plan_out, &h->d_tail_out, &h->d_rep_sync, &h->d_nom_count, &h->d_out_len, &h->d_rep_out_off, &h->d_rep_out, &h->d_blob,
+            for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_out_off, &h->d_out_list, &h->d_cold_rec, &h->d_cold_edges, &h->d_chain_byte, &h->d_chain_run, &h->d_slot_pair, &h->d_pairs, &h->d_pat_bytes, &h->d_dense_img, &h->d_merge_counts, &h->d_merge_sync, &h->d_rep_off, &h->d_rep_bytes, &h->d_plan, &h->d_plan_out, &h->d_tail_out, &h->d_rep_sync, &h->d_nom_count, &h->d_out_len, &h->d_rep_out_off, &h->d_rep_out, &h->d_blob,
                               &h->d_off, &h->d_sync[0], &h->d_sync[1], &h->d_item_base[0], &h->d_item_hay[0], &h->d_item_rec[0], &h->d_zero[0], &h->d_isync[0],
                               &h->d_item_base[1], &h->d_item_hay[1], &h->d_item_rec[1], &h->d_zero[1], &h->d_isync[1],
                               &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->fly[0].d_prefix, &h->fly[0].d_out, &h->fly[1].d_prefix, &h->fly[1].d_out, &h->d_runs, &h->d_run_count})
@@ -1298,6 +1457,16 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
         if (!live(h)) return ACMI_E_INVALID;
         if (!key) return ACMI_E_ARG;
         const std::string k(key);
+        if (k == "split") {
+            if (h->aut.finalized()) return ACMI_E_FINALIZED;
+            h->split_opt = value < 0 ? -1 : (value ? 1 : 0);
+            return ACMI_OK;
+        }
+        if (!h->is_part) {
+            h->option_log.emplace_back(k, value);
+            for (acmi_handle *c : h->part)   // ("any time" options reach the parts of a split set too)
+                if (c) (void)acmi_set_option(c, key, value);
+        }
         if (k == "lds_bytes") {
             if (h->aut.finalized()) return ACMI_E_FINALIZED;
             if (value < 2048 || value > 160 * 1024 - 64) return ACMI_E_ARG;
@@ -1396,6 +1565,13 @@ int acmi_get_stat(const acmi_handle *h, const char *key, double *value) {
         if (!live(h)) return ACMI_E_INVALID;
         if (!key || !value) return ACMI_E_ARG;
         const std::string k(key);
+        if (k == "split") { *value = h->part[0] ? 1 : 0; return ACMI_OK; }
+        if (k == "split_long_patterns" || k == "split_short_patterns") {
+            *value = h->part[0] ? double(h->part[k == "split_long_patterns" ? 0 : 1]->aut.accepted_count()) : 0.0;
+            return ACMI_OK;
+        }
+        if (h->part[0] && (k.rfind("anchor", 0) == 0 || k == "compact" || k == "built_on_device"))
+            return acmi_get_stat(h->part[0], key, value);   // (the filter is the long part's)
         const FlatAutomaton &fa = h->aut.flat();
         if (k == "nodes") *value = double(h->aut.node_count());
         else if (k == "accepted") *value = double(h->aut.accepted_count());
@@ -1452,6 +1628,8 @@ int acmi_set_stream(acmi_handle *h, void *hip_stream) {
             return ACMI_E_ARG;
         }
         h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+        for (acmi_handle *c : h->part)
+            if (c) c->stream = h->stream;
         return ACMI_OK;
     });
 }

@@ -3286,6 +3286,78 @@ void launch_replace_emit(const ReplaceArgs &R, uint64_t cap, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Split pattern sets (engine.cpp): a set that as a whole is not eligible for the anchor filter -- a few patterns under 7 B
+// among thousands of long ones -- is matched as TWO automata over the same batch, the long patterns through the filter, the
+// rest through the table walk, and the two match arrays are merged here.  All patterns of part A are longer than all of
+// part B, and the records of one position come longest pattern first (node.c:424-441): per haystack the merged order is
+// position ascending, at equal position A's records before B's.  A record's final slot is its own index plus the number of
+// records of the other part that go before it, found by binary search in that part's segment of the haystack: one thread per
+// record, no serial merge.  findAll = false (all records of the FIRST event only): the parts each kept their own first
+// event; the earlier position wins, at equal positions both stay.
+// ------------------------------------------------------------------------------------------
+__global__ void k_merge_counts(const uint64_t *pa, const uint4 *ra, const uint64_t *pb, const uint4 *rb, uint32_t nh, uint32_t first_only,
+                               uint64_t *counts) {
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= nh) return;
+    const uint64_t a0 = pa[h], a1 = pa[h + 1], b0 = pb[h], b1 = pb[h + 1];
+    uint64_t n = (a1 - a0) + (b1 - b0);
+    if (first_only && a1 > a0 && b1 > b0) {
+        const uint32_t posa = ra[a0].y, posb = rb[b0].y;
+        if (posa < posb) n = a1 - a0; else if (posb < posa) n = b1 - b0;
+    }
+    counts[h] = n;
+}
+
+__global__ void k_merge_parts(const uint64_t *pa, const uint4 *ra, uint64_t ta, const uint64_t *pb, const uint4 *rb, uint64_t tb, uint32_t nh,
+                              uint32_t first_only, const uint64_t *out_prefix, uint4 *out) {
+    const uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (g >= ta + tb) return;
+    const bool is_a = g < ta;
+    const uint4 rec = is_a ? ra[g] : rb[g - ta];
+    const uint32_t h = rec.x;
+    const uint64_t a0 = pa[h], a1 = pa[h + 1], b0 = pb[h], b1 = pb[h + 1];
+    if (first_only && a1 > a0 && b1 > b0) {   // both parts have a first event: the later one goes
+        const uint32_t posa = ra[a0].y, posb = rb[b0].y;
+        if ((is_a && posb < posa) || (!is_a && posa < posb)) return;
+        if (posa != posb) {   // the other part's event was dropped: this part's records are the haystack's
+            out[out_prefix[h] + (is_a ? g - a0 : g - ta - b0)] = rec;
+            return;
+        }
+    }
+    // records of the other part that go before this one: strictly earlier positions for A, earlier or equal for B
+    const uint4 *other = is_a ? rb : ra;
+    uint64_t lo = is_a ? b0 : a0, hi = is_a ? b1 : a1;
+    const uint64_t seg0 = lo;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        const uint32_t p = other[mid].y;
+        if (is_a ? p < rec.y : p <= rec.y) lo = mid + 1; else hi = mid;
+    }
+    out[out_prefix[h] + (is_a ? g - a0 : g - ta - b0) + (lo - seg0)] = rec;
+}
+
+// find_all: the merged prefix is the sum of the parts' (no scan needed)
+__global__ void k_merge_prefix_sum(const uint64_t *pa, const uint64_t *pb, uint32_t nh, uint64_t *out_prefix) {
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h <= nh) out_prefix[h] = pa[h] + pb[h];
+}
+
+void launch_merge_counts(const uint64_t *pa, const void *ra, const uint64_t *pb, const void *rb, uint32_t nh, uint32_t first_only, uint64_t *counts,
+                         hipStream_t st) {
+    if (nh) hipLaunchKernelGGL(k_merge_counts, dim3((nh + 255) / 256), dim3(256), 0, st, pa, static_cast<const uint4 *>(ra), pb,
+                               static_cast<const uint4 *>(rb), nh, first_only, counts);
+}
+void launch_merge_prefix_sum(const uint64_t *pa, const uint64_t *pb, uint32_t nh, uint64_t *out_prefix, hipStream_t st) {
+    hipLaunchKernelGGL(k_merge_prefix_sum, dim3((nh + 256) / 256), dim3(256), 0, st, pa, pb, nh, out_prefix);
+}
+void launch_merge_parts(const uint64_t *pa, const void *ra, uint64_t ta, const uint64_t *pb, const void *rb, uint64_t tb, uint32_t nh,
+                        uint32_t first_only, const uint64_t *out_prefix, void *out, hipStream_t st) {
+    if (ta + tb == 0) return;
+    hipLaunchKernelGGL(k_merge_parts, dim3(uint32_t((ta + tb + 255) / 256)), dim3(256), 0, st, pa, static_cast<const uint4 *>(ra), ta, pb,
+                       static_cast<const uint4 *>(rb), tb, nh, first_only, out_prefix, static_cast<uint4 *>(out));
+}
+
+// ------------------------------------------------------------------------------------------
 // k_gather_pack: this rank's half of the all-gatherv of match arrays (engine.cpp acmi_comm_allgather_result).
 // Ranks own contiguous haystack ranges in rank order, so the global arrays are the ranks' arrays back to back: a rank
 // writes its own slice of them -- haystack ids made global, prefix words moved by the records of the ranks before it --

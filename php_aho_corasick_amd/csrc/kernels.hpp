@@ -40,6 +40,12 @@ void launch_replace_emit(const ReplaceArgs &R, uint64_t cap, hipStream_t st);
 void launch_scan_u64(const uint64_t *in, uint64_t n, uint64_t *out, uint32_t *sync, uint64_t *total_host, hipStream_t st);
 void launch_gather_pack(const uint64_t *prefix, const uint4 *records, uint64_t nh, uint64_t nrec, uint64_t hay_base, uint64_t rec_base,
                         uint64_t *out_prefix, uint4 *out_records, uint64_t *closing, uint64_t total_rec, hipStream_t st);
+// split pattern sets: the two parts' match arrays merged per haystack (position ascending, part A before part B at equal positions)
+void launch_merge_counts(const uint64_t *pa, const void *ra, const uint64_t *pb, const void *rb, uint32_t nh, uint32_t first_only, uint64_t *counts,
+                         hipStream_t st);
+void launch_merge_prefix_sum(const uint64_t *pa, const uint64_t *pb, uint32_t nh, uint64_t *out_prefix, hipStream_t st);
+void launch_merge_parts(const uint64_t *pa, const void *ra, uint64_t ta, const uint64_t *pb, const void *rb, uint64_t tb, uint32_t nh,
+                        uint32_t first_only, const uint64_t *out_prefix, void *out, hipStream_t st);
 void launch_stream_read(const void *src, uint64_t bytes, uint32_t *sink, hipStream_t st);
 
 }  // namespace acmi

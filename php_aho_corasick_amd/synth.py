@@ -365,6 +365,41 @@ def k3() -> Dataset:
     return ds
 
 
-TARGETED = {"T256": t256, "T512": t512, "T1K": t1k, "TRAG": trag, "S3K": s3k, "S2K5": s2k5, "B512": b512, "BRAG": brag, "B3K": b3k, "K1": k1, "K2": k2, "K3": k3}
+# ---- a few short patterns among many long ones: the split set (engine.cpp build_parts) ------------------------------------
+
+def _with_short(name, base: Dataset, shorts: list[bytes], every: int) -> Dataset:
+    """`base`'s patterns with `shorts` spliced in between (so that caller-order indices interleave), its haystacks with a short
+    pattern planted into every `every`-th one -- right behind a long plant where there is room (events of both parts at one
+    position and at neighbouring ones)."""
+    pats = base.patterns()
+    step = max(1, len(pats) // (len(shorts) + 1))
+    for i, sp in enumerate(shorts):
+        pats.insert((i + 1) * step + i, sp)
+    pat_blob, pat_off = pack(pats)
+    ds = Dataset(name, pat_blob, pat_off, base.hay_blob.copy(), base.hay_off.copy())
+    for h in range(0, ds.n_haystacks, every):
+        lo, hi = int(ds.hay_off[h]), int(ds.hay_off[h + 1])
+        sp = np.frombuffer(shorts[(h // every) % len(shorts)], dtype=np.uint8)
+        if hi - lo >= 64:
+            at = lo + (hi - lo) // 3
+            ds.hay_blob[at:at + len(sp)] = sp
+    return ds
+
+
+def x1() -> Dataset:
+    """2,048 patterns x 16 B over abcdef PLUS eight of 1..6 B, some over the same letters (they match by the dozen), some over
+    others, one a suffix of a long pattern's tail, one a duplicate of another short one."""
+    base = _planted_ragged("X1", 35, 2048, 16, 16, 90, 0, 5000, b"abcdef", 4)
+    tail = base.pattern(7)[-3:]
+    return _with_short("X1", base, [b"uvw", b"fedcba", tail, b"xy", b"abcab", b"z", b"uvw", b"ddddd"], 2)
+
+
+def x2() -> Dataset:
+    """5,000 patterns of 9..24 B over 16 letters (the big-set filter) plus three short ones."""
+    base = _planted_ragged("X2", 36, 5000, 9, 24, 40, 0, 9000, b"abcdefghijklmnop", 6)
+    return _with_short("X2", base, [b"qrs", b"ponm", b"ab"], 1)
+
+
+TARGETED = {"T256": t256, "T512": t512, "T1K": t1k, "TRAG": trag, "S3K": s3k, "S2K5": s2k5, "B512": b512, "BRAG": brag, "B3K": b3k, "K1": k1, "K2": k2, "K3": k3, "X1": x1, "X2": x2}
 
 NAMED = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "R1": r1, "R2": r2, "R3": r3, "R4": r4, "R5": r5, "R6": r6, "R7": r7, "R8": r8}
