@@ -2179,14 +2179,16 @@ __global__ __launch_bounds__(kWalkThreads) void k_verify_dense(DevAutomaton A, B
 
 // With the LDS image the decision is split in two kernels, because what bounds it is memory LATENCY, not work: one thread per
 // item deciding its ~ 100 windows one after the other waits for a window-list load and a text load per window, a few
-// microseconds each (k_verify_dense<.., true> as first written: 0.89 ms per GiB of keyword text, more than the filter).
-//   k_dense_decide   one thread per HIT WINDOW (thread t: item t / run_cap, window t % run_cap -- a wave's 64 windows belong
-//                    to one item, so the item's record is a scalar load, the window list one coalesced 256-byte read and the
-//                    text loads fall into a few neighbouring lines): the LDS lookup of verify_dense, result written next to
-//                    the window list -- the record index of the occurrence found, kDenseNone, or kDenseMany (several
-//                    patterns with that prefix are there, or the text load would cross the item's end);
-//   k_dense_emit     one thread per item: reads the results in order (contiguous, no dependent loads), clusters windows
+// microseconds each (0.89 ms per GiB of keyword text, more than the filter), and a per-item pass over ALL windows reads its
+// 4-byte entries a 128-byte line at a time (4 GB of L2 misses per GiB of text).
+//   k_dense_decide   one WAVE per item, 64 hit windows per step: the window list in one coalesced read, the text loads (they
+//                    fall into the item's own few lines), the LDS lookup, and the windows that hold an occurrence compacted
+//                    in place -- with the record index of the occurrence, or kDenseMany (several patterns with that prefix
+//                    are there, or the text load would cross the item's end);
+//   k_dense_emit     one thread per item over the FEW entries left (nine hit windows in ten hold nothing): clusters those
 //                    whose ranges touch, emits the events in position order; only kDenseMany windows are looked at again.
+// What is left of the cost is the text itself: the decide kernel reads every line of it again (TCC_MISS x 128 B = the
+// batch), 0.29 ms per GiB -- the price of deciding in a kernel of its own instead of inside the scan.
 constexpr uint32_t kDenseNone = 0xFFFFFFFFu, kDenseMany = 0xFFFFFFFEu;
 
 // One WAVE per item, 64 hit windows per step: the window starts in one coalesced read, the text loads (they fall into the
