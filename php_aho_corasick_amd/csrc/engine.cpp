@@ -374,7 +374,10 @@ int ensure_finalized(acmi_handle *h) {
     // LDS-tile pass ends up walking whole items anyway (keyword lists, dense sets) -- start on the exact walk.  The
     // usual probing applies from there (the fast kernel gets its chance after `exact_left` batches).
     const FlatAutomaton &fa = h->aut.flat();
-    if (fa.est_flag_rate * 8192.0 > double(h->run_cap)) {
+    // (not for the short part of a split set: its few patterns were split off because they are unlike the rest -- the text is
+    // expected to look like the LONG patterns, and the estimate "text over the short patterns' own alphabet" says nothing; the
+    // first batch's statistics decide)
+    if (fa.est_flag_rate * 8192.0 > double(h->run_cap) && !h->is_part) {
         h->exact_only = true;
         h->exact_left = h->exact_span;
         h->refill_armed = true;   // (dense sets: the first batch will want its overflowed items drained)
