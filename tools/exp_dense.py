@@ -6,10 +6,11 @@ import numpy as np, torch
 from php_aho_corasick_amd import api, batch, synth
 
 opts = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
+only = opts.pop("text", "")   # text=kw: the keyword text only (counter passes)
 alpha = bytes(range(ord("a"), ord("z") + 1)) + b"     "
 ds = synth.generate("words", 33, 2048, 4, 12, 8192, 8192, alpha)
 nh = 1 << 17
-for label, blob in (("keyword text", ds.hay_blob), ("upper-case text (no hit window)", np.where(ds.hay_blob >= 97, ds.hay_blob - 32, ds.hay_blob).astype(np.uint8))):
+for label, blob in [x for x in (("keyword text", ds.hay_blob), ("upper-case text (no hit window)", np.where(ds.hay_blob >= 97, ds.hay_blob - 32, ds.hay_blob).astype(np.uint8))) if not only or x[0].startswith("keyword")]:
     res = api.ahocorasick_init([{"id": k, "value": p} for k, p in enumerate(ds.patterns())])
     for k, v in opts.items():
         res.set_option(k, int(v))
