@@ -775,7 +775,9 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     uint32_t *sync_cur = h->d_sync[h->sync_turn & 1].as<uint32_t>();
     uint32_t *sync_next = h->d_sync[(h->sync_turn + 1) & 1].as<uint32_t>();
     ++h->sync_turn;
-    uint64_t *status0 = reinterpret_cast<uint64_t *>(sync_cur + 32), *status1 = status0 + h->sync_tiles;
+    // (status words of k_expand's scan: tiles of 1,024 items -- the block holds 2 x sync_tiles words, sized for tiles of 2,048;
+    // k_items has sync words of its own, d_isync)
+    uint64_t *status1 = reinterpret_cast<uint64_t *>(sync_cur + 32);
     HIPCHK(h, h->d_rec_base.ensure_keep((max_items + 2) * 8, h->retired));
     HIPCHK(h, h->d_slab.ensure_keep(max_items * K * 8, h->retired));
     HIPCHK(h, h->d_ovf.ensure_keep(max_items * 4, h->retired));

@@ -2558,7 +2558,7 @@ __device__ __forceinline__ uint64_t emit_event(const DevAutomaton &A, uint4 *out
 // capacity of the previous call and re-runs it after growing the buffer if the batch did not fit.
 //
 // SCAN = true (the pipeline's launch): the exclusive scan of the per-item record counts is done HERE, single pass with
-// look-back like k_items -- a tile of 2,048 items per workgroup, two per thread -- so that the record base of an item is known
+// look-back like k_items -- a tile of 1,024 items per workgroup, one per thread -- so that the record base of an item is known
 // in the kernel that expands it (k_rec_scan used to be a launch of its own: 14 us + a kernel boundary per batch).  rec_base[]
 // is still written (the drain of overflowed items and a re-expansion read it).  The per-haystack prefix of the record array
 // comes from the items too: the thread of a haystack's FIRST item writes that haystack's word -- and those of the empty
@@ -2566,8 +2566,11 @@ __device__ __forceinline__ uint64_t emit_event(const DevAutomaton &A, uint4 *out
 // summary {total records, work items} for the host's single read-back next to the overflow counter; and the first workgroup
 // zeroes the sync block of the NEXT batch (counters, tickets, scan status words).
 // SCAN = false (re-expansion into a grown buffer): rec_base[] is read.
+// (one item per thread, tiles of 1,024: with two items per thread and 2,048-item tiles the expansion of a batch with a dozen
+// events per item -- chains of dependent loads per event -- took 74 us on half the compute units)
 constexpr int kExpandThreads = 1024;
-constexpr int kExpandPerThread = kScanTile / kExpandThreads;   // 2
+constexpr int kExpandPerThread = 1;
+constexpr int kExpandTile = kExpandThreads * kExpandPerThread;
 
 template <bool SCAN>
 __global__ __launch_bounds__(kExpandThreads) void k_expand(DevAutomaton A, BatchArgs B, uint64_t *rec_base, uint4 *out, uint64_t cap,
@@ -2590,8 +2593,8 @@ __global__ __launch_bounds__(kExpandThreads) void k_expand(DevAutomaton A, Batch
     __syncthreads();
     const uint32_t tile = s_tile;
     const uint64_t items = B.item_base[B.n_haystacks];
-    if (uint64_t(tile) * kScanTile > items) return;  // (so does every later tile: nobody looks back at this one)
-    const uint64_t base = uint64_t(tile) * kScanTile + uint64_t(threadIdx.x) * kExpandPerThread;
+    if (uint64_t(tile) * kExpandTile > items) return;  // (so does every later tile: nobody looks back at this one)
+    const uint64_t base = uint64_t(tile) * kExpandTile + uint64_t(threadIdx.x) * kExpandPerThread;
     uint64_t v[kExpandPerThread], rb[kExpandPerThread + 1];
 #pragma unroll
     for (int i = 0; i < kExpandPerThread; ++i) v[i] = base + i < items ? B.rec_count[base + i] : 0ull;
@@ -3522,7 +3525,7 @@ void launch_expand(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items
                    uint64_t cap, uint64_t *prefix, uint32_t *host_counters, uint32_t *next_sync, uint32_t next_sync_words,
                    uint32_t *ticket, uint64_t *status, const uint32_t *bad_offsets, bool scan, hipStream_t st,
                    uint32_t *next_isync, uint32_t next_isync_words) {
-    const uint32_t blocks = scan_tiles(max_items + 1);
+    const uint32_t blocks = uint32_t((max_items + 1 + kExpandTile - 1) / kExpandTile);
     if (scan)
         hipLaunchKernelGGL(k_expand<true>, dim3(blocks), dim3(kExpandThreads), 0, st, A, B, rec_base, static_cast<uint4 *>(out), cap, prefix,
                            host_counters, next_sync, next_sync_words, ticket, status, bad_offsets, next_isync, next_isync_words);
