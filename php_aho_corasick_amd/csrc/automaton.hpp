@@ -200,16 +200,18 @@ constexpr uint32_t kAnchorMaxBucketBits = 21;        // mode 2: up to 2 M bucket
 // never equal a window's fingerprint there -- that is the "empty" marker (anchor_empty).
 inline uint32_t anchor_fold(uint32_t d) { return d ^ (d >> 11); }
 inline uint32_t anchor_hash(const uint32_t *words, uint32_t n_words, uint32_t mul) {
-    // a lone dword (4-byte windows) is hashed raw: its low three bytes times the multiplier plus its high three bytes --
-    // a shift and a multiply-add on the device, where fold + multiply-add of the folded value took four instructions per
-    // window (the big-set filter spends a fifth of its vector instructions hashing)
-    if (n_words == 1) return (words[0] & 0xFFFFFFu) * (mul & 0xFFFFFFu) + (words[0] >> 8);
+    // a lone dword (4-byte windows) is hashed raw: its low three bytes times the multiplier plus the dword shifted down by 13
+    // bits -- a shift and a multiply-add on the device (fold + multiply-add of the folded value took four instructions per
+    // window).  The shift matters: a product spreads a byte's influence UPWARD only, and word lists are full of families that
+    // share their first three letters ("conc", "cond", "conf", ...) -- with the fourth byte reaching the fingerprint bits
+    // only, such a family met in one or two buckets of four slots and no seed could place it.  Shifted by 13, the fourth byte
+    // lands on bits 11..18 (six bits of the bucket index), the third on bits 3..10.
+    if (n_words == 1) return (words[0] & 0xFFFFFFu) * (mul & 0xFFFFFFu) + (words[0] >> 13);
     uint32_t h = anchor_fold(words[0]);
     for (uint32_t i = 1; i < n_words; ++i) h = (h & 0xFFFFFFu) * (mul & 0xFFFFFFu) + anchor_fold(words[i]);
     return h;
 }
-// dense form: ONE multiply-add on the raw window (v_lshrrev + v_mad_u32_u24 on the device): its low three bytes times
-// the multiplier plus its high three bytes -- every byte reaches bucket and fingerprint bits
+// dense form: ONE multiply-add on the raw window (v_lshrrev + v_mad_u32_u24 on the device), see anchor_hash
 inline uint32_t anchor_hash_dense(uint32_t w, uint32_t mul) { return anchor_hash(&w, 1, mul); }
 inline uint16_t anchor_empty(uint32_t bucket) { return uint16_t(((bucket >> (kAnchorBucketBits - 1)) & 1u) ^ 1u); }
 

@@ -795,7 +795,7 @@ __device__ __forceinline__ bool verify_candidate(const DevAutomaton &A, const ui
     uint32_t h;
     if (nw == 1u) {  // the raw window, one multiply-add (automaton.hpp anchor_hash)
         const uint32_t t4 = load4u(p + w);
-        h = anchor_mad(t4, A.anchor_mul, t4 >> 8);
+        h = anchor_mad(t4, A.anchor_mul, t4 >> 13);
     } else {
         h = anchor_fold_dev(load4u(p + w));
 #pragma unroll 1
@@ -1440,10 +1440,10 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                 }
             }
             if constexpr (QW == 1) {  // lone dwords are hashed raw (automaton.hpp anchor_hash): a shift and a multiply-add
-                h4[0] = anchor_mad(buf[r].x, mul, buf[r].x >> 8);
-                h4[1] = anchor_mad(buf[r].y, mul, buf[r].y >> 8);
-                h4[2] = anchor_mad(buf[r].z, mul, buf[r].z >> 8);
-                h4[3] = anchor_mad(buf[r].w, mul, buf[r].w >> 8);
+                h4[0] = anchor_mad(buf[r].x, mul, buf[r].x >> 13);
+                h4[1] = anchor_mad(buf[r].y, mul, buf[r].y >> 13);
+                h4[2] = anchor_mad(buf[r].z, mul, buf[r].z >> 13);
+                h4[3] = anchor_mad(buf[r].w, mul, buf[r].w >> 13);
                 return;
             }
             uint32_t f[4];
@@ -1607,10 +1607,10 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                     const uint32_t dm = j == 0 ? left : j == 1 ? buf[r].x : j == 2 ? buf[r].y : buf[r].z;
                     uint32_t *h4 = hh[t & 1];
                     const uint32_t w1 = __builtin_amdgcn_alignbyte(dj, dm, 1), w2 = __builtin_amdgcn_alignbyte(dj, dm, 2), w3 = __builtin_amdgcn_alignbyte(dj, dm, 3);
-                    h4[0] = anchor_mad(w1, mul, w1 >> 8);
-                    h4[1] = anchor_mad(w2, mul, w2 >> 8);
-                    h4[2] = anchor_mad(w3, mul, w3 >> 8);
-                    h4[3] = anchor_mad(dj, mul, dj >> 8);
+                    h4[0] = anchor_mad(w1, mul, w1 >> 13);
+                    h4[1] = anchor_mad(w2, mul, w2 >> 13);
+                    h4[2] = anchor_mad(w3, mul, w3 >> 13);
+                    h4[3] = anchor_mad(dj, mul, dj >> 13);
                 }
                 // the row is consumed: reload its registers with the same row of the task two steps ahead
                 if (j == 3) buf[r] = load_quad(ld, r);

@@ -103,7 +103,7 @@ class FlatTables:
         words = np.frombuffer(window[:q], dtype="<u4").astype(np.uint64)
         if len(words) == 1:   # a lone dword is hashed raw, one multiply-add (automaton.hpp anchor_hash)
             w = int(words[0])
-            h = ((w & 0xFFFFFF) * (self.anchor_mul & 0xFFFFFF) + (w >> 8)) & 0xFFFFFFFF
+            h = ((w & 0xFFFFFF) * (self.anchor_mul & 0xFFFFFF) + (w >> 13)) & 0xFFFFFFFF
         else:
             fold = [(int(w) ^ (int(w) >> 11)) & 0xFFFFFFFF for w in words]
             h = fold[0]

@@ -185,3 +185,26 @@ def test_dense_anchor_form_only_when_selective():
     api.ahocorasick_finalize(res)
     assert res.stat("anchor_q") == 0
     api.ahocorasick_deinit(res)
+
+
+def test_window_hash_places_families_that_share_three_bytes():
+    """Word lists are full of families that share their first three letters (conc, cond, conf, ...): the 4-byte window hash must
+    spread them over buckets (a product alone moves a byte's influence upward only: with the fourth byte reaching the
+    fingerprint bits only, such a family met in two buckets of four slots and the filter was refused)."""
+    import itertools
+    family = [("con" + c + "xyz").encode() for c in "cdefgjnqstvabhik"] + [b"inter", b"internal", b"integer", b"house"]
+    aligned = [("abc" + c + "mno").encode() for c in "abcdefghijklmnopqrstuvwxyz"]
+    suffix = [(c + "abcmnop").encode() for c in "abcdefghijklmnopqrstuvwxyz"]
+    every = [("".join(t) + "zz").encode() for t in itertools.product("abcdefgh", repeat=4)]
+    for pats, dense in ((family, 1), (aligned, 0), (suffix, 0), (every, 1)):
+        res = api.ahocorasick_init([{"value": w} for w in pats])
+        res.set_option("keep_host_tables", 1)
+        if dense:
+            res.set_option("anchor_dense", 1)
+        api.ahocorasick_finalize(res)
+        ft = FlatTables(res)
+        assert ft.anchor_q == 4 and ft.anchor_mode == 1 and ft.anchor_dense == dense
+        for p in pats:
+            for o in ((0,) if dense else range(4)):
+                assert ft.anchor_probe(p[o:o + 4]), (p, o)
+        api.ahocorasick_deinit(res)
