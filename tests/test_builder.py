@@ -172,8 +172,13 @@ def test_dense_anchor_form_only_when_selective():
     base = synth.g1(1)
     pats = base.patterns() + [b"abcde"]
     res = api.ahocorasick_init([{"value": p} for p in pats])
+    res.set_option("split", 0)   # (as ONE set; by default it is split in two: the long patterns keep the aligned filter)
     api.ahocorasick_finalize(res)
     assert res.stat("anchor_q") == 0 and res.stat("anchor_dense") == 0 and res.stat("anchor_dense_rate") * 8192 > 160
+    api.ahocorasick_deinit(res)
+    res = api.ahocorasick_init([{"value": p} for p in pats])
+    api.ahocorasick_finalize(res)
+    assert res.stat("split") == 1 and res.stat("split_long_patterns") == 2048 and res.stat("split_short_patterns") == 1 and res.stat("anchor_q") == 12
     api.ahocorasick_deinit(res)
     res = api.ahocorasick_init([{"value": p} for p in pats])
     res.set_option("anchor_dense", 1)
