@@ -298,6 +298,8 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *                    pattern anchored by its first four bytes, the window tested at every byte offset of the text: -1 (default)
  *                    when at most ~ 160 windows per 8 KiB are expected to hit on text that looks like the patterns, 0 never,
  *                    1 whenever the shortest pattern allows                                         [before finalize]
+ *   "anchor_slots2"  dense anchor form: two-slot buckets (2^15 of them) when the keys are at most 3,072 -- one 4-byte LDS read and one
+ *                    packed subtract per window: -1 / 1 (default) yes, 0 always four slots                [before finalize]
  *   "dense_hot"      dense anchor form: the scan variant that works out which windows hit in every step, branch-free (+ 10 VALU per
  *                    dword) instead of behind a rarely-taken branch: -1 (default) when a dozen or more hit windows are expected
  *                    per 8 KiB, 0 never, 1 always                                                  [before the first match]
@@ -345,7 +347,7 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value);
  * "max_pattern_length", "items", "overflow_items", "walked_bytes", "fallback_bytes", "kernel_used" (0, 1, 2, 4 as the
  * "kernel" option; 5 = the one-launch small-batch path), "anchor_variant" (the k_scan_anchor template the last batch ran:
  * window dwords in bits 0-2 | 8 big set (LDS bitmap + L2 table) | 16 short-row variant | 32 tiny-item variant | 64 windows
- * at every byte offset | 128 its many-hits variant; 0 = another kernel), "tiny_waves" (wave batches that took the tiny-item path), "scan_ms",
+ * at every byte offset | 128 its many-hits variant | 256 two-slot buckets; 0 = another kernel), "tiny_waves" (wave batches that took the tiny-item path), "scan_ms",
  * "total_ms". */
 int acmi_get_stat(const acmi_handle *h, const char *key, double *value);
 
@@ -394,6 +396,7 @@ typedef struct acmi_tables {
     const uint8_t *chain_run;     /* per such state: how many steps from it on lead to id + 1, again such a state (capped at 255) */
     const uint32_t *out_off;      /* per state: first entry of its flat output list */
     const uint32_t *out_list;     /* 2 words per entry: pattern index, pattern length; longest first */
+    uint32_t anchor_slots;        /* slots per bucket of the mode-1 table: 4 (2^14 buckets, hash bits 3..16) or 2 (2^15 buckets, bits 2..16) */
     uint32_t anchor_dense;        /* 1: the filter tests the 4-byte window at EVERY byte offset against the patterns' first four bytes
                                      (shortest pattern 4..6 B); anchor_q = 4, anchor_mode = 1, one key per pattern */
 } acmi_tables;

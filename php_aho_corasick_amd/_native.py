@@ -51,7 +51,7 @@ class Tables(C.Structure):
                 ("dense_f_end", C.c_uint32), ("n_dense_rows", C.c_uint32), ("n_cold_edges", C.c_uint32),
                 ("cold_rec", C.POINTER(C.c_uint32)), ("cold_edges", C.POINTER(C.c_uint32)),
                 ("chain_lo", C.c_uint32), ("chain_byte", C.POINTER(C.c_uint8)), ("chain_run", C.POINTER(C.c_uint8)),
-                ("out_off", C.POINTER(C.c_uint32)), ("out_list", C.POINTER(C.c_uint32)), ("anchor_dense", C.c_uint32)]
+                ("out_off", C.POINTER(C.c_uint32)), ("out_list", C.POINTER(C.c_uint32)), ("anchor_slots", C.c_uint32), ("anchor_dense", C.c_uint32)]
 
 
 Handle = C.c_void_p

@@ -688,40 +688,48 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
         // (every_offset: the window is hashed raw, see anchor_hash_dense)
         auto key_hash = [&](const std::array<uint32_t, 4> &k, uint32_t mul_) { return every_offset ? anchor_hash_dense(k[0], mul_) : anchor_hash(k.data(), q / 4, mul_); };
         if (keys.size() <= kAnchorMaxKeys) {
-            std::vector<uint16_t> tab(size_t(kAnchorBuckets) * 4);
-            for (int attempt = 0; attempt < 512 && fa.anchor_q == 0; ++attempt, mul = mul * 0x2545F491u + 0x6B43A9B5u) {
-                mul = (mul | 1u) & 0xFFFFFFu;
-                std::vector<uint8_t> used(kAnchorBuckets, 0);
-                for (uint32_t b = 0; b < kAnchorBuckets; ++b) std::fill_n(&tab[size_t(b) * 4], 4, anchor_empty(b));
-                bool ok = true;
-                for (size_t ki = 0; ki < keys.size(); ++ki) {
-                    const uint32_t h = key_hash(keys[ki], mul);
-                    const uint16_t fp = uint16_t(h >> 16);                   // fingerprint: high half
-                    const uint32_t bucket = (h >> 3) & (kAnchorBuckets - 1);  // bits 3..16
-                    uint16_t *b = &tab[size_t(bucket) * 4];
-                    uint32_t slot = 0;
-                    while (slot < used[bucket] && b[slot] != fp) ++slot;
-                    if (slot == 4) { ok = false; break; }  // bucket overflow: take another seed
-                    if (slot == used[bucket]) b[used[bucket]++] = fp;
-                }
-                if (ok) {  // which slot each key went to (only for the seed that is kept)
-                    std::vector<size_t> slot_of(keys.size());
+            // 4 slots per bucket; the dense form tries 2 first when its keys are few (a bucket of two overflows sooner:
+            // 2,048 keys in 2^15 buckets find a seed in a few attempts, 4,096 never do)
+            fa.anchor_slots = 4;
+            for (uint32_t slots : {2u, 4u}) {
+                if (fa.anchor_q) break;
+                if (slots == 2 && !(every_offset && opt.anchor_slots2 != 0 && keys.size() <= 3072)) continue;
+                const uint32_t bits = slots == 2 ? kAnchorBucketBits + 1 : kAnchorBucketBits, n_buckets = 1u << bits, shift = slots == 2 ? 2u : 3u;
+                std::vector<uint16_t> tab(size_t(n_buckets) * slots);
+                mul = 0x9E3779B1u;
+                for (int attempt = 0; attempt < (slots == 2 ? 192 : 512) && fa.anchor_q == 0; ++attempt, mul = mul * 0x2545F491u + 0x6B43A9B5u) {
+                    mul = (mul | 1u) & 0xFFFFFFu;
+                    std::vector<uint8_t> used(n_buckets, 0);
+                    for (uint32_t b = 0; b < n_buckets; ++b) std::fill_n(&tab[size_t(b) * slots], slots, anchor_empty(b, bits));
+                    bool ok = true;
                     for (size_t ki = 0; ki < keys.size(); ++ki) {
                         const uint32_t h = key_hash(keys[ki], mul);
-                        const uint16_t fp = uint16_t(h >> 16);
-                        const uint32_t bucket = (h >> 3) & (kAnchorBuckets - 1);
+                        const uint16_t fp = uint16_t(h >> 16);                   // fingerprint: high half
+                        const uint32_t bucket = (h >> shift) & (n_buckets - 1);  // bits 3..16 (2..16)
+                        uint16_t *b = &tab[size_t(bucket) * slots];
                         uint32_t slot = 0;
-                        while (tab[size_t(bucket) * 4 + slot] != fp) ++slot;
-                        slot_of[ki] = size_t(bucket) * 4 + slot;
+                        while (slot < used[bucket] && b[slot] != fp) ++slot;
+                        if (slot == slots) { ok = false; break; }  // bucket overflow: take another seed
+                        if (slot == used[bucket]) b[used[bucket]++] = fp;
                     }
-                    make_slot_pairs(size_t(kAnchorBuckets) * 4, slot_of);
-                }
-                if (ok) {
-                    fa.anchor_q = q;
-                    fa.anchor_mode = 1;
-                    fa.anchor_mul = mul;
-                    fa.anchor_table = tab;
-                    fa.anchor_dense = every_offset ? 1u : 0u;
+                    if (ok) {  // which slot each key went to (only for the seed that is kept)
+                        std::vector<size_t> slot_of(keys.size());
+                        for (size_t ki = 0; ki < keys.size(); ++ki) {
+                            const uint32_t h = key_hash(keys[ki], mul);
+                            const uint16_t fp = uint16_t(h >> 16);
+                            const uint32_t bucket = (h >> shift) & (n_buckets - 1);
+                            uint32_t slot = 0;
+                            while (tab[size_t(bucket) * slots + slot] != fp) ++slot;
+                            slot_of[ki] = size_t(bucket) * slots + slot;
+                        }
+                        make_slot_pairs(size_t(n_buckets) * slots, slot_of);
+                        fa.anchor_q = q;
+                        fa.anchor_mode = 1;
+                        fa.anchor_mul = mul;
+                        fa.anchor_table = tab;
+                        fa.anchor_dense = every_offset ? 1u : 0u;
+                        fa.anchor_slots = slots;
+                    }
                 }
             }
         } else {

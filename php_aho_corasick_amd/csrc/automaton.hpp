@@ -42,6 +42,7 @@ struct BuildOptions {
     int anchor_dense = -1;                  // pattern sets whose shortest pattern is 4..6 B: anchor filter over the 4-byte window at EVERY
                                             // byte offset, keys = the patterns' first 4 bytes (-1 = when the keys are selective enough
                                             // on text that looks like the patterns, 0 = never, 1 = whenever the shortest pattern is >= 4 B)
+    int anchor_slots2 = -1;                 // dense form: two-slot buckets when the keys are few (-1 / 1 = up to 3,072 keys, 0 = never)
     int anchor_choice = -1;                 // big-set anchor filter: pick each pattern's anchor windows so that they share
                                             // bitmap bits (-1 / 1 = yes, 0 = the first aligned window as in the small-set table)
     uint64_t dense_bytes = 4ull << 20;      // compact: dense rows are kept for the LDS tile, every state of trie depth <= 1
@@ -151,6 +152,9 @@ struct FlatAutomaton {
     // every byte offset of the text, not only the aligned ones -- for sets whose shortest pattern is 4..6 B (keyword lists),
     // which have no aligned dword inside every occurrence.  One key per pattern instead of four, hash anchor_hash_dense.
     uint32_t anchor_dense = 0;
+    // slots per bucket of the LDS table (mode 1): 4 (2^14 buckets, bucket = hash bits 3..16) or -- dense form with few keys -- 2
+    // (2^15 buckets, bits 2..16: one 4-byte read and one packed subtract per window instead of 8 bytes and three operations)
+    uint32_t anchor_slots = 4;
     double anchor_dense_rate = 0; // expected hit windows per text byte, text drawn from the patterns' own byte frequencies
     // Dense form, small sets: everything the verification of a hit window needs, laid out to be staged into LDS by
     // k_verify_dense (a hit is decided without a single table access in global memory; the dense form has tens of hits per
@@ -213,7 +217,7 @@ inline uint32_t anchor_hash(const uint32_t *words, uint32_t n_words, uint32_t mu
 }
 // dense form: ONE multiply-add on the raw window (v_lshrrev + v_mad_u32_u24 on the device), see anchor_hash
 inline uint32_t anchor_hash_dense(uint32_t w, uint32_t mul) { return anchor_hash(&w, 1, mul); }
-inline uint16_t anchor_empty(uint32_t bucket) { return uint16_t(((bucket >> (kAnchorBucketBits - 1)) & 1u) ^ 1u); }
+inline uint16_t anchor_empty(uint32_t bucket, uint32_t bucket_bits = kAnchorBucketBits) { return uint16_t(((bucket >> (bucket_bits - 1)) & 1u) ^ 1u); }
 
 class Automaton {
 public:

@@ -52,6 +52,7 @@ struct DevAutomaton {
     uint32_t anchor_mode, anchor_bucket_mask, anchor_bucket_shift;   // mode 2: bucket = (hash >> shift) & mask
     uint32_t anchor_choice;      // 1: a pattern's anchor window may lie deeper than its first aligned dword (offset in the pair record)
     uint32_t anchor_dense;       // 1: windows at every byte offset, keys = the patterns' first four bytes (automaton.hpp)
+    uint32_t anchor_slots;       // slots per bucket of the LDS table: 4, or 2 (dense form with few keys: 2^15 buckets)
     uint32_t anchor_dense_hot;   // dense form: a dozen or more hit windows expected per 8 KiB -- the kernel variant that works out every step's hits branch-free
     const uint32_t *dense_image; // dense form, small sets: the verification data k_verify_dense stages into LDS (automaton.hpp), or null
     uint32_t dense_image_words;

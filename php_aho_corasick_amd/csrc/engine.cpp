@@ -560,6 +560,7 @@ int ensure_device(acmi_handle *h) {
     A.anchor_bucket_mask = fa.anchor_mode == 2 ? (1u << fa.anchor_bucket_bits) - 1u : 0u;
     A.anchor_choice = fa.anchor_choice;
     A.anchor_dense = fa.anchor_dense;
+    A.anchor_slots = fa.anchor_slots;
     A.anchor_dense_hot = (h->dense_hot > 0 || (h->dense_hot < 0 && fa.anchor_dense_rate * 8192.0 > 12.0)) ? 1u : 0u;
     A.anchor_bucket_shift = fa.anchor_bucket_shift;
     A.anchor_mul = fa.anchor_mul;
@@ -1527,6 +1528,9 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
         } else if (k == "compact") {
             if (h->aut.finalized()) return ACMI_E_FINALIZED;
             h->bopt.compact = value < 0 ? -1 : (value ? 1 : 0);
+        } else if (k == "anchor_slots2") {
+            if (h->aut.finalized()) return ACMI_E_FINALIZED;
+            h->bopt.anchor_slots2 = value < 0 ? -1 : (value ? 1 : 0);
         } else if (k == "anchor_dense") {
             if (h->aut.finalized()) return ACMI_E_FINALIZED;
             h->bopt.anchor_dense = value < 0 ? -1 : (value ? 1 : 0);
@@ -1614,6 +1618,7 @@ int acmi_get_stat(const acmi_handle *h, const char *key, double *value) {
         else if (k == "anchor_pairs") *value = double(fa.anchor_pairs_count);
         else if (k == "anchor_choice") *value = fa.anchor_choice;
         else if (k == "anchor_dense") *value = fa.anchor_dense;
+        else if (k == "anchor_slots") *value = fa.anchor_slots;
         else if (k == "anchor_dense_rate") *value = fa.anchor_dense_rate;
         else if (k == "dense_image_bytes") *value = double(h->dA.dense_image_words) * 4;
         else if (k == "built_on_device") *value = h->aut.built_on_device() ? 1 : 0;
@@ -1686,6 +1691,7 @@ int acmi_debug_tables(const acmi_handle *h, acmi_tables *out) {
         out->out_off = fa.out_off.empty() ? nullptr : fa.out_off.data();
         out->out_list = fa.out_list.empty() ? nullptr : fa.out_list.data();
         out->anchor_dense = fa.anchor_dense;
+        out->anchor_slots = fa.anchor_slots;
         return ACMI_OK;
     });
 }

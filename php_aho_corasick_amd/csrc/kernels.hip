@@ -813,6 +813,12 @@ __device__ __forceinline__ bool verify_candidate(const DevAutomaton &A, const ui
             if ((bv[i] >> 16) == fp) slot = bucket * 8u + uint32_t(i) * 2u + 1u;
             if ((bv[i] & 0xffffu) == fp) slot = bucket * 8u + uint32_t(i) * 2u;
         }
+    } else if (A.anchor_slots == 2u) {
+        const uint32_t bucket = (h >> 2) & 0x7FFFu;
+        const uint32_t b = static_cast<const uint32_t *>(A.anchor_table)[bucket];
+        const uint32_t fp = h >> 16;
+        if ((b >> 16) == fp) slot = bucket * 2u + 1u;
+        if ((b & 0xffffu) == fp) slot = bucket * 2u;
     } else {
         const uint32_t bucket = (h >> 3) & 0x3FFFu;
         const uint2 b = static_cast<const uint2 *>(A.anchor_table)[bucket];
@@ -1325,8 +1331,11 @@ __device__ __forceinline__ bool anchor_next(const DevAutomaton &A, const BatchAr
 // HOT (dense form): many hit windows expected (a dozen or more per 8 KiB) -- which of a step's four windows hit is worked out
 // for every step, branch-free (31 VALU), instead of a cheap any-hit test (21) with the exact one behind a branch (+ 35 when
 // taken: with three hits per step that was most of the kernel's instructions).
-template <int QW, bool BIG, bool SHORT, bool TINY = false, bool DENSE = false, bool HOT = false>
+// SL2 (dense form, few keys): the LDS table has two slots per bucket, 2^15 buckets -- one ds_read_b32 and one packed subtract
+// per window.
+template <int QW, bool BIG, bool SHORT, bool TINY = false, bool DENSE = false, bool HOT = false, bool SL2 = false>
 __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, BatchArgs B) {
+    static_assert(!SL2 || DENSE, "two-slot buckets exist for the dense form only");
     static_assert(!DENSE || (QW == 1 && !BIG), "the dense form exists for 4-byte windows and the LDS table only");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int G = BIG ? 4 : 8;  // 16-byte quads per lane and task
@@ -1583,7 +1592,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
         // flight while step t-1's are compared.  The dword to the left of a quad's first is the neighbouring lane's last
         // (DPP), lane 0's the last dword of lane 63 in the previous row (tail[0]: raw text here, not a hash prefix).
         uint32_t hh[2][4];
-        u32x2 bb[2][4];
+        u32x2 bb[2][4];   // (SL2: .x holds the bucket's two slots, .y a copy -- the compares below then see every slot twice)
         uint32_t rows = SHORT ? ((sc.nq - sc.c * TQ < TQ ? sc.nq - sc.c * TQ : TQ) + 63u) >> 6 : uint32_t(G);
         if constexpr (TINY) {
             if (tiny_on) rows = tcnt - tscan * uint32_t(G) < uint32_t(G) ? tcnt - tscan * uint32_t(G) : uint32_t(G);
@@ -1616,14 +1625,47 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                 if (j == 3) buf[r] = load_quad(ld, r);
                 if (live) {
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) bb[t & 1][w] = anchor_bucket(hh[t & 1][w]);
+                    for (int w = 0; w < 4; ++w) {
+                        if constexpr (SL2) bb[t & 1][w].x = *reinterpret_cast<LdsU1Ptr>(hh[t & 1][w] & 0x1FFFCu);   // bucket = hash bits 2..16
+                        else bb[t & 1][w] = anchor_bucket(hh[t & 1][w]);
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
             if (t > 0 && (!SHORT || uint32_t((t - 1) >> 2) < rows)) {
                 const u32x2 *b4 = bb[(t - 1) & 1];
                 const uint32_t *h4 = hh[(t - 1) & 1];
-                if constexpr (HOT) {
+                if constexpr (SL2) {
+                    // two slots: the subtract's result is the whole test.  HOT: exact per window, every step; else a running
+                    // minimum with the exact test behind a branch
+                    if constexpr (HOT) {
+                        uint32_t dd = 0;
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            uint32_t x;
+                            asm("v_pk_sub_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(x) : "v"(b4[w].x), "v"(h4[w]));
+                            const uint32_t d = (x - 0x00010001u) & ~x;
+                            dd |= (d >> (3 - w)) & (0x80008000u >> (3 - w));
+                        }
+                        const uint32_t m = __builtin_amdgcn_ubfe(dd | (dd >> 16), 12u, 4u);
+                        z[(t - 1) >> 2] |= m << (4 * ((t - 1) & 3));
+                        zany |= m;
+                    } else {
+                        uint32_t x4[4], zz = 0xFFFFFFFFu;
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            asm("v_pk_sub_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(x4[w]) : "v"(b4[w].x), "v"(h4[w]));
+                            asm("v_pk_min_u16 %0, %1, %2" : "=v"(zz) : "v"(zz), "v"(x4[w]));
+                        }
+                        if (__builtin_expect(__any(has_zero_half(zz)), 0)) {
+                            uint32_t m = 0;
+#pragma unroll
+                            for (int w = 0; w < 4; ++w) m |= has_zero_half(x4[w]) ? (1u << w) : 0u;
+                            z[(t - 1) >> 2] |= m << (4 * ((t - 1) & 3));
+                            zany |= m;
+                        }
+                    }
+                } else if constexpr (HOT) {
                     // per window: the bucket's four slots minus the fingerprint, their minimum per halfword pair, the
                     // zero-halfword test (bits 15 / 31), shifted to the window's own bit positions and merged
                     uint32_t dd = 0;
@@ -3444,7 +3486,7 @@ static hipError_t launch_anchor(const DevAutomaton &A, const BatchArgs &B, uint6
     if (variant) {
         const bool big = A.anchor_mode == 2, tiny = B.tiny_items != 0;
         const bool shrt = !big && (tiny || B.short_items != 0);
-        *variant = (A.anchor_q / 4u) | (big ? 8u : 0u) | (shrt ? 16u : 0u) | (tiny ? 32u : 0u) | (A.anchor_dense ? 64u : 0u) | (A.anchor_dense && A.anchor_dense_hot ? 128u : 0u);
+        *variant = (A.anchor_q / 4u) | (big ? 8u : 0u) | (shrt ? 16u : 0u) | (tiny ? 32u : 0u) | (A.anchor_dense ? 64u : 0u) | (A.anchor_dense && A.anchor_dense_hot ? 128u : 0u) | (A.anchor_slots == 2u ? 256u : 0u);
     }
     const uint64_t per_block = uint64_t(kLdsThreads / 64u) * B.wave_items;
     const uint64_t want = (max_items + per_block - 1) / per_block;
@@ -3458,6 +3500,16 @@ static hipError_t launch_anchor(const DevAutomaton &A, const BatchArgs &B, uint6
         return hipGetLastError();
     };
     if (A.anchor_dense) {  // windows at every byte offset (shortest pattern 4..6 B)
+        if (A.anchor_slots == 2u) {
+            if (A.anchor_dense_hot) {
+                if (B.tiny_items) return go(k_scan_anchor<1, false, true, true, true, true, true>);
+                if (B.short_items) return go(k_scan_anchor<1, false, true, false, true, true, true>);
+                return go(k_scan_anchor<1, false, false, false, true, true, true>);
+            }
+            if (B.tiny_items) return go(k_scan_anchor<1, false, true, true, true, false, true>);
+            if (B.short_items) return go(k_scan_anchor<1, false, true, false, true, false, true>);
+            return go(k_scan_anchor<1, false, false, false, true, false, true>);
+        }
         if (A.anchor_dense_hot) {
             if (B.tiny_items) return go(k_scan_anchor<1, false, true, true, true, true>);
             if (B.short_items) return go(k_scan_anchor<1, false, true, false, true, true>);

@@ -85,11 +85,12 @@ class FlatTables:
         self.anchor_bucket_shift = t.anchor_bucket_shift
         self.anchor_choice = t.anchor_choice
         self.anchor_dense = t.anchor_dense
+        self.anchor_slots = t.anchor_slots
         self.anchor_offsets = None   # filled by test code that knows the pattern count
         self._anchor_offsets_ptr = t.anchor_offsets
         self.anchor = self.anchor_bitmap = None
         if t.anchor_mode == 1:
-            self.anchor = np.ctypeslib.as_array(t.anchor_table, shape=(16384, 4)).copy()
+            self.anchor = np.ctypeslib.as_array(t.anchor_table, shape=(16384 * 4 // t.anchor_slots, t.anchor_slots)).copy()
         elif t.anchor_mode == 2:
             self.anchor = np.ctypeslib.as_array(t.anchor_table, shape=(1 << t.anchor_bucket_bits, 8)).copy()
             self.anchor_bitmap = np.ctypeslib.as_array(t.anchor_bitmap, shape=(1 << 15,)).copy()
@@ -113,6 +114,8 @@ class FlatTables:
             if not (int(self.anchor_bitmap[h >> 17]) >> ((h >> 12) & 31)) & 1:
                 return False
             return int((h >> 16) | 1) in [int(x) for x in self.anchor[(h >> self.anchor_bucket_shift) & ((1 << self.anchor_bucket_bits) - 1)]]
+        if self.anchor_slots == 2:   # 2^15 buckets of two slots: hash bits 2..16
+            return int(h >> 16) in [int(x) for x in self.anchor[(h >> 2) & 0x7FFF]]
         return int(h >> 16) in [int(x) for x in self.anchor[(h >> 3) & 0x3FFF]]
 
     def cold_step(self, s: int, b: int) -> int:

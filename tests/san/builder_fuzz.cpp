@@ -118,6 +118,11 @@ long anchor_slot(const FlatAutomaton &fa, const uint8_t *window) {
         return -1;
     }
     const uint16_t fp = uint16_t(h >> 16);
+    if (fa.anchor_slots == 2) {
+        const size_t bucket = (h >> 2) & (2 * kAnchorBuckets - 1);
+        for (int i = 0; i < 2; ++i) if (fa.anchor_table[bucket * 2 + i] == fp) return long(bucket * 2 + i);
+        return -1;
+    }
     const size_t bucket = (h >> 3) & (kAnchorBuckets - 1);
     for (int i = 0; i < 4; ++i) if (fa.anchor_table[bucket * 4 + i] == fp) return long(bucket * 4 + i);
     return -1;
@@ -135,6 +140,10 @@ bool anchor_probe(const FlatAutomaton &fa, const uint8_t *window) {
         return false;
     }
     const uint16_t fp = uint16_t(h >> 16);
+    if (fa.anchor_slots == 2) {
+        const uint16_t *b2 = &fa.anchor_table[size_t((h >> 2) & (2 * kAnchorBuckets - 1)) * 2];
+        return b2[0] == fp || b2[1] == fp;
+    }
     const uint16_t *b = &fa.anchor_table[size_t((h >> 3) & (kAnchorBuckets - 1)) * 4];
     for (int i = 0; i < 4; ++i) if (b[i] == fp) return true;
     return false;
@@ -182,7 +191,8 @@ int run_case(uint64_t seed, bool verbose) {
     static const uint64_t dense_opts[] = {0, 4096, 65536, 4ull << 20};
     opt.dense_bytes = dense_opts[r.below(4)];
     opt.max_flat_outputs = r.below(4) == 0 ? 0 : (1ull << 25);
-    opt.anchor_dense = int(r.below(3)) - 1;   // the dense anchor form (shortest pattern 4..6 B): automatic, never, whenever possible
+    opt.anchor_dense = int(r.below(3)) - 1;
+    opt.anchor_slots2 = int(r.below(2));   // the dense anchor form (shortest pattern 4..6 B): automatic, never, whenever possible
 
     Automaton aut;
     orc_trie *o = orc_create();

@@ -55,7 +55,7 @@ def test_targeted_goldens_automatic_variant(name, path, targeted):
 OPTIONS = [dict(tiny_rows=0), dict(tiny_rows=0, short_rows=0), dict(short_rows=1), dict(wave_items=1), dict(wave_items=7, persistent=1),
            dict(wave_items=64, persistent=0), dict(chunk_bytes=512), dict(chunk_bytes=1024, run_cap=1), dict(slab_events=1, refill=2),
            dict(verify=0), dict(kernel=1), dict(kernel=4), dict(kernel=0), dict(run_cap=3), dict(run_cap=200, chunk_bytes=256), dict(anchor_dense=0),
-           dict(short_rows=0, tiny_rows=0, persistent=1), dict(dense_hot=1), dict(dense_hot=0), dict(dense_hot=1, tiny_rows=0, chunk_bytes=2048), dict(early_stop=2, compact=1, dense_bytes=0, lds_bytes=4096)]
+           dict(short_rows=0, tiny_rows=0, persistent=1), dict(dense_hot=1), dict(dense_hot=0), dict(anchor_slots2=0), dict(anchor_slots2=0, dense_hot=1), dict(anchor_slots2=1, dense_hot=0, verify=0), dict(dense_hot=1, tiny_rows=0, chunk_bytes=2048), dict(early_stop=2, compact=1, dense_bytes=0, lds_bytes=4096)]
 
 
 @pytest.mark.parametrize("name", list(EXPECT))
