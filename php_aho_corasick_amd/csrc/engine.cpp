@@ -824,7 +824,9 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     // persistent workgroups pay off once a CU would otherwise run several workgroups back to back
     // (measured: 1 KiB items -18 %, 2 x 8 KiB per lane +2.5 %)
     {   // anchor kernel: items per wave batch -- 64 when the batch can give every wave that many
-        const uint64_t est = std::max<uint64_t>(1, blob_bytes / chunk);
+        // (at least one item per haystack: a GiB of 256-byte haystacks is 4 M items, not the 131,072 its bytes suggest -- with
+        // 32 items per wave batch the batch's fixed costs were most of the tiny-item kernel's time)
+        const uint64_t est = std::max<uint64_t>(1, std::max<uint64_t>(blob_bytes / chunk, nh));
         const uint64_t waves = 256ull * 16;
         B.wave_items = uint32_t(std::min<uint64_t>(64, std::max<uint64_t>(1, est / waves)));
         if (h->wave_items > 0) B.wave_items = uint32_t(h->wave_items);
