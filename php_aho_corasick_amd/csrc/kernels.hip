@@ -1374,12 +1374,19 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     if (lane < B.wave_items && wave_first + lane < total_items) rec = B.item_rec[wave_first + lane];
     // TINY: every item of this batch is one aligned row at most?  (wave-uniform; else the wave takes the usual path)
     bool tiny_on = false;
-    uint32_t tcnt = 0, tscan = 0, tload = 0;  // items of the batch; task being scanned / being loaded (G items each)
+    uint32_t tcnt = 0, tscan = 0, tload = 0;  // items of the batch; task being scanned / being loaded (G x tpack items each)
+    uint32_t tpack = 1, tshift = 6;           // items per row of a task, log2 of the lanes per item
     if constexpr (TINY) {
         const bool fits = rec.z == 0u || (((reinterpret_cast<uintptr_t>(B.blob) + rec.x) & 15u) == 0u && rec.z <= 1024u);
         tiny_on = B.align_warm == 1u && __all(fits);
         tcnt = uint32_t(__builtin_popcountll(__ballot(rec.z != 0u)));
         if (tiny_on && lane == 0) atomicAdd(&B.counters[18], 1u);  // statistic ("tiny_waves"): which path the batch's waves took
+        // items of a quarter / half row at most (haystacks of <= 256 / 512 B) are packed FOUR / TWO to a row: lane l of row r holds
+        // quad l mod 16 (32) of item (8 t + r) * 4 (2) + l / 16 (32) -- else three lanes in four of a 256-byte item's row idle
+        if (!BIG && !DENSE && tiny_on) {
+            if (__all(rec.z <= 256u)) { tpack = 4u; tshift = 4u; }
+            else if (__all(rec.z <= 512u)) { tpack = 2u; tshift = 5u; }
+        }
     }
     AnchorCursor ld, sc;  // load cursor runs one task ahead of the scan cursor
     anchor_open<TQ>(A, B, rec, 0, ld);
@@ -1417,12 +1424,21 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
         uint32_t qi = cur.c * TQ + uint32_t(r) * 64u + lane;
         if constexpr (TINY) {
             if (tiny_on) {  // row r of task `tload` = item tload * G + r (a row that is not there repeats the last item)
-                uint32_t k = tload * uint32_t(G) + uint32_t(r);
-                k = k < tcnt ? k : tcnt - 1u;
-                const uint32_t x = __builtin_amdgcn_readlane(rec.x, k), y = __builtin_amdgcn_readlane(rec.y, k);
-                base = reinterpret_cast<const uint4 *>(B.blob + (uint64_t(y & 0x3FFFu) << 32 | x));
-                last = ((__builtin_amdgcn_readlane(rec.z, k) + 15u) >> 4) - 1u;
-                qi = lane;
+                if (tpack == 1u) {
+                    uint32_t k = tload * uint32_t(G) + uint32_t(r);
+                    k = k < tcnt ? k : tcnt - 1u;
+                    const uint32_t x = __builtin_amdgcn_readlane(rec.x, k), y = __builtin_amdgcn_readlane(rec.y, k);
+                    base = reinterpret_cast<const uint4 *>(B.blob + (uint64_t(y & 0x3FFFu) << 32 | x));
+                    last = ((__builtin_amdgcn_readlane(rec.z, k) + 15u) >> 4) - 1u;
+                    qi = lane;
+                } else {  // several items per row: every lane fetches its own item's record from the lane that holds it
+                    uint32_t k = (tload * uint32_t(G) + uint32_t(r)) * tpack + (lane >> tshift);
+                    k = k < tcnt ? k : tcnt - 1u;
+                    const uint32_t x = uint32_t(__shfl(int(rec.x), int(k), 64)), y = uint32_t(__shfl(int(rec.y), int(k), 64));
+                    base = reinterpret_cast<const uint4 *>(B.blob + (uint64_t(y & 0x3FFFu) << 32 | x));
+                    last = ((uint32_t(__shfl(int(rec.z), int(k), 64)) + 15u) >> 4) - 1u;
+                    qi = lane & ((1u << tshift) - 1u);
+                }
             }
         }
         return stream_load(base + (qi < last ? qi : last));  // (one load instruction either way: only the address differs)
@@ -1470,6 +1486,9 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                 // lane 0 <- lane 63 of the previous wave-load (rotate), lanes 1..63 <- lane l-1 of this one
                 const uint32_t wrap = __builtin_amdgcn_mov_dpp(tail[n - 1], 0x13C /* wave_ror:1 */, 0xf, 0xf, false);
                 left[n - 1] = __builtin_amdgcn_update_dpp(wrap, h, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                if constexpr (TINY) {  // packed rows: the lane that holds an item's first quad has nothing to its left
+                    if (tpack > 1u && (lane & ((1u << tshift) - 1u)) == 0u) left[n - 1] = 0u;
+                }
             }
 #pragma unroll
             for (int n = 1; n < QW; ++n) tail[n - 1] = mine[n - 1];
@@ -1705,7 +1724,10 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
         // SHORT: rows of 64 quads this task has (an item of 4 KiB fills half a task); the others are only reloaded
         uint32_t rows = SHORT ? ((sc.nq - sc.c * TQ < TQ ? sc.nq - sc.c * TQ : TQ) + 63u) >> 6 : uint32_t(G);
         if constexpr (TINY) {
-            if (tiny_on) rows = tcnt - tscan * uint32_t(G) < uint32_t(G) ? tcnt - tscan * uint32_t(G) : uint32_t(G);
+            if (tiny_on) {
+                const uint32_t left_items = tcnt - tscan * uint32_t(G) * tpack;
+                rows = (left_items + tpack - 1u) / tpack < uint32_t(G) ? (left_items + tpack - 1u) / tpack : uint32_t(G);
+            }
         }
 #pragma unroll
         for (int r = 0; r <= G; ++r) {
@@ -1840,17 +1862,25 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
 #pragma unroll
                     for (int r = 0; r < G; ++r) {
                         uint64_t who = __ballot(z[r] != 0);
-                        const uint32_t k = tscan * uint32_t(G) + uint32_t(r);
-                        if (who == 0 || k >= tcnt) continue;
-                        anchor_open<TQ>(A, B, rec, k, sc);
-                        nrun = 0;
-                        run_hi = 0;
+                        if (who == 0) continue;
+                        // the row's items in lane order (one, or tpack of them); an item's run count goes to its lane when its
+                        // last hit has been flagged
+                        uint32_t cur_k = 0xFFFFFFFFu;
                         while (who != 0) {
                             const uint32_t l = uint32_t(__builtin_ctzll(who));
-                            flag(0u, l, __builtin_amdgcn_readlane(z[r], l));
                             who &= who - 1;
+                            const uint32_t k = (tscan * uint32_t(G) + uint32_t(r)) * tpack + (l >> tshift);
+                            if (k >= tcnt) continue;   // (a slot behind the batch's last item repeats that item: not its hits again)
+                            if (k != cur_k) {
+                                if (cur_k != 0xFFFFFFFFu) nrun_vec = lane == cur_k ? nrun : nrun_vec;
+                                anchor_open<TQ>(A, B, rec, k, sc);
+                                nrun = 0;
+                                run_hi = 0;
+                                cur_k = k;
+                            }
+                            flag(0u, l & ((1u << tshift) - 1u), __builtin_amdgcn_readlane(z[r], l));
                         }
-                        nrun_vec = lane == k ? nrun : nrun_vec;
+                        if (cur_k != 0xFFFFFFFFu) nrun_vec = lane == cur_k ? nrun : nrun_vec;
                     }
                 }
                 return;
@@ -1939,10 +1969,10 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
             for (;;) {
                 tload = tscan + 2u;
                 scan_task(buf0);
-                if (++tscan * uint32_t(G) >= tcnt) break;
+                if (++tscan * uint32_t(G) * tpack >= tcnt) break;
                 tload = tscan + 2u;
                 scan_task(buf1);
-                if (++tscan * uint32_t(G) >= tcnt) break;
+                if (++tscan * uint32_t(G) * tpack >= tcnt) break;
             }
             done_tiny = true;
         }
