@@ -631,7 +631,6 @@ def main():
         pci_bus = int(torch.cuda.get_device_properties(dev_index).pci_bus_id)
     except Exception:
         pci_bus = None
-    clocks_start = _sclk_mhz(pci_bus)
 
     # ---- automaton (replicated on every rank) ----
     t0 = time.perf_counter()
@@ -734,6 +733,7 @@ def main():
     if gather:
         dist.barrier()
     torch.cuda.synchronize()
+    clocks_start = _sclk_mhz(pci_bus)   # (right behind the warm-up steps: the level the timed region starts on)
     t0 = time.perf_counter()
     run_steps(args.steps, depth)
     gathered = drain()
