@@ -632,6 +632,12 @@ uint32_t choose_chunk(const acmi_handle *h, uint64_t blob_bytes, size_t nh, int 
     const uint64_t target_items = 256ull * 1024 * 2 * (kernel == 4 ? 4 : 1);
     uint64_t c0 = (blob_bytes + target_items - 1) / target_items;
     uint64_t cmin = std::max<uint64_t>(kernel == 4 ? 1024 : 256, (uint64_t(warm) * 8 + 127) & ~uint64_t(127));
+    // ... and a batch with fewer 1-KiB items than the chip has lanes (under 256 MiB) takes them smaller still: the walk is a
+    // chain of dependent LDS reads per lane and only more lanes hide it (32 MiB of a^1..a^16: 32 K items on 256 K lanes)
+    if (kernel == 4 && blob_bytes < 1024ull * 256 * 1024) {
+        const uint64_t per_lane = (blob_bytes / (256ull * 1024) + 127) & ~uint64_t(127);
+        cmin = std::max<uint64_t>(std::max<uint64_t>(256, per_lane), (uint64_t(warm) * 8 + 127) & ~uint64_t(127));
+    }
     // the anchor kernel streams an item 8 KiB (one wave step) at a time: smaller items idle its lanes
     if (kernel == 2) {
         cmin = std::max<uint64_t>(cmin, 8192);
