@@ -611,8 +611,9 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
                     fa.anchor_slot_pair[all[i].slot] = uint32_t(fa.anchor_pairs.size() / 4) | uint32_t(e - i - 1) << 28;
                     for (size_t k = i; k < e; ++k) {
                         const PatternMeta &m = patterns_[all[k].pattern];
-                        fa.anchor_pairs.insert(fa.anchor_pairs.end(), {all[k].pattern, all[k].offset | (m.length << 8), uint32_t(m.byte_off),
-                                                                       pattern_state[all[k].pattern]});
+                        // (the final state's record count rides along: the candidate check needs no load of its own for it)
+                        fa.anchor_pairs.insert(fa.anchor_pairs.end(), {fa.out_count[pattern_state[all[k].pattern]], all[k].offset | (m.length << 8),
+                                                                       uint32_t(m.byte_off), pattern_state[all[k].pattern]});
                     }
                 }
                 i = e;

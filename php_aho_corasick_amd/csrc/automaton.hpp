@@ -177,7 +177,7 @@ struct FlatAutomaton {
     // Candidate verification by text compare (k_walk_runs).  A hit window whose q-gram belongs to exactly one
     // (pattern, offset) pair can only be the anchor of that pattern: comparing the pattern's bytes with the text
     // decides the candidate without a single automaton step.  anchor_slot_pair[bucket * slots + slot] = index of
-    // the 4-word record {pattern, offset | length << 8, byte offset in pattern_bytes, final state} in anchor_pairs,
+    // the 4-word record {out_count of the final state, offset | length << 8, byte offset in pattern_bytes, final state} in anchor_pairs,
     // or kNone when the slot stands for several pairs (patterns sharing a q-gram, two q-grams sharing a fingerprint):
     // those candidates are walked.
     std::vector<uint32_t> anchor_slot_pair;

@@ -796,6 +796,11 @@ __device__ __forceinline__ bool verify_candidate(const DevAutomaton &A, const ui
     if (nw == 1u) {  // the raw window, one multiply-add (automaton.hpp anchor_hash)
         const uint32_t t4 = load4u(p + w);
         h = anchor_mad(t4, A.anchor_mul, t4 >> 13);
+    } else if (w + 16u <= n) {  // one request for the whole window (what bounds this kernel is its count of divergent requests)
+        const uint4 t = load16u(p + w);
+        h = anchor_mad(anchor_fold_dev(t.x), A.anchor_mul, anchor_fold_dev(t.y));
+        if (nw >= 3u) h = anchor_mad(h, A.anchor_mul, anchor_fold_dev(t.z));
+        if (nw >= 4u) h = anchor_mad(h, A.anchor_mul, anchor_fold_dev(t.w));
     } else {
         h = anchor_fold_dev(load4u(p + w));
 #pragma unroll 1
@@ -841,7 +846,7 @@ __device__ __forceinline__ bool verify_candidate(const DevAutomaton &A, const ui
         const uint32_t o = rec.y & 0xffu, len = rec.y >> 8;
         if (w < o + floor || w - o + len > n) continue;  // would begin before / end after this item's bytes: no occurrence here
         const uint8_t *tp = p + (w - o), *pp = A.pattern_bytes + rec.z;
-        const uint32_t oc = A.out_count[rec.w];
+        const uint32_t oc = rec.x;   // out_count of the pattern's final state
         uint32_t diff = 0;
         if (len >= 16u) {
             // (requesting four clamped 16-byte pieces of both texts up front -- one round trip whatever the length -- was
@@ -852,8 +857,10 @@ __device__ __forceinline__ bool verify_candidate(const DevAutomaton &A, const ui
                 const uint4 a = load16u(tp + c), b = load16u(pp + c);
                 diff |= (a.x ^ b.x) | (a.y ^ b.y) | (a.z ^ b.z) | (a.w ^ b.w);
             }
-            const uint4 a = load16u(tp + len - 16u), b = load16u(pp + len - 16u);  // the last 16 bytes (may overlap)
-            diff |= (a.x ^ b.x) | (a.y ^ b.y) | (a.z ^ b.z) | (a.w ^ b.w);
+            if (len & 15u) {
+                const uint4 a = load16u(tp + len - 16u), b = load16u(pp + len - 16u);  // the last 16 bytes (may overlap)
+                diff |= (a.x ^ b.x) | (a.y ^ b.y) | (a.z ^ b.z) | (a.w ^ b.w);
+            }
         } else if (len >= 8u) {
             const uint2 a0 = load8u(tp), b0 = load8u(pp), a1 = load8u(tp + len - 8u), b1 = load8u(pp + len - 8u);
             diff = (a0.x ^ b0.x) | (a0.y ^ b0.y) | (a1.x ^ b1.x) | (a1.y ^ b1.y);

@@ -253,12 +253,13 @@ int run_case(uint64_t seed, bool verbose) {
                 for (uint32_t k = 0; k <= (sp >> 28); ++k) {
                     const uint32_t *rec = &fa.anchor_pairs[(size_t(sp & 0x0FFFFFFFu) + k) * 4];
                     const uint32_t st = rec[3];
-                    if (st >= fa.n_states || fa.own_pattern[st] != rec[0] || (rec[1] >> 8) != aut.patterns()[rec[0]].length ||
-                        rec[2] != aut.patterns()[rec[0]].byte_off) {
+                    const uint32_t own = st < fa.n_states ? fa.own_pattern[st] : kNone;
+                    if (own == kNone || fa.out_count[st] != rec[0] || (rec[1] >> 8) != aut.patterns()[own].length ||
+                        rec[2] != aut.patterns()[own].byte_off) {
                         std::fprintf(stderr, "seed %llu: malformed verification pair\n", (unsigned long long)seed);
                         bad = 1;
                     }
-                    found = found || (rec[0] == pi && (rec[1] & 0xffu) == off);
+                    found = found || (own == pi && (rec[1] & 0xffu) == off);
                 }
                 if (!found) {
                     std::fprintf(stderr, "seed %llu: verification pairs of pattern %zu offset %u are missing\n", (unsigned long long)seed, pi, off);
