@@ -16,28 +16,60 @@ inline uint64_t mix(uint64_t k) {
     return k ^ (k >> 29);
 }
 
+// Sort `v` by a 64-bit key (LSD radix sort of {key, index} pairs, 11 bits a pass, passes in which every key has the same
+// digit skipped), elements with equal keys ordered by `tie`: the sorts of a large pattern set's q-gram triples -- 24-byte
+// records under a three-level comparison -- were a third of its anchor-table build.
+template <typename T, typename Key, typename Tie>
+void sort_by_u64(std::vector<T> &v, Key key, Tie tie) {
+    const size_t n = v.size();
+    if (n < 4096) {
+        std::sort(v.begin(), v.end(), [&](const T &a, const T &b) { return key(a) != key(b) ? key(a) < key(b) : tie(a, b); });
+        return;
+    }
+    struct KI { uint64_t k; uint32_t i; };
+    std::vector<KI> a(n), b(n);
+    uint64_t all_or = 0, all_and = ~0ull;
+    for (size_t i = 0; i < n; ++i) {
+        a[i] = KI{key(v[i]), uint32_t(i)};
+        all_or |= a[i].k;
+        all_and &= a[i].k;
+    }
+    const uint64_t varying = all_or ^ all_and;   // bits that differ between some two keys
+    for (uint32_t shift = 0; shift < 64; shift += 11) {
+        if (((varying >> shift) & 0x7FFu) == 0) continue;
+        size_t count[2049] = {0};
+        for (size_t i = 0; i < n; ++i) ++count[((a[i].k >> shift) & 0x7FFu) + 1];
+        for (int d = 0; d < 2048; ++d) count[d + 1] += count[d];
+        for (size_t i = 0; i < n; ++i) b[count[(a[i].k >> shift) & 0x7FFu]++] = a[i];
+        a.swap(b);
+    }
+    std::vector<T> out(n);
+    for (size_t i = 0; i < n; ++i) out[i] = v[a[i].i];
+    for (size_t i = 0; i < n;) {
+        size_t e = i + 1;
+        while (e < n && a[e].k == a[i].k) ++e;
+        if (e - i > 1) std::sort(out.begin() + i, out.begin() + e, tie);
+        i = e;
+    }
+    v.swap(out);
+}
 // Dense rows.  `dense` = how many states, in BFS order, get a row (all of them when not compact); a state's row
-// index is its id below dense_nf_end and dense_nf_end + id - f2 for the dense cold final ones.
+// index is its id below dense_nf_end and dense_nf_end + id - f2 for the dense cold final ones.  Trie arrays by BFS
+// position (Automaton::finalize): children of position i = positions [cfirst[i], cfirst[i+1]).
 template <typename E>
-void build_tables(FlatAutomaton &fa, const std::vector<uint32_t> &order, uint32_t dense,
-                  const std::vector<uint32_t> &fail, const std::vector<uint32_t> &newid,
-                  const std::vector<uint32_t> &child_off, const std::vector<uint32_t> &child_list,
-                  const std::vector<uint8_t> &in_byte) {
+void build_tables(FlatAutomaton &fa, uint32_t dense, const std::vector<uint32_t> &fail_b, const std::vector<uint32_t> &newid,
+                  const std::vector<uint32_t> &cfirst, const std::vector<uint8_t> &byte_b) {
     const size_t nc = fa.n_columns;
     fa.table.assign(size_t(fa.n_dense_rows) * nc * sizeof(E), 0);
     fa.table_bytes = fa.table.size();
     E *tab = reinterpret_cast<E *>(fa.table.data());
     auto row_of = [&](uint32_t id) { return size_t(id < fa.dense_nf_end ? id : fa.dense_nf_end + (id - fa.f2)); };
     for (uint32_t i = 0; i < dense; ++i) {  // BFS order: the failure state's row is already complete
-        const uint32_t u = order[i];
-        E *row = tab + row_of(newid[u]) * nc;
-        if (u != 0)
-            std::memcpy(row, tab + row_of(newid[fail[u]]) * nc, nc * sizeof(E));
+        E *row = tab + row_of(newid[i]) * nc;
+        if (i != 0)
+            std::memcpy(row, tab + row_of(newid[fail_b[i]]) * nc, nc * sizeof(E));
         // (root row stays all-zero: every byte without a goto edge returns to the root)
-        for (uint32_t e = child_off[u]; e < child_off[u + 1]; ++e) {
-            uint32_t c = child_list[e];
-            row[fa.class_of_byte[in_byte[c]]] = E(newid[c]);
-        }
+        for (uint32_t c = cfirst[i]; c < cfirst[i + 1]; ++c) row[fa.class_of_byte[byte_b[c]]] = E(newid[c]);
     }
     E *trap_row = tab + size_t(fa.trap) * nc;
     for (size_t j = 0; j < nc; ++j) trap_row[j] = E(fa.trap);
@@ -190,67 +222,78 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
     FlatAutomaton &fa = flat_;
 
     // ---- children in CSR form, BFS order ------------------------------------------------
-    std::vector<uint32_t> child_off(ns + 1, 0), child_list(ns > 1 ? ns - 1 : 0);
-    for (uint32_t v = 1; v < ns; ++v) ++child_off[parent_[v] + 1];
-    for (uint32_t v = 0; v < ns; ++v) child_off[v + 1] += child_off[v];
+    // From here on a node is named by its POSITION in BFS order (order[i] = the node at position i): the children of
+    // position i are the consecutive positions [cfirst[i], cfirst[i+1]), a parent lies before its children, and so does
+    // a failure target.  Every later pass over the trie then reads its arrays front to back -- indexed by node id (the
+    // order the patterns were added in) each of them was a pass of cache misses over millions of nodes.
+    std::vector<uint32_t> order(ns), cfirst(size_t(ns) + 1), parent_pos(ns, 0);
+    std::vector<uint8_t> depth(ns, 0), byte_b(ns, 0);
     {
-        std::vector<uint32_t> cur(child_off.begin(), child_off.end() - 1);
-        for (uint32_t v = 1; v < ns; ++v) child_list[cur[parent_[v]]++] = v;
-    }
-    std::vector<uint32_t> order;
-    order.reserve(ns);
-    order.push_back(0);
-    for (size_t head = 0; head < order.size(); ++head) {
-        const uint32_t u = order[head];
-        for (uint32_t e = child_off[u]; e < child_off[u + 1]; ++e) order.push_back(child_list[e]);
+        std::vector<uint32_t> child_off(size_t(ns) + 1, 0), child_list(ns > 1 ? ns - 1 : 0);
+        for (uint32_t v = 1; v < ns; ++v) ++child_off[parent_[v] + 1];
+        for (uint32_t v = 0; v < ns; ++v) child_off[v + 1] += child_off[v];
+        {
+            std::vector<uint32_t> cur(child_off.begin(), child_off.end() - 1);
+            for (uint32_t v = 1; v < ns; ++v) child_list[cur[parent_[v]]++] = v;
+        }
+        order[0] = 0;
+        uint32_t tail = 1;
+        for (uint32_t head = 0; head < ns; ++head) {
+            const uint32_t u = order[head];
+            cfirst[head] = tail;
+            const uint8_t d = uint8_t(std::min<uint32_t>(depth[head] + 1u, 255u));
+            for (uint32_t e = child_off[u]; e < child_off[u + 1]; ++e) {
+                const uint32_t v = child_list[e];
+                order[tail] = v;
+                depth[tail] = d;
+                parent_pos[tail] = head;
+                byte_b[tail] = in_byte_[v];
+                ++tail;
+            }
+        }
+        cfirst[ns] = ns;
     }
 
     // ---- failure links (textbook BFS; same function as ahocorasick.c:344-368 defines) and per-state output:
     // final flag, record count, dictionary link (node.c:424-441).  Level-synchronous: on the device when the engine
-    // offers it (one launch per trie depth), else here.
-    std::vector<uint32_t> fail(ns, 0);
-    std::vector<uint8_t> is_final(ns, 0);
-    std::vector<uint32_t> cnt(ns, 0), dict(ns, kNone);
+    // offers it (one launch per trie depth), else here.  All by BFS position, the links as positions.
+    std::vector<uint32_t> fail_b(ns, 0);
+    std::vector<uint8_t> final_b(ns, 0);
+    std::vector<uint32_t> cnt_b(ns, 0), dict_b(ns, kNone);
     bool done = false;
     if (accel && accel->fail_and_outputs) {
-        std::vector<uint32_t> level_off{0};
-        {   // BFS order is depth order: a level ends where a node's parent lies in the current level
-            std::vector<uint32_t> depth_of(ns, 0);
-            uint32_t cur = 0;
-            for (uint32_t i = 1; i < ns; ++i) {
-                const uint32_t u = order[i];
-                depth_of[u] = depth_of[parent_[u]] + 1;
-                if (depth_of[u] != cur) { level_off.push_back(i); cur = depth_of[u]; }
-            }
-            level_off.push_back(ns);
-        }
+        // level d + 1 = the children of level d: it begins where level d ends and ends where the children of the first
+        // position behind level d begin
+        std::vector<uint32_t> level_off{0, 1};
+        while (level_off.back() < ns) level_off.push_back(cfirst[level_off.back()]);
         TrieView tv{ns, parent_.data(), in_byte_.data(), own_.data(), order.data(), level_off.data(), uint32_t(level_off.size() - 1),
                     map_keys_.data(), map_vals_.data(), map_keys_.size()};
-        done = accel->fail_and_outputs(accel->ctx, tv, fail.data(), is_final.data(), cnt.data(), dict.data());
+        done = accel->fail_and_outputs(accel->ctx, tv, fail_b.data(), final_b.data(), cnt_b.data(), dict_b.data());
         built_on_device_ = done;
         lap(done ? "failure links + outputs (device)" : "device build declined");
     }
     if (!done) {
-        for (uint32_t u : order) {
-            if (u == 0) continue;
-            const uint32_t p = parent_[u];
+        std::vector<uint32_t> pos(ns);
+        for (uint32_t i = 0; i < ns; ++i) pos[order[i]] = i;
+        for (uint32_t i = 1; i < ns; ++i) {
+            const uint32_t p = parent_pos[i];
             if (p == 0) continue;
-            const uint8_t b = in_byte_[u];
-            uint32_t f = fail[p];
+            const uint8_t b = byte_b[i];
+            uint32_t f = fail_b[p];
             for (;;) {
-                const uint32_t c = find_child(f, b);
-                if (c != kNone) { fail[u] = c; break; }
+                const uint32_t c = find_child(order[f], b);
+                if (c != kNone) { fail_b[i] = pos[c]; break; }
                 if (f == 0) break;
-                f = fail[f];
+                f = fail_b[f];
             }
         }
         lap("children CSR + failure links");
-        for (uint32_t u : order) {
-            if (u == 0) continue;
-            const uint32_t f = fail[u];
-            is_final[u] = (own_[u] != kNone) || is_final[f];
-            cnt[u] = (own_[u] != kNone ? 1u : 0u) + cnt[f];
-            dict[u] = own_[f] != kNone ? f : dict[f];
+        for (uint32_t i = 1; i < ns; ++i) {
+            const uint32_t f = fail_b[i];
+            const bool owns = own_[order[i]] != kNone;
+            final_b[i] = owns || final_b[f];
+            cnt_b[i] = (owns ? 1u : 0u) + cnt_b[f];
+            dict_b[i] = own_[order[f]] != kNone ? f : dict_b[f];
         }
     }
 
@@ -317,14 +360,7 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
     uint64_t max_rows = opt.lds_bytes > class_tab ? (opt.lds_bytes - class_tab) / row_bytes : 0;
     if (max_rows < 2) max_rows = 2;  // root + trap always fit (row <= 1 KiB)
     const uint32_t hot = uint32_t(std::min<uint64_t>(ns, max_rows - 1));
-    std::vector<uint32_t> newid(ns);
-    std::vector<uint8_t> depth(ns, 0);
-    uint32_t n_shallow1 = 0;  // states of trie depth <= 1
-    for (uint32_t i = 0; i < ns; ++i) {
-        const uint32_t u = order[i];
-        if (i) depth[u] = uint8_t(std::min<uint32_t>(depth[parent_[u]] + 1u, 255u));
-        n_shallow1 += depth[u] <= 1;
-    }
+    const uint32_t n_shallow1 = cfirst[1];  // states of trie depth <= 1: the root and its children, positions [0, cfirst[1])
     // Dense set = a prefix of the BFS order (closed under failure links, so that a row can be copied from the
     // failure state's): everything when not compact; else the LDS tile, trie depth <= 1 (the failure walk of a
     // compact state then always ends on a dense row after at most one record per level) and what the budget allows.
@@ -334,18 +370,44 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
         dense = uint32_t(std::min<uint64_t>(ns, std::max<uint64_t>(std::max<uint64_t>(hot, n_shallow1), by_budget)));
     }
     // Compact: cold non-final states with exactly one trie child (the inside of a long pattern) are numbered last
-    // among the cold non-final ones, in trie preorder: a chain s1 -> s2 -> ... has consecutive ids and its 8-byte
+    // among the cold non-final ones, chain by chain: a chain s1 -> s2 -> ... has consecutive ids and its 8-byte
     // records are read sequentially, 16 steps per 128-byte line.  Depth <= 2 keeps BFS numbering (the early stop
     // of candidate walks tests "non-final, depth <= 2" as an id range).
+    // One pass counts the classes, the shallow states (non-final states of trie depth <= 2 are a prefix of their id class
+    // -- ids follow BFS order within a class: [0, shallow_hot) and (trap, shallow_cold_end); the exact walk of an anchor
+    // candidate stops on them, see run_epilogue: no pattern begun at the candidate's window can still be alive there) and
+    // the events + tile exits per byte of uniform text over the used alphabet (see est_flag_rate).
     std::vector<uint8_t> in_chain(compact ? ns : 0, 0);
     uint32_t hot_nf = 0, cold_nf = 0, cold_chain = 0, dense_cold_nf = 0, dense_cold_f = 0;
-    for (uint32_t i = 0; i < ns; ++i) {
-        const uint32_t u = order[i];
-        if (!is_final[u]) {
-            (i < hot ? hot_nf : cold_nf)++;
-            if (compact && i >= dense && depth[u] >= 3 && child_off[u + 1] - child_off[u] == 1) { in_chain[u] = 1; ++cold_chain; }
+    {
+        uint32_t sh = 0, sc = 0;
+        uint64_t d1 = 0, d3 = 0;
+        std::vector<double> w(256, 0.0);
+        w[0] = 1.0;
+        for (int d = 1; d < 256; ++d) w[d] = w[d - 1] / double(std::max<uint32_t>(nused, 1));
+        double rate = 0;
+        for (uint32_t i = 0; i < ns; ++i) {
+            const bool fin = final_b[i] != 0;
+            const uint32_t d = depth[i];
+            if (!fin) {
+                (i < hot ? hot_nf : cold_nf)++;
+                if (compact && i >= dense && d >= 3 && cfirst[i + 1] - cfirst[i] == 1) { in_chain[i] = 1; ++cold_chain; }
+                if (d <= 2) (i < hot ? sh : sc)++;
+            }
+            if (i >= hot && i < dense) (fin ? dense_cold_f : dense_cold_nf)++;
+            d1 += d == 1;
+            d3 += d == 3;
+            if (i) {
+                if (fin) rate += w[d];
+                else if (i >= hot && parent_pos[i] < hot) rate += w[d];  // first cold state on its path
+            }
         }
-        if (i >= hot && i < dense) (is_final[u] ? dense_cold_f : dense_cold_nf)++;
+        fa.shallow_hot = sh;
+        fa.shallow_cold_end = hot + 1 + sc;
+        // When every 3-gram over the first-byte alphabet is a trie path (2048 x 16 B over 6 letters: 216 of 216)
+        // a walk on in-alphabet text never falls back to depth <= 2 and the test would only cost time.
+        fa.early_stop_useful = d3 < d1 * d1 * d1;
+        fa.est_flag_rate = rate;
     }
     fa.f1 = hot_nf;
     fa.trap = hot;
@@ -355,64 +417,33 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
     fa.n_dense_rows = compact ? fa.dense_nf_end + dense_cold_f : fa.n_states;
     const uint32_t chain_lo = fa.f2 - cold_chain;
     fa.chain_lo = chain_lo;
-    // Non-final states of trie depth <= 2 are a prefix of their id class (ids follow BFS order within a class):
-    // [0, shallow_hot) and (trap, shallow_cold_end).  The exact walk of an anchor candidate stops on them (see
-    // run_epilogue): no pattern begun at the candidate's window can still be alive there.
-    {
-        uint32_t sh = 0, sc = 0;
-        for (uint32_t i = 0; i < ns; ++i) {
-            const uint32_t u = order[i];
-            if (is_final[u] || depth[u] > 2) continue;
-            if (i < hot) ++sh; else ++sc;
-        }
-        fa.shallow_hot = sh;
-        fa.shallow_cold_end = hot + 1 + sc;
-        // When every 3-gram over the first-byte alphabet is a trie path (2048 x 16 B over 6 letters: 216 of 216)
-        // a walk on in-alphabet text never falls back to depth <= 2 and the test would only cost time.
-        uint64_t d1 = 0, d3 = 0;
-        for (uint32_t u = 1; u < ns; ++u) { d1 += depth[u] == 1; d3 += depth[u] == 3; }
-        fa.early_stop_useful = d3 < d1 * d1 * d1;
-        // events + tile exits per byte of uniform text over the used alphabet (see est_flag_rate)
-        std::vector<double> w(256, 0.0);
-        w[0] = 1.0;
-        for (int d = 1; d < 256; ++d) w[d] = w[d - 1] / double(std::max<uint32_t>(nused, 1));
-        std::vector<uint32_t> bfs_pos(ns);
-        for (uint32_t i = 0; i < ns; ++i) bfs_pos[order[i]] = i;
-        double rate = 0;
-        for (uint32_t i = 1; i < ns; ++i) {
-            const uint32_t u = order[i];
-            if (is_final[u]) rate += w[depth[u]];
-            else if (i >= hot && bfs_pos[parent_[u]] < hot) rate += w[depth[u]];  // first cold state on its path
-        }
-        fa.est_flag_rate = rate;
-    }
+    std::vector<uint32_t> newid(ns);   // by BFS position, ascending within each class
     {
         uint32_t a = 0, b = hot_nf, c = hot + 1, d = fa.f2;
         for (uint32_t i = 0; i < ns; ++i) {
-            const uint32_t u = order[i];
-            if (i < hot) newid[u] = is_final[u] ? b++ : a++;
-            else if (is_final[u]) newid[u] = d++;
-            else if (!compact || !in_chain[u]) newid[u] = c++;
+            if (i < hot) newid[i] = final_b[i] ? b++ : a++;
+            else if (final_b[i]) newid[i] = d++;
+            else if (!compact || !in_chain[i]) newid[i] = c++;
         }
     }
     if (cold_chain) {
+        // a chain is numbered from its head (the first of its states whose parent is not of this kind) along its only
+        // children; the heads in BFS order
         uint32_t c = chain_lo;
-        std::vector<uint32_t> stack{0};
-        while (!stack.empty()) {  // trie preorder; children pushed in reverse so they pop in byte order
-            const uint32_t u = stack.back();
-            stack.pop_back();
-            if (in_chain[u]) newid[u] = c++;
-            for (uint32_t e = child_off[u + 1]; e > child_off[u]; --e) stack.push_back(child_list[e - 1]);
+        for (uint32_t i = dense; i < ns; ++i) {
+            if (!in_chain[i] || in_chain[parent_pos[i]]) continue;
+            for (uint32_t j = i; j < ns && in_chain[j]; j = cfirst[j]) newid[j] = c++;
         }
     }
 
     lap("outputs, classes, numbering");
     // ---- tables ----------------------------------------------------------------------------------
     if (fa.entry_bytes == 2)
-        build_tables<uint16_t>(fa, order, dense, fail, newid, child_off, child_list, in_byte_);
+        build_tables<uint16_t>(fa, dense, fail_b, newid, cfirst, byte_b);
     else
-        build_tables<uint32_t>(fa, order, dense, fail, newid, child_off, child_list, in_byte_);
+        build_tables<uint32_t>(fa, dense, fail_b, newid, cfirst, byte_b);
 
+    lap("  tables");
     // ---- compact records of the states without a dense row ------------------------------------------
     fa.cold_rec.clear();
     fa.cold_edges.clear();
@@ -420,28 +451,24 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
         fa.cold_rec.assign(size_t(fa.n_states) * 2, 0u);
         std::vector<uint32_t> tmp;
         for (uint32_t i = dense; i < ns; ++i) {
-            const uint32_t u = order[i];
-            const uint32_t nk = child_off[u + 1] - child_off[u];
+            const uint32_t c0 = cfirst[i], nk = cfirst[i + 1] - c0;
             uint32_t x = 0, code = 0;
             if (nk == 1) {
-                const uint32_t v = child_list[child_off[u]];
-                x = (newid[v] << 8) | in_byte_[v];
+                x = (newid[c0] << 8) | byte_b[c0];
                 code = 1;
             } else if (nk >= 2) {
                 tmp.clear();
-                for (uint32_t e = child_off[u]; e < child_off[u + 1]; ++e) {
-                    const uint32_t v = child_list[e];
-                    tmp.push_back((newid[v] << 8) | in_byte_[v]);
-                }
+                for (uint32_t v = c0; v < c0 + nk; ++v) tmp.push_back((newid[v] << 8) | byte_b[v]);
                 std::sort(tmp.begin(), tmp.end(), [](uint32_t p, uint32_t q) { return (p & 0xffu) < (q & 0xffu); });
                 x = uint32_t(fa.cold_edges.size());
                 if (nk >= 255) { code = 255; fa.cold_edges.push_back(nk); } else code = nk;
                 fa.cold_edges.insert(fa.cold_edges.end(), tmp.begin(), tmp.end());
             }
-            fa.cold_rec[size_t(newid[u]) * 2] = x;
-            fa.cold_rec[size_t(newid[u]) * 2 + 1] = newid[fail[u]] | (code << 24);
+            fa.cold_rec[size_t(newid[i]) * 2] = x;
+            fa.cold_rec[size_t(newid[i]) * 2 + 1] = newid[fail_b[i]] | (code << 24);
         }
     }
+    lap("  cold records");
     fa.chain_byte.clear();
     fa.chain_run.clear();
     if (compact && cold_chain) {
@@ -458,13 +485,21 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
         }
     }
 
+    lap("  chain runs");
     fa.own_pattern.assign(fa.n_states, kNone);
     fa.dict_link.assign(fa.n_states, kNone);
     fa.out_count.assign(fa.n_states, 0);
-    for (uint32_t u = 0; u < ns; ++u) {
-        fa.own_pattern[newid[u]] = own_[u];
-        fa.dict_link[newid[u]] = dict[u] == kNone ? kNone : newid[dict[u]];
-        fa.out_count[newid[u]] = cnt[u];
+    // final state of every accepted pattern (the state whose own pattern it is)
+    std::vector<uint32_t> pattern_state(patterns_.size(), kNone);
+    for (uint32_t i = 0; i < ns; ++i) {
+        // (a state that is not final owns no pattern, has no dictionary link and no records: the defaults -- and most states of
+        // a large set are the insides of patterns, numbered chain by chain, i.e. all over the arrays in this order)
+        if (!final_b[i]) continue;
+        const uint32_t id = newid[i], own = own_[order[i]];
+        fa.own_pattern[id] = own;
+        fa.dict_link[id] = dict_b[i] == kNone ? kNone : newid[dict_b[i]];
+        fa.out_count[id] = cnt_b[i];
+        if (own != kNone) pattern_state[own] = id;
     }
     fa.pattern_length.resize(patterns_.size());
     fa.max_pattern_length = 0;
@@ -473,6 +508,7 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
         if (patterns_[i].accepted) fa.max_pattern_length = std::max(fa.max_pattern_length, patterns_[i].length);
     }
 
+    lap("  own/dict/count");
     // ---- flat output lists (matched[] of the reference's nodes) ------------------------------------
     fa.out_off.clear();
     fa.out_list.clear();
@@ -503,10 +539,6 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
     }
 
     lap("rows, records, output lists");
-    // final state of every accepted pattern (the state whose own pattern it is)
-    std::vector<uint32_t> pattern_state(patterns_.size(), kNone);
-    for (uint32_t u = 0; u < ns; ++u)
-        if (own_[u] != kNone) pattern_state[own_[u]] = newid[u];
 
     // ---- anchor filter table -------------------------------------------------------------------
     fa.min_pattern_length = 0;
@@ -573,9 +605,12 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
                     triples.push_back(t);
                 }
             }
-            std::sort(triples.begin(), triples.end(), [](const Triple &a, const Triple &b) {
+            lap("    triples");
+            // (by the first two words as one number, then everything: the order the whole comparison gives)
+            sort_by_u64(triples, [](const Triple &t) { return uint64_t(t.key[0]) << 32 | t.key[1]; }, [](const Triple &a, const Triple &b) {
                 return a.key != b.key ? a.key < b.key : (a.pattern != b.pattern ? a.pattern < b.pattern : a.offset < b.offset);
             });
+            lap("    sort");
             keys.clear();
             key_first.clear();
             key_trip.clear();
@@ -599,7 +634,7 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
             all.reserve(key_trip.size());
             for (size_t ki = 0; ki < keys.size(); ++ki)
                 for (uint32_t t = key_first[ki]; t < key_first[ki + 1]; ++t) all.push_back({slot_of_key[ki], key_trip[t].first, key_trip[t].second});
-            std::sort(all.begin(), all.end(), [](const Entry &a, const Entry &b) {
+            sort_by_u64(all, [](const Entry &e) { return uint64_t(e.slot) << 32 | e.pattern; }, [](const Entry &a, const Entry &b) {
                 return a.slot != b.slot ? a.slot < b.slot : (a.pattern != b.pattern ? a.pattern < b.pattern : a.offset < b.offset);
             });
             fa.anchor_slot_pair.assign(n_slots, kNone);
@@ -620,7 +655,31 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
             }
             fa.anchor_pairs_count = fa.anchor_pairs.size() / 4;
         };
-        build_keys();
+        // A set that is certainly a big one (more distinct first windows than the LDS table takes) gets its keys after the
+        // window choice below: listing them here as well -- a sort of every (pattern, class) triple -- only told that much.
+        bool big_known = false;
+        if (!every_offset && opt.anchor_choice != 0 && accepted_ * 4 > kAnchorMaxKeys) {
+            // distinct 64-bit hashes of the windows in a flat open-addressing set, until there are too many for the LDS table
+            // (a collision could only make the count smaller: then the keys are listed after all)
+            size_t cap = 1024, distinct = 0;
+            while (cap < size_t(kAnchorMaxKeys) * 4) cap *= 2;
+            std::vector<uint64_t> seen(cap, 0);
+            for (size_t pi = 0; pi < patterns_.size() && distinct <= kAnchorMaxKeys; ++pi) {
+                const PatternMeta &m = patterns_[pi];
+                if (!m.accepted) continue;
+                for (uint32_t a = 0; a < 4; ++a) {
+                    uint64_t w[2] = {0, 0};
+                    std::memcpy(w, pattern_bytes_.data() + m.byte_off + a, q);
+                    uint64_t h = mix(w[0] ^ mix(w[1] + 0x632BE59BD9B4E019ull));
+                    h += h == 0;
+                    size_t at = size_t(h >> 7) & (cap - 1);
+                    while (seen[at] != 0 && seen[at] != h) at = (at + 1) & (cap - 1);
+                    if (seen[at] == 0) { seen[at] = h; ++distinct; }
+                }
+            }
+            big_known = distinct > kAnchorMaxKeys;
+        }
+        if (!big_known) build_keys();
         lap("anchor keys");
         // Big sets: WHICH aligned window of a pattern is its anchor is free -- an occurrence whose first aligned text
         // dword lies a bytes into the pattern contains the windows at a, a+4, a+8, ... -- and the LDS bitmap passes a
@@ -634,6 +693,10 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
             std::vector<uint32_t> pair_begin{0}, cand_bit;
             std::vector<uint8_t> cand_off;
             std::vector<uint32_t> pair_id;  // pattern * 4 + class
+            cand_bit.reserve(pattern_bytes_.size());   // (a pattern has at most one candidate per byte over its four classes)
+            cand_off.reserve(pattern_bytes_.size());
+            pair_begin.reserve(accepted_ * 4 + 1);
+            pair_id.reserve(accepted_ * 4);
             for (size_t pi = 0; pi < patterns_.size(); ++pi) {
                 const PatternMeta &m = patterns_[pi];
                 if (!m.accepted) continue;
@@ -648,6 +711,7 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
                     pair_id.push_back(uint32_t(pi * 4 + a));
                 }
             }
+            lap("    candidates");
             const uint32_t n_pairs = uint32_t(pair_id.size());
             // bit -> the pairs it is a candidate of (CSR)
             std::vector<uint32_t> bit_off(kBits + 1, 0), bit_pairs(cand_bit.size());
@@ -658,6 +722,7 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
                 for (uint32_t pr = 0; pr < n_pairs; ++pr)
                     for (uint32_t c = pair_begin[pr]; c < pair_begin[pr + 1]; ++c) bit_pairs[cur[cand_bit[c]]++] = pr;
             }
+            lap("    bit CSR");
             // Lazy greedy: bits queued by the number of uncovered pairs they would cover when last counted, taken from the
             // largest count down; a bit whose count has dropped meanwhile moves to the queue of its fresh count (always
             // a lower one, visited later).  Counts are small (2.1 candidates per bit on average), so the queues are
@@ -680,6 +745,7 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
                 }
                 std::vector<uint32_t>().swap(queue[c]);
             }
+            lap("    greedy");
             for (uint32_t pr = 0; pr < n_pairs; ++pr)
                 for (uint32_t c = pair_begin[pr]; c < pair_begin[pr + 1]; ++c)
                     if (bit_chosen[cand_bit[c]]) { fa.anchor_offsets[pair_id[pr]] = cand_off[c]; break; }
@@ -688,7 +754,7 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
         uint32_t mul = 0x9E3779B1u;
         // (every_offset: the window is hashed raw, see anchor_hash_dense)
         auto key_hash = [&](const std::array<uint32_t, 4> &k, uint32_t mul_) { return every_offset ? anchor_hash_dense(k[0], mul_) : anchor_hash(k.data(), q / 4, mul_); };
-        if (keys.size() <= kAnchorMaxKeys) {
+        if (!big_known && keys.size() <= kAnchorMaxKeys) {
             // 4 slots per bucket; the dense form tries 2 first when its keys are few (a bucket of two overflows sooner:
             // 2,048 keys in 2^15 buckets find a seed in a few attempts, 4,096 never do)
             fa.anchor_slots = 4;
@@ -735,10 +801,9 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
             }
         } else {
             // mode 2: as many 8-slot buckets as q-grams (load 1: a bucket overflows with probability 1e-6)
-            uint32_t bits = 15;
-            while ((size_t(1) << bits) < keys.size() && bits < kAnchorMaxBucketBits) ++bits;
-            if ((size_t(1) << bits) >= keys.size()) {
-                const uint32_t nb = 1u << bits;
+            // (the table is sized by the keys of the first attempt -- listed above, or below once the windows are chosen)
+            uint32_t bits = 0, nb = 0;
+            {
                 std::vector<uint16_t> tab;
                 std::vector<uint8_t> used;
                 // A bucket overflows with probability ~ 1e-6 (load 1 of 8): 0.3 per seed for 262,144 buckets.  The first
@@ -756,6 +821,12 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
                             fa.anchor_choice = 1;
                             lap("anchor keys again");
                         }
+                    }
+                    if (attempt == 0) {
+                        bits = 15;
+                        while ((size_t(1) << bits) < keys.size() && bits < kAnchorMaxBucketBits) ++bits;
+                        if ((size_t(1) << bits) < keys.size()) break;   // more q-grams than the largest table takes: no filter
+                        nb = 1u << bits;
                     }
                     tab.assign(size_t(nb) * 8, uint16_t(0));
                     used.assign(nb, 0);

@@ -67,7 +67,9 @@ struct TrieView {
 };
 struct BuildAccel {
     void *ctx = nullptr;
-    // fills fail / is_final / cnt / dict (all n_nodes entries); false: not done, the host computes them
+    // fills fail / is_final / cnt / dict (all n_nodes entries, indexed by BFS POSITION -- entry i belongs to node order[i] --
+    // and fail / dict naming their targets by position too, dict kNone when there is none); false: not done, the host
+    // computes them
     bool (*fail_and_outputs)(void *ctx, const TrieView &tv, uint32_t *fail, uint8_t *is_final, uint32_t *cnt, uint32_t *dict) = nullptr;
 };
 

@@ -287,14 +287,15 @@ bool device_fail_and_outputs(void *ctx, const TrieView &tv, uint32_t *fail, uint
     hipStream_t st = restore.st;
     lap("runtime + device");
     const size_t n = tv.n_nodes;
-    DevBuf d_parent, d_byte, d_own, d_order, d_keys, d_vals, d_fail, d_cnt, d_dict, d_final;
+    DevBuf d_parent, d_byte, d_own, d_order, d_keys, d_vals, d_fail, d_cnt, d_dict, d_final, d_pos, d_fail_b, d_cnt_b, d_dict_b, d_final_b;
     auto up = [&](DevBuf &b, const void *src, size_t bytes) {
         return b.ensure(bytes) == hipSuccess && copy_h2d(b.p, src, bytes) == hipSuccess;
     };
     bool ok = up(d_parent, tv.parent, n * 4) && up(d_byte, tv.in_byte, n) && up(d_own, tv.own, n * 4) && up(d_order, tv.order, n * 4) &&
               up(d_keys, tv.map_keys, tv.map_size * 8) && up(d_vals, tv.map_vals, tv.map_size * 4) &&
               d_fail.ensure(n * 4) == hipSuccess && d_cnt.ensure(n * 4) == hipSuccess && d_dict.ensure(n * 4) == hipSuccess &&
-              d_final.ensure(n) == hipSuccess;
+              d_final.ensure(n) == hipSuccess && d_pos.ensure(n * 4) == hipSuccess && d_fail_b.ensure(n * 4) == hipSuccess &&
+              d_cnt_b.ensure(n * 4) == hipSuccess && d_dict_b.ensure(n * 4) == hipSuccess && d_final_b.ensure(n) == hipSuccess;
     if (ok) {
         // the root: no failure link, no output (the level loop starts at depth 1 and reads these)
         ok = hipMemsetAsync(d_fail.p, 0, 4, st) == hipSuccess && hipMemsetAsync(d_cnt.p, 0, 4, st) == hipSuccess &&
@@ -305,16 +306,19 @@ bool device_fail_and_outputs(void *ctx, const TrieView &tv, uint32_t *fail, uint
         BuildArgs T{d_parent.as<uint32_t>(), d_byte.as<uint8_t>(), d_own.as<uint32_t>(), d_order.as<uint32_t>(), d_keys.as<uint64_t>(),
                     d_vals.as<uint32_t>(), tv.map_size, d_fail.as<uint32_t>(), d_cnt.as<uint32_t>(), d_dict.as<uint32_t>(), d_final.as<uint8_t>()};
         for (uint32_t d = 1; d < tv.n_levels; ++d) launch_build_level(T, tv.level_off[d], tv.level_off[d + 1], st);
+        // results by BFS position, links as positions (what the host goes on with)
+        launch_build_by_position(T, uint32_t(n), d_pos.as<uint32_t>(), d_fail_b.as<uint32_t>(), d_cnt_b.as<uint32_t>(), d_dict_b.as<uint32_t>(),
+                                 d_final_b.as<uint8_t>(), st);
         ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
         lap("level kernels");
-        ok = ok && hipMemcpy(fail, d_fail.p, n * 4, hipMemcpyDeviceToHost) == hipSuccess &&
-             hipMemcpy(cnt, d_cnt.p, n * 4, hipMemcpyDeviceToHost) == hipSuccess &&
-             hipMemcpy(dict, d_dict.p, n * 4, hipMemcpyDeviceToHost) == hipSuccess &&
-             hipMemcpy(is_final, d_final.p, n, hipMemcpyDeviceToHost) == hipSuccess;
+        ok = ok && hipMemcpy(fail, d_fail_b.p, n * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+             hipMemcpy(cnt, d_cnt_b.p, n * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+             hipMemcpy(dict, d_dict_b.p, n * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+             hipMemcpy(is_final, d_final_b.p, n, hipMemcpyDeviceToHost) == hipSuccess;
     }
     if (!ok) (void)hipGetLastError();
     lap("download");
-    for (DevBuf *b : {&d_parent, &d_byte, &d_own, &d_order, &d_keys, &d_vals, &d_fail, &d_cnt, &d_dict, &d_final}) b->release();
+    for (DevBuf *b : {&d_parent, &d_byte, &d_own, &d_order, &d_keys, &d_vals, &d_fail, &d_cnt, &d_dict, &d_final, &d_pos, &d_fail_b, &d_cnt_b, &d_dict_b, &d_final_b}) b->release();
     lap("release");
     return ok;
 }

@@ -3181,6 +3181,32 @@ void launch_build_level(const BuildArgs &T, uint32_t lo, uint32_t hi, hipStream_
     if (hi > lo) hipLaunchKernelGGL(k_build_level, dim3((hi - lo + 255) / 256), dim3(256), 0, st, T, lo, hi);
 }
 
+// The host continues in BFS positions (automaton.cpp finalize: its passes then stream): the results are handed back indexed
+// by position, links as positions.
+__global__ void k_build_positions(const uint32_t *order, uint32_t n, uint32_t *pos) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) pos[order[i]] = i;
+}
+
+__global__ void k_build_by_position(BuildArgs T, uint32_t n, const uint32_t *pos, uint32_t *fail_b, uint32_t *cnt_b, uint32_t *dict_b,
+                                    uint8_t *final_b) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t u = T.order[i];
+    fail_b[i] = pos[T.fail[u]];
+    cnt_b[i] = T.cnt[u];
+    const uint32_t d = T.dict[u];
+    dict_b[i] = d == 0xFFFFFFFFu ? d : pos[d];
+    final_b[i] = T.is_final[u];
+}
+
+void launch_build_by_position(const BuildArgs &T, uint32_t n, uint32_t *pos, uint32_t *fail_b, uint32_t *cnt_b, uint32_t *dict_b,
+                              uint8_t *final_b, hipStream_t st) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_build_positions, dim3((n + 255) / 256), dim3(256), 0, st, T.order, n, pos);
+    hipLaunchKernelGGL(k_build_by_position, dim3((n + 255) / 256), dim3(256), 0, st, T, n, pos, fail_b, cnt_b, dict_b, final_b);
+}
+
 // ------------------------------------------------------------------------------------------
 // Search and replace: multifast_replace + multifast_rep_flush(keep=0) (reference src/multifast/replace.c:469-568) as a
 // post-pass over the match records of a batch.

@@ -34,6 +34,8 @@ hipError_t launch_match_small(const DevAutomaton &A, const uint64_t *offsets, co
                               uint32_t max_pattern_length, int entry_bytes, int class_mode, uint64_t *out_summary,
                               uint64_t *out_prefix, void *out_records, uint32_t cap, hipStream_t st);
 void launch_build_level(const BuildArgs &T, uint32_t lo, uint32_t hi, hipStream_t st);
+void launch_build_by_position(const BuildArgs &T, uint32_t n, uint32_t *pos, uint32_t *fail_b, uint32_t *cnt_b, uint32_t *dict_b,
+                              uint8_t *final_b, hipStream_t st);
 void launch_replace_plan(const ReplaceArgs &R, hipStream_t st);
 void launch_replace_emit(const ReplaceArgs &R, uint64_t cap, hipStream_t st);
 // exclusive scan of n 64-bit values into out[0..n]; sync = {ticket, pad, scan_tiles(n + 1) status words}, zeroed; total_host (mapped, may be null) receives out[n]
