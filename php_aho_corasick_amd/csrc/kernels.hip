@@ -1810,7 +1810,59 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
             // of the shortest length would end inside it -- counts them, a wave prefix sum gives each its index in the
             // item's run list, and the lanes write their own entries into the LDS stage (flushed to the run lists in bulk).
             // Runs are not clamped against each other: [start + m_min - 1, start + Lmax) each, possibly overlapping.
-            if (__any(zany != 0)) {
+            bool by_row = __any(zany != 0);
+            bool tiny_rows_now = false;
+            if constexpr (TINY) tiny_rows_now = tiny_on;
+            if (by_row && !tiny_rows_now) {
+                // One item per task (the usual case): the hits of all eight rows are placed with THREE wave prefix sums -- the
+                // lanes' hit counts of the task, then the per-row counts packed four to a word (a task of at most 255 hits
+                // cannot carry between the bytes) -- instead of one per row, and the masks for windows that stick out of the
+                // item run for its first row and its last two quads only: per row this part cost as much as two of its four
+                // probe steps.
+                if (nrun > B.run_cap) return;   // the item is walked whole anyway
+                const uint32_t qi0 = sc.c * TQ + lane, pos00 = sc.head + (qi0 << 4);   // row r: + 64 r quads, + 1024 r bytes
+                uint32_t pk_lo = 0, pk_hi = 0;
+#pragma unroll
+                for (int r = 0; r < G; ++r) {
+                    uint32_t zr = qi0 + 64u * uint32_t(r) < sc.nq ? z[r] : 0u;
+                    const uint32_t row_first = sc.c * TQ + 64u * uint32_t(r);   // (wave-uniform)
+                    if (row_first == 0u || row_first + 65u >= sc.nq) {
+                        const uint32_t pos0 = pos00 + 1024u * uint32_t(r);
+                        if (pos0 < 3u) zr &= ~((1u << (3u - pos0)) - 1u);   // start = pos0 + e - 3 >= 0
+                        const int32_t emax = int32_t(sc.n + 3u) - int32_t(m_min) - int32_t(pos0);   // start + m_min <= n
+                        if (emax < 15) zr = emax < 0 ? 0u : (zr & ((2u << emax) - 1u));
+                    }
+                    z[r] = zr;
+                    const uint32_t c = uint32_t(__builtin_popcount(zr));
+                    if (r < 4) pk_lo |= c << (8 * r); else pk_hi |= c << (8 * (r - 4));
+                }
+                const uint32_t mine = ((pk_lo * 0x01010101u) >> 24) + ((pk_hi * 0x01010101u) >> 24);
+                const uint32_t T = __builtin_amdgcn_readlane(wave_inclusive_sum(mine), 63);
+                if (T == 0u) return;
+                if (T <= 255u) {
+                    if (nrun + T > B.run_cap) { nrun = B.run_cap + 1u; return; }   // more windows than the run list holds: the item is walked
+                    if (stage.count + T > kDenseStage) dense_flush(B, wave_first, stage, lane);
+                    const uint32_t in_lo = wave_inclusive_sum(pk_lo), in_hi = wave_inclusive_sum(pk_hi);
+                    const uint32_t tot_lo = __builtin_amdgcn_readlane(in_lo, 63), tot_hi = __builtin_amdgcn_readlane(in_hi, 63);
+                    uint2 *slots2 = reinterpret_cast<uint2 *>(stage.slots);
+                    uint32_t rowbase = 0;   // hits of the rows before this one (wave-uniform)
+#pragma unroll
+                    for (int r = 0; r < G; ++r) {
+                        const uint32_t sh = 8u * uint32_t(r & 3);
+                        const uint32_t cnt = ((r < 4 ? pk_lo : pk_hi) >> sh) & 0xffu, incl = ((r < 4 ? in_lo : in_hi) >> sh) & 0xffu;
+                        uint32_t at = stage.count + rowbase + incl - cnt, idx = nrun + rowbase + incl - cnt;
+                        const uint32_t pos0 = pos00 + 1024u * uint32_t(r);
+                        for (uint32_t m = z[r]; m != 0; m &= m - 1, ++at, ++idx)
+                            slots2[at] = make_uint2(sc.k | (idx << 8), pos0 + uint32_t(__builtin_ctz(m)) - 3u);
+                        rowbase += ((r < 4 ? tot_lo : tot_hi) >> sh) & 0xffu;
+                    }
+                    stage.count += T;
+                    nrun += T;
+                    return;
+                }
+                // (more than 255 hits in one task: row by row below, with the masks applied already)
+            }
+            if (by_row) {
 #pragma unroll
                 for (int r = 0; r < G; ++r) {
                     if (__ballot(z[r] != 0) == 0) continue;
