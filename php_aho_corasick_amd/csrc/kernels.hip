@@ -3273,10 +3273,11 @@ void launch_build_by_position(const BuildArgs &T, uint32_t n, uint32_t *pos, uin
 //   k_replace_plan  one thread per haystack: nominees from its records, the booking rule, where in the haystack's output
 //                   every kept nominee's piece (gap + replacement) begins, the output length;
 //   k_scan_u64      exclusive scan of the output lengths -> output offsets, on the device (single pass, look-back);
-//   k_replace_emit  the copy, cut by OUTPUT bytes, not by haystack: a wave takes 32 KiB of the output blob at a time,
-//                   finds the haystack and the piece its range begins in by binary search and copies pieces -- 16 bytes
-//                   per lane, stores aligned -- until the range is full.  One huge haystack (the README's "one big file")
-//                   is spread over the whole chip, thousands of tiny ones do not get a wave each.
+//   k_replace_emit  the copy, cut by OUTPUT bytes, not by haystack: every wave takes one contiguous share of the output blob
+//                   (a multiple of 32 KiB), finds the haystack and the piece its share begins in by binary search and copies
+//                   pieces -- 16 bytes per lane, four loads in flight, stores aligned -- until the share is full.  One huge
+//                   haystack (the README's "one big file") is spread over the whole chip, thousands of tiny ones do not
+//                   get a wave each.
 // ------------------------------------------------------------------------------------------
 __global__ void k_replace_plan(ReplaceArgs R) {
     const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3365,21 +3366,34 @@ __device__ __forceinline__ void wave_copy(uint8_t *dst, const uint8_t *src, uint
     const uint64_t body = (n - head) >> 4;
     uint4 *d16 = reinterpret_cast<uint4 *>(dst + head);
     const uint8_t *s = src + head;
-    for (uint64_t i = lane; i < body; i += 64u) d16[i] = load16u(s + (i << 4));
+    // four loads in flight per lane (4 KiB per wave and step): one at a time, every 1 KiB step waited for its own round trip
+    uint64_t i = lane;
+    for (; i + 192u < body; i += 256u) {
+        const uint4 v0 = load16u(s + (i << 4)), v1 = load16u(s + ((i + 64u) << 4)), v2 = load16u(s + ((i + 128u) << 4)),
+                    v3 = load16u(s + ((i + 192u) << 4));
+        d16[i] = v0;
+        d16[i + 64u] = v1;
+        d16[i + 128u] = v2;
+        d16[i + 192u] = v3;
+    }
+    for (; i < body; i += 64u) d16[i] = load16u(s + (i << 4));
     const uint64_t done = head + (body << 4);
     if (done + lane < n) dst[done + lane] = src[done + lane];
 }
 
-constexpr uint64_t kEmitRange = 32u * 1024u;   // output bytes a wave takes at a time
+constexpr uint64_t kEmitRange = 32u * 1024u;   // a wave's share of the output is a multiple of this
 
 __global__ __launch_bounds__(256) void k_replace_emit(ReplaceArgs R, uint64_t cap) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t waves = uint64_t(gridDim.x) * (blockDim.x / 64u);
     const uint64_t total = R.out_off[R.n_haystacks];
     if (total > cap) return;   // the optimistic output buffer is too small: the host grows it and launches again
-    for (uint64_t g = uint64_t(blockIdx.x) * (blockDim.x / 64u) + (threadIdx.x >> 6); g * kEmitRange < total; g += waves) {
-        uint64_t a = g * kEmitRange;
-        const uint64_t b = a + kEmitRange < total ? a + kEmitRange : total;
+    // a wave's ranges are consecutive -- one binary search for its first byte, the haystacks behind it in order (strided over
+    // the output, every 32 KiB began with 17 dependent loads: as long as the copy itself)
+    const uint64_t per_wave = ((total + kEmitRange - 1) / kEmitRange + waves - 1) / waves * kEmitRange;
+    for (uint64_t g = uint64_t(blockIdx.x) * (blockDim.x / 64u) + (threadIdx.x >> 6); g < waves && g * per_wave < total; g += waves) {
+        uint64_t a = g * per_wave;
+        const uint64_t b = a + per_wave < total ? a + per_wave : total;
         // the haystack whose output holds byte a: the LAST h with out_off[h] <= a (haystacks with empty outputs share an offset)
         uint64_t lo = 0, hi = R.n_haystacks;
         while (hi - lo > 1) {
