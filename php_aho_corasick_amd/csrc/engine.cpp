@@ -843,6 +843,7 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     }
     B.persistent = h->persistent >= 0 ? uint32_t(h->persistent != 0)
                                       : uint32_t(blob_bytes / chunk > 3ull * 256 * 1024 * uint64_t(h->ilp));
+    B.wave_grab = 1u;
     if (h->persistent < 0 && (kernel == 1 || kernel == 2)) {
         // A static split gives a workgroup 16 x wave_items items (anchor kernel) or 1,024 x ILP (tile walk), and a CU runs
         // one workgroup at a time: fine when the workgroups are a multiple of the 256 CUs (the headline batch: 512, and
@@ -856,6 +857,16 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
         const uint64_t items = nh * ((hay_len + chunk - 1) / chunk);
         const uint64_t groups = (items + per_group - 1) / per_group;
         if (blob_bytes % nh != 0 || (groups > 256 && groups % 256 != 0)) B.persistent = 1u;
+    }
+    if (B.persistent) {
+        // Every batch a wave pulls is one device atomic on ONE word, and the chip retires those at ~ 12 ns each whoever issues
+        // them: 4 GiB of 256-byte haystacks are 262,144 wave batches = 3.1 ms of atomics under a kernel that needs 0.5 (the same
+        // went for the statistic every tiny batch used to add to: both found as "a wave batch costs 50 us whatever it holds").
+        // A wave therefore takes up to 16 batches per atomic, so that a launch has ~ 16,384 of them at most.
+        const uint64_t est = std::max<uint64_t>(1, std::max<uint64_t>(blob_bytes / chunk, nh));
+        const uint64_t per_batch = kernel == 2 ? B.wave_items : 64ull * uint64_t(std::max(1, h->ilp));
+        const uint64_t batches = (est + per_batch - 1) / per_batch;
+        B.wave_grab = uint32_t(std::min<uint64_t>(16, std::max<uint64_t>(1, (batches + 16383) / 16384)));
     }
 
     // item counts, their scan, the item table, zeroed per-item counters: one launch

@@ -915,7 +915,8 @@ __device__ __forceinline__ void emit_verified(const BatchArgs &B, uint64_t item,
 // that stands for more than 8 pairs, or with more than kClusterMax occurrences are walked as one range.
 template <typename E, int MODE, bool EXTRA>
 __device__ __forceinline__ uint32_t run_epilogue_fast(const DevAutomaton &A, const BatchArgs &B, const uint8_t *tile,
-                                                      uint32_t tile_rows, uint64_t item, const ItemDesc &it, uint32_t nr) {
+                                                      uint32_t tile_rows, uint64_t item, const ItemDesc &it, uint32_t nr,
+                                                      uint32_t &fallback16) {
     const uint8_t *p = B.blob + (it.begin - it.warm);
     const uint32_t n = it.warm + it.len;
     const uint32_t pos_bias = it.pos0 - it.warm + 1u;
@@ -924,7 +925,8 @@ __device__ __forceinline__ uint32_t run_epilogue_fast(const DevAutomaton &A, con
     if (nr > B.run_cap) {
         walked = n;
         exact_range<E, MODE, EXTRA>(A, B, nullptr, tile, tile_rows, item, p, it.floor, n, it.warm, pos_bias, 0u, ev);
-        atomicAdd(&B.counters[7], (n + 15u) >> 4);  // statistic: walked through the automaton, not decided by a text compare
+        fallback16 += (n + 15u) >> 4;  // statistic: walked through the automaton, not decided by a text compare (summed per workgroup:
+                                       // an atomic per cluster on one word serialises the launch at ~ 12 ns each)
     } else {
         const uint4 *runs = B.runs + item;
         uint32_t r = 0;
@@ -975,7 +977,7 @@ __device__ __forceinline__ uint32_t run_epilogue_fast(const DevAutomaton &A, con
             }
             if (from < it.floor) from = it.floor;  // (the bytes below are another haystack's)
             walk_fast<E, MODE, EXTRA>(A, B, tile, tile_rows, item, p, from, hi, n, rep_from, pos_bias, st, ev, stop_from);
-            atomicAdd(&B.counters[7], (hi - from + 15u) >> 4);  // statistic: bytes walked because verification could not decide
+            fallback16 += (hi - from + 15u) >> 4;  // statistic: bytes walked because verification could not decide
         }
     }
     if (ev.n_ev) {
@@ -1065,11 +1067,19 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchA
     // 64 x ILP consecutive work items from a global counter until none are left.  Waves drift out
     // of phase, so while one wave sits in its latency-bound exact epilogue the other 15 keep the
     // LDS and HBM busy, and the tail of the launch is one wave-batch, not one workgroup.
+    uint32_t grab_next = 0, grab_left = 0;   // persistent mode: the batches taken with one atomic (BatchArgs::wave_grab)
+    uint32_t walked_all = 0;                 // this lane's exactly-walked bytes over all its batches
     for (;;) {
     uint32_t batch_first = (blockIdx.x * (kLdsThreads / 64u) + (threadIdx.x >> 6)) * (64u * ILP);  // static split
     if (B.persistent) {
-        if ((threadIdx.x & 63u) == 0) batch_first = atomicAdd(&B.counters[1], 64u * ILP);
-        batch_first = __builtin_amdgcn_readfirstlane(batch_first);
+        if (grab_left == 0) {
+            if ((threadIdx.x & 63u) == 0) grab_next = atomicAdd(&B.counters[1], 64u * ILP * B.wave_grab);
+            grab_next = __builtin_amdgcn_readfirstlane(grab_next);
+            grab_left = B.wave_grab;
+        }
+        batch_first = grab_next;
+        grab_next += 64u * ILP;
+        --grab_left;
     }
     if (batch_first >= total_items) break;
     const uint64_t item0 = uint64_t(batch_first) + uint64_t(threadIdx.x & 63u) * ILP;
@@ -1227,9 +1237,10 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchA
                                             item0 + k, it, nrun[k]);
         }
     }
-    account_walked(B, walked);
+    walked_all += walked;
     if (!B.persistent) break;
     }  // next batch of this wave
+    account_walked(B, walked_all);   // (once per wave, not per batch: same-address device atomics retire at ~ 12 ns each)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1363,14 +1374,21 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     const uint32_t lo_bias = DENSE ? m_min - 1u : (A.anchor_choice ? q - 1u : m_min - 4u);
     const uint64_t total_items = B.item_base[B.n_haystacks];
 
-    // Persistent mode: waves pull batches of items from counters[1] until none are left.
+    // Persistent mode: waves pull batches of items from counters[1] until none are left, wave_grab batches per atomic.
+    uint32_t grab_next = 0, grab_left = 0, tiny_batches = 0;
     for (;;) {
     // a wave takes `wave_items` (1..64) consecutive items per batch: 64 for big batches, fewer when
     // there are not enough items to give every wave of the chip 64 of them
     uint32_t batch_first = (blockIdx.x * (kLdsThreads / 64u) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * B.wave_items;
     if (B.persistent) {
-        if (lane == 0) batch_first = atomicAdd(&B.counters[1], B.wave_items);
-        batch_first = __builtin_amdgcn_readfirstlane(batch_first);
+        if (grab_left == 0) {
+            if (lane == 0) grab_next = atomicAdd(&B.counters[1], B.wave_items * B.wave_grab);
+            grab_next = __builtin_amdgcn_readfirstlane(grab_next);
+            grab_left = B.wave_grab;
+        }
+        batch_first = grab_next;
+        grab_next += B.wave_items;
+        --grab_left;
     }
     if (batch_first >= total_items) break;
     const uint64_t wave_first = batch_first;
@@ -1387,7 +1405,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
         const bool fits = rec.z == 0u || (((reinterpret_cast<uintptr_t>(B.blob) + rec.x) & 15u) == 0u && rec.z <= 1024u);
         tiny_on = B.align_warm == 1u && __all(fits);
         tcnt = uint32_t(__builtin_popcountll(__ballot(rec.z != 0u)));
-        if (tiny_on && lane == 0) atomicAdd(&B.counters[18], 1u);  // statistic ("tiny_waves"): which path the batch's waves took
+        tiny_batches += tiny_on ? 1u : 0u;  // statistic ("tiny_waves"): which path the batch's waves took -- summed up at the kernel's end
         // items of a quarter / half row at most (haystacks of <= 256 / 512 B) are packed FOUR / TWO to a row: lane l of row r holds
         // quad l mod 16 (32) of item (8 t + r) * 4 (2) + l / 16 (32) -- else three lanes in four of a 256-byte item's row idle
         if (!BIG && !DENSE && tiny_on) {
@@ -1665,15 +1683,16 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                     // two slots: the subtract's result is the whole test.  HOT: exact per window, every step; else a running
                     // minimum with the exact test behind a branch
                     if constexpr (HOT) {
-                        uint32_t dd = 0;
+                        // (written as plain compares hipcc emits two v_cmp_eq_u32_sdwa per window -- halfword operands, the verdict in a
+                        // scalar register pair -- an s_or and a v_cndmask: 14 VALU + 4 SALU per step against 19 VALU for the packed
+                        // subtract and zero-halfword test; filter 0.442 -> 0.431 ms per GiB of the keyword set)
+                        uint32_t m = 0;
 #pragma unroll
                         for (int w = 0; w < 4; ++w) {
-                            uint32_t x;
-                            asm("v_pk_sub_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(x) : "v"(b4[w].x), "v"(h4[w]));
-                            const uint32_t d = (x - 0x00010001u) & ~x;
-                            dd |= (d >> (3 - w)) & (0x80008000u >> (3 - w));
+                            const uint32_t fp = h4[w] >> 16;
+                            const bool hit = ((b4[w].x & 0xffffu) == fp) | ((b4[w].x >> 16) == fp);
+                            m |= hit ? (1u << w) : 0u;
                         }
-                        const uint32_t m = __builtin_amdgcn_ubfe(dd | (dd >> 16), 12u, 4u);
                         z[(t - 1) >> 2] |= m << (4 * ((t - 1) & 3));
                         zany |= m;
                     } else {
@@ -2056,6 +2075,18 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     if (rec.z != 0) B.run_count[wave_first + lane] = nrun_vec;
     if (!B.persistent) break;
     }  // next batch of this wave
+    if constexpr (TINY) {
+        // one device atomic per WORKGROUP (through the waves' own LDS regions, free by now): one per batch on a single word
+        // was the longest thing in the launch (see wave_grab)
+        uint32_t *mine = reinterpret_cast<uint32_t *>(smem + kAnchorLdsBytes + (threadIdx.x >> 6) * 2048u);
+        if (lane == 0) *mine = tiny_batches;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t sum = 0;
+            for (uint32_t w = 0; w < kLdsThreads / 64u; ++w) sum += *reinterpret_cast<const uint32_t *>(smem + kAnchorLdsBytes + w * 2048u);
+            if (sum) atomicAdd(&B.counters[18], sum);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2080,8 +2111,8 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_runs(DevAutomaton A, Batc
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint64_t total_items = B.item_base[B.n_haystacks];
     if (uint64_t(blockIdx.x) * kWalkThreads >= total_items) return;
-    __shared__ uint32_t s_walked, s_done;
-    if (threadIdx.x == 0) { s_walked = 0; s_done = 0; }
+    __shared__ uint32_t s_walked, s_done, s_fallback;
+    if (threadIdx.x == 0) { s_walked = 0; s_done = 0; s_fallback = 0; }
     const uint64_t item = uint64_t(blockIdx.x) * kWalkThreads + threadIdx.x;
     // issue the item's own loads first: they are in flight while the tile is staged
     uint32_t nr = 0;
@@ -2108,11 +2139,11 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_runs(DevAutomaton A, Batc
         }
     }
     __syncthreads();
-    uint32_t walked = 0;
+    uint32_t walked = 0, fallback16 = 0;
     if (nr != 0) {
         ItemDesc it;
         unpack_item(rec.x, rec.y, rec.z, rec.w, it);
-        walked = run_epilogue_fast<E, MODE, EXTRA>(A, B, smem, tile_rows, item, it, nr);
+        walked = run_epilogue_fast<E, MODE, EXTRA>(A, B, smem, tile_rows, item, it, nr, fallback16);
     }
     // statistic: bytes walked, one device atomic per WORKGROUP (8,192 same-address device atomics took 0.1 ms on their own,
     // and per-wave atomics spread over eight words of one line doubled this kernel's time), handed in by the workgroup's
@@ -2120,14 +2151,19 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_runs(DevAutomaton A, Batc
     // has to be WALKED takes ~ 100 us) and kept the CU from starting the next workgroup; with one such item in a thousand
     // almost every workgroup had one (0.66 ms instead of 0.16 on such a batch; 0.39 without the barrier).
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) walked += __shfl_xor(walked, d, 64);
+    for (int d = 32; d >= 1; d >>= 1) {
+        walked += __shfl_xor(walked, d, 64);
+        fallback16 += __shfl_xor(fallback16, d, 64);
+    }
     if ((threadIdx.x & 63u) == 0) {
         if (walked) atomicAdd(&s_walked, (walked + 15u) >> 4);
+        if (fallback16) atomicAdd(&s_fallback, fallback16);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (atomicAdd(&s_done, 1u) == kWalkThreads / 64u - 1u) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const uint32_t total = atomicAdd(&s_walked, 0u);
+            const uint32_t total = atomicAdd(&s_walked, 0u), fb = atomicAdd(&s_fallback, 0u);
             if (total) atomicAdd(&B.counters[8u + (blockIdx.x & 7u)], total);
+            if (fb) atomicAdd(&B.counters[7], fb);
         }
     }
 }
@@ -2216,8 +2252,8 @@ __global__ __launch_bounds__(kWalkThreads) void k_verify_dense(DevAutomaton A, B
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint64_t total_items = B.item_base[B.n_haystacks];
     if (uint64_t(blockIdx.x) * kWalkThreads >= total_items) return;
-    __shared__ uint32_t s_walked, s_done;
-    if (threadIdx.x == 0) { s_walked = 0; s_done = 0; }
+    __shared__ uint32_t s_walked, s_done, s_fallback;
+    if (threadIdx.x == 0) { s_walked = 0; s_done = 0; s_fallback = 0; }
     const uint64_t item = uint64_t(blockIdx.x) * kWalkThreads + threadIdx.x;
     uint32_t nr = 0;
     uint4 rec = make_uint4(0u, 0u, 0u, 0u);
@@ -2233,7 +2269,7 @@ __global__ __launch_bounds__(kWalkThreads) void k_verify_dense(DevAutomaton A, B
     }
     __syncthreads();
     const uint32_t *img = reinterpret_cast<const uint32_t *>(smem);
-    uint32_t walked = 0;
+    uint32_t walked = 0, fallback16 = 0;
     if (nr != 0) {
         ItemDesc it;
         unpack_item(rec.x, rec.y, rec.z, rec.w, it);
@@ -2245,7 +2281,7 @@ __global__ __launch_bounds__(kWalkThreads) void k_verify_dense(DevAutomaton A, B
         if (nr > B.run_cap) {   // more hit windows than the list holds (or an unaligned head): the whole item, exactly
             walked = n;
             exact_range<E, MODE, false>(A, B, nullptr, nullptr, 0u, item, p, it.floor, n, it.warm, pos_bias, 0u, ev);
-            atomicAdd(&B.counters[7], (n + 15u) >> 4);
+            fallback16 += (n + 15u) >> 4;
         } else {
             const uint32_t *starts = reinterpret_cast<const uint32_t *>(B.runs) + item * uint64_t(B.run_cap);
             uint32_t r = 0;
@@ -2286,7 +2322,7 @@ __global__ __launch_bounds__(kWalkThreads) void k_verify_dense(DevAutomaton A, B
                 // every pattern that ends in the cluster begins at one of its windows, the first being the leftmost
                 const uint32_t from = first > it.floor ? first : it.floor;
                 exact_range<E, MODE, false>(A, B, nullptr, nullptr, 0u, item, p, from, hi, rep_from, pos_bias, 0u, ev);
-                atomicAdd(&B.counters[7], (hi - from + 15u) >> 4);
+                fallback16 += (hi - from + 15u) >> 4;
             }
         }
         if (ev.n_ev) {
@@ -2296,14 +2332,19 @@ __global__ __launch_bounds__(kWalkThreads) void k_verify_dense(DevAutomaton A, B
         }
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) walked += __shfl_xor(walked, d, 64);
+    for (int d = 32; d >= 1; d >>= 1) {
+        walked += __shfl_xor(walked, d, 64);
+        fallback16 += __shfl_xor(fallback16, d, 64);
+    }
     if ((threadIdx.x & 63u) == 0) {
         if (walked) atomicAdd(&s_walked, (walked + 15u) >> 4);
+        if (fallback16) atomicAdd(&s_fallback, fallback16);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (atomicAdd(&s_done, 1u) == kWalkThreads / 64u - 1u) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const uint32_t total = atomicAdd(&s_walked, 0u);
+            const uint32_t total = atomicAdd(&s_walked, 0u), fb = atomicAdd(&s_fallback, 0u);
             if (total) atomicAdd(&B.counters[8u + (blockIdx.x & 7u)], total);
+            if (fb) atomicAdd(&B.counters[7], fb);
         }
     }
 }
@@ -2410,10 +2451,10 @@ template <typename E, int MODE>
 __global__ __launch_bounds__(256) void k_dense_emit(DevAutomaton A, BatchArgs B, const uint32_t *found_idx) {
     const uint64_t total_items = B.item_base[B.n_haystacks];
     const uint64_t item = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    __shared__ uint32_t s_walked;
-    if (threadIdx.x == 0) s_walked = 0;
+    __shared__ uint32_t s_walked, s_fallback;
+    if (threadIdx.x == 0) { s_walked = 0; s_fallback = 0; }
     __syncthreads();
-    uint32_t walked = 0;
+    uint32_t walked = 0, fallback16 = 0;
     const uint32_t nf = item < total_items ? B.run_count[item] : 0u;   // occurrences found (> run_cap: the window list overflowed)
     if (nf != 0) {
         const uint4 rec = B.item_rec[item];
@@ -2429,7 +2470,7 @@ __global__ __launch_bounds__(256) void k_dense_emit(DevAutomaton A, BatchArgs B,
         if (nf > B.run_cap) {
             walked = n;
             exact_range<E, MODE, false>(A, B, nullptr, nullptr, 0u, item, p, it.floor, n, it.warm, pos_bias, 0u, ev);
-            atomicAdd(&B.counters[7], (n + 15u) >> 4);
+            fallback16 += (n + 15u) >> 4;
         } else {
             const uint32_t *starts = reinterpret_cast<const uint32_t *>(B.runs) + item * uint64_t(B.run_cap);
             const uint32_t *fidx = found_idx + item * uint64_t(B.run_cap);
@@ -2480,7 +2521,7 @@ __global__ __launch_bounds__(256) void k_dense_emit(DevAutomaton A, BatchArgs B,
                 // every occurrence that ends in the cluster begins at one of its windows, the first being the leftmost
                 const uint32_t from = first > it.floor ? first : it.floor;
                 exact_range<E, MODE, false>(A, B, nullptr, nullptr, 0u, item, p, from, hi, rep_from, pos_bias, 0u, ev);
-                atomicAdd(&B.counters[7], (hi - from + 15u) >> 4);
+                fallback16 += (hi - from + 15u) >> 4;
             }
         }
         if (ev.n_ev) {
@@ -2490,10 +2531,15 @@ __global__ __launch_bounds__(256) void k_dense_emit(DevAutomaton A, BatchArgs B,
         }
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) walked += __shfl_xor(walked, d, 64);
+    for (int d = 32; d >= 1; d >>= 1) {
+        walked += __shfl_xor(walked, d, 64);
+        fallback16 += __shfl_xor(fallback16, d, 64);
+    }
     if ((threadIdx.x & 63u) == 0 && walked) atomicAdd(&s_walked, (walked + 15u) >> 4);
+    if ((threadIdx.x & 63u) == 0 && fallback16) atomicAdd(&s_fallback, fallback16);
     __syncthreads();
     if (threadIdx.x == 0 && s_walked) atomicAdd(&B.counters[8u + (blockIdx.x & 7u)], s_walked);
+    if (threadIdx.x == 0 && s_fallback) atomicAdd(&B.counters[7], s_fallback);
 }
 
 static hipError_t launch_verify_dense(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,
