@@ -2904,12 +2904,36 @@ __host__ __device__ constexpr uint32_t refill_wave_lds(uint32_t nb) {
 
 template <typename E, uint32_t NB>
 __global__ __launch_bounds__(kRefillThreads) void k_refill_wave(DevAutomaton A, BatchArgs B, const uint64_t *rec_base,
-                                                                uint4 *out, uint64_t cap) {
+                                                                uint4 *out, uint64_t cap, uint32_t tile_budget) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint4 *stage = reinterpret_cast<uint4 *>(smem + wave * refill_wave_lds(NB));
     uint32_t *cum = reinterpret_cast<uint32_t *>(stage + (NB + NB / 16u));  // kRefillTile + 1 slots
     uint32_t *stt = cum + kRefillTile + 1;
+    // Behind the waves' regions: the byte classes and as many of the first (shallowest) table rows as the launch left room
+    // for.  A lane walks Lmax-1 + 4 bytes per tile of 256 positions, every step a dependent lookup: from the global table
+    // that was ~ 1 us a step, and an item with tens -- not thousands -- of records per tile spent its time there (short
+    // patterns over their own alphabet: 70 M records per GiB at 0.19 TB/s of records).
+    const uint16_t *cls = reinterpret_cast<const uint16_t *>(smem + (kRefillThreads / 64u) * refill_wave_lds(NB));
+    const uint8_t *tile = reinterpret_cast<const uint8_t *>(cls + 256);
+    const uint32_t tile_rows = A.row_bytes ? (tile_budget / A.row_bytes < A.trap ? tile_budget / A.row_bytes : A.trap) : 0u;
+    {
+        uint16_t *cdst = const_cast<uint16_t *>(cls);
+        for (uint32_t t = threadIdx.x; t < 256u; t += kRefillThreads) cdst[t] = A.class_off[t];
+        const uint32_t *tsrc = reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(A.lds_image) + A.tile_offset);
+        uint32_t *tdst = reinterpret_cast<uint32_t *>(const_cast<uint8_t *>(tile));
+        const uint32_t n4 = (tile_rows * A.row_bytes + 3u) >> 2;
+        for (uint32_t t = threadIdx.x; t < n4; t += kRefillThreads) tdst[t] = tsrc[t];
+    }
+    __syncthreads();
+    auto step = [&](uint32_t s, uint32_t byte) __attribute__((always_inline)) -> uint32_t {
+        const uint32_t coff = cls[byte];
+        if (s < tile_rows) {
+            const uint32_t w = *reinterpret_cast<const E *>(tile + s * A.row_bytes + coff);
+            if (w < A.trap) return w;   // (the image's rows name a cold target by the trap row)
+        }
+        return cold_step<E>(A, s, byte, coff);
+    };
     const uint32_t n_overflow = B.counters[0];
     const uint32_t waves_total = gridDim.x * (kRefillThreads / 64);
     for (uint32_t t = blockIdx.x * (kRefillThreads / 64) + wave; t < n_overflow; t += waves_total) {
@@ -2921,8 +2945,24 @@ __global__ __launch_bounds__(kRefillThreads) void k_refill_wave(DevAutomaton A, 
         const uint8_t *p = B.blob + (it.begin - it.warm);
 #pragma unroll 1
         for (uint32_t q_tile = 0; q_tile < it.len; q_tile += kRefillTile) {
-            // 1. exact walk of this lane's S positions
+            // 1. exact walk of this lane's S positions.  The tile's text -- its 256 positions and the warm-up in front of them,
+            // at most 319 bytes -- comes into LDS with one round of coalesced byte loads (the staging window is idle until step
+            // 3): read from memory by every lane for itself it was a round trip per step.
             const uint32_t q0 = q_tile + lane * kRefillS;
+            uint8_t *txt = reinterpret_cast<uint8_t *>(stage);
+            const uint32_t r_end = it.warm + (q_tile + kRefillTile < it.len ? q_tile + kRefillTile : it.len);
+            const uint32_t r0 = it.warm + q_tile > B.warm_bytes ? it.warm + q_tile - B.warm_bytes : 0u;   // (wave-uniform)
+            const bool staged = B.warm_bytes + kRefillTile <= 320u;   // (longer warm-ups -- the kernel forced on long patterns -- read memory)
+            if (staged) {
+                uint32_t tb[5];
+#pragma unroll
+                for (uint32_t u = 0; u < 5u; ++u) tb[u] = r0 + lane + 64u * u < r_end ? load8g(p + r0 + lane + 64u * u) : 0u;
+#pragma unroll
+                for (uint32_t u = 0; u < 5u; ++u) txt[lane + 64u * u] = uint8_t(tb[u]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
             uint32_t st[kRefillS], cnt[kRefillS], sum = 0;
 #pragma unroll
             for (uint32_t k = 0; k < kRefillS; ++k) { st[k] = 0; cnt[k] = 0; }
@@ -2931,11 +2971,11 @@ __global__ __launch_bounds__(kRefillThreads) void k_refill_wave(DevAutomaton A, 
                 uint32_t j = j_rep > B.warm_bytes ? j_rep - B.warm_bytes : 0u;
                 uint32_t s = 0;
 #pragma unroll 1
-                for (; j < j_rep; ++j) s = exact_step<E>(A, nullptr, s, p[j]);
+                for (; j < j_rep; ++j) s = step(s, staged ? uint32_t(txt[j - r0]) : uint32_t(p[j]));
 #pragma unroll
                 for (uint32_t k = 0; k < kRefillS; ++k) {
                     if (q0 + k < it.len) {
-                        s = exact_step<E>(A, nullptr, s, p[j_rep + k]);
+                        s = step(s, staged ? uint32_t(txt[j_rep + k - r0]) : uint32_t(p[j_rep + k]));
                         st[k] = s;
                         cnt[k] = is_final(A, s) ? A.out_count[s] : 0u;
                         sum += cnt[k];
@@ -2961,8 +3001,33 @@ __global__ __launch_bounds__(kRefillThreads) void k_refill_wave(DevAutomaton A, 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // 3. expand 64 positions at a time through the staging window
-            if (T != 0) {
+            // 3. expand.  A tile whose records fit ONE window (tens of records, not thousands: short patterns over their own
+            // alphabet) is expanded by the lanes that walked it, each its own kRefillS positions from the states it still holds:
+            // the loads of all four positions are in flight together and the tile is written with one copy -- 64 positions at
+            // a time it was four rounds of two dependent round trips each, and those were the kernel (70 M records per GiB
+            // at 0.19 TB/s of records).
+            if (T != 0 && T <= NB && A.out_list != nullptr) {
+                uint32_t off[kRefillS];
+#pragma unroll
+                for (uint32_t k = 0; k < kRefillS; ++k) off[k] = cnt[k] ? A.out_off[st[k]] : 0u;
+                uint32_t slot = incl - sum;
+#pragma unroll
+                for (uint32_t k = 0; k < kRefillS; ++k) {
+                    const uint32_t pos = it.pos0 + q0 + k + 1u;
+                    const uint2 *ol = A.out_list + off[k];
+                    for (uint32_t i = 0; i < cnt[k]; ++i, ++slot) {
+                        const uint2 e = ol[i];
+                        stage[slot + (slot >> 4)] = make_uint4(it.hay, pos, pos - e.y, e.x);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                uint4 *dst = out + w;
+                for (uint32_t r = lane; r < T; r += 64u) dst[r] = stage[r + (r >> 4)];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            } else if (T != 0) {
 #pragma unroll 1
                 for (uint32_t g = 0; g < kRefillS; ++g) {
                     const uint32_t pp = g * 64u + lane;
@@ -3778,12 +3843,18 @@ void launch_refill(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items
         // window = what 64 positions can produce at most (one pass per group), up to 1024 records: smaller
         // windows leave LDS for more resident waves
         const uint32_t nb = A.max_out_count <= 4u ? 256u : A.max_out_count <= 8u ? 512u : 1024u;
-        const uint32_t lds = refill_wave_lds(nb) * uint32_t(per_block);
-        const uint32_t per_cu = std::min<uint32_t>(8u, (160u * 1024u) / lds);
-        const uint32_t blocks = uint32_t(std::min<uint64_t>((max_items + per_block - 1) / per_block, uint64_t(num_cus()) * per_cu));
+        const uint32_t lds_waves = refill_wave_lds(nb) * uint32_t(per_block);
+        // workgroups per CU: what the staging windows allow, four at most (the rest of a workgroup's share of the LDS holds the
+        // byte classes and the first rows of the table)
+        const uint32_t per_cu = std::min<uint32_t>(4u, (160u * 1024u) / (lds_waves + 1024u));
+        const uint32_t share = (160u * 1024u) / std::max<uint32_t>(per_cu, 1u);
+        const uint32_t hot_bytes = (A.trap * A.row_bytes + 15u) & ~15u;
+        const uint32_t tile_budget = std::min<uint32_t>(hot_bytes, share > lds_waves + 512u + 64u ? ((share - lds_waves - 512u - 64u) & ~15u) : 0u);
+        const uint32_t lds = lds_waves + 512u + tile_budget;
+        const uint32_t blocks = uint32_t(std::min<uint64_t>((max_items + per_block - 1) / per_block, uint64_t(num_cus()) * std::max<uint32_t>(per_cu, 1u)));
         auto go = [&](auto fn) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-            hipLaunchKernelGGL(fn, dim3(blocks), dim3(kRefillThreads), lds, st, A, B, rec_base, static_cast<uint4 *>(out), cap);
+            hipLaunchKernelGGL(fn, dim3(blocks), dim3(kRefillThreads), lds, st, A, B, rec_base, static_cast<uint4 *>(out), cap, tile_budget);
         };
         if (entry_bytes == 2) {
             if (nb == 256u) go(k_refill_wave<uint16_t, 256>); else if (nb == 512u) go(k_refill_wave<uint16_t, 512>); else go(k_refill_wave<uint16_t, 1024>);
