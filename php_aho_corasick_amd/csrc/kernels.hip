@@ -2107,7 +2107,7 @@ constexpr uint32_t kWalkTileBytes = 64u * 1024u;
 // 0.160 / 0.084 ms, against 0.163 / 0.077 ms as it is: occupancy is not what bounds the kernel.)
 
 template <typename E, int MODE, bool EXTRA>
-__global__ __launch_bounds__(kWalkThreads) void k_walk_runs(DevAutomaton A, BatchArgs B) {
+__global__ __launch_bounds__(kWalkThreads) void k_walk_runs(DevAutomaton A, BatchArgs B, uint32_t tile_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint64_t total_items = B.item_base[B.n_haystacks];
     if (uint64_t(blockIdx.x) * kWalkThreads >= total_items) return;
@@ -2121,7 +2121,7 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_runs(DevAutomaton A, Batc
         nr = B.run_count[item];
         rec = B.item_rec[item];
     }
-    const uint32_t tile_rows = A.row_bytes ? (kWalkTileBytes / A.row_bytes < A.trap ? kWalkTileBytes / A.row_bytes : A.trap) : 0u;
+    const uint32_t tile_rows = A.row_bytes ? (tile_bytes / A.row_bytes < A.trap ? tile_bytes / A.row_bytes : A.trap) : 0u;
     {
         const uint4 *tsrc = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(A.lds_image) + A.tile_offset);
         uint4 *tdst = reinterpret_cast<uint4 *>(smem);
@@ -2176,11 +2176,14 @@ hipError_t launch_walk_runs(const DevAutomaton &A, const BatchArgs &B, uint64_t 
     if (max_items == 0) return hipSuccess;
     if (B.run_dense) return launch_verify_dense(A, B, max_items, entry_bytes, class_mode, st);
     const uint32_t blocks = uint32_t((max_items + kWalkThreads - 1) / kWalkThreads);
-    const uint32_t lds = kWalkTileBytes;
+    // (no tile at all when candidates are decided by text compares: 52 -> 49.5 us on the headline batch, 0.148 -> 0.141 ms on
+    // config 3 -- not worth walking every fallback cluster through L2)
+    const uint32_t tile_bytes = kWalkTileBytes;
+    const uint32_t lds = tile_bytes;
     auto go = [&](auto fn) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(fn, dim3(blocks), dim3(kWalkThreads), lds, st, A, B);
+        hipLaunchKernelGGL(fn, dim3(blocks), dim3(kWalkThreads), lds, st, A, B, tile_bytes);
         return hipGetLastError();
     };
     const bool extra = A.early_stop != 0u;
