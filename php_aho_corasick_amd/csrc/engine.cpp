@@ -867,6 +867,7 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
         const uint64_t per_batch = kernel == 2 ? B.wave_items : 64ull * uint64_t(std::max(1, h->ilp));
         const uint64_t batches = (est + per_batch - 1) / per_batch;
         B.wave_grab = uint32_t(std::min<uint64_t>(16, std::max<uint64_t>(1, (batches + 16383) / 16384)));
+        if (max_items > (1ull << 31)) B.wave_grab = 1u;   // (the 32-bit item counter overshoots by what the waves take past the end)
     }
 
     // item counts, their scan, the item table, zeroed per-item counters: one launch
