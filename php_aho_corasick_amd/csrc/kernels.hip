@@ -1073,9 +1073,9 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_lds(DevAutomaton A, BatchA
     uint32_t batch_first = (blockIdx.x * (kLdsThreads / 64u) + (threadIdx.x >> 6)) * (64u * ILP);  // static split
     if (B.persistent) {
         if (grab_left == 0) {
-            if ((threadIdx.x & 63u) == 0) grab_next = atomicAdd(&B.counters[1], 64u * ILP * B.wave_grab);
+            if ((threadIdx.x & 63u) == 0) grab_next = atomicAdd(&B.counters[1], 64u * ILP * (B.wave_grab ? B.wave_grab : 1u));
             grab_next = __builtin_amdgcn_readfirstlane(grab_next);
-            grab_left = B.wave_grab;
+            grab_left = B.wave_grab ? B.wave_grab : 1u;
         }
         batch_first = grab_next;
         grab_next += 64u * ILP;
@@ -1382,9 +1382,9 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     uint32_t batch_first = (blockIdx.x * (kLdsThreads / 64u) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * B.wave_items;
     if (B.persistent) {
         if (grab_left == 0) {
-            if (lane == 0) grab_next = atomicAdd(&B.counters[1], B.wave_items * B.wave_grab);
+            if (lane == 0) grab_next = atomicAdd(&B.counters[1], B.wave_items * (B.wave_grab ? B.wave_grab : 1u));
             grab_next = __builtin_amdgcn_readfirstlane(grab_next);
-            grab_left = B.wave_grab;
+            grab_left = B.wave_grab ? B.wave_grab : 1u;
         }
         batch_first = grab_next;
         grab_next += B.wave_items;
