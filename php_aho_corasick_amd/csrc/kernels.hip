@@ -3515,58 +3515,84 @@ __global__ __launch_bounds__(256) void k_replace_emit(ReplaceArgs R, uint64_t ca
             if (R.out_off[mid] <= a) lo = mid; else hi = mid;
         }
         uint32_t h = uint32_t(lo);
+        // the gap [at, at + n_bytes) of a haystack's output, clipped to this wave's part [la, le) of it
+        auto copy_clip = [&](uint8_t *out, uint64_t at, const uint8_t *src, uint64_t n_bytes, uint64_t la, uint64_t le) {
+            const uint64_t p0 = at > la ? at : la, p1 = at + n_bytes < le ? at + n_bytes : le;
+            if (p0 < p1) wave_copy(out + p0, src + (p0 - at), p1 - p0, lane);
+        };
+        auto rl32 = [](uint32_t v, uint32_t j) { return uint32_t(__builtin_amdgcn_readlane(int(v), int(j))); };
+        auto rl64 = [&](uint64_t v, uint32_t j) { return uint64_t(rl32(uint32_t(v >> 32), j)) << 32 | rl32(uint32_t(v), j); };
         while (a < b) {
-            const uint64_t hb = R.out_off[h], he = R.out_off[h + 1];
-            if (he <= a) { ++h; continue; }
-            const uint64_t seg_end = b < he ? b : he;
-            const uint64_t la = a - hb, le = seg_end - hb;      // this range inside haystack h's output
-            const uint8_t *text = R.blob + R.offsets[h];
-            const uint32_t len = uint32_t(R.offsets[h + 1] - R.offsets[h]);
-            const uint32_t n = R.nom_count[h];
-            const uint2 *plan = R.plan + R.prefix[h];
-            const uint64_t *pout = R.plan_out + R.prefix[h];
-            uint8_t *out = R.out_blob + hb;
-            // first piece that reaches past la: the last k <= n with begin(k) <= la (begin(n) = the tail's)
-            const uint64_t tail_at = R.tail_out[h];
-            uint32_t k = 0;
-            if (n) {
-                uint32_t klo = 0, khi = n + 1u;   // begin(klo) <= la < begin(khi)
-                while (khi - klo > 1u) {
-                    const uint32_t mid = (klo + khi) >> 1;
-                    const uint64_t at = mid < n ? pout[mid] : tail_at;
-                    if (at <= la) klo = mid; else khi = mid;
-                }
-                k = klo;
+            // The bookkeeping of the NEXT 64 haystacks, a lane each, three dependent rounds for all of them -- one haystack at a
+            // time the wave sat out three round trips before every 8-KiB piece, about as long as the piece's copy.  Lane j:
+            // haystack h + j; with at most one nominee (the usual text) everything its pieces need is in these registers.
+            const uint32_t hj = h + lane < R.n_haystacks ? h + lane : R.n_haystacks - 1u;
+            const uint64_t v_ob = R.out_off[hj], v_oe = R.out_off[hj + 1], v_tb = R.offsets[hj], v_te = R.offsets[hj + 1];
+            const uint64_t v_pf = R.prefix[hj], v_tail = R.tail_out[hj];
+            const uint32_t v_n = R.nom_count[hj];
+            uint2 v_plan = make_uint2(0u, 0u);
+            uint64_t v_pout = 0, v_ro = 0;
+            uint32_t v_plen = 0;
+            if (v_n >= 1u) {
+                v_plan = R.plan[v_pf];
+                v_pout = R.plan_out[v_pf];
+                v_plen = R.pattern_length[v_plan.y];
+                v_ro = R.rep_off[v_plan.y];
             }
-            for (; k <= n; ++k) {
-                const uint64_t at = k < n ? pout[k] : tail_at;
-                if (at >= le) break;
-                const uint32_t cursor = k ? plan[k - 1].x : 0u;
-                uint64_t gap_len, rep_len = 0;
-                const uint8_t *rep = nullptr;
-                if (k < n) {
-                    const uint2 nom = plan[k];
-                    const uint32_t start = nom.x - R.pattern_length[nom.y];
-                    gap_len = start >= cursor ? start - cursor : 0u;
-                    const uint64_t ro = R.rep_off[nom.y];
-                    rep = R.rep_bytes + (ro >> 32);
-                    rep_len = uint32_t(ro);
+            for (uint32_t j = 0; j < 64u && a < b; ++j, ++h) {
+                if (h >= R.n_haystacks) { a = b; break; }   // (cannot happen: b <= the last haystack's end)
+                const uint64_t hb = rl64(v_ob, j), he = rl64(v_oe, j);
+                if (he <= a) continue;
+                const uint64_t seg_end = b < he ? b : he;
+                const uint64_t la = a - hb, le = seg_end - hb;      // this range inside haystack h's output
+                const uint64_t tb = rl64(v_tb, j);
+                const uint8_t *text = R.blob + tb;
+                const uint32_t len = uint32_t(rl64(v_te, j) - tb);
+                const uint32_t n = rl32(v_n, j);
+                const uint64_t pf = rl64(v_pf, j), tail_at = rl64(v_tail, j);
+                uint8_t *out = R.out_blob + hb;
+                if (n <= 1u) {
+                    uint32_t cursor = 0;
+                    if (n == 1u) {   // [text before the nominee][its replacement]
+                        const uint32_t end = rl32(v_plan.x, j), start = end - rl32(v_plen, j);
+                        const uint64_t at = rl64(v_pout, j), ro = rl64(v_ro, j);
+                        copy_clip(out, at, text, start, la, le);
+                        if (uint32_t(ro)) copy_clip(out, at + start, R.rep_bytes + (ro >> 32), uint32_t(ro), la, le);
+                        cursor = end;
+                    }
+                    copy_clip(out, tail_at, text + cursor, len > cursor ? len - cursor : 0u, la, le);   // the text behind it
                 } else {
-                    gap_len = len > cursor ? len - cursor : 0u;
+                    const uint2 *plan = R.plan + pf;
+                    const uint64_t *pout = R.plan_out + pf;
+                    // first piece that reaches past la: the last k <= n with begin(k) <= la (begin(n) = the tail's)
+                    uint32_t klo = 0, khi = n + 1u;   // begin(klo) <= la < begin(khi)
+                    while (khi - klo > 1u) {
+                        const uint32_t mid = (klo + khi) >> 1;
+                        const uint64_t at = mid < n ? pout[mid] : tail_at;
+                        if (at <= la) klo = mid; else khi = mid;
+                    }
+                    for (uint32_t k = klo; k <= n; ++k) {
+                        const uint64_t at = k < n ? pout[k] : tail_at;
+                        if (at >= le) break;
+                        const uint32_t cursor = k ? plan[k - 1].x : 0u;
+                        uint64_t gap_len, rep_len = 0;
+                        const uint8_t *rep = nullptr;
+                        if (k < n) {
+                            const uint2 nom = plan[k];
+                            const uint32_t start = nom.x - R.pattern_length[nom.y];
+                            gap_len = start >= cursor ? start - cursor : 0u;
+                            const uint64_t ro = R.rep_off[nom.y];
+                            rep = R.rep_bytes + (ro >> 32);
+                            rep_len = uint32_t(ro);
+                        } else {
+                            gap_len = len > cursor ? len - cursor : 0u;
+                        }
+                        copy_clip(out, at, text + cursor, gap_len, la, le);
+                        if (rep_len) copy_clip(out, at + gap_len, rep, rep_len, la, le);
+                    }
                 }
-                // the gap [at, at + gap_len) and the replacement behind it, both clipped to [la, le)
-                {
-                    const uint64_t p0 = at > la ? at : la, p1 = at + gap_len < le ? at + gap_len : le;
-                    if (p0 < p1) wave_copy(out + p0, text + cursor + (p0 - at), p1 - p0, lane);
-                }
-                if (rep_len) {
-                    const uint64_t r0 = at + gap_len;
-                    const uint64_t p0 = r0 > la ? r0 : la, p1 = r0 + rep_len < le ? r0 + rep_len : le;
-                    if (p0 < p1) wave_copy(out + p0, rep + (p0 - r0), p1 - p0, lane);
-                }
+                a = seg_end;
             }
-            a = seg_end;
-            if (a == he) ++h;
         }
     }
 }
