@@ -266,8 +266,8 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
 
 /* Integer options, set before finalize unless noted:
  *   "lds_bytes"      LDS budget for the hot-state tile (default 160 KiB minus slack)
- *   "slab_events"    per work-item event slots before the overflow path (default 8; 32 with the dense anchor form)
- *   "run_cap"        per work-item fix-up runs before the item is rescanned whole (default 8; the dense anchor form: 256 entries of 4 bytes)
+ *   "slab_events"    per work-item event slots before the overflow path (default 16; 32 with the dense anchor form)
+ *   "run_cap"        per work-item fix-up runs before the item is rescanned whole (default 16; the dense anchor form: 256 entries of 4 bytes)
  *   "chunk_bytes"    force the work-item size (0 = automatic)            [any time]
  *   "kernel"         0 = plain global-table walk, 1 = LDS-tile table walk, 2 = anchor q-gram
  *                    filter + exact table walk of the candidates (needs a shortest pattern

@@ -96,8 +96,8 @@ struct acmi_handle {
     DevBuf d_merge_counts, d_merge_sync;
 
     // options
-    uint32_t slab_events = 8;
-    uint32_t run_cap = 8;
+    uint32_t slab_events = 16;   // (8 until round 3: an item with a ninth match went to the drain, one with a ninth candidate was walked whole)
+    uint32_t run_cap = 16;
     bool slab_set = false;     // "slab_events" set by the caller; else the dense anchor form takes 32
     bool run_cap_set = false;  // by the caller; else the dense anchor form takes 64 (a work item has tens of candidate windows there)
     uint64_t chunk_opt = 0;
@@ -790,12 +790,17 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     // k_items has sync words of its own, d_isync)
     uint64_t *status1 = reinterpret_cast<uint64_t *>(sync_cur + 32);
     HIPCHK(h, h->d_rec_base.ensure_keep((max_items + 2) * 8, h->retired));
-    HIPCHK(h, h->d_slab.ensure_keep(max_items * K * 8, h->retired));
+    // Run lists and event slabs are index-major (entry r of every item, then entry r + 1 ...): the distance between an item's
+    // consecutive entries must not be a power of two.  2^17 haystacks of 8 KiB made it 4 MiB, an item's six candidate windows
+    // fell into one cache set of one channel, and k_walk_runs took 2.4 ms instead of 0.075 (tools/exp_hits.py: five plants per
+    // haystack fine, six 35 x slower; any run_cap but 8 fine too, which moved the buffers).  Hence 328 entries of padding.
+    const uint64_t run_stride = max_items + 328;
+    HIPCHK(h, h->d_slab.ensure_keep(run_stride * K * 8, h->retired));
     HIPCHK(h, h->d_ovf.ensure_keep(max_items * 4, h->retired));
     // dense anchor form: hit windows per item by the dozen -- 4-byte entries, 256 of them unless the caller says otherwise
     const bool dense = kernel == 2 && fa.anchor_dense != 0;
     const uint32_t Q = (!h->run_cap_set && dense) ? 256u : std::max<uint32_t>(1, h->run_cap);
-    HIPCHK(h, h->d_runs.ensure_keep(max_items * Q * (dense ? 8 : 16), h->retired));   // (dense: window starts, then k_dense_decide's results)
+    HIPCHK(h, h->d_runs.ensure_keep(run_stride * Q * (dense ? 8 : 16), h->retired));   // (dense: window starts, then k_dense_decide's results)
     HIPCHK(h, h->d_run_count.ensure_keep(max_items * 4, h->retired));
     uint8_t *zero = d_zero.as<uint8_t>();
     uint32_t *d_counters = sync_cur;
@@ -829,7 +834,7 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     B.run_count = h->d_run_count.as<uint32_t>();
     B.run_cap = Q;
     B.run_dense = dense ? 1u : 0u;
-    B.run_stride = max_items;
+    B.run_stride = run_stride;
     B.poison_quads = std::max<uint32_t>(1, (fa.max_pattern_length + 15) / 16);
     // persistent workgroups pay off once a CU would otherwise run several workgroups back to back
     // (measured: 1 KiB items -18 %, 2 x 8 KiB per lane +2.5 %)

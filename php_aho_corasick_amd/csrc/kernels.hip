@@ -584,7 +584,7 @@ __device__ __forceinline__ uint32_t exact_range(const DevAutomaton &A, const Bat
                                                 const uint8_t *tile, uint32_t tile_rows, uint64_t item,
                                                 const uint8_t *p, uint32_t j0, uint32_t j1, uint32_t rep_from,
                                                 uint32_t pos_bias, uint32_t s, EventRegs &ev,
-                                                uint32_t stop_from = 0xFFFFFFFFu) {
+                                                uint32_t stop_from = 0xFFFFFFFFu, bool store = true) {
     // Haystack bytes come in aligned 16-byte blocks, the next block requested one block ahead: one
     // exposed memory round trip per call instead of one per dword (the walks are latency chains).
     // A block is only touched when it holds a needed byte, so it lies inside a mapped page.
@@ -612,7 +612,7 @@ __device__ __forceinline__ uint32_t exact_range(const DevAutomaton &A, const Bat
         s = w;
         if (j >= rep_from && is_final(A, s) && !(B.first_only && ev.n_ev)) {
             ev.n_rec += A.out_count[s];
-            if (ev.n_ev < B.slab_events) B.slab[uint64_t(ev.n_ev) * B.run_stride + item] = make_uint2(pos_bias + j, s);
+            if (store && ev.n_ev < B.slab_events) B.slab[uint64_t(ev.n_ev) * B.run_stride + item] = make_uint2(pos_bias + j, s);
             ++ev.n_ev;
         }
         // an anchor candidate's walk: from byte stop_from on, a non-final state of trie depth <= 2 means that
@@ -2140,10 +2140,54 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_runs(DevAutomaton A, Batc
     }
     __syncthreads();
     uint32_t walked = 0, fallback16 = 0;
+    bool whole = false;
     if (nr != 0) {
         ItemDesc it;
         unpack_item(rec.x, rec.y, rec.z, rec.w, it);
-        walked = run_epilogue_fast<E, MODE, EXTRA>(A, B, smem, tile_rows, item, it, nr, fallback16);
+        // (a run list that overflowed -- more candidate windows than it holds -- means the whole item: not by this lane alone,
+        // see below; findAll = false keeps the old way, the first event needs the order)
+        if (nr > B.run_cap && !B.first_only) whole = true;
+        else walked = run_epilogue_fast<E, MODE, EXTRA>(A, B, smem, tile_rows, item, it, nr, fallback16);
+    }
+    // Items whose run list overflowed are walked by the WAVE, a 64th of the item per lane (entered from the root Lmax-1 bytes
+    // early, like every chunk), and only COUNTED: events and records go to the item's counters, the item to the overflow list,
+    // and the drain (k_refill_wave) writes its records as it does for any item with more events than its slab holds.  One
+    // lane walking its 8 KiB alone took 2.4 ms -- the whole kernel, for ONE such item in a batch of any size (tools/exp_hits.py:
+    // six matches per haystack and one accidental candidate more somewhere: 0.075 -> 2.4 ms).
+    for (uint64_t todo = __ballot(whole); todo != 0; todo &= todo - 1) {
+        const uint32_t l = uint32_t(__builtin_ctzll(todo));
+        const uint64_t item_l = item - (threadIdx.x & 63u) + l;
+        ItemDesc it;
+        unpack_item(uint32_t(__builtin_amdgcn_readlane(int(rec.x), int(l))), uint32_t(__builtin_amdgcn_readlane(int(rec.y), int(l))),
+                    uint32_t(__builtin_amdgcn_readlane(int(rec.z), int(l))), uint32_t(__builtin_amdgcn_readlane(int(rec.w), int(l))), it);
+        const uint8_t *p = B.blob + (it.begin - it.warm);
+        const uint32_t n = it.warm + it.len, lane = threadIdx.x & 63u;
+        const uint32_t seg = (it.len + 63u) >> 6;
+        const uint32_t s0 = it.warm + lane * seg, s1 = s0 + seg < n ? s0 + seg : n;
+        EventRegs ev{0, 0};
+        if (s0 < s1) {
+            uint32_t from = s0 > B.warm_bytes ? s0 - B.warm_bytes : 0u;
+            if (from < it.floor) from = it.floor;
+            exact_range<E, MODE, false>(A, B, nullptr, smem, tile_rows, item_l, p, from, s1, s0, it.pos0 - it.warm + 1u, 0u, ev, 0xFFFFFFFFu, false);
+        }
+        uint32_t n_ev = ev.n_ev, rec_lo = uint32_t(ev.n_rec), rec_hi = uint32_t(ev.n_rec >> 32);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            n_ev += __shfl_xor(n_ev, d, 64);
+            const uint32_t lo2 = __shfl_xor(rec_lo, d, 64), hi2 = __shfl_xor(rec_hi, d, 64);
+            const uint64_t sum = (uint64_t(rec_hi) << 32 | rec_lo) + (uint64_t(hi2) << 32 | lo2);
+            rec_lo = uint32_t(sum);
+            rec_hi = uint32_t(sum >> 32);
+        }
+        if (lane == 0) {
+            if (n_ev) {
+                B.ev_count[item_l] = n_ev > B.slab_events ? n_ev : B.slab_events + 1u;   // (its events are not in the slab: the drain's)
+                B.rec_count[item_l] = uint64_t(rec_hi) << 32 | rec_lo;
+                B.overflow_list[atomicAdd(&B.counters[0], 1u)] = uint32_t(item_l);
+            }
+            walked += n;
+            fallback16 += (n + 15u) >> 4;
+        }
     }
     // statistic: bytes walked, one device atomic per WORKGROUP (8,192 same-address device atomics took 0.1 ms on their own,
     // and per-wave atomics spread over eight words of one line doubled this kernel's time), handed in by the workgroup's
