@@ -2106,6 +2106,53 @@ constexpr uint32_t kWalkTileBytes = 64u * 1024u;
 // the headline batch: 64 registers forced (24 spilled) 0.183 / 0.077 ms, three 8-wave workgroups with 48 KiB tiles
 // 0.160 / 0.084 ms, against 0.163 / 0.077 ms as it is: occupancy is not what bounds the kernel.)
 
+// Items whose run list overflowed are walked by the WAVE, a 64th of the item per lane (entered from the root Lmax-1 bytes
+// early, like every chunk), and only COUNTED: events and records go to the item's counters, the item to the overflow list,
+// and the drain (k_refill_wave) writes its records as it does for any item with more events than its slab holds.  One
+// lane walking its 8 KiB alone took 2.4 ms -- the whole kernel, for ONE such item in a batch of any size (tools/exp_hits.py:
+// six matches per haystack and one accidental candidate more somewhere: 0.075 -> 2.4 ms).  `whole`: this lane's item is
+// one of them (`rec` its packed record, `item` its index); must be reached by every lane of the wave.
+template <typename E, int MODE>
+__device__ __forceinline__ void wave_walk_whole(const DevAutomaton &A, const BatchArgs &B, const uint8_t *tile, uint32_t tile_rows,
+                                                bool whole, const uint4 &rec, uint64_t item, uint32_t &walked, uint32_t &fallback16) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint64_t todo = __ballot(whole); todo != 0; todo &= todo - 1) {
+        const uint32_t l = uint32_t(__builtin_ctzll(todo));
+        const uint64_t item_l = item - lane + l;
+        ItemDesc it;
+        unpack_item(uint32_t(__builtin_amdgcn_readlane(int(rec.x), int(l))), uint32_t(__builtin_amdgcn_readlane(int(rec.y), int(l))),
+                    uint32_t(__builtin_amdgcn_readlane(int(rec.z), int(l))), uint32_t(__builtin_amdgcn_readlane(int(rec.w), int(l))), it);
+        const uint8_t *p = B.blob + (it.begin - it.warm);
+        const uint32_t n = it.warm + it.len;
+        const uint32_t seg = (it.len + 63u) >> 6;
+        const uint32_t s0 = it.warm + lane * seg, s1 = s0 + seg < n ? s0 + seg : n;
+        EventRegs ev{0, 0};
+        if (s0 < s1) {
+            uint32_t from = s0 > B.warm_bytes ? s0 - B.warm_bytes : 0u;
+            if (from < it.floor) from = it.floor;
+            exact_range<E, MODE, false>(A, B, nullptr, tile, tile_rows, item_l, p, from, s1, s0, it.pos0 - it.warm + 1u, 0u, ev, 0xFFFFFFFFu, false);
+        }
+        uint32_t n_ev = ev.n_ev, rec_lo = uint32_t(ev.n_rec), rec_hi = uint32_t(ev.n_rec >> 32);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            n_ev += __shfl_xor(n_ev, d, 64);
+            const uint32_t lo2 = __shfl_xor(rec_lo, d, 64), hi2 = __shfl_xor(rec_hi, d, 64);
+            const uint64_t sum = (uint64_t(rec_hi) << 32 | rec_lo) + (uint64_t(hi2) << 32 | lo2);
+            rec_lo = uint32_t(sum);
+            rec_hi = uint32_t(sum >> 32);
+        }
+        if (lane == 0) {
+            if (n_ev) {
+                B.ev_count[item_l] = n_ev > B.slab_events ? n_ev : B.slab_events + 1u;   // (its events are not in the slab: the drain's)
+                B.rec_count[item_l] = uint64_t(rec_hi) << 32 | rec_lo;
+                B.overflow_list[atomicAdd(&B.counters[0], 1u)] = uint32_t(item_l);
+            }
+            walked += n;
+            fallback16 += (n + 15u) >> 4;
+        }
+    }
+}
+
 template <typename E, int MODE, bool EXTRA>
 __global__ __launch_bounds__(kWalkThreads) void k_walk_runs(DevAutomaton A, BatchArgs B, uint32_t tile_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -2149,46 +2196,7 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_runs(DevAutomaton A, Batc
         if (nr > B.run_cap && !B.first_only) whole = true;
         else walked = run_epilogue_fast<E, MODE, EXTRA>(A, B, smem, tile_rows, item, it, nr, fallback16);
     }
-    // Items whose run list overflowed are walked by the WAVE, a 64th of the item per lane (entered from the root Lmax-1 bytes
-    // early, like every chunk), and only COUNTED: events and records go to the item's counters, the item to the overflow list,
-    // and the drain (k_refill_wave) writes its records as it does for any item with more events than its slab holds.  One
-    // lane walking its 8 KiB alone took 2.4 ms -- the whole kernel, for ONE such item in a batch of any size (tools/exp_hits.py:
-    // six matches per haystack and one accidental candidate more somewhere: 0.075 -> 2.4 ms).
-    for (uint64_t todo = __ballot(whole); todo != 0; todo &= todo - 1) {
-        const uint32_t l = uint32_t(__builtin_ctzll(todo));
-        const uint64_t item_l = item - (threadIdx.x & 63u) + l;
-        ItemDesc it;
-        unpack_item(uint32_t(__builtin_amdgcn_readlane(int(rec.x), int(l))), uint32_t(__builtin_amdgcn_readlane(int(rec.y), int(l))),
-                    uint32_t(__builtin_amdgcn_readlane(int(rec.z), int(l))), uint32_t(__builtin_amdgcn_readlane(int(rec.w), int(l))), it);
-        const uint8_t *p = B.blob + (it.begin - it.warm);
-        const uint32_t n = it.warm + it.len, lane = threadIdx.x & 63u;
-        const uint32_t seg = (it.len + 63u) >> 6;
-        const uint32_t s0 = it.warm + lane * seg, s1 = s0 + seg < n ? s0 + seg : n;
-        EventRegs ev{0, 0};
-        if (s0 < s1) {
-            uint32_t from = s0 > B.warm_bytes ? s0 - B.warm_bytes : 0u;
-            if (from < it.floor) from = it.floor;
-            exact_range<E, MODE, false>(A, B, nullptr, smem, tile_rows, item_l, p, from, s1, s0, it.pos0 - it.warm + 1u, 0u, ev, 0xFFFFFFFFu, false);
-        }
-        uint32_t n_ev = ev.n_ev, rec_lo = uint32_t(ev.n_rec), rec_hi = uint32_t(ev.n_rec >> 32);
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            n_ev += __shfl_xor(n_ev, d, 64);
-            const uint32_t lo2 = __shfl_xor(rec_lo, d, 64), hi2 = __shfl_xor(rec_hi, d, 64);
-            const uint64_t sum = (uint64_t(rec_hi) << 32 | rec_lo) + (uint64_t(hi2) << 32 | lo2);
-            rec_lo = uint32_t(sum);
-            rec_hi = uint32_t(sum >> 32);
-        }
-        if (lane == 0) {
-            if (n_ev) {
-                B.ev_count[item_l] = n_ev > B.slab_events ? n_ev : B.slab_events + 1u;   // (its events are not in the slab: the drain's)
-                B.rec_count[item_l] = uint64_t(rec_hi) << 32 | rec_lo;
-                B.overflow_list[atomicAdd(&B.counters[0], 1u)] = uint32_t(item_l);
-            }
-            walked += n;
-            fallback16 += (n + 15u) >> 4;
-        }
-    }
+    wave_walk_whole<E, MODE>(A, B, smem, tile_rows, whole, rec, item, walked, fallback16);
     // statistic: bytes walked, one device atomic per WORKGROUP (8,192 same-address device atomics took 0.1 ms on their own,
     // and per-wave atomics spread over eight words of one line doubled this kernel's time), handed in by the workgroup's
     // LAST wave to finish -- no barrier: a barrier made every wave of a workgroup wait for its slowest lane (a cluster that
@@ -2317,6 +2325,7 @@ __global__ __launch_bounds__(kWalkThreads) void k_verify_dense(DevAutomaton A, B
     __syncthreads();
     const uint32_t *img = reinterpret_cast<const uint32_t *>(smem);
     uint32_t walked = 0, fallback16 = 0;
+    bool whole = false;
     if (nr != 0) {
         ItemDesc it;
         unpack_item(rec.x, rec.y, rec.z, rec.w, it);
@@ -2325,7 +2334,9 @@ __global__ __launch_bounds__(kWalkThreads) void k_verify_dense(DevAutomaton A, B
         const uint32_t pos_bias = it.pos0 - it.warm + 1u;
         const uint32_t m_min = A.min_pattern_length, l_max = A.max_pattern_length;
         EventRegs ev{0, 0};
-        if (nr > B.run_cap) {   // more hit windows than the list holds (or an unaligned head): the whole item, exactly
+        if (nr > B.run_cap && !B.first_only) {   // more hit windows than the list holds (or an unaligned head): the whole item,
+            whole = true;                         // exactly -- by the wave, below (wave_walk_whole)
+        } else if (nr > B.run_cap) {
             walked = n;
             exact_range<E, MODE, false>(A, B, nullptr, nullptr, 0u, item, p, it.floor, n, it.warm, pos_bias, 0u, ev);
             fallback16 += (n + 15u) >> 4;
@@ -2378,6 +2389,7 @@ __global__ __launch_bounds__(kWalkThreads) void k_verify_dense(DevAutomaton A, B
             if (ev.n_ev > B.slab_events) B.overflow_list[atomicAdd(&B.counters[0], 1u)] = uint32_t(item);
         }
     }
+    wave_walk_whole<E, MODE>(A, B, nullptr, 0u, whole, rec, item, walked, fallback16);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         walked += __shfl_xor(walked, d, 64);
@@ -2502,9 +2514,11 @@ __global__ __launch_bounds__(256) void k_dense_emit(DevAutomaton A, BatchArgs B,
     if (threadIdx.x == 0) { s_walked = 0; s_fallback = 0; }
     __syncthreads();
     uint32_t walked = 0, fallback16 = 0;
+    bool whole = false;
     const uint32_t nf = item < total_items ? B.run_count[item] : 0u;   // occurrences found (> run_cap: the window list overflowed)
+    uint4 rec = make_uint4(0u, 0u, 0u, 0u);
     if (nf != 0) {
-        const uint4 rec = B.item_rec[item];
+        rec = B.item_rec[item];
         ItemDesc it;
         unpack_item(rec.x, rec.y, rec.z, rec.w, it);
         const uint8_t *p = B.blob + (it.begin - it.warm);
@@ -2514,7 +2528,9 @@ __global__ __launch_bounds__(256) void k_dense_emit(DevAutomaton A, BatchArgs B,
         const uint32_t *img = A.dense_image;              // (records read through the cache: a few KiB, shared by everyone)
         const uint32_t *recs = img + img[2];
         EventRegs ev{0, 0};
-        if (nf > B.run_cap) {
+        if (nf > B.run_cap && !B.first_only) {
+            whole = true;   // (the wave walks it together, below: wave_walk_whole)
+        } else if (nf > B.run_cap) {
             walked = n;
             exact_range<E, MODE, false>(A, B, nullptr, nullptr, 0u, item, p, it.floor, n, it.warm, pos_bias, 0u, ev);
             fallback16 += (n + 15u) >> 4;
@@ -2577,6 +2593,7 @@ __global__ __launch_bounds__(256) void k_dense_emit(DevAutomaton A, BatchArgs B,
             if (ev.n_ev > B.slab_events) B.overflow_list[atomicAdd(&B.counters[0], 1u)] = uint32_t(item);
         }
     }
+    wave_walk_whole<E, MODE>(A, B, nullptr, 0u, whole, rec, item, walked, fallback16);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         walked += __shfl_xor(walked, d, 64);
