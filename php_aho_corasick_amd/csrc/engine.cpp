@@ -96,6 +96,8 @@ struct acmi_handle {
     DevBuf d_merge_counts, d_merge_sync;
 
     // options
+    bool dense_output = false;   // the last batch produced a record per two bytes of text or more (which drain: refill_mode)
+    uint32_t slab_auto = 0;      // slots per item the data has asked for so far (automatic slab size, enqueue_batch)
     uint32_t slab_events = 16;   // (8 until round 3: an item with a ninth match went to the drain, one with a ninth candidate was walked whole)
     uint32_t run_cap = 16;
     bool slab_set = false;     // "slab_events" set by the caller; else the dense anchor form takes 32
@@ -190,6 +192,8 @@ struct acmi_handle {
         hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
         hipStream_t stream = nullptr;  // the stream this batch was enqueued on (acmi_set_stream is refused while batches are in flight)
         uint32_t anchor_variant = 0;   // template of k_scan_anchor that ran (acmi_get_stat "anchor_variant")
+        uint32_t slab_used = 0;        // event slots per item of this batch
+        uint64_t est_items = 0;
         bool refill_launched = false;  // the drain of overflowed items was enqueued with the pipeline (else: only if the batch turns out to need it)
         DevBuf d_prefix, d_out;        // valid from this batch's end until the second begin after its own
     };
@@ -385,6 +389,7 @@ int ensure_finalized(acmi_handle *h) {
         h->exact_only = true;
         h->exact_left = h->exact_span;
         h->refill_armed = true;   // (dense sets: the first batch will want its overflowed items drained)
+        h->dense_output = fa.est_flag_rate >= 0.5;   // (an event every other byte of the patterns' own alphabet: the wave drain from the first batch on)
     }
     // Split?  The set as a whole cannot use the anchor filter, but without its few short patterns it could.
     if (!h->is_part && h->split_opt != 0 && fa.anchor_q == 0 && h->kernel == 3) {
@@ -622,6 +627,12 @@ int ensure_device(acmi_handle *h) {
     return ACMI_OK;
 }
 
+// Which drain takes the items whose events overflowed their slabs: the caller's choice ("refill" 1 / 2), else the whole-item walk
+// again in its record-writing form for the batches that kernel scanned (mode 3), else launch_refill's own choice.
+// (not when the text answers with a record per two bytes or more -- a^1..a^16, every string over {a,b}: thousands of records
+// per item, which only the wave drain writes as whole rows; `dense_output` is what the batch before produced)
+int refill_mode(const acmi_handle *h, int kernel) { return h->refill != 0 ? h->refill : (kernel == 4 && !h->dense_output ? 3 : 0); }
+
 uint32_t choose_chunk(const acmi_handle *h, uint64_t blob_bytes, size_t nh, int kernel) {
     const uint32_t warm = h->aut.flat().max_pattern_length ? h->aut.flat().max_pattern_length - 1 : 0;
     if (h->chunk_opt) {
@@ -754,8 +765,24 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     F.kernel_used = kernel;
     const uint32_t chunk = choose_chunk(h, blob_bytes, nh, kernel);
     const uint64_t max_items = blob_bytes / chunk + nh;
-    // (event slots per item: the dense anchor form is for sets with a few matches per KiB of text)
-    const uint32_t K = (!h->slab_set && kernel == 2 && fa.anchor_dense) ? 32u : std::max<uint32_t>(1, h->slab_events);
+    // Event slots per item.  An item with more events than its slab holds is walked AGAIN by the drain, a wave per item, and
+    // for text with tens to hundreds of matches per item -- a word list over ordinary prose -- that costs ten times what a
+    // bigger slab does (tools/exp_kw_hits.py: 53 records per 8 KiB haystack 8.8 -> 1.1 ms per GiB, 200: 10.7 -> 3.1).  Unless the
+    // caller fixes the size, a handle starts small (16 slots, 32 with the dense anchor form) and LEARNS: a batch that sent more
+    // than 1 item in 64 to the drain quadruples the slabs of the batches after it (slab_auto, set at the batch's end) -- up to 256
+    // slots per item, half the batch's bytes (8 bytes a slot, the expected item count) and 2 GiB in all.
+    uint32_t K = std::max<uint32_t>(1, h->slab_events);
+    const uint64_t est_items = std::max<uint64_t>(1, std::max<uint64_t>(blob_bytes / chunk, nh));
+    if (!h->slab_set) {
+        const uint32_t base = (kernel == 2 && fa.anchor_dense) ? 32u : 16u;
+        uint64_t k = blob_bytes / 2 / (est_items * 8);
+        k = std::min<uint64_t>(k, (2ull << 30) / ((max_items + 328) * 8));
+        uint32_t kmax = base;
+        while (kmax * 2 <= k && kmax < 256) kmax *= 2;
+        K = std::min(std::max(base, h->slab_auto), kmax);
+    }
+    F.slab_used = K;
+    F.est_items = est_items;
     F.chunk_used = chunk;
 
     DevBuf &d_item_base = h->d_item_base[slot_index], &d_item_hay = h->d_item_hay[slot_index], &d_item_rec = h->d_item_rec[slot_index],
@@ -922,7 +949,7 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
                   h->d_isync[slot_index ^ 1].as<uint32_t>(), uint32_t((h->d_isync[slot_index ^ 1].cap & ~size_t(15)) / 4));
     h->isync_clean[slot_index ^ 1] = h->d_isync[slot_index ^ 1].p != nullptr;
     F.refill_launched = find_all && h->refill_armed;
-    if (F.refill_launched) launch_refill(h->dA, B, max_items, int(fa.entry_bytes), h->d_rec_base.as<uint64_t>(), F.d_out.p, cap, h->refill, st);
+    if (F.refill_launched) launch_refill(h->dA, B, max_items, int(fa.entry_bytes), h->d_rec_base.as<uint64_t>(), F.d_out.p, cap, refill_mode(h, kernel), st, int(fa.class_mode));
     F.sync_next = sync_next;
     F.sync_words = sync_words;
     HIPCHK(h, hipEventRecord(F.ev[4], st));  // (always: the end waits for THIS batch, not for the one queued behind it)
@@ -1025,6 +1052,8 @@ int run_batch_end(acmi_handle *h) {
     uint64_t total = pinned[1];
     h->items = pinned[2];
     h->overflow_items = n_ovf;
+    h->dense_output = total * 2 >= F.blob_bytes && F.blob_bytes != 0;
+    if (!h->slab_set && uint64_t(n_ovf) * 64 >= F.est_items && F.slab_used < 256u) h->slab_auto = std::max(h->slab_auto, std::min(256u, F.slab_used * 4u));
     h->walked_bytes = 0;  // counters[7..15]: k_scan_lds adds to [7], k_walk_runs spreads its workgroups over [8..15]
     for (int i = 7; i < 16; ++i) h->walked_bytes += uint64_t(pinned32[i]) * 16;
     h->fallback_bytes = F.kernel_used == 2 ? uint64_t(pinned32[7]) * 16 : 0;
@@ -1080,7 +1109,7 @@ int run_batch_end(acmi_handle *h) {
                               h->d_isync[slot_index].as<uint32_t>() + 1, false, st);
             if (F.find_all)
                 launch_refill(h->dA, F.args, F.max_items, int(fa.entry_bytes), h->d_rec_base.as<uint64_t>(),
-                              F.d_out.p, cap, h->refill, st);
+                              F.d_out.p, cap, refill_mode(h, F.kernel_used), st, int(fa.class_mode));
             HIPCHK(h, hipGetLastError());
             HIPCHK(h, hipStreamSynchronize(st));
         } else {

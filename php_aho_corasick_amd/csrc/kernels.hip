@@ -2661,15 +2661,33 @@ static hipError_t launch_verify_dense(const DevAutomaton &A, const BatchArgs &B,
 // two workgroups per CU share the 160 KiB: 79 KiB each, 512 B of it the byte classes
 constexpr uint32_t kItemsTileBytes = 78u * 1024u;
 
-template <typename E, int MODE, int LB>
-__global__ __launch_bounds__(kWalkThreads, (LB <= 4 ? 8 : 4)) void k_walk_items(DevAutomaton A, BatchArgs B) {
+__device__ __forceinline__ uint64_t emit_event(const DevAutomaton &A, uint4 *out, uint64_t w, uint32_t hay, uint32_t pos, uint32_t state);
+
+// EMIT: the same walk as the DRAIN of a batch this kernel scanned -- a thread per OVERFLOWED item (its events did not fit
+// the slab), records written straight into their final slots.  Items of <= 1 KiB are what this kernel is given, and at tens of
+// events per item a wave per item (k_refill_wave: a round of dependent loads per 256 positions) was five times slower than
+// walking them again one per thread (a word list over text made of its words: 14 -> 3.6 ms per GiB).
+template <typename E, int MODE, int LB, bool EMIT = false>
+__global__ __launch_bounds__(kWalkThreads, (LB <= 4 ? 8 : 4)) void k_walk_items(DevAutomaton A, BatchArgs B, const uint64_t *rec_base,
+                                                                                uint4 *out, uint64_t cap) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint64_t total_items = B.item_base[B.n_haystacks];
+    const uint64_t total_items = EMIT ? uint64_t(B.counters[0]) : B.item_base[B.n_haystacks];   // (EMIT: entries of the overflow list)
     if (uint64_t(blockIdx.x) * kWalkThreads >= total_items) return;
-    const uint64_t item = uint64_t(blockIdx.x) * kWalkThreads + threadIdx.x;
+    const uint64_t slot = uint64_t(blockIdx.x) * kWalkThreads + threadIdx.x;
+    const uint64_t item = EMIT ? (slot < total_items ? uint64_t(B.overflow_list[slot]) : 0ull) : slot;
     __shared__ uint32_t s_walked;
     if (threadIdx.x == 0) s_walked = 0;
-    const uint4 rec = item < total_items ? B.item_rec[item] : make_uint4(0u, 0u, 0u, 0u);
+    uint4 rec = slot < total_items ? B.item_rec[item] : make_uint4(0u, 0u, 0u, 0u);
+    uint64_t w = 0;
+    uint32_t hay = 0;
+    if constexpr (EMIT) {
+        if (slot < total_items && rec_base[item + 1] <= cap) {
+            w = rec_base[item];
+            hay = B.item_hay[item];
+        } else {
+            rec.z = 0u;   // (nothing to do: past the list, or the output buffer is too small -- the host grows it and launches again)
+        }
+    }
     // LDS: [512 B byte classes (TABLE mode)] [tile rows]
     const uint32_t cls_bytes = (MODE == 0) ? 512u : 0u;
     const uint32_t tile_rows = A.row_bytes ? (kItemsTileBytes / A.row_bytes < A.trap ? kItemsTileBytes / A.row_bytes : A.trap) : 0u;
@@ -2705,8 +2723,12 @@ __global__ __launch_bounds__(kWalkThreads, (LB <= 4 ? 8 : 4)) void k_walk_items(
         if (w >= A.trap) w = cold_step<E>(A, st, byte, coff);
         st = w;
         if (jj >= warm && is_final(A, st) && !(B.first_only && ev.n_ev)) {
-            ev.n_rec += st < cnt_rows ? cnt_lds[st] : A.out_count[st];
-            if (ev.n_ev < B.slab_events) B.slab[uint64_t(ev.n_ev) * B.run_stride + item] = make_uint2(pos_bias + jj, st);
+            if constexpr (EMIT) {
+                w = emit_event(A, out, w, hay, pos_bias + jj, st);
+            } else {
+                ev.n_rec += st < cnt_rows ? cnt_lds[st] : A.out_count[st];
+                if (ev.n_ev < B.slab_events) B.slab[uint64_t(ev.n_ev) * B.run_stride + item] = make_uint2(pos_bias + jj, st);
+            }
             ++ev.n_ev;
         }
     };
@@ -2746,6 +2768,7 @@ __global__ __launch_bounds__(kWalkThreads, (LB <= 4 ? 8 : 4)) void k_walk_items(
     for (; j + 16u <= n; j += 16u) step_block(*reinterpret_cast<const uint4 *>(p + j), j);
     for (; j < n; ++j) step(p[j], j);
 
+    if constexpr (EMIT) return;
     uint32_t walked = n;
     if (ev.n_ev) {
         B.ev_count[item] = ev.n_ev;
@@ -2767,7 +2790,8 @@ hipError_t launch_walk_items(const DevAutomaton &A, const BatchArgs &B, uint64_t
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return e;
         const uint32_t blocks = uint32_t((max_items + kWalkThreads - 1) / kWalkThreads);
-        hipLaunchKernelGGL(fn, dim3(blocks), dim3(kWalkThreads), lds, st, A, B);
+        hipLaunchKernelGGL(fn, dim3(blocks), dim3(kWalkThreads), lds, st, A, B, static_cast<const uint64_t *>(nullptr), static_cast<uint4 *>(nullptr),
+                           uint64_t(0));
         return hipGetLastError();
     };
     // group = 16-byte blocks a lane requests back to back: 1 (the first version), 4 or 8 (a whole line)
@@ -3924,8 +3948,19 @@ void launch_expand(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items
 }
 
 void launch_refill(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes,
-                   const uint64_t *rec_base, void *out, uint64_t cap, int mode, hipStream_t st) {
+                   const uint64_t *rec_base, void *out, uint64_t cap, int mode, hipStream_t st, int class_mode) {
     if (max_items == 0) return;
+    if (mode == 3) {   // a batch of k_walk_items: the same walk again, a thread per overflowed item, writing records
+        const uint32_t lds = kItemsTileBytes + (class_mode == 0 ? 512u : 0u);
+        const uint32_t blocks = uint32_t((max_items + kWalkThreads - 1) / kWalkThreads);   // (workgroups past the list's end leave at once)
+        auto go = [&](auto fn) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+            hipLaunchKernelGGL(fn, dim3(blocks), dim3(kWalkThreads), lds, st, A, B, rec_base, static_cast<uint4 *>(out), cap);
+        };
+        if (entry_bytes == 2) { if (class_mode == 1) go(k_walk_items<uint16_t, 1, 4, true>); else go(k_walk_items<uint16_t, 0, 4, true>); }
+        else { if (class_mode == 1) go(k_walk_items<uint32_t, 1, 4, true>); else go(k_walk_items<uint32_t, 0, 4, true>); }
+        return;
+    }
     // mode 0: the wave kernel unless a lane's (Lmax-1)-byte warm-up would dwarf its kRefillS positions
     const bool wave = mode == 2 || (mode == 0 && A.max_pattern_length <= 64u);
     if (wave) {

@@ -27,7 +27,7 @@ void launch_expand(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items
                    uint32_t *ticket, uint64_t *status, const uint32_t *bad_offsets, bool scan, hipStream_t st,
                    uint32_t *next_isync = nullptr, uint32_t next_isync_words = 0);
 void launch_refill(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes,
-                   const uint64_t *rec_base, void *out, uint64_t cap, int mode, hipStream_t st);
+                   const uint64_t *rec_base, void *out, uint64_t cap, int mode, hipStream_t st, int class_mode = 0);
 // one-launch path for small host batches (<= 64 KiB, <= 1024 haystacks): reads / writes pinned host memory
 constexpr uint32_t kSmallPathMaxBytes = 64u * 1024u, kSmallPathMaxHay = 1024u;
 hipError_t launch_match_small(const DevAutomaton &A, const uint64_t *offsets, const uint8_t *blob, uint32_t nh, int find_all,
