@@ -847,7 +847,7 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     // on everything else (short items, last chunks, the 513th quad of an 8-KiB haystack that starts unaligned)
     const bool regular = blob_bytes % nh == 0 && (blob_bytes / nh) % 8192 == 0 && (reinterpret_cast<uintptr_t>(d_blob) & 15u) == 0;
     B.short_items = kernel != 2 ? 0u : h->short_rows >= 0 ? uint32_t(h->short_rows) : (regular ? 0u : 1u);
-    B.tiny_items = (kernel == 2 && h->tiny_rows != 0 && blob_bytes / nh <= 1024) ? 1u : 0u;
+    B.tiny_items = (kernel == 2 && h->tiny_rows != 0 && blob_bytes / nh <= 2048) ? 1u : 0u;   // (waves whose items do not all fit a row take the usual path: the average may be skewed by a few long haystacks)
     B.slab_events = K;
     B.first_only = find_all ? 0u : 1u;
     B.item_hay = d_item_hay.as<uint32_t>();
