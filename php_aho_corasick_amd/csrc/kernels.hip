@@ -2678,11 +2678,11 @@ __global__ __launch_bounds__(kWalkThreads, (LB <= 4 ? 8 : 4)) void k_walk_items(
     __shared__ uint32_t s_walked;
     if (threadIdx.x == 0) s_walked = 0;
     uint4 rec = slot < total_items ? B.item_rec[item] : make_uint4(0u, 0u, 0u, 0u);
-    uint64_t w = 0;
+    uint64_t wr = 0;   // EMIT: where the item's next record goes
     uint32_t hay = 0;
     if constexpr (EMIT) {
         if (slot < total_items && rec_base[item + 1] <= cap) {
-            w = rec_base[item];
+            wr = rec_base[item];
             hay = B.item_hay[item];
         } else {
             rec.z = 0u;   // (nothing to do: past the list, or the output buffer is too small -- the host grows it and launches again)
@@ -2724,7 +2724,7 @@ __global__ __launch_bounds__(kWalkThreads, (LB <= 4 ? 8 : 4)) void k_walk_items(
         st = w;
         if (jj >= warm && is_final(A, st) && !(B.first_only && ev.n_ev)) {
             if constexpr (EMIT) {
-                w = emit_event(A, out, w, hay, pos_bias + jj, st);
+                wr = emit_event(A, out, wr, hay, pos_bias + jj, st);
             } else {
                 ev.n_rec += st < cnt_rows ? cnt_lds[st] : A.out_count[st];
                 if (ev.n_ev < B.slab_events) B.slab[uint64_t(ev.n_ev) * B.run_stride + item] = make_uint2(pos_bias + jj, st);

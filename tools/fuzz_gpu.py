@@ -50,6 +50,12 @@ for case in range(n_cases):
             p, rr = path(res, ds, find_all)
             if not (np.array_equal(p, pe) and np.array_equal(rr, re_)):
                 bad += 1
+                if os.environ.get("FUZZ_VERBOSE"):
+                    k = 0
+                    while k < min(len(rr), len(re_)) and (rr[k] == re_[k]).all():
+                        k += 1
+                    print("  first difference at record", k, "got", rr[max(0, k - 1):k + 4].tolist(), "expected", re_[max(0, k - 1):k + 4].tolist(),
+                          "prefix equal", bool(np.array_equal(p, pe)), flush=True)
                 print("MISMATCH", seed, opts, dict(alpha=alpha, lmin=lmin, lmax=lmax, n_pat=n_pat, n_hay=n_hay, hmax=hmax,
                                                    plants=plants, calls=calls), find_all, path.__name__, len(rr), len(re_), flush=True)
     api.ahocorasick_deinit(res)
