@@ -267,7 +267,7 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
 /* Integer options, set before finalize unless noted:
  *   "lds_bytes"      LDS budget for the hot-state tile (default 160 KiB minus slack)
  *   "slab_events"    per work-item event slots before the overflow path (default: learned -- 16, or 32 with the dense anchor form, quadrupled after a batch that sent more than 1 item in 64 to the drain, up to 256 per item, half the batch's bytes and 2 GiB in all)
- *   "run_cap"        per work-item fix-up runs before the item is rescanned whole (default 16; the dense anchor form: 256 entries of 4 bytes)
+ *   "run_cap"        per work-item fix-up runs before the item is rescanned whole (default: learned -- 16, quadrupled up to 64 after a batch whose filter lost to overflowed run lists; the dense anchor form: 256 entries of 4 bytes)
  *   "chunk_bytes"    force the work-item size (0 = automatic)            [any time]
  *   "kernel"         0 = plain global-table walk, 1 = LDS-tile table walk, 2 = anchor q-gram
  *                    filter + exact table walk of the candidates (needs a shortest pattern

@@ -97,6 +97,7 @@ struct acmi_handle {
 
     // options
     bool dense_output = false;   // the last batch produced a record per two bytes of text or more (which drain: refill_mode)
+    uint32_t run_auto = 0;       // run-list entries per item the data has asked for so far
     uint32_t slab_auto = 0;      // slots per item the data has asked for so far (automatic slab size, enqueue_batch)
     uint32_t slab_events = 16;   // (8 until round 3: an item with a ninth match went to the drain, one with a ninth candidate was walked whole)
     uint32_t run_cap = 16;
@@ -143,7 +144,7 @@ struct acmi_handle {
     DevBuf d_table, d_lds, d_class, d_own, d_dict, d_cnt, d_plen, d_anchor, d_bitmap, d_out_off, d_out_list, d_cold_rec, d_cold_edges, d_chain_byte, d_chain_run, d_slot_pair, d_pairs, d_pat_bytes, d_dense_img;
 
     // workspace (grow-only)
-    DevBuf d_blob, d_off, d_rec_base, d_slab, d_ovf, d_counters, d_runs, d_run_count;
+    DevBuf d_blob, d_off, d_rec_base, d_slab, d_ovf, d_counters, d_runs, d_run_count, d_first;
     // The item table of a batch (item_base, item -> haystack, packed item records, zeroed per-item counters, k_items' own sync
     // words) exists once per slot: k_items needs nothing from the batch before, so with "items_ahead" it runs on a side stream
     // while that batch's scan is still on the chip, and the pipeline proper waits for its event.
@@ -194,6 +195,7 @@ struct acmi_handle {
         uint32_t anchor_variant = 0;   // template of k_scan_anchor that ran (acmi_get_stat "anchor_variant")
         uint32_t slab_used = 0;        // event slots per item of this batch
         uint64_t est_items = 0;
+        uint32_t run_used = 0, run_max = 0;   // run-list entries per item of this batch; what it could have had
         bool refill_launched = false;  // the drain of overflowed items was enqueued with the pipeline (else: only if the batch turns out to need it)
         DevBuf d_prefix, d_out;        // valid from this batch's end until the second begin after its own
     };
@@ -826,7 +828,13 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     HIPCHK(h, h->d_ovf.ensure_keep(max_items * 4, h->retired));
     // dense anchor form: hit windows per item by the dozen -- 4-byte entries, 256 of them unless the caller says otherwise
     const bool dense = kernel == 2 && fa.anchor_dense != 0;
-    const uint32_t Q = (!h->run_cap_set && dense) ? 256u : std::max<uint32_t>(1, h->run_cap);
+    // (run lists learn like the slabs: 16 entries, quadrupled -- up to 64 and an eighth of the batch's bytes -- after a batch
+    // whose filter lost because items overflowed them, before the automatic choice gives the filter up: run_batch_end)
+    uint32_t run_max = 16;
+    while (run_max < 64u && uint64_t(run_max) * 2 * 16 * est_items * 8 <= blob_bytes) run_max *= 2;
+    const uint32_t Q = h->run_cap_set ? std::max<uint32_t>(1, h->run_cap) : dense ? 256u : std::min(std::max(16u, h->run_auto), run_max);
+    F.run_used = Q;
+    F.run_max = (h->run_cap_set || dense) ? Q : run_max;
     HIPCHK(h, h->d_runs.ensure_keep(run_stride * Q * (dense ? 8 : 16), h->retired));   // (dense: window starts, then k_dense_decide's results)
     HIPCHK(h, h->d_run_count.ensure_keep(max_items * 4, h->retired));
     uint8_t *zero = d_zero.as<uint8_t>();
@@ -935,7 +943,11 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     if (kernel == 2) HIPCHK(h, launch_walk_runs(h->dA, B, max_items, int(fa.entry_bytes), int(fa.class_mode), st));
     if (h->profile > 1) HIPCHK(h, hipEventRecord(F.ev[3], st));
 
-    if (!find_all) launch_first_only(B, st);
+    if (!find_all) {
+        HIPCHK(h, h->d_first.ensure_keep(nh * 4, h->retired));
+        HIPCHK(h, hipMemsetAsync(h->d_first.p, 0xFF, nh * 4, st));
+        launch_first_only(B, h->d_first.as<uint32_t>(), max_items, st);
+    }
 
     // Expansion is enqueued optimistically with the output capacity of the previous call, so the
     // whole pipeline needs ONE host synchronisation (the read-back of the summary at the end).  Only
@@ -1065,7 +1077,9 @@ int run_batch_end(acmi_handle *h) {
     // matches keeps the anchor kernel.)
     const bool decisive = h->kernel == 3 && F.blob_bytes >= kAutoMinBytes;
     if (decisive && F.kernel_used == 2) {
-        if (h->fallback_bytes * 4 > F.blob_bytes) {
+        if (h->fallback_bytes * 4 > F.blob_bytes && F.run_used < F.run_max) {
+            h->run_auto = F.run_used * 4;   // (longer run lists first: the next batch shows whether that was it)
+        } else if (h->fallback_bytes * 4 > F.blob_bytes) {
             h->anchor_off = true;
             h->anchor_left = h->anchor_span;
             h->anchor_span = std::min<uint32_t>(h->anchor_span * 2, 1024);
@@ -1298,7 +1312,7 @@ int acmi_destroy(acmi_handle *h) {
             for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_out_off, &h->d_out_list, &h->d_cold_rec, &h->d_cold_edges, &h->d_chain_byte, &h->d_chain_run, &h->d_slot_pair, &h->d_pairs, &h->d_pat_bytes, &h->d_dense_img, &h->d_merge_counts, &h->d_merge_sync, &h->d_rep_off, &h->d_rep_bytes, &h->d_plan, &h->d_plan_out, &h->d_tail_out, &h->d_rep_sync, &h->d_nom_count, &h->d_out_len, &h->d_rep_out_off, &h->d_rep_out, &h->d_blob,
                               &h->d_off, &h->d_sync[0], &h->d_sync[1], &h->d_item_base[0], &h->d_item_hay[0], &h->d_item_rec[0], &h->d_zero[0], &h->d_isync[0],
                               &h->d_item_base[1], &h->d_item_hay[1], &h->d_item_rec[1], &h->d_zero[1], &h->d_isync[1],
-                              &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->fly[0].d_prefix, &h->fly[0].d_out, &h->fly[1].d_prefix, &h->fly[1].d_out, &h->d_runs, &h->d_run_count})
+                              &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_first, &h->fly[0].d_prefix, &h->fly[0].d_out, &h->fly[1].d_prefix, &h->fly[1].d_out, &h->d_runs, &h->d_run_count})
                 b->release();
             for (void *q : h->retired) (void)hipFree(q);
             for (auto &evt : h->ev)

@@ -15,7 +15,7 @@
 //     k_scan_lds                                       otherwise: optimistic LDS-tile table walk, flagged
 //                                                      byte runs walked exactly in its dense epilogue
 //                                                      events -> per-item slabs
-//   k_first_only   (findAll == false)                  keep only the first event per haystack
+//   k_first_only_* (findAll == false)                  keep only the first event per haystack
 //   k_tile_sums + k_tile_scan of per-item record counts -> record base of every item
 //   k_hay_prefix                                       -> per-haystack prefix array + batch summary
 //   k_expand                                           slab events -> records (callback order)
@@ -2804,14 +2804,25 @@ hipError_t launch_walk_items(const DevAutomaton &A, const BatchArgs &B, uint64_t
 // ------------------------------------------------------------------------------------------
 // findAll == false: keep the first event of the first item (per haystack) that has one
 // ------------------------------------------------------------------------------------------
-__global__ void k_first_only(BatchArgs B) {
-    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= B.n_haystacks) return;
-    bool found = false;
-    for (uint64_t i = B.item_base[h]; i < B.item_base[h + 1]; ++i) {
-        if (found) { B.ev_count[i] = 0; B.rec_count[i] = 0; }
-        else if (B.ev_count[i]) found = true;
-    }
+// Item-parallel, two launches: the first item with an event per haystack by atomicMin, then everything behind it dropped.  (A
+// thread per HAYSTACK looping over its items took 5.8 ms on a batch with one 256-MiB haystack: 32,768 items behind one thread.)
+__global__ void k_first_only_mark(BatchArgs B, uint32_t *first_item) {
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= B.item_base[B.n_haystacks]) return;
+    // (a long haystack's items all name the same word: an item behind what is recorded already says nothing, and a wave whose
+    // lanes share the haystack sends its smallest candidate only -- 33,000 same-address atomics were 0.4 ms a haystack)
+    const uint32_t hay = B.item_hay[i];
+    const bool cand = B.ev_count[i] != 0 && first_item[hay] > uint32_t(i);
+    const uint64_t who = __ballot(cand);
+    if (who == 0) return;
+    const uint32_t lead = uint32_t(__builtin_ctzll(who));   // the wave's first candidate: items ascend with the lane
+    const uint32_t hay0 = uint32_t(__builtin_amdgcn_readlane(int(hay), int(lead)));
+    if (cand && (hay != hay0 || (threadIdx.x & 63u) == lead)) atomicMin(&first_item[hay], uint32_t(i));
+}
+__global__ void k_first_only_drop(BatchArgs B, const uint32_t *first_item) {
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= B.item_base[B.n_haystacks]) return;
+    if (B.ev_count[i] && first_item[B.item_hay[i]] != uint32_t(i)) { B.ev_count[i] = 0; B.rec_count[i] = 0; }
 }
 
 // Expand one event into records, longest pattern first (node.c:424-441 order).
@@ -3929,9 +3940,11 @@ hipError_t launch_scan(const DevAutomaton &A, const BatchArgs &B, uint64_t max_i
                            : launch_lds_m<uint32_t, 0>(A, B, max_items, lds, ilp, group_quads, st);
 }
 
-void launch_first_only(const BatchArgs &B, hipStream_t st) {
-    if (B.n_haystacks == 0) return;
-    hipLaunchKernelGGL(k_first_only, dim3((B.n_haystacks + 255) / 256), dim3(256), 0, st, B);
+void launch_first_only(const BatchArgs &B, uint32_t *first_item, uint64_t max_items, hipStream_t st) {   // first_item: n_haystacks words of 0xFFFFFFFF
+    if (B.n_haystacks == 0 || max_items == 0) return;
+    const uint32_t blocks = uint32_t((max_items + 255) / 256);
+    hipLaunchKernelGGL(k_first_only_mark, dim3(blocks), dim3(256), 0, st, B, first_item);
+    hipLaunchKernelGGL(k_first_only_drop, dim3(blocks), dim3(256), 0, st, B, static_cast<const uint32_t *>(first_item));
 }
 
 void launch_expand(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, uint64_t *rec_base, void *out,

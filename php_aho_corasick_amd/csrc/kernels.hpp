@@ -20,7 +20,7 @@ hipError_t launch_walk_runs(const DevAutomaton &A, const BatchArgs &B, uint64_t 
                             hipStream_t st);
 hipError_t launch_walk_items(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,
                              int ilp, hipStream_t st);
-void launch_first_only(const BatchArgs &B, hipStream_t st);
+void launch_first_only(const BatchArgs &B, uint32_t *first_item, uint64_t max_items, hipStream_t st);
 // scan = true: also the exclusive scan of the per-item record counts (ticket / status: zeroed sync words); false: rec_base is read
 void launch_expand(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, uint64_t *rec_base, void *out,
                    uint64_t cap, uint64_t *prefix, uint32_t *host_counters, uint32_t *next_sync, uint32_t next_sync_words,

@@ -15,14 +15,15 @@ from php_aho_corasick_amd import batch, synth  # noqa: E402
 plants = [int(a) for a in sys.argv[1:] if "=" not in a] or [1, 4, 8, 9, 16, 64]
 opts = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
 HL, TILE, NH = 8192, 4096, int(os.environ.get("EXP_NH", 1 << 17))
+BIG = os.environ.get("EXP_SET") == "cfg3"   # the 65,536-pattern set of BASELINE configs[2] (random bytes) instead of the headline's
 for P in plants:
-    ds = synth.generate("L", 1, 2048, 16, 16, TILE, HL, b"abcdef")
+    ds = synth.g6(n_hay=TILE, hay_len=HL) if BIG else synth.generate("L", 1, 2048, 16, 16, TILE, HL, b"abcdef")
     r = np.random.default_rng(7)
     for h in range(TILE):
         for k in range(P):
             pat = np.frombuffer(ds.pattern(int(r.integers(ds.n_patterns))), dtype=np.uint8)
-            at = int(ds.hay_off[h]) + (HL // P) * k + int(r.integers(0, max(1, HL // P - 16)))
-            ds.hay_blob[at:at + 16] = pat
+            at = int(ds.hay_off[h]) + (HL // P) * k + int(r.integers(0, max(1, HL // P - len(pat))))
+            ds.hay_blob[at:at + len(pat)] = pat
     res = api.ahocorasick_init([{"id": k, "value": ds.pattern(k)} for k in range(ds.n_patterns)])
     for k, v in opts.items():
         res.set_option(k, int(v))

@@ -21,17 +21,18 @@ shapes = {
     "786432 x 1 KiB + 1 x 256 MiB": torch.cat([torch.arange(786432 + 1, dtype=torch.int64) * 1024, torch.tensor([total_bytes], dtype=torch.int64)]),
     "4 x 256 MiB": torch.arange(5, dtype=torch.int64) * (256 << 20),
 }
+FIND_ALL = os.environ.get("EXP_FIND_ALL", "1") != "0"
 for name, off in shapes.items():
     res = api.ahocorasick_init(pats)
     d_off = off.cuda()
     batch.bind_current_stream(res)
     for _ in range(3):
-        total = batch.match_device(res, d_blob, d_off)
+        total = batch.match_device(res, d_blob, d_off, FIND_ALL)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     n = 5
     for _ in range(n):
-        total = batch.match_device(res, d_blob, d_off)
+        total = batch.match_device(res, d_blob, d_off, FIND_ALL)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     res.set_option("profile", 2)
