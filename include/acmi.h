@@ -327,7 +327,9 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *                    in-alphabet text), 2 = always                                        [any time]
  *   "refill"         drain of work items whose events overflowed their slab (dense-match inputs):
  *                    1 = one thread per item, 2 = one wave per item with whole-row record stores,
- *                    0 = automatic (default): 2 unless the longest pattern exceeds 64 B   [any time]
+ *                    0 = automatic (default): batches scanned by the whole-item walk (items of <= 1 KiB) are drained by the
+ *                    same walk writing records, a thread per item, unless the output is dense (a record per two bytes of
+ *                    text or more); else 2 unless the longest pattern exceeds 64 B   [any time]
  *   "items_ahead"    1: a batch's work-item table (k_items: it needs the offsets only) is built on a second stream of the handle,
  *                    behind the scan kernel of the batch begun before it, next to that batch's candidate walk and expansion,
  *                    and the batch's pipeline waits for it.  (Measured on the headline batch: no gain -- the small kernels do
