@@ -2428,12 +2428,17 @@ constexpr uint32_t kDenseNone = 0xFFFFFFFFu, kDenseMany = 0xFFFFFFFEu;
 // its record index -- or kDenseMany -- behind the lists; run_count[item] becomes the number found.  Most hit windows hold
 // nothing (a keyword list: nine in ten are a word's first four letters and no more), so k_dense_emit is left with a
 // handful of entries per item.
+// IMG = false (sets the LDS image does not hold: more than 4,096 patterns, patterns over 16 B): the same pass as a FILTER --
+// a window is kept when the text compare through the global tables (verify_candidate) finds an occurrence or cannot decide,
+// marked kDenseMany, and k_dense_emit decides the few that are left again.  One thread per item deciding its hundreds of
+// windows one after the other (k_verify_dense) took 1.1 ms per GiB for 8,192 words.
+template <bool IMG>
 __global__ __launch_bounds__(1024) void k_dense_decide(DevAutomaton A, BatchArgs B, uint32_t *found_idx) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint64_t total_items = B.item_base[B.n_haystacks];
     const uint32_t Q = B.run_cap;
     if (uint64_t(blockIdx.x) * 16u >= total_items) return;
-    {   // the image is staged once per workgroup; the workgroups are persistent (a few per CU) and stride over the items
+    if constexpr (IMG) {   // the image is staged once per workgroup; the workgroups are persistent (a few per CU) and stride over the items
         const uint4 *src = reinterpret_cast<const uint4 *>(A.dense_image);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
         const uint32_t n16 = A.dense_image_words >> 2;
@@ -2441,9 +2446,9 @@ __global__ __launch_bounds__(1024) void k_dense_decide(DevAutomaton A, BatchArgs
     }
     __syncthreads();
     const uint32_t *img = reinterpret_cast<const uint32_t *>(smem);
-    const uint32_t mask = img[0];
-    const uint32_t *ht = img + img[1], *recs = img + img[2], *tails = img + img[3];
-    const uint32_t hmul = img[5];
+    const uint32_t mask = IMG ? img[0] : 0u;
+    const uint32_t *ht = IMG ? img + img[1] : nullptr, *recs = IMG ? img + img[2] : nullptr, *tails = IMG ? img + img[3] : nullptr;
+    const uint32_t hmul = IMG ? img[5] : 0u;
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t *starts_all = reinterpret_cast<uint32_t *>(B.runs);
     for (uint64_t item = uint64_t(blockIdx.x) * 16u + (threadIdx.x >> 6); item < total_items; item += uint64_t(gridDim.x) * 16u) {
@@ -2462,6 +2467,14 @@ __global__ __launch_bounds__(1024) void k_dense_decide(DevAutomaton A, BatchArgs
             const bool active = r < nr;
             const uint32_t start = active ? starts[r] : 0u;
             uint32_t out = kDenseNone;
+            if constexpr (!IMG) {
+                if (active) {
+                    Verified v[kClusterMax];
+                    uint32_t nv = 0;
+                    const bool decided = verify_candidate(A, p, n, it.floor, start, v, nv);
+                    if (!decided || nv != 0) out = kDenseMany;
+                }
+            } else
             if (active) {
                 if (start + 16u > n) {
                     out = start + 4u <= n ? kDenseMany : kDenseNone;   // (decided by k_dense_emit, which reads single bytes)
@@ -2525,8 +2538,8 @@ __global__ __launch_bounds__(256) void k_dense_emit(DevAutomaton A, BatchArgs B,
         const uint32_t n = it.warm + it.len;
         const uint32_t pos_bias = it.pos0 - it.warm + 1u;
         const uint32_t m_min = A.min_pattern_length, l_max = A.max_pattern_length;
-        const uint32_t *img = A.dense_image;              // (records read through the cache: a few KiB, shared by everyone)
-        const uint32_t *recs = img + img[2];
+        const uint32_t *img = A.dense_image;              // (records read through the cache: a few KiB, shared by everyone; none: every
+        const uint32_t *recs = img ? img + img[2] : nullptr;   //  kept window is marked kDenseMany)
         EventRegs ev{0, 0};
         if (nf > B.run_cap && !B.first_only) {
             whole = true;   // (the wave walks it together, below: wave_walk_whole)
@@ -2609,15 +2622,18 @@ __global__ __launch_bounds__(256) void k_dense_emit(DevAutomaton A, BatchArgs B,
 static hipError_t launch_verify_dense(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,
                                       hipStream_t st) {
     const uint32_t blocks = uint32_t((max_items + kWalkThreads - 1) / kWalkThreads);
-    if (A.dense_image != nullptr) {
+    if (A.dense_image != nullptr || A.anchor_pairs != nullptr) {
         // results live behind the window lists in the same buffer (engine.cpp sizes it: 8 bytes per window slot)
         uint32_t *results = reinterpret_cast<uint32_t *>(B.runs) + B.run_stride * uint64_t(B.run_cap);
-        const uint32_t lds1 = A.dense_image_words * 4u;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_decide), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds1));
+        const bool image = A.dense_image != nullptr;
+        const uint32_t lds1 = image ? A.dense_image_words * 4u : 16u;
+        hipError_t e = image ? hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_decide<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds1))
+                             : hipSuccess;
         if (e != hipSuccess) return e;
         const uint32_t per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(2u, (160u * 1024u) / std::max<uint32_t>(lds1, 1u)));
         const uint64_t blocks1 = std::min<uint64_t>((max_items + 15) / 16, uint64_t(num_cus()) * per_cu);
-        hipLaunchKernelGGL(k_dense_decide, dim3(uint32_t(blocks1)), dim3(1024), lds1, st, A, B, results);
+        if (image) hipLaunchKernelGGL(k_dense_decide<true>, dim3(uint32_t(blocks1)), dim3(1024), lds1, st, A, B, results);
+        else hipLaunchKernelGGL(k_dense_decide<false>, dim3(uint32_t(blocks1)), dim3(1024), lds1, st, A, B, results);
         const uint32_t blocks2 = uint32_t((max_items + 255) / 256);
         if (entry_bytes == 2) {
             if (class_mode == 1) hipLaunchKernelGGL((k_dense_emit<uint16_t, 1>), dim3(blocks2), dim3(256), 0, st, A, B, results);
