@@ -1077,9 +1077,11 @@ int run_batch_end(acmi_handle *h) {
     // matches keeps the anchor kernel.)
     const bool decisive = h->kernel == 3 && F.blob_bytes >= kAutoMinBytes;
     if (decisive && F.kernel_used == 2) {
-        if (h->fallback_bytes * 4 > F.blob_bytes && F.run_used < F.run_max) {
-            h->run_auto = F.run_used * 4;   // (longer run lists first: the next batch shows whether that was it)
+        if (h->fallback_bytes * 64 > F.blob_bytes && F.run_used < F.run_max) {
+            h->run_auto = F.run_used * 4;   // (longer run lists first -- from 1 item in 64 walked whole on: the next batch shows whether that was it)
         } else if (h->fallback_bytes * 4 > F.blob_bytes) {
+            // (also for the compact automata of big pattern sets, whose table walk is slow -- 9 ms per GiB for 65,536 patterns: a
+            // filter whose items are all walked whole by their waves and drained again is ten times slower still, measured)
             h->anchor_off = true;
             h->anchor_left = h->anchor_span;
             h->anchor_span = std::min<uint32_t>(h->anchor_span * 2, 1024);
