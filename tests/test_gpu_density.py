@@ -1,0 +1,97 @@
+"""Many matches per haystack: items whose run lists or event slabs overflow, the sizes a handle learns from its
+data, the drains that write such items' records, and findAll = false on haystacks of many work items -- all record for record
+against the oracle.  Needs an MI355X: -m gpu."""
+import numpy as np
+import pytest
+
+from gpu_util import device_match, resource_for
+from oracle.pyoracle import Oracle
+from php_aho_corasick_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _planted(n_hay, hay_len, per_hay, seed=3, n_pat=2048, plen=16, alpha=b"abcdef"):
+    """Headline-like set over `n_hay` haystacks with `per_hay` occurrences planted in each."""
+    ds = synth.generate("D", seed, n_pat, plen, plen, n_hay, hay_len, alpha)
+    r = np.random.default_rng(seed)
+    for h in range(n_hay):
+        for k in range(per_hay):
+            p = np.frombuffer(ds.pattern(int(r.integers(n_pat))), dtype=np.uint8)
+            at = int(ds.hay_off[h]) + (hay_len // per_hay) * k + int(r.integers(0, max(1, hay_len // per_hay - plen)))
+            ds.hay_blob[at:at + plen] = p
+    return ds
+
+
+def _oracle(ds, find_all=True):
+    o = Oracle("port")
+    o.add_patterns((ds.pat_blob, ds.pat_off))
+    out = o.match_batch(ds.hay_blob, ds.hay_off, find_all)
+    o.close()
+    return out
+
+
+@pytest.mark.parametrize("per_hay", [6, 17, 40, 100])
+def test_many_candidates_per_item_through_the_filter(per_hay):
+    """More candidate windows per 8-KiB item than the first run lists (16) and slabs hold: the items are walked by their waves and
+    drained, and the handle's lists and slabs grow for the calls after -- same records every time."""
+    ds = _planted(512, 8192, per_hay)
+    pe, re_ = _oracle(ds)
+    res = resource_for(ds)
+    overflow = []
+    for _ in range(4):
+        p, r = device_match(res, ds)
+        assert np.array_equal(p, pe) and np.array_equal(r, re_)
+        overflow.append(int(res.stat("overflow_items")))
+    if per_hay <= 40:   # what the lists (<= 64) and slabs (<= 256) can learn to hold
+        assert overflow[-1] == 0 and res.stat("kernel_used") == 2, overflow
+    if 17 <= per_hay <= 40:
+        assert overflow[0] > 0, overflow
+    api.ahocorasick_deinit(res)
+
+
+@pytest.mark.parametrize("kernel", [1, 4])
+def test_event_slabs_learn_their_size(kernel):
+    """Dense-ish text through the table-walk kernels: the first call sends most items to the drain, later calls none (the slabs
+    grew), and a caller who fixes `slab_events` keeps the drain -- same records all along."""
+    ds = _planted(256, 8192, 200, seed=5, n_pat=64, plen=12, alpha=b"ab")   # ~ 80 events per 2-KiB work item
+    pe, re_ = _oracle(ds)
+    res = resource_for(ds, kernel=kernel, chunk_bytes=2048)   # (slabs may take half the batch's bytes: 128 slots for such items)
+    seen = []
+    for _ in range(5):
+        p, r = device_match(res, ds)
+        assert np.array_equal(p, pe) and np.array_equal(r, re_)
+        seen.append(int(res.stat("overflow_items")))
+    assert seen[0] > 0 and seen[-1] < seen[0], seen
+    api.ahocorasick_deinit(res)
+    res = resource_for(ds, kernel=kernel, chunk_bytes=2048, slab_events=2)
+    for _ in range(3):
+        p, r = device_match(res, ds)
+        assert np.array_equal(p, pe) and np.array_equal(r, re_)
+        assert res.stat("overflow_items") > 0
+    api.ahocorasick_deinit(res)
+
+
+@pytest.mark.parametrize("kernel", [1, 2, 4])
+def test_find_first_on_haystacks_of_many_items(kernel):
+    """findAll = false: the first event of every haystack, also when the haystack is cut into hundreds of work items and its
+    first match lies deep inside it (the filter that keeps a haystack's first item is item-parallel)."""
+    lens = [200_000, 0, 5, 90_000, 17, 300_000, 64, 1]
+    r = np.random.default_rng(9)
+    pats = [bytes(r.choice(np.frombuffer(b"abcdef", dtype=np.uint8), size=16).tolist()) for _ in range(300)]
+    hays = []
+    for n in lens:
+        t = r.choice(np.frombuffer(b"abcdef", dtype=np.uint8), size=n).astype(np.uint8)
+        for at in range(int(n * 0.6), n - 16, 9000):   # first occurrence 60 % into the haystack, more behind it
+            t[at:at + 16] = np.frombuffer(pats[int(r.integers(len(pats)))], dtype=np.uint8)
+        hays.append(t.tobytes())
+    pb, po = synth.pack(pats)
+    hb, ho = synth.pack(hays)
+    ds = synth.Dataset("first", pb, po, hb, ho)
+    for find_all in (False, True):
+        pe, re_ = _oracle(ds, find_all)
+        res = resource_for(ds, kernel=kernel, chunk_bytes=1024)
+        for _ in range(2):
+            p, rr = device_match(res, ds, find_all)
+            assert np.array_equal(p, pe) and np.array_equal(rr, re_)
+        api.ahocorasick_deinit(res)
