@@ -1085,6 +1085,13 @@ int run_batch_end(acmi_handle *h) {
             h->anchor_off = true;
             h->anchor_left = h->anchor_span;
             h->anchor_span = std::min<uint32_t>(h->anchor_span * 2, 1024);
+        } else if (!fa.compact && !fa.anchor_dense && total * 160 > F.blob_bytes) {
+            // More than ~ 50 matches per 8 KiB: the aligned filter flags its hits one by one through the scalar unit and checks
+            // its candidates 64 to a thread -- 3.2 ms per GiB at 64 per haystack against 1.8 for the whole-item walk of a small
+            // automaton (tools/exp_hits.py).  (Not for compact automata, whose walk costs 9 ms per GiB.)
+            h->anchor_off = true;
+            h->anchor_left = h->anchor_span;
+            h->anchor_span = std::min<uint32_t>(h->anchor_span * 2, 1024);
         } else {
             h->anchor_span = 16;
         }
