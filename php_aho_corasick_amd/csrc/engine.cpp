@@ -101,8 +101,8 @@ struct acmi_handle {
     uint32_t slab_auto = 0;      // slots per item the data has asked for so far (automatic slab size, enqueue_batch)
     uint32_t slab_events = 16;   // (8 until round 3: an item with a ninth match went to the drain, one with a ninth candidate was walked whole)
     uint32_t run_cap = 16;
-    bool slab_set = false;     // "slab_events" set by the caller; else the dense anchor form takes 32
-    bool run_cap_set = false;  // by the caller; else the dense anchor form takes 64 (a work item has tens of candidate windows there)
+    bool slab_set = false;     // "slab_events" set by the caller; else learned from the data (slab_auto: 16 / 32 .. 256 slots)
+    bool run_cap_set = false;  // by the caller; else learned (run_auto: 16 .. 64 entries); the dense anchor form takes 256 window starts
     uint64_t chunk_opt = 0;
     int kernel = 3;  // 0 plain global table, 1 LDS-tile walk, 2 anchor filter (if eligible), 3 automatic
     // automatic mode: a batch on which the fast kernel lost (most bytes had to be walked exactly anyway) moves the
