@@ -1085,8 +1085,11 @@ int run_batch_end(acmi_handle *h) {
             h->anchor_off = true;
             h->anchor_left = h->anchor_span;
             h->anchor_span = std::min<uint32_t>(h->anchor_span * 2, 1024);
-        } else if (!fa.compact && !fa.anchor_dense && total * 160 > F.blob_bytes) {
-            // More than ~ 50 matches per 8 KiB: the aligned filter flags its hits one by one through the scalar unit and checks
+        } else if (!fa.compact && !fa.anchor_dense && (total * 160 > F.blob_bytes ||
+                                                           h->walked_bytes * 256 > F.blob_bytes * uint64_t(fa.max_pattern_length - fa.min_pattern_length + 4))) {
+            // More than ~ 50 matches per 8 KiB, or more than ~ 32 CANDIDATES per 8 KiB (cluster bytes / the length of one candidate's range; accidental ones count:
+            // 12-byte patterns over six letters hit the 8-byte windows of random text a dozen times per 8 KiB -- 1.27 ms per GiB on
+            // the filter, 0.52 on the tile walk): the aligned filter flags its hits one by one through the scalar unit and checks
             // its candidates 64 to a thread -- 3.2 ms per GiB at 64 per haystack against 1.8 for the whole-item walk of a small
             // automaton (tools/exp_hits.py).  (Not for compact automata, whose walk costs 9 ms per GiB.)
             h->anchor_off = true;

@@ -44,7 +44,9 @@ def test_many_candidates_per_item_through_the_filter(per_hay):
         assert np.array_equal(p, pe) and np.array_equal(r, re_)
         overflow.append(int(res.stat("overflow_items")))
     if per_hay <= 40:   # what the lists (<= 64) and slabs (<= 256) can learn to hold
-        assert overflow[-1] == 0 and res.stat("kernel_used") == 2, overflow
+        assert overflow[-1] == 0, overflow
+    if per_hay <= 17:   # (from ~ 32 candidates per 8 KiB on the automatic choice prefers the table walk)
+        assert res.stat("kernel_used") == 2
     if 17 <= per_hay <= 40:
         assert overflow[0] > 0, overflow
     api.ahocorasick_deinit(res)

@@ -41,7 +41,7 @@ for L in lens:
         batch.match_device(res, d_blob, d_off)
         print(f"patterns of {L:4d} B, haystacks of {HL:6d} B: {dt*1e3:7.3f} ms per GiB = {d_blob.numel()/dt/1e9:7.1f} GB/s, records {total} (expected {NH}), "
               f"kernel {int(res.stat('kernel_used'))}, scan {res.stat('scan_ms'):.3f} walk {res.stat('walk_ms'):.3f} ms, build {build*1e3:.0f} ms, "
-              f"table {int(res.stat('automaton_bytes'))>>20} MiB, item {int(res.stat('chunk_bytes'))} B", flush=True)
+              f"walked {int(res.stat('walked_bytes'))>>20} MiB fallback {int(res.stat('fallback_bytes'))>>20} MiB, table {int(res.stat('automaton_bytes'))>>20} MiB, item {int(res.stat('chunk_bytes'))} B", flush=True)
         api.ahocorasick_deinit(res)
         del d_blob, d_off
         torch.cuda.empty_cache()
