@@ -15,8 +15,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libacmi.so")
-SOURCES = ["automaton.cpp", "engine.cpp", "kernels.hip"]
-HEADERS = ["automaton.hpp", "device_types.hpp", "kernels.hpp", "scan_asm.inc", os.path.join("..", "..", "include", "acmi.h")]
+SOURCES = ["automaton.cpp", "engine.cpp", "k_anchor.hip", "k_lds.hip", "k_walk.hip", "k_drain.hip", "k_pipeline.hip", "k_small.hip", "k_misc.hip"]
+HEADERS = ["automaton.hpp", "device_types.hpp", "kernels.hpp", "kdev.hpp", "scan_asm.inc", os.path.join("..", "..", "include", "acmi.h")]
 
 
 def _hipcc() -> str:
@@ -42,12 +42,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     hipcc = _hipcc()
     os.makedirs(OBJ_DIR, exist_ok=True)
-    hdr_time = max(os.path.getmtime(os.path.join(CSRC, f)) for f in HEADERS)
     procs, objs = [], []
     for src in SOURCES:
         obj = os.path.join(OBJ_DIR, src + ".o")
         objs.append(obj)
         path = os.path.join(CSRC, src)
+        # (the device-side helpers are only seen by the kernel files: a change there leaves the host objects alone)
+        deps = HEADERS if src.endswith(".hip") else [h for h in HEADERS if h not in ("kdev.hpp", "scan_asm.inc")]
+        hdr_time = max(os.path.getmtime(os.path.join(CSRC, f)) for f in deps)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_time):
             continue
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

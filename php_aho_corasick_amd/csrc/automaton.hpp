@@ -50,7 +50,7 @@ struct BuildOptions {
     uint64_t max_flat_outputs = 1ull << 25; // flat output lists up to this many entries (256 MiB), else dictionary links only
 };
 
-// The part of finalize() that a device can take over (engine.cpp / kernels.hip k_build_level): failure links and
+// The part of finalize() that a device can take over (engine.cpp / k_misc.hip k_build_level): failure links and
 // per-state outputs are level-synchronous -- a node needs only shallower nodes' results -- so one kernel launch per
 // trie depth computes them for all nodes of that depth at once, walking the same open-addressing child map.
 struct TrieView {
@@ -111,7 +111,7 @@ struct FlatAutomaton {
     // The single-child states that are numbered along their patterns, ids [chain_lo, f2): edge byte per state and
     // how many steps from this state on lead to the next id, which is again such a state (capped at 255).  A candidate walk that
     // reaches such a state compares up to 16 text bytes against 16 edge bytes at once instead of taking 16
-    // dependent steps (kernels.hip walk_fast).  Both arrays carry 16 bytes of padding.
+    // dependent steps (kdev.hpp walk_fast).  Both arrays carry 16 bytes of padding.
     uint32_t chain_lo = 0;
     std::vector<uint8_t> chain_byte, chain_run;
     uint32_t class_mode = kClassTable;
@@ -140,7 +140,7 @@ struct FlatAutomaton {
     uint64_t n_flat_outputs = 0;        // entries of out_list (kept when the host copy is released)
     uint32_t max_out_count = 0;
 
-    // ---- anchor filter (optional front end of the scan, see kernels.hip k_scan_anchor) ----
+    // ---- anchor filter (optional front end of the scan, see k_anchor.hip k_scan_anchor) ----
     // Every occurrence of a pattern of length >= q + 3 contains a 4-byte-aligned text dword within
     // its first 4 bytes; the q bytes from there are P[o, o+q) for o in 0..3 ("anchor q-grams").
     //   mode 1 (<= kAnchorMaxKeys q-grams): anchor_table = kAnchorBuckets buckets x 4 slots of 16-bit

@@ -256,7 +256,7 @@ hipError_t copy_h2d(void *dst, const void *src, size_t bytes) {
     return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
 }
 
-// Failure links and per-state outputs on the device, one launch per trie depth (kernels.hip k_build_level).  Used for
+// Failure links and per-state outputs on the device, one launch per trie depth (k_misc.hip k_build_level).  Used for
 // big tries when a gfx950 device is there ("device_build": -1 automatic from 200,000 nodes, 0 never, 1 always);
 // anything that goes wrong hands the work back to the host loop -- the results are the same words either way.
 bool device_fail_and_outputs(void *ctx, const TrieView &tv, uint32_t *fail, uint8_t *is_final, uint32_t *cnt, uint32_t *dict) {

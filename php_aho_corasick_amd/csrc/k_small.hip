@@ -1,0 +1,190 @@
+// k_small.hip -- k_match_small: a whole small host batch in one launch
+#include "kdev.hpp"
+
+namespace acmi {
+
+// ------------------------------------------------------------------------------------------
+// k_match_small: a whole small batch (<= 64 KiB of haystacks, <= 1024 of them) in ONE launch.
+//
+// The batch pipeline above is a dozen dependent launches, ~110 us end to end whatever the size --
+// which is what one ahocorasick_match() of a few KiB costs, and PHP code calls it in a loop
+// (examples/benchmark.php:65-67).  Here one 1024-thread workgroup reads offsets and bytes straight from
+// pinned host memory into LDS (coalesced 16-byte reads over PCIe), walks 64-byte work items with the
+// usual Lmax-1 warm-up through an LDS tile of the transition table (cold rows from the global table),
+// prefix-sums the record counts in LDS and writes prefix array and records back to pinned host memory:
+// one launch, one synchronisation, no copies.  Same exact walk, same order, same findAll=false rule.
+// A batch whose records do not fit `cap` reports so and the host takes the general path.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kSmallMaxBytes = 64u * 1024u;
+constexpr uint32_t kSmallMaxHay = 1024;
+constexpr uint32_t kSmallChunk = 64;
+constexpr uint32_t kSmallMaxItems = kSmallMaxBytes / kSmallChunk + kSmallMaxHay;  // 2048
+constexpr uint32_t kSmallEvents = 2;            // events kept per item; more -> the item is walked again
+constexpr uint32_t kSmallTileBytes = 36u * 1024u;
+constexpr uint32_t kSmallThreads = 1024;
+
+// exclusive scan of v[0..n) (n <= 2 * kSmallThreads) in LDS, in place; returns the total.  All threads call.
+__device__ __forceinline__ uint32_t small_scan(uint32_t *v, uint32_t n, uint32_t *wave_tmp) {
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t a = 2 * t < n ? v[2 * t] : 0u, b = 2 * t + 1 < n ? v[2 * t + 1] : 0u;
+    const uint32_t sum = a + b;
+    uint32_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= uint32_t(d)) inc += o;
+    }
+    if (lane == 63) wave_tmp[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    for (uint32_t w = 0; w < kSmallThreads / 64u; ++w) {
+        const uint32_t x = wave_tmp[w];
+        if (w < wave) base += x;
+        total += x;
+    }
+    const uint32_t ex = base + inc - sum;
+    if (2 * t < n) v[2 * t] = ex;
+    if (2 * t + 1 < n) v[2 * t + 1] = ex + a;
+    __syncthreads();
+    return total;
+}
+
+template <typename E, int MODE>
+__global__ __launch_bounds__(kSmallThreads) void k_match_small(DevAutomaton A, const uint64_t *offsets, const uint8_t *blob,
+                                                               uint32_t nh, uint32_t find_all, uint32_t max_pattern_length,
+                                                               uint64_t *out_summary, uint64_t *out_prefix, uint4 *out_records,
+                                                               uint32_t cap) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *in_bytes = smem;                                                       // 64 KiB
+    const uint8_t *tile = smem + kSmallMaxBytes;                                    // 36 KiB
+    uint2 *ev = reinterpret_cast<uint2 *>(smem + kSmallMaxBytes + kSmallTileBytes); // 2048 x 2 x 8 B = 32 KiB
+    uint32_t *cnt_ev = reinterpret_cast<uint32_t *>(ev + kSmallMaxItems * kSmallEvents);  // 8 KiB
+    uint32_t *cnt_rec = cnt_ev + kSmallMaxItems;                                     // 8 KiB
+    uint32_t *item_base = cnt_rec + kSmallMaxItems;                                  // 1025 x 4 (+ pad) = 4.5 KiB
+    uint32_t *hay_off = item_base + kSmallMaxHay + 8;                                // 1025 x 4
+    uint32_t *wave_tmp = hay_off + kSmallMaxHay + 8;                                 // 16 x 4
+    uint16_t *cls = reinterpret_cast<uint16_t *>(wave_tmp + 16);                     // 512 B (TABLE mode)
+
+    const uint32_t t = threadIdx.x;
+    const uint64_t off0 = offsets[0];
+    // offsets -> LDS (relative to the first one), items per haystack
+    for (uint32_t h = t; h <= nh; h += kSmallThreads) hay_off[h] = uint32_t(offsets[h] - off0);
+    __syncthreads();
+    const uint32_t n_bytes = hay_off[nh];
+    for (uint32_t h = t; h < kSmallMaxHay + 1; h += kSmallThreads)
+        item_base[h] = h < nh ? (hay_off[h + 1] - hay_off[h] + kSmallChunk - 1) / kSmallChunk : 0u;
+    {   // haystack bytes: 16 bytes per lane, coalesced, from pinned host memory (16-byte aligned by the host)
+        const uint4 *src = reinterpret_cast<const uint4 *>(blob);
+        uint4 *dst = reinterpret_cast<uint4 *>(in_bytes);
+        for (uint32_t i = t; i < (n_bytes + 15u) / 16u; i += kSmallThreads) dst[i] = src[i];
+        const uint32_t tile_rows_b = A.row_bytes ? (kSmallTileBytes / A.row_bytes < A.trap ? kSmallTileBytes / A.row_bytes : A.trap) * A.row_bytes : 0u;
+        const uint4 *tsrc = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(A.lds_image) + A.tile_offset);
+        uint4 *tdst = reinterpret_cast<uint4 *>(smem + kSmallMaxBytes);
+        for (uint32_t i = t; i < (tile_rows_b + 15u) / 16u; i += kSmallThreads) tdst[i] = tsrc[i];
+        if (MODE == 0 && t < 256) cls[t] = A.class_off[t];
+    }
+    __syncthreads();
+    const uint32_t tile_rows = A.row_bytes ? (kSmallTileBytes / A.row_bytes < A.trap ? kSmallTileBytes / A.row_bytes : A.trap) : 0u;
+    const uint32_t n_items = small_scan(item_base, nh + 1, wave_tmp);  // item_base[h] = first item of haystack h; [nh] = total
+
+    auto step = [&](uint32_t s, uint32_t byte) -> uint32_t {
+        const uint32_t coff = class_offset<E, MODE>(A, cls, byte);
+        uint32_t w = A.trap;
+        if (s < tile_rows) w = *reinterpret_cast<const E *>(tile + s * A.row_bytes + coff);
+        if (w >= A.trap) w = cold_step<E>(A, s, byte, coff);
+        return w;
+    };
+    // item i -> (haystack, first byte, bytes, warm-up bytes, position of its first byte)
+    auto decode = [&](uint32_t i, uint32_t &h, uint32_t &begin, uint32_t &len, uint32_t &warm, uint32_t &pos0) {
+        uint32_t lo = 0, hi = nh;  // item_base[lo] <= i < item_base[hi]
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (item_base[mid] <= i) lo = mid; else hi = mid;
+        }
+        h = lo;
+        pos0 = (i - item_base[h]) * kSmallChunk;
+        begin = hay_off[h] + pos0;
+        const uint32_t rest = hay_off[h + 1] - begin;
+        len = rest < kSmallChunk ? rest : kSmallChunk;
+        const uint32_t wmax = max_pattern_length ? max_pattern_length - 1u : 0u;
+        warm = pos0 < wmax ? pos0 : wmax;
+    };
+
+    // ---- walk: count events and records per item, keep the first kSmallEvents events ----
+    for (uint32_t i = t; i < kSmallMaxItems; i += kSmallThreads) {
+        uint32_t n_ev = 0, n_rec = 0;
+        if (i < n_items) {
+            uint32_t h, begin, len, warm, pos0;
+            decode(i, h, begin, len, warm, pos0);
+            uint32_t s = 0;
+            const uint8_t *p = in_bytes + begin - warm;
+            for (uint32_t j = 0; j < warm + len; ++j) {
+                s = step(s, p[j]);
+                if (j >= warm && is_final(A, s)) {
+                    n_rec += A.out_count[s];
+                    if (n_ev < kSmallEvents) ev[i * kSmallEvents + n_ev] = make_uint2(pos0 + (j - warm) + 1u, s);
+                    ++n_ev;
+                }
+            }
+        }
+        cnt_ev[i] = n_ev;
+        cnt_rec[i] = n_rec;
+    }
+    __syncthreads();
+    // ---- findAll == false: only the first event of each haystack (php_ahocorasick.c:588) ----
+    if (!find_all) {
+        for (uint32_t h = t; h < nh; h += kSmallThreads) {
+            bool found = false;
+            for (uint32_t i = item_base[h]; i < item_base[h + 1]; ++i) {
+                if (found) { cnt_ev[i] = 0; cnt_rec[i] = 0; }
+                else if (cnt_ev[i]) {
+                    found = true;
+                    cnt_ev[i] = 1;
+                    cnt_rec[i] = A.out_count[ev[i * kSmallEvents].y];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- record offsets ----
+    const uint32_t total = small_scan(cnt_rec, kSmallMaxItems, wave_tmp);  // cnt_rec[i] = first record of item i
+    for (uint32_t h = t; h <= nh; h += kSmallThreads)
+        out_prefix[h] = (h < nh && item_base[h] < kSmallMaxItems) ? cnt_rec[item_base[h]] : total;
+    if (t == 0) { out_summary[0] = total; out_summary[1] = n_items; out_summary[2] = total > cap ? 1u : 0u; }
+    if (total > cap) return;
+    // ---- records ----
+    for (uint32_t i = t; i < n_items; i += kSmallThreads) {
+        const uint32_t n_ev = cnt_ev[i];
+        if (n_ev == 0) continue;
+        uint32_t h, begin, len, warm, pos0;
+        decode(i, h, begin, len, warm, pos0);
+        uint64_t w = cnt_rec[i];
+        if (n_ev <= kSmallEvents) {
+            for (uint32_t e = 0; e < n_ev; ++e) w = emit_event(A, out_records, w, h, ev[i * kSmallEvents + e].x, ev[i * kSmallEvents + e].y);
+        } else {  // dense item: walk it again, writing records straight to their slots
+            uint32_t s = 0;
+            const uint8_t *p = in_bytes + begin - warm;
+            for (uint32_t j = 0; j < warm + len; ++j) {
+                s = step(s, p[j]);
+                if (j >= warm && is_final(A, s)) w = emit_event(A, out_records, w, h, pos0 + (j - warm) + 1u, s);
+            }
+        }
+    }
+}
+
+hipError_t launch_match_small(const DevAutomaton &A, const uint64_t *offsets, const uint8_t *blob, uint32_t nh, int find_all,
+                              uint32_t max_pattern_length, int entry_bytes, int class_mode, uint64_t *out_summary,
+                              uint64_t *out_prefix, void *out_records, uint32_t cap, hipStream_t st) {
+    const uint32_t lds = kSmallMaxBytes + kSmallTileBytes + kSmallMaxItems * (kSmallEvents * 8u + 8u) + (kSmallMaxHay + 8u) * 8u + 64u + 512u;
+    auto go = [&](auto fn) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(fn, dim3(1), dim3(kSmallThreads), lds, st, A, offsets, blob, nh, uint32_t(find_all ? 1 : 0),
+                           max_pattern_length, out_summary, out_prefix, static_cast<uint4 *>(out_records), cap);
+        return hipGetLastError();
+    };
+    if (entry_bytes == 2) return class_mode == 1 ? go(k_match_small<uint16_t, 1>) : go(k_match_small<uint16_t, 0>);
+    return class_mode == 1 ? go(k_match_small<uint32_t, 1>) : go(k_match_small<uint32_t, 0>);
+}
+
+}  // namespace acmi

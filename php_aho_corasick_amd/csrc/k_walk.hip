@@ -1,0 +1,744 @@
+// k_walk.hip -- the exact walks behind the filter and in place of it: k_walk_runs, the dense form's decision kernels, k_walk_items
+#include "kdev.hpp"
+
+namespace acmi {
+
+// ------------------------------------------------------------------------------------------
+// k_walk_runs: exact walk of the byte runs k_scan_anchor flagged, one thread per work item.
+//
+// The anchor kernel used to do this itself, lane k walking item k after the wave had streamed its 64
+// items: a chain of ~26 dependent memory round trips (run list, haystack dwords, 11 cold table rows)
+// during which the wave streams nothing -- 0.15 ms of a 0.97 ms kernel for one hit per 8 KiB.  As a
+// kernel of its own the same walks run at full occupancy, all 2^19 of them at once, and the latency
+// chain is paid once instead of once per wave batch.  The first rows of the transition tile are
+// staged in LDS (same image as k_scan_lds uses) so that only deep states go to L2.  Items without runs
+// (run_count 0) cost one coalesced 4-byte load.
+// ------------------------------------------------------------------------------------------
+// (k_walk_runs keeps 79 registers, so a CU holds ONE of its 16-wave workgroups.  Measured alternatives on config 3 /
+// the headline batch: 64 registers forced (24 spilled) 0.183 / 0.077 ms, three 8-wave workgroups with 48 KiB tiles
+// 0.160 / 0.084 ms, against 0.163 / 0.077 ms as it is: occupancy is not what bounds the kernel.)
+
+// Items whose run list overflowed are walked by the WAVE, a 64th of the item per lane (entered from the root Lmax-1 bytes
+// early, like every chunk), and only COUNTED: events and records go to the item's counters, the item to the overflow list,
+// and the drain (k_refill_wave) writes its records as it does for any item with more events than its slab holds.  One
+// lane walking its 8 KiB alone took 2.4 ms -- the whole kernel, for ONE such item in a batch of any size (tools/exp_hits.py:
+// six matches per haystack and one accidental candidate more somewhere: 0.075 -> 2.4 ms).  `whole`: this lane's item is
+// one of them (`rec` its packed record, `item` its index); must be reached by every lane of the wave.
+template <typename E, int MODE>
+__device__ __forceinline__ void wave_walk_whole(const DevAutomaton &A, const BatchArgs &B, const uint8_t *tile, uint32_t tile_rows,
+                                                bool whole, const uint4 &rec, uint64_t item, uint32_t &walked, uint32_t &fallback16) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint64_t todo = __ballot(whole); todo != 0; todo &= todo - 1) {
+        const uint32_t l = uint32_t(__builtin_ctzll(todo));
+        const uint64_t item_l = item - lane + l;
+        ItemDesc it;
+        unpack_item(uint32_t(__builtin_amdgcn_readlane(int(rec.x), int(l))), uint32_t(__builtin_amdgcn_readlane(int(rec.y), int(l))),
+                    uint32_t(__builtin_amdgcn_readlane(int(rec.z), int(l))), uint32_t(__builtin_amdgcn_readlane(int(rec.w), int(l))), it);
+        const uint8_t *p = B.blob + (it.begin - it.warm);
+        const uint32_t n = it.warm + it.len;
+        const uint32_t seg = (it.len + 63u) >> 6;
+        const uint32_t s0 = it.warm + lane * seg, s1 = s0 + seg < n ? s0 + seg : n;
+        EventRegs ev{0, 0};
+        if (s0 < s1) {
+            uint32_t from = s0 > B.warm_bytes ? s0 - B.warm_bytes : 0u;
+            if (from < it.floor) from = it.floor;
+            exact_range<E, MODE, false>(A, B, nullptr, tile, tile_rows, item_l, p, from, s1, s0, it.pos0 - it.warm + 1u, 0u, ev, 0xFFFFFFFFu, false);
+        }
+        uint32_t n_ev = ev.n_ev, rec_lo = uint32_t(ev.n_rec), rec_hi = uint32_t(ev.n_rec >> 32);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            n_ev += __shfl_xor(n_ev, d, 64);
+            const uint32_t lo2 = __shfl_xor(rec_lo, d, 64), hi2 = __shfl_xor(rec_hi, d, 64);
+            const uint64_t sum = (uint64_t(rec_hi) << 32 | rec_lo) + (uint64_t(hi2) << 32 | lo2);
+            rec_lo = uint32_t(sum);
+            rec_hi = uint32_t(sum >> 32);
+        }
+        if (lane == 0) {
+            if (n_ev) {
+                B.ev_count[item_l] = n_ev > B.slab_events ? n_ev : B.slab_events + 1u;   // (its events are not in the slab: the drain's)
+                B.rec_count[item_l] = uint64_t(rec_hi) << 32 | rec_lo;
+                B.overflow_list[atomicAdd(&B.counters[0], 1u)] = uint32_t(item_l);
+            }
+            walked += n;
+            fallback16 += (n + 15u) >> 4;
+        }
+    }
+}
+
+template <typename E, int MODE, bool EXTRA>
+__global__ __launch_bounds__(kWalkThreads) void k_walk_runs(DevAutomaton A, BatchArgs B, uint32_t tile_bytes) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint64_t total_items = B.item_base[B.n_haystacks];
+    if (uint64_t(blockIdx.x) * kWalkThreads >= total_items) return;
+    __shared__ uint32_t s_walked, s_done, s_fallback;
+    if (threadIdx.x == 0) { s_walked = 0; s_done = 0; s_fallback = 0; }
+    const uint64_t item = uint64_t(blockIdx.x) * kWalkThreads + threadIdx.x;
+    // issue the item's own loads first: they are in flight while the tile is staged
+    uint32_t nr = 0;
+    uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+    if (item < total_items) {
+        nr = B.run_count[item];
+        rec = B.item_rec[item];
+    }
+    const uint32_t tile_rows = A.row_bytes ? (tile_bytes / A.row_bytes < A.trap ? tile_bytes / A.row_bytes : A.trap) : 0u;
+    {
+        const uint4 *tsrc = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(A.lds_image) + A.tile_offset);
+        uint4 *tdst = reinterpret_cast<uint4 *>(smem);
+        const uint32_t n16 = (tile_rows * A.row_bytes + 15u) >> 4;  // <= 4096: at most 4 per thread, loaded back to back
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t t = threadIdx.x + uint32_t(u) * kWalkThreads;
+            v[u] = tsrc[t < n16 ? t : 0u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t t = threadIdx.x + uint32_t(u) * kWalkThreads;
+            if (t < n16) tdst[t] = v[u];
+        }
+    }
+    __syncthreads();
+    uint32_t walked = 0, fallback16 = 0;
+    bool whole = false;
+    if (nr != 0) {
+        ItemDesc it;
+        unpack_item(rec.x, rec.y, rec.z, rec.w, it);
+        // (a run list that overflowed -- more candidate windows than it holds -- means the whole item: not by this lane alone,
+        // see below; findAll = false keeps the old way, the first event needs the order)
+        if (nr > B.run_cap && !B.first_only) whole = true;
+        else walked = run_epilogue_fast<E, MODE, EXTRA>(A, B, smem, tile_rows, item, it, nr, fallback16);
+    }
+    wave_walk_whole<E, MODE>(A, B, smem, tile_rows, whole, rec, item, walked, fallback16);
+    // statistic: bytes walked, one device atomic per WORKGROUP (8,192 same-address device atomics took 0.1 ms on their own,
+    // and per-wave atomics spread over eight words of one line doubled this kernel's time), handed in by the workgroup's
+    // LAST wave to finish -- no barrier: a barrier made every wave of a workgroup wait for its slowest lane (a cluster that
+    // has to be WALKED takes ~ 100 us) and kept the CU from starting the next workgroup; with one such item in a thousand
+    // almost every workgroup had one (0.66 ms instead of 0.16 on such a batch; 0.39 without the barrier).
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        walked += __shfl_xor(walked, d, 64);
+        fallback16 += __shfl_xor(fallback16, d, 64);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        if (walked) atomicAdd(&s_walked, (walked + 15u) >> 4);
+        if (fallback16) atomicAdd(&s_fallback, fallback16);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (atomicAdd(&s_done, 1u) == kWalkThreads / 64u - 1u) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const uint32_t total = atomicAdd(&s_walked, 0u), fb = atomicAdd(&s_fallback, 0u);
+            if (total) atomicAdd(&B.counters[8u + (blockIdx.x & 7u)], total);
+            if (fb) atomicAdd(&B.counters[7], fb);
+        }
+    }
+}
+
+static hipError_t launch_verify_dense(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,
+                                      hipStream_t st);
+
+hipError_t launch_walk_runs(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,
+                            hipStream_t st) {
+    if (max_items == 0) return hipSuccess;
+    if (B.run_dense) return launch_verify_dense(A, B, max_items, entry_bytes, class_mode, st);
+    const uint32_t blocks = uint32_t((max_items + kWalkThreads - 1) / kWalkThreads);
+    // (no tile at all when candidates are decided by text compares: 52 -> 49.5 us on the headline batch, 0.148 -> 0.141 ms on
+    // config 3 -- not worth walking every fallback cluster through L2)
+    const uint32_t tile_bytes = kWalkTileBytes;
+    const uint32_t lds = tile_bytes;
+    auto go = [&](auto fn) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(fn, dim3(blocks), dim3(kWalkThreads), lds, st, A, B, tile_bytes);
+        return hipGetLastError();
+    };
+    const bool extra = A.early_stop != 0u;
+#define ACMI_WALK_RUNS(E, M) (extra ? go(k_walk_runs<E, M, true>) : go(k_walk_runs<E, M, false>))
+    if (entry_bytes == 2) return class_mode == 1 ? ACMI_WALK_RUNS(uint16_t, 1) : ACMI_WALK_RUNS(uint16_t, 0);
+    return class_mode == 1 ? ACMI_WALK_RUNS(uint32_t, 1) : ACMI_WALK_RUNS(uint32_t, 0);
+#undef ACMI_WALK_RUNS
+}
+
+// ------------------------------------------------------------------------------------------
+// k_verify_dense: k_walk_runs for the dense anchor form (windows at every byte offset, shortest pattern 4..6 B).
+//
+// A work item has tens of hit windows there (a keyword list: ~ 100 per 8 KiB), and deciding each through the tables in
+// global memory -- fingerprint bucket, slot, pair record, pattern text: five dependent round trips, ~ 15 divergent
+// requests -- made this step three times the filter's own time.  For small sets (<= 4,096 patterns of <= 16 B) everything
+// the decision needs is staged into LDS instead (automaton.hpp dense_image: a hash table keyed by the window itself, a
+// record per pattern, the patterns' bytes from the fifth on), and a hit costs ONE global access, the 16 text bytes at the
+// window, requested a hit ahead.  The run list is the 4-byte window starts of the item, contiguous (item-major); a run's
+// bounds follow from its start: patterns BEGIN at their window, so everything anchored at `start` ends in
+// [start + m_min - 1, start + Lmax).  Runs that touch or overlap form a cluster, decided as in run_epilogue_fast: its
+// occurrences in position order, or -- more than six of them, a text load that would cross the item's end -- one exact
+// walk from the cluster's first window.  Bigger sets verify through the global tables (VLDS = false).
+// ------------------------------------------------------------------------------------------
+template <bool VLDS>
+__device__ __forceinline__ bool verify_dense(const DevAutomaton &A, const uint32_t *img, const uint8_t *p, uint32_t n, uint32_t floor,
+                                             uint32_t start, const uint4 &t, Verified (&v)[kClusterMax], uint32_t &nv) {
+    if (start + 4u > n) return true;   // no pattern fits
+    if constexpr (!VLDS) {
+        if (A.anchor_pairs == nullptr) return false;   // "verify" 0: every candidate is walked
+        return verify_candidate(A, p, n, floor, start, v, nv);
+    } else {
+        if (start + 16u > n) return false;   // (the 16 text bytes were not loaded: the cluster is walked)
+        const uint32_t mask = img[0];
+        const uint32_t *ht = img + img[1], *recs = img + img[2], *tails = img + img[3];
+        uint32_t slot = ((t.x * img[5]) >> 16) & mask;
+        uint32_t e1;
+        for (;;) {
+            e1 = ht[2u * slot + 1u];
+            if (e1 == 0xFFFFFFFFu) return true;   // not a key at all: a fingerprint twin
+            if (ht[2u * slot] == t.x) break;
+            slot = (slot + 1u) & mask;
+        }
+        const uint32_t first = e1 & 0xFFFFu, count = e1 >> 16;
+#pragma unroll 1
+        for (uint32_t k = 0; k < count; ++k) {
+            const uint32_t r0 = recs[2u * (first + k)], r1 = recs[2u * (first + k) + 1u];
+            const uint32_t len = r0 >> 24, state = r0 & 0xFFFFFFu, toff = r1 & 0xFFFFu;
+            if (start < floor || start + len > n) continue;   // would begin before / end after this item's bytes
+            const uint32_t tl = len - 4u;                      // 0..12 bytes behind the window
+            const uint32_t m0 = tl >= 4u ? 0xFFFFFFFFu : (1u << (8u * tl)) - 1u;
+            const uint32_t m1 = tl >= 8u ? 0xFFFFFFFFu : tl > 4u ? (1u << (8u * (tl - 4u))) - 1u : 0u;
+            const uint32_t m2 = tl >= 12u ? 0xFFFFFFFFu : tl > 8u ? (1u << (8u * (tl - 8u))) - 1u : 0u;
+            const uint32_t diff = ((t.y ^ tails[toff]) & m0) | ((t.z ^ tails[toff + 1u]) & m1) | ((t.w ^ tails[toff + 2u]) & m2);
+            if (diff) continue;
+            if (nv >= kClusterMax) return false;
+            uint32_t oc = r1 >> 16;
+            if (oc == 65535u) oc = A.out_count[state];
+            const Verified vv{start + len - 1u, state, oc};
+#pragma unroll
+            for (uint32_t i = 0; i < kClusterMax; ++i) if (i == nv) v[i] = vv;
+            ++nv;
+        }
+        return true;
+    }
+}
+
+template <typename E, int MODE, bool VLDS>
+__global__ __launch_bounds__(kWalkThreads) void k_verify_dense(DevAutomaton A, BatchArgs B) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint64_t total_items = B.item_base[B.n_haystacks];
+    if (uint64_t(blockIdx.x) * kWalkThreads >= total_items) return;
+    __shared__ uint32_t s_walked, s_done, s_fallback;
+    if (threadIdx.x == 0) { s_walked = 0; s_done = 0; s_fallback = 0; }
+    const uint64_t item = uint64_t(blockIdx.x) * kWalkThreads + threadIdx.x;
+    uint32_t nr = 0;
+    uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+    if (item < total_items) {
+        nr = B.run_count[item];
+        rec = B.item_rec[item];
+    }
+    if constexpr (VLDS) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(A.dense_image);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        const uint32_t n16 = A.dense_image_words >> 2;
+        for (uint32_t t = threadIdx.x; t < n16; t += kWalkThreads) dst[t] = src[t];
+    }
+    __syncthreads();
+    const uint32_t *img = reinterpret_cast<const uint32_t *>(smem);
+    uint32_t walked = 0, fallback16 = 0;
+    bool whole = false;
+    if (nr != 0) {
+        ItemDesc it;
+        unpack_item(rec.x, rec.y, rec.z, rec.w, it);
+        const uint8_t *p = B.blob + (it.begin - it.warm);
+        const uint32_t n = it.warm + it.len;
+        const uint32_t pos_bias = it.pos0 - it.warm + 1u;
+        const uint32_t m_min = A.min_pattern_length, l_max = A.max_pattern_length;
+        EventRegs ev{0, 0};
+        if (nr > B.run_cap && !B.first_only) {   // more hit windows than the list holds (or an unaligned head): the whole item,
+            whole = true;                         // exactly -- by the wave, below (wave_walk_whole)
+        } else if (nr > B.run_cap) {
+            walked = n;
+            exact_range<E, MODE, false>(A, B, nullptr, nullptr, 0u, item, p, it.floor, n, it.warm, pos_bias, 0u, ev);
+            fallback16 += (n + 15u) >> 4;
+        } else {
+            const uint32_t *starts = reinterpret_cast<const uint32_t *>(B.runs) + item * uint64_t(B.run_cap);
+            uint32_t r = 0;
+            uint32_t cur = starts[0];
+            // the 16 text bytes at a window, requested one window ahead (where they lie inside the item)
+            auto text_at = [&](uint32_t st) -> uint4 { return (VLDS && st + 16u <= n) ? load16u(p + st) : make_uint4(0u, 0u, 0u, 0u); };
+            uint4 t_cur = text_at(cur);
+#pragma unroll 1
+            while (r < nr) {
+                const uint32_t first = cur;
+                uint32_t hi = first + l_max < n ? first + l_max : n, nv = 0;
+                Verified v[kClusterMax];
+#pragma unroll
+                for (uint32_t i = 0; i < kClusterMax; ++i) v[i] = Verified{0xFFFFFFFFu, 0u, 0u};
+                bool windows = true;
+#pragma unroll 1
+                for (;;) {
+                    const uint32_t st = cur;
+                    const uint4 t = t_cur;
+                    ++r;
+                    if (r < nr) {   // (the next window's text is in flight while this one is decided)
+                        cur = starts[r];
+                        t_cur = text_at(cur);
+                    }
+                    if (windows) windows = verify_dense<VLDS>(A, img, p, n, it.floor, st, t, v, nv);
+                    if (r >= nr || cur + m_min - 1u > hi) break;   // neither adjacent nor overlapping: the next cluster
+                    const uint32_t h2 = cur + l_max < n ? cur + l_max : n;
+                    hi = h2 > hi ? h2 : hi;
+                }
+                const uint32_t lo = first + m_min - 1u;
+                if (lo >= n) continue;
+                const uint32_t rep_from = lo > it.warm ? lo : it.warm;
+                walked += hi - lo;
+                if (windows) {
+                    emit_verified(B, item, v, rep_from, hi, pos_bias, ev);
+                    continue;
+                }
+                // every pattern that ends in the cluster begins at one of its windows, the first being the leftmost
+                const uint32_t from = first > it.floor ? first : it.floor;
+                exact_range<E, MODE, false>(A, B, nullptr, nullptr, 0u, item, p, from, hi, rep_from, pos_bias, 0u, ev);
+                fallback16 += (hi - from + 15u) >> 4;
+            }
+        }
+        if (ev.n_ev) {
+            B.ev_count[item] = ev.n_ev;
+            B.rec_count[item] = ev.n_rec;
+            if (ev.n_ev > B.slab_events) B.overflow_list[atomicAdd(&B.counters[0], 1u)] = uint32_t(item);
+        }
+    }
+    wave_walk_whole<E, MODE>(A, B, nullptr, 0u, whole, rec, item, walked, fallback16);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        walked += __shfl_xor(walked, d, 64);
+        fallback16 += __shfl_xor(fallback16, d, 64);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        if (walked) atomicAdd(&s_walked, (walked + 15u) >> 4);
+        if (fallback16) atomicAdd(&s_fallback, fallback16);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (atomicAdd(&s_done, 1u) == kWalkThreads / 64u - 1u) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const uint32_t total = atomicAdd(&s_walked, 0u), fb = atomicAdd(&s_fallback, 0u);
+            if (total) atomicAdd(&B.counters[8u + (blockIdx.x & 7u)], total);
+            if (fb) atomicAdd(&B.counters[7], fb);
+        }
+    }
+}
+
+// With the LDS image the decision is split in two kernels, because what bounds it is memory LATENCY, not work: one thread per
+// item deciding its ~ 100 windows one after the other waits for a window-list load and a text load per window, a few
+// microseconds each (0.89 ms per GiB of keyword text, more than the filter), and a per-item pass over ALL windows reads its
+// 4-byte entries a 128-byte line at a time (4 GB of L2 misses per GiB of text).
+//   k_dense_decide   one WAVE per item, 64 hit windows per step: the window list in one coalesced read, the text loads (they
+//                    fall into the item's own few lines), the LDS lookup, and the windows that hold an occurrence compacted
+//                    in place -- with the record index of the occurrence, or kDenseMany (several patterns with that prefix
+//                    are there, or the text load would cross the item's end);
+//   k_dense_emit     one thread per item over the FEW entries left (nine hit windows in ten hold nothing): clusters those
+//                    whose ranges touch, emits the events in position order; only kDenseMany windows are looked at again.
+// What is left of the cost is the text itself: the decide kernel reads every line of it again (TCC_MISS x 128 B = the
+// batch), 0.29 ms per GiB -- the price of deciding in a kernel of its own instead of inside the scan.
+constexpr uint32_t kDenseNone = 0xFFFFFFFFu, kDenseMany = 0xFFFFFFFEu;
+
+// One WAVE per item, 64 hit windows per step: the window starts in one coalesced read, the text loads (they fall into the
+// item's own few lines), the LDS lookup, and the windows that hold an occurrence COMPACTED (ballot + mbcnt, running base):
+// found[item * Q + i] = start of the i-th such window (written over the window list: i never exceeds the index read) and
+// its record index -- or kDenseMany -- behind the lists; run_count[item] becomes the number found.  Most hit windows hold
+// nothing (a keyword list: nine in ten are a word's first four letters and no more), so k_dense_emit is left with a
+// handful of entries per item.
+// IMG = false (sets the LDS image does not hold: more than 4,096 patterns, patterns over 16 B): the same pass as a FILTER --
+// a window is kept when the text compare through the global tables (verify_candidate) finds an occurrence or cannot decide,
+// marked kDenseMany, and k_dense_emit decides the few that are left again.  One thread per item deciding its hundreds of
+// windows one after the other (k_verify_dense) took 1.1 ms per GiB for 8,192 words.
+template <bool IMG>
+__global__ __launch_bounds__(1024) void k_dense_decide(DevAutomaton A, BatchArgs B, uint32_t *found_idx) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint64_t total_items = B.item_base[B.n_haystacks];
+    const uint32_t Q = B.run_cap;
+    if (uint64_t(blockIdx.x) * 16u >= total_items) return;
+    if constexpr (IMG) {   // the image is staged once per workgroup; the workgroups are persistent (a few per CU) and stride over the items
+        const uint4 *src = reinterpret_cast<const uint4 *>(A.dense_image);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        const uint32_t n16 = A.dense_image_words >> 2;
+        for (uint32_t t = threadIdx.x; t < n16; t += 1024u) dst[t] = src[t];
+    }
+    __syncthreads();
+    const uint32_t *img = reinterpret_cast<const uint32_t *>(smem);
+    const uint32_t mask = IMG ? img[0] : 0u;
+    const uint32_t *ht = IMG ? img + img[1] : nullptr, *recs = IMG ? img + img[2] : nullptr, *tails = IMG ? img + img[3] : nullptr;
+    const uint32_t hmul = IMG ? img[5] : 0u;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t *starts_all = reinterpret_cast<uint32_t *>(B.runs);
+    for (uint64_t item = uint64_t(blockIdx.x) * 16u + (threadIdx.x >> 6); item < total_items; item += uint64_t(gridDim.x) * 16u) {
+        const uint32_t nr = __builtin_amdgcn_readfirstlane(B.run_count[item]);
+        if (nr == 0 || nr > Q) continue;   // (more windows than the list holds: k_dense_emit walks the whole item)
+        const uint4 rec = B.item_rec[item];
+        ItemDesc it;
+        unpack_item(rec.x, rec.y, rec.z, rec.w, it);
+        const uint8_t *p = B.blob + (it.begin - it.warm);
+        const uint32_t n = it.warm + it.len;
+        uint32_t *starts = starts_all + item * uint64_t(Q), *fidx = found_idx + item * uint64_t(Q);
+        uint32_t base = 0;
+#pragma unroll 1
+        for (uint32_t c = 0; c < nr; c += 64u) {
+            const uint32_t r = c + lane;
+            const bool active = r < nr;
+            const uint32_t start = active ? starts[r] : 0u;
+            uint32_t out = kDenseNone;
+            if constexpr (!IMG) {
+                if (active) {
+                    Verified v[kClusterMax];
+                    uint32_t nv = 0;
+                    const bool decided = verify_candidate(A, p, n, it.floor, start, v, nv);
+                    if (!decided || nv != 0) out = kDenseMany;
+                }
+            } else
+            if (active) {
+                if (start + 16u > n) {
+                    out = start + 4u <= n ? kDenseMany : kDenseNone;   // (decided by k_dense_emit, which reads single bytes)
+                } else {
+                    const uint4 tx = load16u(p + start);
+                    uint32_t slot = ((tx.x * hmul) >> 16) & mask, e1;
+                    for (;;) {
+                        e1 = ht[2u * slot + 1u];
+                        if (e1 == 0xFFFFFFFFu || ht[2u * slot] == tx.x) break;
+                        slot = (slot + 1u) & mask;
+                    }
+                    if (e1 != 0xFFFFFFFFu) {
+                        const uint32_t first = e1 & 0xFFFFu, count = e1 >> 16;
+#pragma unroll 1
+                        for (uint32_t k = 0; k < count; ++k) {
+                            const uint32_t r0 = recs[2u * (first + k)], r1 = recs[2u * (first + k) + 1u];
+                            const uint32_t len = r0 >> 24, toff = r1 & 0xFFFFu;
+                            if (start < it.floor || start + len > n) continue;
+                            const uint32_t tl = len - 4u;
+                            const uint32_t m0 = tl >= 4u ? 0xFFFFFFFFu : (1u << (8u * tl)) - 1u;
+                            const uint32_t m1 = tl >= 8u ? 0xFFFFFFFFu : tl > 4u ? (1u << (8u * (tl - 4u))) - 1u : 0u;
+                            const uint32_t m2 = tl >= 12u ? 0xFFFFFFFFu : tl > 8u ? (1u << (8u * (tl - 8u))) - 1u : 0u;
+                            const uint32_t diff = ((tx.y ^ tails[toff]) & m0) | ((tx.z ^ tails[toff + 1u]) & m1) | ((tx.w ^ tails[toff + 2u]) & m2);
+                            if (diff) continue;
+                            out = out == kDenseNone ? first + k : kDenseMany;
+                        }
+                    }
+                }
+            }
+            const bool keep = out != kDenseNone;
+            const uint64_t km = __ballot(keep);
+            if (km != 0) {
+                const uint32_t at = base + __builtin_amdgcn_mbcnt_hi(uint32_t(km >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(km), 0u));
+                if (keep) {
+                    starts[at] = start;   // at <= r: every lane of this step has read its start, earlier steps' are consumed
+                    fidx[at] = out;
+                }
+                base += uint32_t(__builtin_popcountll(km));
+            }
+        }
+        if (lane == 0) B.run_count[item] = base;
+    }
+}
+
+template <typename E, int MODE>
+__global__ __launch_bounds__(256) void k_dense_emit(DevAutomaton A, BatchArgs B, const uint32_t *found_idx) {
+    const uint64_t total_items = B.item_base[B.n_haystacks];
+    const uint64_t item = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    __shared__ uint32_t s_walked, s_fallback;
+    if (threadIdx.x == 0) { s_walked = 0; s_fallback = 0; }
+    __syncthreads();
+    uint32_t walked = 0, fallback16 = 0;
+    bool whole = false;
+    const uint32_t nf = item < total_items ? B.run_count[item] : 0u;   // occurrences found (> run_cap: the window list overflowed)
+    uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+    if (nf != 0) {
+        rec = B.item_rec[item];
+        ItemDesc it;
+        unpack_item(rec.x, rec.y, rec.z, rec.w, it);
+        const uint8_t *p = B.blob + (it.begin - it.warm);
+        const uint32_t n = it.warm + it.len;
+        const uint32_t pos_bias = it.pos0 - it.warm + 1u;
+        const uint32_t m_min = A.min_pattern_length, l_max = A.max_pattern_length;
+        const uint32_t *img = A.dense_image;              // (records read through the cache: a few KiB, shared by everyone; none: every
+        const uint32_t *recs = img ? img + img[2] : nullptr;   //  kept window is marked kDenseMany)
+        EventRegs ev{0, 0};
+        if (nf > B.run_cap && !B.first_only) {
+            whole = true;   // (the wave walks it together, below: wave_walk_whole)
+        } else if (nf > B.run_cap) {
+            walked = n;
+            exact_range<E, MODE, false>(A, B, nullptr, nullptr, 0u, item, p, it.floor, n, it.warm, pos_bias, 0u, ev);
+            fallback16 += (n + 15u) >> 4;
+        } else {
+            const uint32_t *starts = reinterpret_cast<const uint32_t *>(B.runs) + item * uint64_t(B.run_cap);
+            const uint32_t *fidx = found_idx + item * uint64_t(B.run_cap);
+            uint32_t r = 0;
+#pragma unroll 1
+            while (r < nf) {
+                // a cluster: occurrences whose possible ranges [start + m_min - 1, start + Lmax) touch or overlap
+                const uint32_t first = starts[r];
+                uint32_t hi = first + l_max < n ? first + l_max : n, nv = 0;
+                Verified v[kClusterMax];
+#pragma unroll
+                for (uint32_t i = 0; i < kClusterMax; ++i) v[i] = Verified{0xFFFFFFFFu, 0u, 0u};
+                bool windows = true;
+                uint32_t st = first;
+#pragma unroll 1
+                for (;;) {
+                    const uint32_t got = fidx[r];
+                    if (got == kDenseMany) {
+                        // several patterns with this prefix, or a window in the item's last bytes: decided here
+                        if (windows) windows = A.anchor_pairs != nullptr && verify_candidate(A, p, n, it.floor, st, v, nv);
+                    } else if (windows) {
+                        if (nv >= kClusterMax) windows = false;
+                        else {
+                            const uint32_t r0 = recs[2u * got], r1 = recs[2u * got + 1u];
+                            uint32_t oc = r1 >> 16;
+                            if (oc == 65535u) oc = A.out_count[r0 & 0xFFFFFFu];
+                            const Verified vv{st + (r0 >> 24) - 1u, r0 & 0xFFFFFFu, oc};
+#pragma unroll
+                            for (uint32_t i = 0; i < kClusterMax; ++i) if (i == nv) v[i] = vv;
+                            ++nv;
+                        }
+                    }
+                    ++r;
+                    if (r >= nf) break;
+                    st = starts[r];
+                    if (st + m_min - 1u > hi) break;   // neither adjacent nor overlapping: the next cluster
+                    const uint32_t h2 = st + l_max < n ? st + l_max : n;
+                    hi = h2 > hi ? h2 : hi;
+                }
+                const uint32_t lo = first + m_min - 1u;
+                if (lo >= n) continue;
+                const uint32_t rep_from = lo > it.warm ? lo : it.warm;
+                walked += hi - lo;
+                if (windows) {
+                    if (nv) emit_verified(B, item, v, rep_from, hi, pos_bias, ev);
+                    continue;
+                }
+                // every occurrence that ends in the cluster begins at one of its windows, the first being the leftmost
+                const uint32_t from = first > it.floor ? first : it.floor;
+                exact_range<E, MODE, false>(A, B, nullptr, nullptr, 0u, item, p, from, hi, rep_from, pos_bias, 0u, ev);
+                fallback16 += (hi - from + 15u) >> 4;
+            }
+        }
+        if (ev.n_ev) {
+            B.ev_count[item] = ev.n_ev;
+            B.rec_count[item] = ev.n_rec;
+            if (ev.n_ev > B.slab_events) B.overflow_list[atomicAdd(&B.counters[0], 1u)] = uint32_t(item);
+        }
+    }
+    wave_walk_whole<E, MODE>(A, B, nullptr, 0u, whole, rec, item, walked, fallback16);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        walked += __shfl_xor(walked, d, 64);
+        fallback16 += __shfl_xor(fallback16, d, 64);
+    }
+    if ((threadIdx.x & 63u) == 0 && walked) atomicAdd(&s_walked, (walked + 15u) >> 4);
+    if ((threadIdx.x & 63u) == 0 && fallback16) atomicAdd(&s_fallback, fallback16);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_walked) atomicAdd(&B.counters[8u + (blockIdx.x & 7u)], s_walked);
+    if (threadIdx.x == 0 && s_fallback) atomicAdd(&B.counters[7], s_fallback);
+}
+
+static hipError_t launch_verify_dense(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,
+                                      hipStream_t st) {
+    const uint32_t blocks = uint32_t((max_items + kWalkThreads - 1) / kWalkThreads);
+    if (A.dense_image != nullptr || A.anchor_pairs != nullptr) {
+        // results live behind the window lists in the same buffer (engine.cpp sizes it: 8 bytes per window slot)
+        uint32_t *results = reinterpret_cast<uint32_t *>(B.runs) + B.run_stride * uint64_t(B.run_cap);
+        const bool image = A.dense_image != nullptr;
+        const uint32_t lds1 = image ? A.dense_image_words * 4u : 16u;
+        hipError_t e = image ? hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_decide<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds1))
+                             : hipSuccess;
+        if (e != hipSuccess) return e;
+        const uint32_t per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(2u, (160u * 1024u) / std::max<uint32_t>(lds1, 1u)));
+        const uint64_t blocks1 = std::min<uint64_t>((max_items + 15) / 16, uint64_t(num_cus()) * per_cu);
+        if (image) hipLaunchKernelGGL(k_dense_decide<true>, dim3(uint32_t(blocks1)), dim3(1024), lds1, st, A, B, results);
+        else hipLaunchKernelGGL(k_dense_decide<false>, dim3(uint32_t(blocks1)), dim3(1024), lds1, st, A, B, results);
+        const uint32_t blocks2 = uint32_t((max_items + 255) / 256);
+        if (entry_bytes == 2) {
+            if (class_mode == 1) hipLaunchKernelGGL((k_dense_emit<uint16_t, 1>), dim3(blocks2), dim3(256), 0, st, A, B, results);
+            else hipLaunchKernelGGL((k_dense_emit<uint16_t, 0>), dim3(blocks2), dim3(256), 0, st, A, B, results);
+        } else {
+            if (class_mode == 1) hipLaunchKernelGGL((k_dense_emit<uint32_t, 1>), dim3(blocks2), dim3(256), 0, st, A, B, results);
+            else hipLaunchKernelGGL((k_dense_emit<uint32_t, 0>), dim3(blocks2), dim3(256), 0, st, A, B, results);
+        }
+        return hipGetLastError();
+    }
+    const uint32_t lds = 16u;   // (no image: candidates are verified through the tables in global memory)
+    auto go = [&](auto fn) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(fn, dim3(blocks), dim3(kWalkThreads), lds, st, A, B);
+        return hipGetLastError();
+    };
+#define ACMI_VERIFY_DENSE(E, M) go(k_verify_dense<E, M, false>)
+    if (entry_bytes == 2) return class_mode == 1 ? ACMI_VERIFY_DENSE(uint16_t, 1) : ACMI_VERIFY_DENSE(uint16_t, 0);
+    return class_mode == 1 ? ACMI_VERIFY_DENSE(uint32_t, 1) : ACMI_VERIFY_DENSE(uint32_t, 0);
+#undef ACMI_VERIFY_DENSE
+}
+
+// ------------------------------------------------------------------------------------------
+// k_walk_items: exact walk of WHOLE work items, one per thread (kernel 4).
+//
+// For text on which k_scan_lds' optimistic pass flags everything anyway -- keyword-like sets with events
+// in every wave-quad, the dense sets of BASELINE configs[4] -- the table walk is all there is.  One item per
+// thread, 2,048 walks per CU.  What bounded the first version was HBM, not the walk: a lane's bytes share a
+// 128-byte line with no other lane's, 2^19 lanes hold 64 MiB of such lines open at once -- twice the L2 --
+// and with one 16-byte block requested at a time every line was fetched from HBM again for each of its
+// blocks (TCC_MISS x 128 B = 8.5 x the haystack bytes, 6.3 TB/s of HBM traffic for 0.74 TB/s of text).  So a
+// lane requests LB blocks of one line back to back, one group ahead, and walks the group it holds: LB x 16
+// unrolled steps, no per-byte select.  LB = 4 (64 bytes) is the most that fits the 64 VGPRs of 8 waves per
+// SIMD and is the default: 1.16 ms per GiB of the keyword set of tools/bench_words.py against 1.42 ms with
+// single blocks; LB = 8 (whole lines, 96 VGPRs, 4 waves per SIMD) 1.59 ms.  Byte classes and the first 64 KiB of
+// the tile are in LDS; the cold-row load and the event block are the only branches.  Two items per thread
+// (their blocks side by side, conditional or unconditional cold loads) measured equal or slower and was dropped.
+// Same event rule and slab layout as run_epilogue.
+// ------------------------------------------------------------------------------------------
+// two workgroups per CU share the 160 KiB: 79 KiB each, 512 B of it the byte classes
+
+__device__ __forceinline__ uint64_t emit_event(const DevAutomaton &A, uint4 *out, uint64_t w, uint32_t hay, uint32_t pos, uint32_t state);
+
+// EMIT: the same walk as the DRAIN of a batch this kernel scanned -- a thread per OVERFLOWED item (its events did not fit
+// the slab), records written straight into their final slots.  Items of <= 1 KiB are what this kernel is given, and at tens of
+// events per item a wave per item (k_refill_wave: a round of dependent loads per 256 positions) was five times slower than
+// walking them again one per thread (a word list over text made of its words: 14 -> 3.6 ms per GiB).
+template <typename E, int MODE, int LB, bool EMIT = false>
+__global__ __launch_bounds__(kWalkThreads, (LB <= 4 ? 8 : 4)) void k_walk_items(DevAutomaton A, BatchArgs B, const uint64_t *rec_base,
+                                                                                uint4 *out, uint64_t cap) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint64_t total_items = EMIT ? uint64_t(B.counters[0]) : B.item_base[B.n_haystacks];   // (EMIT: entries of the overflow list)
+    if (uint64_t(blockIdx.x) * kWalkThreads >= total_items) return;
+    const uint64_t slot = uint64_t(blockIdx.x) * kWalkThreads + threadIdx.x;
+    const uint64_t item = EMIT ? (slot < total_items ? uint64_t(B.overflow_list[slot]) : 0ull) : slot;
+    __shared__ uint32_t s_walked;
+    if (threadIdx.x == 0) s_walked = 0;
+    uint4 rec = slot < total_items ? B.item_rec[item] : make_uint4(0u, 0u, 0u, 0u);
+    uint64_t wr = 0;   // EMIT: where the item's next record goes
+    uint32_t hay = 0;
+    if constexpr (EMIT) {
+        if (slot < total_items && rec_base[item + 1] <= cap) {
+            wr = rec_base[item];
+            hay = B.item_hay[item];
+        } else {
+            rec.z = 0u;   // (nothing to do: past the list, or the output buffer is too small -- the host grows it and launches again)
+        }
+    }
+    // LDS: [512 B byte classes (TABLE mode)] [tile rows]
+    const uint32_t cls_bytes = (MODE == 0) ? 512u : 0u;
+    const uint32_t tile_rows = A.row_bytes ? (kItemsTileBytes / A.row_bytes < A.trap ? kItemsTileBytes / A.row_bytes : A.trap) : 0u;
+    const uint16_t *cls_lds = (MODE == 0) ? reinterpret_cast<const uint16_t *>(smem) : nullptr;
+    const uint8_t *tile = smem + cls_bytes;
+    // a tile that leaves room takes its states' record counts along: where nearly every byte ends a pattern (a^1..a^16)
+    // the count was a dependent global load per byte, and that load was most of the kernel (0.33 ms per 32 MiB)
+    const uint32_t tile_bytes = (tile_rows * A.row_bytes + 15u) & ~15u;
+    const uint32_t cnt_rows = tile_bytes + tile_rows * 4u <= kItemsTileBytes ? tile_rows : 0u;
+    const uint32_t *cnt_lds = reinterpret_cast<const uint32_t *>(tile + tile_bytes);
+    {
+        if (MODE == 0 && threadIdx.x < 256) reinterpret_cast<uint16_t *>(smem)[threadIdx.x] = A.class_off[threadIdx.x];
+        const uint4 *tsrc = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(A.lds_image) + A.tile_offset);
+        uint4 *tdst = reinterpret_cast<uint4 *>(smem + cls_bytes);
+        const uint32_t n16 = tile_bytes >> 4;
+        for (uint32_t t = threadIdx.x; t < n16; t += kWalkThreads) tdst[t] = tsrc[t];
+        uint32_t *cdst = reinterpret_cast<uint32_t *>(smem + cls_bytes + tile_bytes);
+        for (uint32_t t = threadIdx.x; t < cnt_rows; t += kWalkThreads) cdst[t] = A.out_count[t];
+    }
+    __syncthreads();
+
+    ItemDesc it;
+    unpack_item(rec.x, rec.y, rec.z, rec.w, it);
+    const uint32_t n = rec.z;  // 0 for threads past the last item
+    const uint8_t *p = B.blob + (n ? it.begin - it.warm : 0);
+    const uint32_t warm = it.warm, pos_bias = it.pos0 - it.warm + 1u;
+    uint32_t st = 0;
+    EventRegs ev{0, 0};
+    auto step = [&](uint32_t byte, uint32_t jj) __attribute__((always_inline)) {
+        const uint32_t coff = class_offset<E, MODE>(A, cls_lds, byte);
+        uint32_t w = A.trap;
+        if (st < tile_rows) w = *reinterpret_cast<const E *>(tile + __umul24(st, A.row_bytes) + coff);
+        if (w >= A.trap) w = cold_step<E>(A, st, byte, coff);
+        st = w;
+        if (jj >= warm && is_final(A, st) && !(B.first_only && ev.n_ev)) {
+            if constexpr (EMIT) {
+                wr = emit_event(A, out, wr, hay, pos_bias + jj, st);
+            } else {
+                ev.n_rec += st < cnt_rows ? cnt_lds[st] : A.out_count[st];
+                if (ev.n_ev < B.slab_events) B.slab[uint64_t(ev.n_ev) * B.run_stride + item] = make_uint2(pos_bias + jj, st);
+            }
+            ++ev.n_ev;
+        }
+    };
+    // (written out: as a loop over an array of the four words hipcc kept the array in scratch memory)
+#define ACMI_STEP4(wd, jj) \
+    step((wd) & 0xffu, (jj)); step(((wd) >> 8) & 0xffu, (jj) + 1u); step(((wd) >> 16) & 0xffu, (jj) + 2u); step((wd) >> 24, (jj) + 3u);
+    auto step_block = [&](const uint4 &blk, uint32_t jj) __attribute__((always_inline)) {
+        ACMI_STEP4(blk.x, jj) ACMI_STEP4(blk.y, jj + 4u) ACMI_STEP4(blk.z, jj + 8u) ACMI_STEP4(blk.w, jj + 12u)
+    };
+#undef ACMI_STEP4
+    uint32_t j = 0;
+    // head: single bytes up to a 16-byte boundary, single blocks up to a group boundary
+    for (; j < n && (reinterpret_cast<uintptr_t>(p + j) & 15u) != 0; ++j) step(p[j], j);
+    for (; j + 16u <= n && (reinterpret_cast<uintptr_t>(p + j) & (16u * LB - 1u)) != 0; j += 16u)
+        step_block(*reinterpret_cast<const uint4 *>(p + j), j);
+    // body: groups of LB blocks of one line, the next group requested (back to back, clamped index) while this
+    // one is walked
+    const uint32_t ng = (n - j) / (16u * LB);
+    if (ng) {
+        const uint4 *q = reinterpret_cast<const uint4 *>(p + j);
+        uint4 cur[LB], nxt[LB];
+#pragma unroll
+        for (int i = 0; i < LB; ++i) cur[i] = q[i];
+#pragma unroll 1
+        for (uint32_t g = 0; g < ng; ++g) {
+            const uint4 *qn = q + (g + 1u < ng ? g + 1u : g) * LB;
+#pragma unroll
+            for (int i = 0; i < LB; ++i) nxt[i] = qn[i];
+#pragma unroll
+            for (int i = 0; i < LB; ++i) step_block(cur[i], j + 16u * uint32_t(i));
+#pragma unroll
+            for (int i = 0; i < LB; ++i) cur[i] = nxt[i];
+            j += 16u * LB;
+        }
+    }
+    // what is left: whole blocks, then bytes
+    for (; j + 16u <= n; j += 16u) step_block(*reinterpret_cast<const uint4 *>(p + j), j);
+    for (; j < n; ++j) step(p[j], j);
+
+    if constexpr (EMIT) return;
+    uint32_t walked = n;
+    if (ev.n_ev) {
+        B.ev_count[item] = ev.n_ev;
+        B.rec_count[item] = ev.n_rec;
+        if (ev.n_ev > B.slab_events) B.overflow_list[atomicAdd(&B.counters[0], 1u)] = uint32_t(item);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) walked += __shfl_xor(walked, d, 64);
+    if ((threadIdx.x & 63u) == 0 && walked) atomicAdd(&s_walked, (walked + 15u) >> 4);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_walked) atomicAdd(&B.counters[8u + (blockIdx.x & 7u)], s_walked);
+}
+
+hipError_t launch_walk_items(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,
+                             int group, hipStream_t st) {
+    if (max_items == 0) return hipSuccess;
+    const uint32_t lds = kItemsTileBytes + (class_mode == 0 ? 512u : 0u);
+    auto go = [&](auto fn) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        if (e != hipSuccess) return e;
+        const uint32_t blocks = uint32_t((max_items + kWalkThreads - 1) / kWalkThreads);
+        hipLaunchKernelGGL(fn, dim3(blocks), dim3(kWalkThreads), lds, st, A, B, static_cast<const uint64_t *>(nullptr), static_cast<uint4 *>(nullptr),
+                           uint64_t(0));
+        return hipGetLastError();
+    };
+    // group = 16-byte blocks a lane requests back to back: 1 (the first version), 4 or 8 (a whole line)
+#define ACMI_WALK_ITEMS(E, M) (group >= 8 ? go(k_walk_items<E, M, 8>) : group >= 4 ? go(k_walk_items<E, M, 4>) : go(k_walk_items<E, M, 1>))
+    if (entry_bytes == 2) return class_mode == 1 ? ACMI_WALK_ITEMS(uint16_t, 1) : ACMI_WALK_ITEMS(uint16_t, 0);
+    return class_mode == 1 ? ACMI_WALK_ITEMS(uint32_t, 1) : ACMI_WALK_ITEMS(uint32_t, 0);
+#undef ACMI_WALK_ITEMS
+}
+
+// The drain of a batch this kernel scanned (launch_refill mode 3): a thread per overflowed item, records written in place.
+void launch_walk_items_emit(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, const uint64_t *rec_base, void *out,
+                            uint64_t cap, hipStream_t st, int class_mode) {
+    const uint32_t lds = kItemsTileBytes + (class_mode == 0 ? 512u : 0u);
+    const uint32_t blocks = uint32_t((max_items + kWalkThreads - 1) / kWalkThreads);   // (workgroups past the list's end leave at once)
+    auto go = [&](auto fn) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        hipLaunchKernelGGL(fn, dim3(blocks), dim3(kWalkThreads), lds, st, A, B, rec_base, static_cast<uint4 *>(out), cap);
+    };
+    if (entry_bytes == 2) { if (class_mode == 1) go(k_walk_items<uint16_t, 1, 4, true>); else go(k_walk_items<uint16_t, 0, 4, true>); }
+    else { if (class_mode == 1) go(k_walk_items<uint32_t, 1, 4, true>); else go(k_walk_items<uint32_t, 0, 4, true>); }
+}
+
+}  // namespace acmi

@@ -1,4 +1,4 @@
-// kernels.hpp -- launchers implemented in kernels.hip.
+// kernels.hpp -- launchers implemented in the kernel family files k_*.hip (device helpers they share: kdev.hpp).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -10,7 +10,7 @@
 
 namespace acmi {
 
-// single-pass scans (kernels.hip): tiles of 2048 elements, one status word per tile
+// single-pass scans (kdev.hpp, k_pipeline.hip): tiles of 2048 elements, one status word per tile
 uint32_t scan_tiles(uint64_t n);
 // isync: 8 + 8 x scan_tiles(n_haystacks + 1) zeroed bytes {ticket, bad-offsets flag, status words}
 void launch_items(const BatchArgs &B, uint64_t blob_bytes, uint64_t max_items, uint64_t *item_base, uint32_t *isync, hipStream_t st);

@@ -119,7 +119,7 @@ class FlatTables:
         return int(h >> 16) in [int(x) for x in self.anchor[(h >> 3) & 0x3FFF]]
 
     def cold_step(self, s: int, b: int) -> int:
-        """kernels.hip cold_step(): dense row, or goto / failure records until a dense row is reached."""
+        """kdev.hpp cold_step(): dense row, or goto / failure records until a dense row is reached."""
         c = int(self.cls[b])
         if not self.compact:
             return int(self.table[s, c])

@@ -1,7 +1,7 @@
 // builder_fuzz.cpp -- TEST INFRASTRUCTURE.  The host side of libacmi (csrc/automaton.cpp: trie insertion, BFS failure
 // links, state numbering, dense rows, compact goto/failure records, flat output lists, anchor tables) compiled
 // with -fsanitize=address,undefined and driven by seeded random pattern sets; the flat automaton is walked here
-// exactly as the device's exact path walks it (kernels.hip exact_step / cold_step / emit_event) and every
+// exactly as the device's exact path walks it (kdev.hpp exact_step / cold_step / emit_event) and every
 // record is compared with the oracle (oracle/ac_oracle.c, itself pinned to the reference's goldens).
 //
 //   builder_fuzz <cases> <seed>      exit status 0 = all cases identical, no sanitizer report
@@ -48,7 +48,7 @@ uint32_t tile_entry(const FlatAutomaton &fa, size_t row, uint32_t col) {
                                : reinterpret_cast<const uint32_t *>(fa.lds_image.data())[row * fa.n_columns + col];
 }
 
-// kernels.hip cold_step
+// kdev.hpp cold_step
 uint32_t cold_step(const FlatAutomaton &fa, uint32_t s, uint32_t byte) {
     const uint32_t col = fa.class_of_byte[byte];
     if (!fa.compact) return dense_entry(fa, s, col);
@@ -106,7 +106,7 @@ void walk(const FlatAutomaton &fa, const uint8_t *text, size_t n, int find_all, 
     }
 }
 
-// slot of a window in the fingerprint table (as kernels.hip verify_candidate finds it), or -1
+// slot of a window in the fingerprint table (as kdev.hpp verify_candidate finds it), or -1
 long anchor_slot(const FlatAutomaton &fa, const uint8_t *window) {
     uint32_t words[4] = {0, 0, 0, 0};
     std::memcpy(words, window, fa.anchor_q);

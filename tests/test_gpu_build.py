@@ -1,5 +1,5 @@
 """The level-synchronous part of the automaton build on the device (failure links + per-state outputs, one launch per
-trie depth: kernels.hip k_build_level) must leave byte-identical tables (reference: ac_trie_set_failure,
+trie depth: k_misc.hip k_build_level) must leave byte-identical tables (reference: ac_trie_set_failure,
 ahocorasick.c:344-368; node_collect_matches, node.c:424-441)."""
 import time
 
