@@ -276,7 +276,11 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *                    and back to 1 for a while if a batch shows the text defeats the filter (the fast
  *                    kernel is probed again after 16, 32, ... batches); from 1 on to 4 if a batch shows
  *                    that its optimistic pass flags most bytes anyway; 4 = exact table walk of whole
- *                    work items only (keyword-like and dense-match text)                 [any time]
+ *                    work items only (keyword-like and dense-match text); 6 = the tile walk: the same exact
+ *                    walk with a work item spread over the lanes of a wave and the records placed by a running
+ *                    sum in ONE pass -- no slabs, no drain (findAll = true, patterns of <= 129 B; what automatic
+ *                    mode takes instead of 4 unless the output is denser than a record per two bytes) [any time]
+ *   "tile_w", "tile_p"  kernel 6: bytes per lane (16, 32, 64) and lanes per work item (1..64); 0 = automatic [any time]
  *   "tiny_rows"      kernel 2: 1 (default) batches of haystacks of <= 1 KiB on average take the variant whose
  *                    waves pack one-row work items eight to a step, 0 never                [any time]
  *   "short_rows"     kernel 2: the variant that skips the 1-KiB rows a work item lacks: -1 (default)

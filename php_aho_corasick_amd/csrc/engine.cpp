@@ -104,7 +104,8 @@ struct acmi_handle {
     bool slab_set = false;     // "slab_events" set by the caller; else learned from the data (slab_auto: 16 / 32 .. 256 slots)
     bool run_cap_set = false;  // by the caller; else learned (run_auto: 16 .. 64 entries); the dense anchor form takes 256 window starts
     uint64_t chunk_opt = 0;
-    int kernel = 3;  // 0 plain global table, 1 LDS-tile walk, 2 anchor filter (if eligible), 3 automatic
+    int kernel = 3;  // 0 plain global table, 1 LDS-tile walk, 2 anchor filter (if eligible), 3 automatic, 4 whole-item walk, 6 tile walk (single pass, ordered output)
+    int tile_w = 0, tile_p = 0;   // k_walk_tiles: bytes per lane / lanes per item (0: tiles_geometry chooses)
     // automatic mode: a batch on which the fast kernel lost (most bytes had to be walked exactly anyway) moves the
     // handle to the slower, safer kernel -- for `*_left` batches, then the fast one is probed again; every further
     // loss doubles the span (16 .. 1024 batches), a win resets it.  Batches under kAutoMinBytes decide nothing.
@@ -145,6 +146,7 @@ struct acmi_handle {
 
     // workspace (grow-only)
     DevBuf d_blob, d_off, d_rec_base, d_slab, d_ovf, d_counters, d_runs, d_run_count, d_first;
+    DevBuf d_tile_queue, d_tile_sync;   // k_walk_tiles: the waves' event queues; {ticket, look-back words}
     // The item table of a batch (item_base, item -> haystack, packed item records, zeroed per-item counters, k_items' own sync
     // words) exists once per slot: k_items needs nothing from the batch before, so with "items_ahead" it runs on a side stream
     // while that batch's scan is still on the chip, and the pipeline proper waits for its event.
@@ -196,6 +198,7 @@ struct acmi_handle {
         uint32_t slab_used = 0;        // event slots per item of this batch
         uint64_t est_items = 0;
         uint32_t run_used = 0, run_max = 0;   // run-list entries per item of this batch; what it could have had
+        uint32_t tile_w = 0, tile_p = 0;      // k_walk_tiles geometry of this batch
         bool refill_launched = false;  // the drain of overflowed items was enqueued with the pipeline (else: only if the batch turns out to need it)
         DevBuf d_prefix, d_out;        // valid from this batch's end until the second begin after its own
     };
@@ -368,6 +371,12 @@ int build_parts(acmi_handle *h) {
     return ACMI_OK;
 }
 
+// A split that could not be built leaves no half of itself behind: the handle goes on as the single automaton it is.
+void drop_parts(acmi_handle *h) {
+    for (acmi_handle *&c : h->part)
+        if (c) { (void)acmi_destroy(c); c = nullptr; }
+}
+
 int ensure_finalized(acmi_handle *h) {
     if (h->aut.finalized()) return 0;
     std::string err;
@@ -400,8 +409,10 @@ int ensure_finalized(acmi_handle *h) {
             if (m.accepted) (m.length >= 7 ? n_long : n_short)++;
         const bool want = n_long > 0 && n_short > 0 && (h->split_opt > 0 || (n_short <= 256 && n_long >= 16 * n_short));
         if (want) {
-            const int rc = build_parts(h);
-            if (rc < 0) return rc;
+            int rc;
+            try { rc = build_parts(h); } catch (...) { drop_parts(h); throw; }
+            // (out of memory, a part that cannot be finalized: matched unsplit, through the table walk -- slower, same records)
+            if (rc < 0) drop_parts(h);
         }
     }
     return 1;
@@ -764,8 +775,22 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     // asks for.)
     if (h->kernel == 3 && kernel == 2 && !h->exact_only && blob_bytes >= kAutoMinBytes && blob_bytes / nh < kSmallItemBytes) kernel = 1;
     if (h->kernel == 3 && kernel == 1 && h->exact_only) kernel = 4;
+    // The whole-item walk's successor for everything but output that is denser than a record per two bytes (which the wave drain
+    // writes as whole rows) and findAll = false (one event per haystack: the slabs are exact there): k_walk_tiles, one pass,
+    // records placed by a running sum instead of slab -> overflow -> second walk.
+    uint32_t tile_w = 0, tile_p = 0;
+    if ((h->kernel == 6 || (h->kernel == 3 && kernel == 4 && !h->dense_output)) && find_all &&
+        tiles_geometry(fa.max_pattern_length, fa.n_states, blob_bytes, nh, &tile_w, &tile_p)) {
+        kernel = 6;
+        if (h->tile_w) tile_w = uint32_t(h->tile_w);
+        if (h->tile_p) tile_p = uint32_t(h->tile_p);
+    } else if (h->kernel == 6) {
+        kernel = 4;
+    }
     F.kernel_used = kernel;
-    const uint32_t chunk = choose_chunk(h, blob_bytes, nh, kernel);
+    F.tile_w = tile_w;
+    F.tile_p = tile_p;
+    const uint32_t chunk = kernel == 6 ? tile_w * tile_p : choose_chunk(h, blob_bytes, nh, kernel);
     const uint64_t max_items = blob_bytes / chunk + nh;
     // Event slots per item.  An item with more events than its slab holds is walked AGAIN by the drain, a wave per item, and
     // for text with tens to hundreds of matches per item -- a word list over ordinary prose -- that costs ten times what a
@@ -832,7 +857,14 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     // whose filter lost because items overflowed them, before the automatic choice gives the filter up: run_batch_end)
     uint32_t run_max = 16;
     while (run_max < 64u && uint64_t(run_max) * 2 * 16 * est_items * 8 <= blob_bytes) run_max *= 2;
-    const uint32_t Q = h->run_cap_set ? std::max<uint32_t>(1, h->run_cap) : dense ? 256u : std::min(std::max(16u, h->run_auto), run_max);
+    // (dense form: an item of L bytes has at most L hit windows, and 256 entries for every 256-byte haystack would be 8 x the batch:
+    // what an average item can hold, at least 16, and never more than a quarter of the batch's bytes in all)
+    uint32_t dense_q = 256u;
+    if (dense) {
+        const uint64_t avg = std::max<uint64_t>(16, blob_bytes / est_items);
+        while (dense_q > 16u && (dense_q > avg || run_stride * dense_q * 8 > std::max<uint64_t>(blob_bytes / 4, 64ull << 20))) dense_q /= 2;
+    }
+    const uint32_t Q = h->run_cap_set ? std::max<uint32_t>(1, h->run_cap) : dense ? dense_q : std::min(std::max(16u, h->run_auto), run_max);
     F.run_used = Q;
     F.run_max = (h->run_cap_set || dense) ? Q : run_max;
     HIPCHK(h, h->d_runs.ensure_keep(run_stride * Q * (dense ? 8 : 16), h->retired));   // (dense: window starts, then k_dense_decide's results)
@@ -929,8 +961,20 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
         }
     }
 
+    // Records are written optimistically into a buffer of the capacity the batches before needed (at least): ONE host
+    // synchronisation per batch; a batch that produced more is run again into a grown buffer (run_batch_end).
+    HIPCHK(h, F.d_out.ensure(std::max<size_t>(16, h->out_want)));
+    const uint64_t cap = F.d_out.cap / 16;
+    if (kernel == 6) {
+        HIPCHK(h, h->d_tile_queue.ensure_keep(tiles_queue_entries(tile_w) * 8, h->retired));
+        HIPCHK(h, h->d_tile_sync.ensure_keep(8 + tiles_status_words(max_items, tile_p) * 8, h->retired));
+        HIPCHK(h, hipMemsetAsync(h->d_tile_sync.p, 0, 8 + tiles_status_words(max_items, tile_p) * 8, st));
+    }
     if (h->profile) HIPCHK(h, hipEventRecord(F.ev[1], st));
-    if (kernel == 4) {
+    if (kernel == 6) {
+        HIPCHK(h, launch_walk_tiles(h->dA, B, max_items, int(fa.entry_bytes), int(fa.class_mode), tile_w, tile_p, h->d_tile_queue.p,
+                                    h->d_tile_sync.as<uint32_t>(), h->d_tile_sync.as<uint64_t>() + 1, F.d_out.p, cap, st));
+    } else if (kernel == 4) {
         // exact walk only (k_walk_items): for text on which k_scan_lds' optimistic
         // pass flags everything anyway (events in every wave-quad)
         HIPCHK(h, launch_walk_items(h->dA, B, max_items, int(fa.entry_bytes), int(fa.class_mode), h->walk_group, st));
@@ -952,15 +996,16 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     // Expansion is enqueued optimistically with the output capacity of the previous call, so the
     // whole pipeline needs ONE host synchronisation (the read-back of the summary at the end).  Only
     // when the batch produced more records than fit is the buffer grown and the expansion re-run.
-    HIPCHK(h, F.d_out.ensure(std::max<size_t>(16, h->out_want)));  // (at least what any earlier batch of this handle needed)
-    const uint64_t cap = F.d_out.cap / 16;
     // (also: per-haystack prefix, the summary for the host next to the overflow counter -- counters[2..3] = total
     // records, [4..5] = items -- and the zeroing of the next batch's sync block)
     launch_expand(h->dA, B, max_items, h->d_rec_base.as<uint64_t>(), F.d_out.p, cap, F.d_prefix.as<uint64_t>(),
                   pinned_dev, sync_next, sync_words, sync_cur + 17, status1, d_isync.as<uint32_t>() + 1, true, st,
-                  h->d_isync[slot_index ^ 1].as<uint32_t>(), uint32_t((h->d_isync[slot_index ^ 1].cap & ~size_t(15)) / 4));
-    h->isync_clean[slot_index ^ 1] = h->d_isync[slot_index ^ 1].p != nullptr;
-    F.refill_launched = find_all && h->refill_armed;
+                  h->items_ahead ? nullptr : h->d_isync[slot_index ^ 1].as<uint32_t>(),
+                  h->items_ahead ? 0u : uint32_t((h->d_isync[slot_index ^ 1].cap & ~size_t(15)) / 4));
+    // ("items_ahead": the next batch's k_items may already be running on the side stream, behind this batch's SCAN only -- its
+    // sync words are zeroed by that stream's own memset, never from here)
+    h->isync_clean[slot_index ^ 1] = !h->items_ahead && h->d_isync[slot_index ^ 1].p != nullptr;
+    F.refill_launched = find_all && h->refill_armed && kernel != 6;   // (k_walk_tiles leaves no item to drain)
     if (F.refill_launched) launch_refill(h->dA, B, max_items, int(fa.entry_bytes), h->d_rec_base.as<uint64_t>(), F.d_out.p, cap, refill_mode(h, kernel), st, int(fa.class_mode));
     F.sync_next = sync_next;
     F.sync_words = sync_words;
@@ -1129,11 +1174,16 @@ int run_batch_end(acmi_handle *h) {
         if (h->enqueue_seq == F.seq) {
             if (too_small) HIPCHK(h, F.d_out.ensure(total * 16));
             const uint64_t cap = F.d_out.cap / 16;
-            if (too_small)
+            if (F.kernel_used == 6) {   // the walk again, into the grown buffer (prefix array and summary stand)
+                const size_t sync_bytes = 8 + tiles_status_words(F.max_items, F.tile_p) * 8;
+                HIPCHK(h, hipMemsetAsync(h->d_tile_sync.p, 0, sync_bytes, st));
+                HIPCHK(h, launch_walk_tiles(h->dA, F.args, F.max_items, int(fa.entry_bytes), int(fa.class_mode), F.tile_w, F.tile_p, h->d_tile_queue.p,
+                                            h->d_tile_sync.as<uint32_t>(), h->d_tile_sync.as<uint64_t>() + 1, F.d_out.p, cap, st));
+            } else if (too_small)
                 launch_expand(h->dA, F.args, F.max_items, h->d_rec_base.as<uint64_t>(), F.d_out.p, cap, F.d_prefix.as<uint64_t>(),
                               h->pinned_dev + kPinWords * slot_index, F.sync_next, F.sync_words, nullptr, nullptr,
                               h->d_isync[slot_index].as<uint32_t>() + 1, false, st);
-            if (F.find_all)
+            if (F.find_all && F.kernel_used != 6)
                 launch_refill(h->dA, F.args, F.max_items, int(fa.entry_bytes), h->d_rec_base.as<uint64_t>(),
                               F.d_out.p, cap, refill_mode(h, F.kernel_used), st, int(fa.class_mode));
             HIPCHK(h, hipGetLastError());
@@ -1324,7 +1374,7 @@ int acmi_destroy(acmi_handle *h) {
             for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_out_off, &h->d_out_list, &h->d_cold_rec, &h->d_cold_edges, &h->d_chain_byte, &h->d_chain_run, &h->d_slot_pair, &h->d_pairs, &h->d_pat_bytes, &h->d_dense_img, &h->d_merge_counts, &h->d_merge_sync, &h->d_rep_off, &h->d_rep_bytes, &h->d_plan, &h->d_plan_out, &h->d_tail_out, &h->d_rep_sync, &h->d_nom_count, &h->d_out_len, &h->d_rep_out_off, &h->d_rep_out, &h->d_blob,
                               &h->d_off, &h->d_sync[0], &h->d_sync[1], &h->d_item_base[0], &h->d_item_hay[0], &h->d_item_rec[0], &h->d_zero[0], &h->d_isync[0],
                               &h->d_item_base[1], &h->d_item_hay[1], &h->d_item_rec[1], &h->d_zero[1], &h->d_isync[1],
-                              &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_first, &h->fly[0].d_prefix, &h->fly[0].d_out, &h->fly[1].d_prefix, &h->fly[1].d_out, &h->d_runs, &h->d_run_count})
+                              &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_first, &h->d_tile_queue, &h->d_tile_sync, &h->fly[0].d_prefix, &h->fly[0].d_out, &h->fly[1].d_prefix, &h->fly[1].d_out, &h->d_runs, &h->d_run_count})
                 b->release();
             for (void *q : h->retired) (void)hipFree(q);
             for (auto &evt : h->ev)
@@ -1542,21 +1592,8 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out) {
     });
 }
 
-int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
-    return guarded(h, [&]() -> int {
-        if (!live(h)) return ACMI_E_INVALID;
-        if (!key) return ACMI_E_ARG;
-        const std::string k(key);
-        if (k == "split") {
-            if (h->aut.finalized()) return ACMI_E_FINALIZED;
-            h->split_opt = value < 0 ? -1 : (value ? 1 : 0);
-            return ACMI_OK;
-        }
-        if (!h->is_part) {
-            h->option_log.emplace_back(k, value);
-            for (acmi_handle *c : h->part)   // ("any time" options reach the parts of a split set too)
-                if (c) (void)acmi_set_option(c, key, value);
-        }
+// One option validated and applied to ONE handle (acmi_set_option logs and forwards it afterwards).
+static int apply_option(acmi_handle *h, const std::string &k, int64_t value) {
         if (k == "lds_bytes") {
             if (h->aut.finalized()) return ACMI_E_FINALIZED;
             if (value < 2048 || value > 160 * 1024 - 64) return ACMI_E_ARG;
@@ -1573,11 +1610,17 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
             if (value < 0) return ACMI_E_ARG;
             h->chunk_opt = uint64_t(value);
         } else if (k == "kernel") {
-            if (value < 0 || value > 4) return ACMI_E_ARG;
+            if (value < 0 || value > 6 || value == 5) return ACMI_E_ARG;
             h->kernel = int(value);
             h->anchor_off = false;
             h->exact_only = false;
             h->anchor_span = h->exact_span = 16;
+        } else if (k == "tile_w") {   // k_walk_tiles: bytes per lane (0: automatic)
+            if (value != 0 && value != 16 && value != 32 && value != 64) return ACMI_E_ARG;
+            h->tile_w = int(value);
+        } else if (k == "tile_p") {   // k_walk_tiles: lanes per work item (0: automatic)
+            if (value < 0 || value > 64) return ACMI_E_ARG;
+            h->tile_p = int(value);
         } else if (k == "ilp") {
             if (value != 1 && value != 2) return ACMI_E_ARG;
             h->ilp = int(value);
@@ -1650,6 +1693,31 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
             return ACMI_E_ARG;
         }
         return ACMI_OK;
+}
+
+int acmi_set_option(acmi_handle *h, const char *key, int64_t value) {
+    return guarded(h, [&]() -> int {
+        if (!live(h)) return ACMI_E_INVALID;
+        if (!key) return ACMI_E_ARG;
+        const std::string k(key);
+        if (k == "split") {
+            if (h->aut.finalized()) return ACMI_E_FINALIZED;
+            h->split_opt = value < 0 ? -1 : (value ? 1 : 0);
+            return ACMI_OK;
+        }
+        // this handle first: a value it rejects is neither logged (the log is replayed on the parts of a split set) nor
+        // forwarded, so that the handle and its parts cannot come to differ
+        int rc = apply_option(h, k, value);
+        if (rc != ACMI_OK) return rc;
+        if (!h->is_part) {
+            h->option_log.emplace_back(k, value);
+            for (acmi_handle *c : h->part) {   // ("any time" options reach the parts of a split set too)
+                if (!c) continue;
+                const int rc2 = acmi_set_option(c, key, value);
+                if (rc2 < 0) { h->last_error = "a part of the split set refused the option"; rc = rc2; }
+            }
+        }
+        return rc;
     });
 }
 
@@ -1948,10 +2016,10 @@ int comm_allgather(acmi_comm *c, const void *send, void *recv, size_t bytes, hip
     }
     if (c->fabric) {
         LocalFabric &F = *c->fabric;
-        if (hipEventRecord(F.ready[size_t(c->rank)], st) != hipSuccess) return ACMI_E_DEVICE;
+        // (an error on this rank travels THROUGH both barriers: a rank that left early would leave its peers waiting for ever)
+        int rc = hipEventRecord(F.ready[size_t(c->rank)], st) == hipSuccess ? ACMI_OK : ACMI_E_DEVICE;
         F.send[size_t(c->rank)] = send;
         F.barrier();
-        int rc = ACMI_OK;
         for (int r = 0; r < c->world && rc == ACMI_OK; ++r) {
             if (hipStreamWaitEvent(st, F.ready[size_t(r)], 0) != hipSuccess ||
                 hipMemcpyAsync(static_cast<uint8_t *>(recv) + size_t(r) * bytes, F.send[size_t(r)], bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
@@ -1972,10 +2040,9 @@ int comm_bcast_group(acmi_comm *c, const std::vector<BcastOp> &ops, hipStream_t 
     if (c->world == 1 || ops.empty()) return ACMI_OK;
     if (c->fabric) {
         LocalFabric &F = *c->fabric;
-        if (hipEventRecord(F.ready[size_t(c->rank)], st) != hipSuccess) return ACMI_E_DEVICE;
+        int rc = hipEventRecord(F.ready[size_t(c->rank)], st) == hipSuccess ? ACMI_OK : ACMI_E_DEVICE;
         F.ops[size_t(c->rank)] = ops;
         F.barrier();
-        int rc = ACMI_OK;
         for (size_t i = 0; i < ops.size() && rc == ACMI_OK; ++i) {
             const BcastOp &mine = ops[i];
             if (mine.root == c->rank || mine.bytes == 0) continue;
@@ -2166,7 +2233,12 @@ int acmi_comm_allgather_result(acmi_comm *c, acmi_handle *h, uint64_t n_haystack
             if (rc < 0) return comm_fail(h, c, rc, c->last_error.empty() ? "status exchange failed" : c->last_error);
             for (int r = 0; r < W; ++r)
                 if (all[size_t(r) * kHdrWords + 2] != kCommOk) {
-                    c->cap_rec = c->cap_hay = 0;   // (every rank: the next call tries again from scratch)
+                    // (every rank: the next call tries again from scratch -- also the rank whose allocation failed, which
+                    // would otherwise report "out of memory" in every later header round without ever trying again)
+                    c->cap_rec = c->cap_hay = 0;
+                    c->cap_ok = true;
+                    c->d_prefix.release();
+                    c->d_records.release();
                     return comm_fail(h, c, r == c->rank ? ACMI_E_NOMEM : ACMI_E_DEVICE, "rank " + std::to_string(r) + " is out of device memory");
                 }
         }

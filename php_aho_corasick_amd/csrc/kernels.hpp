@@ -20,6 +20,13 @@ hipError_t launch_walk_runs(const DevAutomaton &A, const BatchArgs &B, uint64_t 
                             hipStream_t st);
 hipError_t launch_walk_items(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,
                              int ilp, hipStream_t st);
+// k_walk_tiles (k_tiles.hip, kernel 6): the exact walk with exact-sized ordered output in one pass.  Geometry: W bytes per lane,
+// P lanes per work item (chunk_bytes = P x W, items from k_items with align_warm = 0); false: not for this automaton.
+bool tiles_geometry(uint32_t max_pattern_length, uint32_t n_states, uint64_t blob_bytes, uint64_t n_haystacks, uint32_t *W, uint32_t *P);
+uint64_t tiles_queue_entries(uint32_t W);                       // 8-byte entries of the waves' event queues
+uint64_t tiles_status_words(uint64_t max_items, uint32_t P);    // 8-byte look-back words (zeroed, behind an 8-byte ticket)
+hipError_t launch_walk_tiles(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode, uint32_t W, uint32_t P,
+                             void *queue, uint32_t *ticket, uint64_t *status, void *out, uint64_t cap, hipStream_t st);
 void launch_first_only(const BatchArgs &B, uint32_t *first_item, uint64_t max_items, hipStream_t st);
 // scan = true: also the exclusive scan of the per-item record counts (ticket / status: zeroed sync words); false: rec_base is read
 void launch_expand(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, uint64_t *rec_base, void *out,

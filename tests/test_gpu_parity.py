@@ -93,6 +93,11 @@ VARIANTS = [dict(kernel=1, persistent=1, chunk_bytes=64), dict(kernel=1, persist
             # exact walk of whole items, 1 / 2 / 4 items per thread
             dict(kernel=4, walk_group=1), dict(kernel=4, walk_group=4, chunk_bytes=48, slab_events=1), dict(kernel=4, walk_group=8, chunk_bytes=256, lds_bytes=4096),
             dict(kernel=4, walk_group=8, slab_events=2, refill=2),
+            # the tile walk (k_walk_tiles): automatic geometry, every piece size, odd lane counts per item, tiny LDS tile + compact
+            # records, no flat output lists
+            dict(kernel=6, small_path=0), dict(kernel=6, small_path=0, tile_w=16, tile_p=3), dict(kernel=6, small_path=0, tile_w=32, tile_p=64),
+            dict(kernel=6, small_path=0, tile_w=64, tile_p=1), dict(kernel=6, small_path=0, tile_w=16, tile_p=64, compact=1, dense_bytes=0, lds_bytes=2048),
+            dict(kernel=6, small_path=0, tile_w=64, tile_p=7, max_flat_outputs=0),
             # early stop of single-window anchor walks: forced on / off
             dict(kernel=2, early_stop=2), dict(kernel=2, early_stop=2, chunk_bytes=256, compact=1, dense_bytes=0, lds_bytes=2048), dict(kernel=2, early_stop=0)]
 
