@@ -31,11 +31,14 @@ using namespace acmi;
 
 namespace {
 
+uint64_t g_dev_allocs = 0;   // device allocations made so far (a batch during whose enqueue one happened is not timed: hipMalloc stalls the host between its launches)
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
+        ++g_dev_allocs;
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
@@ -50,6 +53,7 @@ struct DevBuf {
     // device, which would serialise the two batches, and the older batch's arguments keep pointing at live memory.
     hipError_t ensure_keep(size_t bytes, std::vector<void *> &retired) {
         if (bytes <= cap) return hipSuccess;
+        ++g_dev_allocs;
         void *fresh = nullptr;
         const size_t want = bytes + bytes / 8 + 256;
         hipError_t e = hipMalloc(&fresh, want);
@@ -113,9 +117,21 @@ struct acmi_handle {
     // boundary even when there is nothing to drain: it is enqueued with the pipeline only while batches need it (the batch
     // before did, or the pattern set is a dense one); a batch that needs it unexpectedly gets it at its end.
     bool refill_armed = false;
-    bool anchor_off = false;  // the anchor filter lost on this handle's data: table walk meanwhile
-    bool exact_only = false;  // k_scan_lds' optimistic pass flagged most of a batch: exact whole-item walk meanwhile
-    uint32_t anchor_left = 0, anchor_span = 16, exact_left = 0, exact_span = 16;
+    // Automatic mode (kernel = 3) is a MEASURED choice (choose_strategy / learn_strategy below): per class of batch (findAll x
+    // size) the handle keeps what a byte cost on every scan strategy it has run -- from the two events every batch records
+    // around its pipeline -- runs the cheapest, and probes an alternative when the current one costs more than 1.5 x what that
+    // alternative is known (or, untried, expected) to cost, each alternative on its own back-off (16, 32 .. 1,024 batches after a
+    // lost probe).  Round 3 had thresholds here (bytes walked, matches per byte, candidates per byte), each found as a 5-10 x cliff.
+    enum Strategy { kStratAnchor = 0, kStratLds = 1, kStratTiles = 2, kStratItems = 3, kStratCount = 4 };
+    struct ChoiceClass {
+        float cost[kStratCount] = {0, 0, 0, 0};      // ms per GiB of haystack bytes, moving average of the batches run on it (0: never run)
+        uint32_t wait[kStratCount] = {0, 0, 0, 0};   // batches until this alternative may be probed again
+        uint32_t span[kStratCount] = {16, 16, 16, 16};   // its back-off after the next lost probe
+        int cur = -1;                                // strategy in use (-1: not seeded yet)
+        uint32_t pending = 0;                        // bit s: probe strategy s with one of the next batches
+    };
+    ChoiceClass choice[2][8];   // [findAll][size class | short haystacks << 2]
+    uint32_t probes = 0, switches = 0;   // statistics ("choice_probes", "choice_switches")
     int ilp = 1;
     int group_quads = 8;
     int small_path = 1;   // 1: host batches of <= 64 KiB / <= 1024 haystacks take the one-launch kernel
@@ -199,6 +215,9 @@ struct acmi_handle {
         uint64_t est_items = 0;
         uint32_t run_used = 0, run_max = 0;   // run-list entries per item of this batch; what it could have had
         uint32_t tile_w = 0, tile_p = 0;      // k_walk_tiles geometry of this batch
+        int strategy = -1, choice_class = 0;  // automatic mode: the strategy this batch ran on (-1: the caller fixed the kernel)
+        bool probe = false;                   // ... as a probe of an alternative
+        bool timed = false;                   // nothing was allocated while it was enqueued: its events say what it cost
         bool refill_launched = false;  // the drain of overflowed items was enqueued with the pipeline (else: only if the batch turns out to need it)
         DevBuf d_prefix, d_out;        // valid from this batch's end until the second begin after its own
     };
@@ -397,8 +416,6 @@ int ensure_finalized(acmi_handle *h) {
     // expected to look like the LONG patterns, and the estimate "text over the short patterns' own alphabet" says nothing; the
     // first batch's statistics decide)
     if (fa.est_flag_rate * 8192.0 > double(h->run_cap) && !h->is_part) {
-        h->exact_only = true;
-        h->exact_left = h->exact_span;
         h->refill_armed = true;   // (dense sets: the first batch will want its overflowed items drained)
         h->dense_output = fa.est_flag_rate >= 0.5;   // (an event every other byte of the patterns' own alphabet: the wave drain from the first batch on)
     }
@@ -682,6 +699,102 @@ uint32_t choose_chunk(const acmi_handle *h, uint64_t blob_bytes, size_t nh, int 
     return uint32_t(std::min<uint64_t>(c, 1u << 30));
 }
 
+// ---- automatic mode: the measured choice of the scan strategy --------------------------------------------------------------
+// Batches are told apart by size (small ones are launch-bound whatever scans them) and by whether their haystacks are short
+// (under 512 B on average: the anchor kernel spends a wave step per work item, the walks a lane): what one kind of batch
+// taught the handle says little about the other.
+int choice_class(uint64_t blob_bytes, size_t nh) {
+    const int size = blob_bytes < (16ull << 20) ? 0 : blob_bytes < (256ull << 20) ? 1 : blob_bytes < (4ull << 30) ? 2 : 3;
+    return size | ((nh && blob_bytes / nh < 512) ? 4 : 0);
+}
+
+// What a GiB is EXPECTED to cost (ms) on a strategy this handle has not run yet: the rate the kernel reaches on text it
+// suits.  Only decides whether an untried alternative is worth a probe (one whose best case is no better than what the current
+// strategy measures is never tried); every decision between strategies that have run is taken on measured times.
+float nominal_cost(const acmi_handle *h, int strat, uint64_t blob_bytes, size_t nh) {
+    const FlatAutomaton &fa = h->aut.flat();
+    const double avg = nh ? double(blob_bytes) / double(nh) : 0.0;
+    switch (strat) {
+    case acmi_handle::kStratAnchor: {
+        double c = fa.anchor_dense ? 0.45 : fa.anchor_mode == 2 ? 0.30 : 0.19;
+        if (avg < 2048.0) c *= 2048.0 / std::max(avg, 128.0) * 0.5 + 0.5;          // (a wave step per work item: short haystacks idle its lanes)
+        return float(c);
+    }
+    case acmi_handle::kStratLds: return fa.compact ? 2.0f : 0.33f;
+    case acmi_handle::kStratTiles: return fa.compact ? 6.0f : (uint64_t(fa.trap) * (fa.n_columns * fa.entry_bytes + 4u) <= 60u * 1024u && fa.trap + 1u == fa.n_states) ? 1.0f : 1.7f;
+    default: return fa.compact ? 8.0f : 1.3f;
+    }
+}
+
+bool strategy_eligible(const acmi_handle *h, int strat, uint64_t blob_bytes, size_t nh, int find_all) {
+    const FlatAutomaton &fa = h->aut.flat();
+    uint32_t w = 0, p = 0;
+    switch (strat) {
+    case acmi_handle::kStratAnchor: return fa.anchor_q != 0;
+    case acmi_handle::kStratTiles: return find_all && tiles_geometry(fa.max_pattern_length, fa.n_states, blob_bytes, nh, &w, &p);
+    default: return true;
+    }
+}
+
+// Where a handle starts, before anything is measured: what the pattern set suggests.
+int seed_strategy(const acmi_handle *h, uint64_t blob_bytes, size_t nh, int find_all) {
+    const FlatAutomaton &fa = h->aut.flat();
+    // text over the patterns' own alphabet would flag more of an 8 KiB item than its run list holds (keyword lists, dense sets):
+    // the optimistic LDS-tile pass ends up walking whole items anyway
+    const bool flagged = fa.est_flag_rate * 8192.0 > double(h->run_cap) && !h->is_part;
+    if (fa.anchor_q && !(blob_bytes >= kAutoMinBytes && nh && blob_bytes / nh < kSmallItemBytes && !flagged)) return acmi_handle::kStratAnchor;
+    if (!flagged) return acmi_handle::kStratLds;
+    // the wave drain writes output denser than a record per two bytes as whole rows; everything else in one pass
+    if (!h->dense_output && strategy_eligible(h, acmi_handle::kStratTiles, blob_bytes, nh, find_all)) return acmi_handle::kStratTiles;
+    return acmi_handle::kStratItems;
+}
+
+int choose_strategy(acmi_handle *h, acmi_handle::FlySlot &F, uint64_t blob_bytes, size_t nh, int find_all) {
+    acmi_handle::ChoiceClass &C = h->choice[find_all ? 1 : 0][F.choice_class];
+    F.probe = false;
+    if (C.cur < 0 || !strategy_eligible(h, C.cur, blob_bytes, nh, find_all)) C.cur = seed_strategy(h, blob_bytes, nh, find_all);
+    if (blob_bytes < kAutoMinBytes) return C.cur;   // (launch-bound either way: decides nothing, probes nothing)
+    for (int s = 0; s < acmi_handle::kStratCount; ++s)
+        if (C.wait[s]) --C.wait[s];
+    for (int s = 0; s < acmi_handle::kStratCount; ++s) {
+        if (!(C.pending >> s & 1u)) continue;
+        C.pending &= ~(1u << s);
+        if (s == C.cur || !strategy_eligible(h, s, blob_bytes, nh, find_all)) continue;
+        F.probe = true;
+        ++h->probes;
+        return s;
+    }
+    return C.cur;
+}
+
+void learn_strategy(acmi_handle *h, const acmi_handle::FlySlot &F, double ms_per_gib) {
+    acmi_handle::ChoiceClass &C = h->choice[F.find_all ? 1 : 0][F.choice_class];
+    const int s = F.strategy;
+    C.cost[s] = C.cost[s] > 0.f ? 0.5f * C.cost[s] + 0.5f * float(ms_per_gib) : float(ms_per_gib);
+    if (F.probe && s != C.cur) {
+        // a probe wins when it is at least 1.25 x cheaper than what the strategy in use costs now; a lost one backs off
+        if (C.cost[C.cur] > 0.f && C.cost[s] * 1.25f < C.cost[C.cur]) {
+            C.cur = s;
+            C.span[s] = 16;
+            ++h->switches;
+        } else {
+            C.wait[s] = C.span[s];
+            C.span[s] = std::min<uint32_t>(C.span[s] * 2, 1024);
+        }
+        return;
+    }
+    if (s != C.cur) return;
+    // The strategy in use: every alternative whose kernel, on text that suits it, would be clearly cheaper than this is probed --
+    // once its back-off allows: what it cost on EARLIER text (a filter that lost on dense matches) does not keep it out for good,
+    // the text may have changed.  (Expected cost: the kernel's rate plus what any pipeline costs whatever it scans, ~ 60 us --
+    // small batches are launch-bound on every strategy and probe nothing.)
+    for (int a = 0; a < acmi_handle::kStratCount; ++a) {
+        if (a == s || C.wait[a] || !strategy_eligible(h, a, F.blob_bytes, F.nh, F.find_all)) continue;
+        const float ref = nominal_cost(h, a, F.blob_bytes, F.nh) + 0.06f * float(1ull << 30) / float(F.blob_bytes);
+        if (C.cost[s] > 1.5f * ref) C.pending |= 1u << a;
+    }
+}
+
 // The batch pipeline on device-resident input, first half: enqueue everything, no host wait.
 int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob, uint64_t blob_bytes, const uint64_t *d_off,
                   size_t nh, int find_all);
@@ -744,7 +857,9 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     F.kernel_used = 0;
     F.chunk_used = 0;
     F.max_items = 0;
-    if (h->profile > 1) HIPCHK(h, hipEventRecord(F.ev[0], st));
+    const uint64_t allocs_before = g_dev_allocs;
+    F.timed = false;
+    HIPCHK(h, hipEventRecord(F.ev[0], st));   // (with ev[4]: what this batch's pipeline took -- the measured kernel choice, "total_ms")
     const int slot_index = int(&F - h->fly);
     uint32_t *const pinned_dev = h->pinned_dev + kPinWords * slot_index;
 
@@ -757,34 +872,20 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     F.trivial = false;
 
     const FlatAutomaton &fa = h->aut.flat();
-    // the anchor filter needs a pattern set that allows it; automatic mode also leaves it once a batch
-    // showed that this handle's text defeats it (see run_batch_end)
-    if (h->kernel == 3 && blob_bytes >= kAutoMinBytes) {  // time to probe the fast kernel again?
-        if (h->anchor_off && h->anchor_left-- == 0) h->anchor_off = false;
-        else if (h->exact_only && !(fa.anchor_q && !h->anchor_off) && h->exact_left-- == 0) h->exact_only = false;
+    int kernel = (h->kernel == 2 && !fa.anchor_q) ? 1 : h->kernel;
+    F.strategy = -1;
+    F.choice_class = choice_class(blob_bytes, nh);
+    if (h->kernel == 3) {
+        F.strategy = choose_strategy(h, F, blob_bytes, nh, find_all);
+        kernel = F.strategy == acmi_handle::kStratAnchor ? 2 : F.strategy == acmi_handle::kStratLds ? 1 : F.strategy == acmi_handle::kStratTiles ? 6 : 4;
     }
-    int kernel = h->kernel == 3 ? ((fa.anchor_q && !h->anchor_off) ? 2 : 1)
-                                : ((h->kernel == 2 && !fa.anchor_q) ? 1 : h->kernel);
-    // Small haystacks: the anchor kernel gives a wave one work item per step (its short-item variant skips the 1-KiB rows
-    // an item lacks; its tiny-item variant, from 1 KiB per haystack down, packs one-row items eight to a step), so its
-    // rate falls with the item size -- headline patterns over 4 GiB: 5.4 TB/s at 8 KiB, 4.8 at 4 KiB, 3.5 at 2 KiB, 3.95 at
-    // 1 KiB, 2.6 at 512 B, 1.44 at 256 B, 0.75 at 128 B -- while the LDS-tile walk gives every LANE its own items (2.3 /
-    // 1.75 / 1.27 / 0.84 TB/s at 1 KiB / 512 / 256 / 128 B).  Under 192 B per haystack on average automatic mode takes
-    // the tile walk -- unless the automaton's estimate or an earlier batch says its optimistic pass does not work on this
-    // handle's data (exact_only).  (Batches under 1 MiB are launch-bound either way and keep the kernel the pattern set
-    // asks for.)
-    if (h->kernel == 3 && kernel == 2 && !h->exact_only && blob_bytes >= kAutoMinBytes && blob_bytes / nh < kSmallItemBytes) kernel = 1;
-    if (h->kernel == 3 && kernel == 1 && h->exact_only) kernel = 4;
-    // The whole-item walk's successor for everything but output that is denser than a record per two bytes (which the wave drain
-    // writes as whole rows) and findAll = false (one event per haystack: the slabs are exact there): k_walk_tiles, one pass,
-    // records placed by a running sum instead of slab -> overflow -> second walk.
+    // k_walk_tiles: one pass, records placed by a running sum instead of slab -> overflow -> second walk (findAll = true, patterns
+    // of <= 129 B; else the whole-item walk)
     uint32_t tile_w = 0, tile_p = 0;
-    if ((h->kernel == 6 || (h->kernel == 3 && kernel == 4 && !h->dense_output)) && find_all &&
-        tiles_geometry(fa.max_pattern_length, fa.n_states, blob_bytes, nh, &tile_w, &tile_p)) {
-        kernel = 6;
+    if (kernel == 6 && find_all && tiles_geometry(fa.max_pattern_length, fa.n_states, blob_bytes, nh, &tile_w, &tile_p)) {
         if (h->tile_w) tile_w = uint32_t(h->tile_w);
         if (h->tile_p) tile_p = uint32_t(h->tile_p);
-    } else if (h->kernel == 6) {
+    } else if (kernel == 6) {
         kernel = 4;
     }
     F.kernel_used = kernel;
@@ -858,11 +959,11 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     uint32_t run_max = 16;
     while (run_max < 64u && uint64_t(run_max) * 2 * 16 * est_items * 8 <= blob_bytes) run_max *= 2;
     // (dense form: an item of L bytes has at most L hit windows, and 256 entries for every 256-byte haystack would be 8 x the batch:
-    // what an average item can hold, at least 16, and never more than a quarter of the batch's bytes in all)
+    // what an average item can hold, at least 16, and never more than the batch's own bytes in all)
     uint32_t dense_q = 256u;
     if (dense) {
         const uint64_t avg = std::max<uint64_t>(16, blob_bytes / est_items);
-        while (dense_q > 16u && (dense_q > avg || run_stride * dense_q * 8 > std::max<uint64_t>(blob_bytes / 4, 64ull << 20))) dense_q /= 2;
+        while (dense_q > 16u && (dense_q > avg || run_stride * dense_q * 8 > std::max<uint64_t>(blob_bytes, 64ull << 20))) dense_q /= 2;
     }
     const uint32_t Q = h->run_cap_set ? std::max<uint32_t>(1, h->run_cap) : dense ? dense_q : std::min(std::max(16u, h->run_auto), run_max);
     F.run_used = Q;
@@ -1011,6 +1112,7 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     F.sync_words = sync_words;
     HIPCHK(h, hipEventRecord(F.ev[4], st));  // (always: the end waits for THIS batch, not for the one queued behind it)
     HIPCHK(h, hipGetLastError());
+    F.timed = g_dev_allocs == allocs_before;
     F.args = B;
     F.max_items = max_items;
     return ACMI_OK;
@@ -1116,45 +1218,13 @@ int run_batch_end(acmi_handle *h) {
     h->fallback_bytes = F.kernel_used == 2 ? uint64_t(pinned32[7]) * 16 : 0;
     if (F.kernel_used == 2) h->walked_bytes -= h->fallback_bytes;  // (counters[7] is k_scan_lds' own share otherwise)
     h->tiny_waves = pinned32[18];
-    // automatic mode: a batch of which more than a quarter had to be WALKED through the automaton defeats the filter --
-    // `fallback_bytes`: clusters verification could not decide, head / tail / unknown runs, items whose run list
-    // overflowed.  (Clusters decided by the text compare are in walked_bytes but cost no walk: text with many true
-    // matches keeps the anchor kernel.)
-    const bool decisive = h->kernel == 3 && F.blob_bytes >= kAutoMinBytes;
-    if (decisive && F.kernel_used == 2) {
-        if (h->fallback_bytes * 64 > F.blob_bytes && F.run_used < F.run_max) {
-            h->run_auto = F.run_used * 4;   // (longer run lists first -- from 1 item in 64 walked whole on: the next batch shows whether that was it)
-        } else if (h->fallback_bytes * 4 > F.blob_bytes) {
-            // (also for the compact automata of big pattern sets, whose table walk is slow -- 9 ms per GiB for 65,536 patterns: a
-            // filter whose items are all walked whole by their waves and drained again is ten times slower still, measured)
-            h->anchor_off = true;
-            h->anchor_left = h->anchor_span;
-            h->anchor_span = std::min<uint32_t>(h->anchor_span * 2, 1024);
-        } else if (!fa.compact && !fa.anchor_dense && (total * 160 > F.blob_bytes ||
-                                                           h->walked_bytes * 256 > F.blob_bytes * uint64_t(fa.max_pattern_length - fa.min_pattern_length + 4))) {
-            // More than ~ 50 matches per 8 KiB, or more than ~ 32 CANDIDATES per 8 KiB (cluster bytes / the length of one candidate's range; accidental ones count:
-            // 12-byte patterns over six letters hit the 8-byte windows of random text a dozen times per 8 KiB -- 1.27 ms per GiB on
-            // the filter, 0.52 on the tile walk): the aligned filter flags its hits one by one through the scalar unit and checks
-            // its candidates 64 to a thread -- 3.2 ms per GiB at 64 per haystack against 1.8 for the whole-item walk of a small
-            // automaton (tools/exp_hits.py).  (Not for compact automata, whose walk costs 9 ms per GiB.)
-            h->anchor_off = true;
-            h->anchor_left = h->anchor_span;
-            h->anchor_span = std::min<uint32_t>(h->anchor_span * 2, 1024);
-        } else {
-            h->anchor_span = 16;
-        }
-    }
-    // ... and one of which more than half was flagged by the LDS-tile kernel's optimistic pass (events or tile
-    // exits in most wave-quads: keyword-like and dense-match text) is walked exactly right away
-    if (decisive && F.kernel_used == 1) {
-        if (h->walked_bytes * 2 > F.blob_bytes) {
-            h->exact_only = true;
-            h->exact_left = h->exact_span;
-            h->exact_span = std::min<uint32_t>(h->exact_span * 2, 1024);
-        } else {
-            h->exact_span = 16;
-        }
-    }
+    // run lists learn like the slabs: longer ones for the batches after one whose filter walked more than a 64th of the bytes
+    // whole (items whose candidate windows overflowed the list)
+    if (h->kernel == 3 && F.blob_bytes >= kAutoMinBytes && F.kernel_used == 2 && h->fallback_bytes * 64 > F.blob_bytes && F.run_used < F.run_max)
+        h->run_auto = F.run_used * 4;
+    float pipeline_ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&pipeline_ms, F.ev[0], F.ev[4]));
+    h->total_ms = pipeline_ms;
     if (h->profile) {
         float ms = 0;
         HIPCHK(h, hipEventElapsedTime(&ms, F.ev[1], F.ev[2]));
@@ -1162,14 +1232,17 @@ int run_batch_end(acmi_handle *h) {
         if (h->profile > 1) {
             HIPCHK(h, hipEventElapsedTime(&ms, F.ev[2], F.ev[3]));
             h->walk_ms = F.kernel_used == 2 ? ms : 0.0;
-            HIPCHK(h, hipEventElapsedTime(&ms, F.ev[0], F.ev[4]));
-            h->total_ms = ms;
         }
     }
     h->out_want = std::max<size_t>(h->out_want, size_t(total) * 16);
     const bool too_small = total > F.d_out.cap / 16;             // did not fit the optimistic capacity: grow, expand again
     const bool undrained = n_ovf > 0 && !F.refill_launched;      // items overflowed their slabs and the drain was not enqueued
     h->refill_armed = n_ovf > 0;
+    // (a pipeline that has to be completed or run again below says nothing about what the strategy costs)
+    if (F.strategy >= 0 && F.blob_bytes >= kAutoMinBytes) {
+        if (F.timed && !too_small && !undrained) learn_strategy(h, F, double(pipeline_ms) * double(1ull << 30) / double(F.blob_bytes));
+        else if (F.probe) h->choice[F.find_all ? 1 : 0][F.choice_class].pending |= 1u << F.strategy;   // (the probe is taken again)
+    }
     if (too_small || undrained) {
         if (h->enqueue_seq == F.seq) {
             if (too_small) HIPCHK(h, F.d_out.ensure(total * 16));
@@ -1612,9 +1685,8 @@ static int apply_option(acmi_handle *h, const std::string &k, int64_t value) {
         } else if (k == "kernel") {
             if (value < 0 || value > 6 || value == 5) return ACMI_E_ARG;
             h->kernel = int(value);
-            h->anchor_off = false;
-            h->exact_only = false;
-            h->anchor_span = h->exact_span = 16;
+            for (auto &row : h->choice)
+                for (auto &c : row) c = acmi_handle::ChoiceClass{};
         } else if (k == "tile_w") {   // k_walk_tiles: bytes per lane (0: automatic)
             if (value != 0 && value != 16 && value != 32 && value != 64) return ACMI_E_ARG;
             h->tile_w = int(value);
@@ -1754,6 +1826,8 @@ int acmi_get_stat(const acmi_handle *h, const char *key, double *value) {
         else if (k == "overflow_items") *value = h->overflow_items;
         else if (k == "walked_bytes") *value = double(h->walked_bytes);
         else if (k == "fallback_bytes") *value = double(h->fallback_bytes);
+        else if (k == "choice_probes") *value = h->probes;
+        else if (k == "choice_switches") *value = h->switches;
         else if (k == "scan_ms") *value = h->scan_ms;
         else if (k == "walk_ms") *value = h->walk_ms;
         else if (k == "kernel_used") *value = h->kernel_used;

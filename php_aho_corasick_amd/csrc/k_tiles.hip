@@ -24,20 +24,24 @@
 //     records go to base + (records of the lanes before its owner) + (its own offset): the reference's order -- position
 //     ascending, longest pattern first (node.c:424-441) -- without a sort and without knowing any count in advance.
 // The per-item record counts are left for k_expand (per-haystack prefix, summary), which finds no event to expand.
+#include <cstdlib>
+
 #include "kdev.hpp"
 
 namespace acmi {
 
 constexpr uint32_t kTilesThreads = 1024;
 constexpr uint32_t kTilesWaves = kTilesThreads / 64;
+constexpr uint32_t kTilesRing = 128;   // events a wave stages in LDS (flushed to its queue 64 at a time)
 
 struct TileArgs {
     uint32_t W;           // bytes per lane piece: 16, 32 or 64
     uint32_t P;           // pieces (lanes) per item
     uint32_t R;           // items per wave = 64 / P
-    uint32_t WB;          // warm-up blocks of 16 bytes = ceil((Lmax - 1) / 16)
-    uint32_t qcap;        // queue entries per wave
+    uint32_t back;        // bytes a lane enters its piece early = Lmax - 1
+    uint32_t qcap;        // queue entries per wave (a multiple of 64)
     uint32_t tile_bytes;  // LDS budget of the table tile (+ record counts)
+    uint32_t flags;       // analysis only (ACMI_TILES_DEBUG): 1 no expansion, 2 no events
     uint2 *queue;         // grid waves x qcap entries
     uint32_t *ticket;     // zeroed
     uint64_t *status;     // zeroed, one word per workgroup tile
@@ -53,6 +57,14 @@ __device__ __forceinline__ uint32_t tile_wave_max(uint32_t v) {
     }
     return v;
 }
+__device__ __forceinline__ uint32_t tile_wave_min(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = __shfl_xor(v, d, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
 
 // One lane's piece: what it walks and what it reports.
 struct Piece {
@@ -64,58 +76,90 @@ struct Piece {
     uint32_t hay;
 };
 
+// The wave's event queue: a ring in LDS, flushed 64 entries at a time to the wave's region in global memory (which stays in
+// L2: the wave reads it back microseconds later).  A store per event from inside the walk made every step wait for the store
+// before (the stores share the counter the cold rows' loads are waited on with).
+struct TileQueue {
+    uint2 *ring;          // LDS, kTilesRing entries
+    uint2 *spill;         // global, qcap entries
+    uint32_t qcap;
+    uint32_t total;       // events so far (wave-uniform)
+    uint32_t flushed;     // of which in `spill` (a multiple of 64)
+};
+
+__device__ __forceinline__ void tiles_flush(TileQueue &Q, uint32_t lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint2 e = Q.ring[(Q.flushed + lane) & (kTilesRing - 1u)];
+    if (Q.flushed + lane < Q.qcap) Q.spill[Q.flushed + lane] = e;
+    Q.flushed += 64u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // One exact transition of a lane: the LDS tile's row when the state has one, else the global table / the compact records.
-template <typename E, int MODE>
-__device__ __forceinline__ uint32_t tiles_step(const DevAutomaton &A, const uint16_t *cls_lds, const uint8_t *tile, uint32_t tile_rows,
-                                               uint32_t st, uint32_t byte) {
-    const uint32_t coff = class_offset<E, MODE>(A, cls_lds, byte);
+// ALLHOT: every state has its row in the tile -- no test, no cold path compiled in.
+template <typename E, bool ALLHOT>
+__device__ __forceinline__ uint32_t tiles_step(const DevAutomaton &A, const uint8_t *tile, uint32_t tile_rows, uint32_t st, uint32_t byte,
+                                               uint32_t coff) {
+    if constexpr (ALLHOT) return *reinterpret_cast<const E *>(tile + __umul24(st, A.row_bytes) + coff);
     uint32_t w = A.trap;
     if (st < tile_rows) w = *reinterpret_cast<const E *>(tile + __umul24(st, A.row_bytes) + coff);
     if (w >= A.trap) w = cold_step<E>(A, st, byte, coff);
     return w;
 }
 
+template <bool ALLHOT>
+__device__ __forceinline__ bool tiles_final(const DevAutomaton &A, uint32_t s) {
+    if constexpr (ALLHOT) return s >= A.f1;   // (no cold states, and the trap row is never entered)
+    return is_final(A, s);
+}
+
 // The walk of one piece, counting: events go to the wave's queue, n_rec sums the records they stand for.  All 64 lanes of
 // the wave call this together and run the same number of steps (a lane past its own bytes walks on without reporting).
-template <typename E, int MODE>
+template <typename E, int MODE, bool ALLHOT>
 __device__ __forceinline__ void tiles_walk(const DevAutomaton &A, const Piece &pc, const uint16_t *cls_lds, const uint8_t *tile,
-                                           uint32_t tile_rows, const uint32_t *cnt_lds, uint32_t cnt_rows, uint2 *queue, uint32_t qcap,
-                                           uint32_t lane, uint32_t &n_rec, uint32_t &qn) {
+                                           uint32_t tile_rows, const uint32_t *cnt_lds, uint32_t cnt_rows, TileQueue &Q, uint32_t lane,
+                                           uint32_t &n_rec, bool events) {
     uint32_t st = 0;
     auto event = [&](uint32_t jj) __attribute__((always_inline)) {
-        const bool ev = jj - pc.rep_lo < pc.rep_len && is_final(A, st);
+        const bool ev = jj - pc.rep_lo < pc.rep_len && tiles_final<ALLHOT>(A, st);
         // the lanes that have an event at this step: the ballot is taken by ALL lanes, so that the queue index stays wave-uniform
         const uint64_t m = __ballot(ev);
         if (m) {
             if (ev) {
-                const uint32_t c = st < cnt_rows ? cnt_lds[st] : A.out_count[st];
+                const uint32_t c = (ALLHOT || st < cnt_rows) ? cnt_lds[st] : A.out_count[st];
                 const uint32_t my = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
-                if (qn + my < qcap) queue[qn + my] = make_uint2(st | lane << 24, jj | n_rec << 9);
+                if (events) Q.ring[(Q.total + my) & (kTilesRing - 1u)] = make_uint2(st | lane << 24, jj | n_rec << 9);
                 n_rec += c;
             }
-            qn += uint32_t(__builtin_popcountll(m));
+            Q.total += uint32_t(__builtin_popcountll(m));
+            if (Q.total - Q.flushed >= 64u) tiles_flush(Q, lane);
         }
     };
-    // A piece is its warm-up block(s) and at most 64 bytes = one group of a line: all of it is requested at once, back to back
-    // (a line fetched in pieces over the microseconds of a walk comes from HBM again for every piece, k_walk_items' lesson); what
-    // a longer warm-up or an unaligned last piece adds is requested as the buffers free up.
+    // A piece is its warm-up and at most 64 bytes = one group of a line: all of it is requested at once, back to back (a line
+    // fetched in pieces over the microseconds of a walk comes from HBM again for every piece, k_walk_items' lesson); what a
+    // longer warm-up or an unaligned last piece adds is requested as the buffers free up.
     const uint4 *q = reinterpret_cast<const uint4 *>(pc.pb);
     const uint32_t last = pc.nblk ? pc.nblk - 1u : 0u;
     const uint32_t blocks = tile_wave_max(pc.nblk);
     if (blocks == 0u) return;
-    const uint4 first = q[0];
+    const uint4 first = q[pc.start_j < 16u ? 0u : (last ? 1u : 0u)];   // (start_j == 16: block 0 is virtual, see the caller)
     uint4 b0 = q[1u < last ? 1u : last], b1 = q[2u < last ? 2u : last], b2 = q[3u < last ? 3u : last], b3 = q[4u < last ? 4u : last];
-    // the first block: the walk may begin inside it (a haystack that starts unaligned) -- byte by byte, the state held in the
-    // root up to the first byte that counts; not unrolled (a sixteenth of the steps at most)
+    // the first block: the walk begins inside it (Lmax - 1 bytes before the piece, or at the haystack's first byte) -- byte by
+    // byte, the state held in the root up to the lane's own first byte; not unrolled
+    const uint32_t jmin = tile_wave_min(pc.nblk ? pc.start_j : 16u);
 #pragma unroll 1
-    for (uint32_t jj = 0; jj < 16u; ++jj) {
+    for (uint32_t jj = jmin; jj < 16u; ++jj) {
         const uint32_t wd = jj < 8u ? (jj < 4u ? first.x : first.y) : (jj < 12u ? first.z : first.w);
         const uint32_t byte = (wd >> (8u * (jj & 3u))) & 0xffu;
-        const uint32_t w = tiles_step<E, MODE>(A, cls_lds, tile, tile_rows, st, byte);
+        const uint32_t w = tiles_step<E, ALLHOT>(A, tile, tile_rows, st, byte, class_offset<E, MODE>(A, cls_lds, byte));
         st = jj < pc.start_j ? 0u : w;
         event(jj);
     }
-    // the blocks behind it: sixteen unrolled steps per block, the buffers rotating
+    // the blocks behind it: sixteen unrolled steps per block, the buffers rotating; the column offsets of a dword's four bytes
+    // are worked out together (SWAR3: a handful of operations for all four; TABLE: four independent LDS reads)
 #pragma unroll 1
     for (uint32_t k = 1u; k < blocks; ++k) {
         const uint4 cur = b0;
@@ -123,29 +167,56 @@ __device__ __forceinline__ void tiles_walk(const DevAutomaton &A, const Piece &p
         const uint32_t kn = k + 4u;
         if (kn < blocks) b3 = q[kn < last ? kn : last];
         const uint32_t j0 = k * 16u;
-#define ACMI_TSTEP(wd, sh, jj) { st = tiles_step<E, MODE>(A, cls_lds, tile, tile_rows, st, ((wd) >> (sh)) & 0xffu); event(jj); }
-#define ACMI_TSTEP4(wd, jj) ACMI_TSTEP(wd, 0, jj) ACMI_TSTEP(wd, 8, (jj) + 1u) ACMI_TSTEP(wd, 16, (jj) + 2u) ACMI_TSTEP(wd, 24, (jj) + 3u)
-        ACMI_TSTEP4(cur.x, j0) ACMI_TSTEP4(cur.y, j0 + 4u) ACMI_TSTEP4(cur.z, j0 + 8u) ACMI_TSTEP4(cur.w, j0 + 12u)
-#undef ACMI_TSTEP4
-#undef ACMI_TSTEP
+        auto dword = [&](uint32_t wd, uint32_t jj) __attribute__((always_inline)) {
+            uint32_t c0, c1, c2, c3;
+            if constexpr (MODE == 1) {
+                const uint32_t c4 = swar_columns<E>(A, wd);
+                c0 = c4 & 0xffu; c1 = (c4 >> 8) & 0xffu; c2 = (c4 >> 16) & 0xffu; c3 = c4 >> 24;
+            } else {
+                c0 = class_offset<E, MODE>(A, cls_lds, wd & 0xffu); c1 = class_offset<E, MODE>(A, cls_lds, (wd >> 8) & 0xffu);
+                c2 = class_offset<E, MODE>(A, cls_lds, (wd >> 16) & 0xffu); c3 = class_offset<E, MODE>(A, cls_lds, wd >> 24);
+            }
+            st = tiles_step<E, ALLHOT>(A, tile, tile_rows, st, wd & 0xffu, c0); event(jj);
+            st = tiles_step<E, ALLHOT>(A, tile, tile_rows, st, (wd >> 8) & 0xffu, c1); event(jj + 1u);
+            st = tiles_step<E, ALLHOT>(A, tile, tile_rows, st, (wd >> 16) & 0xffu, c2); event(jj + 2u);
+            st = tiles_step<E, ALLHOT>(A, tile, tile_rows, st, wd >> 24, c3); event(jj + 3u);
+        };
+        dword(cur.x, j0); dword(cur.y, j0 + 4u); dword(cur.z, j0 + 8u); dword(cur.w, j0 + 12u);
     }
 }
 
 // The same walk writing records in place: for the waves whose events did not fit their queue (dense output, rare, and bound by
 // its stores): every lane on its own, bytes straight from memory (the lines are in L2: the wave has just read them).
-template <typename E, int MODE>
+template <typename E, int MODE, bool ALLHOT>
 __device__ __forceinline__ void tiles_emit(const DevAutomaton &A, const Piece &pc, const uint16_t *cls_lds, const uint8_t *tile,
                                            uint32_t tile_rows, uint4 *out, uint64_t wr) {
     uint32_t st = 0;
     const uint32_t end = pc.rep_lo + pc.rep_len;
 #pragma unroll 1
     for (uint32_t jj = pc.start_j; jj < end; ++jj) {
-        st = tiles_step<E, MODE>(A, cls_lds, tile, tile_rows, st, load8g(pc.pb + jj));
-        if (jj >= pc.rep_lo && is_final(A, st)) wr = emit_event(A, out, wr, pc.hay, pc.pos_bias + jj, st);
+        const uint32_t byte = load8g(pc.pb + jj);
+        st = tiles_step<E, ALLHOT>(A, tile, tile_rows, st, byte, class_offset<E, MODE>(A, cls_lds, byte));
+        if (jj >= pc.rep_lo && tiles_final<ALLHOT>(A, st)) wr = emit_event(A, out, wr, pc.hay, pc.pos_bias + jj, st);
     }
 }
 
-template <typename E, int MODE>
+// An event's records, longest pattern first, at `dst`.
+__device__ __forceinline__ void tiles_expand(const DevAutomaton &A, uint4 *dst, uint32_t hay, uint32_t pos, uint32_t s, uint32_t c) {
+    if (A.out_list != nullptr) {
+        const uint2 *ol = A.out_list + A.out_off[s];
+        for (uint32_t k = 0; k < c; ++k) {
+            const uint2 o = ol[k];
+            dst[k] = make_uint4(hay, pos, pos - o.y, o.x);
+        }
+    } else {
+        (void)emit_event(A, dst, 0, hay, pos, s);
+    }
+}
+
+// Two workgroups per CU (64 registers, 8 waves per SIMD): what hides the round trips of rows that are not in LDS is the number
+// of waves, not the size of the tile -- one workgroup with the whole LDS for its tile (twice the rows, 80-odd registers, no
+// spills) measured 8-12 % slower on a word list and on the headline set with 64 plants per haystack.
+template <typename E, int MODE, bool ALLHOT>
 __global__ __launch_bounds__(kTilesThreads, 8) void k_walk_tiles(DevAutomaton A, BatchArgs B, TileArgs T) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ uint32_t s_tile, s_walked;
@@ -153,25 +224,29 @@ __global__ __launch_bounds__(kTilesThreads, 8) void k_walk_tiles(DevAutomaton A,
     __shared__ uint64_t s_wave_tot[kTilesWaves];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint64_t total_items = B.item_base[B.n_haystacks];
-    // LDS: [512 B byte classes (TABLE mode)] [tile rows] [their record counts]
+    // LDS: [the waves' event rings] [512 B byte classes (TABLE mode)] [tile rows] [their record counts]
+    const uint32_t ring_bytes = kTilesWaves * kTilesRing * 8u;
     const uint32_t cls_bytes = (MODE == 0) ? 512u : 0u;
     const uint32_t tile_rows = A.row_bytes ? (T.tile_bytes / (A.row_bytes + 4u) < A.trap ? T.tile_bytes / (A.row_bytes + 4u) : A.trap) : 0u;
-    const uint16_t *cls_lds = (MODE == 0) ? reinterpret_cast<const uint16_t *>(smem) : nullptr;
-    const uint8_t *tile = smem + cls_bytes;
+    const uint16_t *cls_lds = (MODE == 0) ? reinterpret_cast<const uint16_t *>(smem + ring_bytes) : nullptr;
+    const uint8_t *tile = smem + ring_bytes + cls_bytes;
     const uint32_t tile_bytes = (tile_rows * A.row_bytes + 15u) & ~15u;
     const uint32_t cnt_rows = tile_rows;
     const uint32_t *cnt_lds = reinterpret_cast<const uint32_t *>(tile + tile_bytes);
     {
-        if (MODE == 0 && threadIdx.x < 256) reinterpret_cast<uint16_t *>(smem)[threadIdx.x] = A.class_off[threadIdx.x];
+        if (MODE == 0 && threadIdx.x < 256) reinterpret_cast<uint16_t *>(smem + ring_bytes)[threadIdx.x] = A.class_off[threadIdx.x];
         const uint4 *tsrc = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(A.lds_image) + A.tile_offset);
-        uint4 *tdst = reinterpret_cast<uint4 *>(smem + cls_bytes);
+        uint4 *tdst = reinterpret_cast<uint4 *>(smem + ring_bytes + cls_bytes);
         const uint32_t n16 = tile_bytes >> 4;
         for (uint32_t t = threadIdx.x; t < n16; t += kTilesThreads) tdst[t] = tsrc[t];
-        uint32_t *cdst = reinterpret_cast<uint32_t *>(smem + cls_bytes + tile_bytes);
+        uint32_t *cdst = reinterpret_cast<uint32_t *>(smem + ring_bytes + cls_bytes + tile_bytes);
         for (uint32_t t = threadIdx.x; t < cnt_rows; t += kTilesThreads) cdst[t] = A.out_count[t];
     }
     if (threadIdx.x == 0) s_walked = 0;
-    uint2 *queue = T.queue + (uint64_t(blockIdx.x) * kTilesWaves + wave) * T.qcap;
+    TileQueue Q;
+    Q.ring = reinterpret_cast<uint2 *>(smem) + wave * kTilesRing;
+    Q.spill = T.queue + (uint64_t(blockIdx.x) * kTilesWaves + wave) * T.qcap;
+    Q.qcap = T.qcap;
     const uint32_t r = lane / T.P, qi = lane - r * T.P;   // item of the wave, piece of the item
     const uint64_t per_group = uint64_t(kTilesWaves) * T.R;
     const uintptr_t beta = reinterpret_cast<uintptr_t>(B.blob) & 15u;
@@ -206,9 +281,13 @@ __global__ __launch_bounds__(kTilesThreads, 8) void k_walk_tiles(DevAutomaton A,
             const uint32_t hi = (qi + 1u == T.P) ? end : (a + T.W < end ? a + T.W : end);
             if (lo < hi) {
                 const int64_t hs = int64_t(d0) - int64_t(it.pos0);   // the haystack's first byte
-                int64_t xs = int64_t(a) - int64_t(T.WB) * 16;
+                int64_t xs = int64_t(lo) - int64_t(T.back);           // Lmax - 1 bytes early: exact from there on
                 if (xs < hs) xs = hs;
-                const int64_t xb = xs & ~int64_t(15);
+                // (the first block is walked byte by byte from start_j on, by the whole wave as long as its earliest lane: a lane
+                // whose walk begins ON a block boundary -- a haystack that starts aligned -- takes the block below as its first,
+                // virtually: start_j = 16, nothing of it is loaded or walked)
+                int64_t xb = xs & ~int64_t(15);
+                if (xb == xs) xb -= 16;
                 pc.pb = abase + G + xb;
                 pc.start_j = uint32_t(xs - xb);
                 pc.rep_lo = uint32_t(int64_t(lo) - xb);
@@ -218,8 +297,9 @@ __global__ __launch_bounds__(kTilesThreads, 8) void k_walk_tiles(DevAutomaton A,
                 walked16 += pc.nblk;
             }
         }
-        uint32_t n_rec = 0, qn = 0;
-        tiles_walk<E, MODE>(A, pc, cls_lds, tile, tile_rows, cnt_lds, cnt_rows, queue, T.qcap, lane, n_rec, qn);
+        uint32_t n_rec = 0;
+        Q.total = Q.flushed = 0;
+        tiles_walk<E, MODE, ALLHOT>(A, pc, cls_lds, tile, tile_rows, cnt_lds, cnt_rows, Q, lane, n_rec, (T.flags & 2u) == 0u);
         // records: exclusive prefix over the wave's lanes, the items' totals, the wave's total
         const uint32_t incl = wave_inclusive_sum(n_rec);
         const uint32_t excl = incl - n_rec;
@@ -244,34 +324,34 @@ __global__ __launch_bounds__(kTilesThreads, 8) void k_walk_tiles(DevAutomaton A,
         }
         __syncthreads();
         const uint64_t base = s_before + wave_base;
-        if (wave_tot == 0u || base + wave_tot > T.cap) continue;   // (too small a buffer: the host grows it and runs the batch again)
-        if (qn <= T.qcap) {
-            // every lane expands events, 64 per round: an event's slot = the records of the lanes before its owner + its own offset
+        if (wave_tot == 0u || base + wave_tot > T.cap || (T.flags & 1u)) continue;   // (too small a buffer: the host grows it and runs the batch again)
+        if (Q.total <= Q.qcap) {
+            // every lane expands events, 64 per round whatever their distribution over the pieces: an event's slot = the records
+            // of the lanes before its owner + its own offset.  Rounds [0, flushed) come from the wave's queue in memory (written by
+            // this wave's own lanes, through the CU's write-through L1: visible to them once the stores have landed; an
+            // agent-scope release here wrote the whole L2 back, 5 ms per GiB), the rest from the ring.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (the flushes have landed: a wait, no cache maintenance)
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll 1
-            for (uint32_t e0 = 0; e0 < qn; e0 += 64u) {
+            for (uint32_t e0 = 0; e0 < Q.total; e0 += 64u) {
                 const uint32_t e = e0 + lane;
-                const bool valid = e < qn;
-                const uint2 ent = valid ? queue[e] : make_uint2(0u, 0u);
+                const bool valid = e < Q.total;
+                uint2 ent = make_uint2(0u, 0u);
+                if (e0 < Q.flushed) {
+                    ent = Q.spill[e];
+                } else if (valid) {
+                    ent = Q.ring[e & (kTilesRing - 1u)];
+                }
                 const uint32_t owner = ent.x >> 24, s = ent.x & 0xFFFFFFu;
                 const uint32_t slot = uint32_t(__shfl(int(excl), int(owner), 64)) + (ent.y >> 9);
                 const uint32_t pos = uint32_t(__shfl(int(pc.pos_bias), int(owner), 64)) + (ent.y & 511u);
                 const uint32_t hay = uint32_t(__shfl(int(pc.hay), int(owner), 64));
-                if (!valid) continue;
-                uint4 *dst = T.out + base + slot;
-                if (A.out_list != nullptr) {
-                    const uint32_t c = s < cnt_rows ? cnt_lds[s] : A.out_count[s];
-                    const uint2 *ol = A.out_list + A.out_off[s];
-                    for (uint32_t k = 0; k < c; ++k) {
-                        const uint2 o = ol[k];
-                        dst[k] = make_uint4(hay, pos, pos - o.y, o.x);
-                    }
-                } else {
-                    (void)emit_event(A, dst, 0, hay, pos, s);
-                }
+                if (valid) tiles_expand(A, T.out + base + slot, hay, pos, s, (ALLHOT || s < cnt_rows) ? cnt_lds[s] : A.out_count[s]);
             }
-        } else {
+        } else if (pc.nblk) {
             // more events than the queue holds (dense output): every lane walks its piece again and writes its records in place
-            if (pc.nblk) tiles_emit<E, MODE>(A, pc, cls_lds, tile, tile_rows, T.out, base + excl);
+            tiles_emit<E, MODE, ALLHOT>(A, pc, cls_lds, tile, tile_rows, T.out, base + excl);
         }
     }
     // statistic: 16-byte blocks walked (what the automatic kernel choice reads), summed per workgroup
@@ -314,15 +394,20 @@ hipError_t launch_walk_tiles(const DevAutomaton &A, const BatchArgs &B, uint64_t
     T.W = W;
     T.P = P;
     T.R = 64u / P;
-    T.WB = A.max_pattern_length ? (A.max_pattern_length - 1u + 15u) / 16u : 0u;
+    T.back = A.max_pattern_length ? A.max_pattern_length - 1u : 0u;
     T.qcap = 64u * W / 4u;
-    T.tile_bytes = 78u * 1024u;
+    const uint32_t ring_bytes = kTilesWaves * kTilesRing * 8u;
+    static const uint32_t debug_flags = [] { const char *e = std::getenv("ACMI_TILES_DEBUG"); return e ? uint32_t(std::atoi(e)) : 0u; }();
+    T.flags = debug_flags;
     T.queue = static_cast<uint2 *>(queue);
     T.ticket = ticket;
     T.status = status;
     T.out = static_cast<uint4 *>(out);
     T.cap = cap;
-    const uint32_t lds = T.tile_bytes + 16u + (class_mode == 0 ? 512u : 0u);
+    T.tile_bytes = 79u * 1024u - ring_bytes - 768u;   // two workgroups per CU share the 160 KiB
+    const uint32_t lds = ring_bytes + T.tile_bytes + 16u + (class_mode == 0 ? 512u : 0u);
+    // every state's row in the tile (small automata): the variant without the cold path
+    const bool allhot = A.trap + 1u == A.n_states && A.row_bytes && uint64_t(A.trap) * (A.row_bytes + 4u) <= T.tile_bytes;
     const uint64_t groups = (max_items + uint64_t(kTilesWaves) * T.R - 1u) / (uint64_t(kTilesWaves) * T.R);
     const uint32_t blocks = uint32_t(std::min<uint64_t>(groups, tiles_grid()));
     auto go = [&](auto fn) {
@@ -331,8 +416,10 @@ hipError_t launch_walk_tiles(const DevAutomaton &A, const BatchArgs &B, uint64_t
         hipLaunchKernelGGL(fn, dim3(blocks), dim3(kTilesThreads), lds, st, A, B, T);
         return hipGetLastError();
     };
-    if (entry_bytes == 2) return class_mode == 1 ? go(k_walk_tiles<uint16_t, 1>) : go(k_walk_tiles<uint16_t, 0>);
-    return class_mode == 1 ? go(k_walk_tiles<uint32_t, 1>) : go(k_walk_tiles<uint32_t, 0>);
+#define ACMI_TILES(E, M) (allhot ? go(k_walk_tiles<E, M, true>) : go(k_walk_tiles<E, M, false>))
+    if (entry_bytes == 2) return class_mode == 1 ? ACMI_TILES(uint16_t, 1) : ACMI_TILES(uint16_t, 0);
+    return class_mode == 1 ? ACMI_TILES(uint32_t, 1) : ACMI_TILES(uint32_t, 0);
+#undef ACMI_TILES
 }
 
 }  // namespace acmi

@@ -402,4 +402,61 @@ def x2() -> Dataset:
 
 TARGETED = {"T256": t256, "T512": t512, "T1K": t1k, "TRAG": trag, "S3K": s3k, "S2K5": s2k5, "B512": b512, "BRAG": brag, "B3K": b3k, "K1": k1, "K2": k2, "K3": k3, "X1": x1, "X2": x2}
 
+
+# ---- match-density workloads (tests/test_gpu_cliffs.py, bench.py density_sweep) --------------------------------------------
+def density_set(kind: str) -> Dataset:
+    """Pattern sets of the density matrix with a 1 MiB tile of text without plants: "headline" (2,048 x 16 B over abcdef),
+    "words" (2,048 words of 4..12 letters over letters and spaces), "cfg3" (65,536 patterns of 8..64 B, Sigma = 256)."""
+    if kind == "headline":
+        return generate("D-headline", 1, 2048, 16, 16, 128, 8192, b"abcdef")
+    if kind == "words":
+        letters = bytes(range(ord("a"), ord("z") + 1))
+        text = generate("D-words", 33, 2048, 4, 12, 128, 8192, letters + b"     ")
+        pats = generate("D-words", 34, 2048, 4, 12, 1, 16, letters)
+        return Dataset("D-words", pats.pat_blob, pats.pat_off, text.hay_blob, text.hay_off)
+    if kind == "cfg3":
+        return generate("D-cfg3", 7, 65536, 8, 64, 128, 8192, None)
+    raise ValueError(kind)
+
+
+def plant_density(ds: Dataset, per_8k: int, hay_len: int, seed: int = 5) -> Dataset:
+    """`ds`'s text tile cut into haystacks of `hay_len` bytes (a divisor or a multiple of 8 KiB) with `per_8k` occurrences of
+    patterns of the set planted per 8 KiB of text, one per slot of 8192 / per_8k bytes, none across a haystack border."""
+    blob = ds.hay_blob.copy()
+    n = len(blob)
+    slot = 8192 // per_8k
+    lens = np.diff(ds.pat_off.astype(np.int64))
+    fits = np.nonzero(lens <= min(slot, hay_len))[0]
+    r = np.random.default_rng(seed)
+    picks = fits[r.integers(0, len(fits), size=n // slot)]
+    offs = r.integers(0, 1 << 30, size=n // slot)
+    for k in range(n // slot):
+        p = int(picks[k])
+        ln = int(lens[p])
+        at = k * slot + int(offs[k]) % (slot - ln + 1)
+        cell = at // hay_len
+        at = min(at, (cell + 1) * hay_len - ln)
+        blob[at:at + ln] = ds.pat_blob[int(ds.pat_off[p]):int(ds.pat_off[p]) + ln]
+    off = np.arange(n // hay_len + 1, dtype=np.uint64) * np.uint64(hay_len)
+    return Dataset(f"{ds.name}-{per_8k}-{hay_len}", ds.pat_blob, ds.pat_off, blob, off)
+
+
+def prose(ds: Dataset, share: float, seed: int = 11) -> Dataset:
+    """Text of `ds` (8 KiB haystacks) of which a share is REPLACED by listed words, a space behind each (share 1: nothing but
+    listed words): the word-list-over-prose workload of DESIGN 4.12 (tools/exp_kw_hits.py)."""
+    blob = ds.hay_blob.copy()
+    words = ds.patterns()
+    r = np.random.default_rng(seed)
+    for h in range(ds.n_haystacks):
+        at, end = int(ds.hay_off[h]), int(ds.hay_off[h + 1])
+        while at < end - 16:
+            if r.random() < share:
+                w = np.frombuffer(words[int(r.integers(len(words)))], dtype=np.uint8)
+                blob[at:at + len(w)] = w
+                blob[at + len(w)] = 32
+                at += len(w) + 1
+            else:
+                at += 8
+    return Dataset(f"{ds.name}-prose{share}", ds.pat_blob, ds.pat_off, blob, ds.hay_off.copy())
+
 NAMED = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "R1": r1, "R2": r2, "R3": r3, "R4": r4, "R5": r5, "R6": r6, "R7": r7, "R8": r8}

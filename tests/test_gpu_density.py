@@ -45,8 +45,7 @@ def test_many_candidates_per_item_through_the_filter(per_hay):
         overflow.append(int(res.stat("overflow_items")))
     if per_hay <= 40:   # what the lists (<= 64) and slabs (<= 256) can learn to hold
         assert overflow[-1] == 0, overflow
-    if per_hay <= 17:   # (from ~ 32 candidates per 8 KiB on the automatic choice prefers the table walk)
-        assert res.stat("kernel_used") == 2
+    # (which kernel the later calls run on is a measured choice: tests/test_gpu_cliffs.py)
     if 17 <= per_hay <= 40:
         assert overflow[0] > 0, overflow
     api.ahocorasick_deinit(res)

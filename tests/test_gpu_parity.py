@@ -156,12 +156,14 @@ def test_automatic_choice_of_exact_walk(golden):
     d_blob, d_off = torch.from_numpy(hay).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()
     batch.bind_current_stream(res)
     used = []
-    for _ in range(3):
+    for _ in range(6):
         total = batch.match_device(res, d_blob, d_off, True)
         used.append(int(res.stat("kernel_used")))
         p, r = batch.result_numpy(res, 256, total)
         assert np.array_equal(p, pe) and np.array_equal(r, re_)
-    assert used[0] == 1 and used[1] == 4 and used[2] == 4, used
+    # measured choice: the optimistic kernel first (what the pattern set suggests), then -- it cost several times what an exact
+    # walk is expected to -- the exact walks are probed and one of them kept
+    assert used[0] == 1 and used[-1] in (4, 6) and res.stat("choice_switches") >= 1, used
     api.ahocorasick_deinit(res)
     # the same set with the dense anchor form (shortest pattern 6 B: windows at every byte offset): this text has a hit window
     # every six bytes, the window lists overflow, whole items are walked -- the handle leaves the filter after the first batch
@@ -170,12 +172,12 @@ def test_automatic_choice_of_exact_walk(golden):
     assert res.stat("anchor_q") == 4 and res.stat("anchor_dense") == 1
     batch.bind_current_stream(res)
     used = []
-    for _ in range(3):
+    for _ in range(6):
         total = batch.match_device(res, d_blob, d_off, True)
         used.append(int(res.stat("kernel_used")))
         p, r = batch.result_numpy(res, 256, total)
         assert np.array_equal(p, pe) and np.array_equal(r, re_)
-    assert used[0] == 2 and used[1] != 2, used
+    assert used[0] == 2 and used[-1] != 2, used
     api.ahocorasick_deinit(res)
 
 
@@ -335,7 +337,7 @@ def test_automatic_kernel_choice_and_fallback():
     api.ahocorasick_deinit(res)
     res = resource_for(synth.r1())
     host_match(res, synth.r1())
-    assert res.stat("kernel_used") == 4                  # short patterns: not eligible, and dense by the builder's estimate
+    assert res.stat("kernel_used") in (4, 6)             # short patterns: not eligible, and dense by the builder's estimate: an exact walk
     api.ahocorasick_deinit(res)
     # adversarial text: every haystack is a pattern's first 15 bytes repeated -> anchors everywhere
     # (2 MiB: batches under 1 MiB decide nothing)
@@ -344,19 +346,17 @@ def test_automatic_kernel_choice_and_fallback():
     ds.hay_blob[:] = np.tile(frag, 256)
     o = Oracle("port")
     o.add_patterns((ds.pat_blob, ds.pat_off))
+    pe, re_ = o.match_batch(ds.hay_blob, ds.hay_off)
     res = resource_for(ds)
-    # (the filter first gets longer run lists -- one more batch -- before the handle gives it up)
-    for expect_kernel in (2, 2, 1, 4):  # the same text defeats the LDS kernel's optimistic pass too -> exact walk
-        p, r = host_match(res, ds)
-        pe, re_ = o.match_batch(ds.hay_blob, ds.hay_off)
-        assert np.array_equal(p, pe) and np.array_equal(r, re_)
-        assert res.stat("kernel_used") == expect_kernel
-    # ... not for good: after 16 batches on the exact walk the LDS kernel is probed again, loses again (span doubles)
+    # measured choice: the filter costs this text many times what the other strategies are expected to -- they are probed, the
+    # cheapest is kept; the filter is probed again on its back-off (16, 32, ... batches), loses again, and the results never change
     used = []
-    for _ in range(18):
-        host_match(res, ds)
+    for _ in range(60):
+        p, r = host_match(res, ds)
+        assert np.array_equal(p, pe) and np.array_equal(r, re_)
         used.append(int(res.stat("kernel_used")))
-    assert used.count(1) == 1 and used[16] == 1 and used[17] == 4, used
+    assert used[0] == 2 and used[8] != 2 and used[-1] != 2, used
+    assert used[8:].count(2) <= 3 and res.stat("choice_switches") >= 1 and res.stat("choice_probes") >= 2, used
     api.ahocorasick_deinit(res)
 
 

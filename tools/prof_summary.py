@@ -42,7 +42,7 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
                 acc[k][r.get("Counter_Name")] += float(r.get("Counter_Value", 0))
                 cnt[k].add(r.get("Dispatch_Id"))
         for k, cs in acc.items():
-            if not any(t in k for t in ("k_scan_lds", "k_scan_anchor", "k_walk_runs", "k_walk_items", "k_scan_simple", "k_expand", "k_refill", "k_stream_read", "k_dense_", "k_items", "k_merge", "k_replace")):
+            if not any(t in k for t in ("k_scan_lds", "k_scan_anchor", "k_walk_runs", "k_walk_items", "k_walk_tiles", "k_scan_simple", "k_expand", "k_refill", "k_stream_read", "k_dense_", "k_items", "k_merge", "k_replace")):
                 continue
             n = max(1, len(cnt[k]))
             print(f"{k}: dispatches={n}")
