@@ -42,6 +42,17 @@ TILE_HAYSTACKS = 8192  # 64 MiB generated on the host, replicated on the device
 HAY_LEN = 8192
 
 
+def _cgroup_cpu_max():
+    """The CPU time this process may use per period, if its cgroup says so ("max 100000": no limit): an all-cores figure
+    far under cores x the one-core rate is this quota, or the memory system, not the trie."""
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            return open(path).read().strip()
+        except Exception:
+            pass
+    return None
+
+
 def cpu_baseline(ds, seconds_target: float = 12.0):
     """Reference CPU path over a bounded sample: 1 thread (the reference as shipped) and all cores
     (one trie per thread -- AC_TRIE_t is not re-entrant, ahocorasick.h:49-65)."""
@@ -74,25 +85,26 @@ def cpu_baseline(ds, seconds_target: float = 12.0):
                      f"workload, callback = count + checksum, {n_rec} records per pass",
            "build_ms": round(build_s * 1e3, 2)}
 
-    cores = os.cpu_count() or 1
+    # All cores: one trie replica and ONE call per thread, the repetitions looped in C (*_php_scan_checksum_reps) over the whole
+    # sample -- >= 0.5 s of trie work per thread.  (Round 3 gave each thread 8 haystacks x 14 Python-level calls: 22 ms of work
+    # behind 3,584 GIL hand-overs, 13.7 x one core on 256 cores -- that measured the interpreter.)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     tries = [make()[0] for _ in range(cores)]
-    per = nh // cores
-    reps_mt = max(1, reps // 2)
+    per_pass = probe   # seconds one thread needs for one pass over the sample
+    reps_mt = max(1, int(round(max(0.8, seconds_target / 8) / max(per_pass, 1e-3))))
 
     def work(i):
-        lo, hi = i * per, (i + 1) * per
-        off = ds.hay_off[lo:hi + 1] - ds.hay_off[lo]
-        blob = ds.hay_blob[int(ds.hay_off[lo]):int(ds.hay_off[hi])]
-        for _ in range(reps_mt):
-            tries[i].scan_checksum(blob, off)  # ctypes releases the GIL
+        tries[i].scan_checksum_reps(sub_blob, sub_off, reps_mt)   # ctypes releases the GIL for the whole call
 
     th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
     t0 = time.perf_counter()
     [t.start() for t in th]
     [t.join() for t in th]
     dt = time.perf_counter() - t0
-    allc = {"value": round(reps_mt * per * cores * HAY_LEN / dt / 1e9, 5), "unit": "GB/s", "cores": cores,
-            "kind": kind, "sample": f"{reps_mt} x {per * cores} haystacks, one trie replica per thread"}
+    allc = {"value": round(cores * reps_mt * len(sub_blob) / dt / 1e9, 5), "unit": "GB/s", "cores": cores,
+            "kind": kind, "speedup_over_one_core": round(cores * reps_mt * len(sub_blob) / dt / 1e9 / one["value"], 1),
+            "cgroup_cpu_max": _cgroup_cpu_max(),
+            "sample": f"{cores} threads x {reps_mt} x {nh} haystacks x {HAY_LEN} B ({reps_mt * len(sub_blob) >> 20} MiB each), one trie replica and one C call per thread"}
     return one, allc
 
 
@@ -107,18 +119,19 @@ def dense_leg(torch, api, batch, synth, dev, nh=4096, k=16):
     d_off = torch.arange(nh + 1, dtype=torch.int64, device=dev) * HAY_LEN
     batch.bind_current_stream(res)
     ms, total = [], 0
-    for i in range(7):
+    for i in range(13):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         total = batch.match_device(res, d_blob, d_off, True)  # returns after the call's one host synchronisation
-        if i >= 2:  # the first call grows the record buffer and runs the expansion twice
+        if i >= 6:  # the first call grows the record buffer and runs the expansion twice; automatic mode may probe a kernel early on
             ms.append(time.perf_counter() - t0)
-    t = float(np.mean(ms))
+    t = float(np.median(ms))
     expect = nh * (k * HAY_LEN - k * (k - 1) // 2)
     out = {"workload": f"patterns a^1..a^{k} over {nh} haystacks x {HAY_LEN} B of 'a' ({k} records per byte)",
            "records": total, "count_ok": bool(total == expect), "ms_per_call": round(t * 1e3, 3),
            "matches_per_s": round(total / t, 1), "written_GB_per_s": round(total * 16 / t / 1e9, 1),
-           "frac_of_hbm_peak": round(total * 16 / t / 1e9 / HBM_PEAK_GBS, 4), "overflow_items": int(res.stat("overflow_items"))}
+           "frac_of_hbm_peak": round(total * 16 / t / 1e9 / HBM_PEAK_GBS, 4), "overflow_items": int(res.stat("overflow_items")),
+           "kernel": KERNEL_NAMES.get(int(res.stat("kernel_used")), "?"), "choice_probes": int(res.stat("choice_probes"))}
     api.ahocorasick_deinit(res)
     return out
 
@@ -180,7 +193,7 @@ def _leg_summary(workload, blob_bytes, nh, total, ms, scan, walk, res, ok):
             "frac_whole_call_two_in_flight": round(algo / (_timed_calls.two_in_flight_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
 
-def config3_leg(torch, api, batch, synth, dev, nh=1 << 20):
+def config3_leg(torch, api, batch, synth, dev, nh=1 << 20, cpu=True):
     """BASELINE configs[2]: 65,536 patterns of 8..64 B over Sigma=256 (2.27 M states, seed 7: the G6 automaton),
     2^20 haystacks x 4 KiB = 4 GiB resident, one planted pattern per haystack.  Check: every haystack's plant is
     reported at its place (pattern, start and end), and the tile's record count repeats."""
@@ -218,6 +231,153 @@ def config3_leg(torch, api, batch, synth, dev, nh=1 << 20):
                 "compact": int(res.stat("compact")), "anchor_keys": int(res.stat("anchor_keys"))})
     api.ahocorasick_deinit(res)
     del d_blob
+    if cpu:
+        out["cpu_baseline"] = config3_cpu_baseline(ds, tile_h, hl, nh)
+    return out
+
+
+def config3_cpu_baseline(ds, tile_h, hl, full_nh):
+    """BASELINE.md section 3 for configs[2]: the reference's own C (or the port) on ONE core over a 4,096-haystack subsample of the
+    leg's tile, the time for the whole batch extrapolated from it (the scan is linear in the text; the build is paid once)."""
+    from oracle import pyoracle
+    kind = "reference" if pyoracle.have_reference() else "port"
+    o = pyoracle.Oracle(kind)
+    t0 = time.perf_counter()
+    o.add_patterns((ds.pat_blob, ds.pat_off))
+    o.finalize()
+    build_s = time.perf_counter() - t0
+    nh = min(4096, tile_h)
+    off = ds.hay_off[:nh + 1]
+    blob = ds.hay_blob[:int(off[-1])]
+    t0 = time.perf_counter()
+    n_rec, _ck = o.scan_checksum(blob, off)
+    dt = time.perf_counter() - t0
+    o.close()
+    rate = len(blob) / dt / 1e9
+    return {"value": round(rate, 5), "unit": "GB/s", "cores": 1, "kind": kind, "build_ms": round(build_s * 1e3, 1),
+            "sample": f"{nh} haystacks x {hl} B ({len(blob) >> 20} MiB) of the leg's workload, callback = count + checksum, {n_rec} records",
+            "extrapolated_s_for_the_whole_batch": round(full_nh * hl / (rate * 1e9), 1),
+            "extrapolation": "scan time is linear in the text: subsample rate x the batch's bytes; the build is not in it"}
+
+
+def benchmark_php_leg(api, synth, samples=10):
+    """The reference's only published number (README.md:182-187) is a SAMPLE of examples/benchmark.php:55-72: init (2,048 needles of
+    16 chars) + 256 x ahocorasick_match (8,192 chars each) + deinit, averaged over 10 samples.  The same loop through this library's
+    mirror of the PHP functions (one launch per ahocorasick_match call: k_match_small), the same with ONE ahocorasick_match_batch
+    call for the 256 haystacks, and the reference's own C (oracle/_ref, no Zend layer: no result arrays are built) doing the same
+    loop on this box's CPU.  Build and scan are reported separately."""
+    from oracle import pyoracle
+    ds = synth.g2()   # the literal BASELINE configs[1] shape with a planted occurrence per haystack (G1 has no match at all)
+    pats = [{"id": k, "value": ds.pattern(k)} for k in range(ds.n_patterns)]
+    hays = [ds.haystack(h) for h in range(ds.n_haystacks)]
+    kind = "reference" if pyoracle.have_reference() else "port"
+    o = pyoracle.Oracle(kind)
+    n_ref, b_s, s_s, r_s = o.benchmark_sample(ds.pat_blob, ds.pat_off, ds.hay_blob, ds.hay_off, samples)
+    o.close()
+    out = {"workload": f"{samples} samples x (ahocorasick_init of 2,048 x 16 B + 256 x ahocorasick_match of 8,192 B + ahocorasick_deinit): examples/benchmark.php:55-72",
+           "reference_published_s_per_sample": 0.174326, "reference_published_on": "unspecified hardware, PHP + Zend arrays included (README.md:183)",
+           "cpu": {"kind": kind, "cores": 1, "build_ms_per_sample": round(b_s / samples * 1e3, 3), "scan_ms_per_sample": round(s_s / samples * 1e3, 3),
+                   "release_ms_per_sample": round(r_s / samples * 1e3, 3), "s_per_sample": round((b_s + s_s + r_s) / samples, 5), "records_per_sample": n_ref,
+                   "note": "the reference's MultiFast C without the Zend layer (callback = count + checksum)"}}
+    for name, batched in (("per_call", False), ("one_match_batch", True)):
+        build = scan = deinit = 0.0
+        n_rec = 0
+        for i in range(samples + 1):   # (the first sample pays the runtime's first use of the kernels: not counted)
+            t0 = time.perf_counter()
+            res = api.ahocorasick_init(pats)
+            api.ahocorasick_finalize(res)
+            t1 = time.perf_counter()
+            if batched:
+                got = api.ahocorasick_match_batch(hays, res)
+                n_rec = sum(len(g) for g in got)
+            else:
+                n_rec = 0
+                for hay in hays:
+                    n_rec += len(api.ahocorasick_match(hay, res))
+            t2 = time.perf_counter()
+            api.ahocorasick_deinit(res)
+            t3 = time.perf_counter()
+            if i:
+                build += t1 - t0
+                scan += t2 - t1
+                deinit += t3 - t2
+        out[name] = {"build_ms_per_sample": round(build / samples * 1e3, 3), "scan_ms_per_sample": round(scan / samples * 1e3, 3),
+                     "deinit_ms_per_sample": round(deinit / samples * 1e3, 3), "s_per_sample": round((build + scan + deinit) / samples, 5),
+                     "records_per_sample": n_rec, "check_ok": bool(n_rec == n_ref),
+                     "note": "through the Python mirror of the PHP functions: result arrays (pos / keyIdx / start_postion / value) are built for every record"}
+    return out
+
+
+def density_leg(torch, api, batch, synth, dev, nh=1 << 17):
+    """How a whole call degrades with the density of matches: the headline patterns with 1 / 16 / 64 / 256
+    planted occurrences per 8 KiB haystack, and the 2,048-word list over prose of which a share is listed words (53 / 200 / 910
+    records per 8 KiB), 1 GiB each, automatic kernel choice (measured: engine.cpp choose_strategy); the first 32 haystacks of
+    every cell against the oracle.  ms per algorithmic GB is what neighbouring cells are compared by."""
+    from oracle import pyoracle
+    cells = []
+    sets = {"headline": synth.density_set("headline"), "words": synth.density_set("words")}
+    plan = [("headline", "plants", p) for p in (1, 16, 64, 256)] + [("words", "prose", sh) for sh in (0.05, 0.2, 1.0)]
+    oracles, handles = {}, {}
+    for kind, base in sets.items():
+        o = pyoracle.Oracle("port")
+        o.add_patterns((base.pat_blob, base.pat_off))
+        oracles[kind] = o
+    for kind, how, level in plan:
+        base = sets[kind]
+        ds = synth.plant_density(base, level, HAY_LEN) if how == "plants" else synth.prose(base, level)
+        res = api.ahocorasick_init([{"id": k, "value": p} for k, p in enumerate(base.patterns())])
+        reps = nh // ds.n_haystacks
+        d_blob = torch.from_numpy(ds.hay_blob).to(dev).repeat(reps).contiguous()
+        d_off = torch.arange(nh + 1, dtype=torch.int64, device=dev) * HAY_LEN
+        batch.bind_current_stream(res)
+        for _ in range(10):   # the measured choice settles
+            total = batch.match_device(res, d_blob, d_off, True)
+        ms = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            total = batch.match_device(res, d_blob, d_off, True)
+            ms.append((time.perf_counter() - t0) * 1e3)
+        t = float(np.median(ms))
+        prefix, rec = batch.result_numpy(res, nh, total)
+        n_chk = 32
+        pe, re_ = oracles[kind].match_batch(ds.hay_blob[:int(ds.hay_off[n_chk])], ds.hay_off[:n_chk + 1], True)
+        ok = np.array_equal(prefix[:n_chk + 1], pe) and np.array_equal(rec[:int(pe[-1])], re_) and total == int(prefix[ds.n_haystacks]) * reps
+        algo = d_blob.numel() + 16 * total + 8 * nh
+        cells.append({"set": kind, "text": f"{level} planted occurrences per 8 KiB" if how == "plants" else f"prose, {int(level * 100)} % of it listed words",
+                      "records_per_8KiB": round(total / nh, 1), "ms_per_call": round(t, 4), "kernel": KERNEL_NAMES.get(int(res.stat("kernel_used")), "?"),
+                      "algorithmic_bytes": int(algo), "ms_per_algorithmic_GB": round(t / (algo / 1e9), 4),
+                      "frac_whole_call": round(algo / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "check_ok": bool(ok),
+                      "choice_probes": int(res.stat("choice_probes")), "choice_switches": int(res.stat("choice_switches"))})
+        api.ahocorasick_deinit(res)
+        del d_blob, d_off
+        torch.cuda.empty_cache()
+    for o in oracles.values():
+        o.close()
+    worst = 0.0
+    for a, b in zip(cells[:-1], cells[1:]):
+        if a["set"] == b["set"]:
+            r = max(a["ms_per_algorithmic_GB"], b["ms_per_algorithmic_GB"]) / min(a["ms_per_algorithmic_GB"], b["ms_per_algorithmic_GB"])
+            worst = max(worst, r)
+    return {"cells": cells, "min_frac_whole_call": min(c["frac_whole_call"] for c in cells), "max_ratio_between_neighbours": round(worst, 2),
+            "all_check_ok": bool(all(c["check_ok"] for c in cells))}
+
+
+def choice_matrix_leg():
+    """The cliff detector of tests/test_gpu_cliffs.py as a driver-visible figure: {2,048 x 16 B; 2,048 words; 65,536 x 8..64 B} x
+    {1, 8, 32, 128, 512 occurrences per 8 KiB} x {256 B, 8 KiB, 1 MiB haystacks}, 64 MiB batches; in every cell the automatic
+    mode (10 batches to settle) against every forced scan kernel, all record arrays equal (the oracle on a slice)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_cliffs import run_matrix
+    out = {"cells": [], "violations": []}
+    for kind in ("headline", "words", "cfg3"):
+        rows, bad = run_matrix(kind)
+        out["cells"] += [{"set": r["set"], "per_8KiB": r["per_8k"], "haystack_bytes": r["hay_len"], "records": r["records"], "automatic_ms": r["auto_ms"],
+                          "automatic_kernel": r["auto_kernel"], "best_forced_ms": r["best_forced_ms"], "best_forced_kernel": r["best_forced_kernel"],
+                          "forced_ms": r["forced_ms"]} for r in rows]
+        out["violations"] += bad
+    out["worst_ratio_automatic_over_best_forced"] = round(max(c["automatic_ms"] / c["best_forced_ms"] for c in out["cells"]), 3)
+    out["rule"] = "automatic <= 1.3 x best forced + 0.03 ms, every result equal to the oracle's"
     return out
 
 
@@ -885,7 +1045,13 @@ def main():
         if want_leg("short_patterns") and args.workload == "headline":
             out["short_patterns"] = short_patterns_leg(torch, api, batch, synth, dev, ds)
         if want_leg("config3") and args.workload == "headline":
-            out["config3"] = config3_leg(torch, api, batch, synth, dev)
+            out["config3"] = config3_leg(torch, api, batch, synth, dev, cpu=not args.no_cpu)
+        if want_leg("density_sweep"):
+            out["density_sweep"] = density_leg(torch, api, batch, synth, dev)
+        if want_leg("choice_matrix"):
+            out["choice_matrix"] = choice_matrix_leg()
+        if want_leg("benchmark_php_sample") and args.workload == "headline":
+            out["benchmark_php_sample"] = benchmark_php_leg(api, synth)
         if args.phase_times:
             out["host_us_per_step"] = {k: round(v / args.steps * 1e6, 1) for k, v in phase.items()}
         print(json.dumps(out), flush=True)

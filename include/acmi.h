@@ -281,6 +281,9 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *                    sum in ONE pass -- no slabs, no drain (findAll = true, patterns of <= 129 B; what automatic
  *                    mode takes instead of 4 unless the output is denser than a record per two bytes) [any time]
  *   "tile_w", "tile_p"  kernel 6: bytes per lane (16, 32, 64) and lanes per work item (1..64); 0 = automatic [any time]
+ *   "part_kernel"    split sets (see "split"): the "kernel" of the SHORT part alone, -1 (default) its own automatic choice; with 6
+ *                    and a small short part the long part's records are merged into the result as the short part's are
+ *                    written -- no merge pass                                                    [any time]
  *   "tiny_rows"      kernel 2: 1 (default) batches of haystacks of <= 1 KiB on average take the variant whose
  *                    waves pack one-row work items eight to a step, 0 never                [any time]
  *   "short_rows"     kernel 2: the variant that skips the 1-KiB rows a work item lacks: -1 (default)

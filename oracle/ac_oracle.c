@@ -584,3 +584,36 @@ size_t orc_php_scan_checksum(orc_trie *t, const uint8_t *blob, const uint64_t *o
         *checksum = p.checksum;
     return p.n;
 }
+
+/* The same scan `reps` times in one call (bench.py's all-cores baseline: one call per thread, the loop in C). */
+size_t orc_php_scan_checksum_reps(orc_trie *t, const uint8_t *blob, const uint64_t *off, size_t nh, size_t reps, uint64_t *checksum)
+{
+    size_t n = 0;
+    for (size_t r = 0; r < reps; r++)
+        n = orc_php_scan_checksum(t, blob, off, nh, checksum);
+    return n;
+}
+
+/* examples/benchmark.php:55-72 over this restatement: `samples` x (create, add in PHP's reverse order, finalize, one search
+ * per haystack, release); seconds[0] += build, [1] += searches, [2] += release.  Returns the last sample's records. */
+#include <time.h>
+static double orc_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+size_t orc_benchmark_sample(const uint8_t *pat_blob, const uint64_t *pat_off, size_t np, const uint8_t *hay_blob, const uint64_t *hay_off,
+                            size_t nh, size_t samples, double *seconds)
+{
+    size_t n = 0;
+    for (size_t s = 0; s < samples; s++) {
+        double t0 = orc_now();
+        orc_trie *t = orc_create();
+        orc_php_add_patterns(t, pat_blob, pat_off, np, 0);
+        orc_finalize(t);
+        double t1 = orc_now();
+        uint64_t ck = 0;
+        n = orc_php_scan_checksum(t, hay_blob, hay_off, nh, &ck);
+        double t2 = orc_now();
+        orc_release(t);
+        double t3 = orc_now();
+        seconds[0] += t1 - t0; seconds[1] += t2 - t1; seconds[2] += t3 - t2;
+    }
+    return n;
+}

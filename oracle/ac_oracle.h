@@ -119,6 +119,11 @@ size_t orc_php_match_batch(orc_trie *t, const uint8_t *blob, const uint64_t *off
 size_t orc_php_scan_checksum(orc_trie *t, const uint8_t *blob, const uint64_t *off,
                              size_t nh, uint64_t *checksum);
 
+/* the same `reps` times in one call; examples/benchmark.php:55-72 (samples x build + one search per haystack + release) */
+size_t orc_php_scan_checksum_reps(orc_trie *t, const uint8_t *blob, const uint64_t *off, size_t nh, size_t reps, uint64_t *checksum);
+size_t orc_benchmark_sample(const uint8_t *pat_blob, const uint64_t *pat_off, size_t np, const uint8_t *hay_blob, const uint64_t *hay_off,
+                            size_t nh, size_t samples, double *seconds);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,8 @@ class Oracle:
         f("php_match_batch", C.c_size_t, C.c_void_p, _u8p, _u64p, C.c_size_t, C.c_int, _u64p, _u32p,
           C.c_size_t)
         f("php_scan_checksum", C.c_size_t, C.c_void_p, _u8p, _u64p, C.c_size_t, _u64p)
+        f("php_scan_checksum_reps", C.c_size_t, C.c_void_p, _u8p, _u64p, C.c_size_t, C.c_size_t, _u64p)
+        f("benchmark_sample", C.c_size_t, _u8p, _u64p, C.c_size_t, _u8p, _u64p, C.c_size_t, C.c_size_t, C.POINTER(C.c_double))
         f("stream_feed", C.c_size_t, C.c_void_p, _u8p, C.c_size_t, C.c_int, _u32p, C.c_size_t)
         f("set_replacement", None, C.c_void_p, C.c_uint32, C.c_char_p, C.c_size_t)
         f("replace", C.c_size_t, C.c_void_p, _u8p, C.c_size_t, C.c_int, _u8p, C.c_size_t)
@@ -180,6 +182,24 @@ class Oracle:
         n = self._c("php_scan_checksum")(self.t, _ptr(blob, _u8p), _ptr(off, _u64p), len(off) - 1,
                                          C.byref(ck))
         return int(n), int(ck.value)
+
+
+    def scan_checksum_reps(self, blob: np.ndarray, off: np.ndarray, reps: int):
+        """The same scan `reps` times in ONE call (the loop is in C: what a thread of the all-cores baseline runs)."""
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        ck = C.c_uint64(0)
+        n = self._c("php_scan_checksum_reps")(self.t, _ptr(blob, _u8p), _ptr(off, _u64p), len(off) - 1, int(reps), C.byref(ck))
+        return int(n), int(ck.value)
+
+    def benchmark_sample(self, pat_blob, pat_off, hay_blob, hay_off, samples: int):
+        """examples/benchmark.php:55-72 in C: samples x (create + add + finalize, one search per haystack, release).  Returns
+        (records of a sample, seconds of build, of the searches, of release) summed over the samples."""
+        pb, po = np.ascontiguousarray(pat_blob, dtype=np.uint8), np.ascontiguousarray(pat_off, dtype=np.uint64)
+        hb, ho = np.ascontiguousarray(hay_blob, dtype=np.uint8), np.ascontiguousarray(hay_off, dtype=np.uint64)
+        sec = (C.c_double * 3)(0.0, 0.0, 0.0)
+        n = self._c("benchmark_sample")(_ptr(pb, _u8p), _ptr(po, _u64p), len(po) - 1, _ptr(hb, _u8p), _ptr(ho, _u64p), len(ho) - 1, int(samples), sec)
+        return int(n), sec[0], sec[1], sec[2]
 
 
 def record_checksum(records: np.ndarray) -> int:

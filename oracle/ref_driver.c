@@ -177,6 +177,42 @@ size_t ref_php_scan_checksum(void *t, const uint8_t *blob, const uint64_t *off, 
     return p.n;
 }
 
+/* The same scan `reps` times in one call: what bench.py's all-cores baseline gives each thread (one ctypes call per
+ * thread, the loop in C -- a Python loop of short calls measured the interpreter's thread scheduling, not the trie). */
+size_t ref_php_scan_checksum_reps(void *t, const uint8_t *blob, const uint64_t *off, size_t nh, size_t reps, uint64_t *checksum)
+{
+    size_t n = 0;
+    for (size_t r = 0; r < reps; r++)
+        n = ref_php_scan_checksum(t, blob, off, nh, checksum);
+    return n;
+}
+
+/* examples/benchmark.php:55-72 with the reference's own C underneath: `samples` x (create, add every pattern in PHP's
+ * reverse order, finalize -- lazily, on the first match, php_ahocorasick.c:707 --, one ac_trie_search per haystack,
+ * release).  seconds[0] += build (create + add + finalize), seconds[1] += the searches, seconds[2] += release.  Returns
+ * the records of the last sample.  (No Zend layer: no zval arrays are built for the records.) */
+#include <time.h>
+static double ref_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+size_t ref_benchmark_sample(const uint8_t *pat_blob, const uint64_t *pat_off, size_t np, const uint8_t *hay_blob, const uint64_t *hay_off,
+                            size_t nh, size_t samples, double *seconds)
+{
+    size_t n = 0;
+    for (size_t s = 0; s < samples; s++) {
+        double t0 = ref_now();
+        void *t = ref_create();
+        ref_php_add_patterns(t, pat_blob, pat_off, np, 0);
+        ref_finalize(t);
+        double t1 = ref_now();
+        uint64_t ck = 0;
+        n = ref_php_scan_checksum(t, hay_blob, hay_off, nh, &ck);
+        double t2 = ref_now();
+        ref_release(t);
+        double t3 = ref_now();
+        seconds[0] += t1 - t0; seconds[1] += t2 - t1; seconds[2] += t3 - t2;
+    }
+    return n;
+}
+
 /* multifast_replace + multifast_rep_flush(keep=0) over one whole text, the callback's chunks concatenated */
 typedef struct { uint8_t *out; size_t cap, n; } ref_rep_out;
 static void ref_rep_cb(AC_TEXT_t *txt, void *param)

@@ -98,6 +98,9 @@ struct acmi_handle {
     int split_opt = -1;   // -1 automatic, 0 never, 1 whenever there are patterns on both sides of 7 B
     std::vector<std::pair<std::string, int64_t>> option_log;   // every option set on this handle: replayed on the parts
     DevBuf d_merge_counts, d_merge_sync;
+    // (part 1 of a split set) the batch being begun may merge part 0's match arrays into the parent's result buffer as it writes
+    // its own records (k_walk_tiles, lane-list variant): set by the parent around the part's begin
+    struct MergeInto { const uint64_t *prefix = nullptr; const void *records = nullptr; void *out = nullptr; uint64_t cap = 0; } merge_into;
 
     // options
     bool dense_output = false;   // the last batch produced a record per two bytes of text or more (which drain: refill_mode)
@@ -110,6 +113,7 @@ struct acmi_handle {
     uint64_t chunk_opt = 0;
     int kernel = 3;  // 0 plain global table, 1 LDS-tile walk, 2 anchor filter (if eligible), 3 automatic, 4 whole-item walk, 6 tile walk (single pass, ordered output)
     int tile_w = 0, tile_p = 0;   // k_walk_tiles: bytes per lane / lanes per item (0: tiles_geometry chooses)
+    int part_kernel = -1;         // split sets: the kernel forced on the SHORT part (-1: its own automatic choice)
     // automatic mode: a batch on which the fast kernel lost (most bytes had to be walked exactly anyway) moves the
     // handle to the slower, safer kernel -- for `*_left` batches, then the fast one is probed again; every further
     // loss doubles the span (16 .. 1024 batches), a win resets it.  Batches under kAutoMinBytes decide nothing.
@@ -132,6 +136,7 @@ struct acmi_handle {
     };
     ChoiceClass choice[2][8];   // [findAll][size class | short haystacks << 2]
     uint32_t probes = 0, switches = 0;   // statistics ("choice_probes", "choice_switches")
+    uint32_t merged_batches = 0;         // split sets: batches whose records the short part's walk wrote merged ("merged_batches")
     int ilp = 1;
     int group_quads = 8;
     int small_path = 1;   // 1: host batches of <= 64 KiB / <= 1024 haystacks take the one-launch kernel
@@ -218,6 +223,8 @@ struct acmi_handle {
         int strategy = -1, choice_class = 0;  // automatic mode: the strategy this batch ran on (-1: the caller fixed the kernel)
         bool probe = false;                   // ... as a probe of an alternative
         bool timed = false;                   // nothing was allocated while it was enqueued: its events say what it cost
+        bool merged = false;                  // (part 1 of a split set) this batch wrote the MERGED records into the parent's buffer
+        bool reran = false;                   // the end had to complete or repeat the pipeline: what ran behind it on the stream saw unfinished results
         bool refill_launched = false;  // the drain of overflowed items was enqueued with the pipeline (else: only if the batch turns out to need it)
         DevBuf d_prefix, d_out;        // valid from this batch's end until the second begin after its own
     };
@@ -386,6 +393,7 @@ int build_parts(acmi_handle *h) {
         c->aut.add_batch(vals.data(), lens.data(), types.data(), ids.data(), users.data(), pats.size());
         const int rc = ensure_finalized(c);
         if (rc < 0) { h->last_error = c->last_error; return rc; }
+        if (side == 1 && h->part_kernel >= 0) (void)acmi_set_option(c, "kernel", h->part_kernel);
     }
     return ACMI_OK;
 }
@@ -711,18 +719,25 @@ int choice_class(uint64_t blob_bytes, size_t nh) {
 // What a GiB is EXPECTED to cost (ms) on a strategy this handle has not run yet: the rate the kernel reaches on text it
 // suits.  Only decides whether an untried alternative is worth a probe (one whose best case is no better than what the current
 // strategy measures is never tried); every decision between strategies that have run is taken on measured times.
-float nominal_cost(const acmi_handle *h, int strat, uint64_t blob_bytes, size_t nh) {
+float nominal_cost(const acmi_handle *h, int strat, uint64_t blob_bytes, size_t nh, double density) {
     const FlatAutomaton &fa = h->aut.flat();
     const double avg = nh ? double(blob_bytes) / double(nh) : 0.0;
+    // `density` = records per byte of the batch just ended: what the text is like is known even for a strategy that never ran on
+    // it -- the filter pays for every candidate (a match is one), the optimistic pass walks again wherever there is an event,
+    // every record is 16 bytes written (17 GB per GiB of text at a record per byte).  Without these terms a^1..a^16 kept
+    // probing kernels that had no chance (each probe a batch at a third of the rate).
     switch (strat) {
     case acmi_handle::kStratAnchor: {
         double c = fa.anchor_dense ? 0.45 : fa.anchor_mode == 2 ? 0.30 : 0.19;
         if (avg < 2048.0) c *= 2048.0 / std::max(avg, 128.0) * 0.5 + 0.5;          // (a wave step per work item: short haystacks idle its lanes)
-        return float(c);
+        return float(c + density * 250.0);
     }
-    case acmi_handle::kStratLds: return fa.compact ? 2.0f : 0.33f;
-    case acmi_handle::kStratTiles: return fa.compact ? 6.0f : (uint64_t(fa.trap) * (fa.n_columns * fa.entry_bytes + 4u) <= 60u * 1024u && fa.trap + 1u == fa.n_states) ? 1.0f : 1.7f;
-    default: return fa.compact ? 8.0f : 1.3f;
+    case acmi_handle::kStratLds: return float((fa.compact ? 2.0 : 0.33) + density * 300.0);
+    case acmi_handle::kStratTiles: {
+        const bool allhot = uint64_t(fa.trap) * (fa.n_columns * fa.entry_bytes + 4u) <= 60u * 1024u && fa.trap + 1u == fa.n_states;
+        return float((fa.compact ? 6.0 : allhot ? 1.0 : 1.7) + density * (density > 0.25 ? 20.0 : 4.5));   // (past an event per 4 bytes: the second walk)
+    }
+    default: return float((fa.compact ? 8.0 : 1.3) + density * 3.5);
     }
 }
 
@@ -767,7 +782,7 @@ int choose_strategy(acmi_handle *h, acmi_handle::FlySlot &F, uint64_t blob_bytes
     return C.cur;
 }
 
-void learn_strategy(acmi_handle *h, const acmi_handle::FlySlot &F, double ms_per_gib) {
+void learn_strategy(acmi_handle *h, const acmi_handle::FlySlot &F, double ms_per_gib, double density) {
     acmi_handle::ChoiceClass &C = h->choice[F.find_all ? 1 : 0][F.choice_class];
     const int s = F.strategy;
     C.cost[s] = C.cost[s] > 0.f ? 0.5f * C.cost[s] + 0.5f * float(ms_per_gib) : float(ms_per_gib);
@@ -790,7 +805,7 @@ void learn_strategy(acmi_handle *h, const acmi_handle::FlySlot &F, double ms_per
     // small batches are launch-bound on every strategy and probe nothing.)
     for (int a = 0; a < acmi_handle::kStratCount; ++a) {
         if (a == s || C.wait[a] || !strategy_eligible(h, a, F.blob_bytes, F.nh, F.find_all)) continue;
-        const float ref = nominal_cost(h, a, F.blob_bytes, F.nh) + 0.06f * float(1ull << 30) / float(F.blob_bytes);
+        const float ref = nominal_cost(h, a, F.blob_bytes, F.nh, density) + 0.06f * float(1ull << 30) / float(F.blob_bytes);
         if (C.cost[s] > 1.5f * ref) C.pending |= 1u << a;
     }
 }
@@ -814,7 +829,22 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
         for (acmi_handle *c : h->part) {
             c->stream = h->stream;
             c->profile = h->profile;
+            c->merge_into = acmi_handle::MergeInto{};
+            if (c == h->part[1] && find_all && nh && tiles_can_merge(c->dA, int(c->aut.flat().entry_bytes))) {
+                // the short part's tile walk can place the long part's records among its own as it writes them: no merge pass
+                // over the whole result (the short part's 70 M records per GiB were copied once more, 0.5 ms)
+                acmi_handle *a = h->part[0];
+                acmi_handle::FlySlot &FA = a->fly[a->begin_seq & 1];   // the batch part 0 has just begun
+                if (!FA.trivial && FA.d_out.p) {
+                    HIPCHK(h, F.d_out.ensure(std::max<size_t>(16, h->out_want)));
+                    c->merge_into.prefix = FA.d_prefix.as<uint64_t>();
+                    c->merge_into.records = FA.d_out.p;
+                    c->merge_into.out = F.d_out.p;
+                    c->merge_into.cap = F.d_out.cap / 16;
+                }
+            }
             const int rc = run_batch_begin(c, d_blob, blob_bytes, d_off, nh, find_all);
+            c->merge_into = acmi_handle::MergeInto{};
             if (rc < 0) {
                 h->last_error = c->last_error;
                 if (c == h->part[1]) (void)run_batch_end(h->part[0]);   // (the first part's batch is not left in flight)
@@ -1072,9 +1102,13 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
         HIPCHK(h, hipMemsetAsync(h->d_tile_sync.p, 0, 8 + tiles_status_words(max_items, tile_p) * 8, st));
     }
     if (h->profile) HIPCHK(h, hipEventRecord(F.ev[1], st));
+    F.merged = false;
+    F.reran = false;
     if (kernel == 6) {
+        F.merged = h->merge_into.out != nullptr;
         HIPCHK(h, launch_walk_tiles(h->dA, B, max_items, int(fa.entry_bytes), int(fa.class_mode), tile_w, tile_p, h->d_tile_queue.p,
-                                    h->d_tile_sync.as<uint32_t>(), h->d_tile_sync.as<uint64_t>() + 1, F.d_out.p, cap, st));
+                                    h->d_tile_sync.as<uint32_t>(), h->d_tile_sync.as<uint64_t>() + 1, F.merged ? h->merge_into.out : F.d_out.p,
+                                    F.merged ? h->merge_into.cap : cap, st, F.merged ? h->merge_into.prefix : nullptr, F.merged ? h->merge_into.records : nullptr));
     } else if (kernel == 4) {
         // exact walk only (k_walk_items): for text on which k_scan_lds' optimistic
         // pass flags everything anyway (events in every wave-quad)
@@ -1131,10 +1165,34 @@ int run_split_end(acmi_handle *h) {
     const uint32_t nh = uint32_t(F.nh), first_only = F.find_all ? 0u : 1u;
     const uint64_t ta = a->last_total, tb = b->last_total;
     HIPCHK(h, F.d_prefix.ensure((size_t(nh) + 1) * 8));
+    acmi_handle::FlySlot &FA = a->fly[a->cur], &FB = b->fly[b->cur];
+    bool merged = FB.merged;
+    h->out_want = std::max<size_t>(h->out_want, size_t(ta + tb) * 16);
+    if (merged && (FA.reran || (ta + tb) * 16 > F.d_out.cap)) {
+        // Part 1 merged part 0's records while writing its own -- but part 0's were not final when it ran (their buffer had to
+        // grow, items had to be drained at the end), or the merged array outgrew this handle's buffer: part 1's batch once more,
+        // now that everything is known.  (A later begin may have taken part 1's intermediates: the whole pipeline, as
+        // run_batch_end does for a batch whose records outgrew its buffer.)
+        HIPCHK(h, hipStreamSynchronize(st));
+        HIPCHK(h, F.d_out.ensure((ta + tb) * 16));
+        b->merge_into.prefix = FA.d_prefix.as<uint64_t>();
+        b->merge_into.records = FA.d_out.p;
+        b->merge_into.out = F.d_out.p;
+        b->merge_into.cap = F.d_out.cap / 16;
+        const int rr = enqueue_batch(b, FB, FB.d_blob, FB.blob_bytes, FB.d_off, FB.nh, FB.find_all);
+        b->merge_into = acmi_handle::MergeInto{};
+        if (rr < 0) { b->sync_tiles = 0; h->last_error = b->last_error; return rr; }
+        b->enqueue_seq = FB.seq;
+        HIPCHK(h, hipStreamSynchronize(st));
+        merged = FB.merged;
+    }
     HIPCHK(h, F.d_out.ensure(std::max<uint64_t>(16, (ta + tb) * 16)));
     const uint64_t *pa = a->d_prefix().as<uint64_t>(), *pb = b->d_prefix().as<uint64_t>();
     uint64_t total = ta + tb;
-    if (!first_only) {
+    if (merged) {
+        ++h->merged_batches;
+        launch_merge_prefix_sum(pa, pb, nh, F.d_prefix.as<uint64_t>(), st);   // (the records are in place already)
+    } else if (!first_only) {
         launch_merge_prefix_sum(pa, pb, nh, F.d_prefix.as<uint64_t>(), st);
     } else {
         // findAll = false: a haystack keeps the earlier of the parts' first events (both at equal positions): counts, then their scan
@@ -1147,7 +1205,7 @@ int run_split_end(acmi_handle *h) {
         launch_scan_u64(h->d_merge_counts.as<uint64_t>(), nh, F.d_prefix.as<uint64_t>(), h->d_merge_sync.as<uint32_t>(),
                         reinterpret_cast<uint64_t *>(h->pinned_dev + kPinWords * slot_index), st);
     }
-    launch_merge_parts(pa, a->d_out().p, ta, pb, b->d_out().p, tb, nh, first_only, F.d_prefix.as<uint64_t>(), F.d_out.p, st);
+    if (!merged) launch_merge_parts(pa, a->d_out().p, ta, pb, b->d_out().p, tb, nh, first_only, F.d_prefix.as<uint64_t>(), F.d_out.p, st);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(st));
     if (first_only) total = h->pinned[(kPinWords / 2) * int(&F - h->fly)];
@@ -1234,15 +1292,17 @@ int run_batch_end(acmi_handle *h) {
             h->walk_ms = F.kernel_used == 2 ? ms : 0.0;
         }
     }
-    h->out_want = std::max<size_t>(h->out_want, size_t(total) * 16);
-    const bool too_small = total > F.d_out.cap / 16;             // did not fit the optimistic capacity: grow, expand again
+    if (!F.merged) h->out_want = std::max<size_t>(h->out_want, size_t(total) * 16);
+    // (a merged batch wrote into the parent's buffer: whether THAT was big enough is the parent's business, run_split_end)
+    const bool too_small = !F.merged && total > F.d_out.cap / 16;   // did not fit the optimistic capacity: grow, expand again
     const bool undrained = n_ovf > 0 && !F.refill_launched;      // items overflowed their slabs and the drain was not enqueued
     h->refill_armed = n_ovf > 0;
     // (a pipeline that has to be completed or run again below says nothing about what the strategy costs)
     if (F.strategy >= 0 && F.blob_bytes >= kAutoMinBytes) {
-        if (F.timed && !too_small && !undrained) learn_strategy(h, F, double(pipeline_ms) * double(1ull << 30) / double(F.blob_bytes));
+        if (F.timed && !too_small && !undrained) learn_strategy(h, F, double(pipeline_ms) * double(1ull << 30) / double(F.blob_bytes), double(total) / double(F.blob_bytes));
         else if (F.probe) h->choice[F.find_all ? 1 : 0][F.choice_class].pending |= 1u << F.strategy;   // (the probe is taken again)
     }
+    F.reran = too_small || undrained;
     if (too_small || undrained) {
         if (h->enqueue_seq == F.seq) {
             if (too_small) HIPCHK(h, F.d_out.ensure(total * 16));
@@ -1687,6 +1747,10 @@ static int apply_option(acmi_handle *h, const std::string &k, int64_t value) {
             h->kernel = int(value);
             for (auto &row : h->choice)
                 for (auto &c : row) c = acmi_handle::ChoiceClass{};
+        } else if (k == "part_kernel") {   // split sets: "kernel" of the short part alone (the long part keeps the filter); -1 automatic
+            if (value < -1 || value > 6 || value == 5 || value == 2) return ACMI_E_ARG;
+            h->part_kernel = int(value);
+            if (h->is_part && h->aut.accepted_count() && h->aut.flat().max_pattern_length < 7 && h->aut.finalized()) return apply_option(h, "kernel", value < 0 ? 3 : value);
         } else if (k == "tile_w") {   // k_walk_tiles: bytes per lane (0: automatic)
             if (value != 0 && value != 16 && value != 32 && value != 64) return ACMI_E_ARG;
             h->tile_w = int(value);
@@ -1799,6 +1863,7 @@ int acmi_get_stat(const acmi_handle *h, const char *key, double *value) {
         if (!key || !value) return ACMI_E_ARG;
         const std::string k(key);
         if (k == "split") { *value = h->part[0] ? 1 : 0; return ACMI_OK; }
+        if (k == "merged_batches") { *value = h->merged_batches; return ACMI_OK; }
         if (k == "split_long_patterns" || k == "split_short_patterns") {
             *value = h->part[0] ? double(h->part[k == "split_long_patterns" ? 0 : 1]->aut.accepted_count()) : 0.0;
             return ACMI_OK;

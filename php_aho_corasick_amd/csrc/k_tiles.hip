@@ -25,6 +25,7 @@
 //     ascending, longest pattern first (node.c:424-441) -- without a sort and without knowing any count in advance.
 // The per-item record counts are left for k_expand (per-haystack prefix, summary), which finds no event to expand.
 #include <cstdlib>
+#include <type_traits>
 
 #include "kdev.hpp"
 
@@ -33,6 +34,7 @@ namespace acmi {
 constexpr uint32_t kTilesThreads = 1024;
 constexpr uint32_t kTilesWaves = kTilesThreads / 64;
 constexpr uint32_t kTilesRing = 128;   // events a wave stages in LDS (flushed to its queue 64 at a time)
+constexpr uint32_t kTilesLaneCap = 16; // LANEQ: events a LANE keeps in LDS (more: the wave walks its pieces again)
 
 struct TileArgs {
     uint32_t W;           // bytes per lane piece: 16, 32 or 64
@@ -47,6 +49,11 @@ struct TileArgs {
     uint64_t *status;     // zeroed, one word per workgroup tile
     uint4 *out;
     uint64_t cap;         // records `out` holds
+    // split pattern sets (engine.cpp): the match arrays of the OTHER part of the set over the same batch -- all its patterns longer
+    // than all of this automaton's -- are merged into `out` as this kernel writes it (LANEQ variants): per haystack position
+    // ascending, the other part's records first at equal positions (node.c:424-441: longest first).  Null: nothing to merge.
+    const uint64_t *m_prefix;
+    const uint4 *m_records;
 };
 
 __device__ __forceinline__ uint32_t tile_wave_max(uint32_t v) {
@@ -74,6 +81,8 @@ struct Piece {
     uint32_t rep_lo, rep_len;   // bytes [rep_lo, rep_lo + rep_len) report
     uint32_t pos_bias;    // position of byte jj = pos_bias + jj
     uint32_t hay;
+    uint64_t m_first;     // merging: first record of the other part that ends inside this piece ...
+    uint32_t m_count;     // ... and how many do
 };
 
 // The wave's event queue: a ring in LDS, flushed 64 entries at a time to the wave's region in global memory (which stays in
@@ -85,6 +94,8 @@ struct TileQueue {
     uint32_t qcap;
     uint32_t total;       // events so far (wave-uniform)
     uint32_t flushed;     // of which in `spill` (a multiple of 64)
+    uint32_t *lists;      // LANEQ: this wave's lane lists (LDS): entry e of lane l at lists[e * 64 + l] = row offset | byte index << 16
+    uint32_t n_ev;        // LANEQ: this lane's events so far
 };
 
 __device__ __forceinline__ void tiles_flush(TileQueue &Q, uint32_t lane) {
@@ -99,40 +110,73 @@ __device__ __forceinline__ void tiles_flush(TileQueue &Q, uint32_t lane) {
 }
 
 // One exact transition of a lane: the LDS tile's row when the state has one, else the global table / the compact records.
-// ALLHOT: every state has its row in the tile -- no test, no cold path compiled in.
+// ALLHOT (every state has its row in the tile: small automata): no test, no cold path compiled in, and a state is held as the
+// BYTE OFFSET of its row -- the tile's entries are stored that way (hot_stage) -- so that a step is one add and one read.
 template <typename E, bool ALLHOT>
 __device__ __forceinline__ uint32_t tiles_step(const DevAutomaton &A, const uint8_t *tile, uint32_t tile_rows, uint32_t st, uint32_t byte,
                                                uint32_t coff) {
-    if constexpr (ALLHOT) return *reinterpret_cast<const E *>(tile + __umul24(st, A.row_bytes) + coff);
+    if constexpr (ALLHOT) return *reinterpret_cast<const E *>(tile + st + coff);
     uint32_t w = A.trap;
     if (st < tile_rows) w = *reinterpret_cast<const E *>(tile + __umul24(st, A.row_bytes) + coff);
     if (w >= A.trap) w = cold_step<E>(A, st, byte, coff);
     return w;
 }
 
-template <bool ALLHOT>
-__device__ __forceinline__ bool tiles_final(const DevAutomaton &A, uint32_t s) {
-    if constexpr (ALLHOT) return s >= A.f1;   // (no cold states, and the trap row is never entered)
+// What the walk needs besides the automaton: where the tile's data lies in LDS
+struct TileLds {
+    const uint16_t *cls;      // byte classes (TABLE mode), else null
+    const uint8_t *tile;
+    uint32_t rows;            // rows of the tile
+    uint32_t stride;          // ALLHOT: bytes from row to row = row_bytes + 2 x sizeof(E): {record count, state id} behind the transitions
+    uint32_t final_from;      // ALLHOT: f1 x stride -- a state (row offset) is final from here on
+    const uint32_t *cnt;      // !ALLHOT: record counts of the tile's rows
+    const uint2 *out1;        // ALLHOT, when there is room: the first {pattern, length} of every state's output list, else null
+};
+
+template <typename E, bool ALLHOT>
+__device__ __forceinline__ bool tiles_final(const DevAutomaton &A, const TileLds &L, uint32_t s) {
+    if constexpr (ALLHOT) return s >= L.final_from;   // (no cold states, and the trap row is never entered)
     return is_final(A, s);
+}
+
+// {state id, record count} of a final state the walk is in
+template <typename E, bool ALLHOT>
+__device__ __forceinline__ uint2 tiles_meta(const DevAutomaton &A, const TileLds &L, uint32_t s) {
+    if constexpr (ALLHOT) {
+        const E *m = reinterpret_cast<const E *>(L.tile + s + A.row_bytes);
+        return make_uint2(uint32_t(m[1]), uint32_t(m[0]));
+    }
+    return make_uint2(s, s < L.rows ? L.cnt[s] : A.out_count[s]);
 }
 
 // The walk of one piece, counting: events go to the wave's queue, n_rec sums the records they stand for.  All 64 lanes of
 // the wave call this together and run the same number of steps (a lane past its own bytes walks on without reporting).
-template <typename E, int MODE, bool ALLHOT>
-__device__ __forceinline__ void tiles_walk(const DevAutomaton &A, const Piece &pc, const uint16_t *cls_lds, const uint8_t *tile,
-                                           uint32_t tile_rows, const uint32_t *cnt_lds, uint32_t cnt_rows, TileQueue &Q, uint32_t lane,
+// LANEQ (small automata, whose tile leaves the LDS free): events go to a list of the LANE's own -- a shift, an or, a store -- and
+// are counted and expanded by the lane afterwards.  With the wave-shared queue an event costs ~ 13 operations (ballot, rank,
+// record count, packing, ring address) which the whole wave issues at every step in which ANY of its lanes has one: at a match
+// per 15 bytes that is 99 % of the steps, and it was more than half of the kernel's instructions.
+template <typename E, int MODE, bool ALLHOT, bool LANEQ>
+__device__ __forceinline__ void tiles_walk(const DevAutomaton &A, const Piece &pc, const TileLds &L, TileQueue &Q, uint32_t lane,
                                            uint32_t &n_rec, bool events) {
     uint32_t st = 0;
-    auto event = [&](uint32_t jj) __attribute__((always_inline)) {
-        const bool ev = jj - pc.rep_lo < pc.rep_len && tiles_final<ALLHOT>(A, st);
-        // the lanes that have an event at this step: the ballot is taken by ALL lanes, so that the queue index stays wave-uniform
+    // `inside`: the byte reports (it lies in the lane's own range); the lanes that have an event at this step: the ballot is
+    // taken by ALL lanes, so that the queue index stays wave-uniform
+    auto event = [&](uint32_t jj, bool inside) __attribute__((always_inline)) {
+        const bool ev = inside && tiles_final<E, ALLHOT>(A, L, st);
+        if constexpr (LANEQ) {
+            if (ev) {
+                if (Q.n_ev < kTilesLaneCap) Q.lists[Q.n_ev * 64u + lane] = st | jj << 16;
+                ++Q.n_ev;
+            }
+            return;
+        }
         const uint64_t m = __ballot(ev);
         if (m) {
             if (ev) {
-                const uint32_t c = (ALLHOT || st < cnt_rows) ? cnt_lds[st] : A.out_count[st];
+                const uint2 meta = tiles_meta<E, ALLHOT>(A, L, st);
                 const uint32_t my = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
-                if (events) Q.ring[(Q.total + my) & (kTilesRing - 1u)] = make_uint2(st | lane << 24, jj | n_rec << 9);
-                n_rec += c;
+                if (events) Q.ring[(Q.total + my) & (kTilesRing - 1u)] = make_uint2(meta.x | lane << 24, jj | n_rec << 9);
+                n_rec += meta.y;
             }
             Q.total += uint32_t(__builtin_popcountll(m));
             if (Q.total - Q.flushed >= 64u) tiles_flush(Q, lane);
@@ -154,12 +198,13 @@ __device__ __forceinline__ void tiles_walk(const DevAutomaton &A, const Piece &p
     for (uint32_t jj = jmin; jj < 16u; ++jj) {
         const uint32_t wd = jj < 8u ? (jj < 4u ? first.x : first.y) : (jj < 12u ? first.z : first.w);
         const uint32_t byte = (wd >> (8u * (jj & 3u))) & 0xffu;
-        const uint32_t w = tiles_step<E, ALLHOT>(A, tile, tile_rows, st, byte, class_offset<E, MODE>(A, cls_lds, byte));
+        const uint32_t w = tiles_step<E, ALLHOT>(A, L.tile, L.rows, st, byte, class_offset<E, MODE>(A, L.cls, byte));
         st = jj < pc.start_j ? 0u : w;
-        event(jj);
+        event(jj, jj - pc.rep_lo < pc.rep_len);
     }
     // the blocks behind it: sixteen unrolled steps per block, the buffers rotating; the column offsets of a dword's four bytes
-    // are worked out together (SWAR3: a handful of operations for all four; TABLE: four independent LDS reads)
+    // are worked out together (SWAR3: a handful of operations for all four; TABLE: four independent LDS reads).  A block that
+    // lies inside EVERY lane's own range -- all but the first and the last of a piece -- takes the body without the range test.
 #pragma unroll 1
     for (uint32_t k = 1u; k < blocks; ++k) {
         const uint4 cur = b0;
@@ -167,44 +212,78 @@ __device__ __forceinline__ void tiles_walk(const DevAutomaton &A, const Piece &p
         const uint32_t kn = k + 4u;
         if (kn < blocks) b3 = q[kn < last ? kn : last];
         const uint32_t j0 = k * 16u;
-        auto dword = [&](uint32_t wd, uint32_t jj) __attribute__((always_inline)) {
+        auto dword = [&](uint32_t wd, uint32_t jj, auto checked) __attribute__((always_inline)) {
             uint32_t c0, c1, c2, c3;
             if constexpr (MODE == 1) {
                 const uint32_t c4 = swar_columns<E>(A, wd);
                 c0 = c4 & 0xffu; c1 = (c4 >> 8) & 0xffu; c2 = (c4 >> 16) & 0xffu; c3 = c4 >> 24;
             } else {
-                c0 = class_offset<E, MODE>(A, cls_lds, wd & 0xffu); c1 = class_offset<E, MODE>(A, cls_lds, (wd >> 8) & 0xffu);
-                c2 = class_offset<E, MODE>(A, cls_lds, (wd >> 16) & 0xffu); c3 = class_offset<E, MODE>(A, cls_lds, wd >> 24);
+                c0 = class_offset<E, MODE>(A, L.cls, wd & 0xffu); c1 = class_offset<E, MODE>(A, L.cls, (wd >> 8) & 0xffu);
+                c2 = class_offset<E, MODE>(A, L.cls, (wd >> 16) & 0xffu); c3 = class_offset<E, MODE>(A, L.cls, wd >> 24);
             }
-            st = tiles_step<E, ALLHOT>(A, tile, tile_rows, st, wd & 0xffu, c0); event(jj);
-            st = tiles_step<E, ALLHOT>(A, tile, tile_rows, st, (wd >> 8) & 0xffu, c1); event(jj + 1u);
-            st = tiles_step<E, ALLHOT>(A, tile, tile_rows, st, (wd >> 16) & 0xffu, c2); event(jj + 2u);
-            st = tiles_step<E, ALLHOT>(A, tile, tile_rows, st, wd >> 24, c3); event(jj + 3u);
+            constexpr bool C = decltype(checked)::value;
+            st = tiles_step<E, ALLHOT>(A, L.tile, L.rows, st, wd & 0xffu, c0); event(jj, !C || jj - pc.rep_lo < pc.rep_len);
+            st = tiles_step<E, ALLHOT>(A, L.tile, L.rows, st, (wd >> 8) & 0xffu, c1); event(jj + 1u, !C || jj + 1u - pc.rep_lo < pc.rep_len);
+            st = tiles_step<E, ALLHOT>(A, L.tile, L.rows, st, (wd >> 16) & 0xffu, c2); event(jj + 2u, !C || jj + 2u - pc.rep_lo < pc.rep_len);
+            st = tiles_step<E, ALLHOT>(A, L.tile, L.rows, st, wd >> 24, c3); event(jj + 3u, !C || jj + 3u - pc.rep_lo < pc.rep_len);
         };
-        dword(cur.x, j0); dword(cur.y, j0 + 4u); dword(cur.z, j0 + 8u); dword(cur.w, j0 + 12u);
+        const bool full = j0 >= pc.rep_lo && j0 + 16u <= pc.rep_lo + pc.rep_len;
+        if (__all(full)) {
+            dword(cur.x, j0, std::false_type{}); dword(cur.y, j0 + 4u, std::false_type{}); dword(cur.z, j0 + 8u, std::false_type{}); dword(cur.w, j0 + 12u, std::false_type{});
+        } else {
+            dword(cur.x, j0, std::true_type{}); dword(cur.y, j0 + 4u, std::true_type{}); dword(cur.z, j0 + 8u, std::true_type{}); dword(cur.w, j0 + 12u, std::true_type{});
+        }
     }
+}
+
+// The records of a piece, counted by a plain walk (LANEQ: a lane of the wave had more events than its list holds).
+template <typename E, int MODE, bool ALLHOT>
+__device__ __forceinline__ uint32_t tiles_count(const DevAutomaton &A, const Piece &pc, const TileLds &L) {
+    uint32_t st = 0, n = 0;
+    const uint32_t end = pc.rep_lo + pc.rep_len;
+#pragma unroll 1
+    for (uint32_t jj = pc.start_j; jj < end; ++jj) {
+        const uint32_t byte = load8g(pc.pb + jj);
+        st = tiles_step<E, ALLHOT>(A, L.tile, L.rows, st, byte, class_offset<E, MODE>(A, L.cls, byte));
+        if (jj >= pc.rep_lo && tiles_final<E, ALLHOT>(A, L, st)) n += tiles_meta<E, ALLHOT>(A, L, st).y;
+    }
+    return n;
 }
 
 // The same walk writing records in place: for the waves whose events did not fit their queue (dense output, rare, and bound by
 // its stores): every lane on its own, bytes straight from memory (the lines are in L2: the wave has just read them).
 template <typename E, int MODE, bool ALLHOT>
-__device__ __forceinline__ void tiles_emit(const DevAutomaton &A, const Piece &pc, const uint16_t *cls_lds, const uint8_t *tile,
-                                           uint32_t tile_rows, uint4 *out, uint64_t wr) {
-    uint32_t st = 0;
+__device__ __forceinline__ void tiles_emit(const DevAutomaton &A, const Piece &pc, const TileLds &L, const uint4 *m_records, uint4 *out, uint64_t wr) {
+    uint32_t st = 0, i0 = 0;
+    uint32_t next0 = pc.m_count ? m_records[pc.m_first].y : 0xFFFFFFFFu;   // position of the other part's next record
     const uint32_t end = pc.rep_lo + pc.rep_len;
 #pragma unroll 1
     for (uint32_t jj = pc.start_j; jj < end; ++jj) {
         const uint32_t byte = load8g(pc.pb + jj);
-        st = tiles_step<E, ALLHOT>(A, tile, tile_rows, st, byte, class_offset<E, MODE>(A, cls_lds, byte));
-        if (jj >= pc.rep_lo && tiles_final<ALLHOT>(A, st)) wr = emit_event(A, out, wr, pc.hay, pc.pos_bias + jj, st);
+        st = tiles_step<E, ALLHOT>(A, L.tile, L.rows, st, byte, class_offset<E, MODE>(A, L.cls, byte));
+        if (jj < pc.rep_lo) continue;
+        while (next0 <= pc.pos_bias + jj) {   // (the other part's patterns are the longer ones: first at equal positions)
+            out[wr++] = m_records[pc.m_first + i0];
+            ++i0;
+            next0 = i0 < pc.m_count ? m_records[pc.m_first + i0].y : 0xFFFFFFFFu;
+        }
+        if (tiles_final<E, ALLHOT>(A, L, st)) wr = emit_event(A, out, wr, pc.hay, pc.pos_bias + jj, tiles_meta<E, ALLHOT>(A, L, st).x);
     }
 }
 
-// An event's records, longest pattern first, at `dst`.
-__device__ __forceinline__ void tiles_expand(const DevAutomaton &A, uint4 *dst, uint32_t hay, uint32_t pos, uint32_t s, uint32_t c) {
+// An event's records, longest pattern first, at `dst`.  The first entry of a small automaton's lists is in LDS (out1): most
+// events stand for one record, and the two dependent loads per event were most of the expansion.
+__device__ __forceinline__ void tiles_expand(const DevAutomaton &A, const TileLds &L, uint4 *dst, uint32_t hay, uint32_t pos, uint32_t s, uint32_t c) {
     if (A.out_list != nullptr) {
+        uint32_t k = 0;
+        if (L.out1 != nullptr) {
+            const uint2 o = L.out1[s];
+            dst[0] = make_uint4(hay, pos, pos - o.y, o.x);
+            if (c == 1u) return;
+            k = 1;
+        }
         const uint2 *ol = A.out_list + A.out_off[s];
-        for (uint32_t k = 0; k < c; ++k) {
+        for (; k < c; ++k) {
             const uint2 o = ol[k];
             dst[k] = make_uint4(hay, pos, pos - o.y, o.x);
         }
@@ -216,7 +295,7 @@ __device__ __forceinline__ void tiles_expand(const DevAutomaton &A, uint4 *dst, 
 // Two workgroups per CU (64 registers, 8 waves per SIMD): what hides the round trips of rows that are not in LDS is the number
 // of waves, not the size of the tile -- one workgroup with the whole LDS for its tile (twice the rows, 80-odd registers, no
 // spills) measured 8-12 % slower on a word list and on the headline set with 64 plants per haystack.
-template <typename E, int MODE, bool ALLHOT>
+template <typename E, int MODE, bool ALLHOT, bool LANEQ>
 __global__ __launch_bounds__(kTilesThreads, 8) void k_walk_tiles(DevAutomaton A, BatchArgs B, TileArgs T) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ uint32_t s_tile, s_walked;
@@ -224,27 +303,52 @@ __global__ __launch_bounds__(kTilesThreads, 8) void k_walk_tiles(DevAutomaton A,
     __shared__ uint64_t s_wave_tot[kTilesWaves];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint64_t total_items = B.item_base[B.n_haystacks];
-    // LDS: [the waves' event rings] [512 B byte classes (TABLE mode)] [tile rows] [their record counts]
-    const uint32_t ring_bytes = kTilesWaves * kTilesRing * 8u;
+    // LDS: [the waves' event rings] [512 B byte classes (TABLE mode)] [tile rows] [record counts | first output entries]
+    const uint32_t ring_bytes = LANEQ ? kTilesWaves * kTilesLaneCap * 256u : kTilesWaves * kTilesRing * 8u;
     const uint32_t cls_bytes = (MODE == 0) ? 512u : 0u;
-    const uint32_t tile_rows = A.row_bytes ? (T.tile_bytes / (A.row_bytes + 4u) < A.trap ? T.tile_bytes / (A.row_bytes + 4u) : A.trap) : 0u;
-    const uint16_t *cls_lds = (MODE == 0) ? reinterpret_cast<const uint16_t *>(smem + ring_bytes) : nullptr;
-    const uint8_t *tile = smem + ring_bytes + cls_bytes;
-    const uint32_t tile_bytes = (tile_rows * A.row_bytes + 15u) & ~15u;
-    const uint32_t cnt_rows = tile_rows;
-    const uint32_t *cnt_lds = reinterpret_cast<const uint32_t *>(tile + tile_bytes);
-    {
-        if (MODE == 0 && threadIdx.x < 256) reinterpret_cast<uint16_t *>(smem + ring_bytes)[threadIdx.x] = A.class_off[threadIdx.x];
-        const uint4 *tsrc = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(A.lds_image) + A.tile_offset);
+    TileLds L;
+    L.cls = (MODE == 0) ? reinterpret_cast<const uint16_t *>(smem + ring_bytes) : nullptr;
+    L.tile = smem + ring_bytes + cls_bytes;
+    L.out1 = nullptr;
+    L.cnt = nullptr;
+    if (MODE == 0 && threadIdx.x < 256) reinterpret_cast<uint16_t *>(smem + ring_bytes)[threadIdx.x] = A.class_off[threadIdx.x];
+    const uint8_t *src = static_cast<const uint8_t *>(A.lds_image) + A.tile_offset;
+    if constexpr (ALLHOT) {
+        // every state: its transitions as ROW OFFSETS, then {record count, state id}
+        L.rows = A.trap;
+        L.stride = A.row_bytes + 2u * uint32_t(sizeof(E));
+        L.final_from = A.f1 * L.stride;
+        const uint32_t per_row = A.n_columns + 2u;
+        uint8_t *dst = smem + ring_bytes + cls_bytes;
+        for (uint32_t t = threadIdx.x; t < L.rows * per_row; t += kTilesThreads) {
+            const uint32_t row = t / per_row, c = t - row * per_row;
+            uint32_t v;
+            if (c < A.n_columns) v = uint32_t(reinterpret_cast<const E *>(src + row * A.row_bytes)[c]) * L.stride;
+            else v = c == A.n_columns ? A.out_count[row] : row;
+            reinterpret_cast<E *>(dst + row * L.stride)[c] = E(v);
+        }
+        const uint32_t used = (L.rows * L.stride + 7u) & ~7u;
+        if (A.out_list != nullptr && used + L.rows * 8u <= T.tile_bytes) {
+            uint2 *o1 = reinterpret_cast<uint2 *>(dst + used);
+            for (uint32_t t = threadIdx.x; t < L.rows; t += kTilesThreads) o1[t] = A.out_count[t] ? A.out_list[A.out_off[t]] : make_uint2(0u, 0u);
+            L.out1 = o1;
+        }
+    } else {
+        L.rows = A.row_bytes ? (T.tile_bytes / (A.row_bytes + 4u) < A.trap ? T.tile_bytes / (A.row_bytes + 4u) : A.trap) : 0u;
+        L.stride = A.row_bytes;
+        L.final_from = 0;
+        const uint32_t tile_bytes = (L.rows * A.row_bytes + 15u) & ~15u;
         uint4 *tdst = reinterpret_cast<uint4 *>(smem + ring_bytes + cls_bytes);
-        const uint32_t n16 = tile_bytes >> 4;
-        for (uint32_t t = threadIdx.x; t < n16; t += kTilesThreads) tdst[t] = tsrc[t];
+        const uint4 *tsrc = reinterpret_cast<const uint4 *>(src);
+        for (uint32_t t = threadIdx.x; t < (tile_bytes >> 4); t += kTilesThreads) tdst[t] = tsrc[t];
         uint32_t *cdst = reinterpret_cast<uint32_t *>(smem + ring_bytes + cls_bytes + tile_bytes);
-        for (uint32_t t = threadIdx.x; t < cnt_rows; t += kTilesThreads) cdst[t] = A.out_count[t];
+        for (uint32_t t = threadIdx.x; t < L.rows; t += kTilesThreads) cdst[t] = A.out_count[t];
+        L.cnt = cdst;
     }
     if (threadIdx.x == 0) s_walked = 0;
     TileQueue Q;
     Q.ring = reinterpret_cast<uint2 *>(smem) + wave * kTilesRing;
+    Q.lists = reinterpret_cast<uint32_t *>(smem) + wave * kTilesLaneCap * 64u;
     Q.spill = T.queue + (uint64_t(blockIdx.x) * kTilesWaves + wave) * T.qcap;
     Q.qcap = T.qcap;
     const uint32_t r = lane / T.P, qi = lane - r * T.P;   // item of the wave, piece of the item
@@ -266,6 +370,8 @@ __global__ __launch_bounds__(kTilesThreads, 8) void k_walk_tiles(DevAutomaton A,
         pc.pb = A.pad16;
         pc.nblk = 0;
         pc.start_j = pc.rep_lo = pc.rep_len = pc.pos_bias = pc.hay = 0;
+        pc.m_first = 0;
+        pc.m_count = 0;
         if (have) {
             const uint4 rec = B.item_rec[item];
             ItemDesc it;
@@ -295,18 +401,50 @@ __global__ __launch_bounds__(kTilesThreads, 8) void k_walk_tiles(DevAutomaton A,
                 pc.nblk = (pc.rep_lo + pc.rep_len + 15u) >> 4;
                 pc.pos_bias = uint32_t(xb) - d0 + it.pos0 + 1u;
                 walked16 += pc.nblk;
+                if constexpr (LANEQ) {
+                    if (T.m_prefix != nullptr) {
+                        // the other part's records that END inside this piece: positions [p_lo, p_hi] of this haystack
+                        const uint64_t s0 = T.m_prefix[pc.hay], s1 = T.m_prefix[pc.hay + 1u];
+                        const uint32_t p_lo = pc.pos_bias + pc.rep_lo, p_hi = p_lo + pc.rep_len - 1u;
+                        uint64_t a = s0, b = s1;
+                        while (a < b) { const uint64_t mid = (a + b) >> 1; if (T.m_records[mid].y < p_lo) a = mid + 1; else b = mid; }
+                        pc.m_first = a;
+                        b = s1;
+                        while (a < b) { const uint64_t mid = (a + b) >> 1; if (T.m_records[mid].y <= p_hi) a = mid + 1; else b = mid; }
+                        pc.m_count = uint32_t(a - pc.m_first);
+                    }
+                }
             }
         }
         uint32_t n_rec = 0;
-        Q.total = Q.flushed = 0;
-        tiles_walk<E, MODE, ALLHOT>(A, pc, cls_lds, tile, tile_rows, cnt_lds, cnt_rows, Q, lane, n_rec, (T.flags & 2u) == 0u);
+        Q.total = Q.flushed = Q.n_ev = 0;
+        tiles_walk<E, MODE, ALLHOT, LANEQ>(A, pc, L, Q, lane, n_rec, (T.flags & 2u) == 0u);
+        bool lane_over = false;   // LANEQ: some lane of the wave had more events than its list holds
+        uint32_t ev_max = 0;
+        if constexpr (LANEQ) {
+            ev_max = tile_wave_max(Q.n_ev);
+            lane_over = ev_max > kTilesLaneCap;
+            if (!lane_over) {
+#pragma unroll 1
+                for (uint32_t e = 0; e < ev_max; ++e)
+                    if (e < Q.n_ev) n_rec += tiles_meta<E, ALLHOT>(A, L, Q.lists[e * 64u + lane] & 0xffffu).y;
+            } else if (pc.nblk) {
+                n_rec = tiles_count<E, MODE, ALLHOT>(A, pc, L);
+            }
+        }
+        // (merging: the running sum places the other part's records too; the item totals k_expand turns into this part's own
+        // per-haystack prefix stay this part's)
+        const uint32_t own_rec = n_rec;
+        n_rec += pc.m_count;
         // records: exclusive prefix over the wave's lanes, the items' totals, the wave's total
         const uint32_t incl = wave_inclusive_sum(n_rec);
         const uint32_t excl = incl - n_rec;
         const uint32_t wave_tot = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
         {
             const uint32_t last_lane = r * T.P + T.P - 1u;
-            const uint32_t item_tot = uint32_t(__shfl(int(incl), int(last_lane < 64u ? last_lane : 63u), 64)) - uint32_t(__shfl(int(excl), int(r * T.P < 64u ? r * T.P : 63u), 64));
+            uint32_t i_incl = incl, i_excl = excl;
+            if (LANEQ && T.m_prefix != nullptr) { i_incl = wave_inclusive_sum(own_rec); i_excl = i_incl - own_rec; }
+            const uint32_t item_tot = uint32_t(__shfl(int(i_incl), int(last_lane < 64u ? last_lane : 63u), 64)) - uint32_t(__shfl(int(i_excl), int(r * T.P < 64u ? r * T.P : 63u), 64));
             if (have && qi == 0u && item_tot) B.rec_count[item] = item_tot;
         }
         if (lane == 0) s_wave_tot[wave] = wave_tot;
@@ -325,6 +463,32 @@ __global__ __launch_bounds__(kTilesThreads, 8) void k_walk_tiles(DevAutomaton A,
         __syncthreads();
         const uint64_t base = s_before + wave_base;
         if (wave_tot == 0u || base + wave_tot > T.cap || (T.flags & 1u)) continue;   // (too small a buffer: the host grows it and runs the batch again)
+        if constexpr (LANEQ) {
+            if (!lane_over) {
+                // every lane its own events, in the order it met them: its records are one contiguous piece of the output
+                uint4 *dst = T.out + base + excl;
+                uint32_t i0 = 0;
+                uint32_t next0 = pc.m_count ? T.m_records[pc.m_first].y : 0xFFFFFFFFu;   // position of the other part's next record
+#pragma unroll 1
+                for (uint32_t e = 0; e < ev_max; ++e) {
+                    if (e >= Q.n_ev) continue;
+                    const uint32_t ent = Q.lists[e * 64u + lane];
+                    const uint2 meta = tiles_meta<E, ALLHOT>(A, L, ent & 0xffffu);
+                    const uint32_t pos = pc.pos_bias + (ent >> 16);
+                    while (next0 <= pos) {   // (rare: the other part's patterns are the long ones)
+                        *dst++ = T.m_records[pc.m_first + i0];
+                        ++i0;
+                        next0 = i0 < pc.m_count ? T.m_records[pc.m_first + i0].y : 0xFFFFFFFFu;
+                    }
+                    tiles_expand(A, L, dst, pc.hay, pos, meta.x, meta.y);
+                    dst += meta.y;
+                }
+                for (; i0 < pc.m_count; ++i0) *dst++ = T.m_records[pc.m_first + i0];
+            } else if (pc.nblk) {
+                tiles_emit<E, MODE, ALLHOT>(A, pc, L, T.m_records, T.out, base + excl);
+            }
+            continue;
+        }
         if (Q.total <= Q.qcap) {
             // every lane expands events, 64 per round whatever their distribution over the pieces: an event's slot = the records
             // of the lanes before its owner + its own offset.  Rounds [0, flushed) come from the wave's queue in memory (written by
@@ -347,11 +511,16 @@ __global__ __launch_bounds__(kTilesThreads, 8) void k_walk_tiles(DevAutomaton A,
                 const uint32_t slot = uint32_t(__shfl(int(excl), int(owner), 64)) + (ent.y >> 9);
                 const uint32_t pos = uint32_t(__shfl(int(pc.pos_bias), int(owner), 64)) + (ent.y & 511u);
                 const uint32_t hay = uint32_t(__shfl(int(pc.hay), int(owner), 64));
-                if (valid) tiles_expand(A, T.out + base + slot, hay, pos, s, (ALLHOT || s < cnt_rows) ? cnt_lds[s] : A.out_count[s]);
+                if (valid) {
+                    uint32_t c;
+                    if constexpr (ALLHOT) c = uint32_t(reinterpret_cast<const E *>(L.tile + s * L.stride + A.row_bytes)[0]);
+                    else c = s < L.rows ? L.cnt[s] : A.out_count[s];
+                    tiles_expand(A, L, T.out + base + slot, hay, pos, s, c);
+                }
             }
         } else if (pc.nblk) {
             // more events than the queue holds (dense output): every lane walks its piece again and writes its records in place
-            tiles_emit<E, MODE, ALLHOT>(A, pc, cls_lds, tile, tile_rows, T.out, base + excl);
+            tiles_emit<E, MODE, ALLHOT>(A, pc, L, nullptr, T.out, base + excl);
         }
     }
     // statistic: 16-byte blocks walked (what the automatic kernel choice reads), summed per workgroup
@@ -387,8 +556,17 @@ uint32_t tiles_grid() { return 2u * uint32_t(num_cus()); }
 uint64_t tiles_queue_entries(uint32_t W) { return uint64_t(tiles_grid()) * kTilesWaves * (64u * W / 4u); }
 uint64_t tiles_status_words(uint64_t max_items, uint32_t P) { return max_items / (uint64_t(kTilesWaves) * (64u / P)) + 2u; }
 
+// Can this automaton's walk merge another part's match arrays as it writes (the lane-list variant)?
+bool tiles_can_merge(const DevAutomaton &A, int entry_bytes) {
+    const uint32_t share = 79u * 1024u - 768u, ring_l = kTilesWaves * kTilesLaneCap * 256u;
+    const uint64_t hot_stride = uint64_t(A.row_bytes) + 2u * uint32_t(entry_bytes);
+    return A.trap + 1u == A.n_states && A.row_bytes && A.max_out_count < 65536u && uint64_t(A.trap + 1u) * hot_stride < 65536u &&
+           uint64_t(A.trap) * hot_stride + 8u <= share - ring_l;
+}
+
 hipError_t launch_walk_tiles(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode, uint32_t W, uint32_t P,
-                             void *queue, uint32_t *ticket, uint64_t *status, void *out, uint64_t cap, hipStream_t st) {
+                             void *queue, uint32_t *ticket, uint64_t *status, void *out, uint64_t cap, hipStream_t st,
+                             const uint64_t *merge_prefix, const void *merge_records) {
     if (max_items == 0) return hipSuccess;
     TileArgs T{};
     T.W = W;
@@ -396,7 +574,6 @@ hipError_t launch_walk_tiles(const DevAutomaton &A, const BatchArgs &B, uint64_t
     T.R = 64u / P;
     T.back = A.max_pattern_length ? A.max_pattern_length - 1u : 0u;
     T.qcap = 64u * W / 4u;
-    const uint32_t ring_bytes = kTilesWaves * kTilesRing * 8u;
     static const uint32_t debug_flags = [] { const char *e = std::getenv("ACMI_TILES_DEBUG"); return e ? uint32_t(std::atoi(e)) : 0u; }();
     T.flags = debug_flags;
     T.queue = static_cast<uint2 *>(queue);
@@ -404,10 +581,22 @@ hipError_t launch_walk_tiles(const DevAutomaton &A, const BatchArgs &B, uint64_t
     T.status = status;
     T.out = static_cast<uint4 *>(out);
     T.cap = cap;
-    T.tile_bytes = 79u * 1024u - ring_bytes - 768u;   // two workgroups per CU share the 160 KiB
+    T.m_prefix = merge_prefix;
+    T.m_records = static_cast<const uint4 *>(merge_records);
+    // Two workgroups per CU share the 160 KiB.  Every state's row in the tile (small automata): the variant without the cold
+    // path, states held as row offsets (which must fit the table's entry type); and when the tile is small enough to leave 64 KiB
+    // of a workgroup's LDS free, the lanes keep their events in lists of their own there (LANEQ)
+    const uint32_t share = 79u * 1024u - 768u;
+    const uint64_t hot_stride = uint64_t(A.row_bytes) + 2u * uint32_t(entry_bytes);
+    const uint64_t hot_bytes = uint64_t(A.trap) * hot_stride + 8u;
+    const uint32_t ring_q = kTilesWaves * kTilesRing * 8u, ring_l = kTilesWaves * kTilesLaneCap * 256u;
+    const bool hot_ok = A.trap + 1u == A.n_states && A.row_bytes && (entry_bytes == 4 || uint64_t(A.trap + 1u) * hot_stride < 65536u) && A.max_out_count < 65536u;
+    const bool laneq = hot_ok && hot_bytes <= share - ring_l && uint64_t(A.trap + 1u) * hot_stride < 65536u && (!(debug_flags & 16u) || merge_prefix);
+    if (merge_prefix && !laneq) return hipErrorInvalidValue;   // (the caller asks tiles_can_merge first)
+    const bool allhot = laneq || (hot_ok && hot_bytes <= share - ring_q);
+    const uint32_t ring_bytes = laneq ? ring_l : ring_q;
+    T.tile_bytes = share - ring_bytes;
     const uint32_t lds = ring_bytes + T.tile_bytes + 16u + (class_mode == 0 ? 512u : 0u);
-    // every state's row in the tile (small automata): the variant without the cold path
-    const bool allhot = A.trap + 1u == A.n_states && A.row_bytes && uint64_t(A.trap) * (A.row_bytes + 4u) <= T.tile_bytes;
     const uint64_t groups = (max_items + uint64_t(kTilesWaves) * T.R - 1u) / (uint64_t(kTilesWaves) * T.R);
     const uint32_t blocks = uint32_t(std::min<uint64_t>(groups, tiles_grid()));
     auto go = [&](auto fn) {
@@ -416,7 +605,7 @@ hipError_t launch_walk_tiles(const DevAutomaton &A, const BatchArgs &B, uint64_t
         hipLaunchKernelGGL(fn, dim3(blocks), dim3(kTilesThreads), lds, st, A, B, T);
         return hipGetLastError();
     };
-#define ACMI_TILES(E, M) (allhot ? go(k_walk_tiles<E, M, true>) : go(k_walk_tiles<E, M, false>))
+#define ACMI_TILES(E, M) (laneq ? go(k_walk_tiles<E, M, true, true>) : allhot ? go(k_walk_tiles<E, M, true, false>) : go(k_walk_tiles<E, M, false, false>))
     if (entry_bytes == 2) return class_mode == 1 ? ACMI_TILES(uint16_t, 1) : ACMI_TILES(uint16_t, 0);
     return class_mode == 1 ? ACMI_TILES(uint32_t, 1) : ACMI_TILES(uint32_t, 0);
 #undef ACMI_TILES

@@ -25,8 +25,11 @@ hipError_t launch_walk_items(const DevAutomaton &A, const BatchArgs &B, uint64_t
 bool tiles_geometry(uint32_t max_pattern_length, uint32_t n_states, uint64_t blob_bytes, uint64_t n_haystacks, uint32_t *W, uint32_t *P);
 uint64_t tiles_queue_entries(uint32_t W);                       // 8-byte entries of the waves' event queues
 uint64_t tiles_status_words(uint64_t max_items, uint32_t P);    // 8-byte look-back words (zeroed, behind an 8-byte ticket)
+// merge_prefix / merge_records (tiles_can_merge only): the match arrays of the other part of a split set, merged into `out`
 hipError_t launch_walk_tiles(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode, uint32_t W, uint32_t P,
-                             void *queue, uint32_t *ticket, uint64_t *status, void *out, uint64_t cap, hipStream_t st);
+                             void *queue, uint32_t *ticket, uint64_t *status, void *out, uint64_t cap, hipStream_t st,
+                             const uint64_t *merge_prefix = nullptr, const void *merge_records = nullptr);
+bool tiles_can_merge(const DevAutomaton &A, int entry_bytes);
 void launch_first_only(const BatchArgs &B, uint32_t *first_item, uint64_t max_items, hipStream_t st);
 // scan = true: also the exclusive scan of the per-item record counts (ticket / status: zeroed sync words); false: rec_base is read
 void launch_expand(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, uint64_t *rec_base, void *out,

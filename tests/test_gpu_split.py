@@ -42,7 +42,9 @@ def test_split_set_goldens(name, path, targeted):
 
 @pytest.mark.parametrize("name", ["X1", "X2"])
 @pytest.mark.parametrize("options", [dict(split=0), dict(split=1, chunk_bytes=256), dict(split=1, slab_events=1, run_cap=1), dict(split=-1, verify=0),
-                                     dict(split=1, tiny_rows=0, short_rows=0), dict(kernel=1), dict(kernel=4)])
+                                     dict(split=1, tiny_rows=0, short_rows=0), dict(kernel=1), dict(kernel=4),
+                                     # the short part through the tile walk, which merges the long part's records as it writes its own
+                                     dict(split=1, part_kernel=6), dict(split=1, part_kernel=6, tile_w=16, tile_p=5), dict(split=1, part_kernel=4)])
 def test_split_set_options(name, options, targeted):
     """Not split (one automaton, the table walk), split with chunked items / overflowing slabs and run lists / walked candidates,
     and a forced kernel (which keeps the set whole): the same records."""
@@ -92,3 +94,38 @@ def test_split_set_two_batches_in_flight_and_replace():
     got = api.ahocorasick_match(ds.haystack(2), res)
     assert [(g["pos"], g["start_postion"]) for g in got] == [(int(r[1]), int(r[2])) for r in want[want[:, 0] == 2]]
     api.ahocorasick_deinit(res)
+
+
+def test_merged_output_of_a_split_set_at_mid_density():
+    """The headline set + short patterns over the text's own alphabet (~ 540 records per 8 KiB): the short part's tile walk writes
+    the merged array -- the long part's records placed among its own -- in one pass; first call (the buffers grow: the part runs
+    again), steady state, two batches in flight, and the automatic choice finding this path by itself."""
+    import torch
+    from php_aho_corasick_amd import batch
+    base = synth.bench_batch(256, 8192, seed=1, planted=True)
+    sp = synth.generate("short", 41, 8, 2, 6, 1, 16, b"abcdef")
+    pb, po = synth.pack(base.patterns() + sp.patterns())
+    ds = synth.Dataset("XM", pb, po, base.hay_blob, base.hay_off)
+    o = Oracle("port")
+    o.add_patterns((ds.pat_blob, ds.pat_off))
+    pe, re_ = o.match_batch(ds.hay_blob, ds.hay_off, True)
+    assert len(re_) > 100 * ds.n_haystacks
+    for options in (dict(part_kernel=6), {}):
+        res = resource_for(ds, **options)
+        for _ in range(8 if not options else 3):
+            p, r = device_match(res, ds)
+            assert np.array_equal(p, pe) and np.array_equal(r, re_)
+        assert res.stat("split") == 1 and res.stat("merged_batches") >= 1, options
+        d_blob, d_off = torch.from_numpy(ds.hay_blob).cuda(), torch.from_numpy(ds.hay_off.astype(np.int64)).cuda()
+        batch.bind_current_stream(res)
+        batch.match_device_begin(res, d_blob, d_off, True)
+        batch.match_device_begin(res, d_blob, d_off, True)
+        for _ in range(2):
+            total = batch.match_device_end(res)
+            p, r = batch.result_numpy(res, ds.n_haystacks, total)
+            assert np.array_equal(p, pe) and np.array_equal(r, re_)
+        pf, rf = o.match_batch(ds.hay_blob, ds.hay_off, False)
+        p, r = device_match(res, ds, False)
+        assert np.array_equal(p, pf) and np.array_equal(r, rf)
+        api.ahocorasick_deinit(res)
+    o.close()
