@@ -54,12 +54,18 @@ def build(force: bool = False, verbose: bool = False) -> str:
             continue
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
                "-c", path, "-o", obj]
+        if src.endswith(".hip"):
+            cmd.insert(1, "-save-temps=obj")   # keeps the device assembly next to the object: tools/check_asm.py, tests/test_asm.py
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))
     for cmd, p in procs:
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
+    # (of what -save-temps leaves behind only the device assembly is kept)
+    for f in os.listdir(OBJ_DIR):
+        if f.endswith((".bc", ".hipi", ".hipfb", ".out", ".resolution.txt")) or (f.endswith(".s") and "gfx950" not in f) or f.endswith("gfx950.o"):
+            os.remove(os.path.join(OBJ_DIR, f))
     cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     static_assert(!SL2 || DENSE, "two-slot buckets exist for the dense form only");
     static_assert(!DENSE || (QW == 1 && !BIG), "the dense form exists for 4-byte windows and the LDS table only");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    constexpr int G = BIG ? 4 : 8;  // 16-byte quads per lane and task
+    constexpr int G = (BIG || DENSE) ? 4 : 8;  // 16-byte quads per lane and task (dense form: four -- with eight its sixteen windows per quad spilled a dozen registers into the streaming loop)
     constexpr uint32_t TQ = G * 64u;  // quads per task: 8 KiB, BIG 4 KiB (two tasks in flight in the registers of one)
     constexpr int NC = QW > 1 ? QW - 1 : 1;  // carries between quads (none for QW == 1; arrays keep one element)
     if (uint64_t(blockIdx.x) * (B.persistent ? 1u : kLdsThreads / 64u) * B.wave_items >= B.item_base[B.n_haystacks]) return;

@@ -292,9 +292,11 @@ __device__ __forceinline__ void tiles_expand(const DevAutomaton &A, const TileLd
     }
 }
 
-// Two workgroups per CU (64 registers, 8 waves per SIMD): what hides the round trips of rows that are not in LDS is the number
-// of waves, not the size of the tile -- one workgroup with the whole LDS for its tile (twice the rows, 80-odd registers, no
-// spills) measured 8-12 % slower on a word list and on the headline set with 64 plants per haystack.
+// Two workgroups per CU (64 registers, 8 waves per SIMD): what hides the round trips of rows that are not in LDS -- and the
+// dependent LDS reads of every step -- is the number of waves, not the size of the tile or a spill-free register file: one
+// workgroup with the whole LDS for its tile (twice the rows, 80-odd registers, no spills) measured 8-12 % slower on a word list
+// and on the headline set with 64 plants per haystack, three workgroups of 512 threads (6 waves per SIMD, 80 registers, no
+// spills in any loop) 8-15 % slower on every workload tried.  (The dozen registers spilled at 64 are touched once per tile.)
 template <typename E, int MODE, bool ALLHOT, bool LANEQ>
 __global__ __launch_bounds__(kTilesThreads, 8) void k_walk_tiles(DevAutomaton A, BatchArgs B, TileArgs T) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
