@@ -207,6 +207,7 @@ __device__ __forceinline__ void tiles_walk(const DevAutomaton &A, const Piece &p
     // lies inside EVERY lane's own range -- all but the first and the last of a piece -- takes the body without the range test.
 #pragma unroll 1
     for (uint32_t k = 1u; k < blocks; ++k) {
+        asm volatile("; acmi-hot-begin");   // (tools/check_asm.py: no scratch traffic between the markers)
         const uint4 cur = b0;
         b0 = b1; b1 = b2; b2 = b3;
         const uint32_t kn = k + 4u;
@@ -233,6 +234,7 @@ __device__ __forceinline__ void tiles_walk(const DevAutomaton &A, const Piece &p
         } else {
             dword(cur.x, j0, std::true_type{}); dword(cur.y, j0 + 4u, std::true_type{}); dword(cur.z, j0 + 8u, std::true_type{}); dword(cur.w, j0 + 12u, std::true_type{});
         }
+        asm volatile("; acmi-hot-end");
     }
 }
 
@@ -403,24 +405,25 @@ __global__ __launch_bounds__(kTilesThreads, 8) void k_walk_tiles(DevAutomaton A,
                 pc.nblk = (pc.rep_lo + pc.rep_len + 15u) >> 4;
                 pc.pos_bias = uint32_t(xb) - d0 + it.pos0 + 1u;
                 walked16 += pc.nblk;
-                if constexpr (LANEQ) {
-                    if (T.m_prefix != nullptr) {
-                        // the other part's records that END inside this piece: positions [p_lo, p_hi] of this haystack
-                        const uint64_t s0 = T.m_prefix[pc.hay], s1 = T.m_prefix[pc.hay + 1u];
-                        const uint32_t p_lo = pc.pos_bias + pc.rep_lo, p_hi = p_lo + pc.rep_len - 1u;
-                        uint64_t a = s0, b = s1;
-                        while (a < b) { const uint64_t mid = (a + b) >> 1; if (T.m_records[mid].y < p_lo) a = mid + 1; else b = mid; }
-                        pc.m_first = a;
-                        b = s1;
-                        while (a < b) { const uint64_t mid = (a + b) >> 1; if (T.m_records[mid].y <= p_hi) a = mid + 1; else b = mid; }
-                        pc.m_count = uint32_t(a - pc.m_first);
-                    }
-                }
             }
         }
         uint32_t n_rec = 0;
         Q.total = Q.flushed = Q.n_ev = 0;
         tiles_walk<E, MODE, ALLHOT, LANEQ>(A, pc, L, Q, lane, n_rec, (T.flags & 2u) == 0u);
+        if constexpr (LANEQ) {
+            if (T.m_prefix != nullptr && pc.nblk) {
+                // the other part's records that END inside this piece: positions [p_lo, p_hi] of this haystack (looked up behind
+                // the walk: three registers less to keep through it)
+                const uint64_t s0 = T.m_prefix[pc.hay], s1 = T.m_prefix[pc.hay + 1u];
+                const uint32_t p_lo = pc.pos_bias + pc.rep_lo, p_hi = p_lo + pc.rep_len - 1u;
+                uint64_t a = s0, b = s1;
+                while (a < b) { const uint64_t mid = (a + b) >> 1; if (T.m_records[mid].y < p_lo) a = mid + 1; else b = mid; }
+                pc.m_first = a;
+                b = s1;
+                while (a < b) { const uint64_t mid = (a + b) >> 1; if (T.m_records[mid].y <= p_hi) a = mid + 1; else b = mid; }
+                pc.m_count = uint32_t(a - pc.m_first);
+            }
+        }
         bool lane_over = false;   // LANEQ: some lane of the wave had more events than its list holds
         uint32_t ev_max = 0;
         if constexpr (LANEQ) {
