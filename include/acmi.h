@@ -51,6 +51,11 @@ extern "C" {
 #define ACMI_E_NO_DEVICE  (-7)   /* no usable gfx950 device: matching is refused, there is NO CPU fallback */
 #define ACMI_E_TOO_LARGE  (-8)   /* automaton or result exceeds a hard limit      */
 #define ACMI_E_NO_REPLACEMENT (-9) /* acmi_replace_batch: no pattern carries a replacement text (multifast_replace's -2) */
+#define ACMI_E_PARTIAL    (-10)  /* "max_result_bytes" is set and the batch's records exceed it: the result holds the first k
+                                  * haystacks COMPLETE (their records, the prefix array's first k + 1 words; *n_records is their
+                                  * count), k = acmi_get_stat "resume_haystack" >= 1: match the haystacks from k on as the next
+                                  * batch.  The reference hands records to its callback one event at a time and holds none
+                                  * (php_ahocorasick.c:542-589); a batch API has to bound what it holds itself. */
 
 /* Pattern identifier kinds: src/multifast/actypes.h:57-62 (enum ac_pattid_type). */
 #define ACMI_ID_DEFAULT 0
@@ -281,6 +286,10 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *                    sum in ONE pass -- no slabs, no drain (findAll = true, patterns of <= 129 B; what automatic
  *                    mode takes instead of 4 unless the output is denser than a record per two bytes) [any time]
  *   "tile_w", "tile_p"  kernel 6: bytes per lane (16, 32, 64) and lanes per work item (1..64); 0 = automatic [any time]
+ *   "max_result_bytes"  0 (default): the result buffers grow to whatever a batch produces (16 B per record; a^1..a^16 over
+ *                    1 GiB: 275 GB -- ACMI_E_NOMEM); else the device-resident batch entries return ACMI_E_PARTIAL with the
+ *                    first haystacks whose records fit (see there), never allocating more.  A single haystack whose own
+ *                    records exceed the cap fails with ACMI_E_TOO_LARGE.  >= 4096                     [any time]
  *   "part_kernel"    split sets (see "split"): the "kernel" of the SHORT part alone, -1 (default) its own automatic choice; with 6
  *                    and a small short part the long part's records are merged into the result as the short part's are
  *                    written -- no merge pass                                                    [any time]

@@ -13,8 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # ACMI_LIBRARY selects another build of the same ABI (A/B kernel comparisons inside one process launch)
 LIB_PATH = os.environ.get("ACMI_LIBRARY") or os.path.join(HERE, "libacmi.so")
 
-OK, E_INVALID, E_NOT_INIT, E_FINALIZED, E_ARG, E_NOMEM, E_DEVICE, E_NO_DEVICE, E_TOO_LARGE, E_NO_REPLACEMENT = \
-    0, -1, -2, -3, -4, -5, -6, -7, -8, -9
+OK, E_INVALID, E_NOT_INIT, E_FINALIZED, E_ARG, E_NOMEM, E_DEVICE, E_NO_DEVICE, E_TOO_LARGE, E_NO_REPLACEMENT, E_PARTIAL = \
+    0, -1, -2, -3, -4, -5, -6, -7, -8, -9, -10
 ID_DEFAULT, ID_NUMBER, ID_STRING = 0, 1, 2
 
 

@@ -45,6 +45,27 @@ def match_device(res: AhoResource, d_blob, d_off, find_all: bool = True) -> int:
     return int(total.value)
 
 
+def match_device_bounded(res: AhoResource, d_blob, d_off, find_all: bool = True):
+    """A resident batch under "max_result_bytes" (acmi.h): yields (first haystack, haystacks, records) per segment -- after every
+    yield the segment's result is the handle's current one (``result_view`` / ``result_numpy``: haystack ids count from the
+    segment's first haystack) -- resuming behind the last complete haystack until the batch is done."""
+    nh = d_off.numel() - 1
+    first = 0
+    while first < nh or nh == 0:
+        total = C.c_uint64(0)
+        rc = N.lib.acmi_match_batch_device(res._h, C.c_void_p(d_blob.data_ptr()), d_blob.numel(), C.c_void_p(d_off.data_ptr() + 8 * first),
+                                           nh - first, 1 if find_all else 0, C.byref(total))
+        if rc == N.E_PARTIAL:
+            k = int(res.stat("resume_haystack"))
+        else:
+            N.check(rc, res._h)
+            k = nh - first
+        yield first, k, int(total.value)
+        first += k
+        if nh == 0:
+            break
+
+
 def match_device_begin(res: AhoResource, d_blob, d_off, find_all: bool = True) -> None:
     """Enqueue the scan of a resident batch and return immediately (see ``match_device_end``).  Up to two batches may
     be in flight per resource: the second one's kernels queue behind the first one's (acmi.h)."""

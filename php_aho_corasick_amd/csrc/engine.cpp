@@ -114,6 +114,8 @@ struct acmi_handle {
     int kernel = 3;  // 0 plain global table, 1 LDS-tile walk, 2 anchor filter (if eligible), 3 automatic, 4 whole-item walk, 6 tile walk (single pass, ordered output)
     int tile_w = 0, tile_p = 0;   // k_walk_tiles: bytes per lane / lanes per item (0: tiles_geometry chooses)
     int part_kernel = -1;         // split sets: the kernel forced on the SHORT part (-1: its own automatic choice)
+    uint64_t max_result_bytes = 0;   // 0: unbounded; else a batch hands out at most this much (ACMI_E_PARTIAL + "resume_haystack")
+    uint64_t resume_haystack = 0;    // after ACMI_E_PARTIAL: the first haystack that is NOT in the result
     // automatic mode: a batch on which the fast kernel lost (most bytes had to be walked exactly anyway) moves the
     // handle to the slower, safer kernel -- for `*_left` batches, then the fast one is probed again; every further
     // loss doubles the span (16 .. 1024 batches), a win resets it.  Batches under kAutoMinBytes decide nothing.
@@ -223,6 +225,7 @@ struct acmi_handle {
         int strategy = -1, choice_class = 0;  // automatic mode: the strategy this batch ran on (-1: the caller fixed the kernel)
         bool probe = false;                   // ... as a probe of an alternative
         bool timed = false;                   // nothing was allocated while it was enqueued: its events say what it cost
+        uint64_t out_cap = 0;                 // records the batch's kernels were allowed to write
         bool merged = false;                  // (part 1 of a split set) this batch wrote the MERGED records into the parent's buffer
         bool reran = false;                   // the end had to complete or repeat the pipeline: what ran behind it on the stream saw unfinished results
         bool refill_launched = false;  // the drain of overflowed items was enqueued with the pipeline (else: only if the batch turns out to need it)
@@ -1094,8 +1097,11 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
 
     // Records are written optimistically into a buffer of the capacity the batches before needed (at least): ONE host
     // synchronisation per batch; a batch that produced more is run again into a grown buffer (run_batch_end).
-    HIPCHK(h, F.d_out.ensure(std::max<size_t>(16, h->out_want)));
-    const uint64_t cap = F.d_out.cap / 16;
+    HIPCHK(h, F.d_out.ensure(std::max<size_t>(16, h->max_result_bytes ? std::min<size_t>(h->out_want, h->max_result_bytes) : h->out_want)));
+    // ("max_result_bytes": no record past the cap is written even where the allocation has slack -- what the host hands out is
+    // whole haystacks below it)
+    const uint64_t cap = h->max_result_bytes ? std::min<uint64_t>(F.d_out.cap / 16, h->max_result_bytes / 16) : F.d_out.cap / 16;
+    F.out_cap = cap;
     if (kernel == 6) {
         HIPCHK(h, h->d_tile_queue.ensure_keep(tiles_queue_entries(tile_w) * 8, h->retired));
         HIPCHK(h, h->d_tile_sync.ensure_keep(8 + tiles_status_words(max_items, tile_p) * 8, h->retired));
@@ -1292,9 +1298,13 @@ int run_batch_end(acmi_handle *h) {
             h->walk_ms = F.kernel_used == 2 ? ms : 0.0;
         }
     }
-    if (!F.merged) h->out_want = std::max<size_t>(h->out_want, size_t(total) * 16);
+    // "max_result_bytes": a batch whose records exceed the cap hands out the haystacks that fit below it
+    const uint64_t bound = (h->max_result_bytes && !h->is_part) ? h->max_result_bytes / 16 : ~0ull;
+    const bool partial = total > bound;
+    const uint64_t need = partial ? bound : total;   // records the buffer must hold
+    if (!F.merged) h->out_want = std::max<size_t>(h->out_want, size_t(need) * 16);
     // (a merged batch wrote into the parent's buffer: whether THAT was big enough is the parent's business, run_split_end)
-    const bool too_small = !F.merged && total > F.d_out.cap / 16;   // did not fit the optimistic capacity: grow, expand again
+    const bool too_small = !F.merged && need > F.out_cap;   // did not fit the optimistic capacity: grow, expand again
     const bool undrained = n_ovf > 0 && !F.refill_launched;      // items overflowed their slabs and the drain was not enqueued
     h->refill_armed = n_ovf > 0;
     // (a pipeline that has to be completed or run again below says nothing about what the strategy costs)
@@ -1305,8 +1315,9 @@ int run_batch_end(acmi_handle *h) {
     F.reran = too_small || undrained;
     if (too_small || undrained) {
         if (h->enqueue_seq == F.seq) {
-            if (too_small) HIPCHK(h, F.d_out.ensure(total * 16));
-            const uint64_t cap = F.d_out.cap / 16;
+            if (too_small) HIPCHK(h, F.d_out.ensure(need * 16));
+            const uint64_t cap = partial ? bound : F.d_out.cap / 16;
+            F.out_cap = cap;
             if (F.kernel_used == 6) {   // the walk again, into the grown buffer (prefix array and summary stand)
                 const size_t sync_bytes = 8 + tiles_status_words(F.max_items, F.tile_p) * 8;
                 HIPCHK(h, hipMemsetAsync(h->d_tile_sync.p, 0, sync_bytes, st));
@@ -1328,18 +1339,42 @@ int run_batch_end(acmi_handle *h) {
                 const hipError_t e = hipStreamSynchronize(st);
                 if (e != hipSuccess) { h->sync_tiles = 0; return fail_hip(h, e, "hipStreamSynchronize"); }
             }
-            if (too_small) HIPCHK(h, F.d_out.ensure(total * 16));
+            if (too_small) { h->out_want = std::max<size_t>(h->out_want, size_t(need) * 16); HIPCHK(h, F.d_out.ensure(need * 16)); }
             h->refill_armed = true;
             const int rc = enqueue_batch(h, F, F.d_blob, F.blob_bytes, F.d_off, F.nh, F.find_all);
             if (rc < 0) { h->sync_tiles = 0; return rc; }
             h->enqueue_seq = F.seq;
             HIPCHK(h, hipStreamSynchronize(st));
-            total = pinned[1];
-            if (total > F.d_out.cap / 16) { h->last_error = "record count changed between two runs of one batch"; return ACMI_E_DEVICE; }
+            if (pinned[1] != total) { h->last_error = "record count changed between two runs of one batch"; return ACMI_E_DEVICE; }
         }
     }
     h->last_total = total;
     h->have_result = true;
+    h->resume_haystack = F.nh;
+    if (partial) {
+        // the haystacks whose records lie wholly below the cap: the largest k with prefix[k] <= bound (the prefix array is on the
+        // device: a binary search by single-word copies -- this path is an exception, not a rate)
+        const uint64_t *d_prefix = F.d_prefix.as<uint64_t>();
+        uint64_t lo = 0, hi = F.nh;   // prefix[lo] <= bound < prefix[hi]
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            uint64_t v = 0;
+            HIPCHK(h, hipMemcpy(&v, d_prefix + mid, 8, hipMemcpyDeviceToHost));
+            if (v <= bound) lo = mid; else hi = mid;
+        }
+        if (lo == 0) {
+            h->have_result = false;
+            h->last_error = "the records of one haystack alone exceed max_result_bytes";
+            return ACMI_E_TOO_LARGE;
+        }
+        uint64_t v = 0;
+        HIPCHK(h, hipMemcpy(&v, d_prefix + lo, 8, hipMemcpyDeviceToHost));
+        h->last_nh = uint32_t(lo);
+        h->last_total = v;
+        h->resume_haystack = lo;
+        h->last_error = "the batch's records exceed max_result_bytes: the result holds the first haystacks only (resume_haystack)";
+        return ACMI_E_PARTIAL;
+    }
     return ACMI_OK;
 }
 
@@ -1537,9 +1572,9 @@ int acmi_match_batch_device(acmi_handle *h, const void *d_blob, uint64_t blob_by
         if (n_haystacks && !d_offsets) return ACMI_E_ARG;
         rc = run_batch(h, static_cast<const uint8_t *>(d_blob), blob_bytes, static_cast<const uint64_t *>(d_offsets),
                        n_haystacks, find_all);
-        if (rc < 0) return rc;
+        if (rc < 0 && rc != ACMI_E_PARTIAL) return rc;
         if (n_records) *n_records = h->last_total;
-        return ACMI_OK;
+        return rc;
     });
 }
 
@@ -1559,9 +1594,9 @@ int acmi_match_batch_device_end(acmi_handle *h, uint64_t *n_records) {
         if (!live(h)) return ACMI_E_INVALID;
         HIPCHK(h, hipSetDevice(h->dev_id));
         int rc = run_batch_end(h);
-        if (rc < 0) return rc;
+        if (rc < 0 && rc != ACMI_E_PARTIAL) return rc;
         if (n_records) *n_records = h->last_total;
-        return ACMI_OK;
+        return rc;
     });
 }
 
@@ -1637,12 +1672,42 @@ int acmi_match_batch(acmi_handle *h, const uint8_t *blob, const uint64_t *offset
         if (blob_bytes) HIPCHK(h, hipMemcpyAsync(h->d_blob.p, blob, blob_bytes, hipMemcpyHostToDevice, st));
         if (n_haystacks) HIPCHK(h, hipMemcpyAsync(h->d_off.p, offsets, (n_haystacks + 1) * 8, hipMemcpyHostToDevice, st));
         rc = run_batch(h, h->d_blob.as<uint8_t>(), blob_bytes, h->d_off.as<uint64_t>(), n_haystacks, find_all);
-        if (rc < 0) return rc;
+        if (rc < 0 && rc != ACMI_E_PARTIAL) return rc;
         // drain: device match buffer -> host records
         h->h_prefix.assign(n_haystacks + 1, 0);
-        h->h_records.resize(h->last_total);
-        rc = acmi_result_to_host(h, h->h_prefix.data(), h->h_records.data());
-        if (rc < 0) return rc;
+        if (rc == ACMI_OK) {
+            h->h_records.resize(h->last_total);
+            rc = acmi_result_to_host(h, h->h_prefix.data(), h->h_records.data());
+            if (rc < 0) return rc;
+        } else {
+            // "max_result_bytes": the device hands out the haystacks whose records fit its result buffer; the rest of the batch is
+            // matched again from the first haystack that did not, until all of it is drained (the overflow -> drain -> resume of
+            // BASELINE configs[4]: the host's arrays are the only ones that hold the whole result)
+            h->h_records.clear();
+            size_t first = 0;
+            uint64_t before = 0;
+            std::vector<uint64_t> seg;
+            for (;;) {
+                const size_t k = rc == ACMI_E_PARTIAL ? size_t(h->resume_haystack) : n_haystacks - first;
+                const uint64_t n = h->last_total;
+                seg.assign(k + 1, 0);
+                const size_t at = h->h_records.size();
+                h->h_records.resize(at + n);
+                const int rr = acmi_result_to_host(h, seg.data(), n ? h->h_records.data() + at : nullptr);
+                if (rr < 0) return rr;
+                for (size_t i = 0; i <= k; ++i) h->h_prefix[first + i] = before + seg[i];
+                if (first)
+                    for (size_t i = at; i < at + n; ++i) h->h_records[i].hay += uint32_t(first);
+                before += n;
+                first += k;
+                if (rc != ACMI_E_PARTIAL) break;
+                rc = run_batch(h, h->d_blob.as<uint8_t>(), blob_bytes, h->d_off.as<uint64_t>() + first, n_haystacks - first, find_all);
+                if (rc < 0 && rc != ACMI_E_PARTIAL) return rc;
+            }
+            h->last_total = before;
+            h->last_nh = uint32_t(n_haystacks);
+            h->have_result = false;   // (the whole result is in host memory only)
+        }
         if (prefix) *prefix = h->h_prefix.data();
         if (records) *records = h->h_records.data();
         if (n_records) *n_records = h->last_total;
@@ -1747,6 +1812,9 @@ static int apply_option(acmi_handle *h, const std::string &k, int64_t value) {
             h->kernel = int(value);
             for (auto &row : h->choice)
                 for (auto &c : row) c = acmi_handle::ChoiceClass{};
+        } else if (k == "max_result_bytes") {
+            if (value != 0 && value < 4096) return ACMI_E_ARG;
+            h->max_result_bytes = uint64_t(value);
         } else if (k == "part_kernel") {   // split sets: "kernel" of the short part alone (the long part keeps the filter); -1 automatic
             if (value < -1 || value > 6 || value == 5 || value == 2) return ACMI_E_ARG;
             h->part_kernel = int(value);
@@ -1864,6 +1932,7 @@ int acmi_get_stat(const acmi_handle *h, const char *key, double *value) {
         const std::string k(key);
         if (k == "split") { *value = h->part[0] ? 1 : 0; return ACMI_OK; }
         if (k == "merged_batches") { *value = h->merged_batches; return ACMI_OK; }
+        if (k == "resume_haystack") { *value = double(h->resume_haystack); return ACMI_OK; }
         if (k == "split_long_patterns" || k == "split_short_patterns") {
             *value = h->part[0] ? double(h->part[k == "split_long_patterns" ? 0 : 1]->aut.accepted_count()) : 0.0;
             return ACMI_OK;
@@ -2018,6 +2087,7 @@ const char *acmi_strerror(int status) {
     case ACMI_E_NO_DEVICE: return "no usable gfx950 device (no CPU fallback)";
     case ACMI_E_TOO_LARGE: return "automaton or result too large";
     case ACMI_E_NO_REPLACEMENT: return "no pattern has a replacement text";
+    case ACMI_E_PARTIAL: return "result holds the first haystacks only (max_result_bytes)";
     default: return status > 0 ? "ok" : "unknown error";
     }
 }

@@ -255,7 +255,8 @@ __device__ __forceinline__ uint32_t tiles_count(const DevAutomaton &A, const Pie
 // The same walk writing records in place: for the waves whose events did not fit their queue (dense output, rare, and bound by
 // its stores): every lane on its own, bytes straight from memory (the lines are in L2: the wave has just read them).
 template <typename E, int MODE, bool ALLHOT>
-__device__ __forceinline__ void tiles_emit(const DevAutomaton &A, const Piece &pc, const TileLds &L, const uint4 *m_records, uint4 *out, uint64_t wr) {
+__device__ __forceinline__ void tiles_emit(const DevAutomaton &A, const Piece &pc, const TileLds &L, const uint4 *m_records, uint4 *out, uint64_t wr,
+                                           uint64_t limit) {
     uint32_t st = 0, i0 = 0;
     uint32_t next0 = pc.m_count ? m_records[pc.m_first].y : 0xFFFFFFFFu;   // position of the other part's next record
     const uint32_t end = pc.rep_lo + pc.rep_len;
@@ -265,11 +266,16 @@ __device__ __forceinline__ void tiles_emit(const DevAutomaton &A, const Piece &p
         st = tiles_step<E, ALLHOT>(A, L.tile, L.rows, st, byte, class_offset<E, MODE>(A, L.cls, byte));
         if (jj < pc.rep_lo) continue;
         while (next0 <= pc.pos_bias + jj) {   // (the other part's patterns are the longer ones: first at equal positions)
-            out[wr++] = m_records[pc.m_first + i0];
+            if (wr < limit) out[wr] = m_records[pc.m_first + i0];
+            ++wr;
             ++i0;
             next0 = i0 < pc.m_count ? m_records[pc.m_first + i0].y : 0xFFFFFFFFu;
         }
-        if (tiles_final<E, ALLHOT>(A, L, st)) wr = emit_event(A, out, wr, pc.hay, pc.pos_bias + jj, tiles_meta<E, ALLHOT>(A, L, st).x);
+        if (tiles_final<E, ALLHOT>(A, L, st)) {
+            const uint2 meta = tiles_meta<E, ALLHOT>(A, L, st);
+            if (wr + meta.y <= limit) (void)emit_event(A, out, wr, pc.hay, pc.pos_bias + jj, meta.x);   // (records past the buffer's end are not written: the host grows it, or hands out what fits)
+            wr += meta.y;
+        }
     }
 }
 
@@ -467,11 +473,15 @@ __global__ __launch_bounds__(kTilesThreads, 8) void k_walk_tiles(DevAutomaton A,
         }
         __syncthreads();
         const uint64_t base = s_before + wave_base;
-        if (wave_tot == 0u || base + wave_tot > T.cap || (T.flags & 1u)) continue;   // (too small a buffer: the host grows it and runs the batch again)
+        // (too small a buffer: what fits is written -- whole events, in order -- and the host grows it and runs the batch again, or
+        // hands out the haystacks that are complete: "max_result_bytes")
+        if (wave_tot == 0u || base >= T.cap || (T.flags & 1u)) continue;
+        const uint64_t room = T.cap - base;   // records this wave may write
         if constexpr (LANEQ) {
             if (!lane_over) {
                 // every lane its own events, in the order it met them: its records are one contiguous piece of the output
-                uint4 *dst = T.out + base + excl;
+                uint4 *dst = T.out + base;
+                uint64_t at = excl;   // this lane's next record, counted from the wave's base
                 uint32_t i0 = 0;
                 uint32_t next0 = pc.m_count ? T.m_records[pc.m_first].y : 0xFFFFFFFFu;   // position of the other part's next record
 #pragma unroll 1
@@ -481,16 +491,18 @@ __global__ __launch_bounds__(kTilesThreads, 8) void k_walk_tiles(DevAutomaton A,
                     const uint2 meta = tiles_meta<E, ALLHOT>(A, L, ent & 0xffffu);
                     const uint32_t pos = pc.pos_bias + (ent >> 16);
                     while (next0 <= pos) {   // (rare: the other part's patterns are the long ones)
-                        *dst++ = T.m_records[pc.m_first + i0];
+                        if (at < room) dst[at] = T.m_records[pc.m_first + i0];
+                        ++at;
                         ++i0;
                         next0 = i0 < pc.m_count ? T.m_records[pc.m_first + i0].y : 0xFFFFFFFFu;
                     }
-                    tiles_expand(A, L, dst, pc.hay, pos, meta.x, meta.y);
-                    dst += meta.y;
+                    if (at + meta.y <= room) tiles_expand(A, L, dst + at, pc.hay, pos, meta.x, meta.y);
+                    at += meta.y;
                 }
-                for (; i0 < pc.m_count; ++i0) *dst++ = T.m_records[pc.m_first + i0];
+                for (; i0 < pc.m_count; ++i0, ++at)
+                    if (at < room) dst[at] = T.m_records[pc.m_first + i0];
             } else if (pc.nblk) {
-                tiles_emit<E, MODE, ALLHOT>(A, pc, L, T.m_records, T.out, base + excl);
+                tiles_emit<E, MODE, ALLHOT>(A, pc, L, T.m_records, T.out, base + excl, T.cap);
             }
             continue;
         }
@@ -520,12 +532,12 @@ __global__ __launch_bounds__(kTilesThreads, 8) void k_walk_tiles(DevAutomaton A,
                     uint32_t c;
                     if constexpr (ALLHOT) c = uint32_t(reinterpret_cast<const E *>(L.tile + s * L.stride + A.row_bytes)[0]);
                     else c = s < L.rows ? L.cnt[s] : A.out_count[s];
-                    tiles_expand(A, L, T.out + base + slot, hay, pos, s, c);
+                    if (uint64_t(slot) + c <= room) tiles_expand(A, L, T.out + base + slot, hay, pos, s, c);
                 }
             }
         } else if (pc.nblk) {
             // more events than the queue holds (dense output): every lane walks its piece again and writes its records in place
-            tiles_emit<E, MODE, ALLHOT>(A, pc, L, nullptr, T.out, base + excl);
+            tiles_emit<E, MODE, ALLHOT>(A, pc, L, nullptr, T.out, base + excl, T.cap);
         }
     }
     // statistic: 16-byte blocks walked (what the automatic kernel choice reads), summed per workgroup

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from gpu_util import resource_for
+from gpu_util import host_match, resource_for
 from oracle.pyoracle import Oracle
 from php_aho_corasick_amd import api, batch, synth
 
@@ -166,3 +166,43 @@ def test_config3_full_size_planted_hits():
             assert n64 == g["n_records"] and sha(rec[:n64]) == g["sha256"]
         api.ahocorasick_deinit(res)
     assert results[0] == results[1]
+
+
+@pytest.mark.parametrize("kernel", [3, 4, 6, 1])
+def test_bounded_result_memory_drains_and_resumes(kernel):
+    """BASELINE configs[4]'s "overflow -> drain -> resume" with a HARD bound on the device's result memory ("max_result_bytes"): G3
+    (16 records per byte: 8.4 MB of records per 32 KiB of text) under a 1 MiB cap -- the device-resident entry returns
+    ACMI_E_PARTIAL with the haystacks that fit and the index to resume from, the host entry drains segment by segment; either way
+    the concatenation is the oracle's array bit for bit, and nothing above the cap was ever allocated for records."""
+    import torch
+    from php_aho_corasick_amd import batch, _native as N
+    ds = synth.g3(n_hay=24, hay_len=4096)
+    o = Oracle("port")
+    o.add_patterns((ds.pat_blob, ds.pat_off))
+    pe, re_ = o.match_batch(ds.hay_blob, ds.hay_off, True)
+    per_hay = int(pe[1])
+    cap = 3 * per_hay * 16 + 4096          # three haystacks' records and a bit
+    res = resource_for(ds, kernel=kernel, max_result_bytes=cap, small_path=0)
+    d_blob = torch.from_numpy(ds.hay_blob).cuda()
+    d_off = torch.from_numpy(ds.hay_off.astype(np.int64)).cuda()
+    batch.bind_current_stream(res)
+    got, segments = [], []
+    for first, k, total in batch.match_device_bounded(res, d_blob, d_off):
+        p, r = batch.result_numpy(res, k, total)
+        assert int(p[-1]) == total and 1 <= k <= 3
+        r = r.copy()
+        r[:, 0] += first
+        got.append(r)
+        segments.append(k)
+    assert sum(segments) == ds.n_haystacks and len(segments) == 8
+    assert np.array_equal(np.concatenate(got), re_)
+    # the host-buffer entry (what the Zend shim calls) drains the same way inside the library
+    p, r = host_match(res, ds)
+    assert np.array_equal(p, pe) and np.array_equal(r, re_)
+    # one haystack whose records alone exceed the cap: an error, not a hang
+    res.set_option("max_result_bytes", 4096)
+    with pytest.raises(N.AcmiError) as e:
+        batch.match_device(res, d_blob, d_off, True)
+    assert e.value.status == N.E_TOO_LARGE
+    api.ahocorasick_deinit(res)
+    o.close()
