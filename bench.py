@@ -512,11 +512,28 @@ def host_leg(api, synth, ds, expect_per_tile):
     for _ in range(200):
         api.ahocorasick_match(one, res)
     single = (time.perf_counter() - t0) / 200
+    # the same call through the C ABI alone (what a Zend shim pays before it builds its result arrays)
+    import ctypes as C
+    from php_aho_corasick_amd import _native as N
+    buf = np.frombuffer(one, dtype=np.uint8)
+    recs, n_out = C.POINTER(N.Record)(), C.c_size_t(0)
+    c_args = (res._h, buf.ctypes.data, len(one), 1, C.byref(recs), C.byref(n_out))
+    for _ in range(5):
+        N.lib.acmi_match(*c_args)
+    t0 = time.perf_counter()
+    for _ in range(200):
+        N.lib.acmi_match(*c_args)
+    single_c = (time.perf_counter() - t0) / 200
+    res.set_option("profile", 1)
+    api.ahocorasick_match(one, res)
+    small_kernel_us = res.stat("scan_ms") * 1e3
+    res.set_option("profile", 0)
     out = {"batch_512MiB": {"GB_per_s_pcie_inclusive": round(blob.nbytes / best / 1e9, 2), "ms": round(best * 1e3, 2), "records": n_rec,
                             "check_ok": bool(n_rec == expect_per_tile * (nh // TILE_HAYSTACKS)),
                             "h2d_copy_alone_GB_per_s": round(blob.nbytes / h2d / 1e9, 2), "pcie_gen5_x16_spec_GB_per_s": 63.0},
            "literal_256x8KiB_one_call_ms": round(float(np.median(lit)) * 1e3, 4), "literal_records": len(r2),
-           "single_match_8KiB_us": round(single * 1e6, 1)}
+           "single_match_8KiB_us": round(single * 1e6, 1), "single_match_8KiB_us_c_abi_only": round(single_c * 1e6, 1),
+           "single_match_8KiB_kernel_us": round(small_kernel_us, 1)}
     api.ahocorasick_deinit(res)
     return out
 
@@ -745,6 +762,7 @@ def main():
     ap.add_argument("--in-flight", type=int, default=2, help="batches begun before the oldest is ended (1 or 2)")
     ap.add_argument("--phase-times", action="store_true", help="analysis: add the host time per step phase to the JSON")
     ap.add_argument("--items-ahead", action="store_true", help="analysis: every batch's item table on the handle's side stream (acmi.h \"items_ahead\" 1; measured: no gain)")
+    ap.add_argument("--reserve-cus", type=int, default=0, help="analysis: acmi.h \"reserve_cus\" -- the scan leaves N compute units to a collective in flight")
     ap.add_argument("--no-c-abi-gather", action="store_true", help="N > 1: skip the untimed exchange through acmi_comm_* after the timed steps")
     args = ap.parse_args()
 
@@ -806,6 +824,8 @@ def main():
         res.set_option("group_quads", args.group_quads)
     if args.kernel >= 0:
         res.set_option("kernel", args.kernel)
+    if args.reserve_cus:
+        res.set_option("reserve_cus", args.reserve_cus)
     if args.items_ahead:   # analysis: every batch's work-item table built on the handle's side stream (acmi.h "items_ahead")
         res.set_option("items_ahead", 1)
 
@@ -974,7 +994,7 @@ def main():
                        "patterns": ds.n_patterns, "haystacks_per_gpu": nh, "haystack_bytes": wl.hay_len,
                        "states": int(res.stat("states")), "hot_states": int(res.stat("hot_states")),
                        "lds_tile_bytes": int(res.stat("lds_image_bytes")), "work_item_bytes": int(res.stat("chunk_bytes")),
-                       "ilp": args.ilp or 1, "items_ahead": int(args.items_ahead), "sharding": f"{world} contiguous haystack ranges, {backend} all-gatherv of match arrays" if world > 1 else "none"},
+                       "ilp": args.ilp or 1, "items_ahead": int(args.items_ahead), "reserve_cus": args.reserve_cus, "sharding": f"{world} contiguous haystack ranges, {backend} all-gatherv of match arrays" if world > 1 else "none"},
             "ranks": {"launched": world, "process_group": (dist.get_world_size() if gather else 1), "joined_a_collective": ranks_in_collective,
                       "backend": backend if gather else None, "gpus_on_box": n_dev,
                       "gathered_records": gathered_records, "gathered_haystacks": gathered_haystacks, "c_abi_exchange": None,

@@ -248,7 +248,7 @@ int acmi_comm_destroy(acmi_comm *c);
  * return every rank holds the GLOBAL arrays in device memory owned by the communicator (valid until its next call):
  * prefix = uint64[*n_haystacks + 1], records = acmi_record[*n_records] with hay counted over all ranks.
  * Collectives: 32 bytes per rank of sizes and status (the call's one host wait), then ONE group of per-rank broadcasts,
- * each exactly its shard's size, received in place -- nothing is padded to the largest shard, staged or unpacked.  A rank
+ * each exactly its shard's size, received in place -- nothing is padded to the largest shard or staged.  A rank
  * that cannot take part (no result for the count it gave, out of memory) reports it in the size round, which it still
  * joins: every rank then returns an error (ACMI_E_ARG / ACMI_E_NOMEM on the rank at fault, ACMI_E_DEVICE on its peers)
  * instead of waiting inside a collective.  When the global arrays have to grow, a second 32-byte round confirms that every
@@ -256,6 +256,18 @@ int acmi_comm_destroy(acmi_comm *c);
  * GPU); the process-local transport runs the same code on one. */
 int acmi_comm_allgather_result(acmi_comm *c, acmi_handle *h, uint64_t n_haystacks_local, const void **d_prefix,
                                const void **d_records, uint64_t *n_records, uint64_t *n_haystacks);
+/* On the wire a record is 8 bytes {pos, pattern}, not 16: its haystack follows from the prefix array (which travels anyway)
+ * and its start from the pattern's length (start = pos - length, php_ahocorasick.c:578); the receiver expands what arrives
+ * ("bytes_sent" = 8 per record + 8 per haystack of this rank's shard).
+ * acmi_comm_gather_result: the same exchange with ONE receiver -- the PHP caller lives on one host, and for dense results
+ * (BASELINE configs[4]: gigabytes of records per rank) seven of eight copies of everything are wasted links: every rank sends
+ * its shard to `root` (ncclSend / ncclRecv in one group), only `root` gets the global arrays (the others *d_prefix =
+ * *d_records = NULL; *n_records / *n_haystacks are the global totals everywhere). */
+int acmi_comm_gather_result(acmi_comm *c, acmi_handle *h, uint64_t n_haystacks_local, int root, const void **d_prefix,
+                            const void **d_records, uint64_t *n_records, uint64_t *n_haystacks);
+/* The gathered arrays of the last exchange copied to host memory (prefix: *n_haystacks + 1 words; records: *n_records): for
+ * hosts that do not speak HIP themselves.  Either pointer may be NULL. */
+int acmi_comm_result_to_host(acmi_comm *c, uint64_t *prefix, acmi_record *records);
 /* "world", "rank", "backend_ranks" (what ncclCommCount reports), "transport" (0 none, 1 RCCL, 2 process-local), and of the
  * last exchange: "rounds" (collectives), "bytes_sent", "bytes_received", "records", "haystacks". */
 int acmi_comm_get_stat(const acmi_comm *c, const char *key, double *value);
@@ -286,6 +298,8 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *                    sum in ONE pass -- no slabs, no drain (findAll = true, patterns of <= 129 B; what automatic
  *                    mode takes instead of 4 unless the output is denser than a record per two bytes) [any time]
  *   "tile_w", "tile_p"  kernel 6: bytes per lane (16, 32, 64) and lanes per work item (1..64); 0 = automatic [any time]
+ *   "reserve_cus"    N (default 0): the scan kernels run as persistent workgroups on all but N compute units, so that the kernels
+ *                    of a collective in flight (acmi_comm_*, RCCL) find CUs and LDS while a scan runs          [any time]
  *   "max_result_bytes"  0 (default): the result buffers grow to whatever a batch produces (16 B per record; a^1..a^16 over
  *                    1 GiB: 275 GB -- ACMI_E_NOMEM); else the device-resident batch entries return ACMI_E_PARTIAL with the
  *                    first haystacks whose records fit (see there), never allocating more.  A single haystack whose own

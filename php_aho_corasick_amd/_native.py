@@ -91,6 +91,9 @@ SYMBOLS = {
     "acmi_comm_destroy": (C.c_int, [C.c_void_p]),
     "acmi_comm_allgather_result": (C.c_int, [C.c_void_p, Handle, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                              C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "acmi_comm_gather_result": (C.c_int, [C.c_void_p, Handle, C.c_uint64, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "acmi_comm_result_to_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "acmi_comm_create_local": (C.c_int, [C.POINTER(Handle), C.c_int, C.POINTER(C.c_void_p)]),
     "acmi_comm_get_stat": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]),
     "acmi_comm_last_error": (C.c_char_p, [C.c_void_p]),

@@ -93,6 +93,7 @@ struct BatchArgs {
     uint32_t persistent;         // 1: one workgroup per CU, waves pull item batches from counters[1]
     uint32_t wave_items;         // k_scan_anchor: items a wave takes per batch (1..64)
     uint32_t wave_grab;          // persistent mode: batches a wave takes from counters[1] per atomic (>= 1; see engine.cpp)
+    uint32_t reserve_cus;        // persistent scan kernels launch this many workgroups fewer than the chip has CUs ("reserve_cus")
 };
 
 // one trie depth of the automaton build (k_build_level); all pointers are device pointers

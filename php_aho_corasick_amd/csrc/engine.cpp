@@ -10,6 +10,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
@@ -113,6 +114,7 @@ struct acmi_handle {
     uint64_t chunk_opt = 0;
     int kernel = 3;  // 0 plain global table, 1 LDS-tile walk, 2 anchor filter (if eligible), 3 automatic, 4 whole-item walk, 6 tile walk (single pass, ordered output)
     int tile_w = 0, tile_p = 0;   // k_walk_tiles: bytes per lane / lanes per item (0: tiles_geometry chooses)
+    int reserve_cus = 0;          // compute units the persistent scan kernels leave free (a collective's kernels need some while a scan runs)
     int part_kernel = -1;         // split sets: the kernel forced on the SHORT part (-1: its own automatic choice)
     uint64_t max_result_bytes = 0;   // 0: unbounded; else a batch hands out at most this much (ACMI_E_PARTIAL + "resume_haystack")
     uint64_t resume_haystack = 0;    // after ACMI_E_PARTIAL: the first haystack that is NOT in the result
@@ -143,6 +145,7 @@ struct acmi_handle {
     int group_quads = 8;
     int small_path = 1;   // 1: host batches of <= 64 KiB / <= 1024 haystacks take the one-launch kernel
     uint8_t *pin_small = nullptr;  // pinned host memory of the small path: [summary | prefix | records | offsets | bytes]
+    uint64_t small_seq = 0;        // calls of the small path so far: the kernel stores it into the summary when it is done
     int wave_items = 0;   // 0 automatic, else 1..64 items per wave batch of the anchor kernel
     int persistent = -1;  // -1 automatic, 0 one workgroup per 1024 x ILP items, 1 persistent workgroups
     int tiny_rows = 1;    // anchor kernel: 1 (default) haystacks of <= 1 KiB on average take the variant that packs one-row items
@@ -1064,6 +1067,10 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
         const uint64_t groups = (items + per_group - 1) / per_group;
         if (blob_bytes % nh != 0 || (groups > 256 && groups % 256 != 0)) B.persistent = 1u;
     }
+    // "reserve_cus": a scan that holds every CU's whole LDS for most of a step leaves a collective's kernels (RCCL's need LDS and
+    // CUs of their own) only the gaps between scans: N CUs are kept free of scan workgroups -- which takes persistent workgroups
+    B.reserve_cus = uint32_t(h->reserve_cus);
+    if (h->reserve_cus > 0 && (kernel == 1 || kernel == 2)) B.persistent = 1u;
     if (B.persistent) {
         // Every batch a wave pulls is one device atomic on ONE word, and the chip retires those at ~ 12 ns each whoever issues
         // them: 4 GiB of 256-byte haystacks are 262,144 wave batches = 3.1 ms of atomics under a kernel that needs 0.5 (the same
@@ -1396,7 +1403,7 @@ int run_batch(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, const 
 // Small host batches: one launch that reads and writes pinned host memory (k_match_small).  Returns 1 when
 // the batch does not qualify or its records do not fit, and the caller takes the general path.
 constexpr uint32_t kSmallCap = 8192;  // records
-constexpr size_t kSmallSummaryOff = 0, kSmallPrefixOff = 64, kSmallRecordsOff = kSmallPrefixOff + (kSmallPathMaxHay + 8) * 8,
+constexpr size_t kSmallSummaryOff = 0, kSmallPrefixOff = 128, kSmallRecordsOff = kSmallPrefixOff + (kSmallPathMaxHay + 8) * 8,
                  kSmallOffsetsOff = kSmallRecordsOff + size_t(kSmallCap) * 16, kSmallBytesOff = kSmallOffsetsOff + (kSmallPathMaxHay + 8) * 8,
                  kSmallPinBytes = kSmallBytesOff + kSmallPathMaxBytes + 64;
 
@@ -1423,10 +1430,26 @@ int run_small(acmi_handle *h, const uint8_t *blob, const uint64_t *offsets, size
     HIPCHK(h, launch_match_small(h->dA, reinterpret_cast<const uint64_t *>(d + kSmallOffsetsOff), d + kSmallBytesOff, uint32_t(nh),
                                  find_all, fa.max_pattern_length, int(fa.entry_bytes), int(fa.class_mode),
                                  reinterpret_cast<uint64_t *>(d + kSmallSummaryOff), reinterpret_cast<uint64_t *>(d + kSmallPrefixOff),
-                                 d + kSmallRecordsOff, kSmallCap, st));
+                                 d + kSmallRecordsOff, kSmallCap, uint32_t(span), ++h->small_seq, st));
     if (h->profile) HIPCHK(h, hipEventRecord(h->ev[4], st));
-    HIPCHK(h, hipStreamSynchronize(st));
     const uint64_t *summary = reinterpret_cast<const uint64_t *>(pin + kSmallSummaryOff);
+    {
+        // The kernel's last store is the call's sequence number into the pinned summary: poll it (the whole call is ~ 15 us of
+        // device time; hipStreamSynchronize sleeps and is woken by an interrupt, ~ 8 us more) -- for a few hundred microseconds,
+        // then wait the ordinary way.  (With events on the stream -- "profile" -- the stream is synchronised anyway.)
+        const volatile uint64_t *flag = reinterpret_cast<const volatile uint64_t *>(summary + 3);
+        const auto t_poll = std::chrono::steady_clock::now();
+        bool done = false;
+        while (!h->profile) {
+            if (*flag == h->small_seq) { done = true; break; }
+            if (std::chrono::steady_clock::now() - t_poll > std::chrono::microseconds(300)) break;
+        }
+        if (done) std::atomic_thread_fence(std::memory_order_acquire);
+        else HIPCHK(h, hipStreamSynchronize(st));
+    }
+    if (std::getenv("ACMI_SMALL_TRACE"))
+        std::fprintf(stderr, "[acmi small] staged %.1f  items %.1f  walked %.1f  scanned %.1f  written %.1f us\n", summary[4] / 100.0, summary[5] / 100.0,
+                     summary[6] / 100.0, summary[7] / 100.0, summary[8] / 100.0);
     if (summary[2] != 0) return 1;  // more records than the pinned buffer holds: general path
     const uint64_t total = summary[0];
     h->items = summary[1];
@@ -1812,6 +1835,9 @@ static int apply_option(acmi_handle *h, const std::string &k, int64_t value) {
             h->kernel = int(value);
             for (auto &row : h->choice)
                 for (auto &c : row) c = acmi_handle::ChoiceClass{};
+        } else if (k == "reserve_cus") {
+            if (value < 0 || value > 128) return ACMI_E_ARG;
+            h->reserve_cus = int(value);
         } else if (k == "max_result_bytes") {
             if (value != 0 && value < 4096) return ACMI_E_ARG;
             h->max_result_bytes = uint64_t(value);
@@ -2122,6 +2148,8 @@ struct Rccl {
     int (*CommInitRank)(void **, int, acmi_comm_id, int) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
     int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     int (*CommCount)(void *, int *) = nullptr;
@@ -2148,6 +2176,8 @@ Rccl &rccl() {
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
         r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
         r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(dlsym(r.lib, "ncclBroadcast"));
+        r.Send = reinterpret_cast<decltype(r.Send)>(dlsym(r.lib, "ncclSend"));
+        r.Recv = reinterpret_cast<decltype(r.Recv)>(dlsym(r.lib, "ncclRecv"));
         r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(r.lib, "ncclGroupStart"));
         r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(r.lib, "ncclGroupEnd"));
         r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.lib, "ncclCommCount"));
@@ -2196,7 +2226,7 @@ struct acmi_comm {
     LocalFabric *fabric = nullptr;  // process-local transport
     int rank = 0, world = 1, dev = 0;
     int backend_ranks = 1;          // ranks the backend itself reports (ncclCommCount)
-    DevBuf d_hdr, d_prefix, d_records;
+    DevBuf d_hdr, d_prefix, d_records, d_wire;   // (d_wire: every rank's records as they travel, 8 bytes each {pos, pattern})
     uint64_t *h_hdr = nullptr;      // pinned: [mine 4 | all world x 4] words
     // capacities every rank holds, kept identical on all ranks (they grow by the same rule from the same headers)
     uint64_t cap_rec = 0, cap_hay = 0;
@@ -2244,8 +2274,9 @@ int comm_allgather(acmi_comm *c, const void *send, void *recv, size_t bytes, hip
     return ACMI_OK;
 }
 
-// one group of broadcasts; every rank passes the same list (same order, sizes and roots)
-int comm_bcast_group(acmi_comm *c, const std::vector<BcastOp> &ops, hipStream_t st) {
+// one group of broadcasts; every rank passes the same list (same order, sizes and roots).  dest >= 0: only rank `dest` receives
+// (a gather: a send from every root to dest, ncclSend / ncclRecv in one group)
+int comm_bcast_group(acmi_comm *c, const std::vector<BcastOp> &ops, hipStream_t st, int dest = -1) {
     if (c->world == 1 || ops.empty()) return ACMI_OK;
     if (c->fabric) {
         LocalFabric &F = *c->fabric;
@@ -2254,7 +2285,7 @@ int comm_bcast_group(acmi_comm *c, const std::vector<BcastOp> &ops, hipStream_t 
         F.barrier();
         for (size_t i = 0; i < ops.size() && rc == ACMI_OK; ++i) {
             const BcastOp &mine = ops[i];
-            if (mine.root == c->rank || mine.bytes == 0) continue;
+            if (mine.root == c->rank || mine.bytes == 0 || (dest >= 0 && dest != c->rank)) continue;
             const BcastOp &theirs = F.ops[size_t(mine.root)][i];
             if (hipStreamWaitEvent(st, F.ready[size_t(mine.root)], 0) != hipSuccess ||
                 hipMemcpyAsync(mine.recv, theirs.send, mine.bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
@@ -2265,9 +2296,15 @@ int comm_bcast_group(acmi_comm *c, const std::vector<BcastOp> &ops, hipStream_t 
         return rc;
     }
     Rccl &R = rccl();
+    if (dest >= 0 && (!R.Send || !R.Recv)) { c->last_error = "librccl.so lacks ncclSend / ncclRecv"; return ACMI_E_NO_DEVICE; }
     int e = R.GroupStart();
-    for (size_t i = 0; i < ops.size() && e == 0; ++i)
-        if (ops[i].bytes) e = R.Broadcast(ops[i].send, ops[i].recv, ops[i].bytes, kNcclUint8, ops[i].root, c->comm, st);
+    for (size_t i = 0; i < ops.size() && e == 0; ++i) {
+        if (!ops[i].bytes) continue;
+        if (dest < 0) e = R.Broadcast(ops[i].send, ops[i].recv, ops[i].bytes, kNcclUint8, ops[i].root, c->comm, st);
+        else if (ops[i].root == dest) continue;
+        else if (c->rank == ops[i].root) e = R.Send(ops[i].send, ops[i].bytes, kNcclUint8, dest, c->comm, st);
+        else if (c->rank == dest) e = R.Recv(ops[i].recv, ops[i].bytes, kNcclUint8, ops[i].root, c->comm, st);
+    }
     const int e2 = R.GroupEnd();
     if (e == 0) e = e2;
     if (e != 0) { c->last_error = std::string("ncclBroadcast: ") + (R.GetErrorString ? R.GetErrorString(e) : "error"); return ACMI_E_DEVICE; }
@@ -2393,21 +2430,24 @@ int acmi_comm_destroy(acmi_comm *c) {
                 delete c->fabric;
             }
         }
-        for (DevBuf *b : {&c->d_hdr, &c->d_prefix, &c->d_records}) b->release();
+        for (DevBuf *b : {&c->d_hdr, &c->d_prefix, &c->d_records, &c->d_wire}) b->release();
         if (c->h_hdr) (void)hipHostFree(c->h_hdr);
         delete c;
         return ACMI_OK;
     });
 }
 
-int acmi_comm_allgather_result(acmi_comm *c, acmi_handle *h, uint64_t n_haystacks_local, const void **d_prefix,
-                               const void **d_records, uint64_t *n_records, uint64_t *n_haystacks) {
+// root < 0: all-gatherv (every rank ends with the global arrays); else a gather to `root`
+static int comm_exchange(acmi_comm *c, acmi_handle *h, uint64_t n_haystacks_local, int root, const void **d_prefix,
+                         const void **d_records, uint64_t *n_records, uint64_t *n_haystacks) {
     return guarded(h, [&]() -> int {
         if (!c) return ACMI_E_ARG;
         if (!live(h)) return ACMI_E_INVALID;   // (no stream to join a collective on: the caller broke the contract)
+        if (root >= c->world) return ACMI_E_ARG;
         HIPCHK(h, hipSetDevice(h->dev_id));
         hipStream_t st = h->stream;
         const int W = c->world;
+        const bool receiver = root < 0 || root == c->rank;
         c->rounds = c->bytes_sent = c->bytes_received = 0;
         // what is wrong on THIS rank travels in the header; the rank joins the header round all the same
         uint64_t status = kCommOk;
@@ -2432,11 +2472,13 @@ int acmi_comm_allgather_result(acmi_comm *c, acmi_handle *h, uint64_t n_haystack
         }
         const uint64_t total_rec = rec_base[W], total_hay = hay_base[W];
         // Global arrays: grown by the same rule on every rank (the totals are the same everywhere), and a rank whose
-        // allocation fails tells the others in a second, tiny round -- taken by all ranks or by none.
+        // allocation fails tells the others in a second, tiny round -- taken by all ranks or by none.  (A rank that only
+        // sends -- a gather's non-root -- holds its own slice of the prefix words and of the wire, no more.)
         if (total_rec > c->cap_rec || total_hay > c->cap_hay || !c->d_prefix.p) {
             c->cap_rec = std::max(c->cap_rec, total_rec + total_rec / 4);
             c->cap_hay = std::max(c->cap_hay, total_hay + total_hay / 4);
-            c->cap_ok = c->d_prefix.ensure((c->cap_hay + 1) * 8) == hipSuccess && c->d_records.ensure(std::max<uint64_t>(16, c->cap_rec * 16)) == hipSuccess;
+            c->cap_ok = c->d_prefix.ensure((c->cap_hay + 1) * 8) == hipSuccess && c->d_wire.ensure(std::max<uint64_t>(16, c->cap_rec * 8)) == hipSuccess &&
+                        (!receiver || c->d_records.ensure(std::max<uint64_t>(16, c->cap_rec * 16)) == hipSuccess);
             if (!c->cap_ok) (void)hipGetLastError();
             rc = comm_headers(c, 0, 0, c->cap_ok ? kCommOk : kCommNoMemory, st);
             if (rc < 0) return comm_fail(h, c, rc, c->last_error.empty() ? "status exchange failed" : c->last_error);
@@ -2448,34 +2490,67 @@ int acmi_comm_allgather_result(acmi_comm *c, acmi_handle *h, uint64_t n_haystack
                     c->cap_ok = true;
                     c->d_prefix.release();
                     c->d_records.release();
+                    c->d_wire.release();
                     return comm_fail(h, c, r == c->rank ? ACMI_E_NOMEM : ACMI_E_DEVICE, "rank " + std::to_string(r) + " is out of device memory");
                 }
         }
-        // this rank's slice, already global: haystack ids + hay_base, prefix words + rec_base (and the closing word)
+        if (receiver && c->d_records.cap < std::max<uint64_t>(16, total_rec * 16)) {   // (a rank that was a gather's sender so far)
+            if (c->d_records.ensure(std::max<uint64_t>(16, c->cap_rec * 16)) != hipSuccess) { (void)hipGetLastError(); return comm_fail(h, c, ACMI_E_NOMEM, "out of device memory for the gathered records"); }
+        }
+        // this rank's slice, already global: haystack ids + hay_base, prefix words + rec_base (and the closing word); its
+        // records a second time in the 8-byte form that travels
         uint64_t *g_prefix = c->d_prefix.as<uint64_t>();
-        uint4 *g_records = c->d_records.as<uint4>();
+        uint4 *g_records = receiver ? c->d_records.as<uint4>() : nullptr;
+        uint2 *g_wire = c->d_wire.as<uint2>();
         launch_gather_pack(h->d_prefix().as<uint64_t>(), h->d_out().as<uint4>(), my_hay, my_rec, hay_base[c->rank], rec_base[c->rank],
-                           g_prefix + hay_base[c->rank], g_records + rec_base[c->rank], g_prefix + total_hay, total_rec, st);
+                           g_prefix + hay_base[c->rank], g_records ? g_records + rec_base[c->rank] : nullptr, g_wire + rec_base[c->rank],
+                           g_prefix + total_hay, total_rec, st);
         HIPCHK(h, hipGetLastError());
         // one group: rank r's slices from rank r, exactly their size
         std::vector<BcastOp> ops;
         for (int r = 0; r < W; ++r) {
             const uint64_t nr = rec_base[r + 1] - rec_base[r], nh = hay_base[r + 1] - hay_base[r];
-            ops.push_back({g_records + rec_base[r], g_records + rec_base[r], size_t(nr) * 16, r});
+            ops.push_back({g_wire + rec_base[r], g_wire + rec_base[r], size_t(nr) * 8, r});
             ops.push_back({g_prefix + hay_base[r], g_prefix + hay_base[r], size_t(nh) * 8, r});
-            if (r == c->rank) c->bytes_sent = (W > 1 ? nr * 16 + nh * 8 : 0);
-            else c->bytes_received += nr * 16 + nh * 8;
+            if (r == c->rank) c->bytes_sent = (W > 1 && root != c->rank ? nr * 8 + nh * 8 : 0);
+            else if (receiver) c->bytes_received += nr * 8 + nh * 8;
         }
-        rc = comm_bcast_group(c, ops, st);
+        rc = comm_bcast_group(c, ops, st, root);
         if (rc < 0) return comm_fail(h, c, rc, c->last_error.empty() ? "payload exchange failed" : c->last_error);
         ++c->rounds;
+        // the other ranks' records, expanded where they belong: haystack from the prefix array, start = pos - pattern length
+        if (receiver && W > 1)
+            launch_gather_unpack(g_prefix, total_hay, g_wire, total_rec, rec_base[c->rank], rec_base[c->rank + 1], h->dA.pattern_length, g_records, st);
+        HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipStreamSynchronize(st));
-        c->total_rec = total_rec;
-        c->total_hay = total_hay;
-        if (d_prefix) *d_prefix = c->d_prefix.p;
-        if (d_records) *d_records = c->d_records.p;
+        c->total_rec = receiver ? total_rec : 0;
+        c->total_hay = receiver ? total_hay : 0;
+        if (d_prefix) *d_prefix = receiver ? c->d_prefix.p : nullptr;
+        if (d_records) *d_records = receiver ? c->d_records.p : nullptr;
         if (n_records) *n_records = total_rec;
         if (n_haystacks) *n_haystacks = total_hay;
+        return ACMI_OK;
+    });
+}
+
+int acmi_comm_allgather_result(acmi_comm *c, acmi_handle *h, uint64_t n_haystacks_local, const void **d_prefix,
+                               const void **d_records, uint64_t *n_records, uint64_t *n_haystacks) {
+    return comm_exchange(c, h, n_haystacks_local, -1, d_prefix, d_records, n_records, n_haystacks);
+}
+
+int acmi_comm_gather_result(acmi_comm *c, acmi_handle *h, uint64_t n_haystacks_local, int root, const void **d_prefix,
+                            const void **d_records, uint64_t *n_records, uint64_t *n_haystacks) {
+    if (root < 0) return ACMI_E_ARG;
+    return comm_exchange(c, h, n_haystacks_local, root, d_prefix, d_records, n_records, n_haystacks);
+}
+
+int acmi_comm_result_to_host(acmi_comm *c, uint64_t *prefix, acmi_record *records) {
+    return guarded(nullptr, [&]() -> int {
+        if (!c) return ACMI_E_ARG;
+        if (!c->d_prefix.p || (c->total_rec && !c->d_records.p)) return ACMI_E_ARG;   // (no gathered result on this rank)
+        if (hipSetDevice(c->dev) != hipSuccess) return ACMI_E_DEVICE;
+        if (prefix && hipMemcpy(prefix, c->d_prefix.p, (c->total_hay + 1) * 8, hipMemcpyDeviceToHost) != hipSuccess) return ACMI_E_DEVICE;
+        if (records && c->total_rec && hipMemcpy(records, c->d_records.p, c->total_rec * 16, hipMemcpyDeviceToHost) != hipSuccess) return ACMI_E_DEVICE;
         return ACMI_OK;
     });
 }

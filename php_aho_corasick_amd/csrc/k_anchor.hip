@@ -858,7 +858,7 @@ hipError_t launch_anchor(const DevAutomaton &A, const BatchArgs &B, uint64_t max
     }
     const uint64_t per_block = uint64_t(kLdsThreads / 64u) * B.wave_items;
     const uint64_t want = (max_items + per_block - 1) / per_block;
-    const uint32_t blocks = B.persistent ? uint32_t(std::min<uint64_t>(want, uint64_t(num_cus()))) : uint32_t(want);
+    const uint32_t blocks = B.persistent ? uint32_t(std::min<uint64_t>(want, uint64_t(std::max(1, num_cus() - int(B.reserve_cus))))) : uint32_t(want);
     auto go = [&](auto fn) {
         const uint32_t lds = kAnchorLdsBytes + (kLdsThreads / 64u) * kStageSlots * 16u;  // table + run staging = 160 KiB
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),

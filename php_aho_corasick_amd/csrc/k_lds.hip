@@ -263,7 +263,7 @@ static hipError_t launch_lds_t(const DevAutomaton &A, const BatchArgs &B, uint64
     // persistent: at most one workgroup per CU (the tile fills the CU's LDS), fewer for small batches
     const uint64_t per_block = uint64_t(kLdsThreads) * ILP;
     const uint64_t want = (max_items + per_block - 1) / per_block;
-    const uint32_t blocks = B.persistent ? uint32_t(std::min<uint64_t>(want, uint64_t(num_cus()))) : uint32_t(want);
+    const uint32_t blocks = B.persistent ? uint32_t(std::min<uint64_t>(want, uint64_t(std::max(1, num_cus() - int(B.reserve_cus))))) : uint32_t(want);
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(kLdsThreads), lds_bytes, st, A, B);
     return hipGetLastError();
 }

@@ -406,29 +406,68 @@ void launch_merge_parts(const uint64_t *pa, const void *ra, uint64_t ta, const u
 }
 
 // ------------------------------------------------------------------------------------------
-// k_gather_pack: this rank's half of the all-gatherv of match arrays (engine.cpp acmi_comm_allgather_result).
-// Ranks own contiguous haystack ranges in rank order, so the global arrays are the ranks' arrays back to back: a rank
-// writes its own slice of them -- haystack ids made global, prefix words moved by the records of the ranks before it --
-// and the per-rank broadcasts that follow fill in the other slices, each exactly its size.  Nothing is unpacked
-// afterwards.  `closing` = the global prefix array's last word (the total), written by every rank for itself.
+// k_gather_pack / k_gather_unpack: the all-gatherv of match arrays (engine.cpp acmi_comm_allgather_result / _gather_result).
+// Ranks own contiguous haystack ranges in rank order, so the global arrays are the ranks' arrays back to back.  A rank writes
+// its own slice of them -- haystack ids made global, prefix words moved by the records of the ranks before it -- and, for the
+// wire, its records as 8 bytes each {pos, pattern}: a record's haystack follows from the prefix array that travels anyway and
+// its start from the pattern's length (start = pos - length, php_ahocorasick.c:578), so half of every 16-byte record need not
+// cross the links.  What arrives from the other ranks is expanded in place by k_gather_unpack: the haystack of global record
+// g is the h with prefix[h] <= g < prefix[h + 1].  `closing` = the global prefix array's last word (the total).
 // ------------------------------------------------------------------------------------------
 __global__ void k_gather_pack(const uint64_t *prefix, const uint4 *records, uint64_t nh, uint64_t nrec, uint64_t hay_base,
-                              uint64_t rec_base, uint64_t *out_prefix, uint4 *out_records, uint64_t *closing, uint64_t total_rec) {
+                              uint64_t rec_base, uint64_t *out_prefix, uint4 *out_records, uint2 *out_wire, uint64_t *closing, uint64_t total_rec) {
     const uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (g < nrec) {
         uint4 v = records[g];
         v.x += uint32_t(hay_base);
-        out_records[g] = v;
+        if (out_records) out_records[g] = v;
+        out_wire[g] = make_uint2(v.y, v.w);
     }
     if (g < nh) out_prefix[g] = prefix[g] + rec_base;
-    if (g == 0) *closing = total_rec;
+    if (g == 0 && closing) *closing = total_rec;
 }
 
 void launch_gather_pack(const uint64_t *prefix, const uint4 *records, uint64_t nh, uint64_t nrec, uint64_t hay_base, uint64_t rec_base,
-                        uint64_t *out_prefix, uint4 *out_records, uint64_t *closing, uint64_t total_rec, hipStream_t st) {
+                        uint64_t *out_prefix, uint4 *out_records, uint2 *out_wire, uint64_t *closing, uint64_t total_rec, hipStream_t st) {
     const uint64_t threads = std::max<uint64_t>(1, std::max(nrec, nh));
     hipLaunchKernelGGL(k_gather_pack, dim3(uint32_t((threads + 255) / 256)), dim3(256), 0, st, prefix, records, nh, nrec, hay_base,
-                       rec_base, out_prefix, out_records, closing, total_rec);
+                       rec_base, out_prefix, out_records, out_wire, closing, total_rec);
+}
+
+// Records [skip_lo, skip_hi) are this rank's own (written whole by k_gather_pack); every other one is expanded from the wire.
+__global__ void k_gather_unpack(const uint64_t *prefix, uint64_t total_hay, const uint2 *wire, uint64_t total_rec, uint64_t skip_lo, uint64_t skip_hi,
+                                const uint32_t *pattern_length, uint4 *out_records) {
+    __shared__ uint64_t s_lo, s_hi;
+    const uint64_t g0 = uint64_t(blockIdx.x) * blockDim.x;
+    if (g0 >= total_rec) return;
+    const uint64_t g1 = g0 + blockDim.x - 1u < total_rec ? g0 + blockDim.x - 1u : total_rec - 1u;
+    // the haystacks this block's records lie in: the last h with prefix[h] <= g, for its first and its last record
+    if (threadIdx.x < 2u) {
+        const uint64_t g = threadIdx.x ? g1 : g0;
+        uint64_t lo = 0, hi = total_hay;   // prefix[lo] <= g < prefix[hi] (prefix[total_hay] = total_rec > g)
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (prefix[mid] <= g) lo = mid; else hi = mid;
+        }
+        (threadIdx.x ? s_hi : s_lo) = lo;
+    }
+    __syncthreads();
+    const uint64_t g = g0 + threadIdx.x;
+    if (g >= total_rec || (g >= skip_lo && g < skip_hi)) return;
+    uint64_t lo = s_lo, hi = s_hi + 1;
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (prefix[mid] <= g) lo = mid; else hi = mid;
+    }
+    const uint2 w = wire[g];
+    out_records[g] = make_uint4(uint32_t(lo), w.x, w.x - pattern_length[w.y], w.y);
+}
+
+void launch_gather_unpack(const uint64_t *prefix, uint64_t total_hay, const uint2 *wire, uint64_t total_rec, uint64_t skip_lo, uint64_t skip_hi,
+                          const uint32_t *pattern_length, uint4 *out_records, hipStream_t st) {
+    if (total_rec == 0) return;
+    hipLaunchKernelGGL(k_gather_unpack, dim3(uint32_t((total_rec + 255) / 256)), dim3(256), 0, st, prefix, total_hay, wire, total_rec, skip_lo, skip_hi,
+                       pattern_length, out_records);
 }
 
 }  // namespace acmi

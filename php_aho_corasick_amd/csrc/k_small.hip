@@ -15,13 +15,33 @@ namespace acmi {
 // one launch, one synchronisation, no copies.  Same exact walk, same order, same findAll=false rule.
 // A batch whose records do not fit `cap` reports so and the host takes the general path.
 // ------------------------------------------------------------------------------------------
-constexpr uint32_t kSmallMaxBytes = 64u * 1024u;
 constexpr uint32_t kSmallMaxHay = 1024;
-constexpr uint32_t kSmallChunk = 64;
-constexpr uint32_t kSmallMaxItems = kSmallMaxBytes / kSmallChunk + kSmallMaxHay;  // 2048
+constexpr uint32_t kSmallMaxItems = 2048;       // small_scan handles 2 x 1024 values
 constexpr uint32_t kSmallEvents = 2;            // events kept per item; more -> the item is walked again
-constexpr uint32_t kSmallTileBytes = 36u * 1024u;
 constexpr uint32_t kSmallThreads = 1024;
+constexpr uint32_t kSmallLds = 160u * 1024u - 256u;
+
+struct SmallLayout {
+    uint32_t chunk;       // bytes per work item: 16, 32 or 64 -- the smallest that leaves the batch <= 2,048 items
+    uint32_t max_items;   // item slots (a multiple of 2, <= kSmallMaxItems)
+    uint32_t in_bytes;    // LDS for the haystack bytes (their span rounded up to 16)
+    uint32_t tile_bytes;  // LDS for the transition tile: what is left
+};
+
+static SmallLayout small_layout(uint32_t span, uint32_t nh, uint32_t hot_bytes, bool table_mode) {
+    SmallLayout Y{};
+    // (the smallest items that still fit the item arrays: more lanes walk, each fewer steps -- the warm-up of Lmax - 1 bytes per
+    // item is cheap next to a chip that would otherwise run two waves)
+    Y.chunk = (span + 15u) / 16u + nh <= kSmallMaxItems ? 16u : (span + 31u) / 32u + nh <= kSmallMaxItems ? 32u : 64u;
+    Y.max_items = std::min<uint32_t>(kSmallMaxItems, ((span + Y.chunk - 1u) / Y.chunk + nh + 1u) & ~1u);
+    if (Y.max_items < 2u) Y.max_items = 2u;
+    Y.in_bytes = (span + 15u) & ~15u;
+    (void)table_mode;
+    const uint32_t fixed = Y.max_items * (kSmallEvents * 8u + 8u) + (kSmallMaxHay + 8u) * 8u + 64u + 512u;
+    const uint32_t room = kSmallLds > Y.in_bytes + fixed ? kSmallLds - Y.in_bytes - fixed : 0u;
+    Y.tile_bytes = std::min<uint32_t>(room, (hot_bytes + 15u) & ~15u) & ~15u;
+    return Y;
+}
 
 // exclusive scan of v[0..n) (n <= 2 * kSmallThreads) in LDS, in place; returns the total.  All threads call.
 __device__ __forceinline__ uint32_t small_scan(uint32_t *v, uint32_t n, uint32_t *wave_tmp) {
@@ -53,39 +73,49 @@ template <typename E, int MODE>
 __global__ __launch_bounds__(kSmallThreads) void k_match_small(DevAutomaton A, const uint64_t *offsets, const uint8_t *blob,
                                                                uint32_t nh, uint32_t find_all, uint32_t max_pattern_length,
                                                                uint64_t *out_summary, uint64_t *out_prefix, uint4 *out_records,
-                                                               uint32_t cap) {
+                                                               uint32_t cap, SmallLayout Y, uint64_t seq) {
+    // LDS, laid out by the host for THIS batch (small_layout): the bytes and per-item arrays take what the batch needs, the tile
+    // of the transition table everything else -- one 8 KiB haystack leaves ~ 140 KiB to the tile (every state of the first nine
+    // trie levels of the headline set) where a fixed 64 KiB for the bytes left 36: with two waves on the chip nothing hides a row
+    // that comes from L2, and 94 % of the lockstep steps had one (24 of the kernel's 31 us).
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t *in_bytes = smem;                                                       // 64 KiB
-    const uint8_t *tile = smem + kSmallMaxBytes;                                    // 36 KiB
-    uint2 *ev = reinterpret_cast<uint2 *>(smem + kSmallMaxBytes + kSmallTileBytes); // 2048 x 2 x 8 B = 32 KiB
-    uint32_t *cnt_ev = reinterpret_cast<uint32_t *>(ev + kSmallMaxItems * kSmallEvents);  // 8 KiB
-    uint32_t *cnt_rec = cnt_ev + kSmallMaxItems;                                     // 8 KiB
-    uint32_t *item_base = cnt_rec + kSmallMaxItems;                                  // 1025 x 4 (+ pad) = 4.5 KiB
+    const uint32_t kChunk = Y.chunk, kItems = Y.max_items;
+    uint8_t *in_bytes = smem;
+    const uint8_t *tile = smem + Y.in_bytes;
+    uint2 *ev = reinterpret_cast<uint2 *>(smem + Y.in_bytes + Y.tile_bytes);
+    uint32_t *cnt_ev = reinterpret_cast<uint32_t *>(ev + kItems * kSmallEvents);
+    uint32_t *cnt_rec = cnt_ev + kItems;
+    uint32_t *item_base = cnt_rec + kItems;                                          // 1025 x 4 (+ pad) = 4.5 KiB
     uint32_t *hay_off = item_base + kSmallMaxHay + 8;                                // 1025 x 4
     uint32_t *wave_tmp = hay_off + kSmallMaxHay + 8;                                 // 16 x 4
     uint16_t *cls = reinterpret_cast<uint16_t *>(wave_tmp + 16);                     // 512 B (TABLE mode)
 
     const uint32_t t = threadIdx.x;
+    // (phase stamps of thread 0, 100 MHz: summary[4..10] -- ACMI_SMALL_TRACE prints them; seven stores to pinned memory)
+    const uint64_t t_start = wall_clock64();
+    auto stamp = [&](int i) { if (t == 0) out_summary[4 + i] = wall_clock64() - t_start; };
     const uint64_t off0 = offsets[0];
     // offsets -> LDS (relative to the first one), items per haystack
     for (uint32_t h = t; h <= nh; h += kSmallThreads) hay_off[h] = uint32_t(offsets[h] - off0);
     __syncthreads();
     const uint32_t n_bytes = hay_off[nh];
     for (uint32_t h = t; h < kSmallMaxHay + 1; h += kSmallThreads)
-        item_base[h] = h < nh ? (hay_off[h + 1] - hay_off[h] + kSmallChunk - 1) / kSmallChunk : 0u;
+        item_base[h] = h < nh ? (hay_off[h + 1] - hay_off[h] + kChunk - 1) / kChunk : 0u;
     {   // haystack bytes: 16 bytes per lane, coalesced, from pinned host memory (16-byte aligned by the host)
         const uint4 *src = reinterpret_cast<const uint4 *>(blob);
         uint4 *dst = reinterpret_cast<uint4 *>(in_bytes);
         for (uint32_t i = t; i < (n_bytes + 15u) / 16u; i += kSmallThreads) dst[i] = src[i];
-        const uint32_t tile_rows_b = A.row_bytes ? (kSmallTileBytes / A.row_bytes < A.trap ? kSmallTileBytes / A.row_bytes : A.trap) * A.row_bytes : 0u;
+        const uint32_t tile_rows_b = A.row_bytes ? (Y.tile_bytes / A.row_bytes < A.trap ? Y.tile_bytes / A.row_bytes : A.trap) * A.row_bytes : 0u;
         const uint4 *tsrc = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(A.lds_image) + A.tile_offset);
-        uint4 *tdst = reinterpret_cast<uint4 *>(smem + kSmallMaxBytes);
+        uint4 *tdst = reinterpret_cast<uint4 *>(smem + Y.in_bytes);
         for (uint32_t i = t; i < (tile_rows_b + 15u) / 16u; i += kSmallThreads) tdst[i] = tsrc[i];
         if (MODE == 0 && t < 256) cls[t] = A.class_off[t];
     }
     __syncthreads();
-    const uint32_t tile_rows = A.row_bytes ? (kSmallTileBytes / A.row_bytes < A.trap ? kSmallTileBytes / A.row_bytes : A.trap) : 0u;
-    const uint32_t n_items = small_scan(item_base, nh + 1, wave_tmp);  // item_base[h] = first item of haystack h; [nh] = total
+    stamp(0);   // offsets, bytes and tile are in LDS
+    const uint32_t tile_rows = A.row_bytes ? (Y.tile_bytes / A.row_bytes < A.trap ? Y.tile_bytes / A.row_bytes : A.trap) : 0u;
+    const uint32_t n_items = small_scan(item_base, nh + 1, wave_tmp);
+    stamp(1);  // item_base[h] = first item of haystack h; [nh] = total
 
     auto step = [&](uint32_t s, uint32_t byte) -> uint32_t {
         const uint32_t coff = class_offset<E, MODE>(A, cls, byte);
@@ -102,35 +132,45 @@ __global__ __launch_bounds__(kSmallThreads) void k_match_small(DevAutomaton A, c
             if (item_base[mid] <= i) lo = mid; else hi = mid;
         }
         h = lo;
-        pos0 = (i - item_base[h]) * kSmallChunk;
+        pos0 = (i - item_base[h]) * kChunk;
         begin = hay_off[h] + pos0;
         const uint32_t rest = hay_off[h + 1] - begin;
-        len = rest < kSmallChunk ? rest : kSmallChunk;
+        len = rest < kChunk ? rest : kChunk;
         const uint32_t wmax = max_pattern_length ? max_pattern_length - 1u : 0u;
         warm = pos0 < wmax ? pos0 : wmax;
     };
 
     // ---- walk: count events and records per item, keep the first kSmallEvents events ----
-    for (uint32_t i = t; i < kSmallMaxItems; i += kSmallThreads) {
+    for (uint32_t i = t; i < kItems; i += kSmallThreads) {
         uint32_t n_ev = 0, n_rec = 0;
         if (i < n_items) {
             uint32_t h, begin, len, warm, pos0;
             decode(i, h, begin, len, warm, pos0);
             uint32_t s = 0;
             const uint8_t *p = in_bytes + begin - warm;
-            for (uint32_t j = 0; j < warm + len; ++j) {
-                s = step(s, p[j]);
+            const uint32_t n = warm + len;
+            auto one = [&](uint32_t byte, uint32_t j) {
+                s = step(s, byte);
                 if (j >= warm && is_final(A, s)) {
                     n_rec += A.out_count[s];
                     if (n_ev < kSmallEvents) ev[i * kSmallEvents + n_ev] = make_uint2(pos0 + (j - warm) + 1u, s);
                     ++n_ev;
                 }
+            };
+            // (the bytes of four steps are read together, ahead of the steps: the text does not depend on the state, and with a
+            // handful of waves on the chip a dependent LDS read per byte in front of the table's was a third of a step)
+            uint32_t j = 0;
+            for (; j + 4u <= n; j += 4u) {
+                const uint32_t b0 = p[j], b1 = p[j + 1u], b2 = p[j + 2u], b3 = p[j + 3u];
+                one(b0, j); one(b1, j + 1u); one(b2, j + 2u); one(b3, j + 3u);
             }
+            for (; j < n; ++j) one(p[j], j);
         }
         cnt_ev[i] = n_ev;
         cnt_rec[i] = n_rec;
     }
     __syncthreads();
+    stamp(2);   // walked
     // ---- findAll == false: only the first event of each haystack (php_ahocorasick.c:588) ----
     if (!find_all) {
         for (uint32_t h = t; h < nh; h += kSmallThreads) {
@@ -147,11 +187,19 @@ __global__ __launch_bounds__(kSmallThreads) void k_match_small(DevAutomaton A, c
         __syncthreads();
     }
     // ---- record offsets ----
-    const uint32_t total = small_scan(cnt_rec, kSmallMaxItems, wave_tmp);  // cnt_rec[i] = first record of item i
+    const uint32_t total = small_scan(cnt_rec, kItems, wave_tmp);  // cnt_rec[i] = first record of item i
     for (uint32_t h = t; h <= nh; h += kSmallThreads)
-        out_prefix[h] = (h < nh && item_base[h] < kSmallMaxItems) ? cnt_rec[item_base[h]] : total;
+        out_prefix[h] = (h < nh && item_base[h] < kItems) ? cnt_rec[item_base[h]] : total;
     if (t == 0) { out_summary[0] = total; out_summary[1] = n_items; out_summary[2] = total > cap ? 1u : 0u; }
-    if (total > cap) return;
+    stamp(3);   // scanned, prefix written
+    // summary[3] = the call's sequence number, stored LAST behind a system-scope fence: the host polls it in its pinned memory
+    // instead of sleeping on the stream (an interrupt and a thread wake-up, ~ 8 us of a 30 us call)
+    if (total > cap) {
+        __threadfence_system();
+        __syncthreads();
+        if (t == 0) __hip_atomic_store(out_summary + 3, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     // ---- records ----
     for (uint32_t i = t; i < n_items; i += kSmallThreads) {
         const uint32_t n_ev = cnt_ev[i];
@@ -170,17 +218,22 @@ __global__ __launch_bounds__(kSmallThreads) void k_match_small(DevAutomaton A, c
             }
         }
     }
+    stamp(4);   // records written
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(out_summary + 3, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 hipError_t launch_match_small(const DevAutomaton &A, const uint64_t *offsets, const uint8_t *blob, uint32_t nh, int find_all,
                               uint32_t max_pattern_length, int entry_bytes, int class_mode, uint64_t *out_summary,
-                              uint64_t *out_prefix, void *out_records, uint32_t cap, hipStream_t st) {
-    const uint32_t lds = kSmallMaxBytes + kSmallTileBytes + kSmallMaxItems * (kSmallEvents * 8u + 8u) + (kSmallMaxHay + 8u) * 8u + 64u + 512u;
+                              uint64_t *out_prefix, void *out_records, uint32_t cap, uint32_t span_bytes, uint64_t seq, hipStream_t st) {
+    const SmallLayout Y = small_layout(span_bytes, nh, A.trap * A.row_bytes, class_mode == 0);
+    const uint32_t lds = Y.in_bytes + Y.tile_bytes + Y.max_items * (kSmallEvents * 8u + 8u) + (kSmallMaxHay + 8u) * 8u + 64u + 512u;
     auto go = [&](auto fn) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(kSmallLds));
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(fn, dim3(1), dim3(kSmallThreads), lds, st, A, offsets, blob, nh, uint32_t(find_all ? 1 : 0),
-                           max_pattern_length, out_summary, out_prefix, static_cast<uint4 *>(out_records), cap);
+                           max_pattern_length, out_summary, out_prefix, static_cast<uint4 *>(out_records), cap, Y, seq);
         return hipGetLastError();
     };
     if (entry_bytes == 2) return class_mode == 1 ? go(k_match_small<uint16_t, 1>) : go(k_match_small<uint16_t, 0>);

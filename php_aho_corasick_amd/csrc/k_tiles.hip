@@ -615,7 +615,7 @@ hipError_t launch_walk_tiles(const DevAutomaton &A, const BatchArgs &B, uint64_t
     T.tile_bytes = share - ring_bytes;
     const uint32_t lds = ring_bytes + T.tile_bytes + 16u + (class_mode == 0 ? 512u : 0u);
     const uint64_t groups = (max_items + uint64_t(kTilesWaves) * T.R - 1u) / (uint64_t(kTilesWaves) * T.R);
-    const uint32_t blocks = uint32_t(std::min<uint64_t>(groups, tiles_grid()));
+    const uint32_t blocks = uint32_t(std::min<uint64_t>(groups, tiles_grid() - 2u * std::min<uint32_t>(B.reserve_cus, tiles_grid() / 2u - 1u)));
     auto go = [&](auto fn) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return e;

@@ -42,7 +42,7 @@ void launch_refill(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items
 constexpr uint32_t kSmallPathMaxBytes = 64u * 1024u, kSmallPathMaxHay = 1024u;
 hipError_t launch_match_small(const DevAutomaton &A, const uint64_t *offsets, const uint8_t *blob, uint32_t nh, int find_all,
                               uint32_t max_pattern_length, int entry_bytes, int class_mode, uint64_t *out_summary,
-                              uint64_t *out_prefix, void *out_records, uint32_t cap, hipStream_t st);
+                              uint64_t *out_prefix, void *out_records, uint32_t cap, uint32_t span_bytes, uint64_t seq, hipStream_t st);
 void launch_build_level(const BuildArgs &T, uint32_t lo, uint32_t hi, hipStream_t st);
 void launch_build_by_position(const BuildArgs &T, uint32_t n, uint32_t *pos, uint32_t *fail_b, uint32_t *cnt_b, uint32_t *dict_b,
                               uint8_t *final_b, hipStream_t st);
@@ -50,8 +50,12 @@ void launch_replace_plan(const ReplaceArgs &R, hipStream_t st);
 void launch_replace_emit(const ReplaceArgs &R, uint64_t cap, hipStream_t st);
 // exclusive scan of n 64-bit values into out[0..n]; sync = {ticket, pad, scan_tiles(n + 1) status words}, zeroed; total_host (mapped, may be null) receives out[n]
 void launch_scan_u64(const uint64_t *in, uint64_t n, uint64_t *out, uint32_t *sync, uint64_t *total_host, hipStream_t st);
+// all-gatherv of the match arrays (k_misc.hip): this rank's slice of the global arrays + its records in the 8-byte wire form
+// {pos, pattern}; the other ranks' records expanded from the wire behind the exchange
 void launch_gather_pack(const uint64_t *prefix, const uint4 *records, uint64_t nh, uint64_t nrec, uint64_t hay_base, uint64_t rec_base,
-                        uint64_t *out_prefix, uint4 *out_records, uint64_t *closing, uint64_t total_rec, hipStream_t st);
+                        uint64_t *out_prefix, uint4 *out_records, uint2 *out_wire, uint64_t *closing, uint64_t total_rec, hipStream_t st);
+void launch_gather_unpack(const uint64_t *prefix, uint64_t total_hay, const uint2 *wire, uint64_t total_rec, uint64_t skip_lo, uint64_t skip_hi,
+                          const uint32_t *pattern_length, uint4 *out_records, hipStream_t st);
 // split pattern sets: the two parts' match arrays merged per haystack (position ascending, part A before part B at equal positions)
 void launch_merge_counts(const uint64_t *pa, const void *ra, const uint64_t *pb, const void *rb, uint32_t nh, uint32_t first_only, uint64_t *counts,
                          hipStream_t st);

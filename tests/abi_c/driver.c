@@ -10,9 +10,15 @@
  *   driver layout   print sizeof / offsetof of every ABI struct (compared with the ctypes mirror)
  *   driver cpu      lifecycle, status codes, pattern metadata -- no device needed
  *   driver kat      tests/test1.phpt (KAT-1) through acmi_match on the GPU, findAll true and false
+ *   driver comm8    BASELINE configs[3] in miniature, no python anywhere: the 65,536-pattern set (8..64 B, Sigma = 256) on EIGHT
+ *                   handles of this process, one thread each (acmi_comm_create_local), every rank matching its contiguous shard,
+ *                   then the all-gatherv and a gather to one root -- checked against one handle matching the whole batch
  */
+#define _POSIX_C_SOURCE 200809L
+#include <pthread.h>
 #include <stddef.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "acmi.h"
@@ -147,11 +153,149 @@ static int run_kat(void)
     return 0;
 }
 
+/* ---- comm8 ------------------------------------------------------------------------------------------------------ */
+#define W8 8
+#define NPAT 65536u
+#define NHAY 64u
+#define HAYLEN 4096u
+
+static uint64_t sm_state;
+static uint64_t splitmix(void)
+{
+    uint64_t z;
+    sm_state += 0x9E3779B97F4A7C15ull;
+    z = sm_state;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+typedef struct {
+    int rank;
+    acmi_handle *h;
+    acmi_comm *comm;
+    const uint8_t *blob;
+    const uint64_t *off;      /* global offsets, NHAY + 1 */
+    const uint64_t *ref_prefix;
+    const acmi_record *ref_rec;
+    size_t ref_n;
+    int failed;
+} rank_ctx;
+
+static int rank_body(rank_ctx *c)
+{
+    const size_t lo = (size_t)NHAY * (size_t)c->rank / W8, hi = (size_t)NHAY * (size_t)(c->rank + 1) / W8, nh = hi - lo;
+    uint64_t off[NHAY + 1];
+    const uint64_t *prefix = NULL;
+    const acmi_record *rec = NULL;
+    size_t n = 0, i;
+    const void *dp = NULL, *dr = NULL;
+    uint64_t g_rec = 0, g_hay = 0;
+    double sent = 0, received = 0;
+    uint64_t *hp;
+    acmi_record *hr;
+    int mode;
+    for (i = 0; i <= nh; i++) off[i] = c->off[lo + i] - c->off[lo];
+    CHECK(acmi_match_batch(c->h, c->blob + c->off[lo], off, nh, 1, &prefix, &rec, &n) == ACMI_OK);
+    CHECK(n == (size_t)(c->ref_prefix[hi] - c->ref_prefix[lo]));
+    hp = (uint64_t *)malloc((NHAY + 1) * sizeof(uint64_t));
+    hr = (acmi_record *)malloc((c->ref_n + 1) * sizeof(acmi_record));
+    CHECK(hp && hr);
+    for (mode = 0; mode < 2; mode++) {   /* 0: all-gatherv; 1: gather to rank 3 */
+        const int root = 3, receiver = mode == 0 || c->rank == root;
+        int rc = mode == 0 ? acmi_comm_allgather_result(c->comm, c->h, nh, &dp, &dr, &g_rec, &g_hay)
+                           : acmi_comm_gather_result(c->comm, c->h, nh, root, &dp, &dr, &g_rec, &g_hay);
+        if (rc != ACMI_OK) { fprintf(stderr, "rank %d: exchange: %s (%s)\n", c->rank, acmi_strerror(rc), acmi_comm_last_error(c->comm)); return 1; }
+        CHECK(g_rec == c->ref_n && g_hay == NHAY);
+        CHECK(acmi_comm_get_stat(c->comm, "bytes_sent", &sent) == ACMI_OK && acmi_comm_get_stat(c->comm, "bytes_received", &received) == ACMI_OK);
+        /* 8 bytes per record on the wire (half a record) + 8 per haystack; a gather's root sends nothing, its senders receive nothing */
+        CHECK(sent == ((mode == 1 && c->rank == root) ? 0.0 : (double)(8 * n + 8 * nh)));
+        CHECK(received == (receiver ? (double)(8 * (c->ref_n - n) + 8 * (NHAY - nh)) : 0.0));
+        if (!receiver) { CHECK(dp == NULL && dr == NULL); continue; }
+        CHECK(dp != NULL && acmi_comm_result_to_host(c->comm, hp, hr) == ACMI_OK);
+        CHECK(memcmp(hp, c->ref_prefix, (NHAY + 1) * sizeof(uint64_t)) == 0);
+        CHECK(memcmp(hr, c->ref_rec, c->ref_n * sizeof(acmi_record)) == 0);
+    }
+    free(hp);
+    free(hr);
+    return 0;
+}
+
+static void *rank_main(void *p)
+{
+    rank_ctx *c = (rank_ctx *)p;
+    c->failed = rank_body(c);
+    return NULL;
+}
+
+static int run_comm8(void)
+{
+    static uint8_t pat_bytes[NPAT * 64u];
+    static acmi_pattern pats[NPAT];
+    static uint8_t blob[NHAY * HAYLEN];
+    uint64_t off[NHAY + 1];
+    acmi_handle *h[W8], *whole = NULL;
+    acmi_comm *comm[W8];
+    rank_ctx ctx[W8];
+    pthread_t th[W8];
+    const uint64_t *prefix = NULL;
+    const acmi_record *rec = NULL;
+    uint64_t *ref_prefix;
+    acmi_record *ref_rec;
+    size_t n = 0, i, k, accepted = 0;
+    int r, bad = 0;
+    sm_state = 7;
+    for (i = 0; i < sizeof(pat_bytes); i++) pat_bytes[i] = (uint8_t)splitmix();
+    for (k = 0; k < NPAT; k++) {
+        pats[k].value = pat_bytes + 64u * k;
+        pats[k].length = 8u + (uint32_t)((k * 2654435761ull) >> 7) % 57u;
+        pats[k].id_type = ACMI_ID_NUMBER;
+        pats[k].id_number = (int64_t)k;
+        pats[k].user = 0;
+    }
+    for (i = 0; i < sizeof(blob); i++) blob[i] = (uint8_t)splitmix();
+    for (k = 0; k <= NHAY; k++) off[k] = (uint64_t)k * HAYLEN;
+    for (k = 0; k < NHAY; k++) {   /* two planted patterns per haystack */
+        const size_t p1 = (1021u * k + 17u) % NPAT, p2 = (4099u * k + 5u) % NPAT;
+        memcpy(blob + k * HAYLEN + (37u * k + 11u) % (HAYLEN / 2u - 64u), pats[p1].value, pats[p1].length);
+        memcpy(blob + k * HAYLEN + HAYLEN / 2u + (53u * k + 3u) % (HAYLEN / 2u - 64u), pats[p2].value, pats[p2].length);
+    }
+    /* one handle over the whole batch: what the ranks' shards must add up to */
+    CHECK(acmi_create(-1, &whole) == ACMI_OK && acmi_add_patterns(whole, pats, NPAT, &accepted) == ACMI_OK && accepted == NPAT);
+    CHECK(acmi_match_batch(whole, blob, off, NHAY, 1, &prefix, &rec, &n) == ACMI_OK);
+    CHECK(n >= 2u * NHAY);
+    ref_prefix = (uint64_t *)malloc((NHAY + 1) * sizeof(uint64_t));
+    ref_rec = (acmi_record *)malloc((n + 1) * sizeof(acmi_record));
+    CHECK(ref_prefix && ref_rec);
+    memcpy(ref_prefix, prefix, (NHAY + 1) * sizeof(uint64_t));
+    memcpy(ref_rec, rec, n * sizeof(acmi_record));
+    for (r = 0; r < W8; r++) {
+        CHECK(acmi_create(-1, &h[r]) == ACMI_OK && acmi_add_patterns(h[r], pats, NPAT, &accepted) == ACMI_OK);
+        CHECK(acmi_set_option(h[r], "small_path", 0) == ACMI_OK);   /* (the shards' results must stay on the device for the exchange) */
+        CHECK(acmi_finalize(h[r]) >= 0);
+    }
+    CHECK(acmi_comm_create_local(h, W8, comm) == ACMI_OK);
+    for (r = 0; r < W8; r++) {
+        ctx[r].rank = r; ctx[r].h = h[r]; ctx[r].comm = comm[r]; ctx[r].blob = blob; ctx[r].off = off;
+        ctx[r].ref_prefix = ref_prefix; ctx[r].ref_rec = ref_rec; ctx[r].ref_n = n; ctx[r].failed = 1;
+        CHECK(pthread_create(&th[r], NULL, rank_main, &ctx[r]) == 0);
+    }
+    for (r = 0; r < W8; r++) { pthread_join(th[r], NULL); bad |= ctx[r].failed; }
+    CHECK(!bad);
+    for (r = 0; r < W8; r++) { CHECK(acmi_comm_destroy(comm[r]) == ACMI_OK); CHECK(acmi_destroy(h[r]) == ACMI_OK); }
+    CHECK(acmi_destroy(whole) == ACMI_OK);
+    free(ref_prefix);
+    free(ref_rec);
+    printf("comm8 ok: %zu records of %u haystacks gathered on %d ranks\n", n, NHAY, W8);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     if (argc == 2 && strcmp(argv[1], "layout") == 0) return run_layout();
     if (argc == 2 && strcmp(argv[1], "cpu") == 0) return run_cpu();
     if (argc == 2 && strcmp(argv[1], "kat") == 0) return run_kat();
-    fprintf(stderr, "usage: %s layout|cpu|kat\n", argv[0]);
+    if (argc == 2 && strcmp(argv[1], "comm8") == 0) return run_comm8();
+    fprintf(stderr, "usage: %s layout|cpu|kat|comm8\n", argv[0]);
     return 2;
 }

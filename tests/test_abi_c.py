@@ -32,7 +32,7 @@ def driver():
     if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(SRC), os.path.getmtime(N.LIB_PATH),
                                                                os.path.getmtime(os.path.join(ROOT, "include", "acmi.h"))):
         subprocess.run([gcc, "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-O1", "-I" + os.path.join(ROOT, "include"), SRC,
-                        "-L" + PKG, "-lacmi", "-Wl,-rpath," + PKG, "-Wl,-rpath-link," + _hip_lib_dir(), "-o", EXE], check=True)
+                        "-L" + PKG, "-lacmi", "-pthread", "-Wl,-rpath," + PKG, "-Wl,-rpath-link," + _hip_lib_dir(), "-o", EXE], check=True)
     env = dict(os.environ)
     env["LD_LIBRARY_PATH"] = _hip_lib_dir() + ":" + env.get("LD_LIBRARY_PATH", "")
 
@@ -63,3 +63,11 @@ def test_kat1_through_acmi_match_from_c(driver):
     """tests/test1.phpt through acmi_match(), no python in the call path."""
     out = driver("kat")
     assert out.returncode == 0 and out.stdout.strip().endswith("kat ok"), out.stderr + out.stdout
+
+
+@pytest.mark.gpu
+def test_eight_ranks_of_one_process_exchange_config3_results_from_c(driver):
+    """acmi_comm_create_local with W = 8 handles of the 65,536-pattern set, a thread per rank, all-gatherv and gather-to-root:
+    8-byte wire records (bytes_sent = 8 per record + 8 per haystack), results equal to one handle over the whole batch."""
+    out = driver("comm8")
+    assert out.returncode == 0 and "comm8 ok" in out.stdout, out.stderr[-3000:] + out.stdout[-1000:]

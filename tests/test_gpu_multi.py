@@ -147,7 +147,7 @@ def test_allgatherv_layout_with_several_ranks_on_one_gpu(name, world, find_all):
     sizes = []
     for r in range(world):
         lo, hi = batch.shard_range(ds.n_haystacks, r, world)
-        sizes.append((int(pe[hi] - pe[lo]) * 16 + (hi - lo) * 8))
+        sizes.append((int(pe[hi] - pe[lo]) * 8 + (hi - lo) * 8))   # 8 bytes per record on the wire {pos, pattern}, 8 per haystack
     for r, (rc, prefix, rec, st) in enumerate(out):
         assert rc == 0, out[r]
         assert np.array_equal(prefix, pe) and np.array_equal(rec.reshape(-1, 4), re_), (name, r)
