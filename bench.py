@@ -762,6 +762,7 @@ def main():
     ap.add_argument("--in-flight", type=int, default=2, help="batches begun before the oldest is ended (1 or 2)")
     ap.add_argument("--phase-times", action="store_true", help="analysis: add the host time per step phase to the JSON")
     ap.add_argument("--items-ahead", action="store_true", help="analysis: every batch's item table on the handle's side stream (acmi.h \"items_ahead\" 1; measured: no gain)")
+    ap.add_argument("--offsets-entry", action="store_true", help="time acmi_match_batch_device_begin (explicit offsets array) instead of _begin_uniform")
     ap.add_argument("--reserve-cus", type=int, default=0, help="analysis: acmi.h \"reserve_cus\" -- the scan leaves N compute units to a collective in flight")
     ap.add_argument("--no-c-abi-gather", action="store_true", help="N > 1: skip the untimed exchange through acmi_comm_* after the timed steps")
     args = ap.parse_args()
@@ -866,7 +867,12 @@ def main():
 
     def begin_one():
         t_a = time.perf_counter()
-        batch.match_device_begin(res, d_blob, d_off, True)
+        # (the batch is uniform -- every haystack wl.hay_len bytes, back to back, like examples/benchmark.php's buffers: the entry
+        # for that shape needs no offsets array and writes the work-item table in closed form; --offsets-entry: the general one)
+        if args.offsets_entry:
+            batch.match_device_begin(res, d_blob, d_off, True)
+        else:
+            batch.match_device_begin_uniform(res, d_blob, wl.hay_len, nh, True)
         phase["begin"] += time.perf_counter() - t_a
 
     def end_one():
@@ -994,7 +1000,8 @@ def main():
                        "patterns": ds.n_patterns, "haystacks_per_gpu": nh, "haystack_bytes": wl.hay_len,
                        "states": int(res.stat("states")), "hot_states": int(res.stat("hot_states")),
                        "lds_tile_bytes": int(res.stat("lds_image_bytes")), "work_item_bytes": int(res.stat("chunk_bytes")),
-                       "ilp": args.ilp or 1, "items_ahead": int(args.items_ahead), "reserve_cus": args.reserve_cus, "sharding": f"{world} contiguous haystack ranges, {backend} all-gatherv of match arrays" if world > 1 else "none"},
+                       "ilp": args.ilp or 1, "items_ahead": int(args.items_ahead), "reserve_cus": args.reserve_cus,
+                       "entry": "acmi_match_batch_device_begin" if args.offsets_entry else "acmi_match_batch_device_begin_uniform", "sharding": f"{world} contiguous haystack ranges, {backend} all-gatherv of match arrays" if world > 1 else "none"},
             "ranks": {"launched": world, "process_group": (dist.get_world_size() if gather else 1), "joined_a_collective": ranks_in_collective,
                       "backend": backend if gather else None, "gpus_on_box": n_dev,
                       "gathered_records": gathered_records, "gathered_haystacks": gathered_haystacks, "c_abi_exchange": None,

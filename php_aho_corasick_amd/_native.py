@@ -76,6 +76,7 @@ SYMBOLS = {
     "acmi_match_batch_device": (C.c_int, [Handle, C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t, C.c_int,
                                           C.POINTER(C.c_uint64)]),
     "acmi_match_batch_device_begin": (C.c_int, [Handle, C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t, C.c_int]),
+    "acmi_match_batch_device_begin_uniform": (C.c_int, [Handle, C.c_void_p, C.c_uint64, C.c_size_t, C.c_int]),
     "acmi_match_batch_device_end": (C.c_int, [Handle, C.POINTER(C.c_uint64)]),
     "acmi_result_device": (C.c_int, [Handle, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                      C.POINTER(C.c_uint64)]),

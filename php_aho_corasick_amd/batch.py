@@ -75,6 +75,14 @@ def match_device_begin(res: AhoResource, d_blob, d_off, find_all: bool = True) -
                                                 1 if find_all else 0), res._h)
 
 
+def match_device_begin_uniform(res: AhoResource, d_blob, haystack_bytes: int, n_haystacks: int, find_all: bool = True) -> None:
+    """``match_device_begin`` for a batch of ``n_haystacks`` haystacks of ``haystack_bytes`` each, back to back in ``d_blob``: no
+    offsets tensor; the library writes the work-item table in closed form (acmi.h)."""
+    assert d_blob.is_cuda and d_blob.is_contiguous() and d_blob.numel() >= haystack_bytes * n_haystacks
+    N.check(N.lib.acmi_match_batch_device_begin_uniform(res._h, C.c_void_p(d_blob.data_ptr()), haystack_bytes, n_haystacks,
+                                                        1 if find_all else 0), res._h)
+
+
 def match_device_end(res: AhoResource) -> int:
     """Wait for the OLDEST batch enqueued by ``match_device_begin``; returns its record count.  Its result
     (``result_view`` / ``result_numpy`` / ...) stays valid until the second begin after its own."""

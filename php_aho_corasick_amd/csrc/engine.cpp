@@ -173,6 +173,11 @@ struct acmi_handle {
     // workspace (grow-only)
     DevBuf d_blob, d_off, d_rec_base, d_slab, d_ovf, d_counters, d_runs, d_run_count, d_first;
     DevBuf d_tile_queue, d_tile_sync;   // k_walk_tiles: the waves' event queues; {ticket, look-back words}
+    // uniform batches (acmi_match_batch_device_begin_uniform): the offsets array the library makes itself, one per slot, and the
+    // geometry it holds; uniform_len != 0 while such a batch is being enqueued
+    DevBuf d_uni_off[2];
+    uint64_t uni_nh[2] = {0, 0}, uni_len[2] = {0, 0};
+    uint64_t uniform_len = 0;
     // The item table of a batch (item_base, item -> haystack, packed item records, zeroed per-item counters, k_items' own sync
     // words) exists once per slot: k_items needs nothing from the batch before, so with "items_ahead" it runs on a side stream
     // while that batch's scan is still on the chip, and the pipeline proper waits for its event.
@@ -835,6 +840,7 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
         for (acmi_handle *c : h->part) {
             c->stream = h->stream;
             c->profile = h->profile;
+            c->uniform_len = h->uniform_len;
             c->merge_into = acmi_handle::MergeInto{};
             if (c == h->part[1] && find_all && nh && tiles_can_merge(c->dA, int(c->aut.flat().entry_bytes))) {
                 // the short part's tile walk can place the long part's records among its own as it writes them: no merge pass
@@ -1095,7 +1101,8 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
         // batch had no pipeline, failed, or this k_items runs ahead of it)
         if (!h->isync_clean[slot_index] || ist != st) HIPCHK(h, hipMemsetAsync(d_isync.p, 0, d_isync.cap & ~size_t(15), ist));
         h->isync_clean[slot_index] = false;
-        launch_items(B, blob_bytes, max_items, d_item_base.as<uint64_t>(), d_isync.as<uint32_t>(), ist);
+        if (h->uniform_len && blob_bytes == h->uniform_len * nh) launch_items_uniform(B, h->uniform_len, d_item_base.as<uint64_t>(), ist);
+        else launch_items(B, blob_bytes, max_items, d_item_base.as<uint64_t>(), d_isync.as<uint32_t>(), ist);
         if (ist != st) {
             HIPCHK(h, hipEventRecord(h->ev_items[slot_index], ist));
             HIPCHK(h, hipStreamWaitEvent(st, h->ev_items[slot_index], 0));
@@ -1565,7 +1572,7 @@ int acmi_destroy(acmi_handle *h) {
             for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_out_off, &h->d_out_list, &h->d_cold_rec, &h->d_cold_edges, &h->d_chain_byte, &h->d_chain_run, &h->d_slot_pair, &h->d_pairs, &h->d_pat_bytes, &h->d_dense_img, &h->d_merge_counts, &h->d_merge_sync, &h->d_rep_off, &h->d_rep_bytes, &h->d_plan, &h->d_plan_out, &h->d_tail_out, &h->d_rep_sync, &h->d_nom_count, &h->d_out_len, &h->d_rep_out_off, &h->d_rep_out, &h->d_blob,
                               &h->d_off, &h->d_sync[0], &h->d_sync[1], &h->d_item_base[0], &h->d_item_hay[0], &h->d_item_rec[0], &h->d_zero[0], &h->d_isync[0],
                               &h->d_item_base[1], &h->d_item_hay[1], &h->d_item_rec[1], &h->d_zero[1], &h->d_isync[1],
-                              &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_first, &h->d_tile_queue, &h->d_tile_sync, &h->fly[0].d_prefix, &h->fly[0].d_out, &h->fly[1].d_prefix, &h->fly[1].d_out, &h->d_runs, &h->d_run_count})
+                              &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_first, &h->d_tile_queue, &h->d_tile_sync, &h->d_uni_off[0], &h->d_uni_off[1], &h->fly[0].d_prefix, &h->fly[0].d_out, &h->fly[1].d_prefix, &h->fly[1].d_out, &h->d_runs, &h->d_run_count})
                 b->release();
             for (void *q : h->retired) (void)hipFree(q);
             for (auto &evt : h->ev)
@@ -1609,6 +1616,28 @@ int acmi_match_batch_device_begin(acmi_handle *h, const void *d_blob, uint64_t b
         if (n_haystacks && !d_offsets) return ACMI_E_ARG;
         return run_batch_begin(h, static_cast<const uint8_t *>(d_blob), blob_bytes, static_cast<const uint64_t *>(d_offsets),
                                n_haystacks, find_all);
+    });
+}
+
+int acmi_match_batch_device_begin_uniform(acmi_handle *h, const void *d_blob, uint64_t haystack_bytes, size_t n_haystacks, int find_all) {
+    return guarded(h, [&]() -> int {
+        int rc = check_ready(h);
+        if (rc < 0) return rc;
+        if (haystack_bytes >= 0xFFFFFFFFull) { h->last_error = "haystack of 4 GiB or more"; return ACMI_E_ARG; }
+        if (h->begin_seq - h->end_seq >= 2) { h->last_error = "two batches are in flight already: end the older one first"; return ACMI_E_ARG; }
+        // the offsets array of this geometry: the slot's own copy, written again only when the geometry changes
+        const int slot = int((h->begin_seq + 1) & 1);
+        if (n_haystacks && (h->uni_nh[slot] != n_haystacks || h->uni_len[slot] != haystack_bytes || !h->d_uni_off[slot].p)) {
+            HIPCHK(h, h->d_uni_off[slot].ensure_keep((n_haystacks + 1) * 8, h->retired));
+            launch_uniform_offsets(h->d_uni_off[slot].as<uint64_t>(), n_haystacks, haystack_bytes, h->stream);
+            HIPCHK(h, hipGetLastError());
+            h->uni_nh[slot] = n_haystacks;
+            h->uni_len[slot] = haystack_bytes;
+        }
+        h->uniform_len = haystack_bytes;
+        rc = run_batch_begin(h, static_cast<const uint8_t *>(d_blob), haystack_bytes * n_haystacks, h->d_uni_off[slot].as<uint64_t>(), n_haystacks, find_all);
+        h->uniform_len = 0;
+        return rc;
     });
 }
 

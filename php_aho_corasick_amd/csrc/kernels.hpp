@@ -14,6 +14,9 @@ namespace acmi {
 uint32_t scan_tiles(uint64_t n);
 // isync: 8 + 8 x scan_tiles(n_haystacks + 1) zeroed bytes {ticket, bad-offsets flag, status words}
 void launch_items(const BatchArgs &B, uint64_t blob_bytes, uint64_t max_items, uint64_t *item_base, uint32_t *isync, hipStream_t st);
+// uniform batches (every haystack `haystack_bytes` long, back to back): the item table in closed form; the offsets array itself
+void launch_items_uniform(const BatchArgs &B, uint64_t haystack_bytes, uint64_t *item_base, hipStream_t st);
+void launch_uniform_offsets(uint64_t *offsets, uint64_t n, uint64_t haystack_bytes, hipStream_t st);
 hipError_t launch_scan(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int kernel,
                        int class_mode, int ilp, int group_quads, hipStream_t st, uint32_t *anchor_variant = nullptr);
 hipError_t launch_walk_runs(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,

@@ -607,3 +607,42 @@ def test_anchor_occurrences_at_and_across_haystack_borders(plen, short_rows):
             assert np.array_equal(p, pe) and np.array_equal(r, re_), (find_all, path.__name__)
     api.ahocorasick_deinit(res)
     o.close()
+
+
+def test_uniform_batch_entry_equals_the_offsets_entry():
+    """acmi_match_batch_device_begin_uniform: haystacks of one length, back to back, no offsets array -- the same records as the
+    general entry for one item per haystack, chunked haystacks, tiny ones, a geometry that changes between two batches in flight,
+    and findAll = false."""
+    import torch
+    from php_aho_corasick_amd import batch
+    ds = synth.g2()
+    o = Oracle("port")
+    o.add_patterns((ds.pat_blob, ds.pat_off))
+    blob = ds.hay_blob
+    d_blob = torch.from_numpy(blob).cuda()
+    for options in ({}, dict(kernel=1), dict(kernel=6), dict(chunk_bytes=1024), dict(kernel=4, chunk_bytes=256)):
+        res = resource_for(ds, **options)
+        batch.bind_current_stream(res)
+        shapes = [(8192, 256), (4096, 512), (256, 8192), (8192, 100), (65536, 32)]
+        want = {}
+        for hl, nh in shapes:
+            off = np.arange(nh + 1, dtype=np.uint64) * np.uint64(hl)
+            want[(hl, nh)] = o.match_batch(blob[:hl * nh], off, True)
+        # two in flight, the geometry changing from batch to batch
+        began = ended = 0
+        while ended < len(shapes):
+            while began < len(shapes) and began - ended < 2:
+                batch.match_device_begin_uniform(res, d_blob, shapes[began][0], shapes[began][1], True)
+                began += 1
+            total = batch.match_device_end(res)
+            hl, nh = shapes[ended]
+            p, r = batch.result_numpy(res, nh, total)
+            assert np.array_equal(p, want[(hl, nh)][0]) and np.array_equal(r, want[(hl, nh)][1]), (options, hl, nh)
+            ended += 1
+        batch.match_device_begin_uniform(res, d_blob, 8192, 256, False)
+        total = batch.match_device_end(res)
+        pf, rf = o.match_batch(blob, ds.hay_off, False)
+        p, r = batch.result_numpy(res, 256, total)
+        assert np.array_equal(p, pf) and np.array_equal(r, rf)
+        api.ahocorasick_deinit(res)
+    o.close()
