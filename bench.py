@@ -88,7 +88,15 @@ def cpu_baseline(ds, seconds_target: float = 12.0):
     # All cores: one trie replica and ONE call per thread, the repetitions looped in C (*_php_scan_checksum_reps) over the whole
     # sample -- >= 0.5 s of trie work per thread.  (Round 3 gave each thread 8 haystacks x 14 Python-level calls: 22 ms of work
     # behind 3,584 GIL hand-overs, 13.7 x one core on 256 cores -- that measured the interpreter.)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = visible
+    quota = _cgroup_cpu_max()
+    try:   # "1600000 100000": this container may use 16 CPUs' worth of time however many it sees -- more threads only take turns
+        q, period = quota.split()
+        if q != "max":
+            cores = max(1, min(visible, int(round(int(q) / int(period)))))
+    except Exception:
+        pass
     tries = [make()[0] for _ in range(cores)]
     per_pass = probe   # seconds one thread needs for one pass over the sample
     reps_mt = max(1, int(round(max(0.8, seconds_target / 8) / max(per_pass, 1e-3))))
@@ -103,7 +111,7 @@ def cpu_baseline(ds, seconds_target: float = 12.0):
     dt = time.perf_counter() - t0
     allc = {"value": round(cores * reps_mt * len(sub_blob) / dt / 1e9, 5), "unit": "GB/s", "cores": cores,
             "kind": kind, "speedup_over_one_core": round(cores * reps_mt * len(sub_blob) / dt / 1e9 / one["value"], 1),
-            "cgroup_cpu_max": _cgroup_cpu_max(),
+            "cores_visible": visible, "cgroup_cpu_max": quota,
             "sample": f"{cores} threads x {reps_mt} x {nh} haystacks x {HAY_LEN} B ({reps_mt * len(sub_blob) >> 20} MiB each), one trie replica and one C call per thread"}
     return one, allc
 
