@@ -1,0 +1,109 @@
+// engine_choice.cpp -- automatic mode: the measured choice of the scan strategy
+#include "engine.hpp"
+
+namespace acmi_engine {
+
+// ---- automatic mode: the measured choice of the scan strategy --------------------------------------------------------------
+// Batches are told apart by size (small ones are launch-bound whatever scans them) and by whether their haystacks are short
+// (under 512 B on average: the anchor kernel spends a wave step per work item, the walks a lane): what one kind of batch
+// taught the handle says little about the other.
+int choice_class(uint64_t blob_bytes, size_t nh) {
+    const int size = blob_bytes < (16ull << 20) ? 0 : blob_bytes < (256ull << 20) ? 1 : blob_bytes < (4ull << 30) ? 2 : 3;
+    return size | ((nh && blob_bytes / nh < 512) ? 4 : 0);
+}
+
+// What a GiB is EXPECTED to cost (ms) on a strategy this handle has not run yet: the rate the kernel reaches on text it
+// suits.  Only decides whether an untried alternative is worth a probe (one whose best case is no better than what the current
+// strategy measures is never tried); every decision between strategies that have run is taken on measured times.
+float nominal_cost(const acmi_handle *h, int strat, uint64_t blob_bytes, size_t nh, double density) {
+    const FlatAutomaton &fa = h->aut.flat();
+    const double avg = nh ? double(blob_bytes) / double(nh) : 0.0;
+    // `density` = records per byte of the batch just ended: what the text is like is known even for a strategy that never ran on
+    // it -- the filter pays for every candidate (a match is one), the optimistic pass walks again wherever there is an event,
+    // every record is 16 bytes written (17 GB per GiB of text at a record per byte).  Without these terms a^1..a^16 kept
+    // probing kernels that had no chance (each probe a batch at a third of the rate).
+    switch (strat) {
+    case acmi_handle::kStratAnchor: {
+        double c = fa.anchor_dense ? 0.45 : fa.anchor_mode == 2 ? 0.30 : 0.19;
+        if (avg < 2048.0) c *= 2048.0 / std::max(avg, 128.0) * 0.5 + 0.5;          // (a wave step per work item: short haystacks idle its lanes)
+        return float(c + density * 250.0);
+    }
+    case acmi_handle::kStratLds: return float((fa.compact ? 2.0 : 0.33) + density * 300.0);
+    case acmi_handle::kStratTiles: {
+        const bool allhot = uint64_t(fa.trap) * (fa.n_columns * fa.entry_bytes + 4u) <= 60u * 1024u && fa.trap + 1u == fa.n_states;
+        return float((fa.compact ? 6.0 : allhot ? 1.0 : 1.7) + density * (density > 0.25 ? 20.0 : 4.5));   // (past an event per 4 bytes: the second walk)
+    }
+    default: return float((fa.compact ? 8.0 : 1.3) + density * 3.5);
+    }
+}
+
+bool strategy_eligible(const acmi_handle *h, int strat, uint64_t blob_bytes, size_t nh, int find_all) {
+    const FlatAutomaton &fa = h->aut.flat();
+    uint32_t w = 0, p = 0;
+    switch (strat) {
+    case acmi_handle::kStratAnchor: return fa.anchor_q != 0;
+    case acmi_handle::kStratTiles: return find_all && tiles_geometry(fa.max_pattern_length, fa.n_states, blob_bytes, nh, &w, &p);
+    default: return true;
+    }
+}
+
+// Where a handle starts, before anything is measured: what the pattern set suggests.
+int seed_strategy(const acmi_handle *h, uint64_t blob_bytes, size_t nh, int find_all) {
+    const FlatAutomaton &fa = h->aut.flat();
+    // text over the patterns' own alphabet would flag more of an 8 KiB item than its run list holds (keyword lists, dense sets):
+    // the optimistic LDS-tile pass ends up walking whole items anyway
+    const bool flagged = fa.est_flag_rate * 8192.0 > double(h->run_cap) && !h->is_part;
+    if (fa.anchor_q && !(blob_bytes >= kAutoMinBytes && nh && blob_bytes / nh < kSmallItemBytes && !flagged)) return acmi_handle::kStratAnchor;
+    if (!flagged) return acmi_handle::kStratLds;
+    // the wave drain writes output denser than a record per two bytes as whole rows; everything else in one pass
+    if (!h->dense_output && strategy_eligible(h, acmi_handle::kStratTiles, blob_bytes, nh, find_all)) return acmi_handle::kStratTiles;
+    return acmi_handle::kStratItems;
+}
+
+int choose_strategy(acmi_handle *h, acmi_handle::FlySlot &F, uint64_t blob_bytes, size_t nh, int find_all) {
+    acmi_handle::ChoiceClass &C = h->choice[find_all ? 1 : 0][F.choice_class];
+    F.probe = false;
+    if (C.cur < 0 || !strategy_eligible(h, C.cur, blob_bytes, nh, find_all)) C.cur = seed_strategy(h, blob_bytes, nh, find_all);
+    if (blob_bytes < kAutoMinBytes) return C.cur;   // (launch-bound either way: decides nothing, probes nothing)
+    for (int s = 0; s < acmi_handle::kStratCount; ++s)
+        if (C.wait[s]) --C.wait[s];
+    for (int s = 0; s < acmi_handle::kStratCount; ++s) {
+        if (!(C.pending >> s & 1u)) continue;
+        C.pending &= ~(1u << s);
+        if (s == C.cur || !strategy_eligible(h, s, blob_bytes, nh, find_all)) continue;
+        F.probe = true;
+        ++h->probes;
+        return s;
+    }
+    return C.cur;
+}
+
+void learn_strategy(acmi_handle *h, const acmi_handle::FlySlot &F, double ms_per_gib, double density) {
+    acmi_handle::ChoiceClass &C = h->choice[F.find_all ? 1 : 0][F.choice_class];
+    const int s = F.strategy;
+    C.cost[s] = C.cost[s] > 0.f ? 0.5f * C.cost[s] + 0.5f * float(ms_per_gib) : float(ms_per_gib);
+    if (F.probe && s != C.cur) {
+        // a probe wins when it is at least 1.25 x cheaper than what the strategy in use costs now; a lost one backs off
+        if (C.cost[C.cur] > 0.f && C.cost[s] * 1.25f < C.cost[C.cur]) {
+            C.cur = s;
+            C.span[s] = 16;
+            ++h->switches;
+        } else {
+            C.wait[s] = C.span[s];
+            C.span[s] = std::min<uint32_t>(C.span[s] * 2, 1024);
+        }
+        return;
+    }
+    if (s != C.cur) return;
+    // The strategy in use: every alternative whose kernel, on text that suits it, would be clearly cheaper than this is probed --
+    // once its back-off allows: what it cost on EARLIER text (a filter that lost on dense matches) does not keep it out for good,
+    // the text may have changed.  (Expected cost: the kernel's rate plus what any pipeline costs whatever it scans, ~ 60 us --
+    // small batches are launch-bound on every strategy and probe nothing.)
+    for (int a = 0; a < acmi_handle::kStratCount; ++a) {
+        if (a == s || C.wait[a] || !strategy_eligible(h, a, F.blob_bytes, F.nh, F.find_all)) continue;
+        const float ref = nominal_cost(h, a, F.blob_bytes, F.nh, density) + 0.06f * float(1ull << 30) / float(F.blob_bytes);
+        if (C.cost[s] > 1.5f * ref) C.pending |= 1u << a;
+    }
+}
+
+}  // namespace acmi_engine
