@@ -377,7 +377,10 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
     // -- ids follow BFS order within a class: [0, shallow_hot) and (trap, shallow_cold_end); the exact walk of an anchor
     // candidate stops on them, see run_epilogue: no pattern begun at the candidate's window can still be alive there) and
     // the events + tile exits per byte of uniform text over the used alphabet (see est_flag_rate).
-    std::vector<uint8_t> in_chain(compact ? ns : 0, 0);
+    // Dense-row automata number the same chains the same way: the rows of one planted occurrence then share two or three
+    // 128-byte lines instead of one line per byte, and walk_fast skips along them by comparing 16 bytes at a time.
+    const uint32_t chain_from = compact ? dense : hot;
+    std::vector<uint8_t> in_chain(ns, 0);
     uint32_t hot_nf = 0, cold_nf = 0, cold_chain = 0, dense_cold_nf = 0, dense_cold_f = 0;
     {
         uint32_t sh = 0, sc = 0;
@@ -391,7 +394,7 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
             const uint32_t d = depth[i];
             if (!fin) {
                 (i < hot ? hot_nf : cold_nf)++;
-                if (compact && i >= dense && d >= 3 && cfirst[i + 1] - cfirst[i] == 1) { in_chain[i] = 1; ++cold_chain; }
+                if (i >= chain_from && d >= 3 && cfirst[i + 1] - cfirst[i] == 1) { in_chain[i] = 1; ++cold_chain; }
                 if (d <= 2) (i < hot ? sh : sc)++;
             }
             if (i >= hot && i < dense) (fin ? dense_cold_f : dense_cold_nf)++;
@@ -423,14 +426,14 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
         for (uint32_t i = 0; i < ns; ++i) {
             if (i < hot) newid[i] = final_b[i] ? b++ : a++;
             else if (final_b[i]) newid[i] = d++;
-            else if (!compact || !in_chain[i]) newid[i] = c++;
+            else if (!in_chain[i]) newid[i] = c++;
         }
     }
     if (cold_chain) {
         // a chain is numbered from its head (the first of its states whose parent is not of this kind) along its only
         // children; the heads in BFS order
         uint32_t c = chain_lo;
-        for (uint32_t i = dense; i < ns; ++i) {
+        for (uint32_t i = chain_from; i < ns; ++i) {
             if (!in_chain[i] || in_chain[parent_pos[i]]) continue;
             for (uint32_t j = i; j < ns && in_chain[j]; j = cfirst[j]) newid[j] = c++;
         }
@@ -471,16 +474,21 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
     lap("  cold records");
     fa.chain_byte.clear();
     fa.chain_run.clear();
-    if (compact && cold_chain) {
+    if (cold_chain) {
         fa.chain_byte.assign(size_t(cold_chain) + 16, 0);
         fa.chain_run.assign(size_t(cold_chain) + 16, 0);
+        std::vector<uint32_t> child(cold_chain, 0);
+        for (uint32_t i = chain_from; i < ns; ++i) {
+            if (!in_chain[i]) continue;
+            const uint32_t k = newid[i] - chain_lo, c0 = cfirst[i];
+            fa.chain_byte[k] = byte_b[c0];
+            child[k] = newid[c0];
+        }
         for (uint32_t id = fa.f2; id-- > chain_lo;) {  // backwards: a state's run extends its successor's
-            const uint32_t x = fa.cold_rec[size_t(id) * 2];
             const uint32_t k = id - chain_lo;
-            fa.chain_byte[k] = uint8_t(x & 0xffu);
             // steps that can be taken blindly: the states they LAND on must be of this kind too (non-final, deeper
             // than 2: no event, no early stop to test); a child numbered elsewhere or a final one ends the run
-            if ((x >> 8) != id + 1 || id + 1 >= fa.f2) continue;
+            if (child[k] != id + 1 || id + 1 >= fa.f2) continue;
             fa.chain_run[k] = uint8_t(std::min<uint32_t>(255u, 1u + fa.chain_run[k + 1]));
         }
     }

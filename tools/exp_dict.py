@@ -19,12 +19,14 @@ for N in [int(a) for a in sys.argv[1:]] or [2048, 8192, 16384, 65536]:
     ds = synth.Dataset("words", pats.pat_blob, pats.pat_off, text.hay_blob, text.hay_off)
     t0 = time.perf_counter()
     res = api.ahocorasick_init([{"id": k, "value": p} for k, p in enumerate(ds.patterns())])
+    if os.environ.get('KERNEL'):
+        res.set_option('kernel', int(os.environ['KERNEL']))
     api.ahocorasick_finalize(res)
     build = time.perf_counter() - t0
     d_blob = torch.from_numpy(ds.hay_blob).cuda().repeat(NH // TILE).contiguous()
     d_off = torch.arange(NH + 1, dtype=torch.int64, device="cuda") * HL
     batch.bind_current_stream(res)
-    for _ in range(4):
+    for _ in range(12):
         total = batch.match_device(res, d_blob, d_off)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
