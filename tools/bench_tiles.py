@@ -53,7 +53,7 @@ for c in cases:
     elif c.startswith("prose"):
         w = synth.density_set("words")
         ds = synth.prose(w, int(c[5:]) / 100.0)
-        run(c, w.patterns(), ds.hay_blob, nh, [dict(kernel=3), dict(kernel=2), dict(kernel=4), dict(kernel=6), dict(kernel=1)])
+        run(c, w.patterns(), ds.hay_blob, nh, [dict(kernel=int(os.environ['K']))] if os.environ.get('K') else [dict(kernel=3), dict(kernel=2), dict(kernel=4), dict(kernel=6), dict(kernel=1)])
     elif c.startswith("headline"):
         per = int(c[8:])
         ds = synth.bench_batch(2048, HL, seed=1, planted=False)
@@ -64,4 +64,4 @@ for c in cases:
                 p = np.frombuffer(ds.pattern(int(r.integers(2048))), dtype=np.uint8)
                 at = h * HL + (HL // per) * k + int(r.integers(0, max(1, HL // per - 16)))
                 blob[at:at + 16] = p
-        run(c, ds.patterns(), blob, nh, [dict(kernel=2, chunk_bytes=1024), dict(kernel=2, chunk_bytes=512), dict(kernel=2, chunk_bytes=2048), dict(kernel=2, run_cap=64), dict(kernel=2, run_cap=256, slab_events=256)][(-1 if os.environ.get('ANCHOR') == '2' else 0):] if os.environ.get('ANCHOR') else [dict(kernel=3), dict(kernel=2), dict(kernel=1), dict(kernel=4), dict(kernel=6)])
+        run(c, ds.patterns(), blob, nh, [dict(kernel=2, chunk_bytes=1024), dict(kernel=2, chunk_bytes=512), dict(kernel=2, chunk_bytes=2048), dict(kernel=2, run_cap=64), dict(kernel=2, run_cap=256, slab_events=256)][(-1 if os.environ.get('ANCHOR') == '2' else 0):] if os.environ.get('ANCHOR') else [dict(kernel=int(os.environ['K']))] if os.environ.get('K') else [dict(kernel=3), dict(kernel=2), dict(kernel=1), dict(kernel=4), dict(kernel=6)])
