@@ -43,7 +43,7 @@ struct TileArgs {
     uint32_t back;        // bytes a lane enters its piece early = Lmax - 1
     uint32_t qcap;        // queue entries per wave (a multiple of 64)
     uint32_t tile_bytes;  // LDS budget of the table tile (+ record counts)
-    uint32_t flags;       // analysis only (ACMI_TILES_DEBUG): 1 no expansion, 2 no events
+    uint32_t flags;       // reserved (0)
     uint2 *queue;         // grid waves x qcap entries
     uint32_t *ticket;     // zeroed
     uint64_t *status;     // zeroed, one word per workgroup tile
@@ -165,7 +165,10 @@ __device__ __forceinline__ void tiles_walk(const DevAutomaton &A, const Piece &p
         const bool ev = inside && tiles_final<E, ALLHOT>(A, L, st);
         if constexpr (LANEQ) {
             if (ev) {
-                if (Q.n_ev < kTilesLaneCap) Q.lists[Q.n_ev * 64u + lane] = st | jj << 16;
+                // (a list that overflows is not used -- the lane walks its piece again, tiles_emit --: its last entry may as well
+                // be overwritten, and the store needs no test of its own)
+                const uint32_t at = Q.n_ev < kTilesLaneCap - 1u ? Q.n_ev : kTilesLaneCap - 1u;
+                Q.lists[at * 64u + lane] = st + uint32_t(__builtin_amdgcn_readfirstlane(int(jj << 16)));   // (jj is wave-uniform: one scalar, one add)
                 ++Q.n_ev;
             }
             return;
@@ -415,7 +418,7 @@ __global__ __launch_bounds__(kTilesThreads, 8) void k_walk_tiles(DevAutomaton A,
         }
         uint32_t n_rec = 0;
         Q.total = Q.flushed = Q.n_ev = 0;
-        tiles_walk<E, MODE, ALLHOT, LANEQ>(A, pc, L, Q, lane, n_rec, (T.flags & 2u) == 0u);
+        tiles_walk<E, MODE, ALLHOT, LANEQ>(A, pc, L, Q, lane, n_rec, true);
         if constexpr (LANEQ) {
             if (T.m_prefix != nullptr && pc.nblk) {
                 // the other part's records that END inside this piece: positions [p_lo, p_hi] of this haystack (looked up behind
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(kTilesThreads, 8) void k_walk_tiles(DevAutomaton A,
         const uint64_t base = s_before + wave_base;
         // (too small a buffer: what fits is written -- whole events, in order -- and the host grows it and runs the batch again, or
         // hands out the haystacks that are complete: "max_result_bytes")
-        if (wave_tot == 0u || base >= T.cap || (T.flags & 1u)) continue;
+        if (wave_tot == 0u || base >= T.cap) continue;
         const uint64_t room = T.cap - base;   // records this wave may write
         if constexpr (LANEQ) {
             if (!lane_over) {
@@ -591,8 +594,9 @@ hipError_t launch_walk_tiles(const DevAutomaton &A, const BatchArgs &B, uint64_t
     T.R = 64u / P;
     T.back = A.max_pattern_length ? A.max_pattern_length - 1u : 0u;
     T.qcap = 64u * W / 4u;
-    static const uint32_t debug_flags = [] { const char *e = std::getenv("ACMI_TILES_DEBUG"); return e ? uint32_t(std::atoi(e)) : 0u; }();
-    T.flags = debug_flags;
+    // ACMI_TILES_LISTS=0 (measurements): the shared ring instead of the lanes' own lists where both are possible -- same records
+    static const bool no_lists = [] { const char *e = std::getenv("ACMI_TILES_LISTS"); return e && e[0] == '0'; }();
+    T.flags = 0;
     T.queue = static_cast<uint2 *>(queue);
     T.ticket = ticket;
     T.status = status;
@@ -608,7 +612,7 @@ hipError_t launch_walk_tiles(const DevAutomaton &A, const BatchArgs &B, uint64_t
     const uint64_t hot_bytes = uint64_t(A.trap) * hot_stride + 8u;
     const uint32_t ring_q = kTilesWaves * kTilesRing * 8u, ring_l = kTilesWaves * kTilesLaneCap * 256u;
     const bool hot_ok = A.trap + 1u == A.n_states && A.row_bytes && (entry_bytes == 4 || uint64_t(A.trap + 1u) * hot_stride < 65536u) && A.max_out_count < 65536u;
-    const bool laneq = hot_ok && hot_bytes <= share - ring_l && uint64_t(A.trap + 1u) * hot_stride < 65536u && (!(debug_flags & 16u) || merge_prefix);
+    const bool laneq = hot_ok && hot_bytes <= share - ring_l && uint64_t(A.trap + 1u) * hot_stride < 65536u && (!no_lists || merge_prefix);
     if (merge_prefix && !laneq) return hipErrorInvalidValue;   // (the caller asks tiles_can_merge first)
     const bool allhot = laneq || (hot_ok && hot_bytes <= share - ring_q);
     const uint32_t ring_bytes = laneq ? ring_l : ring_q;
