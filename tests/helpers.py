@@ -71,7 +71,7 @@ class FlatTables:
         _ = dt
         self.chain_lo = t.chain_lo
         self.chain_byte = self.chain_run = None
-        if t.compact and t.chain_byte:
+        if t.chain_byte:
             nchain = self.f2 - t.chain_lo
             self.chain_byte = np.ctypeslib.as_array(t.chain_byte, shape=(nchain + 16,)).astype(np.int64)
             self.chain_run = np.ctypeslib.as_array(t.chain_run, shape=(nchain + 16,)).astype(np.int64)

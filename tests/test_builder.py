@@ -63,6 +63,20 @@ def test_tables_match_oracle(name, lds, compact):
                 run[k] = min(255, 1 + run[k + 1]) if consecutive[k] else 0
             assert np.array_equal(run[:-1], ft.chain_run[:ids.size])
             assert np.all(ft.chain_byte[ids.size:] == 0) and np.all(ft.chain_run[ids.size:] == 0)
+    if compact != 1 and ft.chain_byte is not None:
+        # dense rows (round 4): the single-child states below the tile are numbered along their patterns too -- the arrays of the
+        # bulk compare restate the TABLE: the edge byte's column of a chain state leads to its trie child, which is the next id
+        # for as long as the run says
+        ids = np.arange(ft.chain_lo, ft.f2)
+        assert ids.size > 0 and ft.chain_lo > ft.trap
+        child = ft.table[ids, ft.cls[ft.chain_byte[:ids.size]]]
+        consecutive = (child == ids + 1) & (ids + 1 < ft.f2)
+        run = np.zeros(ids.size + 1, np.int64)
+        for k in range(ids.size - 1, -1, -1):
+            run[k] = min(255, 1 + run[k + 1]) if consecutive[k] else 0
+        assert np.array_equal(run[:-1], ft.chain_run[:ids.size])
+        if name in ("G2", "R3") and lds:
+            assert np.mean(consecutive) > 0.5
     # numbering invariants the kernels rely on
     assert 0 < ft.f1 <= ft.trap < ft.n_states and ft.trap < ft.f2 <= ft.n_states
     assert np.all(ft.lds <= ft.trap)                      # tile never points outside itself
