@@ -647,6 +647,22 @@ def short_haystacks_leg(torch, api, batch, synth, dev):
                            nh * hl, nh, total, ms, scan, walk, res, ok)
         leg.update({"haystack_bytes": hl, "anchor_variant": int(res.stat("anchor_variant")), "tiny_waves": int(res.stat("tiny_waves")),
                     "work_item_bytes": int(res.stat("chunk_bytes"))})
+        if hl % 16 == 0:
+            # the entry the headline uses (acmi_match_batch_device_begin_uniform: no offsets array, the item table in closed form):
+            # what a caller with a regular batch gets; the figures above are the offsets entry's, as in earlier rounds
+            res.set_option("profile", 0)
+            uni = []
+            for i in range(7):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                batch.match_device_begin_uniform(res, d_blob, hl, nh, True)
+                t_uni = batch.match_device_end(res)
+                if i >= 2:
+                    uni.append((time.perf_counter() - t0) * 1e3)
+            p_uni, r_uni = batch.result_numpy(res, nh, t_uni)
+            leg["uniform_entry"] = {"ms_per_call": round(float(np.median(uni)), 4),
+                                    "frac_whole_call": round(leg["algorithmic_bytes"] / (float(np.median(uni)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "check_ok": bool(t_uni == total and np.array_equal(p_uni, prefix) and np.array_equal(r_uni, rec))}
         out.append(leg)
         api.ahocorasick_deinit(res)
         del d_blob, d_off

@@ -546,6 +546,17 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
         }
     }
 
+    fa.out_head.clear();
+    if (patterns_.size() < (1u << 24)) {
+        fa.out_head.assign(size_t(fa.n_states) * 2, 0u);
+        for (uint32_t s = 0; s < fa.n_states; ++s) {
+            if (fa.out_count[s] == 0) continue;
+            const uint32_t t = fa.own_pattern[s] != kNone ? s : fa.dict_link[s];
+            const uint32_t pat = fa.own_pattern[t];
+            fa.out_head[size_t(s) * 2] = pat | (std::min<uint32_t>(fa.out_count[s], 255u) << 24);
+            fa.out_head[size_t(s) * 2 + 1] = fa.pattern_length[pat];
+        }
+    }
     lap("rows, records, output lists");
 
     // ---- anchor filter table -------------------------------------------------------------------

@@ -138,6 +138,10 @@ struct FlatAutomaton {
     std::vector<uint32_t> out_off;      // per state (valid where out_count > 0)
     std::vector<uint32_t> out_list;     // 2 words per entry: pattern, length
     uint64_t n_flat_outputs = 0;        // entries of out_list (kept when the host copy is released)
+    // The head of every final state's output: {first (longest) pattern | min(records, 255) << 24, its length} -- what an event
+    // with ONE record needs (most events), in one 8-byte read instead of three dependent ones (own_pattern / dict_link,
+    // pattern_length, out_count).  Empty for more than 2^24 patterns.
+    std::vector<uint32_t> out_head;     // 2 words per state
     uint32_t max_out_count = 0;
 
     // ---- anchor filter (optional front end of the scan, see k_anchor.hip k_scan_anchor) ----
@@ -259,6 +263,7 @@ public:
         std::vector<uint32_t>().swap(flat_.anchor_slot_pair);
         std::vector<uint32_t>().swap(flat_.anchor_pairs);
         std::vector<uint32_t>().swap(flat_.out_list);
+        std::vector<uint32_t>().swap(flat_.out_head);
         std::vector<uint32_t>().swap(flat_.dense_image);
         host_tables_released_ = true;
     }

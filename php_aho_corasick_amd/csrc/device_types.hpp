@@ -18,6 +18,7 @@ struct DevAutomaton {
     const uint32_t *pattern_length;  // per pattern
     const uint32_t *out_off;     // per state: first entry of its flat output list (null: follow dict_link)
     const uint2 *out_list;       // {pattern, length}, longest first
+    const uint2 *out_head;       // per state: {first pattern | min(records, 255) << 24, its length} (null: more than 2^24 patterns)
     uint32_t max_out_count;      // longest output list
     // compact form (automaton.hpp): dense rows for ids [0,dense_nf_end) and [f2,dense_f_end) (the latter at row
     // dense_nf_end + id - f2); every other state has a record {x, failure | code << 24} and maybe sorted edges

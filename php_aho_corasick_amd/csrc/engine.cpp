@@ -294,6 +294,10 @@ int ensure_device(acmi_handle *h) {
     if (!fa.pattern_length.empty())
         HIPCHK(h, copy_h2d(h->d_plen.p, fa.pattern_length.data(), fa.pattern_length.size() * 4));
 
+    if (!fa.out_head.empty()) {
+        HIPCHK(h, h->d_out_head.ensure(fa.out_head.size() * 4));
+        HIPCHK(h, copy_h2d(h->d_out_head.p, fa.out_head.data(), fa.out_head.size() * 4));
+    }
     if (!fa.out_off.empty()) {
         HIPCHK(h, h->d_out_off.ensure(ns4));
         HIPCHK(h, copy_h2d(h->d_out_off.p, fa.out_off.data(), ns4));
@@ -372,6 +376,7 @@ int ensure_device(acmi_handle *h) {
     A.pattern_length = h->d_plen.as<uint32_t>();
     A.out_off = fa.out_off.empty() ? nullptr : h->d_out_off.as<uint32_t>();
     A.out_list = fa.out_off.empty() ? nullptr : h->d_out_list.as<uint2>();
+    A.out_head = fa.out_head.empty() ? nullptr : h->d_out_head.as<uint2>();
     A.max_out_count = fa.max_out_count;
     A.compact = fa.compact;
     A.dense_nf_end = fa.dense_nf_end;
@@ -489,7 +494,7 @@ int acmi_destroy(acmi_handle *h) {
         if (h->dev_touched) {  // also after a failed upload: release whatever was created
             (void)hipSetDevice(h->dev_id);
             if (h->stream) (void)hipStreamSynchronize(h->stream);
-            for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_out_off, &h->d_out_list, &h->d_cold_rec, &h->d_cold_edges, &h->d_chain_byte, &h->d_chain_run, &h->d_slot_pair, &h->d_pairs, &h->d_pat_bytes, &h->d_dense_img, &h->d_merge_counts, &h->d_merge_sync, &h->d_rep_off, &h->d_rep_bytes, &h->d_plan, &h->d_plan_out, &h->d_tail_out, &h->d_rep_sync, &h->d_nom_count, &h->d_out_len, &h->d_rep_out_off, &h->d_rep_out, &h->d_blob,
+            for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_out_off, &h->d_out_list, &h->d_out_head, &h->d_cold_rec, &h->d_cold_edges, &h->d_chain_byte, &h->d_chain_run, &h->d_slot_pair, &h->d_pairs, &h->d_pat_bytes, &h->d_dense_img, &h->d_merge_counts, &h->d_merge_sync, &h->d_rep_off, &h->d_rep_bytes, &h->d_plan, &h->d_plan_out, &h->d_tail_out, &h->d_rep_sync, &h->d_nom_count, &h->d_out_len, &h->d_rep_out_off, &h->d_rep_out, &h->d_blob,
                               &h->d_off, &h->d_sync[0], &h->d_sync[1], &h->d_item_base[0], &h->d_item_hay[0], &h->d_item_rec[0], &h->d_zero[0], &h->d_isync[0],
                               &h->d_item_base[1], &h->d_item_hay[1], &h->d_item_rec[1], &h->d_zero[1], &h->d_isync[1],
                               &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_first, &h->d_tile_queue, &h->d_tile_sync, &h->d_uni_off[0], &h->d_uni_off[1], &h->fly[0].d_prefix, &h->fly[0].d_out, &h->fly[1].d_prefix, &h->fly[1].d_out, &h->d_runs, &h->d_run_count})

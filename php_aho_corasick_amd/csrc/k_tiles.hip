@@ -146,7 +146,12 @@ __device__ __forceinline__ uint2 tiles_meta(const DevAutomaton &A, const TileLds
         const E *m = reinterpret_cast<const E *>(L.tile + s + A.row_bytes);
         return make_uint2(uint32_t(m[1]), uint32_t(m[0]));
     }
-    return make_uint2(s, s < L.rows ? L.cnt[s] : A.out_count[s]);
+    if (s < L.rows) return make_uint2(s, L.cnt[s]);
+    if (A.out_head != nullptr) {   // (the line the expansion reads again)
+        const uint32_t c = A.out_head[s].x >> 24;
+        if (c < 255u) return make_uint2(s, c);
+    }
+    return make_uint2(s, A.out_count[s]);
 }
 
 // The walk of one piece, counting: events go to the wave's queue, n_rec sums the records they stand for.  All 64 lanes of
@@ -290,6 +295,12 @@ __device__ __forceinline__ void tiles_expand(const DevAutomaton &A, const TileLd
         if (L.out1 != nullptr) {
             const uint2 o = L.out1[s];
             dst[0] = make_uint4(hay, pos, pos - o.y, o.x);
+            if (c == 1u) return;
+            k = 1;
+        }
+        if (k == 0 && A.out_head != nullptr) {   // (states without a row in the tile: the head of the list in one read)
+            const uint2 h = A.out_head[s];
+            dst[0] = make_uint4(hay, pos, pos - h.y, h.x & 0xFFFFFFu);
             if (c == 1u) return;
             k = 1;
         }
@@ -534,7 +545,7 @@ __global__ __launch_bounds__(kTilesThreads, 8) void k_walk_tiles(DevAutomaton A,
                 if (valid) {
                     uint32_t c;
                     if constexpr (ALLHOT) c = uint32_t(reinterpret_cast<const E *>(L.tile + s * L.stride + A.row_bytes)[0]);
-                    else c = s < L.rows ? L.cnt[s] : A.out_count[s];
+                    else c = tiles_meta<E, ALLHOT>(A, L, s).y;
                     if (uint64_t(slot) + c <= room) tiles_expand(A, L, T.out + base + slot, hay, pos, s, c);
                 }
             }

@@ -905,6 +905,13 @@ constexpr uint32_t kItemsTileBytes = 78u * 1024u;
 // Expand one event into records, longest pattern first (node.c:424-441 order).
 __device__ __forceinline__ uint64_t emit_event(const DevAutomaton &A, uint4 *out, uint64_t w, uint32_t hay,
                                                uint32_t pos, uint32_t state) {
+    if (A.out_head != nullptr) {   // most events stand for one record: everything it needs in one 8-byte read
+        const uint2 h = A.out_head[state];
+        if ((h.x >> 24) == 1u) {
+            out[w] = make_uint4(hay, pos, pos - h.y, h.x & 0xFFFFFFu);
+            return w + 1;
+        }
+    }
     uint32_t t = A.own_pattern[state] != 0xFFFFFFFFu ? state : A.dict_link[state];
     while (t != 0xFFFFFFFFu) {
         const uint32_t pat = A.own_pattern[t];
