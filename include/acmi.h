@@ -316,8 +316,9 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *                    waves pack one-row work items eight to a step, 0 never                [any time]
  *   "short_rows"     kernel 2: the variant that skips the 1-KiB rows a work item lacks: -1 (default)
  *                    unless every haystack is a multiple of 8 KiB on an aligned blob, 0 never, 1 always [any time]
- *   "walk_group"     kernel 4: 16-byte haystack blocks a lane requests back to back: 1, 4 (default: half a
- *                    line, the most that fits 8 waves per SIMD) or 8 (a whole 128-byte line)  [any time]
+ *   "walk_group"     kernel 4: 16-byte haystack blocks a lane requests back to back.  Always 4 since round 4 (half a
+ *                    line, the most that fits 8 waves per SIMD: the variants with 1 and 8 measured 1.2-1.4 x slower
+ *                    and were most of the library's compile time); 1, 4, 8 are accepted and ignored  [any time]
  *   "ilp"            streams per lane in the LDS-tile kernel (1 or 2)    [any time]
  *   "group_quads"    16-byte loads per lane per fetch group, 4 or 8 (ILP 1) [any time]
  *   "small_path"     1 (default): host batches of <= 64 KiB in <= 1024 haystacks (every acmi_match of a few

@@ -15,8 +15,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libacmi.so")
-SOURCES = ["automaton.cpp", "engine.cpp", "engine_pipeline.cpp", "engine_choice.cpp", "engine_comm.cpp", "engine_replace.cpp", "k_anchor.hip", "k_anchor_dense.hip", "k_lds.hip", "k_walk.hip", "k_tiles.hip", "k_drain.hip", "k_pipeline.hip", "k_small.hip", "k_misc.hip"]
-HEADERS = ["automaton.hpp", "device_types.hpp", "kernels.hpp", "engine.hpp", "kdev.hpp", "k_anchor_impl.hpp", "scan_asm.inc", os.path.join("..", "..", "include", "acmi.h")]
+SOURCES = ["automaton.cpp", "engine.cpp", "engine_pipeline.cpp", "engine_choice.cpp", "engine_comm.cpp", "engine_replace.cpp", "k_anchor.hip", "k_anchor_dense.hip", "k_lds.hip", "k_walk.hip", "k_walk_items.hip", "k_walk_items_emit.hip", "k_tiles.hip", "k_drain.hip", "k_pipeline.hip", "k_small.hip", "k_misc.hip"]
+HEADERS = ["automaton.hpp", "device_types.hpp", "kernels.hpp", "engine.hpp", "kdev.hpp", "k_anchor_impl.hpp", "k_walk_items_impl.hpp", "scan_asm.inc", os.path.join("..", "..", "include", "acmi.h")]
 
 
 def _hipcc() -> str:
@@ -48,7 +48,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         objs.append(obj)
         path = os.path.join(CSRC, src)
         # (the device-side helpers are only seen by the kernel files: a change there leaves the host objects alone)
-        deps = [h for h in HEADERS if h != "engine.hpp"] if src.endswith(".hip") else [h for h in HEADERS if h not in ("kdev.hpp", "k_anchor_impl.hpp", "scan_asm.inc")]
+        deps = [h for h in HEADERS if h != "engine.hpp"] if src.endswith(".hip") else [h for h in HEADERS if h not in ("kdev.hpp", "k_anchor_impl.hpp", "k_walk_items_impl.hpp", "scan_asm.inc")]
         hdr_time = max(os.path.getmtime(os.path.join(CSRC, f)) for f in deps)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_time):
             continue
@@ -58,7 +58,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             cmd.insert(1, "-save-temps=obj")   # keeps the device assembly next to the object: tools/check_asm.py, tests/test_asm.py
         jobs.append(cmd)
     # the longest translation units first, as many at a time as the machine has CPUs
-    order = {"k_anchor.hip": 0, "k_anchor_dense.hip": 1, "k_lds.hip": 2, "k_walk.hip": 3, "engine_pipeline.cpp": 4, "engine.cpp": 5}
+    order = {"k_anchor.hip": 0, "k_walk_items.hip": 1, "k_walk_items_emit.hip": 2, "k_anchor_dense.hip": 3, "k_lds.hip": 4, "k_tiles.hip": 5, "k_walk.hip": 6, "engine_pipeline.cpp": 7, "engine.cpp": 8}
     jobs.sort(key=lambda c: order.get(os.path.basename(c[-3]), 9))
     running, limit = [], max(2, os.cpu_count() or 4)
     while jobs or running:
