@@ -112,13 +112,21 @@ __device__ __forceinline__ void tiles_flush(TileQueue &Q, uint32_t lane) {
 // One exact transition of a lane: the LDS tile's row when the state has one, else the global table / the compact records.
 // ALLHOT (every state has its row in the tile: small automata): no test, no cold path compiled in, and a state is held as the
 // BYTE OFFSET of its row -- the tile's entries are stored that way (hot_stage) -- so that a step is one add and one read.
-template <typename E, bool ALLHOT>
+// D32 (dense rows, the whole table below 4 GiB -- everything but compact automata): the row that is not in the tile is one load
+// at a 32-bit offset from the table's base (a multiply-add and the load; the general form went through a 64-bit multiply and a
+// test of the automaton's form, and carried the compact form's record loop in every step of the unrolled walk).
+// The tile has one row more than it holds states: row `tile_rows` = the trap's (every entry "not here"), which is where a state
+// without a row looks -- a minimum instead of a test and an exec mask around the read.
+template <typename E, bool ALLHOT, bool D32 = false>
 __device__ __forceinline__ uint32_t tiles_step(const DevAutomaton &A, const uint8_t *tile, uint32_t tile_rows, uint32_t st, uint32_t byte,
                                                uint32_t coff) {
     if constexpr (ALLHOT) return *reinterpret_cast<const E *>(tile + st + coff);
-    uint32_t w = A.trap;
-    if (st < tile_rows) w = *reinterpret_cast<const E *>(tile + __umul24(st, A.row_bytes) + coff);
-    if (w >= A.trap) w = cold_step<E>(A, st, byte, coff);
+    const uint32_t row = st < tile_rows ? st : tile_rows;
+    uint32_t w = *reinterpret_cast<const E *>(tile + __umul24(row, A.row_bytes) + coff);
+    if (w >= A.trap) {
+        if constexpr (D32) w = *reinterpret_cast<const E *>(static_cast<const uint8_t *>(A.table) + (__umul24(st, A.row_bytes) + coff));
+        else w = cold_step<E>(A, st, byte, coff);
+    }
     return w;
 }
 
@@ -160,7 +168,7 @@ __device__ __forceinline__ uint2 tiles_meta(const DevAutomaton &A, const TileLds
 // are counted and expanded by the lane afterwards.  With the wave-shared queue an event costs ~ 13 operations (ballot, rank,
 // record count, packing, ring address) which the whole wave issues at every step in which ANY of its lanes has one: at a match
 // per 15 bytes that is 99 % of the steps, and it was more than half of the kernel's instructions.
-template <typename E, int MODE, bool ALLHOT, bool LANEQ>
+template <typename E, int MODE, bool ALLHOT, bool LANEQ, bool D32>
 __device__ __forceinline__ void tiles_walk(const DevAutomaton &A, const Piece &pc, const TileLds &L, TileQueue &Q, uint32_t lane,
                                            uint32_t &n_rec, bool events) {
     uint32_t st = 0;
@@ -178,7 +186,7 @@ __device__ __forceinline__ void tiles_walk(const DevAutomaton &A, const Piece &p
             }
             return;
         }
-        const uint64_t m = __ballot(ev);
+        const uint64_t m = __builtin_amdgcn_ballot_w64(ev);
         if (m) {
             if (ev) {
                 const uint2 meta = tiles_meta<E, ALLHOT>(A, L, st);
@@ -206,7 +214,7 @@ __device__ __forceinline__ void tiles_walk(const DevAutomaton &A, const Piece &p
     for (uint32_t jj = jmin; jj < 16u; ++jj) {
         const uint32_t wd = jj < 8u ? (jj < 4u ? first.x : first.y) : (jj < 12u ? first.z : first.w);
         const uint32_t byte = (wd >> (8u * (jj & 3u))) & 0xffu;
-        const uint32_t w = tiles_step<E, ALLHOT>(A, L.tile, L.rows, st, byte, class_offset<E, MODE>(A, L.cls, byte));
+        const uint32_t w = tiles_step<E, ALLHOT, D32>(A, L.tile, L.rows, st, byte, class_offset<E, MODE>(A, L.cls, byte));
         st = jj < pc.start_j ? 0u : w;
         event(jj, jj - pc.rep_lo < pc.rep_len);
     }
@@ -231,10 +239,10 @@ __device__ __forceinline__ void tiles_walk(const DevAutomaton &A, const Piece &p
                 c2 = class_offset<E, MODE>(A, L.cls, (wd >> 16) & 0xffu); c3 = class_offset<E, MODE>(A, L.cls, wd >> 24);
             }
             constexpr bool C = decltype(checked)::value;
-            st = tiles_step<E, ALLHOT>(A, L.tile, L.rows, st, wd & 0xffu, c0); event(jj, !C || jj - pc.rep_lo < pc.rep_len);
-            st = tiles_step<E, ALLHOT>(A, L.tile, L.rows, st, (wd >> 8) & 0xffu, c1); event(jj + 1u, !C || jj + 1u - pc.rep_lo < pc.rep_len);
-            st = tiles_step<E, ALLHOT>(A, L.tile, L.rows, st, (wd >> 16) & 0xffu, c2); event(jj + 2u, !C || jj + 2u - pc.rep_lo < pc.rep_len);
-            st = tiles_step<E, ALLHOT>(A, L.tile, L.rows, st, wd >> 24, c3); event(jj + 3u, !C || jj + 3u - pc.rep_lo < pc.rep_len);
+            st = tiles_step<E, ALLHOT, D32>(A, L.tile, L.rows, st, wd & 0xffu, c0); event(jj, !C || jj - pc.rep_lo < pc.rep_len);
+            st = tiles_step<E, ALLHOT, D32>(A, L.tile, L.rows, st, (wd >> 8) & 0xffu, c1); event(jj + 1u, !C || jj + 1u - pc.rep_lo < pc.rep_len);
+            st = tiles_step<E, ALLHOT, D32>(A, L.tile, L.rows, st, (wd >> 16) & 0xffu, c2); event(jj + 2u, !C || jj + 2u - pc.rep_lo < pc.rep_len);
+            st = tiles_step<E, ALLHOT, D32>(A, L.tile, L.rows, st, wd >> 24, c3); event(jj + 3u, !C || jj + 3u - pc.rep_lo < pc.rep_len);
         };
         const bool full = j0 >= pc.rep_lo && j0 + 16u <= pc.rep_lo + pc.rep_len;
         if (__all(full)) {
@@ -319,7 +327,7 @@ __device__ __forceinline__ void tiles_expand(const DevAutomaton &A, const TileLd
 // workgroup with the whole LDS for its tile (twice the rows, 80-odd registers, no spills) measured 8-12 % slower on a word list
 // and on the headline set with 64 plants per haystack, three workgroups of 512 threads (6 waves per SIMD, 80 registers, no
 // spills in any loop) 8-15 % slower on every workload tried.  (The dozen registers spilled at 64 are touched once per tile.)
-template <typename E, int MODE, bool ALLHOT, bool LANEQ>
+template <typename E, int MODE, bool ALLHOT, bool LANEQ, bool D32>
 __global__ __launch_bounds__(kTilesThreads, 8) void k_walk_tiles(DevAutomaton A, BatchArgs B, TileArgs T) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ uint32_t s_tile, s_walked;
@@ -358,13 +366,20 @@ __global__ __launch_bounds__(kTilesThreads, 8) void k_walk_tiles(DevAutomaton A,
             L.out1 = o1;
         }
     } else {
-        L.rows = A.row_bytes ? (T.tile_bytes / (A.row_bytes + 4u) < A.trap ? T.tile_bytes / (A.row_bytes + 4u) : A.trap) : 0u;
+        // rows [0, L.rows) and, behind them, the row of "not here" entries (tiles_step); the image's own row `trap` is one
+        const uint32_t fit = A.row_bytes && T.tile_bytes > A.row_bytes + 16u ? (T.tile_bytes - A.row_bytes - 16u) / (A.row_bytes + 4u) : 0u;
+        L.rows = fit < A.trap ? fit : A.trap;
         L.stride = A.row_bytes;
         L.final_from = 0;
-        const uint32_t tile_bytes = (L.rows * A.row_bytes + 15u) & ~15u;
+        const uint32_t tile_bytes = ((L.rows + 1u) * A.row_bytes + 15u) & ~15u;
         uint4 *tdst = reinterpret_cast<uint4 *>(smem + ring_bytes + cls_bytes);
         const uint4 *tsrc = reinterpret_cast<const uint4 *>(src);
         for (uint32_t t = threadIdx.x; t < (tile_bytes >> 4); t += kTilesThreads) tdst[t] = tsrc[t];
+        if (L.rows < A.trap) {
+            __syncthreads();   // (the copy above wrote whole 16-byte blocks across this row)
+            E *trap_row = reinterpret_cast<E *>(smem + ring_bytes + cls_bytes + L.rows * A.row_bytes);
+            for (uint32_t t = threadIdx.x; t < A.n_columns; t += kTilesThreads) trap_row[t] = E(A.trap);
+        }
         uint32_t *cdst = reinterpret_cast<uint32_t *>(smem + ring_bytes + cls_bytes + tile_bytes);
         for (uint32_t t = threadIdx.x; t < L.rows; t += kTilesThreads) cdst[t] = A.out_count[t];
         L.cnt = cdst;
@@ -429,7 +444,7 @@ __global__ __launch_bounds__(kTilesThreads, 8) void k_walk_tiles(DevAutomaton A,
         }
         uint32_t n_rec = 0;
         Q.total = Q.flushed = Q.n_ev = 0;
-        tiles_walk<E, MODE, ALLHOT, LANEQ>(A, pc, L, Q, lane, n_rec, true);
+        tiles_walk<E, MODE, ALLHOT, LANEQ, D32>(A, pc, L, Q, lane, n_rec, true);
         if constexpr (LANEQ) {
             if (T.m_prefix != nullptr && pc.nblk) {
                 // the other part's records that END inside this piece: positions [p_lo, p_hi] of this haystack (looked up behind
@@ -637,7 +652,10 @@ hipError_t launch_walk_tiles(const DevAutomaton &A, const BatchArgs &B, uint64_t
         hipLaunchKernelGGL(fn, dim3(blocks), dim3(kTilesThreads), lds, st, A, B, T);
         return hipGetLastError();
     };
-#define ACMI_TILES(E, M) (laneq ? go(k_walk_tiles<E, M, true, true>) : allhot ? go(k_walk_tiles<E, M, true, false>) : go(k_walk_tiles<E, M, false, false>))
+    // (the rows outside the tile at 32-bit offsets: dense rows, the table below 4 GiB)
+    const bool d32 = !A.compact && uint64_t(A.n_states) * A.row_bytes < (1ull << 32);
+#define ACMI_TILES(E, M) (laneq ? go(k_walk_tiles<E, M, true, true, false>) : allhot ? go(k_walk_tiles<E, M, true, false, false>) : \
+                          d32 ? go(k_walk_tiles<E, M, false, false, true>) : go(k_walk_tiles<E, M, false, false, false>))
     if (entry_bytes == 2) return class_mode == 1 ? ACMI_TILES(uint16_t, 1) : ACMI_TILES(uint16_t, 0);
     return class_mode == 1 ? ACMI_TILES(uint32_t, 1) : ACMI_TILES(uint32_t, 0);
 #undef ACMI_TILES

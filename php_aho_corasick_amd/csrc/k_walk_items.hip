@@ -18,7 +18,8 @@ hipError_t launch_walk_items(const DevAutomaton &A, const BatchArgs &B, uint64_t
     // 16-byte blocks a lane requests back to back: 4 (`group`, the "walk_group" option, is kept for its callers: single blocks --
     // the first version, 1.42 ms per GiB against 1.16 -- and whole lines of 8 are no longer compiled)
     (void)group;
-#define ACMI_WALK_ITEMS(E, M) go(k_walk_items<E, M, 4>)
+    const bool d32 = !A.compact && uint64_t(A.n_states) * A.row_bytes < (1ull << 32) && A.n_states < (1u << 24);
+#define ACMI_WALK_ITEMS(E, M) (d32 ? go(k_walk_items<E, M, 4, false, true>) : go(k_walk_items<E, M, 4, false, false>))
     if (entry_bytes == 2) return class_mode == 1 ? ACMI_WALK_ITEMS(uint16_t, 1) : ACMI_WALK_ITEMS(uint16_t, 0);
     return class_mode == 1 ? ACMI_WALK_ITEMS(uint32_t, 1) : ACMI_WALK_ITEMS(uint32_t, 0);
 #undef ACMI_WALK_ITEMS

@@ -29,7 +29,10 @@ __device__ __forceinline__ uint64_t emit_event(const DevAutomaton &A, uint4 *out
 // the slab), records written straight into their final slots.  Items of <= 1 KiB are what this kernel is given, and at tens of
 // events per item a wave per item (k_refill_wave: a round of dependent loads per 256 positions) was five times slower than
 // walking them again one per thread (a word list over text made of its words: 14 -> 3.6 ms per GiB).
-template <typename E, int MODE, int LB, bool EMIT = false>
+// D32 (dense rows, the table below 4 GiB): a row outside the tile is one load at a 32-bit offset from the table's base -- no test
+// of the automaton's form, no 64-bit multiply, none of the compact form's record loop in the 64 unrolled steps (k_walk_tiles'
+// lesson: 17 % there).  The tile ends with a row of "not here" entries for the states it does not hold.
+template <typename E, int MODE, int LB, bool EMIT = false, bool D32 = false>
 __global__ __launch_bounds__(kWalkThreads, (LB <= 4 ? 8 : 4)) void k_walk_items(DevAutomaton A, BatchArgs B, const uint64_t *rec_base,
                                                                                 uint4 *out, uint64_t cap) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -52,12 +55,13 @@ __global__ __launch_bounds__(kWalkThreads, (LB <= 4 ? 8 : 4)) void k_walk_items(
     }
     // LDS: [512 B byte classes (TABLE mode)] [tile rows]
     const uint32_t cls_bytes = (MODE == 0) ? 512u : 0u;
-    const uint32_t tile_rows = A.row_bytes ? (kItemsTileBytes / A.row_bytes < A.trap ? kItemsTileBytes / A.row_bytes : A.trap) : 0u;
+    const uint32_t fit = A.row_bytes ? (kItemsTileBytes - 16u) / A.row_bytes - 1u : 0u;   // (one row more than states: the trap's)
+    const uint32_t tile_rows = fit < A.trap ? fit : A.trap;
     const uint16_t *cls_lds = (MODE == 0) ? reinterpret_cast<const uint16_t *>(smem) : nullptr;
     const uint8_t *tile = smem + cls_bytes;
     // a tile that leaves room takes its states' record counts along: where nearly every byte ends a pattern (a^1..a^16)
     // the count was a dependent global load per byte, and that load was most of the kernel (0.33 ms per 32 MiB)
-    const uint32_t tile_bytes = (tile_rows * A.row_bytes + 15u) & ~15u;
+    const uint32_t tile_bytes = ((tile_rows + 1u) * A.row_bytes + 15u) & ~15u;
     const uint32_t cnt_rows = tile_bytes + tile_rows * 4u <= kItemsTileBytes ? tile_rows : 0u;
     const uint32_t *cnt_lds = reinterpret_cast<const uint32_t *>(tile + tile_bytes);
     {
@@ -68,6 +72,11 @@ __global__ __launch_bounds__(kWalkThreads, (LB <= 4 ? 8 : 4)) void k_walk_items(
         for (uint32_t t = threadIdx.x; t < n16; t += kWalkThreads) tdst[t] = tsrc[t];
         uint32_t *cdst = reinterpret_cast<uint32_t *>(smem + cls_bytes + tile_bytes);
         for (uint32_t t = threadIdx.x; t < cnt_rows; t += kWalkThreads) cdst[t] = A.out_count[t];
+        if (tile_rows < A.trap) {   // the image's own row `trap` is such a row; a shorter tile gets one written behind its last
+            __syncthreads();
+            E *trap_row = reinterpret_cast<E *>(smem + cls_bytes + tile_rows * A.row_bytes);
+            for (uint32_t t = threadIdx.x; t < A.n_columns; t += kWalkThreads) trap_row[t] = E(A.trap);
+        }
     }
     __syncthreads();
 
@@ -80,9 +89,12 @@ __global__ __launch_bounds__(kWalkThreads, (LB <= 4 ? 8 : 4)) void k_walk_items(
     EventRegs ev{0, 0};
     auto step = [&](uint32_t byte, uint32_t jj) __attribute__((always_inline)) {
         const uint32_t coff = class_offset<E, MODE>(A, cls_lds, byte);
-        uint32_t w = A.trap;
-        if (st < tile_rows) w = *reinterpret_cast<const E *>(tile + __umul24(st, A.row_bytes) + coff);
-        if (w >= A.trap) w = cold_step<E>(A, st, byte, coff);
+        const uint32_t row = st < tile_rows ? st : tile_rows;
+        uint32_t w = *reinterpret_cast<const E *>(tile + __umul24(row, A.row_bytes) + coff);
+        if (w >= A.trap) {
+            if constexpr (D32) w = *reinterpret_cast<const E *>(static_cast<const uint8_t *>(A.table) + (__umul24(st, A.row_bytes) + coff));
+            else w = cold_step<E>(A, st, byte, coff);
+        }
         st = w;
         if (jj >= warm && is_final(A, st) && !(B.first_only && ev.n_ev)) {
             if constexpr (EMIT) {

@@ -27,11 +27,11 @@ HOT = [
     ("k_scan_lds<unsigned short, 1, 1, 8>", 0),                          # general_path
     # k_walk_tiles marks its step loop in the source (the per-TILE code around it -- piece set-up, scans, look-back, once per
     # 64 x 69 byte steps -- reloads the dozen registers spilled at 64 registers = 8 waves per SIMD, which is what makes it fast)
-    ("k_walk_tiles<unsigned short, 1, true, true>", 0),                  # short patterns over their own alphabet
-    ("k_walk_tiles<unsigned short, 1, true, false>", 2),                 # (the wave-queue variants reload a pointer pair or two per
-    ("k_walk_tiles<unsigned short, 0, false, false>", 4),                # block of sixteen steps, ~ 1,000-4,000 instructions: word lists,
-    ("k_walk_tiles<unsigned short, 1, false, false>", 4),                # the headline set at many matches per haystack)
-    ("k_walk_items<unsigned short, 0, 4, false>", 0),
+    ("k_walk_tiles<unsigned short, 1, true, true, false>", 0),                  # short patterns over their own alphabet
+    ("k_walk_tiles<unsigned short, 1, true, false, false>", 2),                 # (the wave-queue variants reload a pointer pair or two per
+    ("k_walk_tiles<unsigned short, 0, false, false, true>", 4),                # block of sixteen steps, ~ 1,000-4,000 instructions: word lists,
+    ("k_walk_tiles<unsigned short, 1, false, false, true>", 4),                # the headline set at many matches per haystack)
+    ("k_walk_items<unsigned short, 0, 4, false, true>", 0),
     ("k_refill_wave<unsigned short, 1024u>", 0),                         # config 5
     ("k_walk_runs<unsigned short, 1, false>", 0),
     ("k_replace_emit", 0),
