@@ -87,8 +87,7 @@ __global__ __launch_bounds__(kWalkThreads, (LB <= 4 ? 8 : 4)) void k_walk_items(
     const uint32_t warm = it.warm, pos_bias = it.pos0 - it.warm + 1u;
     uint32_t st = 0;
     EventRegs ev{0, 0};
-    auto step = [&](uint32_t byte, uint32_t jj) __attribute__((always_inline)) {
-        const uint32_t coff = class_offset<E, MODE>(A, cls_lds, byte);
+    auto step_c = [&](uint32_t byte, uint32_t coff, uint32_t jj) __attribute__((always_inline)) {
         const uint32_t row = st < tile_rows ? st : tile_rows;
         uint32_t w = *reinterpret_cast<const E *>(tile + __umul24(row, A.row_bytes) + coff);
         if (w >= A.trap) {
@@ -106,16 +105,26 @@ __global__ __launch_bounds__(kWalkThreads, (LB <= 4 ? 8 : 4)) void k_walk_items(
             ++ev.n_ev;
         }
     };
+#define ACMI_STEP1(b, jj) step_c((b), class_offset<E, MODE>(A, cls_lds, (b)), (jj))
+    // SWAR3: the column offsets of a dword's four bytes together (a handful of operations for all four instead of eight per byte;
+    // TABLE stays byte by byte: four class reads in flight cost this kernel the registers it has; so does the drain form, which
+    // the compiler then gave 37 registers and an array in scratch memory: 3.9 -> 4.7 ms on the short patterns' drain)
+    auto step4 = [&](uint32_t wd, uint32_t jj) __attribute__((always_inline)) {
+        const uint32_t c4 = swar_columns<E>(A, wd);
+        step_c(wd & 0xffu, c4 & 0xffu, jj); step_c((wd >> 8) & 0xffu, (c4 >> 8) & 0xffu, jj + 1u);
+        step_c((wd >> 16) & 0xffu, (c4 >> 16) & 0xffu, jj + 2u); step_c(wd >> 24, c4 >> 24, jj + 3u);
+    };
     // (written out: as a loop over an array of the four words hipcc kept the array in scratch memory)
 #define ACMI_STEP4(wd, jj) \
-    step((wd) & 0xffu, (jj)); step(((wd) >> 8) & 0xffu, (jj) + 1u); step(((wd) >> 16) & 0xffu, (jj) + 2u); step((wd) >> 24, (jj) + 3u);
+    if constexpr (MODE == 1 && !EMIT) { step4((wd), (jj)); } \
+    else { ACMI_STEP1((wd) & 0xffu, (jj)); ACMI_STEP1(((wd) >> 8) & 0xffu, (jj) + 1u); ACMI_STEP1(((wd) >> 16) & 0xffu, (jj) + 2u); ACMI_STEP1((wd) >> 24, (jj) + 3u); }
     auto step_block = [&](const uint4 &blk, uint32_t jj) __attribute__((always_inline)) {
         ACMI_STEP4(blk.x, jj) ACMI_STEP4(blk.y, jj + 4u) ACMI_STEP4(blk.z, jj + 8u) ACMI_STEP4(blk.w, jj + 12u)
     };
 #undef ACMI_STEP4
     uint32_t j = 0;
     // head: single bytes up to a 16-byte boundary, single blocks up to a group boundary
-    for (; j < n && (reinterpret_cast<uintptr_t>(p + j) & 15u) != 0; ++j) step(p[j], j);
+    for (; j < n && (reinterpret_cast<uintptr_t>(p + j) & 15u) != 0; ++j) ACMI_STEP1(uint32_t(p[j]), j);
     for (; j + 16u <= n && (reinterpret_cast<uintptr_t>(p + j) & (16u * LB - 1u)) != 0; j += 16u)
         step_block(*reinterpret_cast<const uint4 *>(p + j), j);
     // body: groups of LB blocks of one line, the next group requested (back to back, clamped index) while this
@@ -140,7 +149,8 @@ __global__ __launch_bounds__(kWalkThreads, (LB <= 4 ? 8 : 4)) void k_walk_items(
     }
     // what is left: whole blocks, then bytes
     for (; j + 16u <= n; j += 16u) step_block(*reinterpret_cast<const uint4 *>(p + j), j);
-    for (; j < n; ++j) step(p[j], j);
+    for (; j < n; ++j) ACMI_STEP1(uint32_t(p[j]), j);
+#undef ACMI_STEP1
 
     if constexpr (EMIT) return;
     uint32_t walked = n;
