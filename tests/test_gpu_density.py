@@ -96,3 +96,22 @@ def test_find_first_on_haystacks_of_many_items(kernel):
             p, rr = device_match(res, ds, find_all)
             assert np.array_equal(p, pe) and np.array_equal(rr, re_)
         api.ahocorasick_deinit(res)
+
+
+@pytest.mark.parametrize("kernel", [0, 1, 4, 6])
+def test_events_of_more_than_255_records(kernel):
+    """A nested family a^1 .. a^300: the deepest final state stands for 300 records, more than the one-word head of a state's
+    output (`out_head`: the first pattern and min(count, 255)) can say -- the kernels fall back to the full count and list.
+    Two haystacks: long enough for every state, and a short one."""
+    pats = [b"a" * k for k in range(1, 301)] + [b"ba", b"ab"]
+    hays = [b"b" + b"a" * 700 + b"b" + b"a" * 40, b"aaab", b""]
+    pb, po = synth.pack(pats)
+    hb, ho = synth.pack(hays)
+    ds = synth.Dataset("nested300", pb, po, hb, ho)
+    res = resource_for(ds, kernel=kernel)
+    for find_all in (True, False):
+        pe, re_ = _oracle(ds, find_all)
+        p, r = device_match(res, ds, find_all)
+        assert np.array_equal(p, pe) and np.array_equal(r, re_), (kernel, find_all, len(r), len(re_))
+    assert int(pe[-1]) >= 1 and len(_oracle(ds)[1]) > 150000
+    api.ahocorasick_deinit(res)
