@@ -34,6 +34,7 @@ namespace acmi {
 constexpr uint32_t kTilesThreads = 1024;
 constexpr uint32_t kTilesWaves = kTilesThreads / 64;
 constexpr uint32_t kTilesRing = 128;   // events a wave stages in LDS (flushed to its queue 64 at a time)
+constexpr uint32_t kTilesFinals = 8192;  // !ALLHOT: up to this many final states keep their record counts in LDS, a byte each
 constexpr uint32_t kTilesLaneCap = 16; // LANEQ: events a LANE keeps in LDS (more: the wave walks its pieces again)
 
 struct TileArgs {
@@ -137,7 +138,9 @@ struct TileLds {
     uint32_t rows;            // rows of the tile
     uint32_t stride;          // ALLHOT: bytes from row to row = row_bytes + 2 x sizeof(E): {record count, state id} behind the transitions
     uint32_t final_from;      // ALLHOT: f1 x stride -- a state (row offset) is final from here on
-    const uint32_t *cnt;      // !ALLHOT: record counts of the tile's rows
+    const uint32_t *cnt;      // !ALLHOT, many final states: record counts of the tile's rows
+    const uint8_t *fcnt;      // !ALLHOT, <= kTilesFinals final states: min(records, 255) of EVERY final state, hot ones first (else null)
+    uint32_t hot_finals;      // trap - f1
     const uint2 *out1;        // ALLHOT, when there is room: the first {pattern, length} of every state's output list, else null
 };
 
@@ -154,7 +157,10 @@ __device__ __forceinline__ uint2 tiles_meta(const DevAutomaton &A, const TileLds
         const E *m = reinterpret_cast<const E *>(L.tile + s + A.row_bytes);
         return make_uint2(uint32_t(m[1]), uint32_t(m[0]));
     }
-    if (s < L.rows) return make_uint2(s, L.cnt[s]);
+    if (L.fcnt != nullptr) {   // (what the walk asks at every event: a global read here was a second L2 round trip in the step)
+        const uint32_t c = L.fcnt[s >= A.f2 ? s - A.f2 + L.hot_finals : s - A.f1];
+        if (c < 255u) return make_uint2(s, c);
+    } else if (s < L.rows) return make_uint2(s, L.cnt[s]);
     if (A.out_head != nullptr) {   // (the line the expansion reads again)
         const uint32_t c = A.out_head[s].x >> 24;
         if (c < 255u) return make_uint2(s, c);
@@ -343,6 +349,8 @@ __global__ __launch_bounds__(kTilesThreads, 8) void k_walk_tiles(DevAutomaton A,
     L.tile = smem + ring_bytes + cls_bytes;
     L.out1 = nullptr;
     L.cnt = nullptr;
+    L.fcnt = nullptr;
+    L.hot_finals = A.trap - A.f1;
     if (MODE == 0 && threadIdx.x < 256) reinterpret_cast<uint16_t *>(smem + ring_bytes)[threadIdx.x] = A.class_off[threadIdx.x];
     const uint8_t *src = static_cast<const uint8_t *>(A.lds_image) + A.tile_offset;
     if constexpr (ALLHOT) {
@@ -366,8 +374,15 @@ __global__ __launch_bounds__(kTilesThreads, 8) void k_walk_tiles(DevAutomaton A,
             L.out1 = o1;
         }
     } else {
-        // rows [0, L.rows) and, behind them, the row of "not here" entries (tiles_step); the image's own row `trap` is one
-        const uint32_t fit = A.row_bytes && T.tile_bytes > A.row_bytes + 16u ? (T.tile_bytes - A.row_bytes - 16u) / (A.row_bytes + 4u) : 0u;
+        // rows [0, L.rows) and, behind them, the row of "not here" entries (tiles_step); the image's own row `trap` is one.
+        // Record counts: of every final state, a byte each, when there are few enough (a pattern set of a few thousand: all of
+        // them) -- the tile's first rows are the shallow states, final states among them are rare, and the count of a final state
+        // OUTSIDE the tile was a global read at every event; else of the tile's rows, a word each, as before.
+        const uint32_t n_final = (A.trap - A.f1) + (A.n_states - A.f2);
+        const bool bytes = n_final <= kTilesFinals;
+        const uint32_t fbytes = bytes ? (n_final + 15u) & ~15u : 0u;
+        const uint32_t per_row = A.row_bytes + (bytes ? 0u : 4u);
+        const uint32_t fit = A.row_bytes && T.tile_bytes > A.row_bytes + 16u + fbytes ? (T.tile_bytes - A.row_bytes - 16u - fbytes) / per_row : 0u;
         L.rows = fit < A.trap ? fit : A.trap;
         L.stride = A.row_bytes;
         L.final_from = 0;
@@ -380,9 +395,19 @@ __global__ __launch_bounds__(kTilesThreads, 8) void k_walk_tiles(DevAutomaton A,
             E *trap_row = reinterpret_cast<E *>(smem + ring_bytes + cls_bytes + L.rows * A.row_bytes);
             for (uint32_t t = threadIdx.x; t < A.n_columns; t += kTilesThreads) trap_row[t] = E(A.trap);
         }
-        uint32_t *cdst = reinterpret_cast<uint32_t *>(smem + ring_bytes + cls_bytes + tile_bytes);
-        for (uint32_t t = threadIdx.x; t < L.rows; t += kTilesThreads) cdst[t] = A.out_count[t];
-        L.cnt = cdst;
+        if (bytes) {
+            uint8_t *fdst = smem + ring_bytes + cls_bytes + tile_bytes;
+            const uint32_t hot_finals = A.trap - A.f1;
+            for (uint32_t t = threadIdx.x; t < n_final; t += kTilesThreads) {
+                const uint32_t c = A.out_count[t < hot_finals ? A.f1 + t : A.f2 + (t - hot_finals)];
+                fdst[t] = uint8_t(c < 255u ? c : 255u);
+            }
+            L.fcnt = fdst;
+        } else {
+            uint32_t *cdst = reinterpret_cast<uint32_t *>(smem + ring_bytes + cls_bytes + tile_bytes);
+            for (uint32_t t = threadIdx.x; t < L.rows; t += kTilesThreads) cdst[t] = A.out_count[t];
+            L.cnt = cdst;
+        }
     }
     if (threadIdx.x == 0) s_walked = 0;
     TileQueue Q;
