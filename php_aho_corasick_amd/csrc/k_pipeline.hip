@@ -174,6 +174,20 @@ __global__ __launch_bounds__(kExpandThreads) void k_expand(DevAutomaton A, Batch
     uint64_t v[kExpandPerThread], rb[kExpandPerThread + 1];
 #pragma unroll
     for (int i = 0; i < kExpandPerThread; ++i) v[i] = base + i < items ? B.rec_count[base + i] : 0ull;
+    // What the item's first event needs does not depend on the scan: requested here, in flight through the scan and the
+    // look-back (four dependent loads used to start behind them; an item usually has one event of one record).
+    static_assert(kExpandPerThread == 1, "the prefetch below is written for one item per thread");
+    uint32_t hay0 = 0, prev0 = 0xFFFFFFFFu, n0 = 0;
+    uint2 ev0 = make_uint2(0u, 0u), head0 = make_uint2(0u, 0u);
+    if (base < items) {
+        hay0 = B.item_hay[base];
+        prev0 = base ? B.item_hay[base - 1] : 0xFFFFFFFFu;
+        n0 = B.ev_count[base];
+        if (n0 != 0u && n0 <= B.slab_events) {
+            ev0 = B.slab[base];
+            if (A.out_head != nullptr) head0 = A.out_head[ev0.y];
+        }
+    }
     if constexpr (SCAN) {
         uint64_t sum = 0;
 #pragma unroll
@@ -225,16 +239,17 @@ __global__ __launch_bounds__(kExpandThreads) void k_expand(DevAutomaton A, Batch
             s_closing = 1u;
             break;
         }
-        const uint32_t hay = B.item_hay[g];
-        const uint32_t prev = g ? B.item_hay[g - 1] : 0xFFFFFFFFu;
+        const uint32_t hay = hay0, prev = prev0;
         if (prev != hay) {  // the haystack's first item: its prefix word, and those of the empty haystacks right before it
             for (uint32_t hh = prev + 1u; hh != hay + 1u; ++hh) prefix[hh] = rb[i];
         }
-        const uint32_t n = B.ev_count[g];
+        const uint32_t n = n0;
         if (n == 0 || n > B.slab_events) continue;  // overflowed items are k_refill's
         if (rb[i + 1] > cap) continue;
         uint64_t w = rb[i];
-        for (uint32_t e = 0; e < n; ++e) {
+        if ((head0.x >> 24) == 1u) out[w++] = make_uint4(hay, ev0.x, ev0.x - head0.y, head0.x & 0xFFFFFFu);
+        else w = emit_event(A, out, w, hay, ev0.x, ev0.y);
+        for (uint32_t e = 1; e < n; ++e) {
             const uint2 ev = B.slab[uint64_t(e) * B.run_stride + g];  // event-major, like the run lists
             w = emit_event(A, out, w, hay, ev.x, ev.y);
         }
