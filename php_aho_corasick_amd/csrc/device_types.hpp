@@ -95,6 +95,8 @@ struct BatchArgs {
     uint32_t wave_items;         // k_scan_anchor: items a wave takes per batch (1..64)
     uint32_t wave_grab;          // persistent mode: batches a wave takes from counters[1] per atomic (>= 1; see engine.cpp)
     uint32_t reserve_cus;        // persistent scan kernels launch this many workgroups fewer than the chip has CUs ("reserve_cus")
+    uint32_t zero_counters;      // 1: the item table is the slot's own from the batch before (same uniform shape): nobody zeroed the
+                                 // per-item counters -- k_walk_runs writes every item's
 };
 
 // one trie depth of the automaton build (k_build_level); all pointers are device pointers

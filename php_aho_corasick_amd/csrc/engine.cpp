@@ -680,6 +680,7 @@ int acmi_get_stat(const acmi_handle *h, const char *key, double *value) {
         const std::string k(key);
         if (k == "split") { *value = h->part[0] ? 1 : 0; return ACMI_OK; }
         if (k == "merged_batches") { *value = h->merged_batches; return ACMI_OK; }
+        if (k == "item_tables_kept") { *value = double(h->item_tables_kept); return ACMI_OK; }
         if (k == "resume_haystack") { *value = double(h->resume_haystack); return ACMI_OK; }
         if (k == "split_long_patterns" || k == "split_short_patterns") {
             *value = h->part[0] ? double(h->part[k == "split_long_patterns" ? 0 : 1]->aut.accepted_count()) : 0.0;

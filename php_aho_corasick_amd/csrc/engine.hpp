@@ -176,6 +176,11 @@ struct acmi_handle {
     // geometry it holds; uniform_len != 0 while such a batch is being enqueued
     DevBuf d_uni_off[2];
     uint64_t uni_nh[2] = {0, 0}, uni_len[2] = {0, 0};
+    // the item table a slot holds (uniform batches through the filter: written once, not per batch): what it was made from
+    struct ItemKey { uint64_t nh = 0, len = 0, max_items = 0; uint32_t chunk = 0, warm = 0, align = 0, blob_mis = 0; const void *rec = nullptr, *hay = nullptr, *base = nullptr, *zero = nullptr; bool valid = false;
+        bool operator==(const ItemKey &o) const { return nh == o.nh && len == o.len && max_items == o.max_items && chunk == o.chunk && warm == o.warm && align == o.align && blob_mis == o.blob_mis && rec == o.rec && hay == o.hay && base == o.base && zero == o.zero; } };
+    ItemKey item_key[2];
+    uint64_t item_tables_kept = 0;   // batches that reused their slot's item table (acmi_get_stat "item_tables_kept")
     uint64_t uniform_len = 0;
     // The item table of a batch (item_base, item -> haystack, packed item records, zeroed per-item counters, k_items' own sync
     // words) exists once per slot: k_items needs nothing from the batch before, so with "items_ahead" it runs on a side stream

@@ -326,8 +326,25 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
         // batch had no pipeline, failed, or this k_items runs ahead of it)
         if (!h->isync_clean[slot_index] || ist != st) HIPCHK(h, hipMemsetAsync(d_isync.p, 0, d_isync.cap & ~size_t(15), ist));
         h->isync_clean[slot_index] = false;
-        if (h->uniform_len && blob_bytes == h->uniform_len * nh) launch_items_uniform(B, h->uniform_len, d_item_base.as<uint64_t>(), ist);
-        else launch_items(B, blob_bytes, max_items, d_item_base.as<uint64_t>(), d_isync.as<uint32_t>(), ist);
+        // A uniform batch's item table is a function of its shape alone: a slot that holds the table of the same shape keeps it
+        // (through the filter + k_walk_runs, which then writes every item's counters itself: a launch and its boundary less per
+        // batch, ~ 10 us of the headline's step)
+        const bool uniform = h->uniform_len && blob_bytes == h->uniform_len * nh;
+        acmi_handle::ItemKey key;
+        key.nh = nh; key.len = h->uniform_len; key.max_items = max_items; key.chunk = B.chunk_bytes; key.warm = B.warm_bytes; key.align = B.align_warm;
+        key.blob_mis = uint32_t(reinterpret_cast<uintptr_t>(B.blob) & 127u);
+        key.rec = d_item_rec.p; key.hay = d_item_hay.p; key.base = d_item_base.p; key.zero = d_zero.p;
+        acmi_handle::ItemKey &held = h->item_key[slot_index];
+        const bool reuse = uniform && held.valid && held == key && kernel == 2 && !fa.anchor_dense && ist == st;
+        B.zero_counters = reuse ? 1u : 0u;
+        if (reuse) {
+            ++h->item_tables_kept;
+        } else {
+            held.valid = false;
+            if (uniform) launch_items_uniform(B, h->uniform_len, d_item_base.as<uint64_t>(), ist);
+            else launch_items(B, blob_bytes, max_items, d_item_base.as<uint64_t>(), d_isync.as<uint32_t>(), ist);
+            if (uniform) { held = key; held.valid = true; }
+        }
         if (ist != st) {
             HIPCHK(h, hipEventRecord(h->ev_items[slot_index], ist));
             HIPCHK(h, hipStreamWaitEvent(st, h->ev_items[slot_index], 0));

@@ -79,6 +79,10 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_runs(DevAutomaton A, Batc
     if (item < total_items) {
         nr = B.run_count[item];
         rec = B.item_rec[item];
+        if (B.zero_counters) {   // (the table is the batch before's: so are these, until an item with events overwrites them below)
+            B.ev_count[item] = 0u;
+            B.rec_count[item] = 0ull;
+        }
     }
     const uint32_t tile_rows = A.row_bytes ? (tile_bytes / A.row_bytes < A.trap ? tile_bytes / A.row_bytes : A.trap) : 0u;
     {

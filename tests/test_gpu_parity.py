@@ -646,3 +646,44 @@ def test_uniform_batch_entry_equals_the_offsets_entry():
         assert np.array_equal(p, pf) and np.array_equal(r, rf)
         api.ahocorasick_deinit(res)
     o.close()
+
+
+def test_uniform_batches_keep_their_item_table():
+    """A slot that holds the item table of the same uniform shape keeps it (no k_items_uniform: k_walk_runs writes every item's
+    counters): the same shape again with OTHER text -- events in other haystacks, in none, findAll on and off --, other shapes in
+    between, an unaligned blob, two batches in flight: always the records of the general entry."""
+    import torch
+    from php_aho_corasick_amd import batch
+    ds = synth.g2()
+    o = Oracle("port")
+    o.add_patterns((ds.pat_blob, ds.pat_off))
+    texts = [ds.hay_blob.copy() for _ in range(3)]
+    texts[1][:] = np.roll(ds.hay_blob, 4099)          # the plants elsewhere
+    texts[2][:] = ord("x")                            # nothing to find
+    n_bytes = len(ds.hay_blob)
+    d_texts = [torch.from_numpy(np.concatenate([np.zeros(48, np.uint8), t])).cuda() for t in texts]   # + room for an unaligned view
+    res = resource_for(ds, kernel=2)
+    batch.bind_current_stream(res)
+    plan = [(0, 8192, 0, True), (1, 8192, 0, True), (2, 8192, 0, True), (0, 8192, 0, False), (1, 4096, 0, True), (1, 8192, 0, True),
+            (0, 8192, 16, True), (1, 8192, 16, True), (2, 8192, 16, False), (0, 8192, 0, True), (0, 8192, 0, True), (1, 8192, 0, True)]
+    want = []
+    for t, hl, shift, fa in plan:
+        nh = (n_bytes - 64) // hl
+        src = np.concatenate([np.zeros(48, np.uint8), texts[t]])[48 + shift: 48 + shift + hl * nh]
+        want.append(o.match_batch(src, np.arange(nh + 1, dtype=np.uint64) * np.uint64(hl), fa))
+    began = ended = 0
+    while ended < len(plan):
+        while began < len(plan) and began - ended < 2:
+            t, hl, shift, fa = plan[began]
+            nh = (n_bytes - 64) // hl
+            batch.match_device_begin_uniform(res, d_texts[t][48 + shift:], hl, nh, fa)
+            began += 1
+        total = batch.match_device_end(res)
+        t, hl, shift, fa = plan[ended]
+        nh = (n_bytes - 64) // hl
+        p, r = batch.result_numpy(res, nh, total)
+        assert np.array_equal(p, want[ended][0]) and np.array_equal(r, want[ended][1]), (ended, plan[ended], total, len(want[ended][1]))
+        ended += 1
+    assert res.stat("item_tables_kept") >= 3
+    api.ahocorasick_deinit(res)
+    o.close()
