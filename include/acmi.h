@@ -178,7 +178,9 @@ int acmi_match_batch_device_begin(acmi_handle *h, const void *d_blob, uint64_t b
                                   const void *d_offsets, size_t n_haystacks, int find_all);
 /* The same for a UNIFORM batch -- n_haystacks haystacks of haystack_bytes each, back to back from d_blob (the shape of
  * examples/benchmark.php's buffers: 256 x 8,192): no offsets array is needed, the library keeps its own, and the work-item table
- * is written in closed form instead of being counted and scanned (19 -> 4 us per 2^19 haystacks).  Ended by
+ * is written in closed form instead of being counted and scanned (19 -> 4 us per 2^19 haystacks) -- and kept: a batch of the
+ * shape its slot saw last (same count, length, alignment of d_blob modulo 128) through the anchor filter launches nothing for it
+ * (acmi_get_stat "item_tables_kept").  Ended by
  * acmi_match_batch_device_end like any other begun batch; results and lifetimes are the same. */
 int acmi_match_batch_device_begin_uniform(acmi_handle *h, const void *d_blob, uint64_t haystack_bytes, size_t n_haystacks, int find_all);
 int acmi_match_batch_device_end(acmi_handle *h, uint64_t *n_records);
