@@ -22,6 +22,7 @@ bool live(const acmi_handle *h) {
 
 int fail_hip(acmi_handle *h, hipError_t e, const char *what) {
     h->last_error = std::string(what) + ": " + hipGetErrorString(e);
+    h->item_key[0].valid = h->item_key[1].valid = false;   // (whatever was enqueued may not have run: no table is taken on trust)
     return (e == hipErrorOutOfMemory) ? ACMI_E_NOMEM : ACMI_E_DEVICE;
 }
 
