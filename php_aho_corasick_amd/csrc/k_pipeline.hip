@@ -178,13 +178,14 @@ __global__ __launch_bounds__(kExpandThreads) void k_expand(DevAutomaton A, Batch
     // look-back (four dependent loads used to start behind them; an item usually has one event of one record).
     static_assert(kExpandPerThread == 1, "the prefetch below is written for one item per thread");
     uint32_t hay0 = 0, prev0 = 0xFFFFFFFFu, n0 = 0;
-    uint2 ev0 = make_uint2(0u, 0u), head0 = make_uint2(0u, 0u);
+    uint2 ev0 = make_uint2(0u, 0u), ev1 = make_uint2(0u, 0u), head0 = make_uint2(0u, 0u);
     if (base < items) {
         hay0 = B.item_hay[base];
         prev0 = base ? B.item_hay[base - 1] : 0xFFFFFFFFu;
         n0 = B.ev_count[base];
         if (n0 != 0u && n0 <= B.slab_events) {
             ev0 = B.slab[base];
+            if (n0 > 1u) ev1 = B.slab[B.run_stride + base];
             if (A.out_head != nullptr) head0 = A.out_head[ev0.y];
         }
     }
@@ -247,11 +248,18 @@ __global__ __launch_bounds__(kExpandThreads) void k_expand(DevAutomaton A, Batch
         if (n == 0 || n > B.slab_events) continue;  // overflowed items are k_refill's
         if (rb[i + 1] > cap) continue;
         uint64_t w = rb[i];
-        if ((head0.x >> 24) == 1u) out[w++] = make_uint4(hay, ev0.x, ev0.x - head0.y, head0.x & 0xFFFFFFu);
-        else w = emit_event(A, out, w, hay, ev0.x, ev0.y);
-        for (uint32_t e = 1; e < n; ++e) {
-            const uint2 ev = B.slab[uint64_t(e) * B.run_stride + g];  // event-major, like the run lists
-            w = emit_event(A, out, w, hay, ev.x, ev.y);
+        // an item with many events (tens per item on text full of matches): event e + 2 and the output head of event e + 1 are
+        // requested before event e is written -- one round trip per event instead of two dependent ones
+        uint2 ev_a = ev0, hd_a = head0, ev_b = ev1;
+        for (uint32_t e = 0; e < n; ++e) {
+            uint2 ev_c = make_uint2(0u, 0u), hd_b = make_uint2(0u, 0u);
+            if (e + 2u < n) ev_c = B.slab[uint64_t(e + 2u) * B.run_stride + g];  // event-major, like the run lists
+            if (e + 1u < n && A.out_head != nullptr) hd_b = A.out_head[ev_b.y];
+            if ((hd_a.x >> 24) == 1u) out[w++] = make_uint4(hay, ev_a.x, ev_a.x - hd_a.y, hd_a.x & 0xFFFFFFu);
+            else w = emit_event(A, out, w, hay, ev_a.x, ev_a.y);
+            ev_a = ev_b;
+            hd_a = hd_b;
+            ev_b = ev_c;
         }
     }
     __syncthreads();
