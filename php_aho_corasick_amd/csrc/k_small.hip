@@ -32,7 +32,8 @@ static SmallLayout small_layout(uint32_t span, uint32_t nh, uint32_t hot_bytes, 
     SmallLayout Y{};
     // (the smallest items that still fit the item arrays: more lanes walk, each fewer steps -- the warm-up of Lmax - 1 bytes per
     // item is cheap next to a chip that would otherwise run two waves)
-    Y.chunk = (span + 15u) / 16u + nh <= kSmallMaxItems ? 16u : (span + 31u) / 32u + nh <= kSmallMaxItems ? 32u : 64u;
+    // (8 bytes when that gives every thread ONE item: one 8 KiB haystack = 1,024 items of 8 + 15 steps instead of 512 of 16 + 15)
+    Y.chunk = (span + 7u) / 8u + nh <= kSmallThreads + 1u ? 8u : (span + 15u) / 16u + nh <= kSmallMaxItems ? 16u : (span + 31u) / 32u + nh <= kSmallMaxItems ? 32u : 64u;
     Y.max_items = std::min<uint32_t>(kSmallMaxItems, ((span + Y.chunk - 1u) / Y.chunk + nh + 1u) & ~1u);
     if (Y.max_items < 2u) Y.max_items = 2u;
     Y.in_bytes = (span + 15u) & ~15u;
