@@ -94,7 +94,10 @@ __global__ __launch_bounds__(kSmallThreads) void k_match_small(DevAutomaton A, c
     const uint32_t t = threadIdx.x;
     // (phase stamps of thread 0, 100 MHz: summary[4..10] -- ACMI_SMALL_TRACE prints them; seven stores to pinned memory)
     const uint64_t t_start = wall_clock64();
-    auto stamp = [&](int i) { if (t == 0) out_summary[4 + i] = wall_clock64() - t_start; };
+    // (only when asked for -- find_all bit 1: seven stores into pinned host memory that the system-scope fence at the end waits for)
+    const bool stamps = (find_all & 2u) != 0u;
+    find_all &= 1u;
+    auto stamp = [&](int i) { if (stamps && t == 0) out_summary[4 + i] = wall_clock64() - t_start; };
     const uint64_t off0 = offsets[0];
     // offsets -> LDS (relative to the first one), items per haystack
     for (uint32_t h = t; h <= nh; h += kSmallThreads) hay_off[h] = uint32_t(offsets[h] - off0);
@@ -233,7 +236,8 @@ hipError_t launch_match_small(const DevAutomaton &A, const uint64_t *offsets, co
     auto go = [&](auto fn) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(kSmallLds));
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(fn, dim3(1), dim3(kSmallThreads), lds, st, A, offsets, blob, nh, uint32_t(find_all ? 1 : 0),
+        static const bool trace = std::getenv("ACMI_SMALL_TRACE") != nullptr;
+        hipLaunchKernelGGL(fn, dim3(1), dim3(kSmallThreads), lds, st, A, offsets, blob, nh, uint32_t(find_all ? 1 : 0) | (trace ? 2u : 0u),
                            max_pattern_length, out_summary, out_prefix, static_cast<uint4 *>(out_records), cap, Y, seq);
         return hipGetLastError();
     };
