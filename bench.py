@@ -447,6 +447,50 @@ def keywords_leg(torch, api, batch, synth, dev, nh=1 << 17, words_only=False):
     return out
 
 
+L2_LINES_PER_S = 34.5e12 / 128   # MI355X_MICROARCH.md: the L2s' 34.5 TB/s in 128-byte lines: what a table walk's rows outside LDS cost
+
+
+def dictionary_leg(torch, api, batch, synth, dev, nh=1 << 17):
+    """Big dictionaries of short words (the reference's README: "especially effective if there is a large database of needles"):
+    16,384 and 65,536 words of 4..12 letters over 1 GiB of letters and spaces, automatic kernel choice, the first 16 haystacks
+    against the oracle.  No filter applies (14 % of all byte offsets of such text start a 4-gram of the 65,536-word list, and
+    nothing shorter than the shortest word can be hashed): it is a table walk, nearly every step of which leaves the LDS tile --
+    so next to the HBM fraction the leg states the floor the L2's request rate sets (one 128-byte line per text byte)."""
+    from oracle import pyoracle
+    letters = bytes(range(ord("a"), ord("z") + 1))
+    text = synth.generate("words", 33, 1, 4, 12, 2048, HAY_LEN, letters + b"     ")
+    out = []
+    for n_words in (16384, 65536):
+        pats = synth.generate("words", 34, n_words, 4, 12, 1, 16, letters)
+        t0 = time.perf_counter()
+        res = api.ahocorasick_init([{"id": k, "value": p} for k, p in enumerate(pats.patterns())])
+        api.ahocorasick_finalize(res)
+        build_ms = (time.perf_counter() - t0) * 1e3
+        d_blob = torch.from_numpy(text.hay_blob).to(dev).repeat(nh // 2048).contiguous()
+        d_off = torch.arange(nh + 1, dtype=torch.int64, device=dev) * HAY_LEN
+        batch.bind_current_stream(res)
+        ms, scan, walk, total = _timed_calls(torch, batch, res, d_blob, d_off, calls=4, skip=1)
+        prefix, rec = batch.result_numpy(res, nh, total)
+        o = pyoracle.Oracle("port")
+        o.add_patterns((pats.pat_blob, pats.pat_off))
+        n_chk = 16
+        pe, re_ = o.match_batch(text.hay_blob[:int(text.hay_off[n_chk])], text.hay_off[:n_chk + 1], True)
+        o.close()
+        ok = np.array_equal(prefix[:n_chk + 1], pe) and np.array_equal(rec[:int(pe[-1])], re_) and total == int(prefix[2048]) * (nh // 2048)
+        leg = _leg_summary(f"{n_words} words of 4..12 letters over letters + spaces, {nh} haystacks x {HAY_LEN} B ({nh * HAY_LEN >> 20} MiB)",
+                           nh * HAY_LEN, nh, total, ms, scan, walk, res, ok)
+        floor_ms = nh * HAY_LEN / L2_LINES_PER_S * 1e3
+        leg.update({"words": n_words, "states": int(res.stat("states")), "automaton_bytes": int(res.stat("automaton_bytes")), "build_ms": round(build_ms, 1),
+                    "records_per_haystack": round(total / nh, 2),
+                    "l2_request_floor_ms": round(floor_ms, 3), "l2_request_floor": "one 128-byte line per text byte (every step outside the LDS tile: the 65,536-word list; the 16,384-word list leaves it at ~ 0.6 of its steps) at the L2s' 34.5 TB/s (DESIGN 4.16)",
+                    "floor_over_measured": round(floor_ms / ms, 3)})
+        out.append(leg)
+        api.ahocorasick_deinit(res)
+        del d_blob, d_off
+        torch.cuda.empty_cache()
+    return out
+
+
 def short_patterns_leg(torch, api, batch, synth, dev, ds, nh=1 << 17):
     """The headline pattern set (2,048 x 16 B over abcdef) PLUS eight patterns of 2..6 B -- the reference takes any length from
     1 to 1,024 B in one trie (src/multifast/ahocorasick.c:101-105); here a pattern under 7 B takes the whole set off the
@@ -1101,6 +1145,8 @@ def main():
             out["short_patterns"] = short_patterns_leg(torch, api, batch, synth, dev, ds)
         if want_leg("config3") and args.workload == "headline":
             out["config3"] = config3_leg(torch, api, batch, synth, dev, cpu=not args.no_cpu)
+        if want_leg("big_dictionary"):
+            out["big_dictionary"] = dictionary_leg(torch, api, batch, synth, dev)
         if want_leg("density_sweep"):
             out["density_sweep"] = density_leg(torch, api, batch, synth, dev)
         if want_leg("choice_matrix"):

@@ -12,6 +12,8 @@ for k, v in (d.get("short_patterns") or {}).items():
     if isinstance(v, dict): print("short_patterns", k, v.get("ms_per_call"), v.get("frac_whole_call"), v.get("kernel"))
 for s in d.get("short_haystacks") or []:
     print("short_haystacks", s["haystack_bytes"], s["ms_per_call"], s["frac_whole_call"], s.get("uniform_entry"))
+for b in d.get("big_dictionary") or []:
+    print("dictionary", b["words"], b["ms_per_call"], b["kernel"], b["frac_whole_call"], "floor/measured", b["floor_over_measured"], b["check_ok"])
 ds = d.get("density_sweep")
 if ds:
     for c in ds["cells"]:
