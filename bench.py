@@ -17,7 +17,9 @@ Workload (config.workload): BASELINE.json configs[1] shape -- 2048 patterns x 16
 haystacks, alphabet abcdef, one planted hit per haystack -- scaled to 2^19 haystacks (4 GiB) per
 GPU, because the literal 256-haystack / 2 MiB batch is 0.3 us of HBM time, below launch latency.
 
-Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes of one scan launch
+The LAST stdout line (rank 0) is the result: one JSON object under 4 KB with the contract keys, `roofline`, `cpu_baseline`
+and one {frac, ok} pair per secondary leg (`legs`).  The legs in full go to an earlier line prefixed "BENCH_DETAIL " and to
+gpurun_out/bench_legs.json.  `roofline.achieved` = algorithmic bytes of one scan launch
 (haystack bytes + 16 B per record + 8 B per haystack) / mean duration of the scan
 kernel measured with HIP events on the stream it runs on.  `cpu_baseline` = the reference's own
 MultiFast C (oracle/_ref, kind "reference") or our restatement (kind "port") timed on this box's
@@ -754,6 +756,78 @@ def replace_leg(torch, api, batch, synth, dev, nh=1 << 17):
     return leg
 
 
+def _leg_scalar(name, leg):
+    """One leg of the bench reduced to what the result line carries: the smallest roofline fraction any of its cells reached
+    (whole calls; a leg that reports no fraction carries its own headline figure) and whether every check in it passed."""
+    fracs, oks = [], []
+
+    def walk(x):
+        if isinstance(x, dict):
+            for k, v in x.items():
+                if k in ("frac_whole_call", "frac_of_hbm_peak") and isinstance(v, (int, float)):
+                    fracs.append(float(v))
+                elif k in ("check_ok", "count_ok", "all_check_ok", "ok") and isinstance(v, bool):
+                    oks.append(v)
+                else:
+                    walk(v)
+        elif isinstance(x, list):
+            for v in x:
+                walk(v)
+    walk(leg)
+    s = {"ok": bool(all(oks)) if oks else None}
+    if fracs:
+        s["frac"] = round(min(fracs), 4)
+    if name == "choice_matrix":
+        s = {"ok": not leg["violations"], "violations": len(leg["violations"]), "worst_ratio": leg["worst_ratio_automatic_over_best_forced"]}
+    elif name == "host_entry":
+        s["pcie_inclusive_GB_per_s"] = leg["batch_512MiB"]["GB_per_s_pcie_inclusive"]
+        s["single_match_8KiB_us"] = leg.get("single_match_8KiB_us")
+    elif name == "benchmark_php_sample":
+        for k in ("s_per_sample", "gpu_s_per_sample"):
+            if k in leg:
+                s[k] = leg[k]
+    return s
+
+
+RESULT_LINE_LIMIT = 4096   # bytes; the driver reads the LAST stdout line, and a 26 KB one (round 4) was more than it takes
+
+
+def _result_line(out, detail, leg_s):
+    """The bench's result: the contract keys, `roofline`, `cpu_baseline` and one scalar pair per secondary leg -- short enough
+    for the driver to parse.  Everything else (`detail`) goes to an earlier, prefixed line and to gpurun_out/bench_legs.json."""
+    line = dict(out)
+    line["legs"] = {name: _leg_scalar(name, leg) for name, leg in detail.items()}
+    line["legs_seconds"] = round(sum(leg_s.values()), 1)
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= RESULT_LINE_LIMIT - 256:   # never expected; what goes first is commentary, not a figure
+        for key in ("note",):
+            line.get("ranks", {}).pop(key, None)
+        for key in ("kernel_ms_per_step", "host_ms_between_step_ends", "kernels_of_timed_steps", "sclk_mhz_start", "sclk_mhz_end"):
+            line.get("roofline", {}).pop(key, None)
+        for c in (line.get("cpu_baseline"), line.get("cpu_baseline_all_cores")):
+            if c:
+                c["sample"] = c["sample"][:80]
+        text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < RESULT_LINE_LIMIT, f"result line of {len(text)} bytes"
+    return text
+
+
+def _emit(out, detail, leg_s):
+    full = dict(out)
+    full.update(detail)
+    full["leg_seconds"] = leg_s
+    blob = json.dumps(full)
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "bench_legs.json"), "w") as f:
+            f.write(blob + "\n")
+    except OSError:
+        pass
+    if detail:
+        print("BENCH_DETAIL " + blob, flush=True)   # (prefixed: not a JSON line, cannot be taken for the result)
+    print(_result_line(out, detail, leg_s), flush=True)
+
+
 def _spawn(args):
     """`python bench.py --gpus N` without a launcher: become N ranks under torch.distributed.run (one per GPU, RCCL).
     Fewer than N GPUs is an error, not a silent single-GPU run (ACMI_BENCH_BACKEND=gloo, ranks sharing GPU 0, exists to
@@ -825,6 +899,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-dense", action="store_true", help="skip the secondary BASELINE configs[4] (dense-match) measurement")
     ap.add_argument("--no-legs", action="store_true", help="skip the other secondary legs (config 3, general path, keyword set, host-buffer entry, ...)")
+    ap.add_argument("--choice-matrix", type=int, default=1, help="0: leave the kernel-choice matrix (tests/test_gpu_cliffs.py's, the longest leg) out of the default legs")
     ap.add_argument("--legs", default="", help="comma-separated subset of the secondary legs to run (default: all)")
     ap.add_argument("--events", type=int, default=1, help="analysis: 0 = no HIP events around the scan kernel in the timed region (roofline fields are then meaningless)")
     ap.add_argument("--in-flight", type=int, default=2, help="batches begun before the oldest is ended (1 or 2)")
@@ -1111,7 +1186,7 @@ def main():
             if not done.wait(120):
                 if rank == 0:
                     out["ranks"]["c_abi_exchange"] = {"ok": False, "error": "acmi_comm_allgather_result did not return within 120 s"}
-                    print(json.dumps(out), flush=True)
+                    print(_result_line(out, {}, {}), flush=True)
                 os._exit(0 if rank == 0 else 3)
         threading.Thread(target=watchdog, daemon=True).start()
         try:
@@ -1124,38 +1199,45 @@ def main():
     if rank == 0:
         legs = set(x for x in args.legs.split(",") if x)
         want_leg = lambda name: world == 1 and not args.no_legs and (not legs or name in legs)  # noqa: E731
+        detail, leg_s = {}, {}
+
+        def run_leg(name, fn, *a, **kw):
+            t_leg = time.perf_counter()
+            detail[name] = fn(*a, **kw)
+            leg_s[name] = round(time.perf_counter() - t_leg, 2)
+
         if world == 1 and not args.no_dense and (not legs or "config5_dense" in legs):
-            out["config5_dense"] = dense_leg(torch, api, batch, synth, dev)
+            run_leg("config5_dense", dense_leg, torch, api, batch, synth, dev)
         # secondary figures, measured outside the timed region on the same GPU, same process
         if want_leg("general_path") and args.workload == "headline":
-            out["general_path"] = general_leg(torch, api, batch, wl.patterns(), d_blob, d_off, nh, records_per_step)
+            run_leg("general_path", general_leg, torch, api, batch, wl.patterns(), d_blob, d_off, nh, records_per_step)
         if want_leg("host_entry") and args.workload == "headline":
-            out["host_entry"] = host_leg(api, synth, ds, tile_count)
+            run_leg("host_entry", host_leg, api, synth, ds, tile_count)
         del d_blob
         torch.cuda.empty_cache()
         if want_leg("short_haystacks"):
-            out["short_haystacks"] = short_haystacks_leg(torch, api, batch, synth, dev)
+            run_leg("short_haystacks", short_haystacks_leg, torch, api, batch, synth, dev)
         if want_leg("replace"):
-            out["replace"] = replace_leg(torch, api, batch, synth, dev)
+            run_leg("replace", replace_leg, torch, api, batch, synth, dev)
         if want_leg("keyword_set"):
-            out["keyword_set"] = keywords_leg(torch, api, batch, synth, dev)
+            run_leg("keyword_set", keywords_leg, torch, api, batch, synth, dev)
         if want_leg("keyword_words"):
-            out["keyword_words"] = keywords_leg(torch, api, batch, synth, dev, words_only=True)
+            run_leg("keyword_words", keywords_leg, torch, api, batch, synth, dev, words_only=True)
         if want_leg("short_patterns") and args.workload == "headline":
-            out["short_patterns"] = short_patterns_leg(torch, api, batch, synth, dev, ds)
+            run_leg("short_patterns", short_patterns_leg, torch, api, batch, synth, dev, ds)
         if want_leg("config3") and args.workload == "headline":
-            out["config3"] = config3_leg(torch, api, batch, synth, dev, cpu=not args.no_cpu)
+            run_leg("config3", config3_leg, torch, api, batch, synth, dev, cpu=not args.no_cpu)
         if want_leg("big_dictionary"):
-            out["big_dictionary"] = dictionary_leg(torch, api, batch, synth, dev)
+            run_leg("big_dictionary", dictionary_leg, torch, api, batch, synth, dev)
         if want_leg("density_sweep"):
-            out["density_sweep"] = density_leg(torch, api, batch, synth, dev)
-        if want_leg("choice_matrix"):
-            out["choice_matrix"] = choice_matrix_leg()
+            run_leg("density_sweep", density_leg, torch, api, batch, synth, dev)
+        if want_leg("choice_matrix") and (args.choice_matrix or "choice_matrix" in legs):
+            run_leg("choice_matrix", choice_matrix_leg)
         if want_leg("benchmark_php_sample") and args.workload == "headline":
-            out["benchmark_php_sample"] = benchmark_php_leg(api, synth)
+            run_leg("benchmark_php_sample", benchmark_php_leg, api, synth)
         if args.phase_times:
             out["host_us_per_step"] = {k: round(v / args.steps * 1e6, 1) for k, v in phase.items()}
-        print(json.dumps(out), flush=True)
+        _emit(out, detail, leg_s)
     api.ahocorasick_deinit(res)
     if gather:
         dist.barrier()

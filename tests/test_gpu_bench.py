@@ -63,3 +63,35 @@ def test_bench_one_rank_has_the_contract_fields():
     assert line["n_gpus"] == 1 and line["check_ok"] is True and line["cpu_baseline"]["kind"] in ("reference", "port")
     r = line["roofline"]
     assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and r["kernel_ms_per_step"]["min"] <= r["kernel_ms_per_step"]["median"] <= r["kernel_ms_per_step"]["max"]
+
+
+@pytest.mark.gpu
+def test_default_command_prints_a_result_line_the_driver_can_read():
+    """`python bench.py` exactly as the driver runs it (every leg): the LAST stdout line is the result, one JSON object under
+    4 KB carrying the contract keys with `roofline` and `cpu_baseline`; the legs in full are on an earlier, prefixed line and
+    in gpurun_out/bench_legs.json.  (Round 4's 26 KB last line was not parsed by the driver.)"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"], env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = out.stdout.rstrip("\n").split("\n")
+    last = lines[-1]
+    assert len(last) < 4096 and last.startswith("{"), (len(last), last[:200])
+    line = json.loads(last)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline", "check_ok", "matches_per_s", "legs"):
+        assert key in line, key
+    assert line["steps"] == 20 and line["warmup"] == 5 and line["check_ok"] is True
+    assert 0 < line["roofline"]["frac"] < 1 and line["roofline"]["bound"] == "hbm" and line["cpu_baseline"]["value"] > 0
+    assert line["cpu_baseline"]["cores"] == 1 and line["cpu_baseline_all_cores"]["value"] > 0
+    want = {"config5_dense", "general_path", "host_entry", "short_haystacks", "replace", "keyword_set", "keyword_words", "short_patterns",
+            "config3", "big_dictionary", "density_sweep", "choice_matrix", "benchmark_php_sample"}
+    assert want <= set(line["legs"]), want - set(line["legs"])
+    assert all(v["ok"] is not False for k, v in line["legs"].items() if k != "choice_matrix"), line["legs"]
+    assert all(set(v) <= {"ok", "frac", "violations", "worst_ratio", "pcie_inclusive_GB_per_s", "single_match_8KiB_us", "s_per_sample", "gpu_s_per_sample"} for v in line["legs"].values())
+    detail = [l for l in lines[:-1] if l.startswith("BENCH_DETAIL ")]
+    assert len(detail) == 1 and not [l for l in lines[:-1] if l.startswith("{")]
+    full = json.loads(detail[0][len("BENCH_DETAIL "):])
+    assert want <= set(full) and full["value"] == line["value"]
+    assert json.load(open(os.path.join(ROOT, "gpurun_out", "bench_legs.json")))["value"] == line["value"]
