@@ -55,7 +55,7 @@ def _cgroup_cpu_max():
     return None
 
 
-def cpu_baseline(ds, seconds_target: float = 12.0):
+def cpu_baseline(ds, seconds_target: float = 10.0):
     """Reference CPU path over a bounded sample: 1 thread (the reference as shipped) and all cores
     (one trie per thread -- AC_TRIE_t is not re-entrant, ahocorasick.h:49-65)."""
     from oracle import pyoracle
@@ -203,7 +203,23 @@ def _leg_summary(workload, blob_bytes, nh, total, ms, scan, walk, res, ok):
             "frac_whole_call_two_in_flight": round(algo / (_timed_calls.two_in_flight_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
 
-def config3_leg(torch, api, batch, synth, dev, nh=1 << 20, cpu=True):
+def config3_cpu_start(synth, nh=1 << 20):
+    """The config-3 leg's CPU baseline (the reference's trie of 65,536 patterns takes seconds to build, on one core) on a thread of
+    its own, begun behind the timed region: it runs -- in C, the GIL released -- next to the GPU legs and is joined by config3_leg."""
+    box = {}
+
+    def work():
+        try:
+            ds = synth.g6(n_hay=4096, hay_len=4096)
+            box["out"] = config3_cpu_baseline(ds, 4096, 4096, max(1, nh // 4096) * 4096)
+        except Exception as e:   # reported with the leg, not fatal
+            box["out"] = {"error": str(e)[:200]}
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    return th, box
+
+
+def config3_leg(torch, api, batch, synth, dev, nh=1 << 20, cpu=None):
     """BASELINE configs[2]: 65,536 patterns of 8..64 B over Sigma=256 (2.27 M states, seed 7: the G6 automaton),
     2^20 haystacks x 4 KiB = 4 GiB resident, one planted pattern per haystack.  Check: every haystack's plant is
     reported at its place (pattern, start and end), and the tile's record count repeats."""
@@ -242,7 +258,8 @@ def config3_leg(torch, api, batch, synth, dev, nh=1 << 20, cpu=True):
     api.ahocorasick_deinit(res)
     del d_blob
     if cpu:
-        out["cpu_baseline"] = config3_cpu_baseline(ds, tile_h, hl, nh)
+        cpu[0].join()
+        out["cpu_baseline"] = cpu[1].get("out")
     return out
 
 
@@ -373,15 +390,16 @@ def density_leg(torch, api, batch, synth, dev, nh=1 << 17):
             "all_check_ok": bool(all(c["check_ok"] for c in cells))}
 
 
-def choice_matrix_leg():
+def choice_matrix_leg(full=False):
     """The cliff detector of tests/test_gpu_cliffs.py as a driver-visible figure: {2,048 x 16 B; 2,048 words; 65,536 x 8..64 B} x
-    {1, 8, 32, 128, 512 occurrences per 8 KiB} x {256 B, 8 KiB, 1 MiB haystacks}, 64 MiB batches; in every cell the automatic
-    mode (10 batches to settle) against every forced scan kernel, all record arrays equal (the oracle on a slice)."""
+    {1, 32, 512 occurrences per 8 KiB} x {256 B, 8 KiB, 1 MiB haystacks} (--choice-matrix 2: the test's own five densities), 64 MiB
+    batches; in every cell the automatic mode (10 batches to settle) against every forced scan kernel, all record arrays equal
+    (the oracle on a slice).  The test itself runs the whole matrix; profiles/r05/cliffs_*.txt are five runs of it."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from test_gpu_cliffs import run_matrix
+    from test_gpu_cliffs import run_matrix, DENSITIES
     out = {"cells": [], "violations": []}
     for kind in ("headline", "words", "cfg3"):
-        rows, bad = run_matrix(kind)
+        rows, bad = run_matrix(kind, densities=DENSITIES if full else (1, 32, 512))
         out["cells"] += [{"set": r["set"], "per_8KiB": r["per_8k"], "haystack_bytes": r["hay_len"], "records": r["records"], "automatic_ms": r["auto_ms"],
                           "automatic_kernel": r["auto_kernel"], "best_forced_ms": r["best_forced_ms"], "best_forced_kernel": r["best_forced_kernel"],
                           "forced_ms": r["forced_ms"]} for r in rows]
@@ -899,7 +917,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-dense", action="store_true", help="skip the secondary BASELINE configs[4] (dense-match) measurement")
     ap.add_argument("--no-legs", action="store_true", help="skip the other secondary legs (config 3, general path, keyword set, host-buffer entry, ...)")
-    ap.add_argument("--choice-matrix", type=int, default=1, help="0: leave the kernel-choice matrix (tests/test_gpu_cliffs.py's, the longest leg) out of the default legs")
+    ap.add_argument("--choice-matrix", type=int, default=1, help="0: leave the kernel-choice matrix (tests/test_gpu_cliffs.py's, the longest leg) out of the default legs; 2: all five densities of the test instead of three")
     ap.add_argument("--legs", default="", help="comma-separated subset of the secondary legs to run (default: all)")
     ap.add_argument("--events", type=int, default=1, help="analysis: 0 = no HIP events around the scan kernel in the timed region (roofline fields are then meaningless)")
     ap.add_argument("--in-flight", type=int, default=2, help="batches begun before the oldest is ended (1 or 2)")
@@ -1200,6 +1218,7 @@ def main():
         legs = set(x for x in args.legs.split(",") if x)
         want_leg = lambda name: world == 1 and not args.no_legs and (not legs or name in legs)  # noqa: E731
         detail, leg_s = {}, {}
+        cfg3_cpu = config3_cpu_start(synth) if (want_leg("config3") and args.workload == "headline" and not args.no_cpu) else None
 
         def run_leg(name, fn, *a, **kw):
             t_leg = time.perf_counter()
@@ -1226,13 +1245,13 @@ def main():
         if want_leg("short_patterns") and args.workload == "headline":
             run_leg("short_patterns", short_patterns_leg, torch, api, batch, synth, dev, ds)
         if want_leg("config3") and args.workload == "headline":
-            run_leg("config3", config3_leg, torch, api, batch, synth, dev, cpu=not args.no_cpu)
+            run_leg("config3", config3_leg, torch, api, batch, synth, dev, cpu=cfg3_cpu)
         if want_leg("big_dictionary"):
             run_leg("big_dictionary", dictionary_leg, torch, api, batch, synth, dev)
         if want_leg("density_sweep"):
             run_leg("density_sweep", density_leg, torch, api, batch, synth, dev)
         if want_leg("choice_matrix") and (args.choice_matrix or "choice_matrix" in legs):
-            run_leg("choice_matrix", choice_matrix_leg)
+            run_leg("choice_matrix", choice_matrix_leg, full=args.choice_matrix > 1)
         if want_leg("benchmark_php_sample") and args.workload == "headline":
             run_leg("benchmark_php_sample", benchmark_php_leg, api, synth)
         if args.phase_times:

@@ -310,7 +310,10 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *   "max_result_bytes"  0 (default): the result buffers grow to whatever a batch produces (16 B per record; a^1..a^16 over
  *                    1 GiB: 275 GB -- ACMI_E_NOMEM); else the device-resident batch entries return ACMI_E_PARTIAL with the
  *                    first haystacks whose records fit (see there), never allocating more.  A single haystack whose own
- *                    records exceed the cap fails with ACMI_E_TOO_LARGE.  >= 4096                     [any time]
+ *                    records exceed the cap fails with ACMI_E_TOO_LARGE.  >= 4096.  A split set (see "split") bounds each
+ *                    of its two match arrays and the merged one alike.  acmi_replace_batch(_device) needs every match of
+ *                    the batch at once: under a bound its records exceed it fails with ACMI_E_PARTIAL and no output --
+ *                    pass smaller batches                                                        [any time]
  *   "part_kernel"    split sets (see "split"): the "kernel" of the SHORT part alone, -1 (default) its own automatic choice; with 6
  *                    and a small short part the long part's records are merged into the result as the short part's are
  *                    written -- no merge pass                                                    [any time]

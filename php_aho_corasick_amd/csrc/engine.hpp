@@ -114,6 +114,7 @@ struct acmi_handle {
     int kernel = 3;  // 0 plain global table, 1 LDS-tile walk, 2 anchor filter (if eligible), 3 automatic, 4 whole-item walk, 6 tile walk (single pass, ordered output)
     int tile_w = 0, tile_p = 0;   // k_walk_tiles: bytes per lane / lanes per item (0: tiles_geometry chooses)
     int reserve_cus = 0;          // compute units the persistent scan kernels leave free (a collective's kernels need some while a scan runs)
+    int rerun_kernel = -1;        // >= 0 while a batch is enqueued AGAIN: the kernel of its first run (enqueue_batch takes it, no probe, nothing learned)
     int part_kernel = -1;         // split sets: the kernel forced on the SHORT part (-1: its own automatic choice)
     uint64_t max_result_bytes = 0;   // 0: unbounded; else a batch hands out at most this much (ACMI_E_PARTIAL + "resume_haystack")
     uint64_t resume_haystack = 0;    // after ACMI_E_PARTIAL: the first haystack that is NOT in the result
@@ -131,7 +132,9 @@ struct acmi_handle {
     // lost probe).  Round 3 had thresholds here (bytes walked, matches per byte, candidates per byte), each found as a 5-10 x cliff.
     enum Strategy { kStratAnchor = 0, kStratLds = 1, kStratTiles = 2, kStratItems = 3, kStratCount = 4 };
     struct ChoiceClass {
-        float cost[kStratCount] = {0, 0, 0, 0};      // ms per GiB of haystack bytes, moving average of the batches run on it (0: never run)
+        float cost[kStratCount] = {0, 0, 0, 0};      // ms per GiB of haystack bytes: the lower of its last two batches (0: never run)
+        float last[kStratCount] = {0, 0, 0, 0};      // ... what its last batch measured
+        uint32_t seen = 0;                           // batches in a row the strategy in use has been measured on (probes of others wait for two)
         uint32_t wait[kStratCount] = {0, 0, 0, 0};   // batches until this alternative may be probed again
         uint32_t span[kStratCount] = {16, 16, 16, 16};   // its back-off after the next lost probe
         int cur = -1;                                // strategy in use (-1: not seeded yet)
@@ -177,8 +180,10 @@ struct acmi_handle {
     DevBuf d_uni_off[2];
     uint64_t uni_nh[2] = {0, 0}, uni_len[2] = {0, 0};
     // the item table a slot holds (uniform batches through the filter: written once, not per batch): what it was made from
-    struct ItemKey { uint64_t nh = 0, len = 0, max_items = 0; uint32_t chunk = 0, warm = 0, align = 0, blob_mis = 0; const void *rec = nullptr, *hay = nullptr, *base = nullptr, *zero = nullptr; bool valid = false;
-        bool operator==(const ItemKey &o) const { return nh == o.nh && len == o.len && max_items == o.max_items && chunk == o.chunk && warm == o.warm && align == o.align && blob_mis == o.blob_mis && rec == o.rec && hay == o.hay && base == o.base && zero == o.zero; } };
+    // (the kept table stands only while k_walk_runs -- which zeroes every item's counters itself -- is the one kernel that touches them
+    // before the expansion: the kernel and findAll are part of the key, tests/test_gpu_variants.py compares kept with fresh tables)
+    struct ItemKey { uint64_t nh = 0, len = 0, max_items = 0; uint32_t chunk = 0, warm = 0, align = 0, blob_mis = 0, first_only = 0; int kernel = 0; const void *rec = nullptr, *hay = nullptr, *base = nullptr, *zero = nullptr; bool valid = false;
+        bool operator==(const ItemKey &o) const { return kernel == o.kernel && first_only == o.first_only && nh == o.nh && len == o.len && max_items == o.max_items && chunk == o.chunk && warm == o.warm && align == o.align && blob_mis == o.blob_mis && rec == o.rec && hay == o.hay && base == o.base && zero == o.zero; } };
     ItemKey item_key[2];
     uint64_t item_tables_kept = 0;   // batches that reused their slot's item table (acmi_get_stat "item_tables_kept")
     uint64_t uniform_len = 0;

@@ -3,6 +3,12 @@
 
 namespace acmi_engine {
 
+// ACMI_CHOICE_TRACE=1: every decision of the automatic mode on stderr (tools/exp_choice.py reads it)
+static bool choice_trace() {
+    static const bool on = std::getenv("ACMI_CHOICE_TRACE") != nullptr;
+    return on;
+}
+
 // ---- automatic mode: the measured choice of the scan strategy --------------------------------------------------------------
 // Batches are told apart by size (small ones are launch-bound whatever scans them) and by whether their haystacks are short
 // (under 512 B on average: the anchor kernel spends a wave step per work item, the walks a lane): what one kind of batch
@@ -73,6 +79,7 @@ int choose_strategy(acmi_handle *h, acmi_handle::FlySlot &F, uint64_t blob_bytes
         if (s == C.cur || !strategy_eligible(h, s, blob_bytes, nh, find_all)) continue;
         F.probe = true;
         ++h->probes;
+        if (choice_trace()) std::fprintf(stderr, "[acmi choice] class %d: probe %d (in use %d)\n", F.choice_class, s, C.cur);
         return s;
     }
     return C.cur;
@@ -81,7 +88,18 @@ int choose_strategy(acmi_handle *h, acmi_handle::FlySlot &F, uint64_t blob_bytes
 void learn_strategy(acmi_handle *h, const acmi_handle::FlySlot &F, double ms_per_gib, double density) {
     acmi_handle::ChoiceClass &C = h->choice[F.find_all ? 1 : 0][F.choice_class];
     const int s = F.strategy;
-    C.cost[s] = C.cost[s] > 0.f ? 0.5f * C.cost[s] + 0.5f * float(ms_per_gib) : float(ms_per_gib);
+    if (choice_trace())
+        std::fprintf(stderr, "[acmi choice] class %d: strategy %d%s measured %.3f ms/GiB (had %.3f), in use %d at %.3f, density %.5f\n", F.choice_class, s,
+                     F.probe ? " (probe)" : "", ms_per_gib, double(C.cost[s]), C.cur, C.cur >= 0 ? double(C.cost[C.cur]) : 0.0, density);
+    // What a strategy costs is the LOWER of its last two batches: a measurement errs upwards only (the two events span the host's
+    // enqueue -- a descheduled host thread, a clock that has not ramped yet, another process on the chip), and one batch at 3.6 x
+    // its usual time used to send the next three batches out as probes of every alternative (round 4's "cliff" of cfg3 / 256 B in
+    // one bench run of two: the timed calls were the spike and two probes).  A probe stands on its own measurement: what the
+    // strategy cost when it last ran was another text.
+    const float now = float(ms_per_gib);
+    const bool first = C.last[s] <= 0.f || (F.probe && s != C.cur);
+    C.cost[s] = first ? now : std::min(C.last[s], now);
+    C.last[s] = now;
     if (F.probe && s != C.cur) {
         // a probe wins when it is at least 1.12 x cheaper than what the strategy in use costs now (both MEASURED on this text: the
         // margin only has to cover the run-to-run spread, a few per cent; at 1.25 a 2,048-word list over prose stayed on a filter
@@ -89,11 +107,12 @@ void learn_strategy(acmi_handle *h, const acmi_handle::FlySlot &F, double ms_per
         if (C.cost[C.cur] > 0.f && C.cost[s] * 1.12f < C.cost[C.cur]) {
             C.cur = s;
             C.span[s] = 16;
+            C.seen = 1;
             ++h->switches;
         } else if (C.span[s] == 16 && C.cost[s] < 1.5f * C.cost[C.cur]) {
             // a close first loss is measured once more at once: a strategy's first batch on a handle carries its kernel's first
             // launch (code object, LDS attribute) -- the 2,048-word list over prose lost 2.33 against 2.77 ms that way
-            C.cost[s] = 0.f;
+            C.cost[s] = C.last[s] = 0.f;
             C.span[s] = 32;
             C.pending |= 1u << s;
         } else {
@@ -107,6 +126,8 @@ void learn_strategy(acmi_handle *h, const acmi_handle::FlySlot &F, double ms_per
     // once its back-off allows: what it cost on EARLIER text (a filter that lost on dense matches) does not keep it out for good,
     // the text may have changed.  (Expected cost: the kernel's rate plus what any pipeline costs whatever it scans, ~ 60 us --
     // small batches are launch-bound on every strategy and probe nothing.)
+    // (... and only on the evidence of two batches in a row: `cost` is then the lower of the two)
+    if (C.seen < 2 && ++C.seen < 2) return;
     for (int a = 0; a < acmi_handle::kStratCount; ++a) {
         if (a == s || C.wait[a] || !strategy_eligible(h, a, F.blob_bytes, F.nh, F.find_all)) continue;
         const float ref = nominal_cost(h, a, F.blob_bytes, F.nh, density) + 0.06f * float(1ull << 30) / float(F.blob_bytes);

@@ -67,7 +67,8 @@ int run_batch_begin(acmi_handle *h, const uint8_t *d_blob, uint64_t blob_bytes, 
             c->profile = h->profile;
             c->uniform_len = h->uniform_len;
             c->merge_into = acmi_handle::MergeInto{};
-            if (c == h->part[1] && find_all && nh && tiles_can_merge(c->dA, int(c->aut.flat().entry_bytes))) {
+            c->max_result_bytes = h->max_result_bytes;   // (each part alone is bounded like the whole: run_split_end)
+            if (c == h->part[1] && find_all && nh && !h->max_result_bytes && tiles_can_merge(c->dA, int(c->aut.flat().entry_bytes))) {
                 // the short part's tile walk can place the long part's records among its own as it writes them: no merge pass
                 // over the whole result (the short part's 70 M records per GiB were copied once more, 0.5 ms)
                 acmi_handle *a = h->part[0];
@@ -142,7 +143,12 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     int kernel = (h->kernel == 2 && !fa.anchor_q) ? 1 : h->kernel;
     F.strategy = -1;
     F.choice_class = choice_class(blob_bytes, nh);
-    if (h->kernel == 3) {
+    if (h->rerun_kernel >= 0) {
+        // a batch that is run again (its records outgrew the buffer; a split set's short part after the long part's records
+        // changed) takes the kernel of its first run: the automatic choice may hold a pending probe of another one, and what the
+        // caller of the re-run set up -- the merged output of k_walk_tiles -- belongs to that kernel
+        kernel = h->rerun_kernel;
+    } else if (h->kernel == 3) {
         F.strategy = choose_strategy(h, F, blob_bytes, nh, find_all);
         kernel = F.strategy == acmi_handle::kStratAnchor ? 2 : F.strategy == acmi_handle::kStratLds ? 1 : F.strategy == acmi_handle::kStratTiles ? 6 : 4;
     }
@@ -331,6 +337,7 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
         // batch, ~ 10 us of the headline's step)
         const bool uniform = h->uniform_len && blob_bytes == h->uniform_len * nh;
         acmi_handle::ItemKey key;
+        key.kernel = kernel; key.first_only = find_all ? 0u : 1u;
         key.nh = nh; key.len = h->uniform_len; key.max_items = max_items; key.chunk = B.chunk_bytes; key.warm = B.warm_bytes; key.align = B.align_warm;
         key.blob_mis = uint32_t(reinterpret_cast<uintptr_t>(B.blob) & 127u);
         key.rec = d_item_rec.p; key.hay = d_item_hay.p; key.base = d_item_base.p; key.zero = d_zero.p;
@@ -422,10 +429,51 @@ int run_split_end(acmi_handle *h) {
     acmi_handle *a = h->part[0], *b = h->part[1];
     int rc = run_batch_end(a);
     const int rc2 = run_batch_end(b);
-    if (rc < 0 || rc2 < 0) { h->last_error = rc < 0 ? a->last_error : b->last_error; return rc < 0 ? rc : rc2; }
+    if ((rc < 0 && rc != ACMI_E_PARTIAL) || (rc2 < 0 && rc2 != ACMI_E_PARTIAL)) {
+        const bool first = rc < 0 && rc != ACMI_E_PARTIAL;
+        h->last_error = first ? a->last_error : b->last_error;
+        return first ? rc : rc2;
+    }
     hipStream_t st = F.stream;
-    const uint32_t nh = uint32_t(F.nh), first_only = F.find_all ? 0u : 1u;
-    const uint64_t ta = a->last_total, tb = b->last_total;
+    uint32_t nh = uint32_t(F.nh);
+    const uint32_t first_only = F.find_all ? 0u : 1u;
+    uint64_t ta = a->last_total, tb = b->last_total;
+    bool partial = false;
+    if (h->max_result_bytes) {
+        // "max_result_bytes" on a split set: each part was bounded on its own (ACMI_E_PARTIAL: it holds the records of its first
+        // resume_haystack haystacks); the merged result takes the haystacks BOTH hold whose records together fit the bound --
+        // the largest k with pa[k] + pb[k] <= bound, by single-word copies (an exception, not a rate)
+        const uint64_t bound = h->max_result_bytes / 16;
+        uint64_t k = std::min<uint64_t>(rc == ACMI_E_PARTIAL ? a->resume_haystack : nh, rc2 == ACMI_E_PARTIAL ? b->resume_haystack : nh);
+        const uint64_t *dpa = a->d_prefix().as<uint64_t>(), *dpb = b->d_prefix().as<uint64_t>();
+        auto both = [&](uint64_t i, uint64_t *va, uint64_t *vb) -> hipError_t {
+            hipError_t e = hipMemcpy(va, dpa + i, 8, hipMemcpyDeviceToHost);
+            return e != hipSuccess ? e : hipMemcpy(vb, dpb + i, 8, hipMemcpyDeviceToHost);
+        };
+        uint64_t va = 0, vb = 0;
+        HIPCHK(h, both(k, &va, &vb));
+        if (va + vb > bound) {
+            uint64_t lo = 0, hi = k;   // sum[lo] <= bound < sum[hi]
+            while (hi - lo > 1) {
+                const uint64_t mid = (lo + hi) >> 1;
+                HIPCHK(h, both(mid, &va, &vb));
+                if (va + vb <= bound) lo = mid; else hi = mid;
+            }
+            k = lo;
+            HIPCHK(h, both(k, &va, &vb));
+        }
+        if (k < nh) {
+            if (k == 0) {
+                h->have_result = false;
+                h->last_error = "the records of one haystack alone exceed max_result_bytes";
+                return ACMI_E_TOO_LARGE;
+            }
+            partial = true;
+            nh = uint32_t(k);
+            ta = va;
+            tb = vb;
+        }
+    }
     HIPCHK(h, F.d_prefix.ensure((size_t(nh) + 1) * 8));
     acmi_handle::FlySlot &FA = a->fly[a->cur], &FB = b->fly[b->cur];
     bool merged = FB.merged;
@@ -441,12 +489,21 @@ int run_split_end(acmi_handle *h) {
         b->merge_into.records = FA.d_out.p;
         b->merge_into.out = F.d_out.p;
         b->merge_into.cap = F.d_out.cap / 16;
-        const int rr = enqueue_batch(b, FB, FB.d_blob, FB.blob_bytes, FB.d_off, FB.nh, FB.find_all);
+        b->rerun_kernel = FB.kernel_used;
+        int rr = enqueue_batch(b, FB, FB.d_blob, FB.blob_bytes, FB.d_off, FB.nh, FB.find_all);
         b->merge_into = acmi_handle::MergeInto{};
+        if (rr >= 0 && !FB.merged) {
+            // (cannot happen while the kernel is pinned and the geometry is a function of the batch: if the re-run did not merge
+            // after all, the part's OWN buffer must hold its records before k_merge_parts reads them)
+            b->out_want = std::max<size_t>(b->out_want, size_t(tb) * 16);
+            rr = enqueue_batch(b, FB, FB.d_blob, FB.blob_bytes, FB.d_off, FB.nh, FB.find_all);
+        }
+        b->rerun_kernel = -1;
         if (rr < 0) { b->sync_tiles = 0; h->last_error = b->last_error; return rr; }
         b->enqueue_seq = FB.seq;
         HIPCHK(h, hipStreamSynchronize(st));
         merged = FB.merged;
+        if (!merged && FB.out_cap < tb) { h->last_error = "split set: the short part's records did not fit its buffer on the second run"; return ACMI_E_DEVICE; }
     }
     HIPCHK(h, F.d_out.ensure(std::max<uint64_t>(16, (ta + tb) * 16)));
     const uint64_t *pa = a->d_prefix().as<uint64_t>(), *pb = b->d_prefix().as<uint64_t>();
@@ -486,6 +543,11 @@ int run_split_end(acmi_handle *h) {
     h->scan_ms = a->scan_ms + b->scan_ms;
     h->walk_ms = a->walk_ms + b->walk_ms;
     h->total_ms = a->total_ms + b->total_ms;
+    h->resume_haystack = nh;
+    if (partial) {
+        h->last_error = "the batch's records exceed max_result_bytes: the result holds the first haystacks only (resume_haystack)";
+        return ACMI_E_PARTIAL;
+    }
     return ACMI_OK;
 }
 
@@ -555,7 +617,7 @@ int run_batch_end(acmi_handle *h) {
         }
     }
     // "max_result_bytes": a batch whose records exceed the cap hands out the haystacks that fit below it
-    const uint64_t bound = (h->max_result_bytes && !h->is_part) ? h->max_result_bytes / 16 : ~0ull;
+    const uint64_t bound = h->max_result_bytes ? h->max_result_bytes / 16 : ~0ull;   // (a split set's parts too: run_split_end takes what both hold)
     const bool partial = total > bound;
     const uint64_t need = partial ? bound : total;   // records the buffer must hold
     if (!F.merged) h->out_want = std::max<size_t>(h->out_want, size_t(need) * 16);
@@ -597,7 +659,9 @@ int run_batch_end(acmi_handle *h) {
             }
             if (too_small) { h->out_want = std::max<size_t>(h->out_want, size_t(need) * 16); HIPCHK(h, F.d_out.ensure(need * 16)); }
             h->refill_armed = true;
+            h->rerun_kernel = F.kernel_used;
             const int rc = enqueue_batch(h, F, F.d_blob, F.blob_bytes, F.d_off, F.nh, F.find_all);
+            h->rerun_kernel = -1;
             if (rc < 0) { h->sync_tiles = 0; return rc; }
             h->enqueue_seq = F.seq;
             HIPCHK(h, hipStreamSynchronize(st));
@@ -696,7 +760,7 @@ int run_small(acmi_handle *h, const uint8_t *blob, const uint64_t *offsets, size
         if (done) std::atomic_thread_fence(std::memory_order_acquire);
         else HIPCHK(h, hipStreamSynchronize(st));
     }
-    if (std::getenv("ACMI_SMALL_TRACE"))
+    if (small_trace())
         std::fprintf(stderr, "[acmi small] staged %.1f  items %.1f  walked %.1f  scanned %.1f  written %.1f us\n", summary[4] / 100.0, summary[5] / 100.0,
                      summary[6] / 100.0, summary[7] / 100.0, summary[8] / 100.0);
     if (summary[2] != 0) return 1;  // more records than the pinned buffer holds: general path

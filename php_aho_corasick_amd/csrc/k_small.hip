@@ -228,6 +228,11 @@ __global__ __launch_bounds__(kSmallThreads) void k_match_small(DevAutomaton A, c
     if (t == 0) __hip_atomic_store(out_summary + 3, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+bool small_trace() {
+    static const bool on = std::getenv("ACMI_SMALL_TRACE") != nullptr;
+    return on;
+}
+
 hipError_t launch_match_small(const DevAutomaton &A, const uint64_t *offsets, const uint8_t *blob, uint32_t nh, int find_all,
                               uint32_t max_pattern_length, int entry_bytes, int class_mode, uint64_t *out_summary,
                               uint64_t *out_prefix, void *out_records, uint32_t cap, uint32_t span_bytes, uint64_t seq, hipStream_t st) {
@@ -236,7 +241,7 @@ hipError_t launch_match_small(const DevAutomaton &A, const uint64_t *offsets, co
     auto go = [&](auto fn) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(kSmallLds));
         if (e != hipSuccess) return e;
-        static const bool trace = std::getenv("ACMI_SMALL_TRACE") != nullptr;
+        const bool trace = small_trace();
         hipLaunchKernelGGL(fn, dim3(1), dim3(kSmallThreads), lds, st, A, offsets, blob, nh, uint32_t(find_all ? 1 : 0) | (trace ? 2u : 0u),
                            max_pattern_length, out_summary, out_prefix, static_cast<uint4 *>(out_records), cap, Y, seq);
         return hipGetLastError();

@@ -10,6 +10,8 @@
 
 namespace acmi {
 
+bool small_trace();   // ACMI_SMALL_TRACE is set (read once: k_small.hip's launch and engine_pipeline.cpp's run_small share it)
+
 // single-pass scans (kdev.hpp, k_pipeline.hip): tiles of 2048 elements, one status word per tile
 uint32_t scan_tiles(uint64_t n);
 // isync: 8 + 8 x scan_tiles(n_haystacks + 1) zeroed bytes {ticket, bad-offsets flag, status words}

@@ -129,3 +129,47 @@ def test_merged_output_of_a_split_set_at_mid_density():
         assert np.array_equal(p, pf) and np.array_equal(r, rf)
         api.ahocorasick_deinit(res)
     o.close()
+
+
+@pytest.mark.parametrize("name", ["X1", "X2"])
+@pytest.mark.parametrize("options", [dict(split=1), dict(split=1, part_kernel=6), dict(split=1, part_kernel=4), dict(split=1, part_kernel=1)])
+@pytest.mark.parametrize("find_all", [True, False])
+def test_split_set_under_a_result_bound(name, options, find_all):
+    """"max_result_bytes" on a split set (acmi.h: "never allocating more", ACMI_E_PARTIAL): each part is bounded like a whole
+    handle, the merged result takes the haystacks both parts hold whose records together fit -- segment by segment the
+    concatenation is the oracle's array, and no segment exceeds the bound."""
+    import torch
+    from php_aho_corasick_amd import batch, _native as N
+    ds = synth.TARGETED[name]()
+    o = Oracle("port")
+    o.add_patterns((ds.pat_blob, ds.pat_off))
+    pe, re_ = o.match_batch(ds.hay_blob, ds.hay_off, find_all)
+    per_hay = np.diff(pe)
+    cap = max(4096, (int(per_hay.max()) * 16 + 15) & ~15, int(pe[-1]) * 16 // 5 & ~15)   # about five segments; the largest haystack fits
+    res = resource_for(ds, max_result_bytes=cap, small_path=0, **options)
+    d_blob = torch.from_numpy(ds.hay_blob).cuda()
+    d_off = torch.from_numpy(ds.hay_off.astype(np.int64)).cuda()
+    batch.bind_current_stream(res)
+    got, segments = [], 0
+    for first, k, total in batch.match_device_bounded(res, d_blob, d_off, find_all):
+        p, r = batch.result_numpy(res, k, total)
+        assert int(p[-1]) == total and total * 16 <= cap and k >= 1
+        assert np.array_equal(p, pe[first:first + k + 1] - pe[first])
+        r = r.copy()
+        r[:, 0] += first
+        got.append(r)
+        segments += 1
+    assert res.stat("split") == 1 and segments >= 3
+    assert np.array_equal(np.concatenate(got), re_)
+    p, r = host_match(res, ds, find_all)                   # the host-buffer entry drains the same way inside the library
+    assert np.array_equal(p, pe) and np.array_equal(r, re_)
+    res.set_option("max_result_bytes", 4096)
+    if int(per_hay.max()) * 16 > 4096:
+        with pytest.raises(N.AcmiError) as e:
+            batch.match_device(res, d_blob, d_off, find_all)
+        assert e.value.status == N.E_TOO_LARGE
+    res.set_option("max_result_bytes", 0)                  # ... and without the bound the merged path is back
+    p, r = device_match(res, ds, find_all)
+    assert np.array_equal(p, pe) and np.array_equal(r, re_)
+    api.ahocorasick_deinit(res)
+    o.close()
