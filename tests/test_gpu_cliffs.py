@@ -36,14 +36,17 @@ def _timed(torch, batch, res, d_blob, d_off, warm, n=3):
     return best * 1e3, total
 
 
-def run_matrix(kind, densities=DENSITIES, hay_sizes=HAY_SIZES, verbose=False):
+def run_matrix(kind, densities=DENSITIES, hay_sizes=HAY_SIZES, verbose=False, oracle=True):
     import torch
     from oracle.pyoracle import Oracle
     from php_aho_corasick_amd import api, batch, synth
     base = synth.density_set(kind)
     pats = [{"id": k, "value": p} for k, p in enumerate(base.patterns())]
-    o = Oracle("port")
-    o.add_patterns((base.pat_blob, base.pat_off))
+    # (oracle=False -- bench.py's leg for the 65,536-pattern set, whose CPU trie takes seconds to build: the kernels are compared
+    # with each other only, four independent walks; this test always checks against the oracle)
+    o = Oracle("port") if oracle else None
+    if o:
+        o.add_patterns((base.pat_blob, base.pat_off))
     handles = {}
     for kern in (3,) + KERNELS:
         res = api.ahocorasick_init(pats)
@@ -63,7 +66,7 @@ def run_matrix(kind, densities=DENSITIES, hay_sizes=HAY_SIZES, verbose=False):
             d_blob = torch.from_numpy(ds.hay_blob).cuda().repeat(reps).contiguous()
             d_off = torch.arange(nh + 1, dtype=torch.int64, device="cuda") * hay_len
             n_chk = max(1, min(ds.n_haystacks, (128 << 10) // hay_len))
-            pe, re_ = o.match_batch(ds.hay_blob[:int(ds.hay_off[n_chk])], ds.hay_off[:n_chk + 1], True)
+            pe, re_ = o.match_batch(ds.hay_blob[:int(ds.hay_off[n_chk])], ds.hay_off[:n_chk + 1], True) if o else (None, None)
             ref = None
             cell = {}
             for kern, res in handles.items():
@@ -77,7 +80,7 @@ def run_matrix(kind, densities=DENSITIES, hay_sizes=HAY_SIZES, verbose=False):
                 if ref is None:
                     ref = rec.clone()
                     p, r = batch.result_numpy(res, nh, total)
-                    ok = np.array_equal(p[:n_chk + 1], pe) and np.array_equal(r[:int(pe[-1])], re_) and int(p[-1]) == total
+                    ok = int(p[-1]) == total and (o is None or (np.array_equal(p[:n_chk + 1], pe) and np.array_equal(r[:int(pe[-1])], re_)))
                     if not ok:
                         bad.append(f"{kind} {per}/8KiB hay {hay_len}: kernel {kern} differs from the oracle")
                 elif total != ref.shape[0] or not torch.equal(rec, ref):
@@ -97,7 +100,8 @@ def run_matrix(kind, densities=DENSITIES, hay_sizes=HAY_SIZES, verbose=False):
             del d_blob, d_off, ref
     for res in handles.values():
         api.ahocorasick_deinit(res)
-    o.close()
+    if o:
+        o.close()
     torch.cuda.empty_cache()
     return rows, bad
 

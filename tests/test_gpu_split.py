@@ -159,7 +159,7 @@ def test_split_set_under_a_result_bound(name, options, find_all):
         r[:, 0] += first
         got.append(r)
         segments += 1
-    assert res.stat("split") == 1 and segments >= 3
+    assert res.stat("split") == 1 and segments >= (3 if int(pe[-1]) * 16 >= 3 * cap else 1)
     assert np.array_equal(np.concatenate(got), re_)
     p, r = host_match(res, ds, find_all)                   # the host-buffer entry drains the same way inside the library
     assert np.array_equal(p, pe) and np.array_equal(r, re_)
