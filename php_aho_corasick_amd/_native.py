@@ -51,7 +51,10 @@ class Tables(C.Structure):
                 ("dense_f_end", C.c_uint32), ("n_dense_rows", C.c_uint32), ("n_cold_edges", C.c_uint32),
                 ("cold_rec", C.POINTER(C.c_uint32)), ("cold_edges", C.POINTER(C.c_uint32)),
                 ("chain_lo", C.c_uint32), ("chain_byte", C.POINTER(C.c_uint8)), ("chain_run", C.POINTER(C.c_uint8)),
-                ("out_off", C.POINTER(C.c_uint32)), ("out_list", C.POINTER(C.c_uint32)), ("anchor_slots", C.c_uint32), ("anchor_dense", C.c_uint32)]
+                ("out_off", C.POINTER(C.c_uint32)), ("out_list", C.POINTER(C.c_uint32)), ("anchor_slots", C.c_uint32), ("anchor_dense", C.c_uint32),
+                ("chain_image", C.POINTER(C.c_uint8)), ("chain_bytes", C.c_uint32), ("chain_dense", C.c_uint32), ("chain_index", C.c_uint32),
+                ("chain_rec_off", C.c_uint32), ("chain_cnt_off", C.c_uint32), ("chain_cnt_n", C.c_uint32),
+                ("chain_orig", C.POINTER(C.c_uint32)), ("chain_head", C.POINTER(C.c_uint32))]
 
 
 Handle = C.c_void_p

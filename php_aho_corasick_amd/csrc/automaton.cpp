@@ -207,6 +207,113 @@ size_t Automaton::add_batch(const uint8_t *const *values, const uint32_t *length
     return accepted;
 }
 
+// ---- chain-compressed image (automaton.hpp ChainImage) ----------------------------------------------------------------------
+// All arguments by BFS position (finalize): children of i = [cfirst[i], cfirst[i+1]), in byte `byte_b`; failure position; final
+// flag; records of the state's event; newid = the state id of the other tables.
+static void build_chain_image(FlatAutomaton &fa, uint32_t budget, uint32_t ns, const std::vector<uint32_t> &cfirst, const std::vector<uint32_t> &parent_pos,
+                              const std::vector<uint8_t> &byte_b, const std::vector<uint32_t> &fail_b, const std::vector<uint8_t> &final_b,
+                              const std::vector<uint32_t> &cnt_b, const std::vector<uint32_t> &newid) {
+    ChainImage &ci = fa.chain;
+    ci = ChainImage{};
+    if (budget == 0 || ns > 32767u || fa.n_columns > 512u || fa.out_head.empty()) return;
+    const uint32_t row_bytes = fa.n_columns * 2u;
+    if (uint64_t(ns) * 4u > budget) return;
+    // D: branching states and the root; closed under "failure state of a state outside D" and "parent of a state inside D"
+    // (a failure state and a parent lie before their state in BFS order: one backward pass closes both)
+    std::vector<uint8_t> in_d(ns, 0);
+    in_d[0] = 1;
+    for (uint32_t i = 0; i < ns; ++i)
+        if (cfirst[i + 1] - cfirst[i] >= 2u) in_d[i] = 1;
+    for (uint32_t i = ns; i-- > 1;) {
+        if (in_d[i]) in_d[parent_pos[i]] = 1;
+        else in_d[fail_b[i]] = 1;
+    }
+    // (position i is only ever marked from positions behind it, all of them visited before it: its mark is final when it is read)
+    uint32_t n_dense = 0;
+    for (uint32_t i = 0; i < ns; ++i) n_dense += in_d[i];
+    const uint64_t rows_bytes = (uint64_t(n_dense) * row_bytes + 3u) & ~uint64_t(3);
+    if (rows_bytes + uint64_t(ns - n_dense) * 4u > budget) return;
+    // indices: D in BFS order; then the chains (a C state whose parent is D, followed along its only children), final heads first
+    std::vector<uint32_t> idx(ns, 0xFFFFFFFFu);
+    uint32_t next = 0;
+    for (uint32_t i = 0; i < ns; ++i)
+        if (in_d[i]) idx[i] = next++;
+    uint32_t cnt_n = n_dense;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (uint32_t i = 1; i < ns; ++i) {
+            if (in_d[i] || !in_d[parent_pos[i]] || (final_b[i] != 0) != (pass == 0)) continue;
+            for (uint32_t j = i;; j = cfirst[j]) {
+                idx[j] = next++;
+                if (cfirst[j + 1] == cfirst[j]) break;
+            }
+        }
+        if (pass == 0) cnt_n = next;
+    }
+    if (next != ns) return;   // (cannot happen: every C state hangs below a D state by a chain of C states)
+    bool any_row_final = false;   // does any row lead to a final state at all?  (no: the count bytes are not needed)
+    for (uint32_t i = 1; i < ns && !any_row_final; ++i)
+        if (final_b[i] && in_d[parent_pos[i]]) any_row_final = true;
+    if (!any_row_final) cnt_n = 0;
+    const uint64_t rec_off = rows_bytes, cnt_off = rec_off + uint64_t(ns - n_dense) * 4u;
+    const uint64_t total = (cnt_off + cnt_n + 3u) & ~uint64_t(3);
+    if (total > budget) return;
+    ci.n_dense = n_dense;
+    ci.n_index = ns;
+    ci.row_bytes = row_bytes;
+    ci.rec_off = uint32_t(rec_off);
+    ci.cnt_off = uint32_t(cnt_off);
+    ci.cnt_n = cnt_n;
+    ci.image.assign(size_t(total), 0);
+    ci.head.assign(size_t(ns) * 2, 0u);
+    ci.orig.assign(ns, 0u);
+    // class -> the byte that has it (the "other" class: none)
+    int byte_of_class[512];
+    for (uint32_t c = 0; c < fa.n_columns; ++c) byte_of_class[c] = -1;
+    {
+        bool used[256] = {false};
+        for (uint32_t v = 1; v < ns; ++v) used[byte_b[v]] = true;
+        for (int b = 0; b < 256; ++b)
+            if (used[b]) byte_of_class[fa.class_of_byte[b]] = b;
+    }
+    auto child_by = [&](uint32_t i, int b) -> uint32_t {
+        for (uint32_t v = cfirst[i]; v < cfirst[i + 1]; ++v)
+            if (byte_b[v] == b) return v;
+        return 0xFFFFFFFFu;
+    };
+    uint16_t *rows = reinterpret_cast<uint16_t *>(ci.image.data());
+    uint32_t *recs = reinterpret_cast<uint32_t *>(ci.image.data() + rec_off);
+    uint8_t *cnt = ci.image.data() + cnt_off;
+    for (uint32_t i = 0; i < ns; ++i) {
+        const uint32_t k = idx[i];
+        ci.orig[k] = newid[i];
+        ci.head[size_t(k) * 2] = fa.out_head[size_t(newid[i]) * 2];
+        ci.head[size_t(k) * 2 + 1] = fa.out_head[size_t(newid[i]) * 2 + 1];
+        if (k < cnt_n) cnt[k] = uint8_t(std::min<uint32_t>(cnt_b[i], 255u));
+        if (in_d[i]) {
+            for (uint32_t c = 0; c < fa.n_columns; ++c) {
+                uint32_t t = 0;   // the root
+                const int b = byte_of_class[c];
+                if (b >= 0) {
+                    for (uint32_t f = i;; f = fail_b[f]) {   // ahocorasick.c:199-212, folded into the row
+                        const uint32_t v = child_by(f, b);
+                        if (v != 0xFFFFFFFFu) { t = v; break; }
+                        if (f == 0) break;
+                    }
+                }
+                rows[size_t(k) * fa.n_columns + c] = uint16_t(idx[t] | (final_b[t] ? 0x8000u : 0u));
+            }
+        } else {
+            uint32_t key = 0x3FFu, code = 0;
+            if (cfirst[i + 1] != cfirst[i]) {
+                const uint32_t v = cfirst[i];
+                key = fa.class_of_byte[byte_b[v]];
+                if (final_b[v]) code = 0x20u | std::min<uint32_t>(cnt_b[v], 31u);
+            }
+            recs[k - n_dense] = key | code << 10 | idx[fail_b[i]] << 16;
+        }
+    }
+}
+
 bool Automaton::finalize(const BuildOptions &opt, std::string *error, const BuildAccel *accel) {
     if (finalized_) return true;
     // ACMI_BUILD_TRACE=1: phase times on stderr
@@ -558,6 +665,10 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
         }
     }
     lap("rows, records, output lists");
+    // the whole automaton for the LDS -- unless every state's dense row fits there anyway (the kernels then walk those)
+    fa.chain = ChainImage{};
+    if (uint64_t(fa.trap) + 1u < fa.n_states) build_chain_image(fa, opt.chain_bytes, ns, cfirst, parent_pos, byte_b, fail_b, final_b, cnt_b, newid);
+    lap("chain image");
 
     // ---- anchor filter table -------------------------------------------------------------------
     fa.min_pattern_length = 0;

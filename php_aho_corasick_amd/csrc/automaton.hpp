@@ -48,6 +48,31 @@ struct BuildOptions {
     uint64_t dense_bytes = 4ull << 20;      // compact: dense rows are kept for the LDS tile, every state of trie depth <= 1
                                             // and further BFS-first states up to this many bytes of rows
     uint64_t max_flat_outputs = 1ull << 25; // flat output lists up to this many entries (256 MiB), else dictionary links only
+    // chain-compressed image of the WHOLE automaton for LDS (ChainImage): built when it fits this many bytes -- a CU's 160 KiB less
+    // the walk kernel's event lists (16 KiB), the byte classes (512 B) and its static shared variables; 0 = never
+    uint32_t chain_bytes = 160 * 1024 - 16 * 1024 - 512 - 256;
+};
+
+// The whole automaton in a form that fits the LDS of one CU where dense rows for every state do not (k_chain.hip k_walk_chain):
+// the goto edge + failure pointer of MultiFast's nodes (node.h:37-67) for the states that have ONE child or none -- the inside of
+// the patterns, 85-90 % of a set of a few thousand -- and failure-free dense rows for the rest.
+//   * D states, index [0, n_dense): every state with two or more children, the root, every failure target of a state that is not
+//     one of them, and every ancestor of such a state (so that a C state's child is a C state and its failure state a D state).
+//     Row = n_columns x uint16: the target's index | 0x8000 when the target is final.
+//   * C states, index [n_dense, n_index): numbered chain by chain -- a C state's only child is the next index.  Record (4 B):
+//     bits 0..9 class of the edge byte (0x3FF: no child); bits 10..14 min(records of the child's event, 31), bit 15 the child is
+//     final; bits 16..31 index of the failure state (a D state).  delta(s, b) = b is the edge ? s + 1 : row[fail(s)][b] --
+//     ahocorasick.c:199-212's hop loop, ended after one hop by construction.
+//   * cnt: min(records, 255) of the states whose index is below cnt_n (every final state a ROW can lead to lies there: D states
+//     and the chains whose head is final); the others are only ever entered along their chain, the count is in the parent's record.
+// image = rows | records | cnt (each part 4-byte aligned).  head / orig: per index, what an event's expansion needs (global memory).
+struct ChainImage {
+    uint32_t n_dense = 0, n_index = 0, row_bytes = 0;
+    uint32_t rec_off = 0, cnt_off = 0, cnt_n = 0;
+    std::vector<uint8_t> image;
+    std::vector<uint32_t> head;   // 2 words per index: {first (longest) pattern | min(records, 255) << 24, its length} (out_head's form)
+    std::vector<uint32_t> orig;   // per index: the state id of the other tables
+    bool present() const { return !image.empty(); }
 };
 
 // The part of finalize() that a device can take over (engine.cpp / k_misc.hip k_build_level): failure links and
@@ -193,6 +218,7 @@ struct FlatAutomaton {
     // a bytes into the pattern (a itself; with anchor_choice a + 4j, see automaton.cpp)
     uint32_t anchor_choice = 0;
     std::vector<uint8_t> anchor_offsets;
+    ChainImage chain;             // empty when the set does not fit (or fits the LDS as dense rows anyway)
 };
 
 constexpr uint32_t kAnchorBucketBits = 14;
@@ -265,6 +291,9 @@ public:
         std::vector<uint32_t>().swap(flat_.out_list);
         std::vector<uint32_t>().swap(flat_.out_head);
         std::vector<uint32_t>().swap(flat_.dense_image);
+        std::vector<uint8_t>().swap(flat_.chain.image);
+        std::vector<uint32_t>().swap(flat_.chain.head);
+        std::vector<uint32_t>().swap(flat_.chain.orig);
         host_tables_released_ = true;
     }
     bool host_tables_released() const { return host_tables_released_; }

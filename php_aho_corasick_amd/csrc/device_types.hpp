@@ -30,6 +30,11 @@ struct DevAutomaton {
     // "child == id + 1" states from here on (automaton.hpp); null when there are none
     uint32_t chain_lo;
     const uint8_t *chain_byte, *chain_run;
+    // chain-compressed image of the whole automaton (automaton.hpp ChainImage, k_chain.hip): null when there is none
+    const uint8_t *chain_img;    // rows | records | counts, staged into LDS as a whole
+    uint32_t chain_img_bytes, chain_dense, chain_index, chain_rec_off, chain_cnt_off, chain_cnt_n;
+    const uint2 *chain_head;     // per index: {first pattern | min(records, 255) << 24, its length}
+    const uint32_t *chain_orig;  // per index: state id
     const uint8_t *pad16;        // 16 readable bytes: where unconditional loads of lanes with nothing to load go
     uint32_t shallow_hot, shallow_cold_end;  // non-final states of trie depth <= 2: [0,shallow_hot), (trap,shallow_cold_end)
     uint32_t early_stop;         // 1: walks of anchor candidates stop on them (run_epilogue)

@@ -321,6 +321,16 @@ int ensure_device(acmi_handle *h) {
         }
     }
 
+    if (fa.chain.present()) {
+        const ChainImage &ci = fa.chain;
+        HIPCHK(h, h->d_chain_img.ensure(ci.image.size() + 16));
+        HIPCHK(h, copy_h2d(h->d_chain_img.p, ci.image.data(), ci.image.size()));
+        HIPCHK(h, h->d_chain_head.ensure(ci.head.size() * 4));
+        HIPCHK(h, copy_h2d(h->d_chain_head.p, ci.head.data(), ci.head.size() * 4));
+        HIPCHK(h, h->d_chain_orig.ensure(ci.orig.size() * 4));
+        HIPCHK(h, copy_h2d(h->d_chain_orig.p, ci.orig.data(), ci.orig.size() * 4));
+    }
+
     if (fa.anchor_q) {
         HIPCHK(h, h->d_anchor.ensure(fa.anchor_table.size() * 2));
         HIPCHK(h, copy_h2d(h->d_anchor.p, fa.anchor_table.data(), fa.anchor_table.size() * 2));
@@ -387,6 +397,15 @@ int ensure_device(acmi_handle *h) {
     A.chain_lo = fa.chain_lo;
     A.chain_byte = fa.chain_byte.empty() ? nullptr : h->d_chain_byte.as<uint8_t>();
     A.chain_run = fa.chain_byte.empty() ? nullptr : h->d_chain_run.as<uint8_t>();
+    A.chain_img = fa.chain.present() ? h->d_chain_img.as<uint8_t>() : nullptr;
+    A.chain_img_bytes = uint32_t(fa.chain.image.size());
+    A.chain_dense = fa.chain.n_dense;
+    A.chain_index = fa.chain.n_index;
+    A.chain_rec_off = fa.chain.rec_off;
+    A.chain_cnt_off = fa.chain.cnt_off;
+    A.chain_cnt_n = fa.chain.cnt_n;
+    A.chain_head = fa.chain.present() ? h->d_chain_head.as<uint2>() : nullptr;
+    A.chain_orig = fa.chain.present() ? h->d_chain_orig.as<uint32_t>() : nullptr;
     A.pad16 = h->d_class.as<uint8_t>();  // (512 bytes, always present)
     A.shallow_hot = fa.shallow_hot;
     A.shallow_cold_end = fa.shallow_cold_end;
@@ -495,7 +514,7 @@ int acmi_destroy(acmi_handle *h) {
         if (h->dev_touched) {  // also after a failed upload: release whatever was created
             (void)hipSetDevice(h->dev_id);
             if (h->stream) (void)hipStreamSynchronize(h->stream);
-            for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_out_off, &h->d_out_list, &h->d_out_head, &h->d_cold_rec, &h->d_cold_edges, &h->d_chain_byte, &h->d_chain_run, &h->d_slot_pair, &h->d_pairs, &h->d_pat_bytes, &h->d_dense_img, &h->d_merge_counts, &h->d_merge_sync, &h->d_rep_off, &h->d_rep_bytes, &h->d_plan, &h->d_plan_out, &h->d_tail_out, &h->d_rep_sync, &h->d_nom_count, &h->d_out_len, &h->d_rep_out_off, &h->d_rep_out, &h->d_blob,
+            for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_out_off, &h->d_out_list, &h->d_out_head, &h->d_cold_rec, &h->d_cold_edges, &h->d_chain_byte, &h->d_chain_run, &h->d_chain_img, &h->d_chain_head, &h->d_chain_orig, &h->d_slot_pair, &h->d_pairs, &h->d_pat_bytes, &h->d_dense_img, &h->d_merge_counts, &h->d_merge_sync, &h->d_rep_off, &h->d_rep_bytes, &h->d_plan, &h->d_plan_out, &h->d_tail_out, &h->d_rep_sync, &h->d_nom_count, &h->d_out_len, &h->d_rep_out_off, &h->d_rep_out, &h->d_blob,
                               &h->d_off, &h->d_sync[0], &h->d_sync[1], &h->d_item_base[0], &h->d_item_hay[0], &h->d_item_rec[0], &h->d_zero[0], &h->d_isync[0],
                               &h->d_item_base[1], &h->d_item_hay[1], &h->d_item_rec[1], &h->d_zero[1], &h->d_isync[1],
                               &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_first, &h->d_tile_queue, &h->d_tile_sync, &h->d_uni_off[0], &h->d_uni_off[1], &h->fly[0].d_prefix, &h->fly[0].d_out, &h->fly[1].d_prefix, &h->fly[1].d_out, &h->d_runs, &h->d_run_count})
@@ -617,6 +636,10 @@ static int apply_option(acmi_handle *h, const std::string &k, int64_t value) {
         } else if (k == "anchor_choice") {
             if (h->aut.finalized()) return ACMI_E_FINALIZED;
             h->bopt.anchor_choice = value < 0 ? -1 : (value ? 1 : 0);
+        } else if (k == "chain_bytes") {   // budget of the chain-compressed LDS image of the whole automaton (0: none is built)
+            if (h->aut.finalized()) return ACMI_E_FINALIZED;
+            if (value < 0 || value > 160 * 1024 - 16 * 1024 - 512 - 256) return ACMI_E_ARG;
+            h->bopt.chain_bytes = uint32_t(value);
         } else if (k == "dense_bytes") {
             if (h->aut.finalized()) return ACMI_E_FINALIZED;
             if (value < 0) return ACMI_E_ARG;
@@ -731,6 +754,8 @@ int acmi_get_stat(const acmi_handle *h, const char *key, double *value) {
         else if (k == "anchor_slots") *value = fa.anchor_slots;
         else if (k == "anchor_dense_rate") *value = fa.anchor_dense_rate;
         else if (k == "dense_image_bytes") *value = double(h->dA.dense_image_words) * 4;
+        else if (k == "chain_image_bytes") *value = double(h->aut.flat().chain.image.size() ? h->aut.flat().chain.image.size() : h->dA.chain_img_bytes);
+        else if (k == "chain_dense_states") *value = h->aut.flat().chain.n_dense;
         else if (k == "built_on_device") *value = h->aut.built_on_device() ? 1 : 0;
         else if (k == "compact") *value = fa.compact;
         else if (k == "dense_rows") *value = fa.n_dense_rows;
@@ -802,6 +827,16 @@ int acmi_debug_tables(const acmi_handle *h, acmi_tables *out) {
         out->out_list = fa.out_list.empty() ? nullptr : fa.out_list.data();
         out->anchor_dense = fa.anchor_dense;
         out->anchor_slots = fa.anchor_slots;
+        const ChainImage &ci = fa.chain;
+        out->chain_image = ci.present() ? ci.image.data() : nullptr;
+        out->chain_bytes = uint32_t(ci.image.size());
+        out->chain_dense = ci.n_dense;
+        out->chain_index = ci.n_index;
+        out->chain_rec_off = ci.rec_off;
+        out->chain_cnt_off = ci.cnt_off;
+        out->chain_cnt_n = ci.cnt_n;
+        out->chain_orig = ci.present() ? ci.orig.data() : nullptr;
+        out->chain_head = ci.present() ? ci.head.data() : nullptr;
         return ACMI_OK;
     });
 }

@@ -79,6 +79,15 @@ class FlatTables:
         if t.out_off:
             self.out_off = np.ctypeslib.as_array(t.out_off, shape=(t.n_states,)).astype(np.int64)
             self.out_list = np.ctypeslib.as_array(t.out_list, shape=(max(t.n_flat_outputs, 1), 2)).astype(np.int64)[:t.n_flat_outputs]
+        self.chain = None
+        if t.chain_image:
+            img = np.ctypeslib.as_array(t.chain_image, shape=(t.chain_bytes,)).copy()
+            self.chain = dict(n_dense=t.chain_dense, n_index=t.chain_index, bytes=t.chain_bytes, cnt_n=t.chain_cnt_n,
+                              rows=img[:t.chain_dense * t.n_columns * 2].view("<u2").astype(np.int64).reshape(t.chain_dense, t.n_columns),
+                              recs=img[t.chain_rec_off:t.chain_rec_off + 4 * (t.chain_index - t.chain_dense)].view("<u4").astype(np.int64),
+                              cnt=img[t.chain_cnt_off:t.chain_cnt_off + t.chain_cnt_n].astype(np.int64),
+                              orig=np.ctypeslib.as_array(t.chain_orig, shape=(t.chain_index,)).astype(np.int64),
+                              head=np.ctypeslib.as_array(t.chain_head, shape=(t.chain_index, 2)).astype(np.int64))
         self.anchor_q, self.anchor_mul, self.min_pattern_length = t.anchor_q, t.anchor_mul, t.min_pattern_length
         self.anchor_keys = t.anchor_keys
         self.anchor_mode, self.anchor_bucket_bits = t.anchor_mode, t.anchor_bucket_bits
@@ -142,6 +151,44 @@ class FlatTables:
                     return int(hit[0]) >> 8
             assert (y & 0xFFFFFF) != s
             s = y & 0xFFFFFF
+
+    def walk_chain(self, text: bytes, pat_len, hay: int = 0, find_all: bool = True):
+        """Scan one haystack over the chain-compressed image exactly as k_walk_chain steps through it (automaton.hpp ChainImage): a
+        C state's record first -- the edge's class leads to the next index, the parent's record says whether that state is final and
+        how many records its event has --, else the row of its failure state (a D state's own row), whose entry carries the final bit."""
+        ch = self.chain
+        nd, rows, recs_, cnt, orig, head = ch["n_dense"], ch["rows"], ch["recs"], ch["cnt"], ch["orig"], ch["head"]
+        out, e = [], 0
+        for j, b in enumerate(text):
+            c = int(self.cls[b])
+            final, n = False, 0
+            if e >= nd:
+                r = int(recs_[e - nd])
+                assert (r >> 16) < nd, "a C state's failure state must be a D state"
+                if (r & 0x3FF) == c:
+                    e, final, n = e + 1, bool(r & 0x8000), (r >> 10) & 31
+                    assert e >= nd and e < ch["n_index"], "a C state's child is the next index, a C state"
+                else:
+                    t = int(rows[r >> 16, c])
+                    e, final = t & 0x7FFF, bool(t & 0x8000)
+                    n = int(cnt[e]) if final else 0
+            else:
+                t = int(rows[e, c])
+                e, final = t & 0x7FFF, bool(t & 0x8000)
+                n = int(cnt[e]) if final else 0
+            s = int(orig[e])
+            assert final == self.is_final(s)
+            if final:
+                if n in (31, 255) or n == 0:
+                    n = int(self.cnt[s])
+                assert n == self.cnt[s] and (int(head[e, 0]) >> 24) == min(n, 255)
+                pos = j + 1
+                o = int(self.out_off[s])
+                assert (int(head[e, 0]) & 0xFFFFFF, int(head[e, 1])) == (int(self.out_list[o, 0]), int(self.out_list[o, 1]))
+                out += [(hay, pos, pos - int(l), int(p)) for p, l in self.out_list[o:o + n]]
+                if not find_all:
+                    break
+        return out
 
     def is_final(self, s: int) -> bool:
         return (self.f1 <= s < self.trap) or s >= self.f2

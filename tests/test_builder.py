@@ -90,6 +90,47 @@ def test_tables_match_oracle(name, lds, compact):
     api.ahocorasick_deinit(res)
 
 
+@pytest.mark.parametrize("name,lds,fits", [("G2", 2048, True), ("G2", None, True), ("G4", 2048, True), ("G5", 2048, True), ("R1", 2048, True), ("R2", 2048, True),
+                                           ("R3", 2048, False),    # 38,357 states: more than an index has bits for
+                                           ("K1", 8192, True), ("K2", 8192, False), ("X1", 2048, False)])   # rows of 512 B / 26 B: too big
+def test_chain_image_walks_like_the_oracle(name, lds, fits):
+    """The chain-compressed image of the whole automaton (automaton.hpp ChainImage: dense rows for the branching states, goto edge +
+    failure pointer for the insides of the patterns -- node.h:37-67's record) walked in numpy the way k_walk_chain does."""
+    ds = (synth.NAMED.get(name) or synth.TARGETED[name])()
+    opts = {"lds_bytes": lds} if lds else {}
+    res = resource_for(ds, split=0, **opts)
+    api.ahocorasick_finalize(res)
+    ft = FlatTables(res)
+    if ft.trap + 1 == ft.n_states:
+        assert ft.chain is None          # every row fits the LDS: no second form
+        api.ahocorasick_deinit(res)
+        return
+    assert (ft.chain is not None) == fits, (name, ft.n_states)
+    if not fits:
+        api.ahocorasick_deinit(res)
+        return
+    ch = ft.chain
+    assert ch["n_index"] == ft.n_states - 1 and 0 < ch["n_dense"] <= ch["n_index"] and ch["bytes"] <= 160 * 1024 - 16 * 1024 - 768
+    assert sorted(ch["orig"].tolist()) == sorted(set(range(ft.n_states)) - {ft.trap})      # every state once
+    nd = ch["n_dense"]
+    key = ch["recs"] & 0x3FF
+    assert np.all((ch["recs"] >> 16) < nd) and np.all((key < ft.n_columns) | (key == 0x3FF))
+    assert np.all(key[-1:] == 0x3FF)                                                        # (the last chain ends)
+    o = Oracle("port")
+    o.add_patterns(ds.patterns())
+    plen = np.diff(ds.pat_off.astype(np.int64))
+    for h in range(min(ds.n_haystacks, 4)):
+        for find_all in (True, False):
+            exp = [tuple(int(x) for x in r) for r in o.match(ds.haystack(h), find_all, h)]
+            assert ft.walk_chain(ds.haystack(h), plen, h, find_all) == exp, (name, h, find_all)
+    o.close()
+    res2 = resource_for(ds, split=0, chain_bytes=0, **opts)
+    api.ahocorasick_finalize(res2)
+    assert FlatTables(res2).chain is None
+    api.ahocorasick_deinit(res)
+    api.ahocorasick_deinit(res2)
+
+
 def test_incremental_calls_and_duplicates():
     ds = synth.r1()
     res = resource_for(ds, calls=5)
