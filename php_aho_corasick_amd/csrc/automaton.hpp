@@ -63,8 +63,9 @@ struct BuildOptions {
 //     bits 0..9 class of the edge byte (0x3FF: no child); bits 10..14 min(records of the child's event, 31), bit 15 the child is
 //     final; bits 16..31 index of the failure state (a D state).  delta(s, b) = b is the edge ? s + 1 : row[fail(s)][b] --
 //     ahocorasick.c:199-212's hop loop, ended after one hop by construction.
-//   * cnt: min(records, 255) of the states whose index is below cnt_n (every final state a ROW can lead to lies there: D states
-//     and the chains whose head is final); the others are only ever entered along their chain, the count is in the parent's record.
+//   * cnt: min(records, 255) of the states whose index is below cnt_n: the D states and the chains whose head is final -- the final
+//     states a row leads to, but for the odd one inside a chain (the child of a C state on the row's failure path), whose count
+//     is looked up with the event's expansion; a state entered along its chain has its count in the parent's record.
 // image = rows | records | cnt (each part 4-byte aligned).  head / orig: per index, what an event's expansion needs (global memory).
 struct ChainImage {
     uint32_t n_dense = 0, n_index = 0, row_bytes = 0;

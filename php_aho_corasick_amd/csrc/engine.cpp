@@ -636,6 +636,9 @@ static int apply_option(acmi_handle *h, const std::string &k, int64_t value) {
         } else if (k == "anchor_choice") {
             if (h->aut.finalized()) return ACMI_E_FINALIZED;
             h->bopt.anchor_choice = value < 0 ? -1 : (value ? 1 : 0);
+        } else if (k == "chain_walk") {   // kernel 6: -1 / 1 k_walk_chain where the set carries the chain-compressed image, 0 always k_walk_tiles
+            if (value < -1 || value > 1) return ACMI_E_ARG;
+            h->chain_walk = int(value);
         } else if (k == "chain_bytes") {   // budget of the chain-compressed LDS image of the whole automaton (0: none is built)
             if (h->aut.finalized()) return ACMI_E_FINALIZED;
             if (value < 0 || value > 160 * 1024 - 16 * 1024 - 512 - 256) return ACMI_E_ARG;
@@ -754,6 +757,7 @@ int acmi_get_stat(const acmi_handle *h, const char *key, double *value) {
         else if (k == "anchor_slots") *value = fa.anchor_slots;
         else if (k == "anchor_dense_rate") *value = fa.anchor_dense_rate;
         else if (k == "dense_image_bytes") *value = double(h->dA.dense_image_words) * 4;
+        else if (k == "chain_walk_used") *value = h->chain_used ? 1 : 0;
         else if (k == "chain_image_bytes") *value = double(h->aut.flat().chain.image.size() ? h->aut.flat().chain.image.size() : h->dA.chain_img_bytes);
         else if (k == "chain_dense_states") *value = h->aut.flat().chain.n_dense;
         else if (k == "built_on_device") *value = h->aut.built_on_device() ? 1 : 0;

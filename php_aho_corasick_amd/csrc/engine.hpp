@@ -114,6 +114,8 @@ struct acmi_handle {
     int kernel = 3;  // 0 plain global table, 1 LDS-tile walk, 2 anchor filter (if eligible), 3 automatic, 4 whole-item walk, 6 tile walk (single pass, ordered output)
     int tile_w = 0, tile_p = 0;   // k_walk_tiles: bytes per lane / lanes per item (0: tiles_geometry chooses)
     int reserve_cus = 0;          // compute units the persistent scan kernels leave free (a collective's kernels need some while a scan runs)
+    int chain_walk = -1;          // kernel 6 over the chain-compressed LDS image where the set has one: -1 / 1 yes, 0 never (k_walk_tiles)
+    bool chain_used = false;      // ... the last batch did ("chain_walk_used")
     int rerun_kernel = -1;        // >= 0 while a batch is enqueued AGAIN: the kernel of its first run (enqueue_batch takes it, no probe, nothing learned)
     int part_kernel = -1;         // split sets: the kernel forced on the SHORT part (-1: its own automatic choice)
     uint64_t max_result_bytes = 0;   // 0: unbounded; else a batch hands out at most this much (ACMI_E_PARTIAL + "resume_haystack")
@@ -243,6 +245,7 @@ struct acmi_handle {
         bool probe = false;                   // ... as a probe of an alternative
         bool timed = false;                   // nothing was allocated while it was enqueued: its events say what it cost
         uint64_t out_cap = 0;                 // records the batch's kernels were allowed to write
+        bool chain = false;                   // kernel 6 ran as k_walk_chain (the whole automaton in LDS, chain-compressed)
         bool merged = false;                  // (part 1 of a split set) this batch wrote the MERGED records into the parent's buffer
         bool reran = false;                   // the end had to complete or repeat the pipeline: what ran behind it on the stream saw unfinished results
         bool refill_launched = false;  // the drain of overflowed items was enqueued with the pipeline (else: only if the batch turns out to need it)

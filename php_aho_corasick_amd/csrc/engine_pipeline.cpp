@@ -365,15 +365,22 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     // whole haystacks below it)
     const uint64_t cap = h->max_result_bytes ? std::min<uint64_t>(F.d_out.cap / 16, h->max_result_bytes / 16) : F.d_out.cap / 16;
     F.out_cap = cap;
+    // kernel 6 over the whole automaton in LDS (k_walk_chain) when the set carries the chain-compressed image -- not for the short part
+    // of a split set that merges the long part's records as it writes (k_walk_tiles' lane-list variant does that)
+    F.chain = kernel == 6 && h->chain_walk != 0 && chain_walk_ok(h->dA) && h->merge_into.out == nullptr;
     if (kernel == 6) {
-        HIPCHK(h, h->d_tile_queue.ensure_keep(tiles_queue_entries(tile_w) * 8, h->retired));
-        HIPCHK(h, h->d_tile_sync.ensure_keep(8 + tiles_status_words(max_items, tile_p) * 8, h->retired));
-        HIPCHK(h, hipMemsetAsync(h->d_tile_sync.p, 0, 8 + tiles_status_words(max_items, tile_p) * 8, st));
+        const uint64_t status_words = F.chain ? chain_status_words(max_items, tile_p) : tiles_status_words(max_items, tile_p);
+        HIPCHK(h, h->d_tile_queue.ensure_keep(F.chain ? chain_spill_words(tile_w) * 4 : tiles_queue_entries(tile_w) * 8, h->retired));
+        HIPCHK(h, h->d_tile_sync.ensure_keep(8 + status_words * 8, h->retired));
+        HIPCHK(h, hipMemsetAsync(h->d_tile_sync.p, 0, 8 + status_words * 8, st));
     }
     if (h->profile) HIPCHK(h, hipEventRecord(F.ev[1], st));
     F.merged = false;
     F.reran = false;
-    if (kernel == 6) {
+    if (kernel == 6 && F.chain) {
+        HIPCHK(h, launch_walk_chain(h->dA, B, max_items, int(fa.class_mode), tile_w, tile_p, h->d_tile_queue.p, h->d_tile_sync.as<uint32_t>(),
+                                    h->d_tile_sync.as<uint64_t>() + 1, F.d_out.p, cap, st));
+    } else if (kernel == 6) {
         F.merged = h->merge_into.out != nullptr;
         HIPCHK(h, launch_walk_tiles(h->dA, B, max_items, int(fa.entry_bytes), int(fa.class_mode), tile_w, tile_p, h->d_tile_queue.p,
                                     h->d_tile_sync.as<uint32_t>(), h->d_tile_sync.as<uint64_t>() + 1, F.merged ? h->merge_into.out : F.d_out.p,
@@ -580,6 +587,7 @@ int run_batch_end(acmi_handle *h) {
     h->chunk_used = F.chunk_used;
     h->anchor_variant = F.anchor_variant;
     h->tiny_waves = 0;
+    h->chain_used = F.chain && F.kernel_used == 6;
     if (F.trivial) {
         h->have_result = true;
         return ACMI_OK;
@@ -637,10 +645,14 @@ int run_batch_end(acmi_handle *h) {
             const uint64_t cap = partial ? bound : F.d_out.cap / 16;
             F.out_cap = cap;
             if (F.kernel_used == 6) {   // the walk again, into the grown buffer (prefix array and summary stand)
-                const size_t sync_bytes = 8 + tiles_status_words(F.max_items, F.tile_p) * 8;
+                const size_t sync_bytes = 8 + (F.chain ? chain_status_words(F.max_items, F.tile_p) : tiles_status_words(F.max_items, F.tile_p)) * 8;
                 HIPCHK(h, hipMemsetAsync(h->d_tile_sync.p, 0, sync_bytes, st));
-                HIPCHK(h, launch_walk_tiles(h->dA, F.args, F.max_items, int(fa.entry_bytes), int(fa.class_mode), F.tile_w, F.tile_p, h->d_tile_queue.p,
-                                            h->d_tile_sync.as<uint32_t>(), h->d_tile_sync.as<uint64_t>() + 1, F.d_out.p, cap, st));
+                if (F.chain)
+                    HIPCHK(h, launch_walk_chain(h->dA, F.args, F.max_items, int(fa.class_mode), F.tile_w, F.tile_p, h->d_tile_queue.p, h->d_tile_sync.as<uint32_t>(),
+                                                h->d_tile_sync.as<uint64_t>() + 1, F.d_out.p, cap, st));
+                else
+                    HIPCHK(h, launch_walk_tiles(h->dA, F.args, F.max_items, int(fa.entry_bytes), int(fa.class_mode), F.tile_w, F.tile_p, h->d_tile_queue.p,
+                                                h->d_tile_sync.as<uint32_t>(), h->d_tile_sync.as<uint64_t>() + 1, F.d_out.p, cap, st));
             } else if (too_small)
                 launch_expand(h->dA, F.args, F.max_items, h->d_rec_base.as<uint64_t>(), F.d_out.p, cap, F.d_prefix.as<uint64_t>(),
                               h->pinned_dev + kPinWords * slot_index, F.sync_next, F.sync_words, nullptr, nullptr,

@@ -171,11 +171,11 @@ class FlatTables:
                 else:
                     t = int(rows[r >> 16, c])
                     e, final = t & 0x7FFF, bool(t & 0x8000)
-                    n = int(cnt[e]) if final else 0
+                    n = (int(cnt[e]) if e < ch["cnt_n"] else 255) if final else 0
             else:
                 t = int(rows[e, c])
                 e, final = t & 0x7FFF, bool(t & 0x8000)
-                n = int(cnt[e]) if final else 0
+                n = (int(cnt[e]) if e < ch["cnt_n"] else 255) if final else 0
             s = int(orig[e])
             assert final == self.is_final(s)
             if final:

@@ -1,0 +1,142 @@
+"""k_walk_chain (kernel 6 over the chain-compressed LDS image of the WHOLE automaton, csrc/k_chain.hip): dense rows for the branching
+states, goto edge + failure pointer -- the reference's node record, src/multifast/node.h:37-67 -- for the insides of the patterns, the
+hop loop of ahocorasick.c:199-212 ended after one hop by construction.  Every result record for record against the oracle
+(position ascending, longest pattern first: node.c:424-441).  Needs an MI355X: -m gpu."""
+import numpy as np
+import pytest
+
+from gpu_util import device_match, host_match, resource_for
+from helpers import load_json, sha
+from oracle.pyoracle import Oracle
+from php_aho_corasick_amd import api, batch, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(ds, find_all=True):
+    o = Oracle("port")
+    o.add_patterns((ds.pat_blob, ds.pat_off))
+    out = o.match_batch(ds.hay_blob, ds.hay_off, find_all)
+    o.close()
+    return out
+
+
+def _check(res, ds, pe, re_, calls=2):
+    for _ in range(calls):   # the first call grows the record buffer and runs the walk twice
+        p, r = device_match(res, ds)
+        assert res.stat("kernel_used") == 6 and res.stat("chain_walk_used") == 1
+        assert np.array_equal(p, pe) and np.array_equal(r, re_)
+
+
+@pytest.mark.parametrize("name", ["G1", "G2", "R1", "R2", "K1", "T256", "TRAG", "S3K", "B512", "BRAG"])
+def test_goldens_through_the_chain_walk(name):
+    """The golden datasets whose automaton does not fit a 2 KiB tile as dense rows: hashes made by the compiled reference."""
+    golden = {(c["dataset"], c["find_all"]): c for c in load_json("golden.json")["cases"] + load_json("golden_targeted.json")["cases"]}
+    ds = (synth.NAMED.get(name) or synth.TARGETED[name])()
+    res = resource_for(ds, kernel=6, lds_bytes=2048, small_path=0, split=0)
+    p, r = device_match(res, ds)
+    if res.stat("chain_image_bytes") == 0:
+        api.ahocorasick_deinit(res)
+        pytest.skip("no chain image for this set")
+    assert res.stat("kernel_used") == 6 and res.stat("chain_walk_used") == 1
+    g = golden[(name, True)]
+    assert len(r) == g["n_records"] and sha(r) == g["sha256"] and sha(p) == g["prefix_sha256"]
+    # ... and the same records as k_walk_tiles gives for the same set
+    res.set_option("chain_walk", 0)
+    p2, r2 = device_match(res, ds)
+    assert res.stat("chain_walk_used") == 0 and np.array_equal(p, p2) and np.array_equal(r, r2)
+    api.ahocorasick_deinit(res)
+
+
+@pytest.mark.parametrize("kind", ["headline", "words"])
+@pytest.mark.parametrize("per,hay_len", [(1, 8192), (64, 8192), (512, 8192), (128, 256), (32, 1 << 20), (256, 5000)])
+def test_density_sets_at_their_real_size(kind, per, hay_len):
+    """The two sets the bench's density legs use (2,048 x 16 B over six letters: 25,580 states; 2,048 words: 12,846), whole in LDS."""
+    base = synth.density_set(kind)
+    ds = synth.plant_density(base, per, hay_len)
+    n = max(1, min(ds.n_haystacks, (2 << 20) // hay_len))
+    ds = synth.Dataset(ds.name, ds.pat_blob, ds.pat_off, ds.hay_blob[:int(ds.hay_off[n])], ds.hay_off[:n + 1])
+    pe, re_ = _oracle(ds)
+    res = resource_for(ds, kernel=6, small_path=0)
+    _check(res, ds, pe, re_)
+    assert res.stat("chain_image_bytes") > 100_000
+    api.ahocorasick_deinit(res)
+
+
+@pytest.mark.parametrize("hmax,lmax", [(100, 4), (700, 17), (5000, 33), (20000, 129), (3000, 1)])
+def test_ragged_haystacks_and_pattern_lengths(hmax, lmax):
+    """Unaligned starts, haystacks shorter than a piece and longer than an item, warm-ups of 0 .. 8 blocks."""
+    ds = synth._planted_ragged(f"CR{hmax}", 900 + hmax, 400, 1, lmax, 300, 0, hmax, b"abc", 4)
+    pe, re_ = _oracle(ds)
+    for geometry in ({}, dict(tile_w=16, tile_p=9), dict(tile_w=64, tile_p=64), dict(tile_w=32, tile_p=1)):
+        res = resource_for(ds, kernel=6, small_path=0, lds_bytes=2048, **geometry)
+        p, r = device_match(res, ds)
+        if lmax > 4:
+            assert res.stat("kernel_used") == 6 and res.stat("chain_walk_used") == 1
+        assert np.array_equal(p, pe) and np.array_equal(r, re_), geometry
+        api.ahocorasick_deinit(res)
+
+
+def _nested(n_hay=64, hay_len=4096):
+    """a^1 .. a^48 (an event of up to 48 records: more than the five bits of a record's count) among 80 random patterns over {a, b},
+    over text that is mostly 'a': a record and more per byte, more events per lane than its LDS list holds."""
+    rng = np.random.default_rng(5)
+    pats = [b"a" * k for k in range(1, 49)] + [bytes(rng.choice(list(b"ab"), size=int(rng.integers(12, 30))).tolist()) for _ in range(80)]
+    text = rng.choice(np.frombuffer(b"aaaaaaab", np.uint8), size=n_hay * hay_len).astype(np.uint8)
+    pat_off = np.concatenate([[0], np.cumsum([len(p) for p in pats])]).astype(np.uint64)
+    return synth.Dataset("NEST", np.frombuffer(b"".join(pats), np.uint8).copy(), pat_off, text, (np.arange(n_hay + 1) * hay_len).astype(np.uint64))
+
+
+def test_saturated_counts_and_lane_lists_that_overflow():
+    ds = _nested()
+    pe, re_ = _oracle(ds)
+    assert len(re_) > 4 * ds.hay_blob.size
+    res = resource_for(ds, kernel=6, small_path=0, lds_bytes=2048)
+    _check(res, ds, pe, re_, calls=3)
+    api.ahocorasick_deinit(res)
+
+
+def test_two_batches_in_flight_and_a_buffer_that_is_too_small():
+    import torch
+    base = synth.density_set("words")
+    ds = synth.plant_density(base, 256, 5000)
+    n = min(300, ds.n_haystacks)
+    ds = synth.Dataset(ds.name, ds.pat_blob, ds.pat_off, ds.hay_blob[:int(ds.hay_off[n])], ds.hay_off[:n + 1])
+    pe, re_ = _oracle(ds)
+    res = resource_for(ds, kernel=6, small_path=0)
+    d_blob = torch.from_numpy(ds.hay_blob).cuda()
+    d_off = torch.from_numpy(ds.hay_off.astype(np.int64)).cuda()
+    batch.bind_current_stream(res)
+    batch.match_device_begin(res, d_blob, d_off, True)
+    batch.match_device_begin(res, d_blob, d_off, True)
+    for _ in range(2):
+        total = batch.match_device_end(res)
+        assert res.stat("chain_walk_used") == 1
+        p, r = batch.result_numpy(res, ds.n_haystacks, total)
+        assert np.array_equal(p, pe) and np.array_equal(r, re_)
+    api.ahocorasick_deinit(res)
+
+
+def test_bounded_result_memory_drains_and_resumes():
+    """"max_result_bytes" through the chain walk: what fits is written, whole events in order; the rest is matched again."""
+    import torch
+    ds = _nested(n_hay=24, hay_len=2048)
+    pe, re_ = _oracle(ds)
+    per_hay = int(np.diff(pe).max())
+    cap = 3 * per_hay * 16 + 4096
+    res = resource_for(ds, kernel=6, small_path=0, lds_bytes=2048, max_result_bytes=cap)
+    d_blob = torch.from_numpy(ds.hay_blob).cuda()
+    d_off = torch.from_numpy(ds.hay_off.astype(np.int64)).cuda()
+    batch.bind_current_stream(res)
+    got = []
+    for first, k, total in batch.match_device_bounded(res, d_blob, d_off):
+        assert res.stat("chain_walk_used") == 1
+        p, r = batch.result_numpy(res, k, total)
+        assert int(p[-1]) == total and total * 16 <= cap
+        r = r.copy()
+        r[:, 0] += first
+        got.append(r)
+    assert len(got) >= 6 and np.array_equal(np.concatenate(got), re_)
+    p, r = host_match(res, ds)
+    assert np.array_equal(p, pe) and np.array_equal(r, re_)
+    api.ahocorasick_deinit(res)
