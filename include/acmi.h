@@ -444,8 +444,8 @@ typedef struct acmi_tables {
                                      (shortest pattern 4..6 B); anchor_q = 4, anchor_mode = 1, one key per pattern */
     /* chain-compressed image of the whole automaton for the LDS (null: the set does not fit, or fits there as dense rows):
        rows of the D states (index < chain_dense: n_columns x uint16, target index | 0x8000 when final) at chain_image, 4-byte
-       records of the C states at chain_image + chain_rec_off {class of the edge to index + 1 (0x3FF: none) | min(records of that
-       child, 31) << 10 | child is final << 15 | index of the failure state (a D state) << 16}, min(records, 255) of the indices
+       records of the C states at chain_image + chain_rec_off {index of the failure state (a D state) | 2 x class of the edge to
+       index + 1 (0xFF: none) << 16 | min(records of that child, 31) << 24 | child is final << 31}, min(records, 255) of the indices
        below chain_cnt_n at chain_image + chain_cnt_off; chain_orig[index] = state id, chain_head = out_head's form per index */
     const uint8_t *chain_image;
     uint32_t chain_bytes, chain_dense, chain_index, chain_rec_off, chain_cnt_off, chain_cnt_n;

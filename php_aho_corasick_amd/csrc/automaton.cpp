@@ -215,7 +215,7 @@ static void build_chain_image(FlatAutomaton &fa, uint32_t budget, uint32_t ns, c
                               const std::vector<uint32_t> &cnt_b, const std::vector<uint32_t> &newid) {
     ChainImage &ci = fa.chain;
     ci = ChainImage{};
-    if (budget == 0 || ns > 32767u || fa.n_columns > 512u || fa.out_head.empty()) return;
+    if (budget == 0 || ns > 32767u || fa.n_columns > 127u || fa.out_head.empty()) return;   // (a record's key: twice the class, in a byte)
     const uint32_t row_bytes = fa.n_columns * 2u;
     if (uint64_t(ns) * 4u > budget) return;
     // D: branching states and the root; closed under "failure state of a state outside D" and "parent of a state inside D"
@@ -303,13 +303,13 @@ static void build_chain_image(FlatAutomaton &fa, uint32_t budget, uint32_t ns, c
                 rows[size_t(k) * fa.n_columns + c] = uint16_t(idx[t] | (final_b[t] ? 0x8000u : 0u));
             }
         } else {
-            uint32_t key = 0x3FFu, code = 0;
+            uint32_t key = 0xFFu, code = 0;
             if (cfirst[i + 1] != cfirst[i]) {
                 const uint32_t v = cfirst[i];
-                key = fa.class_of_byte[byte_b[v]];
-                if (final_b[v]) code = 0x20u | std::min<uint32_t>(cnt_b[v], 31u);
+                key = 2u * fa.class_of_byte[byte_b[v]];
+                if (final_b[v]) code = 0x80u | std::min<uint32_t>(cnt_b[v], 31u);
             }
-            recs[k - n_dense] = key | code << 10 | idx[fail_b[i]] << 16;
+            recs[k - n_dense] = idx[fail_b[i]] | key << 16 | code << 24;
         }
     }
 }

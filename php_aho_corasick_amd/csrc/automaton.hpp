@@ -60,8 +60,9 @@ struct BuildOptions {
 //     one of them, and every ancestor of such a state (so that a C state's child is a C state and its failure state a D state).
 //     Row = n_columns x uint16: the target's index | 0x8000 when the target is final.
 //   * C states, index [n_dense, n_index): numbered chain by chain -- a C state's only child is the next index.  Record (4 B):
-//     bits 0..9 class of the edge byte (0x3FF: no child); bits 10..14 min(records of the child's event, 31), bit 15 the child is
-//     final; bits 16..31 index of the failure state (a D state).  delta(s, b) = b is the edge ? s + 1 : row[fail(s)][b] --
+//     bits 0..15 index of the failure state (a D state); byte 2 twice the class of the edge byte (the column offset a step has
+//     in hand; 0xFF: no child -- at most 127 classes); bits 24..28 min(records of the child's event, 31), bit 31 the child is
+//     final (a row entry read as a signed halfword and a record are then "final" by the same test: negative).  delta(s, b) = b is the edge ? s + 1 : row[fail(s)][b] --
 //     ahocorasick.c:199-212's hop loop, ended after one hop by construction.
 //   * cnt: min(records, 255) of the states whose index is below cnt_n: the D states and the chains whose head is final -- the final
 //     states a row leads to, but for the odd one inside a chain (the child of a C state on the row's failure path), whose count

@@ -517,7 +517,7 @@ int acmi_destroy(acmi_handle *h) {
             for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_out_off, &h->d_out_list, &h->d_out_head, &h->d_cold_rec, &h->d_cold_edges, &h->d_chain_byte, &h->d_chain_run, &h->d_chain_img, &h->d_chain_head, &h->d_chain_orig, &h->d_slot_pair, &h->d_pairs, &h->d_pat_bytes, &h->d_dense_img, &h->d_merge_counts, &h->d_merge_sync, &h->d_rep_off, &h->d_rep_bytes, &h->d_plan, &h->d_plan_out, &h->d_tail_out, &h->d_rep_sync, &h->d_nom_count, &h->d_out_len, &h->d_rep_out_off, &h->d_rep_out, &h->d_blob,
                               &h->d_off, &h->d_sync[0], &h->d_sync[1], &h->d_item_base[0], &h->d_item_hay[0], &h->d_item_rec[0], &h->d_zero[0], &h->d_isync[0],
                               &h->d_item_base[1], &h->d_item_hay[1], &h->d_item_rec[1], &h->d_zero[1], &h->d_isync[1],
-                              &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_first, &h->d_tile_queue, &h->d_tile_sync, &h->d_uni_off[0], &h->d_uni_off[1], &h->fly[0].d_prefix, &h->fly[0].d_out, &h->fly[1].d_prefix, &h->fly[1].d_out, &h->d_runs, &h->d_run_count})
+                              &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_first, &h->d_tile_queue, &h->d_tile_sync, &h->d_chain_log, &h->d_chain_tiles, &h->d_uni_off[0], &h->d_uni_off[1], &h->fly[0].d_prefix, &h->fly[0].d_out, &h->fly[1].d_prefix, &h->fly[1].d_out, &h->d_runs, &h->d_run_count})
                 b->release();
             for (void *q : h->retired) (void)hipFree(q);
             for (auto &evt : h->ev)
@@ -758,6 +758,7 @@ int acmi_get_stat(const acmi_handle *h, const char *key, double *value) {
         else if (k == "anchor_dense_rate") *value = fa.anchor_dense_rate;
         else if (k == "dense_image_bytes") *value = double(h->dA.dense_image_words) * 4;
         else if (k == "chain_walk_used") *value = h->chain_used ? 1 : 0;
+        else if (k == "chain_log_reruns") *value = h->chain_log_reruns;
         else if (k == "chain_image_bytes") *value = double(h->aut.flat().chain.image.size() ? h->aut.flat().chain.image.size() : h->dA.chain_img_bytes);
         else if (k == "chain_dense_states") *value = h->aut.flat().chain.n_dense;
         else if (k == "built_on_device") *value = h->aut.built_on_device() ? 1 : 0;

@@ -177,6 +177,9 @@ struct acmi_handle {
     // workspace (grow-only)
     DevBuf d_blob, d_off, d_rec_base, d_slab, d_ovf, d_counters, d_runs, d_run_count, d_first;
     DevBuf d_tile_queue, d_tile_sync;   // k_walk_tiles: the waves' event queues; {ticket, look-back words}
+    DevBuf d_chain_log, d_chain_tiles;  // k_walk_chain: the waves' event logs; per tile {log offset | events per lane}
+    uint32_t chain_log_div = 32;        // ... the logs hold an event per this many bytes of text (learned: 32 -> 4 -> 1)
+    uint32_t chain_log_reruns = 0;      // batches run again because they overflowed the logs ("chain_log_reruns")
     // uniform batches (acmi_match_batch_device_begin_uniform): the offsets array the library makes itself, one per slot, and the
     // geometry it holds; uniform_len != 0 while such a batch is being enqueued
     DevBuf d_uni_off[2];
@@ -246,6 +249,7 @@ struct acmi_handle {
         bool timed = false;                   // nothing was allocated while it was enqueued: its events say what it cost
         uint64_t out_cap = 0;                 // records the batch's kernels were allowed to write
         bool chain = false;                   // kernel 6 ran as k_walk_chain (the whole automaton in LDS, chain-compressed)
+        ChainBuffers chain_buf{};             // ... with these buffers (k_chain_emit again into a grown record buffer)
         bool merged = false;                  // (part 1 of a split set) this batch wrote the MERGED records into the parent's buffer
         bool reran = false;                   // the end had to complete or repeat the pipeline: what ran behind it on the stream saw unfinished results
         bool refill_launched = false;  // the drain of overflowed items was enqueued with the pipeline (else: only if the batch turns out to need it)

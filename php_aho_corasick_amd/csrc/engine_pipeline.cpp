@@ -368,18 +368,28 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     // kernel 6 over the whole automaton in LDS (k_walk_chain) when the set carries the chain-compressed image -- not for the short part
     // of a split set that merges the long part's records as it writes (k_walk_tiles' lane-list variant does that)
     F.chain = kernel == 6 && h->chain_walk != 0 && chain_walk_ok(h->dA) && h->merge_into.out == nullptr;
-    if (kernel == 6) {
-        const uint64_t status_words = F.chain ? chain_status_words(max_items, tile_p) : tiles_status_words(max_items, tile_p);
-        HIPCHK(h, h->d_tile_queue.ensure_keep(F.chain ? chain_spill_words(tile_w) * 4 : tiles_queue_entries(tile_w) * 8, h->retired));
-        HIPCHK(h, h->d_tile_sync.ensure_keep(8 + status_words * 8, h->retired));
-        HIPCHK(h, hipMemsetAsync(h->d_tile_sync.p, 0, 8 + status_words * 8, st));
+    if (kernel == 6 && F.chain) {
+        // k_walk_chain's buffers: the pieces' overflow lists (per wave, reused tile after tile), the waves' event logs and the tiles'
+        // {log offset, events per lane}.  The logs are sized optimistically -- an event per chain_log_div bytes of text, learned like
+        // the record buffer: a batch that overflows them is run again (run_batch_end) -- and never beyond an event per byte.
+        const uint64_t tiles = chain_tiles(max_items, tile_p), waves = chain_waves();
+        const uint64_t worst = ((tiles + waves - 1) / waves) * 128ull * (tile_w + 16ull);
+        const uint64_t want = (blob_bytes / std::max<uint32_t>(1, h->chain_log_div)) / waves * 5 / 4 + 128ull * (tile_w + 16ull);
+        const uint32_t log_cap = uint32_t(std::min<uint64_t>(std::min(worst, want), 0xFFFFFF00ull));
+        HIPCHK(h, h->d_tile_queue.ensure_keep(chain_spill_words(tile_w) * 4, h->retired));
+        HIPCHK(h, h->d_chain_log.ensure_keep(waves * log_cap * 4, h->retired));
+        HIPCHK(h, h->d_chain_tiles.ensure_keep(tiles * 8, h->retired));
+        F.chain_buf = ChainBuffers{h->d_tile_queue.as<uint32_t>(), h->d_chain_log.as<uint32_t>(), log_cap, h->d_chain_tiles.as<uint32_t>()};
+    } else if (kernel == 6) {
+        HIPCHK(h, h->d_tile_queue.ensure_keep(tiles_queue_entries(tile_w) * 8, h->retired));
+        HIPCHK(h, h->d_tile_sync.ensure_keep(8 + tiles_status_words(max_items, tile_p) * 8, h->retired));
+        HIPCHK(h, hipMemsetAsync(h->d_tile_sync.p, 0, 8 + tiles_status_words(max_items, tile_p) * 8, st));
     }
     if (h->profile) HIPCHK(h, hipEventRecord(F.ev[1], st));
     F.merged = false;
     F.reran = false;
     if (kernel == 6 && F.chain) {
-        HIPCHK(h, launch_walk_chain(h->dA, B, max_items, int(fa.class_mode), tile_w, tile_p, h->d_tile_queue.p, h->d_tile_sync.as<uint32_t>(),
-                                    h->d_tile_sync.as<uint64_t>() + 1, F.d_out.p, cap, st));
+        HIPCHK(h, launch_walk_chain(h->dA, B, max_items, int(fa.class_mode), tile_w, tile_p, F.chain_buf, st));
     } else if (kernel == 6) {
         F.merged = h->merge_into.out != nullptr;
         HIPCHK(h, launch_walk_tiles(h->dA, B, max_items, int(fa.entry_bytes), int(fa.class_mode), tile_w, tile_p, h->d_tile_queue.p,
@@ -416,6 +426,8 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     // ("items_ahead": the next batch's k_items may already be running on the side stream, behind this batch's SCAN only -- its
     // sync words are zeroed by that stream's own memset, never from here)
     h->isync_clean[slot_index ^ 1] = !h->items_ahead && h->d_isync[slot_index ^ 1].p != nullptr;
+    // (k_walk_chain left events in the waves' logs: records at the bases k_expand's scan has just written)
+    if (kernel == 6 && F.chain) HIPCHK(h, launch_chain_emit(h->dA, B, max_items, tile_w, tile_p, F.chain_buf, h->d_rec_base.as<uint64_t>(), F.d_out.p, cap, st));
     F.refill_launched = find_all && h->refill_armed && kernel != 6;   // (k_walk_tiles leaves no item to drain)
     if (F.refill_launched) launch_refill(h->dA, B, max_items, int(fa.entry_bytes), h->d_rec_base.as<uint64_t>(), F.d_out.p, cap, refill_mode(h, kernel), st, int(fa.class_mode));
     F.sync_next = sync_next;
@@ -593,6 +605,24 @@ int run_batch_end(acmi_handle *h) {
         return ACMI_OK;
     }
     const FlatAutomaton &fa = h->aut.flat();
+    // k_walk_chain's event logs are sized for the batches before: one that overflowed them (word 19) is run again with logs for eight
+    // times the events -- from an event per 32 bytes of text to, at most, one per byte
+    for (int tries = 0; F.kernel_used == 6 && F.chain && pinned32[19] != 0u; ++tries) {
+        if (tries == 3 || h->chain_log_div == 1u) { h->last_error = "k_walk_chain: event log overflow at its largest size"; return ACMI_E_DEVICE; }
+        {
+            const hipError_t e = hipStreamSynchronize(st);
+            if (e != hipSuccess) { h->sync_tiles = 0; return fail_hip(h, e, "hipStreamSynchronize"); }
+        }
+        h->chain_log_div = std::max<uint32_t>(1u, h->chain_log_div / 8u);
+        ++h->chain_log_reruns;
+        h->rerun_kernel = 6;
+        const int rc = enqueue_batch(h, F, F.d_blob, F.blob_bytes, F.d_off, F.nh, F.find_all);
+        h->rerun_kernel = -1;
+        if (rc < 0) { h->sync_tiles = 0; return rc; }
+        h->enqueue_seq = F.seq;
+        F.timed = false;
+        HIPCHK(h, hipStreamSynchronize(st));
+    }
     if (pinned32[6] != 0u) {
         h->last_error = "offsets must be non-decreasing, inside the blob, and every haystack shorter than 4 GiB";
         return ACMI_E_ARG;
@@ -644,15 +674,13 @@ int run_batch_end(acmi_handle *h) {
             if (too_small) HIPCHK(h, F.d_out.ensure(need * 16));
             const uint64_t cap = partial ? bound : F.d_out.cap / 16;
             F.out_cap = cap;
-            if (F.kernel_used == 6) {   // the walk again, into the grown buffer (prefix array and summary stand)
-                const size_t sync_bytes = 8 + (F.chain ? chain_status_words(F.max_items, F.tile_p) : tiles_status_words(F.max_items, F.tile_p)) * 8;
+            if (F.kernel_used == 6 && F.chain) {   // the logs once more, into the grown buffer (bases, prefix array and summary stand)
+                HIPCHK(h, launch_chain_emit(h->dA, F.args, F.max_items, F.tile_w, F.tile_p, F.chain_buf, h->d_rec_base.as<uint64_t>(), F.d_out.p, cap, st));
+            } else if (F.kernel_used == 6) {   // the walk again, into the grown buffer (prefix array and summary stand)
+                const size_t sync_bytes = 8 + tiles_status_words(F.max_items, F.tile_p) * 8;
                 HIPCHK(h, hipMemsetAsync(h->d_tile_sync.p, 0, sync_bytes, st));
-                if (F.chain)
-                    HIPCHK(h, launch_walk_chain(h->dA, F.args, F.max_items, int(fa.class_mode), F.tile_w, F.tile_p, h->d_tile_queue.p, h->d_tile_sync.as<uint32_t>(),
-                                                h->d_tile_sync.as<uint64_t>() + 1, F.d_out.p, cap, st));
-                else
-                    HIPCHK(h, launch_walk_tiles(h->dA, F.args, F.max_items, int(fa.entry_bytes), int(fa.class_mode), F.tile_w, F.tile_p, h->d_tile_queue.p,
-                                                h->d_tile_sync.as<uint32_t>(), h->d_tile_sync.as<uint64_t>() + 1, F.d_out.p, cap, st));
+                HIPCHK(h, launch_walk_tiles(h->dA, F.args, F.max_items, int(fa.entry_bytes), int(fa.class_mode), F.tile_w, F.tile_p, h->d_tile_queue.p,
+                                            h->d_tile_sync.as<uint32_t>(), h->d_tile_sync.as<uint64_t>() + 1, F.d_out.p, cap, st));
             } else if (too_small)
                 launch_expand(h->dA, F.args, F.max_items, h->d_rec_base.as<uint64_t>(), F.d_out.p, cap, F.d_prefix.as<uint64_t>(),
                               h->pinned_dev + kPinWords * slot_index, F.sync_next, F.sync_words, nullptr, nullptr,

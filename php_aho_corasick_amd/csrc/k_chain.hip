@@ -13,12 +13,18 @@
 // A step is the same straight-line code for every lane whatever its state: read the state's record, read the row entry (of the
 // state itself when it is a D state, of its failure state otherwise), select.  Two LDS reads per byte, no branch, no L2 request.
 //
-// Work distribution as in k_walk_tiles (a work item <= P x W bytes of one haystack walked by P lanes, W bytes each, entered from
-// the root Lmax - 1 bytes early), but a WAVE is the unit: it takes a ticket, walks its R = 64 / P items, publishes its record count,
-// looks back over the waves before it (decoupled look-back, one status word per wave tile) and writes its records -- no workgroup
-// barrier in the loop, so that one wave's look-back and its expansion (L2 round trips) overlap the other waves' walks (LDS and
-// VALU).  Events go to a list of the LANE's own: {index, records, byte} in one word -- the first kChainLaneCap in LDS, what a lane
-// has beyond that (it cannot have more than one per byte of its piece) in the wave's region of a global buffer.
+// Work distribution: a work item (<= P x W bytes of one haystack) is walked by P pieces of W bytes, each entered from the root
+// Lmax - 1 bytes early (k_walk_tiles' geometry); a WAVE takes 128 consecutive pieces at a time (a tile: whole items), two per lane,
+// tiles dealt round robin -- no ticket, no barrier.  Events go to a list of the piece's own {index, count code, byte}: the first two
+// in LDS, what a piece has beyond that (it cannot have more than one per byte) in the wave's region of a global buffer.
+//
+// Records are NOT written here.  A wave that places its records needs the number of records before them, and every way of getting
+// that inside the kernel made the waves wait for one another: decoupled look-back per wave tile fell behind (131 tiles finish per
+// microsecond, a window of 64 status words is an L2 round trip: 0.54 of 1.33 ms per GiB was look-back), per batch of sixteen
+// tiles it still cost 0.45 ms (a batch waits for the slowest wave of the batch before and for four windows of words).  Instead
+// the walk leaves, per tile, its events in the wave's LOG (a region of the wave's own: no atomic) and its items' record counts;
+// k_expand's single-pass scan over the item counts -- the pipeline runs it anyway, for the per-haystack prefix -- gives every item
+// its base, and k_chain_emit turns the logs into records at those bases.  The walk: 0.79 ms per GiB with nothing to wait for.
 #include <cstdlib>
 #include <type_traits>
 
@@ -29,18 +35,20 @@ namespace acmi {
 constexpr uint32_t kChainThreads = 1024;
 constexpr uint32_t kChainWaves = kChainThreads / 64;
 constexpr uint32_t kChainLaneCap = 4;   // events per lane kept in LDS: 16 KiB for the workgroup
-constexpr uint32_t kChainBatch = 16;    // wave tiles a workgroup takes from the global ticket at a time: one round of its waves -- the
-                                        // first tile of a batch looks back on the LAST of the batch before, which its workgroup must
-                                        // not walk rounds later (64 per ticket: every workgroup waited three rounds for its neighbour)
 
 struct ChainArgs {
     uint32_t W, P, R, back;
-    uint32_t spill_cap;   // events per lane the wave's global region holds
-    uint32_t *spill;      // grid waves x spill_cap x 64 words
-    uint32_t *ticket;     // zeroed
-    uint64_t *status;     // zeroed, one word per wave tile
-    uint4 *out;
+    uint32_t inv_p;       // ceil(65536 / P): (s x inv_p) >> 16 = s / P for s < 128
+    uint32_t debug;       // measurements only (ACMI_CHAIN_DEBUG): 2 no walk
+    uint32_t spill_cap;   // events per piece the wave's overflow region holds
+    uint32_t *spill;      // grid waves x spill_cap x 128 words
+    uint32_t *log;        // grid waves x log_cap words: the waves' event logs
+    uint32_t log_cap;     // words per wave
+    uint2 *tile_info;     // per tile: {where its events begin in its wave's log, how many}
+    uint32_t n_waves;     // waves of the walk's grid: tile t belongs to wave t % n_waves
+    uint4 *out;           // (k_chain_emit)
     uint64_t cap;
+    const uint64_t *rec_base;   // (k_chain_emit) per item: records before it (k_expand's scan)
 };
 
 struct ChainLds {
@@ -52,35 +60,73 @@ struct ChainLds {
     const uint16_t *cls;      // byte -> 2 x class (TABLE mode), else null
 };
 
-// One transition.  `coff` = 2 x class of the byte.  Returns through `e` the next index; `u` bit 15: that state is final (`hit`: it
-// was entered along its chain, bits 10..14 of `u` are min(its records, 31)).
-__device__ __forceinline__ void chain_step(const ChainLds &L, uint32_t &e, uint32_t coff, uint32_t &u, bool &hit) {
-    const uint32_t r = *reinterpret_cast<const uint32_t *>(L.img + ((e << 2) + L.rec_base));   // (a D state reads a word of the rows: unused)
-    const bool is_d = e < L.n_dense;
-    const uint32_t f = is_d ? e : (r >> 16);
-    uint32_t ra;   // (spelled out: hipcc makes a multiply and a three-operand add of it)
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(ra) : "v"(f), "s"(L.row_bytes), "v"(coff));
-    const uint32_t t = *reinterpret_cast<const uint16_t *>(L.img + ra);
-    hit = !is_d && (r & 0x3FFu) == coff;   // (the records' keys are doubled when the image is staged; 0x3FF -- no child -- is odd)
-    u = hit ? r : t;
-    e = hit ? e + 1u : (t & 0x7FFFu);
+// One transition of two independent walks: their reads issued together (the records', then the rows'), so that one's LDS round
+// trips lie under the other's.  `ca`, `cz` = 2 x class of the bytes.  Through `ea`, `ez` the next indices; `ua`, `uz` negative: that
+// state is final (`ha`, `hz`: it was entered along its chain, bits 24..28 are min(its records, 31)).
+__device__ __forceinline__ void chain_step2(const ChainLds &L, uint32_t &ea, uint32_t &ez, uint32_t ca, uint32_t cz, uint32_t &ua, uint32_t &uz, bool &ha, bool &hz) {
+    const uint32_t ra = *reinterpret_cast<const uint32_t *>(L.img + ((ea << 2) + L.rec_base));
+    const uint32_t rz = *reinterpret_cast<const uint32_t *>(L.img + ((ez << 2) + L.rec_base));
+    const bool da = ea < L.n_dense, dz = ez < L.n_dense;
+    const uint32_t fa = da ? ea : (ra & 0xFFFFu), fz = dz ? ez : (rz & 0xFFFFu);
+    uint32_t aa, az;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(aa) : "v"(fa), "s"(L.row_bytes), "v"(ca));
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(az) : "v"(fz), "s"(L.row_bytes), "v"(cz));
+    // (rows read sign-extended: a final target is negative, like a record whose child is final -- one test for both)
+    const uint32_t ta = uint32_t(int32_t(*reinterpret_cast<const __attribute__((address_space(3))) int16_t *>(aa)));
+    const uint32_t tz = uint32_t(int32_t(*reinterpret_cast<const __attribute__((address_space(3))) int16_t *>(az)));
+    ha = !da && __builtin_amdgcn_ubfe(ra, 16, 8) == ca;   // (a record's key is the column offset; 0xFF -- no child -- is odd)
+    hz = !dz && __builtin_amdgcn_ubfe(rz, 16, 8) == cz;
+    ua = ha ? ra : ta;
+    uz = hz ? rz : tz;
+    ea = ha ? ea + 1u : (ta & 0x7FFFu);
+    ez = hz ? ez + 1u : (tz & 0x7FFFu);
 }
 
-__device__ __forceinline__ uint32_t chain_wave_max(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const uint32_t o = __shfl_xor(v, d, 64);
-        v = o > v ? o : v;
+// One piece of a wave's 128 (k_walk_tiles' geometry): the first block it walks, where in it the walk begins, what reports.
+struct Piece {
+    const uint8_t *pb;   // 16-byte aligned address of the first block it walks
+    uint32_t nblk, start_j, rep_lo, rep_len, pos_bias, hay;
+    uint32_t r, qi;      // item of the wave's tile, piece of the item
+    bool have;
+    uint64_t item;
+};
+__device__ __forceinline__ Piece chain_piece(const DevAutomaton &A, const BatchArgs &B, const ChainArgs &T, uint64_t total_items, uint64_t first_item, uint32_t s) {
+    const uintptr_t beta = reinterpret_cast<uintptr_t>(B.blob) & 15u;
+    const uint8_t *abase = B.blob - beta;   // 16-byte aligned
+    Piece pc;
+    pc.pb = A.pad16;
+    pc.nblk = 0; pc.start_j = 16u; pc.rep_lo = pc.rep_len = pc.pos_bias = pc.hay = 0;
+    pc.r = (s * T.inv_p) >> 16;   // s / P for s < 128 (a division by a run-time value is ~ 30 instructions)
+    pc.qi = s - pc.r * T.P;
+    pc.item = first_item + pc.r;
+    pc.have = pc.r < T.R && pc.item < total_items;
+    if (pc.have) {
+        const uint4 rec = B.item_rec[pc.item];
+        ItemDesc it;
+        unpack_item(rec.x, rec.y, rec.z, rec.w, it);
+        pc.hay = B.item_hay[pc.item];
+        const uint64_t zb = it.begin + beta;
+        const uint64_t G = zb & ~uint64_t(15);
+        const uint32_t d0 = uint32_t(zb - G);
+        const uint32_t a = pc.qi * T.W;
+        const uint32_t lo = a > d0 ? a : d0;
+        const uint32_t end = d0 + it.len;
+        const uint32_t hi = (pc.qi + 1u == T.P) ? end : (a + T.W < end ? a + T.W : end);
+        if (lo < hi) {
+            const int64_t hs = int64_t(d0) - int64_t(it.pos0);   // the haystack's first byte
+            int64_t xs = int64_t(lo) - int64_t(T.back);           // Lmax - 1 bytes early: exact from there on
+            if (xs < hs) xs = hs;
+            int64_t xb = xs & ~int64_t(15);
+            if (xb == xs) xb -= 16;   // (a walk that begins ON a block boundary takes the block below as its first, virtually)
+            pc.pb = abase + G + xb;
+            pc.start_j = uint32_t(xs - xb);
+            pc.rep_lo = uint32_t(int64_t(lo) - xb);
+            pc.rep_len = hi - lo;
+            pc.nblk = (pc.rep_lo + pc.rep_len + 15u) >> 4;
+            pc.pos_bias = uint32_t(xb) - d0 + it.pos0 + 1u;
+        }
     }
-    return v;
-}
-__device__ __forceinline__ uint32_t chain_wave_min(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const uint32_t o = __shfl_xor(v, d, 64);
-        v = o < v ? o : v;
-    }
-    return v;
+    return pc;
 }
 
 // records of the event of index `e` when the short forms saturated
@@ -92,33 +138,19 @@ __device__ __forceinline__ uint32_t chain_count(const DevAutomaton &A, uint32_t 
 template <int MODE>
 __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, BatchArgs B, ChainArgs T) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    // Tickets.  A wave tile is 64 lane pieces (4 KiB of text): a GiB is 262,144 of them, and atomics on ONE word retire at ~ 12 ns
-    // each whoever issues them -- 3.1 ms, the whole kernel's time when every wave took its own (engine_pipeline.cpp has the same
-    // note on the persistent scans).  A workgroup therefore takes kChainBatch consecutive tiles per global atomic and hands them to
-    // its waves, in order, through a counter in LDS: local ticket i = tile i % kChainBatch of the workgroup's batch i / kChainBatch,
-    // whose global number the wave with i % kChainBatch == 0 fetches for all.  Look-back stays deadlock-free: the smallest tile that
-    // has not published is either being walked, or the next one its workgroup hands out.
-    __shared__ uint32_t s_cur, s_bid[4], s_base[4];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint64_t total_items = B.item_base[B.n_haystacks];
-    if (threadIdx.x == 0) s_cur = 0u;
-    if (threadIdx.x < 4) s_bid[threadIdx.x] = 0xFFFFFFFFu;
     // LDS: [image: rows | records | counts] [512 B byte classes (TABLE mode)] [the lanes' event lists]
+    // (the image at offset 0 -- no static shared variable in front of it: a row's address is then the multiply-add's result itself)
     const uint32_t img_bytes = (A.chain_img_bytes + 15u) & ~15u;
     const uint32_t cls_bytes = (MODE == 0) ? 512u : 0u;
+    // (chain_step2 reads the rows at the multiply-add's result itself: the dynamic LDS begins at 0 when nothing static precedes it)
+    if (uint32_t(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint8_t *)smem)) != 0u) __builtin_trap();
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(A.chain_img);   // (the allocation has 16 bytes of slack)
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
         for (uint32_t t = threadIdx.x; t < (img_bytes >> 4); t += kChainThreads) dst[t] = src[t];
         if (MODE == 0 && threadIdx.x < 256) reinterpret_cast<uint16_t *>(smem + img_bytes)[threadIdx.x] = A.class_off[threadIdx.x];
-        __syncthreads();
-        // the records' keys doubled: a step compares them with the byte's column OFFSET
-        uint32_t *recs = reinterpret_cast<uint32_t *>(smem + A.chain_rec_off);
-        const uint32_t n_rec = A.chain_index - A.chain_dense;
-        for (uint32_t t = threadIdx.x; t < n_rec; t += kChainThreads) {
-            const uint32_t w = recs[t], key = w & 0x3FFu;
-            recs[t] = (w & ~0x3FFu) | (key == 0x3FFu ? key : key << 1);
-        }
         __syncthreads();
     }
     ChainLds L;
@@ -128,129 +160,103 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
     L.row_bytes = A.n_columns * 2u;
     L.cnt = smem + A.chain_cnt_off;
     L.cls = (MODE == 0) ? reinterpret_cast<const uint16_t *>(smem + img_bytes) : nullptr;
-    uint32_t *lists = reinterpret_cast<uint32_t *>(smem + img_bytes + cls_bytes) + threadIdx.x;   // entry k of this lane at lists[k * 1024]
-    uint32_t *spill = T.spill + (uint64_t(blockIdx.x) * kChainWaves + wave) * T.spill_cap * 64u + lane;   // entry k at spill[(k - cap) * 64]
-    const uint32_t r = lane / T.P, qi = lane - r * T.P;   // item of the wave, piece of the item
-    const uintptr_t beta = reinterpret_cast<uintptr_t>(B.blob) & 15u;
-    const uint8_t *abase = B.blob - beta;   // 16-byte aligned
+    // A lane walks TWO pieces at once, 2 lane and 2 lane + 1 of the wave's 128: a step is two dependent LDS reads, and with the
+    // whole LDS taken by the image a CU runs one workgroup -- four waves per SIMD, too few to hide them (one piece per lane: 55 % of
+    // the VALU cycles used).  The two walks are independent: their reads are issued together.  A lane's records -- the first
+    // piece's, then the second's -- are one contiguous stretch of the output.
+    // event lists: entry k of piece h of this lane at lists[(2 h + k) * 1024] (kChainLaneCap / 2 each), beyond that in global memory
+    uint32_t *lists = reinterpret_cast<uint32_t *>(smem + img_bytes + cls_bytes) + threadIdx.x;
+    uint32_t *spill = T.spill + (uint64_t(blockIdx.x) * kChainWaves + wave) * T.spill_cap * 128u + lane;   // entry k of piece h at spill[((k - cap) * 2 + h) * 64]
+    constexpr uint32_t kCap = kChainLaneCap / 2u;
     uint32_t walked16 = 0;
     const uint32_t cnt_n = A.chain_cnt_n;
+    const uint32_t gw = blockIdx.x * kChainWaves + wave;   // this wave among the grid's
+    const uint64_t tiles_all = (total_items + T.R - 1u) / T.R;
+    uint32_t *const log = T.log + uint64_t(gw) * T.log_cap;
+    uint32_t log_at = 0;   // words of the wave's log in use
 #pragma unroll 1
-    for (;;) {
-        uint32_t t = 0;
-        if (lane == 0) {
-            const uint32_t i = atomicAdd(&s_cur, 1u);
-            const uint32_t b = i / kChainBatch, o = i % kChainBatch, slot = b & 3u;
-            if (o == 0u) {
-                const uint32_t g = atomicAdd(T.ticket, 1u);
-                __hip_atomic_store(&s_base[slot], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_store(&s_bid[slot], b, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            } else {
-                while (__hip_atomic_load(&s_bid[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != b) __builtin_amdgcn_s_sleep(1);
-            }
-            t = __hip_atomic_load(&s_base[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) * kChainBatch + o;
-        }
-        t = uint32_t(__builtin_amdgcn_readfirstlane(int(t)));
-        const uint64_t first_item = uint64_t(t) * T.R;
-        if (first_item >= total_items) break;
-        const uint64_t item = first_item + r;
-        const bool have = r < T.R && item < total_items;
-        // this lane's piece (k_walk_tiles' geometry): the first block it walks, where in it the walk begins, what reports
-        const uint8_t *pb = A.pad16;
-        uint32_t nblk = 0, start_j = 16u, rep_lo = 0, rep_len = 0, pos_bias = 0, hay = 0;
-        if (have) {
-            const uint4 rec = B.item_rec[item];
-            ItemDesc it;
-            unpack_item(rec.x, rec.y, rec.z, rec.w, it);
-            hay = B.item_hay[item];
-            const uint64_t zb = it.begin + beta;
-            const uint64_t G = zb & ~uint64_t(15);
-            const uint32_t d0 = uint32_t(zb - G);
-            const uint32_t a = qi * T.W;
-            const uint32_t lo = a > d0 ? a : d0;
-            const uint32_t end = d0 + it.len;
-            const uint32_t hi = (qi + 1u == T.P) ? end : (a + T.W < end ? a + T.W : end);
-            if (lo < hi) {
-                const int64_t hs = int64_t(d0) - int64_t(it.pos0);   // the haystack's first byte
-                int64_t xs = int64_t(lo) - int64_t(T.back);           // Lmax - 1 bytes early: exact from there on
-                if (xs < hs) xs = hs;
-                int64_t xb = xs & ~int64_t(15);
-                if (xb == xs) xb -= 16;   // (a walk that begins ON a block boundary takes the block below as its first, virtually)
-                pb = abase + G + xb;
-                start_j = uint32_t(xs - xb);
-                rep_lo = uint32_t(int64_t(lo) - xb);
-                rep_len = hi - lo;
-                nblk = (rep_lo + rep_len + 15u) >> 4;
-                pos_bias = uint32_t(xb) - d0 + it.pos0 + 1u;
-                walked16 += nblk;
-            }
-        }
+    for (uint64_t t = gw; t < tiles_all; t += T.n_waves) {
+        const uint64_t first_item = t * T.R;
+        const Piece pa = chain_piece(A, B, T, total_items, first_item, 2u * lane), pz = chain_piece(A, B, T, total_items, first_item, 2u * lane + 1u);
+        walked16 += pa.nblk + pz.nblk;
         // ---- the walk: all lanes in step, a lane past its own bytes walks on without reporting ----
-        uint32_t e = 0, n_ev = 0, n_rec = 0;
-        const uint32_t blocks = chain_wave_max(nblk);
-        if (blocks) {
+        uint32_t ea = 0, ez = 0, na = 0, nz = 0;   // states and event counts of the two pieces
+        const uint32_t my_blocks = pa.nblk > pz.nblk ? pa.nblk : pz.nblk;
+        if (__any(my_blocks != 0u) && !(T.debug & 2u)) {
             // An event inside the walk is ONE store: {index, what the parent's record says about its records (entered along the
-            // chain; else 0), byte} to the lane's list.  What it stands for is worked out behind the walk, where a lane runs over
+            // chain; else 0), byte} to the piece's list.  What it stands for is worked out behind the walk, where a lane runs over
             // its own events only -- in here the whole wave pays for every step in which ANY lane has one.
-            auto event = [&](uint32_t jj, uint32_t u, bool hit, bool inside) __attribute__((always_inline)) {
-                if ((u & 0xFFFFu) >= 0x8000u && inside) {
-                    const uint32_t ent = e | ((hit ? u : 0u) & 0x7C00u) << 5 | jj << 23;
-                    if (n_ev < kChainLaneCap) lists[n_ev * kChainThreads] = ent;
-                    else *reinterpret_cast<__attribute__((address_space(1))) uint32_t *>(reinterpret_cast<uintptr_t>(spill + (n_ev - kChainLaneCap) * 64u)) = ent;
-                    ++n_ev;
-                }
+            auto event = [&](uint32_t h, uint32_t e, uint32_t &n, uint32_t jj, uint32_t u, bool hit) __attribute__((always_inline)) {
+                const uint32_t ent = e | (((hit ? u : 0u) >> 9) & 0xF8000u) | jj << 23;
+                if (n < kCap) lists[(2u * h + n) * kChainThreads] = ent;
+                else *reinterpret_cast<__attribute__((address_space(1))) uint32_t *>(reinterpret_cast<uintptr_t>(spill + ((n - kCap) * 2u + h) * 64u)) = ent;
+                ++n;
             };
-            // sixteen unrolled steps per block; the column offsets of a dword's four bytes are worked out together (SWAR3: a handful
-            // of operations for all four; TABLE: four independent LDS reads).  CHECKED: the range test of a block that does not lie
-            // inside every lane's own range; WARM: the first block, in which a lane's walk begins (the state is the root before).
-            auto dword = [&](uint32_t wd, uint32_t jj, auto checked, auto warm) __attribute__((always_inline)) {
-                constexpr bool C = decltype(checked)::value, W0 = decltype(warm)::value;
-                uint32_t c0, c1, c2, c3;
+            // four steps of both pieces; the column offsets of a dword's four bytes are worked out together (SWAR3: a handful of
+            // operations for all four; TABLE: four independent LDS reads).  CHECKED: the range test of a block that does not lie
+            // inside every piece's own range; WARM: the first block, in which a walk begins (the state is the root before).
+            auto columns = [&](uint32_t wd, uint32_t (&c)[4]) __attribute__((always_inline)) {
                 if constexpr (MODE == 1) {
                     const uint32_t c4 = swar_columns<uint16_t>(A, wd);
-                    c0 = c4 & 0xffu; c1 = (c4 >> 8) & 0xffu; c2 = (c4 >> 16) & 0xffu; c3 = c4 >> 24;
+                    c[0] = c4 & 0xffu; c[1] = (c4 >> 8) & 0xffu; c[2] = (c4 >> 16) & 0xffu; c[3] = c4 >> 24;
                 } else {
-                    c0 = class_offset<uint16_t, MODE>(A, L.cls, wd & 0xffu); c1 = class_offset<uint16_t, MODE>(A, L.cls, (wd >> 8) & 0xffu);
-                    c2 = class_offset<uint16_t, MODE>(A, L.cls, (wd >> 16) & 0xffu); c3 = class_offset<uint16_t, MODE>(A, L.cls, wd >> 24);
+                    c[0] = class_offset<uint16_t, MODE>(A, L.cls, wd & 0xffu); c[1] = class_offset<uint16_t, MODE>(A, L.cls, (wd >> 8) & 0xffu);
+                    c[2] = class_offset<uint16_t, MODE>(A, L.cls, (wd >> 16) & 0xffu); c[3] = class_offset<uint16_t, MODE>(A, L.cls, wd >> 24);
                 }
-                uint32_t u;
-                bool hit;
-                auto one = [&](uint32_t cx, uint32_t j) __attribute__((always_inline)) {
-                    chain_step(L, e, cx, u, hit);
-                    if (W0) e = j < start_j ? 0u : e;
-                    event(j, u, hit, !C || j - rep_lo < rep_len);   // (rep_lo >= start_j: nothing before the walk's first byte reports)
-                };
-                one(c0, jj); one(c1, jj + 1u); one(c2, jj + 2u); one(c3, jj + 3u);
             };
-            const uint4 *q = reinterpret_cast<const uint4 *>(pb);
-            const uint32_t last = nblk ? nblk - 1u : 0u;
-            const uint4 first = q[start_j < 16u ? 0u : (last ? 1u : 0u)];   // (start_j == 16: block 0 is virtual)
-            uint4 b0 = q[1u < last ? 1u : last], b1 = q[2u < last ? 2u : last], b2 = q[3u < last ? 3u : last], b3 = q[4u < last ? 4u : last];
-            if (chain_wave_min(nblk ? start_j : 16u) < 16u) {   // (every walk of the wave begins on a block boundary: nothing to do in block 0)
-                dword(first.x, 0u, std::true_type{}, std::true_type{}); dword(first.y, 4u, std::true_type{}, std::true_type{});
-                dword(first.z, 8u, std::true_type{}, std::true_type{}); dword(first.w, 12u, std::true_type{}, std::true_type{});
+            auto dword = [&](uint32_t wa, uint32_t wz, uint32_t jj, auto checked, auto warm) __attribute__((always_inline)) {
+                constexpr bool C = decltype(checked)::value, W0 = decltype(warm)::value;
+                uint32_t ca[4], cz[4];
+                columns(wa, ca);
+                columns(wz, cz);
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; ++i) {
+                    const uint32_t j = jj + i;
+                    uint32_t ua, uz;
+                    bool ha, hz;
+                    chain_step2(L, ea, ez, ca[i], cz[i], ua, uz, ha, hz);
+                    if (W0) { ea = j < pa.start_j ? 0u : ea; ez = j < pz.start_j ? 0u : ez; }
+                    // (rep_lo >= start_j: nothing before a walk's first byte reports)
+                    const bool va = int32_t(ua) < 0 && (!C || j - pa.rep_lo < pa.rep_len);
+                    const bool vz = int32_t(uz) < 0 && (!C || j - pz.rep_lo < pz.rep_len);
+                    if (va || vz) {
+                        if (va) event(0u, ea, na, j, ua, ha);
+                        if (vz) event(1u, ez, nz, j, uz, hz);
+                    }
+                }
+            };
+            const uint4 *qa = reinterpret_cast<const uint4 *>(pa.pb), *qz = reinterpret_cast<const uint4 *>(pz.pb);
+            const uint32_t la = pa.nblk ? pa.nblk - 1u : 0u, lz = pz.nblk ? pz.nblk - 1u : 0u;
+            const uint4 fa = qa[pa.start_j < 16u ? 0u : (la ? 1u : 0u)], fz = qz[pz.start_j < 16u ? 0u : (lz ? 1u : 0u)];   // (start_j == 16: block 0 is virtual)
+            uint4 a0 = qa[1u < la ? 1u : la], a1 = qa[2u < la ? 2u : la], a2 = qa[3u < la ? 3u : la], a3 = qa[4u < la ? 4u : la];
+            uint4 z0 = qz[1u < lz ? 1u : lz], z1 = qz[2u < lz ? 2u : lz], z2 = qz[3u < lz ? 3u : lz], z3 = qz[4u < lz ? 4u : lz];
+            const uint32_t sj = pa.nblk ? pa.start_j : 16u, sk = pz.nblk ? pz.start_j : 16u;
+            if (__any(sj < 16u || sk < 16u)) {   // (else every walk of the wave begins on a block boundary: nothing to do in block 0)
+                dword(fa.x, fz.x, 0u, std::true_type{}, std::true_type{}); dword(fa.y, fz.y, 4u, std::true_type{}, std::true_type{});
+                dword(fa.z, fz.z, 8u, std::true_type{}, std::true_type{}); dword(fa.w, fz.w, 12u, std::true_type{}, std::true_type{});
             }
 #pragma unroll 1
-            for (uint32_t k = 1u; k < blocks; ++k) {
+            for (uint32_t k = 1u; __any(k < my_blocks); ++k) {   // (as many blocks as the wave's longest walk has: a ballot, not a reduction)
                 asm volatile("; acmi-hot-begin");   // (tools/check_asm.py: no scratch traffic between the markers)
-                const uint4 cur = b0;
-                b0 = b1; b1 = b2; b2 = b3;
+                const uint4 ca = a0, cz = z0;
+                a0 = a1; a1 = a2; a2 = a3;
+                z0 = z1; z1 = z2; z2 = z3;
                 const uint32_t kn = k + 4u;
-                if (kn < blocks) b3 = q[kn < last ? kn : last];
+                if (kn < my_blocks) { a3 = qa[kn < la ? kn : la]; z3 = qz[kn < lz ? kn : lz]; }
                 const uint32_t j0 = k * 16u;
-                // (a block that lies inside EVERY lane's own range -- all but the first and the last of a piece -- without the range test)
-                const bool full = j0 >= rep_lo && j0 + 16u <= rep_lo + rep_len;
+                // (a block that lies inside EVERY piece's own range -- all but the first and the last of a piece -- without the range test)
+                const bool full = j0 >= pa.rep_lo && j0 + 16u <= pa.rep_lo + pa.rep_len && j0 >= pz.rep_lo && j0 + 16u <= pz.rep_lo + pz.rep_len;
                 if (__all(full)) {
-                    dword(cur.x, j0, std::false_type{}, std::false_type{}); dword(cur.y, j0 + 4u, std::false_type{}, std::false_type{});
-                    dword(cur.z, j0 + 8u, std::false_type{}, std::false_type{}); dword(cur.w, j0 + 12u, std::false_type{}, std::false_type{});
+                    dword(ca.x, cz.x, j0, std::false_type{}, std::false_type{}); dword(ca.y, cz.y, j0 + 4u, std::false_type{}, std::false_type{});
+                    dword(ca.z, cz.z, j0 + 8u, std::false_type{}, std::false_type{}); dword(ca.w, cz.w, j0 + 12u, std::false_type{}, std::false_type{});
                 } else {
-                    dword(cur.x, j0, std::true_type{}, std::false_type{}); dword(cur.y, j0 + 4u, std::true_type{}, std::false_type{});
-                    dword(cur.z, j0 + 8u, std::true_type{}, std::false_type{}); dword(cur.w, j0 + 12u, std::true_type{}, std::false_type{});
+                    dword(ca.x, cz.x, j0, std::true_type{}, std::false_type{}); dword(ca.y, cz.y, j0 + 4u, std::true_type{}, std::false_type{});
+                    dword(ca.z, cz.z, j0 + 8u, std::true_type{}, std::false_type{}); dword(ca.w, cz.w, j0 + 12u, std::true_type{}, std::false_type{});
                 }
                 asm volatile("; acmi-hot-end");
             }
         }
-        if (n_ev > kChainLaneCap) {   // (this lane's own stores: landed before they are read back)
+        if (na > kCap || nz > kCap) {   // (this lane's own stores: landed before they are read back)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
@@ -266,54 +272,115 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
             }
             return chain_count(A, idx);
         };
+        // (entries beyond the LDS list: the lane's own stores, read back from L2 -- the CU's L1 may still hold the line as a tile before left it)
+        auto entry = [&](uint32_t h, uint32_t k) __attribute__((always_inline)) -> uint32_t {
+            return k < kCap ? lists[(2u * h + k) * kChainThreads] : __hip_atomic_load(spill + ((k - kCap) * 2u + h) * 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        uint32_t ra = 0, rz = 0;   // records of the two pieces
 #pragma unroll 1
-        for (uint32_t k = 0; k < n_ev; ++k)
-            n_rec += records_of(k < kChainLaneCap ? lists[k * kChainThreads] : __hip_atomic_load(spill + (k - kChainLaneCap) * 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        // ---- records: exclusive prefix over the wave's lanes, the items' totals, the wave's total; its base by look-back ----
+        for (uint32_t k = 0; k < na; ++k) ra += records_of(entry(0u, k));
+#pragma unroll 1
+        for (uint32_t k = 0; k < nz; ++k) rz += records_of(entry(1u, k));
+        // ---- records: exclusive prefix over the wave's lanes, the items' totals (k_expand's scan turns them into bases) ----
+        const uint32_t n_rec = ra + rz;
         const uint32_t incl = wave_inclusive_sum(n_rec);
         const uint32_t excl = incl - n_rec;
         const uint32_t wave_tot = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
         {
-            const uint32_t first_lane = r * T.P, last_lane = first_lane + T.P - 1u;
-            const uint32_t item_tot = uint32_t(__shfl(int(incl), int(last_lane < 64u ? last_lane : 63u), 64)) - uint32_t(__shfl(int(excl), int(first_lane < 64u ? first_lane : 63u), 64));
-            if (have && qi == 0u && item_tot) B.rec_count[item] = item_tot;
+            // an item's total: the running sum behind its last piece less the sum before its first (pieces 2 l, 2 l + 1 of lane l)
+            auto before = [&](uint32_t s) __attribute__((always_inline)) -> uint32_t {   // records of the pieces before piece s (s < 128)
+                const uint32_t l = s >> 1;
+                const uint32_t ex = uint32_t(__shfl(int(excl), int(l), 64)), mid = uint32_t(__shfl(int(excl + ra), int(l), 64));
+                return (s & 1u) ? mid : ex;
+            };
+            auto item_total = [&](const Piece &pc) __attribute__((always_inline)) {
+                const uint32_t s0 = pc.r * T.P, s1 = s0 + T.P;   // pieces [s0, s1) (s1 <= 128 for an item the wave has)
+                const uint32_t lo = before(s0 < 128u ? s0 : 127u);
+                const uint32_t up = before(s1 < 128u ? s1 : 127u);   // (a shuffle: by ALL lanes, whatever they then keep)
+                const uint32_t hi = s1 < 128u ? up : wave_tot;
+                if (pc.have && pc.qi == 0u && hi != lo) B.rec_count[pc.item] = hi - lo;
+            };
+            item_total(pa);
+            item_total(pz);
         }
-        const uint64_t base = chain_exclusive(T.status, t, wave_tot);
-        // (too small a buffer: what fits is written -- whole events, in order -- and the host grows it and runs the batch again, or hands
-        // out the haystacks that are complete: "max_result_bytes")
-        if (wave_tot == 0u || base >= T.cap) continue;
-        const uint64_t room = T.cap - base;
-        uint4 *dst = T.out + base;
-        uint64_t at = excl;
+        // ---- the tile's events into the wave's log, piece after piece: {index, piece, byte}; where they begin and how many ----
+        const uint32_t ne = na + nz;
+        const uint32_t e_incl = wave_inclusive_sum(ne);
+        const uint32_t e_tot = uint32_t(__builtin_amdgcn_readlane(int(e_incl), 63));
+        if (lane == 0) T.tile_info[t] = make_uint2(log_at, e_tot);
+        if (log_at + e_tot > T.log_cap) {
+            // (the log is sized for the batches before: the host grows it and runs the batch again)
+            if (lane == 0) atomicOr(&B.counters[19], 1u);
+        } else {
+            uint32_t *dst = log + log_at + (e_incl - ne);
+            // (the count code has done its work above: its bits name the piece from here on)
 #pragma unroll 1
-        for (uint32_t k = 0; k < n_ev; ++k) {
-            // (its own stores, read back from L2: the CU's L1 may still hold the line as a tile before left it)
-            const uint32_t ent = k < kChainLaneCap ? lists[k * kChainThreads] : __hip_atomic_load(spill + (k - kChainLaneCap) * 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t idx = ent & 0x7FFFu, pos = pos_bias + (ent >> 23);
-            const uint2 h = A.chain_head[idx];
-            const uint32_t c = records_of(ent);
-            if (at + c <= room) {
-                dst[at] = make_uint4(hay, pos, pos - h.y, h.x & 0xFFFFFFu);
+            for (uint32_t k = 0; k < na; ++k) dst[k] = (entry(0u, k) & 0xFF807FFFu) | (2u * lane) << 15;
+#pragma unroll 1
+            for (uint32_t k = 0; k < nz; ++k) dst[na + k] = (entry(1u, k) & 0xFF807FFFu) | (2u * lane + 1u) << 15;
+        }
+        log_at += e_tot;
+    }
+    // statistic: 16-byte blocks walked (what the automatic kernel choice reads)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) walked16 += __shfl_xor(walked16, d, 64);
+    if (lane == 0 && walked16) atomicAdd(&B.counters[8u + ((blockIdx.x + wave) & 7u)], walked16);
+}
+
+// k_chain_emit: the logs into records.  A wave per tile; the tile's events lie in its wave's log in text order -- piece after piece --
+// and its items are consecutive, so an event's records begin at rec_base[the tile's first item] (k_expand's scan of the counts the
+// walk left) + the records of the tile's events before it: a running sum over the log, 64 events per round whatever their
+// distribution over the pieces -- position ascending, an event's records longest pattern first (node.c:424-441) by construction,
+// and an event of one record (most) is one of 64 consecutive 16-byte stores.  What an event needs of its piece (haystack, the
+// position of its first byte) comes from the lane that would have walked it.
+constexpr uint32_t kEmitThreads = 256;
+__global__ __launch_bounds__(kEmitThreads) void k_chain_emit(DevAutomaton A, BatchArgs B, ChainArgs T) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t total_items = B.item_base[B.n_haystacks];
+    const uint64_t tiles_all = (total_items + T.R - 1u) / T.R;
+    const uint64_t n_waves = uint64_t(gridDim.x) * (kEmitThreads / 64u);
+#pragma unroll 1
+    for (uint64_t t = uint64_t(blockIdx.x) * (kEmitThreads / 64u) + (threadIdx.x >> 6); t < tiles_all; t += n_waves) {
+        const uint2 info = T.tile_info[t];
+        if (info.y == 0u) continue;
+        const uint32_t *ev = T.log + (t % T.n_waves) * uint64_t(T.log_cap) + info.x;
+        const uint64_t first_item = t * T.R;
+        const Piece pa = chain_piece(A, B, T, total_items, first_item, 2u * lane), pz = chain_piece(A, B, T, total_items, first_item, 2u * lane + 1u);
+        uint64_t at = T.rec_base[first_item];
+#pragma unroll 1
+        for (uint32_t e0 = 0; e0 < info.y; e0 += 64u) {
+            const bool valid = e0 + lane < info.y;
+            const uint32_t ent = valid ? ev[e0 + lane] : 0u;
+            const uint32_t idx = ent & 0x7FFFu, piece = (ent >> 15) & 127u, owner = piece >> 1;
+            uint2 hd = make_uint2(0u, 0u);
+            if (valid) hd = A.chain_head[idx];
+            uint32_t c = valid ? hd.x >> 24 : 0u;
+            if (c == 255u) c = A.out_count[A.chain_orig[idx]];
+            const uint32_t ba = uint32_t(__shfl(int(pa.pos_bias), int(owner), 64)), bz = uint32_t(__shfl(int(pz.pos_bias), int(owner), 64));
+            const uint32_t ha = uint32_t(__shfl(int(pa.hay), int(owner), 64)), hz = uint32_t(__shfl(int(pz.hay), int(owner), 64));
+            const uint32_t pos = ((piece & 1u) ? bz : ba) + (ent >> 23), hay = (piece & 1u) ? hz : ha;
+            const uint32_t incl = wave_inclusive_sum(c);
+            const uint64_t mine = at + (incl - c);
+            // (too small a buffer: what fits is written -- whole events, in order -- and the host grows it and has the logs emitted
+            // again, or hands out the haystacks that are complete: "max_result_bytes")
+            if (c != 0u && mine + c <= T.cap) {
+                T.out[mine] = make_uint4(hay, pos, pos - hd.y, hd.x & 0xFFFFFFu);
                 if (c > 1u) {
                     const uint32_t s = A.chain_orig[idx];
                     if (A.out_list != nullptr) {
                         const uint2 *ol = A.out_list + A.out_off[s];
                         for (uint32_t i = 1; i < c; ++i) {
                             const uint2 o = ol[i];
-                            dst[at + i] = make_uint4(hay, pos, pos - o.y, o.x);
+                            T.out[mine + i] = make_uint4(hay, pos, pos - o.y, o.x);
                         }
                     } else {
-                        (void)emit_event(A, dst, at, hay, pos, s);
+                        (void)emit_event(A, T.out, mine, hay, pos, s);
                     }
                 }
             }
-            at += c;
+            at += uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
         }
     }
-    // statistic: 16-byte blocks walked (what the automatic kernel choice reads)
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) walked16 += __shfl_xor(walked16, d, 64);
-    if (lane == 0 && walked16) atomicAdd(&B.counters[8u + ((blockIdx.x + wave) & 7u)], walked16);
 }
 
 // Does this automaton have the image, and does the kernel's LDS layout hold it?
@@ -324,38 +391,58 @@ bool chain_walk_ok(const DevAutomaton &A) {
 }
 
 uint32_t chain_grid() { return uint32_t(num_cus()); }
-uint64_t chain_status_words(uint64_t max_items, uint32_t P) { return max_items / (64u / P) + 66u + uint64_t(chain_grid()) * kChainBatch; }
-// the waves' global event regions: what a lane can have beyond its LDS list, a word each
+uint32_t chain_waves() { return chain_grid() * kChainWaves; }
+uint64_t chain_tiles(uint64_t max_items, uint32_t P) { return max_items / (128u / P) + 1u; }
+// the waves' overflow regions: what a piece can have beyond its LDS list, a word each
 // (an item's last piece takes the item's unaligned head as well: up to W + 15 bytes, an event each)
-uint64_t chain_spill_words(uint32_t W) { return uint64_t(chain_grid()) * kChainWaves * uint64_t(W + 16u) * 64u; }
+uint64_t chain_spill_words(uint32_t W) { return uint64_t(chain_waves()) * uint64_t(W + 16u) * 128u; }
 
-hipError_t launch_walk_chain(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int class_mode, uint32_t W, uint32_t P, void *spill,
-                             uint32_t *ticket, uint64_t *status, void *out, uint64_t cap, hipStream_t st) {
-    if (max_items == 0) return hipSuccess;
-    if (!chain_walk_ok(A)) return hipErrorInvalidValue;
+static ChainArgs chain_args(const DevAutomaton &A, uint32_t W, uint32_t P, const ChainBuffers &C) {
     ChainArgs T{};
     T.W = W;
     T.P = P;
-    T.R = 64u / P;
+    T.R = 128u / P;   // (a lane takes two pieces)
+    T.inv_p = (65536u + P - 1u) / P;
     T.back = A.max_pattern_length ? A.max_pattern_length - 1u : 0u;
     T.spill_cap = W + 16u;
-    T.spill = static_cast<uint32_t *>(spill);
-    T.ticket = ticket;
-    T.status = status;
-    T.out = static_cast<uint4 *>(out);
-    T.cap = cap;
+    T.spill = C.spill;
+    T.log = C.log;
+    T.log_cap = C.log_cap;
+    T.tile_info = reinterpret_cast<uint2 *>(C.tile_info);
+    T.n_waves = chain_waves();
+    return T;
+}
+
+hipError_t launch_walk_chain(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int class_mode, uint32_t W, uint32_t P, const ChainBuffers &C,
+                             hipStream_t st) {
+    if (max_items == 0) return hipSuccess;
+    if (!chain_walk_ok(A)) return hipErrorInvalidValue;
+    ChainArgs T = chain_args(A, W, P, C);
+    static const uint32_t debug = [] { const char *e = std::getenv("ACMI_CHAIN_DEBUG"); return e ? uint32_t(std::atoi(e)) : 0u; }();
+    T.debug = debug;
     const uint32_t img = (A.chain_img_bytes + 15u) & ~15u;
     const uint32_t lds = img + (class_mode == 0 ? 512u : 0u) + kChainWaves * kChainLaneCap * 256u;
-    const uint64_t tiles = (max_items + T.R - 1u) / T.R;
-    const uint32_t grid = chain_grid() - std::min<uint32_t>(B.reserve_cus, chain_grid() - 1u);
-    const uint32_t blocks = uint32_t(std::min<uint64_t>((tiles + kChainWaves - 1u) / kChainWaves, grid));
+    // (always the whole grid: the logs are per wave of THIS grid -- k_chain_emit finds a tile's by t % n_waves)
     auto go = [&](auto fn) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(fn, dim3(blocks), dim3(kChainThreads), lds, st, A, B, T);
+        hipLaunchKernelGGL(fn, dim3(chain_grid()), dim3(kChainThreads), lds, st, A, B, T);
         return hipGetLastError();
     };
     return class_mode == 1 ? go(k_walk_chain<1>) : go(k_walk_chain<0>);
+}
+
+hipError_t launch_chain_emit(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, uint32_t W, uint32_t P, const ChainBuffers &C,
+                             const uint64_t *rec_base, void *out, uint64_t cap, hipStream_t st) {
+    if (max_items == 0) return hipSuccess;
+    ChainArgs T = chain_args(A, W, P, C);
+    T.rec_base = rec_base;
+    T.out = static_cast<uint4 *>(out);
+    T.cap = cap;
+    const uint64_t tiles = chain_tiles(max_items, P);
+    const uint32_t blocks = uint32_t(std::min<uint64_t>((tiles + 3u) / 4u, uint64_t(num_cus()) * 8u));
+    hipLaunchKernelGGL(k_chain_emit, dim3(blocks), dim3(kEmitThreads), 0, st, A, B, T);
+    return hipGetLastError();
 }
 
 }  // namespace acmi

@@ -31,12 +31,22 @@ bool tiles_geometry(uint32_t max_pattern_length, uint32_t n_states, uint64_t blo
 uint64_t tiles_queue_entries(uint32_t W);                       // 8-byte entries of the waves' event queues
 uint64_t tiles_status_words(uint64_t max_items, uint32_t P);    // 8-byte look-back words (zeroed, behind an 8-byte ticket)
 // merge_prefix / merge_records (tiles_can_merge only): the match arrays of the other part of a split set, merged into `out`
-// k_walk_chain (k_chain.hip, kernel 6 for automata that carry the chain-compressed image): the same walk over the whole automaton in LDS
+// k_walk_chain + k_chain_emit (k_chain.hip, kernel 6 for automata that carry the chain-compressed image): the walk over the whole
+// automaton in LDS leaves its events in per-wave logs and the items' record counts; behind k_expand's scan the logs become records
+struct ChainBuffers {
+    uint32_t *spill;       // chain_spill_words(W) words
+    uint32_t *log;         // chain_waves() x log_cap words
+    uint32_t log_cap;
+    uint32_t *tile_info;   // 2 x chain_tiles(max_items, P) words: per tile {where its events begin in its wave's log, how many}
+};
 bool chain_walk_ok(const DevAutomaton &A);
-uint64_t chain_status_words(uint64_t max_items, uint32_t P);    // 8-byte look-back words, one per WAVE tile (zeroed, behind an 8-byte ticket)
-uint64_t chain_spill_words(uint32_t W);                         // 4-byte entries of the waves' overflow event lists
-hipError_t launch_walk_chain(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int class_mode, uint32_t W, uint32_t P, void *spill,
-                             uint32_t *ticket, uint64_t *status, void *out, uint64_t cap, hipStream_t st);
+uint32_t chain_waves();
+uint64_t chain_tiles(uint64_t max_items, uint32_t P);
+uint64_t chain_spill_words(uint32_t W);
+hipError_t launch_walk_chain(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int class_mode, uint32_t W, uint32_t P, const ChainBuffers &C,
+                             hipStream_t st);
+hipError_t launch_chain_emit(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, uint32_t W, uint32_t P, const ChainBuffers &C,
+                             const uint64_t *rec_base, void *out, uint64_t cap, hipStream_t st);
 hipError_t launch_walk_tiles(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode, uint32_t W, uint32_t P,
                              void *queue, uint32_t *ticket, uint64_t *status, void *out, uint64_t cap, hipStream_t st,
                              const uint64_t *merge_prefix = nullptr, const void *merge_records = nullptr);

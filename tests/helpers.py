@@ -164,12 +164,12 @@ class FlatTables:
             final, n = False, 0
             if e >= nd:
                 r = int(recs_[e - nd])
-                assert (r >> 16) < nd, "a C state's failure state must be a D state"
-                if (r & 0x3FF) == c:
-                    e, final, n = e + 1, bool(r & 0x8000), (r >> 10) & 31
+                assert (r & 0xFFFF) < nd, "a C state's failure state must be a D state"
+                if ((r >> 16) & 0xFF) == 2 * c:
+                    e, final, n = e + 1, bool(r >> 31), (r >> 24) & 31
                     assert e >= nd and e < ch["n_index"], "a C state's child is the next index, a C state"
                 else:
-                    t = int(rows[r >> 16, c])
+                    t = int(rows[r & 0xFFFF, c])
                     e, final = t & 0x7FFF, bool(t & 0x8000)
                     n = (int(cnt[e]) if e < ch["cnt_n"] else 255) if final else 0
             else:

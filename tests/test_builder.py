@@ -90,7 +90,8 @@ def test_tables_match_oracle(name, lds, compact):
     api.ahocorasick_deinit(res)
 
 
-@pytest.mark.parametrize("name,lds,fits", [("G2", 2048, True), ("G2", None, True), ("G4", 2048, True), ("G5", 2048, True), ("R1", 2048, True), ("R2", 2048, True),
+@pytest.mark.parametrize("name,lds,fits", [("G2", 2048, True), ("G2", None, True), ("G4", 2048, True), ("G5", 2048, True), ("R1", 2048, True), ("R2", 2048, False),   # 254 byte classes: a record's key byte holds 127
+                                          
                                            ("R3", 2048, False),    # 38,357 states: more than an index has bits for
                                            ("K1", 8192, True), ("K2", 8192, False), ("X1", 2048, False)])   # rows of 512 B / 26 B: too big
 def test_chain_image_walks_like_the_oracle(name, lds, fits):
@@ -113,9 +114,9 @@ def test_chain_image_walks_like_the_oracle(name, lds, fits):
     assert ch["n_index"] == ft.n_states - 1 and 0 < ch["n_dense"] <= ch["n_index"] and ch["bytes"] <= 160 * 1024 - 16 * 1024 - 768
     assert sorted(ch["orig"].tolist()) == sorted(set(range(ft.n_states)) - {ft.trap})      # every state once
     nd = ch["n_dense"]
-    key = ch["recs"] & 0x3FF
-    assert np.all((ch["recs"] >> 16) < nd) and np.all((key < ft.n_columns) | (key == 0x3FF))
-    assert np.all(key[-1:] == 0x3FF)                                                        # (the last chain ends)
+    key = (ch["recs"] >> 16) & 0xFF
+    assert np.all((ch["recs"] & 0xFFFF) < nd) and np.all(((key < 2 * ft.n_columns) & (key % 2 == 0)) | (key == 0xFF))
+    assert np.all(key[-1:] == 0xFF)                                                        # (the last chain ends)
     o = Oracle("port")
     o.add_patterns(ds.patterns())
     plen = np.diff(ds.pat_off.astype(np.int64))
