@@ -187,7 +187,10 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
             // chain; else 0), byte} to the piece's list.  What it stands for is worked out behind the walk, where a lane runs over
             // its own events only -- in here the whole wave pays for every step in which ANY lane has one.
             auto event = [&](uint32_t h, uint32_t e, uint32_t &n, uint32_t jj, uint32_t u, bool hit) __attribute__((always_inline)) {
-                const uint32_t ent = e | (((hit ? u : 0u) >> 9) & 0xF8000u) | jj << 23;
+                // (bits 24..28: the parent record's count of the child's records; a row entry read as a negative halfword has 31 there,
+                // like a saturated count: "look it up")
+                (void)hit;
+                const uint32_t ent = (u & 0x1F000000u) | e | jj << 15;
                 if (n < kCap) lists[(2u * h + n) * kChainThreads] = ent;
                 else *reinterpret_cast<__attribute__((address_space(1))) uint32_t *>(reinterpret_cast<uintptr_t>(spill + ((n - kCap) * 2u + h) * 64u)) = ent;
                 ++n;
@@ -225,11 +228,17 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
                     }
                 }
             };
-            const uint4 *qa = reinterpret_cast<const uint4 *>(pa.pb), *qz = reinterpret_cast<const uint4 *>(pz.pb);
+            // (explicitly global loads: through a generic pointer hipcc emits flat_load, which counts on the LDS counter too -- every
+            // wait for a state's record then also waited for the text requested four blocks ahead)
+            auto block = [](const uint8_t *base, uint32_t i) __attribute__((always_inline)) -> uint4 {
+                const u32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) u32x4 *>(reinterpret_cast<uintptr_t>(base) + 16u * i);
+                return make_uint4(v.x, v.y, v.z, v.w);
+            };
+            const uint8_t *qa = pa.pb, *qz = pz.pb;
             const uint32_t la = pa.nblk ? pa.nblk - 1u : 0u, lz = pz.nblk ? pz.nblk - 1u : 0u;
-            const uint4 fa = qa[pa.start_j < 16u ? 0u : (la ? 1u : 0u)], fz = qz[pz.start_j < 16u ? 0u : (lz ? 1u : 0u)];   // (start_j == 16: block 0 is virtual)
-            uint4 a0 = qa[1u < la ? 1u : la], a1 = qa[2u < la ? 2u : la], a2 = qa[3u < la ? 3u : la], a3 = qa[4u < la ? 4u : la];
-            uint4 z0 = qz[1u < lz ? 1u : lz], z1 = qz[2u < lz ? 2u : lz], z2 = qz[3u < lz ? 3u : lz], z3 = qz[4u < lz ? 4u : lz];
+            const uint4 fa = block(qa, pa.start_j < 16u ? 0u : (la ? 1u : 0u)), fz = block(qz, pz.start_j < 16u ? 0u : (lz ? 1u : 0u));   // (start_j == 16: block 0 is virtual)
+            uint4 a0 = block(qa, 1u < la ? 1u : la), a1 = block(qa, 2u < la ? 2u : la), a2 = block(qa, 3u < la ? 3u : la), a3 = block(qa, 4u < la ? 4u : la);
+            uint4 z0 = block(qz, 1u < lz ? 1u : lz), z1 = block(qz, 2u < lz ? 2u : lz), z2 = block(qz, 3u < lz ? 3u : lz), z3 = block(qz, 4u < lz ? 4u : lz);
             const uint32_t sj = pa.nblk ? pa.start_j : 16u, sk = pz.nblk ? pz.start_j : 16u;
             if (__any(sj < 16u || sk < 16u)) {   // (else every walk of the wave begins on a block boundary: nothing to do in block 0)
                 dword(fa.x, fz.x, 0u, std::true_type{}, std::true_type{}); dword(fa.y, fz.y, 4u, std::true_type{}, std::true_type{});
@@ -242,7 +251,7 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
                 a0 = a1; a1 = a2; a2 = a3;
                 z0 = z1; z1 = z2; z2 = z3;
                 const uint32_t kn = k + 4u;
-                if (kn < my_blocks) { a3 = qa[kn < la ? kn : la]; z3 = qz[kn < lz ? kn : lz]; }
+                if (kn < my_blocks) { a3 = block(qa, kn < la ? kn : la); z3 = block(qz, kn < lz ? kn : lz); }
                 const uint32_t j0 = k * 16u;
                 // (a block that lies inside EVERY piece's own range -- all but the first and the last of a piece -- without the range test)
                 const bool full = j0 >= pa.rep_lo && j0 + 16u <= pa.rep_lo + pa.rep_len && j0 >= pz.rep_lo && j0 + 16u <= pz.rep_lo + pz.rep_len;
@@ -264,9 +273,9 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
         // to -- if it has one: a row may also lead INTO a chain (the child of a C state on the row's failure path) -- else, and for
         // saturated counts, the tables in global memory
         auto records_of = [&](uint32_t ent) __attribute__((always_inline)) -> uint32_t {
-            const uint32_t idx = ent & 0x7FFFu, code = (ent >> 15) & 31u;
-            if (code != 0u && code != 31u) return code;
-            if (code == 0u && idx < cnt_n) {
+            const uint32_t idx = ent & 0x7FFFu, code = (ent >> 24) & 31u;
+            if (code != 31u) return code;
+            if (idx < cnt_n) {
                 const uint32_t c = L.cnt[idx];
                 if (c != 255u) return c;
             }
@@ -315,9 +324,9 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
             uint32_t *dst = log + log_at + (e_incl - ne);
             // (the count code has done its work above: its bits name the piece from here on)
 #pragma unroll 1
-            for (uint32_t k = 0; k < na; ++k) dst[k] = (entry(0u, k) & 0xFF807FFFu) | (2u * lane) << 15;
+            for (uint32_t k = 0; k < na; ++k) dst[k] = (entry(0u, k) & 0x00FFFFFFu) | (2u * lane) << 24;
 #pragma unroll 1
-            for (uint32_t k = 0; k < nz; ++k) dst[na + k] = (entry(1u, k) & 0xFF807FFFu) | (2u * lane + 1u) << 15;
+            for (uint32_t k = 0; k < nz; ++k) dst[na + k] = (entry(1u, k) & 0x00FFFFFFu) | (2u * lane + 1u) << 24;
         }
         log_at += e_tot;
     }
@@ -347,18 +356,21 @@ __global__ __launch_bounds__(kEmitThreads) void k_chain_emit(DevAutomaton A, Bat
         const uint64_t first_item = t * T.R;
         const Piece pa = chain_piece(A, B, T, total_items, first_item, 2u * lane), pz = chain_piece(A, B, T, total_items, first_item, 2u * lane + 1u);
         uint64_t at = T.rec_base[first_item];
-#pragma unroll 1
-        for (uint32_t e0 = 0; e0 < info.y; e0 += 64u) {
+        // two rounds of 64 events at a time: a round is three dependent round trips (the event, its state's output head, the store),
+        // and only the running sum ties one round to the next
+        auto fetch = [&](uint32_t e0, uint32_t &ent, uint2 &hd, uint32_t &c) __attribute__((always_inline)) {
             const bool valid = e0 + lane < info.y;
-            const uint32_t ent = valid ? ev[e0 + lane] : 0u;
-            const uint32_t idx = ent & 0x7FFFu, piece = (ent >> 15) & 127u, owner = piece >> 1;
-            uint2 hd = make_uint2(0u, 0u);
-            if (valid) hd = A.chain_head[idx];
-            uint32_t c = valid ? hd.x >> 24 : 0u;
-            if (c == 255u) c = A.out_count[A.chain_orig[idx]];
+            ent = valid ? ev[e0 + lane] : 0u;
+            hd = make_uint2(0u, 0u);
+            if (valid) hd = A.chain_head[ent & 0x7FFFu];
+            c = valid ? hd.x >> 24 : 0u;
+            if (c == 255u) c = A.out_count[A.chain_orig[ent & 0x7FFFu]];
+        };
+        auto place = [&](uint32_t ent, uint2 hd, uint32_t c) __attribute__((always_inline)) {
+            const uint32_t idx = ent & 0x7FFFu, piece = (ent >> 24) & 127u, owner = piece >> 1;
             const uint32_t ba = uint32_t(__shfl(int(pa.pos_bias), int(owner), 64)), bz = uint32_t(__shfl(int(pz.pos_bias), int(owner), 64));
             const uint32_t ha = uint32_t(__shfl(int(pa.hay), int(owner), 64)), hz = uint32_t(__shfl(int(pz.hay), int(owner), 64));
-            const uint32_t pos = ((piece & 1u) ? bz : ba) + (ent >> 23), hay = (piece & 1u) ? hz : ha;
+            const uint32_t pos = ((piece & 1u) ? bz : ba) + ((ent >> 15) & 511u), hay = (piece & 1u) ? hz : ha;
             const uint32_t incl = wave_inclusive_sum(c);
             const uint64_t mine = at + (incl - c);
             // (too small a buffer: what fits is written -- whole events, in order -- and the host grows it and has the logs emitted
@@ -379,6 +391,15 @@ __global__ __launch_bounds__(kEmitThreads) void k_chain_emit(DevAutomaton A, Bat
                 }
             }
             at += uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
+        };
+#pragma unroll 1
+        for (uint32_t e0 = 0; e0 < info.y; e0 += 128u) {
+            uint32_t ent0, ent1, c0, c1;
+            uint2 hd0, hd1;
+            fetch(e0, ent0, hd0, c0);
+            fetch(e0 + 64u, ent1, hd1, c1);
+            place(ent0, hd0, c0);
+            if (e0 + 64u < info.y) place(ent1, hd1, c1);
         }
     }
 }
@@ -440,7 +461,7 @@ hipError_t launch_chain_emit(const DevAutomaton &A, const BatchArgs &B, uint64_t
     T.out = static_cast<uint4 *>(out);
     T.cap = cap;
     const uint64_t tiles = chain_tiles(max_items, P);
-    const uint32_t blocks = uint32_t(std::min<uint64_t>((tiles + 3u) / 4u, uint64_t(num_cus()) * 8u));
+    const uint32_t blocks = uint32_t(std::min<uint64_t>((tiles + 3u) / 4u, uint64_t(num_cus()) * 16u));
     hipLaunchKernelGGL(k_chain_emit, dim3(blocks), dim3(kEmitThreads), 0, st, A, B, T);
     return hipGetLastError();
 }
