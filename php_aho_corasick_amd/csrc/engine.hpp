@@ -136,6 +136,7 @@ struct acmi_handle {
     struct ChoiceClass {
         float cost[kStratCount] = {0, 0, 0, 0};      // ms per GiB of haystack bytes: the lower of its last two batches (0: never run)
         float last[kStratCount] = {0, 0, 0, 0};      // ... what its last batch measured
+        float density = 0;                           // records per byte of the last batch measured
         uint32_t seen = 0;                           // batches in a row the strategy in use has been measured on (probes of others wait for two)
         uint32_t wait[kStratCount] = {0, 0, 0, 0};   // batches until this alternative may be probed again
         uint32_t span[kStratCount] = {16, 16, 16, 16};   // its back-off after the next lost probe

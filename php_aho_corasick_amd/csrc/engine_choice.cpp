@@ -42,7 +42,7 @@ float nominal_cost(const acmi_handle *h, int strat, uint64_t blob_bytes, size_t 
         const bool allhot = uint64_t(fa.trap) * (fa.n_columns * fa.entry_bytes + 4u) <= 60u * 1024u && fa.trap + 1u == fa.n_states;
         return float((fa.compact ? 6.0 : allhot ? 1.0 : 1.45) + density * (density > 0.25 ? 20.0 : 4.5));   // (past an event per 4 bytes: the second walk)
     }
-    default: return float((fa.compact ? 8.0 : 1.1) + density * 3.5);
+    default: return float((fa.compact ? 8.0 : 1.1) + density * 40.0);   // (measured: 1.43 / 2.37 ms per GiB at a record per 128 / 32 bytes)
     }
 }
 
@@ -76,14 +76,23 @@ int choose_strategy(acmi_handle *h, acmi_handle::FlySlot &F, uint64_t blob_bytes
     if (blob_bytes < kAutoMinBytes) return C.cur;   // (launch-bound either way: decides nothing, probes nothing)
     for (int s = 0; s < acmi_handle::kStratCount; ++s)
         if (C.wait[s]) --C.wait[s];
+    // of the alternatives waiting for a probe, the one that promises most first (what it is expected to cost on text of the density
+    // the last batch had): the headline set at 256 matches per 8 KiB went filter (18 ms per GiB) -> tile walk of the LDS rows (9 ms,
+    // three batches until one was timed) -> whole automaton in LDS (1.3 ms), ten batches on the way
+    int best = -1;
+    float best_cost = 0.f;
     for (int s = 0; s < acmi_handle::kStratCount; ++s) {
         if (!(C.pending >> s & 1u)) continue;
-        C.pending &= ~(1u << s);
-        if (s == C.cur || !strategy_eligible(h, s, blob_bytes, nh, find_all)) continue;
+        if (s == C.cur || !strategy_eligible(h, s, blob_bytes, nh, find_all)) { C.pending &= ~(1u << s); continue; }
+        const float c = nominal_cost(h, s, blob_bytes, nh, C.density);
+        if (best < 0 || c < best_cost) { best = s; best_cost = c; }
+    }
+    if (best >= 0) {
+        C.pending &= ~(1u << best);
         F.probe = true;
         ++h->probes;
-        if (choice_trace()) std::fprintf(stderr, "[acmi choice] class %d: probe %d (in use %d)\n", F.choice_class, s, C.cur);
-        return s;
+        if (choice_trace()) std::fprintf(stderr, "[acmi choice] class %d: probe %d (in use %d)\n", F.choice_class, best, C.cur);
+        return best;
     }
     return C.cur;
 }
@@ -100,6 +109,7 @@ void learn_strategy(acmi_handle *h, const acmi_handle::FlySlot &F, double ms_per
     // one bench run of two: the timed calls were the spike and two probes).  A probe stands on its own measurement: what the
     // strategy cost when it last ran was another text.
     const float now = float(ms_per_gib);
+    C.density = float(density);
     const bool first = C.last[s] <= 0.f || (F.probe && s != C.cur);
     C.cost[s] = first ? now : std::min(C.last[s], now);
     C.last[s] = now;
@@ -108,7 +118,12 @@ void learn_strategy(acmi_handle *h, const acmi_handle::FlySlot &F, double ms_per
         // margin only has to cover the run-to-run spread, a few per cent; at 1.25 a 2,048-word list over prose stayed on a filter
         // that cost 2.77 ms per GiB next to the tile walk's 2.33); a lost one backs off
         if (C.cost[C.cur] > 0.f && C.cost[s] * 1.12f < C.cost[C.cur]) {
+            C.wait[C.cur] = C.span[C.cur];   // (what has just been measured and beaten is not probed again at once)
             C.cur = s;
+            // (... and what was waiting for a probe because the OLD strategy was so slow has to promise something against the new one)
+            for (int a = 0; a < acmi_handle::kStratCount; ++a)
+                if ((C.pending >> a & 1u) && C.cost[s] <= 1.5f * (nominal_cost(h, a, F.blob_bytes, F.nh, density) + 0.06f * float(1ull << 30) / float(F.blob_bytes)))
+                    C.pending &= ~(1u << a);
             C.span[s] = 16;
             C.seen = 1;
             ++h->switches;
@@ -129,12 +144,13 @@ void learn_strategy(acmi_handle *h, const acmi_handle::FlySlot &F, double ms_per
     // once its back-off allows: what it cost on EARLIER text (a filter that lost on dense matches) does not keep it out for good,
     // the text may have changed.  (Expected cost: the kernel's rate plus what any pipeline costs whatever it scans, ~ 60 us --
     // small batches are launch-bound on every strategy and probe nothing.)
-    // (... and only on the evidence of two batches in a row: `cost` is then the lower of the two)
-    if (C.seen < 2 && ++C.seen < 2) return;
+    // (... and only on the evidence of two batches in a row -- `cost` is then the lower of the two -- unless the one batch cost four
+    // times the alternative: no spike explains that, and a filter on text full of matches is 18 ms per GiB a batch)
+    if (C.seen < 2) ++C.seen;
     for (int a = 0; a < acmi_handle::kStratCount; ++a) {
         if (a == s || C.wait[a] || !strategy_eligible(h, a, F.blob_bytes, F.nh, F.find_all)) continue;
         const float ref = nominal_cost(h, a, F.blob_bytes, F.nh, density) + 0.06f * float(1ull << 30) / float(F.blob_bytes);
-        if (C.cost[s] > 1.5f * ref) C.pending |= 1u << a;
+        if (C.cost[s] > (C.seen < 2 ? 4.0f : 1.5f) * ref) C.pending |= 1u << a;
     }
 }
 
