@@ -187,9 +187,9 @@ struct acmi_handle {
     uint64_t uni_nh[2] = {0, 0}, uni_len[2] = {0, 0};
     // the item table a slot holds (uniform batches through the filter: written once, not per batch): what it was made from
     // (the kept table stands only while k_walk_runs -- which zeroes every item's counters itself -- is the one kernel that touches them
-    // before the expansion: the kernel and findAll are part of the key, tests/test_gpu_variants.py compares kept with fresh tables)
-    struct ItemKey { uint64_t nh = 0, len = 0, max_items = 0; uint32_t chunk = 0, warm = 0, align = 0, blob_mis = 0, first_only = 0; int kernel = 0; const void *rec = nullptr, *hay = nullptr, *base = nullptr, *zero = nullptr; bool valid = false;
-        bool operator==(const ItemKey &o) const { return kernel == o.kernel && first_only == o.first_only && nh == o.nh && len == o.len && max_items == o.max_items && chunk == o.chunk && warm == o.warm && align == o.align && blob_mis == o.blob_mis && rec == o.rec && hay == o.hay && base == o.base && zero == o.zero; } };
+    // before the expansion: the kernel is part of the key, tests/test_gpu_variants.py compares kept with fresh tables)
+    struct ItemKey { uint64_t nh = 0, len = 0, max_items = 0; uint32_t chunk = 0, warm = 0, align = 0, blob_mis = 0; int kernel = 0; const void *rec = nullptr, *hay = nullptr, *base = nullptr, *zero = nullptr; bool valid = false;
+        bool operator==(const ItemKey &o) const { return kernel == o.kernel && nh == o.nh && len == o.len && max_items == o.max_items && chunk == o.chunk && warm == o.warm && align == o.align && blob_mis == o.blob_mis && rec == o.rec && hay == o.hay && base == o.base && zero == o.zero; } };
     ItemKey item_key[2];
     uint64_t item_tables_kept = 0;   // batches that reused their slot's item table (acmi_get_stat "item_tables_kept")
     uint64_t uniform_len = 0;

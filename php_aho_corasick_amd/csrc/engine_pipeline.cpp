@@ -337,7 +337,7 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
         // batch, ~ 10 us of the headline's step)
         const bool uniform = h->uniform_len && blob_bytes == h->uniform_len * nh;
         acmi_handle::ItemKey key;
-        key.kernel = kernel; key.first_only = find_all ? 0u : 1u;
+        key.kernel = kernel;   // (findAll is not part of it: the table is the same, the counters are k_walk_runs' either way)
         key.nh = nh; key.len = h->uniform_len; key.max_items = max_items; key.chunk = B.chunk_bytes; key.warm = B.warm_bytes; key.align = B.align_warm;
         key.blob_mis = uint32_t(reinterpret_cast<uintptr_t>(B.blob) & 127u);
         key.rec = d_item_rec.p; key.hay = d_item_hay.p; key.base = d_item_base.p; key.zero = d_zero.p;

@@ -281,15 +281,41 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
             }
             return chain_count(A, idx);
         };
-        // (entries beyond the LDS list: the lane's own stores, read back from L2 -- the CU's L1 may still hold the line as a tile before left it)
-        auto entry = [&](uint32_t h, uint32_t k) __attribute__((always_inline)) -> uint32_t {
-            return k < kCap ? lists[(2u * h + k) * kChainThreads] : __hip_atomic_load(spill + ((k - kCap) * 2u + h) * 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- behind the walk: every event once -- its records counted, the event itself into the wave's log, piece after piece:
+        // {index, byte, piece}.  (Entries beyond the LDS list are the lane's own stores, read back from L2 -- the CU's L1 may still hold
+        // the line as a tile before left it -- FOUR at a time: one after the other, each a round trip of its own, they were most of
+        // the kernel's time on text with an event every nine bytes.)
+        const uint32_t ne = na + nz;
+        const uint32_t e_incl = wave_inclusive_sum(ne);
+        const uint32_t e_tot = uint32_t(__builtin_amdgcn_readlane(int(e_incl), 63));
+        if (lane == 0) T.tile_info[t] = make_uint2(log_at, e_tot);
+        const bool fits = log_at + e_tot <= T.log_cap;
+        // (the log is sized for the batches before: the host grows it and runs the batch again)
+        if (!fits && lane == 0) atomicOr(&B.counters[19], 1u);
+        uint32_t *dst = log + log_at + (e_incl - ne);
+        auto drain = [&](uint32_t h, uint32_t n, uint32_t *to) __attribute__((always_inline)) -> uint32_t {
+            uint32_t recs = 0;
+            const uint32_t tag = (2u * lane + h) << 24;   // (the count code has done its work when the entry is logged: its bits name the piece)
+            auto one = [&](uint32_t k, uint32_t ent) __attribute__((always_inline)) {
+                recs += records_of(ent);
+                if (fits) to[k] = (ent & 0x00FFFFFFu) | tag;
+            };
+            for (uint32_t k = 0; k < kCap; ++k)
+                if (k < n) one(k, lists[(2u * h + k) * kChainThreads]);
+#pragma unroll 1
+            for (uint32_t k = kCap; k < n; k += 4u) {
+                uint32_t e[4];
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; ++i)
+                    e[i] = k + i < n ? __hip_atomic_load(spill + ((k + i - kCap) * 2u + h) * 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; ++i)
+                    if (k + i < n) one(k + i, e[i]);
+            }
+            return recs;
         };
-        uint32_t ra = 0, rz = 0;   // records of the two pieces
-#pragma unroll 1
-        for (uint32_t k = 0; k < na; ++k) ra += records_of(entry(0u, k));
-#pragma unroll 1
-        for (uint32_t k = 0; k < nz; ++k) rz += records_of(entry(1u, k));
+        const uint32_t ra = drain(0u, na, dst), rz = drain(1u, nz, dst + na);   // records of the two pieces
+        log_at += e_tot;
         // ---- records: exclusive prefix over the wave's lanes, the items' totals (k_expand's scan turns them into bases) ----
         const uint32_t n_rec = ra + rz;
         const uint32_t incl = wave_inclusive_sum(n_rec);
@@ -312,23 +338,6 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
             item_total(pa);
             item_total(pz);
         }
-        // ---- the tile's events into the wave's log, piece after piece: {index, piece, byte}; where they begin and how many ----
-        const uint32_t ne = na + nz;
-        const uint32_t e_incl = wave_inclusive_sum(ne);
-        const uint32_t e_tot = uint32_t(__builtin_amdgcn_readlane(int(e_incl), 63));
-        if (lane == 0) T.tile_info[t] = make_uint2(log_at, e_tot);
-        if (log_at + e_tot > T.log_cap) {
-            // (the log is sized for the batches before: the host grows it and runs the batch again)
-            if (lane == 0) atomicOr(&B.counters[19], 1u);
-        } else {
-            uint32_t *dst = log + log_at + (e_incl - ne);
-            // (the count code has done its work above: its bits name the piece from here on)
-#pragma unroll 1
-            for (uint32_t k = 0; k < na; ++k) dst[k] = (entry(0u, k) & 0x00FFFFFFu) | (2u * lane) << 24;
-#pragma unroll 1
-            for (uint32_t k = 0; k < nz; ++k) dst[na + k] = (entry(1u, k) & 0x00FFFFFFu) | (2u * lane + 1u) << 24;
-        }
-        log_at += e_tot;
     }
     // statistic: 16-byte blocks walked (what the automatic kernel choice reads)
 #pragma unroll
@@ -356,16 +365,8 @@ __global__ __launch_bounds__(kEmitThreads) void k_chain_emit(DevAutomaton A, Bat
         const uint64_t first_item = t * T.R;
         const Piece pa = chain_piece(A, B, T, total_items, first_item, 2u * lane), pz = chain_piece(A, B, T, total_items, first_item, 2u * lane + 1u);
         uint64_t at = T.rec_base[first_item];
-        // two rounds of 64 events at a time: a round is three dependent round trips (the event, its state's output head, the store),
-        // and only the running sum ties one round to the next
-        auto fetch = [&](uint32_t e0, uint32_t &ent, uint2 &hd, uint32_t &c) __attribute__((always_inline)) {
-            const bool valid = e0 + lane < info.y;
-            ent = valid ? ev[e0 + lane] : 0u;
-            hd = make_uint2(0u, 0u);
-            if (valid) hd = A.chain_head[ent & 0x7FFFu];
-            c = valid ? hd.x >> 24 : 0u;
-            if (c == 255u) c = A.out_count[A.chain_orig[ent & 0x7FFFu]];
-        };
+        // four rounds of 64 events at a time: a round is three dependent round trips (the event, its state's output head, the store),
+        // and only the running sum ties one round to the next -- the rounds' loads are issued together, kind by kind
         auto place = [&](uint32_t ent, uint2 hd, uint32_t c) __attribute__((always_inline)) {
             const uint32_t idx = ent & 0x7FFFu, piece = (ent >> 24) & 127u, owner = piece >> 1;
             const uint32_t ba = uint32_t(__shfl(int(pa.pos_bias), int(owner), 64)), bz = uint32_t(__shfl(int(pz.pos_bias), int(owner), 64));
@@ -393,13 +394,21 @@ __global__ __launch_bounds__(kEmitThreads) void k_chain_emit(DevAutomaton A, Bat
             at += uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
         };
 #pragma unroll 1
-        for (uint32_t e0 = 0; e0 < info.y; e0 += 128u) {
-            uint32_t ent0, ent1, c0, c1;
-            uint2 hd0, hd1;
-            fetch(e0, ent0, hd0, c0);
-            fetch(e0 + 64u, ent1, hd1, c1);
-            place(ent0, hd0, c0);
-            if (e0 + 64u < info.y) place(ent1, hd1, c1);
+        for (uint32_t e0 = 0; e0 < info.y; e0 += 256u) {
+            uint32_t ent[4], c[4];
+            uint2 hd[4];
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; ++i) ent[i] = e0 + 64u * i + lane < info.y ? ev[e0 + 64u * i + lane] : 0xFFFFFFFFu;
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; ++i) hd[i] = ent[i] != 0xFFFFFFFFu ? A.chain_head[ent[i] & 0x7FFFu] : make_uint2(0u, 0u);
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; ++i) {
+                c[i] = hd[i].x >> 24;   // (no event: 0 -- an entry of all ones is none: piece 127 has no byte 511)
+                if (c[i] == 255u) c[i] = A.out_count[A.chain_orig[ent[i] & 0x7FFFu]];
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; ++i)
+                if (e0 + 64u * i < info.y) place(ent[i], hd[i], c[i]);
         }
     }
 }
