@@ -866,9 +866,10 @@ def _spawn(args):
     return subprocess.call(cmd, env=env)
 
 
-def _c_abi_gather_check(torch, dist, api, batch, res, rank, world, dev, d_blob, d_off, nh, expect_total):
-    """One all-gatherv of a step's match arrays through the C ABI's own communicator (acmi_comm_*: RCCL bound by
-    libacmi.so; the id travels over the process group): the library-level exchange a non-Python host would use."""
+def _c_abi_steps(torch, dist, api, batch, res, rank, world, dev, d_blob, hay_len, nh, expect_total, steps):
+    """K steps whose exchange is the C ABI's own (acmi_comm_allgather_result: RCCL bound by libacmi.so itself -- what a non-Python
+    host would call; the id travels over the process group): scan, then the all-gatherv of the match arrays, one after the other
+    (the C call is synchronous), timed like the torch.distributed steps: barrier + synchronize on both sides, MAX over ranks."""
     import ctypes as C
     from php_aho_corasick_amd import _native as N
     ident = torch.zeros(128, dtype=torch.uint8, device=dev if dist.get_backend() == "nccl" else "cpu")
@@ -880,15 +881,23 @@ def _c_abi_gather_check(torch, dist, api, batch, res, rank, world, dev, d_blob, 
     raw = (C.c_char * 128).from_buffer_copy(ident.cpu().numpy().tobytes())
     comm = C.c_void_p()
     N.check(N.lib.acmi_comm_create(res._h, rank, world, raw, C.byref(comm)), res._h)
-    total = batch.match_device(res, d_blob, d_off, True)
     dp, dr, nr, nhg = C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_uint64()
-    ms = []
-    for _ in range(3):
-        torch.cuda.synchronize()
-        dist.barrier()
-        t0 = time.perf_counter()
+
+    def step():
+        batch.match_device_begin_uniform(res, d_blob, hay_len, nh, True)
+        total = batch.match_device_end(res)
         N.check(N.lib.acmi_comm_allgather_result(comm, res._h, nh, C.byref(dp), C.byref(dr), C.byref(nr), C.byref(nhg)), res._h)
-        ms.append((time.perf_counter() - t0) * 1e3)
+        return total
+    total = step()   # (warm-up: the communicator's buffers)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        total = step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     v = C.c_double()
     stat = {}
     for key in ("backend_ranks", "transport", "rounds", "bytes_sent", "bytes_received"):
@@ -896,7 +905,45 @@ def _c_abi_gather_check(torch, dist, api, batch, res, rank, world, dev, d_blob, 
         stat[key] = int(v.value)
     ok = nr.value == expect_total * world and nhg.value == nh * world and total == expect_total
     N.lib.acmi_comm_destroy(comm)
-    return {"ok": bool(ok), "ms": round(min(ms), 3), "records": int(nr.value), "haystacks": int(nhg.value), **stat}
+    return {"ok": bool(ok), "steps": steps, "ms_per_step": round(float(dt.item()) / steps * 1e3, 4), "records": int(nr.value), "haystacks": int(nhg.value), **stat}
+
+
+def _config3_sharded(torch, dist, api, batch, synth, rank, world, dev, backend, steps=3):
+    """BASELINE configs[3] next to the headline line of an N > 1 run: the 65,536-pattern set over 2^16 haystacks x 4 KiB per rank
+    (256 MiB), sharded like the headline (contiguous haystack ranges, replicated automaton, all-gatherv of the match arrays);
+    every plant of the tile checked on every rank, the gathered arrays against the shards' counts."""
+    wl = Workload("config3", synth)
+    res = api.ahocorasick_init(wl.patterns())
+    api.ahocorasick_finalize(res)
+    nh = 1 << 16
+    reps = nh // wl.tile_h
+    d_blob = torch.from_numpy(wl.ds.hay_blob).to(dev).repeat(reps).contiguous()
+    batch.bind_current_stream(res)
+    gatherer = batch.RecordGatherer(None, dev, capacity=nh + nh // 8, depth=2)
+
+    def step():
+        batch.match_device_begin_uniform(res, d_blob, wl.hay_len, nh, True)
+        total = batch.match_device_end(res)
+        return total, gatherer.finish(gatherer.start(batch.result_view(res, total), nh, rank * nh))
+    total, got = step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        total, got = step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    prefix, rec = batch.result_numpy(res, nh, total)
+    ok, _tile = wl.check(prefix, rec, nh, total)
+    ok = ok and int(got[1].shape[0]) == total * world and int(got[0].shape[0]) - 1 == nh * world
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    api.ahocorasick_deinit(res)
+    t = float(dt.item()) / steps
+    return {"workload": f"{wl.label} over {nh} haystacks x {wl.hay_len} B per rank, {world} ranks ({backend})", "check_ok": bool(flag.item()),
+            "ms_per_step": round(t * 1e3, 4), "haystack_GB_per_s": round(world * nh * wl.hay_len / t / 1e9, 1), "records_per_step": int(got[1].shape[0])}
 
 
 def main():
@@ -1191,29 +1238,39 @@ def main():
                          "sclk_mhz_start": clocks_start, "sclk_mhz_end": clocks_end},
             "cpu_baseline": cpu1, "cpu_baseline_all_cores": cpu_all,
         }
-    # N > 1 over RCCL: one more exchange of the same step's result, untimed, through the C ABI's own communicator (acmi_comm_*:
-    # RCCL bound by libacmi.so itself).  By default at N = 2 only (ACMI_BENCH_C_ABI=1: at every N, 0: never): it is the first
-    # place this transport meets several GPUs, and a fault in it must not cost a scaling run more than one of its points.  A
-    # call that does not return is ended by a watchdog AFTER rank 0 has printed the measured line.
-    want_c_abi = os.environ.get("ACMI_BENCH_C_ABI", "auto")
-    if world > 1 and backend == "nccl" and not args.no_c_abi_gather and (want_c_abi == "1" or (want_c_abi == "auto" and world == 2)):
-        import threading
+    # N > 1: behind the timed steps (whose exchange is torch.distributed's), the same steps with the C ABI's own exchange
+    # (acmi_comm_*: RCCL bound by libacmi.so itself -- what a PHP host would call), timed, at every N; then BASELINE configs[3] for
+    # a few steps.  Both behind a watchdog: rank 0 prints the measured line if either does not return (ACMI_BENCH_C_ABI=0: neither).
+    if world > 1 and os.environ.get("ACMI_BENCH_C_ABI", "1") != "0":
         done = threading.Event()
 
         def watchdog():
-            if not done.wait(120):
+            if not done.wait(180):
                 if rank == 0:
-                    out["ranks"]["c_abi_exchange"] = {"ok": False, "error": "acmi_comm_allgather_result did not return within 120 s"}
+                    out["ranks"].setdefault("c_abi_exchange", {"ok": False, "error": "did not return within 180 s"})
                     print(_result_line(out, {}, {}), flush=True)
                 os._exit(0 if rank == 0 else 3)
         threading.Thread(target=watchdog, daemon=True).start()
-        try:
-            c_abi = _c_abi_gather_check(torch, dist, api, batch, res, rank, world, dev, d_blob, d_off, nh, records_per_step)
-        except Exception as e:  # reported, not fatal: the timed figure stands on the torch.distributed exchange
-            c_abi = {"ok": False, "error": str(e)[:300]}
-        done.set()
+        if backend == "nccl" and not args.no_c_abi_gather:
+            try:
+                c_abi = _c_abi_steps(torch, dist, api, batch, res, rank, world, dev, d_blob, wl.hay_len, nh, records_per_step, max(1, min(args.steps, 10)))
+            except Exception as e:  # reported, not fatal: the timed figure stands on the torch.distributed exchange
+                c_abi = {"ok": False, "error": str(e)[:300]}
+        else:
+            c_abi = {"ok": None, "skipped": f"backend {backend}: the C ABI's communicator is RCCL, one GPU per rank"}
         if rank == 0:
             out["ranks"]["c_abi_exchange"] = c_abi
+        if args.workload == "headline" and not args.no_legs:
+            del d_blob
+            torch.cuda.empty_cache()
+            try:
+                cfg3 = _config3_sharded(torch, dist, api, batch, synth, rank, world, dev, backend)
+            except Exception as e:
+                cfg3 = {"check_ok": False, "error": str(e)[:300]}
+            if rank == 0:
+                out["config3_sharded"] = cfg3
+            d_blob = None
+        done.set()
     if rank == 0:
         legs = set(x for x in args.legs.split(",") if x)
         want_leg = lambda name: world == 1 and not args.no_legs and (not legs or name in legs)  # noqa: E731
@@ -1232,7 +1289,7 @@ def main():
             run_leg("general_path", general_leg, torch, api, batch, wl.patterns(), d_blob, d_off, nh, records_per_step)
         if want_leg("host_entry") and args.workload == "headline":
             run_leg("host_entry", host_leg, api, synth, ds, tile_count)
-        del d_blob
+        d_blob = None
         torch.cuda.empty_cache()
         if want_leg("short_haystacks"):
             run_leg("short_haystacks", short_haystacks_leg, torch, api, batch, synth, dev)

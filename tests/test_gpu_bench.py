@@ -54,6 +54,22 @@ def test_bench_two_ranks_config3():
 
 
 @pytest.mark.gpu
+def test_bench_two_ranks_c_abi_steps_and_config3_leg():
+    """N > 1 readiness (BASELINE configs[3]): behind the timed steps the line carries the steps whose exchange is the C ABI's own
+    communicator (timed under RCCL; with two gloo ranks on one GPU: named as skipped, RCCL wants a GPU per rank) and a short run of
+    the 65,536-pattern workload sharded over the ranks, checked; the result line stays under 4 KB."""
+    out, line = _bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--haystacks", "16384", "--no-cpu", "--no-dense")
+    assert out.returncode == 0 and line is not None, out.stdout[-2000:] + out.stderr[-3000:]
+    last = out.stdout.rstrip("\n").split("\n")[-1]
+    assert last.startswith("{") and len(last) < 4096
+    assert line["n_gpus"] == 2 and line["check_ok"] is True and line["ranks"]["joined_a_collective"] == 2
+    x = line["ranks"]["c_abi_exchange"]
+    assert x["ok"] is None and "RCCL" in x["skipped"]
+    c3 = line["config3_sharded"]
+    assert c3["check_ok"] is True and c3["records_per_step"] >= 2 * 65536 and c3["ms_per_step"] > 0 and "65,536" in c3["workload"]
+
+
+@pytest.mark.gpu
 def test_bench_one_rank_has_the_contract_fields():
     out, line = _bench("--steps", "3", "--warmup", "1", "--haystacks", "16384", "--no-legs", "--no-dense", backend="nccl")
     assert out.returncode == 0 and line is not None, out.stdout[-2000:] + out.stderr[-3000:]
