@@ -228,6 +228,205 @@ __global__ __launch_bounds__(kSmallThreads) void k_match_small(DevAutomaton A, c
     if (t == 0) __hip_atomic_store(out_summary + 3, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ------------------------------------------------------------------------------------------
+// k_match_small_chain: the same call for a pattern set that carries the chain-compressed image (automaton.hpp ChainImage, k_chain.hip):
+// the WHOLE automaton in LDS.  One 8 KiB haystack is 23 dependent steps of 1,024 lanes (8-byte items + Lmax - 1 bytes of warm-up);
+// with a tile of dense rows the lanes that meet the haystack's occurrence leave the tile and every one of their steps is an L2
+// round trip the whole workgroup waits for (round 4: 19.4 us in the kernel) -- here every step is two LDS reads.  The image takes
+// 130-142 KiB for a few thousand patterns: the per-item arrays are cut to the bone (ONE event kept per item, 12 B per item) and
+// the call falls back to k_match_small when text + items do not fit beside the image.
+// ------------------------------------------------------------------------------------------
+struct SmallChainLayout {
+    uint32_t chunk, max_items, in_off, items_off, hay_off, lds;
+};
+
+static bool small_chain_layout(const DevAutomaton &A, uint32_t span, uint32_t nh, bool table_mode, SmallChainLayout &Y) {
+    if (A.chain_img == nullptr || A.chain_head == nullptr || A.chain_orig == nullptr) return false;
+    const uint32_t img = (A.chain_img_bytes + 15u) & ~15u;
+    const uint32_t in_bytes = (span + 15u) & ~15u;
+    Y.in_off = img + (table_mode ? 512u : 0u);
+    Y.items_off = Y.in_off + in_bytes;
+    for (uint32_t chunk : {8u, 16u, 32u, 64u}) {
+        const uint32_t items = ((span + chunk - 1u) / chunk + nh + 1u) & ~1u;
+        if (items > kSmallMaxItems || (chunk == 8u && items > kSmallThreads + 2u)) continue;
+        const uint32_t hay = Y.items_off + std::max(items, 2u) * 12u;
+        const uint32_t lds = hay + (nh + 8u) * 8u + 64u;
+        if (lds > kSmallLds) continue;
+        Y.chunk = chunk;
+        Y.max_items = std::max(items, 2u);
+        Y.hay_off = hay;
+        Y.lds = lds;
+        return true;
+    }
+    return false;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kSmallThreads) void k_match_small_chain(DevAutomaton A, const uint64_t *offsets, const uint8_t *blob, uint32_t nh, uint32_t find_all,
+                                                                     uint32_t max_pattern_length, uint64_t *out_summary, uint64_t *out_prefix, uint4 *out_records,
+                                                                     uint32_t cap, SmallChainLayout Y, uint64_t seq) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t kChunk = Y.chunk, kItems = Y.max_items;
+    const uint32_t img_bytes = (A.chain_img_bytes + 15u) & ~15u;
+    uint16_t *cls = reinterpret_cast<uint16_t *>(smem + img_bytes);   // 512 B (TABLE mode)
+    uint8_t *in_bytes = smem + Y.in_off;
+    uint32_t *ev0 = reinterpret_cast<uint32_t *>(smem + Y.items_off);   // per item: its first event {index | byte of the item << 15}
+    uint32_t *cnt_ev = ev0 + kItems;
+    uint32_t *cnt_rec = cnt_ev + kItems;
+    uint32_t *item_base = reinterpret_cast<uint32_t *>(smem + Y.hay_off);
+    uint32_t *hay_off = item_base + nh + 8;
+    uint32_t *wave_tmp = hay_off + nh + 8;
+    const uint32_t t = threadIdx.x;
+    const uint64_t t_start = wall_clock64();
+    const bool stamps = (find_all & 2u) != 0u;
+    find_all &= 1u;
+    auto stamp = [&](int i) { if (stamps && t == 0) out_summary[4 + i] = wall_clock64() - t_start; };
+    const uint64_t off0 = offsets[0];
+    for (uint32_t h = t; h <= nh; h += kSmallThreads) hay_off[h] = uint32_t(offsets[h] - off0);
+    __syncthreads();
+    const uint32_t n_bytes = hay_off[nh];
+    for (uint32_t h = t; h < nh + 1u; h += kSmallThreads)
+        item_base[h] = h < nh ? (hay_off[h + 1] - hay_off[h] + kChunk - 1) / kChunk : 0u;
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(blob);
+        uint4 *dst = reinterpret_cast<uint4 *>(in_bytes);
+        for (uint32_t i = t; i < (n_bytes + 15u) / 16u; i += kSmallThreads) dst[i] = src[i];
+        const uint4 *isrc = reinterpret_cast<const uint4 *>(A.chain_img);   // (the allocation has 16 bytes of slack)
+        uint4 *idst = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t i = t; i < (img_bytes >> 4); i += kSmallThreads) idst[i] = isrc[i];
+        if (MODE == 0 && t < 256) cls[t] = A.class_off[t];
+    }
+    __syncthreads();
+    stamp(0);
+    const uint32_t n_items = small_scan(item_base, nh + 1, wave_tmp);
+    stamp(1);
+    const uint32_t n_dense = A.chain_dense, rec_base = A.chain_rec_off - 4u * A.chain_dense, row_bytes = A.n_columns * 2u, cnt_n = A.chain_cnt_n;
+    const uint8_t *cnt = smem + A.chain_cnt_off;
+    // one transition (k_chain.hip chain_step2, one walk): the state's record, then the row entry of the state itself (a D state) or of
+    // its failure state; `u` negative: the new state is final
+    auto step = [&](uint32_t &e, uint32_t byte, uint32_t &u, bool &hit) {
+        const uint32_t coff = class_offset<uint16_t, MODE>(A, cls, byte);
+        const uint32_t r = *reinterpret_cast<const uint32_t *>(smem + ((e << 2) + rec_base));
+        const bool is_d = e < n_dense;
+        const uint32_t f = is_d ? e : (r & 0xFFFFu);
+        const uint32_t tt = uint32_t(int32_t(*reinterpret_cast<const int16_t *>(smem + (f * row_bytes + coff))));
+        hit = !is_d && ((r >> 16) & 0xFFu) == coff;
+        u = hit ? r : tt;
+        e = hit ? e + 1u : (tt & 0x7FFFu);
+    };
+    auto records_of = [&](uint32_t idx, uint32_t u, bool hit) -> uint32_t {
+        const uint32_t code = hit ? (u >> 24) & 31u : 31u;
+        if (code != 31u) return code;
+        if (idx < cnt_n) {
+            const uint32_t c = cnt[idx];
+            if (c != 255u) return c;
+        }
+        const uint32_t c = A.chain_head[idx].x >> 24;
+        return c < 255u ? c : A.out_count[A.chain_orig[idx]];
+    };
+    auto decode = [&](uint32_t i, uint32_t &h, uint32_t &begin, uint32_t &len, uint32_t &warm, uint32_t &pos0) {
+        uint32_t lo = 0, hi = nh;  // item_base[lo] <= i < item_base[hi]
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (item_base[mid] <= i) lo = mid; else hi = mid;
+        }
+        h = lo;
+        pos0 = (i - item_base[h]) * kChunk;
+        begin = hay_off[h] + pos0;
+        const uint32_t rest = hay_off[h + 1] - begin;
+        len = rest < kChunk ? rest : kChunk;
+        const uint32_t wmax = max_pattern_length ? max_pattern_length - 1u : 0u;
+        warm = pos0 < wmax ? pos0 : wmax;
+    };
+    // ---- walk: count events and records per item, keep the first event ----
+    for (uint32_t i = t; i < kItems; i += kSmallThreads) {
+        uint32_t n_ev = 0, n_rec = 0;
+        if (i < n_items) {
+            uint32_t h, begin, len, warm, pos0;
+            decode(i, h, begin, len, warm, pos0);
+            uint32_t e = 0;
+            const uint8_t *p = in_bytes + begin - warm;
+            const uint32_t n = warm + len;
+            auto one = [&](uint32_t byte, uint32_t j) {
+                uint32_t u;
+                bool hit;
+                step(e, byte, u, hit);
+                if (j >= warm && int32_t(u) < 0) {
+                    n_rec += records_of(e, u, hit);
+                    if (n_ev == 0u) ev0[i] = e | (j - warm) << 15;
+                    ++n_ev;
+                }
+            };
+            uint32_t j = 0;
+            for (; j + 4u <= n; j += 4u) {
+                const uint32_t b0 = p[j], b1 = p[j + 1u], b2 = p[j + 2u], b3 = p[j + 3u];
+                one(b0, j); one(b1, j + 1u); one(b2, j + 2u); one(b3, j + 3u);
+            }
+            for (; j < n; ++j) one(p[j], j);
+        }
+        cnt_ev[i] = n_ev;
+        cnt_rec[i] = n_rec;
+    }
+    __syncthreads();
+    stamp(2);
+    // ---- findAll == false: only the first event of each haystack (php_ahocorasick.c:588) ----
+    if (!find_all) {
+        for (uint32_t h = t; h < nh; h += kSmallThreads) {
+            bool found = false;
+            for (uint32_t i = item_base[h]; i < item_base[h + 1]; ++i) {
+                if (found) { cnt_ev[i] = 0; cnt_rec[i] = 0; }
+                else if (cnt_ev[i]) {
+                    found = true;
+                    cnt_ev[i] = 1;
+                    const uint32_t idx = ev0[i] & 0x7FFFu;
+                    const uint32_t c = A.chain_head[idx].x >> 24;
+                    cnt_rec[i] = c < 255u ? c : A.out_count[A.chain_orig[idx]];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const uint32_t total = small_scan(cnt_rec, kItems, wave_tmp);  // cnt_rec[i] = first record of item i
+    for (uint32_t h = t; h <= nh; h += kSmallThreads)
+        out_prefix[h] = (h < nh && item_base[h] < kItems) ? cnt_rec[item_base[h]] : total;
+    if (t == 0) { out_summary[0] = total; out_summary[1] = n_items; out_summary[2] = total > cap ? 1u : 0u; }
+    stamp(3);
+    if (total > cap) {
+        __threadfence_system();
+        __syncthreads();
+        if (t == 0) __hip_atomic_store(out_summary + 3, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    // ---- records ----
+    for (uint32_t i = t; i < n_items; i += kSmallThreads) {
+        const uint32_t n_ev = cnt_ev[i];
+        if (n_ev == 0) continue;
+        uint32_t h, begin, len, warm, pos0;
+        decode(i, h, begin, len, warm, pos0);
+        uint64_t w = cnt_rec[i];
+        if (n_ev == 1u) {
+            // (an event of one record -- most -- from the index's own output head: one load, not state id -> head)
+            const uint32_t ent = ev0[i], idx = ent & 0x7FFFu, pos = pos0 + (ent >> 15) + 1u;
+            const uint2 hd = A.chain_head[idx];
+            if ((hd.x >> 24) == 1u) out_records[w] = make_uint4(h, pos, pos - hd.y, hd.x & 0xFFFFFFu);
+            else (void)emit_event(A, out_records, w, h, pos, A.chain_orig[idx]);
+        } else {  // more than one event: the item is walked again, writing records straight to their slots
+            uint32_t e = 0;
+            const uint8_t *p = in_bytes + begin - warm;
+            for (uint32_t j = 0; j < warm + len; ++j) {
+                uint32_t u;
+                bool hit;
+                step(e, p[j], u, hit);
+                if (j >= warm && int32_t(u) < 0) w = emit_event(A, out_records, w, h, pos0 + (j - warm) + 1u, A.chain_orig[e]);
+            }
+        }
+    }
+    stamp(4);
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(out_summary + 3, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 bool small_trace() {
     static const bool on = std::getenv("ACMI_SMALL_TRACE") != nullptr;
     return on;
@@ -236,6 +435,19 @@ bool small_trace() {
 hipError_t launch_match_small(const DevAutomaton &A, const uint64_t *offsets, const uint8_t *blob, uint32_t nh, int find_all,
                               uint32_t max_pattern_length, int entry_bytes, int class_mode, uint64_t *out_summary,
                               uint64_t *out_prefix, void *out_records, uint32_t cap, uint32_t span_bytes, uint64_t seq, hipStream_t st) {
+    static const bool no_chain = [] { const char *e = std::getenv("ACMI_SMALL_CHAIN"); return e && e[0] == '0'; }();
+    SmallChainLayout YC{};
+    // the whole automaton in LDS when the set carries the chain-compressed image and the batch fits beside it (one 8 KiB haystack does)
+    if (!no_chain && A.trap + 1u < A.n_states && small_chain_layout(A, span_bytes, nh, class_mode == 0, YC)) {
+        auto goc = [&](auto fn) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(kSmallLds));
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(fn, dim3(1), dim3(kSmallThreads), YC.lds, st, A, offsets, blob, nh, uint32_t(find_all ? 1 : 0) | (small_trace() ? 2u : 0u),
+                               max_pattern_length, out_summary, out_prefix, static_cast<uint4 *>(out_records), cap, YC, seq);
+            return hipGetLastError();
+        };
+        return class_mode == 1 ? goc(k_match_small_chain<1>) : goc(k_match_small_chain<0>);
+    }
     const SmallLayout Y = small_layout(span_bytes, nh, A.trap * A.row_bytes, class_mode == 0);
     const uint32_t lds = Y.in_bytes + Y.tile_bytes + Y.max_items * (kSmallEvents * 8u + 8u) + (kSmallMaxHay + 8u) * 8u + 64u + 512u;
     auto go = [&](auto fn) {
