@@ -312,6 +312,15 @@ static void build_chain_image(FlatAutomaton &fa, uint32_t budget, uint32_t ns, c
             recs[k - n_dense] = idx[fail_b[i]] | key << 16 | code << 24;
         }
     }
+    // final indices by rank (every index's head is in `head`; the ranked copy is what fits an LDS next to nothing else)
+    ci.frank.assign(ns, uint16_t(0xFFFF));
+    ci.fhead.clear();
+    for (uint32_t k = 0; k < ns; ++k) {
+        if ((ci.head[size_t(k) * 2] >> 24) == 0u) continue;
+        ci.frank[k] = uint16_t(ci.fhead.size() / 2);
+        ci.fhead.push_back(ci.head[size_t(k) * 2]);
+        ci.fhead.push_back(ci.head[size_t(k) * 2 + 1]);
+    }
 }
 
 bool Automaton::finalize(const BuildOptions &opt, std::string *error, const BuildAccel *accel) {

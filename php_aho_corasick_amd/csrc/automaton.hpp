@@ -74,6 +74,10 @@ struct ChainImage {
     std::vector<uint8_t> image;
     std::vector<uint32_t> head;   // 2 words per index: {first (longest) pattern | min(records, 255) << 24, its length} (out_head's form)
     std::vector<uint32_t> orig;   // per index: the state id of the other tables
+    // the same heads for an LDS that has no room for 8 bytes per index (k_chain_emit): rank of every final index among the final
+    // ones (0xFFFF: not final), and the heads by rank
+    std::vector<uint16_t> frank;
+    std::vector<uint32_t> fhead;  // 2 words per final index, in index order
     bool present() const { return !image.empty(); }
 };
 
@@ -296,6 +300,8 @@ public:
         std::vector<uint8_t>().swap(flat_.chain.image);
         std::vector<uint32_t>().swap(flat_.chain.head);
         std::vector<uint32_t>().swap(flat_.chain.orig);
+        std::vector<uint16_t>().swap(flat_.chain.frank);
+        std::vector<uint32_t>().swap(flat_.chain.fhead);
         host_tables_released_ = true;
     }
     bool host_tables_released() const { return host_tables_released_; }

@@ -35,6 +35,9 @@ struct DevAutomaton {
     uint32_t chain_img_bytes, chain_dense, chain_index, chain_rec_off, chain_cnt_off, chain_cnt_n;
     const uint2 *chain_head;     // per index: {first pattern | min(records, 255) << 24, its length}
     const uint32_t *chain_orig;  // per index: state id
+    const uint16_t *chain_frank; // per index: rank among the final indices (0xFFFF: not final) ...
+    const uint2 *chain_fhead;    // ... and the heads by rank (what k_chain_emit stages into LDS)
+    uint32_t chain_finals;
     const uint8_t *pad16;        // 16 readable bytes: where unconditional loads of lanes with nothing to load go
     uint32_t shallow_hot, shallow_cold_end;  // non-final states of trie depth <= 2: [0,shallow_hot), (trap,shallow_cold_end)
     uint32_t early_stop;         // 1: walks of anchor candidates stop on them (run_epilogue)

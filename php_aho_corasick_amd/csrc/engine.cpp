@@ -329,6 +329,11 @@ int ensure_device(acmi_handle *h) {
         HIPCHK(h, copy_h2d(h->d_chain_head.p, ci.head.data(), ci.head.size() * 4));
         HIPCHK(h, h->d_chain_orig.ensure(ci.orig.size() * 4));
         HIPCHK(h, copy_h2d(h->d_chain_orig.p, ci.orig.data(), ci.orig.size() * 4));
+        HIPCHK(h, h->d_chain_frank.ensure(ci.frank.size() * 2 + 16));
+        HIPCHK(h, copy_h2d(h->d_chain_frank.p, ci.frank.data(), ci.frank.size() * 2));
+        HIPCHK(h, h->d_chain_fhead.ensure(ci.fhead.size() * 4 + 16));
+        if (!ci.fhead.empty()) HIPCHK(h, copy_h2d(h->d_chain_fhead.p, ci.fhead.data(), ci.fhead.size() * 4));
+        h->chain_finals = uint32_t(ci.fhead.size() / 2);
     }
 
     if (fa.anchor_q) {
@@ -406,6 +411,9 @@ int ensure_device(acmi_handle *h) {
     A.chain_cnt_n = fa.chain.cnt_n;
     A.chain_head = fa.chain.present() ? h->d_chain_head.as<uint2>() : nullptr;
     A.chain_orig = fa.chain.present() ? h->d_chain_orig.as<uint32_t>() : nullptr;
+    A.chain_frank = fa.chain.present() ? h->d_chain_frank.as<uint16_t>() : nullptr;
+    A.chain_fhead = fa.chain.present() ? h->d_chain_fhead.as<uint2>() : nullptr;
+    A.chain_finals = fa.chain.present() ? h->chain_finals : 0u;
     A.pad16 = h->d_class.as<uint8_t>();  // (512 bytes, always present)
     A.shallow_hot = fa.shallow_hot;
     A.shallow_cold_end = fa.shallow_cold_end;
@@ -514,7 +522,7 @@ int acmi_destroy(acmi_handle *h) {
         if (h->dev_touched) {  // also after a failed upload: release whatever was created
             (void)hipSetDevice(h->dev_id);
             if (h->stream) (void)hipStreamSynchronize(h->stream);
-            for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_out_off, &h->d_out_list, &h->d_out_head, &h->d_cold_rec, &h->d_cold_edges, &h->d_chain_byte, &h->d_chain_run, &h->d_chain_img, &h->d_chain_head, &h->d_chain_orig, &h->d_slot_pair, &h->d_pairs, &h->d_pat_bytes, &h->d_dense_img, &h->d_merge_counts, &h->d_merge_sync, &h->d_rep_off, &h->d_rep_bytes, &h->d_plan, &h->d_plan_out, &h->d_tail_out, &h->d_rep_sync, &h->d_nom_count, &h->d_out_len, &h->d_rep_out_off, &h->d_rep_out, &h->d_blob,
+            for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_out_off, &h->d_out_list, &h->d_out_head, &h->d_cold_rec, &h->d_cold_edges, &h->d_chain_byte, &h->d_chain_run, &h->d_chain_img, &h->d_chain_head, &h->d_chain_orig, &h->d_chain_frank, &h->d_chain_fhead, &h->d_slot_pair, &h->d_pairs, &h->d_pat_bytes, &h->d_dense_img, &h->d_merge_counts, &h->d_merge_sync, &h->d_rep_off, &h->d_rep_bytes, &h->d_plan, &h->d_plan_out, &h->d_tail_out, &h->d_rep_sync, &h->d_nom_count, &h->d_out_len, &h->d_rep_out_off, &h->d_rep_out, &h->d_blob,
                               &h->d_off, &h->d_sync[0], &h->d_sync[1], &h->d_item_base[0], &h->d_item_hay[0], &h->d_item_rec[0], &h->d_zero[0], &h->d_isync[0],
                               &h->d_item_base[1], &h->d_item_hay[1], &h->d_item_rec[1], &h->d_zero[1], &h->d_isync[1],
                               &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_first, &h->d_tile_queue, &h->d_tile_sync, &h->d_chain_log, &h->d_chain_tiles, &h->d_uni_off[0], &h->d_uni_off[1], &h->fly[0].d_prefix, &h->fly[0].d_out, &h->fly[1].d_prefix, &h->fly[1].d_out, &h->d_runs, &h->d_run_count})

@@ -115,6 +115,7 @@ struct acmi_handle {
     int tile_w = 0, tile_p = 0;   // k_walk_tiles: bytes per lane / lanes per item (0: tiles_geometry chooses)
     int reserve_cus = 0;          // compute units the persistent scan kernels leave free (a collective's kernels need some while a scan runs)
     int chain_walk = -1;          // kernel 6 over the chain-compressed LDS image where the set has one: -1 / 1 yes, 0 never (k_walk_tiles)
+    uint32_t chain_finals = 0;    // final indices of the chain image (k_chain_emit's LDS table)
     bool chain_used = false;      // ... the last batch did ("chain_walk_used")
     int rerun_kernel = -1;        // >= 0 while a batch is enqueued AGAIN: the kernel of its first run (enqueue_batch takes it, no probe, nothing learned)
     int part_kernel = -1;         // split sets: the kernel forced on the SHORT part (-1: its own automatic choice)
@@ -173,7 +174,7 @@ struct acmi_handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     DevAutomaton dA{};
-    DevBuf d_table, d_lds, d_class, d_own, d_dict, d_cnt, d_plen, d_anchor, d_bitmap, d_out_off, d_out_list, d_out_head, d_cold_rec, d_cold_edges, d_chain_byte, d_chain_run, d_chain_img, d_chain_head, d_chain_orig, d_slot_pair, d_pairs, d_pat_bytes, d_dense_img;
+    DevBuf d_table, d_lds, d_class, d_own, d_dict, d_cnt, d_plen, d_anchor, d_bitmap, d_out_off, d_out_list, d_out_head, d_cold_rec, d_cold_edges, d_chain_byte, d_chain_run, d_chain_img, d_chain_head, d_chain_orig, d_chain_frank, d_chain_fhead, d_slot_pair, d_pairs, d_pat_bytes, d_dense_img;
 
     // workspace (grow-only)
     DevBuf d_blob, d_off, d_rec_base, d_slab, d_ovf, d_counters, d_runs, d_run_count, d_first;

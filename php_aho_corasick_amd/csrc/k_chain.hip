@@ -351,8 +351,24 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
 // distribution over the pieces -- position ascending, an event's records longest pattern first (node.c:424-441) by construction,
 // and an event of one record (most) is one of 64 consecutive 16-byte stores.  What an event needs of its piece (haystack, the
 // position of its first byte) comes from the lane that would have walked it.
-constexpr uint32_t kEmitThreads = 256;
+constexpr uint32_t kEmitThreads = 1024;
 __global__ __launch_bounds__(kEmitThreads) void k_chain_emit(DevAutomaton A, BatchArgs B, ChainArgs T) {
+    // LDS: every final index's output head, found through its rank -- 2 bytes per index + 8 per final state: a few thousand patterns
+    // take 60-90 KiB, two workgroups a CU.  (From global memory an event's head was an L2 request of its own: 119 M of them a GiB
+    // of prose under a word list, 0.4 of the L2's request rate, 1.0 ms for 1.9 GB of records.)
+    // (T.debug != 0 here: the table does not fit -- a set with very many final states -- and the heads come from global memory)
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const bool in_lds = T.debug == 0u;
+    const uint32_t rank_bytes = (A.chain_index * 2u + 15u) & ~15u;
+    uint16_t *const frank = reinterpret_cast<uint16_t *>(smem);
+    uint2 *const fhead = reinterpret_cast<uint2 *>(smem + rank_bytes);
+    if (in_lds) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(A.chain_frank);   // (both allocations carry 16 bytes of slack)
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t i = threadIdx.x; i < (rank_bytes >> 4); i += kEmitThreads) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < A.chain_finals; i += kEmitThreads) fhead[i] = A.chain_fhead[i];
+        __syncthreads();
+    }
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t total_items = B.item_base[B.n_haystacks];
     const uint64_t tiles_all = (total_items + T.R - 1u) / T.R;
@@ -400,7 +416,8 @@ __global__ __launch_bounds__(kEmitThreads) void k_chain_emit(DevAutomaton A, Bat
 #pragma unroll
             for (uint32_t i = 0; i < 4u; ++i) ent[i] = e0 + 64u * i + lane < info.y ? ev[e0 + 64u * i + lane] : 0xFFFFFFFFu;
 #pragma unroll
-            for (uint32_t i = 0; i < 4u; ++i) hd[i] = ent[i] != 0xFFFFFFFFu ? A.chain_head[ent[i] & 0x7FFFu] : make_uint2(0u, 0u);
+            for (uint32_t i = 0; i < 4u; ++i)
+                hd[i] = ent[i] == 0xFFFFFFFFu ? make_uint2(0u, 0u) : in_lds ? fhead[frank[ent[i] & 0x7FFFu]] : A.chain_head[ent[i] & 0x7FFFu];
 #pragma unroll
             for (uint32_t i = 0; i < 4u; ++i) {
                 c[i] = hd[i].x >> 24;   // (no event: 0 -- an entry of all ones is none: piece 127 has no byte 511)
@@ -415,7 +432,7 @@ __global__ __launch_bounds__(kEmitThreads) void k_chain_emit(DevAutomaton A, Bat
 
 // Does this automaton have the image, and does the kernel's LDS layout hold it?
 bool chain_walk_ok(const DevAutomaton &A) {
-    if (A.chain_img == nullptr || A.chain_head == nullptr) return false;
+    if (A.chain_img == nullptr || A.chain_head == nullptr || A.chain_frank == nullptr) return false;
     const uint32_t img = (A.chain_img_bytes + 15u) & ~15u;
     return img + 512u + kChainWaves * kChainLaneCap * 256u <= 160u * 1024u;
 }
@@ -470,8 +487,13 @@ hipError_t launch_chain_emit(const DevAutomaton &A, const BatchArgs &B, uint64_t
     T.out = static_cast<uint4 *>(out);
     T.cap = cap;
     const uint64_t tiles = chain_tiles(max_items, P);
-    const uint32_t blocks = uint32_t(std::min<uint64_t>((tiles + 3u) / 4u, uint64_t(num_cus()) * 16u));
-    hipLaunchKernelGGL(k_chain_emit, dim3(blocks), dim3(kEmitThreads), 0, st, A, B, T);
+    uint32_t lds = ((A.chain_index * 2u + 15u) & ~15u) + A.chain_finals * 8u;
+    if (lds > 160u * 1024u) { lds = 0; T.debug = 1u; }   // (a set with very many final states: the heads from global memory)
+    const uint32_t per_cu = lds <= 80u * 1024u ? 2u : 1u;
+    const uint32_t blocks = uint32_t(std::min<uint64_t>((tiles + 15u) / 16u, uint64_t(num_cus()) * per_cu));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_chain_emit), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_chain_emit, dim3(blocks), dim3(kEmitThreads), lds, st, A, B, T);
     return hipGetLastError();
 }
 
