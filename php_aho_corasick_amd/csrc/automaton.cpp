@@ -222,11 +222,16 @@ static void build_chain_image(FlatAutomaton &fa, uint32_t budget, uint32_t ns, c
     // (a failure state and a parent lie before their state in BFS order: one backward pass closes both)
     std::vector<uint8_t> in_d(ns, 0);
     in_d[0] = 1;
-    for (uint32_t i = 0; i < ns; ++i)
-        if (cfirst[i + 1] - cfirst[i] >= 2u) in_d[i] = 1;
-    for (uint32_t i = ns; i-- > 1;) {
-        if (in_d[i]) in_d[parent_pos[i]] = 1;
-        else in_d[fail_b[i]] = 1;
+    if (uint64_t(ns) * (row_bytes + 1u) + 4u <= budget) {
+        // (every state's row fits: all of them D states -- a step is then ONE read, k_walk_chain's ALLD form)
+        std::fill(in_d.begin(), in_d.end(), uint8_t(1));
+    } else {
+        for (uint32_t i = 0; i < ns; ++i)
+            if (cfirst[i + 1] - cfirst[i] >= 2u) in_d[i] = 1;
+        for (uint32_t i = ns; i-- > 1;) {
+            if (in_d[i]) in_d[parent_pos[i]] = 1;
+            else in_d[fail_b[i]] = 1;
+        }
     }
     // (position i is only ever marked from positions behind it, all of them visited before it: its mark is final when it is read)
     uint32_t n_dense = 0;
@@ -254,6 +259,7 @@ static void build_chain_image(FlatAutomaton &fa, uint32_t budget, uint32_t ns, c
     for (uint32_t i = 1; i < ns && !any_row_final; ++i)
         if (final_b[i] && in_d[parent_pos[i]]) any_row_final = true;
     if (!any_row_final) cnt_n = 0;
+    if (n_dense == ns) cnt_n = ns;   // (all rows: every final state is entered through a row)
     const uint64_t rec_off = rows_bytes, cnt_off = rec_off + uint64_t(ns - n_dense) * 4u;
     const uint64_t total = (cnt_off + cnt_n + 3u) & ~uint64_t(3);
     if (total > budget) return;
@@ -674,9 +680,9 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
         }
     }
     lap("rows, records, output lists");
-    // the whole automaton for the LDS -- unless every state's dense row fits there anyway (the kernels then walk those)
+    // the whole automaton for the LDS (k_walk_chain): chain-compressed, or -- a small one -- all of its rows
     fa.chain = ChainImage{};
-    if (uint64_t(fa.trap) + 1u < fa.n_states) build_chain_image(fa, opt.chain_bytes, ns, cfirst, parent_pos, byte_b, fail_b, final_b, cnt_b, newid);
+    build_chain_image(fa, opt.chain_bytes, ns, cfirst, parent_pos, byte_b, fail_b, final_b, cnt_b, newid);
     lap("chain image");
 
     // ---- anchor filter table -------------------------------------------------------------------

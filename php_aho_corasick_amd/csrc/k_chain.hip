@@ -63,7 +63,19 @@ struct ChainLds {
 // One transition of two independent walks: their reads issued together (the records', then the rows'), so that one's LDS round
 // trips lie under the other's.  `ca`, `cz` = 2 x class of the bytes.  Through `ea`, `ez` the next indices; `ua`, `uz` negative: that
 // state is final (`ha`, `hz`: it was entered along its chain, bits 24..28 are min(its records, 31)).
+template <bool ALLD>
 __device__ __forceinline__ void chain_step2(const ChainLds &L, uint32_t &ea, uint32_t &ez, uint32_t ca, uint32_t cz, uint32_t &ua, uint32_t &uz, bool &ha, bool &hz) {
+    if constexpr (ALLD) {   // (every state has its row: one read, no record, no chain)
+        uint32_t aa, az;
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(aa) : "v"(ea), "s"(L.row_bytes), "v"(ca));
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(az) : "v"(ez), "s"(L.row_bytes), "v"(cz));
+        ua = uint32_t(int32_t(*reinterpret_cast<const __attribute__((address_space(3))) int16_t *>(aa)));
+        uz = uint32_t(int32_t(*reinterpret_cast<const __attribute__((address_space(3))) int16_t *>(az)));
+        ha = hz = false;
+        ea = ua & 0x7FFFu;
+        ez = uz & 0x7FFFu;
+        return;
+    }
     const uint32_t ra = *reinterpret_cast<const uint32_t *>(L.img + ((ea << 2) + L.rec_base));
     const uint32_t rz = *reinterpret_cast<const uint32_t *>(L.img + ((ez << 2) + L.rec_base));
     const bool da = ea < L.n_dense, dz = ez < L.n_dense;
@@ -135,7 +147,7 @@ __device__ __forceinline__ uint32_t chain_count(const DevAutomaton &A, uint32_t 
     return c < 255u ? c : A.out_count[A.chain_orig[e]];
 }
 
-template <int MODE>
+template <int MODE, bool ALLD>
 __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, BatchArgs B, ChainArgs T) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -217,7 +229,7 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
                     const uint32_t j = jj + i;
                     uint32_t ua, uz;
                     bool ha, hz;
-                    chain_step2(L, ea, ez, ca[i], cz[i], ua, uz, ha, hz);
+                    chain_step2<ALLD>(L, ea, ez, ca[i], cz[i], ua, uz, ha, hz);
                     if (W0) { ea = j < pa.start_j ? 0u : ea; ez = j < pz.start_j ? 0u : ez; }
                     // (rep_lo >= start_j: nothing before a walk's first byte reports)
                     const bool va = int32_t(ua) < 0 && (!C || j - pa.rep_lo < pa.rep_len);
@@ -476,7 +488,9 @@ hipError_t launch_walk_chain(const DevAutomaton &A, const BatchArgs &B, uint64_t
         hipLaunchKernelGGL(fn, dim3(chain_grid()), dim3(kChainThreads), lds, st, A, B, T);
         return hipGetLastError();
     };
-    return class_mode == 1 ? go(k_walk_chain<1>) : go(k_walk_chain<0>);
+    const bool alld = A.chain_dense == A.chain_index;
+    if (alld) return class_mode == 1 ? go(k_walk_chain<1, true>) : go(k_walk_chain<0, true>);
+    return class_mode == 1 ? go(k_walk_chain<1, false>) : go(k_walk_chain<0, false>);
 }
 
 hipError_t launch_chain_emit(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, uint32_t W, uint32_t P, const ChainBuffers &C,
