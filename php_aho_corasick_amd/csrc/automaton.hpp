@@ -49,8 +49,8 @@ struct BuildOptions {
                                             // and further BFS-first states up to this many bytes of rows
     uint64_t max_flat_outputs = 1ull << 25; // flat output lists up to this many entries (256 MiB), else dictionary links only
     // chain-compressed image of the WHOLE automaton for LDS (ChainImage): built when it fits this many bytes -- a CU's 160 KiB less
-    // the walk kernel's event lists (16 KiB), the byte classes (512 B) and its static shared variables; 0 = never
-    uint32_t chain_bytes = 160 * 1024 - 16 * 1024 - 512 - 256;
+    // the byte classes (512 B) and a little slack; 0 = never
+    uint32_t chain_bytes = 160 * 1024 - 512 - 256;
 };
 
 // The whole automaton in a form that fits the LDS of one CU where dense rows for every state do not (k_chain.hip k_walk_chain):

@@ -649,7 +649,7 @@ static int apply_option(acmi_handle *h, const std::string &k, int64_t value) {
             h->chain_walk = int(value);
         } else if (k == "chain_bytes") {   // budget of the chain-compressed LDS image of the whole automaton (0: none is built)
             if (h->aut.finalized()) return ACMI_E_FINALIZED;
-            if (value < 0 || value > 160 * 1024 - 16 * 1024 - 512 - 256) return ACMI_E_ARG;
+            if (value < 0 || value > 160 * 1024 - 512 - 256) return ACMI_E_ARG;
             h->bopt.chain_bytes = uint32_t(value);
         } else if (k == "dense_bytes") {
             if (h->aut.finalized()) return ACMI_E_FINALIZED;

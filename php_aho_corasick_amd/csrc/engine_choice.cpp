@@ -38,7 +38,7 @@ float nominal_cost(const acmi_handle *h, int strat, uint64_t blob_bytes, size_t 
     case acmi_handle::kStratTiles: {
         // (the whole automaton in LDS, chain-compressed: the walk costs 0.9-1.1 ms per GiB on text with a match now and then, 1.4 with
         // one every nine bytes; the logs turn into records at ~ 6 us per million)
-        if (h->chain_walk != 0 && chain_walk_ok(h->dA)) return float(1.0 + density * 10.0);
+        if (h->chain_walk != 0 && chain_walk_ok(h->dA) && (h->chain_walk > 0 || h->dA.chain_dense < h->dA.chain_index)) return float(1.0 + density * 10.0);
         const bool allhot = uint64_t(fa.trap) * (fa.n_columns * fa.entry_bytes + 4u) <= 60u * 1024u && fa.trap + 1u == fa.n_states;
         return float((fa.compact ? 6.0 : allhot ? 1.0 : 1.45) + density * (density > 0.25 ? 20.0 : 4.5));   // (past an event per 4 bytes: the second walk)
     }

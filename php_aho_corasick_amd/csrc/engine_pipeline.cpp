@@ -367,7 +367,10 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     F.out_cap = cap;
     // kernel 6 over the whole automaton in LDS (k_walk_chain) when the set carries the chain-compressed image -- not for the short part
     // of a split set that merges the long part's records as it writes (k_walk_tiles' lane-list variant does that)
-    F.chain = kernel == 6 && h->chain_walk != 0 && chain_walk_ok(h->dA) && h->merge_into.out == nullptr;
+    // (a small automaton, every row of which fits the LDS, keeps k_walk_tiles' lane-list form unless "chain_walk" 1 asks: 8 patterns of
+    // 2-6 B over their own alphabet, 540 records per 8 KiB, 1.32 ms per GiB there against 1.55 here)
+    F.chain = kernel == 6 && h->chain_walk != 0 && chain_walk_ok(h->dA) && h->merge_into.out == nullptr &&
+              (h->chain_walk > 0 || h->dA.chain_dense < h->dA.chain_index);
     if (kernel == 6 && F.chain) {
         // k_walk_chain's buffers: the pieces' overflow lists (per wave, reused tile after tile), the waves' event logs and the tiles'
         // {log offset, events per lane}.  The logs are sized optimistically -- an event per chain_log_div bytes of text, learned like

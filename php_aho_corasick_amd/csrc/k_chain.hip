@@ -34,7 +34,6 @@ namespace acmi {
 
 constexpr uint32_t kChainThreads = 1024;
 constexpr uint32_t kChainWaves = kChainThreads / 64;
-constexpr uint32_t kChainLaneCap = 4;   // events per lane kept in LDS: 16 KiB for the workgroup
 
 struct ChainArgs {
     uint32_t W, P, R, back;
@@ -152,10 +151,9 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint64_t total_items = B.item_base[B.n_haystacks];
-    // LDS: [image: rows | records | counts] [512 B byte classes (TABLE mode)] [the lanes' event lists]
+    // LDS: [image: rows | records | counts] [512 B byte classes (TABLE mode)]
     // (the image at offset 0 -- no static shared variable in front of it: a row's address is then the multiply-add's result itself)
     const uint32_t img_bytes = (A.chain_img_bytes + 15u) & ~15u;
-    const uint32_t cls_bytes = (MODE == 0) ? 512u : 0u;
     // (chain_step2 reads the rows at the multiply-add's result itself: the dynamic LDS begins at 0 when nothing static precedes it)
     if (uint32_t(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint8_t *)smem)) != 0u) __builtin_trap();
     {
@@ -176,10 +174,12 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
     // whole LDS taken by the image a CU runs one workgroup -- four waves per SIMD, too few to hide them (one piece per lane: 55 % of
     // the VALU cycles used).  The two walks are independent: their reads are issued together.  A lane's records -- the first
     // piece's, then the second's -- are one contiguous stretch of the output.
-    // event lists: entry k of piece h of this lane at lists[(2 h + k) * 1024] (kChainLaneCap / 2 each), beyond that in global memory
-    uint32_t *lists = reinterpret_cast<uint32_t *>(smem + img_bytes + cls_bytes) + threadIdx.x;
-    uint32_t *spill = T.spill + (uint64_t(blockIdx.x) * kChainWaves + wave) * T.spill_cap * 128u + lane;   // entry k of piece h at spill[((k - cap) * 2 + h) * 64]
-    constexpr uint32_t kCap = kChainLaneCap / 2u;
+    // Event lists: entry k of piece h of this lane at byte (h x spill_cap + k) x 256 + 4 lane of the wave's region of a global buffer
+    // (L2: written and read back within microseconds).  Not in LDS: two entries per piece there and the rest in memory meant a
+    // compare and two store paths in every step with an event -- 8 VALU and 6 SALU operations per event and piece, which is what
+    // the kernel spent most of its time on once a piece had an event every fifteen bytes; one path, its offset bumped, is 3.
+    uint8_t *const spill = reinterpret_cast<uint8_t *>(T.spill) + uint64_t(__builtin_amdgcn_readfirstlane(int(blockIdx.x * kChainWaves + wave))) * T.spill_cap * 512u;
+    const uint32_t off_a0 = lane * 4u, off_z0 = T.spill_cap * 256u + lane * 4u;
     uint32_t walked16 = 0;
     const uint32_t cnt_n = A.chain_cnt_n;
     const uint32_t gw = blockIdx.x * kChainWaves + wave;   // this wave among the grid's
@@ -192,20 +192,18 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
         const Piece pa = chain_piece(A, B, T, total_items, first_item, 2u * lane), pz = chain_piece(A, B, T, total_items, first_item, 2u * lane + 1u);
         walked16 += pa.nblk + pz.nblk;
         // ---- the walk: all lanes in step, a lane past its own bytes walks on without reporting ----
-        uint32_t ea = 0, ez = 0, na = 0, nz = 0;   // states and event counts of the two pieces
+        uint32_t ea = 0, ez = 0;             // states of the two pieces
+        uint32_t oa = off_a0, oz = off_z0;   // where their next events go
         const uint32_t my_blocks = pa.nblk > pz.nblk ? pa.nblk : pz.nblk;
         if (__any(my_blocks != 0u) && !(T.debug & 2u)) {
             // An event inside the walk is ONE store: {index, what the parent's record says about its records (entered along the
             // chain; else 0), byte} to the piece's list.  What it stands for is worked out behind the walk, where a lane runs over
             // its own events only -- in here the whole wave pays for every step in which ANY lane has one.
-            auto event = [&](uint32_t h, uint32_t e, uint32_t &n, uint32_t jj, uint32_t u, bool hit) __attribute__((always_inline)) {
+            auto event = [&](uint32_t e, uint32_t &off, uint32_t jj, uint32_t u) __attribute__((always_inline)) {
                 // (bits 24..28: the parent record's count of the child's records; a row entry read as a negative halfword has 31 there,
                 // like a saturated count: "look it up")
-                (void)hit;
-                const uint32_t ent = (u & 0x1F000000u) | e | jj << 15;
-                if (n < kCap) lists[(2u * h + n) * kChainThreads] = ent;
-                else *reinterpret_cast<__attribute__((address_space(1))) uint32_t *>(reinterpret_cast<uintptr_t>(spill + ((n - kCap) * 2u + h) * 64u)) = ent;
-                ++n;
+                *reinterpret_cast<__attribute__((address_space(1))) uint32_t *>(reinterpret_cast<uintptr_t>(spill) + off) = (u & 0x1F000000u) | e | jj << 15;
+                off += 256u;
             };
             // four steps of both pieces; the column offsets of a dword's four bytes are worked out together (SWAR3: a handful of
             // operations for all four; TABLE: four independent LDS reads).  CHECKED: the range test of a block that does not lie
@@ -235,8 +233,8 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
                     const bool va = int32_t(ua) < 0 && (!C || j - pa.rep_lo < pa.rep_len);
                     const bool vz = int32_t(uz) < 0 && (!C || j - pz.rep_lo < pz.rep_len);
                     if (va || vz) {
-                        if (va) event(0u, ea, na, j, ua, ha);
-                        if (vz) event(1u, ez, nz, j, uz, hz);
+                        if (va) event(ea, oa, j, ua);
+                        if (vz) event(ez, oz, j, uz);
                     }
                 }
             };
@@ -277,7 +275,8 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
                 asm volatile("; acmi-hot-end");
             }
         }
-        if (na > kCap || nz > kCap) {   // (this lane's own stores: landed before they are read back)
+        const uint32_t na = (oa - off_a0) >> 8, nz = (oz - off_z0) >> 8;   // events of the two pieces
+        if (na | nz) {   // (this lane's own stores: landed before they are read back)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
@@ -305,28 +304,27 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
         // (the log is sized for the batches before: the host grows it and runs the batch again)
         if (!fits && lane == 0) atomicOr(&B.counters[19], 1u);
         uint32_t *dst = log + log_at + (e_incl - ne);
-        auto drain = [&](uint32_t h, uint32_t n, uint32_t *to) __attribute__((always_inline)) -> uint32_t {
+        // (the lane's own stores, read back from L2 -- the CU's L1 may still hold the line as a tile before left it --, four at a time)
+        auto drain = [&](uint32_t h, uint32_t n, uint32_t off0, uint32_t *to) __attribute__((always_inline)) -> uint32_t {
             uint32_t recs = 0;
             const uint32_t tag = (2u * lane + h) << 24;   // (the count code has done its work when the entry is logged: its bits name the piece)
-            auto one = [&](uint32_t k, uint32_t ent) __attribute__((always_inline)) {
-                recs += records_of(ent);
-                if (fits) to[k] = (ent & 0x00FFFFFFu) | tag;
-            };
-            for (uint32_t k = 0; k < kCap; ++k)
-                if (k < n) one(k, lists[(2u * h + k) * kChainThreads]);
 #pragma unroll 1
-            for (uint32_t k = kCap; k < n; k += 4u) {
+            for (uint32_t k = 0; k < n; k += 4u) {
                 uint32_t e[4];
 #pragma unroll
                 for (uint32_t i = 0; i < 4u; ++i)
-                    e[i] = k + i < n ? __hip_atomic_load(spill + ((k + i - kCap) * 2u + h) * 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                    e[i] = k + i < n ? __hip_atomic_load(reinterpret_cast<uint32_t *>(spill + off0 + (k + i) * 256u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 #pragma unroll
-                for (uint32_t i = 0; i < 4u; ++i)
-                    if (k + i < n) one(k + i, e[i]);
+                for (uint32_t i = 0; i < 4u; ++i) {
+                    if (k + i < n) {
+                        recs += records_of(e[i]);
+                        if (fits) to[k + i] = (e[i] & 0x00FFFFFFu) | tag;
+                    }
+                }
             }
             return recs;
         };
-        const uint32_t ra = drain(0u, na, dst), rz = drain(1u, nz, dst + na);   // records of the two pieces
+        const uint32_t ra = drain(0u, na, off_a0, dst), rz = drain(1u, nz, off_z0, dst + na);   // records of the two pieces
         log_at += e_tot;
         // ---- records: exclusive prefix over the wave's lanes, the items' totals (k_expand's scan turns them into bases) ----
         const uint32_t n_rec = ra + rz;
@@ -446,7 +444,7 @@ __global__ __launch_bounds__(kEmitThreads) void k_chain_emit(DevAutomaton A, Bat
 bool chain_walk_ok(const DevAutomaton &A) {
     if (A.chain_img == nullptr || A.chain_head == nullptr || A.chain_frank == nullptr) return false;
     const uint32_t img = (A.chain_img_bytes + 15u) & ~15u;
-    return img + 512u + kChainWaves * kChainLaneCap * 256u <= 160u * 1024u;
+    return img + 512u <= 160u * 1024u;
 }
 
 uint32_t chain_grid() { return uint32_t(num_cus()); }
@@ -480,7 +478,7 @@ hipError_t launch_walk_chain(const DevAutomaton &A, const BatchArgs &B, uint64_t
     static const uint32_t debug = [] { const char *e = std::getenv("ACMI_CHAIN_DEBUG"); return e ? uint32_t(std::atoi(e)) : 0u; }();
     T.debug = debug;
     const uint32_t img = (A.chain_img_bytes + 15u) & ~15u;
-    const uint32_t lds = img + (class_mode == 0 ? 512u : 0u) + kChainWaves * kChainLaneCap * 256u;
+    const uint32_t lds = img + (class_mode == 0 ? 512u : 0u);
     // (always the whole grid: the logs are per wave of THIS grid -- k_chain_emit finds a tile's by t % n_waves)
     auto go = [&](auto fn) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));

@@ -107,8 +107,8 @@ def test_chain_image_walks_like_the_oracle(name, lds, fits):
         api.ahocorasick_deinit(res)
         return
     ch = ft.chain
-    assert ch["n_index"] == ft.n_states - 1 and 0 < ch["n_dense"] <= ch["n_index"] and ch["bytes"] <= 160 * 1024 - 16 * 1024 - 768
-    if (ft.n_states - 1) * (2 * ft.n_columns + 1) + 4 <= 160 * 1024 - 16 * 1024 - 768:
+    assert ch["n_index"] == ft.n_states - 1 and 0 < ch["n_dense"] <= ch["n_index"] and ch["bytes"] <= 160 * 1024 - 768
+    if (ft.n_states - 1) * (2 * ft.n_columns + 1) + 4 <= 160 * 1024 - 768:
         assert ch["n_dense"] == ch["n_index"] and ch["recs"].size == 0          # a small automaton: all of its rows, no records
     assert sorted(ch["orig"].tolist()) == sorted(set(range(ft.n_states)) - {ft.trap})      # every state once
     nd = ch["n_dense"]

@@ -33,7 +33,7 @@ def test_goldens_through_the_chain_walk(name):
     """The golden datasets whose automaton does not fit a 2 KiB tile as dense rows: hashes made by the compiled reference."""
     golden = {(c["dataset"], c["find_all"]): c for c in load_json("golden.json")["cases"] + load_json("golden_targeted.json")["cases"]}
     ds = (synth.NAMED.get(name) or synth.TARGETED[name])()
-    res = resource_for(ds, kernel=6, lds_bytes=2048, small_path=0, split=0)
+    res = resource_for(ds, kernel=6, lds_bytes=2048, small_path=0, split=0, chain_walk=1)
     p, r = device_match(res, ds)
     if res.stat("chain_image_bytes") == 0:
         api.ahocorasick_deinit(res)
@@ -69,12 +69,27 @@ def test_ragged_haystacks_and_pattern_lengths(hmax, lmax):
     ds = synth._planted_ragged(f"CR{hmax}", 900 + hmax, 400, 1, lmax, 300, 0, hmax, b"abc", 4)
     pe, re_ = _oracle(ds)
     for geometry in ({}, dict(tile_w=16, tile_p=9), dict(tile_w=64, tile_p=64), dict(tile_w=32, tile_p=1)):
-        res = resource_for(ds, kernel=6, small_path=0, lds_bytes=2048, **geometry)
+        res = resource_for(ds, kernel=6, small_path=0, lds_bytes=2048, chain_walk=1, **geometry)
         p, r = device_match(res, ds)
         if lmax > 4:
             assert res.stat("kernel_used") == 6 and res.stat("chain_walk_used") == 1
         assert np.array_equal(p, pe) and np.array_equal(r, re_), geometry
         api.ahocorasick_deinit(res)
+
+
+@pytest.mark.parametrize("name", ["G3", "G4", "G5", "R1"])
+def test_small_automata_all_rows_in_lds(name):
+    """A small automaton's image is all of its rows (one read per step): kernel 6 keeps k_walk_tiles for those unless "chain_walk" 1
+    asks for k_walk_chain -- the same records, dense output (a^1..a^16: sixteen records per byte) included."""
+    ds = synth.NAMED[name]()
+    pe, re_ = _oracle(ds)
+    res = resource_for(ds, kernel=6, small_path=0, chain_walk=1)
+    _check(res, ds, pe, re_)
+    assert res.stat("chain_dense_states") == res.stat("states") - 1
+    res.set_option("chain_walk", -1)
+    p, r = device_match(res, ds)
+    assert res.stat("kernel_used") == 6 and res.stat("chain_walk_used") == 0 and np.array_equal(p, pe) and np.array_equal(r, re_)
+    api.ahocorasick_deinit(res)
 
 
 def _nested(n_hay=64, hay_len=4096):
@@ -91,7 +106,7 @@ def test_saturated_counts_and_lane_lists_that_overflow():
     ds = _nested()
     pe, re_ = _oracle(ds)
     assert len(re_) > 4 * ds.hay_blob.size
-    res = resource_for(ds, kernel=6, small_path=0, lds_bytes=2048)
+    res = resource_for(ds, kernel=6, small_path=0, lds_bytes=2048, chain_walk=1)
     _check(res, ds, pe, re_, calls=3)
     api.ahocorasick_deinit(res)
 
@@ -124,7 +139,7 @@ def test_bounded_result_memory_drains_and_resumes():
     pe, re_ = _oracle(ds)
     per_hay = int(np.diff(pe).max())
     cap = 3 * per_hay * 16 + 4096
-    res = resource_for(ds, kernel=6, small_path=0, lds_bytes=2048, max_result_bytes=cap)
+    res = resource_for(ds, kernel=6, small_path=0, lds_bytes=2048, max_result_bytes=cap, chain_walk=1)
     d_blob = torch.from_numpy(ds.hay_blob).cuda()
     d_off = torch.from_numpy(ds.hay_off.astype(np.int64)).cuda()
     batch.bind_current_stream(res)
