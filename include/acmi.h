@@ -305,6 +305,12 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *                    sum in ONE pass -- no slabs, no drain (findAll = true, patterns of <= 129 B; what automatic
  *                    mode takes instead of 4 unless the output is denser than a record per two bytes) [any time]
  *   "tile_w", "tile_p"  kernel 6: bytes per lane (16, 32, 64) and lanes per work item (1..64); 0 = automatic [any time]
+ *   "chain_walk"     kernel 6 for a pattern set that carries the chain-compressed LDS image of its WHOLE automaton (a few thousand
+ *                    patterns: dense rows for the branching states, goto edge + failure pointer -- the reference's node,
+ *                    node.h:37-67 -- for the insides of the patterns; "chain_image_bytes", "chain_dense_states"): -1 (default) the
+ *                    walk over that image (k_walk_chain + k_chain_emit) unless the automaton is so small that all of its dense
+ *                    rows fit the LDS, 1 whenever there is an image, 0 never ("chain_walk_used", "chain_log_reruns")  [any time]
+ *   "chain_bytes"    budget of that image, <= 160 KiB - 768 B (the default); 0: none is built             [before finalize]
  *   "reserve_cus"    N (default 0): the scan kernels run as persistent workgroups on all but N compute units, so that the kernels
  *                    of a collective in flight (acmi_comm_*, RCCL) find CUs and LDS while a scan runs          [any time]
  *   "max_result_bytes"  0 (default): the result buffers grow to whatever a batch produces (16 B per record; a^1..a^16 over
