@@ -108,6 +108,7 @@ struct acmi_comm {
     // capacities every rank holds, kept identical on all ranks (they grow by the same rule from the same headers)
     uint64_t cap_rec = 0, cap_hay = 0;
     bool cap_ok = true;             // this rank's buffers really have that capacity
+    int last_root = -2;             // root of the last exchange (-1: all-gather; -2: none yet)
     uint64_t total_rec = 0, total_hay = 0;
     uint64_t bytes_sent = 0, bytes_received = 0, rounds = 0;  // of the last exchange (statistics)
     std::string last_error;
@@ -351,7 +352,11 @@ static int comm_exchange(acmi_comm *c, acmi_handle *h, uint64_t n_haystacks_loca
         // Global arrays: grown by the same rule on every rank (the totals are the same everywhere), and a rank whose
         // allocation fails tells the others in a second, tiny round -- taken by all ranks or by none.  (A rank that only
         // sends -- a gather's non-root -- holds its own slice of the prefix words and of the wire, no more.)
-        if (total_rec > c->cap_rec || total_hay > c->cap_hay || !c->d_prefix.p) {
+        // (... and when the ROOT is another than last time -- every rank knows that: the rank that becomes the receiver allocates
+        // its record array inside the agreed round, not behind it where a failure would leave its peers waiting in the collective)
+        const bool root_changed = root != c->last_root;
+        c->last_root = root;
+        if (total_rec > c->cap_rec || total_hay > c->cap_hay || !c->d_prefix.p || root_changed) {
             c->cap_rec = std::max(c->cap_rec, total_rec + total_rec / 4);
             c->cap_hay = std::max(c->cap_hay, total_hay + total_hay / 4);
             c->cap_ok = c->d_prefix.ensure((c->cap_hay + 1) * 8) == hipSuccess && c->d_wire.ensure(std::max<uint64_t>(16, c->cap_rec * 8)) == hipSuccess &&
