@@ -419,12 +419,21 @@ __global__ __launch_bounds__(kEmitThreads) void k_chain_emit(DevAutomaton A, Bat
             }
             at += uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
         };
+        // (the next four rounds' events are requested before this round's records are placed: under 2 TB/s of record stores a read
+        // takes microseconds, and one per 256 events in the open was most of a tile's time)
+        auto load4 = [&](uint32_t e0, uint32_t (&ent)[4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; ++i) ent[i] = e0 + 64u * i + lane < info.y ? ev[e0 + 64u * i + lane] : 0xFFFFFFFFu;
+        };
+        uint32_t nxt[4];
+        load4(0u, nxt);
 #pragma unroll 1
         for (uint32_t e0 = 0; e0 < info.y; e0 += 256u) {
             uint32_t ent[4], c[4];
             uint2 hd[4];
 #pragma unroll
-            for (uint32_t i = 0; i < 4u; ++i) ent[i] = e0 + 64u * i + lane < info.y ? ev[e0 + 64u * i + lane] : 0xFFFFFFFFu;
+            for (uint32_t i = 0; i < 4u; ++i) ent[i] = nxt[i];
+            if (e0 + 256u < info.y) load4(e0 + 256u, nxt);
 #pragma unroll
             for (uint32_t i = 0; i < 4u; ++i)
                 hd[i] = ent[i] == 0xFFFFFFFFu ? make_uint2(0u, 0u) : in_lds ? fhead[frank[ent[i] & 0x7FFFu]] : A.chain_head[ent[i] & 0x7FFFu];

@@ -108,6 +108,7 @@ def test_saturated_counts_and_lane_lists_that_overflow():
     assert len(re_) > 4 * ds.hay_blob.size
     res = resource_for(ds, kernel=6, small_path=0, lds_bytes=2048, chain_walk=1)
     _check(res, ds, pe, re_, calls=3)
+    assert res.stat("chain_log_reruns") >= 1      # (an event per byte: the logs, sized for one per 32 bytes, overflowed and the batch ran again)
     api.ahocorasick_deinit(res)
 
 
