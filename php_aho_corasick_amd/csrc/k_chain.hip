@@ -170,6 +170,7 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
     L.row_bytes = A.n_columns * 2u;
     L.cnt = smem + A.chain_cnt_off;
     L.cls = (MODE == 0) ? reinterpret_cast<const uint16_t *>(smem + img_bytes) : nullptr;
+    const uint32_t cls_at = img_bytes;   // LDS offset of the byte classes (the dynamic LDS begins at 0)
     // A lane walks TWO pieces at once, 2 lane and 2 lane + 1 of the wave's 128: a step is two dependent LDS reads, and with the
     // whole LDS taken by the image a CU runs one workgroup -- four waves per SIMD, too few to hide them (one piece per lane: 55 % of
     // the VALU cycles used).  The two walks are independent: their reads are issued together.  A lane's records -- the first
@@ -208,26 +209,41 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
             // four steps of both pieces; the column offsets of a dword's four bytes are worked out together (SWAR3: a handful of
             // operations for all four; TABLE: four independent LDS reads).  CHECKED: the range test of a block that does not lie
             // inside every piece's own range; WARM: the first block, in which a walk begins (the state is the root before).
-            auto columns = [&](uint32_t wd, uint32_t (&c)[4]) __attribute__((always_inline)) {
-                if constexpr (MODE == 1) {
-                    const uint32_t c4 = swar_columns<uint16_t>(A, wd);
-                    c[0] = c4 & 0xffu; c[1] = (c4 >> 8) & 0xffu; c[2] = (c4 >> 16) & 0xffu; c[3] = c4 >> 24;
-                } else {
-                    c[0] = class_offset<uint16_t, MODE>(A, L.cls, wd & 0xffu); c[1] = class_offset<uint16_t, MODE>(A, L.cls, (wd >> 8) & 0xffu);
-                    c[2] = class_offset<uint16_t, MODE>(A, L.cls, (wd >> 16) & 0xffu); c[3] = class_offset<uint16_t, MODE>(A, L.cls, wd >> 24);
-                }
+            // the column offsets of a dword's bytes: SWAR3 a handful of operations for all four; TABLE an LDS read per byte, requested a
+            // byte ahead of its step (all eight of a dword pair up front cost the two registers that spilled into this loop)
+            typedef const __attribute__((address_space(3))) uint16_t *ClsPtr;
+            auto cls_of = [&](uint32_t wd, uint32_t i) __attribute__((always_inline)) -> uint32_t {
+                // (explicitly LDS reads at the table's offset: through class_offset's generic pointer hipcc emitted flat_load_ushort
+                // behind two branches -- a flat load counts on vmcnt too: every byte's class waited for the text requested four
+                // blocks ahead and for the event stores)
+                const uint32_t b2 = i == 0u ? (wd & 0xffu) << 1 : (wd >> (8u * i - 1u)) & 0x1feu;
+                return *reinterpret_cast<ClsPtr>(cls_at + b2);
             };
             auto dword = [&](uint32_t wa, uint32_t wz, uint32_t jj, auto checked, auto warm) __attribute__((always_inline)) {
                 constexpr bool C = decltype(checked)::value, W0 = decltype(warm)::value;
-                uint32_t ca[4], cz[4];
-                columns(wa, ca);
-                columns(wz, cz);
+                uint32_t c4a = 0, c4z = 0, na_c = 0, nz_c = 0;
+                if constexpr (MODE == 1) {
+                    c4a = swar_columns<uint16_t>(A, wa);
+                    c4z = swar_columns<uint16_t>(A, wz);
+                } else {
+                    na_c = cls_of(wa, 0u);
+                    nz_c = cls_of(wz, 0u);
+                }
 #pragma unroll
                 for (uint32_t i = 0; i < 4u; ++i) {
                     const uint32_t j = jj + i;
+                    uint32_t ca_i, cz_i;
+                    if constexpr (MODE == 1) {
+                        ca_i = (c4a >> (8u * i)) & 0xffu;
+                        cz_i = (c4z >> (8u * i)) & 0xffu;
+                    } else {
+                        ca_i = na_c;
+                        cz_i = nz_c;
+                        if (i < 3u) { na_c = cls_of(wa, i + 1u); nz_c = cls_of(wz, i + 1u); }
+                    }
                     uint32_t ua, uz;
                     bool ha, hz;
-                    chain_step2<ALLD>(L, ea, ez, ca[i], cz[i], ua, uz, ha, hz);
+                    chain_step2<ALLD>(L, ea, ez, ca_i, cz_i, ua, uz, ha, hz);
                     if (W0) { ea = j < pa.start_j ? 0u : ea; ez = j < pz.start_j ? 0u : ez; }
                     // (rep_lo >= start_j: nothing before a walk's first byte reports)
                     const bool va = int32_t(ua) < 0 && (!C || j - pa.rep_lo < pa.rep_len);

@@ -448,7 +448,11 @@ __device__ __forceinline__ uint32_t class_offset(const DevAutomaton &A, const ui
         return e == byte ? c * uint32_t(sizeof(E)) : A.swar_other_off;
     }
     if (A.class_identity) return byte * uint32_t(sizeof(E));  // all 256 byte values in use: no lookup (one dependent load less per step)
-    return cls_lds ? cls_lds[byte] : A.class_off[byte];
+    // (explicitly an LDS read: through the generic pointer hipcc emitted flat_load_ushort -- which counts on vmcnt as well, so a
+    // byte's class waited for every global load and store in flight; the low 32 bits of a generic LDS address are its LDS offset)
+    if (cls_lds != nullptr)
+        return *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>(uint32_t(reinterpret_cast<uintptr_t>(cls_lds)) + byte * 2u);
+    return A.class_off[byte];
 }
 
 // Event counters of the item being walked by the epilogue, kept in registers and stored once.

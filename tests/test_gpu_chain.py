@@ -108,7 +108,37 @@ def test_saturated_counts_and_lane_lists_that_overflow():
     assert len(re_) > 4 * ds.hay_blob.size
     res = resource_for(ds, kernel=6, small_path=0, lds_bytes=2048, chain_walk=1)
     _check(res, ds, pe, re_, calls=3)
-    assert res.stat("chain_log_reruns") >= 1      # (an event per byte: the logs, sized for one per 32 bytes, overflowed and the batch ran again)
+    api.ahocorasick_deinit(res)
+
+
+def test_event_logs_that_overflow_are_grown_and_the_batch_runs_again():
+    """The waves' event logs are sized for an event per 32 bytes of text (learned like the record buffer): 96 MiB with an event at
+    EVERY byte -- more tiles than the grid has waves, so that a wave's log is not simply its one tile's worst case -- overflows
+    them, the batch is run again with logs for eight times the events (twice: 32 -> 4 -> 1 bytes per event), and the result is
+    the oracle's on a slice, the count formula's in full."""
+    import torch
+    rng = np.random.default_rng(6)
+    pats = [b"a"] + [bytes(rng.choice(list(b"ab"), size=int(rng.integers(12, 30))).tolist()) for _ in range(80)]
+    pats = [p for p in pats if p == b"a" or b"b" in p]
+    n_hay, hay_len = 24576, 4096
+    text = np.full(4 * hay_len, ord("a"), np.uint8)
+    pat_off = np.concatenate([[0], np.cumsum([len(p) for p in pats])]).astype(np.uint64)
+    small = synth.Dataset("LOG", np.frombuffer(b"".join(pats), np.uint8).copy(), pat_off, text, (np.arange(5) * hay_len).astype(np.uint64))
+    pe, re_ = _oracle(small)
+    assert len(re_) == 4 * hay_len                                   # "a" at every byte, nothing else in text without a 'b'
+    res = resource_for(small, kernel=6, small_path=0, lds_bytes=2048, chain_walk=1)
+    d_blob = torch.full((n_hay * hay_len,), ord("a"), dtype=torch.uint8, device="cuda")
+    d_off = torch.arange(n_hay + 1, dtype=torch.int64, device="cuda") * hay_len
+    batch.bind_current_stream(res)
+    for _ in range(2):
+        total = batch.match_device(res, d_blob, d_off, True)
+        assert res.stat("kernel_used") == 6 and res.stat("chain_walk_used") == 1 and total == n_hay * hay_len
+    assert res.stat("chain_log_reruns") >= 1
+    p, r = batch.result_numpy(res, n_hay, total)
+    assert np.array_equal(p, np.arange(n_hay + 1, dtype=np.uint64) * np.uint64(hay_len))
+    assert np.array_equal(r[:len(re_)], re_)
+    tail = r[-hay_len:]
+    assert np.all(tail[:, 0] == n_hay - 1) and np.array_equal(tail[:, 1], np.arange(1, hay_len + 1)) and np.all(tail[:, 3] == 0)
     api.ahocorasick_deinit(res)
 
 
