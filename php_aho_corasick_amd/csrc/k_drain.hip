@@ -80,7 +80,7 @@ __global__ __launch_bounds__(kRefillThreads) void k_refill_wave(DevAutomaton A, 
     auto step = [&](uint32_t s, uint32_t byte) __attribute__((always_inline)) -> uint32_t {
         const uint32_t coff = cls[byte];
         if (s < tile_rows) {
-            const uint32_t w = *reinterpret_cast<const E *>(tile + s * A.row_bytes + coff);
+            const uint32_t w = lds_read<E>(tile, s * A.row_bytes + coff);
             if (w < A.trap) return w;   // (the image's rows name a cold target by the trap row)
         }
         return cold_step<E>(A, s, byte, coff);

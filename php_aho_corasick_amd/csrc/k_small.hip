@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_match_small(DevAutomaton A, c
     auto step = [&](uint32_t s, uint32_t byte) -> uint32_t {
         const uint32_t coff = class_offset<E, MODE>(A, cls, byte);
         uint32_t w = A.trap;
-        if (s < tile_rows) w = *reinterpret_cast<const E *>(tile + s * A.row_bytes + coff);
+        if (s < tile_rows) w = lds_read<E>(tile, s * A.row_bytes + coff);
         if (w >= A.trap) w = cold_step<E>(A, s, byte, coff);
         return w;
     };

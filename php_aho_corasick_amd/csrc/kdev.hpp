@@ -107,6 +107,14 @@ __device__ __forceinline__ uint32_t anchor_mad(uint32_t h, uint32_t mul, uint32_
     return r;
 }
 
+// A read from LDS through a pointer the compiler only knows as generic (a function parameter, a pointer that may be null): as a
+// plain dereference hipcc emits flat_load, which counts on vmcnt AND lgkmcnt -- the read then waits for every global load and
+// store in flight.  The low 32 bits of a generic LDS address are its LDS offset.
+template <typename T>
+__device__ __forceinline__ T lds_read(const void *generic_lds, uint32_t byte_offset) {
+    return *reinterpret_cast<const __attribute__((address_space(3))) T *>(uint32_t(reinterpret_cast<uintptr_t>(generic_lds)) + byte_offset);
+}
+
 __device__ __forceinline__ bool is_final(const DevAutomaton &A, uint32_t s) {
     return (s >= A.f1 && s < A.trap) || s >= A.f2;
 }
@@ -169,7 +177,7 @@ __device__ __forceinline__ uint32_t exact_step(const DevAutomaton &A, const uint
                                                uint32_t byte) {
     const uint32_t coff = A.class_off[byte];
     if (tile != nullptr && s < A.trap) {
-        const uint32_t w = *reinterpret_cast<const E *>(tile + s * A.row_bytes + coff);
+        const uint32_t w = lds_read<E>(tile, s * A.row_bytes + coff);
         if (w < A.trap) return w;
     }
     return cold_step<E>(A, s, byte, coff);
@@ -480,22 +488,27 @@ __device__ __forceinline__ uint32_t exact_range(const DevAutomaton &A, const Bat
     if (j0 >= j1) return s;
     uintptr_t blk = (base + j0) & ~uintptr_t(15);
     const uintptr_t end = base + j1;
-    uint4 cur = *reinterpret_cast<const uint4 *>(blk), nxt = cur;
-    if (blk + 16 < end) nxt = *reinterpret_cast<const uint4 *>(blk + 16);
+    // (explicitly global: through an address computed as an integer hipcc emits flat_load, whose wait also drains the LDS queue)
+    auto text16 = [](uintptr_t a) __attribute__((always_inline)) -> uint4 {
+        const u32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) u32x4 *>(a);
+        return make_uint4(v.x, v.y, v.z, v.w);
+    };
+    uint4 cur = text16(blk), nxt = cur;
+    if (blk + 16 < end) nxt = text16(blk + 16);
 #pragma unroll 1
     for (uint32_t j = j0; j < j1; ++j) {
         const uintptr_t a = base + j;
         if (j != j0 && (a & 15u) == 0) {
             cur = nxt;
             blk += 16;
-            if (blk + 16 < end) nxt = *reinterpret_cast<const uint4 *>(blk + 16);
+            if (blk + 16 < end) nxt = text16(blk + 16);
         }
         const uint32_t sel = uint32_t(a >> 2) & 3u;
         const uint32_t word = sel == 0 ? cur.x : sel == 1 ? cur.y : sel == 2 ? cur.z : cur.w;
         const uint32_t byte = (word >> (8u * uint32_t(a & 3u))) & 0xffu;
         const uint32_t coff = class_offset<E, MODE>(A, cls_lds, byte);
         uint32_t w = A.trap;
-        if (s < tile_rows) w = *reinterpret_cast<const E *>(tile + s * A.row_bytes + coff);  // LDS-resident row
+        if (s < tile_rows) w = lds_read<E>(tile, s * A.row_bytes + coff);  // LDS-resident row
         if (w >= A.trap) w = cold_step<E>(A, s, byte, coff);  // row not in LDS
         s = w;
         if (j >= rep_from && is_final(A, s) && !(B.first_only && ev.n_ev)) {
@@ -622,7 +635,7 @@ __device__ __forceinline__ uint32_t walk_fast(const DevAutomaton &A, const Batch
         const uint32_t byte = (word >> (8u * (k & 3u))) & 0xffu;
         const uint32_t coff = class_offset<E, MODE>(A, nullptr, byte);
         const uint32_t row = s < tile_rows ? s : 0u;
-        uint32_t w = *reinterpret_cast<const E *>(tile + row * row_bytes + coff);
+        uint32_t w = lds_read<E>(tile, row * row_bytes + coff);
         w = s < tile_rows ? w : trap;
         if (m == 0u && w >= trap) w = cold_step<E>(A, s, byte, coff);
         const bool stepped = m == 0u;
