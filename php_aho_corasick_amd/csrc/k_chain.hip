@@ -451,8 +451,19 @@ __global__ __launch_bounds__(kEmitThreads) void k_chain_emit(DevAutomaton A, Bat
             for (uint32_t i = 0; i < 4u; ++i) ent[i] = nxt[i];
             if (e0 + 256u < info.y) load4(e0 + 256u, nxt);
 #pragma unroll
-            for (uint32_t i = 0; i < 4u; ++i)
-                hd[i] = ent[i] == 0xFFFFFFFFu ? make_uint2(0u, 0u) : in_lds ? fhead[frank[ent[i] & 0x7FFFu]] : A.chain_head[ent[i] & 0x7FFFu];
+            for (uint32_t i = 0; i < 4u; ++i) {
+                hd[i] = make_uint2(0u, 0u);
+                if (ent[i] != 0xFFFFFFFFu) {
+                    // (two reads in their own address spaces: as one select of two pointers hipcc emits a flat load)
+                    if (in_lds) {
+                        const uint32_t rk = lds_read<uint16_t>(frank, (ent[i] & 0x7FFFu) * 2u);
+                        hd[i].x = lds_read<uint32_t>(fhead, rk * 8u);
+                        hd[i].y = lds_read<uint32_t>(fhead, rk * 8u + 4u);
+                    } else {
+                        hd[i] = A.chain_head[ent[i] & 0x7FFFu];
+                    }
+                }
+            }
 #pragma unroll
             for (uint32_t i = 0; i < 4u; ++i) {
                 c[i] = hd[i].x >> 24;   // (no event: 0 -- an entry of all ones is none: piece 127 has no byte 511)
