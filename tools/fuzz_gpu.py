@@ -1,5 +1,7 @@
 """GPU fuzz: many seeded random automata / ragged batches through every kernel and entry point,
-each compared record-for-record with the oracle.  Usage: python tools/fuzz_gpu.py [n_cases] [seed0]"""
+each compared record-for-record with the oracle.  Usage: python tools/fuzz_gpu.py [n_cases] [seed0]
+FUZZ_BIG=1: batches of a few MiB (thousands of haystacks, or long ones) -- many tiles per wave, events by the thousand -- through
+the kernels that place records with running sums (kernel 6: k_walk_chain / k_walk_tiles) and the automatic choice."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -24,6 +26,13 @@ for case in range(n_cases):
     n_hay = int(r.choice([1, 2, 9, 64, 65, 200]))
     hmax = int(r.choice([0, 1, 15, 16, 17, 127, 128, 129, 1000, 5000, 20000]))
     plants = int(r.choice([0, 1, 3, 10]))
+    if os.environ.get("FUZZ_BIG"):
+        n_hay = int(r.choice([300, 2000, 6000]))
+        hmax = int(r.choice([300, 3000, 9000, 70000]))
+        while n_hay * hmax > (12 << 20):
+            n_hay //= 2
+        n_pat = int(r.choice([3, 17, 60, 300, 1500, 4000]))
+        lmax = int(min(200, lmax))
     ds = synth._planted_ragged(f"F{seed}", seed, n_pat, lmin, lmax, n_hay, 0, hmax, alpha, plants) if plants else \
         synth.ragged(f"F{seed}", seed, n_pat, lmin, lmax, n_hay, 0, hmax, alpha)
     if lmin >= 7 and r.integers(3) == 0:   # a few short patterns among the long ones: the split set
@@ -39,10 +48,11 @@ for case in range(n_cases):
     step = (len(pats) + calls - 1) // calls
     for lo in range(0, len(pats), step):
         o.add_patterns(pats[lo:lo + step])
-    opts = dict(kernel=int(r.choice([0, 1, 2, 2, 3, 3, 4, 6, 6])), tile_w=int(r.choice([0, 0, 16, 32, 64])), tile_p=int(r.choice([0, 0, 1, 3, 7, 16, 64])), walk_group=int(r.choice([1, 4, 8])), ilp=int(r.choice([1, 2])), group_quads=int(r.choice([4, 8])),
+    opts = dict(kernel=int(r.choice([6, 6, 6, 3, 3, 2, 4] if os.environ.get("FUZZ_BIG") else [0, 1, 2, 2, 3, 3, 4, 6, 6])), tile_w=int(r.choice([0, 0, 16, 32, 64])), tile_p=int(r.choice([0, 0, 1, 3, 7, 16, 64])), walk_group=int(r.choice([1, 4, 8])), ilp=int(r.choice([1, 2])), group_quads=int(r.choice([4, 8])),
                 chunk_bytes=int(r.choice([0, 0, 16, 48, 256, 1024, 4096])), slab_events=int(r.choice([1, 2, 8])),
                 run_cap=int(r.choice([1, 2, 8])), persistent=int(r.choice([-1, 0, 1])), lds_bytes=int(r.choice([2048, 8192, 65536, 163000])),
-                small_path=int(r.choice([0, 1])), tiny_rows=int(r.choice([0, 1, 1])), short_rows=int(r.choice([-1, 0, 1])), refill=int(r.choice([0, 1, 2, 2])), max_flat_outputs=int(r.choice([0, 1 << 25, 1 << 25])), compact=int(r.choice([-1, 0, 1, 1])), early_stop=int(r.choice([0, 1, 2, 2])), verify=int(r.choice([0, 1, 1])), dense_bytes=int(r.choice([0, 4096, 1 << 22])), anchor_dense=int(r.choice([-1, 1, 1, 0])), dense_hot=int(r.choice([-1, 0, 1])), split=int(r.choice([-1, -1, 0, 1])), anchor_slots2=int(r.choice([-1, 0, 1])))
+                small_path=int(r.choice([0, 1])), tiny_rows=int(r.choice([0, 1, 1])), short_rows=int(r.choice([-1, 0, 1])), refill=int(r.choice([0, 1, 2, 2])), max_flat_outputs=int(r.choice([0, 1 << 25, 1 << 25])), compact=int(r.choice([-1, 0, 1, 1])), early_stop=int(r.choice([0, 1, 2, 2])), verify=int(r.choice([0, 1, 1])), dense_bytes=int(r.choice([0, 4096, 1 << 22])), anchor_dense=int(r.choice([-1, 1, 1, 0])), dense_hot=int(r.choice([-1, 0, 1])), split=int(r.choice([-1, -1, 0, 1])), anchor_slots2=int(r.choice([-1, 0, 1])),
+                chain_walk=int(r.choice([-1, -1, 0, 1, 1])), chain_bytes=int(r.choice([160 * 1024 - 768, 160 * 1024 - 768, 40000, 6000, 0])))
     res = resource_for(ds, calls=calls, **opts)
     for find_all in (True, False):
         pe, re_ = o.match_batch(ds.hay_blob, ds.hay_off, find_all)
