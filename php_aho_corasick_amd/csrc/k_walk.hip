@@ -366,7 +366,11 @@ __global__ __launch_bounds__(1024) void k_dense_decide(DevAutomaton A, BatchArgs
     const uint32_t *ht = IMG ? img + img[1] : nullptr, *recs = IMG ? img + img[2] : nullptr, *tails = IMG ? img + img[3] : nullptr;
     const uint32_t hmul = IMG ? img[5] : 0u;
     const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t blob_end = B.offsets[B.n_haystacks];
     uint32_t *starts_all = reinterpret_cast<uint32_t *>(B.runs);
+    // IMG: the wave's own 64 {window start, record index} behind the image -- an item whose windows are all decided here and hold at
+    // most 64 occurrences is finished by this wave (below), k_dense_emit finds nothing to do for it
+    uint2 *kept = reinterpret_cast<uint2 *>(smem + ((IMG ? A.dense_image_words * 4u : 0u) + 15u & ~15u)) + (threadIdx.x >> 6) * 64u;
     for (uint64_t item = uint64_t(blockIdx.x) * 16u + (threadIdx.x >> 6); item < total_items; item += uint64_t(gridDim.x) * 16u) {
         const uint32_t nr = __builtin_amdgcn_readfirstlane(B.run_count[item]);
         if (nr == 0 || nr > Q) continue;   // (more windows than the list holds: k_dense_emit walks the whole item)
@@ -375,8 +379,11 @@ __global__ __launch_bounds__(1024) void k_dense_decide(DevAutomaton A, BatchArgs
         unpack_item(rec.x, rec.y, rec.z, rec.w, it);
         const uint8_t *p = B.blob + (it.begin - it.warm);
         const uint32_t n = it.warm + it.len;
+        const uint64_t room64 = blob_end - (it.begin - it.warm);   // bytes that can be read from p on
+        const uint32_t room = room64 < 0xFFFFFFFFull ? uint32_t(room64) : 0xFFFFFFFFu;
         uint32_t *starts = starts_all + item * uint64_t(Q), *fidx = found_idx + item * uint64_t(Q);
         uint32_t base = 0;
+        bool many = false;   // (wave-uniform) a window is left to k_dense_emit
 #pragma unroll 1
         for (uint32_t c = 0; c < nr; c += 64u) {
             const uint32_t r = c + lane;
@@ -392,7 +399,7 @@ __global__ __launch_bounds__(1024) void k_dense_decide(DevAutomaton A, BatchArgs
                 }
             } else
             if (active) {
-                if (start + 16u > n) {
+                if (start + 16u > room) {   // (the last bytes of the BLOB: an item's own end is no bound, what lies behind it is masked)
                     out = start + 4u <= n ? kDenseMany : kDenseNone;   // (decided by k_dense_emit, which reads single bytes)
                 } else {
                     const uint4 tx = load16u(p + start);
@@ -424,11 +431,78 @@ __global__ __launch_bounds__(1024) void k_dense_decide(DevAutomaton A, BatchArgs
             const uint64_t km = __ballot(keep);
             if (km != 0) {
                 const uint32_t at = base + __builtin_amdgcn_mbcnt_hi(uint32_t(km >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(km), 0u));
+                many = many || __ballot(out == kDenseMany) != 0;
+                // (an item of one step that this wave finishes itself, below, leaves nothing in the lists)
+                const bool mine = IMG && nr <= 64u && !many && !B.first_only;
                 if (keep) {
-                    starts[at] = start;   // at <= r: every lane of this step has read its start, earlier steps' are consumed
-                    fidx[at] = out;
+                    if (!mine) {
+                        starts[at] = start;   // at <= r: every lane of this step has read its start, earlier steps' are consumed
+                        fidx[at] = out;
+                    }
+                    if (IMG && at < 64u) kept[at] = make_uint2(start, out);
                 }
                 base += uint32_t(__builtin_popcountll(km));
+            }
+        }
+        if constexpr (IMG) {
+            // The item's events, by the wave: every occurrence is known (start, pattern record), none is left to be decided, so
+            // there is nothing to cluster -- an occurrence that ends in the item's own range is an event, of several that end at
+            // the same byte the one that starts first (the longest pattern: its output list carries the others), in order of
+            // their ends (src/multifast/ahocorasick.c:214-231 reports in text order).  k_dense_emit did this a thread per item,
+            // entry by entry: 77 us per GiB of the keyword set for what this wave, waiting for its text lines anyway, does in passing.
+            if (base != 0u && base <= 64u && !many && !B.first_only) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const bool have = lane < base;
+                const uint2 k = have ? kept[lane] : make_uint2(0u, 0u);
+                const uint32_t r0 = have ? recs[2u * k.y] : 0u, r1 = have ? recs[2u * k.y + 1u] : 0u;
+                uint32_t oc = r1 >> 16;
+                if (have && oc == 65535u) oc = A.out_count[r0 & 0xFFFFFFu];
+                const uint32_t j = k.x + (r0 >> 24) - 1u;          // last byte of the occurrence
+                const bool valid = have && j >= it.warm;          // (ends in the warm-up are the item before's)
+                const uint64_t vm = __ballot(valid);
+                // (the usual item: ends ascend with the starts -- every entry is an event of its own, in list order)
+                const uint32_t j_left = uint32_t(__builtin_amdgcn_update_dpp(0, int(j), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+                const bool ascending = __all(!have || lane == 0u || j > j_left) && __all(oc < (1u << 24));
+                bool ev_mine = valid;
+                uint64_t em = vm;
+                uint32_t before, n_rec_lo, n_rec_hi = 0;
+                if (ascending) {
+                    before = __builtin_amdgcn_mbcnt_hi(uint32_t(vm >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(vm), 0u));
+                    n_rec_lo = uint32_t(__builtin_amdgcn_readlane(int(wave_inclusive_sum(valid ? oc : 0u)), 63));
+                } else {
+                    bool dup = false;
+                    for (uint64_t m = vm; m != 0; m &= m - 1) {        // (entries ascend by start: of equal ends the first is the longest)
+                        const uint32_t l = uint32_t(__builtin_ctzll(m));
+                        const uint32_t jl = uint32_t(__builtin_amdgcn_readlane(int(j), int(l)));
+                        dup = dup || (l < lane && jl == j);
+                    }
+                    ev_mine = valid && !dup;
+                    em = __ballot(ev_mine);
+                    before = 0;
+                    n_rec_lo = 0;
+                    for (uint64_t m = em; m != 0; m &= m - 1) {
+                        const uint32_t l = uint32_t(__builtin_ctzll(m));
+                        const uint32_t jl = uint32_t(__builtin_amdgcn_readlane(int(j), int(l)));
+                        before += jl < j ? 1u : 0u;
+                        const uint32_t c = uint32_t(__builtin_amdgcn_readlane(int(oc), int(l)));
+                        n_rec_hi += n_rec_lo + c < n_rec_lo ? 1u : 0u;
+                        n_rec_lo += c;
+                    }
+                }
+                const uint32_t n_ev = uint32_t(__builtin_popcountll(em));
+                if (ev_mine && before < B.slab_events)
+                    B.slab[uint64_t(before) * B.run_stride + item] = make_uint2(it.pos0 - it.warm + 1u + j, r0 & 0xFFFFFFu);
+                if (lane == 0) {
+                    if (n_ev) {
+                        B.ev_count[item] = n_ev;
+                        B.rec_count[item] = uint64_t(n_rec_hi) << 32 | n_rec_lo;
+                        if (n_ev > B.slab_events) B.overflow_list[atomicAdd(&B.counters[0], 1u)] = uint32_t(item);
+                    }
+                    B.run_count[item] = 0u;
+                }
+                continue;
             }
         }
         if (lane == 0) B.run_count[item] = base;
@@ -549,7 +623,7 @@ static hipError_t launch_verify_dense(const DevAutomaton &A, const BatchArgs &B,
         // results live behind the window lists in the same buffer (engine.cpp sizes it: 8 bytes per window slot)
         uint32_t *results = reinterpret_cast<uint32_t *>(B.runs) + B.run_stride * uint64_t(B.run_cap);
         const bool image = A.dense_image != nullptr;
-        const uint32_t lds1 = image ? A.dense_image_words * 4u : 16u;
+        const uint32_t lds1 = image ? ((A.dense_image_words * 4u + 15u) & ~15u) + 16u * 64u * 8u : 16u;   // (+ the waves' kept entries)
         hipError_t e = image ? hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_decide<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds1))
                              : hipSuccess;
         if (e != hipSuccess) return e;

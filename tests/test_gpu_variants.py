@@ -104,3 +104,36 @@ def test_tiny_waves_fall_back_when_an_item_is_longer_than_a_row():
             if wave_items == 16:   # batches of 16 items: three in four have no long item and take the tiny path
                 assert res.stat("tiny_waves") > 0
             api.ahocorasick_deinit(res)
+
+
+def test_dense_form_items_finished_by_the_deciding_wave():
+    """k_dense_decide finishes an item itself when every hit window is decided there (k_walk.hip): occurrences whose ends do not
+    ascend with their starts (a long pattern, shorter ones inside it), several that end at the same byte (one event, the longest's
+    state: node.c:424-441 lists the others behind it), an occurrence that ends in the warm-up of the next work item, one at the
+    blob's last byte -- against the oracle, with the lists' entries left to k_dense_emit where a window holds two patterns."""
+    from oracle.pyoracle import Oracle
+    pats = [b"abcdefghijkl", b"bcdefg", b"cdef", b"fghijkl", b"hijkl", b"mnop", b"mnopq", b"wxyz", b"ghij", b"efghi"]
+    r = np.random.default_rng(5)
+    unit = b"abcdefghijkl....mnopq..wxyz.abcdefg.hijkl..efghij.mnop."
+    hays = []
+    for k in range(400):
+        body = bytearray()
+        while len(body) < 9000:
+            body += unit if r.integers(3) else bytes(r.integers(97, 123, size=int(r.integers(1, 40)), dtype=np.uint8))
+        hays.append(bytes(body[:int(r.integers(4090, 9000))]) + b"abcdefghijkl")
+    # (with "mnopq" next to "mnop" almost every item has a window of two patterns and goes to k_dense_emit; without it none has)
+    for pset in (pats, [q for q in pats if q != b"mnopq"]):
+        ds = synth.Dataset("dense_waves", *synth.pack(pset), *synth.pack(hays))
+        o = Oracle("port")
+        o.add_patterns(pset)
+        for opts in (dict(kernel=2, anchor_dense=1, small_path=0), dict(kernel=2, anchor_dense=1, small_path=0, chunk_bytes=1024),
+                     dict(kernel=2, anchor_dense=1, small_path=0, dense_hot=0, slab_events=2)):
+            res = resource_for(ds, **opts)
+            for find_all in (True, False):
+                pe, re_ = o.match_batch(ds.hay_blob, ds.hay_off, find_all)
+                for path in (host_match, device_match):
+                    p, rec = path(res, ds, find_all)
+                    assert np.array_equal(p, pe) and np.array_equal(rec, re_), (len(pset), opts, find_all, path.__name__)
+            assert int(res.stat("anchor_variant")) & DENSE
+            api.ahocorasick_deinit(res)
+        o.close()
