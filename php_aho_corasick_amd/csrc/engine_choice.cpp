@@ -97,6 +97,12 @@ int choose_strategy(acmi_handle *h, acmi_handle::FlySlot &F, uint64_t blob_bytes
     return C.cur;
 }
 
+// An untried (or backed-off) alternative is probed when the strategy in use costs more than this times what the alternative is
+// expected to: below the 1.3 x the cliff test allows (tests/test_gpu_cliffs.py) -- at 1.5 a 2,048-word list with 8 matches per
+// 8 KiB sat at 2.93 ms per GiB on the filter, 1.49 x the whole-automaton walk's expected 1.97 (measured: 1.92), and whether it was
+// ever probed was a matter of the third digit.
+constexpr float kProbeMargin = 1.25f;
+
 void learn_strategy(acmi_handle *h, const acmi_handle::FlySlot &F, double ms_per_gib, double density) {
     acmi_handle::ChoiceClass &C = h->choice[F.find_all ? 1 : 0][F.choice_class];
     const int s = F.strategy;
@@ -122,7 +128,7 @@ void learn_strategy(acmi_handle *h, const acmi_handle::FlySlot &F, double ms_per
             C.cur = s;
             // (... and what was waiting for a probe because the OLD strategy was so slow has to promise something against the new one)
             for (int a = 0; a < acmi_handle::kStratCount; ++a)
-                if ((C.pending >> a & 1u) && C.cost[s] <= 1.5f * (nominal_cost(h, a, F.blob_bytes, F.nh, density) + 0.06f * float(1ull << 30) / float(F.blob_bytes)))
+                if ((C.pending >> a & 1u) && C.cost[s] <= kProbeMargin * (nominal_cost(h, a, F.blob_bytes, F.nh, density) + 0.06f * float(1ull << 30) / float(F.blob_bytes)))
                     C.pending &= ~(1u << a);
             C.span[s] = 16;
             C.seen = 1;
@@ -150,7 +156,7 @@ void learn_strategy(acmi_handle *h, const acmi_handle::FlySlot &F, double ms_per
     for (int a = 0; a < acmi_handle::kStratCount; ++a) {
         if (a == s || C.wait[a] || !strategy_eligible(h, a, F.blob_bytes, F.nh, F.find_all)) continue;
         const float ref = nominal_cost(h, a, F.blob_bytes, F.nh, density) + 0.06f * float(1ull << 30) / float(F.blob_bytes);
-        if (C.cost[s] > (C.seen < 2 ? 4.0f : 1.5f) * ref) C.pending |= 1u << a;
+        if (C.cost[s] > (C.seen < 2 ? 4.0f : kProbeMargin) * ref) C.pending |= 1u << a;
     }
 }
 
