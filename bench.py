@@ -176,7 +176,7 @@ def dense_leg(torch, api, batch, synth, dev, nh=4096, k=16):
            "records": total, "count_ok": bool(total == expect), "ms_per_call": round(t * 1e3, 3),
            "matches_per_s": round(total / t, 1), "written_GB_per_s": round(total * 16 / t / 1e9, 1),
            "frac_of_hbm_peak": round(total * 16 / t / 1e9 / HBM_PEAK_GBS, 4), "overflow_items": int(res.stat("overflow_items")),
-           "kernel": KERNEL_NAMES.get(int(res.stat("kernel_used")), "?"), "choice_probes": int(res.stat("choice_probes"))}
+           "kernel": _kernel_name(res), "choice_probes": int(res.stat("choice_probes"))}
     api.ahocorasick_deinit(res)
     return out
 
@@ -225,9 +225,15 @@ def _two_in_flight(torch, batch, res, d_blob, d_off, n=6):
 KERNEL_NAMES = {0: "k_scan_simple", 1: "k_scan_lds", 2: "k_scan_anchor", 4: "k_walk_items", 5: "k_match_small", 6: "k_walk_tiles"}
 
 
+def _kernel_name(res):
+    """The scan kernel of the handle's last batch (kernel 6 is k_walk_chain when the whole automaton was walked in LDS)."""
+    k = int(res.stat("kernel_used"))
+    return "k_walk_chain" if k == 6 and int(res.stat("chain_walk_used")) else KERNEL_NAMES.get(k, "?")
+
+
 def _leg_summary(workload, blob_bytes, nh, total, ms, scan, walk, res, ok):
     algo = blob_bytes + 16 * total + 8 * nh  # SURVEY 8(d): 1 B per haystack byte + 16 B per record + 8 B per haystack
-    return {"workload": workload, "kernel": KERNEL_NAMES.get(int(res.stat("kernel_used")), "?"),
+    return {"workload": workload, "kernel": _kernel_name(res),
             "ms_per_call": round(ms, 4), "scan_kernel_ms": round(scan, 4), "walk_kernel_ms": round(walk, 4),
             "haystack_GB_per_s": round(blob_bytes / ms / 1e6, 1), "records": int(total), "check_ok": bool(ok),
             "ms_per_call_two_in_flight": round(_timed_calls.two_in_flight_ms, 4),
@@ -407,7 +413,7 @@ def density_leg(torch, api, batch, synth, dev, nh=1 << 17):
         ok = np.array_equal(prefix[:n_chk + 1], pe) and np.array_equal(rec[:int(pe[-1])], re_) and total == int(prefix[ds.n_haystacks]) * reps
         algo = d_blob.numel() + 16 * total + 8 * nh
         cells.append({"set": kind, "text": f"{level} planted occurrences per 8 KiB" if how == "plants" else f"prose, {int(level * 100)} % of it listed words",
-                      "records_per_8KiB": round(total / nh, 1), "ms_per_call": round(t, 4), "kernel": KERNEL_NAMES.get(int(res.stat("kernel_used")), "?"),
+                      "records_per_8KiB": round(total / nh, 1), "ms_per_call": round(t, 4), "kernel": _kernel_name(res),
                       "algorithmic_bytes": int(algo), "ms_per_algorithmic_GB": round(t / (algo / 1e9), 4),
                       "frac_whole_call": round(algo / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "check_ok": bool(ok),
                       "choice_probes": int(res.stat("choice_probes")), "choice_switches": int(res.stat("choice_switches"))})
