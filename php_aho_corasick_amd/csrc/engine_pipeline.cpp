@@ -409,7 +409,9 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     if (h->profile) HIPCHK(h, hipEventRecord(F.ev[2], st));
     if (h->items_ahead) HIPCHK(h, hipEventRecord(h->ev_scanned[slot_index], st));
     // the anchor kernel only flags byte runs; their exact walk is a kernel of its own (one thread per item)
-    if (kernel == 2) HIPCHK(h, launch_walk_runs(h->dA, B, max_items, int(fa.entry_bytes), int(fa.class_mode), st));
+    // (its LDS tile only where a walk may be needed: no verification by compare, or the batch before walked a cluster)
+    if (kernel == 2) HIPCHK(h, launch_walk_runs(h->dA, B, max_items, int(fa.entry_bytes), int(fa.class_mode), st,
+                                                h->dA.anchor_slot_pair == nullptr || h->fallback_bytes != 0 || !find_all));
     if (h->profile > 1) HIPCHK(h, hipEventRecord(F.ev[3], st));
 
     if (!find_all) {

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_runs(DevAutomaton A, Batc
         }
     }
     const uint32_t tile_rows = A.row_bytes ? (tile_bytes / A.row_bytes < A.trap ? tile_bytes / A.row_bytes : A.trap) : 0u;
-    {
+    if (tile_bytes != 0u) {   // (0: the handle's candidates are decided by text compares -- a walk, should one be needed, reads its rows through the L2)
         const uint4 *tsrc = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(A.lds_image) + A.tile_offset);
         uint4 *tdst = reinterpret_cast<uint4 *>(smem);
         const uint32_t n16 = (tile_rows * A.row_bytes + 15u) >> 4;  // <= 4096: at most 4 per thread, loaded back to back
@@ -140,13 +140,14 @@ static hipError_t launch_verify_dense(const DevAutomaton &A, const BatchArgs &B,
                                       hipStream_t st);
 
 hipError_t launch_walk_runs(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,
-                            hipStream_t st) {
+                            hipStream_t st, bool stage_tile) {
     if (max_items == 0) return hipSuccess;
     if (B.run_dense) return launch_verify_dense(A, B, max_items, entry_bytes, class_mode, st);
     const uint32_t blocks = uint32_t((max_items + kWalkThreads - 1) / kWalkThreads);
-    // (no tile at all when candidates are decided by text compares: 52 -> 49.5 us on the headline batch, 0.148 -> 0.141 ms on
-    // config 3 -- not worth walking every fallback cluster through L2)
-    const uint32_t tile_bytes = kWalkTileBytes;
+    // No tile while the handle's candidates are all decided by text compares (the engine asks for it again as soon as a batch
+    // walked a cluster: every fallback cluster through the L2 is not worth it): 64 KiB staged per 1,024 items were 52 -> 49.5 us on
+    // the headline batch, 0.148 -> 0.141 ms on config 3 -- and most of the kernel for haystacks of 256 B, an item each.
+    const uint32_t tile_bytes = stage_tile ? kWalkTileBytes : 0u;
     const uint32_t lds = tile_bytes;
     auto go = [&](auto fn) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));

@@ -22,7 +22,7 @@ void launch_uniform_offsets(uint64_t *offsets, uint64_t n, uint64_t haystack_byt
 hipError_t launch_scan(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int kernel,
                        int class_mode, int ilp, int group_quads, hipStream_t st, uint32_t *anchor_variant = nullptr);
 hipError_t launch_walk_runs(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,
-                            hipStream_t st);
+                            hipStream_t st, bool stage_tile = true);
 hipError_t launch_walk_items(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,
                              int ilp, hipStream_t st);
 // k_walk_tiles (k_tiles.hip, kernel 6): the exact walk with exact-sized ordered output in one pass.  Geometry: W bytes per lane,
