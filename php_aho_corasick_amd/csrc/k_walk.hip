@@ -365,6 +365,7 @@ __global__ __launch_bounds__(1024) void k_dense_decide(DevAutomaton A, BatchArgs
     const uint32_t *img = reinterpret_cast<const uint32_t *>(smem);
     const uint32_t mask = IMG ? img[0] : 0u;
     const uint32_t *ht = IMG ? img + img[1] : nullptr, *recs = IMG ? img + img[2] : nullptr, *tails = IMG ? img + img[3] : nullptr;
+    const uint2 *recs2 = reinterpret_cast<const uint2 *>(recs);
     const uint32_t hmul = IMG ? img[5] : 0u;
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t blob_end = B.offsets[B.n_haystacks];
@@ -398,33 +399,34 @@ __global__ __launch_bounds__(1024) void k_dense_decide(DevAutomaton A, BatchArgs
                     const bool decided = verify_candidate(A, p, n, it.floor, start, v, nv);
                     if (!decided || nv != 0) out = kDenseMany;
                 }
-            } else
-            if (active) {
-                if (start + 16u > room) {   // (the last bytes of the BLOB: an item's own end is no bound, what lies behind it is masked)
-                    out = start + 4u <= n ? kDenseMany : kDenseNone;   // (decided by k_dense_emit, which reads single bytes)
-                } else {
-                    const uint4 tx = load16u(p + start);
-                    uint32_t slot = ((tx.x * hmul) >> 16) & mask, e1;
-                    for (;;) {
-                        e1 = ht[2u * slot + 1u];
-                        if (e1 == 0xFFFFFFFFu || ht[2u * slot] == tx.x) break;
-                        slot = (slot + 1u) & mask;
-                    }
-                    if (e1 != 0xFFFFFFFFu) {
-                        const uint32_t first = e1 & 0xFFFFu, count = e1 >> 16;
+            } else {
+                // (the 16 bytes at every active window at once, then the LDS look-ups: one pass without a branch for the usual window --
+                // key found at its first slot or not there, one pattern with that prefix)
+                const bool readable = active && start + 16u <= room;   // (not: the last bytes of the BLOB -- an item's own end is no bound, what lies behind it is masked)
+                if (active && !readable) out = start + 4u <= n ? kDenseMany : kDenseNone;   // (decided by k_dense_emit, which reads single bytes)
+                const uint4 tx = load16u(readable ? p + start : A.pad16);
+                uint32_t slot = ((tx.x * hmul) >> 16) & mask;
+                const uint2 *ht2 = reinterpret_cast<const uint2 *>(ht);
+                uint2 e = ht2[slot];
+                while (readable && e.y != 0xFFFFFFFFu && e.x != tx.x) {
+                    slot = (slot + 1u) & mask;
+                    e = ht2[slot];
+                }
+                if (readable && e.y != 0xFFFFFFFFu) {
+                    const uint32_t first = e.y & 0xFFFFu, count = e.y >> 16;
 #pragma unroll 1
-                        for (uint32_t k = 0; k < count; ++k) {
-                            const uint32_t r0 = recs[2u * (first + k)], r1 = recs[2u * (first + k) + 1u];
-                            const uint32_t len = r0 >> 24, toff = r1 & 0xFFFFu;
-                            if (start < it.floor || start + len > n) continue;
-                            const uint32_t tl = len - 4u;
-                            const uint32_t m0 = tl >= 4u ? 0xFFFFFFFFu : (1u << (8u * tl)) - 1u;
-                            const uint32_t m1 = tl >= 8u ? 0xFFFFFFFFu : tl > 4u ? (1u << (8u * (tl - 4u))) - 1u : 0u;
-                            const uint32_t m2 = tl >= 12u ? 0xFFFFFFFFu : tl > 8u ? (1u << (8u * (tl - 8u))) - 1u : 0u;
-                            const uint32_t diff = ((tx.y ^ tails[toff]) & m0) | ((tx.z ^ tails[toff + 1u]) & m1) | ((tx.w ^ tails[toff + 2u]) & m2);
-                            if (diff) continue;
-                            out = out == kDenseNone ? first + k : kDenseMany;
-                        }
+                    for (uint32_t k = 0; k < count; ++k) {
+                        const uint2 rr = recs2[first + k];   // (the records begin at an even word of the image: automaton.cpp)
+                        const uint32_t r0 = rr.x, r1 = rr.y;
+                        const uint32_t len = r0 >> 24, toff = r1 & 0xFFFFu;
+                        const uint32_t tl = len - 4u;
+                        // mask of the tail's bytes: tl of the 12 behind the window's four
+                        const uint64_t lo64 = tl >= 8u ? ~0ull : (1ull << (8u * tl)) - 1ull;
+                        const uint32_t m0 = uint32_t(lo64), m1 = uint32_t(lo64 >> 32);
+                        const uint32_t m2 = tl > 8u ? 0xFFFFFFFFu >> (8u * (12u - tl)) : 0u;
+                        const uint32_t diff = ((tx.y ^ tails[toff]) & m0) | ((tx.z ^ tails[toff + 1u]) & m1) | ((tx.w ^ tails[toff + 2u]) & m2);
+                        const bool hit = diff == 0u && start >= it.floor && start + len <= n;
+                        if (hit) out = out == kDenseNone ? first + k : kDenseMany;
                     }
                 }
             }
@@ -457,7 +459,8 @@ __global__ __launch_bounds__(1024) void k_dense_decide(DevAutomaton A, BatchArgs
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const bool have = lane < base;
                 const uint2 k = have ? kept[lane] : make_uint2(0u, 0u);
-                const uint32_t r0 = have ? recs[2u * k.y] : 0u, r1 = have ? recs[2u * k.y + 1u] : 0u;
+                const uint2 rr = have ? recs2[k.y] : make_uint2(0u, 0u);
+                const uint32_t r0 = rr.x, r1 = rr.y;
                 uint32_t oc = r1 >> 16;
                 if (have && oc == 65535u) oc = A.out_count[r0 & 0xFFFFFFu];
                 const uint32_t j = k.x + (r0 >> 24) - 1u;          // last byte of the occurrence
@@ -471,7 +474,8 @@ __global__ __launch_bounds__(1024) void k_dense_decide(DevAutomaton A, BatchArgs
                 uint32_t before, n_rec_lo, n_rec_hi = 0;
                 if (ascending) {
                     before = __builtin_amdgcn_mbcnt_hi(uint32_t(vm >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(vm), 0u));
-                    n_rec_lo = uint32_t(__builtin_amdgcn_readlane(int(wave_inclusive_sum(valid ? oc : 0u)), 63));
+                    if (__ballot(valid && oc != 1u) == 0) n_rec_lo = uint32_t(__builtin_popcountll(vm));   // (a record per event: the usual list)
+                    else n_rec_lo = uint32_t(__builtin_amdgcn_readlane(int(wave_inclusive_sum(valid ? oc : 0u)), 63));
                 } else {
                     bool dup = false;
                     for (uint64_t m = vm; m != 0; m &= m - 1) {        // (entries ascend by start: of equal ends the first is the longest)
