@@ -42,7 +42,7 @@ base = synth.bench_batch(8192, HL, seed=1, planted=True)
 for c in cases:
     if c == "short8":
         sp = synth.generate("short", 41, 8, 2, 6, 1, 16, b"abcdef")
-        run(c, sp.patterns(), base.hay_blob, nh, [dict(kernel=6)] if os.environ.get("ONLY6") else [dict(kernel=4), dict(kernel=6), dict(kernel=6, tile_w=32), dict(kernel=3)])
+        run(c, sp.patterns(), base.hay_blob, nh, [dict(kernel=6)] if os.environ.get("ONLY6") else [dict(kernel=4), dict(kernel=6), dict(kernel=6, chain_walk=1), dict(kernel=6, tile_w=32), dict(kernel=3)])
     elif c == "split":
         sp = synth.generate("short", 41, 8, 2, 6, 1, 16, b"abcdef")
         run(c, base.patterns() + sp.patterns(), base.hay_blob, nh, [dict(kernel=3), dict(kernel=6, split=0), dict(kernel=4, split=0)])
