@@ -74,7 +74,7 @@ template <typename E, int MODE>
 __global__ __launch_bounds__(kSmallThreads) void k_match_small(DevAutomaton A, const uint64_t *offsets, const uint8_t *blob,
                                                                uint32_t nh, uint32_t find_all, uint32_t max_pattern_length,
                                                                uint64_t *out_summary, uint64_t *out_prefix, uint4 *out_records,
-                                                               uint32_t cap, SmallLayout Y, uint64_t seq) {
+                                                               uint32_t cap, SmallLayout Y, uint64_t seq, uint32_t n_bytes) {
     // LDS, laid out by the host for THIS batch (small_layout): the bytes and per-item arrays take what the batch needs, the tile
     // of the transition table everything else -- one 8 KiB haystack leaves ~ 140 KiB to the tile (every state of the first nine
     // trie levels of the headline set) where a fixed 64 KiB for the bytes left 36: with two waves on the chip nothing hides a row
@@ -98,23 +98,28 @@ __global__ __launch_bounds__(kSmallThreads) void k_match_small(DevAutomaton A, c
     const bool stamps = (find_all & 2u) != 0u;
     find_all &= 1u;
     auto stamp = [&](int i) { if (stamps && t == 0) out_summary[4 + i] = wall_clock64() - t_start; };
+    // offsets and haystack bytes (16 per lane, coalesced, 16-byte aligned by the host) from pinned host memory, requested together
+    // -- the bytes' length comes with the launch: one trip over PCIe, not two (k_match_small_chain below has the story)
+    const uint32_t n16 = (n_bytes + 15u) / 16u;
+    const uint4 *src = reinterpret_cast<const uint4 *>(blob);
     const uint64_t off0 = offsets[0];
-    // offsets -> LDS (relative to the first one), items per haystack
-    for (uint32_t h = t; h <= nh; h += kSmallThreads) hay_off[h] = uint32_t(offsets[h] - off0);
-    __syncthreads();
-    const uint32_t n_bytes = hay_off[nh];
-    for (uint32_t h = t; h < kSmallMaxHay + 1; h += kSmallThreads)
-        item_base[h] = h < nh ? (hay_off[h + 1] - hay_off[h] + kChunk - 1) / kChunk : 0u;
-    {   // haystack bytes: 16 bytes per lane, coalesced, from pinned host memory (16-byte aligned by the host)
-        const uint4 *src = reinterpret_cast<const uint4 *>(blob);
+    const uint64_t off_t = t <= nh ? offsets[t] : 0ull;
+    const uint4 text_t = t < n16 ? src[t] : make_uint4(0u, 0u, 0u, 0u);
+    {
         uint4 *dst = reinterpret_cast<uint4 *>(in_bytes);
-        for (uint32_t i = t; i < (n_bytes + 15u) / 16u; i += kSmallThreads) dst[i] = src[i];
         const uint32_t tile_rows_b = A.row_bytes ? (Y.tile_bytes / A.row_bytes < A.trap ? Y.tile_bytes / A.row_bytes : A.trap) * A.row_bytes : 0u;
         const uint4 *tsrc = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(A.lds_image) + A.tile_offset);
         uint4 *tdst = reinterpret_cast<uint4 *>(smem + Y.in_bytes);
         for (uint32_t i = t; i < (tile_rows_b + 15u) / 16u; i += kSmallThreads) tdst[i] = tsrc[i];
         if (MODE == 0 && t < 256) cls[t] = A.class_off[t];
+        if (t < n16) dst[t] = text_t;
+        for (uint32_t i = t + kSmallThreads; i < n16; i += kSmallThreads) dst[i] = src[i];
+        if (t <= nh) hay_off[t] = uint32_t(off_t - off0);   // (relative to the first one)
+        for (uint32_t h = t + kSmallThreads; h <= nh; h += kSmallThreads) hay_off[h] = uint32_t(offsets[h] - off0);
     }
+    __syncthreads();
+    for (uint32_t h = t; h < kSmallMaxHay + 1; h += kSmallThreads)   // items per haystack
+        item_base[h] = h < nh ? (hay_off[h + 1] - hay_off[h] + kChunk - 1) / kChunk : 0u;
     __syncthreads();
     stamp(0);   // offsets, bytes and tile are in LDS
     const uint32_t tile_rows = A.row_bytes ? (Y.tile_bytes / A.row_bytes < A.trap ? Y.tile_bytes / A.row_bytes : A.trap) : 0u;
@@ -264,7 +269,7 @@ static bool small_chain_layout(const DevAutomaton &A, uint32_t span, uint32_t nh
 template <int MODE>
 __global__ __launch_bounds__(kSmallThreads) void k_match_small_chain(DevAutomaton A, const uint64_t *offsets, const uint8_t *blob, uint32_t nh, uint32_t find_all,
                                                                      uint32_t max_pattern_length, uint64_t *out_summary, uint64_t *out_prefix, uint4 *out_records,
-                                                                     uint32_t cap, SmallChainLayout Y, uint64_t seq) {
+                                                                     uint32_t cap, SmallChainLayout Y, uint64_t seq, uint32_t n_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t kChunk = Y.chunk, kItems = Y.max_items;
     const uint32_t img_bytes = (A.chain_img_bytes + 15u) & ~15u;
@@ -281,21 +286,28 @@ __global__ __launch_bounds__(kSmallThreads) void k_match_small_chain(DevAutomato
     const bool stamps = (find_all & 2u) != 0u;
     find_all &= 1u;
     auto stamp = [&](int i) { if (stamps && t == 0) out_summary[4 + i] = wall_clock64() - t_start; };
+    // Offsets and text lie in the host's pinned memory: a read is a trip over PCIe, ~ 2 us.  The text's length comes with the launch
+    // (n_bytes), so that its first 16 KiB, every thread's offset and the first offset are REQUESTED TOGETHER, the image's loads
+    // (device memory) behind them: one trip where the text used to wait for the offsets' (staging 4.4 us of a 15 us kernel).
+    const uint32_t n16 = (n_bytes + 15u) / 16u;
+    const uint4 *src = reinterpret_cast<const uint4 *>(blob);
     const uint64_t off0 = offsets[0];
-    for (uint32_t h = t; h <= nh; h += kSmallThreads) hay_off[h] = uint32_t(offsets[h] - off0);
-    __syncthreads();
-    const uint32_t n_bytes = hay_off[nh];
-    for (uint32_t h = t; h < nh + 1u; h += kSmallThreads)
-        item_base[h] = h < nh ? (hay_off[h + 1] - hay_off[h] + kChunk - 1) / kChunk : 0u;
+    const uint64_t off_t = t <= nh ? offsets[t] : 0ull;
+    const uint4 text_t = t < n16 ? src[t] : make_uint4(0u, 0u, 0u, 0u);
     {
-        const uint4 *src = reinterpret_cast<const uint4 *>(blob);
-        uint4 *dst = reinterpret_cast<uint4 *>(in_bytes);
-        for (uint32_t i = t; i < (n_bytes + 15u) / 16u; i += kSmallThreads) dst[i] = src[i];
         const uint4 *isrc = reinterpret_cast<const uint4 *>(A.chain_img);   // (the allocation has 16 bytes of slack)
         uint4 *idst = reinterpret_cast<uint4 *>(smem);
         for (uint32_t i = t; i < (img_bytes >> 4); i += kSmallThreads) idst[i] = isrc[i];
         if (MODE == 0 && t < 256) cls[t] = A.class_off[t];
+        uint4 *dst = reinterpret_cast<uint4 *>(in_bytes);
+        if (t < n16) dst[t] = text_t;
+        for (uint32_t i = t + kSmallThreads; i < n16; i += kSmallThreads) dst[i] = src[i];
+        if (t <= nh) hay_off[t] = uint32_t(off_t - off0);
+        for (uint32_t h = t + kSmallThreads; h <= nh; h += kSmallThreads) hay_off[h] = uint32_t(offsets[h] - off0);
     }
+    __syncthreads();
+    for (uint32_t h = t; h < nh + 1u; h += kSmallThreads)
+        item_base[h] = h < nh ? (hay_off[h + 1] - hay_off[h] + kChunk - 1) / kChunk : 0u;
     __syncthreads();
     stamp(0);
     const uint32_t n_items = small_scan(item_base, nh + 1, wave_tmp);
@@ -443,7 +455,7 @@ hipError_t launch_match_small(const DevAutomaton &A, const uint64_t *offsets, co
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(kSmallLds));
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(fn, dim3(1), dim3(kSmallThreads), YC.lds, st, A, offsets, blob, nh, uint32_t(find_all ? 1 : 0) | (small_trace() ? 2u : 0u),
-                               max_pattern_length, out_summary, out_prefix, static_cast<uint4 *>(out_records), cap, YC, seq);
+                               max_pattern_length, out_summary, out_prefix, static_cast<uint4 *>(out_records), cap, YC, seq, span_bytes);
             return hipGetLastError();
         };
         return class_mode == 1 ? goc(k_match_small_chain<1>) : goc(k_match_small_chain<0>);
@@ -455,7 +467,7 @@ hipError_t launch_match_small(const DevAutomaton &A, const uint64_t *offsets, co
         if (e != hipSuccess) return e;
         const bool trace = small_trace();
         hipLaunchKernelGGL(fn, dim3(1), dim3(kSmallThreads), lds, st, A, offsets, blob, nh, uint32_t(find_all ? 1 : 0) | (trace ? 2u : 0u),
-                           max_pattern_length, out_summary, out_prefix, static_cast<uint4 *>(out_records), cap, Y, seq);
+                           max_pattern_length, out_summary, out_prefix, static_cast<uint4 *>(out_records), cap, Y, seq, span_bytes);
         return hipGetLastError();
     };
     if (entry_bytes == 2) return class_mode == 1 ? go(k_match_small<uint16_t, 1>) : go(k_match_small<uint16_t, 0>);
