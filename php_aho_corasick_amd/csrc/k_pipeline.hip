@@ -149,7 +149,7 @@ constexpr int kExpandPerThread = 1;
 constexpr int kExpandTile = kExpandThreads * kExpandPerThread;
 
 template <bool SCAN>
-__global__ __launch_bounds__(kExpandThreads) void k_expand(DevAutomaton A, BatchArgs B, uint64_t *rec_base, uint4 *out, uint64_t cap,
+__global__ __launch_bounds__(kExpandThreads, 8) void k_expand(DevAutomaton A, BatchArgs B, uint64_t *rec_base, uint4 *out, uint64_t cap,
                                                             uint64_t *prefix, uint32_t *host_counters, uint32_t *next_sync,
                                                             uint32_t next_sync_words, uint32_t *ticket, uint64_t *status,
                                                             const uint32_t *bad_offsets, uint32_t *next_isync, uint32_t next_isync_words) {
