@@ -151,6 +151,7 @@ struct acmi_handle {
     int group_quads = 8;
     int small_path = 1;   // 1: host batches of <= 64 KiB / <= 1024 haystacks take the one-launch kernel
     uint8_t *pin_small = nullptr;  // pinned host memory of the small path: [summary | prefix | records | offsets | bytes]
+    uint8_t *pin_small_dev = nullptr;   // its device address
     uint64_t small_seq = 0;        // calls of the small path so far: the kernel stores it into the summary when it is done
     int wave_items = 0;   // 0 automatic, else 1..64 items per wave batch of the anchor kernel
     int persistent = -1;  // -1 automatic, 0 one workgroup per 1024 x ILP items, 1 persistent workgroups

@@ -780,9 +780,12 @@ int run_small(acmi_handle *h, const uint8_t *blob, const uint64_t *offsets, size
     uint8_t *pin = h->pin_small;
     std::memcpy(pin + kSmallOffsetsOff, offsets, (nh + 1) * 8);
     if (span) std::memcpy(pin + kSmallBytesOff, blob + offsets[0], span);
-    void *dev = nullptr;
-    HIPCHK(h, hipHostGetDevicePointer(&dev, pin, 0));
-    uint8_t *d = static_cast<uint8_t *>(dev);
+    if (!h->pin_small_dev) {   // (asked once: the mapping does not move)
+        void *dev = nullptr;
+        HIPCHK(h, hipHostGetDevicePointer(&dev, pin, 0));
+        h->pin_small_dev = static_cast<uint8_t *>(dev);
+    }
+    uint8_t *d = h->pin_small_dev;
     const FlatAutomaton &fa = h->aut.flat();
     hipStream_t st = h->stream;
     if (h->profile) HIPCHK(h, hipEventRecord(h->ev[0], st));
