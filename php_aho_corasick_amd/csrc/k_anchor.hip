@@ -17,8 +17,7 @@ hipError_t launch_anchor(const DevAutomaton &A, const BatchArgs &B, uint64_t max
     const uint32_t blocks = B.persistent ? uint32_t(std::min<uint64_t>(want, uint64_t(std::max(1, num_cus() - int(B.reserve_cus))))) : uint32_t(want);
     auto go = [&](auto fn) {
         const uint32_t lds = kAnchorLdsBytes + (kLdsThreads / 64u) * kStageSlots * 16u;  // table + run staging = 160 KiB
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), uint32_t(lds));
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(fn, dim3(blocks), dim3(kLdsThreads), lds, st, A, B);
         return hipGetLastError();

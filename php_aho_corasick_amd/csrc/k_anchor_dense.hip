@@ -7,8 +7,7 @@ namespace acmi {
 hipError_t launch_anchor_dense(const DevAutomaton &A, const BatchArgs &B, uint32_t blocks, hipStream_t st) {
     auto go = [&](auto fn) {
         const uint32_t lds = kAnchorLdsBytes + (kLdsThreads / 64u) * kStageSlots * 16u;  // table + run staging = 160 KiB
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), uint32_t(lds));
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(fn, dim3(blocks), dim3(kLdsThreads), lds, st, A, B);
         return hipGetLastError();

@@ -517,7 +517,7 @@ hipError_t launch_walk_chain(const DevAutomaton &A, const BatchArgs &B, uint64_t
     const uint32_t lds = img + (class_mode == 0 ? 512u : 0u);
     // (always the whole grid: the logs are per wave of THIS grid -- k_chain_emit finds a tile's by t % n_waves)
     auto go = [&](auto fn) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), uint32_t(lds));
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(fn, dim3(chain_grid()), dim3(kChainThreads), lds, st, A, B, T);
         return hipGetLastError();
@@ -539,7 +539,7 @@ hipError_t launch_chain_emit(const DevAutomaton &A, const BatchArgs &B, uint64_t
     if (lds > 160u * 1024u) { lds = 0; T.debug = 1u; }   // (a set with very many final states: the heads from global memory)
     const uint32_t per_cu = lds <= 80u * 1024u ? 2u : 1u;
     const uint32_t blocks = uint32_t(std::min<uint64_t>((tiles + 15u) / 16u, uint64_t(num_cus()) * per_cu));
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_chain_emit), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(k_chain_emit), uint32_t(lds));
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_chain_emit, dim3(blocks), dim3(kEmitThreads), lds, st, A, B, T);
     return hipGetLastError();

@@ -266,7 +266,7 @@ void launch_refill(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items
         const uint32_t lds = lds_waves + 512u + tile_budget;
         const uint32_t blocks = uint32_t(std::min<uint64_t>((max_items + per_block - 1) / per_block, uint64_t(num_cus()) * std::max<uint32_t>(per_cu, 1u)));
         auto go = [&](auto fn) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+            (void)ensure_dynamic_lds(reinterpret_cast<const void *>(fn), uint32_t(lds));
             hipLaunchKernelGGL(fn, dim3(blocks), dim3(kRefillThreads), lds, st, A, B, rec_base, static_cast<uint4 *>(out), cap, tile_budget);
         };
         if (entry_bytes == 2) {

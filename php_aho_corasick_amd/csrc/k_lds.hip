@@ -257,8 +257,7 @@ template <typename E, int MODE, int ILP, int G>
 static hipError_t launch_lds_t(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, uint32_t lds_bytes,
                                hipStream_t st) {
     auto fn = k_scan_lds<E, MODE, ILP, G>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), uint32_t(lds_bytes));
     if (e != hipSuccess) return e;
     // persistent: at most one workgroup per CU (the tile fills the CU's LDS), fewer for small batches
     const uint64_t per_block = uint64_t(kLdsThreads) * ILP;

@@ -1,7 +1,21 @@
 // k_misc.hip -- k_stream_read, the device-side automaton build, search and replace, split-set merge, the exchange's packing kernel
+#include <mutex>
+#include <unordered_map>
 #include "kdev.hpp"
 
 namespace acmi {
+
+hipError_t ensure_dynamic_lds(const void *kernel, uint32_t bytes) {
+    static std::mutex m;
+    static std::unordered_map<const void *, uint32_t> have;
+    std::lock_guard<std::mutex> g(m);
+    uint32_t &cur = have[kernel];
+    if (bytes <= cur) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes));
+    if (e == hipSuccess) cur = bytes;
+    return e;
+}
+
 
 // ------------------------------------------------------------------------------------------
 // k_stream_read: plain coalesced 16 B/lane streaming read (xor-reduced so it cannot be elided).

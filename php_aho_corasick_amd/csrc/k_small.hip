@@ -444,13 +444,6 @@ bool small_trace() {
     return on;
 }
 
-// hipFuncSetAttribute once per kernel, not per launch (a driver call, ~ 1 us on the path of every single match)
-template <typename F>
-static hipError_t small_lds_once(F fn) {
-    static hipError_t done = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(kSmallLds));
-    return done;
-}
-
 hipError_t launch_match_small(const DevAutomaton &A, const uint64_t *offsets, const uint8_t *blob, uint32_t nh, int find_all,
                               uint32_t max_pattern_length, int entry_bytes, int class_mode, uint64_t *out_summary,
                               uint64_t *out_prefix, void *out_records, uint32_t cap, uint32_t span_bytes, uint64_t seq, hipStream_t st) {
@@ -459,7 +452,7 @@ hipError_t launch_match_small(const DevAutomaton &A, const uint64_t *offsets, co
     // the whole automaton in LDS when the set carries the chain-compressed image and the batch fits beside it (one 8 KiB haystack does)
     if (!no_chain && A.trap + 1u < A.n_states && small_chain_layout(A, span_bytes, nh, class_mode == 0, YC)) {
         auto goc = [&](auto fn) {
-            hipError_t e = small_lds_once(fn);
+            hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), kSmallLds);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(fn, dim3(1), dim3(kSmallThreads), YC.lds, st, A, offsets, blob, nh, uint32_t(find_all ? 1 : 0) | (small_trace() ? 2u : 0u),
                                max_pattern_length, out_summary, out_prefix, static_cast<uint4 *>(out_records), cap, YC, seq, span_bytes);
@@ -470,7 +463,7 @@ hipError_t launch_match_small(const DevAutomaton &A, const uint64_t *offsets, co
     const SmallLayout Y = small_layout(span_bytes, nh, A.trap * A.row_bytes, class_mode == 0);
     const uint32_t lds = Y.in_bytes + Y.tile_bytes + Y.max_items * (kSmallEvents * 8u + 8u) + (kSmallMaxHay + 8u) * 8u + 64u + 512u;
     auto go = [&](auto fn) {
-        hipError_t e = small_lds_once(fn);
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), kSmallLds);
         if (e != hipSuccess) return e;
         const bool trace = small_trace();
         hipLaunchKernelGGL(fn, dim3(1), dim3(kSmallThreads), lds, st, A, offsets, blob, nh, uint32_t(find_all ? 1 : 0) | (trace ? 2u : 0u),

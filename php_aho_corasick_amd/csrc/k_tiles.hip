@@ -672,7 +672,7 @@ hipError_t launch_walk_tiles(const DevAutomaton &A, const BatchArgs &B, uint64_t
     const uint64_t groups = (max_items + uint64_t(kTilesWaves) * T.R - 1u) / (uint64_t(kTilesWaves) * T.R);
     const uint32_t blocks = uint32_t(std::min<uint64_t>(groups, tiles_grid() - 2u * std::min<uint32_t>(B.reserve_cus, tiles_grid() / 2u - 1u)));
     auto go = [&](auto fn) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), uint32_t(lds));
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(fn, dim3(blocks), dim3(kTilesThreads), lds, st, A, B, T);
         return hipGetLastError();

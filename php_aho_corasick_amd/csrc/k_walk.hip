@@ -150,7 +150,7 @@ hipError_t launch_walk_runs(const DevAutomaton &A, const BatchArgs &B, uint64_t 
     const uint32_t tile_bytes = stage_tile ? kWalkTileBytes : 0u;
     const uint32_t lds = tile_bytes;
     auto go = [&](auto fn) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), uint32_t(lds));
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(fn, dim3(blocks), dim3(kWalkThreads), lds, st, A, B, tile_bytes);
         return hipGetLastError();
@@ -629,7 +629,7 @@ static hipError_t launch_verify_dense(const DevAutomaton &A, const BatchArgs &B,
         uint32_t *results = reinterpret_cast<uint32_t *>(B.runs) + B.run_stride * uint64_t(B.run_cap);
         const bool image = A.dense_image != nullptr;
         const uint32_t lds1 = image ? ((A.dense_image_words * 4u + 15u) & ~15u) + 16u * 64u * 8u : 16u;   // (+ the waves' kept entries)
-        hipError_t e = image ? hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_decide<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds1))
+        hipError_t e = image ? ensure_dynamic_lds(reinterpret_cast<const void *>(k_dense_decide<true>), uint32_t(lds1))
                              : hipSuccess;
         if (e != hipSuccess) return e;
         const uint32_t per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(2u, (160u * 1024u) / std::max<uint32_t>(lds1, 1u)));
@@ -648,7 +648,7 @@ static hipError_t launch_verify_dense(const DevAutomaton &A, const BatchArgs &B,
     }
     const uint32_t lds = 16u;   // (no image: candidates are verified through the tables in global memory)
     auto go = [&](auto fn) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), uint32_t(lds));
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(fn, dim3(blocks), dim3(kWalkThreads), lds, st, A, B);
         return hipGetLastError();

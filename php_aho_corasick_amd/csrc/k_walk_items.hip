@@ -8,7 +8,7 @@ hipError_t launch_walk_items(const DevAutomaton &A, const BatchArgs &B, uint64_t
     if (max_items == 0) return hipSuccess;
     const uint32_t lds = kItemsTileBytes + (class_mode == 0 ? 512u : 0u);
     auto go = [&](auto fn) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), uint32_t(lds));
         if (e != hipSuccess) return e;
         const uint32_t blocks = uint32_t((max_items + kWalkThreads - 1) / kWalkThreads);
         hipLaunchKernelGGL(fn, dim3(blocks), dim3(kWalkThreads), lds, st, A, B, static_cast<const uint64_t *>(nullptr), static_cast<uint4 *>(nullptr),

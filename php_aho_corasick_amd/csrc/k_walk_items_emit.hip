@@ -9,7 +9,7 @@ void launch_walk_items_emit(const DevAutomaton &A, const BatchArgs &B, uint64_t 
     const uint32_t lds = kItemsTileBytes + (class_mode == 0 ? 512u : 0u);
     const uint32_t blocks = uint32_t((max_items + kWalkThreads - 1) / kWalkThreads);   // (workgroups past the list's end leave at once)
     auto go = [&](auto fn) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        (void)ensure_dynamic_lds(reinterpret_cast<const void *>(fn), uint32_t(lds));
         hipLaunchKernelGGL(fn, dim3(blocks), dim3(kWalkThreads), lds, st, A, B, rec_base, static_cast<uint4 *>(out), cap);
     };
     if (entry_bytes == 2) { if (class_mode == 1) go(k_walk_items<uint16_t, 1, 4, true>); else go(k_walk_items<uint16_t, 0, 4, true>); }

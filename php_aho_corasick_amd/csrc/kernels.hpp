@@ -10,6 +10,10 @@
 
 namespace acmi {
 
+// hipFuncAttributeMaxDynamicSharedMemorySize of a kernel raised to `bytes` when it is not there yet: the driver call (~ 1 us) once
+// per kernel and size, not per launch (k_misc.hip)
+hipError_t ensure_dynamic_lds(const void *kernel, uint32_t bytes);
+
 bool small_trace();   // ACMI_SMALL_TRACE is set (read once: k_small.hip's launch and engine_pipeline.cpp's run_small share it)
 
 // single-pass scans (kdev.hpp, k_pipeline.hip): tiles of 2048 elements, one status word per tile
