@@ -7,9 +7,11 @@ namespace acmi {
 
 hipError_t ensure_dynamic_lds(const void *kernel, uint32_t bytes) {
     static std::mutex m;
-    static std::unordered_map<const void *, uint32_t> have;
+    static std::unordered_map<uint64_t, uint32_t> have;   // (device, kernel) -> what its attribute is: the attribute is the device's
+    int dev = 0;
+    (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> g(m);
-    uint32_t &cur = have[kernel];
+    uint32_t &cur = have[(uint64_t(uint32_t(dev)) << 56) ^ uint64_t(reinterpret_cast<uintptr_t>(kernel))];
     if (bytes <= cur) return hipSuccess;
     const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes));
     if (e == hipSuccess) cur = bytes;
