@@ -403,6 +403,9 @@ __global__ __launch_bounds__(kEmitThreads) void k_chain_emit(DevAutomaton A, Bat
     for (uint64_t t = uint64_t(blockIdx.x) * (kEmitThreads / 64u) + (threadIdx.x >> 6); t < tiles_all; t += n_waves) {
         const uint2 info = T.tile_info[t];
         if (info.y == 0u) continue;
+        // (a tile whose events did not fit its wave's log wrote none of them: the host has the batch run again with a bigger log,
+        // counters[19] -- nothing of this tile may be read here, its entries would be another tile's or lie behind the log's end)
+        if (uint64_t(info.x) + info.y > T.log_cap) continue;
         const uint32_t *ev = T.log + (t % T.n_waves) * uint64_t(T.log_cap) + info.x;
         const uint64_t first_item = t * T.R;
         const Piece pa = chain_piece(A, B, T, total_items, first_item, 2u * lane), pz = chain_piece(A, B, T, total_items, first_item, 2u * lane + 1u);

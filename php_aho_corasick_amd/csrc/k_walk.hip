@@ -148,7 +148,9 @@ hipError_t launch_walk_runs(const DevAutomaton &A, const BatchArgs &B, uint64_t 
     // walked a cluster: every fallback cluster through the L2 is not worth it): 64 KiB staged per 1,024 items were 52 -> 49.5 us on
     // the headline batch, 0.148 -> 0.141 ms on config 3 -- and most of the kernel for haystacks of 256 B, an item each.
     const uint32_t tile_bytes = stage_tile ? kWalkTileBytes : 0u;
-    const uint32_t lds = tile_bytes;
+    // (without a tile the workgroup still owns one row's worth of LDS: walk_fast reads row 0's column unconditionally and discards
+    // the value -- the read must lie inside the allocation)
+    const uint32_t lds = tile_bytes ? tile_bytes : std::max<uint32_t>(A.row_bytes, 16u);
     auto go = [&](auto fn) {
         hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), uint32_t(lds));
         if (e != hipSuccess) return e;

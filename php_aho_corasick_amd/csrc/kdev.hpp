@@ -263,33 +263,6 @@ __device__ __forceinline__ uint64_t chain_exclusive(uint64_t *status, uint32_t t
     return before;
 }
 
-// The look-back alone (all 64 lanes call): the sum of all tiles before `tile`, whose own word somebody else publishes.
-__device__ __forceinline__ uint64_t chain_before(const uint64_t *status, uint32_t tile) {
-    const uint32_t lane = threadIdx.x & 63u;
-    uint64_t before = 0;
-    uint32_t end = tile;  // tiles [.., end) are still to be added
-    while (end != 0u) {
-        const bool mine = lane < end;
-        uint64_t v = 0;
-        if (mine) v = chain_load(status + (end - 1u - lane));  // lane 0 = the nearest tile
-        const uint64_t inc = __ballot(mine && (v >> 62) == 2u);
-        const uint64_t missing = __ballot(mine && (v >> 62) == 0u);
-        const uint32_t stop = inc ? uint32_t(__builtin_ctzll(inc)) : 64u;
-        const uint32_t gap = missing ? uint32_t(__builtin_ctzll(missing)) : 64u;
-        if (gap < stop && gap < 64u) {  // a nearer tile has not published yet: look again
-            __builtin_amdgcn_s_sleep(1);
-            continue;
-        }
-        uint64_t part = (mine && lane <= stop) ? (v & kChainVal) : 0ull;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
-        before += part;
-        if (stop < 64u || end <= 64u) break;
-        end -= 64u;
-    }
-    return before;
-}
-
 // Block-wide exclusive scan of kScanPerThread values per thread; returns this thread's exclusive base inside the
 // tile and, through tile_sum (valid in every thread), the tile total.
 __device__ __forceinline__ uint64_t tile_exclusive(const uint64_t (&v)[kScanPerThread], uint64_t *wave_sums, uint64_t &tile_sum) {
