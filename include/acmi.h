@@ -372,6 +372,10 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *                    trie depth <= 2 two bytes past the window start: 0 = off, 1 (default) = when some 3-gram
  *                    over the patterns' first-byte alphabet is not a trie path (else it cannot fire on
  *                    in-alphabet text), 2 = always                                        [any time]
+ *   "wave_runs"      work items with more than three candidate windows of the anchor filter are decided a wave per item, a lane
+ *                    per window (k_runs_wave, enqueued while batches report such items): 1 (default) yes, 0 = one lane per
+ *                    item whatever it holds.  Same records either way ("busy_items", "max_windows", "serial_items",
+ *                    "wave_runs_used")                                                          [any time]
  *   "refill"         drain of work items whose events overflowed their slab (dense-match inputs):
  *                    1 = one thread per item, 2 = one wave per item with whole-row record stores,
  *                    0 = automatic (default): batches scanned by the whole-item walk (items of <= 1 KiB) are drained by the

@@ -96,8 +96,14 @@ struct BatchArgs {
     uint64_t run_stride;         // >= number of items
     uint32_t run_cap;
     uint32_t *run_count;         // per item: runs appended by k_scan_anchor, walked by k_walk_runs (> run_cap: whole item)
-    uint32_t run_dense;          // 1 (dense anchor form): `runs` holds 4-byte entries, the hit windows' start offsets, ITEM-major --
-                                 // entry r of item i at ((uint32_t *)runs)[i * run_cap + r]; a run's bounds follow from its start
+    uint32_t run_dense;          // 1 (dense anchor form), 2 (the aligned forms): `runs` holds 4-byte window-list entries (kdev.hpp) --
+                                 // the hit windows' start offsets; a run's bounds follow from its start
+    uint32_t run_major;          // window lists: 1 item-major (entry r of item i at ((uint32_t *)runs)[i * run_cap + r]: the dense form,
+                                 // and long lists), 0 entry-major ([r * run_stride + i])
+    uint32_t *busy_list;         // ... their indices (k_walk_runs appends, counters[20] counts)
+    uint32_t wave_runs;          // 1: items with more than wave_min windows are left to k_runs_wave (a wave per item, a lane per window)
+    uint32_t *dense_list;        // null, or: k_expand leaves items of more than wave_min events to k_expand_dense, their indices here (counters[23] counts)
+    uint32_t wave_min;           // >= kWaveRunsMin: a wave per item only pays where the item's one lane would take longer than the waves' turns
     uint32_t poison_quads;       // ceil(max_pattern_length / 16): quads flagged after a lost state
     uint32_t persistent;         // 1: one workgroup per CU, waves pull item batches from counters[1]
     uint32_t wave_items;         // k_scan_anchor: items a wave takes per batch (1..64)

@@ -525,7 +525,7 @@ int acmi_destroy(acmi_handle *h) {
             for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_out_off, &h->d_out_list, &h->d_out_head, &h->d_cold_rec, &h->d_cold_edges, &h->d_chain_byte, &h->d_chain_run, &h->d_chain_img, &h->d_chain_head, &h->d_chain_orig, &h->d_chain_frank, &h->d_chain_fhead, &h->d_slot_pair, &h->d_pairs, &h->d_pat_bytes, &h->d_dense_img, &h->d_merge_counts, &h->d_merge_sync, &h->d_rep_off, &h->d_rep_bytes, &h->d_plan, &h->d_plan_out, &h->d_tail_out, &h->d_rep_sync, &h->d_nom_count, &h->d_out_len, &h->d_rep_out_off, &h->d_rep_out, &h->d_blob,
                               &h->d_off, &h->d_sync[0], &h->d_sync[1], &h->d_item_base[0], &h->d_item_hay[0], &h->d_item_rec[0], &h->d_zero[0], &h->d_isync[0],
                               &h->d_item_base[1], &h->d_item_hay[1], &h->d_item_rec[1], &h->d_zero[1], &h->d_isync[1],
-                              &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_first, &h->d_tile_queue, &h->d_tile_sync, &h->d_chain_log, &h->d_chain_tiles, &h->d_uni_off[0], &h->d_uni_off[1], &h->fly[0].d_prefix, &h->fly[0].d_out, &h->fly[1].d_prefix, &h->fly[1].d_out, &h->d_runs, &h->d_run_count})
+                              &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_first, &h->d_tile_queue, &h->d_tile_sync, &h->d_chain_log, &h->d_chain_tiles, &h->d_uni_off[0], &h->d_uni_off[1], &h->fly[0].d_prefix, &h->fly[0].d_out, &h->fly[1].d_prefix, &h->fly[1].d_out, &h->d_runs, &h->d_run_count, &h->d_busy, &h->d_dense})
                 b->release();
             for (void *q : h->retired) (void)hipFree(q);
             for (auto &evt : h->ev)
@@ -626,6 +626,8 @@ static int apply_option(acmi_handle *h, const std::string &k, int64_t value) {
             h->early_stop = int(value);
             if (h->aut.finalized())
                 h->dA.early_stop = (value == 2 || (value == 1 && h->aut.flat().early_stop_useful)) ? 1u : 0u;
+        } else if (k == "wave_runs") {
+            h->wave_runs_opt = value ? 1 : 0;
         } else if (k == "refill") {
             if (value < 0 || value > 2) return ACMI_E_ARG;
             h->refill = int(value);
@@ -744,6 +746,10 @@ int acmi_get_stat(const acmi_handle *h, const char *key, double *value) {
         else if (k == "overflow_items") *value = h->overflow_items;
         else if (k == "walked_bytes") *value = double(h->walked_bytes);
         else if (k == "fallback_bytes") *value = double(h->fallback_bytes);
+        else if (k == "busy_items") *value = h->busy_items;
+        else if (k == "max_windows") *value = h->max_windows;
+        else if (k == "serial_items") *value = h->serial_items;
+        else if (k == "wave_runs_used") *value = h->wave_used ? 1 : 0;
         else if (k == "choice_probes") *value = h->probes;
         else if (k == "choice_switches") *value = h->switches;
         else if (k == "scan_ms") *value = h->scan_ms;

@@ -105,6 +105,11 @@ struct acmi_handle {
     // options
     bool dense_output = false;   // the last batch produced a record per two bytes of text or more (which drain: refill_mode)
     uint32_t run_auto = 0;       // run-list entries per item the data has asked for so far
+    bool expand_armed = false;   // the last batch averaged four records a work item or more: k_expand_dense is enqueued with the next
+    bool wave_armed = false;     // the last filter batch had items with more than a few candidate windows: k_runs_wave is enqueued with the next
+    int wave_runs_opt = 1;       // "wave_runs": 0 never launches k_runs_wave (every item is k_walk_runs')
+    uint32_t busy_items = 0, max_windows = 0, serial_items = 0;   // of the last filter batch ("busy_items", "max_windows", "serial_items")
+    bool wave_used = false;      // ... which ran k_runs_wave ("wave_runs_used")
     uint32_t slab_auto = 0;      // slots per item the data has asked for so far (automatic slab size, enqueue_batch)
     uint32_t slab_events = 16;   // (8 until round 3: an item with a ninth match went to the drain, one with a ninth candidate was walked whole)
     uint32_t run_cap = 16;
@@ -178,7 +183,7 @@ struct acmi_handle {
     DevBuf d_table, d_lds, d_class, d_own, d_dict, d_cnt, d_plen, d_anchor, d_bitmap, d_out_off, d_out_list, d_out_head, d_cold_rec, d_cold_edges, d_chain_byte, d_chain_run, d_chain_img, d_chain_head, d_chain_orig, d_chain_frank, d_chain_fhead, d_slot_pair, d_pairs, d_pat_bytes, d_dense_img;
 
     // workspace (grow-only)
-    DevBuf d_blob, d_off, d_rec_base, d_slab, d_ovf, d_counters, d_runs, d_run_count, d_first;
+    DevBuf d_blob, d_off, d_rec_base, d_slab, d_ovf, d_counters, d_runs, d_run_count, d_first, d_busy, d_dense;
     DevBuf d_tile_queue, d_tile_sync;   // k_walk_tiles: the waves' event queues; {ticket, look-back words}
     DevBuf d_chain_log, d_chain_tiles;  // k_walk_chain: the waves' event logs; per tile {log offset | events per lane}
     uint32_t chain_log_div = 32;        // ... the logs hold an event per this many bytes of text (learned: 32 -> 4 -> 1)
@@ -255,6 +260,7 @@ struct acmi_handle {
         ChainBuffers chain_buf{};             // ... with these buffers (k_chain_emit again into a grown record buffer)
         bool merged = false;                  // (part 1 of a split set) this batch wrote the MERGED records into the parent's buffer
         bool reran = false;                   // the end had to complete or repeat the pipeline: what ran behind it on the stream saw unfinished results
+        bool win_lists = false, wave_runs = false;   // the filter handed over window lists; k_runs_wave was enqueued behind k_walk_runs
         bool refill_launched = false;  // the drain of overflowed items was enqueued with the pipeline (else: only if the batch turns out to need it)
         DevBuf d_prefix, d_out;        // valid from this batch's end until the second begin after its own
     };

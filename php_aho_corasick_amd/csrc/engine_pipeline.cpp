@@ -10,6 +10,8 @@ namespace acmi_engine {
 // per item, which only the wave drain writes as whole rows; `dense_output` is what the batch before produced)
 int refill_mode(const acmi_handle *h, int kernel) { return h->refill != 0 ? h->refill : (kernel == 4 && !h->dense_output ? 3 : 0); }
 
+constexpr uint32_t kWaveRunsMinHost = 3;   // (kdev.hpp kWaveRunsMin)
+
 uint32_t choose_chunk(const acmi_handle *h, uint64_t blob_bytes, size_t nh, int kernel) {
     const uint32_t warm = h->aut.flat().max_pattern_length ? h->aut.flat().max_pattern_length - 1 : 0;
     if (h->chunk_opt) {
@@ -231,6 +233,13 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     // whose filter lost because items overflowed them, before the automatic choice gives the filter up: run_batch_end)
     uint32_t run_max = 16;
     while (run_max < 64u && uint64_t(run_max) * 2 * 16 * est_items * 8 <= blob_bytes) run_max *= 2;
+    // the aligned forms of the anchor filter hand over window lists (4-byte entries, kdev.hpp): up to 256 windows an item -- what
+    // k_runs_wave orders -- and an eighth of the batch's bytes (one window per eight bytes of an average item)
+    const bool win = kernel == 2 && !dense;
+    if (win) {
+        run_max = 16;
+        while (run_max < 256u && uint64_t(run_max) * 2 * 8 * est_items <= blob_bytes) run_max *= 2;
+    }
     // (dense form: an item of L bytes has at most L hit windows, and 256 entries for every 256-byte haystack would be 8 x the batch:
     // what an average item can hold, at least 16, and never more than the batch's own bytes in all)
     uint32_t dense_q = 256u;
@@ -241,8 +250,11 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     const uint32_t Q = h->run_cap_set ? std::max<uint32_t>(1, h->run_cap) : dense ? dense_q : std::min(std::max(16u, h->run_auto), run_max);
     F.run_used = Q;
     F.run_max = (h->run_cap_set || dense) ? Q : run_max;
-    HIPCHK(h, h->d_runs.ensure_keep(run_stride * Q * (dense ? 8 : 16), h->retired));   // (dense: window starts, then k_dense_decide's results)
+    HIPCHK(h, h->d_runs.ensure_keep(run_stride * Q * (dense ? 8 : win ? 4 : 16), h->retired));   // (dense: window starts, then k_dense_decide's results)
     HIPCHK(h, h->d_run_count.ensure_keep(max_items * 4, h->retired));
+    // k_runs_wave (the items with many windows, a wave each) is a launch of its own: enqueued while batches report such items
+    const bool wave_runs = win && find_all && h->wave_armed && h->dA.anchor_pairs != nullptr && h->wave_runs_opt != 0;
+    if (wave_runs) HIPCHK(h, h->d_busy.ensure_keep(max_items * 4, h->retired));
     uint8_t *zero = d_zero.as<uint8_t>();
     uint32_t *d_counters = sync_cur;
     uint64_t *d_rec_cnt = reinterpret_cast<uint64_t *>(zero + rec_cnt_off);
@@ -274,7 +286,19 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     B.runs = h->d_runs.as<uint4>();
     B.run_count = h->d_run_count.as<uint32_t>();
     B.run_cap = Q;
-    B.run_dense = dense ? 1u : 0u;
+    B.run_dense = dense ? 1u : win ? 2u : 0u;
+    B.run_major = (dense || (win && Q > 16u)) ? 1u : 0u;   // (short lists entry-major: k_walk_runs' thread per item reads whole lines)
+    B.wave_runs = wave_runs ? 1u : 0u;
+    // a wave per item against a lane per item: the chip holds ~ 8,192 of k_runs_wave's waves at a time and 262,144 of k_walk_runs' lanes,
+    // a window costs either the same chain of round trips -- so an item is the wave kernel's when it has more windows than the
+    // batch's items take turns of waves (64 MiB of 8 KiB items: from four windows on; of 256-byte haystacks: from 33)
+    B.wave_min = uint32_t(std::min<uint64_t>(255, std::max<uint64_t>(kWaveRunsMinHost, est_items / 8192)));
+    // ... and the same for the expansion: k_expand_dense (a wave per item, a lane per event) is enqueued behind k_expand while the
+    // batches before averaged four records an item or more (kernel 6 writes its records itself)
+    const bool expand_dense = find_all && kernel != 6 && h->expand_armed && h->wave_runs_opt != 0;
+    if (expand_dense) HIPCHK(h, h->d_dense.ensure_keep(max_items * 4, h->retired));
+    B.dense_list = expand_dense ? h->d_dense.as<uint32_t>() : nullptr;
+    B.busy_list = wave_runs ? h->d_busy.as<uint32_t>() : nullptr;
     B.run_stride = run_stride;
     B.poison_quads = std::max<uint32_t>(1, (fa.max_pattern_length + 15) / 16);
     // persistent workgroups pay off once a CU would otherwise run several workgroups back to back
@@ -414,6 +438,9 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     // (its LDS tile only where a walk may be needed: no verification by compare, or the batch before walked a cluster)
     if (kernel == 2) HIPCHK(h, launch_walk_runs(h->dA, B, max_items, int(fa.entry_bytes), int(fa.class_mode), st,
                                                 h->dA.anchor_slot_pair == nullptr || h->fallback_bytes != 0 || !find_all));
+    if (B.wave_runs) HIPCHK(h, launch_runs_wave(h->dA, B, max_items, int(fa.entry_bytes), int(fa.class_mode), st));
+    F.wave_runs = B.wave_runs != 0u;
+    F.win_lists = win;
     if (h->profile > 1) HIPCHK(h, hipEventRecord(F.ev[3], st));
 
     if (!find_all) {
@@ -434,6 +461,7 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     // ("items_ahead": the next batch's k_items may already be running on the side stream, behind this batch's SCAN only -- its
     // sync words are zeroed by that stream's own memset, never from here)
     h->isync_clean[slot_index ^ 1] = !h->items_ahead && h->d_isync[slot_index ^ 1].p != nullptr;
+    if (B.dense_list != nullptr) launch_expand_dense(h->dA, B, max_items, h->d_rec_base.as<uint64_t>(), F.d_out.p, cap, st);
     // (k_walk_chain left events in the waves' logs: records at the bases k_expand's scan has just written)
     if (kernel == 6 && F.chain) HIPCHK(h, launch_chain_emit(h->dA, B, max_items, tile_w, tile_p, F.chain_buf, h->d_rec_base.as<uint64_t>(), F.d_out.p, cap, st));
     F.refill_launched = find_all && h->refill_armed && kernel != 6;   // (k_walk_tiles leaves no item to drain)
@@ -650,6 +678,20 @@ int run_batch_end(acmi_handle *h) {
     // whole (items whose candidate windows overflowed the list)
     if (h->kernel == 3 && F.blob_bytes >= kAutoMinBytes && F.kernel_used == 2 && h->fallback_bytes * 64 > F.blob_bytes && F.run_used < F.run_max)
         h->run_auto = F.run_used * 4;
+    if (F.win_lists) {
+        // window lists: the scan reports the longest list the batch asked for (word 21), k_walk_runs the items with more than a few
+        // windows (word 20) -- the lists of the batches behind are sized in one step, and k_runs_wave is enqueued while there are such items
+        h->busy_items = pinned32[20];
+        h->max_windows = pinned32[21];
+        h->serial_items = pinned32[22];
+        h->wave_used = F.wave_runs;
+        h->wave_armed = pinned32[20] != 0u;
+        if (pinned32[21] > F.run_used && F.run_used < F.run_max) {
+            uint32_t want = 16;
+            while (want < pinned32[21] + pinned32[21] / 4u && want < F.run_max) want *= 2;
+            h->run_auto = std::max(h->run_auto, want);
+        }
+    }
     float pipeline_ms = 0;
     HIPCHK(h, hipEventElapsedTime(&pipeline_ms, F.ev[0], F.ev[4]));
     h->total_ms = pipeline_ms;
@@ -689,10 +731,14 @@ int run_batch_end(acmi_handle *h) {
                 HIPCHK(h, hipMemsetAsync(h->d_tile_sync.p, 0, sync_bytes, st));
                 HIPCHK(h, launch_walk_tiles(h->dA, F.args, F.max_items, int(fa.entry_bytes), int(fa.class_mode), F.tile_w, F.tile_p, h->d_tile_queue.p,
                                             h->d_tile_sync.as<uint32_t>(), h->d_tile_sync.as<uint64_t>() + 1, F.d_out.p, cap, st));
-            } else if (too_small)
-                launch_expand(h->dA, F.args, F.max_items, h->d_rec_base.as<uint64_t>(), F.d_out.p, cap, F.d_prefix.as<uint64_t>(),
+            } else if (too_small) {
+                // (every item by k_expand itself this time: the dense items' list was filled by the first expansion)
+                BatchArgs again = F.args;
+                again.dense_list = nullptr;
+                launch_expand(h->dA, again, F.max_items, h->d_rec_base.as<uint64_t>(), F.d_out.p, cap, F.d_prefix.as<uint64_t>(),
                               h->pinned_dev + kPinWords * slot_index, F.sync_next, F.sync_words, nullptr, nullptr,
                               h->d_isync[slot_index].as<uint32_t>() + 1, false, st);
+            }
             if (F.find_all && F.kernel_used != 6)
                 launch_refill(h->dA, F.args, F.max_items, int(fa.entry_bytes), h->d_rec_base.as<uint64_t>(),
                               F.d_out.p, cap, refill_mode(h, F.kernel_used), st, int(fa.class_mode));
@@ -717,6 +763,7 @@ int run_batch_end(acmi_handle *h) {
         }
     }
     h->last_total = total;
+    h->expand_armed = total >= 4 * std::max<uint64_t>(1, h->items);
     h->have_result = true;
     h->resume_haystack = F.nh;
     if (partial) {

@@ -138,6 +138,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
 
     // Persistent mode: waves pull batches of items from counters[1] until none are left, wave_grab batches per atomic.
     uint32_t grab_next = 0, grab_left = 0, tiny_batches = 0;
+    uint32_t nrun_max = 0;   // the longest window list this wave has seen (what the host sizes the next batches' lists by)
     for (;;) {
     // a wave takes `wave_items` (1..64) consecutive items per batch: 64 for big batches, fewer when
     // there are not enough items to give every wave of the chip 64 of them
@@ -181,12 +182,12 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     sc = ld;
     // per wave, behind the table: 2 KiB of run staging -- BIG: [1 KiB probe queue | 256 B hit masks | 768 B run staging]
     uint8_t *wave_lds = smem + kAnchorLdsBytes + (threadIdx.x >> 6) * 2048u;
-    RunStage stage{reinterpret_cast<uint4 *>(wave_lds + (BIG ? 1280u : 0u)), 0u, BIG ? kStageSlotsBig : kStageSlots};
+    RunStage stage{reinterpret_cast<uint4 *>(wave_lds + (BIG ? 1280u : 0u)), 0u, BIG ? kDenseStageBig : kDenseStage};   // (8-byte entries: kdev.hpp, window lists)
     uint2 *const queue = reinterpret_cast<uint2 *>(wave_lds);           // BIG only
     uint32_t *const hitmask = reinterpret_cast<uint32_t *>(wave_lds + 1024u);
     if (BIG) hitmask[lane] = 0u;
-    uint32_t nrun = 0, run_hi = 0;  // run list of the item being scanned (wave-uniform)
-    uint32_t nrun_vec = 0;          // lane k: run count of item wave_first + k
+    uint32_t nrun = 0;              // window-list entries of the item being scanned (wave-uniform; keeps counting past the list's capacity)
+    uint32_t nrun_vec = 0;          // lane k: entry count of item wave_first + k
     // carry[n-1] = hash prefix over the LAST n dwords of a quad (n = 1..QW-1): what a window that
     // begins there and ends in the next quad continues from.  `tail` = the carries of the previous
     // wave-load (its lane 63 is the left neighbour of lane 0).
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
         // (dense form: its run lists hold window starts only -- an item with an unaligned head, the first haystack of an unaligned
         // blob, is walked whole)
         if constexpr (DENSE) nrun = B.run_cap + 1u;
-        else append_run_wave(B, wave_first, stage, sc.k, 0, (sc.head + l_max) < sc.n ? sc.head + l_max : sc.n, 0u, nrun, run_hi, lane);
+        else append_win_wave(B, wave_first, stage, sc.k, kWinSpecial | ((sc.head + l_max) < sc.n ? sc.head + l_max : sc.n), nrun, lane);
     }
 
     uint4 buf0[G], buf1[G];
@@ -559,30 +560,13 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                 const uint32_t w = uint32_t(__builtin_ctz(wmask));
                 // the window ending at dword w of quad qi starts QW-1 dwords earlier
                 const int32_t start = int32_t(sc.head + (qi << 4) + 4u * w) - int32_t(q - 4u);
-                // the end of a pattern anchored here: at least m_min - 4 past the window start when the window is the
-                // pattern's FIRST aligned dword, at least q - 1 when the builder chose a deeper window (anchor_choice)
-                int32_t lo = start + int32_t(lo_bias);
-                uint32_t hi = uint32_t(start + int32_t(l_max));
-                if (lo < 0) lo = 0;
-                if (hi > sc.n) hi = sc.n;
+                // a window that begins before the item's first byte was hashed over zeros, and nothing the item reports can be
+                // anchored there (an occurrence that ends in the item's reporting range begins inside its warm-up)
+                if (start < 0) continue;
                 // a window at the item's very end or in the padding of its last 16-byte block: whatever is anchored there
-                // ends behind the item.  (Not the swallowed-window case below: marking the previous run for a walk on
-                // every such accidental hit put one slow lane into almost every workgroup of k_walk_runs -- 0.65 instead
-                // of 0.16 ms on 4,001-byte haystacks.)
-                if (uint32_t(lo) >= sc.n) continue;
-                // one run per hit window, tagged with the window's start; where an earlier window's run reaches
-                // into this one's range the run starts at that run's end (disjoint, ascending, adjacent)
-                if (nrun > 0 && uint32_t(lo) < run_hi) lo = int32_t(run_hi);
-                // (a window that begins before the item's first quad was hashed over zeros: not a real window)
-                const uint32_t entry = start >= 0 ? (kEntryWindow | uint32_t(start)) : kEntryUnknown;
-                if (uint32_t(lo) < hi) {
-                    append_run_wave(B, wave_first, stage, sc.k, uint32_t(lo), hi, entry, nrun, run_hi, lane);
-                } else if (nrun > 0 && nrun <= B.run_cap) {
-                    // its whole range lies inside the previous run (both end with the item): that run now stands for
-                    // a window it does not name and must be walked.  The previous run is the last staged entry:
-                    // the stage is only flushed right before an append.
-                    if (lane == 0) stage.slots[stage.count - 1].w = kEntryUnknown;
-                }
+                // ends behind the item
+                if (uint32_t(start) + lo_bias >= sc.n) continue;
+                append_win_wave(B, wave_first, stage, sc.k, uint32_t(start), nrun, lane);
             }
         };
         if constexpr (DENSE) {
@@ -712,23 +696,76 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                             const uint32_t k = (tscan * uint32_t(G) + uint32_t(r)) * tpack + (l >> tshift);
                             if (k >= tcnt) continue;   // (a slot behind the batch's last item repeats that item: not its hits again)
                             if (k != cur_k) {
-                                if (cur_k != 0xFFFFFFFFu) nrun_vec = lane == cur_k ? nrun : nrun_vec;
+                                if (cur_k != 0xFFFFFFFFu) { nrun_vec = lane == cur_k ? nrun : nrun_vec; nrun_max = nrun > nrun_max ? nrun : nrun_max; }
                                 anchor_open<TQ>(A, B, rec, k, sc);
                                 nrun = 0;
-                                run_hi = 0;
                                 cur_k = k;
                             }
                             flag(0u, l & ((1u << tshift) - 1u), __builtin_amdgcn_readlane(z[r], l));
                         }
-                        if (cur_k != 0xFFFFFFFFu) nrun_vec = lane == cur_k ? nrun : nrun_vec;
+                        if (cur_k != 0xFFFFFFFFu) { nrun_vec = lane == cur_k ? nrun : nrun_vec; nrun_max = nrun > nrun_max ? nrun : nrun_max; }
                     }
                 }
                 return;
             }
         }
+        // Several lanes hit in one task (text with matches by the dozen per item): the task's windows are placed by VECTOR code, as
+        // the dense form places its own -- every lane keeps the hit windows that can anchor something the item reports, three wave
+        // prefix sums (the lanes' counts of the task, the per-row counts packed four to a word) give each its index in the item's
+        // list, and the lanes write their own entries into the stage.  One hit at a time through the scalar unit -- the path below,
+        // right for the usual task with one hit -- cost ~ 100 ns a hit: 0.1 ms of a 64 MiB batch with 128 occurrences per 8 KiB.
+        // (the big-set kernel only: in the small-set kernel's 128 registers the path spilled sixteen of them into the streaming loop)
+        auto flag_vector = [&]() -> bool {
+            if constexpr (!BIG) return false;
+            const uint32_t qi0 = sc.c * TQ + lane;
+            uint32_t pk_lo = 0, pk_hi = 0;
+#pragma unroll
+            for (int r = 0; r < G; ++r) {
+                const uint32_t qi = qi0 + 64u * uint32_t(r);
+                uint32_t zr = qi < sc.nq ? z[r] : 0u;
+                if (zr != 0u) {
+                    const int32_t s0 = int32_t(sc.head + (qi << 4)) - int32_t(q - 4u);   // the window ending at dword w starts at s0 + 4 w
+                    uint32_t keep = 0;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const int32_t st = s0 + 4 * w;
+                        if (((zr >> w) & 1u) != 0u && st >= 0 && uint32_t(st) + lo_bias < sc.n) keep |= 1u << w;
+                    }
+                    zr = keep;
+                }
+                z[r] = zr;
+                const uint32_t c = uint32_t(__builtin_popcount(zr));
+                if (r < 4) pk_lo |= c << (8 * r); else pk_hi |= c << (8 * (r - 4));
+            }
+            const uint32_t mine = ((pk_lo * 0x01010101u) >> 24) + ((pk_hi * 0x01010101u) >> 24);
+            const uint32_t T = __builtin_amdgcn_readlane(wave_inclusive_sum(mine), 63);
+            if (T == 0u) return true;
+            if (T > 255u || T > stage.cap) return false;   // (the packed row counts would carry / more than the stage holds: one by one)
+            if (nrun + T > B.run_cap) { nrun += T; return true; }   // more windows than the list holds: counted, the item is walked whole
+            if (stage.count + T > stage.cap) dense_flush(B, wave_first, stage, lane);
+            const uint32_t in_lo = wave_inclusive_sum(pk_lo), in_hi = wave_inclusive_sum(pk_hi);
+            const uint32_t tot_lo = __builtin_amdgcn_readlane(in_lo, 63), tot_hi = __builtin_amdgcn_readlane(in_hi, 63);
+            uint2 *slots2 = reinterpret_cast<uint2 *>(stage.slots);
+            uint32_t rowbase = 0;   // hits of the rows before this one (wave-uniform)
+#pragma unroll
+            for (int r = 0; r < G; ++r) {
+                const uint32_t sh = 8u * uint32_t(r & 3);
+                const uint32_t cnt = ((r < 4 ? pk_lo : pk_hi) >> sh) & 0xffu, incl = ((r < 4 ? in_lo : in_hi) >> sh) & 0xffu;
+                uint32_t at = stage.count + rowbase + incl - cnt, idx = nrun + rowbase + incl - cnt;
+                const uint32_t s0 = sc.head + ((qi0 + 64u * uint32_t(r)) << 4) - (q - 4u);
+                for (uint32_t m = z[r]; m != 0; m &= m - 1, ++at, ++idx)
+                    slots2[at] = make_uint2(sc.k | (idx << 8), s0 + 4u * uint32_t(__builtin_ctz(m)));
+                rowbase += ((r < 4 ? tot_lo : tot_hi) >> sh) & 0xffu;
+            }
+            stage.count += T;
+            nrun += T;
+            return true;
+        };
         const uint64_t cand = __ballot(zany != 0);
         if (__builtin_expect(cand != 0, 0)) {
-            if ((cand & (cand - 1)) == 0) {
+            if ((cand & (cand - 1)) != 0 && flag_vector()) {
+                // (placed above)
+            } else if ((cand & (cand - 1)) == 0) {
                 // one lane hit (the usual case): its eight masks go through the scalar unit
                 const uint32_t l = uint32_t(__builtin_ctzll(cand));
 #pragma unroll
@@ -761,31 +798,23 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     auto close_or_advance = [&]() -> bool {  // scan cursor: next chunk, or finish the item and open the next
         if (sc.c + 1u == sc.chunks) {
             // anchors the main loop did not test start after head + 16*nq - q: what they could match
-            // ends at or after head + 16*nq - q + m_min
+            // ends at or after head + 16*nq - q + m_min -- a tail entry, walked (only items with an unaligned head have one)
             uint32_t lo = sc.head + (sc.nq << 4) + (A.anchor_choice ? q : m_min);
             lo = lo > q ? lo - q : 0u;
-            if (nrun > 0 && lo < run_hi) lo = run_hi;
-            if (!DENSE && sc.head + (sc.nq << 4) < sc.n) {
-                if (lo < sc.n) {
-                    append_run_wave(B, wave_first, stage, sc.k, lo, sc.n, kEntryUnknown, nrun, run_hi, lane);
-                } else if (nrun > 0 && nrun <= B.run_cap) {
-                    // the previous run already reaches the item's end: it now also stands for the untested windows
-                    // of the tail and must be walked (it is the last staged entry, see flag())
-                    if (lane == 0) stage.slots[stage.count - 1].w = kEntryUnknown;
-                }
-            }
+            if (!DENSE && sc.head + (sc.nq << 4) < sc.n && lo < sc.n)
+                append_win_wave(B, wave_first, stage, sc.k, kWinSpecial | kWinTail | lo, nrun, lane);
+            nrun_max = nrun > nrun_max ? nrun : nrun_max;
             nrun_vec = lane == sc.k ? nrun : nrun_vec;
         }
         const uint32_t k_before = sc.k;
         const bool more = anchor_next<TQ>(A, B, rec, sc);
         if (more && sc.k != k_before) {
             nrun = 0;
-            run_hi = 0;
             if (sc.head) {
         // (dense form: its run lists hold window starts only -- an item with an unaligned head, the first haystack of an unaligned
         // blob, is walked whole)
         if constexpr (DENSE) nrun = B.run_cap + 1u;
-        else append_run_wave(B, wave_first, stage, sc.k, 0, (sc.head + l_max) < sc.n ? sc.head + l_max : sc.n, 0u, nrun, run_hi, lane);
+        else append_win_wave(B, wave_first, stage, sc.k, kWinSpecial | ((sc.head + l_max) < sc.n ? sc.head + l_max : sc.n), nrun, lane);
     }
         }
         return more;
@@ -831,12 +860,15 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     }
     }
 
-    // hand the run lists over to k_walk_runs (lane k: item wave_first + k)
-    if constexpr (DENSE) dense_flush(B, wave_first, stage, lane);
-    else stage_flush(B, wave_first, stage, lane);
+    // hand the window lists over to the kernels behind (lane k: item wave_first + k)
+    dense_flush(B, wave_first, stage, lane);
     if (rec.z != 0) B.run_count[wave_first + lane] = nrun_vec;
     if (!B.persistent) break;
     }  // next batch of this wave
+    if constexpr (!DENSE) {
+        // the longest list a wave saw, for the host (one atomic per wave and launch, and none for the usual sparse batch)
+        if (lane == 0 && nrun_max > kWaveRunsMin) atomicMax(&B.counters[21], nrun_max);
+    }
     if constexpr (TINY) {
         // one device atomic per WORKGROUP (through the waves' own LDS regions, free by now): one per batch on a single word
         // was the longest thing in the launch (see wave_grab)

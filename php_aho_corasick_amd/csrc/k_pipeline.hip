@@ -230,6 +230,7 @@ __global__ __launch_bounds__(kExpandThreads, LOWREG ? 8 : 4) void k_expand(DevAu
         for (int i = 0; i <= kExpandPerThread; ++i) rb[i] = base + i <= items ? rec_base[base + i] : 0ull;
     }
     // prefix words and the events of this thread's items
+    bool dense_item = false;   // an item of many events, left to k_expand_dense (a wave per item, a lane per event)
 #pragma unroll
     for (int i = 0; i < kExpandPerThread; ++i) {
         const uint64_t g = base + i;
@@ -249,6 +250,7 @@ __global__ __launch_bounds__(kExpandThreads, LOWREG ? 8 : 4) void k_expand(DevAu
         const uint32_t n = n0;
         if (n == 0 || n > B.slab_events) continue;  // overflowed items are k_refill's
         if (rb[i + 1] > cap) continue;
+        if (B.dense_list != nullptr && n > B.wave_min) { dense_item = true; continue; }
         uint64_t w = rb[i];
         // an item with many events (tens per item on text full of matches): event e + 2 and the output head of event e + 1 are
         // requested before event e is written -- one round trip per event instead of two dependent ones
@@ -264,12 +266,68 @@ __global__ __launch_bounds__(kExpandThreads, LOWREG ? 8 : 4) void k_expand(DevAu
             ev_b = ev_c;
         }
     }
+    if (B.dense_list != nullptr) {   // (one atomic per wave that has such items; none for the usual sparse batch)
+        const uint64_t dm = __ballot(dense_item);
+        if (dm != 0) {
+            uint32_t at = 0;
+            if ((threadIdx.x & 63u) == 0) at = atomicAdd(&B.counters[23], uint32_t(__builtin_popcountll(dm)));
+            at = uint32_t(__builtin_amdgcn_readfirstlane(int(at)));
+            if (dense_item) B.dense_list[at + __builtin_amdgcn_mbcnt_hi(uint32_t(dm >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(dm), 0u))] = uint32_t(base);
+        }
+    }
     __syncthreads();
     if (s_closing) {  // prefix words of the haystacks behind the last item (all of them when the batch has no item), the closing word
         const uint64_t total = s_total;
         const uint32_t from = items ? B.item_hay[items - 1] + 1u : 0u;
         for (uint64_t hh = uint64_t(from) + threadIdx.x; hh <= B.n_haystacks; hh += blockDim.x) prefix[hh] = total;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_expand_dense: the items k_expand left in BatchArgs::dense_list -- more events than wave_min -- a wave per item, a lane per
+// event.  k_expand gives an item one thread, and an event costs that thread a round trip (the event, its state's output head,
+// the store): 128 events per item over 8,192 items of a 64 MiB batch were 215 us on eight workgroups, the longest kernel of
+// the batch.  Here the events of an item are read 64 at a time, their record counts summed over the wave (one record per
+// event as a rule: the head says so), and every lane writes its own event's records at its offset.  Enqueued behind
+// k_expand while the batches before averaged several records per item.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_expand_dense(DevAutomaton A, BatchArgs B, const uint64_t *rec_base, uint4 *out, uint64_t cap) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_list = B.counters[23];
+#pragma unroll 1
+    for (uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6); w < n_list; w += gridDim.x * 4u) {
+        const uint64_t g = uint32_t(__builtin_amdgcn_readfirstlane(int(B.dense_list[w])));
+        const uint32_t n = uint32_t(__builtin_amdgcn_readfirstlane(int(B.ev_count[g])));
+        const uint32_t hay = uint32_t(__builtin_amdgcn_readfirstlane(int(B.item_hay[g])));
+        const uint64_t w0 = rec_base[g];
+        if (rec_base[g + 1] > cap) continue;   // (as in k_expand: the host grows the buffer and expands again)
+        uint64_t run = w0;
+#pragma unroll 1
+        for (uint32_t c = 0; c < n; c += 64u) {
+            const uint32_t e = c + lane;
+            const bool active = e < n;
+            const uint2 ev = active ? B.slab[uint64_t(e) * B.run_stride + g] : make_uint2(0u, 0u);
+            uint2 hd = make_uint2(0u, 0u);
+            uint32_t cnt = 0;
+            if (active) {
+                if (A.out_head != nullptr) { hd = A.out_head[ev.y]; cnt = hd.x >> 24; }
+                if (A.out_head == nullptr || cnt == 255u) cnt = A.out_count[ev.y];
+            }
+            const uint32_t incl = wave_inclusive_sum(cnt);
+            const uint64_t at = run + (incl - cnt);
+            if (active) {
+                if ((hd.x >> 24) == 1u) out[at] = make_uint4(hay, ev.x, ev.x - hd.y, hd.x & 0xFFFFFFu);
+                else emit_event(A, out, at, hay, ev.x, ev.y);
+            }
+            run += uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
+        }
+    }
+}
+
+void launch_expand_dense(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, const uint64_t *rec_base, void *out, uint64_t cap, hipStream_t st) {
+    if (max_items == 0 || B.dense_list == nullptr) return;
+    const uint32_t blocks = uint32_t(std::min<uint64_t>((max_items + 3u) / 4u, uint64_t(num_cus()) * 8u));
+    hipLaunchKernelGGL(k_expand_dense, dim3(blocks), dim3(256), 0, st, A, B, rec_base, static_cast<uint4 *>(out), cap);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -70,8 +70,8 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_runs(DevAutomaton A, Batc
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint64_t total_items = B.item_base[B.n_haystacks];
     if (uint64_t(blockIdx.x) * kWalkThreads >= total_items) return;
-    __shared__ uint32_t s_walked, s_done, s_fallback;
-    if (threadIdx.x == 0) { s_walked = 0; s_done = 0; s_fallback = 0; }
+    __shared__ uint32_t s_walked, s_done, s_fallback, s_busy;
+    if (threadIdx.x == 0) { s_walked = 0; s_done = 0; s_fallback = 0; s_busy = 0; }
     const uint64_t item = uint64_t(blockIdx.x) * kWalkThreads + threadIdx.x;
     // issue the item's own loads first: they are in flight while the tile is staged
     uint32_t nr = 0;
@@ -103,16 +103,38 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_runs(DevAutomaton A, Batc
     }
     __syncthreads();
     uint32_t walked = 0, fallback16 = 0;
-    bool whole = false;
+    bool whole = false, busy = false;
     if (nr != 0) {
         ItemDesc it;
         unpack_item(rec.x, rec.y, rec.z, rec.w, it);
         // (a run list that overflowed -- more candidate windows than it holds -- means the whole item: not by this lane alone,
         // see below; findAll = false keeps the old way, the first event needs the order)
+        // (... and an item with more than a few windows is a latency chain per window for its one lane -- eight windows per 8 KiB item,
+        // and a batch of 8,192 items took 0.21 ms instead of 0.08: such items are k_runs_wave's, a wave per item and a lane per
+        // window, launched behind this kernel once a batch has reported some: counters[20])
         if (nr > B.run_cap && !B.first_only) whole = true;
-        else walked = run_epilogue_fast<E, MODE, EXTRA>(A, B, smem, tile_rows, item, it, nr, fallback16);
+        else if (nr > B.wave_min && B.wave_runs && !B.first_only) busy = true;
+        else {
+            busy = nr > B.wave_min;
+            walked = run_epilogue_fast<E, MODE, EXTRA>(A, B, smem, tile_rows, item, it, nr, fallback16);
+        }
     }
     wave_walk_whole<E, MODE>(A, B, smem, tile_rows, whole, rec, item, walked, fallback16);
+    // (armed: the busy items' indices into k_runs_wave's list, one atomic per wave that has any; else they are only counted, per workgroup)
+    uint32_t n_busy = 0;
+    {
+        const uint64_t bm = __ballot(busy);
+        if (bm != 0) {
+            n_busy = uint32_t(__builtin_popcountll(bm));
+            if (B.wave_runs) {
+                uint32_t base = 0;
+                if ((threadIdx.x & 63u) == 0) base = atomicAdd(&B.counters[20], n_busy);
+                base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
+                if (busy) B.busy_list[base + __builtin_amdgcn_mbcnt_hi(uint32_t(bm >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bm), 0u))] = uint32_t(item);
+                n_busy = 0;
+            }
+        }
+    }
     // statistic: bytes walked, one device atomic per WORKGROUP (8,192 same-address device atomics took 0.1 ms on their own,
     // and per-wave atomics spread over eight words of one line doubled this kernel's time), handed in by the workgroup's
     // LAST wave to finish -- no barrier: a barrier made every wave of a workgroup wait for its slowest lane (a cluster that
@@ -126,14 +148,196 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_runs(DevAutomaton A, Batc
     if ((threadIdx.x & 63u) == 0) {
         if (walked) atomicAdd(&s_walked, (walked + 15u) >> 4);
         if (fallback16) atomicAdd(&s_fallback, fallback16);
+        if (n_busy) atomicAdd(&s_busy, n_busy);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (atomicAdd(&s_done, 1u) == kWalkThreads / 64u - 1u) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const uint32_t total = atomicAdd(&s_walked, 0u), fb = atomicAdd(&s_fallback, 0u);
+            const uint32_t total = atomicAdd(&s_walked, 0u), fb = atomicAdd(&s_fallback, 0u), nb = atomicAdd(&s_busy, 0u);
             if (total) atomicAdd(&B.counters[8u + (blockIdx.x & 7u)], total);
             if (fb) atomicAdd(&B.counters[7], fb);
+            if (nb) atomicAdd(&B.counters[20], nb);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_runs_wave: the items of a batch that have MANY candidate windows, a wave per item and a lane per window.
+//
+// k_walk_runs gives an item one lane, and a window costs that lane a chain of four or five dependent memory round trips
+// (window text, fingerprint bucket, slot, pair record, the two texts): fine for the one or two windows of a sparse batch's item,
+// a millisecond for an item of the 65,536-pattern set with 64 planted occurrences, and -- once a list overflowed -- the whole
+// item walked through tables in global memory (round 5: 31-44 ms per 64 MiB forced through the filter at 32 occurrences per
+// 8 KiB).  Here every window of an item is decided at once: lane r verifies window r (verify_candidate: the text compared
+// with the patterns its fingerprint slot names), the occurrences found are compacted into the wave's list in LDS, and the
+// wave ORDERS them -- an occurrence's rank among the distinct ends is its slot in the item's event slab; of several that end
+// at the same byte the one with the most records stays (the longest pattern: its output list carries the others,
+// src/multifast/node.c:424-441).  No cluster logic is needed: with every window of the item decided, the events are the
+// occurrences' ends in ascending order (src/multifast/ahocorasick.c:214-231 reports in text order).  An item that holds
+// something this cannot decide -- an unaligned head or tail entry, a fingerprint slot with too many pairs, more than
+// kWaveOccMax occurrences -- goes through run_epilogue_fast on the wave's first lane, as k_walk_runs would have done it.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kWaveThreads = 256;   // (four waves: a workgroup lives as long as its slowest wave)
+
+template <typename E, int MODE, bool EXTRA>
+__global__ __launch_bounds__(kWaveThreads) void k_runs_wave(DevAutomaton A, BatchArgs B) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t *const oj = reinterpret_cast<uint32_t *>(smem) + wave * (3u * kWaveOccMax), *const os = oj + kWaveOccMax, *const oc = os + kWaveOccMax;
+    const uint32_t n_list = B.counters[20];   // (k_walk_runs' list of the items it left to this kernel)
+    const uint32_t *starts = reinterpret_cast<const uint32_t *>(B.runs);
+    uint32_t walked = 0, fallback16 = 0, serial = 0;
+    {
+#pragma unroll 1
+        for (uint32_t w = blockIdx.x * (kWaveThreads / 64u) + wave; w < n_list; w += gridDim.x * (kWaveThreads / 64u)) {
+            const uint64_t item = uint32_t(__builtin_amdgcn_readfirstlane(int(B.busy_list[w])));
+            const uint32_t nr = uint32_t(__builtin_amdgcn_readfirstlane(int(B.run_count[item])));
+            const uint4 rec = B.item_rec[item];
+            ItemDesc it;
+            unpack_item(rec.x, rec.y, rec.z, rec.w, it);
+            const uint8_t *p = B.blob + (it.begin - it.warm);
+            const uint32_t n = it.warm + it.len;
+            const uint32_t pos_bias = it.pos0 - it.warm + 1u;
+            // ---- every window decided, a lane each; the occurrences into the wave's list ----
+            uint32_t M = 0;
+            bool ok = A.anchor_pairs != nullptr && nr <= kWaveOccMax;
+#pragma unroll 1
+            for (uint32_t c = 0; c < nr && ok; c += 64u) {
+                const uint32_t r = c + lane;
+                const bool active = r < nr;
+                const uint32_t e = active ? starts[win_slot(B, item, r)] : 0u;
+                Verified v[kClusterMax];
+#pragma unroll
+                for (uint32_t i = 0; i < kClusterMax; ++i) v[i] = Verified{0xFFFFFFFFu, 0u, 0u};
+                uint32_t nv = 0;
+                bool decided = (e & kWinSpecial) == 0u;
+                if (active && decided) decided = verify_candidate(A, p, n, it.floor, e, v, nv);
+                if (__any(!decided)) { ok = false; break; }
+                const uint32_t incl = wave_inclusive_sum(nv);
+                const uint32_t tot = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
+                if (M + tot > kWaveOccMax) { ok = false; break; }
+                const uint32_t at = M + incl - nv;
+#pragma unroll
+                for (uint32_t i = 0; i < kClusterMax; ++i) {
+                    if (i < nv) {
+                        // (ends in the warm-up are the item before's: they take no part in the order)
+                        oj[at + i] = v[i].j >= it.warm ? v[i].j : 0xFFFFFFFFu;
+                        os[at + i] = v[i].state;
+                        oc[at + i] = v[i].cnt;
+                    }
+                }
+                M += tot;
+            }
+            if (!ok) {
+                if (lane == 0) {
+                    walked += run_epilogue_fast<E, MODE, EXTRA>(A, B, smem, 0u, item, it, nr, fallback16);
+                    ++serial;
+                }
+                continue;
+            }
+            if (M == 0u) continue;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- the order: entry idx = lane + 64 t.  First the duplicates of an end go (all but the one with the most records),
+            // then an entry's rank is the number of kept ends below its own ----
+            constexpr uint32_t T = kWaveOccMax / 64u;
+            uint32_t j[T], cnt[T];
+            bool keep[T];
+#pragma unroll
+            for (uint32_t t = 0; t < T; ++t) {
+                const uint32_t idx = lane + 64u * t;
+                j[t] = idx < M ? oj[idx] : 0xFFFFFFFFu;
+                cnt[t] = idx < M ? oc[idx] : 0u;
+                keep[t] = j[t] != 0xFFFFFFFFu;
+            }
+            // (the usual item: its ends ascend with its windows -- every entry is an event, in list order)
+            bool ascending = true;
+#pragma unroll
+            for (uint32_t t = 0; t < T; ++t) {
+                const uint32_t idx = lane + 64u * t;
+                if (idx < M) ascending = ascending && keep[t] && (idx == 0u || oj[idx - 1u] < j[t]);
+            }
+            uint32_t rank[T];
+            if (__all(ascending)) {
+#pragma unroll
+                for (uint32_t t = 0; t < T; ++t) rank[t] = lane + 64u * t;
+            } else {
+#pragma unroll 1
+                for (uint32_t i = 0; i < M; ++i) {
+                    const uint32_t ji = oj[i], ci = oc[i];
+#pragma unroll
+                    for (uint32_t t = 0; t < T; ++t)
+                        if (ji == j[t] && (ci > cnt[t] || (ci == cnt[t] && i < lane + 64u * t))) keep[t] = false;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (uint32_t t = 0; t < T; ++t) {
+                    const uint32_t idx = lane + 64u * t;
+                    if (idx < M && !keep[t]) oj[idx] = 0xFFFFFFFFu;
+                    rank[t] = 0;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 1
+                for (uint32_t i = 0; i < M; ++i) {
+                    const uint32_t ji = oj[i];
+#pragma unroll
+                    for (uint32_t t = 0; t < T; ++t) rank[t] += ji < j[t] ? 1u : 0u;
+                }
+            }
+            uint32_t n_ev = 0, rec_lo = 0, rec_hi = 0;
+#pragma unroll
+            for (uint32_t t = 0; t < T; ++t) {
+                const uint32_t idx = lane + 64u * t;
+                const bool mine = idx < M && keep[t];
+                if (mine && rank[t] < B.slab_events) B.slab[uint64_t(rank[t]) * B.run_stride + item] = make_uint2(pos_bias + j[t], os[idx]);
+                n_ev += mine ? 1u : 0u;
+                const uint32_t c = mine ? cnt[t] : 0u;
+                rec_hi += rec_lo + c < rec_lo ? 1u : 0u;
+                rec_lo += c;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                n_ev += __shfl_xor(n_ev, d, 64);
+                const uint32_t lo2 = __shfl_xor(rec_lo, d, 64), hi2 = __shfl_xor(rec_hi, d, 64);
+                const uint64_t sum = (uint64_t(rec_hi) << 32 | rec_lo) + (uint64_t(hi2) << 32 | lo2);
+                rec_lo = uint32_t(sum);
+                rec_hi = uint32_t(sum >> 32);
+            }
+            if (lane == 0 && n_ev) {
+                B.ev_count[item] = n_ev;
+                B.rec_count[item] = uint64_t(rec_hi) << 32 | rec_lo;
+                if (n_ev > B.slab_events) B.overflow_list[atomicAdd(&B.counters[0], 1u)] = uint32_t(item);
+            }
+            __builtin_amdgcn_wave_barrier();   // (the list is the next item's from here on)
+        }
+    }
+    // statistics, once per wave (a wave that took the serial way for nothing adds nothing)
+    if (lane == 0) {
+        if (walked) atomicAdd(&B.counters[8u + (blockIdx.x & 7u)], (walked + 15u) >> 4);
+        if (fallback16) atomicAdd(&B.counters[7], fallback16);
+        if (serial) atomicAdd(&B.counters[22], serial);
+    }
+}
+
+hipError_t launch_runs_wave(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode, hipStream_t st) {
+    if (max_items == 0 || B.first_only) return hipSuccess;
+    const uint32_t lds = (kWaveThreads / 64u) * 3u * kWaveOccMax * 4u;   // 12 KiB
+    // (the list's length is on the device: a wave per item the batch could have, at most eight workgroups a CU)
+    const uint32_t blocks = uint32_t(std::min<uint64_t>((max_items + kWaveThreads / 64u - 1u) / (kWaveThreads / 64u), uint64_t(num_cus()) * 8u));
+    auto go = [&](auto fn) {
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), uint32_t(lds));
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(fn, dim3(blocks), dim3(kWaveThreads), lds, st, A, B);
+        return hipGetLastError();
+    };
+    const bool extra = A.early_stop != 0u;
+#define ACMI_RUNS_WAVE(E, M) (extra ? go(k_runs_wave<E, M, true>) : go(k_runs_wave<E, M, false>))
+    if (entry_bytes == 2) return class_mode == 1 ? ACMI_RUNS_WAVE(uint16_t, 1) : ACMI_RUNS_WAVE(uint16_t, 0);
+    return class_mode == 1 ? ACMI_RUNS_WAVE(uint32_t, 1) : ACMI_RUNS_WAVE(uint32_t, 0);
+#undef ACMI_RUNS_WAVE
 }
 
 static hipError_t launch_verify_dense(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,
@@ -142,7 +346,7 @@ static hipError_t launch_verify_dense(const DevAutomaton &A, const BatchArgs &B,
 hipError_t launch_walk_runs(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,
                             hipStream_t st, bool stage_tile) {
     if (max_items == 0) return hipSuccess;
-    if (B.run_dense) return launch_verify_dense(A, B, max_items, entry_bytes, class_mode, st);
+    if (B.run_dense == 1u) return launch_verify_dense(A, B, max_items, entry_bytes, class_mode, st);   // (2: window lists of the aligned forms, this kernel's)
     const uint32_t blocks = uint32_t((max_items + kWalkThreads - 1) / kWalkThreads);
     // No tile while the handle's candidates are all decided by text compares (the engine asks for it again as soon as a batch
     // walked a cluster: every fallback cluster through the L2 is not worth it): 64 KiB staged per 1,024 items were 52 -> 49.5 us on

@@ -361,45 +361,69 @@ constexpr uint32_t kProbeQueue = 128;     // entries {hash, window | lane << 5} 
 
 // `entry` of a run: the exact automaton state at `lo` (< 2^24), or
 constexpr uint32_t kEntryUnknown = 0xFFFFFFFFu;    // walk from the root Lmax-1 bytes before lo
-// ... or, from k_scan_anchor, kEntryWindow | start of the hit window the run belongs to (item scan coordinates):
-// every pattern anchored there ends in [start + m_min - 4, start + Lmax); the stored `lo` is that lower bound unless
-// an earlier window's run reached further (then it was clamped to that run's end: the two are adjacent).  Runs
-// are never merged, one per hit window: k_walk_runs sees which runs touch and what every run was flagged for.
+// ... or, derived from a window-list entry of k_scan_anchor (load_run), kEntryWindow | start of the hit window the run
+// belongs to (item scan coordinates): every pattern anchored there ends in [start + m_min - 4, start + Lmax).  One run per
+// hit window, never merged or clamped: k_walk_runs sees which runs touch and what every run was flagged for.
 constexpr uint32_t kEntryWindow = 0x80000000u;
 __device__ __forceinline__ bool entry_is_window(uint32_t e) { return (e & kEntryWindow) != 0u && e != kEntryUnknown; }
 
-__device__ __forceinline__ void stage_flush(const BatchArgs &B, uint64_t wave_first, RunStage &st, uint32_t lane) {
-    for (uint32_t i = lane; i < st.count; i += 64u) {
-        const uint4 e = st.slots[i];
-        B.runs[uint64_t(e.x >> 8) * B.run_stride + wave_first + (e.x & 0xffu)] = make_uint4(e.y, e.z, e.w, 0u);
-    }
-    st.count = 0;
+// ------------------------------------------------------------------------------------------
+// Window lists: what k_scan_anchor hands to the kernels behind it (every form of the filter since round 6; the dense form
+// always did).  An entry is 4 bytes: the start of a hit window in item scan coordinates -- a run's bounds follow from it
+// ([start + lo_bias, min(start + Lmax, n)): load_run below) -- or, bit 31 set, one of the two byte ranges that name no window:
+//   kWinSpecial | hi             the unaligned head of an item: bytes [0, hi), walked from the root at byte 0;
+//   kWinSpecial | kWinTail | lo  the tail whose windows the streaming loop did not test: bytes [lo, n), entered Lmax-1 bytes early.
+// Entry r of item i lives at win_slot(): entry-major (r * run_stride + i: a thread per item reads whole lines -- the sparse
+// batches' layout) or item-major (i * run_cap + r: a wave per item does -- the layout of long lists and of the dense form).
+// (Until round 5 the aligned forms wrote 16-byte runs {lo, hi, entry, -}, clamped against each other one hit at a time through
+// the scalar unit; 4-byte entries have no order dependence, so a task's hits are placed by vector code, and a dense batch's
+// lists are a quarter of the size.)
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kWinSpecial = 0x80000000u, kWinTail = 0x40000000u;
+constexpr uint32_t kWaveRunsMin = 3;     // items with more windows than this are k_runs_wave's where the batch has that kernel
+constexpr uint32_t kWaveOccMax = 256;    // occurrences of one item k_runs_wave orders (its LDS list per wave); also the longest list it takes
+__device__ __forceinline__ uint64_t win_slot(const BatchArgs &B, uint64_t item, uint32_t r) {
+    return B.run_major ? item * uint64_t(B.run_cap) + r : uint64_t(r) * B.run_stride + item;
 }
 
 constexpr uint32_t kDenseStage = 256;   // 8-byte entries in the wave's 2 KiB
+constexpr uint32_t kDenseStageBig = 96; // ... in the 768 B the big-set kernel's probe queue leaves
 __device__ __forceinline__ void dense_flush(const BatchArgs &B, uint64_t wave_first, RunStage &st, uint32_t lane) {
     const uint2 *slots2 = reinterpret_cast<const uint2 *>(st.slots);
     uint32_t *runs32 = reinterpret_cast<uint32_t *>(B.runs);
     for (uint32_t i = lane; i < st.count; i += 64u) {
         const uint2 e = slots2[i];
-        runs32[(wave_first + (e.x & 0xffu)) * uint64_t(B.run_cap) + (e.x >> 8)] = e.y;
+        runs32[win_slot(B, wave_first + (e.x & 0xffu), e.x >> 8)] = e.y;
     }
     st.count = 0;
 }
 
-// Bookkeeping as in append_run (n, last_hi stay in scalar registers), but runs are never merged: adjacent runs
-// stay separate entries (k_walk_runs joins them); k = item index inside the wave batch
-__device__ __forceinline__ void append_run_wave(const BatchArgs &B, uint64_t wave_first, RunStage &st, uint32_t k,
-                                                uint32_t lo, uint32_t hi, uint32_t entry, uint32_t &n,
-                                                uint32_t &last_hi, uint32_t lane) {
-    if (n > B.run_cap) return;
+// One entry of item k's window list, from the scalar path of k_scan_anchor (wave-uniform arguments).  The count keeps running
+// past the list's capacity (the host learns the size a batch asked for from it); entries beyond it are not stored, and
+// n > run_cap means "the whole item" to the kernels behind.
+__device__ __forceinline__ void append_win_wave(const BatchArgs &B, uint64_t wave_first, RunStage &st, uint32_t k, uint32_t value,
+                                                uint32_t &n, uint32_t lane) {
     if (n < B.run_cap) {
-        if (st.count == st.cap) stage_flush(B, wave_first, st, lane);
-        if (lane == 0) st.slots[st.count] = make_uint4(k | (n << 8), lo, hi, entry);
+        if (st.count == st.cap) dense_flush(B, wave_first, st, lane);
+        if (lane == 0) reinterpret_cast<uint2 *>(st.slots)[st.count] = make_uint2(k | (n << 8), value);
         ++st.count;
     }
     ++n;
-    last_hi = hi;
+}
+
+// Run r of an item as run_epilogue_fast wants it, {lo, hi, entry, -}, from its window list.
+__device__ __forceinline__ uint4 load_run(const DevAutomaton &A, const BatchArgs &B, uint64_t item, uint32_t r, uint32_t n) {
+    const uint32_t e = reinterpret_cast<const uint32_t *>(B.runs)[win_slot(B, item, r)];
+    if (e & kWinSpecial) {
+        const uint32_t v = e & 0x3FFFFFFFu;
+        return (e & kWinTail) ? make_uint4(v, n, kEntryUnknown, 0u) : make_uint4(0u, v, 0u, 0u);
+    }
+    // the end of a pattern anchored at window e: at least m_min - 4 past the window start when the window is the pattern's FIRST
+    // aligned dword, at least q - 1 when the builder chose a deeper window (anchor_choice); the scan stores no window whose
+    // lower bound lies behind the item's end
+    const uint32_t lo_bias = A.anchor_choice ? A.anchor_q - 1u : A.min_pattern_length - 4u;
+    const uint32_t hi = e + A.max_pattern_length < n ? e + A.max_pattern_length : n;
+    return make_uint4(e + lo_bias, hi, kEntryWindow | e, 0u);
 }
 
 // 4 haystack bytes -> 4 column offsets (one per byte lane of the result), SWAR3 mode.
@@ -779,13 +803,13 @@ __device__ __forceinline__ void emit_verified(const BatchArgs &B, uint64_t item,
     }
 }
 
-// run_epilogue for k_walk_runs.  k_scan_anchor leaves one run per hit window, ascending and disjoint, a run that
-// begins where its predecessor ends being adjacent to it.  Runs that touch form a CLUSTER: everything that ends
-// inside a cluster is an occurrence of a pattern anchored at one of the cluster's windows (an occurrence anchored
+// run_epilogue for k_walk_runs.  k_scan_anchor leaves one window-list entry per hit window, ascending; the run of a window is
+// the byte range in which a pattern anchored there can end (load_run).  Runs that touch or overlap form a CLUSTER: everything
+// that ends inside a cluster is an occurrence of a pattern anchored at one of the cluster's windows (an occurrence anchored
 // elsewhere would have flagged a run of its own, overlapping this range, hence in the cluster).  So a cluster of
 // window runs is decided by verifying its windows (verify_candidate) and emitting the occurrences found in
 // position order -- of two that end at the same byte only the longer is an event, the shorter is in its output
-// list.  Clusters with a run that names no window (unaligned head, tail, a swallowed window), with a fingerprint slot
+// list.  Clusters with a run that names no window (unaligned head, untested tail), with a fingerprint slot
 // that stands for more than 8 pairs, or with more than kClusterMax occurrences are walked as one range.
 template <typename E, int MODE, bool EXTRA>
 __device__ __forceinline__ uint32_t run_epilogue_fast(const DevAutomaton &A, const BatchArgs &B, const uint8_t *tile,
@@ -802,9 +826,8 @@ __device__ __forceinline__ uint32_t run_epilogue_fast(const DevAutomaton &A, con
         fallback16 += (n + 15u) >> 4;  // statistic: walked through the automaton, not decided by a text compare (summed per workgroup:
                                        // an atomic per cluster on one word serialises the launch at ~ 12 ns each)
     } else {
-        const uint4 *runs = B.runs + item;
         uint32_t r = 0;
-        uint4 run = nr ? runs[0] : make_uint4(0u, 0u, 0u, 0u);
+        uint4 run = nr ? load_run(A, B, item, 0u, n) : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll 1
         while (r < nr) {
             // the cluster that starts with run r
@@ -819,8 +842,8 @@ __device__ __forceinline__ uint32_t run_epilogue_fast(const DevAutomaton &A, con
             for (;;) {
                 ++r;
                 if (r >= nr) break;
-                run = runs[uint64_t(r) * B.run_stride];
-                if (run.x > hi) break;  // neither adjacent nor overlapping (the dense form does not clamp its runs): the next cluster
+                run = load_run(A, B, item, r, n);
+                if (run.x > hi) break;  // neither adjacent nor overlapping (runs are not clamped against each other): the next cluster
                 hi = run.y > hi ? run.y : hi;
                 windows = windows && entry_is_window(run.z);
                 if (windows) windows = verify_candidate(A, p, n, it.floor, run.z & ~kEntryWindow, v, nv);

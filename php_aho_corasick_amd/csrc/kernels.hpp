@@ -27,6 +27,8 @@ hipError_t launch_scan(const DevAutomaton &A, const BatchArgs &B, uint64_t max_i
                        int class_mode, int ilp, int group_quads, hipStream_t st, uint32_t *anchor_variant = nullptr);
 hipError_t launch_walk_runs(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,
                             hipStream_t st, bool stage_tile = true);
+// the items k_walk_runs left for it (BatchArgs::wave_runs): a wave per item, a lane per candidate window (k_walk.hip)
+hipError_t launch_runs_wave(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode, hipStream_t st);
 hipError_t launch_walk_items(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,
                              int ilp, hipStream_t st);
 // k_walk_tiles (k_tiles.hip, kernel 6): the exact walk with exact-sized ordered output in one pass.  Geometry: W bytes per lane,
@@ -61,6 +63,8 @@ void launch_expand(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items
                    uint64_t cap, uint64_t *prefix, uint32_t *host_counters, uint32_t *next_sync, uint32_t next_sync_words,
                    uint32_t *ticket, uint64_t *status, const uint32_t *bad_offsets, bool scan, hipStream_t st,
                    uint32_t *next_isync = nullptr, uint32_t next_isync_words = 0);
+// the items k_expand left in BatchArgs::dense_list (more events than wave_min): a wave per item, a lane per event
+void launch_expand_dense(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, const uint64_t *rec_base, void *out, uint64_t cap, hipStream_t st);
 void launch_refill(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes,
                    const uint64_t *rec_base, void *out, uint64_t cap, int mode, hipStream_t st, int class_mode = 0);
 // one-launch path for small host batches (<= 64 KiB, <= 1024 haystacks): reads / writes pinned host memory
