@@ -585,6 +585,8 @@ static int apply_option(acmi_handle *h, const std::string &k, int64_t value) {
             h->kernel = int(value);
             for (auto &row : h->choice)
                 for (auto &c : row) c = acmi_handle::ChoiceClass{};
+            h->anchor_chunk_shift = 0;   // (what the batches before taught the filter's hand-over goes with the measured choice)
+            h->wave_armed = h->expand_armed = false;
         } else if (k == "reserve_cus") {
             if (value < 0 || value > 128) return ACMI_E_ARG;
             h->reserve_cus = int(value);
@@ -746,6 +748,7 @@ int acmi_get_stat(const acmi_handle *h, const char *key, double *value) {
         else if (k == "overflow_items") *value = h->overflow_items;
         else if (k == "walked_bytes") *value = double(h->walked_bytes);
         else if (k == "fallback_bytes") *value = double(h->fallback_bytes);
+        else if (k == "anchor_chunk_shift") *value = h->anchor_chunk_shift;
         else if (k == "busy_items") *value = h->busy_items;
         else if (k == "max_windows") *value = h->max_windows;
         else if (k == "serial_items") *value = h->serial_items;

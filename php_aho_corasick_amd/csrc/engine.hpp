@@ -106,6 +106,7 @@ struct acmi_handle {
     bool dense_output = false;   // the last batch produced a record per two bytes of text or more (which drain: refill_mode)
     uint32_t run_auto = 0;       // run-list entries per item the data has asked for so far
     bool expand_armed = false;   // the last batch averaged four records a work item or more: k_expand_dense is enqueued with the next
+    uint32_t anchor_chunk_shift = 0;   // the anchor filter's work items are 8 KiB >> this (learned from the windows per item; "anchor_chunk_shift")
     bool wave_armed = false;     // the last filter batch had items with more than a few candidate windows: k_runs_wave is enqueued with the next
     int wave_runs_opt = 1;       // "wave_runs": 0 never launches k_runs_wave (every item is k_walk_runs')
     uint32_t busy_items = 0, max_windows = 0, serial_items = 0;   // of the last filter batch ("busy_items", "max_windows", "serial_items")

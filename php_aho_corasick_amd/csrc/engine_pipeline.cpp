@@ -34,15 +34,19 @@ uint32_t choose_chunk(const acmi_handle *h, uint64_t blob_bytes, size_t nh, int 
     }
     // the anchor kernel streams an item 8 KiB (one wave step) at a time: smaller items idle its lanes
     if (kernel == 2) {
-        cmin = std::max<uint64_t>(cmin, 8192);
+        // (text with hundreds of candidate windows per 8 KiB: smaller items -- a window list, an occurrence list in LDS and an event
+        // slab of an item hold a few hundred entries -- "anchor_chunk_shift", learned: run_batch_end)
+        const uint64_t step = 8192u >> std::min<uint32_t>(h->anchor_chunk_shift, 3u);
+        cmin = std::max<uint64_t>(cmin, step);
         // ... and where haystacks are longer than that (they get chunked), a chunk inside its haystack must fit one step
         // WITH its warm-up, which k_items rounds up to a 128-byte boundary (align_warm): 8 KiB chunks were 513-514 quads,
         // i.e. a second, almost empty step per item (24-KiB haystacks: scan kernel 0.83 instead of 0.67 ms per 4 GiB)
-        if (nh && blob_bytes / nh > 8192 && uint64_t(warm) + 32 < 4096) {
-            const uint64_t steps = std::max<uint64_t>(1, (c0 + 8191) / 8192);  // whole steps per chunk, less the warm-up's room
-            const uint64_t c = steps * 8192 - ((uint64_t(warm) + 128 + 127) & ~uint64_t(127));  // (warm-up rounded to a whole line)
+        if (nh && blob_bytes / nh > step && (uint64_t(warm) + 32) * 2 < step) {
+            const uint64_t steps = h->anchor_chunk_shift ? 1 : std::max<uint64_t>(1, (c0 + step - 1) / step);  // whole steps per chunk, less the warm-up's room
+            const uint64_t c = steps * step - ((uint64_t(warm) + 128 + 127) & ~uint64_t(127));  // (warm-up rounded to a whole line)
             return uint32_t(std::min<uint64_t>(c, 1u << 30));
         }
+        if (h->anchor_chunk_shift) return uint32_t(cmin);
     }
     uint64_t c = std::max<uint64_t>(cmin, (c0 + 127) & ~uint64_t(127));
     return uint32_t(std::min<uint64_t>(c, 1u << 30));
@@ -178,7 +182,7 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     const uint64_t est_items = std::max<uint64_t>(1, std::max<uint64_t>(blob_bytes / chunk, nh));
     if (!h->slab_set) {
         const uint32_t base = (kernel == 2 && fa.anchor_dense) ? 32u : 16u;
-        uint64_t k = blob_bytes / 2 / (est_items * 8);
+        uint64_t k = blob_bytes / (est_items * 8);   // (at most the batch's own bytes; round 5: half of them -- 2 KiB items of dense text need 256 slots)
         k = std::min<uint64_t>(k, (2ull << 30) / ((max_items + 328) * 8));
         uint32_t kmax = base;
         while (kmax * 2 <= k && kmax < 256) kmax *= 2;
@@ -233,12 +237,12 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     // whose filter lost because items overflowed them, before the automatic choice gives the filter up: run_batch_end)
     uint32_t run_max = 16;
     while (run_max < 64u && uint64_t(run_max) * 2 * 16 * est_items * 8 <= blob_bytes) run_max *= 2;
-    // the aligned forms of the anchor filter hand over window lists (4-byte entries, kdev.hpp): up to 256 windows an item -- what
-    // k_runs_wave orders -- and an eighth of the batch's bytes (one window per eight bytes of an average item)
+    // the aligned forms of the anchor filter hand over window lists (4-byte entries, kdev.hpp): up to 1,024 windows an item -- what
+    // k_runs_wave orders -- and half the batch's bytes (one window per eight bytes of an average item)
     const bool win = kernel == 2 && !dense;
     if (win) {
         run_max = 16;
-        while (run_max < 256u && uint64_t(run_max) * 2 * 8 * est_items <= blob_bytes) run_max *= 2;
+        while (run_max < 1024u && uint64_t(run_max) * 2 * 8 * est_items <= blob_bytes) run_max *= 2;
     }
     // (dense form: an item of L bytes has at most L hit windows, and 256 entries for every 256-byte haystack would be 8 x the batch:
     // what an average item can hold, at least 16, and never more than the batch's own bytes in all)
@@ -271,7 +275,7 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     // anchor kernel: the variant that skips the 1-KiB rows a task lacks costs the perfectly regular batch -- haystacks of
     // exactly k x 8 KiB on an aligned blob, every task full: the bench's shape -- 4 % (0.704 vs 0.677 ms) and gains up to 2 x
     // on everything else (short items, last chunks, the 513th quad of an 8-KiB haystack that starts unaligned)
-    const bool regular = blob_bytes % nh == 0 && (blob_bytes / nh) % 8192 == 0 && (reinterpret_cast<uintptr_t>(d_blob) & 15u) == 0;
+    const bool regular = blob_bytes % nh == 0 && (blob_bytes / nh) % 8192 == 0 && (reinterpret_cast<uintptr_t>(d_blob) & 15u) == 0 && chunk >= 8192u;
     B.short_items = kernel != 2 ? 0u : h->short_rows >= 0 ? uint32_t(h->short_rows) : (regular ? 0u : 1u);
     B.tiny_items = (kernel == 2 && h->tiny_rows != 0 && blob_bytes / nh <= 2048) ? 1u : 0u;   // (waves whose items do not all fit a row take the usual path: the average may be skewed by a few long haystacks)
     B.slab_events = K;
@@ -691,6 +695,21 @@ int run_batch_end(acmi_handle *h) {
             while (want < pinned32[21] + pinned32[21] / 4u && want < F.run_max) want *= 2;
             h->run_auto = std::max(h->run_auto, want);
         }
+        // (a window is an event at most -- but for patterns that share an anchor: the slabs follow the lists in one step as well)
+        if (!h->slab_set && pinned32[21] > F.slab_used && h->wave_armed) {
+            uint32_t want = 16;
+            while (want < pinned32[21] && want < 256u) want *= 2;
+            h->slab_auto = std::max(h->slab_auto, want);
+        }
+        // more than ~ 200 windows an item: smaller items (8 KiB -> 4, 2, 1 KiB), so that an item has ~ 128 at most
+        if (!h->chunk_opt && pinned32[21] > 192u && F.chunk_used >= 2048u && h->anchor_chunk_shift < 3u) {
+            uint32_t per = pinned32[21], shift = h->anchor_chunk_shift;
+            uint64_t c = F.chunk_used;
+            while (per > 160u && c >= 2048u && shift < 3u) { per = (per + 1u) / 2u; c /= 2; ++shift; }
+            h->anchor_chunk_shift = shift;
+        } else if (!h->chunk_opt && h->anchor_chunk_shift && pinned32[21] <= 60u) {
+            --h->anchor_chunk_shift;   // (sparser text again: items twice the size would still have ~ 120 windows at most)
+        }
     }
     float pipeline_ms = 0;
     HIPCHK(h, hipEventElapsedTime(&pipeline_ms, F.ev[0], F.ev[4]));
@@ -713,9 +732,23 @@ int run_batch_end(acmi_handle *h) {
     const bool too_small = !F.merged && need > F.out_cap;   // did not fit the optimistic capacity: grow, expand again
     const bool undrained = n_ovf > 0 && !F.refill_launched;      // items overflowed their slabs and the drain was not enqueued
     h->refill_armed = n_ovf > 0;
-    // (a pipeline that has to be completed or run again below says nothing about what the strategy costs)
+    // (a pipeline that has to be completed or run again below says nothing about what the strategy costs -- nor does a batch whose
+    // hand-over behind the filter was still sized for other text: its lists overflowed, its items are about to shrink, or the
+    // kernels that take items with many windows / events a wave each were not enqueued yet.  Such a batch cost the filter 25 ms
+    // per 64 MiB of the 65,536-pattern set at 128 occurrences per 8 KiB, the next one 0.19 -- and the measured choice had left by then)
+    bool handover_learning = false;
+    if (F.win_lists) {
+        const uint32_t busy = pinned32[20], maxw = pinned32[21];
+        handover_learning = (maxw > F.run_used && F.run_used < F.run_max) ||
+                            (busy != 0 && !F.wave_runs && F.find_all && h->wave_runs_opt != 0 && h->dA.anchor_pairs != nullptr) ||
+                            (!h->chunk_opt && maxw > 192u && F.chunk_used >= 2048u && h->anchor_chunk_shift < 3u);
+    }
+    if (F.find_all && F.kernel_used != 6 && F.args.dense_list == nullptr && h->wave_runs_opt != 0 && total >= 4 * std::max<uint64_t>(1, h->items))
+        handover_learning = true;   // (k_expand_dense joins from the next batch on)
     if (F.strategy >= 0 && F.blob_bytes >= kAutoMinBytes) {
-        if (F.timed && !too_small && !undrained) learn_strategy(h, F, double(pipeline_ms) * double(1ull << 30) / double(F.blob_bytes), double(total) / double(F.blob_bytes));
+        if (F.timed && !too_small && !undrained && handover_learning) {
+            if (F.probe) h->choice[F.find_all ? 1 : 0][F.choice_class].pending |= 1u << F.strategy;   // (the probe is taken again)
+        } else if (F.timed && !too_small && !undrained) learn_strategy(h, F, double(pipeline_ms) * double(1ull << 30) / double(F.blob_bytes), double(total) / double(F.blob_bytes));
         else if (F.probe) h->choice[F.find_all ? 1 : 0][F.choice_class].pending |= 1u << F.strategy;   // (the probe is taken again)
     }
     F.reran = too_small || undrained;

@@ -717,8 +717,9 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
         // (the big-set kernel only: in the small-set kernel's 128 registers the path spilled sixteen of them into the streaming loop)
         auto flag_vector = [&]() -> bool {
             if constexpr (!BIG) return false;
+            static_assert(!BIG || G == 4, "two row counts to a word");
             const uint32_t qi0 = sc.c * TQ + lane;
-            uint32_t pk_lo = 0, pk_hi = 0;
+            uint32_t pk_lo = 0, pk_hi = 0;   // the lane's hit counts of rows 0, 1 / 2, 3, sixteen bits each (a row of 64 quads has 256 windows)
 #pragma unroll
             for (int r = 0; r < G; ++r) {
                 const uint32_t qi = qi0 + 64u * uint32_t(r);
@@ -735,29 +736,34 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                 }
                 z[r] = zr;
                 const uint32_t c = uint32_t(__builtin_popcount(zr));
-                if (r < 4) pk_lo |= c << (8 * r); else pk_hi |= c << (8 * (r - 4));
+                if (r < 2) pk_lo |= c << (16 * r); else pk_hi |= c << (16 * (r - 2));
             }
-            const uint32_t mine = ((pk_lo * 0x01010101u) >> 24) + ((pk_hi * 0x01010101u) >> 24);
-            const uint32_t T = __builtin_amdgcn_readlane(wave_inclusive_sum(mine), 63);
-            if (T == 0u) return true;
-            if (T > 255u || T > stage.cap) return false;   // (the packed row counts would carry / more than the stage holds: one by one)
-            if (nrun + T > B.run_cap) { nrun += T; return true; }   // more windows than the list holds: counted, the item is walked whole
-            if (stage.count + T > stage.cap) dense_flush(B, wave_first, stage, lane);
             const uint32_t in_lo = wave_inclusive_sum(pk_lo), in_hi = wave_inclusive_sum(pk_hi);
             const uint32_t tot_lo = __builtin_amdgcn_readlane(in_lo, 63), tot_hi = __builtin_amdgcn_readlane(in_hi, 63);
+            const uint32_t T = (tot_lo & 0xffffu) + (tot_lo >> 16) + (tot_hi & 0xffffu) + (tot_hi >> 16);
+            if (T == 0u) return true;
+            if (nrun + T > B.run_cap) { nrun += T; return true; }   // more windows than the list holds: counted, the item is walked whole
+            // few: through the stage, like the single hits; many (more than the stage has room for): straight into the item's list --
+            // consecutive entries, and item-major lists (long lists are) make the lanes' stores contiguous
+            const bool direct = T > stage.cap;
+            if (!direct && stage.count + T > stage.cap) dense_flush(B, wave_first, stage, lane);
             uint2 *slots2 = reinterpret_cast<uint2 *>(stage.slots);
+            uint32_t *runs32 = reinterpret_cast<uint32_t *>(B.runs);
             uint32_t rowbase = 0;   // hits of the rows before this one (wave-uniform)
 #pragma unroll
             for (int r = 0; r < G; ++r) {
-                const uint32_t sh = 8u * uint32_t(r & 3);
-                const uint32_t cnt = ((r < 4 ? pk_lo : pk_hi) >> sh) & 0xffu, incl = ((r < 4 ? in_lo : in_hi) >> sh) & 0xffu;
+                const uint32_t sh = 16u * uint32_t(r & 1);
+                const uint32_t cnt = ((r < 2 ? pk_lo : pk_hi) >> sh) & 0xffffu, incl = ((r < 2 ? in_lo : in_hi) >> sh) & 0xffffu;
                 uint32_t at = stage.count + rowbase + incl - cnt, idx = nrun + rowbase + incl - cnt;
                 const uint32_t s0 = sc.head + ((qi0 + 64u * uint32_t(r)) << 4) - (q - 4u);
-                for (uint32_t m = z[r]; m != 0; m &= m - 1, ++at, ++idx)
-                    slots2[at] = make_uint2(sc.k | (idx << 8), s0 + 4u * uint32_t(__builtin_ctz(m)));
-                rowbase += ((r < 4 ? tot_lo : tot_hi) >> sh) & 0xffu;
+                for (uint32_t m = z[r]; m != 0; m &= m - 1, ++at, ++idx) {
+                    const uint32_t start = s0 + 4u * uint32_t(__builtin_ctz(m));
+                    if (direct) runs32[win_slot(B, wave_first + sc.k, idx)] = start;
+                    else slots2[at] = make_uint2(sc.k | (idx << 8), start);
+                }
+                rowbase += ((r < 2 ? tot_lo : tot_hi) >> sh) & 0xffffu;
             }
-            stage.count += T;
+            if (!direct) stage.count += T;
             nrun += T;
             return true;
         };

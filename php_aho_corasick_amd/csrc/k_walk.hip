@@ -178,141 +178,136 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_runs(DevAutomaton A, Batc
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kWaveThreads = 256;   // (four waves: a workgroup lives as long as its slowest wave)
 
+// occ_max: entries of a wave's occurrence list (LDS: {window, end, state, records} x occ_max per wave), a power of two >= the longest
+// window list of the batch, 256 .. kWaveOccMax
 template <typename E, int MODE, bool EXTRA>
-__global__ __launch_bounds__(kWaveThreads) void k_runs_wave(DevAutomaton A, BatchArgs B) {
+__global__ __launch_bounds__(kWaveThreads) void k_runs_wave(DevAutomaton A, BatchArgs B, uint32_t occ_max) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t *const oj = reinterpret_cast<uint32_t *>(smem) + wave * (3u * kWaveOccMax), *const os = oj + kWaveOccMax, *const oc = os + kWaveOccMax;
+    uint32_t *const ow = reinterpret_cast<uint32_t *>(smem) + wave * (4u * occ_max), *const oj = ow + occ_max, *const os = oj + occ_max, *const oc = os + occ_max;
     const uint32_t n_list = B.counters[20];   // (k_walk_runs' list of the items it left to this kernel)
     const uint32_t *starts = reinterpret_cast<const uint32_t *>(B.runs);
+    const uint32_t l_max = A.max_pattern_length;
     uint32_t walked = 0, fallback16 = 0, serial = 0;
-    {
 #pragma unroll 1
-        for (uint32_t w = blockIdx.x * (kWaveThreads / 64u) + wave; w < n_list; w += gridDim.x * (kWaveThreads / 64u)) {
-            const uint64_t item = uint32_t(__builtin_amdgcn_readfirstlane(int(B.busy_list[w])));
-            const uint32_t nr = uint32_t(__builtin_amdgcn_readfirstlane(int(B.run_count[item])));
-            const uint4 rec = B.item_rec[item];
-            ItemDesc it;
-            unpack_item(rec.x, rec.y, rec.z, rec.w, it);
-            const uint8_t *p = B.blob + (it.begin - it.warm);
-            const uint32_t n = it.warm + it.len;
-            const uint32_t pos_bias = it.pos0 - it.warm + 1u;
-            // ---- every window decided, a lane each; the occurrences into the wave's list ----
-            uint32_t M = 0;
-            bool ok = A.anchor_pairs != nullptr && nr <= kWaveOccMax;
+    for (uint32_t w = blockIdx.x * (kWaveThreads / 64u) + wave; w < n_list; w += gridDim.x * (kWaveThreads / 64u)) {
+        const uint64_t item = uint32_t(__builtin_amdgcn_readfirstlane(int(B.busy_list[w])));
+        const uint32_t nr = uint32_t(__builtin_amdgcn_readfirstlane(int(B.run_count[item])));
+        const uint4 rec = B.item_rec[item];
+        ItemDesc it;
+        unpack_item(rec.x, rec.y, rec.z, rec.w, it);
+        const uint8_t *p = B.blob + (it.begin - it.warm);
+        const uint32_t n = it.warm + it.len;
+        const uint32_t pos_bias = it.pos0 - it.warm + 1u;
+        // ---- every window decided, a lane each; the occurrences into the wave's list, in window order ----
+        uint32_t M = 0;
+        bool ok = A.anchor_pairs != nullptr;
 #pragma unroll 1
-            for (uint32_t c = 0; c < nr && ok; c += 64u) {
-                const uint32_t r = c + lane;
-                const bool active = r < nr;
-                const uint32_t e = active ? starts[win_slot(B, item, r)] : 0u;
-                Verified v[kClusterMax];
+        for (uint32_t c = 0; c < nr && ok; c += 64u) {
+            const uint32_t r = c + lane;
+            const bool active = r < nr;
+            const uint32_t e = active ? starts[win_slot(B, item, r)] : 0u;
+            Verified v[kClusterMax];
 #pragma unroll
-                for (uint32_t i = 0; i < kClusterMax; ++i) v[i] = Verified{0xFFFFFFFFu, 0u, 0u};
-                uint32_t nv = 0;
-                bool decided = (e & kWinSpecial) == 0u;
-                if (active && decided) decided = verify_candidate(A, p, n, it.floor, e, v, nv);
-                if (__any(!decided)) { ok = false; break; }
-                const uint32_t incl = wave_inclusive_sum(nv);
-                const uint32_t tot = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
-                if (M + tot > kWaveOccMax) { ok = false; break; }
-                const uint32_t at = M + incl - nv;
+            for (uint32_t i = 0; i < kClusterMax; ++i) v[i] = Verified{0xFFFFFFFFu, 0u, 0u};
+            uint32_t nv = 0;
+            bool decided = (e & kWinSpecial) == 0u;
+            if (active && decided) decided = verify_candidate(A, p, n, it.floor, e, v, nv);
+            if (__any(!decided)) { ok = false; break; }
+            const uint32_t incl = wave_inclusive_sum(nv);
+            const uint32_t tot = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
+            if (M + tot > occ_max) { ok = false; break; }
+            const uint32_t at = M + incl - nv;
 #pragma unroll
-                for (uint32_t i = 0; i < kClusterMax; ++i) {
-                    if (i < nv) {
-                        // (ends in the warm-up are the item before's: they take no part in the order)
-                        oj[at + i] = v[i].j >= it.warm ? v[i].j : 0xFFFFFFFFu;
-                        os[at + i] = v[i].state;
-                        oc[at + i] = v[i].cnt;
-                    }
+            for (uint32_t i = 0; i < kClusterMax; ++i) {
+                if (i < nv) {
+                    ow[at + i] = e;
+                    // (ends in the warm-up are the item before's: they take no part in the order)
+                    oj[at + i] = v[i].j >= it.warm ? v[i].j : 0xFFFFFFFFu;
+                    os[at + i] = v[i].state;
+                    oc[at + i] = v[i].cnt;
                 }
-                M += tot;
             }
-            if (!ok) {
-                if (lane == 0) {
-                    walked += run_epilogue_fast<E, MODE, EXTRA>(A, B, smem, 0u, item, it, nr, fallback16);
-                    ++serial;
-                }
-                continue;
+            M += tot;
+        }
+        if (!ok) {
+            if (lane == 0) {
+                walked += run_epilogue_fast<E, MODE, EXTRA>(A, B, smem, 0u, item, it, nr, fallback16);
+                ++serial;
             }
-            if (M == 0u) continue;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // ---- the order: entry idx = lane + 64 t.  First the duplicates of an end go (all but the one with the most records),
-            // then an entry's rank is the number of kept ends below its own ----
-            constexpr uint32_t T = kWaveOccMax / 64u;
-            uint32_t j[T], cnt[T];
-            bool keep[T];
-#pragma unroll
-            for (uint32_t t = 0; t < T; ++t) {
-                const uint32_t idx = lane + 64u * t;
-                j[t] = idx < M ? oj[idx] : 0xFFFFFFFFu;
-                cnt[t] = idx < M ? oc[idx] : 0u;
-                keep[t] = j[t] != 0xFFFFFFFFu;
-            }
-            // (the usual item: its ends ascend with its windows -- every entry is an event, in list order)
-            bool ascending = true;
-#pragma unroll
-            for (uint32_t t = 0; t < T; ++t) {
-                const uint32_t idx = lane + 64u * t;
-                if (idx < M) ascending = ascending && keep[t] && (idx == 0u || oj[idx - 1u] < j[t]);
-            }
-            uint32_t rank[T];
-            if (__all(ascending)) {
-#pragma unroll
-                for (uint32_t t = 0; t < T; ++t) rank[t] = lane + 64u * t;
-            } else {
+            continue;
+        }
+        if (M == 0u) continue;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- the order.  The list is in window order, and an occurrence anchored at window w ends in [w + 3, w + Lmax): only
+        // entries whose windows lie less than Lmax bytes apart can end in the other order or at the same byte.  So an entry looks
+        // at its NEIGHBOURHOOD only (a few entries each way, whatever the list's length): first the duplicates of an end go -- all
+        // but the one with the most records, the earlier of equals --, then an entry's rank is its index among the kept entries,
+        // less the kept neighbours before it that end later, plus those behind it that end earlier.
+        const uint32_t rounds = (M + 63u) >> 6;
+        uint32_t keep_bits = 0;   // bit t: entry lane + 64 t is an event
 #pragma unroll 1
-                for (uint32_t i = 0; i < M; ++i) {
-                    const uint32_t ji = oj[i], ci = oc[i];
-#pragma unroll
-                    for (uint32_t t = 0; t < T; ++t)
-                        if (ji == j[t] && (ci > cnt[t] || (ci == cnt[t] && i < lane + 64u * t))) keep[t] = false;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (uint32_t t = 0; t < T; ++t) {
-                    const uint32_t idx = lane + 64u * t;
-                    if (idx < M && !keep[t]) oj[idx] = 0xFFFFFFFFu;
-                    rank[t] = 0;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll 1
-                for (uint32_t i = 0; i < M; ++i) {
-                    const uint32_t ji = oj[i];
-#pragma unroll
-                    for (uint32_t t = 0; t < T; ++t) rank[t] += ji < j[t] ? 1u : 0u;
-                }
+        for (uint32_t t = 0; t < rounds; ++t) {
+            const uint32_t idx = lane + 64u * t;
+            if (idx < M) {
+                const uint32_t wj = ow[idx], j = oj[idx], cnt = oc[idx];
+                bool keep = j != 0xFFFFFFFFu;
+                for (uint32_t i = idx; keep && i > 0u && ow[i - 1u] + l_max > wj; --i)
+                    if (oj[i - 1u] == j && oc[i - 1u] >= cnt) keep = false;
+                for (uint32_t i = idx + 1u; keep && i < M && ow[i] < wj + l_max; ++i)
+                    if (oj[i] == j && oc[i] > cnt) keep = false;
+                keep_bits |= keep ? (1u << t) : 0u;
             }
-            uint32_t n_ev = 0, rec_lo = 0, rec_hi = 0;
-#pragma unroll
-            for (uint32_t t = 0; t < T; ++t) {
-                const uint32_t idx = lane + 64u * t;
-                const bool mine = idx < M && keep[t];
-                if (mine && rank[t] < B.slab_events) B.slab[uint64_t(rank[t]) * B.run_stride + item] = make_uint2(pos_bias + j[t], os[idx]);
-                n_ev += mine ? 1u : 0u;
-                const uint32_t c = mine ? cnt[t] : 0u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+        for (uint32_t t = 0; t < rounds; ++t) {
+            const uint32_t idx = lane + 64u * t;
+            if (idx < M && ((keep_bits >> t) & 1u) == 0u) oj[idx] = 0xFFFFFFFFu;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t before = 0;      // kept entries of the rounds before (wave-uniform)
+        uint32_t rec_lo = 0, rec_hi = 0;
+#pragma unroll 1
+        for (uint32_t t = 0; t < rounds; ++t) {
+            const uint32_t idx = lane + 64u * t;
+            const bool keep = ((keep_bits >> t) & 1u) != 0u;
+            const uint64_t km = __ballot(keep);
+            if (keep) {
+                const uint32_t wj = ow[idx], j = oj[idx];
+                uint32_t rank = before + __builtin_amdgcn_mbcnt_hi(uint32_t(km >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(km), 0u));
+                for (uint32_t i = idx; i > 0u && ow[i - 1u] + l_max > wj; --i) {
+                    const uint32_t ji = oj[i - 1u];
+                    rank -= (ji != 0xFFFFFFFFu && ji > j) ? 1u : 0u;
+                }
+                for (uint32_t i = idx + 1u; i < M && ow[i] < wj + l_max; ++i) rank += oj[i] < j ? 1u : 0u;
+                if (rank < B.slab_events) B.slab[uint64_t(rank) * B.run_stride + item] = make_uint2(pos_bias + j, os[idx]);
+                const uint32_t c = oc[idx];
                 rec_hi += rec_lo + c < rec_lo ? 1u : 0u;
                 rec_lo += c;
             }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                n_ev += __shfl_xor(n_ev, d, 64);
-                const uint32_t lo2 = __shfl_xor(rec_lo, d, 64), hi2 = __shfl_xor(rec_hi, d, 64);
-                const uint64_t sum = (uint64_t(rec_hi) << 32 | rec_lo) + (uint64_t(hi2) << 32 | lo2);
-                rec_lo = uint32_t(sum);
-                rec_hi = uint32_t(sum >> 32);
-            }
-            if (lane == 0 && n_ev) {
-                B.ev_count[item] = n_ev;
-                B.rec_count[item] = uint64_t(rec_hi) << 32 | rec_lo;
-                if (n_ev > B.slab_events) B.overflow_list[atomicAdd(&B.counters[0], 1u)] = uint32_t(item);
-            }
-            __builtin_amdgcn_wave_barrier();   // (the list is the next item's from here on)
+            before += uint32_t(__builtin_popcountll(km));
         }
+        const uint32_t n_ev = before;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const uint32_t lo2 = __shfl_xor(rec_lo, d, 64), hi2 = __shfl_xor(rec_hi, d, 64);
+            const uint64_t sum = (uint64_t(rec_hi) << 32 | rec_lo) + (uint64_t(hi2) << 32 | lo2);
+            rec_lo = uint32_t(sum);
+            rec_hi = uint32_t(sum >> 32);
+        }
+        if (lane == 0 && n_ev) {
+            B.ev_count[item] = n_ev;
+            B.rec_count[item] = uint64_t(rec_hi) << 32 | rec_lo;
+            if (n_ev > B.slab_events) B.overflow_list[atomicAdd(&B.counters[0], 1u)] = uint32_t(item);
+        }
+        __builtin_amdgcn_wave_barrier();   // (the list is the next item's from here on)
     }
     // statistics, once per wave (a wave that took the serial way for nothing adds nothing)
     if (lane == 0) {
@@ -324,13 +319,15 @@ __global__ __launch_bounds__(kWaveThreads) void k_runs_wave(DevAutomaton A, Batc
 
 hipError_t launch_runs_wave(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode, hipStream_t st) {
     if (max_items == 0 || B.first_only) return hipSuccess;
-    const uint32_t lds = (kWaveThreads / 64u) * 3u * kWaveOccMax * 4u;   // 12 KiB
+    uint32_t occ_max = 256;
+    while (occ_max < B.run_cap && occ_max < kWaveOccMax) occ_max *= 2;
+    const uint32_t lds = (kWaveThreads / 64u) * 4u * occ_max * 4u;   // 16 KiB .. 64 KiB
     // (the list's length is on the device: a wave per item the batch could have, at most eight workgroups a CU)
     const uint32_t blocks = uint32_t(std::min<uint64_t>((max_items + kWaveThreads / 64u - 1u) / (kWaveThreads / 64u), uint64_t(num_cus()) * 8u));
     auto go = [&](auto fn) {
         hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), uint32_t(lds));
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(fn, dim3(blocks), dim3(kWaveThreads), lds, st, A, B);
+        hipLaunchKernelGGL(fn, dim3(blocks), dim3(kWaveThreads), lds, st, A, B, occ_max);
         return hipGetLastError();
     };
     const bool extra = A.early_stop != 0u;

@@ -381,7 +381,7 @@ __device__ __forceinline__ bool entry_is_window(uint32_t e) { return (e & kEntry
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kWinSpecial = 0x80000000u, kWinTail = 0x40000000u;
 constexpr uint32_t kWaveRunsMin = 3;     // items with more windows than this are k_runs_wave's where the batch has that kernel
-constexpr uint32_t kWaveOccMax = 256;    // occurrences of one item k_runs_wave orders (its LDS list per wave); also the longest list it takes
+constexpr uint32_t kWaveOccMax = 1024;   // occurrences of one item k_runs_wave orders at most (its LDS list per wave); also the longest window list
 __device__ __forceinline__ uint64_t win_slot(const BatchArgs &B, uint64_t item, uint32_t r) {
     return B.run_major ? item * uint64_t(B.run_cap) + r : uint64_t(r) * B.run_stride + item;
 }
