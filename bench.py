@@ -397,15 +397,19 @@ def benchmark_php_leg(api, synth, samples=10):
 def density_leg(torch, api, batch, synth, dev, nh=1 << 17):
     """How a whole call degrades with the density of matches: the headline patterns with 1 / 16 / 64 / 256
     planted occurrences per 8 KiB haystack, and the 2,048-word list over prose of which a share is listed words (53 / 200 / 910
-    records per 8 KiB), 1 GiB each, automatic kernel choice (measured: engine.cpp choose_strategy); the first 32 haystacks of
-    every cell against the oracle.  ms per algorithmic GB is what neighbouring cells are compared by."""
+    records per 8 KiB), and the 65,536-pattern set of config 3 with 32 / 128 / 512 planted occurrences per 8 KiB (round 6: tens to
+    hundreds of candidate windows per work item behind the big-set filter), 1 GiB each, automatic kernel choice (measured:
+    engine.cpp choose_strategy); the first 32 (cfg3: 8) haystacks of every cell against the oracle.  ms per algorithmic GB is what
+    neighbouring cells are compared by."""
     from oracle import pyoracle
     cells = []
-    sets = {"headline": synth.density_set("headline"), "words": synth.density_set("words")}
-    plan = [("headline", "plants", p) for p in (1, 16, 64, 256)] + [("words", "prose", sh) for sh in (0.05, 0.2, 1.0)]
+    sets = {"headline": synth.density_set("headline"), "words": synth.density_set("words"), "cfg3": synth.density_set("cfg3")}
+    plan = [("headline", "plants", p) for p in (1, 16, 64, 256)] + [("words", "prose", sh) for sh in (0.05, 0.2, 1.0)] + \
+           [("cfg3", "plants", p) for p in (32, 128, 512)]   # (the 65,536-pattern set: round 5's weakest cells, 0.007-0.015)
     oracles, handles = {}, {}
     for kind, base in sets.items():
-        o = pyoracle.Oracle("port")
+        # (the 65,536-pattern trie takes the port seconds to build and the compiled reference half of that: whichever is there)
+        o = pyoracle.Oracle("reference" if kind == "cfg3" and pyoracle.have_reference() else "port")
         o.add_patterns((base.pat_blob, base.pat_off))
         oracles[kind] = o
     for kind, how, level in plan:
@@ -426,7 +430,7 @@ def density_leg(torch, api, batch, synth, dev, nh=1 << 17):
             ms.append((time.perf_counter() - t0) * 1e3)
         t = float(np.median(ms))
         prefix, rec = batch.result_numpy(res, nh, total)
-        n_chk = 32
+        n_chk = 8 if kind == "cfg3" else 32
         pe, re_ = oracles[kind].match_batch(ds.hay_blob[:int(ds.hay_off[n_chk])], ds.hay_off[:n_chk + 1], True)
         ok = np.array_equal(prefix[:n_chk + 1], pe) and np.array_equal(rec[:int(pe[-1])], re_) and total == int(prefix[ds.n_haystacks]) * reps
         algo = d_blob.numel() + 16 * total + 8 * nh

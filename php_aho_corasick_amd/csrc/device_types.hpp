@@ -81,12 +81,13 @@ struct BatchArgs {
                                  // below, a haystack that starts unaligned is scanned from the 16-byte boundary below (ItemDesc::floor);
                                  // 2 (LDS-tile walk) both from the 128-byte line below, the bytes under `floor` masked
     uint32_t slab_events;        // K: event slots per work item
+    uint32_t slab_major;         // 1: the slab is item-major (kdev.hpp slab_slot)
     uint32_t first_only;         // findAll == false
     uint32_t *item_hay;          // per item: haystack index
     uint4 *item_rec;             // per item: {scan offset lo, hi | warm << 16, scan bytes, pos0} (k_scan_anchor)
     uint32_t *ev_count;          // per item: events seen
     uint64_t *rec_count;         // per item: records those events expand to
-    uint2 *slab;                 // event e of item i at slab[e * run_stride + i]: {pos, state}; K events per item
+    uint2 *slab;                 // event e of item i at slab[slab_slot(i, e)] (e * run_stride + i, or i * K + e): {pos, state}; K events per item
     uint32_t *overflow_list;     // items whose events did not fit their slab
     uint32_t *counters;          // [0] = number of overflowed items
     // main loop -> epilogue hand-over inside k_scan_lds: byte runs of an item that need the exact path

@@ -101,7 +101,7 @@ int choose_strategy(acmi_handle *h, acmi_handle::FlySlot &F, uint64_t blob_bytes
 // expected to: below the 1.3 x the cliff test allows (tests/test_gpu_cliffs.py) -- at 1.5 a 2,048-word list with 8 matches per
 // 8 KiB sat at 2.93 ms per GiB on the filter, 1.49 x the whole-automaton walk's expected 1.97 (measured: 1.92), and whether it was
 // ever probed was a matter of the third digit.
-constexpr float kProbeMargin = 1.25f;
+constexpr float kProbeMargin = 1.2f;
 
 void learn_strategy(acmi_handle *h, const acmi_handle::FlySlot &F, double ms_per_gib, double density) {
     acmi_handle::ChoiceClass &C = h->choice[F.find_all ? 1 : 0][F.choice_class];

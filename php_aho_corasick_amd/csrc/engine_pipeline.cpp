@@ -279,6 +279,7 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     B.short_items = kernel != 2 ? 0u : h->short_rows >= 0 ? uint32_t(h->short_rows) : (regular ? 0u : 1u);
     B.tiny_items = (kernel == 2 && h->tiny_rows != 0 && blob_bytes / nh <= 2048) ? 1u : 0u;   // (waves whose items do not all fit a row take the usual path: the average may be skewed by a few long haystacks)
     B.slab_events = K;
+    B.slab_major = K > 16u ? 1u : 0u;   // (big slabs -- text full of matches -- are item-major: kdev.hpp slab_slot)
     B.first_only = find_all ? 0u : 1u;
     B.item_hay = d_item_hay.as<uint32_t>();
     B.item_rec = d_item_rec.as<uint4>();
@@ -295,8 +296,10 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     B.wave_runs = wave_runs ? 1u : 0u;
     // a wave per item against a lane per item: the chip holds ~ 8,192 of k_runs_wave's waves at a time and 262,144 of k_walk_runs' lanes,
     // a window costs either the same chain of round trips -- so an item is the wave kernel's when it has more windows than the
-    // batch's items take turns of waves (64 MiB of 8 KiB items: from four windows on; of 256-byte haystacks: from 33)
-    B.wave_min = uint32_t(std::min<uint64_t>(255, std::max<uint64_t>(kWaveRunsMinHost, est_items / 8192)));
+    // batch's items take turns of waves (64 MiB of 8 KiB items: from four windows on; of 256-byte haystacks: from nine)
+    // (... up to eight: beyond that the one lane's way is not a window's chain eight times over -- clusters of more than six
+    // occurrences are WALKED, through tables in global memory for a big set: 1 KiB items with 64 windows each took 5.6 ms per GiB)
+    B.wave_min = uint32_t(std::min<uint64_t>(8, std::max<uint64_t>(kWaveRunsMinHost, est_items / 8192)));
     // ... and the same for the expansion: k_expand_dense (a wave per item, a lane per event) is enqueued behind k_expand while the
     // batches before averaged four records an item or more (kernel 6 writes its records itself)
     const bool expand_dense = find_all && kernel != 6 && h->expand_armed && h->wave_runs_opt != 0;

@@ -186,8 +186,8 @@ __global__ __launch_bounds__(kExpandThreads, LOWREG ? 8 : 4) void k_expand(DevAu
         prev0 = base ? B.item_hay[base - 1] : 0xFFFFFFFFu;
         n0 = B.ev_count[base];
         if (n0 != 0u && n0 <= B.slab_events) {
-            ev0 = B.slab[base];
-            if (n0 > 1u) ev1 = B.slab[B.run_stride + base];
+            ev0 = B.slab[slab_slot(B, base, 0u)];
+            if (n0 > 1u) ev1 = B.slab[slab_slot(B, base, 1u)];
             if (A.out_head != nullptr) head0 = A.out_head[ev0.y];
         }
     }
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(kExpandThreads, LOWREG ? 8 : 4) void k_expand(DevAu
         uint2 ev_a = ev0, hd_a = head0, ev_b = ev1;
         for (uint32_t e = 0; e < n; ++e) {
             uint2 ev_c = make_uint2(0u, 0u), hd_b = make_uint2(0u, 0u);
-            if (e + 2u < n) ev_c = B.slab[uint64_t(e + 2u) * B.run_stride + g];  // event-major, like the run lists
+            if (e + 2u < n) ev_c = B.slab[slab_slot(B, g, e + 2u)];  // event-major, like the run lists
             if (e + 1u < n && A.out_head != nullptr) hd_b = A.out_head[ev_b.y];
             if ((hd_a.x >> 24) == 1u) out[w++] = make_uint4(hay, ev_a.x, ev_a.x - hd_a.y, hd_a.x & 0xFFFFFFu);
             else w = emit_event(A, out, w, hay, ev_a.x, ev_a.y);
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void k_expand_dense(DevAutomaton A, BatchArgs 
         for (uint32_t c = 0; c < n; c += 64u) {
             const uint32_t e = c + lane;
             const bool active = e < n;
-            const uint2 ev = active ? B.slab[uint64_t(e) * B.run_stride + g] : make_uint2(0u, 0u);
+            const uint2 ev = active ? B.slab[slab_slot(B, g, e)] : make_uint2(0u, 0u);
             uint2 hd = make_uint2(0u, 0u);
             uint32_t cnt = 0;
             if (active) {

@@ -287,7 +287,7 @@ __global__ __launch_bounds__(kWaveThreads) void k_runs_wave(DevAutomaton A, Batc
                     rank -= (ji != 0xFFFFFFFFu && ji > j) ? 1u : 0u;
                 }
                 for (uint32_t i = idx + 1u; i < M && ow[i] < wj + l_max; ++i) rank += oj[i] < j ? 1u : 0u;
-                if (rank < B.slab_events) B.slab[uint64_t(rank) * B.run_stride + item] = make_uint2(pos_bias + j, os[idx]);
+                if (rank < B.slab_events) B.slab[slab_slot(B, item, rank)] = make_uint2(pos_bias + j, os[idx]);
                 const uint32_t c = oc[idx];
                 rec_hi += rec_lo + c < rec_lo ? 1u : 0u;
                 rec_lo += c;
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(1024) void k_dense_decide(DevAutomaton A, BatchArgs
                 }
                 const uint32_t n_ev = uint32_t(__builtin_popcountll(em));
                 if (ev_mine && before < B.slab_events)
-                    B.slab[uint64_t(before) * B.run_stride + item] = make_uint2(it.pos0 - it.warm + 1u + j, r0 & 0xFFFFFFu);
+                    B.slab[slab_slot(B, item, before)] = make_uint2(it.pos0 - it.warm + 1u + j, r0 & 0xFFFFFFu);
                 if (lane == 0) {
                     if (n_ev) {
                         B.ev_count[item] = n_ev;

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(kWalkThreads, (LB <= 4 ? 8 : 4)) void k_walk_items(
                 // on vmcnt AND lgkmcnt -- every event then waited for the text requested a group ahead)
                 if (st < cnt_rows) ev.n_rec += *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>(uint32_t(reinterpret_cast<uintptr_t>(cnt_lds)) + st * 4u);
                 else ev.n_rec += A.out_count[st];
-                if (ev.n_ev < B.slab_events) B.slab[uint64_t(ev.n_ev) * B.run_stride + item] = make_uint2(pos_bias + jj, st);
+                if (ev.n_ev < B.slab_events) B.slab[slab_slot(B, item, ev.n_ev)] = make_uint2(pos_bias + jj, st);
             }
             ++ev.n_ev;
         }

@@ -119,6 +119,13 @@ __device__ __forceinline__ bool is_final(const DevAutomaton &A, uint32_t s) {
     return (s >= A.f1 && s < A.trap) || s >= A.f2;
 }
 
+// Event e of item i in the slab: event-major for small slabs (a thread per item reads and writes whole lines across the items), item-major
+// for big ones (BatchArgs::slab_major: an item's events are one contiguous piece -- what a wave per item writes and reads; event-major,
+// the 67 M events of a GiB of dense text were 67 M partial lines spread over a 1.2 GB slab)
+__device__ __forceinline__ uint64_t slab_slot(const BatchArgs &B, uint64_t item, uint32_t e) {
+    return B.slab_major ? item * uint64_t(B.slab_events) + e : uint64_t(e) * B.run_stride + item;
+}
+
 // Per-item event sink.  Events, not records, are stored: one {pos, state} per arrival in a
 // final state; the per-state output list is expanded later (k_expand / k_refill).  The
 // counters live in global memory (zeroed before the launch) rather than in registers: events
@@ -128,7 +135,7 @@ __device__ __forceinline__ void on_event(const DevAutomaton &A, const BatchArgs 
     const uint32_t n = B.ev_count[item];
     if (B.first_only && n) return;  // findAll=false: the first event only (php_ahocorasick.c:588)
     B.rec_count[item] += A.out_count[s];
-    if (n < B.slab_events) B.slab[uint64_t(n) * B.run_stride + item] = make_uint2(pos, s);
+    if (n < B.slab_events) B.slab[slab_slot(B, item, n)] = make_uint2(pos, s);
     B.ev_count[item] = n + 1;
 }
 
@@ -510,7 +517,7 @@ __device__ __forceinline__ uint32_t exact_range(const DevAutomaton &A, const Bat
         s = w;
         if (j >= rep_from && is_final(A, s) && !(B.first_only && ev.n_ev)) {
             ev.n_rec += A.out_count[s];
-            if (store && ev.n_ev < B.slab_events) B.slab[uint64_t(ev.n_ev) * B.run_stride + item] = make_uint2(pos_bias + j, s);
+            if (store && ev.n_ev < B.slab_events) B.slab[slab_slot(B, item, ev.n_ev)] = make_uint2(pos_bias + j, s);
             ++ev.n_ev;
         }
         // an anchor candidate's walk: from byte stop_from on, a non-final state of trie depth <= 2 means that
@@ -639,7 +646,7 @@ __device__ __forceinline__ uint32_t walk_fast(const DevAutomaton &A, const Batch
         s = stepped ? w : s + m;
         if (stepped && j >= rep_from && is_final(A, s) && !(B.first_only && ev.n_ev)) {
             ev.n_rec += A.out_count[s];
-            if (ev.n_ev < B.slab_events) B.slab[uint64_t(ev.n_ev) * B.run_stride + item] = make_uint2(pos_bias + j, s);
+            if (ev.n_ev < B.slab_events) B.slab[slab_slot(B, item, ev.n_ev)] = make_uint2(pos_bias + j, s);
             ++ev.n_ev;
         }
         if (EXTRA && stepped && j >= stop_from && (s < A.shallow_hot || (s > trap && s < A.shallow_cold_end))) return s;
@@ -797,7 +804,7 @@ __device__ __forceinline__ void emit_verified(const BatchArgs &B, uint64_t item,
         if (j >= rep_from && j < hi && !(B.first_only && ev.n_ev)) {
             const uint32_t s = v[i].state;
             ev.n_rec += v[i].cnt;
-            if (ev.n_ev < B.slab_events) B.slab[uint64_t(ev.n_ev) * B.run_stride + item] = make_uint2(pos_bias + j, s);
+            if (ev.n_ev < B.slab_events) B.slab[slab_slot(B, item, ev.n_ev)] = make_uint2(pos_bias + j, s);
             ++ev.n_ev;
         }
     }

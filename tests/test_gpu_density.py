@@ -115,3 +115,39 @@ def test_events_of_more_than_255_records(kernel):
         assert np.array_equal(p, pe) and np.array_equal(r, re_), (kernel, find_all, len(r), len(re_))
     assert int(pe[-1]) >= 1 and len(_oracle(ds)[1]) > 150000
     api.ahocorasick_deinit(res)
+
+
+_CFG3 = {}
+
+
+@pytest.mark.parametrize("per_8k", [32, 128, 512])
+@pytest.mark.parametrize("hay_len", [8192, 65536])
+def test_cfg3_dense_candidates_against_the_oracle(per_8k, hay_len):
+    """The 65,536-pattern set (8..64 B, Sigma = 256) over text with 32 / 128 / 512 planted occurrences per 8 KiB -- tens to hundreds
+    of candidate windows per work item of the big-set filter: window lists that grow, k_runs_wave (a wave per item, a lane per
+    window, the occurrences ordered in LDS), k_expand_dense, items that shrink at 512 -- through the filter (kernel 2), the
+    automatic choice, and with the wave kernels switched off (a lane per item); every call record for record against the oracle
+    (the reference orders a position's records longest first: tests/test1.phpt:60-157; ahocorasick.c:214-231 reports in text order)."""
+    base = synth.density_set("cfg3")
+    ds = synth.plant_density(base, per_8k, hay_len)
+    n = min(ds.n_haystacks, (512 << 10) // hay_len)    # 512 KiB of the tile: 64 items of 8 KiB
+    sub = synth.Dataset(ds.name, ds.pat_blob, ds.pat_off, ds.hay_blob[:int(ds.hay_off[n])], ds.hay_off[:n + 1])
+    if "o" not in _CFG3:   # (the CPU trie of 65,536 patterns takes seconds to build: once for the six cells)
+        _CFG3["o"] = Oracle("port")
+        _CFG3["o"].add_patterns((base.pat_blob, base.pat_off))
+    pe, re_ = _CFG3["o"].match_batch(sub.hay_blob, sub.hay_off, True)
+    assert len(re_) >= per_8k * 60
+    for opts in (dict(kernel=2), dict(kernel=3), dict(kernel=2, wave_runs=0)):
+        res = resource_for(sub, **opts)
+        seen = []
+        for _ in range(5):   # (the hand-over learns: list and slab sizes, item size, which kernels are enqueued)
+            p, r = device_match(res, sub)
+            assert np.array_equal(p, pe) and np.array_equal(r, re_), (opts, len(r), len(re_))
+            seen.append((int(res.stat("kernel_used")), int(res.stat("wave_runs_used")), int(res.stat("max_windows"))))
+        if opts.get("kernel") == 2 and opts.get("wave_runs", 1):
+            assert seen[-1][1] == 1, seen   # k_runs_wave took the busy items
+        for find_all in (False,):
+            pe1, re1 = _CFG3["o"].match_batch(sub.hay_blob, sub.hay_off, find_all)
+            p, r = device_match(res, sub, find_all)
+            assert np.array_equal(p, pe1) and np.array_equal(r, re1)
+        api.ahocorasick_deinit(res)
