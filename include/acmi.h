@@ -461,6 +461,18 @@ typedef struct acmi_tables {
     uint32_t chain_bytes, chain_dense, chain_index, chain_rec_off, chain_cnt_off, chain_cnt_n;
     const uint32_t *chain_orig;
     const uint32_t *chain_head;
+    /* the two-byte window table of the whole-item walk (kernel 4 on sets whose shortest pattern is >= 3 B; null: none): win_table
+       = 65,536 16-bit cells indexed by a << 8 | b, then win_list_bytes / 2 words of child lists -- cell 0: no node (a, b) or no
+       child; 0x8000 | c: one child, byte c; 0x4000 | f1 << 7 | f2: two children by 7-bit fingerprints (c ^ c >> 3 ^ c >> 5) & 127;
+       0xC000 | u: three or more, their list {count, bytes ...} at byte 2 u of the list area; 0xFFFF: always "maybe".
+       win_state[a << 8 | b] = the state after "ab" read from the root.  win_hash: the trie nodes of depth 3 by their three bytes,
+       2^win_hash_bits slots of {(key + 1) | bit 7 of the child byte << 31, state | simple << 31 | low 7 bits of the child byte << 24}
+       ("simple": one child, not final, failure link of depth <= 2), slot = key * 0x9E3779B1 >> (32 - bits), linear probing, 0 = empty. */
+    const uint16_t *win_table;
+    const uint32_t *win_state;
+    const uint32_t *win_hash;
+    uint32_t win_hash_bits, win_list_bytes;
+    uint32_t shallow_hot, shallow_cold_end;   /* states of trie depth <= 2 that are not final: ids [0, shallow_hot) and (trap, shallow_cold_end) */
 } acmi_tables;
 int acmi_debug_tables(const acmi_handle *h, acmi_tables *out);
 

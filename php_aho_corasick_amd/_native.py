@@ -54,7 +54,9 @@ class Tables(C.Structure):
                 ("out_off", C.POINTER(C.c_uint32)), ("out_list", C.POINTER(C.c_uint32)), ("anchor_slots", C.c_uint32), ("anchor_dense", C.c_uint32),
                 ("chain_image", C.POINTER(C.c_uint8)), ("chain_bytes", C.c_uint32), ("chain_dense", C.c_uint32), ("chain_index", C.c_uint32),
                 ("chain_rec_off", C.c_uint32), ("chain_cnt_off", C.c_uint32), ("chain_cnt_n", C.c_uint32),
-                ("chain_orig", C.POINTER(C.c_uint32)), ("chain_head", C.POINTER(C.c_uint32))]
+                ("chain_orig", C.POINTER(C.c_uint32)), ("chain_head", C.POINTER(C.c_uint32)),
+                ("win_table", C.POINTER(C.c_uint16)), ("win_state", C.POINTER(C.c_uint32)), ("win_hash", C.POINTER(C.c_uint32)),
+                ("win_hash_bits", C.c_uint32), ("win_list_bytes", C.c_uint32), ("shallow_hot", C.c_uint32), ("shallow_cold_end", C.c_uint32)]
 
 
 Handle = C.c_void_p

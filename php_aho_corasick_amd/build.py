@@ -15,7 +15,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libacmi.so")
-SOURCES = ["automaton.cpp", "engine.cpp", "engine_pipeline.cpp", "engine_choice.cpp", "engine_comm.cpp", "engine_replace.cpp", "k_anchor.hip", "k_anchor_dense.hip", "k_lds.hip", "k_walk.hip", "k_walk_items.hip", "k_walk_items_emit.hip", "k_tiles.hip", "k_chain.hip", "k_drain.hip", "k_pipeline.hip", "k_small.hip", "k_misc.hip"]
+SOURCES = ["automaton.cpp", "engine.cpp", "engine_pipeline.cpp", "engine_choice.cpp", "engine_comm.cpp", "engine_replace.cpp", "k_anchor.hip", "k_anchor_dense.hip", "k_lds.hip", "k_walk.hip", "k_walk_items.hip", "k_walk_items_emit.hip", "k_tiles.hip", "k_win.hip", "k_chain.hip", "k_drain.hip", "k_pipeline.hip", "k_small.hip", "k_misc.hip"]
 HEADERS = ["automaton.hpp", "device_types.hpp", "kernels.hpp", "engine.hpp", "kdev.hpp", "k_anchor_impl.hpp", "k_walk_items_impl.hpp", "scan_asm.inc", os.path.join("..", "..", "include", "acmi.h")]
 
 

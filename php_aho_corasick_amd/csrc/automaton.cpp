@@ -562,6 +562,78 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
     }
 
     lap("outputs, classes, numbering");
+    // ---- the two-byte window table (automaton.hpp win_table) ----------------------------------------------------
+    fa.win_present = false;
+    fa.win_table.clear();
+    fa.win_state.clear();
+    fa.win_hash.clear();
+    fa.win_hash_bits = 0;
+    {
+        uint32_t shortest = 0;
+        for (const PatternMeta &m : patterns_)
+            if (m.accepted && (shortest == 0 || m.length < shortest)) shortest = m.length;
+        if (shortest >= 3 && opt.win_table != 0 && (compact || opt.win_table > 0)) {
+            fa.win_present = true;
+            fa.win_table.assign(65536, uint16_t(0));
+            fa.win_state.assign(65536, newid[0]);
+            // depth 1: the state after "xb" is b's node unless (x, b) is a node itself
+            for (uint32_t i = 1; i < ns && depth[i] == 1; ++i)
+                for (uint32_t a = 0; a < 256; ++a) fa.win_state[a << 8 | byte_b[i]] = newid[i];
+            uint32_t n3 = 0;
+            std::vector<uint8_t> lists;   // the child lists of the nodes with three children or more: {count, bytes ...}, each at an even offset
+            for (uint32_t i = 1; i < ns && depth[i] <= 2; ++i) {
+                if (depth[i] != 2) continue;
+                const uint32_t cell = uint32_t(byte_b[parent_pos[i]]) << 8 | byte_b[i];
+                fa.win_state[cell] = newid[i];
+                const uint32_t k = cfirst[i + 1] - cfirst[i];
+                n3 += k;
+                uint32_t v = 0;
+                if (k == 1) {
+                    v = 0x8000u | byte_b[cfirst[i]];
+                } else if (k == 2) {
+                    v = 0x4000u | win_fp7(byte_b[cfirst[i]]) << 7 | win_fp7(byte_b[cfirst[i] + 1]);
+                } else if (k >= 3) {
+                    // (a list of up to 62 bytes while the 32 KiB behind the cells have room; else "always maybe")
+                    if (k <= 62 && lists.size() + k + 2 <= kWinListBytes && lists.size() / 2 < 0x3FFFu) {
+                        v = 0xC000u | uint32_t(lists.size() / 2);
+                        lists.push_back(uint8_t(k));
+                        for (uint32_t c = cfirst[i]; c < cfirst[i + 1]; ++c) lists.push_back(byte_b[c]);
+                        if (lists.size() & 1u) lists.push_back(0);
+                    } else {
+                        v = 0xFFFFu;
+                    }
+                }
+                fa.win_table[cell] = uint16_t(v);
+            }
+            lists.resize(kWinListBytes, 0);
+            for (size_t i = 0; i < lists.size(); i += 2) fa.win_table.push_back(uint16_t(lists[i] | lists[i + 1] << 8));
+            // the nodes of depth 3 by their three bytes: open addressing, {key + 1, state}, at most half full
+            uint32_t bits = 4;
+            while ((1u << bits) < 2 * n3 + 16) ++bits;
+            fa.win_hash_bits = bits;
+            fa.win_hash.assign(size_t(2) << bits, 0u);
+            const uint32_t mask = (1u << bits) - 1u;
+            for (uint32_t i = 1; i < ns && depth[i] <= 3; ++i) {
+                if (depth[i] != 3) continue;
+                const uint32_t p2 = parent_pos[i], p1 = parent_pos[p2];
+                const uint32_t key = uint32_t(byte_b[p1]) << 16 | uint32_t(byte_b[p2]) << 8 | byte_b[i];
+                uint32_t at = win_hash_slot(key, bits);
+                while (fa.win_hash[2 * at] != 0u) at = (at + 1u) & mask;
+                fa.win_hash[2 * at] = key + 1u;
+                // a node of one child that is not final and whose failure link is of depth <= 2 (nearly every depth-3 node of a
+                // big random set) carries that child's byte: text that does not continue with it is back at depth <= 2 without
+                // a step through the records (bit 31 of the state word; the byte in bits 24..30 and bit 31 of the key word)
+                uint32_t st_word = newid[i];
+                if (cfirst[i + 1] - cfirst[i] == 1 && !final_b[i] && depth[fail_b[i]] <= 2 && newid[i] < (1u << 24)) {
+                    const uint32_t cb = byte_b[cfirst[i]];
+                    st_word |= 0x80000000u | (cb & 0x7Fu) << 24;
+                    fa.win_hash[2 * at] |= (cb >> 7) << 31;
+                }
+                fa.win_hash[2 * at + 1] = st_word;
+            }
+            lap("window table");
+        }
+    }
     // ---- tables ----------------------------------------------------------------------------------
     if (fa.entry_bytes == 2)
         build_tables<uint16_t>(fa, dense, fail_b, newid, cfirst, byte_b);

@@ -51,6 +51,9 @@ struct BuildOptions {
     // chain-compressed image of the WHOLE automaton for LDS (ChainImage): built when it fits this many bytes -- a CU's 160 KiB less
     // the byte classes (512 B) and a little slack; 0 = never
     uint32_t chain_bytes = 160 * 1024 - 512 - 256;
+    // the two-byte window table (FlatAutomaton::win_table): -1 = for compact automata (sets far too big for the LDS) whose shortest
+    // pattern is >= 3 B, 0 = never, 1 = whenever the shortest pattern is >= 3 B
+    int win_table = -1;
 };
 
 // The whole automaton in a form that fits the LDS of one CU where dense rows for every state do not (k_chain.hip k_walk_chain):
@@ -145,6 +148,22 @@ struct FlatAutomaton {
     // dependent steps (kdev.hpp walk_fast).  Both arrays carry 16 bytes of padding.
     uint32_t chain_lo = 0;
     std::vector<uint8_t> chain_byte, chain_run;
+    // The two-byte window table (k_win.hip k_walk_win; sets whose shortest pattern is >= 3 B: no state of trie depth <= 2 is final).
+    // While the state is that shallow it is a function of the last two text bytes alone, and what the walk needs to know is
+    // whether the next byte c leaves depth 2 downward from the node of (a, b): win_table[a << 8 | b], 16 bits, staged into LDS --
+    //   0                          no node (a, b) or no child;
+    //   0x8000 | c0                one child: exact;
+    //   0x4000 | f(c1) << 7 | f(c2)   two children, 7-bit fingerprints f (win_fp7): never a false "no";
+    //   0xC000 | offset            three or more: their bytes as a list {count, bytes ...} at 2-byte unit `offset` of the
+    //                              kWinListBytes behind the 65,536 cells (exact); 0xFFFF: no room for the list, always "maybe".
+    // win_state[a << 8 | b] = the state after the text "ab" read from the root (the node of (a, b); else b's; else the root).
+    // win_hash: the nodes of trie depth 3 by their three bytes, {key + 1, state} in 2^win_hash_bits slots (open addressing from
+    // win_hash_slot, linear probing; 0 = empty): a "maybe" is settled by one probe, not by a walk through records and edges.
+    bool win_present = false;
+    std::vector<uint16_t> win_table;   // 65,536 cells + kWinListBytes / 2 list words
+    std::vector<uint32_t> win_state;
+    std::vector<uint32_t> win_hash;
+    uint32_t win_hash_bits = 0;
     uint32_t class_mode = kClassTable;
     uint32_t swar_shift = 0;     // class = (byte >> shift) & 7 when byte is in the alphabet
     uint32_t swar_other = 0;     // column of every byte outside the alphabet
@@ -255,6 +274,9 @@ inline uint32_t anchor_hash(const uint32_t *words, uint32_t n_words, uint32_t mu
 }
 // dense form: ONE multiply-add on the raw window (v_lshrrev + v_mad_u32_u24 on the device), see anchor_hash
 inline uint32_t anchor_hash_dense(uint32_t w, uint32_t mul) { return anchor_hash(&w, 1, mul); }
+inline uint32_t win_fp7(uint32_t c) { return (c ^ (c >> 3) ^ (c >> 5)) & 127u; }   // (k_win.hip has the same)
+constexpr uint32_t kWinListBytes = 30u * 1024u;   // child lists behind the window table's cells (LDS: 128 KiB + this)
+inline uint32_t win_hash_slot(uint32_t key, uint32_t bits) { return (key * 0x9E3779B1u) >> (32u - bits); }
 inline uint16_t anchor_empty(uint32_t bucket, uint32_t bucket_bits = kAnchorBucketBits) { return uint16_t(((bucket >> (bucket_bits - 1)) & 1u) ^ 1u); }
 
 class Automaton {
@@ -292,6 +314,9 @@ public:
         std::vector<uint32_t>().swap(flat_.cold_edges);
         std::vector<uint8_t>().swap(flat_.chain_byte);
         std::vector<uint8_t>().swap(flat_.chain_run);
+        std::vector<uint16_t>().swap(flat_.win_table);
+        std::vector<uint32_t>().swap(flat_.win_state);
+        std::vector<uint32_t>().swap(flat_.win_hash);
         std::vector<uint32_t>().swap(flat_.anchor_slot_pair);
         std::vector<uint32_t>().swap(flat_.anchor_pairs);
         std::vector<uint32_t>().swap(flat_.out_list);

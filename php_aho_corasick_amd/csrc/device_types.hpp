@@ -38,6 +38,11 @@ struct DevAutomaton {
     const uint16_t *chain_frank; // per index: rank among the final indices (0xFFFF: not final) ...
     const uint2 *chain_fhead;    // ... and the heads by rank (what k_chain_emit stages into LDS)
     uint32_t chain_finals;
+    // the two-byte window table (automaton.hpp win_table; k_win.hip): null when the set has none
+    const uint16_t *win_table;   // 65,536 cells + the child lists, staged into LDS
+    const uint32_t *win_state;   // 65,536 states
+    const uint2 *win_hash;       // depth-3 nodes by their three bytes: {key + 1, state}, 2^win_hash_bits slots
+    uint32_t win_hash_bits;
     const uint8_t *pad16;        // 16 readable bytes: where unconditional loads of lanes with nothing to load go
     uint32_t shallow_hot, shallow_cold_end;  // non-final states of trie depth <= 2: [0,shallow_hot), (trap,shallow_cold_end)
     uint32_t early_stop;         // 1: walks of anchor candidates stop on them (run_epilogue)
@@ -146,6 +151,9 @@ struct ReplaceArgs {
     const uint64_t *out_off;     // per haystack (k_replace_emit)
     uint8_t *out_blob;
 };
+
+// k_win.hip: bytes of child lists behind the window table's 65,536 cells (automaton.hpp kWinListBytes: engine.cpp checks they agree)
+constexpr uint32_t kWinListBytesDev = 30u * 1024u;
 
 // multi-GPU exchange (engine.cpp acmi_comm_*): at most kMaxRanks ranks
 constexpr uint32_t kMaxRanks = 64;

@@ -313,6 +313,15 @@ int ensure_device(acmi_handle *h) {
         HIPCHK(h, h->d_cold_edges.ensure(std::max<size_t>(8, fa.cold_edges.size() * 4)));
         if (!fa.cold_edges.empty())
             HIPCHK(h, copy_h2d(h->d_cold_edges.p, fa.cold_edges.data(), fa.cold_edges.size() * 4));
+        static_assert(kWinListBytes == kWinListBytesDev, "the window table's list area");
+        if (fa.win_present) {
+            HIPCHK(h, h->d_win_table.ensure(fa.win_table.size() * 2));
+            HIPCHK(h, copy_h2d(h->d_win_table.p, fa.win_table.data(), fa.win_table.size() * 2));
+            HIPCHK(h, h->d_win_state.ensure(fa.win_state.size() * 4));
+            HIPCHK(h, copy_h2d(h->d_win_state.p, fa.win_state.data(), fa.win_state.size() * 4));
+            HIPCHK(h, h->d_win_hash.ensure(fa.win_hash.size() * 4));
+            HIPCHK(h, copy_h2d(h->d_win_hash.p, fa.win_hash.data(), fa.win_hash.size() * 4));
+        }
         if (!fa.chain_byte.empty()) {
             HIPCHK(h, h->d_chain_byte.ensure(fa.chain_byte.size()));
             HIPCHK(h, copy_h2d(h->d_chain_byte.p, fa.chain_byte.data(), fa.chain_byte.size()));
@@ -402,6 +411,10 @@ int ensure_device(acmi_handle *h) {
     A.chain_lo = fa.chain_lo;
     A.chain_byte = fa.chain_byte.empty() ? nullptr : h->d_chain_byte.as<uint8_t>();
     A.chain_run = fa.chain_byte.empty() ? nullptr : h->d_chain_run.as<uint8_t>();
+    A.win_table = fa.win_present ? h->d_win_table.as<uint16_t>() : nullptr;
+    A.win_state = fa.win_present ? h->d_win_state.as<uint32_t>() : nullptr;
+    A.win_hash = fa.win_present ? h->d_win_hash.as<uint2>() : nullptr;
+    A.win_hash_bits = fa.win_hash_bits;
     A.chain_img = fa.chain.present() ? h->d_chain_img.as<uint8_t>() : nullptr;
     A.chain_img_bytes = uint32_t(fa.chain.image.size());
     A.chain_dense = fa.chain.n_dense;
@@ -522,7 +535,7 @@ int acmi_destroy(acmi_handle *h) {
         if (h->dev_touched) {  // also after a failed upload: release whatever was created
             (void)hipSetDevice(h->dev_id);
             if (h->stream) (void)hipStreamSynchronize(h->stream);
-            for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_out_off, &h->d_out_list, &h->d_out_head, &h->d_cold_rec, &h->d_cold_edges, &h->d_chain_byte, &h->d_chain_run, &h->d_chain_img, &h->d_chain_head, &h->d_chain_orig, &h->d_chain_frank, &h->d_chain_fhead, &h->d_slot_pair, &h->d_pairs, &h->d_pat_bytes, &h->d_dense_img, &h->d_merge_counts, &h->d_merge_sync, &h->d_rep_off, &h->d_rep_bytes, &h->d_plan, &h->d_plan_out, &h->d_tail_out, &h->d_rep_sync, &h->d_nom_count, &h->d_out_len, &h->d_rep_out_off, &h->d_rep_out, &h->d_blob,
+            for (DevBuf *b : {&h->d_table, &h->d_lds, &h->d_class, &h->d_own, &h->d_dict, &h->d_cnt, &h->d_plen, &h->d_anchor, &h->d_bitmap, &h->d_out_off, &h->d_out_list, &h->d_out_head, &h->d_cold_rec, &h->d_cold_edges, &h->d_chain_byte, &h->d_chain_run, &h->d_win_table, &h->d_win_state, &h->d_win_hash, &h->d_chain_img, &h->d_chain_head, &h->d_chain_orig, &h->d_chain_frank, &h->d_chain_fhead, &h->d_slot_pair, &h->d_pairs, &h->d_pat_bytes, &h->d_dense_img, &h->d_merge_counts, &h->d_merge_sync, &h->d_rep_off, &h->d_rep_bytes, &h->d_plan, &h->d_plan_out, &h->d_tail_out, &h->d_rep_sync, &h->d_nom_count, &h->d_out_len, &h->d_rep_out_off, &h->d_rep_out, &h->d_blob,
                               &h->d_off, &h->d_sync[0], &h->d_sync[1], &h->d_item_base[0], &h->d_item_hay[0], &h->d_item_rec[0], &h->d_zero[0], &h->d_isync[0],
                               &h->d_item_base[1], &h->d_item_hay[1], &h->d_item_rec[1], &h->d_zero[1], &h->d_isync[1],
                               &h->d_rec_base, &h->d_slab, &h->d_ovf, &h->d_counters, &h->d_first, &h->d_tile_queue, &h->d_tile_sync, &h->d_chain_log, &h->d_chain_tiles, &h->d_uni_off[0], &h->d_uni_off[1], &h->fly[0].d_prefix, &h->fly[0].d_out, &h->fly[1].d_prefix, &h->fly[1].d_out, &h->d_runs, &h->d_run_count, &h->d_busy, &h->d_dense})
@@ -655,6 +668,11 @@ static int apply_option(acmi_handle *h, const std::string &k, int64_t value) {
             if (h->aut.finalized()) return ACMI_E_FINALIZED;
             if (value < 0 || value > 160 * 1024 - 512 - 256) return ACMI_E_ARG;
             h->bopt.chain_bytes = uint32_t(value);
+        } else if (k == "win_table") {   // the two-byte window table of the whole-item walk (kernel 4): -1 compact automata, 0 never, 1 whenever the shortest pattern is >= 3 B
+            if (h->aut.finalized()) return ACMI_E_FINALIZED;
+            h->bopt.win_table = value < 0 ? -1 : (value ? 1 : 0);
+        } else if (k == "win_walk") {    // 0: kernel 4 walks the tables (k_walk_items) although the set has the window table
+            h->win_walk = value ? 1 : 0;
         } else if (k == "dense_bytes") {
             if (h->aut.finalized()) return ACMI_E_FINALIZED;
             if (value < 0) return ACMI_E_ARG;
@@ -749,6 +767,7 @@ int acmi_get_stat(const acmi_handle *h, const char *key, double *value) {
         else if (k == "walked_bytes") *value = double(h->walked_bytes);
         else if (k == "fallback_bytes") *value = double(h->fallback_bytes);
         else if (k == "anchor_chunk_shift") *value = h->anchor_chunk_shift;
+        else if (k == "win_table") *value = fa.win_present ? 1 : 0;
         else if (k == "busy_items") *value = h->busy_items;
         else if (k == "max_windows") *value = h->max_windows;
         else if (k == "serial_items") *value = h->serial_items;
@@ -859,6 +878,13 @@ int acmi_debug_tables(const acmi_handle *h, acmi_tables *out) {
         out->chain_cnt_n = ci.cnt_n;
         out->chain_orig = ci.present() ? ci.orig.data() : nullptr;
         out->chain_head = ci.present() ? ci.head.data() : nullptr;
+        out->win_table = fa.win_present && !fa.win_table.empty() ? fa.win_table.data() : nullptr;
+        out->win_state = fa.win_present && !fa.win_state.empty() ? fa.win_state.data() : nullptr;
+        out->win_hash = fa.win_present && !fa.win_hash.empty() ? fa.win_hash.data() : nullptr;
+        out->win_hash_bits = fa.win_hash_bits;
+        out->win_list_bytes = kWinListBytes;
+        out->shallow_hot = fa.shallow_hot;
+        out->shallow_cold_end = fa.shallow_cold_end;
         return ACMI_OK;
     });
 }

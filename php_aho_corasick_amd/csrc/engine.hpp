@@ -108,6 +108,7 @@ struct acmi_handle {
     bool expand_armed = false;   // the last batch averaged four records a work item or more: k_expand_dense is enqueued with the next
     uint32_t anchor_chunk_shift = 0;   // the anchor filter's work items are 8 KiB >> this (learned from the windows per item; "anchor_chunk_shift")
     bool wave_armed = false;     // the last filter batch had items with more than a few candidate windows: k_runs_wave is enqueued with the next
+    int win_walk = 1;            // "win_walk": kernel 4 over the two-byte window table where the set has one (k_walk_win), 0 = k_walk_items
     int wave_runs_opt = 1;       // "wave_runs": 0 never launches k_runs_wave (every item is k_walk_runs')
     uint32_t busy_items = 0, max_windows = 0, serial_items = 0;   // of the last filter batch ("busy_items", "max_windows", "serial_items")
     bool wave_used = false;      // ... which ran k_runs_wave ("wave_runs_used")
@@ -181,7 +182,7 @@ struct acmi_handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     DevAutomaton dA{};
-    DevBuf d_table, d_lds, d_class, d_own, d_dict, d_cnt, d_plen, d_anchor, d_bitmap, d_out_off, d_out_list, d_out_head, d_cold_rec, d_cold_edges, d_chain_byte, d_chain_run, d_chain_img, d_chain_head, d_chain_orig, d_chain_frank, d_chain_fhead, d_slot_pair, d_pairs, d_pat_bytes, d_dense_img;
+    DevBuf d_table, d_lds, d_class, d_own, d_dict, d_cnt, d_plen, d_anchor, d_bitmap, d_out_off, d_out_list, d_out_head, d_cold_rec, d_cold_edges, d_chain_byte, d_chain_run, d_win_table, d_win_state, d_win_hash, d_chain_img, d_chain_head, d_chain_orig, d_chain_frank, d_chain_fhead, d_slot_pair, d_pairs, d_pat_bytes, d_dense_img;
 
     // workspace (grow-only)
     DevBuf d_blob, d_off, d_rec_base, d_slab, d_ovf, d_counters, d_runs, d_run_count, d_first, d_busy, d_dense;

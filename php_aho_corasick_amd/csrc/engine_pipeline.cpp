@@ -435,7 +435,8 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     } else if (kernel == 4) {
         // exact walk only (k_walk_items): for text on which k_scan_lds' optimistic
         // pass flags everything anyway (events in every wave-quad)
-        HIPCHK(h, launch_walk_items(h->dA, B, max_items, int(fa.entry_bytes), int(fa.class_mode), h->walk_group, st));
+        if (h->dA.win_table != nullptr && h->win_walk) HIPCHK(h, launch_walk_win(h->dA, B, max_items, int(fa.entry_bytes), st));
+        else HIPCHK(h, launch_walk_items(h->dA, B, max_items, int(fa.entry_bytes), int(fa.class_mode), h->walk_group, st));
     } else {
         HIPCHK(h, launch_scan(h->dA, B, max_items, int(fa.entry_bytes), kernel, int(fa.class_mode), h->ilp, h->group_quads, st, &F.anchor_variant));
     }

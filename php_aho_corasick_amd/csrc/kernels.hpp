@@ -31,6 +31,8 @@ hipError_t launch_walk_runs(const DevAutomaton &A, const BatchArgs &B, uint64_t 
 hipError_t launch_runs_wave(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode, hipStream_t st);
 hipError_t launch_walk_items(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, int class_mode,
                              int ilp, hipStream_t st);
+// kernel 4 over the two-byte window table (k_win.hip): trie depth <= 2 decided in LDS from the text alone
+hipError_t launch_walk_win(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int entry_bytes, hipStream_t st);
 // k_walk_tiles (k_tiles.hip, kernel 6): the exact walk with exact-sized ordered output in one pass.  Geometry: W bytes per lane,
 // P lanes per work item (chunk_bytes = P x W, items from k_items with align_warm = 0); false: not for this automaton.
 bool tiles_geometry(uint32_t max_pattern_length, uint32_t n_states, uint64_t blob_bytes, uint64_t n_haystacks, uint32_t *W, uint32_t *P);

@@ -6,7 +6,7 @@ import numpy as np
 from php_aho_corasick_amd import api
 
 
-BUILD_OPTIONS = ("lds_bytes", "max_table_bytes", "max_flat_outputs", "compact", "dense_bytes", "keep_host_tables", "verify", "anchor_choice", "device_build", "anchor_dense", "dense_hot", "split", "anchor_slots2", "chain_bytes")
+BUILD_OPTIONS = ("lds_bytes", "max_table_bytes", "max_flat_outputs", "compact", "dense_bytes", "keep_host_tables", "verify", "anchor_choice", "device_build", "anchor_dense", "dense_hot", "split", "anchor_slots2", "chain_bytes", "win_table")
 
 
 def resource_for(ds, calls: int = 1, **options):

@@ -88,6 +88,12 @@ class FlatTables:
                               cnt=img[t.chain_cnt_off:t.chain_cnt_off + t.chain_cnt_n].astype(np.int64),
                               orig=np.ctypeslib.as_array(t.chain_orig, shape=(t.chain_index,)).astype(np.int64),
                               head=np.ctypeslib.as_array(t.chain_head, shape=(t.chain_index, 2)).astype(np.int64))
+        self.win = None
+        if t.win_table:
+            self.win = dict(cells=np.ctypeslib.as_array(t.win_table, shape=(65536 + t.win_list_bytes // 2,)).astype(np.int64),
+                            state=np.ctypeslib.as_array(t.win_state, shape=(65536,)).astype(np.int64),
+                            hash=np.ctypeslib.as_array(t.win_hash, shape=(1 << t.win_hash_bits, 2)).astype(np.int64), bits=t.win_hash_bits,
+                            shallow_hot=t.shallow_hot, shallow_cold_end=t.shallow_cold_end)
         self.anchor_q, self.anchor_mul, self.min_pattern_length = t.anchor_q, t.anchor_mul, t.min_pattern_length
         self.anchor_keys = t.anchor_keys
         self.anchor_mode, self.anchor_bucket_bits = t.anchor_mode, t.anchor_bucket_bits
@@ -151,6 +157,82 @@ class FlatTables:
                     return int(hit[0]) >> 8
             assert (y & 0xFFFFFF) != s
             s = y & 0xFFFFFF
+
+    def walk_win(self, text: bytes, pat_len, hay: int = 0, find_all: bool = True):
+        """Scan one haystack as k_walk_win does (csrc/k_win.hip): while the state is of trie depth <= 2 only the last two bytes and the
+        window table decide whether the next byte leaves depth 2 downward; a "maybe" is settled by the depth-3 hash; deeper states
+        step through dense rows / compact records, and a failure link that leads back to depth <= 2 hands the byte to the table."""
+        w = self.win
+        cells, lists = w["cells"][:65536], w["cells"][65536:]
+        mask = (1 << w["bits"]) - 1
+
+        def shallow(s):
+            return s < w["shallow_hot"] or (self.trap < s < w["shallow_cold_end"])
+
+        def maybe(cell, c):
+            kind = cell >> 14
+            if kind == 2:
+                return (cell & 0xFF) == c
+            f = (c ^ (c >> 3) ^ (c >> 5)) & 127
+            if kind == 1:
+                return f == (cell & 127) or f == ((cell >> 7) & 127)
+            if kind == 3:
+                if cell == 0xFFFF:
+                    return True
+                u = cell & 0x3FFF
+                lb = [(int(lists[(2 * u + i) // 2]) >> (8 * ((2 * u + i) & 1))) & 0xFF for i in range(64)]
+                return c in lb[1:1 + lb[0]]
+            return False
+
+        out, deep, st, idx = [], False, 0, 0
+        for j, c in enumerate(text):
+            stepped = False
+            if deep:
+                # one transition, goto edges and failure links of the records; back at depth <= 2 through a failure link: the table's byte
+                s = st
+                while True:
+                    if not self.compact or s < self.dense_nf_end or self.f2 <= s < self.dense_f_end:
+                        st = self.cold_step(s, c)
+                        stepped = True
+                        break
+                    x, y = int(self.cold_rec[s, 0]), int(self.cold_rec[s, 1])
+                    code, nxt = y >> 24, None
+                    if code == 1 and (x & 0xFF) == c:
+                        nxt = x >> 8
+                    elif code >= 2:
+                        n, at = (code, x) if code != 255 else (int(self.cold_edges[x]), x + 1)
+                        hit = [int(e) >> 8 for e in self.cold_edges[at:at + n] if (int(e) & 0xFF) == c]
+                        nxt = hit[0] if hit else None
+                    if nxt is not None:
+                        st, stepped = nxt, True
+                        break
+                    s = y & 0xFFFFFF
+                    if shallow(s):
+                        deep = False
+                        break
+                if stepped:
+                    deep = not shallow(st)
+            if not stepped and j >= 2 and maybe(int(cells[idx]), c):
+                key = (idx << 8 | c) + 1
+                at = ((key - 1) * 0x9E3779B1 & 0xFFFFFFFF) >> (32 - w["bits"])
+                while int(w["hash"][at, 0]) != 0 and (int(w["hash"][at, 0]) & 0x7FFFFFFF) != key:
+                    at = (at + 1) & mask
+                if int(w["hash"][at, 0]) != 0:
+                    word = int(w["hash"][at, 1])
+                    st, deep = (word & 0xFFFFFF if word >> 31 else word), True
+                    if word >> 31:   # the entry's child byte restates the node's record
+                        cb = ((word >> 24) & 0x7F) | (int(w["hash"][at, 0]) >> 31) << 7
+                        assert not self.is_final(st)
+                        if self.compact and not (st < self.dense_nf_end):
+                            assert int(self.cold_rec[st, 1]) >> 24 == 1 and (int(self.cold_rec[st, 0]) & 0xFF) == cb and shallow(int(self.cold_rec[st, 1]) & 0xFFFFFF)
+            idx = ((idx << 8) | c) & 0xFFFF
+            if deep and self.is_final(st):
+                pos = j + 1
+                o, n = int(self.out_off[st]), int(self.cnt[st])
+                out += [(hay, pos, pos - int(l), int(p)) for p, l in self.out_list[o:o + n]]
+                if not find_all:
+                    break
+        return out
 
     def walk_chain(self, text: bytes, pat_len, hay: int = 0, find_all: bool = True):
         """Scan one haystack over the chain-compressed image exactly as k_walk_chain steps through it (automaton.hpp ChainImage): a

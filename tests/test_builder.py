@@ -267,3 +267,48 @@ def test_window_hash_places_families_that_share_three_bytes():
             for o in ((0,) if dense else range(4)):
                 assert ft.anchor_probe(p[o:o + 4]), (p, o)
         api.ahocorasick_deinit(res)
+
+
+@pytest.mark.parametrize("name", ["G2", "R3", "R7", "W1"])
+@pytest.mark.parametrize("compact", [0, 1])
+def test_window_table_walks_like_the_oracle(name, compact):
+    """The two-byte window table (automaton.hpp win_table; k_win.hip k_walk_win) walked in numpy as the kernel walks it, against the
+    oracle: every cell form, the depth-3 hash, the hand-overs between the table and the records (helpers.FlatTables.walk_win)."""
+    if name == "W1":   # families of 1 / 2 / 3 / 9 / 70 third bytes behind one digram, nested patterns
+        r = np.random.default_rng(5)
+        pats = []
+        for a, b, kids in ((1, 2, 1), (3, 4, 2), (5, 6, 3), (7, 8, 9), (9, 10, 70)):
+            for c in r.choice(256, size=kids, replace=False):
+                pats.append(bytes([a, b, int(c)]) + bytes(r.integers(0, 256, size=int(r.integers(0, 9))).tolist()))
+        pats += [bytes([7, 8, 1, 2, 5, 6, 9]), bytes([1, 2, 5, 6]), bytes([2, 5, 6]), bytes([5, 6, 7, 8]), bytes([1, 2, 5])]
+        pats = list(dict.fromkeys(pats))
+        hays = []
+        for _ in range(6):
+            t = r.integers(0, 12, size=600).astype(np.uint8)
+            for _k in range(40):
+                p = pats[int(r.integers(len(pats)))]
+                at = int(r.integers(0, 600 - len(p)))
+                t[at:at + len(p)] = np.frombuffer(p, dtype=np.uint8)
+            hays.append(t.tobytes())
+        pb, po = synth.pack(pats)
+        hb, ho = synth.pack(hays)
+        ds = synth.Dataset("W1", pb, po, hb, ho)
+    else:
+        ds = synth.NAMED[name]()
+    opts = dict(dense_bytes=0, lds_bytes=4096) if compact else {}
+    res = resource_for(ds, win_table=1, compact=compact, **opts)
+    api.ahocorasick_finalize(res)
+    ft = FlatTables(res)
+    assert ft.win is not None and res.stat("win_table") == 1
+    o = Oracle("port")
+    o.add_patterns(ds.patterns())
+    o.finalize()
+    n_rec = 0
+    for h in range(min(ds.n_haystacks, 3 if name in ("G1", "G2", "R3") else 6)):
+        for find_all in (True, False):
+            exp = [tuple(int(x) for x in r) for r in o.match(ds.haystack(h), find_all, h)]
+            assert ft.walk_win(ds.haystack(h), None, h, find_all) == exp, (ds.name, h, find_all)
+            n_rec += len(exp)
+    assert n_rec > 0
+    o.close()
+    api.ahocorasick_deinit(res)
