@@ -40,7 +40,7 @@ __device__ __forceinline__ bool win_maybe(uint32_t cell, uint32_t c) {
 }
 
 template <typename E>
-__global__ __launch_bounds__(kWalkThreads) void k_walk_win(DevAutomaton A, BatchArgs B) {
+__global__ __launch_bounds__(kWalkThreads) void k_walk_win(DevAutomaton A, BatchArgs B, uint32_t dbg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint64_t total_items = B.item_base[B.n_haystacks];
     if (uint64_t(blockIdx.x) * kWalkThreads >= total_items) return;
@@ -79,15 +79,21 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_win(DevAutomaton A, Batch
     // One round: `nb` bytes (<= 16, the low bytes of blk) from item index jj on
     auto step_block = [&](const uint4 &blk, uint32_t jj, uint32_t nb) __attribute__((always_inline)) {
         const uint32_t wd[4] = {blk.x, blk.y, blk.z, blk.w};
-        uint32_t mask = 0, ix = idx;
+        uint32_t mask = 0, listed = 0, ix = idx;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const uint32_t c = (wd[k >> 2] >> (8 * (k & 3))) & 0xffu;
-            mask |= win_maybe(L[ix], c) ? (1u << k) : 0u;
+            const uint32_t cell = L[ix];
+            mask |= win_maybe(cell, c) ? (1u << k) : 0u;
+            listed |= ((cell >> 14) == 3u && cell != 0xFFFFu) ? (1u << k) : 0u;
             ix = ((ix << 8) | c) & 0xFFFFu;
         }
         if (nb < 16u) mask &= (1u << nb) - 1u;
         if (seen < 2u) { mask &= ~((1u << (2u - seen)) - 1u); seen = (seen + nb) < 2u ? seen + nb : 2u; }
+        listed &= mask;
+        if (dbg & 2u) listed = 0u;
+        if (dbg & 1u) mask = 0u;
+        if (dbg & 4u) { idx = ix; return; }
         // (a 64-bit shift of the block's half: as a select of the four words by a lane-variable index hipcc keeps the block in
         // scratch memory and indexes it there)
         const uint64_t half_lo = uint64_t(blk.y) << 32 | blk.x, half_hi = uint64_t(blk.w) << 32 | blk.z;
@@ -100,6 +106,22 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_win(DevAutomaton A, Batch
             if (k >= 2u) return byte_at(k - 2u) << 8 | byte_at(k - 1u);
             return k == 1u ? ((idx << 8) | byte_at(0u)) & 0xFFFFu : idx;
         };
+        // nodes of three children or more (one position in twelve on config 3's set): their lists, exactly -- LDS only, every lane at
+        // its own next such position, BEFORE the loop that goes to global memory (in one loop with it nearly every turn had some lane
+        // waiting for a probe: six round trips per block instead of one or two)
+#pragma unroll 1
+        while (__any(listed != 0u)) {
+            if (listed != 0u) {
+                const uint32_t k = uint32_t(__builtin_ctz(listed));
+                listed &= listed - 1u;
+                const uint32_t cell = L[digram_before(k)], c = byte_at(k);
+                const uint8_t *lp = lists + ((cell & 0x3FFFu) << 1);
+                const uint32_t cnt = lp[0];
+                bool real = false;
+                for (uint32_t i = 1; i <= cnt; ++i) real = real || lp[i] == c;
+                if (!real) mask &= ~(1u << k);
+            }
+        }
         // the rare steps, every lane at its own next position
         uint32_t pos = 0;
         bool active = mask != 0u || deep;
@@ -112,15 +134,8 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_win(DevAutomaton A, Batch
                         active = false;
                     } else {
                         const uint32_t k = uint32_t(__builtin_ctz(rem));
-                        const uint32_t dg = digram_before(k), c = byte_at(k), cell = L[dg];
-                        bool real = true;
-                        if ((cell >> 14) == 3u && cell != 0xFFFFu) {   // three children or more: their list, exactly
-                            const uint8_t *lp = lists + ((cell & 0x3FFFu) << 1);
-                            const uint32_t cnt = lp[0];
-                            real = false;
-                            for (uint32_t i = 1; i <= cnt; ++i) real = real || lp[i] == c;
-                        }
-                        if (real) {
+                        const uint32_t dg = digram_before(k), c = byte_at(k);
+                        {
                             const uint32_t key = (dg << 8 | c) + 1u;
                             uint32_t at = ((key - 1u) * 0x9E3779B1u) >> (32u - hbits);
                             uint2 e = A.win_hash[at];
@@ -246,7 +261,8 @@ hipError_t launch_walk_win(const DevAutomaton &A, const BatchArgs &B, uint64_t m
         hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), kWinLdsBytes);
         if (e != hipSuccess) return e;
         const uint32_t blocks = uint32_t((max_items + kWalkThreads - 1) / kWalkThreads);
-        hipLaunchKernelGGL(fn, dim3(blocks), dim3(kWalkThreads), kWinLdsBytes, st, A, B);
+        static const uint32_t dbg = [] { const char *e = std::getenv("ACMI_WIN_DEBUG"); return e ? uint32_t(std::atoi(e)) : 0u; }();
+        hipLaunchKernelGGL(fn, dim3(blocks), dim3(kWalkThreads), kWinLdsBytes, st, A, B, dbg);
         return hipGetLastError();
     };
     return entry_bytes == 2 ? go(k_walk_win<uint16_t>) : go(k_walk_win<uint32_t>);
