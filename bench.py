@@ -1035,6 +1035,7 @@ def main():
     ap.add_argument("--items-ahead", action="store_true", help="analysis: every batch's item table on the handle's side stream (acmi.h \"items_ahead\" 1; measured: no gain)")
     ap.add_argument("--offsets-entry", action="store_true", help="time acmi_match_batch_device_begin (explicit offsets array) instead of _begin_uniform")
     ap.add_argument("--reserve-cus", type=int, default=0, help="analysis: acmi.h \"reserve_cus\" -- the scan leaves N compute units to a collective in flight")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE", help="analysis: acmi_set_option on the headline handle (repeatable), e.g. --option scan_verify=0")
     ap.add_argument("--no-c-abi-gather", action="store_true", help="N > 1: skip the untimed exchange through acmi_comm_* after the timed steps")
     args = ap.parse_args()
 
@@ -1102,6 +1103,9 @@ def main():
         res.set_option("reserve_cus", args.reserve_cus)
     if args.items_ahead:   # analysis: every batch's work-item table built on the handle's side stream (acmi.h "items_ahead")
         res.set_option("items_ahead", 1)
+    for kv in args.option:
+        k_, v_ = kv.split("=")
+        res.set_option(k_, int(v_))
 
     # ---- batch resident in HBM: the tile replicated to the requested size ----
     want = args.haystacks or wl.default_nh

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     sc = ld;
     // per wave, behind the table: 2 KiB of run staging -- BIG: [1 KiB probe queue | 256 B hit masks | 768 B run staging]
     uint8_t *wave_lds = smem + kAnchorLdsBytes + (threadIdx.x >> 6) * 2048u;
-    RunStage stage{reinterpret_cast<uint4 *>(wave_lds + (BIG ? 1280u : 0u)), 0u, BIG ? kDenseStageBig : kDenseStage};   // (8-byte entries: kdev.hpp, window lists)
+    RunStage stage{reinterpret_cast<uint4 *>(wave_lds + (BIG ? 1280u : 0u)), 0u, BIG ? kDenseStageBig : kDenseStage, false};   // (8-byte entries: kdev.hpp, window lists)
     uint2 *const queue = reinterpret_cast<uint2 *>(wave_lds);           // BIG only
     uint32_t *const hitmask = reinterpret_cast<uint32_t *>(wave_lds + 1024u);
     if (BIG) hitmask[lane] = 0u;
@@ -746,6 +746,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
             // few: through the stage, like the single hits; many (more than the stage has room for): straight into the item's list --
             // consecutive entries, and item-major lists (long lists are) make the lanes' stores contiguous
             const bool direct = T > stage.cap;
+            stage.flushed = stage.flushed || direct;
             if (!direct && stage.count + T > stage.cap) dense_flush(B, wave_first, stage, lane);
             uint2 *slots2 = reinterpret_cast<uint2 *>(stage.slots);
             uint32_t *runs32 = reinterpret_cast<uint32_t *>(B.runs);
@@ -866,6 +867,11 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
     }
     }
 
+    // (Round 6 tried deciding the items that have ONE candidate window here, a lane each behind every wave batch -- the entries are
+    // still in the stage, the streaming loop's registers free -- so that k_walk_runs would find nothing to do on a sparse batch:
+    // A/B in one run, profiles/r06/ab_scan_verify.txt: k_walk_runs 50.7 -> 32.8 us, this kernel 719 -> 750 us, the step 0.805 ->
+    // 0.816 ms.  A wave that waits for its candidates' five round trips does not stream, and its SIMD's other three waves do not
+    // make up for it.  Taken out.)
     // hand the window lists over to the kernels behind (lane k: item wave_first + k)
     dense_flush(B, wave_first, stage, lane);
     if (rec.z != 0) B.run_count[wave_first + lane] = nrun_vec;

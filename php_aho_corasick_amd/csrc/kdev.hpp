@@ -360,7 +360,8 @@ __device__ __forceinline__ void append_run(const BatchArgs &B, uint64_t item, ui
 struct RunStage {
     uint4 *slots;        // this wave's staging slots (LDS)
     uint32_t count;      // staged entries (wave-uniform)
-    uint32_t cap;        // slots: 128 (2 KiB per wave), or 48 in the big-set kernel, whose probe queue shares the 2 KiB
+    uint32_t cap;        // 8-byte entries the stage holds: 256 (2 KiB per wave), or 96 in the big-set kernel, whose probe queue shares the 2 KiB
+    bool flushed;        // entries of this wave batch have left for the lists already (the stage does not hold all of them)
 };
 constexpr uint32_t kStageSlots = 128;
 constexpr uint32_t kStageSlotsBig = 48;   // 768 B behind 1 KiB of probe queue and 256 B of hit masks
@@ -402,6 +403,7 @@ __device__ __forceinline__ void dense_flush(const BatchArgs &B, uint64_t wave_fi
         const uint2 e = slots2[i];
         runs32[win_slot(B, wave_first + (e.x & 0xffu), e.x >> 8)] = e.y;
     }
+    st.flushed = st.flushed || st.count != 0u;
     st.count = 0;
 }
 
