@@ -714,12 +714,17 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
         // prefix sums (the lanes' counts of the task, the per-row counts packed four to a word) give each its index in the item's
         // list, and the lanes write their own entries into the stage.  One hit at a time through the scalar unit -- the path below,
         // right for the usual task with one hit -- cost ~ 100 ns a hit: 0.1 ms of a 64 MiB batch with 128 occurrences per 8 KiB.
-        // (the big-set kernel only: in the small-set kernel's 128 registers the path spilled sixteen of them into the streaming loop)
+        // (the big-set kernel only.  In the small-set kernel's 128 registers the path spills: as a variant of that kernel for batches
+        // known to be dense in hits it was measured on the headline set, round 6 -- 63 registers spilled, 114 scratch operations per
+        // trip of the streaming loop, the scan 0.67-0.69 ms per GiB whatever the hits: better than the scalar path's 0.87 at 64
+        // occurrences per 8 KiB, worse than its 0.37 at 16, and the whole-automaton walk takes such text at 0.97 ms all in.  Not kept.)
         auto flag_vector = [&]() -> bool {
             if constexpr (!BIG) return false;
-            static_assert(!BIG || G == 4, "two row counts to a word");
+            constexpr int NP = G / 2;   // two row counts to a word, sixteen bits each (a row of 64 quads has 256 windows)
             const uint32_t qi0 = sc.c * TQ + lane;
-            uint32_t pk_lo = 0, pk_hi = 0;   // the lane's hit counts of rows 0, 1 / 2, 3, sixteen bits each (a row of 64 quads has 256 windows)
+            uint32_t pk[NP];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) pk[i] = 0;
 #pragma unroll
             for (int r = 0; r < G; ++r) {
                 const uint32_t qi = qi0 + 64u * uint32_t(r);
@@ -735,12 +740,15 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                     zr = keep;
                 }
                 z[r] = zr;
-                const uint32_t c = uint32_t(__builtin_popcount(zr));
-                if (r < 2) pk_lo |= c << (16 * r); else pk_hi |= c << (16 * (r - 2));
+                pk[r >> 1] |= uint32_t(__builtin_popcount(zr)) << (16 * (r & 1));
             }
-            const uint32_t in_lo = wave_inclusive_sum(pk_lo), in_hi = wave_inclusive_sum(pk_hi);
-            const uint32_t tot_lo = __builtin_amdgcn_readlane(in_lo, 63), tot_hi = __builtin_amdgcn_readlane(in_hi, 63);
-            const uint32_t T = (tot_lo & 0xffffu) + (tot_lo >> 16) + (tot_hi & 0xffffu) + (tot_hi >> 16);
+            uint32_t in[NP], tot[NP], T = 0;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                in[i] = wave_inclusive_sum(pk[i]);
+                tot[i] = __builtin_amdgcn_readlane(in[i], 63);
+                T += (tot[i] & 0xffffu) + (tot[i] >> 16);
+            }
             if (T == 0u) return true;
             if (nrun + T > B.run_cap) { nrun += T; return true; }   // more windows than the list holds: counted, the item is walked whole
             // few: through the stage, like the single hits; many (more than the stage has room for): straight into the item's list --
@@ -754,7 +762,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
 #pragma unroll
             for (int r = 0; r < G; ++r) {
                 const uint32_t sh = 16u * uint32_t(r & 1);
-                const uint32_t cnt = ((r < 2 ? pk_lo : pk_hi) >> sh) & 0xffffu, incl = ((r < 2 ? in_lo : in_hi) >> sh) & 0xffffu;
+                const uint32_t cnt = (pk[r >> 1] >> sh) & 0xffffu, incl = (in[r >> 1] >> sh) & 0xffffu;
                 uint32_t at = stage.count + rowbase + incl - cnt, idx = nrun + rowbase + incl - cnt;
                 const uint32_t s0 = sc.head + ((qi0 + 64u * uint32_t(r)) << 4) - (q - 4u);
                 for (uint32_t m = z[r]; m != 0; m &= m - 1, ++at, ++idx) {
@@ -762,7 +770,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                     if (direct) runs32[win_slot(B, wave_first + sc.k, idx)] = start;
                     else slots2[at] = make_uint2(sc.k | (idx << 8), start);
                 }
-                rowbase += ((r < 2 ? tot_lo : tot_hi) >> sh) & 0xffffu;
+                rowbase += (tot[r >> 1] >> sh) & 0xffffu;
             }
             if (!direct) stage.count += T;
             nrun += T;

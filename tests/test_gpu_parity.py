@@ -355,7 +355,9 @@ def test_automatic_kernel_choice_and_fallback():
         p, r = host_match(res, ds)
         assert np.array_equal(p, pe) and np.array_equal(r, re_)
         used.append(int(res.stat("kernel_used")))
-    assert used[0] == 2 and used[8] != 2 and used[-1] != 2, used
+    # (round 6: the filter's hand-over first learns this text -- lists, item size, the wave kernels: two batches that decide nothing --
+    # and then costs 0.09 ms per call instead of 5.7; the whole-automaton walk still wins at 0.05)
+    assert used[0] == 2 and used[12] != 2 and used[-1] != 2, used
     assert used[8:].count(2) <= 3 and res.stat("choice_switches") >= 1 and res.stat("choice_probes") >= 2, used
     api.ahocorasick_deinit(res)
 
