@@ -236,9 +236,12 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
         for (int r = 0; r < G; ++r) buf[r] = load_quad(cur, r);
     };
     auto scan_task = [&](uint4 (&buf)[G]) {
-        uint32_t z[G];  // per quad: bit w set = the window ENDING at dword w of the quad hit (written on hits only)
+        uint32_t z[G];  // dense form, per quad: bit e set = the window ENDING at byte e of the quad hit (written on hits only)
 #pragma unroll
         for (int r = 0; r < G; ++r) z[r] = 0;
+        // aligned forms: four bits per quad -- bit w of nibble r set = the window ending at dword w of quad r hit -- in ONE register
+        // (an array of G words until round 6: seven registers of the streaming loop, and eight v_readlane per hit where one does)
+        uint32_t zpack = 0;
         uint32_t zany = 0;
         if (sc.c == 0) {  // first chunk of an item: nothing to the left of quad 0 (wave-uniform)
 #pragma unroll
@@ -388,8 +391,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
             const uint32_t m = hitmask[lane];
             if (__builtin_expect(__any(m != 0), 0)) {
                 hitmask[lane] = 0u;
-#pragma unroll
-                for (int r = 0; r < G; ++r) z[r] = (m >> (4 * r)) & 15u;
+                zpack = m;
                 zany = m;
             }
         } else if constexpr (DENSE) {
@@ -543,7 +545,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                     uint32_t m = 0;
 #pragma unroll
                     for (int w = 0; w < 4; ++w) m |= has_zero_half(anchor_compare(b4[w], h4[w], 0xFFFFFFFFu)) ? (1u << w) : 0u;
-                    z[r - 1] = m;
+                    zpack |= m << (4 * (r - 1));
                     zany |= m;
                 }
             }
@@ -685,7 +687,8 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                 if (__any(zany != 0)) {
 #pragma unroll
                     for (int r = 0; r < G; ++r) {
-                        uint64_t who = __ballot(z[r] != 0);
+                        const uint32_t zrow = (zpack >> (4 * r)) & 15u;
+                        uint64_t who = __ballot(zrow != 0);
                         if (who == 0) continue;
                         // the row's items in lane order (one, or tpack of them); an item's run count goes to its lane when its
                         // last hit has been flagged
@@ -701,7 +704,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                                 nrun = 0;
                                 cur_k = k;
                             }
-                            flag(0u, l & ((1u << tshift) - 1u), __builtin_amdgcn_readlane(z[r], l));
+                            flag(0u, l & ((1u << tshift) - 1u), __builtin_amdgcn_readlane(zrow, l));
                         }
                         if (cur_k != 0xFFFFFFFFu) { nrun_vec = lane == cur_k ? nrun : nrun_vec; nrun_max = nrun > nrun_max ? nrun : nrun_max; }
                     }
@@ -722,13 +725,13 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
             if constexpr (!BIG) return false;
             constexpr int NP = G / 2;   // two row counts to a word, sixteen bits each (a row of 64 quads has 256 windows)
             const uint32_t qi0 = sc.c * TQ + lane;
-            uint32_t pk[NP];
+            uint32_t pk[NP], zkept = 0;   // (the windows that can anchor something the item reports, nibble r = quad r)
 #pragma unroll
             for (int i = 0; i < NP; ++i) pk[i] = 0;
 #pragma unroll
             for (int r = 0; r < G; ++r) {
                 const uint32_t qi = qi0 + 64u * uint32_t(r);
-                uint32_t zr = qi < sc.nq ? z[r] : 0u;
+                uint32_t zr = qi < sc.nq ? (zpack >> (4 * r)) & 15u : 0u;
                 if (zr != 0u) {
                     const int32_t s0 = int32_t(sc.head + (qi << 4)) - int32_t(q - 4u);   // the window ending at dword w starts at s0 + 4 w
                     uint32_t keep = 0;
@@ -739,7 +742,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                     }
                     zr = keep;
                 }
-                z[r] = zr;
+                zkept |= zr << (4 * r);
                 pk[r >> 1] |= uint32_t(__builtin_popcount(zr)) << (16 * (r & 1));
             }
             uint32_t in[NP], tot[NP], T = 0;
@@ -765,7 +768,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                 const uint32_t cnt = (pk[r >> 1] >> sh) & 0xffffu, incl = (in[r >> 1] >> sh) & 0xffffu;
                 uint32_t at = stage.count + rowbase + incl - cnt, idx = nrun + rowbase + incl - cnt;
                 const uint32_t s0 = sc.head + ((qi0 + 64u * uint32_t(r)) << 4) - (q - 4u);
-                for (uint32_t m = z[r]; m != 0; m &= m - 1, ++at, ++idx) {
+                for (uint32_t m = (zkept >> (4 * r)) & 15u; m != 0; m &= m - 1, ++at, ++idx) {
                     const uint32_t start = s0 + 4u * uint32_t(__builtin_ctz(m));
                     if (direct) runs32[win_slot(B, wave_first + sc.k, idx)] = start;
                     else slots2[at] = make_uint2(sc.k | (idx << 8), start);
@@ -783,23 +786,21 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
             } else if ((cand & (cand - 1)) == 0) {
                 // one lane hit (the usual case): its eight masks go through the scalar unit
                 const uint32_t l = uint32_t(__builtin_ctzll(cand));
-#pragma unroll
-                for (int r = 0; r < G; ++r) {
-                    const uint32_t m = __builtin_amdgcn_readlane(z[r], l);
-                    if (m) flag(uint32_t(r), l, m);
+                // (its windows one by one off the packed word: a turn per hit, not a test per quad)
+                for (uint32_t zp = __builtin_amdgcn_readlane(zpack, l); zp != 0; zp &= zp - 1) {
+                    const uint32_t b = uint32_t(__builtin_ctz(zp));
+                    flag(b >> 2, l, 1u << (b & 3u));
                 }
             } else {
                 uint32_t hits = 0;  // bit r: some window ENDING in this lane's quad r hit
 #pragma unroll
-                for (int r = 0; r < G; ++r) hits |= z[r] ? (1u << r) : 0u;
+                for (int r = 0; r < G; ++r) hits |= ((zpack >> (4 * r)) & 15u) ? (1u << r) : 0u;
                 uint32_t rmask = 0;
                 for (uint64_t w = cand; w != 0; w &= w - 1) rmask |= __builtin_amdgcn_readlane(hits, uint32_t(__builtin_ctzll(w)));
                 while (rmask != 0) {  // ascending quad order (r outer, lane inner) keeps the run list sorted
                     const uint32_t r = uint32_t(__builtin_ctz(rmask));
                     rmask &= rmask - 1;
-                    uint32_t zr = 0;
-#pragma unroll
-                    for (int i = 0; i < G; ++i) zr = uint32_t(i) == r ? z[i] : zr;
+                    const uint32_t zr = (zpack >> (4u * r)) & 15u;
                     uint64_t who = __ballot(zr != 0);
                     while (who != 0) {
                         const uint32_t l = uint32_t(__builtin_ctzll(who));
