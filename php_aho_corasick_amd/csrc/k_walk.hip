@@ -1,4 +1,6 @@
 // k_walk.hip -- the exact walks behind the filter: k_walk_runs and the dense form's decision kernels (k_walk_items: k_walk_items.hip)
+#include <cstdlib>
+
 #include "kdev.hpp"
 
 namespace acmi {
@@ -69,16 +71,17 @@ template <typename E, int MODE, bool EXTRA>
 __global__ __launch_bounds__(kWalkThreads) void k_walk_runs(DevAutomaton A, BatchArgs B, uint32_t tile_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint64_t total_items = B.item_base[B.n_haystacks];
-    if (uint64_t(blockIdx.x) * kWalkThreads >= total_items) return;
+    if (uint64_t(blockIdx.x) * blockDim.x >= total_items) return;
     __shared__ uint32_t s_walked, s_done, s_fallback, s_busy;
     if (threadIdx.x == 0) { s_walked = 0; s_done = 0; s_fallback = 0; s_busy = 0; }
-    const uint64_t item = uint64_t(blockIdx.x) * kWalkThreads + threadIdx.x;
+    const uint64_t item = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     // issue the item's own loads first: they are in flight while the tile is staged
-    uint32_t nr = 0;
+    uint32_t nr = 0, entry0 = 0;
     uint4 rec = make_uint4(0u, 0u, 0u, 0u);
     if (item < total_items) {
         nr = B.run_count[item];
         rec = B.item_rec[item];
+        entry0 = reinterpret_cast<const uint32_t *>(B.runs)[win_slot(B, item, 0u)];   // (valid memory whatever the list holds; used when nr != 0)
         if (B.zero_counters) {   // (the table is the batch before's: so are these, until an item with events overwrites them below)
             B.ev_count[item] = 0u;
             B.rec_count[item] = 0ull;
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_runs(DevAutomaton A, Batc
         else if (nr > B.wave_min && B.wave_runs && !B.first_only) busy = true;
         else {
             busy = nr > B.wave_min;
-            walked = run_epilogue_fast<E, MODE, EXTRA>(A, B, smem, tile_rows, item, it, nr, fallback16);
+            walked = run_epilogue_fast<E, MODE, EXTRA>(A, B, smem, tile_rows, item, it, nr, fallback16, entry0, true);
         }
     }
     wave_walk_whole<E, MODE>(A, B, smem, tile_rows, whole, rec, item, walked, fallback16);
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_runs(DevAutomaton A, Batc
         if (fallback16) atomicAdd(&s_fallback, fallback16);
         if (n_busy) atomicAdd(&s_busy, n_busy);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (atomicAdd(&s_done, 1u) == kWalkThreads / 64u - 1u) {
+        if (atomicAdd(&s_done, 1u) == blockDim.x / 64u - 1u) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             const uint32_t total = atomicAdd(&s_walked, 0u), fb = atomicAdd(&s_fallback, 0u), nb = atomicAdd(&s_busy, 0u);
             if (total) atomicAdd(&B.counters[8u + (blockIdx.x & 7u)], total);
@@ -344,7 +347,10 @@ hipError_t launch_walk_runs(const DevAutomaton &A, const BatchArgs &B, uint64_t 
                             hipStream_t st, bool stage_tile) {
     if (max_items == 0) return hipSuccess;
     if (B.run_dense == 1u) return launch_verify_dense(A, B, max_items, entry_bytes, class_mode, st);   // (2: window lists of the aligned forms, this kernel's)
-    const uint32_t blocks = uint32_t((max_items + kWalkThreads - 1) / kWalkThreads);
+    // (512- and 256-thread workgroups where no tile is staged -- three / six workgroups a CU instead of one of sixteen waves -- were
+    // measured on the headline batch, round 6: 49.8 -> 51.5 / 54.0 us)
+    const uint32_t threads = kWalkThreads;
+    const uint32_t blocks = uint32_t((max_items + threads - 1) / threads);
     // No tile while the handle's candidates are all decided by text compares (the engine asks for it again as soon as a batch
     // walked a cluster: every fallback cluster through the L2 is not worth it): 64 KiB staged per 1,024 items were 52 -> 49.5 us on
     // the headline batch, 0.148 -> 0.141 ms on config 3 -- and most of the kernel for haystacks of 256 B, an item each.
@@ -355,7 +361,7 @@ hipError_t launch_walk_runs(const DevAutomaton &A, const BatchArgs &B, uint64_t 
     auto go = [&](auto fn) {
         hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), uint32_t(lds));
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(fn, dim3(blocks), dim3(kWalkThreads), lds, st, A, B, tile_bytes);
+        hipLaunchKernelGGL(fn, dim3(blocks), dim3(threads), lds, st, A, B, tile_bytes);
         return hipGetLastError();
     };
     const bool extra = A.early_stop != 0u;

@@ -421,8 +421,11 @@ __device__ __forceinline__ void append_win_wave(const BatchArgs &B, uint64_t wav
 }
 
 // Run r of an item as run_epilogue_fast wants it, {lo, hi, entry, -}, from its window list.
+__device__ __forceinline__ uint4 run_of_entry(const DevAutomaton &A, uint32_t e, uint32_t n);
 __device__ __forceinline__ uint4 load_run(const DevAutomaton &A, const BatchArgs &B, uint64_t item, uint32_t r, uint32_t n) {
-    const uint32_t e = reinterpret_cast<const uint32_t *>(B.runs)[win_slot(B, item, r)];
+    return run_of_entry(A, reinterpret_cast<const uint32_t *>(B.runs)[win_slot(B, item, r)], n);
+}
+__device__ __forceinline__ uint4 run_of_entry(const DevAutomaton &A, uint32_t e, uint32_t n) {
     if (e & kWinSpecial) {
         const uint32_t v = e & 0x3FFFFFFFu;
         return (e & kWinTail) ? make_uint4(v, n, kEntryUnknown, 0u) : make_uint4(0u, v, 0u, 0u);
@@ -823,7 +826,7 @@ __device__ __forceinline__ void emit_verified(const BatchArgs &B, uint64_t item,
 template <typename E, int MODE, bool EXTRA>
 __device__ __forceinline__ uint32_t run_epilogue_fast(const DevAutomaton &A, const BatchArgs &B, const uint8_t *tile,
                                                       uint32_t tile_rows, uint64_t item, const ItemDesc &it, uint32_t nr,
-                                                      uint32_t &fallback16) {
+                                                      uint32_t &fallback16, uint32_t entry0 = 0u, bool have_entry0 = false) {
     const uint8_t *p = B.blob + (it.begin - it.warm);
     const uint32_t n = it.warm + it.len;
     const uint32_t pos_bias = it.pos0 - it.warm + 1u;
@@ -836,7 +839,8 @@ __device__ __forceinline__ uint32_t run_epilogue_fast(const DevAutomaton &A, con
                                        // an atomic per cluster on one word serialises the launch at ~ 12 ns each)
     } else {
         uint32_t r = 0;
-        uint4 run = nr ? load_run(A, B, item, 0u, n) : make_uint4(0u, 0u, 0u, 0u);
+        // (entry0: the list's first entry, requested by the caller together with the list's length -- a round trip less per item)
+        uint4 run = nr ? (have_entry0 ? run_of_entry(A, entry0, n) : load_run(A, B, item, 0u, n)) : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll 1
         while (r < nr) {
             // the cluster that starts with run r
