@@ -486,14 +486,16 @@ bool chain_walk_ok(const DevAutomaton &A) {
     return img + 512u <= 160u * 1024u;
 }
 
-uint32_t chain_grid() { return uint32_t(num_cus()); }
-uint32_t chain_waves() { return chain_grid() * kChainWaves; }
+// ("reserve_cus": the walk leaves that many compute units to a collective's kernels, like the persistent scan kernels -- the logs
+// and spill regions are per wave of the grid that runs, so the walk, the emit and the host's sizing take the same count)
+uint32_t chain_grid(uint32_t reserve_cus) { return uint32_t(std::max(1, num_cus() - int(reserve_cus))); }
+uint32_t chain_waves(uint32_t reserve_cus) { return chain_grid(reserve_cus) * kChainWaves; }
 uint64_t chain_tiles(uint64_t max_items, uint32_t P) { return max_items / (128u / P) + 1u; }
 // the waves' overflow regions: what a piece can have beyond its LDS list, a word each
 // (an item's last piece takes the item's unaligned head as well: up to W + 15 bytes, an event each)
-uint64_t chain_spill_words(uint32_t W) { return uint64_t(chain_waves()) * uint64_t(W + 16u) * 128u; }
+uint64_t chain_spill_words(uint32_t W, uint32_t reserve_cus) { return uint64_t(chain_waves(reserve_cus)) * uint64_t(W + 16u) * 128u; }
 
-static ChainArgs chain_args(const DevAutomaton &A, uint32_t W, uint32_t P, const ChainBuffers &C) {
+static ChainArgs chain_args(const DevAutomaton &A, const BatchArgs &B, uint32_t W, uint32_t P, const ChainBuffers &C) {
     ChainArgs T{};
     T.W = W;
     T.P = P;
@@ -505,7 +507,7 @@ static ChainArgs chain_args(const DevAutomaton &A, uint32_t W, uint32_t P, const
     T.log = C.log;
     T.log_cap = C.log_cap;
     T.tile_info = reinterpret_cast<uint2 *>(C.tile_info);
-    T.n_waves = chain_waves();
+    T.n_waves = chain_waves(B.reserve_cus);
     return T;
 }
 
@@ -513,16 +515,16 @@ hipError_t launch_walk_chain(const DevAutomaton &A, const BatchArgs &B, uint64_t
                              hipStream_t st) {
     if (max_items == 0) return hipSuccess;
     if (!chain_walk_ok(A)) return hipErrorInvalidValue;
-    ChainArgs T = chain_args(A, W, P, C);
+    ChainArgs T = chain_args(A, B, W, P, C);
     static const uint32_t debug = [] { const char *e = std::getenv("ACMI_CHAIN_DEBUG"); return e ? uint32_t(std::atoi(e)) : 0u; }();
     T.debug = debug;
     const uint32_t img = (A.chain_img_bytes + 15u) & ~15u;
     const uint32_t lds = img + (class_mode == 0 ? 512u : 0u);
-    // (always the whole grid: the logs are per wave of THIS grid -- k_chain_emit finds a tile's by t % n_waves)
+    // (the logs are per wave of THIS grid -- k_chain_emit finds a tile's by t % n_waves)
     auto go = [&](auto fn) {
         hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), uint32_t(lds));
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(fn, dim3(chain_grid()), dim3(kChainThreads), lds, st, A, B, T);
+        hipLaunchKernelGGL(fn, dim3(chain_grid(B.reserve_cus)), dim3(kChainThreads), lds, st, A, B, T);
         return hipGetLastError();
     };
     const bool alld = A.chain_dense == A.chain_index;
@@ -533,7 +535,7 @@ hipError_t launch_walk_chain(const DevAutomaton &A, const BatchArgs &B, uint64_t
 hipError_t launch_chain_emit(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, uint32_t W, uint32_t P, const ChainBuffers &C,
                              const uint64_t *rec_base, void *out, uint64_t cap, hipStream_t st) {
     if (max_items == 0) return hipSuccess;
-    ChainArgs T = chain_args(A, W, P, C);
+    ChainArgs T = chain_args(A, B, W, P, C);
     T.rec_base = rec_base;
     T.out = static_cast<uint4 *>(out);
     T.cap = cap;

@@ -48,9 +48,9 @@ struct ChainBuffers {
     uint32_t *tile_info;   // 2 x chain_tiles(max_items, P) words: per tile {where its events begin in its wave's log, how many}
 };
 bool chain_walk_ok(const DevAutomaton &A);
-uint32_t chain_waves();
+uint32_t chain_waves(uint32_t reserve_cus = 0);
 uint64_t chain_tiles(uint64_t max_items, uint32_t P);
-uint64_t chain_spill_words(uint32_t W);
+uint64_t chain_spill_words(uint32_t W, uint32_t reserve_cus = 0);
 hipError_t launch_walk_chain(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int class_mode, uint32_t W, uint32_t P, const ChainBuffers &C,
                              hipStream_t st);
 hipError_t launch_chain_emit(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, uint32_t W, uint32_t P, const ChainBuffers &C,

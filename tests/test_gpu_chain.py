@@ -186,3 +186,17 @@ def test_bounded_result_memory_drains_and_resumes():
     p, r = host_match(res, ds)
     assert np.array_equal(p, pe) and np.array_equal(r, re_)
     api.ahocorasick_deinit(res)
+
+
+@pytest.mark.parametrize("reserve", [1, 8, 100])
+def test_reserved_compute_units(reserve):
+    """"reserve_cus" (acmi.h): the walk runs on all but N compute units -- the logs and overflow regions are per wave of the grid that
+    runs, so the walk, the emit and the host's sizing have to agree on it."""
+    base = synth.density_set("headline")
+    ds = synth.plant_density(base, 64, 8192)
+    n = min(128, ds.n_haystacks)
+    ds = synth.Dataset(ds.name, ds.pat_blob, ds.pat_off, ds.hay_blob[:int(ds.hay_off[n])], ds.hay_off[:n + 1])
+    pe, re_ = _oracle(ds)
+    res = resource_for(ds, kernel=6, small_path=0, reserve_cus=reserve)
+    _check(res, ds, pe, re_, calls=3)
+    api.ahocorasick_deinit(res)
