@@ -14,7 +14,7 @@ for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recurs
     shutil.copy(f, os.path.join(dst, prefix + "kernel_stats.csv"))
 if os.path.exists(os.path.join(src, "summary.txt")):
     shutil.copy(os.path.join(src, "summary.txt"), os.path.join(dst, prefix + "rocprofv3_summary.txt"))
-KEEP = ("k_scan_lds", "k_scan_anchor", "k_walk_runs", "k_walk_items", "k_stream_read", "k_refill_wave", "k_expand", "k_items", "k_rec_scan", "k_dense_decide", "k_dense_emit", "k_merge", "k_replace", "k_scan_u64", "k_walk_tiles", "k_match_small", "k_gather", "k_walk_chain", "k_chain_emit")
+KEEP = ("k_scan_lds", "k_scan_anchor", "k_walk_runs", "k_walk_items", "k_stream_read", "k_refill_wave", "k_expand", "k_items", "k_rec_scan", "k_dense_decide", "k_dense_emit", "k_merge", "k_replace", "k_scan_u64", "k_walk_tiles", "k_match_small", "k_gather", "k_walk_chain", "k_chain_emit", "k_runs_wave", "k_expand_dense", "k_walk_win")
 for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         with open(f) as fh:
