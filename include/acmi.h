@@ -372,6 +372,9 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *                    trie depth <= 2 two bytes past the window start: 0 = off, 1 (default) = when some 3-gram
  *                    over the patterns' first-byte alphabet is not a trie path (else it cannot fire on
  *                    in-alphabet text), 2 = always                                        [any time]
+ *   "relist"         1 (default): a batch in which a work item's list of candidate windows overflowed while lists can still grow is
+ *                    run again with the lists (and slabs, item size) the scan's own count asks for, instead of walking such items
+ *                    whole through the tables; 0 = walk them at once ("relist_reruns")                    [any time]
  *   "wave_runs"      work items with more than three candidate windows of the anchor filter are decided a wave per item, a lane
  *                    per window (k_runs_wave, enqueued while batches report such items): 1 (default) yes, 0 = one lane per
  *                    item whatever it holds.  Same records either way ("busy_items", "max_windows", "serial_items",

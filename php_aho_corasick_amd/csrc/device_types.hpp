@@ -109,6 +109,7 @@ struct BatchArgs {
     uint32_t *busy_list;         // ... their indices (k_walk_runs appends, counters[20] counts)
     uint32_t wave_runs;          // 1: items with more than wave_min windows are left to k_runs_wave (a wave per item, a lane per window)
     uint32_t *dense_list;        // null, or: k_expand leaves items of more than wave_min events to k_expand_dense, their indices here (counters[23] counts)
+    uint32_t relist;             // 1: an item whose window list overflowed is left undone -- the host runs the batch again with longer lists
     uint32_t wave_min;           // >= kWaveRunsMin: a wave per item only pays where the item's one lane would take longer than the waves' turns
     uint32_t poison_quads;       // ceil(max_pattern_length / 16): quads flagged after a lost state
     uint32_t persistent;         // 1: one workgroup per CU, waves pull item batches from counters[1]

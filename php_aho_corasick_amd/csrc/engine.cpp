@@ -587,9 +587,9 @@ static int apply_option(acmi_handle *h, const std::string &k, int64_t value) {
             h->slab_events = uint32_t(value);
             h->slab_set = true;
         } else if (k == "run_cap") {
-            if (value < 1 || value > 1024) return ACMI_E_ARG;
-            h->run_cap = uint32_t(value);
-            h->run_cap_set = true;
+            if (value < 0 || value > 1024) return ACMI_E_ARG;
+            h->run_cap = value ? uint32_t(value) : 16u;
+            h->run_cap_set = value != 0;   // (0: learned from the data again)
         } else if (k == "chunk_bytes") {
             if (value < 0) return ACMI_E_ARG;
             h->chunk_opt = uint64_t(value);
@@ -641,6 +641,8 @@ static int apply_option(acmi_handle *h, const std::string &k, int64_t value) {
             h->early_stop = int(value);
             if (h->aut.finalized())
                 h->dA.early_stop = (value == 2 || (value == 1 && h->aut.flat().early_stop_useful)) ? 1u : 0u;
+        } else if (k == "relist") {
+            h->relist_opt = value ? 1 : 0;
         } else if (k == "wave_runs") {
             h->wave_runs_opt = value ? 1 : 0;
         } else if (k == "refill") {
@@ -768,6 +770,7 @@ int acmi_get_stat(const acmi_handle *h, const char *key, double *value) {
         else if (k == "fallback_bytes") *value = double(h->fallback_bytes);
         else if (k == "anchor_chunk_shift") *value = h->anchor_chunk_shift;
         else if (k == "win_table") *value = fa.win_present ? 1 : 0;
+        else if (k == "relist_reruns") *value = h->relist_reruns;
         else if (k == "busy_items") *value = h->busy_items;
         else if (k == "max_windows") *value = h->max_windows;
         else if (k == "serial_items") *value = h->serial_items;

@@ -105,10 +105,14 @@ struct acmi_handle {
     // options
     bool dense_output = false;   // the last batch produced a record per two bytes of text or more (which drain: refill_mode)
     uint32_t run_auto = 0;       // run-list entries per item the data has asked for so far
+    uint32_t sparse_slab_batches = 0;   // ... likewise for the event slabs
+    uint32_t sparse_batches = 0; // filter batches in a row whose longest window list fitted the short form (the long lists are given up after eight)
     bool expand_armed = false;   // the last batch averaged four records a work item or more: k_expand_dense is enqueued with the next
     uint32_t anchor_chunk_shift = 0;   // the anchor filter's work items are 8 KiB >> this (learned from the windows per item; "anchor_chunk_shift")
     bool wave_armed = false;     // the last filter batch had items with more than a few candidate windows: k_runs_wave is enqueued with the next
     int win_walk = 1;            // "win_walk": kernel 4 over the two-byte window table where the set has one (k_walk_win), 0 = k_walk_items
+    int relist_opt = 1;          // "relist": 0 = an item whose window list overflows is walked whole at once (no second run of the batch)
+    uint32_t relist_reruns = 0;  // batches run again for longer window lists ("relist_reruns")
     int wave_runs_opt = 1;       // "wave_runs": 0 never launches k_runs_wave (every item is k_walk_runs')
     uint32_t busy_items = 0, max_windows = 0, serial_items = 0;   // of the last filter batch ("busy_items", "max_windows", "serial_items")
     bool wave_used = false;      // ... which ran k_runs_wave ("wave_runs_used")
@@ -262,6 +266,7 @@ struct acmi_handle {
         ChainBuffers chain_buf{};             // ... with these buffers (k_chain_emit again into a grown record buffer)
         bool merged = false;                  // (part 1 of a split set) this batch wrote the MERGED records into the parent's buffer
         bool reran = false;                   // the end had to complete or repeat the pipeline: what ran behind it on the stream saw unfinished results
+        bool relist = false;                  // items whose window list overflows are left undone and the batch is run again with longer lists
         bool win_lists = false, wave_runs = false;   // the filter handed over window lists; k_runs_wave was enqueued behind k_walk_runs
         bool refill_launched = false;  // the drain of overflowed items was enqueued with the pipeline (else: only if the batch turns out to need it)
         DevBuf d_prefix, d_out;        // valid from this batch's end until the second begin after its own

@@ -294,6 +294,7 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     B.run_dense = dense ? 1u : win ? 2u : 0u;
     B.run_major = (dense || (win && Q > 16u)) ? 1u : 0u;   // (short lists entry-major: k_walk_runs' thread per item reads whole lines)
     B.wave_runs = wave_runs ? 1u : 0u;
+    B.relist = (win && Q < F.run_max && !h->run_cap_set && h->relist_opt != 0) ? 1u : 0u;   // (an item whose list overflows is left undone: run_batch_end runs the batch again with longer lists)
     // a wave per item against a lane per item: the chip holds ~ 8,192 of k_runs_wave's waves at a time and 262,144 of k_walk_runs' lanes,
     // a window costs either the same chain of round trips -- so an item is the wave kernel's when it has more windows than the
     // batch's items take turns of waves (64 MiB of 8 KiB items: from four windows on; of 256-byte haystacks: from nine)
@@ -449,6 +450,7 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
     if (B.wave_runs) HIPCHK(h, launch_runs_wave(h->dA, B, max_items, int(fa.entry_bytes), int(fa.class_mode), st));
     F.wave_runs = B.wave_runs != 0u;
     F.win_lists = win;
+    F.relist = B.relist != 0u;
     if (h->profile > 1) HIPCHK(h, hipEventRecord(F.ev[3], st));
 
     if (!find_all) {
@@ -614,6 +616,47 @@ int run_split_end(acmi_handle *h) {
     return ACMI_OK;
 }
 
+// What the hand-over behind the filter learns from a batch (window lists, round 6): the scan reports the longest list the batch
+// asked for (word 21), k_walk_runs the items with more than a few windows (word 20) -- the lists of the batches behind are sized
+// in one step, and k_runs_wave is enqueued while there are such items.
+static void learn_handover(acmi_handle *h, const acmi_handle::FlySlot &F, const uint32_t *pinned32) {
+    if (F.win_lists) {
+        h->busy_items = pinned32[20];
+        h->max_windows = pinned32[21];
+        h->serial_items = pinned32[22];
+        h->wave_used = F.wave_runs;
+        // (armed by the longest list as well: on a batch whose lists all overflowed k_walk_runs saw no item it could have listed)
+        h->wave_armed = pinned32[20] != 0u || pinned32[21] > F.args.wave_min;
+        if (pinned32[21] > F.run_used && F.run_used < F.run_max) {
+            uint32_t want = 16;
+            while (want < pinned32[21] + pinned32[21] / 4u && want < F.run_max) want *= 2;
+            h->run_auto = std::max(h->run_auto, want);
+        }
+        // ... and back: eight batches in a row whose longest list had room in the short form (16 entries, entry-major: what the thread
+        // per item of a sparse batch reads as whole lines) give the long, item-major lists up again
+        if (!h->run_cap_set && F.run_used > 16u && pinned32[21] <= 12u) {
+            if (++h->sparse_batches >= 8u) { h->run_auto = 16; h->sparse_batches = 0; }
+        } else {
+            h->sparse_batches = 0;
+        }
+        // (a window is an event at most -- but for patterns that share an anchor: the slabs follow the lists in one step as well)
+        if (!h->slab_set && pinned32[21] > F.slab_used && h->wave_armed) {
+            uint32_t want = 16;
+            while (want < pinned32[21] && want < 256u) want *= 2;
+            h->slab_auto = std::max(h->slab_auto, want);
+        }
+        // more than ~ 200 windows an item: smaller items (8 KiB -> 4, 2, 1 KiB), so that an item has ~ 128 at most
+        if (!h->chunk_opt && pinned32[21] > 192u && F.chunk_used >= 2048u && h->anchor_chunk_shift < 3u) {
+            uint32_t per = pinned32[21], shift = h->anchor_chunk_shift;
+            uint64_t c = F.chunk_used;
+            while (per > 160u && c >= 2048u && shift < 3u) { per = (per + 1u) / 2u; c /= 2; ++shift; }
+            h->anchor_chunk_shift = shift;
+        } else if (!h->chunk_opt && h->anchor_chunk_shift && pinned32[21] <= 60u) {
+            --h->anchor_chunk_shift;   // (sparser text again: items twice the size would still have ~ 120 windows at most)
+        }
+    }
+}
+
 int run_batch_end(acmi_handle *h) {
     if (h->begin_seq == h->end_seq) { h->last_error = "no batch in flight"; return ACMI_E_ARG; }
     if (h->part[0]) return run_split_end(h);
@@ -667,6 +710,25 @@ int run_batch_end(acmi_handle *h) {
         F.timed = false;
         HIPCHK(h, hipStreamSynchronize(st));
     }
+    // Window lists that overflowed while they could still grow: k_walk_runs left those items undone (BatchArgs::relist) instead of
+    // walking them whole -- 8 KiB through tables in global memory per item, then the drain's second walk: 34 ms for the first 64 MiB of
+    // dense text a handle of the 65,536-pattern set met -- and the batch runs again with the lists, slabs and items the scan's own
+    // count asks for (0.4 ms).
+    for (int tries = 0; F.relist && pinned32[21] > F.run_used && pinned32[6] == 0u && tries < 4; ++tries) {
+        {
+            const hipError_t e = hipStreamSynchronize(st);
+            if (e != hipSuccess) { h->sync_tiles = 0; return fail_hip(h, e, "hipStreamSynchronize"); }
+        }
+        learn_handover(h, F, pinned32);
+        ++h->relist_reruns;
+        h->rerun_kernel = F.kernel_used;
+        const int rc = enqueue_batch(h, F, F.d_blob, F.blob_bytes, F.d_off, F.nh, F.find_all);
+        h->rerun_kernel = -1;
+        if (rc < 0) { h->sync_tiles = 0; return rc; }
+        h->enqueue_seq = F.seq;
+        F.timed = false;
+        HIPCHK(h, hipStreamSynchronize(st));
+    }
     if (pinned32[6] != 0u) {
         h->last_error = "offsets must be non-decreasing, inside the blob, and every haystack shorter than 4 GiB";
         return ACMI_E_ARG;
@@ -686,35 +748,7 @@ int run_batch_end(acmi_handle *h) {
     // whole (items whose candidate windows overflowed the list)
     if (h->kernel == 3 && F.blob_bytes >= kAutoMinBytes && F.kernel_used == 2 && h->fallback_bytes * 64 > F.blob_bytes && F.run_used < F.run_max)
         h->run_auto = F.run_used * 4;
-    if (F.win_lists) {
-        // window lists: the scan reports the longest list the batch asked for (word 21), k_walk_runs the items with more than a few
-        // windows (word 20) -- the lists of the batches behind are sized in one step, and k_runs_wave is enqueued while there are such items
-        h->busy_items = pinned32[20];
-        h->max_windows = pinned32[21];
-        h->serial_items = pinned32[22];
-        h->wave_used = F.wave_runs;
-        h->wave_armed = pinned32[20] != 0u;
-        if (pinned32[21] > F.run_used && F.run_used < F.run_max) {
-            uint32_t want = 16;
-            while (want < pinned32[21] + pinned32[21] / 4u && want < F.run_max) want *= 2;
-            h->run_auto = std::max(h->run_auto, want);
-        }
-        // (a window is an event at most -- but for patterns that share an anchor: the slabs follow the lists in one step as well)
-        if (!h->slab_set && pinned32[21] > F.slab_used && h->wave_armed) {
-            uint32_t want = 16;
-            while (want < pinned32[21] && want < 256u) want *= 2;
-            h->slab_auto = std::max(h->slab_auto, want);
-        }
-        // more than ~ 200 windows an item: smaller items (8 KiB -> 4, 2, 1 KiB), so that an item has ~ 128 at most
-        if (!h->chunk_opt && pinned32[21] > 192u && F.chunk_used >= 2048u && h->anchor_chunk_shift < 3u) {
-            uint32_t per = pinned32[21], shift = h->anchor_chunk_shift;
-            uint64_t c = F.chunk_used;
-            while (per > 160u && c >= 2048u && shift < 3u) { per = (per + 1u) / 2u; c /= 2; ++shift; }
-            h->anchor_chunk_shift = shift;
-        } else if (!h->chunk_opt && h->anchor_chunk_shift && pinned32[21] <= 60u) {
-            --h->anchor_chunk_shift;   // (sparser text again: items twice the size would still have ~ 120 windows at most)
-        }
-    }
+    learn_handover(h, F, pinned32);
     float pipeline_ms = 0;
     HIPCHK(h, hipEventElapsedTime(&pipeline_ms, F.ev[0], F.ev[4]));
     h->total_ms = pipeline_ms;
@@ -744,7 +778,7 @@ int run_batch_end(acmi_handle *h) {
     if (F.win_lists) {
         const uint32_t busy = pinned32[20], maxw = pinned32[21];
         handover_learning = (maxw > F.run_used && F.run_used < F.run_max) ||
-                            (busy != 0 && !F.wave_runs && F.find_all && h->wave_runs_opt != 0 && h->dA.anchor_pairs != nullptr) ||
+                            ((busy != 0 || maxw > F.args.wave_min) && !F.wave_runs && F.find_all && h->wave_runs_opt != 0 && h->dA.anchor_pairs != nullptr) ||
                             (!h->chunk_opt && maxw > 192u && F.chunk_used >= 2048u && h->anchor_chunk_shift < 3u);
     }
     if (F.find_all && F.kernel_used != 6 && F.args.dense_list == nullptr && h->wave_runs_opt != 0 && total >= 4 * std::max<uint64_t>(1, h->items))
@@ -801,6 +835,13 @@ int run_batch_end(acmi_handle *h) {
     }
     h->last_total = total;
     h->expand_armed = total >= 4 * std::max<uint64_t>(1, h->items);
+    // (big slabs -- item-major, learned from text full of matches -- are given up after eight batches in a row with fewer than two
+    // records an item and nothing drained: the sparse batch's thread per item reads the small, event-major slab as whole lines)
+    if (!h->slab_set && F.slab_used > 32u && total < 2 * std::max<uint64_t>(1, h->items) && n_ovf == 0) {
+        if (++h->sparse_slab_batches >= 8u) { h->slab_auto = 0; h->sparse_slab_batches = 0; }
+    } else {
+        h->sparse_slab_batches = 0;
+    }
     h->have_result = true;
     h->resume_haystack = F.nh;
     if (partial) {

@@ -115,7 +115,8 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_runs(DevAutomaton A, Batc
         // (... and an item with more than a few windows is a latency chain per window for its one lane -- eight windows per 8 KiB item,
         // and a batch of 8,192 items took 0.21 ms instead of 0.08: such items are k_runs_wave's, a wave per item and a lane per
         // window, launched behind this kernel once a batch has reported some: counters[20])
-        if (nr > B.run_cap && !B.first_only) whole = true;
+        if (nr > B.run_cap && B.relist) { /* left undone: the batch runs again with longer lists (run_batch_end) */ }
+        else if (nr > B.run_cap && !B.first_only) whole = true;
         else if (nr > B.wave_min && B.wave_runs && !B.first_only) busy = true;
         else {
             busy = nr > B.wave_min;

@@ -31,23 +31,28 @@ def _oracle(ds, find_all=True):
     return out
 
 
+@pytest.mark.parametrize("relist", [1, 0])
 @pytest.mark.parametrize("per_hay", [6, 17, 40, 100])
-def test_many_candidates_per_item_through_the_filter(per_hay):
-    """More candidate windows per 8-KiB item than the first run lists (16) and slabs hold: the items are walked by their waves and
-    drained, and the handle's lists and slabs grow for the calls after -- same records every time."""
+def test_many_candidates_per_item_through_the_filter(per_hay, relist):
+    """More candidate windows per 8-KiB item than the first window lists (16) and slabs hold.  relist = 1 (default): the batch is run
+    again with the lists the scan's own count asks for ("relist_reruns"); relist = 0: the items are walked by their waves and
+    drained, and the handle's lists and slabs grow for the calls after -- same records every time either way."""
     ds = _planted(512, 8192, per_hay)
     pe, re_ = _oracle(ds)
-    res = resource_for(ds)
+    res = resource_for(ds, relist=relist)
     overflow = []
     for _ in range(4):
         p, r = device_match(res, ds)
         assert np.array_equal(p, pe) and np.array_equal(r, re_)
         overflow.append(int(res.stat("overflow_items")))
-    if per_hay <= 40:   # what the lists (<= 64) and slabs (<= 256) can learn to hold
+    if per_hay <= 40:   # what the lists and slabs (<= 256) can learn to hold
         assert overflow[-1] == 0, overflow
     # (which kernel the later calls run on is a measured choice: tests/test_gpu_cliffs.py)
     if 17 <= per_hay <= 40:
-        assert overflow[0] > 0, overflow
+        if relist:
+            assert res.stat("relist_reruns") >= 1
+        else:
+            assert overflow[0] > 0 and res.stat("relist_reruns") == 0, overflow
     api.ahocorasick_deinit(res)
 
 
