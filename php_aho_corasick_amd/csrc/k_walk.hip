@@ -80,8 +80,12 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_runs(DevAutomaton A, Batc
     uint4 rec = make_uint4(0u, 0u, 0u, 0u);
     if (item < total_items) {
         nr = B.run_count[item];
-        rec = B.item_rec[item];
-        entry0 = reinterpret_cast<const uint32_t *>(B.runs)[win_slot(B, item, 0u)];   // (valid memory whatever the list holds; used when nr != 0)
+        // (batches of tiny haystacks -- 4 M items a GiB, one in thirty with a candidate -- ask for the 16-byte record and the list's first
+        // entry only where there is a list: 84 of the kernel's 130 MB)
+        if (!B.tiny_items || nr != 0u) {
+            rec = B.item_rec[item];
+            entry0 = reinterpret_cast<const uint32_t *>(B.runs)[win_slot(B, item, 0u)];   // (valid memory whatever the list holds; used when nr != 0)
+        }
         if (B.zero_counters) {   // (the table is the batch before's: so are these, until an item with events overwrites them below)
             B.ev_count[item] = 0u;
             B.rec_count[item] = 0ull;
