@@ -797,14 +797,40 @@ __global__ __launch_bounds__(kLdsThreads) void k_scan_anchor(DevAutomaton A, Bat
                 for (int r = 0; r < G; ++r) hits |= ((zpack >> (4 * r)) & 15u) ? (1u << r) : 0u;
                 uint32_t rmask = 0;
                 for (uint64_t w = cand; w != 0; w &= w - 1) rmask |= __builtin_amdgcn_readlane(hits, uint32_t(__builtin_ctzll(w)));
-                while (rmask != 0) {  // ascending quad order (r outer, lane inner) keeps the run list sorted
+                while (rmask != 0) {  // ascending quad order (r outer, lane inner) keeps the window list sorted
                     const uint32_t r = uint32_t(__builtin_ctz(rmask));
                     rmask &= rmask - 1;
                     const uint32_t zr = (zpack >> (4u * r)) & 15u;
-                    uint64_t who = __ballot(zr != 0);
+                    // A row in which every hitting lane has ONE window that can anchor something (the usual row of text with matches
+                    // by the dozen per item): the lanes place their entries themselves, a ballot and a bit count for the index --
+                    // ~ 15 instructions a row instead of ~ 80 a hit through the scalar unit (the headline set at 16 / 64 occurrences
+                    // per 8 KiB: the hits were 0.2 / 0.7 of the scan's 0.37 / 0.87 ms per GiB).
+                    const uint32_t qi = sc.c * TQ + r * 64u + lane;
+                    const int32_t s0 = int32_t(sc.head + (qi << 4)) - int32_t(q - 4u);
+                    uint32_t keep = 0;
+                    if (zr != 0u && qi < sc.nq) {
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            const int32_t st = s0 + 4 * w;
+                            if (((zr >> w) & 1u) != 0u && st >= 0 && uint32_t(st) + lo_bias < sc.n) keep |= 1u << w;
+                        }
+                    }
+                    uint64_t who = __ballot(keep != 0u);
+                    if (who == 0) continue;
+                    const uint32_t cnt = uint32_t(__builtin_popcountll(who));
+                    if (__ballot((keep & (keep - 1u)) != 0u) == 0 && nrun + cnt <= B.run_cap) {
+                        if (stage.count + cnt > stage.cap) dense_flush(B, wave_first, stage, lane);
+                        const uint32_t at = __builtin_amdgcn_mbcnt_hi(uint32_t(who >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(who), 0u));
+                        if (keep != 0u)
+                            reinterpret_cast<uint2 *>(stage.slots)[stage.count + at] = make_uint2(sc.k | ((nrun + at) << 8), uint32_t(s0) + 4u * uint32_t(__builtin_ctz(keep)));
+                        stage.count += cnt;
+                        nrun += cnt;
+                        continue;
+                    }
+                    // (a lane with two windows in the row, or a list about to overflow: one by one)
                     while (who != 0) {
                         const uint32_t l = uint32_t(__builtin_ctzll(who));
-                        flag(r, l, __builtin_amdgcn_readlane(zr, l));
+                        flag(r, l, __builtin_amdgcn_readlane(keep, l));
                         who &= who - 1;
                     }
                 }
