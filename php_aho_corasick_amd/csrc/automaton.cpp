@@ -905,8 +905,10 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
         // instead of 22 %, i.e. 2.3 x fewer probes of the fingerprint table, which is what bounds the filter (L2 request
         // rate).  The chosen offset travels in the pair record (verification) and the run of a hit window becomes
         // [w + q - 1, w + Lmax): a pattern anchored at w ends there whatever its offset.
-        auto choose_offsets = [&](uint32_t mul_) {
-            constexpr uint32_t kBits = 1u << 20;
+        // (log2_bits: 20, the bitmap the kernel has; `dry`: only count the bits a cover over a bitmap of another size would set --
+        // ACMI_COVER_SWEEP with ACMI_BUILD_TRACE, the table of DESIGN 8 item 7)
+        auto choose_offsets = [&](uint32_t mul_, uint32_t log2_bits = 20u, bool dry = false) {
+            const uint32_t kBits = 1u << log2_bits;
             std::vector<uint32_t> pair_begin{0}, cand_bit;
             std::vector<uint8_t> cand_off;
             std::vector<uint32_t> pair_id;  // pattern * 4 + class
@@ -921,7 +923,7 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
                     for (uint32_t o = a; o + q <= m.length && o <= 252u; o += 4) {
                         uint32_t words[4] = {0, 0, 0, 0};
                         std::memcpy(words, pattern_bytes_.data() + m.byte_off + o, q);
-                        cand_bit.push_back(anchor_hash(words, q / 4, mul_) >> 12);
+                        cand_bit.push_back(anchor_hash(words, q / 4, mul_) >> (32u - log2_bits));
                         cand_off.push_back(uint8_t(o));
                     }
                     pair_begin.push_back(uint32_t(cand_bit.size()));
@@ -963,6 +965,13 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
                 std::vector<uint32_t>().swap(queue[c]);
             }
             lap("    greedy");
+            if (dry) {
+                uint32_t chosen = 0;
+                for (uint32_t b = 0; b < kBits; ++b) chosen += bit_chosen[b];
+                std::fprintf(stderr, "[acmi build] cover over 2^%u bits: %u bits set = %.2f %% of the bitmap (what passes of random windows), %u (pattern, class) pairs\n",
+                             log2_bits, chosen, 100.0 * double(chosen) / double(kBits), n_pairs);
+                return;
+            }
             for (uint32_t pr = 0; pr < n_pairs; ++pr)
                 for (uint32_t c = pair_begin[pr]; c < pair_begin[pr + 1]; ++c)
                     if (bit_chosen[cand_bit[c]]) { fa.anchor_offsets[pair_id[pr]] = cand_off[c]; break; }
@@ -1046,6 +1055,8 @@ bool Automaton::finalize(const BuildOptions &opt, std::string *error, const Buil
                         if (attempt) mul = mul * 0x2545F491u + 0x6B43A9B5u;
                         mul = (mul | 1u) & 0xFFFFFFu;
                         if (opt.anchor_choice != 0) {
+                            if (trace && std::getenv("ACMI_COVER_SWEEP") != nullptr)
+                                for (uint32_t lb = 18; lb <= 22; ++lb) choose_offsets(mul, lb, true);
                             choose_offsets(mul);
                             lap("anchor window choice");
                             build_keys();
