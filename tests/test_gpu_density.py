@@ -156,3 +156,33 @@ def test_cfg3_dense_candidates_against_the_oracle(per_8k, hay_len):
             p, r = device_match(res, sub, find_all)
             assert np.array_equal(p, pe1) and np.array_equal(r, re1)
         api.ahocorasick_deinit(res)
+
+
+def test_bounded_result_memory_with_dense_candidates():
+    """"max_result_bytes" (config 5's overflow -> drain -> resume) on text with many matches behind the filter: the segments the
+    device-resident entry hands out -- through window lists that grow, k_runs_wave and k_expand_dense, which must not write past
+    the cap -- concatenate to the oracle's array."""
+    import torch
+    from php_aho_corasick_amd import batch
+    base = synth.density_set("headline")
+    ds = synth.plant_density(base, 64, 8192)
+    n = 96
+    ds = synth.Dataset(ds.name, ds.pat_blob, ds.pat_off, ds.hay_blob[:int(ds.hay_off[n])], ds.hay_off[:n + 1])
+    pe, re_ = _oracle(ds)
+    per_hay = int(pe[-1]) // n + 8
+    res = resource_for(ds, kernel=2, small_path=0, max_result_bytes=max(4096, 10 * per_hay * 16))
+    d_blob = torch.from_numpy(ds.hay_blob).cuda()
+    d_off = torch.from_numpy(ds.hay_off.astype(np.int64)).cuda()
+    batch.bind_current_stream(res)
+    for _ in range(3):   # (the hand-over learns over the calls)
+        got, segs = [], 0
+        for first, k, total in batch.match_device_bounded(res, d_blob, d_off):
+            p, r = batch.result_numpy(res, k, total)
+            assert int(p[-1]) == total and k >= 1
+            r = r.copy()
+            r[:, 0] += first
+            got.append(r)
+            segs += 1
+        assert segs >= 8 and np.array_equal(np.concatenate(got), re_)
+    assert res.stat("kernel_used") == 2
+    api.ahocorasick_deinit(res)
