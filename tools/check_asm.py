@@ -39,6 +39,10 @@ HOT = [
     ("k_refill_wave<unsigned short, 1024u>", 0),                         # config 5
     ("k_walk_runs<unsigned short, 1, false>", 0),
     ("k_replace_emit", 0),
+    ("k_runs_wave<unsigned int, 0, true>", 0),        # config 3 with candidates by the dozen per item (round 6)
+    ("k_runs_wave<unsigned short, 1, false>", 0),     # ... the headline set
+    ("k_expand_dense", 0),
+    ("k_walk_win<unsigned int>", 0),                  # the table walk of big sets over the window table (round 6)
 ]
 
 
