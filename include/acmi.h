@@ -372,6 +372,10 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *                    trie depth <= 2 two bytes past the window start: 0 = off, 1 (default) = when some 3-gram
  *                    over the patterns' first-byte alphabet is not a trie path (else it cannot fire on
  *                    in-alphabet text), 2 = always                                        [any time]
+ *   "win_table"      the two-byte window table of the whole-item walk (kernel 4; k_walk_win): trie depth <= 2 decided in LDS from the last
+ *                    two text bytes, for sets whose shortest pattern is >= 3 B: -1 (default) for compact automata (sets far too
+ *                    big for the LDS), 0 never, 1 whenever the shortest pattern allows ("win_table")   [before finalize]
+ *   "win_walk"       0: kernel 4 walks the tables (k_walk_items) although the set has the window table; 1 (default)   [any time]
  *   "relist"         1 (default): a batch in which a work item's list of candidate windows overflowed while lists can still grow is
  *                    run again with the lists (and slabs, item size) the scan's own count asks for, instead of walking such items
  *                    whole through the tables; 0 = walk them at once ("relist_reruns")                    [any time]
@@ -401,7 +405,10 @@ int acmi_set_option(acmi_handle *h, const char *key, int64_t value);
 /* Numeric facts about the automaton and the last match call, e.g. "states",
  * "hot_states", "columns", "entry_bytes", "lds_image_bytes", "table_bytes",
  * "max_pattern_length", "items", "overflow_items", "walked_bytes", "fallback_bytes", "kernel_used" (0, 1, 2, 4 as the
- * "kernel" option; 5 = the one-launch small-batch path), "anchor_variant" (the k_scan_anchor template the last batch ran:
+ * "kernel" option; 5 = the one-launch small-batch path), "busy_items" / "max_windows" / "serial_items" / "wave_runs_used" /
+ * "relist_reruns" / "anchor_chunk_shift" (the filter's hand-over on the last batch: work items with more than a few candidate
+ * windows, the longest window list, items k_runs_wave handed to one lane, whether it ran, batches run again for longer lists,
+ * the learned shrink of the filter's work items), "win_table" (1: the set has the two-byte window table), "anchor_variant" (the k_scan_anchor template the last batch ran:
  * window dwords in bits 0-2 | 8 big set (LDS bitmap + L2 table) | 16 short-row variant | 32 tiny-item variant | 64 windows
  * at every byte offset | 128 its many-hits variant | 256 two-slot buckets; 0 = another kernel), "tiny_waves" (wave batches that took the tiny-item path), "scan_ms",
  * "total_ms". */
