@@ -611,7 +611,7 @@ static int apply_option(acmi_handle *h, const std::string &k, int64_t value) {
             h->part_kernel = int(value);
             if (h->is_part && h->aut.accepted_count() && h->aut.flat().max_pattern_length < 7 && h->aut.finalized()) return apply_option(h, "kernel", value < 0 ? 3 : value);
         } else if (k == "tile_w") {   // k_walk_tiles: bytes per lane (0: automatic)
-            if (value != 0 && value != 16 && value != 32 && value != 64) return ACMI_E_ARG;
+            if (value != 0 && value != 16 && value != 32 && value != 64 && value != 128) return ACMI_E_ARG;
             h->tile_w = int(value);
         } else if (k == "tile_p") {   // k_walk_tiles: lanes per work item (0: automatic)
             if (value < 0 || value > 64) return ACMI_E_ARG;

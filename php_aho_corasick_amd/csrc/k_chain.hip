@@ -51,42 +51,70 @@ struct ChainArgs {
 };
 
 struct ChainLds {
-    const uint8_t *img;       // rows at 0
-    uint32_t n_dense;
-    uint32_t rec_base;        // rec_off - 4 x n_dense: record of index e at img + rec_base + 4 e
+    const uint8_t *img;       // ALLD: rows at 0
     uint32_t row_bytes;
+    uint32_t rec_at;          // !ALLD: LDS offset of the records, one per index (D states too)
     const uint8_t *cnt;       // min(records, 255) of the indices a row can lead to
-    const uint16_t *cls;      // byte -> 2 x class (TABLE mode), else null
+    const uint16_t *cls;      // ALLD: byte -> 2 x class (TABLE mode), else null
 };
 
+// The LDS image of the walk (!ALLD), made from the automaton's image (automaton.hpp ChainImage) as the workgroup stages it:
+//   [byte -> class, a byte each (TABLE mode: 256 B at offset 0)] [rows of the D states] [a record per INDEX] [count bytes]
+// A record's low half is not the failure state's index but where that state's row lies -- its byte offset from the rows' start
+// (ROW16: the rows end below 64 KiB) or half of it -- and a D state has a record too, naming its own row, with the key no class
+// has.  A step is then the same five operations whatever the state: `row = record.lo + class` (one v_add_u32_sdwa: a halfword
+// and a byte selected in the instruction), `hit = record.key == class` (one v_cmp_eq_u32_sdwa), and the three selects -- round 5
+// looked up "D state?" (a compare), chose between the state and its record's failure index (a select), and multiplied by the row
+// length: 13.5 VALU operations per byte where this has 8, in a kernel that VALU issue bounds.  The price: 4 bytes of
+// LDS per D state (the headline set: 141.6 -> 157.3 KB), and rows that end below 128 KiB.
+template <int MODE>
+struct ChainLayout {
+    static constexpr uint32_t rows_at = MODE == 0 ? 256u : 0u;
+    uint32_t rec_at, cnt_at, total;
+    bool row16, ok;
+};
+template <int MODE>
+__host__ __device__ __forceinline__ ChainLayout<MODE> chain_layout(uint32_t n_dense, uint32_t n_index, uint32_t row_bytes, uint32_t cnt_n) {
+    ChainLayout<MODE> Y;
+    const uint32_t rows_end = n_dense * row_bytes;
+    Y.rec_at = ChainLayout<MODE>::rows_at + ((rows_end + 15u) & ~15u);
+    Y.cnt_at = Y.rec_at + 4u * n_index;
+    Y.total = (Y.cnt_at + cnt_n + 15u) & ~15u;
+    Y.row16 = rows_end <= 65536u;
+    Y.ok = rows_end <= 131072u && Y.total <= 160u * 1024u;
+    return Y;
+}
+
+template <int SEL>   // byte SEL of a dword of four classes; 4: the dword is the class
+__device__ __forceinline__ uint32_t chain_class(uint32_t c4) { return SEL == 4 ? c4 : (c4 >> (8 * SEL)) & 0xffu; }
+
 // One transition of two independent walks: their reads issued together (the records', then the rows'), so that one's LDS round
-// trips lie under the other's.  `ca`, `cz` = 2 x class of the bytes.  Through `ea`, `ez` the next indices; `ua`, `uz` negative: that
-// state is final (`ha`, `hz`: it was entered along its chain, bits 24..28 are min(its records, 31)).
-template <bool ALLD>
-__device__ __forceinline__ void chain_step2(const ChainLds &L, uint32_t &ea, uint32_t &ez, uint32_t ca, uint32_t cz, uint32_t &ua, uint32_t &uz, bool &ha, bool &hz) {
+// trips lie under the other's.  `ca`, `cz`: the bytes' classes (ROW16: twice the class = the column's byte offset), byte SEL of
+// them.  Through `ea`, `ez` the next indices; `ua`, `uz` negative: that state is final (bits 24..28 are min(its records, 31) when
+// it was entered along its chain, 31 -- "look it up" -- when a row led to it).
+template <bool ALLD, bool ROW16, uint32_t ROWS_AT, int SEL>
+__device__ __forceinline__ void chain_step2(const ChainLds &L, uint32_t &ea, uint32_t &ez, uint32_t ca, uint32_t cz, uint32_t &ua, uint32_t &uz) {
+    typedef const __attribute__((address_space(3))) int16_t *RowPtr;
+    typedef const __attribute__((address_space(3))) uint32_t *RecPtr;
+    const uint32_t ka = chain_class<SEL>(ca), kz = chain_class<SEL>(cz);
     if constexpr (ALLD) {   // (every state has its row: one read, no record, no chain)
         uint32_t aa, az;
-        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(aa) : "v"(ea), "s"(L.row_bytes), "v"(ca));
-        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(az) : "v"(ez), "s"(L.row_bytes), "v"(cz));
-        ua = uint32_t(int32_t(*reinterpret_cast<const __attribute__((address_space(3))) int16_t *>(aa)));
-        uz = uint32_t(int32_t(*reinterpret_cast<const __attribute__((address_space(3))) int16_t *>(az)));
-        ha = hz = false;
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(aa) : "v"(ea), "s"(L.row_bytes), "v"(ka));
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(az) : "v"(ez), "s"(L.row_bytes), "v"(kz));
+        ua = uint32_t(int32_t(*reinterpret_cast<RowPtr>(aa)));
+        uz = uint32_t(int32_t(*reinterpret_cast<RowPtr>(az)));
         ea = ua & 0x7FFFu;
         ez = uz & 0x7FFFu;
         return;
     }
-    const uint32_t ra = *reinterpret_cast<const uint32_t *>(L.img + ((ea << 2) + L.rec_base));
-    const uint32_t rz = *reinterpret_cast<const uint32_t *>(L.img + ((ez << 2) + L.rec_base));
-    const bool da = ea < L.n_dense, dz = ez < L.n_dense;
-    const uint32_t fa = da ? ea : (ra & 0xFFFFu), fz = dz ? ez : (rz & 0xFFFFu);
-    uint32_t aa, az;
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(aa) : "v"(fa), "s"(L.row_bytes), "v"(ca));
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(az) : "v"(fz), "s"(L.row_bytes), "v"(cz));
+    const uint32_t ra = *reinterpret_cast<RecPtr>((ea << 2) + L.rec_at);
+    const uint32_t rz = *reinterpret_cast<RecPtr>((ez << 2) + L.rec_at);
+    uint32_t aa = (ra & 0xFFFFu) + ka, az = (rz & 0xFFFFu) + kz;
+    if constexpr (!ROW16) { aa <<= 1; az <<= 1; }
     // (rows read sign-extended: a final target is negative, like a record whose child is final -- one test for both)
-    const uint32_t ta = uint32_t(int32_t(*reinterpret_cast<const __attribute__((address_space(3))) int16_t *>(aa)));
-    const uint32_t tz = uint32_t(int32_t(*reinterpret_cast<const __attribute__((address_space(3))) int16_t *>(az)));
-    ha = !da && __builtin_amdgcn_ubfe(ra, 16, 8) == ca;   // (a record's key is the column offset; 0xFF -- no child -- is odd)
-    hz = !dz && __builtin_amdgcn_ubfe(rz, 16, 8) == cz;
+    const uint32_t ta = uint32_t(int32_t(*reinterpret_cast<RowPtr>(aa + ROWS_AT)));
+    const uint32_t tz = uint32_t(int32_t(*reinterpret_cast<RowPtr>(az + ROWS_AT)));
+    const bool ha = ((ra >> 16) & 0xFFu) == ka, hz = ((rz >> 16) & 0xFFu) == kz;   // (0xFF -- no child, or a D state -- is no class)
     ua = ha ? ra : ta;
     uz = hz ? rz : tz;
     ea = ha ? ea + 1u : (ta & 0x7FFFu);
@@ -146,31 +174,63 @@ __device__ __forceinline__ uint32_t chain_count(const DevAutomaton &A, uint32_t 
     return c < 255u ? c : A.out_count[A.chain_orig[e]];
 }
 
-template <int MODE, bool ALLD>
+template <int MODE, bool ALLD, bool ROW16>
 __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, BatchArgs B, ChainArgs T) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint64_t total_items = B.item_base[B.n_haystacks];
-    // LDS: [image: rows | records | counts] [512 B byte classes (TABLE mode)]
-    // (the image at offset 0 -- no static shared variable in front of it: a row's address is then the multiply-add's result itself)
-    const uint32_t img_bytes = (A.chain_img_bytes + 15u) & ~15u;
-    // (chain_step2 reads the rows at the multiply-add's result itself: the dynamic LDS begins at 0 when nothing static precedes it)
+    // (the image at offset 0 -- no static shared variable in front of it: chain_step2 reads at the offsets it computes)
     if (uint32_t(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint8_t *)smem)) != 0u) __builtin_trap();
-    {
+    ChainLds L;
+    L.img = smem;
+    L.row_bytes = A.n_columns * 2u;
+    L.rec_at = 0;
+    L.cls = nullptr;
+    uint32_t cls_at = 0;   // LDS offset of the byte classes (TABLE mode)
+    constexpr uint32_t kRowsAt = ALLD ? 0u : ChainLayout<MODE>::rows_at;
+    if constexpr (ALLD) {
+        // LDS: [image: rows | counts] [512 B byte classes (TABLE mode)]
+        const uint32_t img_bytes = (A.chain_img_bytes + 15u) & ~15u;
         const uint4 *src = reinterpret_cast<const uint4 *>(A.chain_img);   // (the allocation has 16 bytes of slack)
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
         for (uint32_t t = threadIdx.x; t < (img_bytes >> 4); t += kChainThreads) dst[t] = src[t];
         if (MODE == 0 && threadIdx.x < 256) reinterpret_cast<uint16_t *>(smem + img_bytes)[threadIdx.x] = A.class_off[threadIdx.x];
-        __syncthreads();
+        L.cnt = smem + A.chain_cnt_off;
+        L.cls = (MODE == 0) ? reinterpret_cast<const uint16_t *>(smem + img_bytes) : nullptr;
+        cls_at = img_bytes;
+    } else {
+        // (chain_layout; the records are translated from the image's {failure index | 2 x class | ...} as they are staged)
+        const ChainLayout<MODE> Y = chain_layout<MODE>(A.chain_dense, A.chain_index, L.row_bytes, A.chain_cnt_n);
+        const uint32_t rows_end = A.chain_dense * L.row_bytes;
+        {
+            const uint4 *src = reinterpret_cast<const uint4 *>(A.chain_img);
+            uint4 *dst = reinterpret_cast<uint4 *>(smem + kRowsAt);
+            for (uint32_t t = threadIdx.x; t < ((rows_end + 15u) >> 4); t += kChainThreads) dst[t] = src[t];
+        }
+        {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(A.chain_img + A.chain_rec_off);
+            uint32_t *dst = reinterpret_cast<uint32_t *>(smem + Y.rec_at);
+            for (uint32_t e = threadIdx.x; e < A.chain_index; e += kChainThreads) {
+                uint32_t f = e, hi = 0x00FF0000u;   // a D state: its own row, the key no class has
+                if (e >= A.chain_dense) {
+                    const uint32_t r = src[e - A.chain_dense];
+                    const uint32_t key2 = (r >> 16) & 0xFFu;
+                    f = r & 0xFFFFu;
+                    hi = (r & 0xFF000000u) | (key2 == 0xFFu || ROW16 ? key2 : key2 >> 1) << 16;
+                }
+                dst[e] = hi | (ROW16 ? f * L.row_bytes : (f * L.row_bytes) >> 1);
+            }
+        }
+        {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(A.chain_img + A.chain_cnt_off);   // (4-byte aligned, like the image's end)
+            uint32_t *dst = reinterpret_cast<uint32_t *>(smem + Y.cnt_at);
+            for (uint32_t t = threadIdx.x; t < ((A.chain_cnt_n + 3u) >> 2); t += kChainThreads) dst[t] = src[t];
+        }
+        if (MODE == 0 && threadIdx.x < 256) smem[threadIdx.x] = uint8_t(ROW16 ? A.class_off[threadIdx.x] : A.class_off[threadIdx.x] >> 1);
+        L.rec_at = Y.rec_at;
+        L.cnt = smem + Y.cnt_at;
     }
-    ChainLds L;
-    L.img = smem;
-    L.n_dense = A.chain_dense;
-    L.rec_base = A.chain_rec_off - 4u * A.chain_dense;
-    L.row_bytes = A.n_columns * 2u;
-    L.cnt = smem + A.chain_cnt_off;
-    L.cls = (MODE == 0) ? reinterpret_cast<const uint16_t *>(smem + img_bytes) : nullptr;
-    const uint32_t cls_at = img_bytes;   // LDS offset of the byte classes (the dynamic LDS begins at 0)
+    __syncthreads();
     // A lane walks TWO pieces at once, 2 lane and 2 lane + 1 of the wave's 128: a step is two dependent LDS reads, and with the
     // whole LDS taken by the image a CU runs one workgroup -- four waves per SIMD, too few to hide them (one piece per lane: 55 % of
     // the VALU cycles used).  The two walks are independent: their reads are issued together.  A lane's records -- the first
@@ -197,62 +257,66 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
         uint32_t oa = off_a0, oz = off_z0;   // where their next events go
         const uint32_t my_blocks = pa.nblk > pz.nblk ? pa.nblk : pz.nblk;
         if (__any(my_blocks != 0u) && !(T.debug & 2u)) {
-            // An event inside the walk is ONE store: {index, what the parent's record says about its records (entered along the
-            // chain; else 0), byte} to the piece's list.  What it stands for is worked out behind the walk, where a lane runs over
-            // its own events only -- in here the whole wave pays for every step in which ANY lane has one.
-            auto event = [&](uint32_t e, uint32_t &off, uint32_t jj, uint32_t u) __attribute__((always_inline)) {
-                // (bits 24..28: the parent record's count of the child's records; a row entry read as a negative halfword has 31 there,
-                // like a saturated count: "look it up")
-                *reinterpret_cast<__attribute__((address_space(1))) uint32_t *>(reinterpret_cast<uintptr_t>(spill) + off) = (u & 0x1F000000u) | e | jj << 15;
-                off += 256u;
+            // An event inside the walk is ONE store, {index, byte}, to the piece's list, and the list's offset bumped in place: two
+            // VALU operations.  What it stands for is worked out behind the walk, where a lane runs over its own events only -- in
+            // here the whole wave pays for every step in which ANY lane has one.  (Round 5 carried the parent record's count code
+            // along: an and, a three-way or, and the bump through a copy -- four operations at 0.4-0.9 of the steps; the code is
+            // in LDS where the drain can read it, records_of.)
+            auto event = [&](uint32_t e, uint32_t &off, uint32_t jj) __attribute__((always_inline)) {
+                *reinterpret_cast<__attribute__((address_space(1))) uint32_t *>(reinterpret_cast<uintptr_t>(spill) + off) = e | jj << 15;
+                asm volatile("v_add_u32 %0, 0x100, %0" : "+v"(off));   // (in place: hipcc bumped a copy and moved it back)
             };
             // four steps of both pieces; the column offsets of a dword's four bytes are worked out together (SWAR3: a handful of
             // operations for all four; TABLE: four independent LDS reads).  CHECKED: the range test of a block that does not lie
             // inside every piece's own range; WARM: the first block, in which a walk begins (the state is the root before).
             // the column offsets of a dword's bytes: SWAR3 a handful of operations for all four; TABLE an LDS read per byte, requested a
             // byte ahead of its step (all eight of a dword pair up front cost the two registers that spilled into this loop)
-            typedef const __attribute__((address_space(3))) uint16_t *ClsPtr;
             auto cls_of = [&](uint32_t wd, uint32_t i) __attribute__((always_inline)) -> uint32_t {
                 // (explicitly LDS reads at the table's offset: through class_offset's generic pointer hipcc emitted flat_load_ushort
                 // behind two branches -- a flat load counts on vmcnt too: every byte's class waited for the text requested four
                 // blocks ahead and for the event stores)
-                const uint32_t b2 = i == 0u ? (wd & 0xffu) << 1 : (wd >> (8u * i - 1u)) & 0x1feu;
-                return *reinterpret_cast<ClsPtr>(cls_at + b2);
+                if constexpr (ALLD) {
+                    const uint32_t b2 = i == 0u ? (wd & 0xffu) << 1 : (wd >> (8u * i - 1u)) & 0x1feu;
+                    return *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>(cls_at + b2);
+                } else {   // (a byte per byte value at LDS offset 0: the byte is the address)
+                    return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((wd >> (8u * i)) & 0xffu);
+                }
             };
-            auto dword = [&](uint32_t wa, uint32_t wz, uint32_t jj, auto checked, auto warm) __attribute__((always_inline)) {
-                constexpr bool C = decltype(checked)::value, W0 = decltype(warm)::value;
+            // QUIET: a first block in which no walk of the wave reports and every walk begins at byte 1 (or not at all: such a lane
+            // is put back to the root behind the block) -- no range test, no event test, no reset; SKIP0: its first dword, less byte 0
+            auto dword = [&](uint32_t wa, uint32_t wz, uint32_t jj, auto checked, auto warm, auto quiet, auto skip0) __attribute__((always_inline)) {
+                constexpr bool C = decltype(checked)::value, W0 = decltype(warm)::value, Q = decltype(quiet)::value, S0 = decltype(skip0)::value;
                 uint32_t c4a = 0, c4z = 0, na_c = 0, nz_c = 0;
                 if constexpr (MODE == 1) {
-                    c4a = swar_columns<uint16_t>(A, wa);
+                    c4a = swar_columns<uint16_t>(A, wa);   // (bytes of 2 x class: even, so that a shift leaves the classes)
                     c4z = swar_columns<uint16_t>(A, wz);
+                    if constexpr (!ALLD && !ROW16) { c4a >>= 1; c4z >>= 1; }
                 } else {
-                    na_c = cls_of(wa, 0u);
-                    nz_c = cls_of(wz, 0u);
+                    na_c = cls_of(wa, S0 ? 1u : 0u);
+                    nz_c = cls_of(wz, S0 ? 1u : 0u);
                 }
-#pragma unroll
-                for (uint32_t i = 0; i < 4u; ++i) {
+                auto one = [&](auto sel) __attribute__((always_inline)) {
+                    constexpr uint32_t i = decltype(sel)::value;
+                    if constexpr (S0 && i == 0u) return;
                     const uint32_t j = jj + i;
-                    uint32_t ca_i, cz_i;
-                    if constexpr (MODE == 1) {
-                        ca_i = (c4a >> (8u * i)) & 0xffu;
-                        cz_i = (c4z >> (8u * i)) & 0xffu;
-                    } else {
-                        ca_i = na_c;
-                        cz_i = nz_c;
-                        if (i < 3u) { na_c = cls_of(wa, i + 1u); nz_c = cls_of(wz, i + 1u); }
-                    }
                     uint32_t ua, uz;
-                    bool ha, hz;
-                    chain_step2<ALLD>(L, ea, ez, ca_i, cz_i, ua, uz, ha, hz);
+                    if constexpr (MODE == 1) {
+                        chain_step2<ALLD, ROW16, kRowsAt, int(i)>(L, ea, ez, c4a, c4z, ua, uz);
+                    } else {
+                        const uint32_t ca_i = na_c, cz_i = nz_c;
+                        if constexpr (i < 3u) { na_c = cls_of(wa, i + 1u); nz_c = cls_of(wz, i + 1u); }
+                        chain_step2<ALLD, ROW16, kRowsAt, 4>(L, ea, ez, ca_i, cz_i, ua, uz);
+                    }
                     if (W0) { ea = j < pa.start_j ? 0u : ea; ez = j < pz.start_j ? 0u : ez; }
+                    if constexpr (Q) return;
                     // (rep_lo >= start_j: nothing before a walk's first byte reports)
                     const bool va = int32_t(ua) < 0 && (!C || j - pa.rep_lo < pa.rep_len);
                     const bool vz = int32_t(uz) < 0 && (!C || j - pz.rep_lo < pz.rep_len);
-                    if (va || vz) {
-                        if (va) event(ea, oa, j, ua);
-                        if (vz) event(ez, oz, j, uz);
-                    }
-                }
+                    if (va) event(ea, oa, j);
+                    if (vz) event(ez, oz, j);
+                };
+                one(std::integral_constant<uint32_t, 0u>{}); one(std::integral_constant<uint32_t, 1u>{});
+                one(std::integral_constant<uint32_t, 2u>{}); one(std::integral_constant<uint32_t, 3u>{});
             };
             // (explicitly global loads: through a generic pointer hipcc emits flat_load, which counts on the LDS counter too -- every
             // wait for a state's record then also waited for the text requested four blocks ahead)
@@ -266,9 +330,25 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
             uint4 a0 = block(qa, 1u < la ? 1u : la), a1 = block(qa, 2u < la ? 2u : la), a2 = block(qa, 3u < la ? 3u : la), a3 = block(qa, 4u < la ? 4u : la);
             uint4 z0 = block(qz, 1u < lz ? 1u : lz), z1 = block(qz, 2u < lz ? 2u : lz), z2 = block(qz, 3u < lz ? 3u : lz), z3 = block(qz, 4u < lz ? 4u : lz);
             const uint32_t sj = pa.nblk ? pa.start_j : 16u, sk = pz.nblk ? pz.start_j : 16u;
-            if (__any(sj < 16u || sk < 16u)) {   // (else every walk of the wave begins on a block boundary: nothing to do in block 0)
-                dword(fa.x, fz.x, 0u, std::true_type{}, std::true_type{}); dword(fa.y, fz.y, 4u, std::true_type{}, std::true_type{});
-                dword(fa.z, fz.z, 8u, std::true_type{}, std::true_type{}); dword(fa.w, fz.w, 12u, std::true_type{}, std::true_type{});
+            constexpr std::true_type yes{};
+            constexpr std::false_type no{};
+            // (the usual tile: Lmax - 1 <= 15 bytes of warm-up in front of pieces that begin on block boundaries -- fifteen steps from
+            // the root for every lane, nothing to test: 26 -> 18 VALU operations per step of the pair in a sixth of the tile's steps)
+            const bool silent = (!pa.nblk || pa.rep_lo >= 16u) && (!pz.nblk || pz.rep_lo >= 16u);   // nothing reports in block 0
+            const bool plain = silent && (sj == 1u || sj >= 16u) && (sk == 1u || sk >= 16u);
+            if (__all(plain)) {
+                if (__any(sj < 16u || sk < 16u)) {
+                    dword(fa.x, fz.x, 0u, no, no, yes, yes); dword(fa.y, fz.y, 4u, no, no, yes, no);
+                    dword(fa.z, fz.z, 8u, no, no, yes, no); dword(fa.w, fz.w, 12u, no, no, yes, no);
+                    ea = sj >= 16u ? 0u : ea;
+                    ez = sk >= 16u ? 0u : ez;
+                }
+            } else if (__all(silent)) {   // (shorter patterns: the walks begin further inside the block -- the reset per step, no tests)
+                dword(fa.x, fz.x, 0u, no, yes, yes, no); dword(fa.y, fz.y, 4u, no, yes, yes, no);
+                dword(fa.z, fz.z, 8u, no, yes, yes, no); dword(fa.w, fz.w, 12u, no, yes, yes, no);
+            } else {   // (some walk begins inside the block, or reports in it)
+                dword(fa.x, fz.x, 0u, yes, yes, no, no); dword(fa.y, fz.y, 4u, yes, yes, no, no);
+                dword(fa.z, fz.z, 8u, yes, yes, no, no); dword(fa.w, fz.w, 12u, yes, yes, no, no);
             }
 #pragma unroll 1
             for (uint32_t k = 1u; __any(k < my_blocks); ++k) {   // (as many blocks as the wave's longest walk has: a ballot, not a reduction)
@@ -282,11 +362,11 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
                 // (a block that lies inside EVERY piece's own range -- all but the first and the last of a piece -- without the range test)
                 const bool full = j0 >= pa.rep_lo && j0 + 16u <= pa.rep_lo + pa.rep_len && j0 >= pz.rep_lo && j0 + 16u <= pz.rep_lo + pz.rep_len;
                 if (__all(full)) {
-                    dword(ca.x, cz.x, j0, std::false_type{}, std::false_type{}); dword(ca.y, cz.y, j0 + 4u, std::false_type{}, std::false_type{});
-                    dword(ca.z, cz.z, j0 + 8u, std::false_type{}, std::false_type{}); dword(ca.w, cz.w, j0 + 12u, std::false_type{}, std::false_type{});
+                    dword(ca.x, cz.x, j0, no, no, no, no); dword(ca.y, cz.y, j0 + 4u, no, no, no, no);
+                    dword(ca.z, cz.z, j0 + 8u, no, no, no, no); dword(ca.w, cz.w, j0 + 12u, no, no, no, no);
                 } else {
-                    dword(ca.x, cz.x, j0, std::true_type{}, std::false_type{}); dword(ca.y, cz.y, j0 + 4u, std::true_type{}, std::false_type{});
-                    dword(ca.z, cz.z, j0 + 8u, std::true_type{}, std::false_type{}); dword(ca.w, cz.w, j0 + 12u, std::true_type{}, std::false_type{});
+                    dword(ca.x, cz.x, j0, yes, no, no, no); dword(ca.y, cz.y, j0 + 4u, yes, no, no, no);
+                    dword(ca.z, cz.z, j0 + 8u, yes, no, no, no); dword(ca.w, cz.w, j0 + 12u, yes, no, no, no);
                 }
                 asm volatile("; acmi-hot-end");
             }
@@ -296,12 +376,17 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
-        // records of an event: five bits of the parent's record (entered along the chain), else the count byte of a state a row led
-        // to -- if it has one: a row may also lead INTO a chain (the child of a C state on the row's failure path) -- else, and for
-        // saturated counts, the tables in global memory
+        // records of an event: the five bits the PARENT's record has for its child (a C state's child is the next index: the
+        // insides and ends of the patterns -- where a planted occurrence ends) unless they are saturated; else the count byte of
+        // a state a row can lead to -- if it has one: a row may also lead INTO a chain (the child of a C state on the row's failure
+        // path) -- else, and for saturated counts, the tables in global memory
         auto records_of = [&](uint32_t ent) __attribute__((always_inline)) -> uint32_t {
-            const uint32_t idx = ent & 0x7FFFu, code = (ent >> 24) & 31u;
-            if (code != 31u) return code;
+            const uint32_t idx = ent & 0x7FFFu;
+            if constexpr (!ALLD) {
+                const uint32_t r = lds_read<uint32_t>(smem, L.rec_at + 4u * (idx - 1u));   // (the root, index 0, is no event)
+                const uint32_t code = (r >> 24) & 31u;
+                if (((r >> 16) & 0xFFu) != 0xFFu && code != 31u) return code;   // (a D state's record, a chain's last: no child)
+            }
             if (idx < cnt_n) {
                 const uint32_t c = L.cnt[idx];
                 if (c != 255u) return c;
@@ -479,11 +564,11 @@ __global__ __launch_bounds__(kEmitThreads) void k_chain_emit(DevAutomaton A, Bat
     }
 }
 
-// Does this automaton have the image, and does the kernel's LDS layout hold it?
+// Does this automaton have the image, and does the kernel's LDS layout hold it?  (TABLE mode's layout is the bigger one by 256 bytes)
 bool chain_walk_ok(const DevAutomaton &A) {
     if (A.chain_img == nullptr || A.chain_head == nullptr || A.chain_frank == nullptr) return false;
-    const uint32_t img = (A.chain_img_bytes + 15u) & ~15u;
-    return img + 512u <= 160u * 1024u;
+    if (A.chain_dense == A.chain_index) return ((A.chain_img_bytes + 15u) & ~15u) + 512u <= 160u * 1024u;
+    return chain_layout<0>(A.chain_dense, A.chain_index, A.n_columns * 2u, A.chain_cnt_n).ok;
 }
 
 // ("reserve_cus": the walk leaves that many compute units to a collective's kernels, like the persistent scan kernels -- the logs
@@ -518,8 +603,10 @@ hipError_t launch_walk_chain(const DevAutomaton &A, const BatchArgs &B, uint64_t
     ChainArgs T = chain_args(A, B, W, P, C);
     static const uint32_t debug = [] { const char *e = std::getenv("ACMI_CHAIN_DEBUG"); return e ? uint32_t(std::atoi(e)) : 0u; }();
     T.debug = debug;
-    const uint32_t img = (A.chain_img_bytes + 15u) & ~15u;
-    const uint32_t lds = img + (class_mode == 0 ? 512u : 0u);
+    const bool alld = A.chain_dense == A.chain_index;
+    const ChainLayout<0> Y0 = chain_layout<0>(A.chain_dense, A.chain_index, A.n_columns * 2u, A.chain_cnt_n);
+    const ChainLayout<1> Y1 = chain_layout<1>(A.chain_dense, A.chain_index, A.n_columns * 2u, A.chain_cnt_n);
+    const uint32_t lds = alld ? ((A.chain_img_bytes + 15u) & ~15u) + (class_mode == 0 ? 512u : 0u) : class_mode == 0 ? Y0.total : Y1.total;
     // (the logs are per wave of THIS grid -- k_chain_emit finds a tile's by t % n_waves)
     auto go = [&](auto fn) {
         hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), uint32_t(lds));
@@ -527,9 +614,11 @@ hipError_t launch_walk_chain(const DevAutomaton &A, const BatchArgs &B, uint64_t
         hipLaunchKernelGGL(fn, dim3(chain_grid(B.reserve_cus)), dim3(kChainThreads), lds, st, A, B, T);
         return hipGetLastError();
     };
-    const bool alld = A.chain_dense == A.chain_index;
-    if (alld) return class_mode == 1 ? go(k_walk_chain<1, true>) : go(k_walk_chain<0, true>);
-    return class_mode == 1 ? go(k_walk_chain<1, false>) : go(k_walk_chain<0, false>);
+    if (alld) return class_mode == 1 ? go(k_walk_chain<1, true, true>) : go(k_walk_chain<0, true, true>);
+    // ACMI_CHAIN_ROW16=0 (measurements): the halved row offsets where the whole ones fit
+    static const bool no_row16 = [] { const char *e = std::getenv("ACMI_CHAIN_ROW16"); return e && e[0] == '0'; }();
+    if (Y0.row16 && !no_row16) return class_mode == 1 ? go(k_walk_chain<1, false, true>) : go(k_walk_chain<0, false, true>);
+    return class_mode == 1 ? go(k_walk_chain<1, false, false>) : go(k_walk_chain<0, false, false>);
 }
 
 hipError_t launch_chain_emit(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, uint32_t W, uint32_t P, const ChainBuffers &C,
