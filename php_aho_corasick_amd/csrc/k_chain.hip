@@ -90,35 +90,74 @@ __device__ __forceinline__ uint32_t chain_class(uint32_t c4) { return SEL == 4 ?
 
 // One transition of two independent walks: their reads issued together (the records', then the rows'), so that one's LDS round
 // trips lie under the other's.  `ca`, `cz`: the bytes' classes (ROW16: twice the class = the column's byte offset), byte SEL of
-// them.  Through `ea`, `ez` the next indices; `ua`, `uz` negative: that state is final (bits 24..28 are min(its records, 31) when
-// it was entered along its chain, 31 -- "look it up" -- when a row led to it).
-template <bool ALLD, bool ROW16, uint32_t ROWS_AT, int SEL>
+// them.  Through `ea`, `ez` the next indices.
+// ALLD: `ua`, `uz` negative: the state ENTERED is final.  Else `ua`, `uz` are the records of the states the step LEAVES, negative
+// when that state is final: a record says so of its own state (set as the image is staged), the rows hold plain indices, and an
+// event is found one step late, when the state's record is read anyway -- no select of "record or row entry" for the flag and no
+// mask for the index: 6 VALU operations per byte and piece (lshl_add, add_sdwa, cmp_sdwa, add, cndmask; the event's compare).
+template <int SEL>
 __device__ __forceinline__ void chain_step2(const ChainLds &L, uint32_t &ea, uint32_t &ez, uint32_t ca, uint32_t cz, uint32_t &ua, uint32_t &uz) {
+    // ALLD: every state has its row -- one read, no record, no chain
     typedef const __attribute__((address_space(3))) int16_t *RowPtr;
-    typedef const __attribute__((address_space(3))) uint32_t *RecPtr;
     const uint32_t ka = chain_class<SEL>(ca), kz = chain_class<SEL>(cz);
-    if constexpr (ALLD) {   // (every state has its row: one read, no record, no chain)
-        uint32_t aa, az;
-        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(aa) : "v"(ea), "s"(L.row_bytes), "v"(ka));
-        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(az) : "v"(ez), "s"(L.row_bytes), "v"(kz));
-        ua = uint32_t(int32_t(*reinterpret_cast<RowPtr>(aa)));
-        uz = uint32_t(int32_t(*reinterpret_cast<RowPtr>(az)));
-        ea = ua & 0x7FFFu;
-        ez = uz & 0x7FFFu;
-        return;
-    }
-    const uint32_t ra = *reinterpret_cast<RecPtr>((ea << 2) + L.rec_at);
-    const uint32_t rz = *reinterpret_cast<RecPtr>((ez << 2) + L.rec_at);
-    uint32_t aa = (ra & 0xFFFFu) + ka, az = (rz & 0xFFFFu) + kz;
+    uint32_t aa, az;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(aa) : "v"(ea), "s"(L.row_bytes), "v"(ka));
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(az) : "v"(ez), "s"(L.row_bytes), "v"(kz));
+    ua = uint32_t(int32_t(*reinterpret_cast<RowPtr>(aa)));   // (sign-extended: a final target is negative)
+    uz = uint32_t(int32_t(*reinterpret_cast<RowPtr>(az)));
+    ea = ua & 0x7FFFu;
+    ez = uz & 0x7FFFu;
+}
+
+// The same for an image with records (!ALLD), in two halves so that the events of the states the step leaves are stored while the
+// rows' reads are under way: chain_read2 -> `ua`, `uz` the records of the states, `ta`, `tz` the row entries (requested);
+// chain_next2 -> the next indices.  The operand selections are spelled out: hipcc found `record.lo + class byte` and `record.key ==
+// class byte` as one SDWA operation each in a small test and in half of this kernel's instantiations, and shifts, masks and
+// three-input logic in the rest -- and it sank the second piece's row read into a branch on "no hit" (an exec mask, a jump, the
+// read issued only when the first had come back); as the asm's operand it is read whatever the keys say.
+#define ACMI_SEL(n) ((n) == 0 ? "BYTE_0" : (n) == 1 ? "BYTE_1" : (n) == 2 ? "BYTE_2" : (n) == 3 ? "BYTE_3" : "DWORD")
+template <int SEL>
+__device__ __forceinline__ uint32_t chain_row_of(uint32_t rec, uint32_t c) {   // record.lo + class
+    uint32_t r;
+    if constexpr (SEL == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:BYTE_0" : "=v"(r) : "v"(rec), "v"(c));
+    else if constexpr (SEL == 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:BYTE_1" : "=v"(r) : "v"(rec), "v"(c));
+    else if constexpr (SEL == 2) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:BYTE_2" : "=v"(r) : "v"(rec), "v"(c));
+    else if constexpr (SEL == 3) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:BYTE_3" : "=v"(r) : "v"(rec), "v"(c));
+    else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(r) : "v"(rec), "v"(c));
+    return r;
+}
+// e1 = record.key == class ? e1 : row entry (a halfword; two wait states between an SDWA compare's VCC and its reader)
+template <int SEL>
+__device__ __forceinline__ void chain_select(uint32_t &e1, uint32_t t, uint32_t rec, uint32_t c) {
+#define ACMI_SELECT(S) asm volatile("v_cmp_eq_u32_sdwa vcc, %2, %3 src0_sel:BYTE_2 src1_sel:" S "\n\ts_nop 1\n\t" \
+                                    "v_cndmask_b32_e32 %0, %1, %0, vcc" \
+                                    : "+v"(e1) : "v"(t), "v"(rec), "v"(c) : "vcc")
+    if constexpr (SEL == 0) ACMI_SELECT("BYTE_0");
+    else if constexpr (SEL == 1) ACMI_SELECT("BYTE_1");
+    else if constexpr (SEL == 2) ACMI_SELECT("BYTE_2");
+    else if constexpr (SEL == 3) ACMI_SELECT("BYTE_3");
+    else ACMI_SELECT("DWORD");
+#undef ACMI_SELECT
+}
+#undef ACMI_SEL
+template <bool ROW16, uint32_t ROWS_AT, int SEL>
+__device__ __forceinline__ void chain_read2(const ChainLds &L, uint32_t ea, uint32_t ez, uint32_t ca, uint32_t cz, uint32_t &ua, uint32_t &uz, uint32_t &ta, uint32_t &tz) {
+    typedef const __attribute__((address_space(3))) uint32_t *RecPtr;
+    typedef const __attribute__((address_space(3))) uint16_t *RowPtr;
+    ua = *reinterpret_cast<RecPtr>((ea << 2) + L.rec_at);
+    uz = *reinterpret_cast<RecPtr>((ez << 2) + L.rec_at);
+    __builtin_amdgcn_sched_barrier(0);   // (both records requested before either is waited for: the scheduler put the first's add in between)
+    uint32_t aa = chain_row_of<SEL>(ua, ca), az = chain_row_of<SEL>(uz, cz);
     if constexpr (!ROW16) { aa <<= 1; az <<= 1; }
-    // (rows read sign-extended: a final target is negative, like a record whose child is final -- one test for both)
-    const uint32_t ta = uint32_t(int32_t(*reinterpret_cast<RowPtr>(aa + ROWS_AT)));
-    const uint32_t tz = uint32_t(int32_t(*reinterpret_cast<RowPtr>(az + ROWS_AT)));
-    const bool ha = ((ra >> 16) & 0xFFu) == ka, hz = ((rz >> 16) & 0xFFu) == kz;   // (0xFF -- no child, or a D state -- is no class)
-    ua = ha ? ra : ta;
-    uz = hz ? rz : tz;
-    ea = ha ? ea + 1u : (ta & 0x7FFFu);
-    ez = hz ? ez + 1u : (tz & 0x7FFFu);
+    ta = *reinterpret_cast<RowPtr>(aa + ROWS_AT);
+    tz = *reinterpret_cast<RowPtr>(az + ROWS_AT);
+}
+template <int SEL>
+__device__ __forceinline__ void chain_next2(uint32_t &ea, uint32_t &ez, uint32_t ca, uint32_t cz, uint32_t ua, uint32_t uz, uint32_t ta, uint32_t tz) {
+    ++ea;
+    ++ez;
+    chain_select<SEL>(ea, ta, ua, ca);   // (0xFF -- no child, or a D state -- is no class)
+    chain_select<SEL>(ez, tz, uz, cz);
 }
 
 // One piece of a wave's 128 (k_walk_tiles' geometry): the first block it walks, where in it the walk begins, what reports.
@@ -205,7 +244,11 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
         {
             const uint4 *src = reinterpret_cast<const uint4 *>(A.chain_img);
             uint4 *dst = reinterpret_cast<uint4 *>(smem + kRowsAt);
-            for (uint32_t t = threadIdx.x; t < ((rows_end + 15u) >> 4); t += kChainThreads) dst[t] = src[t];
+            // (plain indices: whether a state is final its own record says)
+            for (uint32_t t = threadIdx.x; t < ((rows_end + 15u) >> 4); t += kChainThreads) {
+                const uint4 v = src[t];
+                dst[t] = make_uint4(v.x & 0x7FFF7FFFu, v.y & 0x7FFF7FFFu, v.z & 0x7FFF7FFFu, v.w & 0x7FFF7FFFu);
+            }
         }
         {
             const uint32_t *src = reinterpret_cast<const uint32_t *>(A.chain_img + A.chain_rec_off);
@@ -216,8 +259,9 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
                     const uint32_t r = src[e - A.chain_dense];
                     const uint32_t key2 = (r >> 16) & 0xFFu;
                     f = r & 0xFFFFu;
-                    hi = (r & 0xFF000000u) | (key2 == 0xFFu || ROW16 ? key2 : key2 >> 1) << 16;
+                    hi = (r & 0x1F000000u) | (key2 == 0xFFu || ROW16 ? key2 : key2 >> 1) << 16;   // (bits 24..28: the child's count code)
                 }
+                if (A.chain_frank[e] != 0xFFFFu) hi |= 0x80000000u;   // this state is final
                 dst[e] = hi | (ROW16 ? f * L.row_bytes : (f * L.row_bytes) >> 1);
             }
         }
@@ -284,8 +328,8 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
             };
             // QUIET: a first block in which no walk of the wave reports and every walk begins at byte 1 (or not at all: such a lane
             // is put back to the root behind the block) -- no range test, no event test, no reset; SKIP0: its first dword, less byte 0
-            auto dword = [&](uint32_t wa, uint32_t wz, uint32_t jj, auto checked, auto warm, auto quiet, auto skip0) __attribute__((always_inline)) {
-                constexpr bool C = decltype(checked)::value, W0 = decltype(warm)::value, Q = decltype(quiet)::value, S0 = decltype(skip0)::value;
+            auto dword = [&](uint32_t wa, uint32_t wz, uint32_t jj, auto checked, auto warm, auto quiet, auto skip0, auto first) __attribute__((always_inline)) {
+                constexpr bool C = decltype(checked)::value, W0 = decltype(warm)::value, Q = decltype(quiet)::value, S0 = decltype(skip0)::value, F = decltype(first)::value;
                 uint32_t c4a = 0, c4z = 0, na_c = 0, nz_c = 0;
                 if constexpr (MODE == 1) {
                     c4a = swar_columns<uint16_t>(A, wa);   // (bytes of 2 x class: even, so that a shift leaves the classes)
@@ -299,21 +343,39 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
                     constexpr uint32_t i = decltype(sel)::value;
                     if constexpr (S0 && i == 0u) return;
                     const uint32_t j = jj + i;
-                    uint32_t ua, uz;
-                    if constexpr (MODE == 1) {
-                        chain_step2<ALLD, ROW16, kRowsAt, int(i)>(L, ea, ez, c4a, c4z, ua, uz);
-                    } else {
-                        const uint32_t ca_i = na_c, cz_i = nz_c;
+                    uint32_t ua, uz, ca_i = c4a, cz_i = c4z;
+                    constexpr int SEL = MODE == 1 ? int(i) : 4;
+                    if constexpr (MODE != 1) {
+                        ca_i = na_c; cz_i = nz_c;
                         if constexpr (i < 3u) { na_c = cls_of(wa, i + 1u); nz_c = cls_of(wz, i + 1u); }
-                        chain_step2<ALLD, ROW16, kRowsAt, 4>(L, ea, ez, ca_i, cz_i, ua, uz);
                     }
-                    if (W0) { ea = j < pa.start_j ? 0u : ea; ez = j < pz.start_j ? 0u : ez; }
-                    if constexpr (Q) return;
-                    // (rep_lo >= start_j: nothing before a walk's first byte reports)
-                    const bool va = int32_t(ua) < 0 && (!C || j - pa.rep_lo < pa.rep_len);
-                    const bool vz = int32_t(uz) < 0 && (!C || j - pz.rep_lo < pz.rep_len);
-                    if (va) event(ea, oa, j);
-                    if (vz) event(ez, oz, j);
+                    if constexpr (ALLD) {
+                        chain_step2<SEL>(L, ea, ez, ca_i, cz_i, ua, uz);
+                        if (W0) { ea = j < pa.start_j ? 0u : ea; ez = j < pz.start_j ? 0u : ez; }
+                        if constexpr (Q) return;
+                        // (rep_lo >= start_j: nothing before a walk's first byte reports)
+                        const bool va = int32_t(ua) < 0 && (!C || j - pa.rep_lo < pa.rep_len);
+                        const bool vz = int32_t(uz) < 0 && (!C || j - pz.rep_lo < pz.rep_len);
+                        if (va) event(ea, oa, j);
+                        if (vz) event(ez, oz, j);
+                    } else {
+                        uint32_t ta, tz;
+                        const uint32_t ea0 = ea, ez0 = ez;
+                        chain_read2<ROW16, kRowsAt, SEL>(L, ea, ez, ca_i, cz_i, ua, uz, ta, tz);
+                        chain_next2<SEL>(ea, ez, ca_i, cz_i, ua, uz, ta, tz);
+                        if constexpr (!Q) {
+                            // (the state the step LEFT, entered with byte j - 1: a block's first step looks back into the block before,
+                            // which may lie in front of the piece's own range -- that one step is tested whatever the block.  Behind
+                            // the selects: between the rows' reads and the selects, the branches around the stores cut the reads
+                            // off from their zero-extension -- an and per read -- and invited hipcc to sink the second read)
+                            constexpr bool T = C || (F && i == 0u);
+                            const bool va = int32_t(ua) < 0 && (!T || j - 1u - pa.rep_lo < pa.rep_len);
+                            const bool vz = int32_t(uz) < 0 && (!T || j - 1u - pz.rep_lo < pz.rep_len);
+                            if (va) event(ea0, oa, j - 1u);
+                            if (vz) event(ez0, oz, j - 1u);
+                        }
+                        if (W0) { ea = j < pa.start_j ? 0u : ea; ez = j < pz.start_j ? 0u : ez; }
+                    }
                 };
                 one(std::integral_constant<uint32_t, 0u>{}); one(std::integral_constant<uint32_t, 1u>{});
                 one(std::integral_constant<uint32_t, 2u>{}); one(std::integral_constant<uint32_t, 3u>{});
@@ -338,20 +400,21 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
             const bool plain = silent && (sj == 1u || sj >= 16u) && (sk == 1u || sk >= 16u);
             if (__all(plain)) {
                 if (__any(sj < 16u || sk < 16u)) {
-                    dword(fa.x, fz.x, 0u, no, no, yes, yes); dword(fa.y, fz.y, 4u, no, no, yes, no);
-                    dword(fa.z, fz.z, 8u, no, no, yes, no); dword(fa.w, fz.w, 12u, no, no, yes, no);
+                    dword(fa.x, fz.x, 0u, no, no, yes, yes, yes); dword(fa.y, fz.y, 4u, no, no, yes, no, no);
+                    dword(fa.z, fz.z, 8u, no, no, yes, no, no); dword(fa.w, fz.w, 12u, no, no, yes, no, no);
                     ea = sj >= 16u ? 0u : ea;
                     ez = sk >= 16u ? 0u : ez;
                 }
             } else if (__all(silent)) {   // (shorter patterns: the walks begin further inside the block -- the reset per step, no tests)
-                dword(fa.x, fz.x, 0u, no, yes, yes, no); dword(fa.y, fz.y, 4u, no, yes, yes, no);
-                dword(fa.z, fz.z, 8u, no, yes, yes, no); dword(fa.w, fz.w, 12u, no, yes, yes, no);
+                dword(fa.x, fz.x, 0u, no, yes, yes, no, yes); dword(fa.y, fz.y, 4u, no, yes, yes, no, no);
+                dword(fa.z, fz.z, 8u, no, yes, yes, no, no); dword(fa.w, fz.w, 12u, no, yes, yes, no, no);
             } else {   // (some walk begins inside the block, or reports in it)
-                dword(fa.x, fz.x, 0u, yes, yes, no, no); dword(fa.y, fz.y, 4u, yes, yes, no, no);
-                dword(fa.z, fz.z, 8u, yes, yes, no, no); dword(fa.w, fz.w, 12u, yes, yes, no, no);
+                dword(fa.x, fz.x, 0u, yes, yes, no, no, yes); dword(fa.y, fz.y, 4u, yes, yes, no, no, no);
+                dword(fa.z, fz.z, 8u, yes, yes, no, no, no); dword(fa.w, fz.w, 12u, yes, yes, no, no, no);
             }
+            uint32_t k = 1u;
 #pragma unroll 1
-            for (uint32_t k = 1u; __any(k < my_blocks); ++k) {   // (as many blocks as the wave's longest walk has: a ballot, not a reduction)
+            for (; __any(k < my_blocks); ++k) {   // (as many blocks as the wave's longest walk has: a ballot, not a reduction)
                 asm volatile("; acmi-hot-begin");   // (tools/check_asm.py: no scratch traffic between the markers)
                 const uint4 ca = a0, cz = z0;
                 a0 = a1; a1 = a2; a2 = a3;
@@ -362,13 +425,19 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
                 // (a block that lies inside EVERY piece's own range -- all but the first and the last of a piece -- without the range test)
                 const bool full = j0 >= pa.rep_lo && j0 + 16u <= pa.rep_lo + pa.rep_len && j0 >= pz.rep_lo && j0 + 16u <= pz.rep_lo + pz.rep_len;
                 if (__all(full)) {
-                    dword(ca.x, cz.x, j0, no, no, no, no); dword(ca.y, cz.y, j0 + 4u, no, no, no, no);
-                    dword(ca.z, cz.z, j0 + 8u, no, no, no, no); dword(ca.w, cz.w, j0 + 12u, no, no, no, no);
+                    dword(ca.x, cz.x, j0, no, no, no, no, yes); dword(ca.y, cz.y, j0 + 4u, no, no, no, no, no);
+                    dword(ca.z, cz.z, j0 + 8u, no, no, no, no, no); dword(ca.w, cz.w, j0 + 12u, no, no, no, no, no);
                 } else {
-                    dword(ca.x, cz.x, j0, yes, no, no, no); dword(ca.y, cz.y, j0 + 4u, yes, no, no, no);
-                    dword(ca.z, cz.z, j0 + 8u, yes, no, no, no); dword(ca.w, cz.w, j0 + 12u, yes, no, no, no);
+                    dword(ca.x, cz.x, j0, yes, no, no, no, yes); dword(ca.y, cz.y, j0 + 4u, yes, no, no, no, no);
+                    dword(ca.z, cz.z, j0 + 8u, yes, no, no, no, no); dword(ca.w, cz.w, j0 + 12u, yes, no, no, no, no);
                 }
                 asm volatile("; acmi-hot-end");
+            }
+            if constexpr (!ALLD) {   // the states the walks end in: entered with the last byte walked, 16 k - 1
+                const uint32_t jl = 16u * k - 1u;
+                const uint32_t ua = lds_read<uint32_t>(smem, (ea << 2) + L.rec_at), uz = lds_read<uint32_t>(smem, (ez << 2) + L.rec_at);
+                if (int32_t(ua) < 0 && jl - pa.rep_lo < pa.rep_len) event(ea, oa, jl);
+                if (int32_t(uz) < 0 && jl - pz.rep_lo < pz.rep_len) event(ez, oz, jl);
             }
         }
         const uint32_t na = (oa - off_a0) >> 8, nz = (oz - off_z0) >> 8;   // events of the two pieces
