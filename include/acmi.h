@@ -304,7 +304,8 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *                    walk with a work item spread over the lanes of a wave and the records placed by a running
  *                    sum in ONE pass -- no slabs, no drain (findAll = true, patterns of <= 129 B; what automatic
  *                    mode takes instead of 4 unless the output is denser than a record per two bytes) [any time]
- *   "tile_w", "tile_p"  kernel 6: bytes per lane (16, 32, 64) and lanes per work item (1..64); 0 = automatic [any time]
+ *   "tile_w", "tile_p"  kernel 6: bytes per lane (16, 32, 64; 128: k_walk_chain only, else taken as 64) and lanes per work item
+ *                    (1..64); 0 = automatic [any time]
  *   "chain_walk"     kernel 6 for a pattern set that carries the chain-compressed LDS image of its WHOLE automaton (a few thousand
  *                    patterns: dense rows for the branching states, goto edge + failure pointer -- the reference's node,
  *                    node.h:37-67 -- for the insides of the patterns; "chain_image_bytes", "chain_dense_states"): -1 (default) the

@@ -68,7 +68,8 @@ def test_ragged_haystacks_and_pattern_lengths(hmax, lmax):
     """Unaligned starts, haystacks shorter than a piece and longer than an item, warm-ups of 0 .. 8 blocks."""
     ds = synth._planted_ragged(f"CR{hmax}", 900 + hmax, 400, 1, lmax, 300, 0, hmax, b"abc", 4)
     pe, re_ = _oracle(ds)
-    for geometry in ({}, dict(tile_w=16, tile_p=9), dict(tile_w=64, tile_p=64), dict(tile_w=32, tile_p=1)):
+    for geometry in ({}, dict(tile_w=16, tile_p=9), dict(tile_w=64, tile_p=64), dict(tile_w=32, tile_p=1), dict(tile_w=128, tile_p=5),
+                     dict(tile_w=128, tile_p=64)):   # (128: round 6, k_walk_chain's pieces over big batches)
         res = resource_for(ds, kernel=6, small_path=0, lds_bytes=2048, chain_walk=1, **geometry)
         p, r = device_match(res, ds)
         if lmax > 4:

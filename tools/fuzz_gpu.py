@@ -48,7 +48,7 @@ for case in range(n_cases):
     step = (len(pats) + calls - 1) // calls
     for lo in range(0, len(pats), step):
         o.add_patterns(pats[lo:lo + step])
-    opts = dict(kernel=int(r.choice([6, 6, 6, 3, 3, 2, 4] if os.environ.get("FUZZ_BIG") else [0, 1, 2, 2, 3, 3, 4, 6, 6])), tile_w=int(r.choice([0, 0, 16, 32, 64])), tile_p=int(r.choice([0, 0, 1, 3, 7, 16, 64])), walk_group=int(r.choice([1, 4, 8])), ilp=int(r.choice([1, 2])), group_quads=int(r.choice([4, 8])),
+    opts = dict(kernel=int(r.choice([6, 6, 6, 3, 3, 2, 4] if os.environ.get("FUZZ_BIG") else [0, 1, 2, 2, 3, 3, 4, 6, 6])), tile_w=int(r.choice([0, 0, 16, 32, 64, 128])), tile_p=int(r.choice([0, 0, 1, 3, 7, 16, 64])), walk_group=int(r.choice([1, 4, 8])), ilp=int(r.choice([1, 2])), group_quads=int(r.choice([4, 8])),
                 chunk_bytes=int(r.choice([0, 0, 16, 48, 256, 1024, 4096])), slab_events=int(r.choice([1, 2, 8])),
                 run_cap=int(r.choice([0, 1, 2, 8])), relist=int(r.choice([0, 1, 1])), persistent=int(r.choice([-1, 0, 1])), lds_bytes=int(r.choice([2048, 8192, 65536, 163000])),
                 small_path=int(r.choice([0, 1])), tiny_rows=int(r.choice([0, 1, 1])), short_rows=int(r.choice([-1, 0, 1])), refill=int(r.choice([0, 1, 2, 2])), max_flat_outputs=int(r.choice([0, 1 << 25, 1 << 25])), compact=int(r.choice([-1, 0, 1, 1])), early_stop=int(r.choice([0, 1, 2, 2])), verify=int(r.choice([0, 1, 1])), dense_bytes=int(r.choice([0, 4096, 1 << 22])), anchor_dense=int(r.choice([-1, 1, 1, 0])), dense_hot=int(r.choice([-1, 0, 1])), split=int(r.choice([-1, -1, 0, 1])), anchor_slots2=int(r.choice([-1, 0, 1])),
