@@ -36,9 +36,11 @@ float nominal_cost(const acmi_handle *h, int strat, uint64_t blob_bytes, size_t 
     }
     case acmi_handle::kStratLds: return float((fa.compact ? 2.0 : 0.33) + density * 300.0);
     case acmi_handle::kStratTiles: {
-        // (the whole automaton in LDS, chain-compressed: the walk costs 0.9-1.1 ms per GiB on text with a match now and then, 1.4 with
-        // one every nine bytes; the logs turn into records at ~ 6 us per million)
-        if (h->chain_walk != 0 && chain_walk_ok(h->dA) && (h->chain_walk > 0 || h->dA.chain_dense < h->dA.chain_index)) return float(1.0 + density * 10.0);
+        // (the whole automaton in LDS, chain-compressed: round 6's walk costs 0.68-0.74 ms per GiB whatever the text, the call 0.78 at
+        // a record per 128 bytes and 0.98 at one per 32; the logs turn into records at ~ 6 us per million.  Round 5's 1.0 kept the
+        // headline set at 64 occurrences per 8 KiB on the filter's 0.90-0.92 ms: 1.2 x the expectation was above it, no probe -- the
+        // expectation is the walk's own time, the best case, so that the margin does not hide a 15 % better strategy)
+        if (h->chain_walk != 0 && chain_walk_ok(h->dA) && (h->chain_walk > 0 || h->dA.chain_dense < h->dA.chain_index)) return float(0.62 + density * 9.0);
         const bool allhot = uint64_t(fa.trap) * (fa.n_columns * fa.entry_bytes + 4u) <= 60u * 1024u && fa.trap + 1u == fa.n_states;
         return float((fa.compact ? 6.0 : allhot ? 1.0 : 1.45) + density * (density > 0.25 ? 20.0 : 4.5));   // (past an event per 4 bytes: the second walk)
     }

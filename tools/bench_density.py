@@ -1,17 +1,18 @@
 """One cell of the density matrix (tests/test_gpu_cliffs.py) on its own: set x planted occurrences per 8 KiB x haystack size, a 64 MiB
 batch, N calls -- per call the host time, the kernel times and what the filter's hand-over reported.  Analysis tool.
-    python tools/bench_density.py cfg3 128 8192 [calls=8] [kernel=2] [option=value ...]      (under tools/prof_cmd.sh for the kernel table)"""
+    python tools/bench_density.py cfg3 128 8192 [calls=8] [kernel=2] [option=value ...]      (under tools/prof_cmd.sh for the kernel table)
+    python tools/bench_density.py words prose:1.0 8192 ...      the word list over prose of which that share is listed words (bench.py's cells)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from php_aho_corasick_amd import api, batch, synth
 
-kind, per, hay_len = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+kind, per, hay_len = sys.argv[1], sys.argv[2], int(sys.argv[3])
 opts = dict(a.split("=") for a in sys.argv[4:])
 calls = int(opts.pop("calls", 8))
 mib = int(opts.pop("mib", 64))
 base = synth.density_set(kind)
-ds = synth.plant_density(base, per, hay_len)
+ds = synth.prose(base, float(per[6:])) if per.startswith("prose:") else synth.plant_density(base, int(per), hay_len)
 res = api.ahocorasick_init([{"id": k, "value": p} for k, p in enumerate(base.patterns())])
 for k, v in opts.items():
     res.set_option(k, int(v))
