@@ -53,6 +53,7 @@ for case in range(n_cases):
                 run_cap=int(r.choice([0, 1, 2, 8])), relist=int(r.choice([0, 1, 1])), persistent=int(r.choice([-1, 0, 1])), lds_bytes=int(r.choice([2048, 8192, 65536, 163000])),
                 small_path=int(r.choice([0, 1])), tiny_rows=int(r.choice([0, 1, 1])), short_rows=int(r.choice([-1, 0, 1])), refill=int(r.choice([0, 1, 2, 2])), max_flat_outputs=int(r.choice([0, 1 << 25, 1 << 25])), compact=int(r.choice([-1, 0, 1, 1])), early_stop=int(r.choice([0, 1, 2, 2])), verify=int(r.choice([0, 1, 1])), dense_bytes=int(r.choice([0, 4096, 1 << 22])), anchor_dense=int(r.choice([-1, 1, 1, 0])), dense_hot=int(r.choice([-1, 0, 1])), split=int(r.choice([-1, -1, 0, 1])), anchor_slots2=int(r.choice([-1, 0, 1])),
                 win_table=int(r.choice([-1, 0, 1, 1])), win_walk=int(r.choice([0, 1, 1])), wave_runs=int(r.choice([0, 1, 1])), chain_walk=int(r.choice([-1, -1, 0, 1, 1])), chain_bytes=int(r.choice([160 * 1024 - 768, 160 * 1024 - 768, 40000, 6000, 0])))
+    t_case = time.time()
     res = resource_for(ds, calls=calls, **opts)
     for find_all in (True, False):
         pe, re_ = o.match_batch(ds.hay_blob, ds.hay_off, find_all)
@@ -70,5 +71,7 @@ for case in range(n_cases):
                                                    plants=plants, calls=calls), find_all, path.__name__, len(rr), len(re_), flush=True)
     api.ahocorasick_deinit(res)
     o.close()
+    if os.environ.get("FUZZ_TIMES") and time.time() - t_case > float(os.environ["FUZZ_TIMES"]):   # cases slower than this many seconds
+        print("SLOW", seed, round(time.time() - t_case, 1), opts, dict(lmin=lmin, lmax=lmax, n_pat=n_pat, n_hay=n_hay, hmax=hmax, plants=plants), flush=True)
 print(f"fuzz: {n_cases} cases from seed {seed0}, {bad} mismatches, {time.time()-t0:.1f}s")
 sys.exit(1 if bad else 0)
