@@ -421,8 +421,8 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
         // the record buffer: a batch that overflows them is run again (run_batch_end) -- and never beyond an event per byte.
         const uint64_t tiles = chain_tiles(max_items, tile_p), waves = chain_waves(B.reserve_cus);
         const uint64_t active = std::min(tiles, waves);   // (a small batch has fewer tiles than the grid has waves: the others touch nothing)
-        const uint64_t worst = ((tiles + waves - 1) / waves) * 128ull * (tile_w + 16ull);
-        const uint64_t want = (blob_bytes / std::max<uint32_t>(1, h->chain_log_div)) / waves * 5 / 4 + 128ull * (tile_w + 16ull);
+        const uint64_t worst = ((tiles + waves - 1) / waves) * 64ull * chain_np() * (tile_w + 16ull);
+        const uint64_t want = (blob_bytes / std::max<uint32_t>(1, h->chain_log_div)) / waves * 5 / 4 + 64ull * chain_np() * (tile_w + 16ull);
         // (at an event per byte the AVERAGE wave's share is no bound -- tiles are dealt t % waves, and haystacks whose density recurs
         // with the grid's period give one wave more than the mean: the last size is the true per-wave bound, `worst`)
         const uint32_t log_cap = uint32_t(std::min<uint64_t>(h->chain_log_div <= 1u ? worst : std::min(worst, want), 0xFFFFFF00ull));

@@ -37,10 +37,11 @@ constexpr uint32_t kChainWaves = kChainThreads / 64;
 
 struct ChainArgs {
     uint32_t W, P, R, back;
-    uint32_t inv_p;       // ceil(65536 / P): (s x inv_p) >> 16 = s / P for s < 128
+    uint32_t inv_p;       // ceil(65536 / P): (s x inv_p) >> 16 = s / P for s < 192
+    uint32_t np;          // pieces a lane walks at once: a wave's tile is 64 np pieces (chain_np())
     uint32_t debug;       // measurements only (ACMI_CHAIN_DEBUG): 2 no walk
     uint32_t spill_cap;   // events per piece the wave's overflow region holds
-    uint32_t *spill;      // grid waves x spill_cap x 128 words
+    uint32_t *spill;      // grid waves x spill_cap x 64 np words
     uint32_t *log;        // grid waves x log_cap words: the waves' event logs
     uint32_t log_cap;     // words per wave
     uint2 *tile_info;     // per tile: {where its events begin in its wave's log, how many}
@@ -95,23 +96,25 @@ __device__ __forceinline__ uint32_t chain_class(uint32_t c4) { return SEL == 4 ?
 // when that state is final: a record says so of its own state (set as the image is staged), the rows hold plain indices, and an
 // event is found one step late, when the state's record is read anyway -- no select of "record or row entry" for the flag and no
 // mask for the index: 6 VALU operations per byte and piece (lshl_add, add_sdwa, cmp_sdwa, add, cndmask; the event's compare).
-template <int SEL>
-__device__ __forceinline__ void chain_step2(const ChainLds &L, uint32_t &ea, uint32_t &ez, uint32_t ca, uint32_t cz, uint32_t &ua, uint32_t &uz) {
+template <uint32_t NP, int SEL>
+__device__ __forceinline__ void chain_step_rows(const ChainLds &L, uint32_t (&e)[NP], const uint32_t (&c)[NP], uint32_t (&u)[NP]) {
     // ALLD: every state has its row -- one read, no record, no chain
     typedef const __attribute__((address_space(3))) int16_t *RowPtr;
-    const uint32_t ka = chain_class<SEL>(ca), kz = chain_class<SEL>(cz);
-    uint32_t aa, az;
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(aa) : "v"(ea), "s"(L.row_bytes), "v"(ka));
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(az) : "v"(ez), "s"(L.row_bytes), "v"(kz));
-    ua = uint32_t(int32_t(*reinterpret_cast<RowPtr>(aa)));   // (sign-extended: a final target is negative)
-    uz = uint32_t(int32_t(*reinterpret_cast<RowPtr>(az)));
-    ea = ua & 0x7FFFu;
-    ez = uz & 0x7FFFu;
+    uint32_t aa[NP];
+#pragma unroll
+    for (uint32_t h = 0; h < NP; ++h) {
+        const uint32_t k = chain_class<SEL>(c[h]);
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(aa[h]) : "v"(e[h]), "s"(L.row_bytes), "v"(k));
+    }
+#pragma unroll
+    for (uint32_t h = 0; h < NP; ++h) u[h] = uint32_t(int32_t(*reinterpret_cast<RowPtr>(aa[h])));   // (sign-extended: a final target is negative)
+#pragma unroll
+    for (uint32_t h = 0; h < NP; ++h) e[h] = u[h] & 0x7FFFu;
 }
 
 // The same for an image with records (!ALLD), in two halves so that the events of the states the step leaves are stored while the
-// rows' reads are under way: chain_read2 -> `ua`, `uz` the records of the states, `ta`, `tz` the row entries (requested);
-// chain_next2 -> the next indices.  The operand selections are spelled out: hipcc found `record.lo + class byte` and `record.key ==
+// rows' reads are under way: chain_read -> `u` the records of the states, `t` the row entries (requested); chain_next -> the next
+// indices.  The operand selections are spelled out: hipcc found `record.lo + class byte` and `record.key ==
 // class byte` as one SDWA operation each in a small test and in half of this kernel's instantiations, and shifts, masks and
 // three-input logic in the rest -- and it sank the second piece's row read into a branch on "no hit" (an exec mask, a jump, the
 // read issued only when the first had come back); as the asm's operand it is read whatever the keys say.
@@ -140,24 +143,27 @@ __device__ __forceinline__ void chain_select(uint32_t &e1, uint32_t t, uint32_t 
 #undef ACMI_SELECT
 }
 #undef ACMI_SEL
-template <bool ROW16, uint32_t ROWS_AT, int SEL>
-__device__ __forceinline__ void chain_read2(const ChainLds &L, uint32_t ea, uint32_t ez, uint32_t ca, uint32_t cz, uint32_t &ua, uint32_t &uz, uint32_t &ta, uint32_t &tz) {
+template <uint32_t NP, bool ROW16, uint32_t ROWS_AT, int SEL>
+__device__ __forceinline__ void chain_read(const ChainLds &L, const uint32_t (&e)[NP], const uint32_t (&c)[NP], uint32_t (&u)[NP], uint32_t (&t)[NP]) {
     typedef const __attribute__((address_space(3))) uint32_t *RecPtr;
     typedef const __attribute__((address_space(3))) uint16_t *RowPtr;
-    ua = *reinterpret_cast<RecPtr>((ea << 2) + L.rec_at);
-    uz = *reinterpret_cast<RecPtr>((ez << 2) + L.rec_at);
-    __builtin_amdgcn_sched_barrier(0);   // (both records requested before either is waited for: the scheduler put the first's add in between)
-    uint32_t aa = chain_row_of<SEL>(ua, ca), az = chain_row_of<SEL>(uz, cz);
-    if constexpr (!ROW16) { aa <<= 1; az <<= 1; }
-    ta = *reinterpret_cast<RowPtr>(aa + ROWS_AT);
-    tz = *reinterpret_cast<RowPtr>(az + ROWS_AT);
+#pragma unroll
+    for (uint32_t h = 0; h < NP; ++h) u[h] = *reinterpret_cast<RecPtr>((e[h] << 2) + L.rec_at);
+    __builtin_amdgcn_sched_barrier(0);   // (every piece's record requested before any is waited for: the scheduler put the first's add in between)
+#pragma unroll
+    for (uint32_t h = 0; h < NP; ++h) {
+        uint32_t aa = chain_row_of<SEL>(u[h], c[h]);
+        if constexpr (!ROW16) aa <<= 1;
+        t[h] = *reinterpret_cast<RowPtr>(aa + ROWS_AT);
+    }
 }
-template <int SEL>
-__device__ __forceinline__ void chain_next2(uint32_t &ea, uint32_t &ez, uint32_t ca, uint32_t cz, uint32_t ua, uint32_t uz, uint32_t ta, uint32_t tz) {
-    ++ea;
-    ++ez;
-    chain_select<SEL>(ea, ta, ua, ca);   // (0xFF -- no child, or a D state -- is no class)
-    chain_select<SEL>(ez, tz, uz, cz);
+template <uint32_t NP, int SEL>
+__device__ __forceinline__ void chain_next(uint32_t (&e)[NP], const uint32_t (&c)[NP], const uint32_t (&u)[NP], const uint32_t (&t)[NP]) {
+#pragma unroll
+    for (uint32_t h = 0; h < NP; ++h) {
+        ++e[h];
+        chain_select<SEL>(e[h], t[h], u[h], c[h]);   // (0xFF -- no child, or a D state -- is no class)
+    }
 }
 
 // One piece of a wave's 128 (k_walk_tiles' geometry): the first block it walks, where in it the walk begins, what reports.
@@ -174,7 +180,7 @@ __device__ __forceinline__ Piece chain_piece(const DevAutomaton &A, const BatchA
     Piece pc;
     pc.pb = A.pad16;
     pc.nblk = 0; pc.start_j = 16u; pc.rep_lo = pc.rep_len = pc.pos_bias = pc.hay = 0;
-    pc.r = (s * T.inv_p) >> 16;   // s / P for s < 128 (a division by a run-time value is ~ 30 instructions)
+    pc.r = (s * T.inv_p) >> 16;   // s / P for s < 192, P <= 64 (a division by a run-time value is ~ 30 instructions)
     pc.qi = s - pc.r * T.P;
     pc.item = first_item + pc.r;
     pc.have = pc.r < T.R && pc.item < total_items;
@@ -213,12 +219,12 @@ __device__ __forceinline__ uint32_t chain_count(const DevAutomaton &A, uint32_t 
     return c < 255u ? c : A.out_count[A.chain_orig[e]];
 }
 
-template <int MODE, bool ALLD, bool ROW16>
+template <int MODE, bool ALLD, bool ROW16, uint32_t NP>
 __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, BatchArgs B, ChainArgs T) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint64_t total_items = B.item_base[B.n_haystacks];
-    // (the image at offset 0 -- no static shared variable in front of it: chain_step2 reads at the offsets it computes)
+    // (the image at offset 0 -- no static shared variable in front of it: the steps read at the offsets they compute)
     if (uint32_t(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint8_t *)smem)) != 0u) __builtin_trap();
     ChainLds L;
     L.img = smem;
@@ -275,16 +281,20 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
         L.cnt = smem + Y.cnt_at;
     }
     __syncthreads();
-    // A lane walks TWO pieces at once, 2 lane and 2 lane + 1 of the wave's 128: a step is two dependent LDS reads, and with the
-    // whole LDS taken by the image a CU runs one workgroup -- four waves per SIMD, too few to hide them (one piece per lane: 55 % of
-    // the VALU cycles used).  The two walks are independent: their reads are issued together.  A lane's records -- the first
-    // piece's, then the second's -- are one contiguous stretch of the output.
+    // A lane walks NP pieces at once, NP lane .. NP lane + NP - 1 of the wave's 64 NP: a step is two dependent LDS reads, and with
+    // the whole LDS taken by the image a CU runs one workgroup -- four waves per SIMD, too few to hide them (one piece per lane:
+    // 55 % of the VALU cycles used).  The walks are independent: their reads are issued together.  A lane's records -- the first
+    // piece's, then the next's -- are one contiguous stretch of the output.
     // Event lists: entry k of piece h of this lane at byte (h x spill_cap + k) x 256 + 4 lane of the wave's region of a global buffer
     // (L2: written and read back within microseconds).  Not in LDS: two entries per piece there and the rest in memory meant a
     // compare and two store paths in every step with an event -- 8 VALU and 6 SALU operations per event and piece, which is what
-    // the kernel spent most of its time on once a piece had an event every fifteen bytes; one path, its offset bumped, is 3.
-    uint8_t *const spill = reinterpret_cast<uint8_t *>(T.spill) + uint64_t(__builtin_amdgcn_readfirstlane(int(blockIdx.x * kChainWaves + wave))) * T.spill_cap * 512u;
-    const uint32_t off_a0 = lane * 4u, off_z0 = T.spill_cap * 256u + lane * 4u;
+    // the kernel spent most of its time on once a piece had an event every fifteen bytes; one path, its offset bumped, is 2.
+    constexpr uint32_t kPieces = 64u * NP;   // pieces of a wave's tile
+    constexpr uint32_t kAhead = NP == 2 ? 4u : 3u;   // text blocks requested ahead of the one that is walked (the registers of 4 waves per SIMD: 128)
+    uint8_t *const spill = reinterpret_cast<uint8_t *>(T.spill) + uint64_t(__builtin_amdgcn_readfirstlane(int(blockIdx.x * kChainWaves + wave))) * T.spill_cap * (256u * NP);
+    uint32_t off0[NP];
+#pragma unroll
+    for (uint32_t h = 0; h < NP; ++h) off0[h] = h * T.spill_cap * 256u + lane * 4u;
     uint32_t walked16 = 0;
     const uint32_t cnt_n = A.chain_cnt_n;
     const uint32_t gw = blockIdx.x * kChainWaves + wave;   // this wave among the grid's
@@ -294,27 +304,30 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
 #pragma unroll 1
     for (uint64_t t = gw; t < tiles_all; t += T.n_waves) {
         const uint64_t first_item = t * T.R;
-        const Piece pa = chain_piece(A, B, T, total_items, first_item, 2u * lane), pz = chain_piece(A, B, T, total_items, first_item, 2u * lane + 1u);
-        walked16 += pa.nblk + pz.nblk;
+        Piece pc[NP];
+        uint32_t e[NP], o[NP];   // the pieces' states, where their next events go
+        uint32_t my_blocks = 0;
+#pragma unroll
+        for (uint32_t h = 0; h < NP; ++h) {
+            pc[h] = chain_piece(A, B, T, total_items, first_item, NP * lane + h);
+            walked16 += pc[h].nblk;
+            my_blocks = pc[h].nblk > my_blocks ? pc[h].nblk : my_blocks;
+            e[h] = 0u;
+            o[h] = off0[h];
+        }
         // ---- the walk: all lanes in step, a lane past its own bytes walks on without reporting ----
-        uint32_t ea = 0, ez = 0;             // states of the two pieces
-        uint32_t oa = off_a0, oz = off_z0;   // where their next events go
-        const uint32_t my_blocks = pa.nblk > pz.nblk ? pa.nblk : pz.nblk;
         if (__any(my_blocks != 0u) && !(T.debug & 2u)) {
             // An event inside the walk is ONE store, {index, byte}, to the piece's list, and the list's offset bumped in place: two
             // VALU operations.  What it stands for is worked out behind the walk, where a lane runs over its own events only -- in
             // here the whole wave pays for every step in which ANY lane has one.  (Round 5 carried the parent record's count code
             // along: an and, a three-way or, and the bump through a copy -- four operations at 0.4-0.9 of the steps; the code is
             // in LDS where the drain can read it, records_of.)
-            auto event = [&](uint32_t e, uint32_t &off, uint32_t jj) __attribute__((always_inline)) {
-                *reinterpret_cast<__attribute__((address_space(1))) uint32_t *>(reinterpret_cast<uintptr_t>(spill) + off) = e | jj << 15;
+            auto event = [&](uint32_t idx, uint32_t &off, uint32_t jj) __attribute__((always_inline)) {
+                *reinterpret_cast<__attribute__((address_space(1))) uint32_t *>(reinterpret_cast<uintptr_t>(spill) + off) = idx | jj << 15;
                 asm volatile("v_add_u32 %0, 0x100, %0" : "+v"(off));   // (in place: hipcc bumped a copy and moved it back)
             };
-            // four steps of both pieces; the column offsets of a dword's four bytes are worked out together (SWAR3: a handful of
-            // operations for all four; TABLE: four independent LDS reads).  CHECKED: the range test of a block that does not lie
-            // inside every piece's own range; WARM: the first block, in which a walk begins (the state is the root before).
             // the column offsets of a dword's bytes: SWAR3 a handful of operations for all four; TABLE an LDS read per byte, requested a
-            // byte ahead of its step (all eight of a dword pair up front cost the two registers that spilled into this loop)
+            // byte ahead of its step (all of a dword's up front cost the registers that spilled into this loop)
             auto cls_of = [&](uint32_t wd, uint32_t i) __attribute__((always_inline)) -> uint32_t {
                 // (explicitly LDS reads at the table's offset: through class_offset's generic pointer hipcc emitted flat_load_ushort
                 // behind two branches -- a flat load counts on vmcnt too: every byte's class waited for the text requested four
@@ -326,59 +339,85 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
                     return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((wd >> (8u * i)) & 0xffu);
                 }
             };
+            // four steps of every piece.  CHECKED: the range test of a block that does not lie inside every piece's own range; WARM:
+            // the first block, in which a walk begins (the state is the root before).
             // QUIET: a first block in which no walk of the wave reports and every walk begins at byte 1 (or not at all: such a lane
             // is put back to the root behind the block) -- no range test, no event test, no reset; SKIP0: its first dword, less byte 0
-            auto dword = [&](uint32_t wa, uint32_t wz, uint32_t jj, auto checked, auto warm, auto quiet, auto skip0, auto first) __attribute__((always_inline)) {
+            auto dword = [&](const uint32_t (&w)[NP], uint32_t jj, auto checked, auto warm, auto quiet, auto skip0, auto first) __attribute__((always_inline)) {
                 constexpr bool C = decltype(checked)::value, W0 = decltype(warm)::value, Q = decltype(quiet)::value, S0 = decltype(skip0)::value, F = decltype(first)::value;
-                uint32_t c4a = 0, c4z = 0, na_c = 0, nz_c = 0;
-                if constexpr (MODE == 1) {
-                    c4a = swar_columns<uint16_t>(A, wa);   // (bytes of 2 x class: even, so that a shift leaves the classes)
-                    c4z = swar_columns<uint16_t>(A, wz);
-                    if constexpr (!ALLD && !ROW16) { c4a >>= 1; c4z >>= 1; }
-                } else {
-                    na_c = cls_of(wa, S0 ? 1u : 0u);
-                    nz_c = cls_of(wz, S0 ? 1u : 0u);
+                uint32_t c4[NP], nc[NP];
+#pragma unroll
+                for (uint32_t h = 0; h < NP; ++h) {
+                    c4[h] = nc[h] = 0u;
+                    if constexpr (MODE == 1) {
+                        c4[h] = swar_columns<uint16_t>(A, w[h]);   // (bytes of 2 x class: even, so that a shift leaves the classes)
+                        if constexpr (!ALLD && !ROW16) c4[h] >>= 1;
+                    } else {
+                        nc[h] = cls_of(w[h], S0 ? 1u : 0u);
+                    }
                 }
                 auto one = [&](auto sel) __attribute__((always_inline)) {
                     constexpr uint32_t i = decltype(sel)::value;
                     if constexpr (S0 && i == 0u) return;
                     const uint32_t j = jj + i;
-                    uint32_t ua, uz, ca_i = c4a, cz_i = c4z;
                     constexpr int SEL = MODE == 1 ? int(i) : 4;
-                    if constexpr (MODE != 1) {
-                        ca_i = na_c; cz_i = nz_c;
-                        if constexpr (i < 3u) { na_c = cls_of(wa, i + 1u); nz_c = cls_of(wz, i + 1u); }
+                    uint32_t c[NP], u[NP];
+#pragma unroll
+                    for (uint32_t h = 0; h < NP; ++h) {
+                        c[h] = c4[h];
+                        if constexpr (MODE != 1) {
+                            c[h] = nc[h];
+                            if constexpr (i < 3u) nc[h] = cls_of(w[h], i + 1u);
+                        }
                     }
                     if constexpr (ALLD) {
-                        chain_step2<SEL>(L, ea, ez, ca_i, cz_i, ua, uz);
-                        if (W0) { ea = j < pa.start_j ? 0u : ea; ez = j < pz.start_j ? 0u : ez; }
-                        if constexpr (Q) return;
-                        // (rep_lo >= start_j: nothing before a walk's first byte reports)
-                        const bool va = int32_t(ua) < 0 && (!C || j - pa.rep_lo < pa.rep_len);
-                        const bool vz = int32_t(uz) < 0 && (!C || j - pz.rep_lo < pz.rep_len);
-                        if (va) event(ea, oa, j);
-                        if (vz) event(ez, oz, j);
-                    } else {
-                        uint32_t ta, tz;
-                        const uint32_t ea0 = ea, ez0 = ez;
-                        chain_read2<ROW16, kRowsAt, SEL>(L, ea, ez, ca_i, cz_i, ua, uz, ta, tz);
-                        chain_next2<SEL>(ea, ez, ca_i, cz_i, ua, uz, ta, tz);
-                        if constexpr (!Q) {
-                            // (the state the step LEFT, entered with byte j - 1: a block's first step looks back into the block before,
-                            // which may lie in front of the piece's own range -- that one step is tested whatever the block.  Behind
-                            // the selects: between the rows' reads and the selects, the branches around the stores cut the reads
-                            // off from their zero-extension -- an and per read -- and invited hipcc to sink the second read)
-                            constexpr bool T = C || (F && i == 0u);
-                            const bool va = int32_t(ua) < 0 && (!T || j - 1u - pa.rep_lo < pa.rep_len);
-                            const bool vz = int32_t(uz) < 0 && (!T || j - 1u - pz.rep_lo < pz.rep_len);
-                            if (va) event(ea0, oa, j - 1u);
-                            if (vz) event(ez0, oz, j - 1u);
+                        chain_step_rows<NP, SEL>(L, e, c, u);
+#pragma unroll
+                        for (uint32_t h = 0; h < NP; ++h) {
+                            if (W0) e[h] = j < pc[h].start_j ? 0u : e[h];
+                            if constexpr (!Q) {   // (rep_lo >= start_j: nothing before a walk's first byte reports)
+                                if (int32_t(u[h]) < 0 && (!C || j - pc[h].rep_lo < pc[h].rep_len)) event(e[h], o[h], j);
+                            }
                         }
-                        if (W0) { ea = j < pa.start_j ? 0u : ea; ez = j < pz.start_j ? 0u : ez; }
+                    } else {
+                        uint32_t tr[NP], e0[NP];
+#pragma unroll
+                        for (uint32_t h = 0; h < NP; ++h) e0[h] = e[h];
+                        chain_read<NP, ROW16, kRowsAt, SEL>(L, e, c, u, tr);
+                        chain_next<NP, SEL>(e, c, u, tr);
+#pragma unroll
+                        for (uint32_t h = 0; h < NP; ++h) {
+                            if constexpr (!Q) {
+                                // (the state the step LEFT, entered with byte j - 1: a block's first step looks back into the block before,
+                                // which may lie in front of the piece's own range -- that one step is tested whatever the block.  Behind
+                                // the selects: between the rows' reads and the selects, the branches around the stores cut the reads
+                                // off from their zero-extension -- an and per read -- and invited hipcc to sink a read)
+                                constexpr bool TT = C || (F && i == 0u);
+                                if (int32_t(u[h]) < 0 && (!TT || j - 1u - pc[h].rep_lo < pc[h].rep_len)) event(e0[h], o[h], j - 1u);
+                            }
+                            if (W0) e[h] = j < pc[h].start_j ? 0u : e[h];
+                        }
                     }
                 };
                 one(std::integral_constant<uint32_t, 0u>{}); one(std::integral_constant<uint32_t, 1u>{});
                 one(std::integral_constant<uint32_t, 2u>{}); one(std::integral_constant<uint32_t, 3u>{});
+            };
+            auto block4 = [&](const uint4 (&v)[NP], uint32_t j0, auto checked, auto warm, auto quiet, auto skip0) __attribute__((always_inline)) {
+                constexpr std::true_type yes{};
+                constexpr std::false_type no{};
+                uint32_t w[NP];
+#pragma unroll
+                for (uint32_t h = 0; h < NP; ++h) w[h] = v[h].x;
+                dword(w, j0, checked, warm, quiet, skip0, yes);
+#pragma unroll
+                for (uint32_t h = 0; h < NP; ++h) w[h] = v[h].y;
+                dword(w, j0 + 4u, checked, warm, quiet, no, no);
+#pragma unroll
+                for (uint32_t h = 0; h < NP; ++h) w[h] = v[h].z;
+                dword(w, j0 + 8u, checked, warm, quiet, no, no);
+#pragma unroll
+                for (uint32_t h = 0; h < NP; ++h) w[h] = v[h].w;
+                dword(w, j0 + 12u, checked, warm, quiet, no, no);
             };
             // (explicitly global loads: through a generic pointer hipcc emits flat_load, which counts on the LDS counter too -- every
             // wait for a state's record then also waited for the text requested four blocks ahead)
@@ -386,62 +425,72 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
                 const u32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) u32x4 *>(reinterpret_cast<uintptr_t>(base) + 16u * i);
                 return make_uint4(v.x, v.y, v.z, v.w);
             };
-            const uint8_t *qa = pa.pb, *qz = pz.pb;
-            const uint32_t la = pa.nblk ? pa.nblk - 1u : 0u, lz = pz.nblk ? pz.nblk - 1u : 0u;
-            const uint4 fa = block(qa, pa.start_j < 16u ? 0u : (la ? 1u : 0u)), fz = block(qz, pz.start_j < 16u ? 0u : (lz ? 1u : 0u));   // (start_j == 16: block 0 is virtual)
-            uint4 a0 = block(qa, 1u < la ? 1u : la), a1 = block(qa, 2u < la ? 2u : la), a2 = block(qa, 3u < la ? 3u : la), a3 = block(qa, 4u < la ? 4u : la);
-            uint4 z0 = block(qz, 1u < lz ? 1u : lz), z1 = block(qz, 2u < lz ? 2u : lz), z2 = block(qz, 3u < lz ? 3u : lz), z3 = block(qz, 4u < lz ? 4u : lz);
-            const uint32_t sj = pa.nblk ? pa.start_j : 16u, sk = pz.nblk ? pz.start_j : 16u;
             constexpr std::true_type yes{};
             constexpr std::false_type no{};
+            uint32_t last[NP], sj[NP];
+            uint4 fb[NP], buf[NP][kAhead];
+            bool silent = true, plain = true, any_first = false;
+#pragma unroll
+            for (uint32_t h = 0; h < NP; ++h) {
+                last[h] = pc[h].nblk ? pc[h].nblk - 1u : 0u;
+                fb[h] = block(pc[h].pb, pc[h].start_j < 16u ? 0u : (last[h] ? 1u : 0u));   // (start_j == 16: block 0 is virtual)
+#pragma unroll
+                for (uint32_t d = 0; d < kAhead; ++d) buf[h][d] = block(pc[h].pb, d + 1u < last[h] ? d + 1u : last[h]);
+                sj[h] = pc[h].nblk ? pc[h].start_j : 16u;
+                silent = silent && (!pc[h].nblk || pc[h].rep_lo >= 16u);   // nothing reports in block 0
+                plain = plain && (sj[h] == 1u || sj[h] >= 16u);
+                any_first = any_first || sj[h] < 16u;
+            }
+            plain = plain && silent;
             // (the usual tile: Lmax - 1 <= 15 bytes of warm-up in front of pieces that begin on block boundaries -- fifteen steps from
-            // the root for every lane, nothing to test: 26 -> 18 VALU operations per step of the pair in a sixth of the tile's steps)
-            const bool silent = (!pa.nblk || pa.rep_lo >= 16u) && (!pz.nblk || pz.rep_lo >= 16u);   // nothing reports in block 0
-            const bool plain = silent && (sj == 1u || sj >= 16u) && (sk == 1u || sk >= 16u);
+            // the root for every lane, nothing to test)
             if (__all(plain)) {
-                if (__any(sj < 16u || sk < 16u)) {
-                    dword(fa.x, fz.x, 0u, no, no, yes, yes, yes); dword(fa.y, fz.y, 4u, no, no, yes, no, no);
-                    dword(fa.z, fz.z, 8u, no, no, yes, no, no); dword(fa.w, fz.w, 12u, no, no, yes, no, no);
-                    ea = sj >= 16u ? 0u : ea;
-                    ez = sk >= 16u ? 0u : ez;
+                if (__any(any_first)) {
+                    block4(fb, 0u, no, no, yes, yes);
+#pragma unroll
+                    for (uint32_t h = 0; h < NP; ++h) e[h] = sj[h] >= 16u ? 0u : e[h];
                 }
             } else if (__all(silent)) {   // (shorter patterns: the walks begin further inside the block -- the reset per step, no tests)
-                dword(fa.x, fz.x, 0u, no, yes, yes, no, yes); dword(fa.y, fz.y, 4u, no, yes, yes, no, no);
-                dword(fa.z, fz.z, 8u, no, yes, yes, no, no); dword(fa.w, fz.w, 12u, no, yes, yes, no, no);
+                block4(fb, 0u, no, yes, yes, no);
             } else {   // (some walk begins inside the block, or reports in it)
-                dword(fa.x, fz.x, 0u, yes, yes, no, no, yes); dword(fa.y, fz.y, 4u, yes, yes, no, no, no);
-                dword(fa.z, fz.z, 8u, yes, yes, no, no, no); dword(fa.w, fz.w, 12u, yes, yes, no, no, no);
+                block4(fb, 0u, yes, yes, no, no);
             }
             uint32_t k = 1u;
 #pragma unroll 1
             for (; __any(k < my_blocks); ++k) {   // (as many blocks as the wave's longest walk has: a ballot, not a reduction)
                 asm volatile("; acmi-hot-begin");   // (tools/check_asm.py: no scratch traffic between the markers)
-                const uint4 ca = a0, cz = z0;
-                a0 = a1; a1 = a2; a2 = a3;
-                z0 = z1; z1 = z2; z2 = z3;
-                const uint32_t kn = k + 4u;
-                if (kn < my_blocks) { a3 = block(qa, kn < la ? kn : la); z3 = block(qz, kn < lz ? kn : lz); }
-                const uint32_t j0 = k * 16u;
-                // (a block that lies inside EVERY piece's own range -- all but the first and the last of a piece -- without the range test)
-                const bool full = j0 >= pa.rep_lo && j0 + 16u <= pa.rep_lo + pa.rep_len && j0 >= pz.rep_lo && j0 + 16u <= pz.rep_lo + pz.rep_len;
-                if (__all(full)) {
-                    dword(ca.x, cz.x, j0, no, no, no, no, yes); dword(ca.y, cz.y, j0 + 4u, no, no, no, no, no);
-                    dword(ca.z, cz.z, j0 + 8u, no, no, no, no, no); dword(ca.w, cz.w, j0 + 12u, no, no, no, no, no);
-                } else {
-                    dword(ca.x, cz.x, j0, yes, no, no, no, yes); dword(ca.y, cz.y, j0 + 4u, yes, no, no, no, no);
-                    dword(ca.z, cz.z, j0 + 8u, yes, no, no, no, no); dword(ca.w, cz.w, j0 + 12u, yes, no, no, no, no);
+                uint4 cur[NP];
+                const uint32_t kn = k + kAhead, j0 = k * 16u;
+                bool full = true;
+#pragma unroll
+                for (uint32_t h = 0; h < NP; ++h) {
+                    cur[h] = buf[h][0];
+#pragma unroll
+                    for (uint32_t d = 0; d + 1u < kAhead; ++d) buf[h][d] = buf[h][d + 1u];
+                    if (kn < my_blocks) buf[h][kAhead - 1u] = block(pc[h].pb, kn < last[h] ? kn : last[h]);
+                    // (a block that lies inside EVERY piece's own range -- all but the first and the last of a piece -- without the range test)
+                    full = full && j0 >= pc[h].rep_lo && j0 + 16u <= pc[h].rep_lo + pc[h].rep_len;
                 }
+                if (__all(full)) block4(cur, j0, no, no, no, no);
+                else block4(cur, j0, yes, no, no, no);
                 asm volatile("; acmi-hot-end");
             }
             if constexpr (!ALLD) {   // the states the walks end in: entered with the last byte walked, 16 k - 1
                 const uint32_t jl = 16u * k - 1u;
-                const uint32_t ua = lds_read<uint32_t>(smem, (ea << 2) + L.rec_at), uz = lds_read<uint32_t>(smem, (ez << 2) + L.rec_at);
-                if (int32_t(ua) < 0 && jl - pa.rep_lo < pa.rep_len) event(ea, oa, jl);
-                if (int32_t(uz) < 0 && jl - pz.rep_lo < pz.rep_len) event(ez, oz, jl);
+#pragma unroll
+                for (uint32_t h = 0; h < NP; ++h) {
+                    const uint32_t u = lds_read<uint32_t>(smem, (e[h] << 2) + L.rec_at);
+                    if (int32_t(u) < 0 && jl - pc[h].rep_lo < pc[h].rep_len) event(e[h], o[h], jl);
+                }
             }
         }
-        const uint32_t na = (oa - off_a0) >> 8, nz = (oz - off_z0) >> 8;   // events of the two pieces
-        if (na | nz) {   // (this lane's own stores: landed before they are read back)
+        uint32_t n[NP], ne = 0;   // events of the pieces
+#pragma unroll
+        for (uint32_t h = 0; h < NP; ++h) {
+            n[h] = (o[h] - off0[h]) >> 8;
+            ne += n[h];
+        }
+        if (ne) {   // (this lane's own stores: landed before they are read back)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
@@ -463,10 +512,9 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
             return chain_count(A, idx);
         };
         // ---- behind the walk: every event once -- its records counted, the event itself into the wave's log, piece after piece:
-        // {index, byte, piece}.  (Entries beyond the LDS list are the lane's own stores, read back from L2 -- the CU's L1 may still hold
-        // the line as a tile before left it -- FOUR at a time: one after the other, each a round trip of its own, they were most of
-        // the kernel's time on text with an event every nine bytes.)
-        const uint32_t ne = na + nz;
+        // {index, byte, piece}.  (The list entries are the lane's own stores, read back from L2 -- the CU's L1 may still hold the line as
+        // a tile before left it -- FOUR at a time: one after the other, each a round trip of its own, they were most of the kernel's
+        // time on text with an event every nine bytes.)
         const uint32_t e_incl = wave_inclusive_sum(ne);
         const uint32_t e_tot = uint32_t(__builtin_amdgcn_readlane(int(e_incl), 63));
         if (lane == 0) T.tile_info[t] = make_uint2(log_at, e_tot);
@@ -474,49 +522,62 @@ __global__ __launch_bounds__(kChainThreads) void k_walk_chain(DevAutomaton A, Ba
         // (the log is sized for the batches before: the host grows it and runs the batch again)
         if (!fits && lane == 0) atomicOr(&B.counters[19], 1u);
         uint32_t *dst = log + log_at + (e_incl - ne);
-        // (the lane's own stores, read back from L2 -- the CU's L1 may still hold the line as a tile before left it --, four at a time)
-        auto drain = [&](uint32_t h, uint32_t n, uint32_t off0, uint32_t *to) __attribute__((always_inline)) -> uint32_t {
+        auto drain = [&](uint32_t h, uint32_t cnt, uint32_t at0, uint32_t *to) __attribute__((always_inline)) -> uint32_t {
             uint32_t recs = 0;
-            const uint32_t tag = (2u * lane + h) << 24;   // (the count code has done its work when the entry is logged: its bits name the piece)
+            const uint32_t tag = (NP * lane + h) << 24;   // (bits 24..31 name the piece)
 #pragma unroll 1
-            for (uint32_t k = 0; k < n; k += 4u) {
-                uint32_t e[4];
+            for (uint32_t q = 0; q < cnt; q += 4u) {
+                uint32_t ev[4];
 #pragma unroll
                 for (uint32_t i = 0; i < 4u; ++i)
-                    e[i] = k + i < n ? __hip_atomic_load(reinterpret_cast<uint32_t *>(spill + off0 + (k + i) * 256u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                    ev[i] = q + i < cnt ? __hip_atomic_load(reinterpret_cast<uint32_t *>(spill + at0 + (q + i) * 256u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 #pragma unroll
                 for (uint32_t i = 0; i < 4u; ++i) {
-                    if (k + i < n) {
-                        recs += records_of(e[i]);
-                        if (fits) to[k + i] = (e[i] & 0x00FFFFFFu) | tag;
+                    if (q + i < cnt) {
+                        recs += records_of(ev[i]);
+                        if (fits) to[q + i] = (ev[i] & 0x00FFFFFFu) | tag;
                     }
                 }
             }
             return recs;
         };
-        const uint32_t ra = drain(0u, na, off_a0, dst), rz = drain(1u, nz, off_z0, dst + na);   // records of the two pieces
+        uint32_t r[NP], n_rec = 0;   // records of the pieces
+#pragma unroll
+        for (uint32_t h = 0; h < NP; ++h) {
+            r[h] = drain(h, n[h], off0[h], dst);
+            dst += n[h];
+            n_rec += r[h];
+        }
         log_at += e_tot;
         // ---- records: exclusive prefix over the wave's lanes, the items' totals (k_expand's scan turns them into bases) ----
-        const uint32_t n_rec = ra + rz;
         const uint32_t incl = wave_inclusive_sum(n_rec);
         const uint32_t excl = incl - n_rec;
         const uint32_t wave_tot = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
         {
-            // an item's total: the running sum behind its last piece less the sum before its first (pieces 2 l, 2 l + 1 of lane l)
-            auto before = [&](uint32_t s) __attribute__((always_inline)) -> uint32_t {   // records of the pieces before piece s (s < 128)
-                const uint32_t l = s >> 1;
-                const uint32_t ex = uint32_t(__shfl(int(excl), int(l), 64)), mid = uint32_t(__shfl(int(excl + ra), int(l), 64));
-                return (s & 1u) ? mid : ex;
+            // an item's total: the running sum behind its last piece less the sum before its first (pieces NP l .. NP l + NP - 1 of lane l)
+            uint32_t upto[NP];   // records before this lane's piece h
+            upto[0] = excl;
+#pragma unroll
+            for (uint32_t h = 1; h < NP; ++h) upto[h] = upto[h - 1u] + r[h - 1u];
+            auto before = [&](uint32_t s) __attribute__((always_inline)) -> uint32_t {   // records of the pieces before piece s (s < 64 NP)
+                const uint32_t l = NP == 2 ? s >> 1 : (s * 171u) >> 9;   // (s / 3 for s < 256)
+                const uint32_t h = s - l * NP;
+                uint32_t v = uint32_t(__shfl(int(upto[0]), int(l), 64));
+#pragma unroll
+                for (uint32_t g = 1; g < NP; ++g) {
+                    const uint32_t x = uint32_t(__shfl(int(upto[g]), int(l), 64));
+                    v = h == g ? x : v;
+                }
+                return v;
             };
-            auto item_total = [&](const Piece &pc) __attribute__((always_inline)) {
-                const uint32_t s0 = pc.r * T.P, s1 = s0 + T.P;   // pieces [s0, s1) (s1 <= 128 for an item the wave has)
-                const uint32_t lo = before(s0 < 128u ? s0 : 127u);
-                const uint32_t up = before(s1 < 128u ? s1 : 127u);   // (a shuffle: by ALL lanes, whatever they then keep)
-                const uint32_t hi = s1 < 128u ? up : wave_tot;
-                if (pc.have && pc.qi == 0u && hi != lo) B.rec_count[pc.item] = hi - lo;
-            };
-            item_total(pa);
-            item_total(pz);
+#pragma unroll
+            for (uint32_t h = 0; h < NP; ++h) {
+                const uint32_t s0 = pc[h].r * T.P, s1 = s0 + T.P;   // pieces [s0, s1) (s1 <= 64 NP for an item the wave has)
+                const uint32_t lo = before(s0 < kPieces ? s0 : kPieces - 1u);
+                const uint32_t up = before(s1 < kPieces ? s1 : kPieces - 1u);   // (a shuffle: by ALL lanes, whatever they then keep)
+                const uint32_t hi = s1 < kPieces ? up : wave_tot;
+                if (pc[h].have && pc[h].qi == 0u && hi != lo) B.rec_count[pc[h].item] = hi - lo;
+            }
         }
     }
     // statistic: 16-byte blocks walked (what the automatic kernel choice reads)
@@ -562,15 +623,17 @@ __global__ __launch_bounds__(kEmitThreads) void k_chain_emit(DevAutomaton A, Bat
         if (uint64_t(info.x) + info.y > T.log_cap) continue;
         const uint32_t *ev = T.log + (t % T.n_waves) * uint64_t(T.log_cap) + info.x;
         const uint64_t first_item = t * T.R;
-        const Piece pa = chain_piece(A, B, T, total_items, first_item, 2u * lane), pz = chain_piece(A, B, T, total_items, first_item, 2u * lane + 1u);
+        // (what an event needs of its piece: the lane that walked piece s is s / np, np = 2 or 3 pieces a lane)
+        const Piece pa = chain_piece(A, B, T, total_items, first_item, T.np * lane), pz = chain_piece(A, B, T, total_items, first_item, T.np * lane + 1u);
+        const Piece pm = T.np > 2u ? chain_piece(A, B, T, total_items, first_item, T.np * lane + 2u) : pz;
         uint64_t at = T.rec_base[first_item];
         // four rounds of 64 events at a time: a round is three dependent round trips (the event, its state's output head, the store),
         // and only the running sum ties one round to the next -- the rounds' loads are issued together, kind by kind
         auto place = [&](uint32_t ent, uint2 hd, uint32_t c) __attribute__((always_inline)) {
-            const uint32_t idx = ent & 0x7FFFu, piece = (ent >> 24) & 127u, owner = piece >> 1;
-            const uint32_t ba = uint32_t(__shfl(int(pa.pos_bias), int(owner), 64)), bz = uint32_t(__shfl(int(pz.pos_bias), int(owner), 64));
-            const uint32_t ha = uint32_t(__shfl(int(pa.hay), int(owner), 64)), hz = uint32_t(__shfl(int(pz.hay), int(owner), 64));
-            const uint32_t pos = ((piece & 1u) ? bz : ba) + ((ent >> 15) & 511u), hay = (piece & 1u) ? hz : ha;
+            const uint32_t idx = ent & 0x7FFFu, piece = ent >> 24, owner = T.np == 2u ? (piece >> 1) & 63u : ((piece * 171u) >> 9) & 63u, which = piece - owner * T.np;
+            const uint32_t ba = uint32_t(__shfl(int(pa.pos_bias), int(owner), 64)), bz = uint32_t(__shfl(int(pz.pos_bias), int(owner), 64)), bm = uint32_t(__shfl(int(pm.pos_bias), int(owner), 64));
+            const uint32_t ha = uint32_t(__shfl(int(pa.hay), int(owner), 64)), hz = uint32_t(__shfl(int(pz.hay), int(owner), 64)), hm = uint32_t(__shfl(int(pm.hay), int(owner), 64));
+            const uint32_t pos = (which == 0u ? ba : which == 1u ? bz : bm) + ((ent >> 15) & 511u), hay = which == 0u ? ha : which == 1u ? hz : hm;
             const uint32_t incl = wave_inclusive_sum(c);
             const uint64_t mine = at + (incl - c);
             // (too small a buffer: what fits is written -- whole events, in order -- and the host grows it and has the logs emitted
@@ -644,16 +707,22 @@ bool chain_walk_ok(const DevAutomaton &A) {
 // and spill regions are per wave of the grid that runs, so the walk, the emit and the host's sizing take the same count)
 uint32_t chain_grid(uint32_t reserve_cus) { return uint32_t(std::max(1, num_cus() - int(reserve_cus))); }
 uint32_t chain_waves(uint32_t reserve_cus) { return chain_grid(reserve_cus) * kChainWaves; }
-uint64_t chain_tiles(uint64_t max_items, uint32_t P) { return max_items / (128u / P) + 1u; }
+// pieces a lane walks at once.  (The kernel is written for any number; THREE were built and measured in round 6 -- text blocks three
+// ahead instead of four, 128 registers with 24-41 spilled around the tile loop, none inside it -- and were slower everywhere: 1 GiB of
+// the headline set at 64 / 256 occurrences per 8 KiB 0.68 -> 0.92 / 0.72 -> 1.02 ms for the walk, the word list 0.72 -> 0.99: a third
+// stream of random reads queues behind the same LDS pipe, which is what bounds the kernel)
+uint32_t chain_np() { return 2u; }
+uint64_t chain_tiles(uint64_t max_items, uint32_t P) { return max_items / (64u * chain_np() / P) + 1u; }
 // the waves' overflow regions: what a piece can have beyond its LDS list, a word each
 // (an item's last piece takes the item's unaligned head as well: up to W + 15 bytes, an event each)
-uint64_t chain_spill_words(uint32_t W, uint32_t reserve_cus) { return uint64_t(chain_waves(reserve_cus)) * uint64_t(W + 16u) * 128u; }
+uint64_t chain_spill_words(uint32_t W, uint32_t reserve_cus) { return uint64_t(chain_waves(reserve_cus)) * uint64_t(W + 16u) * 64u * chain_np(); }
 
 static ChainArgs chain_args(const DevAutomaton &A, const BatchArgs &B, uint32_t W, uint32_t P, const ChainBuffers &C) {
     ChainArgs T{};
     T.W = W;
     T.P = P;
-    T.R = 128u / P;   // (a lane takes two pieces)
+    T.np = chain_np();
+    T.R = 64u * T.np / P;   // (a lane takes np pieces)
     T.inv_p = (65536u + P - 1u) / P;
     T.back = A.max_pattern_length ? A.max_pattern_length - 1u : 0u;
     T.spill_cap = W + 16u;
@@ -683,11 +752,11 @@ hipError_t launch_walk_chain(const DevAutomaton &A, const BatchArgs &B, uint64_t
         hipLaunchKernelGGL(fn, dim3(chain_grid(B.reserve_cus)), dim3(kChainThreads), lds, st, A, B, T);
         return hipGetLastError();
     };
-    if (alld) return class_mode == 1 ? go(k_walk_chain<1, true, true>) : go(k_walk_chain<0, true, true>);
+    if (alld) return class_mode == 1 ? go(k_walk_chain<1, true, true, 2>) : go(k_walk_chain<0, true, true, 2>);
     // ACMI_CHAIN_ROW16=0 (measurements): the halved row offsets where the whole ones fit
     static const bool no_row16 = [] { const char *e = std::getenv("ACMI_CHAIN_ROW16"); return e && e[0] == '0'; }();
-    if (Y0.row16 && !no_row16) return class_mode == 1 ? go(k_walk_chain<1, false, true>) : go(k_walk_chain<0, false, true>);
-    return class_mode == 1 ? go(k_walk_chain<1, false, false>) : go(k_walk_chain<0, false, false>);
+    if (Y0.row16 && !no_row16) return class_mode == 1 ? go(k_walk_chain<1, false, true, 2>) : go(k_walk_chain<0, false, true, 2>);
+    return class_mode == 1 ? go(k_walk_chain<1, false, false, 2>) : go(k_walk_chain<0, false, false, 2>);
 }
 
 hipError_t launch_chain_emit(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, uint32_t W, uint32_t P, const ChainBuffers &C,

@@ -49,6 +49,7 @@ struct ChainBuffers {
 };
 bool chain_walk_ok(const DevAutomaton &A);
 uint32_t chain_waves(uint32_t reserve_cus = 0);
+uint32_t chain_np();   // pieces a lane of k_walk_chain walks at once: a wave's tile is 64 x that many pieces
 uint64_t chain_tiles(uint64_t max_items, uint32_t P);
 uint64_t chain_spill_words(uint32_t W, uint32_t reserve_cus = 0);
 hipError_t launch_walk_chain(const DevAutomaton &A, const BatchArgs &B, uint64_t max_items, int class_mode, uint32_t W, uint32_t P, const ChainBuffers &C,

@@ -31,10 +31,10 @@ HOT = [
     ("k_walk_tiles<unsigned short, 1, true, false, false>", 2),                 # (the wave-queue variants reload a pointer pair or two per
     ("k_walk_tiles<unsigned short, 0, false, false, true>", 4),                # block of sixteen steps, ~ 1,000-4,000 instructions: word lists,
     ("k_walk_tiles<unsigned short, 1, false, false, true>", 4),                # the headline set at many matches per haystack)
-    ("k_walk_chain<1, false, true>", 0),                                              # the whole automaton in LDS: the headline set at many matches per haystack
-    ("k_walk_chain<0, false, false>", 0),                                              # ... word lists over prose
-    ("k_walk_chain<1, true, true>", 0),                                               # small automata, every row in LDS: short patterns over their own alphabet
-    ("k_walk_chain<0, true, true>", 0),
+    ("k_walk_chain<1, false, true, 2u>", 0),                                              # the whole automaton in LDS: the headline set at many matches per haystack
+    ("k_walk_chain<0, false, false, 2u>", 0),                                              # ... word lists over prose
+    ("k_walk_chain<1, true, true, 2u>", 0),                                               # small automata, every row in LDS: short patterns over their own alphabet
+    ("k_walk_chain<0, true, true, 2u>", 0),
     ("k_walk_items<unsigned short, 0, 4, false, true>", 0),
     ("k_refill_wave<unsigned short, 1024u>", 0),                         # config 5
     ("k_walk_runs<unsigned short, 1, false>", 0),
