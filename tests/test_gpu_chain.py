@@ -201,3 +201,40 @@ def test_reserved_compute_units(reserve):
     res = resource_for(ds, kernel=6, small_path=0, reserve_cus=reserve)
     _check(res, ds, pe, re_, calls=3)
     api.ahocorasick_deinit(res)
+
+
+@pytest.mark.parametrize("pairs,tail,expect_chain", [(280, 5, 1), (430, 2, 0)])
+def test_wide_rows_take_the_halved_offsets_or_leave_the_chain_walk(pairs, tail, expect_chain):
+    """Round 6's LDS layout (k_chain.hip chain_layout): a record names its failure state's row by a 16-bit offset -- whole while the
+    rows end below 64 KiB, halved up to 128 KiB -- and a D state has a record of its own.  120 byte values in use (121 classes: rows of
+    242 B, TABLE mode): 280 branching depth-2 states put the rows' end at ~ 97 KB (halved offsets), 430 at ~ 133 KB -- the builder
+    still makes the image (it fits its budget), the kernel's layout does not hold it and kernel 6 is k_walk_tiles."""
+    r = np.random.default_rng(4242 + pairs)
+    alpha = np.arange(8, 128, dtype=np.uint8)
+    pats = []
+    for x in alpha:   # every depth-1 state branches
+        pats.append(bytes([int(x), int(alpha[0])]) + bytes(r.choice(alpha, size=tail - 1).tolist()))
+    for _ in range(pairs):   # depth-2 states with two children
+        head = bytes(r.choice(alpha, size=2).tolist())
+        a, b = r.choice(alpha, size=2, replace=False)
+        pats.append(head + bytes([int(a)]) + bytes(r.choice(alpha, size=tail).tolist()))
+        pats.append(head + bytes([int(b)]) + bytes(r.choice(alpha, size=tail).tolist()))
+    pats = list(dict.fromkeys(pats))
+    n_hay, hay_len = 96, 3000
+    text = r.choice(alpha, size=n_hay * hay_len).astype(np.uint8)
+    for k in range(0, len(text) - 16, 97):   # occurrences and near misses
+        p = np.frombuffer(pats[int(r.integers(len(pats)))], dtype=np.uint8)
+        text[k:k + len(p) - (k // 97) % 2] = p[:len(p) - (k // 97) % 2]
+    pb, po = synth.pack(pats)
+    ds = synth.Dataset(f"WIDE{pairs}", pb, po, text, (np.arange(n_hay + 1, dtype=np.uint64) * hay_len))
+    pe, re_ = _oracle(ds)
+    assert len(re_) > 500
+    res = resource_for(ds, kernel=6, small_path=0, split=0, lds_bytes=2048)
+    for _ in range(2):
+        p, rr = device_match(res, ds)
+        assert np.array_equal(p, pe) and np.array_equal(rr, re_)
+    assert res.stat("chain_image_bytes") > 60_000
+    assert res.stat("kernel_used") == 6 and res.stat("chain_walk_used") == expect_chain
+    rows_end = res.stat("chain_dense_states") * res.stat("columns") * 2
+    assert (65_536 < rows_end <= 131_072) if expect_chain else rows_end > 131_072
+    api.ahocorasick_deinit(res)
