@@ -12,11 +12,14 @@
 //     delta(s, b) = b is the edge ? s + 1 : row[fail(s)][b] -- the reference's hop loop, ended after one hop.
 // A step is the same straight-line code for every lane whatever its state: read the state's record, read the row entry (of the
 // state itself when it is a D state, of its failure state otherwise), select.  Two LDS reads per byte, no branch, no L2 request.
+// (Round 6: in LDS a record names its failure state's ROW, every index has a record and the record says whether its own state is
+// final -- chain_layout, chain_read / chain_next below: 6 VALU operations per byte and piece where round 5 had 13.5; what bounds the
+// kernel since is the LDS itself, 64 random reads per instruction.)
 //
 // Work distribution: a work item (<= P x W bytes of one haystack) is walked by P pieces of W bytes, each entered from the root
-// Lmax - 1 bytes early (k_walk_tiles' geometry); a WAVE takes 128 consecutive pieces at a time (a tile: whole items), two per lane,
-// tiles dealt round robin -- no ticket, no barrier.  Events go to a list of the piece's own {index, count code, byte}: the first two
-// in LDS, what a piece has beyond that (it cannot have more than one per byte) in the wave's region of a global buffer.
+// Lmax - 1 bytes early (k_walk_tiles' geometry; W = 128 for batches of 64 MiB and more); a WAVE takes 128 consecutive pieces at a
+// time (a tile: whole items), two per lane, tiles dealt round robin -- no ticket, no barrier.  Events go to a list of the piece's
+// own {index, byte} in the wave's region of a global buffer (a piece cannot have more than one per byte).
 //
 // Records are NOT written here.  A wave that places its records needs the number of records before them, and every way of getting
 // that inside the kernel made the waves wait for one another: decoupled look-back per wave tile fell behind (131 tiles finish per
@@ -24,7 +27,8 @@
 // tiles it still cost 0.45 ms (a batch waits for the slowest wave of the batch before and for four windows of words).  Instead
 // the walk leaves, per tile, its events in the wave's LOG (a region of the wave's own: no atomic) and its items' record counts;
 // k_expand's single-pass scan over the item counts -- the pipeline runs it anyway, for the per-haystack prefix -- gives every item
-// its base, and k_chain_emit turns the logs into records at those bases.  The walk: 0.79 ms per GiB with nothing to wait for.
+// its base, and k_chain_emit turns the logs into records at those bases.  The walk: 0.79 ms per GiB with nothing to wait for
+// (round 6: 0.68).
 #include <cstdlib>
 #include <type_traits>
 
