@@ -310,7 +310,10 @@ int acmi_pattern_info(const acmi_handle *h, uint32_t index, acmi_pattern *out);
  *                    patterns: dense rows for the branching states, goto edge + failure pointer -- the reference's node,
  *                    node.h:37-67 -- for the insides of the patterns; "chain_image_bytes", "chain_dense_states"): -1 (default) the
  *                    walk over that image (k_walk_chain + k_chain_emit) unless the automaton is so small that all of its dense
- *                    rows fit the LDS, 1 whenever there is an image, 0 never ("chain_walk_used", "chain_log_reruns")  [any time]
+ *                    rows fit the LDS, 1 whenever there is an image, 0 never ("chain_walk_used", "chain_log_reruns").  The
+ *                    kernel's own LDS layout adds 4 bytes per branching state to the image and addresses rows by 16 bits: an
+ *                    image whose rows end beyond 128 KiB, or that no longer fits 160 KiB with those bytes, is walked by
+ *                    k_walk_tiles as if there were none                                                     [any time]
  *   "chain_bytes"    budget of that image, <= 160 KiB - 768 B (the default); 0: none is built             [before finalize]
  *   "reserve_cus"    N (default 0): the scan kernels run as persistent workgroups on all but N compute units, so that the kernels
  *                    of a collective in flight (acmi_comm_*, RCCL) find CUs and LDS while a scan runs          [any time]
