@@ -166,8 +166,8 @@ int enqueue_batch(acmi_handle *h, acmi_handle::FlySlot &F, const uint8_t *d_blob
         const bool will_chain = h->chain_walk != 0 && chain_walk_ok(h->dA) && h->merge_into.out == nullptr && (h->chain_walk > 0 || h->dA.chain_dense < h->dA.chain_index);
         if (h->tile_w) tile_w = h->tile_w == 128 && !will_chain ? 64u : uint32_t(h->tile_w);
         else if (will_chain && tile_w == 64u && blob_bytes >= (64ull << 20) && blob_bytes / nh >= 256u && h->chain_log_div >= 32u) {
-            // k_walk_chain over a big batch (a tile of 16 KiB for every wave of the chip: 64 MiB): pieces of 128 bytes -- the Lmax - 1 bytes of warm-up are a ninth of a piece's steps
-            // instead of a fifth, and half as many items and tiles go through k_items, k_expand and k_chain_emit (1 GiB of the
+            // k_walk_chain over a big batch (a tile of 16 KiB for every wave of the chip: 64 MiB): pieces of 128 bytes -- the Lmax - 1
+            // bytes of warm-up are a ninth of a piece's steps instead of a fifth, and half as many items and tiles go through k_items, k_expand and k_chain_emit (1 GiB of the
             // headline set at 64 occurrences per 8 KiB: the walk 0.738 -> 0.734 ms, the call 0.880 -> 0.824).  Not for text whose
             // events have overflowed the logs' first size (more than one per 26 bytes): a piece's event list is written and read
             // back through L2, and at an event per 9 bytes the lists of 128-byte pieces no longer fit it (the word list over
