@@ -618,9 +618,14 @@ __global__ __launch_bounds__(kEmitThreads) void k_chain_emit(DevAutomaton A, Bat
     const uint64_t total_items = B.item_base[B.n_haystacks];
     const uint64_t tiles_all = (total_items + T.R - 1u) / T.R;
     const uint64_t n_waves = uint64_t(gridDim.x) * (kEmitThreads / 64u);
+    // (a tile is two dependent round trips -- where its events lie, then the events, its pieces and its base together -- and a wave
+    // takes its tiles one after the other: the next tile's {log offset, count} is requested while this one's records are placed)
+    uint64_t t = uint64_t(blockIdx.x) * (kEmitThreads / 64u) + (threadIdx.x >> 6);
+    uint2 info_next = t < tiles_all ? T.tile_info[t] : make_uint2(0u, 0u);
 #pragma unroll 1
-    for (uint64_t t = uint64_t(blockIdx.x) * (kEmitThreads / 64u) + (threadIdx.x >> 6); t < tiles_all; t += n_waves) {
-        const uint2 info = T.tile_info[t];
+    for (; t < tiles_all; t += n_waves) {
+        const uint2 info = info_next;
+        if (t + n_waves < tiles_all) info_next = T.tile_info[t + n_waves];
         if (info.y == 0u) continue;
         // (a tile whose events did not fit its wave's log wrote none of them: the host has the batch run again with a bigger log,
         // counters[19] -- nothing of this tile may be read here, its entries would be another tile's or lie behind the log's end)
